@@ -1,0 +1,156 @@
+/*
+ * spex_hip.h — C ABI of libspexhip.so: the MI355X (gfx950) implementation of the SPEX LightGCN / NGCF graph
+ * convolution + negative-sampled scoring hot path.
+ *
+ * The reference (XMUDM/SPEX) is pure Python on stock PyTorch: it has no FFI / plugin layer of its own, so there is no
+ * existing binding to match symbol-for-symbol.  Each entry point below therefore names the reference call it
+ * replaces (file:line relative to the reference root) — these are the calls a maintainer re-points at this
+ * library (INTEGRATION.md shows the ctypes stub and the drop-in Python modules that already do so).
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in signatures; `stream` is a hipStream_t passed as void* (NULL = default stream)
+ *   - every dense pointer is a DEVICE pointer owned by the caller (e.g. torch.Tensor.data_ptr()); the library never
+ *     frees or retains them past the call.  Row-major fp32, leading dimension == d, 16-byte aligned.
+ *   - host pointers are marked `h_`.
+ *   - every call is asynchronous on `stream` unless stated; no hidden device synchronisation, no allocation after
+ *     spex_graph_create / spex_workspace_* (safe to capture in a hipGraph).
+ *   - return 0 on success, a negative spex_status otherwise; spex_last_error() gives the thread-local message.
+ */
+#ifndef SPEX_HIP_H
+#define SPEX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum spex_status {
+    SPEX_OK = 0,
+    SPEX_ERR_INVALID = -1,     /* bad argument (null pointer, negative size, unsorted CSR, ...) */
+    SPEX_ERR_HIP = -2,         /* a HIP runtime call failed                                      */
+    SPEX_ERR_COMM = -3,        /* reserved: collective failure (collectives live in the host layer) */
+    SPEX_ERR_UNSUPPORTED = -4  /* e.g. d not a multiple of 4                                     */
+} spex_status;
+
+typedef struct spex_graph spex_graph_t;
+
+int spex_version(void);                 /* ABI version, currently 1 */
+const char *spex_last_error(void);      /* thread-local, never NULL */
+
+/* ------------------------------------------------------------------------------------------------ graph handle
+ * Replaces: the torch sparse tensor the reference builds once and keeps on the device —
+ *   LightGCN_SPEX/code/utility1/dataloader.py:179-185,221-222 (_convert_sp_mat_to_sp_tensor + coalesce + .cuda()),
+ *   NGCF_SPEX/code/main_rec.py:47,102-108 (sparse_mx_to_torch_sparse_tensor).
+ * Input is host CSR (rows sorted, columns ascending within a row = the coalesced COO order), copied to HBM once.
+ * `h_edge_id` (optional, may be NULL = identity) gives, per stored entry, the index used to look the entry up in an
+ * edge keep-mask (see spex_graph_set_edge_mask): a transposed copy of a graph passes the permutation back to the
+ * original entry order so forward and backward drop the same edges.
+ * The handle may hold any row block of a larger matrix (1-D row partition): n_rows local rows, column indices
+ * global in [0, n_cols).
+ * Synchronous (host -> device copies); builds the long-row segment table used for load balance.
+ */
+int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, const float *h_val, const int32_t *h_edge_id,
+                      int32_t n_rows, int32_t n_cols, int64_t nnz, spex_graph_t **out);
+int spex_graph_destroy(spex_graph_t *g);
+/* n_rows, n_cols, nnz, number of long rows, number of long-row segments (any pointer may be NULL) */
+int spex_graph_info(const spex_graph_t *g, int32_t *n_rows, int32_t *n_cols, int64_t *nnz, int32_t *n_long_rows,
+                    int32_t *n_segments);
+
+/* Edge dropout — replaces LightGCN.__dropout_x, utility1/model.py:46-55: keep entry e iff floor(rand_e + keep_prob),
+ * kept values divided by keep_prob.  Two modes:
+ *   injected : d_keep = device uint8[mask_len], indexed by edge_id (parity tests inject the reference's mask)
+ *   sampled  : d_keep = NULL; the mask is counter-based: keep_e = (philox4x32-10(seed, edge_id).x * 2^-32 + keep_prob
+ *              >= 1), recomputed inside the SpMM, identical in forward / backward and across layers for one seed.
+ * keep_prob >= 1 or mode 0 switches dropout off.  Takes effect for subsequent launches on this handle.
+ */
+int spex_graph_set_edge_mask(spex_graph_t *g, int mode /*0 off, 1 injected, 2 sampled*/, const uint8_t *d_keep,
+                             float keep_prob, uint64_t seed);
+
+/* ------------------------------------------------------------------------------------------------ SpMM
+ * Replaces: torch.sparse.mm(Graph, all_emb) — utility1/model.py:91 (and :87 for the A_split row blocks),
+ * NGCF_SPEX/code/main_rec.py:76; and its autograd backward (A^T g) when called on the transposed handle.
+ *
+ *   y[r,:]       = sum_e val[e] * X[col[e],:]               (fp32 fmaf chain, ascending column order)
+ *   if add_in:     y += add_in[r,:] / add_div               (backward of the layer mean: g/(L+1) + A^T G)
+ *   if Y:          Y[r,:] = y
+ *   if acc_out:    acc_out[r,:] = (acc_in[r,:] + y) / acc_div   (running layer sum; acc_div = L+1 on the last layer)
+ *
+ * X: [n_cols, d]; Y, add_in, acc_in, acc_out: [n_rows, d].  acc_in may equal acc_out.  X must not alias Y / acc_out.
+ * d must be a multiple of 4 (d == 64 takes the tuned path).
+ */
+int spex_spmm_f32(const spex_graph_t *g, const float *X, float *Y, const float *add_in, float add_div,
+                  const float *acc_in, float *acc_out, float acc_div, int32_t d, void *stream);
+
+/* Whole LightGCN.computer(), utility1/model.py:66-97, for a graph held entirely on this device (n_rows == n_cols):
+ *   E^{l+1} = A E^l (l < L);  mean_out = (E^0 + ... + E^L) / (L+1).
+ * ws: caller-provided device workspace of 2 * n_rows * d floats (ping-pong layer buffers).
+ * layers_out (optional): L * n_rows * d floats receiving E^1..E^L (then ws may be NULL).
+ */
+int spex_propagate_f32(const spex_graph_t *g, const float *E0, float *mean_out, float *layers_out, float *ws,
+                       int32_t L, int32_t d, void *stream);
+
+/* Backward of the above w.r.t. E0 given g_out = d loss / d mean_out  (autograd of model.py:83-95):
+ *   G_L = g_out/(L+1);  G_l = g_out/(L+1) + A^T G_{l+1};  grad_E0 = G_0.
+ * gt is the handle of A^T (for the symmetric LightGCN adjacency the same handle).  ws: 2 * n_rows * d floats.
+ */
+int spex_propagate_bwd_f32(const spex_graph_t *gt, const float *g_out, float *grad_E0, float *ws, int32_t L,
+                           int32_t d, void *stream);
+
+/* ------------------------------------------------------------------------------------------------ scoring
+ * Replaces LightGCN.forward, utility1/model.py:111-121 (gather rows, elementwise product, sum, BCEWithLogitsLoss)
+ * and NGCF compute_rec_loss, NGCF_SPEX/code/main_rec.py:89-91,96-100 — plus their autograd backward into the two
+ * gathered tables.
+ *   gamma[b] = <users[u_idx[b]], items[i_idx[b]]>
+ *   labels != NULL: loss_sum += sum_b BCEWithLogits(gamma[b], labels[b])     (caller divides by B; *loss_sum must be
+ *                   zeroed by the caller, it is accumulated with atomics)
+ *   grad_users/grad_items != NULL: grad_users[u_idx[b],:] += dg_b * items[i_idx[b],:], grad_items likewise, with
+ *                   dg_b = (sigmoid(gamma[b]) - labels[b]) * grad_scale   (grad_scale = upstream_grad / B).
+ *                   The grad tables are accumulated into (atomics): zero them first.
+ * ldu / ldi: row strides (floats) of users / items and of their grad tables (d for LightGCN, 2d.. for NGCF concat).
+ * u_idx, i_idx: device int64 (what torch DataLoader hands over, main_rec.py:33-34).
+ */
+int spex_score_bce_f32(const float *users, const float *items, int32_t ldu, int32_t ldi, const int64_t *u_idx,
+                       const int64_t *i_idx, const float *labels, int32_t B, int32_t d, float *gamma,
+                       float *loss_sum, float *grad_users, float *grad_items, float grad_scale, void *stream);
+
+/* North-star extension (no counterpart in the reference): BPR over (u, i+, i-) triples.
+ *   x_t = <U_read[u], I_read[i-] - I_read[i+]>;  loss_sum += softplus(x_t)
+ * Fused gather + dot + sigmoid + SGD: with s_t = sigmoid(x_t)/T,
+ *   U_w[u]  -= lr * (s_t (i- - i+) + reg u / T);  I_w[i+] -= lr * (-s_t u + reg i+ / T);  I_w[i-] -= lr * (s_t u + reg i- / T)
+ * Batch-synchronous when the read tables differ from the write tables; passing the same tables gives in-place
+ * (hogwild) matrix-factorisation BPR.  Updates use float atomics (duplicates in a batch accumulate).
+ * If lr == 0 and grad tables are wanted instead, pass U_w/I_w = gradient accumulators and lr = -1 (adds the gradient).
+ */
+int spex_bpr_sgd_step_f32(const float *U_read, const float *I_read, float *U_w, float *I_w, const int64_t *u,
+                          const int64_t *i_pos, const int64_t *i_neg, int64_t T, int32_t d, float lr, float reg,
+                          float *loss_sum, void *stream);
+
+/* ------------------------------------------------------------------------------------------------ optimiser
+ * Replaces torch.optim.Adam(...).step() over the dense embedding tables — LightGCN_SPEX/code/main_rec.py:23,37.
+ * One fused pass: m, v, p updated in place (bias-corrected, eps outside the sqrt as torch does), t = step count >= 1.
+ */
+int spex_adam_step_f32(float *p, const float *g, float *m, float *v, int64_t n, int32_t t, float lr, float beta1,
+                       float beta2, float eps, void *stream);
+
+/* ------------------------------------------------------------------------------------------------ NGCF epilogue
+ * Replaces NGCF_SPEX/code/main_rec.py:77-83 for one layer (inference / dropout off):
+ *   s    = LeakyReLU(side W_gc^T + b_gc);  b = LeakyReLU((ego * side) W_bi^T + b_bi);  e1 = s + b
+ *   out[r, 0:d] = ego[r,:];  out[r, d:2d] = e1 / max(||e1||_2, 1e-12)
+ * side = A ego comes from spex_spmm_f32.  W_*: [d,d] row-major as nn.Linear stores them (out x in); d == 64.
+ * e1_out (optional, [n,d]) receives the un-normalised e1 (needed by the backward / a second layer).
+ */
+int spex_ngcf_layer_f32(const float *ego, const float *side, const float *W_gc, const float *b_gc, const float *W_bi,
+                        const float *b_bi, float *out, int32_t ld_out, float *e1_out, int32_t n, int32_t d,
+                        float slope, void *stream);
+
+/* Replaces the two-expert gate of the dual-task model, utility1/model_expert_s.py:156-161:
+ *   att = softmax([raw | prop] att_exp, dim=1) ([n,2d] x [2d,2]);  mixed = raw * att[:,0] + prop * att[:,1]
+ */
+int spex_expert_gate_f32(const float *raw, const float *prop, const float *att_exp /*[2d,2]*/, float *mixed, int32_t n,
+                         int32_t d, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPEX_HIP_H */

@@ -1,0 +1,136 @@
+// Graph handle: CSR in HBM + the long-row segment table.  See include/spex_hip.h for the contract.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include <vector>
+
+#include "spex_common.h"
+
+namespace spex {
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace spex
+
+extern "C" int spex_version(void) { return 1; }
+extern "C" const char *spex_last_error(void) { return spex::g_err; }
+
+template <typename T>
+static int upload(T **dst, const T *src, size_t n)
+{
+    *dst = nullptr;
+    if (n == 0) return SPEX_OK;
+    SPEX_HIP(hipMalloc((void **)dst, n * sizeof(T)));
+    SPEX_HIP(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return SPEX_OK;
+}
+
+extern "C" int spex_graph_destroy(spex_graph_t *g)
+{
+    if (!g) return SPEX_OK;
+    void *ptrs[] = {g->rowptr, g->col, g->val, g->edge_id, g->seg_beg, g->seg_end, g->long_row, g->long_seg0, g->partial};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete g;
+    return SPEX_OK;
+}
+
+extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, const float *h_val,
+                                 const int32_t *h_edge_id, int32_t n_rows, int32_t n_cols, int64_t nnz,
+                                 spex_graph_t **out)
+{
+    SPEX_CHECK_ARG(out, "spex_graph_create: out is NULL");
+    *out = nullptr;
+    SPEX_CHECK_ARG(h_rowptr && n_rows >= 0 && n_cols >= 0 && nnz >= 0, "spex_graph_create: bad sizes / NULL rowptr");
+    SPEX_CHECK_ARG(nnz == 0 || (h_col && h_val), "spex_graph_create: NULL col/val with nnz > 0");
+    SPEX_CHECK_ARG(nnz < (int64_t)INT32_MAX, "spex_graph_create: nnz %lld does not fit int32 entry offsets", (long long)nnz);
+    SPEX_CHECK_ARG(h_rowptr[0] == 0 && h_rowptr[n_rows] == nnz, "spex_graph_create: rowptr[0] != 0 or rowptr[n_rows] != nnz");
+    // Validate on the host what the kernels assume (a bad column index would be an out-of-bounds gather on the GPU).
+    for (int32_t r = 0; r < n_rows; ++r) {
+        SPEX_CHECK_ARG(h_rowptr[r] <= h_rowptr[r + 1], "spex_graph_create: rowptr not monotone at row %d", r);
+        for (int32_t e = h_rowptr[r]; e < h_rowptr[r + 1]; ++e) {
+            SPEX_CHECK_ARG(h_col[e] >= 0 && h_col[e] < n_cols, "spex_graph_create: column %d out of range at entry %d", h_col[e], e);
+            SPEX_CHECK_ARG(e == h_rowptr[r] || h_col[e - 1] < h_col[e], "spex_graph_create: columns not strictly ascending in row %d (coalesce first)", r);
+        }
+    }
+    if (h_edge_id)
+        for (int64_t e = 0; e < nnz; ++e)
+            SPEX_CHECK_ARG(h_edge_id[e] >= 0, "spex_graph_create: negative edge_id at entry %lld", (long long)e);
+
+    spex_graph *g = new spex_graph();
+    g->n_rows = n_rows;
+    g->n_cols = n_cols;
+    g->nnz = nnz;
+
+    // long rows -> segments of kSegLen entries; partial sums are combined in segment order by the fix-up kernel
+    std::vector<int32_t> seg_beg, seg_end, long_row, long_seg0;
+    for (int32_t r = 0; r < n_rows; ++r) {
+        const int32_t b = h_rowptr[r], e = h_rowptr[r + 1];
+        if (e - b > spex::kLongRow) {
+            long_row.push_back(r);
+            long_seg0.push_back((int32_t)seg_beg.size());
+            for (int32_t s = b; s < e; s += spex::kSegLen) {
+                seg_beg.push_back(s);
+                seg_end.push_back(s + spex::kSegLen < e ? s + spex::kSegLen : e);
+            }
+        }
+    }
+    long_seg0.push_back((int32_t)seg_beg.size());
+    g->n_long = (int32_t)long_row.size();
+    g->n_seg = (int32_t)seg_beg.size();
+
+    int rc = SPEX_OK;
+    if ((rc = upload(&g->rowptr, h_rowptr, (size_t)n_rows + 1)) || (rc = upload(&g->col, h_col, (size_t)nnz)) ||
+        (rc = upload(&g->val, h_val, (size_t)nnz)) ||
+        (h_edge_id && (rc = upload(&g->edge_id, h_edge_id, (size_t)nnz))) ||
+        (rc = upload(&g->seg_beg, seg_beg.data(), seg_beg.size())) ||
+        (rc = upload(&g->seg_end, seg_end.data(), seg_end.size())) ||
+        (rc = upload(&g->long_row, long_row.data(), long_row.size())) ||
+        (rc = upload(&g->long_seg0, long_seg0.data(), long_seg0.size()))) {
+        spex_graph_destroy(g);
+        return rc;
+    }
+    if (g->n_seg > 0) {
+        g->partial_cap = (int64_t)g->n_seg * 64;
+        hipError_t e = hipMalloc((void **)&g->partial, (size_t)g->partial_cap * sizeof(float));
+        if (e != hipSuccess) {
+            spex::set_error("hipMalloc(partial) failed: %s", hipGetErrorString(e));
+            spex_graph_destroy(g);
+            return SPEX_ERR_HIP;
+        }
+    }
+    *out = g;
+    return SPEX_OK;
+}
+
+extern "C" int spex_graph_info(const spex_graph_t *g, int32_t *n_rows, int32_t *n_cols, int64_t *nnz,
+                               int32_t *n_long_rows, int32_t *n_segments)
+{
+    SPEX_CHECK_ARG(g, "spex_graph_info: NULL handle");
+    if (n_rows) *n_rows = g->n_rows;
+    if (n_cols) *n_cols = g->n_cols;
+    if (nnz) *nnz = g->nnz;
+    if (n_long_rows) *n_long_rows = g->n_long;
+    if (n_segments) *n_segments = g->n_seg;
+    return SPEX_OK;
+}
+
+extern "C" int spex_graph_set_edge_mask(spex_graph_t *g, int mode, const uint8_t *d_keep, float keep_prob,
+                                        uint64_t seed)
+{
+    SPEX_CHECK_ARG(g, "spex_graph_set_edge_mask: NULL handle");
+    SPEX_CHECK_ARG(mode >= 0 && mode <= 2, "spex_graph_set_edge_mask: mode %d not in {0,1,2}", mode);
+    SPEX_CHECK_ARG(mode != 1 || d_keep, "spex_graph_set_edge_mask: injected mode needs a device mask");
+    SPEX_CHECK_ARG(mode == 0 || (keep_prob > 0.0f), "spex_graph_set_edge_mask: keep_prob must be > 0");
+    if (mode != 0 && keep_prob >= 1.0f && mode == 2) mode = 0;
+    g->mask_mode = mode;
+    g->keep = (mode == 1) ? d_keep : nullptr;
+    g->keep_prob = keep_prob;
+    g->seed = seed;
+    return SPEX_OK;
+}

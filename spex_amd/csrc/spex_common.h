@@ -1,0 +1,58 @@
+// Internal helpers shared by the libspexhip.so translation units (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/spex_hip.h"
+
+namespace spex {
+
+void set_error(const char *fmt, ...);
+
+#define SPEX_CHECK_ARG(cond, ...)             \
+    do {                                      \
+        if (!(cond)) {                        \
+            ::spex::set_error(__VA_ARGS__);   \
+            return SPEX_ERR_INVALID;          \
+        }                                     \
+    } while (0)
+
+#define SPEX_HIP(call)                                                                          \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            ::spex::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return SPEX_ERR_HIP;                                                                \
+        }                                                                                       \
+    } while (0)
+
+constexpr int kWave = 64;          // CDNA wavefront
+constexpr int kWavesPerBlock = 4;  // 256-thread workgroups
+constexpr int kLongRow = 128;      // rows with more stored entries are cut into segments
+constexpr int kSegLen = 128;       // entries per long-row segment
+
+}  // namespace spex
+
+// The opaque handle.  All pointers are device memory owned by the handle.
+struct spex_graph {
+    int32_t n_rows = 0, n_cols = 0;
+    int64_t nnz = 0;
+    int32_t *rowptr = nullptr;   // [n_rows+1]
+    int32_t *col = nullptr;      // [nnz]
+    float *val = nullptr;        // [nnz]
+    int32_t *edge_id = nullptr;  // [nnz] or null (identity)
+    // long rows (> kLongRow entries): segment table + per-segment partial rows + per-row fix-up table
+    int32_t n_long = 0, n_seg = 0;
+    int32_t *seg_beg = nullptr;   // [n_seg] first entry of the segment
+    int32_t *seg_end = nullptr;   // [n_seg]
+    int32_t *long_row = nullptr;  // [n_long] row index
+    int32_t *long_seg0 = nullptr; // [n_long+1] first segment of each long row
+    float *partial = nullptr;     // [n_seg * d_cap] scratch, grown on demand
+    int64_t partial_cap = 0;      // floats
+    // edge dropout
+    int mask_mode = 0;
+    const uint8_t *keep = nullptr;
+    float keep_prob = 1.0f;
+    uint64_t seed = 0;
+};
