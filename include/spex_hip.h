@@ -30,7 +30,7 @@ typedef enum spex_status {
     SPEX_ERR_INVALID = -1,     /* bad argument (null pointer, negative size, unsorted CSR, ...) */
     SPEX_ERR_HIP = -2,         /* a HIP runtime call failed                                      */
     SPEX_ERR_COMM = -3,        /* reserved: collective failure (collectives live in the host layer) */
-    SPEX_ERR_UNSUPPORTED = -4  /* e.g. d not a multiple of 4                                     */
+    SPEX_ERR_UNSUPPORTED = -4  /* e.g. the NGCF epilogue at d != 64                              */
 } spex_status;
 
 typedef struct spex_graph spex_graph_t;
@@ -77,7 +77,8 @@ int spex_graph_set_edge_mask(spex_graph_t *g, int mode /*0 off, 1 injected, 2 sa
  *   if acc_out:    acc_out[r,:] = (acc_in[r,:] + y) / acc_div   (running layer sum; acc_div = L+1 on the last layer)
  *
  * X: [n_cols, d]; Y, add_in, acc_in, acc_out: [n_rows, d].  acc_in may equal acc_out.  X must not alias Y / acc_out.
- * d must be a multiple of 4 (d == 64 takes the tuned path).
+ * Any d >= 1 (d == 64 takes the tuned path: one lane per column).  On a graph with long rows, calls on one handle
+ * must be stream-ordered (they share the handle's partial-sum scratch).
  */
 int spex_spmm_f32(const spex_graph_t *g, const float *X, float *Y, const float *add_in, float add_div,
                   const float *acc_in, float *acc_out, float acc_div, int32_t d, void *stream);
@@ -92,7 +93,8 @@ int spex_propagate_f32(const spex_graph_t *g, const float *E0, float *mean_out, 
 
 /* Backward of the above w.r.t. E0 given g_out = d loss / d mean_out  (autograd of model.py:83-95):
  *   G_L = g_out/(L+1);  G_l = g_out/(L+1) + A^T G_{l+1};  grad_E0 = G_0.
- * gt is the handle of A^T (for the symmetric LightGCN adjacency the same handle).  ws: 2 * n_rows * d floats.
+ * gt is the handle of A^T (for the symmetric LightGCN adjacency the same handle).  ws: 3 * n_rows * d floats
+ * (the scaled gradient g_out/(L+1) plus two ping-pong layer buffers).
  */
 int spex_propagate_bwd_f32(const spex_graph_t *gt, const float *g_out, float *grad_E0, float *ws, int32_t L,
                            int32_t d, void *stream);
@@ -109,10 +111,13 @@ int spex_propagate_bwd_f32(const spex_graph_t *gt, const float *g_out, float *gr
  *                   The grad tables are accumulated into (atomics): zero them first.
  * ldu / ldi: row strides (floats) of users / items and of their grad tables (d for LightGCN, 2d.. for NGCF concat).
  * u_idx, i_idx: device int64 (what torch DataLoader hands over, main_rec.py:33-34).
+ * n_user_rows / n_item_rows: table heights; a sample whose index falls outside is skipped (gamma = NaN) instead of
+ * gathering out of bounds.
  */
-int spex_score_bce_f32(const float *users, const float *items, int32_t ldu, int32_t ldi, const int64_t *u_idx,
-                       const int64_t *i_idx, const float *labels, int32_t B, int32_t d, float *gamma,
-                       float *loss_sum, float *grad_users, float *grad_items, float grad_scale, void *stream);
+int spex_score_bce_f32(const float *users, const float *items, int32_t ldu, int32_t ldi, int64_t n_user_rows,
+                       int64_t n_item_rows, const int64_t *u_idx, const int64_t *i_idx, const float *labels, int32_t B,
+                       int32_t d, float *gamma, float *loss_sum, float *grad_users, float *grad_items,
+                       float grad_scale, void *stream);
 
 /* North-star extension (no counterpart in the reference): BPR over (u, i+, i-) triples.
  *   x_t = <U_read[u], I_read[i-] - I_read[i+]>;  loss_sum += softplus(x_t)
@@ -120,11 +125,19 @@ int spex_score_bce_f32(const float *users, const float *items, int32_t ldu, int3
  *   U_w[u]  -= lr * (s_t (i- - i+) + reg u / T);  I_w[i+] -= lr * (-s_t u + reg i+ / T);  I_w[i-] -= lr * (s_t u + reg i- / T)
  * Batch-synchronous when the read tables differ from the write tables; passing the same tables gives in-place
  * (hogwild) matrix-factorisation BPR.  Updates use float atomics (duplicates in a batch accumulate).
- * If lr == 0 and grad tables are wanted instead, pass U_w/I_w = gradient accumulators and lr = -1 (adds the gradient).
  */
-int spex_bpr_sgd_step_f32(const float *U_read, const float *I_read, float *U_w, float *I_w, const int64_t *u,
-                          const int64_t *i_pos, const int64_t *i_neg, int64_t T, int32_t d, float lr, float reg,
-                          float *loss_sum, void *stream);
+int spex_bpr_sgd_step_f32(const float *U_read, const float *I_read, float *U_w, float *I_w, int64_t n_user_rows,
+                          int64_t n_item_rows, const int64_t *u, const int64_t *i_pos, const int64_t *i_neg, int64_t T,
+                          int32_t d, float lr, float reg, float *loss_sum, void *stream);
+
+/* The same triples scored for autograd instead of a fused update (bpr_loss() of the drop-in model):
+ *   loss_sum += sum_t softplus(x_t);  grad_users[u] += grad_scale * sigmoid(x_t) (i- - i+);
+ *   grad_items[i+] -= grad_scale * sigmoid(x_t) u;  grad_items[i-] += grad_scale * sigmoid(x_t) u.
+ * grad tables may be NULL (loss only).  Accumulates with atomics: zero loss_sum / grad tables first.
+ */
+int spex_bpr_loss_f32(const float *users, const float *items, int64_t n_user_rows, int64_t n_item_rows,
+                      const int64_t *u, const int64_t *i_pos, const int64_t *i_neg, int64_t T, int32_t d,
+                      float *loss_sum, float *grad_users, float *grad_items, float grad_scale, void *stream);
 
 /* ------------------------------------------------------------------------------------------------ optimiser
  * Replaces torch.optim.Adam(...).step() over the dense embedding tables — LightGCN_SPEX/code/main_rec.py:23,37.

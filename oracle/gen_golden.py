@@ -228,7 +228,10 @@ def stage_lightgcn(skip_epinion_test=False):
         out.update(nnz=len(col), rowptr_sha=sha(rowptr), col_sha=sha(col), val_sha=sha(val))
         grng = np.random.default_rng(11)
         if full:
-            out.update(rowptr=rowptr, col=col, val=val, train_pairs=tiny_pairs)
+            tus = list(dataset.testRatings.keys())
+            out.update(rowptr=rowptr, col=col, val=val, train_pairs=tiny_pairs, test_users=np.asarray(tus),
+                       test_pos=np.asarray([dataset.testRatings[u][0] for u in tus]),
+                       test_neg=np.asarray([dataset.testNegatives[u] for u in tus]))
         else:
             eidx = np.sort(grng.choice(len(col), 4096, replace=False))
             out.update(edge_idx=eidx, edge_col=col[eidx], edge_val=val[eidx], rowptr=rowptr)

@@ -1,0 +1,70 @@
+"""ctypes binding of libspexhip.so (the C ABI declared in include/spex_hip.h).
+
+There is no CPU fallback: if the library is missing, or a call fails, this module raises.  Build it with
+`python -c "import __graft_entry__ as g; g.build()"` (or `make -C spex_amd/csrc`).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libspexhip.so")
+
+c_i32, c_i64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/spex_hip.h one-to-one (tests/test_abi.py parses the header and checks)
+SIGNATURES = {
+    "spex_version": (ctypes.c_int, []),
+    "spex_last_error": (ctypes.c_char_p, []),
+    "spex_graph_create": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, ctypes.POINTER(c_vp)]),
+    "spex_graph_destroy": (ctypes.c_int, [c_vp]),
+    "spex_graph_info": (ctypes.c_int, [c_vp, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), ctypes.POINTER(c_i64),
+                                       ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
+    "spex_graph_set_edge_mask": (ctypes.c_int, [c_vp, ctypes.c_int, c_vp, c_f32, ctypes.c_uint64]),
+    "spex_spmm_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_f32, c_i32, c_vp]),
+    "spex_propagate_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "spex_propagate_bwd_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "spex_score_bce_f32": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i64, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp,
+                                          c_vp, c_vp, c_vp, c_f32, c_vp]),
+    "spex_bpr_sgd_step_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32,
+                                             c_f32, c_f32, c_vp, c_vp]),
+    "spex_bpr_loss_f32": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp,
+                                         c_f32, c_vp]),
+    "spex_adam_step_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_f32, c_f32, c_vp]),
+    "spex_ngcf_layer_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_f32,
+                                           c_vp]),
+    "spex_expert_gate_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
+}
+
+_lib = None
+
+
+class SpexError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libspexhip.so and bind every symbol of the ABI.  Raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SpexError(
+            f"{LIB_PATH} not found: the HIP extension is not built and spex_amd has no CPU fallback. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` from the repo root.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().spex_last_error().decode("utf-8", "replace")
+        raise SpexError(f"{what or 'libspexhip'} failed with status {rc}: {msg}")
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args), name)

@@ -1,0 +1,71 @@
+// Fused Adam over a dense fp32 table — replaces torch.optim.Adam(...).step(), LightGCN_SPEX/code/main_rec.py:23,37.
+//
+// torch runs this as several elementwise passes (lerp, mul/addcmul, sqrt/div/add, addcdiv); here it is one pass:
+// 16 B read per parameter (p, g, m, v) and 12 B written (p, m, v) = 28 B/param, pure HBM streaming, float4 per lane.
+// Arithmetic order follows torch's single-tensor Adam so that the result matches it to rounding:
+//   m += (g - m) * (1 - beta1);  v = v * beta2 + (1 - beta2) * g * g
+//   denom = sqrt(v) / sqrt(1 - beta2^t) + eps;  p -= (lr / (1 - beta1^t)) * (m / denom)
+#include <math.h>
+
+#include "spex_common.h"
+
+namespace {
+
+__device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, float w1, float beta2, float w2,
+                                      float bc2_sqrt, float eps, float step_size)
+{
+    m = m + w1 * (g - m);
+    v = v * beta2 + w2 * g * g;
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    p = p - step_size * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g,
+                                                   float *__restrict__ m, float *__restrict__ v, int64_t n4,
+                                                   int64_t rem, float w1, float beta2, float w2, float bc2_sqrt,
+                                                   float eps, float step_size)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 P = reinterpret_cast<float4 *>(p)[i];
+        const float4 G = reinterpret_cast<const float4 *>(g)[i];
+        float4 M = reinterpret_cast<float4 *>(m)[i];
+        float4 V = reinterpret_cast<float4 *>(v)[i];
+        adam1(P.x, G.x, M.x, V.x, w1, beta2, w2, bc2_sqrt, eps, step_size);
+        adam1(P.y, G.y, M.y, V.y, w1, beta2, w2, bc2_sqrt, eps, step_size);
+        adam1(P.z, G.z, M.z, V.z, w1, beta2, w2, bc2_sqrt, eps, step_size);
+        adam1(P.w, G.w, M.w, V.w, w1, beta2, w2, bc2_sqrt, eps, step_size);
+        reinterpret_cast<float4 *>(p)[i] = P;
+        reinterpret_cast<float4 *>(m)[i] = M;
+        reinterpret_cast<float4 *>(v)[i] = V;
+    }
+    if (blockIdx.x == 0 && (int64_t)threadIdx.x < rem) {
+        const int64_t i = n4 * 4 + threadIdx.x;
+        float P = p[i], M = m[i], V = v[i];
+        adam1(P, g[i], M, V, w1, beta2, w2, bc2_sqrt, eps, step_size);
+        p[i] = P; m[i] = M; v[i] = V;
+    }
+}
+
+}  // namespace
+
+extern "C" int spex_adam_step_f32(float *p, const float *g, float *m, float *v, int64_t n, int32_t t, float lr,
+                                  float beta1, float beta2, float eps, void *stream)
+{
+    SPEX_CHECK_ARG(p && g && m && v, "spex_adam_step_f32: NULL pointer");
+    SPEX_CHECK_ARG(n >= 0 && t >= 1, "spex_adam_step_f32: n=%lld t=%d (t counts from 1)", (long long)n, t);
+    SPEX_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "spex_adam_step_f32: pointers must be 16-byte aligned");
+    if (n == 0) return SPEX_OK;
+    const double bc1 = 1.0 - pow((double)beta1, (double)t);
+    const double bc2 = 1.0 - pow((double)beta2, (double)t);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    const int64_t n4 = n / 4, rem = n % 4;
+    int64_t blocks = (n4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, rem,
+                       1.0f - beta1, beta2, 1.0f - beta2, bc2_sqrt, eps, step_size);
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}

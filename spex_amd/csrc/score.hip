@@ -1,0 +1,171 @@
+// Negative-sampled scoring kernels: gather + dot + BCE-with-logits (reference semantics) and BPR (north-star
+// extension), forward and backward fused, one wavefront per sample / triple.
+//
+// Replaces LightGCN.forward, LightGCN_SPEX/code/utility1/model.py:111-121, and NGCF compute_rec_loss,
+// NGCF_SPEX/code/main_rec.py:89-100, together with their autograd backward into the gathered tables.
+//
+// A sample touches two (BPR: three) 256-byte rows and writes as many gradient rows: ~1 KB (1.5 KB) of traffic for 128
+// (192) flops — HBM/L2-bound gather/scatter.  Lane == embedding column: each row access is one coalesced 256-byte
+// wave load, the dot product is a 6-step cross-lane butterfly, the gradient rows are added with hardware float
+// atomics shaped as one contiguous 256-byte wave instruction per row (the full-rate shape on MI355X; duplicates of a
+// user within a batch accumulate correctly).
+#include "spex_common.h"
+
+using namespace spex;
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+__device__ __forceinline__ float softplus_f(float x) { return fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x))); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Per-block loss reduction: lane 0 of each wave holds a partial; one atomic per block.
+__device__ __forceinline__ void block_loss_add(float wave_partial, float *loss_sum)
+{
+    __shared__ float s_part[kWavesPerBlock];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    if (lane == 0) s_part[wave] = wave_partial;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < kWavesPerBlock; ++w) t += s_part[w];
+        atomicAdd(loss_sum, t);
+    }
+}
+
+__global__ __launch_bounds__(kWave *kWavesPerBlock) void score_bce_kernel(
+    const float *__restrict__ users, const float *__restrict__ items, int ldu, int ldi, const int64_t *__restrict__ u_idx,
+    const int64_t *__restrict__ i_idx, const float *__restrict__ labels, int B, int d, int64_t n_user_rows,
+    int64_t n_item_rows, float *__restrict__ gamma, float *loss_sum, float *grad_users, float *grad_items,
+    float grad_scale)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave_global = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int n_waves = gridDim.x * kWavesPerBlock;
+    float lsum = 0.0f;
+    for (int b = wave_global; b < B; b += n_waves) {
+        const int64_t u = u_idx[b], it = i_idx[b];
+        if (u < 0 || u >= n_user_rows || it < 0 || it >= n_item_rows) {  // never gather out of bounds
+            if (lane == 0 && gamma) gamma[b] = __int_as_float(0x7fc00000);
+            continue;
+        }
+        const float *pu = users + (size_t)u * ldu, *pi = items + (size_t)it * ldi;
+        float s = 0.0f;
+        for (int c = lane; c < d; c += kWave) s = fmaf(pu[c], pi[c], s);
+        const float x = wave_sum(s);
+        if (lane == 0 && gamma) gamma[b] = x;
+        if (labels) {
+            const float y = labels[b];
+            lsum += fmaxf(x, 0.0f) - x * y + log1pf(expf(-fabsf(x)));
+            if (grad_users) {
+                const float dg = (sigmoid_f(x) - y) * grad_scale;
+                float *gu = grad_users + (size_t)u * ldu, *gi = grad_items + (size_t)it * ldi;
+                for (int c = lane; c < d; c += kWave) {
+                    atomicAdd(gu + c, dg * pi[c]);
+                    atomicAdd(gi + c, dg * pu[c]);
+                }
+            }
+        }
+    }
+    if (labels && loss_sum) block_loss_add(lsum, loss_sum);
+}
+
+// a_coef: multiplies sigmoid(x) (SGD: -lr/T, autograd: grad_scale); b_coef: multiplies the read row (SGD: -lr*reg/T).
+__global__ __launch_bounds__(kWave *kWavesPerBlock) void bpr_kernel(
+    const float *__restrict__ U_read, const float *__restrict__ I_read, float *U_w, float *I_w,
+    const int64_t *__restrict__ u_idx, const int64_t *__restrict__ p_idx, const int64_t *__restrict__ n_idx, int64_t T,
+    int d, int64_t n_user_rows, int64_t n_item_rows, float a_coef, float b_coef, float *loss_sum)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wave_global = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * kWavesPerBlock;
+    float lsum = 0.0f;
+    for (int64_t t = wave_global; t < T; t += n_waves) {
+        const int64_t u = u_idx[t], ip = p_idx[t], in = n_idx[t];
+        if (u < 0 || u >= n_user_rows || ip < 0 || ip >= n_item_rows || in < 0 || in >= n_item_rows) continue;
+        const float *pu = U_read + (size_t)u * d, *pp = I_read + (size_t)ip * d, *pn = I_read + (size_t)in * d;
+        float sp = 0.0f, sn = 0.0f;
+        for (int c = lane; c < d; c += kWave) {
+            const float uu = pu[c];
+            sp = fmaf(uu, pp[c], sp);
+            sn = fmaf(uu, pn[c], sn);
+        }
+        const float x = wave_sum(sn) - wave_sum(sp);  // neg_score - pos_score
+        lsum += softplus_f(x);
+        if (U_w) {
+            const float a = a_coef * sigmoid_f(x);
+            for (int c = lane; c < d; c += kWave) {
+                const float uu = pu[c], vp = pp[c], vn = pn[c];
+                atomicAdd(U_w + (size_t)u * d + c, a * (vn - vp) + b_coef * uu);
+                atomicAdd(I_w + (size_t)ip * d + c, -a * uu + b_coef * vp);
+                atomicAdd(I_w + (size_t)in * d + c, a * uu + b_coef * vn);
+            }
+        }
+    }
+    if (loss_sum) block_loss_add(lsum, loss_sum);
+}
+
+inline unsigned grid_for(int64_t waves_wanted)
+{
+    int64_t blocks = (waves_wanted + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 8) blocks = 256 * 8;  // 8 blocks per CU, grid-stride beyond
+    return (unsigned)blocks;
+}
+
+}  // namespace
+
+extern "C" int spex_score_bce_f32(const float *users, const float *items, int32_t ldu, int32_t ldi,
+                                  int64_t n_user_rows, int64_t n_item_rows, const int64_t *u_idx, const int64_t *i_idx,
+                                  const float *labels, int32_t B, int32_t d, float *gamma, float *loss_sum,
+                                  float *grad_users, float *grad_items, float grad_scale, void *stream)
+{
+    SPEX_CHECK_ARG(users && items && u_idx && i_idx, "spex_score_bce_f32: NULL table or index pointer");
+    SPEX_CHECK_ARG(B >= 0 && d >= 1 && ldu >= d && ldi >= d, "spex_score_bce_f32: B=%d d=%d ldu=%d ldi=%d", B, d, ldu, ldi);
+    SPEX_CHECK_ARG(n_user_rows >= 0 && n_item_rows >= 0, "spex_score_bce_f32: negative table size");
+    SPEX_CHECK_ARG((grad_users == nullptr) == (grad_items == nullptr), "spex_score_bce_f32: give both grad tables or neither");
+    SPEX_CHECK_ARG(!grad_users || labels, "spex_score_bce_f32: gradients need labels");
+    SPEX_CHECK_ARG(gamma || labels, "spex_score_bce_f32: nothing to compute");
+    if (B == 0) return SPEX_OK;
+    hipLaunchKernelGGL(score_bce_kernel, dim3(grid_for(B)), dim3(kWave * kWavesPerBlock), 0, (hipStream_t)stream, users,
+                       items, ldu, ldi, u_idx, i_idx, labels, B, d, n_user_rows, n_item_rows, gamma, loss_sum, grad_users,
+                       grad_items, grad_scale);
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}
+
+extern "C" int spex_bpr_sgd_step_f32(const float *U_read, const float *I_read, float *U_w, float *I_w,
+                                     int64_t n_user_rows, int64_t n_item_rows, const int64_t *u, const int64_t *i_pos,
+                                     const int64_t *i_neg, int64_t T, int32_t d, float lr, float reg, float *loss_sum,
+                                     void *stream)
+{
+    SPEX_CHECK_ARG(U_read && I_read && U_w && I_w && u && i_pos && i_neg, "spex_bpr_sgd_step_f32: NULL pointer");
+    SPEX_CHECK_ARG(T >= 0 && d >= 1, "spex_bpr_sgd_step_f32: T=%lld d=%d", (long long)T, d);
+    if (T == 0) return SPEX_OK;
+    hipLaunchKernelGGL(bpr_kernel, dim3(grid_for(T)), dim3(kWave * kWavesPerBlock), 0, (hipStream_t)stream, U_read, I_read,
+                       U_w, I_w, u, i_pos, i_neg, T, d, n_user_rows, n_item_rows, -lr / (float)T, -lr * reg / (float)T,
+                       loss_sum);
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}
+
+extern "C" int spex_bpr_loss_f32(const float *users, const float *items, int64_t n_user_rows, int64_t n_item_rows,
+                                 const int64_t *u, const int64_t *i_pos, const int64_t *i_neg, int64_t T, int32_t d,
+                                 float *loss_sum, float *grad_users, float *grad_items, float grad_scale, void *stream)
+{
+    SPEX_CHECK_ARG(users && items && u && i_pos && i_neg, "spex_bpr_loss_f32: NULL pointer");
+    SPEX_CHECK_ARG(T >= 0 && d >= 1, "spex_bpr_loss_f32: T=%lld d=%d", (long long)T, d);
+    SPEX_CHECK_ARG((grad_users == nullptr) == (grad_items == nullptr), "spex_bpr_loss_f32: give both grad tables or neither");
+    if (T == 0) return SPEX_OK;
+    hipLaunchKernelGGL(bpr_kernel, dim3(grid_for(T)), dim3(kWave * kWavesPerBlock), 0, (hipStream_t)stream, users, items,
+                       grad_users, grad_items, u, i_pos, i_neg, T, d, n_user_rows, n_item_rows, grad_scale, 0.0f, loss_sum);
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}

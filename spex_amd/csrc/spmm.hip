@@ -1,0 +1,362 @@
+// CSR x dense fp32 SpMM for CDNA4 (gfx950) — the LightGCN / NGCF propagation kernel.
+//
+// Replaces torch.sparse.mm(Graph, all_emb): LightGCN_SPEX/code/utility1/model.py:91, NGCF_SPEX/code/main_rec.py:76.
+//
+// Shape of the work: N rows, ~27 stored entries per row on Epinion2 (median 13, max 1020), each entry gathers one
+// 256-byte embedding row (d = 64 fp32).  0.5 flop per byte: a gather/reduce bound by HBM (or, for the cache-resident
+// named datasets, by L2 / Infinity Cache) — no MFMA, no GEMM reshaping.
+//
+// Mapping: one 64-lane wavefront per row (or per 128-entry segment of a long row); lane == embedding column, so one
+// gathered row is exactly one fully coalesced 256-byte wave load (two 128-byte lines).  The wave first loads up to 64
+// (col, val) pairs with one coalesced load each (lane k holds entry k), then walks them with v_readlane: the column
+// index becomes a scalar, the row address a scalar base + lane offset, and 8 independent row gathers are issued
+// back-to-back before the first fmaf consumes them.  The accumulation is a single fmaf chain in ascending column
+// order, i.e. bit-for-bit the order the reference's CPU kernel uses.
+//
+// Long rows (> 128 entries) would serialise one wave for tens of microseconds, so graph creation cuts them into
+// 128-entry segments; each segment is an ordinary wave task that writes a 256-byte partial row, and a tiny second
+// launch adds a row's partials in segment order (deterministic, no atomics) and applies the epilogue.
+//
+// Epilogue (fused, saves one full pass over the embedding matrix per layer each):
+//   y += add_in / add_div            backward of the layer mean (g/(L+1) + A^T G)
+//   Y = y                            next layer's input (skipped on the last layer)
+//   acc_out = (acc_in + y) / acc_div running sum of layers; acc_div = L+1 on the last layer gives the mean
+//
+// Edge dropout (model.py:46-55) is applied while the (col, val) pairs are loaded: dropped entries are removed from
+// the wave's ballot mask, so they vanish from the sum exactly as if the sparse matrix had been rebuilt without them.
+#include "spex_common.h"
+
+using namespace spex;
+
+namespace {
+
+struct SpmmParams {
+    const int32_t *rowptr, *col;
+    const float *val;
+    const int32_t *edge_id;
+    const int32_t *seg_beg, *seg_end, *long_row, *long_seg0;
+    int32_t n_rows, n_seg, n_long;
+    const float *X;
+    float *Y;
+    const float *add_in;
+    float add_div;
+    const float *acc_in;
+    float *acc_out;
+    float acc_div;
+    float *partial;
+    int32_t d;
+    int mask_mode;
+    const uint8_t *keep;
+    float keep_prob;
+    uint32_t seed_lo, seed_hi;
+};
+
+constexpr int kUnroll = 8;
+
+// philox4x32-10, counter = (edge_id, 0, 0, 0), key = seed.  Returns the first output word.
+__device__ __forceinline__ uint32_t philox_first(uint32_t ctr0, uint32_t k0, uint32_t k1)
+{
+    uint32_t c0 = ctr0, c1 = 0u, c2 = 0u, c3 = 0u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+
+__device__ __forceinline__ bool edge_kept(const SpmmParams &p, int eid)
+{
+    if (p.mask_mode == 1) return p.keep[eid] != 0;
+    // floor(rand + keep_prob) with rand a 24-bit uniform in [0,1), as torch.rand produces (model.py:50-51)
+    const float u = (float)(philox_first((uint32_t)eid, p.seed_lo, p.seed_hi) >> 8) * 5.9604644775390625e-8f;
+    return (u + p.keep_prob) >= 1.0f;
+}
+
+__device__ __forceinline__ float lane_bcast(float v, int src)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+
+// Accumulate entries [beg, end) of one row into acc for the column this lane owns.
+//   Xl      X + (column owned by this lane)
+//   ldx     row stride of X in floats
+//   col_ok  false for lanes beyond d in the generic-d tile
+template <bool MASKED>
+__device__ __forceinline__ float accumulate_range(const SpmmParams &p, int beg, int end, int lane,
+                                                  const float *__restrict__ Xl, int ldx, bool col_ok, float acc)
+{
+    for (int base = beg; base < end; base += kWave) {
+        const int n = (end - base < kWave) ? end - base : kWave;  // wave-uniform
+        int my_col = 0;
+        float my_val = 0.0f;
+        bool my_keep = false;
+        if (lane < n) {
+            my_col = p.col[base + lane];
+            my_val = p.val[base + lane];
+            if (MASKED) {
+                const int eid = p.edge_id ? p.edge_id[base + lane] : base + lane;
+                my_keep = edge_kept(p, eid);
+                my_val = my_val / p.keep_prob;  // values[random_index] / keep_prob, model.py:53
+            }
+        }
+        if (!MASKED) {
+            int i = 0;
+            for (; i + kUnroll <= n; i += kUnroll) {
+                float x[kUnroll];
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    const int c = __builtin_amdgcn_readlane(my_col, i + u);
+                    x[u] = col_ok ? Xl[(size_t)c * ldx] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) acc = fmaf(lane_bcast(my_val, i + u), x[u], acc);
+            }
+            if (i < n) {  // ragged tail: same batch with wave-uniform predicates, loads still issue back-to-back
+                float x[kUnroll];
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    x[u] = 0.0f;
+                    if (i + u < n) {
+                        const int c = __builtin_amdgcn_readlane(my_col, i + u);
+                        x[u] = col_ok ? Xl[(size_t)c * ldx] : 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u)
+                    if (i + u < n) acc = fmaf(lane_bcast(my_val, i + u), x[u], acc);
+            }
+        } else {
+            unsigned long long m = __ballot(my_keep);  // wave-uniform set of surviving entries
+            while (m) {
+                int idx[kUnroll];
+                int cnt = 0;
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    idx[u] = 0;
+                    if (m) {
+                        idx[u] = __builtin_ctzll(m);
+                        m &= m - 1;
+                        cnt = u + 1;
+                    }
+                }
+                float x[kUnroll];
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    x[u] = 0.0f;
+                    if (u < cnt) {
+                        const int c = __builtin_amdgcn_readlane(my_col, idx[u]);
+                        x[u] = col_ok ? Xl[(size_t)c * ldx] : 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u)
+                    if (u < cnt) acc = fmaf(lane_bcast(my_val, idx[u]), x[u], acc);
+            }
+        }
+    }
+    return acc;
+}
+
+__device__ __forceinline__ void finish_row(const SpmmParams &p, int r, int c, float y)
+{
+    const size_t o = (size_t)r * p.d + c;
+    if (p.add_in) y = y + p.add_in[o] / p.add_div;
+    if (p.Y) p.Y[o] = y;
+    if (p.acc_out) p.acc_out[o] = (p.acc_in[o] + y) / p.acc_div;
+}
+
+// Blocks are dealt round-robin over the 8 XCDs; remap so that each XCD walks a contiguous range of row blocks
+// (neighbouring rows share the cache lines where one row's (col,val) run ends and the next begins).  Speed only.
+__device__ __forceinline__ int xcd_contiguous_block(int bid, int nblk)
+{
+    return ((nblk & 7) == 0) ? (bid & 7) * (nblk >> 3) + (bid >> 3) : bid;
+}
+
+// One wave per task.  Tasks [0, n_seg) are long-row segments (heaviest work first), tasks [n_seg, n_seg + n_rows)
+// are rows; rows longer than kLongRow are left to their segments.
+template <bool MASKED, bool D64>
+__global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_rows_kernel(const SpmmParams p)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int task = xcd_contiguous_block(blockIdx.x, gridDim.x) * kWavesPerBlock + wave;
+    const int d = D64 ? 64 : p.d;
+
+    if (task < p.n_seg) {
+        const int beg = p.seg_beg[task], end = p.seg_end[task];
+        for (int c0 = 0; c0 < d; c0 += kWave) {
+            const bool ok = D64 || (c0 + lane < d);
+            const float y = accumulate_range<MASKED>(p, beg, end, lane, p.X + c0 + lane, d, ok, 0.0f);
+            if (ok) p.partial[(size_t)task * d + c0 + lane] = y;
+        }
+        return;
+    }
+    const int r = task - p.n_seg;
+    if (r >= p.n_rows) return;
+    const int beg = p.rowptr[r], end = p.rowptr[r + 1];
+    if (end - beg > kLongRow) return;
+    for (int c0 = 0; c0 < d; c0 += kWave) {
+        const bool ok = D64 || (c0 + lane < d);
+        const float y = accumulate_range<MASKED>(p, beg, end, lane, p.X + c0 + lane, d, ok, 0.0f);
+        if (ok) finish_row(p, r, c0 + lane, y);
+    }
+}
+
+// One wave per long row: add its segment partials in order, then the shared epilogue.
+__global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_long_fixup_kernel(const SpmmParams p)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int i = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (i >= p.n_long) return;
+    const int r = p.long_row[i];
+    const int s0 = p.long_seg0[i], s1 = p.long_seg0[i + 1];
+    for (int c = lane; c < p.d; c += kWave) {
+        float y = 0.0f;
+        int s = s0;
+        for (; s + 4 <= s1; s += 4) {
+            float t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[u] = p.partial[(size_t)(s + u) * p.d + c];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) y = y + t[u];
+        }
+        for (; s < s1; ++s) y = y + p.partial[(size_t)s * p.d + c];
+        finish_row(p, r, c, y);
+    }
+}
+
+// out = in / div, float4-wide grid-stride (the mean's backward share g/(L+1), model.py:95).
+__global__ __launch_bounds__(256) void div_kernel(const float *__restrict__ in, float *__restrict__ out, float div,
+                                                  int64_t n4, int64_t rem)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 v = reinterpret_cast<const float4 *>(in)[i];
+        v.x = v.x / div; v.y = v.y / div; v.z = v.z / div; v.w = v.w / div;
+        reinterpret_cast<float4 *>(out)[i] = v;
+    }
+    if (blockIdx.x == 0 && (int64_t)threadIdx.x < rem) out[n4 * 4 + threadIdx.x] = in[n4 * 4 + threadIdx.x] / div;
+}
+
+int launch_spmm(const spex_graph *g, const float *X, float *Y, const float *add_in, float add_div, const float *acc_in,
+                float *acc_out, float acc_div, int32_t d, hipStream_t stream)
+{
+    if (g->n_rows == 0) return SPEX_OK;
+    SpmmParams p;
+    p.rowptr = g->rowptr; p.col = g->col; p.val = g->val; p.edge_id = g->edge_id;
+    p.seg_beg = g->seg_beg; p.seg_end = g->seg_end; p.long_row = g->long_row; p.long_seg0 = g->long_seg0;
+    p.n_rows = g->n_rows; p.n_seg = g->n_seg; p.n_long = g->n_long;
+    p.X = X; p.Y = Y; p.add_in = add_in; p.add_div = add_div; p.acc_in = acc_in; p.acc_out = acc_out; p.acc_div = acc_div;
+    p.partial = g->partial; p.d = d;
+    p.mask_mode = g->mask_mode; p.keep = g->keep; p.keep_prob = g->keep_prob;
+    p.seed_lo = (uint32_t)g->seed; p.seed_hi = (uint32_t)(g->seed >> 32);
+
+    const int64_t tasks = (int64_t)g->n_seg + g->n_rows;
+    int64_t blocks = (tasks + kWavesPerBlock - 1) / kWavesPerBlock;
+    blocks = (blocks + 7) / 8 * 8;  // multiple of the XCD count so the remap is a bijection
+    const dim3 grid((unsigned)blocks), block(kWave * kWavesPerBlock);
+    const bool masked = g->mask_mode != 0, d64 = d == 64;
+    if (masked && d64) hipLaunchKernelGGL((spmm_rows_kernel<true, true>), grid, block, 0, stream, p);
+    else if (masked) hipLaunchKernelGGL((spmm_rows_kernel<true, false>), grid, block, 0, stream, p);
+    else if (d64) hipLaunchKernelGGL((spmm_rows_kernel<false, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((spmm_rows_kernel<false, false>), grid, block, 0, stream, p);
+    if (g->n_long > 0) {
+        const dim3 fgrid((unsigned)((g->n_long + kWavesPerBlock - 1) / kWavesPerBlock));
+        hipLaunchKernelGGL(spmm_long_fixup_kernel, fgrid, block, 0, stream, p);
+    }
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}
+
+int ensure_partial(spex_graph *g, int32_t d)
+{
+    const int64_t need = (int64_t)g->n_seg * d;
+    if (need <= g->partial_cap) return SPEX_OK;
+    // Only reached for d > 64 on a graph with long rows, on the first call at that d (allocates: do it once outside
+    // any stream capture).
+    SPEX_HIP(hipDeviceSynchronize());
+    if (g->partial) SPEX_HIP(hipFree(g->partial));
+    g->partial = nullptr;
+    SPEX_HIP(hipMalloc((void **)&g->partial, (size_t)need * sizeof(float)));
+    g->partial_cap = need;
+    return SPEX_OK;
+}
+
+}  // namespace
+
+extern "C" int spex_spmm_f32(const spex_graph_t *g, const float *X, float *Y, const float *add_in, float add_div,
+                             const float *acc_in, float *acc_out, float acc_div, int32_t d, void *stream)
+{
+    SPEX_CHECK_ARG(g && X, "spex_spmm_f32: NULL graph or X");
+    SPEX_CHECK_ARG(d >= 1, "spex_spmm_f32: d = %d", d);
+    SPEX_CHECK_ARG(Y || acc_out, "spex_spmm_f32: neither Y nor acc_out given");
+    SPEX_CHECK_ARG(!acc_out || acc_in, "spex_spmm_f32: acc_out needs acc_in");
+    SPEX_CHECK_ARG(X != Y && X != acc_out, "spex_spmm_f32: X must not alias an output");
+    SPEX_CHECK_ARG(!add_in || add_div != 0.0f, "spex_spmm_f32: add_div == 0");
+    SPEX_CHECK_ARG(!acc_out || acc_div != 0.0f, "spex_spmm_f32: acc_div == 0");
+    int rc = ensure_partial(const_cast<spex_graph *>(g), d);
+    if (rc) return rc;
+    return launch_spmm(g, X, Y, add_in, add_div, acc_in, acc_out, acc_div, d, (hipStream_t)stream);
+}
+
+extern "C" int spex_propagate_f32(const spex_graph_t *g, const float *E0, float *mean_out, float *layers_out, float *ws,
+                                  int32_t L, int32_t d, void *stream)
+{
+    SPEX_CHECK_ARG(g && E0 && mean_out, "spex_propagate_f32: NULL argument");
+    SPEX_CHECK_ARG(g->n_rows == g->n_cols, "spex_propagate_f32: needs a square graph (%d x %d); use spex_spmm_f32 per layer for a row block", g->n_rows, g->n_cols);
+    SPEX_CHECK_ARG(L >= 0 && d >= 1, "spex_propagate_f32: L = %d, d = %d", L, d);
+    SPEX_CHECK_ARG(layers_out || ws || L <= 1, "spex_propagate_f32: needs ws or layers_out");
+    SPEX_CHECK_ARG(E0 != mean_out, "spex_propagate_f32: mean_out must not alias E0");
+    int rc = ensure_partial(const_cast<spex_graph *>(g), d);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t sz = (size_t)g->n_rows * d;
+    if (L == 0) {
+        SPEX_HIP(hipMemcpyAsync(mean_out, E0, sz * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return SPEX_OK;
+    }
+    const float *cur = E0;
+    for (int32_t l = 0; l < L; ++l) {
+        const bool last = l == L - 1;
+        float *nxt = layers_out ? layers_out + (size_t)l * sz : (last ? nullptr : ws + (size_t)(l & 1) * sz);
+        rc = launch_spmm(g, cur, nxt, nullptr, 1.0f, l == 0 ? E0 : mean_out, mean_out, last ? (float)(L + 1) : 1.0f, d, s);
+        if (rc) return rc;
+        cur = nxt;
+    }
+    return SPEX_OK;
+}
+
+extern "C" int spex_propagate_bwd_f32(const spex_graph_t *gt, const float *g_out, float *grad_E0, float *ws, int32_t L,
+                                      int32_t d, void *stream)
+{
+    SPEX_CHECK_ARG(gt && g_out && grad_E0 && ws, "spex_propagate_bwd_f32: NULL argument");
+    SPEX_CHECK_ARG(gt->n_rows == gt->n_cols, "spex_propagate_bwd_f32: needs a square graph");
+    SPEX_CHECK_ARG(L >= 0 && d >= 1, "spex_propagate_bwd_f32: L = %d, d = %d", L, d);
+    SPEX_CHECK_ARG(g_out != grad_E0, "spex_propagate_bwd_f32: grad_E0 must not alias g_out");
+    int rc = ensure_partial(const_cast<spex_graph *>(gt), d);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t sz = (size_t)gt->n_rows * d;
+    if (sz == 0) return SPEX_OK;
+    // gs = g_out / (L+1) is every layer's share of the mean's gradient and the first gather source (= G_L).
+    float *gs = (L == 0) ? grad_E0 : ws;
+    {
+        const int64_t n4 = (int64_t)(sz / 4), rem = (int64_t)(sz % 4);
+        const int64_t blocks = (n4 + 255) / 256 < 2048 ? ((n4 + 255) / 256 > 0 ? (n4 + 255) / 256 : 1) : 2048;
+        hipLaunchKernelGGL(div_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g_out, gs, (float)(L + 1), n4, rem);
+    }
+    const float *cur = gs;
+    for (int32_t l = L - 1; l >= 0; --l) {
+        float *nxt = (l == 0) ? grad_E0 : ws + (size_t)(1 + (l & 1)) * sz;
+        rc = launch_spmm(gt, cur, nxt, gs, 1.0f, nullptr, nullptr, 1.0f, d, s);
+        if (rc) return rc;
+        cur = nxt;
+    }
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}

@@ -1,0 +1,192 @@
+"""Adjacency construction (host) and the device graph handle.
+
+Host side builds the normalised user-item adjacency as CSR directly from the interaction pairs — one vectorised
+sort instead of the reference's dok fill + lil slicing (3 s + 7 s on Epinion2, LightGCN_SPEX/code/utility1/
+dataloader.py:98-100,197-212) — with the same fp32 arithmetic, so the values are bit-identical to what the reference
+caches in s_pre_adj_mat.npz.  `SpexGraph` then owns the HBM copy through libspexhip's graph handle.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+# ------------------------------------------------------------------------------------------------ host CSR builders
+def bipartite_csr(users, items, n_u, n_i, self_loops=False):
+    """CSR structure of [[0, R], [R^T, 0]] (+ I): rows ascending, columns ascending within a row (= coalesced COO
+    order, dataloader.py:222).  Repeated (u, i) pairs collapse to one entry, as in the reference's dok assignment
+    (dataloader.py:98-100,110)."""
+    key = np.unique(np.asarray(users, np.int64) * np.int64(n_i) + np.asarray(items, np.int64))
+    uu, ii = key // n_i, key % n_i
+    n = n_u + n_i
+    rows = np.concatenate([uu, ii + n_u])
+    cols = np.concatenate([ii + n_u, uu])
+    if self_loops:
+        eye = np.arange(n, dtype=np.int64)
+        rows, cols = np.concatenate([rows, eye]), np.concatenate([cols, eye])
+    order = np.argsort(rows * np.int64(n) + cols, kind="stable")
+    rows, cols = rows[order], cols[order]
+    rowptr = np.zeros(n + 1, np.int64)
+    np.cumsum(np.bincount(rows, minlength=n), out=rowptr[1:])
+    return rowptr.astype(np.int32), rows.astype(np.int32), cols.astype(np.int32)
+
+
+def lightgcn_norm_adj(users, items, n_user, m_item):
+    """A_hat = D^-1/2 [[0,R],[R^T,0]] D^-1/2 over (n_user + 1 pad row) + m_item nodes; fp32; zero-degree rows stay
+    empty; no self loops.  Mirrors dataloader.py:197-212: val = (d_r^-1/2 * a_rc) * d_c^-1/2 rounded after each
+    product."""
+    rowptr, rows, cols = bipartite_csr(users, items, n_user + 1, m_item)
+    deg = np.diff(rowptr).astype(np.float32)
+    with np.errstate(divide="ignore"):
+        d_inv = np.power(deg, -0.5).astype(np.float32)
+    d_inv[np.isinf(d_inv)] = 0.0
+    val = ((d_inv[rows] * np.float32(1.0)) * d_inv[cols]).astype(np.float32)
+    return rowptr, cols, val
+
+
+def ngcf_norm_adj(users, items, n_users, n_items):
+    """norm_adj = D^-1 (A + I) (NGCF_SPEX/code/utility/load_data.py:135-144,162), computed in float64 as the
+    reference does (sp.eye is float64) and cast to fp32 where the model converts it (NGCF main_rec.py:104)."""
+    rowptr, rows, cols = bipartite_csr(users, items, n_users, n_items, self_loops=True)
+    deg = np.diff(rowptr).astype(np.float64)
+    with np.errstate(divide="ignore"):
+        d_inv = np.power(deg, -1.0)
+    d_inv[np.isinf(d_inv)] = 0.0
+    return rowptr, cols, d_inv[rows].astype(np.float32)
+
+
+def csr_transpose(rowptr, col, val, n_cols):
+    """CSR of A^T plus, per transposed entry, the index of the original entry (edge_id) so that an edge keep-mask
+    drawn for A addresses the same edges in A^T."""
+    n_rows = len(rowptr) - 1
+    rows = np.repeat(np.arange(n_rows, dtype=np.int64), np.diff(rowptr))
+    order = np.argsort(np.asarray(col, np.int64) * np.int64(n_rows) + rows, kind="stable")
+    t_rowptr = np.zeros(n_cols + 1, np.int64)
+    np.cumsum(np.bincount(col, minlength=n_cols), out=t_rowptr[1:])
+    return (t_rowptr.astype(np.int32), rows[order].astype(np.int32), np.asarray(val, np.float32)[order],
+            order.astype(np.int32))
+
+
+def row_block(rowptr, col, val, r0, r1, edge_id=None):
+    """Rows [r0, r1) of a CSR matrix as a CSR block with global column ids (1-D row partition)."""
+    b, e = int(rowptr[r0]), int(rowptr[r1])
+    eid = None if edge_id is None else np.ascontiguousarray(edge_id[b:e])
+    return (np.ascontiguousarray(rowptr[r0:r1 + 1] - rowptr[r0]).astype(np.int32), np.ascontiguousarray(col[b:e]),
+            np.ascontiguousarray(val[b:e]), eid)
+
+
+# ------------------------------------------------------------------------------------------------ device handle
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class SpexGraph:
+    """A CSR matrix (or a row block of one) resident in HBM.  Stands where the reference keeps its
+    torch.sparse.FloatTensor `Graph` (dataloader.py:221-222; model.py:38)."""
+
+    def __init__(self, rowptr, col, val, n_cols=None, edge_id=None, device=None):
+        rowptr = np.ascontiguousarray(rowptr, np.int32)
+        col = np.ascontiguousarray(col, np.int32)
+        val = np.ascontiguousarray(val, np.float32)
+        self.n_rows = len(rowptr) - 1
+        self.n_cols = int(n_cols if n_cols is not None else self.n_rows)
+        self.nnz = int(len(col))
+        self.host = (rowptr, col, val)
+        if edge_id is not None:
+            edge_id = np.ascontiguousarray(edge_id, np.int32)
+        self.device = torch.device(device if device is not None else "cuda")
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.call("spex_graph_create", rowptr.ctypes.data_as(ctypes.c_void_p), col.ctypes.data_as(ctypes.c_void_p),
+                      val.ctypes.data_as(ctypes.c_void_p),
+                      edge_id.ctypes.data_as(ctypes.c_void_p) if edge_id is not None else None,
+                      self.n_rows, self.n_cols, self.nnz, ctypes.byref(handle))
+        self._h = handle
+        nl, ns = ctypes.c_int32(), ctypes.c_int32()
+        _lib.call("spex_graph_info", self._h, None, None, None, ctypes.byref(nl), ctypes.byref(ns))
+        self.n_long_rows, self.n_segments = nl.value, ns.value
+        self._mask_ref = None
+
+    # torch.sparse-like surface used by callers that only inspect the graph (dataloader.py:223 prints .size())
+    def size(self):
+        return torch.Size([self.n_rows, self.n_cols])
+
+    shape = property(size)
+
+    def _nnz(self):
+        return self.nnz
+
+    def to_torch_sparse(self, device="cpu"):
+        rowptr, col, val = self.host
+        rows = np.repeat(np.arange(self.n_rows, dtype=np.int64), np.diff(rowptr))
+        idx = torch.from_numpy(np.stack([rows, col.astype(np.int64)]))
+        return torch.sparse_coo_tensor(idx, torch.from_numpy(val), (self.n_rows, self.n_cols)).coalesce().to(device)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.load().spex_graph_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- edge dropout (model.py:46-55)
+    def set_edge_mask(self, mode=0, keep=None, keep_prob=1.0, seed=0):
+        """mode 0: off; 1: injected device uint8 mask `keep` (indexed by edge id); 2: counter-based sampled mask."""
+        if keep is not None:
+            assert keep.dtype == torch.uint8 and keep.is_cuda and keep.is_contiguous()
+        self._mask_ref = keep  # keep the tensor alive while the handle points at it
+        _lib.call("spex_graph_set_edge_mask", self._h, int(mode), _ptr(keep), float(keep_prob), int(seed))
+
+    # -- kernels
+    def _chk(self, t, rows, d, name):
+        if t is None:
+            return
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise ValueError(f"{name}: need a contiguous fp32 tensor on the GPU")
+        if t.shape != (rows, d):
+            raise ValueError(f"{name}: shape {tuple(t.shape)} != {(rows, d)}")
+
+    def spmm(self, X, Y=None, add_in=None, add_div=1.0, acc_in=None, acc_out=None, acc_div=1.0):
+        """y = A X (+ add_in/add_div); Y = y; acc_out = (acc_in + y)/acc_div.  See spex_spmm_f32."""
+        d = X.shape[1]
+        self._chk(X, self.n_cols, d, "X")
+        if Y is None and acc_out is None:
+            Y = torch.empty((self.n_rows, d), dtype=torch.float32, device=X.device)
+        for t, nm in ((Y, "Y"), (add_in, "add_in"), (acc_in, "acc_in"), (acc_out, "acc_out")):
+            self._chk(t, self.n_rows, d, nm)
+        _lib.call("spex_spmm_f32", self._h, _ptr(X), _ptr(Y), _ptr(add_in), float(add_div), _ptr(acc_in), _ptr(acc_out),
+                  float(acc_div), d, _stream())
+        return Y if Y is not None else acc_out
+
+    def propagate(self, E0, n_layers, mean_out=None, layers_out=None, ws=None):
+        """LightGCN.computer() (model.py:66-97) on a whole graph: returns mean(E0..EL)."""
+        n, d = E0.shape
+        self._chk(E0, self.n_cols, d, "E0")
+        if mean_out is None:
+            mean_out = torch.empty_like(E0)
+        if layers_out is None and ws is None and n_layers > 1:
+            ws = torch.empty((2, n, d), dtype=torch.float32, device=E0.device)
+        _lib.call("spex_propagate_f32", self._h, _ptr(E0), _ptr(mean_out), _ptr(layers_out), _ptr(ws), int(n_layers), d,
+                  _stream())
+        return mean_out
+
+    def propagate_bwd(self, g_out, n_layers, grad_E0=None, ws=None):
+        """Gradient of propagate() w.r.t. E0; `self` must be the handle of A^T."""
+        n, d = g_out.shape
+        self._chk(g_out, self.n_rows, d, "g_out")
+        if grad_E0 is None:
+            grad_E0 = torch.empty_like(g_out)
+        if ws is None:
+            ws = torch.empty((3, n, d), dtype=torch.float32, device=g_out.device)
+        _lib.call("spex_propagate_bwd_f32", self._h, _ptr(g_out), _ptr(grad_E0), _ptr(ws), int(n_layers), d, _stream())
+        return grad_E0

@@ -1,0 +1,190 @@
+"""Thin torch-facing wrappers over libspexhip's kernels and the autograd Functions the drop-in models use.
+
+PyTorch here is plumbing (device memory, streams, autograd bookkeeping); every flop below runs in the HIP kernels of
+spex_amd/csrc/ through the C ABI.  No function in this module has a CPU path.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from .graph import _ptr, _stream
+
+
+def _need(t, name, dtype=torch.float32):
+    if t is None:
+        return
+    if not t.is_cuda or t.dtype != dtype or not t.is_contiguous():
+        raise ValueError(f"{name}: need a contiguous {dtype} CUDA tensor (got {t.dtype}, cuda={t.is_cuda}, "
+                         f"contiguous={t.is_contiguous()})")
+
+
+def _idx(t, device):
+    """Indices as the reference hands them over (int64, possibly on the host: main_rec.py:33-34)."""
+    if not torch.is_tensor(t):
+        t = torch.as_tensor(t)
+    return t.to(device=device, dtype=torch.int64, non_blocking=True).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ raw kernels
+def score_bce(users_tab, items_tab, u_idx, i_idx, labels=None, grad_users=None, grad_items=None, grad_scale=0.0):
+    """gamma (and, with labels, the BCE loss *sum* and optional gradient rows).  spex_score_bce_f32."""
+    _need(users_tab, "users_tab"); _need(items_tab, "items_tab")
+    dev = users_tab.device
+    u_idx, i_idx = _idx(u_idx, dev), _idx(i_idx, dev)
+    B, d = u_idx.numel(), users_tab.shape[1]
+    gamma = torch.empty(B, dtype=torch.float32, device=dev)
+    loss_sum = None
+    if labels is not None:
+        labels = labels.to(device=dev, dtype=torch.float32).contiguous()
+        loss_sum = torch.zeros(1, dtype=torch.float32, device=dev)
+    _need(grad_users, "grad_users"); _need(grad_items, "grad_items")
+    _lib.call("spex_score_bce_f32", _ptr(users_tab), _ptr(items_tab), users_tab.stride(0), items_tab.stride(0),
+              users_tab.shape[0], items_tab.shape[0], _ptr(u_idx), _ptr(i_idx), _ptr(labels), B, d, _ptr(gamma),
+              _ptr(loss_sum), _ptr(grad_users), _ptr(grad_items), float(grad_scale), _stream())
+    return gamma, loss_sum
+
+
+def bpr_sgd_step(U_read, I_read, U_w, I_w, u, i_pos, i_neg, lr, reg=0.0):
+    """Fused gather + dot + sigmoid + SGD over triples (north-star extension).  Returns the loss *sum* tensor."""
+    for t, n in ((U_read, "U_read"), (I_read, "I_read"), (U_w, "U_w"), (I_w, "I_w")):
+        _need(t, n)
+    dev = U_read.device
+    u, i_pos, i_neg = _idx(u, dev), _idx(i_pos, dev), _idx(i_neg, dev)
+    loss_sum = torch.zeros(1, dtype=torch.float32, device=dev)
+    _lib.call("spex_bpr_sgd_step_f32", _ptr(U_read), _ptr(I_read), _ptr(U_w), _ptr(I_w), U_read.shape[0], I_read.shape[0],
+              _ptr(u), _ptr(i_pos), _ptr(i_neg), u.numel(), U_read.shape[1], float(lr), float(reg), _ptr(loss_sum),
+              _stream())
+    return loss_sum
+
+
+def bpr_loss_grad(users_tab, items_tab, u, i_pos, i_neg, grad_users=None, grad_items=None, grad_scale=0.0):
+    _need(users_tab, "users_tab"); _need(items_tab, "items_tab")
+    dev = users_tab.device
+    u, i_pos, i_neg = _idx(u, dev), _idx(i_pos, dev), _idx(i_neg, dev)
+    loss_sum = torch.zeros(1, dtype=torch.float32, device=dev)
+    _lib.call("spex_bpr_loss_f32", _ptr(users_tab), _ptr(items_tab), users_tab.shape[0], items_tab.shape[0], _ptr(u),
+              _ptr(i_pos), _ptr(i_neg), u.numel(), users_tab.shape[1], _ptr(loss_sum), _ptr(grad_users),
+              _ptr(grad_items), float(grad_scale), _stream())
+    return loss_sum
+
+
+def adam_step(p, g, m, v, t, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
+    """In-place fused Adam over one flat fp32 buffer (main_rec.py:23,37).  t counts from 1."""
+    for x, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _need(x, n)
+    _lib.call("spex_adam_step_f32", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), int(t), float(lr), float(beta1),
+              float(beta2), float(eps), _stream())
+
+
+def ngcf_layer(ego, side, W_gc, b_gc, W_bi, b_bi, slope=0.01, want_e1=False):
+    """[ego | normalize(LReLU(side W_gc^T + b) + LReLU((ego*side) W_bi^T + b))] — NGCF main_rec.py:77-85."""
+    for x, n in ((ego, "ego"), (side, "side"), (W_gc, "W_gc"), (b_gc, "b_gc"), (W_bi, "W_bi"), (b_bi, "b_bi")):
+        _need(x, n)
+    n, d = ego.shape
+    out = torch.empty((n, 2 * d), dtype=torch.float32, device=ego.device)
+    e1 = torch.empty((n, d), dtype=torch.float32, device=ego.device) if want_e1 else None
+    _lib.call("spex_ngcf_layer_f32", _ptr(ego), _ptr(side), _ptr(W_gc), _ptr(b_gc), _ptr(W_bi), _ptr(b_bi), _ptr(out),
+              2 * d, _ptr(e1), n, d, float(slope), _stream())
+    return (out, e1) if want_e1 else out
+
+
+def expert_gate(raw, prop, att_exp):
+    """softmax([raw|prop] att_exp) two-way mix — model_expert_s.py:156-161."""
+    for x, n in ((raw, "raw"), (prop, "prop"), (att_exp, "att_exp")):
+        _need(x, n)
+    mixed = torch.empty_like(raw)
+    _lib.call("spex_expert_gate_f32", _ptr(raw), _ptr(prop), _ptr(att_exp), _ptr(mixed), raw.shape[0], raw.shape[1],
+              _stream())
+    return mixed
+
+
+# ------------------------------------------------------------------------------------------------ autograd glue
+def _flat_tables(user_w, item_w):
+    """The two embedding tables as one [N, d] buffer.  The drop-in model allocates them back-to-back so this is a
+    view; otherwise (foreign parameters) it costs one concatenation, like model.py:72."""
+    if (user_w.is_contiguous() and item_w.is_contiguous()
+            and user_w.untyped_storage().data_ptr() == item_w.untyped_storage().data_ptr()
+            and user_w.data_ptr() + user_w.numel() * 4 == item_w.data_ptr()):
+        n = user_w.shape[0] + item_w.shape[0]
+        return torch.as_strided(user_w.detach(), (n, user_w.shape[1]), (user_w.shape[1], 1))
+    return torch.cat([user_w.detach(), item_w.detach()])
+
+
+class PropagateMean(torch.autograd.Function):
+    """light_out = mean_l(A^l E0) — LightGCN.computer(), model.py:66-97, with its autograd backward.
+
+    graph / graph_t: SpexGraph of A and of A^T (the same object for the symmetric LightGCN adjacency without dropout).
+    mask: None or (mode, keep_tensor, keep_prob, seed) applied identically in forward and backward.
+    """
+
+    @staticmethod
+    def forward(ctx, user_w, item_w, graph, graph_t, n_layers, mask):
+        E0 = _flat_tables(user_w, item_w)
+        if mask is not None:
+            graph.set_edge_mask(*mask)
+        try:
+            out = graph.propagate(E0, n_layers)
+        finally:
+            if mask is not None:
+                graph.set_edge_mask(0)
+        ctx.graph_t, ctx.n_layers, ctx.mask, ctx.n_user_rows = graph_t, n_layers, mask, user_w.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        g_out = g_out.contiguous()
+        gt = ctx.graph_t
+        if ctx.mask is not None:
+            gt.set_edge_mask(*ctx.mask)
+        try:
+            gE0 = gt.propagate_bwd(g_out, ctx.n_layers)
+        finally:
+            if ctx.mask is not None:
+                gt.set_edge_mask(0)
+        u = ctx.n_user_rows
+        return gE0[:u], gE0[u:], None, None, None, None
+
+
+class ScoreBCELoss(torch.autograd.Function):
+    """mean BCEWithLogits(<users[u], items[i]>, y) over the batch — model.py:115-120 — on the whole [N, d] table
+    (users first, items after `n_user_rows`); backward yields the dense, mostly-zero table gradient that the
+    propagation backward consumes, exactly like the reference's autograd."""
+
+    @staticmethod
+    def forward(ctx, light_out, n_user_rows, u_idx, i_idx, labels):
+        users_tab, items_tab = light_out[:n_user_rows], light_out[n_user_rows:]
+        B = u_idx.numel()
+        grad = torch.zeros_like(light_out) if ctx.needs_input_grad[0] else None
+        gamma, loss_sum = score_bce(users_tab, items_tab, u_idx, i_idx, labels,
+                                    grad[:n_user_rows] if grad is not None else None,
+                                    grad[n_user_rows:] if grad is not None else None, 1.0 / B)
+        ctx.grad = grad
+        return (loss_sum / B).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        grad = ctx.grad
+        ctx.grad = None
+        return grad * g, None, None, None, None
+
+
+class BPRLoss(torch.autograd.Function):
+    """mean softplus(<u,i-> - <u,i+>) (north-star extension; upstream LightGCN-PyTorch bpr_loss semantics)."""
+
+    @staticmethod
+    def forward(ctx, light_out, n_user_rows, u, i_pos, i_neg):
+        users_tab, items_tab = light_out[:n_user_rows], light_out[n_user_rows:]
+        T = u.numel()
+        grad = torch.zeros_like(light_out) if ctx.needs_input_grad[0] else None
+        loss_sum = bpr_loss_grad(users_tab, items_tab, u, i_pos, i_neg,
+                                 grad[:n_user_rows] if grad is not None else None,
+                                 grad[n_user_rows:] if grad is not None else None, 1.0 / T)
+        ctx.grad = grad
+        return (loss_sum / T).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        grad = ctx.grad
+        ctx.grad = None
+        return grad * g, None, None, None, None

@@ -1,0 +1,70 @@
+"""Autograd-free training steps on pre-allocated HBM buffers — what a production loop (and bench.py) drives.
+
+The drop-in model keeps torch autograd + torch.optim so the reference drivers run unchanged; this class is the same
+mathematics as main_rec.py:30-37 issued as a fixed sequence of libspexhip launches with no allocation, no host
+synchronisation and no Python between kernels beyond the ctypes calls (capturable in a HIP graph):
+
+    exact step  (reference semantics):  L x SpMM (mean fused)  ->  score + BCE + grad rows  ->  L x SpMM^T (g/(L+1)
+                                        fused)  ->  fused Adam over the whole [N, d] table
+    bpr step    (north-star extension): L x SpMM (mean fused)  ->  fused gather + dot + sigmoid + SGD over triples,
+                                        scores read from the propagated table, updates applied to E0
+"""
+import torch
+
+from . import ops
+
+
+class LightGCNStepper:
+    def __init__(self, graph, E0, n_user_rows, n_layers=3, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, graph_t=None):
+        assert E0.is_cuda and E0.dtype == torch.float32 and E0.is_contiguous()
+        self.graph, self.graph_t = graph, (graph_t if graph_t is not None else graph)
+        self.E0, self.n_u, self.L = E0, int(n_user_rows), int(n_layers)
+        self.lr, self.betas, self.eps = lr, betas, eps
+        n, d = E0.shape
+        dev = E0.device
+        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+        self.light_out = z(n, d)
+        self.ws_fwd = z(2, n, d)
+        self.g_out = z(n, d)
+        self.ws_bwd = z(3, n, d)
+        self.grad_E0 = z(n, d)
+        self.m, self.v = z(n, d), z(n, d)
+        self.t = 0
+
+    # -- pieces
+    def propagate(self):
+        return self.graph.propagate(self.E0, self.L, mean_out=self.light_out, ws=self.ws_fwd)
+
+    def step_bce(self, users, items, labels):
+        """One exact reference training step (main_rec.py:32-37).  Returns the mean BCE loss (device tensor)."""
+        self.propagate()
+        self.g_out.zero_()
+        B = users.numel()
+        lo = self.light_out
+        _, loss_sum = ops.score_bce(lo[:self.n_u], lo[self.n_u:], users, items, labels, self.g_out[:self.n_u],
+                                    self.g_out[self.n_u:], 1.0 / B)
+        self.graph_t.propagate_bwd(self.g_out, self.L, grad_E0=self.grad_E0, ws=self.ws_bwd)
+        self.t += 1
+        ops.adam_step(self.E0, self.grad_E0, self.m, self.v, self.t, self.lr, self.betas[0], self.betas[1], self.eps)
+        return loss_sum / B
+
+    def step_bpr_sgd(self, users, pos, neg, lr=None, reg=0.0):
+        """Propagation + fused BPR-SGD kernel (scores from the propagated table, update on E0).  Loss mean."""
+        self.propagate()
+        lo = self.light_out
+        loss_sum = ops.bpr_sgd_step(lo[:self.n_u], lo[self.n_u:], self.E0[:self.n_u], self.E0[self.n_u:], users, pos,
+                                    neg, self.lr if lr is None else lr, reg)
+        return loss_sum / users.numel()
+
+    def step_bpr_exact(self, users, pos, neg):
+        """BPR loss differentiated through the propagation, Adam update (upstream LightGCN training semantics)."""
+        self.propagate()
+        self.g_out.zero_()
+        T = users.numel()
+        lo = self.light_out
+        loss_sum = ops.bpr_loss_grad(lo[:self.n_u], lo[self.n_u:], users, pos, neg, self.g_out[:self.n_u],
+                                     self.g_out[self.n_u:], 1.0 / T)
+        self.graph_t.propagate_bwd(self.g_out, self.L, grad_E0=self.grad_E0, ws=self.ws_bwd)
+        self.t += 1
+        ops.adam_step(self.E0, self.grad_E0, self.m, self.v, self.t, self.lr, self.betas[0], self.betas[1], self.eps)
+        return loss_sum / T

@@ -1,0 +1,82 @@
+"""The C-ABI library loads on a GPU-less host and exports exactly what include/spex_hip.h declares.
+No compute entry point is launched here (argument validation that returns before touching the device is fine)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from spex_amd import _lib
+
+HEADER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "spex_hip.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(spex_[a-z0-9_]+)\s*\(", src)) - {"spex_status"})
+
+
+def test_header_declares_and_library_exports_every_symbol():
+    names = declared_functions()
+    assert len(names) >= 14
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"libspexhip.so does not export {n}"
+    assert sorted(_lib.SIGNATURES) == names, "spex_amd/_lib.py binds a different symbol set than the header declares"
+
+
+def test_binding_arity_matches_header():
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    for name, (_, argtypes) in _lib.SIGNATURES.items():
+        m = re.search(r"\b%s\s*\((.*?)\)\s*;" % name, src, flags=re.S)
+        assert m, name
+        params = m.group(1).strip()
+        n = 0 if params in ("", "void") else params.count(",") + 1
+        assert n == len(argtypes), f"{name}: header has {n} parameters, binding has {len(argtypes)}"
+
+
+def test_version_and_error_string():
+    lib = _lib.load()
+    assert lib.spex_version() == 1
+    assert isinstance(lib.spex_last_error(), bytes)
+
+
+def test_argument_validation_fails_loudly_before_touching_the_device():
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    rowptr = np.array([0, 2, 1], np.int32)      # not monotone
+    col = np.array([0, 1], np.int32)
+    val = np.ones(2, np.float32)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    rc = lib.spex_graph_create(p(rowptr), p(col), p(val), None, 2, 2, 1, ctypes.byref(h))
+    assert rc == -1 and b"rowptr" in lib.spex_last_error()
+    rowptr = np.array([0, 1, 2], np.int32)
+    col = np.array([0, 7], np.int32)            # column out of range: would be an out-of-bounds gather
+    rc = lib.spex_graph_create(p(rowptr), p(col), p(val), None, 2, 2, 2, ctypes.byref(h))
+    assert rc == -1 and b"out of range" in lib.spex_last_error()
+    col = np.array([1, 0, 0], np.int32)
+    rowptr = np.array([0, 3, 3], np.int32)      # unsorted / duplicate columns: not coalesced
+    rc = lib.spex_graph_create(p(rowptr), p(col), p(np.ones(3, np.float32)), None, 2, 2, 3, ctypes.byref(h))
+    assert rc == -1 and b"ascending" in lib.spex_last_error()
+    with pytest.raises(_lib.SpexError):
+        _lib.call("spex_spmm_f32", None, None, None, None, 1.0, None, None, 1.0, 64, None)
+    with pytest.raises(_lib.SpexError):
+        _lib.call("spex_adam_step_f32", None, None, None, None, 10, 1, 1e-3, 0.9, 0.999, 1e-8, None)
+
+
+def test_missing_library_is_an_error_not_a_fallback(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.SpexError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_product_never_imports_the_oracle():
+    root = os.path.join(os.path.dirname(HEADER), "..", "spex_amd")
+    for dp, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "oracle" not in txt.lower() or f in ("datasets.py",), f"{f} mentions the oracle"

@@ -1,0 +1,184 @@
+"""Host-side logic of the drop-in surface, on CPU: flags, file formats, adjacency construction, negative sampler,
+ranking metrics, the evaluation loop's tie semantics, the launcher's import order."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO
+from test_oracle_golden import sha
+
+
+def test_lg_parser_defaults_match_reference_flags():
+    import lg_parser
+    a = lg_parser.parse_args_r([])
+    # lg_parser.py:5-21 of the reference
+    assert (a.cuda_id, a.data_path, a.dataset, a.nb_heads, a.recdim, a.layer) == ("0", "../data/", "twitter", 3, 64, 3)
+    assert (a.lr, a.dropout, a.keepprob, a.a_fold, a.epochs, a.seed) == (0.001, 0, 0.6, 100, 50, 2020)
+    assert (a.A_split, a.batch_size, a.batchSize, a.hiddenSize, a.nonhybrid, a.act) == (0, 256, 256, 64, False, 1)
+    b = lg_parser.parse_args_r("--dataset epinion2 --recdim 32 --layer 2 --dropout 1 --keepprob 0.3 --nonhybrid".split())
+    assert (b.dataset, b.recdim, b.layer, b.dropout, b.keepprob, b.nonhybrid) == ("epinion2", 32, 2, 1, 0.3, True)
+
+
+@pytest.fixture(scope="module")
+def tiny_loader(tmp_path_factory, golden):
+    from spex_amd.datasets import materialise_rating_files
+    import lg_parser
+    import utility1.dataloader as dl
+    g = golden("lightgcn_tiny")
+    root = materialise_rating_files(str(tmp_path_factory.mktemp("data")), "tiny", g["train_pairs"], g["test_users"],
+                                    g["test_pos"], g["test_neg"])
+    args = lg_parser.parse_args_r(["--dataset", "tiny", "--data_path", root])
+    return dl.Loader(args), g
+
+
+def test_loader_surface_and_adjacency_tiny(tiny_loader):
+    ld, g = tiny_loader
+    assert (ld.n_user, ld.m_item, ld.n_users, ld.m_items) == (50, 60, 50, 60)
+    assert ld.rec_train_data == g["train_pairs"].tolist()
+    assert ld.train_mat.shape == (51, 60) and ld.UserItemNet.shape == (51, 60)
+    assert (0, int(g["train_pairs"][0, 1])) in ld.train_mat
+    assert list(ld.testRatings.keys()) == g["test_users"].tolist()
+    assert [ld.testRatings[u][0] for u in ld.testRatings] == g["test_pos"].tolist()
+    assert [ld.testNegatives[u] for u in ld.testNegatives] == g["test_neg"].tolist()
+    rowptr, col, val = ld.build_adjacency()
+    assert np.array_equal(rowptr, g["rowptr"]) and np.array_equal(col, g["col"]) and np.array_equal(val, g["val"])
+
+
+def test_adjacency_builders_epinion2_bit_exact(golden, epinion2):
+    from spex_amd.graph import lightgcn_norm_adj, ngcf_norm_adj, csr_transpose
+    g = golden("lightgcn_epinion2")
+    tr = epinion2["train"]
+    rowptr, col, val = lightgcn_norm_adj(tr[:, 0], tr[:, 1], int(g["n_user"]), int(g["m_item"]))
+    assert (sha(rowptr), sha(col), sha(val)) == (str(g["rowptr_sha"]), str(g["col_sha"]), str(g["val_sha"]))
+    t_rowptr, t_col, t_val, eid = csr_transpose(rowptr, col, val, len(rowptr) - 1)
+    assert np.array_equal(t_rowptr, rowptr) and np.array_equal(t_col, col) and np.array_equal(t_val, val)
+    assert np.array_equal(val[eid], t_val) and sorted(eid.tolist()) == list(range(len(col)))
+    gn = golden("ngcf_epinion2")
+    rowptr, col, val = ngcf_norm_adj(tr[:, 0], tr[:, 1], int(gn["n_users"]), int(gn["n_items"]))
+    assert (sha(rowptr), sha(col), sha(val)) == (str(gn["rowptr_sha"]), str(gn["col_sha"]), str(gn["val_sha"]))
+
+
+def test_adjacency_torch_builder_matches_numpy():
+    from spex_amd.datasets import synthetic_interactions, normalised_adjacency_torch
+    from spex_amd.graph import lightgcn_norm_adj
+    u, i = synthetic_interactions(300, 900, 6000, seed=3)
+    a = normalised_adjacency_torch(u, i, 301, 900)
+    b = lightgcn_norm_adj(u.numpy(), i.numpy(), 300, 900)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.abs(a[2] - b[2]).max() <= 1e-7          # torch pow vs numpy pow may differ in the last bit
+
+
+def test_sampler_replays_reference_stream_tiny(tiny_loader):
+    import utility1.dataloader as dl
+    ld, g = tiny_loader
+    td = dl.LightTrainData(ld.rec_train_data, ld.m_item, ld.train_mat)
+    np.random.seed(2020)
+    td.ng_sample()
+    assert np.array_equal(np.asarray(td.features_ng), g["g6_neg"])
+    assert len(td) == int(g["g6_len"]) == 6 * len(ld.rec_train_data)
+    assert list(td[0]) == g["g6_item0"].tolist() and list(td[len(td) - 1]) == g["g6_item_last"].tolist()
+    assert td.__getitems__([0, len(td) - 1]) == [td[0], td[len(td) - 1]]
+
+
+def test_sampler_replay_dense_case_against_oracle(oracle):
+    """High rejection rate (30 % of all pairs are positives) and the RNG state afterwards must match too."""
+    import scipy.sparse as sp
+    import utility1.dataloader as dl
+    rng = np.random.default_rng(1)
+    U, I = 40, 25
+    dense = rng.random((U, I)) < 0.3
+    dense[:, 0] = True
+    pairs = np.argwhere(dense)
+    mat = sp.coo_matrix((np.ones(len(pairs), np.float32), (pairs[:, 0], pairs[:, 1])), shape=(U + 1, I)).todok()
+    td = dl.LightTrainData(pairs.tolist(), I, mat)
+    np.random.seed(7)
+    td.ng_sample()
+    after_fast = np.random.randint(1 << 30)
+    np.random.seed(7)
+    ref = oracle.ng_sample_replay(pairs.tolist(), I, set(map(tuple, pairs.tolist())))
+    after_ref = np.random.randint(1 << 30)
+    assert td.features_ng == ref
+    assert after_fast == after_ref
+    assert not any((u, j) in mat for u, j in td.features_ng)
+
+
+def test_metrics_match_reference_cases(golden):
+    import utility1.metrics as M
+    g = golden("g5_metric_cases")
+    rel, rec, ndcg = [], [], []
+    for k in range(int(g["n_cases"])):
+        r = [int(x) for x in g[f"r_{k}"]]
+        assert np.allclose([M.recall_at_k(r, K, 1) for K in (10, 20, 50)], g[f"recall_{k}"], atol=0)
+        assert np.allclose([M.ndcg_at_k(r, K) for K in (10, 20, 50)], g[f"ndcg_{k}"], atol=1e-15)
+        rel.append(r + [0] * (50 - len(r))); rec.append(g[f"recall_{k}"]); ndcg.append(g[f"ndcg_{k}"])
+    br, bn = M.rank_metrics_batch(np.asarray(rel), (10, 20, 50), np.ones(len(rel)))
+    assert np.allclose(br, rec, atol=0) and np.allclose(bn, ndcg, atol=1e-15)
+
+
+class _TableModel:
+    """Stands in for the model in the evaluation loop: scores from a fixed table (host logic test)."""
+
+    def __init__(self, table):
+        self.table = table
+
+    def __call__(self, users, items, labels, flag=1, **kw):
+        return torch.from_numpy(self.table[users.numpy(), items.numpy()])
+
+
+def test_eval_loop_tie_and_duplicate_semantics(oracle, monkeypatch):
+    monkeypatch.setattr(sys, "argv", ["x"])
+    import utility1.batch_test as bt
+    rng = np.random.default_rng(4)
+    U, I = 30, 200
+    table = np.round(rng.normal(size=(U, I)), 1).astype(np.float32)      # many ties
+    ratings = {u: [int(rng.integers(I))] for u in range(U)}
+    negs = {}
+    for u in range(U):
+        c = [int(x) for x in rng.permutation(I) if x != ratings[u][0]][:99]
+        if u % 7 == 0:
+            c[5] = c[3]                                                   # duplicated candidate -> dict semantics
+        negs[u] = c
+    got = bt.test(_TableModel(table), ratings, negs)
+    want = oracle.evaluate(lambda u, items: table[u, items], ratings, negs)
+    assert np.array_equal(got["recall"], want["recall"]) and np.allclose(got["ndcg"], want["ndcg"], atol=1e-15)
+    one = bt.test_one_user(3, ratings[3], negs[3], _TableModel(table))
+    r = oracle.ranklist(negs[3] + ratings[3], table[3, negs[3] + ratings[3]], ratings[3])
+    assert np.allclose(one["ndcg"], [oracle.ndcg_at_k(r, k) for k in (10, 20, 50)])
+
+
+def test_model_refuses_cpu(tiny_loader):
+    """No CPU fallback: the model needs the HIP library's device graph."""
+    import utility1.model as model
+    import lg_parser
+    ld, _ = tiny_loader
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(Exception):
+        model.LightGCN(lg_parser.parse_args_r(["--dataset", "tiny"]), ld)
+
+
+def test_launcher_puts_dropin_modules_first(tmp_path):
+    script = tmp_path / "main_probe.py"
+    script.write_text("import lg_parser, utility1.dataloader as d, utility.dataloader as d2, world\n"
+                      "print(lg_parser.__file__); print(d.__file__); print(d2 is d); print(world.config['latent_dim_rec'])\n")
+    out = subprocess.run([sys.executable, "-m", "spex_amd.dropin", str(script), "--recdim", "32"], cwd=REPO,
+                         capture_output=True, text=True, check=True).stdout.split()
+    assert out[0].endswith("spex_amd/dropin/lg_parser.py") and out[1].endswith("spex_amd/dropin/utility1/dataloader.py")
+    assert out[2] == "True" and out[3] == "32"
+
+
+def test_epinion2_fixture_round_trips_through_the_file_format(tmp_path, epinion2):
+    from spex_amd.datasets import materialise_epinion2
+    import lg_parser
+    import utility1.dataloader as dl
+    root = materialise_epinion2(str(tmp_path))
+    ld = dl.Loader(lg_parser.parse_args_r(["--dataset", "epinion2", "--data_path", root]))
+    assert (ld.n_user, ld.m_item, len(ld.rec_train_data)) == (3185, 12407, 209304)
+    assert len(ld.testRatings) == 3185 and all(len(v) == 99 for v in ld.testNegatives.values())
+    assert [ld.testRatings[u][0] for u in ld.testRatings] == epinion2["test_pos"].tolist()
+    rowptr, col, val = ld.build_adjacency()
+    assert len(col) == 418608
