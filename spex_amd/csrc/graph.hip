@@ -134,3 +134,49 @@ extern "C" int spex_graph_set_edge_mask(spex_graph_t *g, int mode, const uint8_t
     g->seed = seed;
     return SPEX_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ profiling hook
+extern "C" int spex_timer_create(int32_t capacity, spex_timer_t **out)
+{
+    SPEX_CHECK_ARG(out && capacity > 0 && capacity <= (1 << 20), "spex_timer_create: bad capacity %d", capacity);
+    spex_timer *t = new spex_timer();
+    t->start.resize(capacity);
+    t->stop.resize(capacity);
+    for (int32_t i = 0; i < capacity; ++i) {
+        SPEX_HIP(hipEventCreate(&t->start[i]));
+        SPEX_HIP(hipEventCreate(&t->stop[i]));
+    }
+    *out = t;
+    return SPEX_OK;
+}
+
+extern "C" int spex_timer_destroy(spex_timer_t *t)
+{
+    if (!t) return SPEX_OK;
+    for (size_t i = 0; i < t->start.size(); ++i) {
+        (void)hipEventDestroy(t->start[i]);
+        (void)hipEventDestroy(t->stop[i]);
+    }
+    delete t;
+    return SPEX_OK;
+}
+
+extern "C" int spex_timer_attach(spex_graph_t *g, spex_timer_t *t)
+{
+    SPEX_CHECK_ARG(g, "spex_timer_attach: NULL graph");
+    g->timer = t;
+    return SPEX_OK;
+}
+
+extern "C" int spex_timer_read(spex_timer_t *t, float *h_ms, int32_t max_count, int32_t *count, int reset)
+{
+    SPEX_CHECK_ARG(t && count, "spex_timer_read: NULL argument");
+    int32_t n = t->used < max_count ? t->used : max_count;
+    for (int32_t i = 0; i < n; ++i) {
+        SPEX_HIP(hipEventSynchronize(t->stop[i]));
+        SPEX_HIP(hipEventElapsedTime(&h_ms[i], t->start[i], t->stop[i]));
+    }
+    *count = n;
+    if (reset) t->used = 0;
+    return SPEX_OK;
+}

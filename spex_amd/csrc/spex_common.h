@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
 
 #include "../../include/spex_hip.h"
 
@@ -34,6 +35,11 @@ constexpr int kSegLen = 128;       // entries per long-row segment
 
 }  // namespace spex
 
+struct spex_timer {
+    std::vector<hipEvent_t> start, stop;
+    int32_t used = 0;
+};
+
 // The opaque handle.  All pointers are device memory owned by the handle.
 struct spex_graph {
     int32_t n_rows = 0, n_cols = 0;
@@ -55,4 +61,5 @@ struct spex_graph {
     const uint8_t *keep = nullptr;
     float keep_prob = 1.0f;
     uint64_t seed = 0;
+    spex_timer *timer = nullptr;  // profiling hook (not owned)
 };

@@ -261,10 +261,17 @@ int launch_spmm(const spex_graph *g, const float *X, float *Y, const float *add_
     blocks = (blocks + 7) / 8 * 8;  // multiple of the XCD count so the remap is a bijection
     const dim3 grid((unsigned)blocks), block(kWave * kWavesPerBlock);
     const bool masked = g->mask_mode != 0, d64 = d == 64;
+    spex_timer *tm = g->timer;
+    const bool timed = tm && tm->used < (int32_t)tm->start.size();
+    if (timed) SPEX_HIP(hipEventRecord(tm->start[tm->used], stream));
     if (masked && d64) hipLaunchKernelGGL((spmm_rows_kernel<true, true>), grid, block, 0, stream, p);
     else if (masked) hipLaunchKernelGGL((spmm_rows_kernel<true, false>), grid, block, 0, stream, p);
     else if (d64) hipLaunchKernelGGL((spmm_rows_kernel<false, true>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((spmm_rows_kernel<false, false>), grid, block, 0, stream, p);
+    if (timed) {
+        SPEX_HIP(hipEventRecord(tm->stop[tm->used], stream));
+        tm->used++;
+    }
     if (g->n_long > 0) {
         const dim3 fgrid((unsigned)((g->n_long + kWavesPerBlock - 1) / kWavesPerBlock));
         hipLaunchKernelGGL(spmm_long_fixup_kernel, fgrid, block, 0, stream, p);

@@ -1,0 +1,145 @@
+"""1-D row partition of the propagation across the GPUs of one node, one process per GPU.
+
+Rank p owns a contiguous block of rows of A_hat (CSR slice, balanced by stored entries) and the same rows of every
+layer's embedding matrix.  A layer is:  all-gather of the current layer's rows over xGMI (RCCL, through
+torch.distributed)  ->  local SpMM on the rank's row block.  This is the schedule the reference's own `A_split` path
+runs serially on one device (LightGCN_SPEX/code/utility1/dataloader.py:167-177, model.py:84-89).
+
+Layout trick: shards are padded to the largest shard so the collective is a plain equal-size all-gather, and the
+rank's column indices are rewritten once, at partition time, into that padded layout — the gathered buffer is used
+by the SpMM as-is, no unpack pass.
+
+Backward (G_l = g/(L+1) + A^T G_{l+1}) uses the same schedule on the row blocks of A^T.  Scoring is owner-computes:
+every rank scores the (small, replicated) batch against the gathered output table and keeps the gradient rows it
+owns, so the only exchange step on the data path is the per-layer all-gather.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .graph import row_block
+
+
+def balanced_row_bounds(rowptr, world, row_cost=4):
+    """Row boundaries r_0=0 < ... < r_P=N giving each rank about the same `entries + row_cost * rows` (an output
+    row costs about as much traffic as one gathered entry: 256 B written + 256 B read of the running sum)."""
+    n = len(rowptr) - 1
+    cost = np.asarray(rowptr, np.int64) + row_cost * np.arange(n + 1, dtype=np.int64)
+    targets = cost[-1] * np.arange(1, world, dtype=np.float64) / world
+    inner = np.searchsorted(cost, targets, side="left")
+    bounds = np.concatenate([[0], inner, [n]]).astype(np.int64)
+    return np.maximum.accumulate(bounds)
+
+
+class RowPartition:
+    """Static description of the partition (identical on every rank)."""
+
+    def __init__(self, rowptr, world, bounds=None):
+        self.n = len(rowptr) - 1
+        self.world = world
+        self.bounds = np.asarray(bounds if bounds is not None else balanced_row_bounds(rowptr, world), np.int64)
+        assert len(self.bounds) == world + 1 and self.bounds[0] == 0 and self.bounds[-1] == self.n
+        self.rows = np.diff(self.bounds)
+        self.max_rows = int(max(1, self.rows.max()))
+        self.n_padded = self.max_rows * world
+
+    def owner(self, g):
+        return np.searchsorted(self.bounds, g, side="right") - 1
+
+    def to_padded(self, g):
+        """Global row id -> position in the gathered, padded [world * max_rows, d] buffer."""
+        g = np.asarray(g, np.int64)
+        o = self.owner(g)
+        return o * self.max_rows + (g - self.bounds[o])
+
+    def to_padded_torch(self, g):
+        b = torch.as_tensor(self.bounds[1:-1], device=g.device)
+        o = torch.bucketize(g, b, right=True)
+        return o * self.max_rows + (g - torch.as_tensor(self.bounds, device=g.device)[o])
+
+    def local_block(self, rowptr, col, val, rank, edge_id=None):
+        r0, r1 = int(self.bounds[rank]), int(self.bounds[rank + 1])
+        lrowptr, lcol, lval, leid = row_block(rowptr, col, val, r0, r1, edge_id)
+        return lrowptr, self.to_padded(lcol).astype(np.int32), lval, leid
+
+
+class PartitionedLightGCN:
+    """LightGCN propagation + scoring step on one rank of a row-partitioned graph.
+
+    graph_factory(rowptr, col, val, n_cols=...) builds the local device graph (SpexGraph on a GPU; the CPU tests of
+    the schedule inject a stand-in with the same .spmm signature).  `group` is a torch.distributed process group
+    (backend "nccl" == RCCL on ROCm, "gloo" in the CPU tests).
+    """
+
+    def __init__(self, rowptr, col, val, n_user_rows, n_layers, d, rank, world, graph_factory, device, group=None,
+                 t_csr=None, bounds=None):
+        self.part = RowPartition(rowptr, world, bounds)
+        self.rank, self.world, self.L, self.d, self.group = rank, world, n_layers, d, group
+        self.n_user_rows = n_user_rows
+        self.device = torch.device(device)
+        p = self.part
+        lr, lc, lv, _ = p.local_block(rowptr, col, val, rank)
+        self.graph = graph_factory(lr, lc, lv, n_cols=p.n_padded)
+        if t_csr is None:       # symmetric adjacency: A^T == A
+            self.graph_t = self.graph
+        else:
+            tr, tc, tv, _ = p.local_block(*t_csr[:3], rank)
+            self.graph_t = graph_factory(tr, tc, tv, n_cols=p.n_padded)
+        self.r0, self.r1 = int(p.bounds[rank]), int(p.bounds[rank + 1])
+        self.n_local = self.r1 - self.r0
+        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=self.device)
+        self.gathered = z(p.n_padded, d)                 # all-gather target == SpMM gather source
+        self.send = z(p.max_rows, d)                     # padded local shard
+        self.buf = [z(self.n_local, d), z(self.n_local, d)]
+        self.light_out = z(self.n_local, d)
+        self.out_gathered = z(p.n_padded, d)
+
+    # -- the one exchange step of the data path
+    def all_gather_rows(self, local, out=None):
+        out = self.gathered if out is None else out
+        self.send[: self.n_local].copy_(local)
+        if self.world == 1:
+            out.copy_(self.send)
+        else:
+            dist.all_gather_into_tensor(out, self.send, group=self.group)
+        return out
+
+    def propagate(self, E0_local):
+        """mean_l(A^l E0) for this rank's rows (LightGCN.computer(), model.py:66-97)."""
+        cur = E0_local
+        for l in range(self.L):
+            X = self.all_gather_rows(cur)
+            last = l == self.L - 1
+            nxt = None if last else self.buf[l & 1]
+            self.graph.spmm(X, Y=nxt, acc_in=E0_local if l == 0 else self.light_out, acc_out=self.light_out,
+                            acc_div=float(self.L + 1) if last else 1.0)
+            cur = nxt
+        if self.L == 0:
+            self.light_out.copy_(E0_local)
+        return self.light_out
+
+    def propagate_bwd(self, g_local, grad_out=None):
+        """d loss / d E0 (local rows) from d loss / d light_out (local rows)."""
+        gs = g_local / float(self.L + 1)
+        cur = gs
+        for l in range(self.L - 1, -1, -1):
+            X = self.all_gather_rows(cur)
+            nxt = (grad_out if (l == 0 and grad_out is not None) else torch.empty_like(gs))
+            self.graph_t.spmm(X, Y=nxt, add_in=gs, add_div=1.0)
+            cur = nxt
+        if self.L == 0 and grad_out is not None:
+            grad_out.copy_(gs)
+            return grad_out
+        return cur
+
+    def gather_output(self):
+        """Full (padded) propagated table on every rank, for scoring."""
+        return self.all_gather_rows(self.light_out, out=self.out_gathered)
+
+    def padded_index(self, users, items):
+        """Batch indices (user ids, item ids) -> rows of the padded gathered table."""
+        return self.part.to_padded_torch(users), self.part.to_padded_torch(items + self.n_user_rows)
+
+    def own_slice(self, padded):
+        s = self.rank * self.part.max_rows
+        return padded[s: s + self.n_local]

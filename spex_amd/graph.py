@@ -130,6 +130,7 @@ class SpexGraph:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
+            self.detach_timer()
             _lib.load().spex_graph_destroy(self._h)
             self._h = ctypes.c_void_p()
 
@@ -138,6 +139,27 @@ class SpexGraph:
             self.close()
         except Exception:
             pass
+
+    # -- profiling hook: hipEvent pairs around the main SpMM kernel, on the stream it is launched on
+    def attach_timer(self, capacity):
+        self.detach_timer()
+        t = ctypes.c_void_p()
+        _lib.call("spex_timer_create", int(capacity), ctypes.byref(t))
+        _lib.call("spex_timer_attach", self._h, t)
+        self._timer, self._timer_cap = t, int(capacity)
+
+    def read_timer(self, reset=True):
+        """Elapsed milliseconds of the SpMM launches recorded since the last reset (synchronises on them)."""
+        buf = (ctypes.c_float * self._timer_cap)()
+        n = ctypes.c_int32()
+        _lib.call("spex_timer_read", self._timer, buf, self._timer_cap, ctypes.byref(n), 1 if reset else 0)
+        return np.frombuffer(buf, dtype=np.float32, count=n.value).copy()
+
+    def detach_timer(self):
+        if getattr(self, "_timer", None) is not None:
+            _lib.call("spex_timer_attach", self._h, None)
+            _lib.call("spex_timer_destroy", self._timer)
+            self._timer = None
 
     # -- edge dropout (model.py:46-55)
     def set_edge_mask(self, mode=0, keep=None, keep_prob=1.0, seed=0):

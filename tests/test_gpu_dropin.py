@@ -1,0 +1,197 @@
+"""The reference's Python surface on the GPU: the call sequence of LightGCN_SPEX/code/main_rec.py (Loader ->
+LightTrainData -> LightGCN(args, dataset).to(device) -> Adam -> forward/backward/step -> test()) against the golden
+vectors the reference produced for the same seeds."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda")
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def data_root(tmp_path_factory, golden):
+    from spex_amd.datasets import materialise_rating_files, materialise_epinion2
+    root = str(tmp_path_factory.mktemp("data"))
+    g = golden("lightgcn_tiny")
+    materialise_rating_files(root, "tiny", g["train_pairs"], g["test_users"], g["test_pos"], g["test_neg"])
+    return materialise_epinion2(root)
+
+
+def build(ds, data_root, extra=()):
+    import lg_parser
+    import utility1.dataloader as dataloader
+    import utility1.model as model
+    import utility1.utils as utils
+    args = lg_parser.parse_args_r(["--dataset", ds, "--data_path", data_root, *extra])
+    utils.set_seed(args.seed)                                   # main_rec.py:15
+    dataset = dataloader.Loader(args)                           # :18
+    net = model.LightGCN(args, dataset).to(DEV)                 # :22
+    return args, dataset, net
+
+
+def test_tiny_same_seed_same_tables_same_outputs(data_root, golden):
+    g = golden("lightgcn_tiny")
+    args, dataset, net = build("tiny", data_root)
+    E0 = torch.cat([net.embedding_user.weight, net.embedding_item.weight]).detach().cpu().numpy()
+    assert np.array_equal(E0, g["E0"])                          # same initialiser stream as model.py:32-35
+    assert net.embedding_user.weight.data_ptr() + net.embedding_user.weight.numel() * 4 == net.embedding_item.weight.data_ptr()
+    net.eval()
+    with torch.no_grad():
+        users, items = net.computer()
+    assert users.shape == (51, 64) and items.shape == (60, 64)
+    assert np.array_equal(torch.cat([users, items]).cpu().numpy(), g["light_out"])
+
+
+def test_training_loop_and_eval_match_reference(data_root, golden):
+    """main_rec.py:25-60 with the golden batches in place of the shuffled DataLoader."""
+    sys.argv = ["main_rec.py"]
+    from utility1.batch_test import test
+    for ds in ("tiny", "epinion2"):
+        g = golden(f"lightgcn_{ds}")
+        args, dataset, net = build(ds, data_root)
+        if ds == "epinion2":                                    # fixture names E0 by seed
+            from spex_amd.datasets import epinion2_tables
+            uw, iw = epinion2_tables(3186, 12407)
+            with torch.no_grad():
+                net.embedding_user.weight.copy_(torch.from_numpy(uw)); net.embedding_item.weight.copy_(torch.from_numpy(iw))
+        opt = torch.optim.Adam(net.parameters(), lr=args.lr)    # :23
+        net.train()
+        for s in range(5):
+            opt.zero_grad()
+            u, i, y = (torch.from_numpy(g[k][s]) for k in ("batch_users", "batch_items", "batch_labels"))
+            if s == 0:
+                gamma = net(users=u.to(DEV), items=i.to(DEV), labels=y.to(DEV), flag=1)
+                assert rel_err(gamma.cpu().numpy(), g["g3_gamma"]) <= 2e-6
+            loss = net(users=u.to(DEV), items=i.to(DEV), labels=y.to(DEV), flag=0)   # :34
+            loss.backward()                                                          # :35
+            assert abs(loss.item() - float(g["g4_losses"][s])) <= 2e-6
+            if s == 0:
+                grad = torch.cat([net.embedding_user.weight.grad, net.embedding_item.weight.grad]).cpu().numpy()
+                got = grad if ds == "tiny" else grad[g["sample_rows"]]
+                assert rel_err(got, g["g3_grad"] if ds == "tiny" else g["g3_grad_rows"]) <= 1e-5
+            opt.step()                                                               # :37
+            if s + 1 in (1, 2, 5):
+                W = torch.cat([net.embedding_user.weight, net.embedding_item.weight]).detach().cpu().numpy()
+                got = W if ds == "tiny" else W[g["sample_rows"]]
+                assert rel_err(got, g[f"g4_w_step{s + 1}"] if ds == "tiny" else g[f"g4_w_step{s + 1}_rows"]) <= 5e-6
+        net.eval()
+        with torch.no_grad():                                                        # :50
+            ret = test(net, dataset.testRatings, dataset.testNegatives)
+            # the acceptance gate: HR@K / NDCG@K within 1e-4 of the reference
+            assert np.abs(ret["recall"] - g["g5_recall"]).max() <= 1e-4
+            assert np.abs(ret["ndcg"] - g["g5_ndcg"]).max() <= 1e-4
+            for k, uu in enumerate(g["g5_users"][:16]):
+                its = dataset.testNegatives[int(uu)] + dataset.testRatings[int(uu)]
+                sc = net(torch.full((len(its),), int(uu)).long(), torch.tensor(its).long(), None, flag=1)
+                assert rel_err(sc.cpu().numpy(), g["g5_scores"][k]) <= 1e-4
+
+
+def test_eval_cache_and_invalidation(data_root):
+    args, dataset, net = build("tiny", data_root)
+    net.eval()
+    with torch.no_grad():
+        a = net._light_out()
+        b = net._light_out()
+        assert a.data_ptr() == b.data_ptr()                      # one propagation for the whole eval loop
+        with torch.no_grad():
+            net.embedding_item.weight.add_(1.0)                  # any in-place parameter update invalidates it
+        c = net._light_out()
+        assert c.data_ptr() != a.data_ptr() or not torch.equal(a, c)
+    net.train()
+    x = net._light_out()
+    assert x.requires_grad
+
+
+def test_dropout_training_path(data_root, golden, oracle):
+    g = golden("lightgcn_tiny")
+    args, dataset, net = build("tiny", data_root, ["--dropout", "1", "--keepprob", "0.6"])
+    keep = oracle.dropout_keep_mask(g["g9_rand"], 0.6)
+    net.train()
+    net.set_edge_mask(torch.from_numpy(keep))
+    users, items = net.computer()
+    assert rel_err(torch.cat([users, items]).detach().cpu().numpy(), g["g9_light_out"]) <= 1e-6
+    # gradient through the masked, non-symmetric operator: compare with dense autograd on the same masked matrix
+    rowptr, col, val = dataset.build_adjacency()
+    n = len(rowptr) - 1
+    rows = np.repeat(np.arange(n), np.diff(rowptr))
+    A = torch.zeros(n, n, dtype=torch.float64)
+    A[rows[keep], col[keep]] = torch.from_numpy((val[keep] / np.float32(0.6)).astype(np.float64))
+    E0 = torch.from_numpy(g["E0"]).double().requires_grad_(True)
+    cur, acc = E0, E0
+    for _ in range(3):
+        cur = A @ cur
+        acc = acc + cur
+    w = torch.randn(n, 64, dtype=torch.float64, generator=torch.Generator().manual_seed(0))
+    ((acc / 4) * w).sum().backward()
+    (torch.cat([users, items]) * w.float().to(DEV)).sum().backward()
+    got = torch.cat([net.embedding_user.weight.grad, net.embedding_item.weight.grad]).cpu().numpy()
+    assert rel_err(got, E0.grad.numpy()) <= 1e-5
+    # sampled masks: a fresh mask per step, finite loss, eval ignores dropout
+    net.set_edge_mask(None)
+    l1 = net(torch.from_numpy(g["batch_users"][0]), torch.from_numpy(g["batch_items"][0]), torch.from_numpy(g["batch_labels"][0]), flag=0)
+    l2 = net(torch.from_numpy(g["batch_users"][0]), torch.from_numpy(g["batch_items"][0]), torch.from_numpy(g["batch_labels"][0]), flag=0)
+    assert torch.isfinite(l1) and torch.isfinite(l2) and l1.item() != l2.item()
+    net.eval()
+    with torch.no_grad():
+        u2, i2 = net.computer()
+    assert np.array_equal(torch.cat([u2, i2]).cpu().numpy(), g["light_out"])
+
+
+def test_a_split_folds_match_unsplit(data_root, golden):
+    g = golden("lightgcn_tiny")
+    args, dataset, net = build("tiny", data_root, ["--A_split", "1", "--a_fold", "7"])
+    assert isinstance(net.Graph, list) and len(net.Graph) == 7
+    net.eval()
+    with torch.no_grad():
+        users, items = net.computer()
+    assert rel_err(torch.cat([users, items]).cpu().numpy(), g["light_out"]) <= 1e-6
+
+
+def test_bpr_loss_extension_against_torch_fp32(data_root, golden):
+    """bpr_loss() has no reference counterpart (parity unpinned): check value and gradient against plain torch ops
+    on the same device (dense adjacency, fp64)."""
+    g = golden("lightgcn_tiny")
+    args, dataset, net = build("tiny", data_root)
+    rng = np.random.default_rng(0)
+    u, p, n_ = (torch.from_numpy(rng.integers(0, hi, 128)) for hi in (50, 60, 60))
+    net.train()
+    loss, reg = net.bpr_loss(u, p, n_)
+    (loss + 1e-4 * reg).backward()
+    got = torch.cat([net.embedding_user.weight.grad, net.embedding_item.weight.grad]).cpu().numpy()
+    A = net.Graph.to_torch_sparse().to_dense().double()
+    E0 = torch.from_numpy(g["E0"]).double().requires_grad_(True)
+    cur, acc = E0, E0
+    for _ in range(3):
+        cur = A @ cur
+        acc = acc + cur
+    out = acc / 4
+    U, I = out[:51], out[51:]
+    x = (U[u] * I[n_]).sum(1) - (U[u] * I[p]).sum(1)
+    ref_loss = torch.nn.functional.softplus(x).mean()
+    ref_reg = 0.5 * (E0[:51][u].pow(2).sum() + E0[51:][p].pow(2).sum() + E0[51:][n_].pow(2).sum()) / 128
+    (ref_loss + 1e-4 * ref_reg).backward()
+    assert abs(loss.item() - ref_loss.item()) <= 1e-6 and abs(reg.item() - ref_reg.item()) <= 1e-6
+    assert rel_err(got, E0.grad.numpy()) <= 1e-5
+
+
+def test_unmodified_style_driver_runs_through_the_launcher(data_root, tmp_path):
+    """A driver written against the reference's import names and call sequence, run with `python -m spex_amd.dropin`
+    exactly as INTEGRATION.md tells a user to run the reference's own main_rec.py."""
+    script = os.path.join(REPO, "tests", "drivers", "rec_driver.py")
+    out = subprocess.run([sys.executable, "-m", "spex_amd.dropin", script, "--dataset", "tiny", "--data_path", data_root,
+                          "--epochs", "2"], cwd=REPO, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("Rec:")]
+    assert len(lines) >= 2 and "recall=" in lines[-1]

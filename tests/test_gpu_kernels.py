@@ -1,0 +1,349 @@
+"""GPU parity tests proper: every libspexhip kernel, called through the C ABI (ctypes via spex_amd), against the CPU
+oracle on the same seeded inputs and against the golden vectors minted from the reference.
+
+Tolerances: the north star asks per-layer embeddings within 1e-5 relative in fp32; the SpMM's fmaf chain is the
+oracle's, so rows handled by one wave are required to match BIT-FOR-BIT, and only rows cut into segments (> 128
+entries) may differ by the re-association of their partial sums (<= 1e-6 relative here).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def random_csr(rng, n_rows, n_cols, degrees):
+    rowptr = np.zeros(n_rows + 1, np.int64)
+    cols = []
+    for r in range(n_rows):
+        k = min(int(degrees[r]), n_cols)
+        cols.append(np.sort(rng.choice(n_cols, k, replace=False)))
+        rowptr[r + 1] = rowptr[r] + k
+    col = np.concatenate(cols).astype(np.int32) if cols else np.zeros(0, np.int32)
+    val = rng.normal(size=len(col)).astype(np.float32)
+    return rowptr.astype(np.int32), col, val
+
+
+@pytest.fixture(scope="module")
+def G():
+    from spex_amd.graph import SpexGraph
+    return SpexGraph
+
+
+# ---------------------------------------------------------------------------------------------- SpMM
+def test_library_is_the_hip_build():
+    from spex_amd import _lib
+    assert _lib.load().spex_version() == 1
+
+
+@pytest.mark.parametrize("d", [64, 32, 100, 128, 1])
+def test_spmm_matches_oracle_random_graph(G, oracle, d):
+    rng = np.random.default_rng(d)
+    n_rows, n_cols = 700, 500
+    deg = rng.integers(0, 60, n_rows)
+    deg[::50] = 0                      # empty rows
+    deg[7], deg[300] = 480, 129        # long rows -> segments (+ ragged last segment)
+    deg[301] = 128                     # exactly at the threshold: still one wave
+    rowptr, col, val = random_csr(rng, n_rows, n_cols, deg)
+    X = rng.normal(size=(n_cols, d)).astype(np.float32)
+    g = G(rowptr, col, val, n_cols=n_cols)
+    assert g.n_long_rows == 2 and g.n_segments == 4 + 2
+    Y = g.spmm(t(X)).cpu().numpy()
+    ref = oracle.spmm(rowptr, col, val, X)
+    short = np.diff(rowptr) <= 128
+    assert np.array_equal(Y[short], ref[short])                    # bit-exact fmaf chain
+    assert rel_err(Y[~short], ref[~short]) <= 1e-6
+    assert np.all(Y[deg == 0] == 0)
+
+
+def test_spmm_fused_epilogues(G, oracle):
+    rng = np.random.default_rng(1)
+    n = 400
+    rowptr, col, val = random_csr(rng, n, n, rng.integers(0, 40, n))
+    X, add, acc = (rng.normal(size=(n, 64)).astype(np.float32) for _ in range(3))
+    g = G(rowptr, col, val)
+    y = oracle.spmm(rowptr, col, val, X)
+    Y, A = torch.empty(n, 64, device=DEV), torch.empty(n, 64, device=DEV)
+    g.spmm(t(X), Y=Y, add_in=t(add), add_div=3.0, acc_in=t(acc), acc_out=A, acc_div=4.0)
+    y2 = y + add / np.float32(3.0)
+    assert np.array_equal(Y.cpu().numpy(), y2)
+    assert np.array_equal(A.cpu().numpy(), (acc + y2) / np.float32(4.0))
+    # acc only (last layer), in place
+    A2 = t(acc)
+    g.spmm(t(X), acc_in=A2, acc_out=A2, acc_div=1.0)
+    assert np.array_equal(A2.cpu().numpy(), acc + y)
+
+
+def test_spmm_edge_cases(G, oracle):
+    from spex_amd._lib import SpexError
+    # empty matrix, matrix without entries, single huge row
+    g0 = G(np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32), n_cols=5)
+    assert g0.spmm(torch.zeros(5, 64, device=DEV)).shape == (0, 64)
+    g1 = G(np.zeros(11, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32), n_cols=3)
+    assert torch.all(g1.spmm(torch.ones(3, 64, device=DEV)) == 0)
+    rng = np.random.default_rng(2)
+    rowptr, col, val = random_csr(rng, 3, 5000, [0, 5000, 1])
+    X = rng.normal(size=(5000, 64)).astype(np.float32)
+    g2 = G(rowptr, col, val, n_cols=5000)
+    assert rel_err(g2.spmm(t(X)).cpu().numpy(), oracle.spmm(rowptr, col, val, X)) <= 1e-6
+    # NaN / Inf in an unrelated source row must not leak (no 0 * Inf from padded lanes)
+    X[4999] = np.inf
+    rowptr, col, val = random_csr(rng, 50, 4999, rng.integers(1, 30, 50))
+    g3 = G(rowptr, col, val, n_cols=5000)
+    assert np.isfinite(g3.spmm(t(X)).cpu().numpy()).all()
+    with pytest.raises(ValueError):
+        g3.spmm(torch.zeros(10, 64, device=DEV))                   # wrong shape is caught on the host
+    with pytest.raises(SpexError):
+        Xa = t(X[:50].copy())
+        G(*random_csr(rng, 50, 50, [1] * 50)).spmm(Xa, Y=Xa)       # aliasing refused
+
+
+def test_spmm_linearity_and_transpose_identity_at_epinion2_size(G, golden, epinion2):
+    """Size-independent properties at the full benchmark size: A(ax + by) = aAx + bAy and <Ax, y> = <x, A^T y>."""
+    from spex_amd.graph import lightgcn_norm_adj
+    tr = epinion2["train"]
+    rowptr, col, val = lightgcn_norm_adj(tr[:, 0], tr[:, 1], 3185, 12407)
+    g = G(rowptr, col, val)
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    x, y = (torch.randn(15593, 64, device=DEV, generator=gen) for _ in range(2))
+    lhs = g.spmm(2.0 * x + 0.5 * y)
+    rhs = 2.0 * g.spmm(x) + 0.5 * g.spmm(y)
+    assert (lhs - rhs).abs().max().item() <= 1e-5 * rhs.abs().max().item()
+    a = (g.spmm(x).double() * y.double()).sum().item()
+    b = (x.double() * g.spmm(y).double()).sum().item()       # A symmetric
+    assert abs(a - b) <= 1e-6 * max(abs(a), 1.0)
+    # rows of A_hat sum to <= sqrt(deg) bound and A 1 is what the host CSR says
+    ones = g.spmm(torch.ones(15593, 64, device=DEV))[:, 0].cpu().numpy()
+    host = np.add.reduceat(np.r_[val, 0.0].astype(np.float64), np.minimum(rowptr[:-1], len(val)))
+    host[np.diff(rowptr) == 0] = 0
+    assert np.allclose(ones, host, rtol=1e-5, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------- propagation vs goldens
+def _epinion2(golden, epinion2):
+    from spex_amd.datasets import epinion2_tables
+    from spex_amd.graph import lightgcn_norm_adj
+    g = golden("lightgcn_epinion2")
+    tr = epinion2["train"]
+    csr = lightgcn_norm_adj(tr[:, 0], tr[:, 1], 3185, 12407)
+    uw, iw = epinion2_tables(3186, 12407)
+    return g, csr, np.concatenate([uw, iw])
+
+
+def test_g2_propagation_tiny_bit_exact_vs_reference(G, golden):
+    g = golden("lightgcn_tiny")
+    gr = G(g["rowptr"], g["col"], g["val"])
+    n, d = g["E0"].shape
+    layers = torch.empty(3, n, d, device=DEV)
+    out = gr.propagate(t(g["E0"]), 3, layers_out=layers)
+    for l in range(3):
+        assert np.array_equal(layers[l].cpu().numpy(), g[f"E{l + 1}"])     # == torch.sparse.mm on CPU, bit for bit
+    assert np.array_equal(out.cpu().numpy(), g["light_out"])
+    out2 = gr.propagate(t(g["E0"]), 3)                                        # ping-pong workspace path
+    assert np.array_equal(out2.cpu().numpy(), g["light_out"])
+
+
+def test_g2_propagation_epinion2_vs_reference(G, golden, epinion2, oracle):
+    g, csr, E0 = _epinion2(golden, epinion2)
+    gr = G(*csr)
+    layers = torch.empty(3, *E0.shape, device=DEV)
+    out = gr.propagate(t(E0), 3, layers_out=layers).cpu().numpy()
+    rows = g["sample_rows"]
+    L = layers.cpu().numpy()
+    for l in range(3):
+        assert rel_err(L[l][rows], g[f"E{l + 1}_rows"]) <= 1e-5                    # the north-star gate
+        assert np.allclose(L[l].astype(np.float64).sum(0), g[f"E{l + 1}_colsum"], rtol=1e-5, atol=1e-6)
+        assert np.isclose(np.sqrt((L[l].astype(np.float64) ** 2).sum()), g[f"E{l + 1}_fro"], rtol=1e-6)
+    assert rel_err(out[rows], g["light_out_rows"]) <= 1e-5
+    # and against the oracle on every row: bit-exact where one wave owns the row
+    ref, ref_layers = oracle.propagate_mean(*csr, E0, 3, n_threads=8, return_layers=True)
+    short = np.diff(csr[0]) <= 128
+    assert np.array_equal(L[0][short], ref_layers[0][short])
+    assert rel_err(out, ref) <= 1e-6
+
+
+def test_g3_g4_training_steps_vs_reference(G, golden, epinion2):
+    """Loss, d loss / d E0 and the tables after 1, 2, 5 Adam steps, through the autograd-free stepper."""
+    from spex_amd.trainer import LightGCNStepper
+    for ds in ("tiny", "epinion2"):
+        if ds == "tiny":
+            g = golden("lightgcn_tiny")
+            csr, E0, n_u = (g["rowptr"], g["col"], g["val"]), g["E0"], int(g["n_user"]) + 1
+        else:
+            g, csr, E0 = _epinion2(golden, epinion2)
+            n_u = 3186
+        st = LightGCNStepper(G(*csr), t(E0.copy()), n_u, n_layers=3, lr=1e-3)
+        for s in range(5):
+            u, i, y = t(g["batch_users"][s]), t(g["batch_items"][s]), t(g["batch_labels"][s].astype(np.float32))
+            loss = st.step_bce(u, i, y).item()
+            assert abs(loss - float(g["g4_losses"][s])) <= 2e-6
+            if s == 0:
+                grad = st.grad_E0.cpu().numpy()
+                want = g["g3_grad"] if ds == "tiny" else g["g3_grad_rows"]
+                got = grad if ds == "tiny" else grad[g["sample_rows"]]
+                assert rel_err(got, want) <= 1e-5
+                assert np.isclose(np.sqrt((grad.astype(np.float64) ** 2).sum()), g["g3_grad_fro"], rtol=1e-5)
+            if s + 1 in (1, 2, 5):
+                W = st.E0.cpu().numpy()
+                want = g[f"g4_w_step{s + 1}"] if ds == "tiny" else g[f"g4_w_step{s + 1}_rows"]
+                got = W if ds == "tiny" else W[g["sample_rows"]]
+                assert rel_err(got, want) <= 5e-6
+                assert np.allclose(W.astype(np.float64).sum(0), g[f"g4_w_step{s + 1}_colsum"], rtol=1e-5, atol=1e-6)
+
+
+def test_g9_dropout_injected_mask_and_backward_consistency(G, golden, oracle):
+    from spex_amd.graph import csr_transpose
+    g = golden("lightgcn_tiny")
+    csr = (g["rowptr"], g["col"], g["val"])
+    keep_prob = float(g["g9_keep"])
+    keep = oracle.dropout_keep_mask(g["g9_rand"], keep_prob)
+    gr = G(*csr)
+    gr.set_edge_mask(1, t(keep.astype(np.uint8)), keep_prob, 0)
+    out = gr.propagate(t(g["E0"]), 3).cpu().numpy()
+    assert rel_err(out, g["g9_light_out"]) <= 1e-6                          # vs the reference with the same mask
+    assert np.array_equal(out, oracle.propagate_mean_masked(*csr, keep, keep_prob, g["E0"], 3))
+    # the transposed handle with the edge-id permutation applies the SAME mask: <A'x, y> == <x, A'^T y>
+    t_rowptr, t_col, t_val, eid = csr_transpose(*csr, len(csr[0]) - 1)
+    gt = G(t_rowptr, t_col, t_val, edge_id=eid)
+    gt.set_edge_mask(1, t(keep.astype(np.uint8)), keep_prob, 0)
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    x, y = (torch.randn(len(csr[0]) - 1, 64, device=DEV, generator=gen) for _ in range(2))
+    a = (gr.spmm(x).double() * y.double()).sum().item()
+    b = (x.double() * gt.spmm(y).double()).sum().item()
+    assert abs(a - b) <= 1e-9 * max(abs(a), 1.0) + 1e-9
+    # sampled (philox) mode: same seed -> same mask in A and A^T; keep rate ~ keep_prob; E[A'] = A
+    gr.set_edge_mask(2, None, keep_prob, 1234)
+    gt.set_edge_mask(2, None, keep_prob, 1234)
+    a = (gr.spmm(x).double() * y.double()).sum().item()
+    b = (x.double() * gt.spmm(y).double()).sum().item()
+    assert abs(a - b) <= 1e-9 * max(abs(a), 1.0) + 1e-9
+    gr.set_edge_mask(0)
+    assert np.array_equal(gr.propagate(t(g["E0"]), 3).cpu().numpy(), g["light_out"])
+
+
+def test_dropout_sampled_mask_statistics(G):
+    n = 4096
+    rowptr = np.arange(n + 1, dtype=np.int32) * 8
+    col = (np.arange(n * 8) % n).reshape(n, 8)
+    col.sort(axis=1)
+    # make columns distinct within a row
+    col = (np.arange(8)[None, :] * 511 + np.arange(n)[:, None]) % n
+    col.sort(axis=1)
+    g = G(rowptr, col.reshape(-1).astype(np.int32), np.ones(n * 8, np.float32))
+    ones = torch.ones(n, 64, device=DEV)
+    for keep_prob in (0.3, 0.6):
+        g.set_edge_mask(2, None, keep_prob, 99)
+        y = g.spmm(ones)[:, 0].cpu().numpy() * keep_prob          # = kept entries per row
+        assert np.allclose(y, np.round(y), atol=1e-4)
+        rate = y.sum() / (n * 8)
+        assert abs(rate - keep_prob) < 0.01
+        g.set_edge_mask(2, None, keep_prob, 100)
+        y2 = g.spmm(ones)[:, 0].cpu().numpy() * keep_prob
+        assert (y != y2).mean() > 0.3                               # a different seed is a different mask
+
+
+# ---------------------------------------------------------------------------------------------- scoring kernels
+def test_score_bce_vs_oracle(oracle):
+    from spex_amd import ops
+    rng = np.random.default_rng(3)
+    U, I, B = 300, 700, 1000
+    users, items = rng.normal(size=(U, 64)).astype(np.float32) * 0.3, rng.normal(size=(I, 64)).astype(np.float32) * 0.3
+    u, i = rng.integers(0, U, B), rng.integers(0, I, B)
+    u[:50] = 7                                                       # duplicates accumulate
+    y = (rng.random(B) < 0.2).astype(np.float32)
+    gamma_o, loss_o, gu_o, gi_o = oracle.score_bce(users, items, u, i, y, want_grad=True)
+    gu, gi = torch.zeros(U, 64, device=DEV), torch.zeros(I, 64, device=DEV)
+    gamma, loss_sum = ops.score_bce(t(users), t(items), t(u), t(i), t(y), gu, gi, 1.0 / B)
+    assert rel_err(gamma.cpu().numpy(), gamma_o) <= 1e-6
+    assert abs(loss_sum.item() / B - float(loss_o)) <= 1e-6
+    assert rel_err(gu.cpu().numpy(), gu_o) <= 1e-5 and rel_err(gi.cpu().numpy(), gi_o) <= 1e-5
+    # scores only, indices handed over on the host as int64 (main_rec.py:33-34 / batch_test.py:33)
+    gamma2, none = ops.score_bce(t(users), t(items), torch.from_numpy(u), torch.from_numpy(i))
+    assert none is None and torch.equal(gamma2, gamma)
+    # out-of-range index: skipped, flagged as NaN, nothing else disturbed
+    bad = u.copy(); bad[3] = U + 5
+    gamma3, _ = ops.score_bce(t(users), t(items), t(bad), t(i))
+    g3 = gamma3.cpu().numpy()
+    assert np.isnan(g3[3]) and np.array_equal(np.delete(g3, 3), np.delete(gamma.cpu().numpy(), 3))
+
+
+def test_bpr_kernels_vs_closed_form(oracle):
+    from spex_amd import ops
+    rng = np.random.default_rng(5)
+    U, I, T = 200, 400, 3000
+    Ut, It = rng.normal(size=(U, 64)).astype(np.float32) * 0.2, rng.normal(size=(I, 64)).astype(np.float32) * 0.2
+    u, p, n = rng.integers(0, U, T), rng.integers(0, I, T), rng.integers(0, I, T)
+    loss_o, Un, In = oracle.bpr_sgd(Ut, It, Ut, It, u, p, n, lr=0.05, reg=1e-3)
+    Uw, Iw = t(Ut.copy()), t(It.copy())
+    loss = ops.bpr_sgd_step(t(Ut), t(It), Uw, Iw, t(u), t(p), t(n), lr=0.05, reg=1e-3)
+    assert abs(loss.item() / T - loss_o) <= 1e-6
+    assert rel_err(Uw.cpu().numpy(), Un) <= 1e-5 and rel_err(Iw.cpu().numpy(), In) <= 1e-5
+    # gradient form: finite-difference free check through the closed form (lr=-1 on a zero table == gradient)
+    _, dU, dI = oracle.bpr_sgd(Ut, It, np.zeros_like(Ut), np.zeros_like(It), u, p, n, lr=-1.0, reg=0.0)
+    gu, gi = torch.zeros(U, 64, device=DEV), torch.zeros(I, 64, device=DEV)
+    ops.bpr_loss_grad(t(Ut), t(It), t(u), t(p), t(n), gu, gi, 1.0 / T)
+    assert rel_err(gu.cpu().numpy(), dU) <= 1e-5 and rel_err(gi.cpu().numpy(), dI) <= 1e-5
+
+
+def test_adam_kernel_vs_oracle(oracle):
+    from spex_amd import ops
+    rng = np.random.default_rng(6)
+    n = 64 * 1001 + 3
+    p, g, m, v = (rng.normal(size=n).astype(np.float32) for _ in range(4))
+    v = np.abs(v)
+    pp, mm, vv = t(p), t(m), t(v)
+    for step in (1, 2, 17):
+        oracle.adam_step(p, g, m, v, step, lr=1e-3)
+        ops.adam_step(pp, t(g), mm, vv, step, lr=1e-3)
+        assert rel_err(pp.cpu().numpy(), p) <= 1e-6 and rel_err(mm.cpu().numpy(), m) <= 1e-6
+        assert rel_err(vv.cpu().numpy(), v) <= 1e-6
+
+
+# ---------------------------------------------------------------------------------------------- NGCF + gate
+@pytest.mark.parametrize("ds", ["tiny", "epinion2"])
+def test_g7_ngcf_forward_vs_reference(G, golden, epinion2, ds):
+    from spex_amd import ops
+    from spex_amd.graph import ngcf_norm_adj
+    from spex_amd.datasets import epinion2_tables
+    g = golden(f"ngcf_{ds}")
+    if ds == "tiny":
+        csr, uw, iw = (g["rowptr"], g["col"], g["val"]), g["user_w"], g["item_w"]
+    else:
+        tr = epinion2["train"]
+        csr = ngcf_norm_adj(tr[:, 0], tr[:, 1], int(g["n_users"]), int(g["n_items"]))
+        uw, iw = epinion2_tables(int(g["n_users"]) + 1, int(g["n_items"]))
+    ego = t(np.concatenate([uw[:-1], iw]))
+    side = G(*csr).spmm(ego)
+    out = ops.ngcf_layer(ego, side, t(g["W_gc"]), t(g["b_gc"]), t(g["W_bi"]), t(g["b_bi"])).cpu().numpy()
+    want = g["all_emb"] if ds == "tiny" else g["all_emb_rows"]
+    got = out if ds == "tiny" else out[g["sample_rows"]]
+    assert rel_err(got, want) <= 1e-5
+    assert np.allclose(out.astype(np.float64).sum(0), g["all_emb_colsum"], rtol=1e-4, atol=1e-5)
+    # loss on the concatenated tables (ld = 128): NGCF main_rec.py:89-100
+    n_u = int(g["n_users"])
+    o = t(out)
+    gamma, loss_sum = ops.score_bce(o[:n_u], o[n_u:], t(g["batch_users"]), t(g["batch_items"]), t(g["batch_labels"]))
+    assert abs(loss_sum.item() / 256 - float(g["loss"])) <= 2e-6
+
+
+def test_g8_expert_gate_vs_reference(G, golden):
+    from spex_amd import ops
+    g = golden("lightgcn_tiny")
+    n_u = int(g["n_user"]) + 1
+    E0 = t(g["E0"])
+    out = G(g["rowptr"], g["col"], g["val"]).propagate(E0, 3)
+    mu = ops.expert_gate(E0[:n_u].contiguous(), out[:n_u].contiguous(), t(g["g8_att_exp1"]))
+    mi = ops.expert_gate(E0[n_u:].contiguous(), out[n_u:].contiguous(), t(g["g8_att_exp2"]))
+    gamma, _ = ops.score_bce(mu, mi, t(g["batch_users"][0]), t(g["batch_items"][0]))
+    assert rel_err(gamma.cpu().numpy(), g["g8_gamma"]) <= 1e-5
