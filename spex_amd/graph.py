@@ -186,8 +186,9 @@ class SpexGraph:
             Y = torch.empty((self.n_rows, d), dtype=torch.float32, device=X.device)
         for t, nm in ((Y, "Y"), (add_in, "add_in"), (acc_in, "acc_in"), (acc_out, "acc_out")):
             self._chk(t, self.n_rows, d, nm)
-        _lib.call("spex_spmm_f32", self._h, _ptr(X), _ptr(Y), _ptr(add_in), float(add_div), _ptr(acc_in), _ptr(acc_out),
-                  float(acc_div), d, _stream())
+        if self.n_rows > 0:     # (an empty tensor has a NULL data_ptr; nothing to launch anyway)
+            _lib.call("spex_spmm_f32", self._h, _ptr(X), _ptr(Y), _ptr(add_in), float(add_div), _ptr(acc_in),
+                      _ptr(acc_out), float(acc_div), d, _stream())
         return Y if Y is not None else acc_out
 
     def propagate(self, E0, n_layers, mean_out=None, layers_out=None, ws=None):

@@ -96,7 +96,13 @@ def test_spmm_edge_cases(G, oracle):
     rowptr, col, val = random_csr(rng, 3, 5000, [0, 5000, 1])
     X = rng.normal(size=(5000, 64)).astype(np.float32)
     g2 = G(rowptr, col, val, n_cols=5000)
-    assert rel_err(g2.spmm(t(X)).cpu().numpy(), oracle.spmm(rowptr, col, val, X)) <= 1e-6
+    got, ref = g2.spmm(t(X)).cpu().numpy(), oracle.spmm(rowptr, col, val, X)
+    # a 5000-term sum of random-sign products: the segmented order and the sequential order are both ~sqrt(n) eps
+    # away from the exact sum; require the north-star 1e-5 and that the GPU is no further from fp64 than the CPU is
+    assert rel_err(got, ref) <= 1e-5
+    import scipy.sparse as sp
+    exact = sp.csr_matrix((val.astype(np.float64), col, rowptr), shape=(3, 5000)) @ X.astype(np.float64)
+    assert rel_err(got, exact) <= 2.0 * rel_err(ref, exact) + 1e-7
     # NaN / Inf in an unrelated source row must not leak (no 0 * Inf from padded lanes)
     X[4999] = np.inf
     rowptr, col, val = random_csr(rng, 50, 4999, rng.integers(1, 30, 50))
@@ -221,13 +227,18 @@ def test_g9_dropout_injected_mask_and_backward_consistency(G, golden, oracle):
     x, y = (torch.randn(len(csr[0]) - 1, 64, device=DEV, generator=gen) for _ in range(2))
     a = (gr.spmm(x).double() * y.double()).sum().item()
     b = (x.double() * gt.spmm(y).double()).sum().item()
-    assert abs(a - b) <= 1e-9 * max(abs(a), 1.0) + 1e-9
+    scale = (gr.spmm(x.abs()).double() * y.abs().double()).sum().item()
+    assert abs(a - b) <= 1e-6 * scale                                       # fp32 products, fp64 reduction
+    # and it is a genuinely different operator from the unmasked one
+    gr.set_edge_mask(0)
+    assert abs((gr.spmm(x).double() * y.double()).sum().item() - a) > 1e-3 * scale
+    gr.set_edge_mask(1, t(keep.astype(np.uint8)), keep_prob, 0)
     # sampled (philox) mode: same seed -> same mask in A and A^T; keep rate ~ keep_prob; E[A'] = A
     gr.set_edge_mask(2, None, keep_prob, 1234)
     gt.set_edge_mask(2, None, keep_prob, 1234)
     a = (gr.spmm(x).double() * y.double()).sum().item()
     b = (x.double() * gt.spmm(y).double()).sum().item()
-    assert abs(a - b) <= 1e-9 * max(abs(a), 1.0) + 1e-9
+    assert abs(a - b) <= 1e-6 * scale
     gr.set_edge_mask(0)
     assert np.array_equal(gr.propagate(t(g["E0"]), 3).cpu().numpy(), g["light_out"])
 
