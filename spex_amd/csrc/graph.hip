@@ -33,7 +33,8 @@ static int upload(T **dst, const T *src, size_t n)
 extern "C" int spex_graph_destroy(spex_graph_t *g)
 {
     if (!g) return SPEX_OK;
-    void *ptrs[] = {g->rowptr, g->col, g->val, g->edge_id, g->seg_beg, g->seg_end, g->long_row, g->long_seg0, g->partial};
+    void *ptrs[] = {g->rowptr, g->col, g->val, g->edge_id, g->seg_beg, g->seg_end, g->long_row, g->long_seg0, g->partial,
+                    g->task, g->entry_row};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete g;
@@ -84,6 +85,48 @@ extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, 
     g->n_long = (int32_t)long_row.size();
     g->n_seg = (int32_t)seg_beg.size();
 
+    // quarter-wave tasks (see spex_common.h): long-row segments, single rows of 17..128 entries, greedy packs of whole
+    // rows with <= 16 entries in total, empty rows.  Stable bucket sort by chunk count, heaviest first.
+    std::vector<int4> task;
+    std::vector<int32_t> entry_row((size_t)nnz);
+    for (size_t s = 0; s < seg_beg.size(); ++s) task.push_back(make_int4(seg_beg[s], seg_end[s], (int32_t)s, -1));
+    {
+        int32_t cur_beg = -1, cur_end = -1;
+        auto close = [&]() {
+            if (cur_beg >= 0 && cur_end > cur_beg) task.push_back(make_int4(cur_beg, cur_end, -1, -1));
+            cur_beg = cur_end = -1;
+        };
+        for (int32_t r = 0; r < n_rows; ++r) {
+            const int32_t b = h_rowptr[r], e = h_rowptr[r + 1];
+            for (int32_t k = b; k < e; ++k) entry_row[k] = r;
+            if (e == b) {
+                task.push_back(make_int4(0, 0, -1, r));
+                continue;
+            }
+            if (e - b > spex::kLongRow) {
+                close();
+                continue;
+            }
+            if (cur_beg >= 0 && cur_end == b && e - cur_beg <= spex::kTaskEntries) {
+                cur_end = e;
+            } else {
+                close();
+                cur_beg = b;
+                cur_end = e;
+            }
+        }
+        close();
+    }
+    {
+        const int n_buckets = spex::kSegLen / 16 + 1;
+        std::vector<std::vector<int4>> bucket(n_buckets);
+        for (const int4 &t : task) bucket[(t.y - t.x + 15) / 16].push_back(t);
+        task.clear();
+        for (int k = n_buckets - 1; k >= 0; --k) task.insert(task.end(), bucket[k].begin(), bucket[k].end());
+        while (task.size() % 4) task.push_back(make_int4(0, 0, -1, -1));
+    }
+    g->n_tasks = (int32_t)task.size();
+
     int rc = SPEX_OK;
     if ((rc = upload(&g->rowptr, h_rowptr, (size_t)n_rows + 1)) || (rc = upload(&g->col, h_col, (size_t)nnz)) ||
         (rc = upload(&g->val, h_val, (size_t)nnz)) ||
@@ -91,7 +134,9 @@ extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, 
         (rc = upload(&g->seg_beg, seg_beg.data(), seg_beg.size())) ||
         (rc = upload(&g->seg_end, seg_end.data(), seg_end.size())) ||
         (rc = upload(&g->long_row, long_row.data(), long_row.size())) ||
-        (rc = upload(&g->long_seg0, long_seg0.data(), long_seg0.size()))) {
+        (rc = upload(&g->long_seg0, long_seg0.data(), long_seg0.size())) ||
+        (rc = upload(&g->task, task.data(), task.size())) ||
+        (rc = upload(&g->entry_row, entry_row.data(), entry_row.size()))) {
         spex_graph_destroy(g);
         return rc;
     }

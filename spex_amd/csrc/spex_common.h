@@ -32,6 +32,7 @@ constexpr int kWave = 64;          // CDNA wavefront
 constexpr int kWavesPerBlock = 4;  // 256-thread workgroups
 constexpr int kLongRow = 128;      // rows with more stored entries are cut into segments
 constexpr int kSegLen = 128;       // entries per long-row segment
+constexpr int kTaskEntries = 16;   // entry budget of a multi-row quarter-wave task (one 16-lane metadata load)
 
 }  // namespace spex
 
@@ -56,6 +57,13 @@ struct spex_graph {
     int32_t *long_seg0 = nullptr; // [n_long+1] first segment of each long row
     float *partial = nullptr;     // [n_seg * d_cap] scratch, grown on demand
     int64_t partial_cap = 0;      // floats
+    // quarter-wave tasks of the d == 64 kernel (16 lanes x float4 per task, 4 tasks per wave): a task is a
+    // contiguous entry range that never splits a short row.  x = first entry, y = one-past-last entry,
+    // z = partial-row slot (>= 0: the task is one 128-entry segment of a long row) or -1, w = row to zero-fill for an
+    // empty row (x == y) or -1.  Sorted by descending 16-entry chunk count so the 4 tasks of a wave are alike.
+    int32_t n_tasks = 0;          // multiple of 4
+    int4 *task = nullptr;         // [n_tasks]
+    int32_t *entry_row = nullptr; // [nnz] row of each stored entry (COO row index, sorted)
     // edge dropout
     int mask_mode = 0;
     const uint8_t *keep = nullptr;

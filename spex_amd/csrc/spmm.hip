@@ -36,6 +36,9 @@ struct SpmmParams {
     const int32_t *edge_id;
     const int32_t *seg_beg, *seg_end, *long_row, *long_seg0;
     int32_t n_rows, n_seg, n_long;
+    const int4 *task;
+    const int32_t *entry_row;
+    int32_t n_tasks;
     const float *X;
     float *Y;
     const float *add_in;
@@ -179,18 +182,18 @@ __device__ __forceinline__ int xcd_contiguous_block(int bid, int nblk)
 
 // One wave per task.  Tasks [0, n_seg) are long-row segments (heaviest work first), tasks [n_seg, n_seg + n_rows)
 // are rows; rows longer than kLongRow are left to their segments.
-template <bool MASKED, bool D64>
+template <bool MASKED>
 __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_rows_kernel(const SpmmParams p)
 {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int task = xcd_contiguous_block(blockIdx.x, gridDim.x) * kWavesPerBlock + wave;
-    const int d = D64 ? 64 : p.d;
+    const int d = p.d;
 
     if (task < p.n_seg) {
         const int beg = p.seg_beg[task], end = p.seg_end[task];
         for (int c0 = 0; c0 < d; c0 += kWave) {
-            const bool ok = D64 || (c0 + lane < d);
+            const bool ok = c0 + lane < d;
             const float y = accumulate_range<MASKED>(p, beg, end, lane, p.X + c0 + lane, d, ok, 0.0f);
             if (ok) p.partial[(size_t)task * d + c0 + lane] = y;
         }
@@ -201,9 +204,143 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_rows_kernel(const 
     const int beg = p.rowptr[r], end = p.rowptr[r + 1];
     if (end - beg > kLongRow) return;
     for (int c0 = 0; c0 < d; c0 += kWave) {
-        const bool ok = D64 || (c0 + lane < d);
+        const bool ok = c0 + lane < d;
         const float y = accumulate_range<MASKED>(p, beg, end, lane, p.X + c0 + lane, d, ok, 0.0f);
         if (ok) finish_row(p, r, c0 + lane, y);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// d == 64 kernel.  A 256-byte embedding row is 16 lanes x float4, so one wave-wide `global_load_dwordx4` gathers FOUR
+// rows (1 KiB per instruction, the widest access the memory pipeline has; 4-byte-per-lane gathers measured 3x fewer
+// bytes per CU-clock on this part).  The wave is therefore split into four 16-lane groups, each walking its own TASK:
+// a contiguous run of stored entries that covers whole short rows (<= 16 entries in total), one row of 17..128
+// entries, or one 128-entry segment of a long row.  Per 16-entry chunk the group's lanes load (col, val, row) with one
+// coalesced load each and hand them round with ds_bpermute; four gathers per group are kept in flight (16 rows per
+// wave) and consumed in order — one fmaf chain per output element, ascending column, the reference's summation
+// order.  A row's epilogue operand (running layer sum, or g/(L+1)) is fetched in the same batch as the row's last
+// gather, so finishing a row never waits on a dependent load.  Divergence is only ever at group granularity.
+constexpr int kQ = 16;      // lanes per group == entries per metadata chunk
+constexpr int kUnrollQ = 4; // gathers in flight per group
+
+__device__ __forceinline__ int bperm_i(int src_lane, int v) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
+__device__ __forceinline__ float bperm_f(int src_lane, float v)
+{
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
+}
+
+template <bool MASKED, int EPI>  // EPI: 0 none, 1 acc (forward), 2 add (backward), 3 both (generic, loads late)
+__global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_q4_kernel(const SpmmParams p)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int q = lane & (kQ - 1);
+    const int gbase = lane & ~(kQ - 1);
+    const int wave = (int)(threadIdx.x >> 6);
+    const int task_id = (xcd_contiguous_block(blockIdx.x, gridDim.x) * kWavesPerBlock + wave) * 4 + (lane >> 4);
+    int4 t = make_int4(0, 0, -1, -1);
+    if (task_id < p.n_tasks) t = p.task[task_id];
+    const int n = t.y - t.x;
+    const bool partial = t.z >= 0;
+    int nmax = n;  // wave-uniform trip count = longest of the four tasks
+    nmax = max(nmax, __shfl_xor(nmax, 16, kWave));
+    nmax = max(nmax, __shfl_xor(nmax, 32, kWave));
+    nmax = __builtin_amdgcn_readfirstlane(nmax);
+
+    const float *__restrict__ Xq = p.X + q * 4;
+    const float *__restrict__ epi_ptr = ((EPI == 1) ? p.acc_in : p.add_in);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (int cb = 0; cb < nmax; cb += kQ) {
+        // this group's next 16 entries, one per lane
+        const int e = t.x + cb + q;
+        const bool valid = cb + q < n;
+        int my_cl = 0, my_row = 0;
+        float my_val = 0.0f;
+        if (valid) {
+            my_cl = p.col[e];
+            my_val = p.val[e];
+            my_row = p.entry_row[e];
+            bool last;
+            if (partial) last = (e + 1 == t.y);
+            else last = (e + 1 < t.y) ? (p.entry_row[e + 1] != my_row) : true;
+            if (last) my_cl |= (int)0x80000000u;
+            if (MASKED) {
+                const int eid = p.edge_id ? p.edge_id[e] : e;
+                if (!edge_kept(p, eid)) my_cl |= 0x40000000;
+                my_val = my_val / p.keep_prob;
+            }
+        }
+        const int cnt = n - cb;  // entries of this group still to do in this chunk (may be <= 0)
+        for (int j0 = 0; j0 < kQ && cb + j0 < nmax; j0 += kUnrollQ) {
+            float4 x[kUnrollQ], ep[kUnrollQ];
+            float v[kUnrollQ];
+            int cl[kUnrollQ], rr[kUnrollQ];
+#pragma unroll
+            for (int u = 0; u < kUnrollQ; ++u) {
+                const int j = j0 + u;
+                cl[u] = bperm_i(gbase + j, my_cl);
+                v[u] = bperm_f(gbase + j, my_val);
+                rr[u] = bperm_i(gbase + j, my_row);
+                x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                ep[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (j < cnt) {
+                    if (!MASKED || !(cl[u] & 0x40000000)) {
+                        const int c = cl[u] & 0x3fffffff;
+                        x[u] = *reinterpret_cast<const float4 *>(Xq + (size_t)c * 64);
+                    }
+                    if ((EPI == 1 || EPI == 2) && cl[u] < 0 && !partial)
+                        ep[u] = *reinterpret_cast<const float4 *>(epi_ptr + (size_t)rr[u] * 64 + q * 4);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kUnrollQ; ++u) {
+                const int j = j0 + u;
+                if (j < cnt) {
+                    if (!MASKED || !(cl[u] & 0x40000000)) {
+                        acc.x = fmaf(v[u], x[u].x, acc.x);
+                        acc.y = fmaf(v[u], x[u].y, acc.y);
+                        acc.z = fmaf(v[u], x[u].z, acc.z);
+                        acc.w = fmaf(v[u], x[u].w, acc.w);
+                    }
+                    if (cl[u] < 0) {  // last entry of a row (or of the segment): emit
+                        if (partial) {
+                            *reinterpret_cast<float4 *>(p.partial + (size_t)t.z * 64 + q * 4) = acc;
+                        } else {
+                            const size_t o = (size_t)rr[u] * 64 + q * 4;
+                            if (EPI == 0) {
+                                *reinterpret_cast<float4 *>(p.Y + o) = acc;
+                            } else if (EPI == 1) {
+                                if (p.Y) *reinterpret_cast<float4 *>(p.Y + o) = acc;
+                                float4 s = make_float4(ep[u].x + acc.x, ep[u].y + acc.y, ep[u].z + acc.z, ep[u].w + acc.w);
+                                if (p.acc_div != 1.0f) {
+                                    s.x = s.x / p.acc_div; s.y = s.y / p.acc_div; s.z = s.z / p.acc_div; s.w = s.w / p.acc_div;
+                                }
+                                *reinterpret_cast<float4 *>(p.acc_out + o) = s;
+                            } else if (EPI == 2) {
+                                float4 a = ep[u];
+                                if (p.add_div != 1.0f) {
+                                    a.x = a.x / p.add_div; a.y = a.y / p.add_div; a.z = a.z / p.add_div; a.w = a.w / p.add_div;
+                                }
+                                *reinterpret_cast<float4 *>(p.Y + o) = make_float4(acc.x + a.x, acc.y + a.y, acc.z + a.z, acc.w + a.w);
+                            } else {
+                                finish_row(p, rr[u], q * 4 + 0, acc.x);
+                                finish_row(p, rr[u], q * 4 + 1, acc.y);
+                                finish_row(p, rr[u], q * 4 + 2, acc.z);
+                                finish_row(p, rr[u], q * 4 + 3, acc.w);
+                            }
+                        }
+                        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+            }
+        }
+    }
+    if (n == 0 && t.w >= 0) {  // a row without stored entries: y = 0, epilogue still applies
+        finish_row(p, t.w, q * 4 + 0, 0.0f);
+        finish_row(p, t.w, q * 4 + 1, 0.0f);
+        finish_row(p, t.w, q * 4 + 2, 0.0f);
+        finish_row(p, t.w, q * 4 + 3, 0.0f);
     }
 }
 
@@ -256,18 +393,35 @@ int launch_spmm(const spex_graph *g, const float *X, float *Y, const float *add_
     p.mask_mode = g->mask_mode; p.keep = g->keep; p.keep_prob = g->keep_prob;
     p.seed_lo = (uint32_t)g->seed; p.seed_hi = (uint32_t)(g->seed >> 32);
 
-    const int64_t tasks = (int64_t)g->n_seg + g->n_rows;
+    p.task = g->task; p.entry_row = g->entry_row; p.n_tasks = g->n_tasks;
+    const bool masked = g->mask_mode != 0, d64 = d == 64;
+    const int64_t tasks = d64 ? (int64_t)g->n_tasks / 4 : (int64_t)g->n_seg + g->n_rows;  // waves
     int64_t blocks = (tasks + kWavesPerBlock - 1) / kWavesPerBlock;
     blocks = (blocks + 7) / 8 * 8;  // multiple of the XCD count so the remap is a bijection
     const dim3 grid((unsigned)blocks), block(kWave * kWavesPerBlock);
-    const bool masked = g->mask_mode != 0, d64 = d == 64;
     spex_timer *tm = g->timer;
     const bool timed = tm && tm->used < (int32_t)tm->start.size();
     if (timed) SPEX_HIP(hipEventRecord(tm->start[tm->used], stream));
-    if (masked && d64) hipLaunchKernelGGL((spmm_rows_kernel<true, true>), grid, block, 0, stream, p);
-    else if (masked) hipLaunchKernelGGL((spmm_rows_kernel<true, false>), grid, block, 0, stream, p);
-    else if (d64) hipLaunchKernelGGL((spmm_rows_kernel<false, true>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((spmm_rows_kernel<false, false>), grid, block, 0, stream, p);
+    if (d64) {
+        const int epi = (acc_out ? 1 : 0) | (add_in ? 2 : 0);
+#define SPEX_LAUNCH_TASKS(M, E) hipLaunchKernelGGL((spmm_q4_kernel<M, E>), grid, block, 0, stream, p)
+        if (masked) {
+            if (epi == 0) SPEX_LAUNCH_TASKS(true, 0);
+            else if (epi == 1) SPEX_LAUNCH_TASKS(true, 1);
+            else if (epi == 2) SPEX_LAUNCH_TASKS(true, 2);
+            else SPEX_LAUNCH_TASKS(true, 3);
+        } else {
+            if (epi == 0) SPEX_LAUNCH_TASKS(false, 0);
+            else if (epi == 1) SPEX_LAUNCH_TASKS(false, 1);
+            else if (epi == 2) SPEX_LAUNCH_TASKS(false, 2);
+            else SPEX_LAUNCH_TASKS(false, 3);
+        }
+#undef SPEX_LAUNCH_TASKS
+    } else if (masked) {
+        hipLaunchKernelGGL((spmm_rows_kernel<true>), grid, block, 0, stream, p);
+    } else {
+        hipLaunchKernelGGL((spmm_rows_kernel<false>), grid, block, 0, stream, p);
+    }
     if (timed) {
         SPEX_HIP(hipEventRecord(tm->stop[tm->used], stream));
         tm->used++;
