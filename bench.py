@@ -9,8 +9,9 @@ One "step" = one pass of the hot path over one batch, inputs resident in HBM:
     3-layer propagation over the normalised user-item graph (3 SpMM launches, layer mean fused)
   + one fused BPR gather+dot+sigmoid+SGD kernel over T = 2048 triples scored on the propagated table.
 N = 1: the Epinion2 graph (BASELINE configs[1]: N = 15 593 nodes, nnz = 418 608, d = 64).
-N > 1: weak scaling — Epinion2 replicated N times with every interaction's item re-targeted to a random replica
-(same degree law per rank), 1-D row partition, RCCL all-gather of the layer's rows before each SpMM.
+N > 1: weak scaling — "Epinion2 x N": N replicas, the N copies of every interaction joined across replicas by a
+random permutation (every node keeps its Epinion2 degree), 1-D row partition, RCCL all-gather of the layer's rows
+before each SpMM.
 
 value = graph-conv edges/s = L * nnz * K / t over the whole job; BPR triples/s of the same timed region and the
 stand-alone kernel rates ride along in "extra".  "roofline" is the SpMM kernel timed with hipEvents inside the timed
@@ -38,18 +39,6 @@ def algorithmic_bytes(nnz, n_rows, d=D):
     """SURVEY.md 8d gather model: per entry int32 col + fp32 val + one gathered fp32 row; per row int32 rowptr + one
     written fp32 row."""
     return nnz * (4 + 4 + 4 * d) + n_rows * (4 + 4 * d)
-
-
-def replicated_epinion2(train, n_rep, n_user, m_item, seed=2020):
-    """Epinion2 x n_rep: user block k keeps its interactions, each pointed at a uniformly drawn replica of the item."""
-    if n_rep == 1:
-        return train[:, 0], train[:, 1], n_user, m_item
-    rng = np.random.default_rng(seed)
-    us, its = [], []
-    for k in range(n_rep):
-        us.append(train[:, 0] + k * n_user)
-        its.append(train[:, 1] + rng.integers(0, n_rep, len(train)) * m_item)
-    return np.concatenate(us), np.concatenate(its), n_user * n_rep, m_item * n_rep
 
 
 def time_events(fn, iters):
@@ -85,14 +74,12 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from spex_amd import ops
-    from spex_amd.datasets import load_epinion2, xavier_uniform_np
+    from spex_amd.datasets import epinion2_replicated, xavier_uniform_np
     from spex_amd.graph import SpexGraph, lightgcn_norm_adj
     from spex_amd.trainer import LightGCNStepper
 
-    ep = load_epinion2()
-    n_user0, m_item0 = int(ep["train"][:, 0].max()) + 1, int(ep["train"][:, 1].max()) + 1
-    uu, ii, n_user, m_item = replicated_epinion2(ep["train"], world, n_user0, m_item0)
-    rowptr, col, val = lightgcn_norm_adj(uu, ii, n_user, m_item)
+    uu, ii, n_user, m_item = epinion2_replicated(world, seed=2020)   # identical on every rank (CPU generator)
+    rowptr, col, val = lightgcn_norm_adj(uu.numpy(), ii.numpy(), n_user, m_item)
     n_nodes, nnz = len(rowptr) - 1, len(col)
     n_u = n_user + 1
     rng = np.random.default_rng(2020)
@@ -168,11 +155,11 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("epinion2 (reference preprocessing of the shipped Epinions .mat; N=%d nnz=%d d=%d L=%d)"
                                 % (n_nodes, nnz, D, L)) if world == 1 else
-                               ("epinion2 x%d replicas, items re-targeted across replicas; N=%d nnz=%d d=%d L=%d; "
+                               ("epinion2 x%d replicas cross-linked by per-interaction permutations; N=%d nnz=%d d=%d L=%d; "
                                 "1-D row partition + RCCL all-gather per layer" % (world, n_nodes, nnz, D, L)),
                    "bpr_triples_per_step": T_TRIPLES, "embeddings": "xavier-uniform seed 2020 (synthetic weights)",
                    "parallelism": "single GPU" if world == 1 else "row-partition x%d" % world},
-        "roofline": {"bound": "hbm", "kernel": "spmm_rows_kernel<false,true>", "achieved": achieved,
+        "roofline": {"bound": "hbm", "kernel": "spmm_chunk_kernel<1>", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "avg_launch_us": spmm_ms * 1e3, "launches_timed": int(len(kernel_ms)),
                      "algorithmic_bytes_per_launch": bytes_launch,
@@ -237,13 +224,15 @@ def main():
                 g2.detach_timer()
                 b2 = algorithmic_bytes(nnz2, n2)
                 ach = b2 / (ms * 1e-3) / 1e9
-                out["roofline_hbm"] = {"bound": "hbm", "kernel": "spmm_rows_kernel<false,true>", "achieved": ach,
+                out["roofline_hbm"] = {"bound": "hbm", "kernel": "spmm_chunk_kernel<1>", "achieved": ach,
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                                        "avg_launch_us": ms * 1e3, "algorithmic_bytes_per_launch": b2,
                                        "edges_per_s": nnz2 / (ms * 1e-3),
-                                       "workload": "synthetic LightGCN adjacency, N=2^%d=%d nodes, nnz=%d, d=64 "
-                                                   "(X = %.2f GB >> 256 MB Infinity Cache), long rows=%d"
-                                                   % (a.hbm_log2_nodes, n2, nnz2, n2 * D * 4 / 1e9, g2.n_long_rows)}
+                                       "workload": "Epinion2 x %d replicas (same degree law, cross-linked), N=%d nodes "
+                                                   "~2^%d, nnz=%d, d=64 (X = %.2f GB >> 256 MB Infinity Cache), "
+                                                   "long rows=%d" % (round((1 << a.hbm_log2_nodes) / 15593), n2,
+                                                                     a.hbm_log2_nodes, nnz2, n2 * D * 4 / 1e9,
+                                                                     g2.n_long_rows)}
                 if os.path.exists(traffic_file):
                     try:
                         out["roofline_hbm"]["traffic"] = json.load(open(traffic_file)).get("hbm_graph_spmm_bytes_per_launch")

@@ -34,7 +34,7 @@ extern "C" int spex_graph_destroy(spex_graph_t *g)
 {
     if (!g) return SPEX_OK;
     void *ptrs[] = {g->rowptr, g->col, g->val, g->edge_id, g->seg_beg, g->seg_end, g->long_row, g->long_seg0, g->partial,
-                    g->task, g->entry_row};
+                    g->task, g->chunk_off, g->chunk_val, g->chunk_mask};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete g;
@@ -85,47 +85,82 @@ extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, 
     g->n_long = (int32_t)long_row.size();
     g->n_seg = (int32_t)seg_beg.size();
 
-    // quarter-wave tasks (see spex_common.h): long-row segments, single rows of 17..128 entries, greedy packs of whole
-    // rows with <= 16 entries in total, empty rows.  Stable bucket sort by chunk count, heaviest first.
+    // Chunked task table (see spex_common.h).  Only when every source-row byte offset fits below kPadOffset.
     std::vector<int4> task;
-    std::vector<int32_t> entry_row((size_t)nnz);
-    for (size_t s = 0; s < seg_beg.size(); ++s) task.push_back(make_int4(seg_beg[s], seg_end[s], (int32_t)s, -1));
-    {
-        int32_t cur_beg = -1, cur_end = -1;
+    std::vector<uint32_t> c_off, c_mask;
+    std::vector<float> c_val;
+    const bool chunked = (int64_t)n_cols * 256 <= (int64_t)spex::kPadOffset && (int64_t)n_rows * 256 <= (int64_t)spex::kPadOffset;
+    if (chunked) {
+        c_off.reserve((size_t)nnz + (size_t)nnz / 4 + 64);
+        c_val.reserve((size_t)nnz + (size_t)nnz / 4 + 64);
+        // emit entries [b, e) as whole chunks; `row_end_is_last`: flag the final entry of every row (packs) or only
+        // the final entry of the range (segments)
+        auto emit_task = [&](int32_t b, int32_t e, int32_t r0, int32_t slot) {
+            const int32_t first_chunk = (int32_t)c_mask.size();
+            int32_t r = r0;
+            for (int32_t k = b; k < e; k += spex::kChunk) {
+                uint32_t mask = 0;
+                for (int32_t u = 0; u < spex::kChunk; ++u) {
+                    const int32_t en = k + u;
+                    if (en < e) {
+                        c_off.push_back((uint32_t)h_col[en] * 256u);
+                        c_val.push_back(h_val[en]);
+                        bool last;
+                        if (slot >= 0) last = (en + 1 == e);
+                        else {
+                            while (h_rowptr[r + 1] <= en) ++r;  // row of entry en (rows in a pack are consecutive)
+                            last = (en + 1 == h_rowptr[r + 1]);
+                        }
+                        if (last) mask |= 1u << u;
+                    } else {
+                        c_off.push_back(spex::kPadOffset);
+                        c_val.push_back(0.0f);
+                    }
+                }
+                c_mask.push_back(mask);
+            }
+            task.push_back(make_int4(first_chunk, (int32_t)c_mask.size() - first_chunk, r0, slot));
+        };
+        for (size_t s = 0; s < seg_beg.size(); ++s) {
+            // row of the segment: found from the long-row table
+            emit_task(seg_beg[s], seg_end[s], 0, (int32_t)s);
+        }
+        int32_t cur_beg = -1, cur_end = -1, cur_r0 = -1, prev_r = -2;
         auto close = [&]() {
-            if (cur_beg >= 0 && cur_end > cur_beg) task.push_back(make_int4(cur_beg, cur_end, -1, -1));
-            cur_beg = cur_end = -1;
+            if (cur_beg >= 0 && cur_end > cur_beg) emit_task(cur_beg, cur_end, cur_r0, -1);
+            cur_beg = cur_end = cur_r0 = -1;
         };
         for (int32_t r = 0; r < n_rows; ++r) {
             const int32_t b = h_rowptr[r], e = h_rowptr[r + 1];
-            for (int32_t k = b; k < e; ++k) entry_row[k] = r;
-            if (e == b) {
-                task.push_back(make_int4(0, 0, -1, r));
+            if (e == b) {  // empty row: zero-fill task; it also breaks the run of consecutive rows
+                close();
+                task.push_back(make_int4(0, 0, r, -1));
                 continue;
             }
             if (e - b > spex::kLongRow) {
                 close();
                 continue;
             }
-            if (cur_beg >= 0 && cur_end == b && e - cur_beg <= spex::kTaskEntries) {
+            if (cur_beg >= 0 && prev_r == r - 1 && cur_end == b && e - cur_beg <= spex::kTaskEntries) {
                 cur_end = e;
             } else {
                 close();
                 cur_beg = b;
                 cur_end = e;
+                cur_r0 = r;
             }
+            prev_r = r;
         }
         close();
-    }
-    {
-        const int n_buckets = spex::kSegLen / 16 + 1;
+        // heaviest first, stable within a weight class (keeps neighbouring tasks on neighbouring chunks)
+        const int n_buckets = spex::kSegLen / spex::kChunk + 1;
         std::vector<std::vector<int4>> bucket(n_buckets);
-        for (const int4 &t : task) bucket[(t.y - t.x + 15) / 16].push_back(t);
+        for (const int4 &t : task) bucket[t.y].push_back(t);
         task.clear();
         for (int k = n_buckets - 1; k >= 0; --k) task.insert(task.end(), bucket[k].begin(), bucket[k].end());
-        while (task.size() % 4) task.push_back(make_int4(0, 0, -1, -1));
     }
     g->n_tasks = (int32_t)task.size();
+    g->n_chunks = (int64_t)c_mask.size();
 
     int rc = SPEX_OK;
     if ((rc = upload(&g->rowptr, h_rowptr, (size_t)n_rows + 1)) || (rc = upload(&g->col, h_col, (size_t)nnz)) ||
@@ -136,7 +171,9 @@ extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, 
         (rc = upload(&g->long_row, long_row.data(), long_row.size())) ||
         (rc = upload(&g->long_seg0, long_seg0.data(), long_seg0.size())) ||
         (rc = upload(&g->task, task.data(), task.size())) ||
-        (rc = upload(&g->entry_row, entry_row.data(), entry_row.size()))) {
+        (rc = upload(&g->chunk_off, c_off.data(), c_off.size())) ||
+        (rc = upload(&g->chunk_val, c_val.data(), c_val.size())) ||
+        (rc = upload(&g->chunk_mask, c_mask.data(), c_mask.size()))) {
         spex_graph_destroy(g);
         return rc;
     }

@@ -32,7 +32,9 @@ constexpr int kWave = 64;          // CDNA wavefront
 constexpr int kWavesPerBlock = 4;  // 256-thread workgroups
 constexpr int kLongRow = 128;      // rows with more stored entries are cut into segments
 constexpr int kSegLen = 128;       // entries per long-row segment
-constexpr int kTaskEntries = 16;   // entry budget of a multi-row quarter-wave task (one 16-lane metadata load)
+constexpr int kTaskEntries = 64;   // entry budget of a multi-row wave task
+constexpr int kChunk = 16;         // entries per chunk (one s_load_dwordx16 of offsets, one of values)
+constexpr uint32_t kPadOffset = 0xFFFFFF00u;  // out-of-range source offset of a padding entry
 
 }  // namespace spex
 
@@ -57,13 +59,19 @@ struct spex_graph {
     int32_t *long_seg0 = nullptr; // [n_long+1] first segment of each long row
     float *partial = nullptr;     // [n_seg * d_cap] scratch, grown on demand
     int64_t partial_cap = 0;      // floats
-    // quarter-wave tasks of the d == 64 kernel (16 lanes x float4 per task, 4 tasks per wave): a task is a
-    // contiguous entry range that never splits a short row.  x = first entry, y = one-past-last entry,
-    // z = partial-row slot (>= 0: the task is one 128-entry segment of a long row) or -1, w = row to zero-fill for an
-    // empty row (x == y) or -1.  Sorted by descending 16-entry chunk count so the 4 tasks of a wave are alike.
-    int32_t n_tasks = 0;          // multiple of 4
-    int4 *task = nullptr;         // [n_tasks]
-    int32_t *entry_row = nullptr; // [nnz] row of each stored entry (COO row index, sorted)
+    // Chunked copy of the matrix for the d == 64 kernel (built when n_cols * 256 B fits a 32-bit buffer offset).
+    // A chunk is 16 stored entries: byte offsets of their source rows (col * 256) and their values, both read by the
+    // kernel with wave-uniform (scalar) loads, plus a 16-bit mask marking entries that end an output row.  A wave
+    // TASK is a run of chunks: whole consecutive short rows (<= 64 entries in total), one row of 65..128 entries, or
+    // one 128-entry segment of a long row.  Tasks are padded to whole chunks with entries whose offset is out of the
+    // buffer's range (the hardware bounds check returns 0 for them without touching memory).
+    //   task.x = first chunk, .y = number of chunks (0: just zero-fill row .z), .z = first row, .w = partial slot or -1
+    int32_t n_tasks = 0;
+    int4 *task = nullptr;          // [n_tasks], heaviest first
+    int64_t n_chunks = 0;
+    uint32_t *chunk_off = nullptr; // [n_chunks * 16]
+    float *chunk_val = nullptr;    // [n_chunks * 16]
+    uint32_t *chunk_mask = nullptr; // [n_chunks]
     // edge dropout
     int mask_mode = 0;
     const uint8_t *keep = nullptr;

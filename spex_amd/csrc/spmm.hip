@@ -36,9 +36,7 @@ struct SpmmParams {
     const int32_t *edge_id;
     const int32_t *seg_beg, *seg_end, *long_row, *long_seg0;
     int32_t n_rows, n_seg, n_long;
-    const int4 *task;
-    const int32_t *entry_row;
-    int32_t n_tasks;
+
     const float *X;
     float *Y;
     const float *add_in;
@@ -212,135 +210,111 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_rows_kernel(const 
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// d == 64 kernel.  A 256-byte embedding row is 16 lanes x float4, so one wave-wide `global_load_dwordx4` gathers FOUR
-// rows (1 KiB per instruction, the widest access the memory pipeline has; 4-byte-per-lane gathers measured 3x fewer
-// bytes per CU-clock on this part).  The wave is therefore split into four 16-lane groups, each walking its own TASK:
-// a contiguous run of stored entries that covers whole short rows (<= 16 entries in total), one row of 17..128
-// entries, or one 128-entry segment of a long row.  Per 16-entry chunk the group's lanes load (col, val, row) with one
-// coalesced load each and hand them round with ds_bpermute; four gathers per group are kept in flight (16 rows per
-// wave) and consumed in order — one fmaf chain per output element, ascending column, the reference's summation
-// order.  A row's epilogue operand (running layer sum, or g/(L+1)) is fetched in the same batch as the row's last
-// gather, so finishing a row never waits on a dependent load.  Divergence is only ever at group granularity.
-constexpr int kQ = 16;      // lanes per group == entries per metadata chunk
-constexpr int kUnrollQ = 4; // gathers in flight per group
+// d == 64 kernel: one wave per TASK (a run of 16-entry chunks, see spex_common.h), lane == embedding column.
+//
+// Measured on MI355X (tools/gather_bench.hip): random 256-byte row gathers run at the same rate — 6.1 TB/s from HBM,
+// 15-20 TB/s from L2/Infinity Cache — whether a row is fetched as 64 x 4 B or 16 x 16 B lanes, as long as ~16 rows
+// per wave are in flight; what separates a kernel from that ceiling is everything it issues AROUND the gathers (the
+// first versions of this kernel spent 15 scalar + 6 vector instructions per gathered row on lane broadcasts, 64-bit
+// address arithmetic and row-boundary tests, saturating the CU's scalar unit at a third of the gather rate).
+// So the per-entry metadata is laid out to be consumed with no arithmetic at all:
+//   * source-row BYTE OFFSETS (col * 256) and values come in through wave-uniform s_load_dwordx16 straight into SGPRs;
+//   * each gather is one `buffer_load_dword v, v_lane4, s[rsrc], s_off offen` — the scalar offset register IS the
+//     loaded metadata word — and one `v_fmac_f32 v_acc, s_val, v_x`;
+//   * padding entries carry an out-of-range offset: the buffer bounds check returns 0 without a memory access;
+//   * a 16-bit mask per chunk marks the entries that end a row; the row's epilogue operand is fetched in the same
+//     batch as its last gather, so emitting a row never waits on a dependent load.
+// The accumulation is still one fmaf chain per output element in ascending column order (bit-exact vs the oracle).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
-__device__ __forceinline__ int bperm_i(int src_lane, int v) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
-__device__ __forceinline__ float bperm_f(int src_lane, float v)
+template <int EPI>  // 0: Y = y;  1: Y = y (optional), acc_out = (acc_in + y) / acc_div;  2: Y = y + add_in / add_div
+__global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_chunk_kernel(
+    const float *__restrict__ X, uint32_t x_bytes, const uint32_t *__restrict__ chunk_off,
+    const float *__restrict__ chunk_val, const uint32_t *__restrict__ chunk_mask, const int4 *__restrict__ task,
+    int n_tasks, float *__restrict__ Y, const float *__restrict__ epi_in, uint32_t epi_bytes, float epi_div,
+    float *__restrict__ acc_out, float *__restrict__ partial)
 {
-    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
-}
+    const int lane4 = (threadIdx.x & (kWave - 1)) * 4;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tid = xcd_contiguous_block(blockIdx.x, gridDim.x) * kWavesPerBlock + wave;
+    if (tid >= n_tasks) return;
+    const int4 t = task[tid];
+    const rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0, (int)x_bytes, 0x00020000);
+    const rsrc_t re = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(EPI ? epi_in : X), 0,
+                                                        (int)(EPI ? epi_bytes : 0u), 0x00020000);
+    const bool is_partial = t.w >= 0;
+    int row = t.z;
+    float acc = 0.0f;
 
-template <bool MASKED, int EPI>  // EPI: 0 none, 1 acc (forward), 2 add (backward), 3 both (generic, loads late)
-__global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_q4_kernel(const SpmmParams p)
-{
-    const int lane = threadIdx.x & (kWave - 1);
-    const int q = lane & (kQ - 1);
-    const int gbase = lane & ~(kQ - 1);
-    const int wave = (int)(threadIdx.x >> 6);
-    const int task_id = (xcd_contiguous_block(blockIdx.x, gridDim.x) * kWavesPerBlock + wave) * 4 + (lane >> 4);
-    int4 t = make_int4(0, 0, -1, -1);
-    if (task_id < p.n_tasks) t = p.task[task_id];
-    const int n = t.y - t.x;
-    const bool partial = t.z >= 0;
-    int nmax = n;  // wave-uniform trip count = longest of the four tasks
-    nmax = max(nmax, __shfl_xor(nmax, 16, kWave));
-    nmax = max(nmax, __shfl_xor(nmax, 32, kWave));
-    nmax = __builtin_amdgcn_readfirstlane(nmax);
-
-    const float *__restrict__ Xq = p.X + q * 4;
-    const float *__restrict__ epi_ptr = ((EPI == 1) ? p.acc_in : p.add_in);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    for (int cb = 0; cb < nmax; cb += kQ) {
-        // this group's next 16 entries, one per lane
-        const int e = t.x + cb + q;
-        const bool valid = cb + q < n;
-        int my_cl = 0, my_row = 0;
-        float my_val = 0.0f;
-        if (valid) {
-            my_cl = p.col[e];
-            my_val = p.val[e];
-            my_row = p.entry_row[e];
-            bool last;
-            if (partial) last = (e + 1 == t.y);
-            else last = (e + 1 < t.y) ? (p.entry_row[e + 1] != my_row) : true;
-            if (last) my_cl |= (int)0x80000000u;
-            if (MASKED) {
-                const int eid = p.edge_id ? p.edge_id[e] : e;
-                if (!edge_kept(p, eid)) my_cl |= 0x40000000;
-                my_val = my_val / p.keep_prob;
-            }
+    auto emit = [&](int r, float y, float e) {
+        if (is_partial) {
+            partial[(size_t)t.w * 64 + (lane4 >> 2)] = y;
+            return;
         }
-        const int cnt = n - cb;  // entries of this group still to do in this chunk (may be <= 0)
-        for (int j0 = 0; j0 < kQ && cb + j0 < nmax; j0 += kUnrollQ) {
-            float4 x[kUnrollQ], ep[kUnrollQ];
-            float v[kUnrollQ];
-            int cl[kUnrollQ], rr[kUnrollQ];
+        const size_t o = (size_t)r * 64 + (lane4 >> 2);
+        if (EPI == 0) {
+            Y[o] = y;
+        } else if (EPI == 1) {
+            if (Y) Y[o] = y;
+            float s = e + y;
+            if (epi_div != 1.0f) s = s / epi_div;
+            acc_out[o] = s;
+        } else {
+            if (epi_div != 1.0f) e = e / epi_div;
+            Y[o] = y + e;
+        }
+    };
+
+    // Metadata of up to 4 chunks (64 entries) per vector load — lane k holds entry k — handed to the scalar side with
+    // v_readlane.  (Feeding it through s_load instead starves on scalar-cache misses once the matrix streams from
+    // HBM: 29 ms vs 13 ms per launch on the 2^23-node graph.)
+    for (int sc = 0; sc < t.y; sc += 4) {
+        const int nc = (t.y - sc < 4) ? t.y - sc : 4;  // chunks in this super-chunk (wave-uniform)
+        const int lane = lane4 >> 2;
+        uint32_t my_off = kPadOffset, my_mask = 0u;
+        float my_val = 0.0f;
+        if (lane < nc * kChunk) {
+            const size_t e = (size_t)(t.x + sc) * kChunk + lane;
+            my_off = chunk_off[e];
+            my_val = chunk_val[e];
+        }
+        if (lane < nc) my_mask = chunk_mask[t.x + sc + lane];
+        for (int c = 0; c < nc; ++c) {
+            const uint32_t mask = (uint32_t)__builtin_amdgcn_readlane((int)my_mask, c);
+            float x[kChunk], ep[kChunk];
 #pragma unroll
-            for (int u = 0; u < kUnrollQ; ++u) {
-                const int j = j0 + u;
-                cl[u] = bperm_i(gbase + j, my_cl);
-                v[u] = bperm_f(gbase + j, my_val);
-                rr[u] = bperm_i(gbase + j, my_row);
-                x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                ep[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (j < cnt) {
-                    if (!MASKED || !(cl[u] & 0x40000000)) {
-                        const int c = cl[u] & 0x3fffffff;
-                        x[u] = *reinterpret_cast<const float4 *>(Xq + (size_t)c * 64);
+            for (int u = 0; u < kChunk; ++u)
+                x[u] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                    rx, lane4, __builtin_amdgcn_readlane((int)my_off, c * kChunk + u), 0));
+            if (EPI != 0 && !is_partial && mask != 0u) {
+                int r = row;
+#pragma unroll
+                for (int u = 0; u < kChunk; ++u) {
+                    ep[u] = 0.0f;
+                    if (mask & (1u << u)) {
+                        ep[u] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(re, lane4, r * 256, 0));
+                        ++r;
                     }
-                    if ((EPI == 1 || EPI == 2) && cl[u] < 0 && !partial)
-                        ep[u] = *reinterpret_cast<const float4 *>(epi_ptr + (size_t)rr[u] * 64 + q * 4);
                 }
+            } else {
+#pragma unroll
+                for (int u = 0; u < kChunk; ++u) ep[u] = 0.0f;
             }
 #pragma unroll
-            for (int u = 0; u < kUnrollQ; ++u) {
-                const int j = j0 + u;
-                if (j < cnt) {
-                    if (!MASKED || !(cl[u] & 0x40000000)) {
-                        acc.x = fmaf(v[u], x[u].x, acc.x);
-                        acc.y = fmaf(v[u], x[u].y, acc.y);
-                        acc.z = fmaf(v[u], x[u].z, acc.z);
-                        acc.w = fmaf(v[u], x[u].w, acc.w);
-                    }
-                    if (cl[u] < 0) {  // last entry of a row (or of the segment): emit
-                        if (partial) {
-                            *reinterpret_cast<float4 *>(p.partial + (size_t)t.z * 64 + q * 4) = acc;
-                        } else {
-                            const size_t o = (size_t)rr[u] * 64 + q * 4;
-                            if (EPI == 0) {
-                                *reinterpret_cast<float4 *>(p.Y + o) = acc;
-                            } else if (EPI == 1) {
-                                if (p.Y) *reinterpret_cast<float4 *>(p.Y + o) = acc;
-                                float4 s = make_float4(ep[u].x + acc.x, ep[u].y + acc.y, ep[u].z + acc.z, ep[u].w + acc.w);
-                                if (p.acc_div != 1.0f) {
-                                    s.x = s.x / p.acc_div; s.y = s.y / p.acc_div; s.z = s.z / p.acc_div; s.w = s.w / p.acc_div;
-                                }
-                                *reinterpret_cast<float4 *>(p.acc_out + o) = s;
-                            } else if (EPI == 2) {
-                                float4 a = ep[u];
-                                if (p.add_div != 1.0f) {
-                                    a.x = a.x / p.add_div; a.y = a.y / p.add_div; a.z = a.z / p.add_div; a.w = a.w / p.add_div;
-                                }
-                                *reinterpret_cast<float4 *>(p.Y + o) = make_float4(acc.x + a.x, acc.y + a.y, acc.z + a.z, acc.w + a.w);
-                            } else {
-                                finish_row(p, rr[u], q * 4 + 0, acc.x);
-                                finish_row(p, rr[u], q * 4 + 1, acc.y);
-                                finish_row(p, rr[u], q * 4 + 2, acc.z);
-                                finish_row(p, rr[u], q * 4 + 3, acc.w);
-                            }
-                        }
-                        acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
+            for (int u = 0; u < kChunk; ++u) {
+                acc = fmaf(lane_bcast(my_val, c * kChunk + u), x[u], acc);
+                if (mask & (1u << u)) {
+                    emit(row, acc, ep[u]);
+                    acc = 0.0f;
+                    ++row;
                 }
             }
         }
     }
-    if (n == 0 && t.w >= 0) {  // a row without stored entries: y = 0, epilogue still applies
-        finish_row(p, t.w, q * 4 + 0, 0.0f);
-        finish_row(p, t.w, q * 4 + 1, 0.0f);
-        finish_row(p, t.w, q * 4 + 2, 0.0f);
-        finish_row(p, t.w, q * 4 + 3, 0.0f);
+    if (t.y == 0) {  // a row without stored entries: y = 0, the epilogue still applies
+        float e = 0.0f;
+        if (EPI != 0) e = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(re, lane4, row * 256, 0));
+        emit(row, 0.0f, e);
     }
 }
 
@@ -393,30 +367,28 @@ int launch_spmm(const spex_graph *g, const float *X, float *Y, const float *add_
     p.mask_mode = g->mask_mode; p.keep = g->keep; p.keep_prob = g->keep_prob;
     p.seed_lo = (uint32_t)g->seed; p.seed_hi = (uint32_t)(g->seed >> 32);
 
-    p.task = g->task; p.entry_row = g->entry_row; p.n_tasks = g->n_tasks;
-    const bool masked = g->mask_mode != 0, d64 = d == 64;
-    const int64_t tasks = d64 ? (int64_t)g->n_tasks / 4 : (int64_t)g->n_seg + g->n_rows;  // waves
+    const bool masked = g->mask_mode != 0;
+    // fast path: d == 64, no dropout, chunked table present, and not both epilogues at once
+    const bool fast = d == 64 && !masked && g->task != nullptr && !(acc_out && add_in);
+    const int64_t tasks = fast ? (int64_t)g->n_tasks : (int64_t)g->n_seg + g->n_rows;  // waves
     int64_t blocks = (tasks + kWavesPerBlock - 1) / kWavesPerBlock;
     blocks = (blocks + 7) / 8 * 8;  // multiple of the XCD count so the remap is a bijection
     const dim3 grid((unsigned)blocks), block(kWave * kWavesPerBlock);
     spex_timer *tm = g->timer;
     const bool timed = tm && tm->used < (int32_t)tm->start.size();
     if (timed) SPEX_HIP(hipEventRecord(tm->start[tm->used], stream));
-    if (d64) {
-        const int epi = (acc_out ? 1 : 0) | (add_in ? 2 : 0);
-#define SPEX_LAUNCH_TASKS(M, E) hipLaunchKernelGGL((spmm_q4_kernel<M, E>), grid, block, 0, stream, p)
-        if (masked) {
-            if (epi == 0) SPEX_LAUNCH_TASKS(true, 0);
-            else if (epi == 1) SPEX_LAUNCH_TASKS(true, 1);
-            else if (epi == 2) SPEX_LAUNCH_TASKS(true, 2);
-            else SPEX_LAUNCH_TASKS(true, 3);
-        } else {
-            if (epi == 0) SPEX_LAUNCH_TASKS(false, 0);
-            else if (epi == 1) SPEX_LAUNCH_TASKS(false, 1);
-            else if (epi == 2) SPEX_LAUNCH_TASKS(false, 2);
-            else SPEX_LAUNCH_TASKS(false, 3);
-        }
-#undef SPEX_LAUNCH_TASKS
+    if (fast) {
+        const uint32_t x_bytes = (uint32_t)((int64_t)g->n_cols * 256), e_bytes = (uint32_t)((int64_t)g->n_rows * 256);
+        if (acc_out)
+            hipLaunchKernelGGL((spmm_chunk_kernel<1>), grid, block, 0, stream, X, x_bytes, g->chunk_off, g->chunk_val,
+                               g->chunk_mask, g->task, g->n_tasks, Y, acc_in, e_bytes, acc_div, acc_out, g->partial);
+        else if (add_in)
+            hipLaunchKernelGGL((spmm_chunk_kernel<2>), grid, block, 0, stream, X, x_bytes, g->chunk_off, g->chunk_val,
+                               g->chunk_mask, g->task, g->n_tasks, Y, add_in, e_bytes, add_div, (float *)nullptr, g->partial);
+        else
+            hipLaunchKernelGGL((spmm_chunk_kernel<0>), grid, block, 0, stream, X, x_bytes, g->chunk_off, g->chunk_val,
+                               g->chunk_mask, g->task, g->n_tasks, Y, (const float *)nullptr, 0u, 1.0f, (float *)nullptr,
+                               g->partial);
     } else if (masked) {
         hipLaunchKernelGGL((spmm_rows_kernel<true>), grid, block, 0, stream, p);
     } else {

@@ -96,13 +96,32 @@ def normalised_adjacency_torch(u, i, n_user_rows, n_items):
     return (rowptr.to(torch.int32).cpu().numpy(), cols.to(torch.int32).cpu().numpy(), val.cpu().numpy())
 
 
-def scaled_graph(log2_nodes, avg_degree=26.8, user_frac=0.2, seed=2020, device="cpu"):
-    """A LightGCN adjacency with ~2^log2_nodes nodes and the Epinion2 degree law's mean (26.8 stored entries per
-    row): the HBM-roofline workload of SURVEY.md 8d.  Returns (rowptr, col, val, n_user_rows)."""
-    n = 1 << log2_nodes
-    n_users = max(2, int(n * user_frac))
-    n_items = n - n_users - 1
-    n_edges = int(n * avg_degree / 2)
-    u, i = synthetic_interactions(n_users, n_items, n_edges, seed=seed, device=device)
-    rowptr, col, val = normalised_adjacency_torch(u, i, n_users + 1, n_items)
-    return rowptr, col, val, n_users + 1
+def epinion2_replicated(k, seed=2020, device="cpu", train=None):
+    """"Epinion2 x K" (SURVEY.md 8d): K replicas of the Epinion2 users and items; the K copies of every interaction
+    connect user replica j to item replica pi(j), pi a random permutation drawn per interaction.  Every replica of a
+    user / item keeps exactly the degree of the original, so the graph has Epinion2's degree law (mean 26.8 stored
+    entries per row, median 13, max 1 020) at any size, while its gathers are spread over the whole K-times larger
+    embedding table.  Returns int64 tensors (u, i) and (n_user, m_item)."""
+    if train is None:
+        train = load_epinion2()["train"]
+    tr = torch.as_tensor(np.asarray(train, np.int64), device=device)
+    n_user, m_item = int(tr[:, 0].max()) + 1, int(tr[:, 1].max()) + 1
+    if k == 1:
+        return tr[:, 0].clone(), tr[:, 1].clone(), n_user, m_item
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    E = tr.shape[0]
+    perm = torch.rand(E, k, generator=g, device=device).argsort(dim=1)          # [E, k] item replica per user replica
+    rep = torch.arange(k, device=device)
+    u = (tr[:, 0:1] + rep[None, :] * n_user).reshape(-1)
+    i = (tr[:, 1:2] + perm * m_item).reshape(-1)
+    return u, i, n_user * k, m_item * k
+
+
+def scaled_graph(log2_nodes, seed=2020, device="cpu"):
+    """The HBM-roofline workload: Epinion2 x K with K chosen so that the graph has about 2^log2_nodes nodes.
+    Returns (rowptr, col, val, n_user_rows) as NumPy CSR."""
+    k = max(1, round((1 << log2_nodes) / 15593))
+    u, i, n_user, m_item = epinion2_replicated(k, seed=seed, device=device)
+    rowptr, col, val = normalised_adjacency_torch(u, i, n_user + 1, m_item)
+    return rowptr, col, val, n_user + 1
