@@ -2,6 +2,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "spex_common.h"
@@ -34,7 +35,7 @@ extern "C" int spex_graph_destroy(spex_graph_t *g)
 {
     if (!g) return SPEX_OK;
     void *ptrs[] = {g->rowptr, g->col, g->val, g->edge_id, g->seg_beg, g->seg_end, g->long_row, g->long_seg0, g->partial,
-                    g->task, g->chunk_off, g->chunk_val, g->chunk_mask};
+                    g->task, g->chunk_off, g->chunk_val, g->chunk_mask, g->hub_row, g->hub_seg0};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete g;
@@ -86,16 +87,19 @@ extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, 
     g->n_seg = (int32_t)seg_beg.size();
 
     // Chunked task table (see spex_common.h).  Only when every source-row byte offset fits below kPadOffset.
+    //   task.w: bits 0-1 kind (0 pack / empty row / null, 1 segment combined in the workgroup, 2 segment through global
+    //           scratch), bit 2 workgroup has a barrier, bit 3 leader (first segment of its row), bits 4-7 position of
+    //           the wave in its workgroup (= LDS slot), bits 8-12 number of segments of the row; kind 2: bits 4.. slot.
     std::vector<int4> task;
     std::vector<uint32_t> c_off, c_mask;
     std::vector<float> c_val;
-    const bool chunked = (int64_t)n_cols * 256 <= (int64_t)spex::kPadOffset && (int64_t)n_rows * 256 <= (int64_t)spex::kPadOffset;
+    std::vector<int32_t> hub_row, hub_seg0;
+    const bool chunked = true;
     if (chunked) {
         c_off.reserve((size_t)nnz + (size_t)nnz / 4 + 64);
         c_val.reserve((size_t)nnz + (size_t)nnz / 4 + 64);
-        // emit entries [b, e) as whole chunks; `row_end_is_last`: flag the final entry of every row (packs) or only
-        // the final entry of the range (segments)
-        auto emit_task = [&](int32_t b, int32_t e, int32_t r0, int32_t slot) {
+        // append entries [b, e) as whole chunks; row_ends: flag the final entry of every row (packs of rows r0..)
+        auto add_chunks = [&](int32_t b, int32_t e, int32_t r0, bool row_ends) -> int2 {
             const int32_t first_chunk = (int32_t)c_mask.size();
             int32_t r = r0;
             for (int32_t k = b; k < e; k += spex::kChunk) {
@@ -103,64 +107,117 @@ extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, 
                 for (int32_t u = 0; u < spex::kChunk; ++u) {
                     const int32_t en = k + u;
                     if (en < e) {
-                        c_off.push_back((uint32_t)h_col[en] * 256u);
+                        c_off.push_back((uint32_t)h_col[en]);
                         c_val.push_back(h_val[en]);
-                        bool last;
-                        if (slot >= 0) last = (en + 1 == e);
-                        else {
-                            while (h_rowptr[r + 1] <= en) ++r;  // row of entry en (rows in a pack are consecutive)
-                            last = (en + 1 == h_rowptr[r + 1]);
+                        if (row_ends) {
+                            while (h_rowptr[r + 1] <= en) ++r;  // rows of a pack are consecutive
+                            if (en + 1 == h_rowptr[r + 1]) mask |= 1u << u;
                         }
-                        if (last) mask |= 1u << u;
-                    } else {
-                        c_off.push_back(spex::kPadOffset);
+                    } else {  // padding: value 0 on the task's last real source row (a line already being fetched)
+                        c_off.push_back((uint32_t)h_col[e - 1]);
                         c_val.push_back(0.0f);
                     }
                 }
                 c_mask.push_back(mask);
             }
-            task.push_back(make_int4(first_chunk, (int32_t)c_mask.size() - first_chunk, r0, slot));
+            return make_int2(first_chunk, (int32_t)c_mask.size() - first_chunk);
         };
-        for (size_t s = 0; s < seg_beg.size(); ++s) {
-            // row of the segment: found from the long-row table
-            emit_task(seg_beg[s], seg_end[s], 0, (int32_t)s);
+        std::vector<int4> normal;                       // packs of short rows, empty rows
+        struct Mid { int32_t row, b, e, nseg; };
+        std::vector<Mid> mids;                          // rows of 65..1024 entries
+        std::vector<int4> hubs;                         // 128-entry segments of rows > 1024 entries
+        {
+            int32_t cur_beg = -1, cur_end = -1, cur_r0 = -1, prev_r = -2;
+            auto close = [&]() {
+                if (cur_beg >= 0 && cur_end > cur_beg) {
+                    const int2 c = add_chunks(cur_beg, cur_end, cur_r0, true);
+                    normal.push_back(make_int4(c.x, c.y, cur_r0, 0));
+                }
+                cur_beg = cur_end = cur_r0 = -1;
+            };
+            size_t long_i = 0;
+            for (int32_t r = 0; r < n_rows; ++r) {
+                const int32_t b = h_rowptr[r], e = h_rowptr[r + 1], deg = e - b;
+                while (long_i < long_row.size() && long_row[long_i] < r) ++long_i;
+                if (deg == 0) {  // empty row: zero-fill task; it also ends the run of consecutive rows
+                    close();
+                    normal.push_back(make_int4(0, 0, r, 0));
+                    continue;
+                }
+                if (deg > spex::kWgRowMax) {  // hub: its kLongRow-table segments go through global scratch
+                    close();
+                    hub_row.push_back(r);
+                    hub_seg0.push_back(long_seg0[long_i]);      // [begin, end) in the kLongRow segment table
+                    hub_seg0.push_back(long_seg0[long_i + 1]);
+                    for (int32_t sgi = long_seg0[long_i]; sgi < long_seg0[long_i + 1]; ++sgi) {
+                        const int2 c = add_chunks(seg_beg[sgi], seg_end[sgi], r, false);
+                        hubs.push_back(make_int4(c.x, c.y, r, 2 | (sgi << 4)));
+                    }
+                    continue;
+                }
+                if (deg > spex::kTaskEntries) {
+                    close();
+                    mids.push_back({r, b, e, (deg + spex::kTaskEntries - 1) / spex::kTaskEntries});
+                    continue;
+                }
+                if (cur_beg >= 0 && prev_r == r - 1 && cur_end == b && e - cur_beg <= spex::kTaskEntries) {
+                    cur_end = e;
+                } else {
+                    close();
+                    cur_beg = b;
+                    cur_end = e;
+                    cur_r0 = r;
+                }
+                prev_r = r;
+            }
+            close();
         }
-        int32_t cur_beg = -1, cur_end = -1, cur_r0 = -1, prev_r = -2;
-        auto close = [&]() {
-            if (cur_beg >= 0 && cur_end > cur_beg) emit_task(cur_beg, cur_end, cur_r0, -1);
-            cur_beg = cur_end = cur_r0 = -1;
+        // assemble 16-wave workgroups: hub segments, then rows combined in-workgroup (heaviest first, first fit, the
+        // rest of such a workgroup filled with ordinary tasks), then the ordinary tasks
+        const int W = spex::kWgWaves;
+        size_t next_normal = 0;
+        auto null_task = make_int4(0, 0, -1, 0);
+        auto fill_wg = [&](bool barrier) {  // complete the current workgroup with ordinary / null tasks
+            while (task.size() % W) {
+                int4 t = next_normal < normal.size() ? normal[next_normal++] : null_task;
+                if (barrier) t.w |= 4;
+                task.push_back(t);
+            }
         };
-        for (int32_t r = 0; r < n_rows; ++r) {
-            const int32_t b = h_rowptr[r], e = h_rowptr[r + 1];
-            if (e == b) {  // empty row: zero-fill task; it also breaks the run of consecutive rows
-                close();
-                task.push_back(make_int4(0, 0, r, -1));
-                continue;
+        for (const int4 &h : hubs) task.push_back(h);
+        fill_wg(false);
+        {
+            // bucket the rows by segment count; fill each workgroup greedily with the largest row that still fits
+            std::vector<std::vector<int32_t>> by_nseg(W + 1);
+            for (size_t m = 0; m < mids.size(); ++m) by_nseg[mids[m].nseg].push_back((int32_t)m);
+            std::vector<size_t> head(W + 1, 0);
+            size_t n_placed = 0;
+            while (n_placed < mids.size()) {
+                int used = 0;
+                for (;;) {
+                    int s = W - used;
+                    while (s >= 2 && head[s] >= by_nseg[s].size()) --s;
+                    if (s < 2) break;
+                    const Mid &md = mids[by_nseg[s][head[s]++]];
+                    for (int32_t sgi = 0; sgi < md.nseg; ++sgi) {
+                        const int32_t sb = md.b + sgi * spex::kTaskEntries;
+                        const int32_t se = sb + spex::kTaskEntries < md.e ? sb + spex::kTaskEntries : md.e;
+                        const int2 c = add_chunks(sb, se, md.row, false);
+                        task.push_back(make_int4(c.x, c.y, md.row,
+                                                 1 | 4 | (sgi == 0 ? 8 : 0) | ((used + sgi) << 4) | (md.nseg << 8)));
+                    }
+                    used += md.nseg;
+                    ++n_placed;
+                }
+                fill_wg(true);
             }
-            if (e - b > spex::kLongRow) {
-                close();
-                continue;
-            }
-            if (cur_beg >= 0 && prev_r == r - 1 && cur_end == b && e - cur_beg <= spex::kTaskEntries) {
-                cur_end = e;
-            } else {
-                close();
-                cur_beg = b;
-                cur_end = e;
-                cur_r0 = r;
-            }
-            prev_r = r;
         }
-        close();
-        // heaviest first, stable within a weight class (keeps neighbouring tasks on neighbouring chunks)
-        const int n_buckets = spex::kSegLen / spex::kChunk + 1;
-        std::vector<std::vector<int4>> bucket(n_buckets);
-        for (const int4 &t : task) bucket[t.y].push_back(t);
-        task.clear();
-        for (int k = n_buckets - 1; k >= 0; --k) task.insert(task.end(), bucket[k].begin(), bucket[k].end());
+        while (next_normal < normal.size()) task.push_back(normal[next_normal++]);
+        fill_wg(false);
     }
     g->n_tasks = (int32_t)task.size();
     g->n_chunks = (int64_t)c_mask.size();
+    g->n_hub = (int32_t)hub_row.size();
 
     int rc = SPEX_OK;
     if ((rc = upload(&g->rowptr, h_rowptr, (size_t)n_rows + 1)) || (rc = upload(&g->col, h_col, (size_t)nnz)) ||
@@ -173,7 +230,9 @@ extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, 
         (rc = upload(&g->task, task.data(), task.size())) ||
         (rc = upload(&g->chunk_off, c_off.data(), c_off.size())) ||
         (rc = upload(&g->chunk_val, c_val.data(), c_val.size())) ||
-        (rc = upload(&g->chunk_mask, c_mask.data(), c_mask.size()))) {
+        (rc = upload(&g->chunk_mask, c_mask.data(), c_mask.size())) ||
+        (rc = upload(&g->hub_row, hub_row.data(), hub_row.size())) ||
+        (rc = upload(&g->hub_seg0, hub_seg0.data(), hub_seg0.size()))) {
         spex_graph_destroy(g);
         return rc;
     }

@@ -32,7 +32,9 @@ constexpr int kWave = 64;          // CDNA wavefront
 constexpr int kWavesPerBlock = 4;  // 256-thread workgroups
 constexpr int kLongRow = 128;      // rows with more stored entries are cut into segments
 constexpr int kSegLen = 128;       // entries per long-row segment
-constexpr int kTaskEntries = 64;   // entry budget of a multi-row wave task
+constexpr int kTaskEntries = 64;   // entries per wave task of the d == 64 kernel (4 chunks: 4 memory round trips)
+constexpr int kWgWaves = 16;       // the d == 64 kernel runs 1024-thread workgroups = 16 wave tasks
+constexpr int kWgRowMax = kWgWaves * kTaskEntries;  // longest row whose segments are combined inside one workgroup
 constexpr int kChunk = 16;         // entries per chunk (one s_load_dwordx16 of offsets, one of values)
 constexpr uint32_t kPadOffset = 0xFFFFFF00u;  // out-of-range source offset of a padding entry
 
@@ -60,18 +62,22 @@ struct spex_graph {
     float *partial = nullptr;     // [n_seg * d_cap] scratch, grown on demand
     int64_t partial_cap = 0;      // floats
     // Chunked copy of the matrix for the d == 64 kernel (built when n_cols * 256 B fits a 32-bit buffer offset).
-    // A chunk is 16 stored entries: byte offsets of their source rows (col * 256) and their values, both read by the
-    // kernel with wave-uniform (scalar) loads, plus a 16-bit mask marking entries that end an output row.  A wave
-    // TASK is a run of chunks: whole consecutive short rows (<= 64 entries in total), one row of 65..128 entries, or
-    // one 128-entry segment of a long row.  Tasks are padded to whole chunks with entries whose offset is out of the
-    // buffer's range (the hardware bounds check returns 0 for them without touching memory).
-    //   task.x = first chunk, .y = number of chunks (0: just zero-fill row .z), .z = first row, .w = partial slot or -1
+    // A chunk is 16 stored entries: byte offsets of their source rows (col * 256), their values, and a 16-bit mask
+    // marking entries that end an output row.  A wave TASK is a run of <= 4 chunks (64 entries): whole consecutive
+    // short rows, or one 64-entry segment of a row with 65..1024 entries — all segments of such a row sit in ONE
+    // 16-wave workgroup and are summed through LDS in segment order — or (rows > 1024 entries only) a 128-entry
+    // segment whose partial row goes through global scratch and the fix-up launch.  Tasks are padded to whole chunks
+    // with entries whose offset is out of the buffer's range (the bounds check returns 0, no memory access).
+    //   task.x = first chunk, .y = number of chunks, .z = (first) row or -1, .w = kind | flags (see graph.hip)
     int32_t n_tasks = 0;
     int4 *task = nullptr;          // [n_tasks], heaviest first
     int64_t n_chunks = 0;
     uint32_t *chunk_off = nullptr; // [n_chunks * 16]
     float *chunk_val = nullptr;    // [n_chunks * 16]
     uint32_t *chunk_mask = nullptr; // [n_chunks]
+    int32_t n_hub = 0;              // rows longer than kWgRowMax (global-scratch path of the d == 64 kernel)
+    int32_t *hub_row = nullptr;     // [n_hub]
+    int32_t *hub_seg0 = nullptr;    // [2 * n_hub] (first, one-past-last) segment of each hub in the kLongRow segment table
     // edge dropout
     int mask_mode = 0;
     const uint8_t *keep = nullptr;

@@ -228,30 +228,26 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_rows_kernel(const 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
 template <int EPI>  // 0: Y = y;  1: Y = y (optional), acc_out = (acc_in + y) / acc_div;  2: Y = y + add_in / add_div
-__global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_chunk_kernel(
+__global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
     const float *__restrict__ X, uint32_t x_bytes, const uint32_t *__restrict__ chunk_off,
     const float *__restrict__ chunk_val, const uint32_t *__restrict__ chunk_mask, const int4 *__restrict__ task,
     int n_tasks, float *__restrict__ Y, const float *__restrict__ epi_in, uint32_t epi_bytes, float epi_div,
     float *__restrict__ acc_out, float *__restrict__ partial)
 {
-    const int lane4 = (threadIdx.x & (kWave - 1)) * 4;
+    __shared__ float s_part[kWgWaves][kWave];  // segment sums of the rows this workgroup combines
+    const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int tid = xcd_contiguous_block(blockIdx.x, gridDim.x) * kWavesPerBlock + wave;
-    if (tid >= n_tasks) return;
+    const int tid = xcd_contiguous_block(blockIdx.x, gridDim.x) * kWgWaves + wave;
+    if (tid >= n_tasks) return;  // whole workgroups only (n_tasks is a multiple of kWgWaves)
     const int4 t = task[tid];
-    const rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0, (int)x_bytes, 0x00020000);
-    const rsrc_t re = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(EPI ? epi_in : X), 0,
-                                                        (int)(EPI ? epi_bytes : 0u), 0x00020000);
-    const bool is_partial = t.w >= 0;
+    const int kind = t.w & 3;
+    const float *__restrict__ Xl = X + lane;
+    const float *__restrict__ El = (EPI ? epi_in : X) + lane;
     int row = t.z;
     float acc = 0.0f;
 
     auto emit = [&](int r, float y, float e) {
-        if (is_partial) {
-            partial[(size_t)t.w * 64 + (lane4 >> 2)] = y;
-            return;
-        }
-        const size_t o = (size_t)r * 64 + (lane4 >> 2);
+        const size_t o = (size_t)r * 64 + lane;
         if (EPI == 0) {
             Y[o] = y;
         } else if (EPI == 1) {
@@ -267,11 +263,10 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_chunk_kernel(
 
     // Metadata of up to 4 chunks (64 entries) per vector load — lane k holds entry k — handed to the scalar side with
     // v_readlane.  (Feeding it through s_load instead starves on scalar-cache misses once the matrix streams from
-    // HBM: 29 ms vs 13 ms per launch on the 2^23-node graph.)
+    // HBM: 29 ms vs 17 ms per launch on a 2^23-node graph.)
     for (int sc = 0; sc < t.y; sc += 4) {
         const int nc = (t.y - sc < 4) ? t.y - sc : 4;  // chunks in this super-chunk (wave-uniform)
-        const int lane = lane4 >> 2;
-        uint32_t my_off = kPadOffset, my_mask = 0u;
+        uint32_t my_off = 0u, my_mask = 0u;
         float my_val = 0.0f;
         if (lane < nc * kChunk) {
             const size_t e = (size_t)(t.x + sc) * kChunk + lane;
@@ -284,15 +279,14 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_chunk_kernel(
             float x[kChunk], ep[kChunk];
 #pragma unroll
             for (int u = 0; u < kChunk; ++u)
-                x[u] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                    rx, lane4, __builtin_amdgcn_readlane((int)my_off, c * kChunk + u), 0));
-            if (EPI != 0 && !is_partial && mask != 0u) {
+                x[u] = Xl[(size_t)(uint32_t)__builtin_amdgcn_readlane((int)my_off, c * kChunk + u) * 64];
+            if (EPI != 0 && mask != 0u) {
                 int r = row;
 #pragma unroll
                 for (int u = 0; u < kChunk; ++u) {
                     ep[u] = 0.0f;
                     if (mask & (1u << u)) {
-                        ep[u] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(re, lane4, r * 256, 0));
+                        ep[u] = El[(size_t)r * 64];
                         ++r;
                     }
                 }
@@ -303,7 +297,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_chunk_kernel(
 #pragma unroll
             for (int u = 0; u < kChunk; ++u) {
                 acc = fmaf(lane_bcast(my_val, c * kChunk + u), x[u], acc);
-                if (mask & (1u << u)) {
+                if (mask & (1u << u)) {  // only packs of whole rows carry mask bits
                     emit(row, acc, ep[u]);
                     acc = 0.0f;
                     ++row;
@@ -311,21 +305,39 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_chunk_kernel(
             }
         }
     }
-    if (t.y == 0) {  // a row without stored entries: y = 0, the epilogue still applies
+    if (kind == 0 && t.y == 0 && t.z >= 0) {  // a row without stored entries: y = 0, the epilogue still applies
         float e = 0.0f;
-        if (EPI != 0) e = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(re, lane4, row * 256, 0));
-        emit(row, 0.0f, e);
+        if (EPI != 0) e = El[(size_t)t.z * 64];
+        emit(t.z, 0.0f, e);
+    }
+    if (kind == 2) partial[(size_t)(t.w >> 4) * 64 + lane] = acc;  // hub segment: summed by the fix-up launch
+    if (t.w & 4) {  // this workgroup combines the segments of rows with 65..1024 entries through LDS
+        const bool leader = kind == 1 && (t.w & 8);
+        const int slot = (t.w >> 4) & 15, nseg = (t.w >> 8) & 31;
+        float e = 0.0f;
+        if (leader && EPI != 0) e = El[(size_t)t.z * 64];
+        if (kind == 1 && !leader) s_part[slot][lane] = acc;
+        __syncthreads();
+        if (leader) {
+            float y = acc;
+            for (int sgi = 1; sgi < nseg; ++sgi) y = y + s_part[slot + sgi][lane];  // segment order: deterministic
+            emit(t.z, y, e);
+        }
     }
 }
 
 // One wave per long row: add its segment partials in order, then the shared epilogue.
-__global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_long_fixup_kernel(const SpmmParams p)
+__global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_long_fixup_kernel(const SpmmParams p,
+                                                                               const int32_t *__restrict__ rows,
+                                                                               const int32_t *__restrict__ seg_lo,
+                                                                               const int32_t *__restrict__ seg_hi,
+                                                                               int seg_stride, int n_list)
 {
     const int lane = threadIdx.x & (kWave - 1);
     const int i = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    if (i >= p.n_long) return;
-    const int r = p.long_row[i];
-    const int s0 = p.long_seg0[i], s1 = p.long_seg0[i + 1];
+    if (i >= n_list) return;
+    const int r = rows[i];
+    const int s0 = seg_lo[(size_t)i * seg_stride], s1 = seg_hi[(size_t)i * seg_stride];
     for (int c = lane; c < p.d; c += kWave) {
         float y = 0.0f;
         int s = s0;
@@ -370,10 +382,11 @@ int launch_spmm(const spex_graph *g, const float *X, float *Y, const float *add_
     const bool masked = g->mask_mode != 0;
     // fast path: d == 64, no dropout, chunked table present, and not both epilogues at once
     const bool fast = d == 64 && !masked && g->task != nullptr && !(acc_out && add_in);
+    const int per_block = fast ? kWgWaves : kWavesPerBlock;
     const int64_t tasks = fast ? (int64_t)g->n_tasks : (int64_t)g->n_seg + g->n_rows;  // waves
-    int64_t blocks = (tasks + kWavesPerBlock - 1) / kWavesPerBlock;
+    int64_t blocks = (tasks + per_block - 1) / per_block;
     blocks = (blocks + 7) / 8 * 8;  // multiple of the XCD count so the remap is a bijection
-    const dim3 grid((unsigned)blocks), block(kWave * kWavesPerBlock);
+    const dim3 grid((unsigned)blocks), block(kWave * per_block), block4(kWave * kWavesPerBlock);
     spex_timer *tm = g->timer;
     const bool timed = tm && tm->used < (int32_t)tm->start.size();
     if (timed) SPEX_HIP(hipEventRecord(tm->start[tm->used], stream));
@@ -398,9 +411,16 @@ int launch_spmm(const spex_graph *g, const float *X, float *Y, const float *add_
         SPEX_HIP(hipEventRecord(tm->stop[tm->used], stream));
         tm->used++;
     }
-    if (g->n_long > 0) {
+    if (fast) {
+        if (g->n_hub > 0) {  // only rows longer than kWgRowMax go through global scratch on the fast path
+            const dim3 fgrid((unsigned)((g->n_hub + kWavesPerBlock - 1) / kWavesPerBlock));
+            hipLaunchKernelGGL(spmm_long_fixup_kernel, fgrid, block4, 0, stream, p, g->hub_row, g->hub_seg0, g->hub_seg0 + 1, 2,
+                               g->n_hub);
+        }
+    } else if (g->n_long > 0) {
         const dim3 fgrid((unsigned)((g->n_long + kWavesPerBlock - 1) / kWavesPerBlock));
-        hipLaunchKernelGGL(spmm_long_fixup_kernel, fgrid, block, 0, stream, p);
+        hipLaunchKernelGGL(spmm_long_fixup_kernel, fgrid, block4, 0, stream, p, g->long_row, g->long_seg0, g->long_seg0 + 1, 1,
+                           g->n_long);
     }
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;

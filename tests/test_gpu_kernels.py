@@ -2,8 +2,9 @@
 oracle on the same seeded inputs and against the golden vectors minted from the reference.
 
 Tolerances: the north star asks per-layer embeddings within 1e-5 relative in fp32; the SpMM's fmaf chain is the
-oracle's, so rows handled by one wave are required to match BIT-FOR-BIT, and only rows cut into segments (> 128
-entries) may differ by the re-association of their partial sums (<= 1e-6 relative here).
+oracle's, so rows handled by one wave are required to match BIT-FOR-BIT, and only rows cut into segments (> 64
+entries on the d == 64 kernel, > 128 on the generic one) may differ by the re-association of their partial sums
+(<= 1e-6 relative here).
 """
 import numpy as np
 import pytest
@@ -61,7 +62,7 @@ def test_spmm_matches_oracle_random_graph(G, oracle, d):
     assert g.n_long_rows == 2 and g.n_segments == 4 + 2
     Y = g.spmm(t(X)).cpu().numpy()
     ref = oracle.spmm(rowptr, col, val, X)
-    short = np.diff(rowptr) <= 128
+    short = np.diff(rowptr) <= (64 if d == 64 else 128)            # rows owned by a single wave
     assert np.array_equal(Y[short], ref[short])                    # bit-exact fmaf chain
     assert rel_err(Y[~short], ref[~short]) <= 1e-6
     assert np.all(Y[deg == 0] == 0)
@@ -174,7 +175,7 @@ def test_g2_propagation_epinion2_vs_reference(G, golden, epinion2, oracle):
     assert rel_err(out[rows], g["light_out_rows"]) <= 1e-5
     # and against the oracle on every row: bit-exact where one wave owns the row
     ref, ref_layers = oracle.propagate_mean(*csr, E0, 3, n_threads=8, return_layers=True)
-    short = np.diff(csr[0]) <= 128
+    short = np.diff(csr[0]) <= 64
     assert np.array_equal(L[0][short], ref_layers[0][short])
     assert rel_err(out, ref) <= 1e-6
 

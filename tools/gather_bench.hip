@@ -145,7 +145,9 @@ int main(int argc, char **argv)
 {
     const int per_wave = 64;
     struct Cfg { size_t rows; size_t waves; const char *name; };
-    Cfg cfgs[] = {{15593, 6540 * 4, "4 MB table (Epinion2-sized, cache-resident), 1.67M gathers"},
+    Cfg cfgs[] = {{15593, 6540, "4 MB table (Epinion2-sized, cache-resident), 418k gathers = one Epinion2 layer"},
+                  {15593, 6540 * 4, "4 MB table (Epinion2-sized, cache-resident), 1.67M gathers"},
+                  {15593, 6540 * 16, "4 MB table (Epinion2-sized, cache-resident), 6.7M gathers"},
                   {1u << 23, 1u << 20, "2 GB table (HBM-resident), 67M gathers"}};
     for (const Cfg &c : cfgs) {
         const size_t n_idx = c.waves * per_wave;
