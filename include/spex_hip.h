@@ -166,11 +166,12 @@ int spex_expert_gate_f32(const float *raw, const float *prop, const float *att_e
 /* ------------------------------------------------------------------------------------------------ profiling hook
  * Not part of any reference interface: lets a caller time the dominant kernel itself, in place, on the stream it is
  * launched on (bench.py's roofline figure).  While a timer is attached to a graph, every launch of the graph's main
- * SpMM kernel (not the long-row fix-up) is bracketed by a hipEvent pair until `capacity` pairs are used.
+ * SpMM kernel (not the long-row fix-up) — or every n-th such launch — is bracketed by a hipEvent pair until
+ * `capacity` pairs are used.
  * spex_timer_read synchronises on the recorded events and returns their elapsed times in milliseconds.
  */
 typedef struct spex_timer spex_timer_t;
-int spex_timer_create(int32_t capacity, spex_timer_t **out);
+int spex_timer_create(int32_t capacity, int32_t every /* bracket every n-th launch */, spex_timer_t **out);
 int spex_timer_destroy(spex_timer_t *t);
 int spex_timer_attach(spex_graph_t *g, spex_timer_t *t /* NULL detaches */);
 int spex_timer_read(spex_timer_t *t, float *h_ms, int32_t max_count, int32_t *count, int reset);

@@ -277,10 +277,12 @@ extern "C" int spex_graph_set_edge_mask(spex_graph_t *g, int mode, const uint8_t
 }
 
 // ------------------------------------------------------------------------------------------------ profiling hook
-extern "C" int spex_timer_create(int32_t capacity, spex_timer_t **out)
+extern "C" int spex_timer_create(int32_t capacity, int32_t every, spex_timer_t **out)
 {
     SPEX_CHECK_ARG(out && capacity > 0 && capacity <= (1 << 20), "spex_timer_create: bad capacity %d", capacity);
+    SPEX_CHECK_ARG(every >= 1, "spex_timer_create: every = %d", every);
     spex_timer *t = new spex_timer();
+    t->every = every;
     t->start.resize(capacity);
     t->stop.resize(capacity);
     for (int32_t i = 0; i < capacity; ++i) {
@@ -318,6 +320,9 @@ extern "C" int spex_timer_read(spex_timer_t *t, float *h_ms, int32_t max_count, 
         SPEX_HIP(hipEventElapsedTime(&h_ms[i], t->start[i], t->stop[i]));
     }
     *count = n;
-    if (reset) t->used = 0;
+    if (reset) {
+        t->used = 0;
+        t->seen = 0;
+    }
     return SPEX_OK;
 }

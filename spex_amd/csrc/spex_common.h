@@ -43,6 +43,8 @@ constexpr uint32_t kPadOffset = 0xFFFFFF00u;  // out-of-range source offset of a
 struct spex_timer {
     std::vector<hipEvent_t> start, stop;
     int32_t used = 0;
+    int32_t every = 1;   // bracket every `every`-th launch
+    int64_t seen = 0;    // launches seen since the last reset
 };
 
 // The opaque handle.  All pointers are device memory owned by the handle.

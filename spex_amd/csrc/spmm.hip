@@ -388,7 +388,7 @@ int launch_spmm(const spex_graph *g, const float *X, float *Y, const float *add_
     blocks = (blocks + 7) / 8 * 8;  // multiple of the XCD count so the remap is a bijection
     const dim3 grid((unsigned)blocks), block(kWave * per_block), block4(kWave * kWavesPerBlock);
     spex_timer *tm = g->timer;
-    const bool timed = tm && tm->used < (int32_t)tm->start.size();
+    const bool timed = tm && tm->used < (int32_t)tm->start.size() && (tm->seen++ % tm->every) == 0;
     if (timed) SPEX_HIP(hipEventRecord(tm->start[tm->used], stream));
     if (fast) {
         const uint32_t x_bytes = (uint32_t)((int64_t)g->n_cols * 256), e_bytes = (uint32_t)((int64_t)g->n_rows * 256);

@@ -141,10 +141,10 @@ class SpexGraph:
             pass
 
     # -- profiling hook: hipEvent pairs around the main SpMM kernel, on the stream it is launched on
-    def attach_timer(self, capacity):
+    def attach_timer(self, capacity, every=1):
         self.detach_timer()
         t = ctypes.c_void_p()
-        _lib.call("spex_timer_create", int(capacity), ctypes.byref(t))
+        _lib.call("spex_timer_create", int(capacity), int(every), ctypes.byref(t))
         _lib.call("spex_timer_attach", self._h, t)
         self._timer, self._timer_cap = t, int(capacity)
 

@@ -45,13 +45,15 @@ def score_bce(users_tab, items_tab, u_idx, i_idx, labels=None, grad_users=None, 
     return gamma, loss_sum
 
 
-def bpr_sgd_step(U_read, I_read, U_w, I_w, u, i_pos, i_neg, lr, reg=0.0):
-    """Fused gather + dot + sigmoid + SGD over triples (north-star extension).  Returns the loss *sum* tensor."""
+def bpr_sgd_step(U_read, I_read, U_w, I_w, u, i_pos, i_neg, lr, reg=0.0, loss_sum=None):
+    """Fused gather + dot + sigmoid + SGD over triples (north-star extension).  Returns the loss *sum* tensor
+    (accumulated into `loss_sum` when the caller provides — and zeroes — the buffer)."""
     for t, n in ((U_read, "U_read"), (I_read, "I_read"), (U_w, "U_w"), (I_w, "I_w")):
         _need(t, n)
     dev = U_read.device
     u, i_pos, i_neg = _idx(u, dev), _idx(i_pos, dev), _idx(i_neg, dev)
-    loss_sum = torch.zeros(1, dtype=torch.float32, device=dev)
+    if loss_sum is None:
+        loss_sum = torch.zeros(1, dtype=torch.float32, device=dev)
     _lib.call("spex_bpr_sgd_step_f32", _ptr(U_read), _ptr(I_read), _ptr(U_w), _ptr(I_w), U_read.shape[0], I_read.shape[0],
               _ptr(u), _ptr(i_pos), _ptr(i_neg), u.numel(), U_read.shape[1], float(lr), float(reg), _ptr(loss_sum),
               _stream())

@@ -29,6 +29,7 @@ class LightGCNStepper:
         self.ws_bwd = z(3, n, d)
         self.grad_E0 = z(n, d)
         self.m, self.v = z(n, d), z(n, d)
+        self.loss_acc = z(1)          # running loss sum of the fused BPR steps (read it when you need it)
         self.t = 0
 
     # -- pieces
@@ -49,12 +50,13 @@ class LightGCNStepper:
         return loss_sum / B
 
     def step_bpr_sgd(self, users, pos, neg, lr=None, reg=0.0):
-        """Propagation + fused BPR-SGD kernel (scores from the propagated table, update on E0).  Loss mean."""
+        """Propagation + fused BPR-SGD kernel (scores from the propagated table, update on E0).  Returns the running
+        loss-sum buffer `loss_acc` (sum over every triple since it was last zeroed; no per-step allocation or sync)."""
         self.propagate()
         lo = self.light_out
-        loss_sum = ops.bpr_sgd_step(lo[:self.n_u], lo[self.n_u:], self.E0[:self.n_u], self.E0[self.n_u:], users, pos,
-                                    neg, self.lr if lr is None else lr, reg)
-        return loss_sum / users.numel()
+        ops.bpr_sgd_step(lo[:self.n_u], lo[self.n_u:], self.E0[:self.n_u], self.E0[self.n_u:], users, pos, neg,
+                         self.lr if lr is None else lr, reg, loss_sum=self.loss_acc)
+        return self.loss_acc
 
     def step_bpr_exact(self, users, pos, neg):
         """BPR loss differentiated through the propagation, Adam update (upstream LightGCN training semantics)."""
