@@ -67,11 +67,19 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal hook for a one-GPU box: SPEX_BENCH_BACKEND=gloo SPEX_BENCH_SHARE_GPU=1 runs the N-rank code path with
+    # every rank on cuda:0 (collectives through gloo).  The driver's real runs use one rank per GPU over RCCL.
+    share = os.environ.get("SPEX_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("SPEX_BENCH_BACKEND", "nccl")
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from spex_amd import ops
     from spex_amd.datasets import epinion2_replicated, xavier_uniform_np
@@ -103,18 +111,26 @@ def main():
                                 lambda r, c, v, n_cols: SpexGraph(r, c, v, n_cols=n_cols, device=dev), dev)
         graph = P.graph
         E0_local = torch.from_numpy(E0_host[P.r0:P.r1].copy()).to(dev)
-        scratch = torch.zeros(P.part.n_padded, D, device=dev)
         pu, pp = P.padded_index(tu, tp)
         _, pn = P.padded_index(tu, tn)
+        pos_all = torch.cat([pu, pp, pn])
+        fetched = torch.zeros(3 * T_TRIPLES, D, device=dev)
+        upd = torch.zeros(3 * T_TRIPLES, D, device=dev)
+        ar = torch.arange(T_TRIPLES, device=dev)
+        cu, cp, cn = ar, ar + T_TRIPLES, ar + 2 * T_TRIPLES        # compact ids into `fetched`
+        loss_acc = torch.zeros(1, device=dev)
+        plan = P.plan_rows(pos_all)
         local_nnz, local_rows = graph.nnz, graph.n_rows
 
         def step():
             P.propagate(E0_local)
-            full = P.gather_output()
-            scratch.zero_()   # owner-computes: every rank scores the replicated batch, keeps the rows it owns
-            loss = ops.bpr_sgd_step(full, full, scratch, scratch, pu, pp, pn, lr, 0.0)
-            E0_local.add_(P.own_slice(scratch))
-            return loss
+            # owner-computes: the (replicated) batch's rows are exchanged, every rank scores the batch and applies
+            # the updates of the rows it owns — no gradient exchange
+            rows = P.fetch_rows(plan, fetched)
+            upd.zero_()
+            ops.bpr_sgd_step(rows, rows, upd, upd, cu, cp, cn, lr, 0.0, loss_sum=loss_acc)
+            E0_local.index_add_(0, plan[1], upd.index_select(0, plan[0]))
+            return loss_acc
 
     def barrier():
         if world > 1:
@@ -169,7 +185,7 @@ def main():
         "extra": {"bpr_triples_per_s_in_step": T_TRIPLES * a.steps / dt},
     }
     traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(traffic_file):
+    if world == 1 and os.path.exists(traffic_file):
         try:
             tr = json.load(open(traffic_file))
             out["roofline"]["traffic"] = tr.get("epinion2_spmm_bytes_per_launch")

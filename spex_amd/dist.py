@@ -136,6 +136,24 @@ class PartitionedLightGCN:
         """Full (padded) propagated table on every rank, for scoring."""
         return self.all_gather_rows(self.light_out, out=self.out_gathered)
 
+    def plan_rows(self, padded_pos):
+        """Which of the given padded positions this rank owns: (indices into padded_pos, local row indices).  Compute
+        once per batch (it sizes tensors from data, i.e. synchronises)."""
+        owner = torch.div(padded_pos, self.part.max_rows, rounding_mode="floor")
+        own_idx = torch.nonzero(owner == self.rank).reshape(-1)
+        return own_idx, padded_pos[own_idx] - self.rank * self.part.max_rows
+
+    def fetch_rows(self, plan, out):
+        """Rows of the propagated table at a batch's positions, on every rank: each rank writes the rows it owns into
+        the zeroed buffer and an all-reduce adds the contributions up — a few MB per batch instead of an all-gather of
+        the whole table."""
+        own_idx, local = plan
+        out.zero_()
+        out.index_copy_(0, own_idx, self.light_out.index_select(0, local))
+        if self.world > 1:
+            dist.all_reduce(out, group=self.group)
+        return out
+
     def padded_index(self, users, items):
         """Batch indices (user ids, item ids) -> rows of the padded gathered table."""
         return self.part.to_padded_torch(users), self.part.to_padded_torch(items + self.n_user_rows)

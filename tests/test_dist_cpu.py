@@ -59,8 +59,11 @@ def _worker(rank, world, port, out_dir):
     grad = P.propagate_bwd(gl).clone()
     u = torch.from_numpy(g["batch_users"][0]); i = torch.from_numpy(g["batch_items"][0])
     pu, pi = P.padded_index(u, i)
+    P.propagate(E0)                                   # fetch_rows reads the rank's current light_out
+    pos = torch.cat([pu, pi])
+    fetched = P.fetch_rows(P.plan_rows(pos), torch.empty(len(pos), 64))
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), lo=lo.numpy(), grad=grad.numpy(), r0=P.r0, r1=P.r1,
-             full_u=full[pu].numpy(), full_i=full[pi].numpy(), own=P.own_slice(full).numpy())
+             full_u=full[pu].numpy(), full_i=full[pi].numpy(), own=P.own_slice(full).numpy(), fetched=fetched.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -86,6 +89,7 @@ def test_partitioned_schedule_matches_single_device(tmp_path, oracle, golden, wo
         assert np.array_equal(d["full_u"], ref[g["batch_users"][0]])
         assert np.array_equal(d["full_i"], ref[n_u + g["batch_items"][0]])
         assert np.array_equal(d["own"], ref[int(d["r0"]):int(d["r1"])])
+        assert np.array_equal(d["fetched"], np.concatenate([ref[g["batch_users"][0]], ref[n_u + g["batch_items"][0]]]))
     # partitioning does not change any row's summation order: bit-identical to the single-device result
     assert np.array_equal(got_lo, ref) and np.array_equal(got_lo, g["light_out"])
     assert np.array_equal(got_grad, G)

@@ -195,3 +195,83 @@ def test_unmodified_style_driver_runs_through_the_launcher(data_root, tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("Rec:")]
     assert len(lines) >= 2 and "recall=" in lines[-1]
+
+
+def test_expert_gate_model_matches_reference_scores(data_root, golden):
+    """model_expert_s rec branch (flag=1) with the reference's gate weights injected: G8."""
+    import lg_parser
+    import utility1.dataloader as dataloader
+    import utility1.model_expert_s as mex
+    from utility1.batch_test import rec_test
+    g = golden("lightgcn_tiny")
+    args = lg_parser.parse_args_r(["--dataset", "tiny", "--data_path", data_root])
+    dataset = dataloader.Loader(args)
+    net = mex.LightGCN(args, dataset).to(DEV)
+    with torch.no_grad():
+        E0 = torch.from_numpy(g["E0"]).to(DEV)
+        net.embedding_user.weight.copy_(E0[:51]); net.embedding_item.weight.copy_(E0[51:])
+        net.att_exp1.copy_(torch.from_numpy(g["g8_att_exp1"])); net.att_exp2.copy_(torch.from_numpy(g["g8_att_exp2"]))
+    net.eval()
+    u, i = torch.from_numpy(g["batch_users"][0]), torch.from_numpy(g["batch_items"][0])
+    with torch.no_grad():
+        gamma = net(u, i, None, None, None, flag=1)                       # fused gate kernel
+    assert rel_err(gamma.cpu().numpy(), g["g8_gamma"]) <= 1e-5
+    net.train()
+    gamma_t = net(u, i, None, None, None, flag=1)                         # autograd (torch-op) gate agrees
+    assert rel_err(gamma_t.detach().cpu().numpy(), g["g8_gamma"]) <= 1e-5
+    loss = net(u, i, torch.from_numpy(g["batch_labels"][0]), None, None, flag=0)
+    loss.backward()
+    assert net.att_exp1.grad.abs().sum() > 0 and net.embedding_user.weight.grad.abs().sum() > 0
+    net.eval()
+    with torch.no_grad():
+        ret = rec_test(net, dataset.testRatings, dataset.testNegatives)  # dual-task eval entry (batch_test.py:43-56)
+    assert 0.0 <= ret["recall"][0] <= 1.0
+    with pytest.raises(NotImplementedError):
+        net(u, i, None, [0], object(), flag=2)
+
+
+def test_ngcf_model_matches_reference(golden, epinion2):
+    """spex_amd.ngcf.NGCF with the reference's weights: forward (fused inference path and autograd path), loss and
+    gradients vs G7."""
+    import argparse
+    import scipy.sparse as sp
+    from spex_amd.graph import ngcf_norm_adj
+    from spex_amd.ngcf import NGCF
+    from spex_amd.datasets import epinion2_tables
+    args = argparse.Namespace(embed_size=64, layer_size="[64]", mess_dropout="[0.1]", regs="[1e-5]")
+    for ds in ("tiny", "epinion2"):
+        g = golden(f"ngcf_{ds}")
+        nu, ni = int(g["n_users"]), int(g["n_items"])
+        if ds == "tiny":
+            csr, uw, iw = (g["rowptr"], g["col"], g["val"]), g["user_w"], g["item_w"]
+        else:
+            tr = epinion2["train"]
+            csr = ngcf_norm_adj(tr[:, 0], tr[:, 1], nu, ni)
+            uw, iw = epinion2_tables(nu + 1, ni)
+        adj = sp.csr_matrix((csr[2], csr[1], csr[0]), shape=(nu + ni, nu + ni))
+        m = NGCF({"n_users": nu, "n_items": ni, "norm_adj": adj}, DEV, args).to(DEV)
+        with torch.no_grad():
+            m.user_embedding.weight.copy_(torch.from_numpy(uw)); m.item_embedding.weight.copy_(torch.from_numpy(iw))
+            m.GC_Linear_list[0].weight.copy_(torch.from_numpy(g["W_gc"])); m.GC_Linear_list[0].bias.copy_(torch.from_numpy(g["b_gc"]))
+            m.Bi_Linear_list[0].weight.copy_(torch.from_numpy(g["W_bi"])); m.Bi_Linear_list[0].bias.copy_(torch.from_numpy(g["b_bi"]))
+        m.eval()
+        rows = g["sample_rows"]
+        want = g["all_emb"] if ds == "tiny" else g["all_emb_rows"]
+        with torch.no_grad():
+            ua, ia = m(None, None, None, flag=1)                          # fused kernels
+        out = torch.cat([ua, ia]).cpu().numpy()
+        assert rel_err(out if ds == "tiny" else out[rows], want) <= 1e-5
+        ua2, ia2 = m(None, None, None, flag=1)                            # autograd path (dropout off in eval)
+        out2 = torch.cat([ua2, ia2]).detach().cpu().numpy()
+        assert rel_err(out2 if ds == "tiny" else out2[rows], want) <= 1e-5
+        loss = m(torch.from_numpy(g["batch_users"]), torch.from_numpy(g["batch_items"]),
+                 torch.from_numpy(g["batch_labels"]), flag=0)
+        loss.backward()
+        assert abs(loss.item() - float(g["loss"])) <= 2e-6
+        assert rel_err(m.GC_Linear_list[0].weight.grad.cpu().numpy(), g["grad_W_gc"]) <= 2e-5
+        assert rel_err(m.Bi_Linear_list[0].weight.grad.cpu().numpy(), g["grad_W_bi"]) <= 2e-5
+        assert rel_err(m.GC_Linear_list[0].bias.grad.cpu().numpy(), g["grad_b_gc"]) <= 2e-5
+        gall = torch.cat([m.user_embedding.weight.grad, m.item_embedding.weight.grad]).cpu().numpy()
+        gr = g["grad_sample_rows"]
+        assert rel_err(gall if ds == "tiny" else gall[gr], g["grad_emb"] if ds == "tiny" else g["grad_emb_rows"]) <= 2e-5
+        assert np.isclose(np.sqrt((gall.astype(np.float64) ** 2).sum()), g["grad_emb_fro"], rtol=1e-4)
