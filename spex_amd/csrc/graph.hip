@@ -35,7 +35,7 @@ extern "C" int spex_graph_destroy(spex_graph_t *g)
 {
     if (!g) return SPEX_OK;
     void *ptrs[] = {g->rowptr, g->col, g->val, g->edge_id, g->seg_beg, g->seg_end, g->long_row, g->long_seg0, g->partial,
-                    g->task, g->chunk_off, g->chunk_val, g->chunk_mask, g->hub_row, g->hub_seg0};
+                    g->task, g->chunk_off, g->chunk_val, g->chunk_mask, g->chunk_eid, g->hub_row, g->hub_seg0};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete g;
@@ -91,13 +91,14 @@ extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, 
     //           scratch), bit 2 workgroup has a barrier, bit 3 leader (first segment of its row), bits 4-7 position of
     //           the wave in its workgroup (= LDS slot), bits 8-12 number of segments of the row; kind 2: bits 4.. slot.
     std::vector<int4> task;
-    std::vector<uint32_t> c_off, c_mask;
+    std::vector<uint32_t> c_off, c_mask, c_eid;
     std::vector<float> c_val;
     std::vector<int32_t> hub_row, hub_seg0;
     const bool chunked = true;
     if (chunked) {
         c_off.reserve((size_t)nnz + (size_t)nnz / 4 + 64);
         c_val.reserve((size_t)nnz + (size_t)nnz / 4 + 64);
+        c_eid.reserve((size_t)nnz + (size_t)nnz / 4 + 64);
         // append entries [b, e) as whole chunks; row_ends: flag the final entry of every row (packs of rows r0..)
         auto add_chunks = [&](int32_t b, int32_t e, int32_t r0, bool row_ends) -> int2 {
             const int32_t first_chunk = (int32_t)c_mask.size();
@@ -109,6 +110,7 @@ extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, 
                     if (en < e) {
                         c_off.push_back((uint32_t)h_col[en]);
                         c_val.push_back(h_val[en]);
+                        c_eid.push_back(h_edge_id ? (uint32_t)h_edge_id[en] : (uint32_t)en);
                         if (row_ends) {
                             while (h_rowptr[r + 1] <= en) ++r;  // rows of a pack are consecutive
                             if (en + 1 == h_rowptr[r + 1]) mask |= 1u << u;
@@ -116,6 +118,7 @@ extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, 
                     } else {  // padding: value 0 on the task's last real source row (a line already being fetched)
                         c_off.push_back((uint32_t)h_col[e - 1]);
                         c_val.push_back(0.0f);
+                        c_eid.push_back(h_edge_id ? (uint32_t)h_edge_id[e - 1] : (uint32_t)(e - 1));
                     }
                 }
                 c_mask.push_back(mask);
@@ -231,6 +234,7 @@ extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, 
         (rc = upload(&g->chunk_off, c_off.data(), c_off.size())) ||
         (rc = upload(&g->chunk_val, c_val.data(), c_val.size())) ||
         (rc = upload(&g->chunk_mask, c_mask.data(), c_mask.size())) ||
+        (rc = upload(&g->chunk_eid, c_eid.data(), c_eid.size())) ||
         (rc = upload(&g->hub_row, hub_row.data(), hub_row.size())) ||
         (rc = upload(&g->hub_seg0, hub_seg0.data(), hub_seg0.size()))) {
         spex_graph_destroy(g);

@@ -77,6 +77,7 @@ struct spex_graph {
     uint32_t *chunk_off = nullptr; // [n_chunks * 16]
     float *chunk_val = nullptr;    // [n_chunks * 16]
     uint32_t *chunk_mask = nullptr; // [n_chunks]
+    uint32_t *chunk_eid = nullptr;  // [n_chunks * 16] edge id of each entry (keep-mask index); read only under dropout
     int32_t n_hub = 0;              // rows longer than kWgRowMax (global-scratch path of the d == 64 kernel)
     int32_t *hub_row = nullptr;     // [n_hub]
     int32_t *hub_seg0 = nullptr;    // [2 * n_hub] (first, one-past-last) segment of each hub in the kLongRow segment table

@@ -227,12 +227,23 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_rows_kernel(const 
 // The accumulation is still one fmaf chain per output element in ascending column order (bit-exact vs the oracle).
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
-template <int EPI>  // 0: Y = y;  1: Y = y (optional), acc_out = (acc_in + y) / acc_div;  2: Y = y + add_in / add_div
+// Edge dropout (MASKED): lane k decides for its own entry (injected mask byte or Philox draw keyed by the entry's edge
+// id, so forward / backward / every layer of a step agree); a dropped entry keeps its slot with value 0 and the
+// source row of the super-chunk's first entry (already being fetched), i.e. it adds +0 and costs no extra traffic.
+struct DropArgs {
+    const uint32_t *chunk_eid;
+    const uint8_t *keep;
+    int mode;
+    float keep_prob;
+    uint32_t seed_lo, seed_hi;
+};
+
+template <int EPI, bool MASKED>  // EPI 0: Y = y;  1: Y = y (optional), acc_out = (acc_in + y) / acc_div;  2: Y = y + add_in / add_div
 __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
-    const float *__restrict__ X, uint32_t x_bytes, const uint32_t *__restrict__ chunk_off,
-    const float *__restrict__ chunk_val, const uint32_t *__restrict__ chunk_mask, const int4 *__restrict__ task,
-    int n_tasks, float *__restrict__ Y, const float *__restrict__ epi_in, uint32_t epi_bytes, float epi_div,
-    float *__restrict__ acc_out, float *__restrict__ partial)
+    const float *__restrict__ X, const uint32_t *__restrict__ chunk_off, const float *__restrict__ chunk_val,
+    const uint32_t *__restrict__ chunk_mask, const int4 *__restrict__ task, int n_tasks, float *__restrict__ Y,
+    const float *__restrict__ epi_in, float epi_div, float *__restrict__ acc_out, float *__restrict__ partial,
+    const DropArgs drop)
 {
     __shared__ float s_part[kWgWaves][kWave];  // segment sums of the rows this workgroup combines
     const int lane = threadIdx.x & (kWave - 1);
@@ -248,16 +259,17 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
 
     auto emit = [&](int r, float y, float e) {
         const size_t o = (size_t)r * 64 + lane;
+        // outputs are streamed (non-temporal): they should not evict the gather source from the XCD's L2
         if (EPI == 0) {
-            Y[o] = y;
+            __builtin_nontemporal_store(y, Y + o);
         } else if (EPI == 1) {
-            if (Y) Y[o] = y;
+            if (Y) __builtin_nontemporal_store(y, Y + o);
             float s = e + y;
             if (epi_div != 1.0f) s = s / epi_div;
-            acc_out[o] = s;
+            __builtin_nontemporal_store(s, acc_out + o);
         } else {
             if (epi_div != 1.0f) e = e / epi_div;
-            Y[o] = y + e;
+            __builtin_nontemporal_store(y + e, Y + o);
         }
     };
 
@@ -270,10 +282,27 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
         float my_val = 0.0f;
         if (lane < nc * kChunk) {
             const size_t e = (size_t)(t.x + sc) * kChunk + lane;
-            my_off = chunk_off[e];
-            my_val = chunk_val[e];
+            my_off = __builtin_nontemporal_load(chunk_off + e);   // metadata is read once per launch
+            my_val = __builtin_nontemporal_load(chunk_val + e);
+            if (MASKED) {
+                const uint32_t eid = __builtin_nontemporal_load(drop.chunk_eid + e);
+                bool kept;
+                if (drop.mode == 1) {
+                    kept = drop.keep[eid] != 0;
+                } else {
+                    const float u01 = (float)(philox_first(eid, drop.seed_lo, drop.seed_hi) >> 8) * 5.9604644775390625e-8f;
+                    kept = (u01 + drop.keep_prob) >= 1.0f;
+                }
+                my_val = kept ? my_val / drop.keep_prob : 0.0f;   // values[random_index] / keep_prob, model.py:53
+                if (!kept) my_off = 0xFFFFFFFFu;
+            }
         }
-        if (lane < nc) my_mask = chunk_mask[t.x + sc + lane];
+        if (MASKED) {
+            const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)my_off, 0);
+            // dropped entries re-read a row this wave fetches anyway (or row 0 of the table if entry 0 was dropped too)
+            if (my_off == 0xFFFFFFFFu) my_off = (first == 0xFFFFFFFFu) ? 0u : first;
+        }
+        if (lane < nc) my_mask = __builtin_nontemporal_load(chunk_mask + t.x + sc + lane);
         for (int c = 0; c < nc; ++c) {
             const uint32_t mask = (uint32_t)__builtin_amdgcn_readlane((int)my_mask, c);
             float x[kChunk], ep[kChunk];
@@ -286,7 +315,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
                 for (int u = 0; u < kChunk; ++u) {
                     ep[u] = 0.0f;
                     if (mask & (1u << u)) {
-                        ep[u] = El[(size_t)r * 64];
+                        ep[u] = __builtin_nontemporal_load(El + (size_t)r * 64);
                         ++r;
                     }
                 }
@@ -380,8 +409,8 @@ int launch_spmm(const spex_graph *g, const float *X, float *Y, const float *add_
     p.seed_lo = (uint32_t)g->seed; p.seed_hi = (uint32_t)(g->seed >> 32);
 
     const bool masked = g->mask_mode != 0;
-    // fast path: d == 64, no dropout, chunked table present, and not both epilogues at once
-    const bool fast = d == 64 && !masked && g->task != nullptr && !(acc_out && add_in);
+    // fast path: d == 64, chunked table present, and not both epilogues at once
+    const bool fast = d == 64 && g->task != nullptr && !(acc_out && add_in);
     const int per_block = fast ? kWgWaves : kWavesPerBlock;
     const int64_t tasks = fast ? (int64_t)g->n_tasks : (int64_t)g->n_seg + g->n_rows;  // waves
     int64_t blocks = (tasks + per_block - 1) / per_block;
@@ -391,17 +420,23 @@ int launch_spmm(const spex_graph *g, const float *X, float *Y, const float *add_
     const bool timed = tm && tm->used < (int32_t)tm->start.size() && (tm->seen++ % tm->every) == 0;
     if (timed) SPEX_HIP(hipEventRecord(tm->start[tm->used], stream));
     if (fast) {
-        const uint32_t x_bytes = (uint32_t)((int64_t)g->n_cols * 256), e_bytes = (uint32_t)((int64_t)g->n_rows * 256);
-        if (acc_out)
-            hipLaunchKernelGGL((spmm_chunk_kernel<1>), grid, block, 0, stream, X, x_bytes, g->chunk_off, g->chunk_val,
-                               g->chunk_mask, g->task, g->n_tasks, Y, acc_in, e_bytes, acc_div, acc_out, g->partial);
-        else if (add_in)
-            hipLaunchKernelGGL((spmm_chunk_kernel<2>), grid, block, 0, stream, X, x_bytes, g->chunk_off, g->chunk_val,
-                               g->chunk_mask, g->task, g->n_tasks, Y, add_in, e_bytes, add_div, (float *)nullptr, g->partial);
-        else
-            hipLaunchKernelGGL((spmm_chunk_kernel<0>), grid, block, 0, stream, X, x_bytes, g->chunk_off, g->chunk_val,
-                               g->chunk_mask, g->task, g->n_tasks, Y, (const float *)nullptr, 0u, 1.0f, (float *)nullptr,
-                               g->partial);
+        DropArgs da;
+        da.chunk_eid = g->chunk_eid; da.keep = g->keep; da.mode = g->mask_mode; da.keep_prob = g->keep_prob;
+        da.seed_lo = (uint32_t)g->seed; da.seed_hi = (uint32_t)(g->seed >> 32);
+#define SPEX_CHUNK(E, M, EIN, EDIV, AOUT)                                                                          \
+    hipLaunchKernelGGL((spmm_chunk_kernel<E, M>), grid, block, 0, stream, X, g->chunk_off, g->chunk_val, g->chunk_mask, \
+                       g->task, g->n_tasks, Y, EIN, EDIV, AOUT, g->partial, da)
+        if (acc_out) {
+            if (masked) SPEX_CHUNK(1, true, acc_in, acc_div, acc_out);
+            else SPEX_CHUNK(1, false, acc_in, acc_div, acc_out);
+        } else if (add_in) {
+            if (masked) SPEX_CHUNK(2, true, add_in, add_div, (float *)nullptr);
+            else SPEX_CHUNK(2, false, add_in, add_div, (float *)nullptr);
+        } else {
+            if (masked) SPEX_CHUNK(0, true, (const float *)nullptr, 1.0f, (float *)nullptr);
+            else SPEX_CHUNK(0, false, (const float *)nullptr, 1.0f, (float *)nullptr);
+        }
+#undef SPEX_CHUNK
     } else if (masked) {
         hipLaunchKernelGGL((spmm_rows_kernel<true>), grid, block, 0, stream, p);
     } else {
