@@ -243,12 +243,18 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
     const float *__restrict__ X, const uint32_t *__restrict__ chunk_off, const float *__restrict__ chunk_val,
     const uint32_t *__restrict__ chunk_mask, const int4 *__restrict__ task, int n_tasks, float *__restrict__ Y,
     const float *__restrict__ epi_in, float epi_div, float *__restrict__ acc_out, float *__restrict__ partial,
-    const DropArgs drop)
+    const DropArgs drop, const int xcd_contiguous)
 {
     __shared__ float s_part[kWgWaves][kWave];  // segment sums of the rows this workgroup combines
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int tid = xcd_contiguous_block(blockIdx.x, gridDim.x) * kWgWaves + wave;
+    // Workgroups are sorted heaviest-first and dealt round-robin over the 8 XCDs by the dispatcher, which gives every
+    // XCD the same mix of weights: right for a graph that streams from HBM (+14 % on Epinion2x538 over handing XCD 0
+    // all the heavy workgroups).  A graph whose whole source table sits in cache instead prefers each XCD to walk a
+    // contiguous range of workgroups (user rows and item rows of the bipartite graph then gather from different
+    // halves of the table in different L2s: 76 % vs 71 % L2 hits on Epinion2).  Placement is a speed matter only.
+    const int wg = xcd_contiguous ? xcd_contiguous_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int tid = wg * kWgWaves + wave;
     if (tid >= n_tasks) return;  // whole workgroups only (n_tasks is a multiple of kWgWaves)
     const int4 t = task[tid];
     const int kind = t.w & 3;
@@ -420,12 +426,13 @@ int launch_spmm(const spex_graph *g, const float *X, float *Y, const float *add_
     const bool timed = tm && tm->used < (int32_t)tm->start.size() && (tm->seen++ % tm->every) == 0;
     if (timed) SPEX_HIP(hipEventRecord(tm->start[tm->used], stream));
     if (fast) {
+        const int xcd_contig = ((int64_t)g->n_cols * d * 4 <= (int64_t)16 << 20) ? 1 : 0;  // source table <= 16 MiB
         DropArgs da;
         da.chunk_eid = g->chunk_eid; da.keep = g->keep; da.mode = g->mask_mode; da.keep_prob = g->keep_prob;
         da.seed_lo = (uint32_t)g->seed; da.seed_hi = (uint32_t)(g->seed >> 32);
 #define SPEX_CHUNK(E, M, EIN, EDIV, AOUT)                                                                          \
     hipLaunchKernelGGL((spmm_chunk_kernel<E, M>), grid, block, 0, stream, X, g->chunk_off, g->chunk_val, g->chunk_mask, \
-                       g->task, g->n_tasks, Y, EIN, EDIV, AOUT, g->partial, da)
+                       g->task, g->n_tasks, Y, EIN, EDIV, AOUT, g->partial, da, xcd_contig)
         if (acc_out) {
             if (masked) SPEX_CHUNK(1, true, acc_in, acc_div, acc_out);
             else SPEX_CHUNK(1, false, acc_in, acc_div, acc_out);
