@@ -15,6 +15,7 @@ singletons and same-named `utility*` packages cannot collide):
   lightgcn  LightGCN_SPEX/code: Loader / LightGCN / Adam / batch_test on `tiny` and
             `epinion2`  -> G1..G6, G8, G9
   ngcf      NGCF_SPEX/code: Data.create_adj_mat + Model_Wrapper.forward -> G7, G10
+  trust     LightGCN_SPEX/code: model_expert_s.LightGCN dual-task forward (rec + trust-path head) -> G11
 
 Harness-side shims (reference files untouched):
   * torch.Tensor.cuda -> identity   (dataloader.py:176,222 hard-call .cuda())
@@ -496,6 +497,78 @@ def stage_ngcf():
         print("ngcf", ds, "N", N, "nnz", norm.nnz, "loss", float(loss.item()))
 
 
+# --------------------------------------------------------------------------- trust head
+def stage_trust():
+    """Dual-task model (model_expert_s.py) on `tiny` with synthetic trust paths: parameters by seed, rec + trust
+    losses (flag=0), trust scores (flag=2), gradients, trust_test5 metrics."""
+    import numpy as np
+    import torch
+    install_shims()
+    torch.set_num_threads(8)
+    code = os.path.join(SCRATCH, "LightGCN_SPEX", "code")
+    os.makedirs(code, exist_ok=True)
+    os.chdir(code)
+    write_tiny(os.path.join(SCRATCH, "LightGCN_SPEX", "data", "tiny", "rec"))
+    sys.path.insert(0, os.path.join(REF, "LightGCN_SPEX", "code"))
+    sys.argv = ["main_auto_expert_s.py", "--dataset", "tiny"]
+    import lg_parser
+    import utility1.dataloader as ref_dl
+    import utility1.utils as ref_utils
+    import utility1.model_expert_s as ref_ex
+    from utility2.utils import Data
+    from utility2.batch_test_gnn import trust_test5
+
+    args = lg_parser.parse_args_r()
+    args.dataset = "tiny"
+    cache = os.path.join(SCRATCH, "LightGCN_SPEX", "data", "tiny", "s_pre_adj_mat.npz")
+    if os.path.exists(cache):
+        os.remove(cache)
+    rng = np.random.default_rng(77)
+    n_users = 50
+    def rand_paths(n):
+        paths, targets = [], []
+        for _ in range(n):
+            l = int(rng.integers(2, 7))                      # 2..6 nodes (data_process_path.py --path_len 6)
+            p = rng.choice(n_users, size=l, replace=False).tolist()
+            paths.append(p)
+            targets.append(int(rng.integers(n_users)))
+        return paths, targets
+    tr_paths, tr_targets = rand_paths(40)
+    te_paths, te_targets = rand_paths(12)
+    te_negs = []
+    for t in te_targets:
+        cand = [u for u in range(n_users) if u != t]
+        te_negs.append(rng.permutation(cand)[:49].tolist() + [t])   # 49 negatives first, target last (trust_test5 :36-37 takes topk(50))
+    ref_utils.set_seed(args.seed)
+    dataset = ref_dl.Loader(args)
+    train_data2 = Data((tr_paths, tr_targets), dataset.n_users, shuffle=False)
+    test_data2 = Data((te_paths, te_targets, te_negs), dataset.n_users, shuffle=False, test=True)
+    model = ref_ex.LightGCN(args, dataset)
+    out = {"state_" + k.replace(".", "__"): v.detach().numpy().copy() for k, v in model.state_dict().items()}
+    out.update(train_inputs=train_data2.inputs, train_mask=train_data2.mask, train_targets=train_data2.targets,
+               test_inputs=test_data2.inputs, test_mask=test_data2.mask, test_targets=test_data2.targets,
+               test_negs=test_data2.neg, n_users=dataset.n_users)
+    g = np.load(os.path.join(GOLD, "lightgcn_tiny.npz"))
+    bu, bi, bl = (torch.from_numpy(g[k][0]) for k in ("batch_users", "batch_items", "batch_labels"))
+    sl = np.arange(0, 30)
+    model.train()
+    model.zero_grad()
+    loss1, loss2 = model(bu, bi, bl, sl, train_data2, flag=0)
+    (loss1 + loss2).backward()
+    out.update(slice_indices=sl, loss1=np.float32(loss1.item()), loss2=np.float32(loss2.item()))
+    for name, p in model.named_parameters():
+        if p.grad is not None:
+            out["grad_" + name.replace(".", "__")] = p.grad.numpy().copy()
+    model.eval()
+    with torch.no_grad():
+        scores, negs = model(None, None, None, np.arange(12), test_data2, flag=2)
+        out.update(trust_scores=scores.numpy(), trust_negs=negs.numpy())
+        model.batch_size = 5                                  # exercises generate_batch's ragged last slice
+        out["trust_test5"] = np.asarray(trust_test5(model, test_data2), np.float64)
+    np.savez_compressed(os.path.join(GOLD, "trust_tiny.npz"), **out)
+    print("trust tiny: loss1 %.6f loss2 %.6f test5 %s" % (loss1.item(), loss2.item(), out["trust_test5"]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--stage", default="all")
@@ -504,7 +577,7 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     if a.stage == "all":
         env = dict(os.environ, PYTHONHASHSEED="0", PYTHONDONTWRITEBYTECODE="1")
-        for st in ("mint", "lightgcn", "ngcf"):
+        for st in ("mint", "lightgcn", "ngcf", "trust"):
             cmd = [sys.executable, os.path.abspath(__file__), "--stage", st]
             if a.skip_epinion_test:
                 cmd.append("--skip-epinion-test")
@@ -515,6 +588,8 @@ def main():
         stage_lightgcn(a.skip_epinion_test)
     elif a.stage == "ngcf":
         stage_ngcf()
+    elif a.stage == "trust":
+        stage_trust()
 
 
 if __name__ == "__main__":

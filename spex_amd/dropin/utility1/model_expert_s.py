@@ -1,34 +1,87 @@
-"""Rec branch of the dual-task model behind the reference's `utility1.model_expert_s` surface.
+"""Dual-task model (recommendation + trust-path prediction, shared user table) behind the reference's
+`utility1.model_expert_s` surface, so LightGCN_SPEX/code/main_auto_expert_s.py runs on it unchanged.
 
-Reference: LightGCN_SPEX/code/utility1/model_expert_s.py — LightGCN propagation (`computer`, :95-126, identical to
-model.py), then a two-expert gate between raw and propagated tables (:154-161), then dot + BCE (:163-168).  The
-trust-path head of the same class (:170-192, utility2/layers.py) is SURVEY.md 8f "next" #1 and is not built yet:
-`flag=2`, and `flag=0` with trust data, raise NotImplementedError.  Without the head's parameters the torch RNG stream
-at construction differs from the reference's, so tests inject weights instead of comparing by seed.
+Reference: LightGCN_SPEX/code/utility1/model_expert_s.py.  Same constructor, parameter names (state_dicts are
+interchangeable), creation order (same values for the same torch seed) and `forward(users, items, labels,
+slice_indices, trust_data, flag)` contract:
 
-    att = softmax([E0 | out] @ att_exp, dim=1);  mixed = E0 * att[:, 0] + out * att[:, 1]     (users and items apart)
+  flag 0  -> (rec BCE loss, trust cross-entropy loss)          flag 1 -> rec scores          flag 2 -> (trust scores, negs)
 
-Inference runs the fused gate kernel (`spex_expert_gate_f32`); under autograd the gate (a [rows,128]x[128,2] product,
-negligible next to the propagation) is expressed with torch ops so it is differentiated for free.
+What runs where
+  * rec branch: HIP propagation (`computer`, :95-126 == model.py:66-97), two-expert gate between raw and propagated
+    tables (:154-161, fused `spex_expert_gate_f32` in inference), dot + BCE (:163-168);
+  * trust branch (SURVEY.md 8f "next" #1, :170-192 + compute_scores :128-148): three path-attention heads, [B*L,192] x
+    [192,64] + ELU, an output attention layer, soft-attention readout, max-pool gate, logits against the whole user
+    table and cross-entropy.  The reference evaluates the attention layers with Python loops over batch x path
+    position; here they are closed-form batched tensor ops (utility2/layers.py).  These are small dense ops
+    ([B, <=6, 64]); they are expressed with torch on the device, differentiable for free.
 """
+import math
+
+import numpy as np
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from spex_amd import ops
-from utility1.model import LightGCN as _LightGCN
+from utility1.model import LightGCN as _RecLightGCN
+from utility2.layers import GraphAttentionLayer
 
 
-class LightGCN(_LightGCN):
+class BasicModel(nn.Module):
+    def getUsersRating(self, users):
+        raise NotImplementedError
+
+
+class LightGCN(_RecLightGCN):
     def __init__(self, args_r, dataset):
-        super().__init__(args_r, dataset)
+        # creation order follows model_expert_s.py:19-70 line by line: the torch RNG is consumed identically
+        nn.Module.__init__(self)
+        self.args_r, self.dataset = args_r, dataset
         self.hidden_size = args_r.hiddenSize
-        self.task_weights = nn.Parameter(torch.zeros(2))
+        self.batch_size = args_r.batchSize
+        self.nonhybrid = args_r.nonhybrid
+        self.linear_one = nn.Linear(self.hidden_size, self.hidden_size, bias=True)
+        self.linear_two = nn.Linear(self.hidden_size, self.hidden_size, bias=True)
+        self.linear_three = nn.Linear(self.hidden_size, 1, bias=False)
+        self.linear_transform = nn.Linear(self.hidden_size * 2, self.hidden_size, bias=True)
+        self.reset_parameters()
+        self.in_att = [GraphAttentionLayer(self.hidden_size, concat=True) for _ in range(args_r.nb_heads)]
+        for i, attention in enumerate(self.in_att):
+            self.add_module("attention_{}".format(i), attention)
+        self.out_att = GraphAttentionLayer(self.hidden_size, concat=False)
+        self.w = nn.Parameter(torch.zeros(size=(args_r.nb_heads * self.hidden_size, self.hidden_size)))
+        nn.init.xavier_uniform_(self.w.data, gain=1.414)
+
+        self.bcel = nn.BCEWithLogitsLoss()
+        self.num_users, self.num_items = dataset.n_users, dataset.m_items
+        self.latent_dim, self.n_layers = args_r.recdim, args_r.layer
+        self.keep_prob, self.A_split = args_r.keepprob, args_r.A_split
+        self.embedding_user = nn.Embedding(self.num_users + 1, self.latent_dim)
+        self.embedding_item = nn.Embedding(self.num_items, self.latent_dim)
+        nn.init.xavier_uniform_(self.embedding_user.weight, gain=1)
+        nn.init.xavier_uniform_(self.embedding_item.weight, gain=1)
+        self._fuse_tables()
+        self.f = nn.Sigmoid()
+        self.Graph = dataset.getSparseGraph()
+        self._graph_t, self._dropout_calls, self._injected_mask, self._cache = None, 0, None, None
+
+        self.task_weights = nn.Parameter(torch.FloatTensor([0.0, 0.0]))
         self.rec_loss = nn.BCEWithLogitsLoss()
-        self.att_exp1 = nn.Parameter(torch.zeros(2 * self.hidden_size, 2))
-        self.att_exp2 = nn.Parameter(torch.zeros(2 * self.hidden_size, 2))
+        self.loss_function = nn.CrossEntropyLoss()
+        self.att_exp1 = nn.Parameter(torch.zeros(size=(2 * self.hidden_size, 2)))
+        self.att_exp2 = nn.Parameter(torch.zeros(size=(2 * self.hidden_size, 2)))
         nn.init.xavier_uniform_(self.att_exp1.data, gain=1)
         nn.init.xavier_uniform_(self.att_exp2.data, gain=1)
+        self.att_t = nn.Parameter(torch.zeros(size=(2 * self.hidden_size, 2)))
+        nn.init.xavier_normal_(self.att_t.data, gain=1)
 
+    def reset_parameters(self):
+        stdv = 1.0 / math.sqrt(self.hidden_size)
+        for weight in self.parameters():
+            weight.data.uniform_(-stdv, stdv)
+
+    # ------------------------------------------------------------------ rec branch
     def _gated_tables(self):
         light_out = self._light_out()
         n_u = self.num_users + 1
@@ -41,14 +94,53 @@ class LightGCN(_LightGCN):
         return (ops.expert_gate(raw_u.detach().contiguous(), out_u.contiguous(), self.att_exp1.detach()),
                 ops.expert_gate(raw_i.detach().contiguous(), out_i.contiguous(), self.att_exp2.detach()))
 
+    # ------------------------------------------------------------------ trust branch
+    def compute_scores(self, hidden, inputs, mask):
+        B = mask.shape[0]
+        last = torch.sum(mask, 1) - 1
+        ht = hidden[torch.arange(B, device=hidden.device), last]
+        q1 = self.linear_one(ht).view(B, 1, -1)
+        q2 = self.linear_two(hidden)
+        alpha = self.linear_three(torch.sigmoid(q1 + q2))
+        a = torch.sum(alpha * hidden * mask.view(B, -1, 1).float(), 1)
+        # the reference leaves p_a undefined under --nonhybrid (NameError at :141); use the pooled vector there
+        p_a = a if self.nonhybrid else self.linear_transform(torch.cat([a, ht], 1))
+        b = self.embedding_user.weight[:-1]
+        p_i = self.embedding_user.weight[inputs] * mask.unsqueeze(2)
+        p_maxpool = torch.max(p_i, dim=1)[0]
+        att = torch.softmax(torch.cat([p_a, p_maxpool], 1) @ self.att_t, 1)
+        a = p_a * att[:, 0].unsqueeze(1) + p_maxpool * att[:, 1].unsqueeze(1)
+        return a @ b.t()
+
+    def _trust_scores(self, inputs, mask):
+        dev = self.embedding_user.weight.device
+        inputs = torch.as_tensor(np.asarray(inputs), device=dev).long()
+        mask = torch.as_tensor(np.asarray(mask), device=dev).long()
+        seq_l = torch.sum(mask, 1)
+        emb = self.embedding_user.weight
+        mul_seq = torch.cat([att(emb, inputs, seq_l) for att in self.in_att], dim=2)          # [B, L, heads*H]
+        mul_one = F.elu(mul_seq.reshape(-1, mul_seq.shape[2]) @ self.w)
+        hidden = self.out_att(emb, mul_one.view(mul_seq.shape[0], mul_seq.shape[1], self.hidden_size), seq_l)
+        return self.compute_scores(hidden, inputs, mask)
+
+    # ------------------------------------------------------------------ forward (:150-193)
     def forward(self, users, items, labels, slice_indices=None, trust_data=None, flag=0):
-        if flag == 2 or (flag == 0 and trust_data is not None):
-            raise NotImplementedError("the trust-path head (model_expert_s.py:170-192) is not part of this build yet")
-        all_users, all_items = self._gated_tables()
-        dev = all_users.device
-        if flag == 1:
-            gamma, _ = ops.score_bce(all_users.detach().contiguous(), all_items.detach().contiguous(), users, items)
-            return gamma
-        users_emb, items_emb = all_users[ops._idx(users, dev)], all_items[ops._idx(items, dev)]
-        gamma = torch.sum(users_emb * items_emb, dim=1)
-        return self.rec_loss(gamma, labels.to(dev).float())
+        loss1 = None
+        if flag in (0, 1):
+            all_users, all_items = self._gated_tables()
+            dev = all_users.device
+            if flag == 1:
+                gamma, _ = ops.score_bce(all_users.detach().contiguous(), all_items.detach().contiguous(), users, items)
+                return gamma
+            users_emb, items_emb = all_users[ops._idx(users, dev)], all_items[ops._idx(items, dev)]
+            loss1 = self.rec_loss(torch.sum(users_emb * items_emb, dim=1), labels.to(dev).float())
+        if flag in (0, 2):
+            if flag == 0:
+                inputs, mask, targets = trust_data.get_slice(slice_indices)
+            else:
+                inputs, mask, targets, negs = trust_data.get_slice(slice_indices)
+            scores = self._trust_scores(inputs, mask)
+            if flag == 2:
+                return scores, torch.as_tensor(np.asarray(negs), device=scores.device).long()
+            loss2 = self.loss_function(scores, torch.as_tensor(np.asarray(targets), device=scores.device).long())
+        return loss1, loss2

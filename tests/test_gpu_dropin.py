@@ -197,16 +197,23 @@ def test_unmodified_style_driver_runs_through_the_launcher(data_root, tmp_path):
     assert len(lines) >= 2 and "recall=" in lines[-1]
 
 
-def test_expert_gate_model_matches_reference_scores(data_root, golden):
-    """model_expert_s rec branch (flag=1) with the reference's gate weights injected: G8."""
+def _dual_task_model(data_root):
     import lg_parser
     import utility1.dataloader as dataloader
     import utility1.model_expert_s as mex
+    import utility1.utils as utils
+    args = lg_parser.parse_args_r(["--dataset", "tiny", "--data_path", data_root])
+    utils.set_seed(args.seed)                                          # main_auto_expert_s.py:22
+    dataset = dataloader.Loader(args)
+    return args, dataset, mex.LightGCN(args, dataset)
+
+
+def test_expert_gate_model_matches_reference_scores(data_root, golden):
+    """model_expert_s rec branch (flag=1) with the reference's gate weights injected: G8."""
     from utility1.batch_test import rec_test
     g = golden("lightgcn_tiny")
-    args = lg_parser.parse_args_r(["--dataset", "tiny", "--data_path", data_root])
-    dataset = dataloader.Loader(args)
-    net = mex.LightGCN(args, dataset).to(DEV)
+    args, dataset, net = _dual_task_model(data_root)
+    net = net.to(DEV)
     with torch.no_grad():
         E0 = torch.from_numpy(g["E0"]).to(DEV)
         net.embedding_user.weight.copy_(E0[:51]); net.embedding_item.weight.copy_(E0[51:])
@@ -219,15 +226,48 @@ def test_expert_gate_model_matches_reference_scores(data_root, golden):
     net.train()
     gamma_t = net(u, i, None, None, None, flag=1)                         # autograd (torch-op) gate agrees
     assert rel_err(gamma_t.detach().cpu().numpy(), g["g8_gamma"]) <= 1e-5
-    loss = net(u, i, torch.from_numpy(g["batch_labels"][0]), None, None, flag=0)
-    loss.backward()
-    assert net.att_exp1.grad.abs().sum() > 0 and net.embedding_user.weight.grad.abs().sum() > 0
     net.eval()
     with torch.no_grad():
         ret = rec_test(net, dataset.testRatings, dataset.testNegatives)  # dual-task eval entry (batch_test.py:43-56)
     assert 0.0 <= ret["recall"][0] <= 1.0
-    with pytest.raises(NotImplementedError):
-        net(u, i, None, [0], object(), flag=2)
+
+
+def test_dual_task_model_matches_reference(data_root, golden):
+    """G11: main_auto_expert_s.py's model — same parameters for the same seed, both losses, their gradients, trust
+    scores and trust_test5 metrics, vs the reference (whose trust head is Python loops over batch x path position)."""
+    from utility2.utils import Data
+    from utility2.batch_test_gnn import trust_test5
+    g = golden("trust_tiny")
+    args, dataset, net = _dual_task_model(data_root)
+    sd = net.state_dict()
+    for k, v in sd.items():
+        assert np.array_equal(v.numpy(), g["state_" + k.replace(".", "__")]), f"{k} differs from the reference init"
+    net = net.to(DEV)
+    lens = g["train_mask"].sum(1)
+    train = Data(([r[:l].tolist() for r, l in zip(g["train_inputs"], lens)], g["train_targets"].tolist()), 50)
+    assert np.array_equal(train.inputs, g["train_inputs"]) and np.array_equal(train.mask, g["train_mask"])
+    tl = g["test_mask"].sum(1)
+    test = Data(([r[:l].tolist() for r, l in zip(g["test_inputs"], tl)], g["test_targets"].tolist(),
+                 g["test_negs"].tolist()), 50, test=True)
+    gl = golden("lightgcn_tiny")
+    bu, bi, bl = (torch.from_numpy(gl[k][0]) for k in ("batch_users", "batch_items", "batch_labels"))
+    net.train()
+    loss1, loss2 = net(bu, bi, bl, g["slice_indices"], train, flag=0)            # main_auto_expert_s.py:73-75
+    assert abs(loss1.item() - float(g["loss1"])) <= 2e-6 and abs(loss2.item() - float(g["loss2"])) <= 2e-5
+    (loss1 + loss2).backward()
+    for name, p in net.named_parameters():
+        key = "grad_" + name.replace(".", "__")
+        if key in g.files:
+            assert p.grad is not None, name
+            assert rel_err(p.grad.cpu().numpy(), g[key]) <= 5e-5, name
+    net.eval()
+    with torch.no_grad():
+        scores, negs = net(None, None, None, np.arange(12), test, flag=2)
+    assert rel_err(scores.cpu().numpy(), g["trust_scores"]) <= 1e-5
+    assert np.array_equal(negs.cpu().numpy(), g["trust_negs"])
+    net.batch_size = 5
+    got = np.asarray(trust_test5(net, test))
+    assert np.abs(got - g["trust_test5"]).max() <= 1e-9
 
 
 def test_ngcf_model_matches_reference(golden, epinion2):

@@ -182,3 +182,52 @@ def test_epinion2_fixture_round_trips_through_the_file_format(tmp_path, epinion2
     assert [ld.testRatings[u][0] for u in ld.testRatings] == epinion2["test_pos"].tolist()
     rowptr, col, val = ld.build_adjacency()
     assert len(col) == 418608
+
+
+def test_path_attention_layer_closed_form_equals_reference_loops():
+    """utility2/layers.py restated as the reference's loops (layers.py:15-71) on CPU tensors vs the batched form."""
+    from utility2.layers import GraphAttentionLayer
+    torch.manual_seed(0)
+    H, B, L, U = 8, 5, 6, 20
+    emb = torch.randn(U + 1, H)
+    seq_l = torch.tensor([2, 6, 3, 5, 4])
+    seq = torch.full((B, L), U)
+    for p in range(B):
+        seq[p, :seq_l[p]] = torch.randperm(U)[:seq_l[p]]
+
+    def loops(layer, emb, seq, seq_l, concat):
+        out = torch.ones(B, L, H)
+        a = layer.a.detach()
+        for p in range(B):
+            l = int(seq_l[p])
+            for i in range(l - 1):
+                if concat:
+                    x = emb[seq[p][i]] + float(l - i)
+                    y = emb[seq[p][i + 1]] + float(l - i - 1)
+                else:
+                    x, y = seq[p][i], seq[p][i + 1]
+                h = torch.stack([torch.cat([x, x]), torch.cat([x, y])])
+                att = torch.softmax((h @ a).squeeze(1), dim=0)
+                out[p][i] = att[0] * x + att[1] * y
+            for i in range(l - 1, L):
+                out[p][i] = emb[seq[p][i]] if concat else seq[p][i]
+        return out
+
+    la = GraphAttentionLayer(H, concat=True)
+    assert torch.allclose(la(emb, seq, seq_l), loops(la, emb, seq, seq_l, True), atol=1e-6)
+    lb = GraphAttentionLayer(H, concat=False)
+    x3 = torch.randn(B, L, H)
+    assert torch.allclose(lb(emb, x3, seq_l), loops(lb, emb, x3, seq_l, False), atol=1e-6)
+
+
+def test_trust_data_batches_like_the_reference(golden):
+    from utility2.utils import Data
+    g = golden("trust_tiny")
+    lens = g["train_mask"].sum(1)
+    paths = [r[:l].tolist() for r, l in zip(g["train_inputs"], lens)]
+    d = Data((paths, g["train_targets"].tolist()), 50)
+    assert np.array_equal(d.inputs, g["train_inputs"]) and np.array_equal(d.mask, g["train_mask"]) and d.len_max == 6
+    sl = d.generate_batch(16)
+    assert [len(s) for s in sl] == [16, 16, 8] and np.array_equal(np.concatenate(sl), np.arange(40))
+    i, m, t = d.get_slice(sl[2])
+    assert np.array_equal(i, g["train_inputs"][32:]) and np.array_equal(t, g["train_targets"][32:])
