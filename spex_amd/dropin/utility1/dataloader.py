@@ -180,25 +180,34 @@ class LightTrainData(Dataset):
         pos[pos == len(self._train_keys)] = 0
         return (self._train_keys[pos] == key) if len(self._train_keys) else np.zeros(len(key), bool)
 
-    def ng_sample(self):
+    def ng_sample(self, block=8192):
+        """Slot k (positive k // num_ng, user u_k) takes the first not-yet-consumed stream value j with (u_k, j) not a
+        training pair; rejected values are consumed too.  The stream is processed in blocks: inside a block the
+        mapping position -> slot is found by fixed-point iteration (a position's slot is its index minus the
+        rejections before it; rejections are sparse, so this settles in a few passes), the running slot offset is
+        carried from block to block, and exactly as many values are drawn as the reference would draw."""
         P = len(self._ps)
         S = P * self.num_ng
         slot_user = np.repeat(self._ps[:, 0], self.num_ng)
-        stream = np.random.randint(self.num_item, size=S).astype(np.int64) if S else np.zeros(0, np.int64)
-        while True:
-            n = len(stream)
-            rej = np.zeros(n, bool)
-            while True:  # fixed point: position p feeds slot p - (#rejections before p)
-                slot = np.arange(n) - (np.cumsum(rej) - rej)
-                new = self._in_train(slot_user[np.minimum(slot, S - 1)], stream) if n else rej
-                if np.array_equal(new, rej):
-                    break
-                rej = new
-            deficit = S - int((~rej).sum())
-            if deficit <= 0:
-                break
-            stream = np.concatenate([stream, np.random.randint(self.num_item, size=deficit).astype(np.int64)])
-        neg_items = stream[~rej]
+        neg_items = np.empty(S, np.int64)
+        k = 0                                           # next slot to fill
+        while k < S:
+            stream = np.random.randint(self.num_item, size=S - k).astype(np.int64)   # never more than still needed
+            pos = 0
+            while pos < len(stream):
+                vals = stream[pos:pos + block]          # len(vals) <= remaining slots, so slots never overrun
+                n = len(vals)
+                rej = np.zeros(n, bool)
+                while True:
+                    slot = k + np.arange(n) - (np.cumsum(rej) - rej)
+                    new = self._in_train(slot_user[slot], vals)
+                    if np.array_equal(new, rej):
+                        break
+                    rej = new
+                acc = vals[~rej]
+                neg_items[k:k + len(acc)] = acc
+                k += len(acc)
+                pos += n
         self.users_fill = np.concatenate([self._ps[:, 0], slot_user])
         self.items_fill = np.concatenate([self._ps[:, 1], neg_items])
         self.labels_fill_np = np.concatenate([np.ones(P, np.int64), np.zeros(S, np.int64)])

@@ -96,7 +96,12 @@ def test_sampler_replay_dense_case_against_oracle(oracle):
     mat = sp.coo_matrix((np.ones(len(pairs), np.float32), (pairs[:, 0], pairs[:, 1])), shape=(U + 1, I)).todok()
     td = dl.LightTrainData(pairs.tolist(), I, mat)
     np.random.seed(7)
+    td.ng_sample(block=13)                     # small blocks: the slot offset is carried across many block seams
+    assert td.features_ng == oracle.ng_sample_replay.__globals__["np"].asarray(td.features_ng).tolist()
+    first = td.features_ng
+    np.random.seed(7)
     td.ng_sample()
+    assert td.features_ng == first             # block size does not change the result
     after_fast = np.random.randint(1 << 30)
     np.random.seed(7)
     ref = oracle.ng_sample_replay(pairs.tolist(), I, set(map(tuple, pairs.tolist())))
