@@ -60,8 +60,9 @@ int spex_graph_info(const spex_graph_t *g, int32_t *n_rows, int32_t *n_cols, int
 /* Edge dropout — replaces LightGCN.__dropout_x, utility1/model.py:46-55: keep entry e iff floor(rand_e + keep_prob),
  * kept values divided by keep_prob.  Two modes:
  *   injected : d_keep = device uint8[mask_len], indexed by edge_id (parity tests inject the reference's mask)
- *   sampled  : d_keep = NULL; the mask is counter-based: keep_e = (philox4x32-10(seed, edge_id).x * 2^-32 + keep_prob
- *              >= 1), recomputed inside the SpMM, identical in forward / backward and across layers for one seed.
+ *   sampled  : d_keep = NULL; the mask is counter-based: keep_e = (u + keep_prob >= 1) with u the top 24 bits of
+ *              philox4x32-10(key = seed, counter = edge_id) scaled to [0,1) (torch.rand's grid), recomputed inside
+ *              the SpMM, identical in forward / backward and across layers for one seed.
  * keep_prob >= 1 or mode 0 switches dropout off.  Takes effect for subsequent launches on this handle.
  */
 int spex_graph_set_edge_mask(spex_graph_t *g, int mode /*0 off, 1 injected, 2 sampled*/, const uint8_t *d_keep,
