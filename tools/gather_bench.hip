@@ -32,6 +32,30 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void *base, uint32_t bytes)
 
 constexpr int U = 16;
 
+template <int UU>
+__global__ __launch_bounds__(256) void k1u(const float *__restrict__ X, const int *__restrict__ idx,
+                                           const float *__restrict__ val, float *__restrict__ Y, int per_wave)
+{
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int *ip = idx + (size_t)w * per_wave;
+    const float *vp = val + (size_t)w * per_wave;
+    float acc = 0.f;
+    for (int base = 0; base < per_wave; base += 64) {
+        const int my_i = ip[base + lane];
+        const float my_v = vp[base + lane];
+        for (int i = 0; i < 64; i += UU) {
+            float x[UU];
+#pragma unroll
+            for (int u = 0; u < UU; ++u) x[u] = X[(size_t)__builtin_amdgcn_readlane(my_i, i + u) * 64 + lane];
+#pragma unroll
+            for (int u = 0; u < UU; ++u)
+                acc = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), i + u)), x[u], acc);
+        }
+    }
+    Y[(size_t)w * 64 + lane] = acc;
+}
+
 __global__ __launch_bounds__(256) void k1(const float *__restrict__ X, const int *__restrict__ idx,
                                           const float *__restrict__ val, float *__restrict__ Y, int per_wave)
 {
@@ -176,7 +200,7 @@ int main(int argc, char **argv)
         CK(hipEventCreate(&e0));
         CK(hipEventCreate(&e1));
         printf("== %s\n", c.name);
-        for (int k = 1; k <= 6; ++k) {
+        for (int k = 1; k <= 9; ++k) {
             float best = 1e30f;
             for (int rep = 0; rep < 6; ++rep) {
                 CK(hipEventRecord(e0));
@@ -187,6 +211,9 @@ int main(int argc, char **argv)
                     case 4: hipLaunchKernelGGL(k4<4>, grid, block, 0, 0, X, idx, val, Y, per_wave); break;
                     case 5: hipLaunchKernelGGL(k4<8>, grid, block, 0, 0, X, idx, val, Y, per_wave); break;
                     case 6: hipLaunchKernelGGL(k4<16>, grid, block, 0, 0, X, idx, val, Y, per_wave); break;
+                    case 7: hipLaunchKernelGGL(k1u<32>, grid, block, 0, 0, X, idx, val, Y, per_wave); break;
+                    case 8: hipLaunchKernelGGL(k1u<64>, grid, block, 0, 0, X, idx, val, Y, per_wave); break;
+                    case 9: hipLaunchKernelGGL(k1u<8>, grid, block, 0, 0, X, idx, val, Y, per_wave); break;
                 }
                 CK(hipEventRecord(e1));
                 CK(hipEventSynchronize(e1));
@@ -198,7 +225,7 @@ int main(int argc, char **argv)
             CK(hipMemcpy(hy.data(), Y, 256, hipMemcpyDeviceToHost));
             const double gb = (double)n_idx * 264.0 / 1e9;
             printf("  K%d%s  %9.1f us   %7.0f GB/s (264 B/gather)   %6.2f G gathers/s   check %.1f\n", k,
-                   k == 4 ? "(x4,4 in flight)" : k == 5 ? "(x4,8)" : k == 6 ? "(x4,16)" : "", best * 1e3, gb / (best * 1e-3),
+                   k == 4 ? "(x4,4 in flight)" : k == 5 ? "(x4,8)" : k == 6 ? "(x4,16)" : k == 7 ? "(K1, 32 in flight)" : k == 8 ? "(K1, 64 in flight)" : k == 9 ? "(K1, 8 in flight)" : "", best * 1e3, gb / (best * 1e-3),
                    n_idx / (best * 1e-3) / 1e9, hy[0]);
         }
         CK(hipFree(X)); CK(hipFree(Y)); CK(hipFree(val)); CK(hipFree(idx)); CK(hipFree(off));
