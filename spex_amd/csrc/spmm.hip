@@ -6,24 +6,23 @@
 // 256-byte embedding row (d = 64 fp32).  0.5 flop per byte: a gather/reduce bound by HBM (or, for the cache-resident
 // named datasets, by L2 / Infinity Cache) — no MFMA, no GEMM reshaping.
 //
-// Mapping: one 64-lane wavefront per row (or per 128-entry segment of a long row); lane == embedding column, so one
-// gathered row is exactly one fully coalesced 256-byte wave load (two 128-byte lines).  The wave first loads up to 64
-// (col, val) pairs with one coalesced load each (lane k holds entry k), then walks them with v_readlane: the column
-// index becomes a scalar, the row address a scalar base + lane offset, and 8 independent row gathers are issued
-// back-to-back before the first fmaf consumes them.  The accumulation is a single fmaf chain in ascending column
-// order, i.e. bit-for-bit the order the reference's CPU kernel uses.
+// Two kernels share the lane mapping (lane == embedding column: one gathered row is one coalesced 256-byte wave load,
+// two 128-byte lines) and the arithmetic (one fmaf chain per output element in ascending column order — bit for bit
+// the order of the reference's CPU kernel):
 //
-// Long rows (> 128 entries) would serialise one wave for tens of microseconds, so graph creation cuts them into
-// 128-entry segments; each segment is an ordinary wave task that writes a 256-byte partial row, and a tiny second
-// launch adds a row's partials in segment order (deterministic, no atomics) and applies the epilogue.
+//   spmm_chunk_kernel  d == 64, the tuned path (described at its definition): 16-wave workgroups, one wave per
+//                      <= 64-entry task read from the chunked task table, long rows summed through LDS.
+//   spmm_rows_kernel   any d: one wave per row (or per 128-entry segment of a row with more than 128 entries), walking
+//                      the plain CSR in column tiles of 64; segment sums go through global scratch and
+//                      spmm_long_fixup_kernel adds them in segment order.  Correct everywhere, tuned nowhere.
 //
-// Epilogue (fused, saves one full pass over the embedding matrix per layer each):
+// Fused epilogue (each saves a full pass over the embedding matrix per layer):
 //   y += add_in / add_div            backward of the layer mean (g/(L+1) + A^T G)
 //   Y = y                            next layer's input (skipped on the last layer)
 //   acc_out = (acc_in + y) / acc_div running sum of layers; acc_div = L+1 on the last layer gives the mean
 //
-// Edge dropout (model.py:46-55) is applied while the (col, val) pairs are loaded: dropped entries are removed from
-// the wave's ballot mask, so they vanish from the sum exactly as if the sparse matrix had been rebuilt without them.
+// Edge dropout (model.py:46-55) is decided per stored entry while its (col, val) pair is loaded — injected mask byte
+// or Philox draw keyed by the entry's edge id — so forward, backward and all layers of a step drop the same edges.
 #include "spex_common.h"
 
 using namespace spex;
@@ -178,8 +177,8 @@ __device__ __forceinline__ int xcd_contiguous_block(int bid, int nblk)
     return ((nblk & 7) == 0) ? (bid & 7) * (nblk >> 3) + (bid >> 3) : bid;
 }
 
-// One wave per task.  Tasks [0, n_seg) are long-row segments (heaviest work first), tasks [n_seg, n_seg + n_rows)
-// are rows; rows longer than kLongRow are left to their segments.
+// Generic-d kernel: one wave per task.  Tasks [0, n_seg) are long-row segments (heaviest work first), tasks
+// [n_seg, n_seg + n_rows) are rows; rows longer than kLongRow are left to their segments.
 template <bool MASKED>
 __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_rows_kernel(const SpmmParams p)
 {
