@@ -35,7 +35,7 @@ extern "C" int spex_graph_destroy(spex_graph_t *g)
 {
     if (!g) return SPEX_OK;
     void *ptrs[] = {g->rowptr, g->col, g->val, g->edge_id, g->seg_beg, g->seg_end, g->long_row, g->long_seg0, g->partial,
-                    g->task, g->chunk_off, g->chunk_val, g->chunk_mask, g->chunk_eid, g->hub_row, g->hub_seg0};
+                    g->task, g->chunk_off, g->chunk_val, g->chunk_mask, g->chunk_eid, g->chunk_row, g->hub_row, g->hub_seg0};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete g;
@@ -92,36 +92,55 @@ extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, 
     //           the wave in its workgroup (= LDS slot), bits 8-12 number of segments of the row; kind 2: bits 4.. slot.
     std::vector<int4> task;
     std::vector<uint32_t> c_off, c_mask, c_eid;
+    std::vector<int32_t> c_row;
     std::vector<float> c_val;
     std::vector<int32_t> hub_row, hub_seg0;
     const bool chunked = true;
+    g->row_ids = (int64_t)n_cols * 256 <= ((int64_t)16 << 20);
     if (chunked) {
         c_off.reserve((size_t)nnz + (size_t)nnz / 4 + 64);
         c_val.reserve((size_t)nnz + (size_t)nnz / 4 + 64);
         c_eid.reserve((size_t)nnz + (size_t)nnz / 4 + 64);
-        // append entries [b, e) as whole chunks; row_ends: flag the final entry of every row (packs of rows r0..)
-        auto add_chunks = [&](int32_t b, int32_t e, int32_t r0, bool row_ends) -> int2 {
+        c_row.reserve((size_t)nnz + (size_t)nnz / 8 + 64);
+        // append the entries of `rows` (each row's whole range, back to back) — or, if rows == nullptr, the range
+        // [b, e) of row r0 without end-of-row flags — as whole chunks
+        auto add_chunks = [&](const int32_t *rows, int32_t n_rows_in, int32_t b, int32_t e, int32_t r0) -> int2 {
             const int32_t first_chunk = (int32_t)c_mask.size();
-            int32_t r = r0;
-            for (int32_t k = b; k < e; k += spex::kChunk) {
-                uint32_t mask = 0;
-                for (int32_t u = 0; u < spex::kChunk; ++u) {
-                    const int32_t en = k + u;
-                    if (en < e) {
-                        c_off.push_back((uint32_t)h_col[en]);
-                        c_val.push_back(h_val[en]);
-                        c_eid.push_back(h_edge_id ? (uint32_t)h_edge_id[en] : (uint32_t)en);
-                        if (row_ends) {
-                            while (h_rowptr[r + 1] <= en) ++r;  // rows of a pack are consecutive
-                            if (en + 1 == h_rowptr[r + 1]) mask |= 1u << u;
-                        }
-                    } else {  // padding: value 0 on the task's last real source row (a line already being fetched)
-                        c_off.push_back((uint32_t)h_col[e - 1]);
-                        c_val.push_back(0.0f);
-                        c_eid.push_back(h_edge_id ? (uint32_t)h_edge_id[e - 1] : (uint32_t)(e - 1));
-                    }
+            int32_t in_chunk = 0, last_col = 0, last_eid = 0, last_row = r0;
+            uint32_t mask = 0;
+            auto push = [&](int32_t en, int32_t r, bool last) {
+                c_off.push_back((uint32_t)h_col[en]);
+                c_val.push_back(h_val[en]);
+                c_eid.push_back(h_edge_id ? (uint32_t)h_edge_id[en] : (uint32_t)en);
+                if (g->row_ids) c_row.push_back(r);
+                if (last) mask |= 1u << in_chunk;
+                last_col = h_col[en];
+                last_eid = h_edge_id ? h_edge_id[en] : en;
+                last_row = r;
+                if (++in_chunk == spex::kChunk) {
+                    c_mask.push_back(mask);
+                    mask = 0;
+                    in_chunk = 0;
                 }
-                c_mask.push_back(mask);
+            };
+            if (rows) {
+                for (int32_t i = 0; i < n_rows_in; ++i) {
+                    const int32_t r = rows[i];
+                    for (int32_t en = h_rowptr[r]; en < h_rowptr[r + 1]; ++en) push(en, r, en + 1 == h_rowptr[r + 1]);
+                }
+            } else {
+                for (int32_t en = b; en < e; ++en) push(en, r0, false);
+            }
+            while (in_chunk != 0) {  // padding: value 0 on the task's last real source row (a line already being fetched)
+                c_off.push_back((uint32_t)last_col);
+                c_val.push_back(0.0f);
+                c_eid.push_back((uint32_t)last_eid);
+                if (g->row_ids) c_row.push_back(last_row);
+                if (++in_chunk == spex::kChunk) {
+                    c_mask.push_back(mask);
+                    mask = 0;
+                    in_chunk = 0;
+                }
             }
             return make_int2(first_chunk, (int32_t)c_mask.size() - first_chunk);
         };
@@ -130,50 +149,62 @@ extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, 
         std::vector<Mid> mids;                          // rows of 65..1024 entries
         std::vector<int4> hubs;                         // 128-entry segments of rows > 1024 entries
         {
-            int32_t cur_beg = -1, cur_end = -1, cur_r0 = -1, prev_r = -2;
-            auto close = [&]() {
-                if (cur_beg >= 0 && cur_end > cur_beg) {
-                    const int2 c = add_chunks(cur_beg, cur_end, cur_r0, true);
-                    normal.push_back(make_int4(c.x, c.y, cur_r0, 0));
+            // Short rows (<= 64 entries) are packed first-fit into a few open tasks, in row order: a row goes into the
+            // first open task with room, a new task evicts the oldest open one.  Tasks fill to ~60 of 64 entries
+            // instead of ~48 with plain next-fit (fewer waves, fewer padding gathers) while a task's rows stay within a
+            // short span of the matrix (packing across the whole matrix scatters the epilogue traffic: -6 % on the HBM
+            // graph).
+            // That is for graphs whose source table sits in cache (<= 16 MiB), where the kernel is bound by wave count
+            // and issue slots.  A graph that streams from HBM keeps plain next-fit over ADJACENT rows instead (one open
+            // task): its kernel then needs no per-entry row ids (4 B/entry less metadata) and writes whole runs of
+            // neighbouring rows — worth 6 % there.
+            struct OpenTask { std::vector<int32_t> rows; int room; };
+            std::vector<OpenTask> open_tasks;
+            const int max_open = g->row_ids ? spex::kOpenTasks : 1;
+            auto close_task = [&](size_t k) {
+                OpenTask &ot = open_tasks[k];
+                const int2 c = add_chunks(ot.rows.data(), (int32_t)ot.rows.size(), 0, 0, ot.rows[0]);
+                normal.push_back(make_int4(c.x, c.y, ot.rows[0], 0));
+                open_tasks.erase(open_tasks.begin() + k);
+            };
+            auto flush_window = [&]() {
+                while (!open_tasks.empty()) close_task(0);
+            };
+            auto place_row = [&](int32_t r, int32_t deg) {
+                if (!g->row_ids && !open_tasks.empty() && open_tasks[0].rows.back() != r - 1) close_task(0);  // adjacency
+                for (size_t k = 0; k < open_tasks.size(); ++k) {
+                    if (open_tasks[k].room >= deg) {
+                        open_tasks[k].rows.push_back(r);
+                        open_tasks[k].room -= deg;
+                        if (open_tasks[k].room == 0) close_task(k);
+                        return;
+                    }
                 }
-                cur_beg = cur_end = cur_r0 = -1;
+                if ((int)open_tasks.size() >= max_open) close_task(0);
+                open_tasks.push_back({{r}, spex::kTaskEntries - deg});
+                if (open_tasks.back().room == 0) close_task(open_tasks.size() - 1);
             };
             size_t long_i = 0;
             for (int32_t r = 0; r < n_rows; ++r) {
                 const int32_t b = h_rowptr[r], e = h_rowptr[r + 1], deg = e - b;
                 while (long_i < long_row.size() && long_row[long_i] < r) ++long_i;
-                if (deg == 0) {  // empty row: zero-fill task; it also ends the run of consecutive rows
-                    close();
-                    normal.push_back(make_int4(0, 0, r, 0));
-                    continue;
-                }
-                if (deg > spex::kWgRowMax) {  // hub: its kLongRow-table segments go through global scratch
-                    close();
+                if (deg == 0) {
+                    normal.push_back(make_int4(0, 0, r, 0));   // zero-fill task
+                } else if (deg > spex::kWgRowMax) {            // hub: its kLongRow-table segments go through global scratch
                     hub_row.push_back(r);
                     hub_seg0.push_back(long_seg0[long_i]);      // [begin, end) in the kLongRow segment table
                     hub_seg0.push_back(long_seg0[long_i + 1]);
                     for (int32_t sgi = long_seg0[long_i]; sgi < long_seg0[long_i + 1]; ++sgi) {
-                        const int2 c = add_chunks(seg_beg[sgi], seg_end[sgi], r, false);
+                        const int2 c = add_chunks(nullptr, 0, seg_beg[sgi], seg_end[sgi], r);
                         hubs.push_back(make_int4(c.x, c.y, r, 2 | (sgi << 4)));
                     }
-                    continue;
-                }
-                if (deg > spex::kTaskEntries) {
-                    close();
+                } else if (deg > spex::kTaskEntries) {
                     mids.push_back({r, b, e, (deg + spex::kTaskEntries - 1) / spex::kTaskEntries});
-                    continue;
-                }
-                if (cur_beg >= 0 && prev_r == r - 1 && cur_end == b && e - cur_beg <= spex::kTaskEntries) {
-                    cur_end = e;
                 } else {
-                    close();
-                    cur_beg = b;
-                    cur_end = e;
-                    cur_r0 = r;
+                    place_row(r, deg);
                 }
-                prev_r = r;
             }
-            close();
+            flush_window();
         }
         // assemble 16-wave workgroups: hub segments, then rows combined in-workgroup (heaviest first, first fit, the
         // rest of such a workgroup filled with ordinary tasks), then the ordinary tasks
@@ -205,7 +236,7 @@ extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, 
                     for (int32_t sgi = 0; sgi < md.nseg; ++sgi) {
                         const int32_t sb = md.b + sgi * spex::kTaskEntries;
                         const int32_t se = sb + spex::kTaskEntries < md.e ? sb + spex::kTaskEntries : md.e;
-                        const int2 c = add_chunks(sb, se, md.row, false);
+                        const int2 c = add_chunks(nullptr, 0, sb, se, md.row);
                         task.push_back(make_int4(c.x, c.y, md.row,
                                                  1 | 4 | (sgi == 0 ? 8 : 0) | ((used + sgi) << 4) | (md.nseg << 8)));
                     }
@@ -235,6 +266,7 @@ extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, 
         (rc = upload(&g->chunk_val, c_val.data(), c_val.size())) ||
         (rc = upload(&g->chunk_mask, c_mask.data(), c_mask.size())) ||
         (rc = upload(&g->chunk_eid, c_eid.data(), c_eid.size())) ||
+        (rc = upload(&g->chunk_row, c_row.data(), c_row.size())) ||
         (rc = upload(&g->hub_row, hub_row.data(), hub_row.size())) ||
         (rc = upload(&g->hub_seg0, hub_seg0.data(), hub_seg0.size()))) {
         spex_graph_destroy(g);

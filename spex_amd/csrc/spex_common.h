@@ -35,6 +35,7 @@ constexpr int kSegLen = 128;       // entries per long-row segment
 constexpr int kTaskEntries = 64;   // entries per wave task of the d == 64 kernel (4 chunks: 4 memory round trips)
 constexpr int kWgWaves = 16;       // the d == 64 kernel runs 1024-thread workgroups = 16 wave tasks
 constexpr int kWgRowMax = kWgWaves * kTaskEntries;  // longest row whose segments are combined inside one workgroup
+constexpr int kOpenTasks = 4;      // first-fit packing of short rows keeps this many tasks open
 constexpr int kChunk = 16;         // entries per chunk (one s_load_dwordx16 of offsets, one of values)
 constexpr uint32_t kPadOffset = 0xFFFFFF00u;  // out-of-range source offset of a padding entry
 
@@ -78,6 +79,8 @@ struct spex_graph {
     float *chunk_val = nullptr;    // [n_chunks * 16]
     uint32_t *chunk_mask = nullptr; // [n_chunks]
     uint32_t *chunk_eid = nullptr;  // [n_chunks * 16] edge id of each entry (keep-mask index); read only under dropout
+    bool row_ids = false;           // tasks pack non-adjacent rows (cache-resident graphs): the kernel reads chunk_row
+    int32_t *chunk_row = nullptr;   // [n_chunks * 16] output row of each entry, only when row_ids
     int32_t n_hub = 0;              // rows longer than kWgRowMax (global-scratch path of the d == 64 kernel)
     int32_t *hub_row = nullptr;     // [n_hub]
     int32_t *hub_seg0 = nullptr;    // [2 * n_hub] (first, one-past-last) segment of each hub in the kLongRow segment table

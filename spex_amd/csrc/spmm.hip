@@ -237,10 +237,11 @@ struct DropArgs {
     uint32_t seed_lo, seed_hi;
 };
 
-template <int EPI, bool MASKED>  // EPI 0: Y = y;  1: Y = y (optional), acc_out = (acc_in + y) / acc_div;  2: Y = y + add_in / add_div
+template <int EPI, bool MASKED, bool ROWIDS>  // ROWIDS: rows of a task are listed per entry (else adjacent from task.z); EPI 0: Y = y;  1: Y = y (optional), acc_out = (acc_in + y) / acc_div;  2: Y = y + add_in / add_div
 __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
     const float *__restrict__ X, const uint32_t *__restrict__ chunk_off, const float *__restrict__ chunk_val,
-    const uint32_t *__restrict__ chunk_mask, const int4 *__restrict__ task, int n_tasks, float *__restrict__ Y,
+    const uint32_t *__restrict__ chunk_mask, const int32_t *__restrict__ chunk_row, const int4 *__restrict__ task,
+    int n_tasks, float *__restrict__ Y,
     const float *__restrict__ epi_in, float epi_div, float *__restrict__ acc_out, float *__restrict__ partial,
     const DropArgs drop, const int xcd_contiguous)
 {
@@ -284,11 +285,13 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
     for (int sc = 0; sc < t.y; sc += 4) {
         const int nc = (t.y - sc < 4) ? t.y - sc : 4;  // chunks in this super-chunk (wave-uniform)
         uint32_t my_off = 0u, my_mask = 0u;
+        int my_row = 0;
         float my_val = 0.0f;
         if (lane < nc * kChunk) {
             const size_t e = (size_t)(t.x + sc) * kChunk + lane;
             my_off = __builtin_nontemporal_load(chunk_off + e);   // metadata is read once per launch
             my_val = __builtin_nontemporal_load(chunk_val + e);
+            if (ROWIDS) my_row = __builtin_nontemporal_load(chunk_row + e);
             if (MASKED) {
                 const uint32_t eid = __builtin_nontemporal_load(drop.chunk_eid + e);
                 bool kept;
@@ -320,7 +323,8 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
                 for (int u = 0; u < kChunk; ++u) {
                     ep[u] = 0.0f;
                     if (mask & (1u << u)) {
-                        ep[u] = __builtin_nontemporal_load(El + (size_t)r * 64);
+                        const int rr = ROWIDS ? __builtin_amdgcn_readlane(my_row, c * kChunk + u) : r;
+                        ep[u] = __builtin_nontemporal_load(El + (size_t)rr * 64);
                         ++r;
                     }
                 }
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
             for (int u = 0; u < kChunk; ++u) {
                 acc = fmaf(lane_bcast(my_val, c * kChunk + u), x[u], acc);
                 if (mask & (1u << u)) {  // only packs of whole rows carry mask bits
-                    emit(row, acc, ep[u]);
+                    emit(ROWIDS ? __builtin_amdgcn_readlane(my_row, c * kChunk + u) : row, acc, ep[u]);
                     acc = 0.0f;
                     ++row;
                 }
@@ -400,6 +404,31 @@ __global__ __launch_bounds__(256) void div_kernel(const float *__restrict__ in, 
     if (blockIdx.x == 0 && (int64_t)threadIdx.x < rem) out[n4 * 4 + threadIdx.x] = in[n4 * 4 + threadIdx.x] / div;
 }
 
+// Pick the instantiation of the d == 64 kernel (epilogue form is a template argument of the caller).
+template <int EPI>
+void launch_chunk(bool masked, bool row_ids, dim3 grid, dim3 block, hipStream_t stream, const float *X, const spex_graph *g,
+                  float *Y, const float *epi_in, float epi_div, float *acc_out, const DropArgs &da, int xcd_contig)
+{
+#define SPEX_GO(M, R)                                                                                                  \
+    hipLaunchKernelGGL((spmm_chunk_kernel<EPI, M, R>), grid, block, 0, stream, X, g->chunk_off, g->chunk_val,          \
+                       g->chunk_mask, g->chunk_row, g->task, g->n_tasks, Y, epi_in, epi_div, acc_out, g->partial, da,  \
+                       xcd_contig)
+    if (masked) {
+        if (row_ids) {
+            SPEX_GO(true, true);
+        } else {
+            SPEX_GO(true, false);
+        }
+    } else {
+        if (row_ids) {
+            SPEX_GO(false, true);
+        } else {
+            SPEX_GO(false, false);
+        }
+    }
+#undef SPEX_GO
+}
+
 int launch_spmm(const spex_graph *g, const float *X, float *Y, const float *add_in, float add_div, const float *acc_in,
                 float *acc_out, float acc_div, int32_t d, hipStream_t stream)
 {
@@ -429,20 +458,9 @@ int launch_spmm(const spex_graph *g, const float *X, float *Y, const float *add_
         DropArgs da;
         da.chunk_eid = g->chunk_eid; da.keep = g->keep; da.mode = g->mask_mode; da.keep_prob = g->keep_prob;
         da.seed_lo = (uint32_t)g->seed; da.seed_hi = (uint32_t)(g->seed >> 32);
-#define SPEX_CHUNK(E, M, EIN, EDIV, AOUT)                                                                          \
-    hipLaunchKernelGGL((spmm_chunk_kernel<E, M>), grid, block, 0, stream, X, g->chunk_off, g->chunk_val, g->chunk_mask, \
-                       g->task, g->n_tasks, Y, EIN, EDIV, AOUT, g->partial, da, xcd_contig)
-        if (acc_out) {
-            if (masked) SPEX_CHUNK(1, true, acc_in, acc_div, acc_out);
-            else SPEX_CHUNK(1, false, acc_in, acc_div, acc_out);
-        } else if (add_in) {
-            if (masked) SPEX_CHUNK(2, true, add_in, add_div, (float *)nullptr);
-            else SPEX_CHUNK(2, false, add_in, add_div, (float *)nullptr);
-        } else {
-            if (masked) SPEX_CHUNK(0, true, (const float *)nullptr, 1.0f, (float *)nullptr);
-            else SPEX_CHUNK(0, false, (const float *)nullptr, 1.0f, (float *)nullptr);
-        }
-#undef SPEX_CHUNK
+        if (acc_out) launch_chunk<1>(masked, g->row_ids, grid, block, stream, X, g, Y, acc_in, acc_div, acc_out, da, xcd_contig);
+        else if (add_in) launch_chunk<2>(masked, g->row_ids, grid, block, stream, X, g, Y, add_in, add_div, nullptr, da, xcd_contig);
+        else launch_chunk<0>(masked, g->row_ids, grid, block, stream, X, g, Y, nullptr, 1.0f, nullptr, da, xcd_contig);
     } else if (masked) {
         hipLaunchKernelGGL((spmm_rows_kernel<true>), grid, block, 0, stream, p);
     } else {

@@ -56,6 +56,55 @@ __global__ __launch_bounds__(256) void k1u(const float *__restrict__ X, const in
     Y[(size_t)w * 64 + lane] = acc;
 }
 
+__global__ __launch_bounds__(1024) void k1_wg1024(const float *__restrict__ X, const int *__restrict__ idx,
+                                                   const float *__restrict__ val, float *__restrict__ Y, int per_wave)
+{
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 16 + (threadIdx.x >> 6);
+    const int *ip = idx + (size_t)w * per_wave;
+    const float *vp = val + (size_t)w * per_wave;
+    float acc = 0.f;
+    for (int base = 0; base < per_wave; base += 64) {
+        const int my_i = ip[base + lane];
+        const float my_v = vp[base + lane];
+        for (int i = 0; i < 64; i += U) {
+            float x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) x[u] = X[(size_t)__builtin_amdgcn_readlane(my_i, i + u) * 64 + lane];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                acc = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), i + u)), x[u], acc);
+        }
+    }
+    Y[(size_t)w * 64 + lane] = acc;
+}
+
+// K1 behind a dependent task-descriptor load (what a task table costs)
+__global__ __launch_bounds__(256) void k1_desc(const float *__restrict__ X, const int *__restrict__ idx,
+                                               const float *__restrict__ val, float *__restrict__ Y, int per_wave,
+                                               const int *__restrict__ desc)
+{
+    const int lane = threadIdx.x & 63;
+    const int w0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int w = desc[w0];
+    const int *ip = idx + (size_t)w * per_wave;
+    const float *vp = val + (size_t)w * per_wave;
+    float acc = 0.f;
+    for (int base = 0; base < per_wave; base += 64) {
+        const int my_i = ip[base + lane];
+        const float my_v = vp[base + lane];
+        for (int i = 0; i < 64; i += U) {
+            float x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) x[u] = X[(size_t)__builtin_amdgcn_readlane(my_i, i + u) * 64 + lane];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                acc = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), i + u)), x[u], acc);
+        }
+    }
+    Y[(size_t)w * 64 + lane] = acc;
+}
+
 __global__ __launch_bounds__(256) void k1(const float *__restrict__ X, const int *__restrict__ idx,
                                           const float *__restrict__ val, float *__restrict__ Y, int per_wave)
 {
@@ -169,7 +218,7 @@ int main(int argc, char **argv)
 {
     const int per_wave = 64;
     struct Cfg { size_t rows; size_t waves; const char *name; };
-    Cfg cfgs[] = {{15593, 6540, "4 MB table (Epinion2-sized, cache-resident), 418k gathers = one Epinion2 layer"},
+    Cfg cfgs[] = {{15593, 6544, "4 MB table (Epinion2-sized, cache-resident), 418k gathers = one Epinion2 layer"},
                   {15593, 6540 * 4, "4 MB table (Epinion2-sized, cache-resident), 1.67M gathers"},
                   {15593, 6540 * 16, "4 MB table (Epinion2-sized, cache-resident), 6.7M gathers"},
                   {1u << 23, 1u << 20, "2 GB table (HBM-resident), 67M gathers"}};
@@ -200,7 +249,10 @@ int main(int argc, char **argv)
         CK(hipEventCreate(&e0));
         CK(hipEventCreate(&e1));
         printf("== %s\n", c.name);
-        for (int k = 1; k <= 9; ++k) {
+        int *desc;
+        CK(hipMalloc(&desc, c.waves * 4));
+        { std::vector<int> hd(c.waves); for (size_t i = 0; i < c.waves; ++i) hd[i] = (int)i; CK(hipMemcpy(desc, hd.data(), c.waves * 4, hipMemcpyHostToDevice)); }
+        for (int k = 1; k <= 11; ++k) {
             float best = 1e30f;
             for (int rep = 0; rep < 6; ++rep) {
                 CK(hipEventRecord(e0));
@@ -214,6 +266,8 @@ int main(int argc, char **argv)
                     case 7: hipLaunchKernelGGL(k1u<32>, grid, block, 0, 0, X, idx, val, Y, per_wave); break;
                     case 8: hipLaunchKernelGGL(k1u<64>, grid, block, 0, 0, X, idx, val, Y, per_wave); break;
                     case 9: hipLaunchKernelGGL(k1u<8>, grid, block, 0, 0, X, idx, val, Y, per_wave); break;
+                    case 10: hipLaunchKernelGGL(k1_wg1024, dim3((unsigned)(c.waves / 16)), dim3(1024), 0, 0, X, idx, val, Y, per_wave); break;
+                    case 11: hipLaunchKernelGGL(k1_desc, grid, block, 0, 0, X, idx, val, Y, per_wave, desc); break;
                 }
                 CK(hipEventRecord(e1));
                 CK(hipEventSynchronize(e1));
@@ -225,9 +279,10 @@ int main(int argc, char **argv)
             CK(hipMemcpy(hy.data(), Y, 256, hipMemcpyDeviceToHost));
             const double gb = (double)n_idx * 264.0 / 1e9;
             printf("  K%d%s  %9.1f us   %7.0f GB/s (264 B/gather)   %6.2f G gathers/s   check %.1f\n", k,
-                   k == 4 ? "(x4,4 in flight)" : k == 5 ? "(x4,8)" : k == 6 ? "(x4,16)" : k == 7 ? "(K1, 32 in flight)" : k == 8 ? "(K1, 64 in flight)" : k == 9 ? "(K1, 8 in flight)" : "", best * 1e3, gb / (best * 1e-3),
+                   k == 4 ? "(x4,4 in flight)" : k == 5 ? "(x4,8)" : k == 6 ? "(x4,16)" : k == 7 ? "(K1, 32 in flight)" : k == 8 ? "(K1, 64 in flight)" : k == 9 ? "(K1, 8 in flight)" : k == 10 ? "(K1, 1024-thread blocks)" : k == 11 ? "(K1 behind a descriptor load)" : "", best * 1e3, gb / (best * 1e-3),
                    n_idx / (best * 1e-3) / 1e9, hy[0]);
         }
+        CK(hipFree(desc));
         CK(hipFree(X)); CK(hipFree(Y)); CK(hipFree(val)); CK(hipFree(idx)); CK(hipFree(off));
     }
     return 0;
