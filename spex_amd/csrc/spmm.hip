@@ -40,6 +40,7 @@ struct SpmmParams {
     float *Y;
     const float *add_in;
     float add_div;
+    float out_div;  // y = (y + add_in / add_div) / out_div
     const float *acc_in;
     float *acc_out;
     float acc_div;
@@ -166,6 +167,7 @@ __device__ __forceinline__ void finish_row(const SpmmParams &p, int r, int c, fl
 {
     const size_t o = (size_t)r * p.d + c;
     if (p.add_in) y = y + p.add_in[o] / p.add_div;
+    if (p.out_div != 1.0f) y = y / p.out_div;
     if (p.Y) p.Y[o] = y;
     if (p.acc_out) p.acc_out[o] = (p.acc_in[o] + y) / p.acc_div;
 }
@@ -242,7 +244,8 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
     const float *__restrict__ X, const uint32_t *__restrict__ chunk_off, const float *__restrict__ chunk_val,
     const uint32_t *__restrict__ chunk_mask, const int32_t *__restrict__ chunk_row, const int4 *__restrict__ task,
     int n_tasks, float *__restrict__ Y,
-    const float *__restrict__ epi_in, float epi_div, float *__restrict__ acc_out, float *__restrict__ partial,
+    const float *__restrict__ epi_in, float epi_div, float out_div, float *__restrict__ acc_out,
+    float *__restrict__ partial,
     const DropArgs drop, const int xcd_contiguous)
 {
     __shared__ float s_part[kWgWaves][kWave];  // segment sums of the rows this workgroup combines
@@ -275,7 +278,9 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
             __builtin_nontemporal_store(s, acc_out + o);
         } else {
             if (epi_div != 1.0f) e = e / epi_div;
-            __builtin_nontemporal_store(y + e, Y + o);
+            float s = y + e;
+            if (out_div != 1.0f) s = s / out_div;
+            __builtin_nontemporal_store(s, Y + o);
         }
     };
 
@@ -407,12 +412,13 @@ __global__ __launch_bounds__(256) void div_kernel(const float *__restrict__ in, 
 // Pick the instantiation of the d == 64 kernel (epilogue form is a template argument of the caller).
 template <int EPI>
 void launch_chunk(bool masked, bool row_ids, dim3 grid, dim3 block, hipStream_t stream, const float *X, const spex_graph *g,
-                  float *Y, const float *epi_in, float epi_div, float *acc_out, const DropArgs &da, int xcd_contig)
+                  float *Y, const float *epi_in, float epi_div, float out_div, float *acc_out, const DropArgs &da,
+                  int xcd_contig)
 {
 #define SPEX_GO(M, R)                                                                                                  \
     hipLaunchKernelGGL((spmm_chunk_kernel<EPI, M, R>), grid, block, 0, stream, X, g->chunk_off, g->chunk_val,          \
-                       g->chunk_mask, g->chunk_row, g->task, g->n_tasks, Y, epi_in, epi_div, acc_out, g->partial, da,  \
-                       xcd_contig)
+                       g->chunk_mask, g->chunk_row, g->task, g->n_tasks, Y, epi_in, epi_div, out_div, acc_out, g->partial, \
+                       da, xcd_contig)
     if (masked) {
         if (row_ids) {
             SPEX_GO(true, true);
@@ -430,14 +436,14 @@ void launch_chunk(bool masked, bool row_ids, dim3 grid, dim3 block, hipStream_t 
 }
 
 int launch_spmm(const spex_graph *g, const float *X, float *Y, const float *add_in, float add_div, const float *acc_in,
-                float *acc_out, float acc_div, int32_t d, hipStream_t stream)
+                float *acc_out, float acc_div, int32_t d, hipStream_t stream, float out_div = 1.0f)
 {
     if (g->n_rows == 0) return SPEX_OK;
     SpmmParams p;
     p.rowptr = g->rowptr; p.col = g->col; p.val = g->val; p.edge_id = g->edge_id;
     p.seg_beg = g->seg_beg; p.seg_end = g->seg_end; p.long_row = g->long_row; p.long_seg0 = g->long_seg0;
     p.n_rows = g->n_rows; p.n_seg = g->n_seg; p.n_long = g->n_long;
-    p.X = X; p.Y = Y; p.add_in = add_in; p.add_div = add_div; p.acc_in = acc_in; p.acc_out = acc_out; p.acc_div = acc_div;
+    p.X = X; p.Y = Y; p.add_in = add_in; p.add_div = add_div; p.out_div = out_div; p.acc_in = acc_in; p.acc_out = acc_out; p.acc_div = acc_div;
     p.partial = g->partial; p.d = d;
     p.mask_mode = g->mask_mode; p.keep = g->keep; p.keep_prob = g->keep_prob;
     p.seed_lo = (uint32_t)g->seed; p.seed_hi = (uint32_t)(g->seed >> 32);
@@ -458,9 +464,9 @@ int launch_spmm(const spex_graph *g, const float *X, float *Y, const float *add_
         DropArgs da;
         da.chunk_eid = g->chunk_eid; da.keep = g->keep; da.mode = g->mask_mode; da.keep_prob = g->keep_prob;
         da.seed_lo = (uint32_t)g->seed; da.seed_hi = (uint32_t)(g->seed >> 32);
-        if (acc_out) launch_chunk<1>(masked, g->row_ids, grid, block, stream, X, g, Y, acc_in, acc_div, acc_out, da, xcd_contig);
-        else if (add_in) launch_chunk<2>(masked, g->row_ids, grid, block, stream, X, g, Y, add_in, add_div, nullptr, da, xcd_contig);
-        else launch_chunk<0>(masked, g->row_ids, grid, block, stream, X, g, Y, nullptr, 1.0f, nullptr, da, xcd_contig);
+        if (acc_out) launch_chunk<1>(masked, g->row_ids, grid, block, stream, X, g, Y, acc_in, acc_div, 1.0f, acc_out, da, xcd_contig);
+        else if (add_in) launch_chunk<2>(masked, g->row_ids, grid, block, stream, X, g, Y, add_in, add_div, out_div, nullptr, da, xcd_contig);
+        else launch_chunk<0>(masked, g->row_ids, grid, block, stream, X, g, Y, nullptr, 1.0f, 1.0f, nullptr, da, xcd_contig);
     } else if (masked) {
         hipLaunchKernelGGL((spmm_rows_kernel<true>), grid, block, 0, stream, p);
     } else {
@@ -555,6 +561,20 @@ extern "C" int spex_propagate_bwd_f32(const spex_graph_t *gt, const float *g_out
     hipStream_t s = (hipStream_t)stream;
     const size_t sz = (size_t)gt->n_rows * d;
     if (sz == 0) return SPEX_OK;
+    if (L >= 1 && ((L + 1) & L) == 0) {
+        // L+1 is a power of two: scaling by it commutes with every rounding below, so carry H_l = (L+1) G_l instead
+        // (H_L = g, H_l = g + A^T H_{l+1}) and divide once in the last launch's epilogue — bit-identical to the
+        // general path, one elementwise pass and one launch fewer.
+        const float *cur = g_out;
+        for (int32_t l = L - 1; l >= 0; --l) {
+            float *nxt = (l == 0) ? grad_E0 : ws + (size_t)(1 + (l & 1)) * sz;
+            rc = launch_spmm(gt, cur, nxt, g_out, 1.0f, nullptr, nullptr, 1.0f, d, s, l == 0 ? (float)(L + 1) : 1.0f);
+            if (rc) return rc;
+            cur = nxt;
+        }
+        SPEX_HIP(hipGetLastError());
+        return SPEX_OK;
+    }
     // gs = g_out / (L+1) is every layer's share of the mean's gradient and the first gather source (= G_L).
     float *gs = (L == 0) ? grad_E0 : ws;
     {
