@@ -164,6 +164,16 @@ int spex_ngcf_layer_f32(const float *ego, const float *side, const float *W_gc, 
 int spex_expert_gate_f32(const float *raw, const float *prop, const float *att_exp /*[2d,2]*/, float *mixed, int32_t n,
                          int32_t d, void *stream);
 
+/* ------------------------------------------------------------------------------------------------ negative sampler
+ * Replaces LightTrainData.ng_sample, LightGCN_SPEX/code/utility1/dataloader.py:250-265 (distribution, not stream):
+ * for each of n_pos positives (user d_pos_user[p]) draw num_ng items uniformly from [0, num_item), redrawing while the
+ * item is in the user's sorted interaction list d_items[d_rowptr[u] : d_rowptr[u+1]] (CSR of R, device).
+ * d_out: int64[n_pos * num_ng], slot p * num_ng + t.  Counter-based (philox4x32-10 keyed by `seed`): reproducible,
+ * order-independent; not NumPy's stream (the host sampler of the drop-in Loader replays that one exactly).
+ */
+int spex_sample_negatives(const int32_t *d_rowptr, const int32_t *d_items, int32_t n_user_rows, const int64_t *d_pos_user,
+                          int64_t n_pos, int32_t num_ng, int32_t num_item, uint64_t seed, int64_t *d_out, void *stream);
+
 /* ------------------------------------------------------------------------------------------------ profiling hook
  * Not part of any reference interface: lets a caller time the dominant kernel itself, in place, on the stream it is
  * launched on (bench.py's roofline figure).  While a timer is attached to a graph, every launch of the graph's main

@@ -180,6 +180,34 @@ class LightTrainData(Dataset):
         pos[pos == len(self._train_keys)] = 0
         return (self._train_keys[pos] == key) if len(self._train_keys) else np.zeros(len(key), bool)
 
+    def ng_sample_device(self, device="cuda", seed=None):
+        """Same distribution as ng_sample(), drawn on the GPU (spex_sample_negatives: one thread per negative, Philox
+        draws, binary search in the user's sorted item list).  Not NumPy's stream: the negatives for a given seed
+        differ from the reference's, their distribution does not.  `seed` defaults to a draw from NumPy's global RNG so
+        that np.random.seed(...) still makes runs reproducible."""
+        import torch
+        from spex_amd import ops
+        if seed is None:
+            seed = int(np.random.randint(0, 2 ** 31 - 1)) * 2654435761 % (2 ** 63)
+        dev = torch.device(device)
+        if getattr(self, "_dev_csr", None) is None or self._dev_csr[0].device != dev:
+            n_rows = int(self._ps[:, 0].max()) + 1 if len(self._ps) else 0
+            if len(self._train_keys):
+                n_rows = max(n_rows, int(self._train_keys[-1] // self.num_item) + 1)
+            users = (self._train_keys // self.num_item).astype(np.int64)
+            rowptr = np.zeros(n_rows + 1, np.int64)
+            np.cumsum(np.bincount(users, minlength=n_rows), out=rowptr[1:])
+            items = (self._train_keys % self.num_item).astype(np.int32)          # keys are sorted: rows come out sorted
+            self._dev_csr = (torch.from_numpy(rowptr.astype(np.int32)).to(dev), torch.from_numpy(items).to(dev),
+                             torch.from_numpy(np.ascontiguousarray(self._ps[:, 0])).to(dev))
+        rowptr, items, pos_user = self._dev_csr
+        neg = ops.sample_negatives(rowptr, items, pos_user, self.num_ng, self.num_item, seed).cpu().numpy()
+        P, S = len(self._ps), len(self._ps) * self.num_ng
+        self.users_fill = np.concatenate([self._ps[:, 0], np.repeat(self._ps[:, 0], self.num_ng)])
+        self.items_fill = np.concatenate([self._ps[:, 1], neg])
+        self.labels_fill_np = np.concatenate([np.ones(P, np.int64), np.zeros(S, np.int64)])
+        self._features_ng = None
+
     def ng_sample(self, block=8192):
         """Slot k (positive k // num_ng, user u_k) takes the first not-yet-consumed stream value j with (u_k, j) not a
         training pair; rejected values are consumed too.  The stream is processed in blocks: inside a block the

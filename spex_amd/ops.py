@@ -101,6 +101,18 @@ def expert_gate(raw, prop, att_exp):
     return mixed
 
 
+def sample_negatives(rowptr, items, pos_user, num_ng, num_item, seed):
+    """num_ng uniform non-interacted items per positive, on the GPU (spex_sample_negatives).  rowptr / items: device
+    int32 CSR of the user-item matrix R with sorted rows; pos_user: device int64.  Returns int64 [len(pos_user)*num_ng]."""
+    for t, n, dt in ((rowptr, "rowptr", torch.int32), (items, "items", torch.int32), (pos_user, "pos_user", torch.int64)):
+        if not (t.is_cuda and t.dtype == dt and t.is_contiguous()):
+            raise ValueError(f"{n}: need a contiguous {dt} CUDA tensor")
+    out = torch.empty(pos_user.numel() * num_ng, dtype=torch.int64, device=pos_user.device)
+    _lib.call("spex_sample_negatives", _ptr(rowptr), _ptr(items), rowptr.numel() - 1, _ptr(pos_user), pos_user.numel(),
+              int(num_ng), int(num_item), int(seed), _ptr(out), _stream())
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ autograd glue
 def _flat_tables(user_w, item_w):
     """The two embedding tables as one [N, d] buffer.  The drop-in model allocates them back-to-back so this is a

@@ -408,3 +408,47 @@ def test_timer_hook_brackets_the_main_kernel(G, golden):
     assert len(gr.read_timer()) == 0                                   # reset by the read
     gr.detach_timer()
     gr.spmm(X)
+
+
+def test_gpu_negative_sampler(epinion2):
+    """spex_sample_negatives: never a training pair, reproducible per seed, uniform over each user's non-interacted
+    items (chi-square on a small catalogue), wired into LightTrainData."""
+    from spex_amd import ops
+    rng = np.random.default_rng(0)
+    U, I, num_ng = 64, 40, 5
+    dense = rng.random((U, I)) < 0.4
+    dense[:, 0] = True
+    dense[7, :] = True
+    dense[7, 33] = False                                   # a user with a single admissible item
+    rowptr = np.r_[0, np.cumsum(dense.sum(1))].astype(np.int32)
+    items = np.concatenate([np.nonzero(r)[0] for r in dense]).astype(np.int32)
+    reps = 4000
+    pos_user = np.repeat(np.arange(U), reps).astype(np.int64)
+    neg = ops.sample_negatives(t(rowptr), t(items), t(pos_user), num_ng, I, seed=123).cpu().numpy().reshape(-1, num_ng)
+    assert not dense[pos_user[:, None].repeat(num_ng, 1), neg].any()
+    assert (neg[pos_user == 7] == 33).all()
+    again = ops.sample_negatives(t(rowptr), t(items), t(pos_user), num_ng, I, seed=123).cpu().numpy().reshape(-1, num_ng)
+    other = ops.sample_negatives(t(rowptr), t(items), t(pos_user), num_ng, I, seed=124).cpu().numpy().reshape(-1, num_ng)
+    assert np.array_equal(neg, again) and (neg != other).mean() > 0.5
+    for u in (0, 1, 30):                                   # chi-square against the uniform law over admissible items
+        adm = np.nonzero(~dense[u])[0]
+        cnt = np.bincount(neg[pos_user == u].reshape(-1), minlength=I)[adm]
+        exp = cnt.sum() / len(adm)
+        chi2 = ((cnt - exp) ** 2 / exp).sum()
+        assert chi2 < 3.0 * len(adm), (u, chi2)            # dof = len(adm)-1; 3x is far out in the tail
+    # through the dataset class on Epinion2
+    import scipy.sparse as sp
+    import utility1.dataloader as dl
+    tr = epinion2["train"]
+    mat = sp.coo_matrix((np.ones(len(tr), np.float32), (tr[:, 0], tr[:, 1])), shape=(3186, 12407)).tocsr()
+    td = dl.LightTrainData(tr.tolist(), 12407, mat)
+    np.random.seed(2020)
+    td.ng_sample_device()
+    assert len(td) == 6 * len(tr) and td.labels_fill_np.sum() == len(tr)
+    ng = np.asarray(td.features_ng)
+    assert np.asarray(mat[ng[:, 0], ng[:, 1]]).sum() == 0            # no negative is a training pair
+    assert np.array_equal(ng[:, 0], np.repeat(tr[:, 0], 5))
+    first = td.items_fill.copy()
+    np.random.seed(2020)
+    td.ng_sample_device()
+    assert np.array_equal(first, td.items_fill)                       # np.random.seed still pins the run
