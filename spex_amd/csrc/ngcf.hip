@@ -35,13 +35,24 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void ngcf_layer_kernel(
     const int j = threadIdx.x & (kWave - 1);
     const int wave_global = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const int n_waves = gridDim.x * kWavesPerBlock;
+    // Lane j keeps row j of both weight matrices in registers.  Reading those rows straight from global memory is a
+    // 256-byte-strided access (64 cache lines per wave instruction, 32 KB per wave): stage the two matrices through
+    // LDS once per workgroup instead — coalesced float4 loads in, padded rows (stride 65) out, conflict-free.
+    __shared__ float s_w[2][64 * 65];
+    for (int i = threadIdx.x; i < 64 * 16; i += blockDim.x) {       // 1024 float4 per matrix
+        const int r = i >> 4, c4 = (i & 15) * 4;
+        const float4 a = *reinterpret_cast<const float4 *>(W_gc + r * 64 + c4);
+        const float4 b = *reinterpret_cast<const float4 *>(W_bi + r * 64 + c4);
+        float *pa = &s_w[0][r * 65 + c4], *pb = &s_w[1][r * 65 + c4];
+        pa[0] = a.x; pa[1] = a.y; pa[2] = a.z; pa[3] = a.w;
+        pb[0] = b.x; pb[1] = b.y; pb[2] = b.z; pb[3] = b.w;
+    }
+    __syncthreads();
     float wg[64], wb[64];
 #pragma unroll
-    for (int k = 0; k < 64; k += 4) {
-        const float4 a = *reinterpret_cast<const float4 *>(W_gc + j * 64 + k);
-        const float4 b = *reinterpret_cast<const float4 *>(W_bi + j * 64 + k);
-        wg[k] = a.x; wg[k + 1] = a.y; wg[k + 2] = a.z; wg[k + 3] = a.w;
-        wb[k] = b.x; wb[k + 1] = b.y; wb[k + 2] = b.z; wb[k + 3] = b.w;
+    for (int k = 0; k < 64; ++k) {
+        wg[k] = s_w[0][j * 65 + k];
+        wb[k] = s_w[1][j * 65 + k];
     }
     const float bg = b_gc[j], bb = b_bi[j];
     for (int r = wave_global; r < n; r += n_waves) {

@@ -90,14 +90,14 @@ class PartitionedLightGCN:
         z = lambda *s: torch.zeros(s, dtype=torch.float32, device=self.device)
         self.gathered = z(p.n_padded, d)                 # all-gather target == SpMM gather source
         self.send = z(p.max_rows, d)                     # padded local shard
-        self.buf = [z(self.n_local, d), z(self.n_local, d)]
         self.light_out = z(self.n_local, d)
         self.out_gathered = z(p.n_padded, d)
 
     # -- the one exchange step of the data path
     def all_gather_rows(self, local, out=None):
         out = self.gathered if out is None else out
-        self.send[: self.n_local].copy_(local)
+        if local.data_ptr() != self.send.data_ptr():      # a layer's SpMM writes straight into the send buffer
+            self.send[: self.n_local].copy_(local)
         if self.world == 1:
             out.copy_(self.send)
         else:
@@ -110,7 +110,7 @@ class PartitionedLightGCN:
         for l in range(self.L):
             X = self.all_gather_rows(cur)
             last = l == self.L - 1
-            nxt = None if last else self.buf[l & 1]
+            nxt = None if last else self.send[: self.n_local]     # next layer's all-gather source, no copy
             self.graph.spmm(X, Y=nxt, acc_in=E0_local if l == 0 else self.light_out, acc_out=self.light_out,
                             acc_div=float(self.L + 1) if last else 1.0)
             cur = nxt
