@@ -176,16 +176,17 @@ int spex_sample_negatives(const int32_t *d_rowptr, const int32_t *d_items, int32
 
 /* ------------------------------------------------------------------------------------------------ profiling hook
  * Not part of any reference interface: lets a caller time the dominant kernel itself, in place, on the stream it is
- * launched on (bench.py's roofline figure).  While a timer is attached to a graph, every launch of the graph's main
- * SpMM kernel (not the long-row fix-up) — or every n-th such launch — is bracketed by a hipEvent pair until
- * `capacity` pairs are used.
- * spex_timer_read synchronises on the recorded events and returns their elapsed times in milliseconds.
+ * launched on (bench.py's roofline figure).  While a timer is attached to a graph, every (or every n-th) call of
+ * spex_spmm_f32 / spex_propagate_f32 / spex_propagate_bwd_f32 on it is bracketed by ONE hipEvent pair around all the
+ * main SpMM launches of that call (a 3-layer propagation = one bracket of three back-to-back launches), until
+ * `capacity` brackets are used.  spex_timer_read synchronises on the recorded events and returns, per bracket, the
+ * elapsed milliseconds and the number of SpMM launches inside it.
  */
 typedef struct spex_timer spex_timer_t;
-int spex_timer_create(int32_t capacity, int32_t every /* bracket every n-th launch */, spex_timer_t **out);
+int spex_timer_create(int32_t capacity, int32_t every /* bracket every n-th call */, spex_timer_t **out);
 int spex_timer_destroy(spex_timer_t *t);
 int spex_timer_attach(spex_graph_t *g, spex_timer_t *t /* NULL detaches */);
-int spex_timer_read(spex_timer_t *t, float *h_ms, int32_t max_count, int32_t *count, int reset);
+int spex_timer_read(spex_timer_t *t, float *h_ms, int32_t *h_launches, int32_t max_count, int32_t *count, int reset);
 
 #ifdef __cplusplus
 }

@@ -37,7 +37,7 @@ SIGNATURES = {
     "spex_timer_create": (ctypes.c_int, [c_i32, c_i32, ctypes.POINTER(c_vp)]),
     "spex_timer_destroy": (ctypes.c_int, [c_vp]),
     "spex_timer_attach": (ctypes.c_int, [c_vp, c_vp]),
-    "spex_timer_read": (ctypes.c_int, [c_vp, c_vp, c_i32, ctypes.POINTER(c_i32), ctypes.c_int]),
+    "spex_timer_read": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, ctypes.POINTER(c_i32), ctypes.c_int]),
 }
 
 _lib = None

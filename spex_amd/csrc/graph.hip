@@ -321,6 +321,7 @@ extern "C" int spex_timer_create(int32_t capacity, int32_t every, spex_timer_t *
     t->every = every;
     t->start.resize(capacity);
     t->stop.resize(capacity);
+    t->launches.assign(capacity, 0);
     for (int32_t i = 0; i < capacity; ++i) {
         SPEX_HIP(hipEventCreate(&t->start[i]));
         SPEX_HIP(hipEventCreate(&t->stop[i]));
@@ -347,13 +348,15 @@ extern "C" int spex_timer_attach(spex_graph_t *g, spex_timer_t *t)
     return SPEX_OK;
 }
 
-extern "C" int spex_timer_read(spex_timer_t *t, float *h_ms, int32_t max_count, int32_t *count, int reset)
+extern "C" int spex_timer_read(spex_timer_t *t, float *h_ms, int32_t *h_launches, int32_t max_count, int32_t *count,
+                               int reset)
 {
     SPEX_CHECK_ARG(t && count, "spex_timer_read: NULL argument");
     int32_t n = t->used < max_count ? t->used : max_count;
     for (int32_t i = 0; i < n; ++i) {
         SPEX_HIP(hipEventSynchronize(t->stop[i]));
         SPEX_HIP(hipEventElapsedTime(&h_ms[i], t->start[i], t->stop[i]));
+        if (h_launches) h_launches[i] = t->launches[i];
     }
     *count = n;
     if (reset) {

@@ -44,8 +44,10 @@ constexpr uint32_t kPadOffset = 0xFFFFFF00u;  // out-of-range source offset of a
 struct spex_timer {
     std::vector<hipEvent_t> start, stop;
     int32_t used = 0;
-    int32_t every = 1;   // bracket every `every`-th launch
-    int64_t seen = 0;    // launches seen since the last reset
+    std::vector<int32_t> launches;  // main-kernel launches inside each bracket
+    int32_t every = 1;   // bracket every `every`-th API call (spmm / propagate / propagate_bwd)
+    int64_t seen = 0;    // API calls seen since the last reset
+    bool open = false;   // a bracket is open (launch_spmm counts its launches instead of bracketing them itself)
 };
 
 // The opaque handle.  All pointers are device memory owned by the handle.

@@ -148,12 +148,18 @@ class SpexGraph:
         _lib.call("spex_timer_attach", self._h, t)
         self._timer, self._timer_cap = t, int(capacity)
 
-    def read_timer(self, reset=True):
-        """Elapsed milliseconds of the SpMM launches recorded since the last reset (synchronises on them)."""
+    def read_timer(self, reset=True, per_launch=True):
+        """Timings recorded since the last reset (synchronises on them).  per_launch=True: milliseconds per SpMM launch
+        of every bracket (bracket time / launches in it); False: (bracket ms, launches per bracket)."""
         buf = (ctypes.c_float * self._timer_cap)()
+        cnt = (ctypes.c_int32 * self._timer_cap)()
         n = ctypes.c_int32()
-        _lib.call("spex_timer_read", self._timer, buf, self._timer_cap, ctypes.byref(n), 1 if reset else 0)
-        return np.frombuffer(buf, dtype=np.float32, count=n.value).copy()
+        _lib.call("spex_timer_read", self._timer, buf, cnt, self._timer_cap, ctypes.byref(n), 1 if reset else 0)
+        ms = np.frombuffer(buf, dtype=np.float32, count=n.value).copy()
+        launches = np.frombuffer(cnt, dtype=np.int32, count=n.value).copy()
+        if per_launch:
+            return ms / np.maximum(launches, 1)
+        return ms, launches
 
     def detach_timer(self):
         if getattr(self, "_timer", None) is not None:

@@ -1,5 +1,5 @@
 import sys, os, torch, numpy as np
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spex_amd.datasets import load_epinion2, xavier_uniform_np
 from spex_amd.graph import SpexGraph, lightgcn_norm_adj
 from spex_amd.trainer import LightGCNStepper
