@@ -5,10 +5,9 @@
 //   out = [ego | e1 / max(||e1||_2, 1e-12)]
 // spex_expert_gate_f32 replaces LightGCN_SPEX/code/utility1/model_expert_s.py:156-161.
 //
-// Both are bandwidth-bound per row (2 x 256 B in, 512 B out; the two 64x64 weight matrices are 32 KB and live in
-// registers: lane j keeps row j of each, and the row's 64 inputs are broadcast lane-by-lane with v_readlane).  The
-// [N,64]x[64,64] products are 8 kflop per row — 128 MFLOP on Epinion2 — far below what would justify staging tiles
-// for MFMA; one wave per row keeps the whole layer a single streaming pass fused behind the SpMM output.
+// Both are bandwidth/latency-bound per row (2 x 256 B in, 512 B out; 8 kflop per row, 128 MFLOP on Epinion2).  The
+// NGCF layer's two [N,64]x[64,64] products run on the matrix cores (f32 MFMA, see the kernel); the gate is a pair of
+// 128-long dot products per row and stays on the vector unit.
 #include "spex_common.h"
 
 using namespace spex;
@@ -27,52 +26,114 @@ __device__ __forceinline__ float bcast(float v, int src)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
 
+// The two [N,64]x[64,64] products are the one GEMM-shaped piece of this path, so they run on the matrix cores:
+// v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate — a k-ordered fmaf chain, bit-identical to the scalar loop it
+// replaces; there is no reduced-precision fp32 path on gfx950 and none is wanted here).  One wave owns a tile of 16
+// rows: the 16x64 `side` tile and the 16x64 (ego * side) tile go through LDS (row stride 66 floats: the A-operand read
+// pattern row*66 + 4s + h then hits 32 distinct banks per half-wave), the two 64x64 weight matrices are staged once
+// per workgroup with the same stride for the B operands, and the four 16x16 output blocks of each product accumulate
+// in 2 x 4 x 4 registers.  Bias, LeakyReLU, the add, the row L2-norm (16-lane butterfly) and the concat write follow
+// in registers.  8 kflop per row is tiny — the kernel stays bandwidth/latency-bound — but the MFMA form needs 128
+// matrix instructions per tile where the vector form needed 2 x 64 x (v_readlane + v_fmac) per ROW.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kLdsStride = 66;
+
 __global__ __launch_bounds__(kWave *kWavesPerBlock) void ngcf_layer_kernel(
     const float *__restrict__ ego, const float *__restrict__ side, const float *__restrict__ W_gc,
     const float *__restrict__ b_gc, const float *__restrict__ W_bi, const float *__restrict__ b_bi,
     float *__restrict__ out, int ld_out, float *__restrict__ e1_out, int n, float slope)
 {
-    const int j = threadIdx.x & (kWave - 1);
-    const int wave_global = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    const int n_waves = gridDim.x * kWavesPerBlock;
-    // Lane j keeps row j of both weight matrices in registers.  Reading those rows straight from global memory is a
-    // 256-byte-strided access (64 cache lines per wave instruction, 32 KB per wave): stage the two matrices through
-    // LDS once per workgroup instead — coalesced float4 loads in, padded rows (stride 65) out, conflict-free.
-    __shared__ float s_w[2][64 * 65];
-    for (int i = threadIdx.x; i < 64 * 16; i += blockDim.x) {       // 1024 float4 per matrix
+    __shared__ float s_w[2][64 * kLdsStride];                       // W_gc, W_bi as [out j][in k]
+    __shared__ float s_t[kWavesPerBlock][2][16 * kLdsStride];       // per wave: side tile, (ego*side) tile
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 64 * 16; i += blockDim.x) {       // 1024 float4 per matrix, coalesced
         const int r = i >> 4, c4 = (i & 15) * 4;
         const float4 a = *reinterpret_cast<const float4 *>(W_gc + r * 64 + c4);
         const float4 b = *reinterpret_cast<const float4 *>(W_bi + r * 64 + c4);
-        float *pa = &s_w[0][r * 65 + c4], *pb = &s_w[1][r * 65 + c4];
+        float *pa = &s_w[0][r * kLdsStride + c4], *pb = &s_w[1][r * kLdsStride + c4];
         pa[0] = a.x; pa[1] = a.y; pa[2] = a.z; pa[3] = a.w;
         pb[0] = b.x; pb[1] = b.y; pb[2] = b.z; pb[3] = b.w;
     }
     __syncthreads();
-    float wg[64], wb[64];
+    const int i16 = lane & 15, h = lane >> 4;                       // MFMA operand coordinates of this lane
+    float bias_g[4], bias_b[4];
 #pragma unroll
-    for (int k = 0; k < 64; ++k) {
-        wg[k] = s_w[0][j * 65 + k];
-        wb[k] = s_w[1][j * 65 + k];
+    for (int b = 0; b < 4; ++b) {
+        bias_g[b] = b_gc[16 * b + i16];
+        bias_b[b] = b_bi[16 * b + i16];
     }
-    const float bg = b_gc[j], bb = b_bi[j];
-    for (int r = wave_global; r < n; r += n_waves) {
-        const float e = ego[(size_t)r * 64 + j], s = side[(size_t)r * 64 + j];
-        const float t = e * s;
-        float a1 = 0.0f, a2 = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 64; ++k) {
-            a1 = fmaf(bcast(s, k), wg[k], a1);
-            a2 = fmaf(bcast(t, k), wb[k], a2);
+    float *t_side = s_t[wave][0], *t_prod = s_t[wave][1];
+    const int n_tiles = (n + 15) >> 4;
+    for (int tile = blockIdx.x * kWavesPerBlock + wave; tile < n_tiles; tile += gridDim.x * kWavesPerBlock) {
+        const int r0 = tile << 4;
+        // stage the tile (lane == column: coalesced 256-byte rows) and pass `ego` through to the output's first half
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int r = r0 + i;
+            float e = 0.0f, sd = 0.0f;
+            if (r < n) {
+                e = ego[(size_t)r * 64 + lane];
+                sd = side[(size_t)r * 64 + lane];
+                out[(size_t)r * ld_out + lane] = e;
+            }
+            t_side[i * kLdsStride + lane] = sd;
+            t_prod[i * kLdsStride + lane] = e * sd;
         }
-        a1 += bg;
-        a2 += bb;
-        a1 = a1 >= 0.0f ? a1 : a1 * slope;
-        a2 = a2 >= 0.0f ? a2 : a2 * slope;
-        const float e1 = a1 + a2;
-        const float nrm = sqrtf(wave_sum(e1 * e1));
-        out[(size_t)r * ld_out + j] = e;
-        out[(size_t)r * ld_out + 64 + j] = e1 / fmaxf(nrm, 1e-12f);
-        if (e1_out) e1_out[(size_t)r * 64 + j] = e1;
+        // (each wave only reads back its own tile: no workgroup barrier, the LDS ops of one wave are ordered)
+        f32x4 acc_g[4], acc_b[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            acc_g[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc_b[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {
+            const int k = 4 * s + h;
+            const float a_g = t_side[i16 * kLdsStride + k];
+            const float a_b = t_prod[i16 * kLdsStride + k];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float w_g = s_w[0][(16 * b + i16) * kLdsStride + k];
+                const float w_b = s_w[1][(16 * b + i16) * kLdsStride + k];
+                acc_g[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_g, w_g, acc_g[b], 0, 0, 0);
+                acc_b[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_b, w_b, acc_b[b], 0, 0, 0);
+            }
+        }
+        // C layout: col = 16 b + i16, row = 4 h + reg
+        float e1[4][4], sq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float x = acc_g[b][q] + bias_g[b], y = acc_b[b][q] + bias_b[b];
+                x = x >= 0.0f ? x : x * slope;
+                y = y >= 0.0f ? y : y * slope;
+                e1[b][q] = x + y;
+            }
+        }
+        // row sums of squares in column order (0..63), as the scalar kernel's butterfly produced them up to rounding:
+        // first the lane's own 4 column blocks, then the 16 lanes of the row group
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v = 0.0f;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) v = fmaf(e1[b][q], e1[b][q], v);
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
+            sq[q] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = r0 + 4 * h + q;
+            if (r < n) {
+                const float den = fmaxf(sqrtf(sq[q]), 1e-12f);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    out[(size_t)r * ld_out + 64 + 16 * b + i16] = e1[b][q] / den;
+                    if (e1_out) e1_out[(size_t)r * 64 + 16 * b + i16] = e1[b][q];
+                }
+            }
+        }
     }
 }
 
@@ -125,7 +186,8 @@ extern "C" int spex_ngcf_layer_f32(const float *ego, const float *side, const fl
     }
     SPEX_CHECK_ARG((((uintptr_t)W_gc | (uintptr_t)W_bi) & 15) == 0, "spex_ngcf_layer_f32: weights must be 16-byte aligned");
     if (n == 0) return SPEX_OK;
-    hipLaunchKernelGGL(ngcf_layer_kernel, dim3(grid_for_rows(n)), dim3(kWave * kWavesPerBlock), 0, (hipStream_t)stream,
+    const int n_tiles = (n + 15) / 16;  // one wave per 16-row tile
+    hipLaunchKernelGGL(ngcf_layer_kernel, dim3(grid_for_rows(n_tiles)), dim3(kWave * kWavesPerBlock), 0, (hipStream_t)stream,
                        ego, side, W_gc, b_gc, W_bi, b_bi, out, ld_out, e1_out, n, slope);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
