@@ -452,3 +452,41 @@ def test_gpu_negative_sampler(epinion2):
     np.random.seed(2020)
     td.ng_sample_device()
     assert np.array_equal(first, td.items_fill)                       # np.random.seed still pins the run
+
+
+def test_spmm_task_builder_fuzz(G, oracle):
+    """Random CSR shapes around every boundary of the task table (chunk = 16, task = 64, in-workgroup rows <= 1024, hub
+    segments of 128): each row either bit-identical to the oracle (<= 64 entries) or within re-association error; all
+    three epilogue forms; source tables on both sides of the 16 MiB packing switch."""
+    rng = np.random.default_rng(42)
+    special = [0, 1, 15, 16, 17, 63, 64, 65, 127, 128, 129, 1023, 1024, 1025, 1500, 2049]
+    for trial in range(12):
+        n_rows = int(rng.integers(1, 400))
+        # trials 2-4: a source table above 16 MiB switches graph creation to the HBM-resident layout (adjacent-row
+        # tasks, no per-entry row ids, round-robin XCD placement)
+        n_cols = 70000 if trial in (2, 3, 4) else int(rng.integers(2100, 4000))
+        deg = rng.integers(0, 70, n_rows)
+        k = min(n_rows, int(rng.integers(0, 12)))
+        deg[rng.choice(n_rows, k, replace=False)] = rng.choice(special, k)
+        if trial == 0:
+            deg[:] = 0                                         # nothing stored at all
+        if trial == 1:
+            deg[:] = 64                                        # every task exactly full
+        rowptr, col, val = random_csr(rng, n_rows, n_cols, deg)
+        X = rng.normal(size=(n_cols, 64)).astype(np.float32)
+        add, acc = (rng.normal(size=(n_rows, 64)).astype(np.float32) for _ in range(2))
+        g = G(rowptr, col, val, n_cols=n_cols)
+        ref = oracle.spmm(rowptr, col, val, X)
+        exact = np.diff(rowptr) <= 64
+        tol = lambda a, b: rel_err(a, b) <= 2e-6 if len(a) else True
+        y = g.spmm(t(X)).cpu().numpy()
+        assert np.array_equal(y[exact], ref[exact]) and tol(y[~exact], ref[~exact]), trial
+        Y, A = torch.empty(n_rows, 64, device=DEV), t(acc)
+        g.spmm(t(X), Y=Y, acc_in=A, acc_out=A, acc_div=4.0)
+        assert np.array_equal(Y.cpu().numpy(), y), trial
+        want = (acc + ref) / np.float32(4.0)
+        a = A.cpu().numpy()
+        assert np.array_equal(a[exact], want[exact]) and tol(a[~exact], want[~exact]), trial
+        Y2 = g.spmm(t(X), add_in=t(add), add_div=3.0).cpu().numpy()
+        want2 = ref + add / np.float32(3.0)
+        assert np.array_equal(Y2[exact], want2[exact]) and tol(Y2[~exact], want2[~exact]), trial
