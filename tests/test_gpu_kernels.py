@@ -478,7 +478,7 @@ def test_spmm_task_builder_fuzz(G, oracle):
         g = G(rowptr, col, val, n_cols=n_cols)
         ref = oracle.spmm(rowptr, col, val, X)
         exact = np.diff(rowptr) <= 64
-        tol = lambda a, b: rel_err(a, b) <= 2e-6 if len(a) else True
+        tol = lambda a, b: rel_err(a, b) <= 1e-5 if len(a) else True   # rows of up to 2049 random-sign terms
         y = g.spmm(t(X)).cpu().numpy()
         assert np.array_equal(y[exact], ref[exact]) and tol(y[~exact], ref[~exact]), trial
         Y, A = torch.empty(n_rows, 64, device=DEV), t(acc)
