@@ -161,3 +161,37 @@ class PartitionedLightGCN:
     def own_slice(self, padded):
         s = self.rank * self.part.max_rows
         return padded[s: s + self.n_local]
+
+
+class PartitionedStepper:
+    """The exact reference training step (BCE, backward through the propagation, Adam — main_rec.py:32-37) on a
+    row-partitioned model.  Every rank holds its rows of E0 and of the Adam moments; the batch is replicated; per step
+    the exchanges are the per-layer all-gathers (forward and backward) plus one all-reduce of the batch's 2B
+    propagated rows.  Gradient rows are computed everywhere and each rank keeps the ones it owns (owner-computes)."""
+
+    def __init__(self, part_model, E0_local, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        from . import ops
+        self.ops, self.P, self.E0 = ops, part_model, E0_local
+        self.lr, self.betas, self.eps, self.t = lr, betas, eps, 0
+        self.m, self.v = torch.zeros_like(E0_local), torch.zeros_like(E0_local)
+        self.g_local = torch.zeros_like(E0_local)
+        self.grad_E0 = torch.zeros_like(E0_local)
+
+    def step_bce(self, users, items, labels):
+        P, ops = self.P, self.ops
+        dev = self.E0.device
+        users, items = users.to(dev), items.to(dev)
+        B = users.numel()
+        P.propagate(self.E0)
+        pu, pi = P.padded_index(users, items)
+        plan = P.plan_rows(torch.cat([pu, pi]))
+        rows = P.fetch_rows(plan, torch.empty((2 * B, P.d), dtype=torch.float32, device=dev))
+        grad_rows = torch.zeros_like(rows)
+        ar = torch.arange(B, device=dev)
+        _, loss_sum = ops.score_bce(rows, rows, ar, ar + B, labels.to(dev), grad_rows, grad_rows, 1.0 / B)
+        self.g_local.zero_()
+        self.g_local.index_add_(0, plan[1], grad_rows.index_select(0, plan[0]))
+        P.propagate_bwd(self.g_local, grad_out=self.grad_E0)
+        self.t += 1
+        ops.adam_step(self.E0, self.grad_E0, self.m, self.v, self.t, self.lr, self.betas[0], self.betas[1], self.eps)
+        return loss_sum / B

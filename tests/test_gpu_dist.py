@@ -46,8 +46,19 @@ def _worker(rank, world, port, out_dir):
     u = torch.arange(0, 3185, 7, device=dev)
     i = torch.arange(0, 12407, 31, device=dev)[: len(u)]
     pu, pi = P.padded_index(u, i)
+    # three exact training steps (BCE + backward + Adam) on the partitioned model
+    from spex_amd.dist import PartitionedStepper
+    E0_local = torch.from_numpy(E0[P.r0:P.r1].copy()).to(dev)
+    st = PartitionedStepper(P, E0_local, lr=1e-3)
+    rng = np.random.default_rng(3)
+    losses = []
+    for _ in range(3):
+        bu = torch.from_numpy(rng.integers(0, 3185, 256)); bi = torch.from_numpy(rng.integers(0, 12407, 256))
+        by = torch.from_numpy((rng.random(256) < 1 / 6).astype(np.float32))
+        losses.append(st.step_bce(bu, bi, by).item())
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), lo=lo.cpu().numpy(), grad=grad.cpu().numpy(), r0=P.r0, r1=P.r1,
-             fu=full[pu].cpu().numpy(), fi=full[pi].cpu().numpy(), u=u.cpu().numpy(), i=i.cpu().numpy())
+             fu=full[pu].cpu().numpy(), fi=full[pi].cpu().numpy(), u=u.cpu().numpy(), i=i.cpu().numpy(),
+             trained=E0_local.cpu().numpy(), losses=np.asarray(losses))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -72,3 +83,19 @@ def test_two_ranks_on_gpu_match_single_device(tmp_path):
         assert np.array_equal(d["fu"], ref[d["u"]]) and np.array_equal(d["fi"], ref[3186 + d["i"]])
     assert np.array_equal(lo, ref)          # a row's summation order does not depend on the partition
     assert np.array_equal(grad, ref_grad)
+    # the same three training steps on one device
+    from spex_amd.trainer import LightGCNStepper
+    st = LightGCNStepper(g, torch.from_numpy(E0.copy()).cuda(), 3186, n_layers=3, lr=1e-3)
+    rng = np.random.default_rng(3)
+    ref_losses = []
+    for _ in range(3):
+        bu = torch.from_numpy(rng.integers(0, 3185, 256)).cuda(); bi = torch.from_numpy(rng.integers(0, 12407, 256)).cuda()
+        by = torch.from_numpy((rng.random(256) < 1 / 6).astype(np.float32)).cuda()
+        ref_losses.append(st.step_bce(bu, bi, by).item())
+    trained = np.zeros_like(ref)
+    for r in range(world):
+        d = np.load(tmp_path / f"rank{r}.npz")
+        trained[int(d["r0"]):int(d["r1"])] = d["trained"]
+        assert np.allclose(d["losses"], ref_losses, rtol=0, atol=2e-6)
+    want = st.E0.cpu().numpy()
+    assert np.abs(trained - want).max() <= 5e-6 * np.abs(want).max()
