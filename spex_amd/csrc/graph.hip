@@ -86,7 +86,7 @@ extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, 
     g->n_long = (int32_t)long_row.size();
     g->n_seg = (int32_t)seg_beg.size();
 
-    // Chunked task table (see spex_common.h).  Only when every source-row byte offset fits below kPadOffset.
+    // Chunked task table (see spex_common.h).
     //   task.w: bits 0-1 kind (0 pack / empty row / null, 1 segment combined in the workgroup, 2 segment through global
     //           scratch), bit 2 workgroup has a barrier, bit 3 leader (first segment of its row), bits 4-7 position of
     //           the wave in its workgroup (= LDS slot), bits 8-12 number of segments of the row; kind 2: bits 4.. slot.

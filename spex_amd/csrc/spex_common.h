@@ -30,14 +30,13 @@ void set_error(const char *fmt, ...);
 
 constexpr int kWave = 64;          // CDNA wavefront
 constexpr int kWavesPerBlock = 4;  // 256-thread workgroups
-constexpr int kLongRow = 128;      // rows with more stored entries are cut into segments
-constexpr int kSegLen = 128;       // entries per long-row segment
+constexpr int kLongRow = 128;      // generic kernel / hub path: rows with more stored entries are cut into segments
+constexpr int kSegLen = 128;       // entries per such segment (partial rows go through global scratch + the fix-up launch)
 constexpr int kTaskEntries = 64;   // entries per wave task of the d == 64 kernel (4 chunks: 4 memory round trips)
 constexpr int kWgWaves = 16;       // the d == 64 kernel runs 1024-thread workgroups = 16 wave tasks
 constexpr int kWgRowMax = kWgWaves * kTaskEntries;  // longest row whose segments are combined inside one workgroup
 constexpr int kOpenTasks = 4;      // first-fit packing of short rows keeps this many tasks open
-constexpr int kChunk = 16;         // entries per chunk (one s_load_dwordx16 of offsets, one of values)
-constexpr uint32_t kPadOffset = 0xFFFFFF00u;  // out-of-range source offset of a padding entry
+constexpr int kChunk = 16;         // entries per chunk = gathers a wave keeps in flight
 
 }  // namespace spex
 

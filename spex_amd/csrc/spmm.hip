@@ -211,22 +211,32 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_rows_kernel(const 
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// d == 64 kernel: one wave per TASK (a run of 16-entry chunks, see spex_common.h), lane == embedding column.
+// d == 64 kernel: 16-wave workgroups, one wave per TASK (a run of <= 4 sixteen-entry chunks, see spex_common.h),
+// lane == embedding column.
 //
-// Measured on MI355X (tools/gather_bench.hip): random 256-byte row gathers run at the same rate — 6.1 TB/s from HBM,
-// 15-20 TB/s from L2/Infinity Cache — whether a row is fetched as 64 x 4 B or 16 x 16 B lanes, as long as ~16 rows
-// per wave are in flight; what separates a kernel from that ceiling is everything it issues AROUND the gathers (the
-// first versions of this kernel spent 15 scalar + 6 vector instructions per gathered row on lane broadcasts, 64-bit
-// address arithmetic and row-boundary tests, saturating the CU's scalar unit at a third of the gather rate).
-// So the per-entry metadata is laid out to be consumed with no arithmetic at all:
-//   * source-row BYTE OFFSETS (col * 256) and values come in through wave-uniform s_load_dwordx16 straight into SGPRs;
-//   * each gather is one `buffer_load_dword v, v_lane4, s[rsrc], s_off offen` — the scalar offset register IS the
-//     loaded metadata word — and one `v_fmac_f32 v_acc, s_val, v_x`;
-//   * padding entries carry an out-of-range offset: the buffer bounds check returns 0 without a memory access;
-//   * a 16-bit mask per chunk marks the entries that end a row; the row's epilogue operand is fetched in the same
-//     batch as its last gather, so emitting a row never waits on a dependent load.
-// The accumulation is still one fmaf chain per output element in ascending column order (bit-exact vs the oracle).
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
+// What was measured on MI355X on the way here (tools/gather_bench.hip, profiles/r01*):
+//   * random 256-byte row gathers run at the same rate — 6.1 TB/s from HBM, 15-24 TB/s from L2 / Infinity Cache —
+//     whether a row is fetched as 64 x 4 B or 16 x 16 B lanes, with 8 or 64 rows in flight per wave: the memory system,
+//     not the load shape, sets the ceiling;
+//   * what separates an SpMM from that ceiling is everything it issues AROUND the gathers.  The first version (one
+//     wave per row, rows walked with per-entry row-boundary tests and 64-bit scalar address arithmetic) spent 15 scalar
+//     + 6 vector instructions per gathered row and saturated the CU's scalar unit at a third of the gather rate;
+//   * feeding the per-entry metadata through scalar loads (s_load_dwordx16) starves on scalar-cache misses as soon
+//     as the matrix streams from HBM (29 ms vs 13 ms per launch on a 2^23-node graph); buffer loads with a scalar
+//     offset are ~25 % slower than global loads when the source table is cache-resident.
+// Hence this shape:
+//   * per 64 entries the wave loads source-row index, value (and, for bin-packed tasks, output row) with ONE coalesced
+//     vector load each — lane k holds entry k — and hands them to the scalar side with v_readlane;
+//   * per 16-entry chunk: 16 independent `global_load_dword` (scalar row base + lane offset) issued back to back,
+//     then 16 x { v_fmac; s_bitcmp on the chunk's end-of-row mask; branch }.  A row's epilogue operand (running layer
+//     sum, or g/(L+1)) is fetched in the same batch as its last gather, so emitting a row never waits on a
+//     dependent load;
+//   * tasks are padded to whole chunks with value-0 entries on the task's last real source row (an L1 hit);
+//   * rows of 65..1024 entries are cut into 64-entry segments that all sit in one workgroup; their sums meet in LDS
+//     and are added in segment order by the row's first wave: deterministic, no atomics, no second launch.  Only rows
+//     beyond 1024 entries go through global scratch and the fix-up launch.
+// The accumulation is one fmaf chain per output element in ascending column order (bit-exact vs the reference's CPU
+// kernel) for every row that fits a task; segmented rows re-associate <= 16 partial sums.
 
 // Edge dropout (MASKED): lane k decides for its own entry (injected mask byte or Philox draw keyed by the entry's edge
 // id, so forward / backward / every layer of a step agree); a dropped entry keeps its slot with value 0 and the
@@ -239,7 +249,9 @@ struct DropArgs {
     uint32_t seed_lo, seed_hi;
 };
 
-template <int EPI, bool MASKED, bool ROWIDS>  // ROWIDS: rows of a task are listed per entry (else adjacent from task.z); EPI 0: Y = y;  1: Y = y (optional), acc_out = (acc_in + y) / acc_div;  2: Y = y + add_in / add_div
+// EPI 0: Y = y;  1: Y = y (optional), acc_out = (acc_in + y) / epi_div;  2: Y = (y + add_in / epi_div) / out_div.
+// ROWIDS: a task's rows are listed per entry (bin-packed tasks) instead of being adjacent from task.z.
+template <int EPI, bool MASKED, bool ROWIDS>
 __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
     const float *__restrict__ X, const uint32_t *__restrict__ chunk_off, const float *__restrict__ chunk_val,
     const uint32_t *__restrict__ chunk_mask, const int32_t *__restrict__ chunk_row, const int4 *__restrict__ task,
