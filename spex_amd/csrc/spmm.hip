@@ -240,7 +240,8 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_rows_kernel(const 
 
 // Edge dropout (MASKED): lane k decides for its own entry (injected mask byte or Philox draw keyed by the entry's edge
 // id, so forward / backward / every layer of a step agree); a dropped entry keeps its slot with value 0 and the
-// source row of the super-chunk's first entry (already being fetched), i.e. it adds +0 and costs no extra traffic.
+// source row of the super-chunk's first kept entry (already being fetched), i.e. it adds +0 and costs no extra traffic.
+// (Unlike the reference, a dropped entry whose stand-in source row holds Inf/NaN contributes 0 * Inf = NaN.)
 struct DropArgs {
     const uint32_t *chunk_eid;
     const uint8_t *keep;
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
     // HBM: 29 ms vs 17 ms per launch on a 2^23-node graph.)
     for (int sc = 0; sc < t.y; sc += 4) {
         const int nc = (t.y - sc < 4) ? t.y - sc : 4;  // chunks in this super-chunk (wave-uniform)
-        uint32_t my_off = 0u, my_mask = 0u;
+        uint32_t my_off = 0u, my_mask = 0u, own_off = 0u;
         int my_row = 0;
         float my_val = 0.0f;
         if (lane < nc * kChunk) {
@@ -319,13 +320,18 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
                     kept = (u01 + drop.keep_prob) >= 1.0f;
                 }
                 my_val = kept ? my_val / drop.keep_prob : 0.0f;   // values[random_index] / keep_prob, model.py:53
+                own_off = my_off;
                 if (!kept) my_off = 0xFFFFFFFFu;
             }
         }
         if (MASKED) {
-            const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)my_off, 0);
-            // dropped entries re-read a row this wave fetches anyway (or row 0 of the table if entry 0 was dropped too)
-            if (my_off == 0xFFFFFFFFu) my_off = (first == 0xFFFFFFFFu) ? 0u : first;
+            // a dropped entry re-reads the source row of the first KEPT entry of this super-chunk (fetched anyway, so
+            // it adds +0 and no traffic); if every entry was dropped each keeps its own row (value 0)
+            const bool dropped = my_off == 0xFFFFFFFFu;      // (lanes past the super-chunk hold 0: neither kept nor dropped)
+            const unsigned long long kept_lanes = __ballot(!dropped && lane < nc * kChunk);
+            const int src = kept_lanes ? (int)__builtin_ctzll(kept_lanes) : 0;
+            const uint32_t stand_in = (uint32_t)__builtin_amdgcn_readlane((int)my_off, src);   // wave-uniform
+            if (dropped) my_off = kept_lanes ? stand_in : own_off;
         }
         if (lane < nc) my_mask = __builtin_nontemporal_load(chunk_mask + t.x + sc + lane);
         for (int c = 0; c < nc; ++c) {

@@ -265,6 +265,28 @@ def test_dropout_sampled_mask_statistics(G):
         assert (y != y2).mean() > 0.3                               # a different seed is a different mask
 
 
+def test_dropout_stand_in_rows_do_not_leak(G, oracle):
+    """A dropped entry keeps its slot with value 0 and gathers a stand-in row; that row must be one the wave's kept
+    entries fetch anyway, never an unrelated row (0 * Inf would be NaN).  Row 0 of the table is referenced by nobody
+    and holds Inf; entry 0 of most rows is dropped."""
+    rng = np.random.default_rng(5)
+    n = 600
+    deg = rng.integers(1, 90, n)
+    deg[10], deg[11] = 700, 2000
+    rowptr, col, val = random_csr(rng, n, n - 1, deg)
+    col = (col + 1).astype(np.int32)                                 # nobody reads source row 0
+    X = rng.normal(size=(n, 64)).astype(np.float32)
+    X[0] = np.inf
+    keep = rng.random(len(col)) < 0.5
+    keep[rowptr[:-1]] = False                                        # first entry of every row dropped
+    g = G(rowptr, col, val, n_cols=n)
+    g.set_edge_mask(1, t(keep.astype(np.uint8)), 0.5, 0)
+    got = g.spmm(t(X)).cpu().numpy()
+    assert np.isfinite(got).all()
+    ref = oracle.spmm(rowptr, col, np.where(keep, val / np.float32(0.5), np.float32(0)).astype(np.float32), np.where(np.isfinite(X), X, np.float32(0)))
+    assert rel_err(got, ref) <= 1e-5
+
+
 # ---------------------------------------------------------------------------------------------- scoring kernels
 def test_score_bce_vs_oracle(oracle):
     from spex_amd import ops
