@@ -174,6 +174,35 @@ int spex_expert_gate_f32(const float *raw, const float *prop, const float *att_e
 int spex_sample_negatives(const int32_t *d_rowptr, const int32_t *d_items, int32_t n_user_rows, const int64_t *d_pos_user,
                           int64_t n_pos, int32_t num_ng, int32_t num_item, uint64_t seed, int64_t *d_out, void *stream);
 
+/* ------------------------------------------------------------------------------------------------ learned edge values
+ * the Diffnet++ social / interest diffusion — the same SpMM on user x user, user x item and item x user
+ * graphs whose stored values are LEARNED (a per-edge parameter pushed through a row softmax), so the values change
+ * every step and need a gradient.  Replaces, on fixed sparsity patterns,
+ *   tf.sparse.softmax(SparseTensor(indices, values))        Diffnet++_SPEX/code/utility/Model.py:275-286
+ *   tf.sparse.sparse_dense_matmul(att_matrix, embedding)    Model.py:18-83 (forward: spex_spmm_f32 after set_values)
+ *   and their gradients w.r.t. the values (tape.gradient, Diffnet++_SPEX/code/main_rec.py:36).
+ * Every per-edge array here is indexed by EDGE ID (h_edge_id of spex_graph_create; identity = CSR entry order), so a
+ * graph and its transposed copy share one values array.  n_val = length of that array (> the largest edge id).
+ */
+
+/* Replace the stored values of the handle by d_val[edge_id] (device, fp32); later SpMM launches on the handle use them. */
+int spex_graph_set_values(spex_graph_t *g, const float *d_val, int64_t n_val, void *stream);
+
+/* Sampled dense-dense product on the handle's pattern: d_out[edge_id(e)] = <A[row(e),:], B[col(e),:]> for every stored
+ * entry e.  A: [n_rows, d], B: [n_cols, d].  With A = dL/dY and B = X this is dL/dval of Y = spmm(val, X).
+ * Entries are not weighted by the stored values.  The first call on a handle builds a per-entry row index (4 B/entry).
+ */
+int spex_sddmm_f32(spex_graph_t *g, const float *A, const float *B, float *d_out, int64_t n_val, int32_t d, void *stream);
+
+/* Row softmax over the stored entries (empty rows: nothing written):
+ *   d_out[id(e)] = exp(d_in[id(e)] - max_row) / sum_row exp(d_in - max_row)
+ * and its backward  d_grad_in[id(e)] = d_out[id(e)] * (d_grad_out[id(e)] - sum_row d_out * d_grad_out).
+ * d_in may equal d_out; d_grad_out may equal d_grad_in.
+ */
+int spex_edge_softmax_f32(const spex_graph_t *g, const float *d_in, float *d_out, int64_t n_val, void *stream);
+int spex_edge_softmax_bwd_f32(const spex_graph_t *g, const float *d_out_val, const float *d_grad_out, float *d_grad_in,
+                              int64_t n_val, void *stream);
+
 /* ------------------------------------------------------------------------------------------------ profiling hook
  * Not part of any reference interface: lets a caller time the dominant kernel itself, in place, on the stream it is
  * launched on (bench.py's roofline figure).  While a timer is attached to a graph, every (or every n-th) call of

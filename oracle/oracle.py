@@ -314,3 +314,40 @@ def expert_gate(raw, prop, att):
     e = np.exp(z)
     a = e / e.sum(1, keepdims=True)
     return (raw * a[:, :1] + prop * a[:, 1:2]).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------------ learned edge values
+# Diffnet++.  PARITY UNPINNED: the reference for these is TensorFlow (tf.sparse.softmax,
+# tf.sparse.sparse_dense_matmul and their gradients), which is not installed in the image, and the reference holds no
+# test or golden vector for them.  Restated from Diffnet++_SPEX/code/utility/Model.py and the ops' definitions; the
+# gradients are additionally checked against finite differences in fp64 (tests/test_oracle_golden.py).
+def _rows_of(rowptr):
+    rowptr = np.asarray(rowptr, np.int64)
+    return np.repeat(np.arange(len(rowptr) - 1, dtype=np.int64), np.diff(rowptr))
+
+
+def edge_softmax(rowptr, v, dtype=np.float32):
+    """tf.sparse.softmax over the stored entries of each row (Model.py:275-286): exp(v - max_row) / sum_row."""
+    v = np.asarray(v, dtype)
+    rows = _rows_of(rowptr)
+    n = len(rowptr) - 1
+    m = np.full(n, -np.inf, dtype)
+    np.maximum.at(m, rows, v)
+    e = np.exp(v - m[rows]).astype(dtype)
+    s = np.zeros(n, dtype)
+    np.add.at(s, rows, e)
+    return (e / s[rows]).astype(dtype)
+
+
+def edge_softmax_bwd(rowptr, y, gy, dtype=np.float32):
+    y, gy = np.asarray(y, dtype), np.asarray(gy, dtype)
+    rows = _rows_of(rowptr)
+    s = np.zeros(len(rowptr) - 1, dtype)
+    np.add.at(s, rows, y * gy)
+    return (y * (gy - s[rows])).astype(dtype)
+
+
+def sddmm(rowptr, col, A, B, dtype=np.float32):
+    """out[e] = <A[row(e)], B[col(e)]>: d/dval of Y = spmm(val, B) contracted with A = dL/dY."""
+    rows = _rows_of(rowptr)
+    return np.einsum("ed,ed->e", np.asarray(A, dtype)[rows], np.asarray(B, dtype)[np.asarray(col, np.int64)]).astype(dtype)

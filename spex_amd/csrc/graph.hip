@@ -35,7 +35,7 @@ extern "C" int spex_graph_destroy(spex_graph_t *g)
 {
     if (!g) return SPEX_OK;
     void *ptrs[] = {g->rowptr, g->col, g->val, g->edge_id, g->seg_beg, g->seg_end, g->long_row, g->long_seg0, g->partial,
-                    g->task, g->chunk_off, g->chunk_val, g->chunk_mask, g->chunk_eid, g->chunk_row, g->hub_row, g->hub_seg0};
+                    g->task, g->chunk_off, g->chunk_val, g->chunk_mask, g->chunk_eid, g->chunk_row, g->hub_row, g->hub_seg0, g->row_of};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete g;
@@ -60,14 +60,20 @@ extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, 
             SPEX_CHECK_ARG(e == h_rowptr[r] || h_col[e - 1] < h_col[e], "spex_graph_create: columns not strictly ascending in row %d (coalesce first)", r);
         }
     }
-    if (h_edge_id)
-        for (int64_t e = 0; e < nnz; ++e)
+    int64_t max_edge_id = nnz - 1;
+    if (h_edge_id) {
+        max_edge_id = -1;
+        for (int64_t e = 0; e < nnz; ++e) {
             SPEX_CHECK_ARG(h_edge_id[e] >= 0, "spex_graph_create: negative edge_id at entry %lld", (long long)e);
+            if (h_edge_id[e] > max_edge_id) max_edge_id = h_edge_id[e];
+        }
+    }
 
     spex_graph *g = new spex_graph();
     g->n_rows = n_rows;
     g->n_cols = n_cols;
     g->nnz = nnz;
+    g->max_edge_id = max_edge_id;
 
     // long rows -> segments of kSegLen entries; partial sums are combined in segment order by the fix-up kernel
     std::vector<int32_t> seg_beg, seg_end, long_row, long_seg0;
@@ -131,13 +137,14 @@ extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, 
             } else {
                 for (int32_t en = b; en < e; ++en) push(en, r0, false);
             }
+            const uint32_t n_pad = in_chunk ? (uint32_t)(spex::kChunk - in_chunk) : 0u;
             while (in_chunk != 0) {  // padding: value 0 on the task's last real source row (a line already being fetched)
                 c_off.push_back((uint32_t)last_col);
                 c_val.push_back(0.0f);
                 c_eid.push_back((uint32_t)last_eid);
                 if (g->row_ids) c_row.push_back(last_row);
                 if (++in_chunk == spex::kChunk) {
-                    c_mask.push_back(mask);
+                    c_mask.push_back(mask | (n_pad << 16));
                     mask = 0;
                     in_chunk = 0;
                 }

@@ -57,6 +57,8 @@ struct spex_graph {
     int32_t *col = nullptr;      // [nnz]
     float *val = nullptr;        // [nnz]
     int32_t *edge_id = nullptr;  // [nnz] or null (identity)
+    int64_t max_edge_id = -1;    // largest edge id (nnz - 1 for identity)
+    int32_t *row_of = nullptr;   // [nnz] row of each stored entry, built by the first spex_sddmm_f32
     // long rows (> kLongRow entries): segment table + per-segment partial rows + per-row fix-up table
     int32_t n_long = 0, n_seg = 0;
     int32_t *seg_beg = nullptr;   // [n_seg] first entry of the segment
@@ -71,14 +73,15 @@ struct spex_graph {
     // short rows, or one 64-entry segment of a row with 65..1024 entries — all segments of such a row sit in ONE
     // 16-wave workgroup and are summed through LDS in segment order — or (rows > 1024 entries only) a 128-entry
     // segment whose partial row goes through global scratch and the fix-up launch.  Tasks are padded to whole chunks
-    // with entries whose offset is out of the buffer's range (the bounds check returns 0, no memory access).
+    // with value-0 entries on the task's last real source row (a line already being fetched); a chunk's padding sits at
+    // its end and chunk_mask bits 16-20 hold its count.
     //   task.x = first chunk, .y = number of chunks, .z = (first) row or -1, .w = kind | flags (see graph.hip)
     int32_t n_tasks = 0;
     int4 *task = nullptr;          // [n_tasks], heaviest first
     int64_t n_chunks = 0;
     uint32_t *chunk_off = nullptr; // [n_chunks * 16]
     float *chunk_val = nullptr;    // [n_chunks * 16]
-    uint32_t *chunk_mask = nullptr; // [n_chunks]
+    uint32_t *chunk_mask = nullptr; // [n_chunks] bits 0-15 end-of-row flags, bits 16-20 number of padding entries
     uint32_t *chunk_eid = nullptr;  // [n_chunks * 16] edge id of each entry (keep-mask index); read only under dropout
     bool row_ids = false;           // tasks pack non-adjacent rows (cache-resident graphs): the kernel reads chunk_row
     int32_t *chunk_row = nullptr;   // [n_chunks * 16] output row of each entry, only when row_ids

@@ -335,7 +335,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
         }
         if (lane < nc) my_mask = __builtin_nontemporal_load(chunk_mask + t.x + sc + lane);
         for (int c = 0; c < nc; ++c) {
-            const uint32_t mask = (uint32_t)__builtin_amdgcn_readlane((int)my_mask, c);
+            const uint32_t mask = (uint32_t)__builtin_amdgcn_readlane((int)my_mask, c) & 0xFFFFu;   // (bits 16-20: padding count)
             float x[kChunk], ep[kChunk];
 #pragma unroll
             for (int u = 0; u < kChunk; ++u)

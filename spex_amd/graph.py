@@ -100,6 +100,7 @@ class SpexGraph:
         self.host = (rowptr, col, val)
         if edge_id is not None:
             edge_id = np.ascontiguousarray(edge_id, np.int32)
+        self._edge_id_host = edge_id
         self.device = torch.device(device if device is not None else "cuda")
         handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
@@ -219,3 +220,54 @@ class SpexGraph:
             ws = torch.empty((3, n, d), dtype=torch.float32, device=g_out.device)
         _lib.call("spex_propagate_bwd_f32", self._h, _ptr(g_out), _ptr(grad_E0), _ptr(ws), int(n_layers), d, _stream())
         return grad_E0
+
+    # -- learned edge values (per-edge arrays are indexed by edge id)
+    def _chk_edges(self, t, name):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 1):
+            raise ValueError(f"{name}: need a contiguous 1-D fp32 tensor on the GPU")
+        if t.numel() < self.n_edge_ids:
+            raise ValueError(f"{name}: {t.numel()} values for {self.n_edge_ids} edge ids")
+
+    @property
+    def n_edge_ids(self):
+        """Length a per-edge array must have (largest edge id + 1; nnz for the identity numbering)."""
+        if getattr(self, "_n_edge_ids", None) is None:
+            self._n_edge_ids = self.nnz if self._edge_id_host is None else (int(self._edge_id_host.max()) + 1 if self.nnz else 0)
+        return self._n_edge_ids
+
+    def set_values(self, val):
+        """Replace the stored values by val[edge id]; later spmm() launches use them (spex_graph_set_values)."""
+        self._chk_edges(val, "val")
+        _lib.call("spex_graph_set_values", self._h, _ptr(val), val.numel(), _stream())
+
+    def sddmm(self, A, B, out=None):
+        """out[edge id] = <A[row], B[col]> on the stored pattern: the SpMM's gradient w.r.t. its values."""
+        d = A.shape[1]
+        self._chk(A, self.n_rows, d, "A")
+        self._chk(B, self.n_cols, d, "B")
+        if out is None:
+            out = torch.zeros(self.n_edge_ids, dtype=torch.float32, device=A.device)
+        self._chk_edges(out, "out")
+        if self.nnz:
+            _lib.call("spex_sddmm_f32", self._h, _ptr(A), _ptr(B), _ptr(out), out.numel(), d, _stream())
+        return out
+
+    def edge_softmax(self, v, out=None):
+        """Row softmax over the stored entries (tf.sparse.softmax on a fixed pattern)."""
+        self._chk_edges(v, "v")
+        if out is None:
+            out = torch.zeros_like(v)
+        self._chk_edges(out, "out")
+        if self.nnz:
+            _lib.call("spex_edge_softmax_f32", self._h, _ptr(v), _ptr(out), v.numel(), _stream())
+        return out
+
+    def edge_softmax_bwd(self, y, grad_y, grad_in=None):
+        self._chk_edges(y, "y")
+        self._chk_edges(grad_y, "grad_y")
+        if grad_in is None:
+            grad_in = torch.zeros_like(y)
+        self._chk_edges(grad_in, "grad_in")
+        if self.nnz:
+            _lib.call("spex_edge_softmax_bwd_f32", self._h, _ptr(y), _ptr(grad_y), _ptr(grad_in), y.numel(), _stream())
+        return grad_in

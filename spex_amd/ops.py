@@ -202,3 +202,57 @@ class BPRLoss(torch.autograd.Function):
         grad = ctx.grad
         ctx.grad = None
         return grad * g, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------ learned edge values
+class EdgeSoftmax(torch.autograd.Function):
+    """Row softmax over the stored entries of `graph` (tf.sparse.softmax on a fixed pattern,
+    Diffnet++_SPEX/code/utility/Model.py:275-286).  v and the result are per-edge arrays indexed by edge id."""
+
+    @staticmethod
+    def forward(ctx, v, graph):
+        y = graph.edge_softmax(v.contiguous())
+        ctx.graph = graph
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        return ctx.graph.edge_softmax_bwd(y, gy.contiguous()), None
+
+
+class SpMMLearned(torch.autograd.Function):
+    """Y = A(val) X with learned values on a fixed pattern (tf.sparse.sparse_dense_matmul, Model.py:18-83):
+    forward = set_values + SpMM; backward: dX = A(val)^T dY on the transposed handle (same values array through its
+    edge ids), dval = SDDMM(dY, X).  The values are re-installed before every launch, so several value sets may share
+    one pair of handles."""
+
+    @staticmethod
+    def forward(ctx, val, X, graph, graph_t):
+        val, X = val.contiguous(), X.contiguous()
+        graph.set_values(val)
+        Y = graph.spmm(X)
+        ctx.graph, ctx.graph_t = graph, graph_t
+        ctx.save_for_backward(val, X)
+        return Y
+
+    @staticmethod
+    def backward(ctx, gY):
+        val, X = ctx.saved_tensors
+        gY = gY.contiguous()
+        g_val = g_X = None
+        if ctx.needs_input_grad[0]:
+            g_val = ctx.graph.sddmm(gY, X)
+        if ctx.needs_input_grad[1]:
+            ctx.graph_t.set_values(val)
+            g_X = ctx.graph_t.spmm(gY)
+        return g_val, g_X, None, None
+
+
+def edge_softmax(v, graph):
+    return EdgeSoftmax.apply(v, graph)
+
+
+def spmm_learned(val, X, graph, graph_t):
+    return SpMMLearned.apply(val, X, graph, graph_t)

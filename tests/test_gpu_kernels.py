@@ -512,3 +512,97 @@ def test_spmm_task_builder_fuzz(G, oracle):
         Y2 = g.spmm(t(X), add_in=t(add), add_div=3.0).cpu().numpy()
         want2 = ref + add / np.float32(3.0)
         assert np.array_equal(Y2[exact], want2[exact]) and tol(Y2[~exact], want2[~exact]), trial
+
+
+# ---------------------------------------------------------------------------------------------- learned edge values
+@pytest.mark.parametrize("d", [64, 128, 20, 3])
+def test_sddmm_and_set_values_vs_oracle(G, oracle, d):
+    """values refreshed on the device, SpMM with them on A and (through the edge ids) on A^T, and the
+    SDDMM that is the SpMM's gradient w.r.t. the values."""
+    from spex_amd.graph import csr_transpose
+    rng = np.random.default_rng(100 + d)
+    n_rows, n_cols = 900, 700
+    deg = rng.integers(0, 70, n_rows)
+    deg[5], deg[6], deg[40] = 0, 650, 130
+    rowptr, col, val = random_csr(rng, n_rows, n_cols, deg)
+    nnz = len(col)
+    g = G(rowptr, col, val, n_cols=n_cols)
+    t_rowptr, t_col, t_val, perm = csr_transpose(rowptr, col, val, n_cols)
+    gt = G(t_rowptr, t_col, t_val, n_cols=n_rows, edge_id=perm)
+    A = rng.normal(size=(n_rows, d)).astype(np.float32)
+    B = rng.normal(size=(n_cols, d)).astype(np.float32)
+    ref = oracle.sddmm(rowptr, col, A, B, np.float64)
+    got = g.sddmm(t(A), t(B)).cpu().numpy()
+    scale = np.sqrt(d) * 4
+    assert np.abs(got - ref).max() <= 2e-6 * scale
+    # the transposed handle writes the same array (edge-id order), from the swapped operands
+    got_t = gt.sddmm(t(B), t(A)).cpu().numpy()
+    assert np.abs(got_t - ref).max() <= 2e-6 * scale
+    # new values: the SpMM on both handles now uses them
+    new = rng.normal(size=nnz).astype(np.float32)
+    g.set_values(t(new))
+    gt.set_values(t(new))
+    Y = g.spmm(t(B)).cpu().numpy()
+    assert rel_err(Y, oracle.spmm(rowptr, col, new, B)) <= 1e-6
+    Yt = gt.spmm(t(A)).cpu().numpy()
+    assert rel_err(Yt, oracle.spmm(t_rowptr, t_col, new[perm], A)) <= 1e-6
+    with pytest.raises(ValueError):
+        g.set_values(t(new[:-1]))
+
+
+def test_edge_softmax_forward_backward_vs_oracle(G, oracle):
+    from spex_amd.graph import csr_transpose
+    rng = np.random.default_rng(21)
+    n_rows, n_cols = 1200, 800
+    deg = rng.integers(0, 50, n_rows)
+    deg[0], deg[1], deg[2], deg[3] = 0, 1, 16, 17
+    deg[9] = 777
+    rowptr, col, val = random_csr(rng, n_rows, n_cols, deg)
+    g = G(rowptr, col, val, n_cols=n_cols)
+    v = (rng.normal(size=len(col)) * 3).astype(np.float32)
+    y = g.edge_softmax(t(v))
+    ref = oracle.edge_softmax(rowptr, v, np.float64)
+    assert np.abs(y.cpu().numpy() - ref).max() <= 1e-6
+    sums = np.add.reduceat(np.r_[y.cpu().numpy(), 0.0], np.minimum(rowptr[:-1], len(col)))[deg > 0]
+    assert np.allclose(sums, 1.0, atol=1e-5)
+    gy = rng.normal(size=len(col)).astype(np.float32)
+    gx = g.edge_softmax_bwd(y, t(gy)).cpu().numpy()
+    assert np.abs(gx - oracle.edge_softmax_bwd(rowptr, ref, gy, np.float64)).max() <= 2e-6
+    # softmax over the rows of A^T through the transposed handle: per-edge arrays stay in A's entry order
+    t_rowptr, t_col, t_val, perm = csr_transpose(rowptr, col, val, n_cols)
+    gt = G(t_rowptr, t_col, t_val, n_cols=n_rows, edge_id=perm)
+    yt = gt.edge_softmax(t(v)).cpu().numpy()
+    ref_t = np.empty(len(col))
+    ref_t[perm] = oracle.edge_softmax(t_rowptr, v[perm], np.float64)
+    assert np.abs(yt - ref_t).max() <= 1e-6
+    # in place
+    buf = t(v)
+    g.edge_softmax(buf, out=buf)
+    assert np.array_equal(buf.cpu().numpy(), y.cpu().numpy())
+
+
+def test_learned_spmm_autograd_matches_torch_sparse(G):
+    """The two autograd Functions end to end against torch's own sparse autograd on the same device."""
+    from spex_amd import ops
+    from spex_amd.graph import csr_transpose
+    rng = np.random.default_rng(8)
+    n_rows, n_cols, d = 500, 400, 64
+    rowptr, col, val = random_csr(rng, n_rows, n_cols, rng.integers(1, 40, n_rows))
+    g = G(rowptr, col, val, n_cols=n_cols)
+    t_rowptr, t_col, t_val, perm = csr_transpose(rowptr, col, val, n_cols)
+    gt = G(t_rowptr, t_col, t_val, n_cols=n_rows, edge_id=perm)
+    p = torch.tensor(rng.normal(size=len(col)).astype(np.float32), device=DEV, requires_grad=True)
+    X = torch.tensor(rng.normal(size=(n_cols, d)).astype(np.float32), device=DEV, requires_grad=True)
+    W = torch.tensor(rng.normal(size=(n_rows, d)).astype(np.float32), device=DEV)
+    loss = (ops.spmm_learned(ops.edge_softmax(torch.exp(torch.sigmoid(p)), g), X, g, gt) * W).sum()
+    loss.backward()
+    rows = np.repeat(np.arange(n_rows), np.diff(rowptr))
+    idx = torch.from_numpy(np.stack([rows, col.astype(np.int64)])).to(DEV)
+    p2 = p.detach().double().requires_grad_()
+    X2 = X.detach().double().requires_grad_()
+    S = torch.sparse.softmax(torch.sparse_coo_tensor(idx, torch.exp(torch.sigmoid(p2)), (n_rows, n_cols)), dim=1)
+    loss2 = (torch.sparse.mm(S, X2) * W.double()).sum()
+    loss2.backward()
+    assert abs(loss.item() - loss2.item()) <= 1e-5 * max(1.0, abs(loss2.item()))
+    assert (p.grad.double() - p2.grad).abs().max().item() <= 1e-5 * p2.grad.abs().max().item()
+    assert (X.grad.double() - X2.grad).abs().max().item() <= 1e-5 * X2.grad.abs().max().item()

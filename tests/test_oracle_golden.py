@@ -230,3 +230,36 @@ def test_bpr_closed_form_self_consistency(oracle):
     Ue = U.astype(np.float64).copy()
     np.add.at(Ue, u, -0.1 * s[:, None] * (I[n].astype(np.float64) - I[p]))
     assert np.allclose(Un, Ue)
+
+
+def test_learned_edge_value_restatements_vs_torch_sparse(oracle):
+    """SURVEY.md 8f #3 (Diffnet++): the reference ops are TensorFlow's (absent here) — parity unpinned; the numpy
+    restatements are at least held against torch's independent CPU implementations of the same documented ops
+    (torch.sparse.softmax, autograd of torch.sparse.mm w.r.t. the values)."""
+    import torch
+    rng = np.random.default_rng(11)
+    n_rows, n_cols, d = 60, 45, 16
+    deg = rng.integers(0, 12, n_rows)
+    deg[3] = 0
+    deg[7] = n_cols
+    rowptr = np.zeros(n_rows + 1, np.int64)
+    rowptr[1:] = np.cumsum(deg)
+    col = np.concatenate([np.sort(rng.choice(n_cols, k, replace=False)) for k in deg]).astype(np.int64)
+    rows = np.repeat(np.arange(n_rows), deg)
+    v = rng.normal(size=len(col))
+    idx = torch.from_numpy(np.stack([rows, col]))
+    tv = torch.tensor(v, dtype=torch.float64, requires_grad=True)
+    S = torch.sparse_coo_tensor(idx, tv, (n_rows, n_cols))
+    y = torch.sparse.softmax(S, dim=1).coalesce().values()
+    got = oracle.edge_softmax(rowptr, v, np.float64)
+    assert np.allclose(got, y.detach().numpy(), rtol=1e-12, atol=1e-14)
+    gy = rng.normal(size=len(col))
+    (y * torch.from_numpy(gy)).sum().backward()
+    assert np.allclose(oracle.edge_softmax_bwd(rowptr, got, gy, np.float64), tv.grad.numpy(), rtol=1e-10, atol=1e-13)
+    # SDDMM == d/dval of sum(G * (A(val) X))
+    X = rng.normal(size=(n_cols, d))
+    G = rng.normal(size=(n_rows, d))
+    tv2 = torch.tensor(v, dtype=torch.float64, requires_grad=True)
+    Y = torch.sparse.mm(torch.sparse_coo_tensor(idx, tv2, (n_rows, n_cols)), torch.from_numpy(X))
+    (Y * torch.from_numpy(G)).sum().backward()
+    assert np.allclose(oracle.sddmm(rowptr, col, G, X, np.float64), tv2.grad.numpy(), rtol=1e-12, atol=1e-13)
