@@ -35,7 +35,7 @@ extern "C" int spex_graph_destroy(spex_graph_t *g)
 {
     if (!g) return SPEX_OK;
     void *ptrs[] = {g->rowptr, g->col, g->val, g->edge_id, g->seg_beg, g->seg_end, g->long_row, g->long_seg0, g->partial,
-                    g->task, g->chunk_off, g->chunk_val, g->chunk_mask, g->chunk_eid, g->chunk_row, g->hub_row, g->hub_seg0, g->row_of};
+                    g->task, g->chunk_off, g->chunk_val, g->chunk_mask, g->chunk_eid, g->chunk_row, g->hub_row, g->hub_seg0, g->row_of, g->tile_row};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete g;
@@ -260,8 +260,20 @@ extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, 
     g->n_chunks = (int64_t)c_mask.size();
     g->n_hub = (int32_t)hub_row.size();
 
+    // rows starting in each tile of kSoftmaxTile consecutive entries (row-softmax kernels, edge.hip)
+    g->n_tiles = (int32_t)((nnz + spex::kSoftmaxTile - 1) / spex::kSoftmaxTile);
+    std::vector<int32_t> tile_row((size_t)g->n_tiles + 1);
+    {
+        int32_t r = 0;
+        for (int32_t t = 0; t <= g->n_tiles; ++t) {
+            const int64_t first = (int64_t)t * spex::kSoftmaxTile;
+            while (r < n_rows && (int64_t)h_rowptr[r] < first) ++r;
+            tile_row[t] = r;
+        }
+    }
+
     int rc = SPEX_OK;
-    if ((rc = upload(&g->rowptr, h_rowptr, (size_t)n_rows + 1)) || (rc = upload(&g->col, h_col, (size_t)nnz)) ||
+    if ((rc = upload(&g->tile_row, tile_row.data(), tile_row.size())) || (rc = upload(&g->rowptr, h_rowptr, (size_t)n_rows + 1)) || (rc = upload(&g->col, h_col, (size_t)nnz)) ||
         (rc = upload(&g->val, h_val, (size_t)nnz)) ||
         (h_edge_id && (rc = upload(&g->edge_id, h_edge_id, (size_t)nnz))) ||
         (rc = upload(&g->seg_beg, seg_beg.data(), seg_beg.size())) ||

@@ -553,10 +553,10 @@ def test_sddmm_and_set_values_vs_oracle(G, oracle, d):
 def test_edge_softmax_forward_backward_vs_oracle(G, oracle):
     from spex_amd.graph import csr_transpose
     rng = np.random.default_rng(21)
-    n_rows, n_cols = 1200, 800
+    n_rows, n_cols = 1200, 2000
     deg = rng.integers(0, 50, n_rows)
     deg[0], deg[1], deg[2], deg[3] = 0, 1, 16, 17
-    deg[9] = 777
+    deg[9], deg[10], deg[700], deg[1199] = 777, 1500, 1024, 1025       # in-tile rows up to 1024 entries, hub rows beyond
     rowptr, col, val = random_csr(rng, n_rows, n_cols, deg)
     g = G(rowptr, col, val, n_cols=n_cols)
     v = (rng.normal(size=len(col)) * 3).astype(np.float32)
