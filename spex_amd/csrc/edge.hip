@@ -123,7 +123,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void edge_softmax_tile_kerne
                                                                                  const int32_t *__restrict__ tile_row,
                                                                                  const int32_t *__restrict__ edge_id,
                                                                                  const float *in, const float *gy,
-                                                                                 float *out)
+                                                                                 float *out, int tile)
 {
     __shared__ float s_x[kSoftmaxTile + kWgRowMax];
     __shared__ float s_g[BWD ? kSoftmaxTile + kWgRowMax : 1];
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void edge_softmax_tile_kerne
     if (r_lo >= r_hi) return;                                      // no row starts in this tile (inside a long row)
     const int32_t e_lo = rowptr[r_lo];
     int32_t e_hi = rowptr[r_hi];
-    const int64_t cap = ((int64_t)blockIdx.x + 1) * kSoftmaxTile + kWgRowMax;   // a non-hub last row ends before this
+    const int64_t cap = ((int64_t)blockIdx.x + 1) * tile + kWgRowMax;   // a non-hub last row ends before this
     if ((int64_t)e_hi > cap) e_hi = (int32_t)cap;
     // everything the workgroup needs from memory is requested here, coalesced and all in flight at once; the per-row
     // phase below touches LDS only.  Measured (Epinion2 x 269, 113 M entries): 0.55-0.6 ms = 1.5-1.7 TB/s of the 8 B per
@@ -309,7 +309,7 @@ static int launch_edge_softmax_impl(const spex_graph *g, const float *in, const 
 {
     const int threads = kWave * kWavesPerBlock;
     hipLaunchKernelGGL(edge_softmax_tile_kernel<BWD>, dim3((unsigned)g->n_tiles), dim3(threads), 0, stream, g->rowptr, g->tile_row,
-                       g->edge_id, in, gy, out);
+                       g->edge_id, in, gy, out, g->tile);
     if (g->n_hub > 0)
         hipLaunchKernelGGL(edge_softmax_hub_kernel<BWD>, dim3((unsigned)g->n_hub), dim3(threads), 0, stream, g->rowptr,
                            g->hub_row, g->edge_id, in, gy, out);

@@ -261,12 +261,13 @@ extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, 
     g->n_hub = (int32_t)hub_row.size();
 
     // rows starting in each tile of kSoftmaxTile consecutive entries (row-softmax kernels, edge.hip)
-    g->n_tiles = (int32_t)((nnz + spex::kSoftmaxTile - 1) / spex::kSoftmaxTile);
+    g->tile = (nnz / spex::kSoftmaxTile < 2048) ? 512 : spex::kSoftmaxTile;
+    g->n_tiles = (int32_t)((nnz + g->tile - 1) / g->tile);
     std::vector<int32_t> tile_row((size_t)g->n_tiles + 1);
     {
         int32_t r = 0;
         for (int32_t t = 0; t <= g->n_tiles; ++t) {
-            const int64_t first = (int64_t)t * spex::kSoftmaxTile;
+            const int64_t first = (int64_t)t * g->tile;
             while (r < n_rows && (int64_t)h_rowptr[r] < first) ++r;
             tile_row[t] = r;
         }

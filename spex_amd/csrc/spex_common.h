@@ -37,7 +37,7 @@ constexpr int kWgWaves = 16;       // the d == 64 kernel runs 1024-thread workgr
 constexpr int kWgRowMax = kWgWaves * kTaskEntries;  // longest row whose segments are combined inside one workgroup
 constexpr int kOpenTasks = 4;      // first-fit packing of short rows keeps this many tasks open
 constexpr int kChunk = 16;         // entries per chunk = gathers a wave keeps in flight
-constexpr int kSoftmaxTile = 2048; // stored entries per workgroup of the row-softmax kernels
+constexpr int kSoftmaxTile = 2048; // stored entries per workgroup of the row-softmax kernels (512 on small graphs)
 
 }  // namespace spex
 
@@ -60,8 +60,9 @@ struct spex_graph {
     int32_t *edge_id = nullptr;  // [nnz] or null (identity)
     int64_t max_edge_id = -1;    // largest edge id (nnz - 1 for identity)
     int32_t *row_of = nullptr;   // [nnz] row of each stored entry, built by the first spex_sddmm_f32
-    int32_t n_tiles = 0;         // ceil(nnz / kSoftmaxTile)
-    int32_t *tile_row = nullptr; // [n_tiles+1] first row starting at or after entry t * kSoftmaxTile
+    int32_t tile = 0;            // stored entries per row-softmax workgroup: kSoftmaxTile, or 512 when that fills < 2 k workgroups
+    int32_t n_tiles = 0;         // ceil(nnz / tile)
+    int32_t *tile_row = nullptr; // [n_tiles+1] first row starting at or after entry t * tile
     // long rows (> kLongRow entries): segment table + per-segment partial rows + per-row fix-up table
     int32_t n_long = 0, n_seg = 0;
     int32_t *seg_beg = nullptr;   // [n_seg] first entry of the segment

@@ -65,7 +65,12 @@ class _Dense(nn.Module):
         self.activation = activation
 
     def forward(self, x):
-        return self.activation(x @ self.kernel + self.bias)
+        # units == 1: a scale (in_features == 1, applied to a per-edge vector) or a row-wise dot product — not a GEMM
+        # (hipBLASLt's N = 1, K = 1 GEMM takes ~1 ms on a 209 k-entry vector; the broadcast multiply takes ~5 us)
+        if self.kernel.shape[0] == 1:
+            return self.activation(x * self.kernel.view(1, 1) + self.bias)
+        # (rocBLAS gemv on a [12 k, 128] operand: ~50 us; multiply + row-sum: ~10 us)
+        return self.activation((x * self.kernel.view(1, -1)).sum(dim=1, keepdim=True) + self.bias)
 
 
 def _leaky(x):
