@@ -252,7 +252,15 @@ struct DropArgs {
 
 // EPI 0: Y = y;  1: Y = y (optional), acc_out = (acc_in + y) / epi_div;  2: Y = (y + add_in / epi_div) / out_div.
 // ROWIDS: a task's rows are listed per entry (bin-packed tasks) instead of being adjacent from task.z.
-template <int EPI, bool MASKED, bool ROWIDS>
+// V: consecutive embedding columns per lane — d = 64 V (64, 128, 256): a gathered row is one coalesced 256 V-byte wave
+// load (dword / dwordx2 / dwordx4 per lane).  The batch of gathers in flight shrinks with V (16 / 8 / 4 rows = 4 KB per
+// wave either way) so the kernel stays inside 128 VGPRs at 16 waves per workgroup.
+template <int V>
+struct VecOf {
+    typedef float T __attribute__((ext_vector_type(V)));
+};
+
+template <int EPI, bool MASKED, bool ROWIDS, int V>
 __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
     const float *__restrict__ X, const uint32_t *__restrict__ chunk_off, const float *__restrict__ chunk_val,
     const uint32_t *__restrict__ chunk_mask, const int32_t *__restrict__ chunk_row, const int4 *__restrict__ task,
@@ -261,7 +269,10 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
     float *__restrict__ partial,
     const DropArgs drop, const int xcd_contiguous)
 {
-    __shared__ float s_part[kWgWaves][kWave];  // segment sums of the rows this workgroup combines
+    typedef typename VecOf<V>::T vec;
+    constexpr int kRow = kWave * V;          // floats per embedding row
+    constexpr int kBatch = kChunk / V;       // gathers issued back to back
+    __shared__ float s_part[kWgWaves][kRow];  // segment sums of the rows this workgroup combines
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // Workgroups are sorted heaviest-first and dealt round-robin over the 8 XCDs by the dispatcher, which gives every
@@ -274,32 +285,32 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
     if (tid >= n_tasks) return;  // whole workgroups only (n_tasks is a multiple of kWgWaves)
     const int4 t = task[tid];
     const int kind = t.w & 3;
-    const float *__restrict__ Xl = X + lane;
-    const float *__restrict__ El = (EPI ? epi_in : X) + lane;
+    const float *__restrict__ Xl = X + lane * V;
+    const float *__restrict__ El = (EPI ? epi_in : X) + lane * V;
     int row = t.z;
-    float acc = 0.0f;
+    vec acc = (vec)(0.0f);
 
-    auto emit = [&](int r, float y, float e) {
-        const size_t o = (size_t)r * 64 + lane;
+    auto emit = [&](int r, vec y, vec e) {
+        const size_t o = (size_t)r * kRow + lane * V;
         // outputs are streamed (non-temporal): they should not evict the gather source from the XCD's L2
         if (EPI == 0) {
-            __builtin_nontemporal_store(y, Y + o);
+            __builtin_nontemporal_store(y, reinterpret_cast<vec *>(Y + o));
         } else if (EPI == 1) {
-            if (Y) __builtin_nontemporal_store(y, Y + o);
-            float s = e + y;
+            if (Y) __builtin_nontemporal_store(y, reinterpret_cast<vec *>(Y + o));
+            vec s = e + y;
             if (epi_div != 1.0f) s = s / epi_div;
-            __builtin_nontemporal_store(s, acc_out + o);
+            __builtin_nontemporal_store(s, reinterpret_cast<vec *>(acc_out + o));
         } else {
             if (epi_div != 1.0f) e = e / epi_div;
-            float s = y + e;
+            vec s = y + e;
             if (out_div != 1.0f) s = s / out_div;
-            __builtin_nontemporal_store(s, Y + o);
+            __builtin_nontemporal_store(s, reinterpret_cast<vec *>(Y + o));
         }
     };
 
     // Metadata of up to 4 chunks (64 entries) per vector load — lane k holds entry k — handed to the scalar side with
     // v_readlane.  (Feeding it through s_load instead starves on scalar-cache misses once the matrix streams from
-    // HBM: 29 ms vs 17 ms per launch on a 2^23-node graph.)
+    // HBM: 29 ms vs 13 ms per launch on a 2^23-node graph.)
     for (int sc = 0; sc < t.y; sc += 4) {
         const int nc = (t.y - sc < 4) ? t.y - sc : 4;  // chunks in this super-chunk (wave-uniform)
         uint32_t my_off = 0u, my_mask = 0u, own_off = 0u;
@@ -336,52 +347,68 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
         if (lane < nc) my_mask = __builtin_nontemporal_load(chunk_mask + t.x + sc + lane);
         for (int c = 0; c < nc; ++c) {
             const uint32_t mask = (uint32_t)__builtin_amdgcn_readlane((int)my_mask, c) & 0xFFFFu;   // (bits 16-20: padding count)
-            float x[kChunk], ep[kChunk];
 #pragma unroll
-            for (int u = 0; u < kChunk; ++u)
-                x[u] = Xl[(size_t)(uint32_t)__builtin_amdgcn_readlane((int)my_off, c * kChunk + u) * 64];
-            if (EPI != 0 && mask != 0u) {
-                int r = row;
+            for (int u0 = 0; u0 < kChunk; u0 += kBatch) {
+                vec x[kBatch], ep[kBatch];
 #pragma unroll
-                for (int u = 0; u < kChunk; ++u) {
-                    ep[u] = 0.0f;
-                    if (mask & (1u << u)) {
-                        const int rr = ROWIDS ? __builtin_amdgcn_readlane(my_row, c * kChunk + u) : r;
-                        ep[u] = __builtin_nontemporal_load(El + (size_t)rr * 64);
-                        ++r;
+                for (int u = 0; u < kBatch; ++u)
+                    x[u] = *reinterpret_cast<const vec *>(
+                        Xl + (size_t)(uint32_t)__builtin_amdgcn_readlane((int)my_off, c * kChunk + u0 + u) * kRow);
+                const uint32_t bmask = (mask >> u0) & ((1u << kBatch) - 1u);
+                if (EPI != 0 && bmask != 0u) {
+                    int r = row;
+#pragma unroll
+                    for (int u = 0; u < kBatch; ++u) {
+                        ep[u] = (vec)(0.0f);
+                        if (bmask & (1u << u)) {
+                            const int rr = ROWIDS ? __builtin_amdgcn_readlane(my_row, c * kChunk + u0 + u) : r;
+                            ep[u] = __builtin_nontemporal_load(reinterpret_cast<const vec *>(El + (size_t)rr * kRow));
+                            ++r;
+                        }
                     }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < kBatch; ++u) ep[u] = (vec)(0.0f);
                 }
-            } else {
 #pragma unroll
-                for (int u = 0; u < kChunk; ++u) ep[u] = 0.0f;
-            }
+                for (int u = 0; u < kBatch; ++u) {
+                    const float a = lane_bcast(my_val, c * kChunk + u0 + u);
 #pragma unroll
-            for (int u = 0; u < kChunk; ++u) {
-                acc = fmaf(lane_bcast(my_val, c * kChunk + u), x[u], acc);
-                if (mask & (1u << u)) {  // only packs of whole rows carry mask bits
-                    emit(ROWIDS ? __builtin_amdgcn_readlane(my_row, c * kChunk + u) : row, acc, ep[u]);
-                    acc = 0.0f;
-                    ++row;
+                    for (int j = 0; j < V; ++j) acc[j] = fmaf(a, x[u][j], acc[j]);
+                    if (bmask & (1u << u)) {  // only packs of whole rows carry mask bits
+                        emit(ROWIDS ? __builtin_amdgcn_readlane(my_row, c * kChunk + u0 + u) : row, acc, ep[u]);
+                        acc = (vec)(0.0f);
+                        ++row;
+                    }
                 }
             }
         }
     }
     if (kind == 0 && t.y == 0 && t.z >= 0) {  // a row without stored entries: y = 0, the epilogue still applies
-        float e = 0.0f;
-        if (EPI != 0) e = El[(size_t)t.z * 64];
-        emit(t.z, 0.0f, e);
+        vec e = (vec)(0.0f);
+        if (EPI != 0) e = *reinterpret_cast<const vec *>(El + (size_t)t.z * kRow);
+        emit(t.z, (vec)(0.0f), e);
     }
-    if (kind == 2) partial[(size_t)(t.w >> 4) * 64 + lane] = acc;  // hub segment: summed by the fix-up launch
+    if (kind == 2) {  // hub segment: summed by the fix-up launch
+#pragma unroll
+        for (int j = 0; j < V; ++j) partial[(size_t)(t.w >> 4) * kRow + lane * V + j] = acc[j];
+    }
     if (t.w & 4) {  // this workgroup combines the segments of rows with 65..1024 entries through LDS
         const bool leader = kind == 1 && (t.w & 8);
         const int slot = (t.w >> 4) & 15, nseg = (t.w >> 8) & 31;
-        float e = 0.0f;
-        if (leader && EPI != 0) e = El[(size_t)t.z * 64];
-        if (kind == 1 && !leader) s_part[slot][lane] = acc;
+        vec e = (vec)(0.0f);
+        if (leader && EPI != 0) e = *reinterpret_cast<const vec *>(El + (size_t)t.z * kRow);
+        if (kind == 1 && !leader) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) s_part[slot][lane + j * kWave] = acc[j];   // column-major per lane: conflict-free
+        }
         __syncthreads();
         if (leader) {
-            float y = acc;
-            for (int sgi = 1; sgi < nseg; ++sgi) y = y + s_part[slot + sgi][lane];  // segment order: deterministic
+            vec y = acc;
+            for (int sgi = 1; sgi < nseg; ++sgi) {  // segment order: deterministic
+#pragma unroll
+                for (int j = 0; j < V; ++j) y[j] = y[j] + s_part[slot + sgi][lane + j * kWave];
+            }
             emit(t.z, y, e);
         }
     }
@@ -427,14 +454,14 @@ __global__ __launch_bounds__(256) void div_kernel(const float *__restrict__ in, 
     if (blockIdx.x == 0 && (int64_t)threadIdx.x < rem) out[n4 * 4 + threadIdx.x] = in[n4 * 4 + threadIdx.x] / div;
 }
 
-// Pick the instantiation of the d == 64 kernel (epilogue form is a template argument of the caller).
-template <int EPI>
-void launch_chunk(bool masked, bool row_ids, dim3 grid, dim3 block, hipStream_t stream, const float *X, const spex_graph *g,
-                  float *Y, const float *epi_in, float epi_div, float out_div, float *acc_out, const DropArgs &da,
-                  int xcd_contig)
+// Pick the instantiation of the chunk kernel (epilogue form is a template argument of the caller; V = d / 64).
+template <int EPI, int V>
+void launch_chunk_v(bool masked, bool row_ids, dim3 grid, dim3 block, hipStream_t stream, const float *X, const spex_graph *g,
+                    float *Y, const float *epi_in, float epi_div, float out_div, float *acc_out, const DropArgs &da,
+                    int xcd_contig)
 {
 #define SPEX_GO(M, R)                                                                                                  \
-    hipLaunchKernelGGL((spmm_chunk_kernel<EPI, M, R>), grid, block, 0, stream, X, g->chunk_off, g->chunk_val,          \
+    hipLaunchKernelGGL((spmm_chunk_kernel<EPI, M, R, V>), grid, block, 0, stream, X, g->chunk_off, g->chunk_val,       \
                        g->chunk_mask, g->chunk_row, g->task, g->n_tasks, Y, epi_in, epi_div, out_div, acc_out, g->partial, \
                        da, xcd_contig)
     if (masked) {
@@ -451,6 +478,16 @@ void launch_chunk(bool masked, bool row_ids, dim3 grid, dim3 block, hipStream_t 
         }
     }
 #undef SPEX_GO
+}
+
+template <int EPI>
+void launch_chunk(int d, bool masked, bool row_ids, dim3 grid, dim3 block, hipStream_t stream, const float *X,
+                  const spex_graph *g, float *Y, const float *epi_in, float epi_div, float out_div, float *acc_out,
+                  const DropArgs &da, int xcd_contig)
+{
+    if (d == 64) launch_chunk_v<EPI, 1>(masked, row_ids, grid, block, stream, X, g, Y, epi_in, epi_div, out_div, acc_out, da, xcd_contig);
+    else if (d == 128) launch_chunk_v<EPI, 2>(masked, row_ids, grid, block, stream, X, g, Y, epi_in, epi_div, out_div, acc_out, da, xcd_contig);
+    else launch_chunk_v<EPI, 4>(masked, row_ids, grid, block, stream, X, g, Y, epi_in, epi_div, out_div, acc_out, da, xcd_contig);
 }
 
 // Profiling hook: one hipEvent pair around ALL the SpMM launches of an API call (a 3-layer propagation is one bracket
@@ -494,8 +531,8 @@ int launch_spmm(const spex_graph *g, const float *X, float *Y, const float *add_
     p.seed_lo = (uint32_t)g->seed; p.seed_hi = (uint32_t)(g->seed >> 32);
 
     const bool masked = g->mask_mode != 0;
-    // fast path: d == 64, chunked table present, and not both epilogues at once
-    const bool fast = d == 64 && g->task != nullptr && !(acc_out && add_in);
+    // fast path: d in {64, 128, 256}, chunked table present, and not both epilogues at once
+    const bool fast = (d == 64 || d == 128 || d == 256) && g->task != nullptr && !(acc_out && add_in);
     const int per_block = fast ? kWgWaves : kWavesPerBlock;
     const int64_t tasks = fast ? (int64_t)g->n_tasks : (int64_t)g->n_seg + g->n_rows;  // waves
     int64_t blocks = (tasks + per_block - 1) / per_block;
@@ -508,9 +545,9 @@ int launch_spmm(const spex_graph *g, const float *X, float *Y, const float *add_
         DropArgs da;
         da.chunk_eid = g->chunk_eid; da.keep = g->keep; da.mode = g->mask_mode; da.keep_prob = g->keep_prob;
         da.seed_lo = (uint32_t)g->seed; da.seed_hi = (uint32_t)(g->seed >> 32);
-        if (acc_out) launch_chunk<1>(masked, g->row_ids, grid, block, stream, X, g, Y, acc_in, acc_div, 1.0f, acc_out, da, xcd_contig);
-        else if (add_in) launch_chunk<2>(masked, g->row_ids, grid, block, stream, X, g, Y, add_in, add_div, out_div, nullptr, da, xcd_contig);
-        else launch_chunk<0>(masked, g->row_ids, grid, block, stream, X, g, Y, nullptr, 1.0f, 1.0f, nullptr, da, xcd_contig);
+        if (acc_out) launch_chunk<1>(d, masked, g->row_ids, grid, block, stream, X, g, Y, acc_in, acc_div, 1.0f, acc_out, da, xcd_contig);
+        else if (add_in) launch_chunk<2>(d, masked, g->row_ids, grid, block, stream, X, g, Y, add_in, add_div, out_div, nullptr, da, xcd_contig);
+        else launch_chunk<0>(d, masked, g->row_ids, grid, block, stream, X, g, Y, nullptr, 1.0f, 1.0f, nullptr, da, xcd_contig);
     } else if (masked) {
         hipLaunchKernelGGL((spmm_rows_kernel<true>), grid, block, 0, stream, p);
     } else {

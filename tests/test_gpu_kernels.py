@@ -3,7 +3,7 @@ oracle on the same seeded inputs and against the golden vectors minted from the 
 
 Tolerances: the north star asks per-layer embeddings within 1e-5 relative in fp32; the SpMM's fmaf chain is the
 oracle's, so rows handled by one wave are required to match BIT-FOR-BIT, and only rows cut into segments (> 64
-entries on the d == 64 kernel, > 128 on the generic one) may differ by the re-association of their partial sums
+entries on the tuned d = 64 / 128 / 256 kernel, > 128 on the generic one) may differ by the re-association of their partial sums
 (<= 1e-6 relative here).
 """
 import numpy as np
@@ -48,7 +48,7 @@ def test_library_is_the_hip_build():
     assert _lib.load().spex_version() == 1
 
 
-@pytest.mark.parametrize("d", [64, 32, 100, 128, 1])
+@pytest.mark.parametrize("d", [64, 32, 100, 128, 256, 1])
 def test_spmm_matches_oracle_random_graph(G, oracle, d):
     rng = np.random.default_rng(d)
     n_rows, n_cols = 700, 500
@@ -62,7 +62,7 @@ def test_spmm_matches_oracle_random_graph(G, oracle, d):
     assert g.n_long_rows == 2 and g.n_segments == 4 + 2
     Y = g.spmm(t(X)).cpu().numpy()
     ref = oracle.spmm(rowptr, col, val, X)
-    short = np.diff(rowptr) <= (64 if d == 64 else 128)            # rows owned by a single wave
+    short = np.diff(rowptr) <= (64 if d in (64, 128, 256) else 128)  # rows owned by a single wave
     assert np.array_equal(Y[short], ref[short])                    # bit-exact fmaf chain
     assert rel_err(Y[~short], ref[~short]) <= 1e-6
     assert np.all(Y[deg == 0] == 0)
@@ -606,3 +606,45 @@ def test_learned_spmm_autograd_matches_torch_sparse(G):
     assert abs(loss.item() - loss2.item()) <= 1e-5 * max(1.0, abs(loss2.item()))
     assert (p.grad.double() - p2.grad).abs().max().item() <= 1e-5 * p2.grad.abs().max().item()
     assert (X.grad.double() - X2.grad).abs().max().item() <= 1e-5 * X2.grad.abs().max().item()
+
+
+@pytest.mark.parametrize("d", [128, 256])
+@pytest.mark.parametrize("n_cols", [900, 70000])           # <= 16 MiB table: bin-packed tasks with row ids; above: adjacent rows
+def test_wide_embeddings_take_the_tuned_kernel(G, oracle, d, n_cols):
+    """d = 128 / 256: the chunk kernel with 2 / 4 columns per lane — every row form (empty, single-wave, combined in the
+    workgroup, hub), the three epilogues and the propagation wrapper."""
+    rng = np.random.default_rng(d + n_cols)
+    n_rows = 400
+    deg = rng.integers(0, 64, n_rows)
+    deg[[0, 1, 2, 3, 4, 5, 6, 7]] = [0, 1, 64, 65, 700, 1024, 1025, 1500][: 8]
+    deg = np.minimum(deg, n_cols)
+    rowptr, col, val = random_csr(rng, n_rows, n_cols, deg)
+    g = G(rowptr, col, val, n_cols=n_cols)
+    X = rng.normal(size=(n_cols, d)).astype(np.float32)
+    add, acc = (rng.normal(size=(n_rows, d)).astype(np.float32) for _ in range(2))
+    y = oracle.spmm(rowptr, col, val, X)
+    exact = np.diff(rowptr) <= 64          # longer rows re-associate <= 16 partial sums of random-sign terms: <= 3e-6
+    got = g.spmm(t(X)).cpu().numpy()
+    assert np.array_equal(got[exact], y[exact]) and rel_err(got, y) <= 3e-6
+    Y, A = torch.empty(n_rows, d, device=DEV), t(acc)
+    g.spmm(t(X), Y=Y, acc_in=A, acc_out=A, acc_div=4.0)
+    assert np.array_equal(Y.cpu().numpy(), got)
+    want = (acc + y) / np.float32(4.0)
+    assert np.array_equal(A.cpu().numpy()[exact], want[exact]) and rel_err(A.cpu().numpy(), want) <= 3e-6
+    Y2 = g.spmm(t(X), add_in=t(add), add_div=3.0).cpu().numpy()
+    want2 = y + add / np.float32(3.0)
+    assert np.array_equal(Y2[exact], want2[exact]) and rel_err(Y2, want2) <= 3e-6
+    if n_cols == 900:
+        # square graph: whole propagation (ping-pong workspace, running mean) at this width
+        rp, cc, vv = random_csr(rng, 900, 900, np.minimum(rng.integers(0, 90, 900) + (np.arange(900) == 5) * 800, 900))
+        vv = (vv * 0.1).astype(np.float32)
+        gs = G(rp, cc, vv)
+        E0 = rng.normal(size=(900, d)).astype(np.float32)
+        out = gs.propagate(t(E0), 3).cpu().numpy()
+        assert rel_err(out, oracle.propagate_mean(rp, cc, vv, E0, 3)) <= 1e-6
+        back = gs.propagate_bwd(t(E0), 3).cpu().numpy()          # (A need not be symmetric: this is A's own operator)
+        cur = E0 / np.float32(4.0)
+        acc_ref = cur.copy()
+        for _ in range(3):
+            acc_ref = cur + oracle.spmm(rp, cc, vv, acc_ref)
+        assert rel_err(back, acc_ref) <= 1e-5

@@ -19,14 +19,14 @@ sys.path.insert(0, ROOT)
 from spex_amd.datasets import scaled_graph           # noqa: E402
 from spex_amd.graph import SpexGraph                 # noqa: E402
 
-D = 64
-
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--lo", type=int, default=14)
     ap.add_argument("--hi", type=int, default=24)
+    ap.add_argument("--d", type=int, default=64)
     a = ap.parse_args()
+    D = a.d
     dev = torch.device("cuda:0")
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     log = open(os.path.join(ROOT, "gpurun_out", "size_sweep.jsonl"), "a")
@@ -50,7 +50,7 @@ def main():
         ms_avg, ms_min = float(ms.mean()), float(ms.min())
         alg = nnz * (8 + 4 * D) + n * (4 + 4 * D)                  # SURVEY.md 8d gather model
         comp = nnz * 8 + n * (4 + 8 * D)                           # compulsory: every table row read once
-        row = {"log2_nodes": lg, "replicas": max(1, round((1 << lg) / 15593)), "n_nodes": n, "nnz": nnz,
+        row = {"d": D, "log2_nodes": lg, "replicas": max(1, round((1 << lg) / 15593)), "n_nodes": n, "nnz": nnz,
                "table_MB": n * D * 4 / 1e6, "launch_us_avg": ms_avg * 1e3, "launch_us_min": ms_min * 1e3,
                "edges_per_s": nnz / (ms_avg * 1e-3), "algorithmic_GBs": alg / (ms_avg * 1e-3) / 1e9,
                "compulsory_GBs": comp / (ms_avg * 1e-3) / 1e9, "frac_of_8TBs": alg / (ms_avg * 1e-3) / 8e12,
