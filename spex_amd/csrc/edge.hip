@@ -43,11 +43,11 @@ __global__ void set_csr_values_kernel(float *__restrict__ val, const int32_t *__
 }
 
 __global__ void set_chunk_values_kernel(float *__restrict__ chunk_val, const uint32_t *__restrict__ chunk_eid,
-                                        const uint32_t *__restrict__ chunk_mask, const float *__restrict__ src,
+                                        const uint8_t *__restrict__ chunk_pad, const float *__restrict__ src,
                                         int64_t n_entries)
 {
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_entries; k += (int64_t)gridDim.x * blockDim.x) {
-        const uint32_t n_pad = (chunk_mask[k / kChunk] >> 16) & 31u;
+        const uint32_t n_pad = chunk_pad[k / kChunk];
         const bool pad = (uint32_t)(k % kChunk) >= (uint32_t)kChunk - n_pad;
         chunk_val[k] = pad ? 0.0f : src[chunk_eid[k]];
     }
@@ -264,7 +264,7 @@ extern "C" int spex_graph_set_values(spex_graph_t *g, const float *d_val, int64_
     const int64_t n_entries = g->n_chunks * kChunk;
     if (n_entries > 0)
         hipLaunchKernelGGL(set_chunk_values_kernel, dim3(stream_grid(n_entries, threads)), dim3(threads), 0, (hipStream_t)stream,
-                           g->chunk_val, g->chunk_eid, g->chunk_mask, d_val, n_entries);
+                           g->chunk_val, g->chunk_eid, g->chunk_pad, d_val, n_entries);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }

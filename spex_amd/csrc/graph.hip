@@ -35,7 +35,7 @@ extern "C" int spex_graph_destroy(spex_graph_t *g)
 {
     if (!g) return SPEX_OK;
     void *ptrs[] = {g->rowptr, g->col, g->val, g->edge_id, g->seg_beg, g->seg_end, g->long_row, g->long_seg0, g->partial,
-                    g->task, g->chunk_off, g->chunk_val, g->chunk_mask, g->chunk_eid, g->chunk_row, g->hub_row, g->hub_seg0, g->row_of, g->tile_row};
+                    g->task, g->chunk_off, g->chunk_val, g->chunk_mask, g->chunk_eid, g->chunk_row, g->hub_row, g->hub_seg0, g->row_of, g->tile_row, g->chunk_pad};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete g;
@@ -98,6 +98,7 @@ extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, 
     //           the wave in its workgroup (= LDS slot), bits 8-12 number of segments of the row; kind 2: bits 4.. slot.
     std::vector<int4> task;
     std::vector<uint32_t> c_off, c_mask, c_eid;
+    std::vector<uint8_t> c_pad;                     // padding entries at the end of each chunk (spex_graph_set_values)
     std::vector<int32_t> c_row;
     std::vector<float> c_val;
     std::vector<int32_t> hub_row, hub_seg0;
@@ -125,6 +126,7 @@ extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, 
                 last_row = r;
                 if (++in_chunk == spex::kChunk) {
                     c_mask.push_back(mask);
+                    c_pad.push_back(0);
                     mask = 0;
                     in_chunk = 0;
                 }
@@ -144,7 +146,8 @@ extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, 
                 c_eid.push_back((uint32_t)last_eid);
                 if (g->row_ids) c_row.push_back(last_row);
                 if (++in_chunk == spex::kChunk) {
-                    c_mask.push_back(mask | (n_pad << 16));
+                    c_mask.push_back(mask);
+                    c_pad.push_back((uint8_t)n_pad);
                     mask = 0;
                     in_chunk = 0;
                 }
@@ -285,6 +288,7 @@ extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, 
         (rc = upload(&g->chunk_off, c_off.data(), c_off.size())) ||
         (rc = upload(&g->chunk_val, c_val.data(), c_val.size())) ||
         (rc = upload(&g->chunk_mask, c_mask.data(), c_mask.size())) ||
+        (rc = upload(&g->chunk_pad, c_pad.data(), c_pad.size())) ||
         (rc = upload(&g->chunk_eid, c_eid.data(), c_eid.size())) ||
         (rc = upload(&g->chunk_row, c_row.data(), c_row.size())) ||
         (rc = upload(&g->hub_row, hub_row.data(), hub_row.size())) ||

@@ -78,14 +78,15 @@ struct spex_graph {
     // 16-wave workgroup and are summed through LDS in segment order — or (rows > 1024 entries only) a 128-entry
     // segment whose partial row goes through global scratch and the fix-up launch.  Tasks are padded to whole chunks
     // with value-0 entries on the task's last real source row (a line already being fetched); a chunk's padding sits at
-    // its end and chunk_mask bits 16-20 hold its count.
+    // its end (count in chunk_pad).
     //   task.x = first chunk, .y = number of chunks, .z = (first) row or -1, .w = kind | flags (see graph.hip)
     int32_t n_tasks = 0;
     int4 *task = nullptr;          // [n_tasks], heaviest first
     int64_t n_chunks = 0;
     uint32_t *chunk_off = nullptr; // [n_chunks * 16]
     float *chunk_val = nullptr;    // [n_chunks * 16]
-    uint32_t *chunk_mask = nullptr; // [n_chunks] bits 0-15 end-of-row flags, bits 16-20 number of padding entries
+    uint32_t *chunk_mask = nullptr; // [n_chunks] end-of-row flags (16 bits)
+    uint8_t *chunk_pad = nullptr;   // [n_chunks] number of padding entries at the end of the chunk
     uint32_t *chunk_eid = nullptr;  // [n_chunks * 16] edge id of each entry (keep-mask index); read only under dropout
     bool row_ids = false;           // tasks pack non-adjacent rows (cache-resident graphs): the kernel reads chunk_row
     int32_t *chunk_row = nullptr;   // [n_chunks * 16] output row of each entry, only when row_ids

@@ -252,8 +252,145 @@ struct DropArgs {
 
 // EPI 0: Y = y;  1: Y = y (optional), acc_out = (acc_in + y) / epi_div;  2: Y = (y + add_in / epi_div) / out_div.
 // ROWIDS: a task's rows are listed per entry (bin-packed tasks) instead of being adjacent from task.z.
-// V: consecutive embedding columns per lane — d = 64 V (64, 128, 256): a gathered row is one coalesced 256 V-byte wave
-// load (dword / dwordx2 / dwordx4 per lane).  The batch of gathers in flight shrinks with V (16 / 8 / 4 rows = 4 KB per
+template <int EPI, bool MASKED, bool ROWIDS>
+__global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
+    const float *__restrict__ X, const uint32_t *__restrict__ chunk_off, const float *__restrict__ chunk_val,
+    const uint32_t *__restrict__ chunk_mask, const int32_t *__restrict__ chunk_row, const int4 *__restrict__ task,
+    int n_tasks, float *__restrict__ Y,
+    const float *__restrict__ epi_in, float epi_div, float out_div, float *__restrict__ acc_out,
+    float *__restrict__ partial,
+    const DropArgs drop, const int xcd_contiguous)
+{
+    __shared__ float s_part[kWgWaves][kWave];  // segment sums of the rows this workgroup combines
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // Workgroups are sorted heaviest-first and dealt round-robin over the 8 XCDs by the dispatcher, which gives every
+    // XCD the same mix of weights: right for a graph that streams from HBM (+14 % on Epinion2x538 over handing XCD 0
+    // all the heavy workgroups).  A graph whose whole source table sits in cache instead prefers each XCD to walk a
+    // contiguous range of workgroups (user rows and item rows of the bipartite graph then gather from different
+    // halves of the table in different L2s: 76 % vs 71 % L2 hits on Epinion2).  Placement is a speed matter only.
+    const int wg = xcd_contiguous ? xcd_contiguous_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int tid = wg * kWgWaves + wave;
+    if (tid >= n_tasks) return;  // whole workgroups only (n_tasks is a multiple of kWgWaves)
+    const int4 t = task[tid];
+    const int kind = t.w & 3;
+    const float *__restrict__ Xl = X + lane;
+    const float *__restrict__ El = (EPI ? epi_in : X) + lane;
+    int row = t.z;
+    float acc = 0.0f;
+
+    auto emit = [&](int r, float y, float e) {
+        const size_t o = (size_t)r * 64 + lane;
+        // outputs are streamed (non-temporal): they should not evict the gather source from the XCD's L2
+        if (EPI == 0) {
+            __builtin_nontemporal_store(y, Y + o);
+        } else if (EPI == 1) {
+            if (Y) __builtin_nontemporal_store(y, Y + o);
+            float s = e + y;
+            if (epi_div != 1.0f) s = s / epi_div;
+            __builtin_nontemporal_store(s, acc_out + o);
+        } else {
+            if (epi_div != 1.0f) e = e / epi_div;
+            float s = y + e;
+            if (out_div != 1.0f) s = s / out_div;
+            __builtin_nontemporal_store(s, Y + o);
+        }
+    };
+
+    // Metadata of up to 4 chunks (64 entries) per vector load — lane k holds entry k — handed to the scalar side with
+    // v_readlane.  (Feeding it through s_load instead starves on scalar-cache misses once the matrix streams from
+    // HBM: 29 ms vs 13 ms per launch on a 2^23-node graph.)
+    for (int sc = 0; sc < t.y; sc += 4) {
+        const int nc = (t.y - sc < 4) ? t.y - sc : 4;  // chunks in this super-chunk (wave-uniform)
+        uint32_t my_off = 0u, my_mask = 0u, own_off = 0u;
+        int my_row = 0;
+        float my_val = 0.0f;
+        if (lane < nc * kChunk) {
+            const size_t e = (size_t)(t.x + sc) * kChunk + lane;
+            my_off = __builtin_nontemporal_load(chunk_off + e);   // metadata is read once per launch
+            my_val = __builtin_nontemporal_load(chunk_val + e);
+            if (ROWIDS) my_row = __builtin_nontemporal_load(chunk_row + e);
+            if (MASKED) {
+                const uint32_t eid = __builtin_nontemporal_load(drop.chunk_eid + e);
+                bool kept;
+                if (drop.mode == 1) {
+                    kept = drop.keep[eid] != 0;
+                } else {
+                    const float u01 = (float)(philox_first(eid, drop.seed_lo, drop.seed_hi) >> 8) * 5.9604644775390625e-8f;
+                    kept = (u01 + drop.keep_prob) >= 1.0f;
+                }
+                my_val = kept ? my_val / drop.keep_prob : 0.0f;   // values[random_index] / keep_prob, model.py:53
+                own_off = my_off;
+                if (!kept) my_off = 0xFFFFFFFFu;
+            }
+        }
+        if (MASKED) {
+            // a dropped entry re-reads the source row of the first KEPT entry of this super-chunk (fetched anyway, so
+            // it adds +0 and no traffic); if every entry was dropped each keeps its own row (value 0)
+            const bool dropped = my_off == 0xFFFFFFFFu;      // (lanes past the super-chunk hold 0: neither kept nor dropped)
+            const unsigned long long kept_lanes = __ballot(!dropped && lane < nc * kChunk);
+            const int src = kept_lanes ? (int)__builtin_ctzll(kept_lanes) : 0;
+            const uint32_t stand_in = (uint32_t)__builtin_amdgcn_readlane((int)my_off, src);   // wave-uniform
+            if (dropped) my_off = kept_lanes ? stand_in : own_off;
+        }
+        if (lane < nc) my_mask = __builtin_nontemporal_load(chunk_mask + t.x + sc + lane);
+        for (int c = 0; c < nc; ++c) {
+            const uint32_t mask = (uint32_t)__builtin_amdgcn_readlane((int)my_mask, c);
+            float x[kChunk], ep[kChunk];
+#pragma unroll
+            for (int u = 0; u < kChunk; ++u)
+                x[u] = Xl[(size_t)(uint32_t)__builtin_amdgcn_readlane((int)my_off, c * kChunk + u) * 64];
+            if (EPI != 0 && mask != 0u) {
+                int r = row;
+#pragma unroll
+                for (int u = 0; u < kChunk; ++u) {
+                    ep[u] = 0.0f;
+                    if (mask & (1u << u)) {
+                        const int rr = ROWIDS ? __builtin_amdgcn_readlane(my_row, c * kChunk + u) : r;
+                        ep[u] = __builtin_nontemporal_load(El + (size_t)rr * 64);
+                        ++r;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < kChunk; ++u) ep[u] = 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < kChunk; ++u) {
+                acc = fmaf(lane_bcast(my_val, c * kChunk + u), x[u], acc);
+                if (mask & (1u << u)) {  // only packs of whole rows carry mask bits
+                    emit(ROWIDS ? __builtin_amdgcn_readlane(my_row, c * kChunk + u) : row, acc, ep[u]);
+                    acc = 0.0f;
+                    ++row;
+                }
+            }
+        }
+    }
+    if (kind == 0 && t.y == 0 && t.z >= 0) {  // a row without stored entries: y = 0, the epilogue still applies
+        float e = 0.0f;
+        if (EPI != 0) e = El[(size_t)t.z * 64];
+        emit(t.z, 0.0f, e);
+    }
+    if (kind == 2) partial[(size_t)(t.w >> 4) * 64 + lane] = acc;  // hub segment: summed by the fix-up launch
+    if (t.w & 4) {  // this workgroup combines the segments of rows with 65..1024 entries through LDS
+        const bool leader = kind == 1 && (t.w & 8);
+        const int slot = (t.w >> 4) & 15, nseg = (t.w >> 8) & 31;
+        float e = 0.0f;
+        if (leader && EPI != 0) e = El[(size_t)t.z * 64];
+        if (kind == 1 && !leader) s_part[slot][lane] = acc;
+        __syncthreads();
+        if (leader) {
+            float y = acc;
+            for (int sgi = 1; sgi < nseg; ++sgi) y = y + s_part[slot + sgi][lane];  // segment order: deterministic
+            emit(t.z, y, e);
+        }
+    }
+}
+
+// The same kernel for wider embeddings.
+// V: consecutive embedding columns per lane — d = 64 V (128, 256; V = 1 is the d == 64 kernel above, kept as its own
+// source because its inner-loop schedule is worth ~10 % there and the generic form schedules differently): a gathered
+// row is one coalesced 256 V-byte wave load (dwordx2 / dwordx4 per lane).  The batch of gathers in flight shrinks with V (16 / 8 / 4 rows = 4 KB per
 // wave either way) so the kernel stays inside 128 VGPRs at 16 waves per workgroup.
 template <int V>
 struct VecOf {
@@ -261,7 +398,7 @@ struct VecOf {
 };
 
 template <int EPI, bool MASKED, bool ROWIDS, int V>
-__global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
+__global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_wide_kernel(
     const float *__restrict__ X, const uint32_t *__restrict__ chunk_off, const float *__restrict__ chunk_val,
     const uint32_t *__restrict__ chunk_mask, const int32_t *__restrict__ chunk_row, const int4 *__restrict__ task,
     int n_tasks, float *__restrict__ Y,
@@ -346,7 +483,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
         }
         if (lane < nc) my_mask = __builtin_nontemporal_load(chunk_mask + t.x + sc + lane);
         for (int c = 0; c < nc; ++c) {
-            const uint32_t mask = (uint32_t)__builtin_amdgcn_readlane((int)my_mask, c) & 0xFFFFu;   // (bits 16-20: padding count)
+            const uint32_t mask = (uint32_t)__builtin_amdgcn_readlane((int)my_mask, c);
 #pragma unroll
             for (int u0 = 0; u0 < kChunk; u0 += kBatch) {
                 vec x[kBatch], ep[kBatch];
@@ -461,9 +598,16 @@ void launch_chunk_v(bool masked, bool row_ids, dim3 grid, dim3 block, hipStream_
                     int xcd_contig)
 {
 #define SPEX_GO(M, R)                                                                                                  \
-    hipLaunchKernelGGL((spmm_chunk_kernel<EPI, M, R, V>), grid, block, 0, stream, X, g->chunk_off, g->chunk_val,       \
-                       g->chunk_mask, g->chunk_row, g->task, g->n_tasks, Y, epi_in, epi_div, out_div, acc_out, g->partial, \
-                       da, xcd_contig)
+    do {                                                                                                               \
+        if (V == 1)                                                                                                    \
+            hipLaunchKernelGGL((spmm_chunk_kernel<EPI, M, R>), grid, block, 0, stream, X, g->chunk_off, g->chunk_val,  \
+                               g->chunk_mask, g->chunk_row, g->task, g->n_tasks, Y, epi_in, epi_div, out_div, acc_out, \
+                               g->partial, da, xcd_contig);                                                            \
+        else                                                                                                           \
+            hipLaunchKernelGGL((spmm_chunk_wide_kernel<EPI, M, R, (V == 1 ? 2 : V)>), grid, block, 0, stream, X,       \
+                               g->chunk_off, g->chunk_val, g->chunk_mask, g->chunk_row, g->task, g->n_tasks, Y, epi_in, \
+                               epi_div, out_div, acc_out, g->partial, da, xcd_contig);                                 \
+    } while (0)
     if (masked) {
         if (row_ids) {
             SPEX_GO(true, true);
