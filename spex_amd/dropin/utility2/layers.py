@@ -30,7 +30,7 @@ class GraphAttentionLayer(nn.Module):
         seq_l = seq_l.to(self.a.device)
         if self.concat:
             seq = seq.to(self.a.device).long()
-            raw = emb[seq]                                                    # [B, L, H]
+            raw = emb.index_select(0, seq.reshape(-1)).view(*seq.shape, H)    # [B, L, H]; index_select: atomic backward
             L = seq.shape[1]
             pos = (seq_l[:, None] - torch.arange(L, device=raw.device)[None, :]).to(raw.dtype)   # l - i
             a = raw + pos[..., None]
