@@ -263,7 +263,10 @@ class LightTrainData(Dataset):
         return int(self.users_fill[idx]), int(self.items_fill[idx]), int(self.labels_fill_np[idx])
 
     def __getitems__(self, indices):
-        """Batched fetch used by torch's DataLoader: one fancy-index instead of 256 __getitem__ calls."""
+        """Batched fetch used by torch's DataLoader: one fancy-index per field instead of 256 __getitem__ calls.  Returns
+        the three fields as int64 tensors; DataLoader's default collate stacks them into one [3, B] tensor, which the
+        caller's `user, item, label = data` (main_rec.py:32) unpacks into the same three [B] int64 tensors the reference's
+        per-sample collate produces — without building and re-parsing 256 Python tuples per step."""
         ix = np.asarray(indices)
-        u, i, l = self.users_fill[ix], self.items_fill[ix], self.labels_fill_np[ix]
-        return [(int(a), int(b), int(c)) for a, b, c in zip(u, i, l)]
+        return [torch.from_numpy(self.users_fill[ix]), torch.from_numpy(self.items_fill[ix]),
+                torch.from_numpy(self.labels_fill_np[ix])]

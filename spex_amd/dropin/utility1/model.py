@@ -133,6 +133,15 @@ class LightGCN(BasicModel):
     def forward(self, users, items, labels, flag=0):
         if flag not in (0, 1):
             raise ValueError("flag must be 0 (loss) or 1 (scores)")
+        uw, iw = self.embedding_user.weight, self.embedding_item.weight
+        if (flag == 0 and uw.is_cuda and torch.is_grad_enabled() and (uw.requires_grad or iw.requires_grad)
+                and not isinstance(self.Graph, (list, tuple))):
+            # training step: propagation + scoring as one autograd node
+            dev = uw.device
+            mask = self._mask_for_step()
+            graph_t = self._transposed() if mask is not None else self.Graph
+            return ops.LightGCNBCELoss.apply(uw, iw, self.Graph, graph_t, self.n_layers, mask, ops._idx(users, dev),
+                                             ops._idx(items, dev), labels.to(device=dev, dtype=torch.float32))
         light_out = self._light_out()
         n_u = self.num_users + 1
         if flag == 1:

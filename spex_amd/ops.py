@@ -183,6 +183,46 @@ class ScoreBCELoss(torch.autograd.Function):
         return grad * g, None, None, None, None
 
 
+class LightGCNBCELoss(torch.autograd.Function):
+    """PropagateMean followed by ScoreBCELoss as ONE autograd node — the training step of model.py:111-121 behind
+    `forward(users, items, labels, flag=0)`: same kernels, one Function.apply and one backward node less per step (the
+    step is host-bound under the reference's driver loop)."""
+
+    @staticmethod
+    def forward(ctx, user_w, item_w, graph, graph_t, n_layers, mask, u_idx, i_idx, labels):
+        E0 = _flat_tables(user_w, item_w)
+        if mask is not None:
+            graph.set_edge_mask(*mask)
+        try:
+            light_out = graph.propagate(E0, n_layers)
+        finally:
+            if mask is not None:
+                graph.set_edge_mask(0)
+        n_u = user_w.shape[0]
+        B = u_idx.numel()
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        grad = torch.zeros_like(light_out) if need else None
+        _, loss_sum = score_bce(light_out[:n_u], light_out[n_u:], u_idx, i_idx, labels,
+                                grad[:n_u] if need else None, grad[n_u:] if need else None, 1.0 / B)
+        ctx.grad, ctx.graph_t, ctx.n_layers, ctx.mask, ctx.n_user_rows = grad, graph_t, n_layers, mask, n_u
+        return (loss_sum / B).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        grad, gt = ctx.grad, ctx.graph_t
+        ctx.grad = None
+        if ctx.mask is not None:
+            gt.set_edge_mask(*ctx.mask)
+        try:
+            gE0 = gt.propagate_bwd(grad, ctx.n_layers)      # linear in `grad`: the upstream scalar is applied after
+        finally:
+            if ctx.mask is not None:
+                gt.set_edge_mask(0)
+        gE0 = gE0 * g
+        u = ctx.n_user_rows
+        return gE0[:u], gE0[u:], None, None, None, None, None, None, None
+
+
 class BPRLoss(torch.autograd.Function):
     """mean softplus(<u,i-> - <u,i+>) (north-star extension; upstream LightGCN-PyTorch bpr_loss semantics)."""
 

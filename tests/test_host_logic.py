@@ -81,7 +81,14 @@ def test_sampler_replays_reference_stream_tiny(tiny_loader):
     assert np.array_equal(np.asarray(td.features_ng), g["g6_neg"])
     assert len(td) == int(g["g6_len"]) == 6 * len(ld.rec_train_data)
     assert list(td[0]) == g["g6_item0"].tolist() and list(td[len(td) - 1]) == g["g6_item_last"].tolist()
-    assert td.__getitems__([0, len(td) - 1]) == [td[0], td[len(td) - 1]]
+    # through torch's DataLoader (batched fetch + default collate) a batch unpacks like the reference's: three [B] int64
+    from torch.utils.data import DataLoader
+    want = [td[k] for k in range(len(td))]
+    got = []
+    for user, item, label in DataLoader(td, batch_size=7, shuffle=False):
+        assert user.dtype == item.dtype == label.dtype == torch.int64 and user.dim() == 1
+        got += list(zip(user.tolist(), item.tolist(), label.tolist()))
+    assert got == [tuple(w) for w in want]
 
 
 def test_sampler_replay_dense_case_against_oracle(oracle):
