@@ -210,6 +210,17 @@ def main():
             ms = time_events(fn, 20)
             ex["bpr_kernel_triples_per_s_T2e20"] = Tb / (ms * 1e-3)
             ex["bpr_kernel_algorithmic_GBs"] = Tb * 1548 / (ms * 1e-3) / 1e9
+            # the same kernel on triples in the sampler's order (5 negatives per training pair, pairs sorted by user —
+            # dataloader.py:250-265): runs of equal user / positive item are accumulated in registers
+            order = np.lexsort((ii.numpy(), uu.numpy()))
+            su = torch.from_numpy(np.repeat(uu.numpy()[order], 5)).to(dev)
+            sp_ = torch.from_numpy(np.repeat(ii.numpy()[order], 5)).to(dev)
+            sn_ = torch.randint(0, m_item, (su.numel(),), device=dev)
+            fn_s = lambda: ops.bpr_sgd_step(lo[:n_u], lo[n_u:], stepper.E0[:n_u], stepper.E0[n_u:], su, sp_, sn_, 1e-6, 0.0)
+            fn_s()
+            ms_s = time_events(fn_s, 20)
+            ex["bpr_kernel_triples_per_s_sampler_order"] = su.numel() / (ms_s * 1e-3)
+            ex["bpr_kernel_sampler_order_T"] = su.numel()
             yb = (torch.rand(256, device=dev) < 1 / 6).float()
             ub, ib = tu[:256], tp[:256]
             fn2 = lambda: stepper.step_bce(ub, ib, yb)

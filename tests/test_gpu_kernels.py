@@ -330,6 +330,39 @@ def test_bpr_kernels_vs_closed_form(oracle):
     assert rel_err(gu.cpu().numpy(), dU) <= 1e-5 and rel_err(gi.cpu().numpy(), dI) <= 1e-5
 
 
+def test_bpr_kernel_run_accumulation_large_batch(oracle):
+    """Large batches give a wave several consecutive triples; runs of equal user / positive item are accumulated in
+    registers and flushed once.  Sampler order (5 negatives per pair, pairs sorted by user), a shuffled copy, and a few
+    out-of-range triples (skipped): all must match the closed form."""
+    from spex_amd import ops
+    rng = np.random.default_rng(17)
+    U, I, P = 300, 500, 60000
+    pu = np.sort(rng.integers(0, U, P))
+    pi = rng.integers(0, I, P)
+    u, p = np.repeat(pu, 5), np.repeat(pi, 5)
+    n = rng.integers(0, I, 5 * P)
+    Ut, It = rng.normal(size=(U, 64)).astype(np.float32) * 0.2, rng.normal(size=(I, 64)).astype(np.float32) * 0.2
+    for order in (np.arange(5 * P), rng.permutation(5 * P)):
+        uu, pp, nn = u[order], p[order], n[order]
+        loss_o, Un, In = oracle.bpr_sgd(Ut, It, Ut, It, uu, pp, nn, lr=0.5, reg=1e-3)
+        Uw, Iw = t(Ut.copy()), t(It.copy())
+        loss = ops.bpr_sgd_step(t(Ut), t(It), Uw, Iw, t(uu), t(pp), t(nn), lr=0.5, reg=1e-3)
+        assert abs(loss.item() / len(uu) - loss_o) <= 2e-6
+        assert rel_err(Uw.cpu().numpy(), Un) <= 1e-5 and rel_err(Iw.cpu().numpy(), In) <= 1e-5
+        _, dU, dI = oracle.bpr_sgd(Ut, It, np.zeros_like(Ut), np.zeros_like(It), uu, pp, nn, lr=-1.0, reg=0.0)
+        gu, gi = torch.zeros(U, 64, device=DEV), torch.zeros(I, 64, device=DEV)
+        ops.bpr_loss_grad(t(Ut), t(It), t(uu), t(pp), t(nn), gu, gi, 1.0 / len(uu))
+        assert rel_err(gu.cpu().numpy(), dU) <= 1e-5 and rel_err(gi.cpu().numpy(), dI) <= 1e-5
+    # out-of-range indices are skipped, the rest of the wave's run is unaffected
+    bad = u.copy()
+    bad[[7, 8, 100000, len(bad) - 1]] = U + 5
+    keep = bad < U
+    _, Un, In = oracle.bpr_sgd(Ut, It, Ut, It, u[keep], p[keep], n[keep], lr=0.5 * keep.sum() / len(u), reg=0.0)
+    Uw, Iw = t(Ut.copy()), t(It.copy())
+    ops.bpr_sgd_step(t(Ut), t(It), Uw, Iw, t(bad), t(p), t(n), lr=0.5, reg=0.0)
+    assert rel_err(Uw.cpu().numpy(), Un) <= 1e-5 and rel_err(Iw.cpu().numpy(), In) <= 1e-5
+
+
 def test_adam_kernel_vs_oracle(oracle):
     from spex_amd import ops
     rng = np.random.default_rng(6)
