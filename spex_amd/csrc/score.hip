@@ -15,6 +15,11 @@ using namespace spex;
 
 namespace {
 
+// 1024-thread workgroups: the loss is reduced per workgroup and added with ONE atomic to a single address; those
+// same-address atomics serialise in the L2 (~5 ns each), so 4-wave workgroups made a 16 k-sample launch 2.5x slower
+// (35 vs 14 us) than the same launch without a loss.
+constexpr int kScoreWaves = 16;
+
 __device__ __forceinline__ float wave_sum(float v)
 {
 #pragma unroll
@@ -28,27 +33,27 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf
 // Per-block loss reduction: lane 0 of each wave holds a partial; one atomic per block.
 __device__ __forceinline__ void block_loss_add(float wave_partial, float *loss_sum)
 {
-    __shared__ float s_part[kWavesPerBlock];
+    __shared__ float s_part[kScoreWaves];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     if (lane == 0) s_part[wave] = wave_partial;
     __syncthreads();
     if (threadIdx.x == 0) {
         float t = 0.0f;
 #pragma unroll
-        for (int w = 0; w < kWavesPerBlock; ++w) t += s_part[w];
+        for (int w = 0; w < kScoreWaves; ++w) t += s_part[w];
         atomicAdd(loss_sum, t);
     }
 }
 
-__global__ __launch_bounds__(kWave *kWavesPerBlock) void score_bce_kernel(
+__global__ __launch_bounds__(kWave *kScoreWaves) void score_bce_kernel(
     const float *__restrict__ users, const float *__restrict__ items, int ldu, int ldi, const int64_t *__restrict__ u_idx,
     const int64_t *__restrict__ i_idx, const float *__restrict__ labels, int B, int d, int64_t n_user_rows,
     int64_t n_item_rows, float *__restrict__ gamma, float *loss_sum, float *grad_users, float *grad_items,
     float grad_scale)
 {
     const int lane = threadIdx.x & (kWave - 1);
-    const int wave_global = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    const int n_waves = gridDim.x * kWavesPerBlock;
+    const int wave_global = blockIdx.x * kScoreWaves + (threadIdx.x >> 6);
+    const int n_waves = gridDim.x * kScoreWaves;
     float lsum = 0.0f;
     for (int b = wave_global; b < B; b += n_waves) {
         const int64_t u = u_idx[b], it = i_idx[b];
@@ -86,14 +91,14 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void score_bce_kernel(
 // Measured at T ~ 1 M on Epinion2's tables: 1.5-1.6 G triples/s in random order, 2.25 G in sampler order (hot rows then
 // serialise in the L2: a user's ~330 consecutive triples are flushed by ~20 waves at about the same time); fetching a
 // run's rows ahead of use (48 loads in flight, 98 VGPRs) changed neither figure.
-__global__ __launch_bounds__(kWave *kWavesPerBlock) void bpr_kernel(
+__global__ __launch_bounds__(kWave *kScoreWaves) void bpr_kernel(
     const float *__restrict__ U_read, const float *__restrict__ I_read, float *U_w, float *I_w,
     const int64_t *__restrict__ u_idx, const int64_t *__restrict__ p_idx, const int64_t *__restrict__ n_idx, int64_t T,
     int d, int64_t n_user_rows, int64_t n_item_rows, float a_coef, float b_coef, float *loss_sum, int per_wave)
 {
     const int lane = threadIdx.x & (kWave - 1);
-    const int64_t wave_global = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    const int64_t n_waves = (int64_t)gridDim.x * kWavesPerBlock;
+    const int64_t wave_global = (int64_t)blockIdx.x * kScoreWaves + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * kScoreWaves;
     float lsum = 0.0f;
     if (d == kWave && U_w) {   // the tuned form: one column per lane, rows held in registers across triples
         for (int64_t t0 = wave_global * per_wave; t0 < T; t0 += n_waves * per_wave) {
@@ -162,7 +167,7 @@ inline int bpr_per_wave(int64_t T)
 
 inline unsigned grid_for(int64_t waves_wanted)
 {
-    int64_t blocks = (waves_wanted + kWavesPerBlock - 1) / kWavesPerBlock;
+    int64_t blocks = (waves_wanted + kScoreWaves - 1) / kScoreWaves;
     if (blocks < 1) blocks = 1;
     if (blocks > 256 * 8) blocks = 256 * 8;  // 8 blocks per CU, grid-stride beyond
     return (unsigned)blocks;
@@ -182,7 +187,7 @@ extern "C" int spex_score_bce_f32(const float *users, const float *items, int32_
     SPEX_CHECK_ARG(!grad_users || labels, "spex_score_bce_f32: gradients need labels");
     SPEX_CHECK_ARG(gamma || labels, "spex_score_bce_f32: nothing to compute");
     if (B == 0) return SPEX_OK;
-    hipLaunchKernelGGL(score_bce_kernel, dim3(grid_for(B)), dim3(kWave * kWavesPerBlock), 0, (hipStream_t)stream, users,
+    hipLaunchKernelGGL(score_bce_kernel, dim3(grid_for(B)), dim3(kWave * kScoreWaves), 0, (hipStream_t)stream, users,
                        items, ldu, ldi, u_idx, i_idx, labels, B, d, n_user_rows, n_item_rows, gamma, loss_sum, grad_users,
                        grad_items, grad_scale);
     SPEX_HIP(hipGetLastError());
@@ -198,7 +203,7 @@ extern "C" int spex_bpr_sgd_step_f32(const float *U_read, const float *I_read, f
     SPEX_CHECK_ARG(T >= 0 && d >= 1, "spex_bpr_sgd_step_f32: T=%lld d=%d", (long long)T, d);
     if (T == 0) return SPEX_OK;
     const int per_wave = bpr_per_wave(T);
-    hipLaunchKernelGGL(bpr_kernel, dim3(grid_for((T + per_wave - 1) / per_wave)), dim3(kWave * kWavesPerBlock), 0,
+    hipLaunchKernelGGL(bpr_kernel, dim3(grid_for((T + per_wave - 1) / per_wave)), dim3(kWave * kScoreWaves), 0,
                        (hipStream_t)stream, U_read, I_read, U_w, I_w, u, i_pos, i_neg, T, d, n_user_rows, n_item_rows,
                        -lr / (float)T, -lr * reg / (float)T, loss_sum, per_wave);
     SPEX_HIP(hipGetLastError());
@@ -214,7 +219,7 @@ extern "C" int spex_bpr_loss_f32(const float *users, const float *items, int64_t
     SPEX_CHECK_ARG((grad_users == nullptr) == (grad_items == nullptr), "spex_bpr_loss_f32: give both grad tables or neither");
     if (T == 0) return SPEX_OK;
     const int per_wave = (grad_users && d == kWave) ? bpr_per_wave(T) : 1;
-    hipLaunchKernelGGL(bpr_kernel, dim3(grid_for((T + per_wave - 1) / per_wave)), dim3(kWave * kWavesPerBlock), 0,
+    hipLaunchKernelGGL(bpr_kernel, dim3(grid_for((T + per_wave - 1) / per_wave)), dim3(kWave * kScoreWaves), 0,
                        (hipStream_t)stream, users, items, grad_users, grad_items, u, i_pos, i_neg, T, d, n_user_rows,
                        n_item_rows, grad_scale, 0.0f, loss_sum, per_wave);
     SPEX_HIP(hipGetLastError());
