@@ -667,6 +667,13 @@ def test_wide_embeddings_take_the_tuned_kernel(G, oracle, d, n_cols):
     Y2 = g.spmm(t(X), add_in=t(add), add_div=3.0).cpu().numpy()
     want2 = y + add / np.float32(3.0)
     assert np.array_equal(Y2[exact], want2[exact]) and rel_err(Y2, want2) <= 3e-6
+    # edge dropout on the wide kernel (injected keep mask; the oracle applies the same mask)
+    keep = rng.random(len(col)) < 0.7
+    g.set_edge_mask(1, t(keep.astype(np.uint8)), 0.7, 0)
+    got_m = g.spmm(t(X)).cpu().numpy()
+    g.set_edge_mask(0)
+    want_m = oracle.spmm_masked(rowptr, col, val, keep, 0.7, X)
+    assert np.array_equal(got_m[exact], want_m[exact]) and rel_err(got_m, want_m) <= 3e-6
     if n_cols == 900:
         # square graph: whole propagation (ping-pong workspace, running mean) at this width
         rp, cc, vv = random_csr(rng, 900, 900, np.minimum(rng.integers(0, 90, 900) + (np.arange(900) == 5) * 800, 900))
