@@ -190,7 +190,8 @@ int spex_graph_set_values(spex_graph_t *g, const float *d_val, int64_t n_val, vo
 
 /* Sampled dense-dense product on the handle's pattern: d_out[edge_id(e)] = <A[row(e),:], B[col(e),:]> for every stored
  * entry e.  A: [n_rows, d], B: [n_cols, d].  With A = dL/dY and B = X this is dL/dval of Y = spmm(val, X).
- * Entries are not weighted by the stored values.  The first call on a handle builds a per-entry row index (4 B/entry).
+ * Entries are not weighted by the stored values.  The first call on a handle allocates and builds a per-entry row
+ * index (4 B/entry): make that call outside any stream capture.
  */
 int spex_sddmm_f32(spex_graph_t *g, const float *A, const float *B, float *d_out, int64_t n_val, int32_t d, void *stream);
 
@@ -202,6 +203,27 @@ int spex_sddmm_f32(spex_graph_t *g, const float *A, const float *B, float *d_out
 int spex_edge_softmax_f32(const spex_graph_t *g, const float *d_in, float *d_out, int64_t n_val, void *stream);
 int spex_edge_softmax_bwd_f32(const spex_graph_t *g, const float *d_out_val, const float *d_grad_out, float *d_grad_in,
                               int64_t n_val, void *stream);
+
+/* ------------------------------------------------------------------------------------------------ trust-path attention
+ * SURVEY.md 8f #1.  Replaces GraphAttentionLayer.forward, LightGCN_SPEX/code/utility2/layers.py:15-71 (Python loops
+ * over batch x path position), for all heads of a layer in one launch, and its autograd backward.
+ *   path p = x_0 .. x_{l-1} (l = seq_l[p] <= L), position i < l - 1, head h with parameter a_h = [a1_h | a2_h] (2 d floats):
+ *     positional != 0 (concat=True,  layers.py:22-31): A = src[seq[p,i]] + (l - i),  Bv = src[seq[p,i+1]] + (l - i - 1)
+ *     positional == 0 (concat=False, layers.py:58-63): A = src[.., i],               Bv = src[.., i + 1]
+ *     att = softmax([A.a1_h + A.a2_h, A.a1_h + Bv.a2_h]);   out[p, i, h*d : (h+1)*d] = att_0 A + att_1 Bv
+ *   positions i >= l - 1 copy the raw source row into every head's slot.
+ * src: [n_src_rows, d] device fp32.  seq: device int64 [B, L] of row indices into src, or NULL = dense source
+ * (src is [B, L, d], row p * L + i; n_src_rows must equal B * L).  seq_l: device int64 [B].  a: [n_heads, 2 d].
+ * out: [B, L, n_heads * d].  w0_out (optional, [B, L, n_heads]): att_0, which the backward reads.  d <= 256.
+ * Backward: grad_src ([n_src_rows, d]) and grad_a ([n_heads, 2 d], may be NULL) are ACCUMULATED with atomics — zero
+ * them first.  (The a1 halves receive nothing: A.a1 cancels in the softmax, their gradient is exactly zero.)
+ */
+int spex_path_attention_f32(const float *src, int64_t n_src_rows, const int64_t *seq, const int64_t *seq_l, const float *a,
+                            int32_t B, int32_t L, int32_t d, int32_t n_heads, int32_t positional, float *out, float *w0_out,
+                            void *stream);
+int spex_path_attention_bwd_f32(const float *src, int64_t n_src_rows, const int64_t *seq, const int64_t *seq_l,
+                                const float *a, int32_t B, int32_t L, int32_t d, int32_t n_heads, int32_t positional,
+                                const float *w0, const float *grad_out, float *grad_src, float *grad_a, void *stream);
 
 /* ------------------------------------------------------------------------------------------------ profiling hook
  * Not part of any reference interface: lets a caller time the dominant kernel itself, in place, on the stream it is

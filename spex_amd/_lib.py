@@ -38,6 +38,10 @@ SIGNATURES = {
     "spex_sddmm_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),
     "spex_edge_softmax_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "spex_edge_softmax_bwd_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "spex_path_attention_f32": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp,
+                                               c_vp]),
+    "spex_path_attention_bwd_f32": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp,
+                                                   c_vp, c_vp, c_vp, c_vp]),
     "spex_timer_create": (ctypes.c_int, [c_i32, c_i32, ctypes.POINTER(c_vp)]),
     "spex_timer_destroy": (ctypes.c_int, [c_vp]),
     "spex_timer_attach": (ctypes.c_int, [c_vp, c_vp]),

@@ -13,8 +13,8 @@ What runs where
   * trust branch (SURVEY.md 8f "next" #1, :170-192 + compute_scores :128-148): three path-attention heads, [B*L,192] x
     [192,64] + ELU, an output attention layer, soft-attention readout, max-pool gate, logits against the whole user
     table and cross-entropy.  The reference evaluates the attention layers with Python loops over batch x path
-    position; here they are closed-form batched tensor ops (utility2/layers.py).  These are small dense ops
-    ([B, <=6, 64]); they are expressed with torch on the device, differentiable for free.
+    position; here each attention layer is one HIP kernel launch over all heads (spex_path_attention_f32, with its
+    backward kernel); the small dense layers around it ([B, <=6, 64]) are torch ops on the device.
 """
 import math
 
@@ -125,7 +125,8 @@ class LightGCN(_RecLightGCN):
         mask = torch.as_tensor(np.asarray(mask), device=dev).long()
         seq_l = torch.sum(mask, 1)
         emb = self.embedding_user.weight
-        mul_seq = torch.cat([att(emb, inputs, seq_l) for att in self.in_att], dim=2)          # [B, L, heads*H]
+        heads = torch.stack([att.a.view(-1) for att in self.in_att])                           # [heads, 2H]
+        mul_seq = ops.path_attention(emb, inputs, seq_l, heads, True)                          # [B, L, heads*H], one launch
         mul_one = F.elu(mul_seq.reshape(-1, mul_seq.shape[2]) @ self.w)
         hidden = self.out_att(emb, mul_one.view(mul_seq.shape[0], mul_seq.shape[1], self.hidden_size), seq_l)
         return self.compute_scores(hidden, inputs, mask)

@@ -296,3 +296,52 @@ def edge_softmax(v, graph):
 
 def spmm_learned(val, X, graph, graph_t):
     return SpMMLearned.apply(val, X, graph, graph_t)
+
+
+# ------------------------------------------------------------------------------------------------ trust-path attention
+class PathAttention(torch.autograd.Function):
+    """All heads of a GraphAttentionLayer (utility2/layers.py:15-71) in one launch, with the matching backward kernel.
+    src: [rows, d] table gathered through `seq` ([B, L] int64) — or, with seq None, a dense [B, L, d] tensor.
+    a: [n_heads, 2d].  Returns [B, L, n_heads * d]."""
+
+    @staticmethod
+    def forward(ctx, src, seq, seq_l, a, positional):
+        src, a = src.contiguous(), a.contiguous()
+        _need(src, "src"); _need(a, "a")
+        dev = src.device
+        seq_l = _idx(seq_l, dev)
+        if seq is not None:
+            seq = _idx(seq, dev)
+            B, L = seq.shape
+            d = src.shape[1]
+            n_rows = src.shape[0]
+        else:
+            B, L, d = src.shape
+            n_rows = B * L
+        n_heads = a.shape[0]
+        if a.shape[1] != 2 * d or seq_l.numel() != B:
+            raise ValueError(f"path_attention: a {tuple(a.shape)} / seq_l {tuple(seq_l.shape)} do not fit B={B} d={d}")
+        out = torch.empty((B, L, n_heads * d), dtype=torch.float32, device=dev)
+        w0 = torch.empty((B, L, n_heads), dtype=torch.float32, device=dev)
+        if B:
+            _lib.call("spex_path_attention_f32", _ptr(src), n_rows, _ptr(seq), _ptr(seq_l), _ptr(a), B, L, d, n_heads,
+                      1 if positional else 0, _ptr(out), _ptr(w0), _stream())
+        ctx.save_for_backward(src, seq, seq_l, a, w0)
+        ctx.dims = (B, L, d, n_heads, n_rows, 1 if positional else 0)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        src, seq, seq_l, a, w0 = ctx.saved_tensors
+        B, L, d, n_heads, n_rows, positional = ctx.dims
+        g = g.contiguous()
+        g_src = torch.zeros_like(src)
+        g_a = torch.zeros_like(a) if ctx.needs_input_grad[3] else None
+        if B:
+            _lib.call("spex_path_attention_bwd_f32", _ptr(src), n_rows, _ptr(seq), _ptr(seq_l), _ptr(a), B, L, d, n_heads,
+                      positional, _ptr(w0), _ptr(g), _ptr(g_src), _ptr(g_a), _stream())
+        return g_src, None, None, g_a, None
+
+
+def path_attention(src, seq, seq_l, a, positional):
+    return PathAttention.apply(src, seq, seq_l, a, positional)

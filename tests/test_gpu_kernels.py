@@ -688,3 +688,53 @@ def test_wide_embeddings_take_the_tuned_kernel(G, oracle, d, n_cols):
         for _ in range(3):
             acc_ref = cur + oracle.spmm(rp, cc, vv, acc_ref)
         assert rel_err(back, acc_ref) <= 1e-5
+
+
+# ---------------------------------------------------------------------------------------------- trust-path attention
+@pytest.mark.parametrize("H,n_heads", [(64, 3), (64, 1), (32, 2), (100, 1)])
+def test_path_attention_kernels_vs_closed_form(H, n_heads):
+    """forward and backward of the path attention layer (all heads in one launch) against the CPU
+    closed form in fp64 (oracle/trust_oracle.py, itself held against the reference's loops in test_host_logic.py)."""
+    from oracle.trust_oracle import path_attention as ref
+    from spex_amd import ops
+    rng = np.random.default_rng(H + n_heads)
+    B, L, U = 37, 6, 90
+    seq_l = rng.integers(1, L + 1, B)
+    seq_l[:3] = [1, 2, L]
+    seq = np.full((B, L), U)
+    for p in range(B):
+        seq[p, :seq_l[p]] = rng.choice(U, seq_l[p], replace=True)       # users repeat within and across paths
+    emb = (rng.normal(size=(U + 1, H)) * 0.5).astype(np.float32)
+    a = (rng.normal(size=(n_heads, 2 * H)) * 0.3).astype(np.float32)
+    gout = rng.normal(size=(B, L, n_heads * H)).astype(np.float32)
+    # gathered, positional (the three in_att heads of model_expert_s.py)
+    E = torch.tensor(emb, device=DEV, requires_grad=True)
+    A = torch.tensor(a, device=DEV, requires_grad=True)
+    out = ops.path_attention(E, t(seq), t(seq_l), A, True)
+    (out * t(gout)).sum().backward()
+    E64 = torch.tensor(emb, dtype=torch.float64, requires_grad=True)
+    A64 = torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    want = torch.cat([ref(E64, torch.from_numpy(seq), torch.from_numpy(seq_l), A64[h], True) for h in range(n_heads)], dim=2)
+    (want * torch.from_numpy(gout).double()).sum().backward()
+    assert (out.detach().cpu().double() - want.detach()).abs().max().item() <= 2e-6 * want.abs().max().item()
+    assert (E.grad.cpu().double() - E64.grad).abs().max().item() <= 1e-5 * E64.grad.abs().max().item()
+    assert (A.grad.cpu().double() - A64.grad).abs().max().item() <= 1e-5 * A64.grad.abs().max().item() + 1e-6
+    assert A.grad[:, :H].abs().max().item() == 0.0                       # a1 cancels in the softmax: exactly no gradient
+    # dense, no offsets (out_att)
+    Xd = (rng.normal(size=(B, L, H))).astype(np.float32)
+    X = torch.tensor(Xd, device=DEV, requires_grad=True)
+    A1 = torch.tensor(a[:1], device=DEV, requires_grad=True)
+    out2 = ops.path_attention(X, None, t(seq_l), A1, False)
+    (out2 * t(gout[..., :H])).sum().backward()
+    X64 = torch.tensor(Xd, dtype=torch.float64, requires_grad=True)
+    A164 = torch.tensor(a[0], dtype=torch.float64, requires_grad=True)
+    want2 = ref(None, X64, torch.from_numpy(seq_l), A164, False)
+    (want2 * torch.from_numpy(gout[..., :H]).double()).sum().backward()
+    assert (out2.detach().cpu().double() - want2.detach()).abs().max().item() <= 2e-6 * want2.abs().max().item()
+    assert (X.grad.cpu().double() - X64.grad).abs().max().item() <= 1e-5 * X64.grad.abs().max().item()
+    assert (A1.grad[0].cpu().double() - A164.grad).abs().max().item() <= 1e-5 * A164.grad.abs().max().item() + 1e-6
+    # an out-of-range index is never gathered (row of zeros in, nothing written back)
+    bad = seq.copy()
+    bad[0, 0] = U + 7
+    ops.path_attention(t(emb), t(bad), t(seq_l), t(a), True)
+    torch.cuda.synchronize()

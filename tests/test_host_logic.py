@@ -197,7 +197,9 @@ def test_epinion2_fixture_round_trips_through_the_file_format(tmp_path, epinion2
 
 
 def test_path_attention_layer_closed_form_equals_reference_loops():
-    """utility2/layers.py restated as the reference's loops (layers.py:15-71) on CPU tensors vs the batched form."""
+    """The closed form the HIP path-attention kernel implements (oracle/trust_oracle.py) against the reference's own
+    loop structure (layers.py:15-71), on CPU tensors."""
+    from oracle.trust_oracle import path_attention
     from utility2.layers import GraphAttentionLayer
     torch.manual_seed(0)
     H, B, L, U = 8, 5, 6, 20
@@ -226,10 +228,12 @@ def test_path_attention_layer_closed_form_equals_reference_loops():
         return out
 
     la = GraphAttentionLayer(H, concat=True)
-    assert torch.allclose(la(emb, seq, seq_l), loops(la, emb, seq, seq_l, True), atol=1e-6)
+    assert torch.allclose(path_attention(emb, seq, seq_l, la.a.detach(), True), loops(la, emb, seq, seq_l, True), atol=1e-6)
     lb = GraphAttentionLayer(H, concat=False)
     x3 = torch.randn(B, L, H)
-    assert torch.allclose(lb(emb, x3, seq_l), loops(lb, emb, x3, seq_l, False), atol=1e-6)
+    assert torch.allclose(path_attention(None, x3, seq_l, lb.a.detach(), False), loops(lb, emb, x3, seq_l, False), atol=1e-6)
+    with pytest.raises(RuntimeError):
+        la(emb, seq, seq_l)                      # the product layer has no CPU path
 
 
 def test_trust_data_batches_like_the_reference(golden):
