@@ -163,6 +163,9 @@ int spex_ngcf_layer_f32(const float *ego, const float *side, const float *W_gc, 
  */
 int spex_expert_gate_f32(const float *raw, const float *prop, const float *att_exp /*[2d,2]*/, float *mixed, int32_t n,
                          int32_t d, void *stream);
+/* Its autograd backward: grad_raw / grad_prop ([n,d]) are written; grad_att ([2d,2]) is ACCUMULATED (zero it first). */
+int spex_expert_gate_bwd_f32(const float *raw, const float *prop, const float *att_exp, const float *grad_mixed,
+                             float *grad_raw, float *grad_prop, float *grad_att, int32_t n, int32_t d, void *stream);
 
 /* ------------------------------------------------------------------------------------------------ negative sampler
  * Replaces LightTrainData.ng_sample, LightGCN_SPEX/code/utility1/dataloader.py:250-265 (distribution, not stream):

@@ -33,6 +33,7 @@ SIGNATURES = {
     "spex_ngcf_layer_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_f32,
                                            c_vp]),
     "spex_expert_gate_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "spex_expert_gate_bwd_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "spex_sample_negatives": (ctypes.c_int, [c_vp, c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, ctypes.c_uint64, c_vp, c_vp]),
     "spex_graph_set_values": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp]),
     "spex_sddmm_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),

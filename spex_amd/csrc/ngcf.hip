@@ -164,6 +164,56 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void expert_gate_kernel(cons
     }
 }
 
+// Backward of the gate.  Per row (one wave): with z = [raw | prop] W, a = softmax(z), mixed = a0 raw + a1 prop and
+// g = dL/dmixed:  da_k = g . src_k;  dz_k = a_k (da_k - (a0 da0 + a1 da1));
+//   d raw = a0 g + dz0 W[c,0] + dz1 W[c,1];  d prop = a1 g + dz0 W[d+c,0] + dz1 W[d+c,1];  dW[c,k] += raw[c] dz_k, dW[d+c,k] += prop[c] dz_k.
+// The parameter gradient ([2d, 2]) is reduced per workgroup in LDS, then added with atomics (zero it first).
+constexpr int kGateWaves = 16;
+
+__global__ __launch_bounds__(kWave *kGateWaves) void expert_gate_bwd_kernel(const float *__restrict__ raw,
+                                                                           const float *__restrict__ prop,
+                                                                           const float *__restrict__ att,
+                                                                           const float *__restrict__ g,
+                                                                           float *__restrict__ d_raw, float *__restrict__ d_prop,
+                                                                           float *d_att, int n, int d)
+{
+    extern __shared__ float s_datt[];   // [2d, 2]
+    const int lane = threadIdx.x & (kWave - 1);
+    for (int k = threadIdx.x; k < 4 * d; k += blockDim.x) s_datt[k] = 0.0f;
+    __syncthreads();
+    const int wave_global = blockIdx.x * kGateWaves + (threadIdx.x >> 6);
+    const int n_waves = gridDim.x * kGateWaves;
+    for (int r = wave_global; r < n; r += n_waves) {
+        float z0 = 0.0f, z1 = 0.0f, da0 = 0.0f, da1 = 0.0f;
+        for (int c = lane; c < d; c += kWave) {
+            const float a = raw[(size_t)r * d + c], b = prop[(size_t)r * d + c], gg = g[(size_t)r * d + c];
+            z0 = fmaf(a, att[2 * c], z0);
+            z1 = fmaf(a, att[2 * c + 1], z1);
+            z0 = fmaf(b, att[2 * (d + c)], z0);
+            z1 = fmaf(b, att[2 * (d + c) + 1], z1);
+            da0 = fmaf(gg, a, da0);
+            da1 = fmaf(gg, b, da1);
+        }
+        z0 = wave_sum(z0); z1 = wave_sum(z1); da0 = wave_sum(da0); da1 = wave_sum(da1);
+        const float mx = fmaxf(z0, z1);
+        const float e0 = expf(z0 - mx), e1 = expf(z1 - mx);
+        const float a0 = e0 / (e0 + e1), a1 = e1 / (e0 + e1);
+        const float dot = a0 * da0 + a1 * da1;
+        const float dz0 = a0 * (da0 - dot), dz1 = a1 * (da1 - dot);
+        for (int c = lane; c < d; c += kWave) {
+            const float a = raw[(size_t)r * d + c], b = prop[(size_t)r * d + c], gg = g[(size_t)r * d + c];
+            d_raw[(size_t)r * d + c] = a0 * gg + dz0 * att[2 * c] + dz1 * att[2 * c + 1];
+            d_prop[(size_t)r * d + c] = a1 * gg + dz0 * att[2 * (d + c)] + dz1 * att[2 * (d + c) + 1];
+            atomicAdd(&s_datt[2 * c], a * dz0);
+            atomicAdd(&s_datt[2 * c + 1], a * dz1);
+            atomicAdd(&s_datt[2 * (d + c)], b * dz0);
+            atomicAdd(&s_datt[2 * (d + c) + 1], b * dz1);
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 4 * d; k += blockDim.x) atomicAdd(d_att + k, s_datt[k]);
+}
+
 inline unsigned grid_for_rows(int n)
 {
     int64_t blocks = ((int64_t)n + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -201,6 +251,20 @@ extern "C" int spex_expert_gate_f32(const float *raw, const float *prop, const f
     if (n == 0) return SPEX_OK;
     hipLaunchKernelGGL(expert_gate_kernel, dim3(grid_for_rows(n)), dim3(kWave * kWavesPerBlock), 0, (hipStream_t)stream, raw,
                        prop, att_exp, mixed, n, d);
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}
+
+extern "C" int spex_expert_gate_bwd_f32(const float *raw, const float *prop, const float *att_exp, const float *grad_mixed,
+                                        float *grad_raw, float *grad_prop, float *grad_att, int32_t n, int32_t d, void *stream)
+{
+    SPEX_CHECK_ARG(raw && prop && att_exp && grad_mixed && grad_raw && grad_prop && grad_att, "spex_expert_gate_bwd_f32: NULL pointer");
+    SPEX_CHECK_ARG(n >= 0 && d >= 1 && (size_t)d * 16 <= 64 * 1024, "spex_expert_gate_bwd_f32: n=%d d=%d", n, d);
+    if (n == 0) return SPEX_OK;
+    int64_t blocks = ((int64_t)n + kGateWaves - 1) / kGateWaves;
+    if (blocks > 256) blocks = 256;                         // one workgroup per CU: 256 x 4d parameter-gradient atomics
+    hipLaunchKernelGGL(expert_gate_bwd_kernel, dim3((unsigned)blocks), dim3(kWave * kGateWaves), (size_t)d * 4 * sizeof(float),
+                       (hipStream_t)stream, raw, prop, att_exp, grad_mixed, grad_raw, grad_prop, grad_att, n, d);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }

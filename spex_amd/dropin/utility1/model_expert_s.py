@@ -9,7 +9,7 @@ slice_indices, trust_data, flag)` contract:
 
 What runs where
   * rec branch: HIP propagation (`computer`, :95-126 == model.py:66-97), two-expert gate between raw and propagated
-    tables (:154-161, fused `spex_expert_gate_f32` in inference), dot + BCE (:163-168);
+    tables (:154-161, `spex_expert_gate_f32` and its backward kernel), dot + BCE (:163-168);
   * trust branch (SURVEY.md 8f "next" #1, :170-192 + compute_scores :128-148): three path-attention heads, [B*L,192] x
     [192,64] + ELU, an output attention layer, soft-attention readout, max-pool gate, logits against the whole user
     table and cross-entropy.  The reference evaluates the attention layers with Python loops over batch x path
@@ -95,9 +95,7 @@ class LightGCN(_RecLightGCN):
         raw_u, raw_i = self.embedding_user.weight, self.embedding_item.weight
         out_u, out_i = light_out[:n_u], light_out[n_u:]
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            a1 = torch.softmax(torch.cat([raw_u, out_u], 1) @ self.att_exp1, 1)
-            a2 = torch.softmax(torch.cat([raw_i, out_i], 1) @ self.att_exp2, 1)
-            return raw_u * a1[:, :1] + out_u * a1[:, 1:], raw_i * a2[:, :1] + out_i * a2[:, 1:]
+            return (ops.expert_gate_autograd(raw_u, out_u, self.att_exp1), ops.expert_gate_autograd(raw_i, out_i, self.att_exp2))
         return (ops.expert_gate(raw_u.detach().contiguous(), out_u.contiguous(), self.att_exp1.detach()),
                 ops.expert_gate(raw_i.detach().contiguous(), out_i.contiguous(), self.att_exp2.detach()))
 

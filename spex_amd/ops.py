@@ -345,3 +345,29 @@ class PathAttention(torch.autograd.Function):
 
 def path_attention(src, seq, seq_l, a, positional):
     return PathAttention.apply(src, seq, seq_l, a, positional)
+
+
+class ExpertGate(torch.autograd.Function):
+    """The two-expert gate of the dual-task model (model_expert_s.py:156-161) with its backward kernel:
+    mixed = raw * a0 + prop * a1, a = softmax([raw | prop] att_exp)."""
+
+    @staticmethod
+    def forward(ctx, raw, prop, att_exp):
+        raw, prop, att_exp = raw.contiguous(), prop.contiguous(), att_exp.contiguous()
+        mixed = expert_gate(raw, prop, att_exp)
+        ctx.save_for_backward(raw, prop, att_exp)
+        return mixed
+
+    @staticmethod
+    def backward(ctx, g):
+        raw, prop, att_exp = ctx.saved_tensors
+        g = g.contiguous()
+        g_raw, g_prop, g_att = torch.empty_like(raw), torch.empty_like(prop), torch.zeros_like(att_exp)
+        if raw.shape[0]:
+            _lib.call("spex_expert_gate_bwd_f32", _ptr(raw), _ptr(prop), _ptr(att_exp), _ptr(g), _ptr(g_raw), _ptr(g_prop),
+                      _ptr(g_att), raw.shape[0], raw.shape[1], _stream())
+        return g_raw, g_prop, g_att
+
+
+def expert_gate_autograd(raw, prop, att_exp):
+    return ExpertGate.apply(raw, prop, att_exp)

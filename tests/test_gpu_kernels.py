@@ -416,6 +416,23 @@ def test_g8_expert_gate_vs_reference(G, golden):
     assert rel_err(gamma.cpu().numpy(), g["g8_gamma"]) <= 1e-5
 
 
+def test_expert_gate_backward_vs_torch_autograd():
+    """The gate's backward kernel against torch autograd of the reference expression (model_expert_s.py:156-161)."""
+    from spex_amd import ops
+    rng = np.random.default_rng(31)
+    for n, d in ((3186, 64), (257, 32), (5, 100)):
+        raw, prop = (rng.normal(size=(n, d)).astype(np.float32) for _ in range(2))
+        att = (rng.normal(size=(2 * d, 2)) * 0.3).astype(np.float32)
+        gm = rng.normal(size=(n, d)).astype(np.float32)
+        R, P, A = (torch.tensor(x, device=DEV, requires_grad=True) for x in (raw, prop, att))
+        (ops.expert_gate_autograd(R, P, A) * t(gm)).sum().backward()
+        R2, P2, A2 = (torch.tensor(x, dtype=torch.float64, requires_grad=True) for x in (raw, prop, att))
+        w = torch.softmax(torch.cat([R2, P2], 1) @ A2, 1)
+        ((R2 * w[:, :1] + P2 * w[:, 1:]) * torch.from_numpy(gm).double()).sum().backward()
+        for got, want in ((R, R2), (P, P2), (A, A2)):
+            assert (got.grad.cpu().double() - want.grad).abs().max().item() <= 1e-5 * want.grad.abs().max().item()
+
+
 # ---------------------------------------------------------------------------------------------- BASELINE configs 3-5 shapes
 @pytest.mark.parametrize("name,n_users,n_items,n_edges", [("weibo-like", 6812, 20000, 400000),
                                                           ("twitter-like", 8930, 20000, 400000)])
