@@ -315,3 +315,41 @@ def test_ngcf_model_matches_reference(golden, epinion2):
         gr = g["grad_sample_rows"]
         assert rel_err(gall if ds == "tiny" else gall[gr], g["grad_emb"] if ds == "tiny" else g["grad_emb_rows"]) <= 2e-5
         assert np.isclose(np.sqrt((gall.astype(np.float64) ** 2).sum()), g["grad_emb_fro"], rtol=1e-4)
+
+
+def test_on_device_epoch_equals_the_driver_loop(data_root):
+    """spex_amd.trainer.train_epoch (negatives by the reference's sampler, the DataLoader's own shuffle order, one
+    LightGCNStepper.step_bce per batch, nothing on the host between steps) against the reference-shaped driver loop
+    (DataLoader + drop-in model + torch Adam, main_rec.py:25-38) for the same NumPy / torch seeds: same batches, same
+    arithmetic => same loss sum and same tables after two epochs."""
+    from torch.utils.data import DataLoader
+    import utility1.dataloader as dl
+    from spex_amd.trainer import LightGCNStepper, train_epoch
+    results = []
+    for fast in (False, True):
+        args, dataset, net = build("tiny", data_root)
+        td = dl.LightTrainData(dataset.rec_train_data, dataset.m_item, dataset.train_mat)
+        np.random.seed(11)
+        torch.manual_seed(12)
+        if fast:
+            E0 = torch.cat([net.embedding_user.weight, net.embedding_item.weight]).detach().clone()
+            st = LightGCNStepper(net.Graph, E0, net.num_users + 1, n_layers=net.n_layers, lr=args.lr)
+            total = sum(train_epoch(st, td).item() for _ in range(2))
+            results.append((total, st.E0.cpu().numpy()))
+        else:
+            loader = DataLoader(td, batch_size=256, shuffle=True)
+            opt = torch.optim.Adam(net.parameters(), lr=args.lr)
+            net.train()
+            total = 0.0
+            for _ in range(2):
+                loader.dataset.ng_sample()
+                for user, item, label in loader:
+                    opt.zero_grad()
+                    loss = net(users=user.to(DEV), items=item.to(DEV), labels=label.to(DEV), flag=0)
+                    loss.backward()
+                    total += loss.item()
+                    opt.step()
+            results.append((total, torch.cat([net.embedding_user.weight, net.embedding_item.weight]).detach().cpu().numpy()))
+    (l0, w0), (l1, w1) = results
+    assert abs(l0 - l1) <= 1e-4 * abs(l0)
+    assert rel_err(w1, w0) <= 2e-5

@@ -247,3 +247,23 @@ def test_trust_data_batches_like_the_reference(golden):
     assert [len(s) for s in sl] == [16, 16, 8] and np.array_equal(np.concatenate(sl), np.arange(40))
     i, m, t = d.get_slice(sl[2])
     assert np.array_equal(i, g["train_inputs"][32:]) and np.array_equal(t, g["train_targets"][32:])
+
+
+def test_epoch_order_is_the_dataloaders_own(tiny_loader):
+    """spex_amd.trainer.dataloader_epoch_order replays the installed torch's DataLoader(shuffle=True) index order from
+    the global RNG, epoch after epoch (so the on-device epoch loop trains on the batches the reference driver would)."""
+    import utility1.dataloader as dl
+    from torch.utils.data import DataLoader
+    from spex_amd.trainer import dataloader_epoch_order
+    ld, _ = tiny_loader
+    td = dl.LightTrainData(ld.rec_train_data, ld.m_item, ld.train_mat)
+    np.random.seed(3)
+    td.ng_sample()
+    loader = DataLoader(td, batch_size=256, shuffle=True)
+    torch.manual_seed(2020)
+    want = [torch.cat([torch.stack([u, i, l]) for u, i, l in loader], dim=1) for _ in range(2)]   # two epochs
+    torch.manual_seed(2020)
+    for epoch in range(2):
+        order = dataloader_epoch_order(len(td)).numpy()
+        got = np.stack([td.users_fill[order], td.items_fill[order], td.labels_fill_np[order]])
+        assert np.array_equal(got, want[epoch].numpy())
