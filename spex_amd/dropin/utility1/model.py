@@ -68,6 +68,11 @@ class LightGCN(BasicModel):
         self._cache = None
         return out
 
+    def flat_table(self):
+        """The two embedding tables as ONE [N, d] tensor sharing the parameters' storage (users first): what
+        spex_amd.trainer.LightGCNStepper trains in place, so the module's own weights are the trained ones."""
+        return ops._flat_tables(self.embedding_user.weight, self.embedding_item.weight)
+
     # ------------------------------------------------------------------ dropout (model.py:46-64)
     def set_edge_mask(self, keep):
         """Test hook: inject a keep mask (bool/uint8 per stored entry, reference entry order) instead of sampling."""

@@ -86,6 +86,14 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _bump(*tensors):
+    """The kernels write through raw pointers, which torch's version counters do not see: tell autograd (and anything
+    keyed on `_version`, e.g. the drop-in model's eval-mode propagation cache) that these tensors were modified."""
+    ts = tuple(t for t in tensors if t is not None)
+    if ts:
+        torch._C._increment_version(ts)      # takes an ITERABLE of tensors (a bare tensor would be iterated row by row)
+
+
 class SpexGraph:
     """A CSR matrix (or a row block of one) resident in HBM.  Stands where the reference keeps its
     torch.sparse.FloatTensor `Graph` (dataloader.py:221-222; model.py:38)."""
@@ -196,6 +204,7 @@ class SpexGraph:
         if self.n_rows > 0:     # (an empty tensor has a NULL data_ptr; nothing to launch anyway)
             _lib.call("spex_spmm_f32", self._h, _ptr(X), _ptr(Y), _ptr(add_in), float(add_div), _ptr(acc_in),
                       _ptr(acc_out), float(acc_div), d, _stream())
+            _bump(Y, acc_out)
         return Y if Y is not None else acc_out
 
     def propagate(self, E0, n_layers, mean_out=None, layers_out=None, ws=None):
@@ -208,6 +217,7 @@ class SpexGraph:
             ws = torch.empty((2, n, d), dtype=torch.float32, device=E0.device)
         _lib.call("spex_propagate_f32", self._h, _ptr(E0), _ptr(mean_out), _ptr(layers_out), _ptr(ws), int(n_layers), d,
                   _stream())
+        _bump(mean_out, layers_out)
         return mean_out
 
     def propagate_bwd(self, g_out, n_layers, grad_E0=None, ws=None):
@@ -219,6 +229,7 @@ class SpexGraph:
         if ws is None:
             ws = torch.empty((3, n, d), dtype=torch.float32, device=g_out.device)
         _lib.call("spex_propagate_bwd_f32", self._h, _ptr(g_out), _ptr(grad_E0), _ptr(ws), int(n_layers), d, _stream())
+        _bump(grad_E0)
         return grad_E0
 
     # -- learned edge values (per-edge arrays are indexed by edge id)
@@ -250,6 +261,7 @@ class SpexGraph:
         self._chk_edges(out, "out")
         if self.nnz:
             _lib.call("spex_sddmm_f32", self._h, _ptr(A), _ptr(B), _ptr(out), out.numel(), d, _stream())
+            _bump(out)
         return out
 
     def edge_softmax(self, v, out=None):
@@ -260,6 +272,7 @@ class SpexGraph:
         self._chk_edges(out, "out")
         if self.nnz:
             _lib.call("spex_edge_softmax_f32", self._h, _ptr(v), _ptr(out), v.numel(), _stream())
+            _bump(out)
         return out
 
     def edge_softmax_bwd(self, y, grad_y, grad_in=None):
@@ -270,4 +283,5 @@ class SpexGraph:
         self._chk_edges(grad_in, "grad_in")
         if self.nnz:
             _lib.call("spex_edge_softmax_bwd_f32", self._h, _ptr(y), _ptr(grad_y), _ptr(grad_in), y.numel(), _stream())
+            _bump(grad_in)
         return grad_in

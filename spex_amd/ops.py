@@ -8,7 +8,7 @@ import ctypes
 import torch
 
 from . import _lib
-from .graph import _ptr, _stream
+from .graph import _bump, _ptr, _stream
 
 
 def _need(t, name, dtype=torch.float32):
@@ -42,6 +42,7 @@ def score_bce(users_tab, items_tab, u_idx, i_idx, labels=None, grad_users=None, 
     _lib.call("spex_score_bce_f32", _ptr(users_tab), _ptr(items_tab), users_tab.stride(0), items_tab.stride(0),
               users_tab.shape[0], items_tab.shape[0], _ptr(u_idx), _ptr(i_idx), _ptr(labels), B, d, _ptr(gamma),
               _ptr(loss_sum), _ptr(grad_users), _ptr(grad_items), float(grad_scale), _stream())
+    _bump(grad_users, grad_items)
     return gamma, loss_sum
 
 
@@ -57,6 +58,7 @@ def bpr_sgd_step(U_read, I_read, U_w, I_w, u, i_pos, i_neg, lr, reg=0.0, loss_su
     _lib.call("spex_bpr_sgd_step_f32", _ptr(U_read), _ptr(I_read), _ptr(U_w), _ptr(I_w), U_read.shape[0], I_read.shape[0],
               _ptr(u), _ptr(i_pos), _ptr(i_neg), u.numel(), U_read.shape[1], float(lr), float(reg), _ptr(loss_sum),
               _stream())
+    _bump(U_w, I_w, loss_sum)
     return loss_sum
 
 
@@ -68,6 +70,7 @@ def bpr_loss_grad(users_tab, items_tab, u, i_pos, i_neg, grad_users=None, grad_i
     _lib.call("spex_bpr_loss_f32", _ptr(users_tab), _ptr(items_tab), users_tab.shape[0], items_tab.shape[0], _ptr(u),
               _ptr(i_pos), _ptr(i_neg), u.numel(), users_tab.shape[1], _ptr(loss_sum), _ptr(grad_users),
               _ptr(grad_items), float(grad_scale), _stream())
+    _bump(grad_users, grad_items)
     return loss_sum
 
 
@@ -77,6 +80,7 @@ def adam_step(p, g, m, v, t, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
         _need(x, n)
     _lib.call("spex_adam_step_f32", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), int(t), float(lr), float(beta1),
               float(beta2), float(eps), _stream())
+    _bump(p, m, v)
 
 
 def ngcf_layer(ego, side, W_gc, b_gc, W_bi, b_bi, slope=0.01, want_e1=False):

@@ -15,7 +15,7 @@ utils.set_seed(args.seed)
 ds = dl.Loader(args)
 net = model.LightGCN(args, ds).cuda()
 td = dl.LightTrainData(ds.rec_train_data, ds.m_item, ds.train_mat)
-E0 = torch.cat([net.embedding_user.weight, net.embedding_item.weight]).detach()      # the model's own (fused) table
+E0 = net.flat_table()                                                                 # the model's own parameters, in place
 st = LightGCNStepper(net.Graph, E0, net.num_users + 1, n_layers=net.n_layers, lr=args.lr)
 for ep in range(3):
     t0 = time.perf_counter()
@@ -24,7 +24,6 @@ for ep in range(3):
     loss = train_epoch(st, td, resample=False).item()
     t2 = time.perf_counter()
     with torch.no_grad():
-        net.embedding_user.weight.copy_(st.E0[:net.num_users + 1]); net.embedding_item.weight.copy_(st.E0[net.num_users + 1:])
         net.eval()
         ret = test(net, ds.testRatings, ds.testNegatives)
     t3 = time.perf_counter()
