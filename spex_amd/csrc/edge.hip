@@ -6,9 +6,9 @@
 //   tf.sparse.sparse_dense_matmul(att, emb)    Model.py:18-83          -> spex_graph_set_values + spex_spmm_f32
 //   d loss / d values (tape.gradient)          main_rec.py:36          -> spex_sddmm_f32
 //
-// All three are bandwidth-bound: the softmax streams 8-12 B per entry; the SDDMM gathers one 4d-byte row of B per entry
-// exactly like the SpMM (algorithmic bytes nnz (4d + 12) + reads of A, which stay in cache because consecutive
-// entries share their row).  Per-edge arrays are addressed by edge id so that a graph and its transposed copy (built
+// The SDDMM gathers one 4d-byte row of B per entry exactly like the SpMM and runs at the same gather ceiling; the
+// softmax streams 8-12 B per entry but is issue-bound (measured, see its kernel); the SDDMM's A rows are cache hits because consecutive
+// entries share their row (algorithmic bytes nnz (4d + 12) + n_rows 4d).  Per-edge arrays are addressed by edge id so that a graph and its transposed copy (built
 // with the permutation as h_edge_id) read and write the same array.
 #include <mutex>
 
@@ -34,7 +34,7 @@ __device__ __forceinline__ float group_max(float v)
     return v;
 }
 
-// ---- values: CSR copy (generic SpMM path) and chunked copy (d == 64 path); padding entries keep value 0
+// ---- values: CSR copy (generic SpMM path) and chunked copy (d = 64 / 128 / 256 path); padding entries keep value 0
 __global__ void set_csr_values_kernel(float *__restrict__ val, const int32_t *__restrict__ edge_id,
                                       const float *__restrict__ src, int64_t nnz)
 {
