@@ -6,10 +6,10 @@
 //   tf.sparse.sparse_dense_matmul(att, emb)    Model.py:18-83          -> spex_graph_set_values + spex_spmm_f32
 //   d loss / d values (tape.gradient)          main_rec.py:36          -> spex_sddmm_f32
 //
-// The SDDMM gathers one 4d-byte row of B per entry exactly like the SpMM and runs at the same gather ceiling; the
-// softmax streams 8-12 B per entry but is issue-bound (measured, see its kernel); the SDDMM's A rows are cache hits because consecutive
-// entries share their row (algorithmic bytes nnz (4d + 12) + n_rows 4d).  Per-edge arrays are addressed by edge id so that a graph and its transposed copy (built
-// with the permutation as h_edge_id) read and write the same array.
+// The SDDMM gathers one 4d-byte row of B per entry exactly like the SpMM and runs at the same gather ceiling (its A
+// rows are cache hits: consecutive entries share their row; algorithmic bytes nnz (4d + 12) + n_rows 4d).  The softmax
+// streams 8-12 B per entry but is issue-bound (measured, see its kernel).  Per-edge arrays are addressed by edge id so
+// that a graph and its transposed copy (built with the permutation as h_edge_id) read and write the same array.
 #include <mutex>
 
 #include "spex_common.h"
