@@ -283,7 +283,17 @@ def main():
                         out["roofline_hbm"]["traffic"] = json.load(open(traffic_file)).get("hbm_graph_spmm_bytes_per_launch")
                     except Exception:
                         pass
-                del g2, X, Y, A2
+                # the exact training step (3 SpMM fwd, scoring, 3 SpMM bwd, Adam over the whole table) on the same graph
+                del Y, A2
+                st2 = LightGCNStepper(g2, X.mul_(0.1), n2 - (n2 // 15593) * 12407, n_layers=L, lr=lr)
+                ub, ib = tu[:256] % 1000, tp[:256] % 1000
+                yb2 = (torch.rand(256, device=dev) < 1 / 6).float()
+                for _ in range(2):
+                    st2.step_bce(ub, ib, yb2)
+                ms_big = time_events(lambda: st2.step_bce(ub, ib, yb2), 3)
+                out["extra"]["exact_train_step_ms_hbm_graph"] = ms_big
+                out["extra"]["exact_train_step_edges_per_s_hbm_graph"] = 2 * L * nnz2 / (ms_big * 1e-3)
+                del g2, X, st2
             except Exception as e:
                 out["roofline_hbm"] = {"error": repr(e)}
 
