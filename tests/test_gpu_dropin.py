@@ -197,6 +197,32 @@ def test_unmodified_style_driver_runs_through_the_launcher(data_root, tmp_path):
     assert len(lines) >= 2 and "recall=" in lines[-1]
 
 
+def test_dual_task_driver_runs_through_the_launcher(data_root, golden):
+    """main_auto_expert_s.py's call sequence (rec loader + trust pickles + model_expert_s + uncertainty-weighted loss +
+    rec_test / trust_test5) as a driver run with `python -m spex_amd.dropin`, two epochs on the tiny graph."""
+    import pickle
+    g = golden("trust_tiny")
+    tdir = os.path.join(data_root, "tiny", "trust")
+    os.makedirs(tdir, exist_ok=True)
+    lens = g["train_mask"].sum(1)
+    with open(os.path.join(tdir, "train.txt"), "wb") as f:
+        pickle.dump(([r[:l].tolist() for r, l in zip(g["train_inputs"], lens)], g["train_targets"].tolist()), f)
+    tl = g["test_mask"].sum(1)
+    with open(os.path.join(tdir, "test2.txt"), "wb") as f:
+        pickle.dump(([r[:l].tolist() for r, l in zip(g["test_inputs"], tl)], g["test_targets"].tolist(),
+                     g["test_negs"].tolist()), f)
+    script = os.path.join(REPO, "tests", "drivers", "dual_driver.py")
+    out = subprocess.run([sys.executable, "-m", "spex_amd.dropin", script, "--dataset", "tiny", "--data_path", data_root,
+                          "--epochs", "2"], cwd=REPO, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = [l for l in out.stdout.splitlines() if l.startswith("Rec:")]
+    trust = [l for l in out.stdout.splitlines() if l.startswith("Trust:")]
+    losses = [l for l in out.stdout.splitlines() if l[:2] in ("0,", "1,")]
+    assert len(rec) == 2 and len(trust) == 2 and len(losses) == 2
+    l0, l1 = (float(l.split(",")[1]) + float(l.split(",")[2]) for l in losses)
+    assert l1 < l0                                                      # both tasks' summed loss goes down
+
+
 def _dual_task_model(data_root):
     import lg_parser
     import utility1.dataloader as dataloader
