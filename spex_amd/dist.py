@@ -72,9 +72,10 @@ class PartitionedLightGCN:
     """
 
     def __init__(self, rowptr, col, val, n_user_rows, n_layers, d, rank, world, graph_factory, device, group=None,
-                 t_csr=None, bounds=None):
+                 t_csr=None, bounds=None, always_collective=False):
         self.part = RowPartition(rowptr, world, bounds)
         self.rank, self.world, self.L, self.d, self.group = rank, world, n_layers, d, group
+        self.always_collective = always_collective      # issue the collectives even at world size 1 (backend smoke tests)
         self.n_user_rows = n_user_rows
         self.device = torch.device(device)
         p = self.part
@@ -98,7 +99,7 @@ class PartitionedLightGCN:
         out = self.gathered if out is None else out
         if local.data_ptr() != self.send.data_ptr():      # a layer's SpMM writes straight into the send buffer
             self.send[: self.n_local].copy_(local)
-        if self.world == 1:
+        if self.world == 1 and not self.always_collective:
             out.copy_(self.send)
         else:
             dist.all_gather_into_tensor(out, self.send, group=self.group)
@@ -150,7 +151,7 @@ class PartitionedLightGCN:
         own_idx, local = plan
         out.zero_()
         out.index_copy_(0, own_idx, self.light_out.index_select(0, local))
-        if self.world > 1:
+        if self.world > 1 or self.always_collective:
             dist.all_reduce(out, group=self.group)
         return out
 

@@ -99,3 +99,47 @@ def test_two_ranks_on_gpu_match_single_device(tmp_path):
         assert np.allclose(d["losses"], ref_losses, rtol=0, atol=2e-6)
     want = st.E0.cpu().numpy()
     assert np.abs(trained - want).max() <= 5e-6 * np.abs(want).max()
+
+
+def _nccl_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from spex_amd.datasets import epinion2_tables, load_epinion2
+    from spex_amd.dist import PartitionedLightGCN, PartitionedStepper
+    from spex_amd.graph import SpexGraph, lightgcn_norm_adj
+    tr = load_epinion2()["train"]
+    csr = lightgcn_norm_adj(tr[:, 0], tr[:, 1], 3185, 12407)
+    uw, iw = epinion2_tables(3186, 12407)
+    E0 = torch.from_numpy(np.concatenate([uw, iw])).to(dev)
+    P = PartitionedLightGCN(*csr, 3186, 3, 64, rank, world,
+                            lambda r, c, v, n_cols: SpexGraph(r, c, v, n_cols=n_cols, device=dev), dev,
+                            always_collective=True)
+    lo = P.propagate(E0.clone()).clone()
+    st = PartitionedStepper(P, E0.clone(), lr=1e-3)
+    rng = np.random.default_rng(3)
+    bu = torch.from_numpy(rng.integers(0, 3185, 256)); bi = torch.from_numpy(rng.integers(0, 12407, 256))
+    by = torch.from_numpy((rng.random(256) < 1 / 6).astype(np.float32))
+    loss = st.step_bce(bu, bi, by).item()
+    dist.barrier()
+    np.savez(os.path.join(out_dir, "nccl.npz"), lo=lo.cpu().numpy(), loss=loss)
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_smoke_world_size_one(tmp_path):
+    """The collectives of the partitioned schedule issued through the real backend (`nccl` == RCCL) on the one GPU of
+    the test box: a one-rank all-gather / all-reduce / barrier on device tensors.  (Multi-rank RCCL needs one GPU per
+    rank; the N-rank schedule itself is covered with gloo above and in tests/test_dist_cpu.py.)"""
+    from spex_amd.datasets import epinion2_tables, load_epinion2
+    from spex_amd.graph import SpexGraph, lightgcn_norm_adj
+    mp.spawn(_nccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    d = np.load(tmp_path / "nccl.npz")
+    tr = load_epinion2()["train"]
+    g = SpexGraph(*lightgcn_norm_adj(tr[:, 0], tr[:, 1], 3185, 12407))
+    uw, iw = epinion2_tables(3186, 12407)
+    ref = g.propagate(torch.from_numpy(np.concatenate([uw, iw])).cuda(), 3).cpu().numpy()
+    assert np.array_equal(d["lo"], ref)
+    assert np.isfinite(float(d["loss"]))
