@@ -24,3 +24,4 @@ for layers in ("[64]", "[64,64,64]"):
     for _ in range(100): step()
     torch.cuda.synchronize()
     print("layers %-12s %.2f ms/step" % (layers, (time.perf_counter() - t0) / 100 * 1e3))
+
