@@ -207,6 +207,21 @@ int spex_edge_softmax_f32(const spex_graph_t *g, const float *d_in, float *d_out
 int spex_edge_softmax_bwd_f32(const spex_graph_t *g, const float *d_out_val, const float *d_grad_out, float *d_grad_in,
                               int64_t n_val, void *stream);
 
+/* Node-level attention fusion of a Diffnet++ layer — Diffnet++_SPEX/code/utility/Model.py:308-345 / 352-385 — one row
+ * per wave, all of it in one launch:
+ *   r_k = [U | X_k] . w1_k   (U == NULL: r_k = X_k . w1_k);   e_k = exp(LeakyReLU_0.2(w2_k tanh(r_k + b1_k) + b2_k)) + c_k
+ *   out = base_coef U + mix_coef (e_1 X_1 + e_2 X_2) / (e_1 + e_2)
+ * users (:308-321): U = user rows, X_1 = from consumed items (c = 0.7), X_2 = from social neighbours (c = 0.3), 1/2, 1/2;
+ * items (:323-343): U = NULL, X_1 = the item rows, X_2 = from customers, c = 1, 1, base 0, mix 1.
+ * p_k: device parameter block of branch k = [ w1_k ((U ? d : 0) + d floats), b1_k, w2_k, b2_k ].  d <= 256.
+ * Backward: grad_U (iff U) / grad_X1 / grad_X2 are written; grad_p1 / grad_p2 are ACCUMULATED (zero them first).
+ */
+int spex_attn_fuse_f32(const float *U, const float *X1, const float *X2, const float *p1, const float *p2, int32_t n,
+                       int32_t d, float c1, float c2, float base_coef, float mix_coef, float *out, void *stream);
+int spex_attn_fuse_bwd_f32(const float *U, const float *X1, const float *X2, const float *p1, const float *p2, int32_t n,
+                           int32_t d, float c1, float c2, float base_coef, float mix_coef, const float *grad_out,
+                           float *grad_U, float *grad_X1, float *grad_X2, float *grad_p1, float *grad_p2, void *stream);
+
 /* ------------------------------------------------------------------------------------------------ trust-path attention
  * SURVEY.md 8f #1.  Replaces GraphAttentionLayer.forward, LightGCN_SPEX/code/utility2/layers.py:15-71 (Python loops
  * over batch x path position), for all heads of a layer in one launch, and its autograd backward.

@@ -39,6 +39,9 @@ SIGNATURES = {
     "spex_sddmm_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),
     "spex_edge_softmax_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "spex_edge_softmax_bwd_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "spex_attn_fuse_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp]),
+    "spex_attn_fuse_bwd_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_f32, c_f32, c_vp,
+                                              c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "spex_path_attention_f32": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp,
                                                c_vp]),
     "spex_path_attention_bwd_f32": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp,

@@ -14,7 +14,8 @@ Per training step the reference evaluates (Model.py:194-290, 293-397)
     381-384 evaluate the item-customer product twice, once is enough)
         -> `spex_graph_set_values` + `spex_spmm_f32`; backward: the transposed handle (same values through the edge
            ids) and `spex_sddmm_f32` for the gradient w.r.t. the values
-  * the node-level attention MLPs ([rows, 2H] x [2H, 1] etc.) and the fusion arithmetic: small dense torch ops.
+  * the node-level attention MLPs ([rows, 2H] x [2H, 1] etc.) and the fusion arithmetic
+        -> `spex_attn_fuse_f32` (+ backward): one launch per side and layer instead of ~40 small tensor ops.
 """
 import numpy as np
 import torch
@@ -127,35 +128,32 @@ class DiffnetPlusPlus(nn.Module):
         self.second_items_users_neighborslow_level_att_matrix = att(
             self.customer, self.second_low_att_layer_for_item_user_layer1, self.icii2)
 
+    def _branch(self, lvl, name):
+        """Parameter block [w1 | b1 | w2 | b2] of one attention branch (its two Dense(1) layers, Model.py:100-140)."""
+        l1, l2 = getattr(self, f"{lvl}_{name}_layer1"), getattr(self, f"{lvl}_{name}_layer2")
+        return torch.cat([l1.kernel.view(-1), l1.bias, l2.kernel.view(-1), l2.bias])
+
     def _layer(self, lvl, user_emb, item_emb, v_social, v_consumed, v_customer):
-        """One influence + interest diffusion layer (Model.py:303-345 and 349-385)."""
+        """One influence + interest diffusion layer (Model.py:303-345 and 349-385): three SpMMs with learned values, then
+        the node-level attention fusion of users and of items — one fused kernel each (spex_attn_fuse_f32)."""
         from_items = self.consumed.matmul(v_consumed, item_emb)
         from_social = self.social.matmul(v_social, user_emb)
-        g = lambda name: getattr(self, f"{lvl}_{name}")
-        a_items = torch.exp(g("user_part_interest_graph_att_layer2")(
-            g("user_part_interest_graph_att_layer1")(torch.cat([user_emb, from_items], 1)))) + 0.7
-        a_social = torch.exp(g("user_part_social_graph_att_layer2")(
-            g("user_part_social_graph_att_layer1")(torch.cat([user_emb, from_social], 1)))) + 0.3
-        tot = a_items + a_social
-        a_items, a_social = a_items / tot, a_social / tot
-        new_user = 0.5 * user_emb + 0.5 * (a_items * from_items + a_social * from_social)
+        new_user = ops.attn_fuse(user_emb, from_items, from_social, self._branch(lvl, "user_part_interest_graph_att"),
+                                 self._branch(lvl, "user_part_social_graph_att"), 0.7, 0.3, 0.5, 0.5)
         from_customers = self.customer.matmul(v_customer, user_emb)
-        a_self = torch.exp(g("item_part_itself_graph_att_layer2")(g("item_part_itself_graph_att_layer1")(item_emb))) + 1.0
-        a_cust = torch.exp(g("item_part_user_graph_att_layer2")(g("item_part_user_graph_att_layer1")(from_customers))) + 1.0
-        tot_i = a_self + a_cust
-        new_item = (a_self / tot_i) * item_emb + (a_cust / tot_i) * from_customers
-        return new_user, new_item, (a_items, a_social)
+        new_item = ops.attn_fuse(None, item_emb, from_customers, self._branch(lvl, "item_part_itself_graph_att"),
+                                 self._branch(lvl, "item_part_user_graph_att"), 1.0, 1.0, 0.0, 1.0)
+        return new_user, new_item
 
     def final_embeddings(self):
         self.computer_somenode()
         u0, i0 = self.user_embedding, self.item_embedding
-        u1, i1, _ = self._layer("first", u0, i0, self.first_social_neighbors_low_level_att_matrix,
-                                self.first_consumed_items_low_level_att_matrix,
-                                self.first_items_users_neighborslow_level_att_matrix)
-        u2, i2, (a_items2, a_social2) = self._layer("second", u1, i1, self.second_social_neighbors_low_level_att_matrix,
-                                                    self.second_consumed_items_low_level_att_matrix,
-                                                    self.second_items_users_neighborslow_level_att_matrix)
-        self.consumed_items_attention_2, self.social_neighbors_attention_2 = a_items2, a_social2
+        u1, i1 = self._layer("first", u0, i0, self.first_social_neighbors_low_level_att_matrix,
+                             self.first_consumed_items_low_level_att_matrix,
+                             self.first_items_users_neighborslow_level_att_matrix)
+        u2, i2 = self._layer("second", u1, i1, self.second_social_neighbors_low_level_att_matrix,
+                             self.second_consumed_items_low_level_att_matrix,
+                             self.second_items_users_neighborslow_level_att_matrix)
         self.final_user_embedding = torch.cat([u1, u2, u0], 1)          # Model.py:388-391
         self.final_item_embedding = torch.cat([i1, i2, i0], 1)
         return self.final_user_embedding, self.final_item_embedding

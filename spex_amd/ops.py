@@ -375,3 +375,43 @@ class ExpertGate(torch.autograd.Function):
 
 def expert_gate_autograd(raw, prop, att_exp):
     return ExpertGate.apply(raw, prop, att_exp)
+
+
+# ------------------------------------------------------------------------------------------------ Diffnet++ node fusion
+class AttnFuse(torch.autograd.Function):
+    """Node-level attention fusion of a Diffnet++ layer (Model.py:308-345) as one kernel forward, one backward.
+    U: [n, d] or None; X1, X2: [n, d]; p1, p2: per-branch parameter blocks [w1 | b1 | w2 | b2]."""
+
+    @staticmethod
+    def forward(ctx, U, X1, X2, p1, p2, c1, c2, base_coef, mix_coef):
+        X1, X2, p1, p2 = X1.contiguous(), X2.contiguous(), p1.contiguous(), p2.contiguous()
+        U = U.contiguous() if U is not None else None
+        for t, nm in ((U, "U"), (X1, "X1"), (X2, "X2"), (p1, "p1"), (p2, "p2")):
+            _need(t, nm)
+        n, d = X1.shape
+        if p1.numel() != (d if U is not None else 0) + d + 3 or p2.numel() != p1.numel():
+            raise ValueError("attn_fuse: parameter blocks must hold w1 | b1 | w2 | b2")
+        out = torch.empty_like(X1)
+        if n:
+            _lib.call("spex_attn_fuse_f32", _ptr(U), _ptr(X1), _ptr(X2), _ptr(p1), _ptr(p2), n, d, float(c1), float(c2),
+                      float(base_coef), float(mix_coef), _ptr(out), _stream())
+        ctx.save_for_backward(U, X1, X2, p1, p2)
+        ctx.consts = (float(c1), float(c2), float(base_coef), float(mix_coef))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        U, X1, X2, p1, p2 = ctx.saved_tensors
+        g = g.contiguous()
+        n, d = X1.shape
+        gU = torch.empty_like(U) if U is not None else None
+        gX1, gX2 = torch.empty_like(X1), torch.empty_like(X2)
+        gp1, gp2 = torch.zeros_like(p1), torch.zeros_like(p2)
+        if n:
+            _lib.call("spex_attn_fuse_bwd_f32", _ptr(U), _ptr(X1), _ptr(X2), _ptr(p1), _ptr(p2), n, d, *ctx.consts, _ptr(g),
+                      _ptr(gU), _ptr(gX1), _ptr(gX2), _ptr(gp1), _ptr(gp2), _stream())
+        return gU, gX1, gX2, gp1, gp2, None, None, None, None
+
+
+def attn_fuse(U, X1, X2, p1, p2, c1, c2, base_coef, mix_coef):
+    return AttnFuse.apply(U, X1, X2, p1, p2, c1, c2, base_coef, mix_coef)

@@ -782,3 +782,39 @@ def test_spmm_properties_on_an_hbm_resident_graph(G, oracle):
     short = (rowptr[rows + 1] - rowptr[rows]) <= 64
     assert np.array_equal(got[short], ref[short])                     # single-wave rows: the oracle's fmaf chain, bit for bit
     assert rel_err(got, ref) <= 2e-6
+
+
+@pytest.mark.parametrize("with_base,d", [(True, 64), (False, 64), (True, 100), (False, 32)])
+def test_attn_fuse_kernels_vs_torch_autograd(with_base, d):
+    """Diffnet++ node-level attention fusion (Model.py:308-345): forward and every gradient against the tensor-op
+    expression in fp64."""
+    import torch.nn.functional as F
+    from spex_amd import ops
+    rng = np.random.default_rng(d + with_base)
+    n = 1500
+    U = rng.normal(size=(n, d)).astype(np.float32) if with_base else None
+    X1, X2, gm = (rng.normal(size=(n, d)).astype(np.float32) for _ in range(3))
+    nw = (d if with_base else 0) + d
+    p1, p2 = ((rng.normal(size=nw + 3) * 0.3).astype(np.float32) for _ in range(2))
+    c1, c2, bc, mc = (0.7, 0.3, 0.5, 0.5) if with_base else (1.0, 1.0, 0.0, 1.0)
+    mk = lambda a, dt, dev: None if a is None else torch.tensor(a, dtype=dt, device=dev, requires_grad=True)
+    got = [mk(a, torch.float32, DEV) for a in (U, X1, X2, p1, p2)]
+    out = ops.attn_fuse(*got, c1, c2, bc, mc)
+    (out * t(gm)).sum().backward()
+    ref = [mk(a, torch.float64, "cpu") for a in (U, X1, X2, p1, p2)]
+    Ur, X1r, X2r, p1r, p2r = ref
+
+    def e(X, p, c):
+        inp = X if Ur is None else torch.cat([Ur, X], 1)
+        tt = torch.tanh(inp @ p[:nw] + p[nw])
+        return torch.exp(F.leaky_relu(p[nw + 1] * tt + p[nw + 2], 0.2)) + c
+    e1, e2 = e(X1r, p1r, c1), e(X2r, p2r, c2)
+    want = mc * ((e1 / (e1 + e2))[:, None] * X1r + (e2 / (e1 + e2))[:, None] * X2r)
+    if Ur is not None:
+        want = want + bc * Ur
+    (want * torch.from_numpy(gm).double()).sum().backward()
+    assert (out.detach().cpu().double() - want.detach()).abs().max().item() <= 2e-6 * want.abs().max().item()
+    for gt, rf in zip(got, ref):
+        if gt is not None:
+            err = (gt.grad.cpu().double() - rf.grad).abs().max().item()
+            assert err <= 2e-5 * rf.grad.abs().max().item() + 1e-6, err
