@@ -35,18 +35,14 @@ __device__ __forceinline__ float group_max(float v)
 }
 
 // ---- values: CSR copy (generic SpMM path) and chunked copy (d = 64 / 128 / 256 path); padding entries keep value 0
-__global__ void set_csr_values_kernel(float *__restrict__ val, const int32_t *__restrict__ edge_id,
-                                      const float *__restrict__ src, int64_t nnz)
+// one launch refreshes both copies
+__global__ void set_values_kernel(float *__restrict__ val, const int32_t *__restrict__ edge_id, int64_t nnz,
+                                  float *__restrict__ chunk_val, const uint32_t *__restrict__ chunk_eid,
+                                  const uint8_t *__restrict__ chunk_pad, int64_t n_entries, const float *__restrict__ src)
 {
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x)
-        val[e] = src[edge_id ? edge_id[e] : e];
-}
-
-__global__ void set_chunk_values_kernel(float *__restrict__ chunk_val, const uint32_t *__restrict__ chunk_eid,
-                                        const uint8_t *__restrict__ chunk_pad, const float *__restrict__ src,
-                                        int64_t n_entries)
-{
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_entries; k += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t e = first; e < nnz; e += stride) val[e] = src[edge_id ? edge_id[e] : e];
+    for (int64_t k = first; k < n_entries; k += stride) {
         const uint32_t n_pad = chunk_pad[k / kChunk];
         const bool pad = (uint32_t)(k % kChunk) >= (uint32_t)kChunk - n_pad;
         chunk_val[k] = pad ? 0.0f : src[chunk_eid[k]];
@@ -259,12 +255,9 @@ extern "C" int spex_graph_set_values(spex_graph_t *g, const float *d_val, int64_
                    (long long)n_val, (long long)g->max_edge_id);
     if (g->nnz == 0) return SPEX_OK;
     const int threads = kWave * kWavesPerBlock;
-    hipLaunchKernelGGL(set_csr_values_kernel, dim3(stream_grid(g->nnz, threads)), dim3(threads), 0, (hipStream_t)stream, g->val,
-                       g->edge_id, d_val, g->nnz);
     const int64_t n_entries = g->n_chunks * kChunk;
-    if (n_entries > 0)
-        hipLaunchKernelGGL(set_chunk_values_kernel, dim3(stream_grid(n_entries, threads)), dim3(threads), 0, (hipStream_t)stream,
-                           g->chunk_val, g->chunk_eid, g->chunk_pad, d_val, n_entries);
+    hipLaunchKernelGGL(set_values_kernel, dim3(stream_grid(n_entries > g->nnz ? n_entries : g->nnz, threads)), dim3(threads), 0,
+                       (hipStream_t)stream, g->val, g->edge_id, g->nnz, g->chunk_val, g->chunk_eid, g->chunk_pad, n_entries, d_val);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }

@@ -114,7 +114,7 @@ class DiffnetPlusPlus(nn.Module):
     # Model.py:195-286: per-edge values and their row softmax
     def computer_somenode(self):
         def att(graph, dense, p):
-            return graph.softmax(torch.exp(dense(p.view(-1, 1))).sum(dim=1))
+            return graph.softmax(torch.exp(dense(p.view(-1, 1))).view(-1))    # (reduce_sum over a size-1 axis, Model.py:197-199)
         self.first_social_neighbors_low_level_att_matrix = att(
             self.social, self.first_low_att_layer_for_social_neighbors_layer1, self.snii1)
         self.second_social_neighbors_low_level_att_matrix = att(

@@ -256,8 +256,9 @@ class SpexGraph:
         d = A.shape[1]
         self._chk(A, self.n_rows, d, "A")
         self._chk(B, self.n_cols, d, "B")
-        if out is None:
-            out = torch.zeros(self.n_edge_ids, dtype=torch.float32, device=A.device)
+        if out is None:   # every edge id is written when the ids are a permutation of the entries
+            alloc = torch.empty if self.n_edge_ids == self.nnz else torch.zeros
+            out = alloc(self.n_edge_ids, dtype=torch.float32, device=A.device)
         self._chk_edges(out, "out")
         if self.nnz:
             _lib.call("spex_sddmm_f32", self._h, _ptr(A), _ptr(B), _ptr(out), out.numel(), d, _stream())
