@@ -72,6 +72,26 @@ class LightGCNStepper:
         return loss_sum / T
 
 
+class LaunchPacer:
+    """Host-side flow control for long launch loops.  The host issues a step's launches in ~30 us, the GPU needs 50-100 us
+    for them, so an unpaced loop runs thousands of launches ahead; past ~1 500 outstanding launches the HIP runtime
+    stalls once for ~40 ms and then throttles every launch to a blocking wait (57 instead of 50 us per step, measured
+    with tools/stall_probe.py).  tick() after each step keeps at most ~2 x `window` steps outstanding by waiting on an
+    event recorded two windows ago — the GPU never runs dry and the queue never fills."""
+
+    def __init__(self, window=64):
+        self.window, self.count, self.events = int(window), 0, []
+
+    def tick(self):
+        self.count += 1
+        if self.count % self.window == 0:
+            e = torch.cuda.Event()
+            e.record()
+            self.events.append(e)
+            if len(self.events) > 2:
+                self.events.pop(0).synchronize()
+
+
 def dataloader_epoch_order(n):
     """The index order `DataLoader(dataset, shuffle=True)` walks in one epoch, drawn from the GLOBAL torch RNG exactly as
     torch's own iterator draws it (a base seed at iterator creation, then RandomSampler's seed, then a randperm from a
@@ -99,6 +119,8 @@ def train_epoch(stepper, train_data, batch_size=256, resample=True):
     items = torch.from_numpy(train_data.items_fill[order]).to(dev)
     labels = torch.from_numpy(train_data.labels_fill_np[order]).to(device=dev, dtype=torch.float32)
     total = torch.zeros((), dtype=torch.float32, device=dev)
+    pacer = LaunchPacer()
     for s in range(0, n, batch_size):
         total += stepper.step_bce(users[s:s + batch_size], items[s:s + batch_size], labels[s:s + batch_size]).reshape(())
+        pacer.tick()
     return total
