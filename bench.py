@@ -139,24 +139,23 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    # The HIP runtime stalls ONCE for ~40 ms around the 3 600th kernel launch of a process (tools/stall_probe.py: chunks
-    # of 100 steps take 2.9 ms of host time, the chunk containing step ~900 takes 43.7 ms, none after it does).  Keep
-    # that one-off out of the timed region: warm up past it (untimed, like the requested warm-up steps).
-    for _ in range(max(0, 1300 - a.warmup)):
-        step()
+    # Python's cyclic GC: a full collection walks every object torch / scipy / numpy created at import — ~40 ms, which
+    # lands once inside any timed region longer than ~900 steps (tools/stall_probe.py: 100-step chunks take 2.9 ms of
+    # host time, the chunk with the collection 40-44 ms).  The step loop creates no cycles: move everything allocated
+    # so far out of the collector's reach, as a long-running training loop would.
+    import gc
+    gc.collect()
+    gc.freeze()
     # one hipEvent pair around the SpMM launches of every n-th propagation of the timed region (three back-to-back
     # launches share the ~3 us an event pair costs on the stream; bracketing single launches charged it to each).
     # At most ~100 brackets per run: with 400 outstanding timing events the runtime's bookkeeping slowed every step
     # of a 2 000-step run by 14 us.
     every = max(5, a.steps // 100) * (1 if world == 1 else L)
     graph.attach_timer(128, every=every)
-    from spex_amd.trainer import LaunchPacer
-    pacer = LaunchPacer()      # host-side flow control: keeps the launch queue from filling on long runs (see its docstring)
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
-        pacer.tick()
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0

@@ -9,6 +9,8 @@ synchronisation and no Python between kernels beyond the ctypes calls (capturabl
     bpr step    (north-star extension): L x SpMM (mean fused)  ->  fused gather + dot + sigmoid + SGD over triples,
                                         scores read from the propagated table, updates applied to E0
 """
+import gc
+
 import torch
 
 from . import ops
@@ -72,26 +74,6 @@ class LightGCNStepper:
         return loss_sum / T
 
 
-class LaunchPacer:
-    """Host-side flow control for long launch loops.  The host issues a step's launches in ~30 us, the GPU needs 50-100 us
-    for them, so an unpaced loop runs thousands of launches ahead; past ~1 500 outstanding launches the HIP runtime
-    stalls once for ~40 ms and then throttles every launch to a blocking wait (57 instead of 50 us per step, measured
-    with tools/stall_probe.py).  tick() after each step keeps at most ~2 x `window` steps outstanding by waiting on an
-    event recorded two windows ago — the GPU never runs dry and the queue never fills."""
-
-    def __init__(self, window=64):
-        self.window, self.count, self.events = int(window), 0, []
-
-    def tick(self):
-        self.count += 1
-        if self.count % self.window == 0:
-            e = torch.cuda.Event()
-            e.record()
-            self.events.append(e)
-            if len(self.events) > 2:
-                self.events.pop(0).synchronize()
-
-
 def dataloader_epoch_order(n):
     """The index order `DataLoader(dataset, shuffle=True)` walks in one epoch, drawn from the GLOBAL torch RNG exactly as
     torch's own iterator draws it (a base seed at iterator creation, then RandomSampler's seed, then a randperm from a
@@ -104,7 +86,7 @@ def dataloader_epoch_order(n):
     return torch.randperm(n, generator=g)
 
 
-def train_epoch(stepper, train_data, batch_size=256, resample=True):
+def train_epoch(stepper, train_data, batch_size=256, resample=True, pause_gc=True):
     """Train() of main_rec.py:25-38 without the per-step host work of its DataLoader loop: negatives are drawn like the
     reference's (`train_data.ng_sample()`, NumPy global RNG), the epoch's sample order is the DataLoader's own
     (dataloader_epoch_order), the whole shuffled epoch is moved to the device once, and every batch is one
@@ -119,8 +101,16 @@ def train_epoch(stepper, train_data, batch_size=256, resample=True):
     items = torch.from_numpy(train_data.items_fill[order]).to(dev)
     labels = torch.from_numpy(train_data.labels_fill_np[order]).to(device=dev, dtype=torch.float32)
     total = torch.zeros((), dtype=torch.float32, device=dev)
-    pacer = LaunchPacer()
-    for s in range(0, n, batch_size):
-        total += stepper.step_bce(users[s:s + batch_size], items[s:s + batch_size], labels[s:s + batch_size]).reshape(())
-        pacer.tick()
+    # A full (generation-2) collection of Python's cyclic GC walks every object torch / scipy / pandas created at import:
+    # ~40 ms, i.e. ~400 steps' worth of launches, whenever it triggers inside the loop (tools/stall_probe.py).  The loop
+    # creates no reference cycles: pause the collector for its duration.
+    gc_was_on = pause_gc and gc.isenabled()
+    if gc_was_on:
+        gc.disable()
+    try:
+        for s in range(0, n, batch_size):
+            total += stepper.step_bce(users[s:s + batch_size], items[s:s + batch_size], labels[s:s + batch_size]).reshape(())
+    finally:
+        if gc_was_on:
+            gc.enable()
     return total

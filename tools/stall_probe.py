@@ -12,6 +12,11 @@ g = SpexGraph(*csr, device=dev)
 E0 = torch.from_numpy(xavier_uniform_np(15593, 64, np.random.default_rng(0))).to(dev)
 st = LightGCNStepper(g, E0, 3186)
 tu = torch.randint(0, 3185, (2048,), device=dev); tp = torch.randint(0, 12407, (2048,), device=dev); tn = torch.randint(0, 12407, (2048,), device=dev)
+import gc
+if len(sys.argv) > 1 and sys.argv[1] == 'freeze':
+    gc.collect(); gc.freeze()
+if len(sys.argv) > 1 and sys.argv[1] == 'disable':
+    gc.disable()
 torch.cuda.synchronize()
 marks = []
 t0 = time.perf_counter()
