@@ -5,7 +5,11 @@
 The driver's own imports (`from lg_parser import parse_args_r`, `import utility1.dataloader as dataloader`,
 `import utility1.model as model`, `from utility1.batch_test import test`, main_rec.py:2-13) then resolve to
 spex_amd/dropin/ because it is placed ahead of the script's directory on sys.path; anything this package does not
-provide (e.g. utility2 for the dual-task drivers) still resolves to the driver's own directory.
+provide still resolves to the driver's own directory.
+
+Before the script starts, the heavy imports it will make anyway (torch, numpy, scipy, pandas) are done here and frozen
+out of Python's cyclic garbage collector: a full collection over their import-time objects takes ~40 ms and otherwise
+lands several times in every epoch of the driver's 4 906-step loop (tools/stall_probe.py).
 """
 import os
 import runpy
@@ -22,6 +26,10 @@ def main():
     sys.path[:] = [here] + [p for p in sys.path if p not in ("", here)] + [os.path.dirname(script)]
     if repo_root not in sys.path:
         sys.path.insert(1, repo_root)
+    import gc
+    import numpy, pandas, scipy.sparse, torch, torch.utils.data   # noqa: F401,E401  (what the drivers and the modules import)
+    gc.collect()
+    gc.freeze()
     runpy.run_path(script, run_name="__main__")
 
 
