@@ -143,9 +143,11 @@ int spex_bpr_loss_f32(const float *users, const float *items, int64_t n_user_row
 /* ------------------------------------------------------------------------------------------------ optimiser
  * Replaces torch.optim.Adam(...).step() over the dense embedding tables — LightGCN_SPEX/code/main_rec.py:23,37.
  * One fused pass: m, v, p updated in place (bias-corrected, eps outside the sqrt as torch does), t = step count >= 1.
+ * zero_buf (optional, n floats, may not alias the operands): cleared in the same pass — the caller's gradient
+ * accumulation table for the next step (saves a separate fill launch per step).
  */
 int spex_adam_step_f32(float *p, const float *g, float *m, float *v, int64_t n, int32_t t, float lr, float beta1,
-                       float beta2, float eps, void *stream);
+                       float beta2, float eps, float *zero_buf, void *stream);
 
 /* ------------------------------------------------------------------------------------------------ NGCF epilogue
  * Replaces NGCF_SPEX/code/main_rec.py:77-83 for one layer (inference / dropout off):

@@ -29,7 +29,7 @@ SIGNATURES = {
                                              c_f32, c_f32, c_vp, c_vp]),
     "spex_bpr_loss_f32": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp,
                                          c_f32, c_vp]),
-    "spex_adam_step_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_f32, c_f32, c_vp]),
+    "spex_adam_step_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp]),
     "spex_ngcf_layer_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_f32,
                                            c_vp]),
     "spex_expert_gate_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),

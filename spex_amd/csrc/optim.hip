@@ -2,6 +2,8 @@
 //
 // torch runs this as several elementwise passes (lerp, mul/addcmul, sqrt/div/add, addcdiv); here it is one pass:
 // 16 B read per parameter (p, g, m, v) and 12 B written (p, m, v) = 28 B/param, pure HBM streaming, float4 per lane.
+// Optionally the same pass clears one more buffer of the same length (the dense d loss / d light_out table the next
+// step's scoring kernel accumulates into): 4 B/param more instead of a separate fill launch.
 // Arithmetic order follows torch's single-tensor Adam so that the result matches it to rounding:
 //   m += (g - m) * (1 - beta1);  v = v * beta2 + (1 - beta2) * g * g
 //   denom = sqrt(v) / sqrt(1 - beta2^t) + eps;  p -= (lr / (1 - beta1^t)) * (m / denom)
@@ -23,7 +25,7 @@ __device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, flo
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g,
                                                    float *__restrict__ m, float *__restrict__ v, int64_t n4,
                                                    int64_t rem, float w1, float beta2, float w2, float bc2_sqrt,
-                                                   float eps, float step_size)
+                                                   float eps, float step_size, float *__restrict__ zero_buf)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -38,23 +40,27 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
         reinterpret_cast<float4 *>(p)[i] = P;
         reinterpret_cast<float4 *>(m)[i] = M;
         reinterpret_cast<float4 *>(v)[i] = V;
+        if (zero_buf) reinterpret_cast<float4 *>(zero_buf)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     if (blockIdx.x == 0 && (int64_t)threadIdx.x < rem) {
         const int64_t i = n4 * 4 + threadIdx.x;
         float P = p[i], M = m[i], V = v[i];
         adam1(P, g[i], M, V, w1, beta2, w2, bc2_sqrt, eps, step_size);
         p[i] = P; m[i] = M; v[i] = V;
+        if (zero_buf) zero_buf[i] = 0.0f;
     }
 }
 
 }  // namespace
 
 extern "C" int spex_adam_step_f32(float *p, const float *g, float *m, float *v, int64_t n, int32_t t, float lr,
-                                  float beta1, float beta2, float eps, void *stream)
+                                  float beta1, float beta2, float eps, float *zero_buf, void *stream)
 {
     SPEX_CHECK_ARG(p && g && m && v, "spex_adam_step_f32: NULL pointer");
     SPEX_CHECK_ARG(n >= 0 && t >= 1, "spex_adam_step_f32: n=%lld t=%d (t counts from 1)", (long long)n, t);
-    SPEX_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "spex_adam_step_f32: pointers must be 16-byte aligned");
+    SPEX_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)zero_buf) & 15) == 0,
+                   "spex_adam_step_f32: pointers must be 16-byte aligned");
+    SPEX_CHECK_ARG(zero_buf != p && zero_buf != m && zero_buf != v && zero_buf != g, "spex_adam_step_f32: zero_buf aliases an operand");
     if (n == 0) return SPEX_OK;
     const double bc1 = 1.0 - pow((double)beta1, (double)t);
     const double bc2 = 1.0 - pow((double)beta2, (double)t);
@@ -65,7 +71,7 @@ extern "C" int spex_adam_step_f32(float *p, const float *g, float *m, float *v, 
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, rem,
-                       1.0f - beta1, beta2, 1.0f - beta2, bc2_sqrt, eps, step_size);
+                       1.0f - beta1, beta2, 1.0f - beta2, bc2_sqrt, eps, step_size, zero_buf);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }

@@ -27,22 +27,27 @@ def _idx(t, device):
 
 
 # ------------------------------------------------------------------------------------------------ raw kernels
-def score_bce(users_tab, items_tab, u_idx, i_idx, labels=None, grad_users=None, grad_items=None, grad_scale=0.0):
-    """gamma (and, with labels, the BCE loss *sum* and optional gradient rows).  spex_score_bce_f32."""
+def score_bce(users_tab, items_tab, u_idx, i_idx, labels=None, grad_users=None, grad_items=None, grad_scale=0.0,
+              loss_sum=None, want_gamma=True):
+    """gamma (and, with labels, the BCE loss *sum* and optional gradient rows).  spex_score_bce_f32.
+    loss_sum: a caller-owned 1-element buffer to ACCUMULATE into (no per-call allocation / fill); want_gamma=False skips
+    the score vector (training steps do not read it)."""
     _need(users_tab, "users_tab"); _need(items_tab, "items_tab")
     dev = users_tab.device
     u_idx, i_idx = _idx(u_idx, dev), _idx(i_idx, dev)
     B, d = u_idx.numel(), users_tab.shape[1]
-    gamma = torch.empty(B, dtype=torch.float32, device=dev)
-    loss_sum = None
+    gamma = torch.empty(B, dtype=torch.float32, device=dev) if (want_gamma or labels is None) else None
     if labels is not None:
         labels = labels.to(device=dev, dtype=torch.float32).contiguous()
-        loss_sum = torch.zeros(1, dtype=torch.float32, device=dev)
+        if loss_sum is None:
+            loss_sum = torch.zeros(1, dtype=torch.float32, device=dev)
+    else:
+        loss_sum = None
     _need(grad_users, "grad_users"); _need(grad_items, "grad_items")
     _lib.call("spex_score_bce_f32", _ptr(users_tab), _ptr(items_tab), users_tab.stride(0), items_tab.stride(0),
               users_tab.shape[0], items_tab.shape[0], _ptr(u_idx), _ptr(i_idx), _ptr(labels), B, d, _ptr(gamma),
               _ptr(loss_sum), _ptr(grad_users), _ptr(grad_items), float(grad_scale), _stream())
-    _bump(grad_users, grad_items)
+    _bump(grad_users, grad_items, loss_sum)
     return gamma, loss_sum
 
 
@@ -74,13 +79,16 @@ def bpr_loss_grad(users_tab, items_tab, u, i_pos, i_neg, grad_users=None, grad_i
     return loss_sum
 
 
-def adam_step(p, g, m, v, t, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
-    """In-place fused Adam over one flat fp32 buffer (main_rec.py:23,37).  t counts from 1."""
-    for x, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+def adam_step(p, g, m, v, t, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, zero=None):
+    """In-place fused Adam over one flat fp32 buffer (main_rec.py:23,37).  t counts from 1.  zero: an optional buffer
+    of the same length cleared in the same pass (the next step's gradient accumulation table)."""
+    for x, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v"), (zero, "zero")):
         _need(x, n)
+    if zero is not None and zero.numel() != p.numel():
+        raise ValueError("adam_step: `zero` must have as many elements as the parameters")
     _lib.call("spex_adam_step_f32", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), int(t), float(lr), float(beta1),
-              float(beta2), float(eps), _stream())
-    _bump(p, m, v)
+              float(beta2), float(eps), _ptr(zero), _stream())
+    _bump(p, m, v, zero)
 
 
 def ngcf_layer(ego, side, W_gc, b_gc, W_bi, b_bi, slope=0.01, want_e1=False):

@@ -38,18 +38,21 @@ class LightGCNStepper:
     def propagate(self):
         return self.graph.propagate(self.E0, self.L, mean_out=self.light_out, ws=self.ws_fwd)
 
-    def step_bce(self, users, items, labels):
-        """One exact reference training step (main_rec.py:32-37).  Returns the mean BCE loss (device tensor)."""
+    def step_bce(self, users, items, labels, loss_acc=None):
+        """One exact reference training step (main_rec.py:32-37).  Returns the mean BCE loss (device tensor) — or, with
+        `loss_acc` (a 1-element device buffer), accumulates the batch's loss SUM into it and returns None: then the
+        step is exactly eight launches (3 SpMM, scoring, 3 SpMM, Adam) with nothing between them.  The gradient table
+        is cleared by the Adam pass of the previous step."""
         self.propagate()
-        self.g_out.zero_()
         B = users.numel()
         lo = self.light_out
         _, loss_sum = ops.score_bce(lo[:self.n_u], lo[self.n_u:], users, items, labels, self.g_out[:self.n_u],
-                                    self.g_out[self.n_u:], 1.0 / B)
+                                    self.g_out[self.n_u:], 1.0 / B, loss_sum=loss_acc, want_gamma=False)
         self.graph_t.propagate_bwd(self.g_out, self.L, grad_E0=self.grad_E0, ws=self.ws_bwd)
         self.t += 1
-        ops.adam_step(self.E0, self.grad_E0, self.m, self.v, self.t, self.lr, self.betas[0], self.betas[1], self.eps)
-        return loss_sum / B
+        ops.adam_step(self.E0, self.grad_E0, self.m, self.v, self.t, self.lr, self.betas[0], self.betas[1], self.eps,
+                      zero=self.g_out)
+        return None if loss_acc is not None else loss_sum / B
 
     def step_bpr_sgd(self, users, pos, neg, lr=None, reg=0.0):
         """Propagation + fused BPR-SGD kernel (scores from the propagated table, update on E0).  Returns the running
@@ -63,14 +66,14 @@ class LightGCNStepper:
     def step_bpr_exact(self, users, pos, neg):
         """BPR loss differentiated through the propagation, Adam update (upstream LightGCN training semantics)."""
         self.propagate()
-        self.g_out.zero_()
         T = users.numel()
         lo = self.light_out
         loss_sum = ops.bpr_loss_grad(lo[:self.n_u], lo[self.n_u:], users, pos, neg, self.g_out[:self.n_u],
                                      self.g_out[self.n_u:], 1.0 / T)
         self.graph_t.propagate_bwd(self.g_out, self.L, grad_E0=self.grad_E0, ws=self.ws_bwd)
         self.t += 1
-        ops.adam_step(self.E0, self.grad_E0, self.m, self.v, self.t, self.lr, self.betas[0], self.betas[1], self.eps)
+        ops.adam_step(self.E0, self.grad_E0, self.m, self.v, self.t, self.lr, self.betas[0], self.betas[1], self.eps,
+                      zero=self.g_out)          # invariant of both exact steps: g_out is all-zero between steps
         return loss_sum / T
 
 
@@ -100,17 +103,21 @@ def train_epoch(stepper, train_data, batch_size=256, resample=True, pause_gc=Tru
     users = torch.from_numpy(train_data.users_fill[order]).to(dev)
     items = torch.from_numpy(train_data.items_fill[order]).to(dev)
     labels = torch.from_numpy(train_data.labels_fill_np[order]).to(device=dev, dtype=torch.float32)
-    total = torch.zeros((), dtype=torch.float32, device=dev)
     # A full (generation-2) collection of Python's cyclic GC walks every object torch / scipy / pandas created at import:
     # ~40 ms, i.e. ~400 steps' worth of launches, whenever it triggers inside the loop (tools/stall_probe.py).  The loop
     # creates no reference cycles: pause the collector for its duration.
     gc_was_on = pause_gc and gc.isenabled()
     if gc_was_on:
         gc.disable()
+    n_full = n // batch_size * batch_size
+    acc = torch.zeros(2, 1, dtype=torch.float32, device=dev)     # loss sums of the full batches / of the ragged last one
     try:
-        for s in range(0, n, batch_size):
-            total += stepper.step_bce(users[s:s + batch_size], items[s:s + batch_size], labels[s:s + batch_size]).reshape(())
+        for s in range(0, n_full, batch_size):
+            stepper.step_bce(users[s:s + batch_size], items[s:s + batch_size], labels[s:s + batch_size], loss_acc=acc[0])
+        if n_full < n:
+            stepper.step_bce(users[n_full:], items[n_full:], labels[n_full:], loss_acc=acc[1])
     finally:
         if gc_was_on:
             gc.enable()
+    total = acc[0, 0] / batch_size + (acc[1, 0] / (n - n_full) if n_full < n else 0.0)   # sum of per-batch mean losses
     return total

@@ -63,7 +63,7 @@ def test_argument_validation_fails_loudly_before_touching_the_device():
     with pytest.raises(_lib.SpexError):
         _lib.call("spex_spmm_f32", None, None, None, None, 1.0, None, None, 1.0, 64, None)
     with pytest.raises(_lib.SpexError):
-        _lib.call("spex_adam_step_f32", None, None, None, None, 10, 1, 1e-3, 0.9, 0.999, 1e-8, None)
+        _lib.call("spex_adam_step_f32", None, None, None, None, 10, 1, 1e-3, 0.9, 0.999, 1e-8, None, None)
 
 
 def test_missing_library_is_an_error_not_a_fallback(monkeypatch, tmp_path):

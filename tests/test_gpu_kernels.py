@@ -375,6 +375,11 @@ def test_adam_kernel_vs_oracle(oracle):
         ops.adam_step(pp, t(g), mm, vv, step, lr=1e-3)
         assert rel_err(pp.cpu().numpy(), p) <= 1e-6 and rel_err(mm.cpu().numpy(), m) <= 1e-6
         assert rel_err(vv.cpu().numpy(), v) <= 1e-6
+    # the same pass can clear one more buffer of the same length (the next step's gradient accumulation table)
+    z = torch.ones(n, device=DEV)
+    oracle.adam_step(p, g, m, v, 18, lr=1e-3)
+    ops.adam_step(pp, t(g), mm, vv, 18, lr=1e-3, zero=z)
+    assert rel_err(pp.cpu().numpy(), p) <= 1e-6 and torch.count_nonzero(z).item() == 0
 
 
 # ---------------------------------------------------------------------------------------------- NGCF + gate
