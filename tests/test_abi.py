@@ -83,3 +83,22 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dp, f)).read()
                 m = bad.search(txt)
                 assert m is None or f == "datasets.py", f"{os.path.join(dp, f)} references the oracle: {m.group(0)!r}"
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/spex_hip.h is the boundary a cgo / JNI / ctypes binding consumes: it must compile as C99 on its own
+    (no C++, no HIP or torch types) and link against the built library."""
+    import subprocess
+    src = tmp_path / "use.c"
+    src.write_text('#include "spex_hip.h"\n#include <stdio.h>\n'
+                   'int main(void) { spex_graph_t *g = 0; int rc = spex_graph_create(0, 0, 0, 0, 0, 0, 0, &g);\n'
+                   '  printf("%d %d %s\\n", spex_version(), rc, spex_last_error()); return rc == SPEX_OK ? 0 : 1; }\n')
+    exe = tmp_path / "use"
+    inc = os.path.dirname(HEADER)
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", inc, str(src), "-o", str(exe),
+                        "-L", libdir, "-lspexhip", "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    # NULL rowptr is refused by argument validation before any device call
+    assert out.returncode == 1 and out.stdout.startswith("1 -1 spex_graph_create"), (out.stdout, out.stderr)
