@@ -576,9 +576,9 @@ def test_sddmm_and_set_values_vs_oracle(G, oracle, d):
     SDDMM that is the SpMM's gradient w.r.t. the values."""
     from spex_amd.graph import csr_transpose
     rng = np.random.default_rng(100 + d)
-    n_rows, n_cols = 900, 700
+    n_rows, n_cols = 900, 2500
     deg = rng.integers(0, 70, n_rows)
-    deg[5], deg[6], deg[40] = 0, 650, 130
+    deg[5], deg[6], deg[40], deg[41], deg[899] = 0, 650, 130, 1500, 1025     # incl. hub rows (> 1024: global-scratch path)
     rowptr, col, val = random_csr(rng, n_rows, n_cols, deg)
     nnz = len(col)
     g = G(rowptr, col, val, n_cols=n_cols)
@@ -598,9 +598,9 @@ def test_sddmm_and_set_values_vs_oracle(G, oracle, d):
     g.set_values(t(new))
     gt.set_values(t(new))
     Y = g.spmm(t(B)).cpu().numpy()
-    assert rel_err(Y, oracle.spmm(rowptr, col, new, B)) <= 1e-6
+    assert rel_err(Y, oracle.spmm(rowptr, col, new, B)) <= 3e-6          # (1 500-term rows: re-associated partial sums)
     Yt = gt.spmm(t(A)).cpu().numpy()
-    assert rel_err(Yt, oracle.spmm(t_rowptr, t_col, new[perm], A)) <= 1e-6
+    assert rel_err(Yt, oracle.spmm(t_rowptr, t_col, new[perm], A)) <= 3e-6
     with pytest.raises(ValueError):
         g.set_values(t(new[:-1]))
 
