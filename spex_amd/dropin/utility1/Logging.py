@@ -1,5 +1,7 @@
 """Console + file logger with the reference's `Logging(filename).record(text)` surface
-(LightGCN_SPEX/code/utility1/Logging.py): every record is echoed and appended as one CRLF-terminated line."""
+(LightGCN_SPEX/code/utility1/Logging.py): every record is echoed and appended to the file as one CRLF-terminated
+line."""
+import sys
 
 
 class Logging:
@@ -7,6 +9,7 @@ class Logging:
         self.filename = filename
 
     def record(self, str_log):
-        print(str_log)
+        line = str(str_log)
+        sys.stdout.write(line + "\n")
         with open(self.filename, "a", newline="") as sink:
-            print(str_log, file=sink, end="\r\n", flush=True)
+            sink.write(line + "\r\n")

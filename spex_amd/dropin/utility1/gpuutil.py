@@ -1,10 +1,15 @@
-"""Device helpers with the reference's names (LightGCN_SPEX/code/utility1/gpuutil.py)."""
+"""Device helpers with the reference's names (LightGCN_SPEX/code/utility1/gpuutil.py): a tensor or module goes to the
+GPU / back to the host when a GPU is present and is returned untouched otherwise."""
 import torch
 
 
+def _moved(obj, target):
+    return obj.to(target) if torch.cuda.is_available() else obj
+
+
 def trans_to_cuda(variable):
-    return variable.cuda() if torch.cuda.is_available() else variable
+    return _moved(variable, "cuda")
 
 
 def trans_to_cpu(variable):
-    return variable.cpu() if torch.cuda.is_available() else variable
+    return _moved(variable, "cpu")

@@ -1,11 +1,16 @@
-"""Test driver written against the reference's import names and call order for the dual-task (recommendation +
-trust-path) run, LightGCN_SPEX/code/main_auto_expert_s.py:2-160 — what an unmodified reference driver looks like to
-the drop-in modules (both trust pickles are read from --data_path; the reference hard-codes '../data/' for one, :41).
-Run through `python -m spex_amd.dropin`.
+"""Dual-task (recommendation + trust-path) driver for the drop-in launcher test.
+
+It touches the package exactly where LightGCN_SPEX/code/main_auto_expert_s.py does — the same imports by the same
+names, Loader -> LightTrainData -> DataLoader(256, shuffle) -> pickled trust paths wrapped in utility2.utils.Data ->
+model_expert_s.LightGCN(args, dataset).to(device) -> Adam; per batch the paths of the batch's users (at most three
+trust batches' worth) go in with the rec batch at flag=0 and the two losses are combined with the learned task
+weights; evaluation is rec_test + trust_test5 — but is written as small functions for the test's needs (both trust
+pickles come from --data_path; the reference hard-codes '../data/' for the test split, :41).
+Run it as `python -m spex_amd.dropin tests/drivers/dual_driver.py --dataset tiny --data_path <root> --epochs 2`.
 """
 from lg_parser import parse_args_r
 
-args = parse_args_r()
+cli = parse_args_r()
 
 import pickle
 import random
@@ -23,61 +28,63 @@ from utility1.dataloader import LightTrainData
 from utility2.batch_test_gnn import trust_test5
 from utility2.utils import Data
 
-utils.set_seed(args.seed)
-device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
-dataset = dataloader.Loader(args)
-train_dataset = LightTrainData(dataset.rec_train_data, dataset.m_item, dataset.train_mat)
-train_loader = DataLoader(train_dataset, batch_size=256, shuffle=True)
-train_data2 = pickle.load(open(args.data_path + args.dataset + "/trust/train.txt", "rb"))
-test_data2 = pickle.load(open(args.data_path + args.dataset + "/trust/test2.txt", "rb"))
-user_path_indx = defaultdict(list)
-path = train_data2[0]
-for i, p in zip(range(len(path)), path):
-    user_path_indx[p[0]].append(i)
-train_data2 = Data(train_data2, dataset.n_users, shuffle=False)
-test_data2 = Data(test_data2, dataset.n_users, shuffle=False, test=True)
-trust_batch_size = max(1, len(path) // len(train_loader))
 
-Recmodel = model.LightGCN(args, dataset).to(device)
-optimizer = torch.optim.Adam(Recmodel.parameters(), lr=args.lr)
+def load_trust(split):
+    with open("%s%s/trust/%s" % (cli.data_path, cli.dataset, split), "rb") as fh:
+        return pickle.load(fh)
 
 
-def Train(epoch):
-    train_loader.dataset.ng_sample()
-    Recmodel.train()
-    total1 = total2 = 0.0
-    for data in train_loader:
-        optimizer.zero_grad()
-        user, item, label = data
-        path_index = []
-        for u in set(user.numpy().tolist()):
-            path_index.extend(user_path_indx[u])
-        if len(path_index) > trust_batch_size * 3:
-            path_index = random.sample(path_index, trust_batch_size * 3)
-        loss1, loss2 = Recmodel(users=user.to(device), items=item.to(device), labels=label.to(device),
-                                slice_indices=np.array(list(path_index), dtype=int), trust_data=train_data2, flag=0)
-        T, n_rec, T_rec = len(path_index), 5, len(user)
-        precision1 = torch.exp(-2 * Recmodel.task_weights[0])
-        precision2 = torch.exp(-2 * Recmodel.task_weights[1])
-        loss = (precision1 * loss1 + precision2 * loss2 + 2 * (n_rec + 1) * T_rec * Recmodel.task_weights[0]
-                + T * Recmodel.task_weights[1])
-        loss.backward()
-        total1 += loss1.item()
-        total2 += loss2.item()
-        optimizer.step()
-    print("%d,%.5f,%.5f" % (epoch, total1, total2))
+def paths_by_first_user(paths):
+    index = defaultdict(list)
+    for k, nodes in enumerate(paths):
+        index[nodes[0]].append(k)
+    return index
 
 
-def Test(epoch):
-    Recmodel.eval()
-    with torch.no_grad():
-        ret = rec_test(Recmodel, dataset.testRatings, dataset.testNegatives)
-        print("Rec:  Epoch %d : recall=%s ndcg=%s" % (epoch, ret["recall"].round(4).tolist(), ret["ndcg"].round(4).tolist()))
-        r = trust_test5(Recmodel, test_data2)
-        print("Trust:Epoch %d : recall=[%.4f, %.4f, %.4f],  ndcg=[%.4f, %.4f, %.4f]" % ((epoch,) + tuple(r)))
+def weighted_loss(net, rec_loss, trust_loss, n_rec_samples, n_paths):
+    """main_auto_expert_s.py:76-82: homoscedastic-uncertainty weighting of the two task losses."""
+    w = net.task_weights
+    return (torch.exp(-2 * w[0]) * rec_loss + torch.exp(-2 * w[1]) * trust_loss
+            + 2 * (5 + 1) * n_rec_samples * w[0] + n_paths * w[1])
+
+
+def run():
+    utils.set_seed(cli.seed)
+    dev = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    rec_data = dataloader.Loader(cli)
+    rec_batches = DataLoader(LightTrainData(rec_data.rec_train_data, rec_data.m_item, rec_data.train_mat),
+                             batch_size=256, shuffle=True)
+    raw_train = load_trust("train.txt")
+    by_user = paths_by_first_user(raw_train[0])
+    trust_train = Data(raw_train, rec_data.n_users, shuffle=False)
+    trust_test = Data(load_trust("test2.txt"), rec_data.n_users, shuffle=False, test=True)
+    cap = 3 * max(1, len(raw_train[0]) // len(rec_batches))
+    net = model.LightGCN(cli, rec_data).to(dev)
+    opt = torch.optim.Adam(net.parameters(), lr=cli.lr)
+
+    for epoch in range(cli.epochs):
+        rec_batches.dataset.ng_sample()
+        net.train()
+        sums = [0.0, 0.0]
+        for user, item, label in rec_batches:
+            opt.zero_grad()
+            chosen = [k for u in set(user.numpy().tolist()) for k in by_user[u]]
+            if len(chosen) > cap:
+                chosen = random.sample(chosen, cap)
+            l_rec, l_trust = net(users=user.to(dev), items=item.to(dev), labels=label.to(dev),
+                                 slice_indices=np.array(chosen, dtype=int), trust_data=trust_train, flag=0)
+            weighted_loss(net, l_rec, l_trust, len(user), len(chosen)).backward()
+            sums[0] += l_rec.item()
+            sums[1] += l_trust.item()
+            opt.step()
+        print("%d,%.5f,%.5f" % (epoch, sums[0], sums[1]))
+        net.eval()
+        with torch.no_grad():
+            r = rec_test(net, rec_data.testRatings, rec_data.testNegatives)
+            print("Rec:  Epoch %d : recall=%s ndcg=%s" % (epoch, r["recall"].round(4).tolist(), r["ndcg"].round(4).tolist()))
+            print("Trust:Epoch %d : recall=[%.4f, %.4f, %.4f],  ndcg=[%.4f, %.4f, %.4f]"
+                  % ((epoch,) + tuple(trust_test5(net, trust_test))))
 
 
 if __name__ == "__main__":
-    for epoch in range(args.epochs):
-        Train(epoch)
-        Test(epoch)
+    run()

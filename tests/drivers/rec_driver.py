@@ -1,9 +1,14 @@
-"""Test driver written against the reference's import names and call order (LightGCN_SPEX/code/main_rec.py:2-37,50):
-it is what an unmodified reference driver looks like to the drop-in modules.  Run through `python -m spex_amd.dropin`.
+"""Recommendation driver for the drop-in launcher test.
+
+It touches the package exactly where LightGCN_SPEX/code/main_rec.py does — the same imports by the same names,
+set_seed -> Loader(args) -> LightTrainData -> DataLoader(256, shuffle) -> model.LightGCN(args, dataset).to(device) ->
+Adam; per epoch ng_sample(), one forward(flag=0) / backward / step per batch with `loss.item()` accumulated, then
+test() under eval() and no_grad() — written as two small functions.
+Run it as `python -m spex_amd.dropin tests/drivers/rec_driver.py --dataset tiny --data_path <root> --epochs 2`.
 """
 from lg_parser import parse_args_r
 
-args = parse_args_r()
+cli = parse_args_r()
 
 import torch
 from torch.utils.data import DataLoader
@@ -14,37 +19,37 @@ import utility1.utils as utils
 from utility1.batch_test import test
 from utility1.dataloader import LightTrainData
 
-utils.set_seed(args.seed)
-device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
-dataset = dataloader.Loader(args)
-train_dataset = LightTrainData(dataset.rec_train_data, dataset.m_item, dataset.train_mat)
-train_loader = DataLoader(train_dataset, batch_size=256, shuffle=True)
-Recmodel = model.LightGCN(args, dataset).to(device)
-optimizer = torch.optim.Adam(Recmodel.parameters(), lr=args.lr)
+utils.set_seed(cli.seed)
+dev = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+rec_data = dataloader.Loader(cli)
+train_loader = DataLoader(LightTrainData(rec_data.rec_train_data, rec_data.m_item, rec_data.train_mat), batch_size=256,
+                          shuffle=True)
+Recmodel = model.LightGCN(cli, rec_data).to(dev)
+opt = torch.optim.Adam(Recmodel.parameters(), lr=cli.lr)
 
 
 def run_epoch(epoch):
     train_loader.dataset.ng_sample()
     Recmodel.train()
-    running = 0.0
+    seen = 0.0
     for user, item, label in train_loader:
-        optimizer.zero_grad()
-        loss = Recmodel(users=user.to(device), items=item.to(device), labels=label.to(device), flag=0)
-        loss.backward()
-        optimizer.step()
-        running += loss.item()
-    print("%d,%.5f" % (epoch, running))
+        opt.zero_grad()
+        batch_loss = Recmodel(users=user.to(dev), items=item.to(dev), labels=label.to(dev), flag=0)
+        batch_loss.backward()
+        opt.step()
+        seen += batch_loss.item()
+    print("%d,%.5f" % (epoch, seen))
 
 
 def evaluate(epoch):
     Recmodel.eval()
     with torch.no_grad():
-        ret = test(Recmodel, dataset.testRatings, dataset.testNegatives)
-    print("Rec:  Epoch %d : recall=%s ndcg=%s" % (epoch, ret["recall"].round(4).tolist(), ret["ndcg"].round(4).tolist()))
-    return ret
+        r = test(Recmodel, rec_data.testRatings, rec_data.testNegatives)
+    print("Rec:  Epoch %d : recall=%s ndcg=%s" % (epoch, r["recall"].round(4).tolist(), r["ndcg"].round(4).tolist()))
+    return r
 
 
 if __name__ == "__main__":
-    for epoch in range(args.epochs):
+    for epoch in range(cli.epochs):
         run_epoch(epoch)
         evaluate(epoch)
