@@ -23,7 +23,7 @@ Harness-side shims (reference files untouched):
   * sys.argv fixed before import    (argparse at import: batch_test.py:5-6)
   * cwd = scratch `<root>/code`     (relative data paths, dataloader.py:74)
 
-Usage:  python oracle/gen_golden.py [--stage all|mint|lightgcn|ngcf] [--skip-epinion-test]
+Usage:  python oracle/gen_golden.py [--stage all|mint|lightgcn|ngcf|trust|epochs] [--skip-epinion-test]
 """
 import argparse
 import hashlib
@@ -569,6 +569,66 @@ def stage_trust():
     print("trust tiny: loss1 %.6f loss2 %.6f test5 %s" % (loss1.item(), loss2.item(), out["trust_test5"]))
 
 
+# --------------------------------------------------------------------------- whole training run (G12)
+def stage_epochs():
+    """G12: the reference's own training run — main_rec.py:15-37,50 executed with the reference's modules (set_seed,
+    Loader, LightTrainData.ng_sample, DataLoader(256, shuffle=True), model.LightGCN, torch Adam, test()) for three
+    epochs on `tiny`: per-epoch loss sums, per-epoch recall / ndcg, the trained tables.  main_rec.py itself runs at
+    import and writes logs, so its Train() / Test() bodies are driven from here, line for line."""
+    import numpy as np
+    import torch
+    from torch.utils.data import DataLoader
+    install_shims()
+    torch.set_num_threads(8)
+    code = os.path.join(SCRATCH, "LightGCN_SPEX", "code")
+    os.makedirs(code, exist_ok=True)
+    os.chdir(code)
+    write_tiny(os.path.join(SCRATCH, "LightGCN_SPEX", "data", "tiny", "rec"))
+    cache = os.path.join(SCRATCH, "LightGCN_SPEX", "data", "tiny", "s_pre_adj_mat.npz")
+    if os.path.exists(cache):
+        os.remove(cache)
+    sys.path.insert(0, os.path.join(REF, "LightGCN_SPEX", "code"))
+    sys.argv = ["main_rec.py", "--dataset", "tiny"]
+    import lg_parser
+    import utility1.dataloader as ref_dl
+    import utility1.model as ref_model
+    import utility1.utils as ref_utils
+    from utility1.batch_test import test as ref_test
+    args = lg_parser.parse_args_r()
+    ref_utils.set_seed(args.seed)                                                   # main_rec.py:15
+    device = torch.device("cpu")
+    dataset = ref_dl.Loader(args)                                                   # :18
+    train_dataset = ref_dl.LightTrainData(dataset.rec_train_data, dataset.m_item, dataset.train_mat)   # :19
+    train_loader = DataLoader(train_dataset, batch_size=256, shuffle=True)          # :20
+    Recmodel = ref_model.LightGCN(args, dataset).to(device)                         # :22
+    optimizer = torch.optim.Adam(Recmodel.parameters(), lr=args.lr)                 # :23
+    losses, recalls, ndcgs, first_batch = [], [], [], None
+    for epoch in range(3):
+        train_loader.dataset.ng_sample()                                            # :26
+        Recmodel.train()
+        total_loss = 0.0
+        for data in train_loader:                                                   # :30-37
+            optimizer.zero_grad()
+            user, item, label = data
+            if first_batch is None:
+                first_batch = np.stack([user.numpy(), item.numpy(), label.numpy()])
+            loss = Recmodel(users=user.to(device), items=item.to(device), labels=label.to(device), flag=0)
+            loss.backward()
+            total_loss += loss.item()
+            optimizer.step()
+        losses.append(total_loss)
+        Recmodel.eval()
+        with torch.no_grad():                                                       # :49-50
+            ret = ref_test(Recmodel, dataset.testRatings, dataset.testNegatives)
+        recalls.append(ret["recall"]); ndcgs.append(ret["ndcg"])
+    np.savez_compressed(os.path.join(GOLD, "lightgcn_tiny_epochs.npz"), seed=args.seed, lr=args.lr,
+                        losses=np.asarray(losses, np.float64), recall=np.asarray(recalls, np.float64),
+                        ndcg=np.asarray(ndcgs, np.float64), first_batch=first_batch,
+                        user_w=Recmodel.embedding_user.weight.detach().numpy(),
+                        item_w=Recmodel.embedding_item.weight.detach().numpy())
+    print("epochs: losses", losses, "recall", recalls[-1], "ndcg", ndcgs[-1])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--stage", default="all")
@@ -577,7 +637,7 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     if a.stage == "all":
         env = dict(os.environ, PYTHONHASHSEED="0", PYTHONDONTWRITEBYTECODE="1")
-        for st in ("mint", "lightgcn", "ngcf", "trust"):
+        for st in ("mint", "lightgcn", "ngcf", "trust", "epochs"):
             cmd = [sys.executable, os.path.abspath(__file__), "--stage", st]
             if a.skip_epinion_test:
                 cmd.append("--skip-epinion-test")
@@ -590,6 +650,8 @@ def main():
         stage_ngcf()
     elif a.stage == "trust":
         stage_trust()
+    elif a.stage == "epochs":
+        stage_epochs()
 
 
 if __name__ == "__main__":

@@ -386,3 +386,46 @@ def test_on_device_epoch_equals_the_driver_loop(data_root):
     (l0, w0), (l1, w1) = results
     assert abs(l0 - l1) <= 1e-4 * abs(l0)
     assert rel_err(w1, w0) <= 2e-5
+
+
+def test_whole_training_run_matches_the_reference(data_root, golden):
+    """G12: the reference's own training run (main_rec.py:15-37,50 — set_seed, Loader, ng_sample, shuffled DataLoader,
+    LightGCN, torch Adam, test(); three epochs on `tiny`, minted by oracle/gen_golden.py --stage epochs from the
+    reference's modules on CPU) replayed through the drop-in modules on the GPU: the same first batch (same negatives,
+    same shuffle), the same per-epoch loss sums, the same HR / NDCG after every epoch, the same trained tables — and
+    the same again through the on-device epoch loop (trainer.train_epoch)."""
+    from torch.utils.data import DataLoader
+    import utility1.dataloader as dl
+    from utility1.batch_test import test
+    from spex_amd.trainer import LightGCNStepper, train_epoch
+    g = golden("lightgcn_tiny_epochs")
+    for fast in (False, True):
+        args, dataset, net = build("tiny", data_root)                 # includes utils.set_seed(args.seed)
+        assert args.seed == int(g["seed"]) and args.lr == float(g["lr"])
+        td = dl.LightTrainData(dataset.rec_train_data, dataset.m_item, dataset.train_mat)
+        loader = DataLoader(td, batch_size=256, shuffle=True)
+        opt = torch.optim.Adam(net.parameters(), lr=args.lr)
+        st = LightGCNStepper(net.Graph, net.flat_table(), net.num_users + 1, n_layers=net.n_layers, lr=args.lr)
+        for epoch in range(3):
+            if fast:
+                total = train_epoch(st, td).item()
+            else:
+                loader.dataset.ng_sample()
+                net.train()
+                total = 0.0
+                for k, (user, item, label) in enumerate(loader):
+                    if epoch == 0 and k == 0:
+                        assert np.array_equal(torch.stack([user, item, label]).numpy(), g["first_batch"])
+                    opt.zero_grad()
+                    loss = net(users=user.to(DEV), items=item.to(DEV), labels=label.to(DEV), flag=0)
+                    loss.backward()
+                    total += loss.item()
+                    opt.step()
+            assert abs(total - g["losses"][epoch]) <= 2e-5 * g["losses"][epoch], (fast, epoch, total)
+            net.eval()
+            with torch.no_grad():
+                ret = test(net, dataset.testRatings, dataset.testNegatives)
+            assert np.abs(ret["recall"] - g["recall"][epoch]).max() <= 1e-4
+            assert np.abs(ret["ndcg"] - g["ndcg"][epoch]).max() <= 1e-4
+        assert rel_err(net.embedding_user.weight.detach().cpu().numpy(), g["user_w"]) <= 2e-5
+        assert rel_err(net.embedding_item.weight.detach().cpu().numpy(), g["item_w"]) <= 2e-5
