@@ -570,7 +570,7 @@ def stage_trust():
 
 
 # --------------------------------------------------------------------------- whole training run (G12)
-def stage_epochs():
+def stage_epochs(ds="tiny", n_epochs=3):
     """G12: the reference's own training run — main_rec.py:15-37,50 executed with the reference's modules (set_seed,
     Loader, LightTrainData.ng_sample, DataLoader(256, shuffle=True), model.LightGCN, torch Adam, test()) for three
     epochs on `tiny`: per-epoch loss sums, per-epoch recall / ndcg, the trained tables.  main_rec.py itself runs at
@@ -583,12 +583,13 @@ def stage_epochs():
     code = os.path.join(SCRATCH, "LightGCN_SPEX", "code")
     os.makedirs(code, exist_ok=True)
     os.chdir(code)
-    write_tiny(os.path.join(SCRATCH, "LightGCN_SPEX", "data", "tiny", "rec"))
-    cache = os.path.join(SCRATCH, "LightGCN_SPEX", "data", "tiny", "s_pre_adj_mat.npz")
+    if ds == "tiny":
+        write_tiny(os.path.join(SCRATCH, "LightGCN_SPEX", "data", "tiny", "rec"))
+    cache = os.path.join(SCRATCH, "LightGCN_SPEX", "data", ds, "s_pre_adj_mat.npz")
     if os.path.exists(cache):
         os.remove(cache)
     sys.path.insert(0, os.path.join(REF, "LightGCN_SPEX", "code"))
-    sys.argv = ["main_rec.py", "--dataset", "tiny"]
+    sys.argv = ["main_rec.py", "--dataset", ds]
     import lg_parser
     import utility1.dataloader as ref_dl
     import utility1.model as ref_model
@@ -603,7 +604,7 @@ def stage_epochs():
     Recmodel = ref_model.LightGCN(args, dataset).to(device)                         # :22
     optimizer = torch.optim.Adam(Recmodel.parameters(), lr=args.lr)                 # :23
     losses, recalls, ndcgs, first_batch = [], [], [], None
-    for epoch in range(3):
+    for epoch in range(n_epochs):
         train_loader.dataset.ng_sample()                                            # :26
         Recmodel.train()
         total_loss = 0.0
@@ -621,11 +622,17 @@ def stage_epochs():
         with torch.no_grad():                                                       # :49-50
             ret = ref_test(Recmodel, dataset.testRatings, dataset.testNegatives)
         recalls.append(ret["recall"]); ndcgs.append(ret["ndcg"])
-    np.savez_compressed(os.path.join(GOLD, "lightgcn_tiny_epochs.npz"), seed=args.seed, lr=args.lr,
+    uw, iw = Recmodel.embedding_user.weight.detach().numpy(), Recmodel.embedding_item.weight.detach().numpy()
+    extra = {}
+    if ds != "tiny":                       # full-size run: keep the fixture small (sampled rows + column sums)
+        rows_u = np.sort(np.random.default_rng(1).choice(uw.shape[0], 256, replace=False))
+        rows_i = np.sort(np.random.default_rng(2).choice(iw.shape[0], 256, replace=False))
+        extra = dict(rows_u=rows_u, rows_i=rows_i, user_w_colsum=uw.astype(np.float64).sum(0),
+                     item_w_colsum=iw.astype(np.float64).sum(0))
+        uw, iw = uw[rows_u], iw[rows_i]
+    np.savez_compressed(os.path.join(GOLD, f"lightgcn_{ds}_epochs.npz"), seed=args.seed, lr=args.lr,
                         losses=np.asarray(losses, np.float64), recall=np.asarray(recalls, np.float64),
-                        ndcg=np.asarray(ndcgs, np.float64), first_batch=first_batch,
-                        user_w=Recmodel.embedding_user.weight.detach().numpy(),
-                        item_w=Recmodel.embedding_item.weight.detach().numpy())
+                        ndcg=np.asarray(ndcgs, np.float64), first_batch=first_batch, user_w=uw, item_w=iw, **extra)
     print("epochs: losses", losses, "recall", recalls[-1], "ndcg", ndcgs[-1])
 
 
@@ -652,6 +659,8 @@ def main():
         stage_trust()
     elif a.stage == "epochs":
         stage_epochs()
+    elif a.stage == "epochs-epinion2":      # ~25 min of CPU: one full Epinion2 epoch + test() through the reference
+        stage_epochs("epinion2", 1)
 
 
 if __name__ == "__main__":
