@@ -636,6 +636,92 @@ def stage_epochs(ds="tiny", n_epochs=3):
     print("epochs: losses", losses, "recall", recalls[-1], "ndcg", ndcgs[-1])
 
 
+def stage_epochs_dual():
+    """G13: the reference's dual-task training run — main_auto_expert_s.py:22-120 executed with the reference's
+    modules (rec loader + shuffled DataLoader, the trust paths of G11 wrapped in utility2.utils.Data, model_expert_s,
+    path selection per batch incl. random.sample, the uncertainty-weighted loss, torch Adam, rec_test + trust_test5)
+    for two epochs on `tiny`: per-epoch loss sums of both tasks, the learned task weights, both tasks' metrics."""
+    import random
+    from collections import defaultdict
+    import numpy as np
+    import torch
+    from torch.utils.data import DataLoader
+    install_shims()
+    torch.set_num_threads(8)
+    code = os.path.join(SCRATCH, "LightGCN_SPEX", "code")
+    os.makedirs(code, exist_ok=True)
+    os.chdir(code)
+    write_tiny(os.path.join(SCRATCH, "LightGCN_SPEX", "data", "tiny", "rec"))
+    cache = os.path.join(SCRATCH, "LightGCN_SPEX", "data", "tiny", "s_pre_adj_mat.npz")
+    if os.path.exists(cache):
+        os.remove(cache)
+    sys.path.insert(0, os.path.join(REF, "LightGCN_SPEX", "code"))
+    sys.argv = ["main_auto_expert_s.py", "--dataset", "tiny"]
+    import lg_parser
+    import utility1.dataloader as ref_dl
+    import utility1.utils as ref_utils
+    import utility1.model_expert_s as ref_ex
+    from utility1.batch_test import rec_test
+    from utility2.utils import Data
+    from utility2.batch_test_gnn import trust_test5
+    args = lg_parser.parse_args_r()
+    g11 = np.load(os.path.join(GOLD, "trust_tiny.npz"))
+    lens, tl = g11["train_mask"].sum(1), g11["test_mask"].sum(1)
+    raw_train = ([r[:l].tolist() for r, l in zip(g11["train_inputs"], lens)], g11["train_targets"].tolist())
+    raw_test = ([r[:l].tolist() for r, l in zip(g11["test_inputs"], tl)], g11["test_targets"].tolist(), g11["test_negs"].tolist())
+    ref_utils.set_seed(args.seed)                                                   # main_auto_expert_s.py:22
+    device = torch.device("cpu")
+    dataset = ref_dl.Loader(args)                                                   # :34
+    train_dataset = ref_dl.LightTrainData(dataset.rec_train_data, dataset.m_item, dataset.train_mat)
+    train_loader = DataLoader(train_dataset, batch_size=256, shuffle=True)          # :36
+    user_path_indx = defaultdict(list)                                              # :42-46
+    path = raw_train[0]
+    for i, p in zip(range(len(path)), path):
+        user_path_indx[p[0]].append(i)
+    train_data2 = Data(raw_train, dataset.n_users, shuffle=False)                   # :47-48
+    test_data2 = Data(raw_test, dataset.n_users, shuffle=False, test=True)
+    trust_batch_size = len(path) // len(train_loader)                               # :49
+    Recmodel = ref_ex.LightGCN(args, dataset).to(device)                            # :51-52
+    optimizer = torch.optim.Adam(Recmodel.parameters(), lr=args.lr)
+    out = dict(loss1=[], loss2=[], task_weights=[], rec_recall=[], rec_ndcg=[], trust=[], n_paths=[])
+    for epoch in range(2):
+        train_loader.dataset.ng_sample()                                            # :56
+        Recmodel.train()
+        t1 = t2 = 0.0
+        for data in train_loader:                                                   # :60-87
+            optimizer.zero_grad()
+            user, item, label = data
+            unique_user = set(user.numpy().tolist())
+            path_index = []
+            for u in unique_user:
+                path_index.extend(user_path_indx[u])
+            if len(path_index) > trust_batch_size * 3:
+                path_index = random.sample(path_index, trust_batch_size * 3)
+            out["n_paths"].append(len(path_index))
+            loss1, loss2 = Recmodel(users=user.to(device), items=item.to(device), labels=label.to(device),
+                                    slice_indices=np.array(list(path_index), dtype=int), trust_data=train_data2, flag=0)
+            T, n_rec, T_rec = len(path_index), 5, len(user)
+            precision1 = torch.exp(-2 * Recmodel.task_weights[0])
+            precision2 = torch.exp(-2 * Recmodel.task_weights[1])
+            loss = precision1 * loss1 + precision2 * loss2 + 2 * (n_rec + 1) * T_rec * Recmodel.task_weights[0] \
+                + T * Recmodel.task_weights[1]
+            loss.backward()
+            t1 += loss1.item()
+            t2 += loss2.item()
+            optimizer.step()
+        out["loss1"].append(t1); out["loss2"].append(t2)
+        out["task_weights"].append(Recmodel.task_weights.detach().numpy().copy())
+        Recmodel.eval()
+        with torch.no_grad():                                                       # :98-114
+            ret = rec_test(Recmodel, dataset.testRatings, dataset.testNegatives)
+            out["rec_recall"].append(ret["recall"]); out["rec_ndcg"].append(ret["ndcg"])
+            out["trust"].append(np.asarray(trust_test5(Recmodel, test_data2), np.float64))
+    np.savez_compressed(os.path.join(GOLD, "dual_tiny_epochs.npz"), seed=args.seed,
+                        **{k: np.asarray(v, np.float64) for k, v in out.items()},
+                        user_w=Recmodel.embedding_user.weight.detach().numpy(), w=Recmodel.w.detach().numpy())
+    print("dual epochs: loss1", out["loss1"], "loss2", out["loss2"], "tw", out["task_weights"][-1], "trust", out["trust"][-1])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--stage", default="all")
@@ -644,7 +730,7 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     if a.stage == "all":
         env = dict(os.environ, PYTHONHASHSEED="0", PYTHONDONTWRITEBYTECODE="1")
-        for st in ("mint", "lightgcn", "ngcf", "trust", "epochs"):
+        for st in ("mint", "lightgcn", "ngcf", "trust", "epochs", "epochs-dual"):
             cmd = [sys.executable, os.path.abspath(__file__), "--stage", st]
             if a.skip_epinion_test:
                 cmd.append("--skip-epinion-test")
@@ -659,6 +745,8 @@ def main():
         stage_trust()
     elif a.stage == "epochs":
         stage_epochs()
+    elif a.stage == "epochs-dual":
+        stage_epochs_dual()
     elif a.stage == "epochs-epinion2":      # ~25 min of CPU: one full Epinion2 epoch + test() through the reference
         stage_epochs("epinion2", 1)
 

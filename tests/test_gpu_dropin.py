@@ -435,3 +435,62 @@ def test_whole_training_run_matches_the_reference(data_root, golden, ds, n_epoch
                 assert np.abs(got.astype(np.float64).sum(0) - want).max() <= 2e-5 * np.abs(want).max()
             uw, iw = uw[g["rows_u"]], iw[g["rows_i"]]
         assert rel_err(uw, g["user_w"]) <= 1e-4 and rel_err(iw, g["item_w"]) <= 1e-4
+
+
+def test_whole_dual_task_run_matches_the_reference(data_root, golden):
+    """G13: the reference's dual-task training run (main_auto_expert_s.py:22-120 driven from the reference's modules on
+    CPU: rec batches, per-batch path selection incl. random.sample, uncertainty-weighted loss, Adam, rec_test +
+    trust_test5; two epochs on `tiny`) replayed through the drop-in modules on the GPU: the same number of paths per
+    batch, the same loss sums of both tasks, the same learned task weights, the same metrics of both tasks."""
+    import random
+    from collections import defaultdict
+    from torch.utils.data import DataLoader
+    import utility1.dataloader as dl
+    from utility1.batch_test import rec_test
+    from utility2.batch_test_gnn import trust_test5
+    from utility2.utils import Data
+    g, g11 = golden("dual_tiny_epochs"), golden("trust_tiny")
+    lens, tl = g11["train_mask"].sum(1), g11["test_mask"].sum(1)
+    raw_train = ([r[:l].tolist() for r, l in zip(g11["train_inputs"], lens)], g11["train_targets"].tolist())
+    raw_test = ([r[:l].tolist() for r, l in zip(g11["test_inputs"], tl)], g11["test_targets"].tolist(), g11["test_negs"].tolist())
+    args, dataset, net = _dual_task_model(data_root)               # includes utils.set_seed (also seeds `random`)
+    assert args.seed == int(g["seed"])
+    loader = DataLoader(dl.LightTrainData(dataset.rec_train_data, dataset.m_item, dataset.train_mat), batch_size=256, shuffle=True)
+    by_user = defaultdict(list)
+    for k, p in enumerate(raw_train[0]):
+        by_user[p[0]].append(k)
+    train2 = Data(raw_train, dataset.n_users, shuffle=False)
+    test2 = Data(raw_test, dataset.n_users, shuffle=False, test=True)
+    cap = 3 * (len(raw_train[0]) // len(loader))
+    net = net.to(DEV)
+    opt = torch.optim.Adam(net.parameters(), lr=args.lr)
+    step = 0
+    for epoch in range(2):
+        loader.dataset.ng_sample()
+        net.train()
+        t1 = t2 = 0.0
+        for user, item, label in loader:
+            opt.zero_grad()
+            chosen = []
+            for u in set(user.numpy().tolist()):
+                chosen.extend(by_user[u])
+            if len(chosen) > cap:
+                chosen = random.sample(chosen, cap)
+            assert len(chosen) == int(g["n_paths"][step])
+            step += 1
+            l1, l2 = net(users=user.to(DEV), items=item.to(DEV), labels=label.to(DEV),
+                         slice_indices=np.array(chosen, dtype=int), trust_data=train2, flag=0)
+            w = net.task_weights
+            (torch.exp(-2 * w[0]) * l1 + torch.exp(-2 * w[1]) * l2 + 2 * 6 * len(user) * w[0] + len(chosen) * w[1]).backward()
+            t1 += l1.item()
+            t2 += l2.item()
+            opt.step()
+        assert abs(t1 - g["loss1"][epoch]) <= 2e-5 * g["loss1"][epoch] and abs(t2 - g["loss2"][epoch]) <= 5e-5 * g["loss2"][epoch]
+        assert np.abs(net.task_weights.detach().cpu().numpy() - g["task_weights"][epoch]).max() <= 1e-6
+        net.eval()
+        with torch.no_grad():
+            ret = rec_test(net, dataset.testRatings, dataset.testNegatives)
+            assert np.abs(ret["recall"] - g["rec_recall"][epoch]).max() <= 1e-4 and np.abs(ret["ndcg"] - g["rec_ndcg"][epoch]).max() <= 1e-4
+            assert np.abs(np.asarray(trust_test5(net, test2)) - g["trust"][epoch]).max() <= 1e-4
+    assert rel_err(net.embedding_user.weight.detach().cpu().numpy(), g["user_w"]) <= 5e-5
+    assert rel_err(net.w.detach().cpu().numpy(), g["w"]) <= 5e-5
