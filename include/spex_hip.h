@@ -84,6 +84,21 @@ int spex_graph_set_edge_mask(spex_graph_t *g, int mode /*0 off, 1 injected, 2 sa
 int spex_spmm_f32(const spex_graph_t *g, const float *X, float *Y, const float *add_in, float add_div,
                   const float *acc_in, float *acc_out, float acc_div, int32_t d, void *stream);
 
+/* The same product for a LIST of rows only (d == 64, no edge dropout):
+ *   for r in { idx_a[k] + off_a : k < n_a } + { idx_b[k] + off_b : k < n_b }:
+ *     y = sum_e val[e] X[col[e],:];   Y[r,:] = y (if Y);   acc_out[r,:] = (acc_in[r,:] + y) / acc_div (if acc_out)
+ * Other rows of Y / acc_out are left untouched.  idx_*: device int64 (a batch's users and items as the DataLoader
+ * hands them over; off_b = n_user_rows).  Duplicates allowed — every copy stores the same value — PROVIDED acc_out
+ * is not acc_in (in place, a second copy could read the row the first has already finished); an index outside
+ * [0, n_rows) is skipped.
+ * The training step reads the last propagation layer (model.py:91-95) at the batch's rows only (model.py:115-116):
+ * this replaces that layer's launch over the whole matrix.  Rows of up to 1024 entries are summed in the order
+ * spex_spmm_f32 uses (bit-identical results).
+ */
+int spex_spmm_rowlist_f32(const spex_graph_t *g, const float *X, const int64_t *idx_a, int32_t n_a, int64_t off_a,
+                          const int64_t *idx_b, int32_t n_b, int64_t off_b, float *Y, const float *acc_in, float *acc_out,
+                          float acc_div, int32_t d, void *stream);
+
 /* Whole LightGCN.computer(), utility1/model.py:66-97, for a graph held entirely on this device (n_rows == n_cols):
  *   E^{l+1} = A E^l (l < L);  mean_out = (E^0 + ... + E^L) / (L+1).
  * ws: caller-provided device workspace of 2 * n_rows * d floats (ping-pong layer buffers).

@@ -21,6 +21,8 @@ SIGNATURES = {
                                        ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
     "spex_graph_set_edge_mask": (ctypes.c_int, [c_vp, ctypes.c_int, c_vp, c_f32, ctypes.c_uint64]),
     "spex_spmm_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_f32, c_i32, c_vp]),
+    "spex_spmm_rowlist_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_vp, c_vp, c_vp, c_f32, c_i32,
+                                             c_vp]),
     "spex_propagate_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "spex_propagate_bwd_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "spex_score_bce_f32": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i64, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp,

@@ -207,6 +207,22 @@ class SpexGraph:
             _bump(Y, acc_out)
         return Y if Y is not None else acc_out
 
+    def spmm_rows(self, X, idx_a, idx_b=None, off_a=0, off_b=0, Y=None, acc_in=None, acc_out=None, acc_div=1.0):
+        """The product for the listed rows only (idx_a + off_a, idx_b + off_b; device int64), other rows of Y / acc_out
+        untouched.  d == 64, no edge dropout.  See spex_spmm_rowlist_f32."""
+        d = X.shape[1]
+        self._chk(X, self.n_cols, d, "X")
+        for t, nm in ((Y, "Y"), (acc_in, "acc_in"), (acc_out, "acc_out")):
+            self._chk(t, self.n_rows, d, nm)
+        for t in (idx_a, idx_b):
+            if t is not None and not (t.is_cuda and t.dtype == torch.int64 and t.is_contiguous()):
+                raise ValueError("spmm_rows: row lists must be contiguous int64 tensors on the GPU")
+        _lib.call("spex_spmm_rowlist_f32", self._h, _ptr(X), _ptr(idx_a), idx_a.numel(), int(off_a), _ptr(idx_b),
+                  0 if idx_b is None else idx_b.numel(), int(off_b), _ptr(Y), _ptr(acc_in), _ptr(acc_out), float(acc_div), d,
+                  _stream())
+        _bump(Y, acc_out)
+        return Y if Y is not None else acc_out
+
     def propagate(self, E0, n_layers, mean_out=None, layers_out=None, ws=None):
         """LightGCN.computer() (model.py:66-97) on a whole graph: returns mean(E0..EL)."""
         n, d = E0.shape

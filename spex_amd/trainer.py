@@ -32,20 +32,42 @@ class LightGCNStepper:
         self.grad_E0 = z(n, d)
         self.m, self.v = z(n, d), z(n, d)
         self.loss_acc = z(1)          # running loss sum of the fused BPR steps (read it when you need it)
+        self.lo_batch = None          # propagated rows of the current batch (propagate_for_batch), allocated on first use
         self.t = 0
 
     # -- pieces
     def propagate(self):
         return self.graph.propagate(self.E0, self.L, mean_out=self.light_out, ws=self.ws_fwd)
 
-    def step_bce(self, users, items, labels, loss_acc=None):
+    def propagate_for_batch(self, users, items):
+        """The propagation as the training step needs it: layers 1 .. L-1 over the whole graph, the LAST layer only at the
+        batch's rows (the loss reads light_out nowhere else, model.py:115-116) — spex_spmm_rowlist_f32 instead of a
+        launch over the whole matrix.  Returns a table that is valid at those rows only.  Falls back to the full propagation
+        when the row-list kernel does not apply (d != 64, L == 0)."""
+        L, g, lo = self.L, self.graph, self.light_out
+        if L == 0 or self.E0.shape[1] != 64:
+            return self.propagate()
+        cur = self.E0
+        for l in range(L - 1):
+            nxt = self.ws_fwd[l & 1]
+            g.spmm(cur, Y=nxt, acc_in=self.E0 if l == 0 else lo, acc_out=lo)
+            cur = nxt
+        # NOT in place: a batch lists the same user several times, and a second workgroup must not read a row the
+        # first one has already finished — the running sum stays in `lo`, the finished rows go to `lo_batch`
+        if self.lo_batch is None:
+            self.lo_batch = torch.zeros_like(lo)
+        g.spmm_rows(cur, users, items, 0, self.n_u, acc_in=self.E0 if L == 1 else lo, acc_out=self.lo_batch,
+                    acc_div=float(L + 1))
+        return self.lo_batch
+
+    def step_bce(self, users, items, labels, loss_acc=None, batch_rows_only=False):
         """One exact reference training step (main_rec.py:32-37).  Returns the mean BCE loss (device tensor) — or, with
         `loss_acc` (a 1-element device buffer), accumulates the batch's loss SUM into it and returns None: then the
         step is exactly eight launches (3 SpMM, scoring, 3 SpMM, Adam) with nothing between them.  The gradient table
-        is cleared by the Adam pass of the previous step."""
-        self.propagate()
+        is cleared by the Adam pass of the previous step.  batch_rows_only: compute the last forward layer at the
+        batch's rows only (same arithmetic for those rows; `self.light_out` is then not the whole table)."""
+        lo = self.propagate_for_batch(users, items) if batch_rows_only else self.propagate()
         B = users.numel()
-        lo = self.light_out
         _, loss_sum = ops.score_bce(lo[:self.n_u], lo[self.n_u:], users, items, labels, self.g_out[:self.n_u],
                                     self.g_out[self.n_u:], 1.0 / B, loss_sum=loss_acc, want_gamma=False)
         self.graph_t.propagate_bwd(self.g_out, self.L, grad_E0=self.grad_E0, ws=self.ws_bwd)
@@ -113,9 +135,10 @@ def train_epoch(stepper, train_data, batch_size=256, resample=True, pause_gc=Tru
     acc = torch.zeros(2, 1, dtype=torch.float32, device=dev)     # loss sums of the full batches / of the ragged last one
     try:
         for s in range(0, n_full, batch_size):
-            stepper.step_bce(users[s:s + batch_size], items[s:s + batch_size], labels[s:s + batch_size], loss_acc=acc[0])
+            stepper.step_bce(users[s:s + batch_size], items[s:s + batch_size], labels[s:s + batch_size], loss_acc=acc[0],
+                             batch_rows_only=True)
         if n_full < n:
-            stepper.step_bce(users[n_full:], items[n_full:], labels[n_full:], loss_acc=acc[1])
+            stepper.step_bce(users[n_full:], items[n_full:], labels[n_full:], loss_acc=acc[1], batch_rows_only=True)
     finally:
         if gc_was_on:
             gc.enable()

@@ -823,3 +823,38 @@ def test_attn_fuse_kernels_vs_torch_autograd(with_base, d):
         if gt is not None:
             err = (gt.grad.cpu().double() - rf.grad).abs().max().item()
             assert err <= 2e-5 * rf.grad.abs().max().item() + 1e-6, err
+
+
+def test_spmm_rowlist_is_the_full_product_at_the_listed_rows(G, golden, epinion2):
+    """spex_spmm_rowlist_f32: bit-identical to the full launch at the listed rows (every row of Epinion2 has <= 1024
+    entries: same segments, same order), other rows untouched; plus a graph with hub rows, empty rows and bad indices."""
+    g_, csr, E0 = _epinion2(golden, epinion2)
+    g = G(*csr)
+    rng = np.random.default_rng(4)
+    X, acc = t(E0), t(rng.normal(size=E0.shape).astype(np.float32))
+    full = torch.empty_like(X)
+    full_acc = torch.empty_like(X)
+    g.spmm(X, Y=full, acc_in=acc, acc_out=full_acc, acc_div=4.0)
+    users = torch.from_numpy(np.r_[rng.integers(0, 3185, 300), np.argsort(-np.diff(csr[0])[:3186])[:8]]).to(DEV)
+    items = torch.from_numpy(rng.integers(0, 12407, 300)).to(DEV)
+    Y = torch.full_like(X, 7.0)
+    A = acc.clone()
+    g.spmm_rows(X, users, items, 0, 3186, Y=Y, acc_in=acc, acc_out=A, acc_div=4.0)     # (users repeat: out of place!)
+    rows = torch.cat([users, items + 3186])
+    assert torch.equal(Y[rows], full[rows]) and torch.equal(A[rows], full_acc[rows])
+    untouched = torch.ones(len(E0), dtype=torch.bool, device=DEV)
+    untouched[rows] = False
+    assert (Y[untouched] == 7.0).all() and torch.equal(A[untouched], acc[untouched])
+    # hub rows (> 1024 entries), an empty row, out-of-range indices
+    deg = rng.integers(0, 50, 300)
+    deg[3], deg[4], deg[5] = 0, 1500, 2600
+    rowptr, col, val = random_csr(rng, 300, 3000, deg)
+    g2 = G(rowptr, col, val, n_cols=3000)
+    X2 = t(rng.normal(size=(3000, 64)).astype(np.float32))
+    want = g2.spmm(X2)
+    idx = torch.tensor([3, 4, 5, 7, 299, 300, -1, 4], device=DEV)
+    got = torch.zeros(300, 64, device=DEV)
+    g2.spmm_rows(X2, idx, Y=got)
+    ok = torch.tensor([3, 4, 5, 7, 299], device=DEV)
+    assert rel_err(got[ok].cpu().numpy(), want[ok].cpu().numpy()) <= 3e-6
+    assert torch.equal(got[torch.tensor([3, 7, 299], device=DEV)], want[torch.tensor([3, 7, 299], device=DEV)])
