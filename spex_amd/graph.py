@@ -184,6 +184,15 @@ class SpexGraph:
         self._mask_ref = keep  # keep the tensor alive while the handle points at it
         _lib.call("spex_graph_set_edge_mask", self._h, int(mode), _ptr(keep), float(keep_prob), int(seed))
 
+    def _scratch(self, key, shape, device):
+        """Per-handle workspace reused across calls (contents are dead once the call's launches are queued: calls on one
+        handle are stream-ordered, see spex_hip.h) — no allocation per training step."""
+        cache = self.__dict__.setdefault("_scratch_cache", {})
+        t = cache.get(key)
+        if t is None or t.shape != shape or t.device != device:
+            t = cache[key] = torch.empty(shape, dtype=torch.float32, device=device)
+        return t
+
     # -- kernels
     def _chk(self, t, rows, d, name):
         if t is None:
@@ -230,7 +239,7 @@ class SpexGraph:
         if mean_out is None:
             mean_out = torch.empty_like(E0)
         if layers_out is None and ws is None and n_layers > 1:
-            ws = torch.empty((2, n, d), dtype=torch.float32, device=E0.device)
+            ws = self._scratch("fwd", (2, n, d), E0.device)
         _lib.call("spex_propagate_f32", self._h, _ptr(E0), _ptr(mean_out), _ptr(layers_out), _ptr(ws), int(n_layers), d,
                   _stream())
         _bump(mean_out, layers_out)
@@ -243,7 +252,7 @@ class SpexGraph:
         if grad_E0 is None:
             grad_E0 = torch.empty_like(g_out)
         if ws is None:
-            ws = torch.empty((3, n, d), dtype=torch.float32, device=g_out.device)
+            ws = self._scratch("bwd", (3, n, d), g_out.device)
         _lib.call("spex_propagate_bwd_f32", self._h, _ptr(g_out), _ptr(grad_E0), _ptr(ws), int(n_layers), d, _stream())
         _bump(grad_E0)
         return grad_E0
