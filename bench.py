@@ -119,17 +119,15 @@ def main():
         ar = torch.arange(T_TRIPLES, device=dev)
         cu, cp, cn = ar, ar + T_TRIPLES, ar + 2 * T_TRIPLES        # compact ids into `fetched`
         loss_acc = torch.zeros(1, device=dev)
-        plan = P.plan_rows(pos_all)
         local_nnz, local_rows = graph.nnz, graph.n_rows
 
         def step():
             P.propagate(E0_local)
-            # owner-computes: the (replicated) batch's rows are exchanged, every rank scores the batch and applies
-            # the updates of the rows it owns — no gradient exchange
-            rows = P.fetch_rows(plan, fetched)
-            upd.zero_()
+            # owner-computes: the (replicated) batch's rows are exchanged (one launch + one small all-reduce), every
+            # rank scores the batch and applies the updates of the rows it owns (one launch) — no gradient exchange
+            rows = P.fetch_rows_at(pos_all, fetched)
             ops.bpr_sgd_step(rows, rows, upd, upd, cu, cp, cn, lr, 0.0, loss_sum=loss_acc)
-            E0_local.index_add_(0, plan[1], upd.index_select(0, plan[0]))
+            P.add_owned_rows(upd, pos_all, E0_local, clear=True)      # leaves `upd` all-zero for the next step
             return loss_acc
 
     def barrier():

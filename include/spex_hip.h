@@ -155,6 +155,17 @@ int spex_bpr_loss_f32(const float *users, const float *items, int64_t n_user_row
                       const int64_t *u, const int64_t *i_pos, const int64_t *i_neg, int64_t T, int32_t d,
                       float *loss_sum, float *grad_users, float *grad_items, float grad_scale, void *stream);
 
+/* Owner-computes exchange of a batch's rows on a 1-D row-partitioned table ("replicate the batch on all
+ * ranks (owner-computes, no comm)" needs the batch's rows of the propagated table everywhere).  pos: device int64[K]
+ * positions in the padded global row layout; this rank owns positions [lo, lo + n_local) = rows of `table`.
+ *   gather : out[k,:] = owned(pos[k]) ? table[pos[k]-lo,:] : 0      -> one all-reduce (sum) of `out` completes it
+ *   scatter: table[pos[k]-lo,:] += upd[k,:] for the owned k (atomics: positions repeat), then upd[k,:] = 0 if clear_upd
+ */
+int spex_gather_owned_rows_f32(const float *table, const int64_t *pos, int64_t K, int64_t lo, int64_t n_local, int32_t d,
+                               float *out, void *stream);
+int spex_scatter_add_owned_rows_f32(float *upd, const int64_t *pos, int64_t K, int64_t lo, int64_t n_local, int32_t d,
+                                    float *table, int32_t clear_upd, void *stream);
+
 /* ------------------------------------------------------------------------------------------------ optimiser
  * Replaces torch.optim.Adam(...).step() over the dense embedding tables — LightGCN_SPEX/code/main_rec.py:23,37.
  * One fused pass: m, v, p updated in place (bias-corrected, eps outside the sqrt as torch does), t = step count >= 1.

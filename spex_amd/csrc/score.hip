@@ -165,6 +165,38 @@ inline int bpr_per_wave(int64_t T)
     return (int)(k < 1 ? 1 : (k > 16 ? 16 : k));
 }
 
+// Owner-computes exchange of a batch's rows on a row-partitioned table (spex_amd/dist.py): every rank contributes the
+// rows it owns to a zero-filled buffer (summed by one small all-reduce), and after scoring adds the update rows it
+// owns back into its shard.  One wave per listed position; `pos` are positions in the padded global layout, the rank
+// owns [lo, lo + n_local).
+__global__ __launch_bounds__(kWave *kScoreWaves) void gather_owned_rows_kernel(const float *__restrict__ table,
+                                                                              const int64_t *__restrict__ pos, int64_t K,
+                                                                              int64_t lo, int64_t n_local, int d,
+                                                                              float *__restrict__ out)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    for (int64_t k = (int64_t)blockIdx.x * kScoreWaves + (threadIdx.x >> 6); k < K; k += (int64_t)gridDim.x * kScoreWaves) {
+        const int64_t p = pos[k] - lo;
+        const bool own = p >= 0 && p < n_local;
+        for (int c = lane; c < d; c += kWave) out[(size_t)k * d + c] = own ? table[(size_t)p * d + c] : 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(kWave *kScoreWaves) void scatter_add_owned_rows_kernel(float *upd, const int64_t *__restrict__ pos,
+                                                                                   int64_t K, int64_t lo, int64_t n_local,
+                                                                                   int d, float *table, int clear)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    for (int64_t k = (int64_t)blockIdx.x * kScoreWaves + (threadIdx.x >> 6); k < K; k += (int64_t)gridDim.x * kScoreWaves) {
+        const int64_t p = pos[k] - lo;
+        const bool own = p >= 0 && p < n_local;
+        for (int c = lane; c < d; c += kWave) {
+            if (own) atomicAdd(table + (size_t)p * d + c, upd[(size_t)k * d + c]);   // positions repeat within a batch
+            if (clear) upd[(size_t)k * d + c] = 0.0f;
+        }
+    }
+}
+
 inline unsigned grid_for(int64_t waves_wanted)
 {
     int64_t blocks = (waves_wanted + kScoreWaves - 1) / kScoreWaves;
@@ -222,6 +254,32 @@ extern "C" int spex_bpr_loss_f32(const float *users, const float *items, int64_t
     hipLaunchKernelGGL(bpr_kernel, dim3(grid_for((T + per_wave - 1) / per_wave)), dim3(kWave * kScoreWaves), 0,
                        (hipStream_t)stream, users, items, grad_users, grad_items, u, i_pos, i_neg, T, d, n_user_rows,
                        n_item_rows, grad_scale, 0.0f, loss_sum, per_wave);
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}
+
+extern "C" int spex_gather_owned_rows_f32(const float *table, const int64_t *pos, int64_t K, int64_t lo, int64_t n_local,
+                                          int32_t d, float *out, void *stream)
+{
+    SPEX_CHECK_ARG((table || n_local == 0) && pos && out, "spex_gather_owned_rows_f32: NULL pointer");
+    SPEX_CHECK_ARG(K >= 0 && n_local >= 0 && d >= 1, "spex_gather_owned_rows_f32: K=%lld n_local=%lld d=%d", (long long)K,
+                   (long long)n_local, d);
+    if (K == 0) return SPEX_OK;
+    hipLaunchKernelGGL(gather_owned_rows_kernel, dim3(grid_for(K)), dim3(kWave * kScoreWaves), 0, (hipStream_t)stream, table, pos,
+                       K, lo, n_local, d, out);
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}
+
+extern "C" int spex_scatter_add_owned_rows_f32(float *upd, const int64_t *pos, int64_t K, int64_t lo, int64_t n_local,
+                                               int32_t d, float *table, int32_t clear_upd, void *stream)
+{
+    SPEX_CHECK_ARG(upd && pos && (table || n_local == 0), "spex_scatter_add_owned_rows_f32: NULL pointer");
+    SPEX_CHECK_ARG(K >= 0 && n_local >= 0 && d >= 1, "spex_scatter_add_owned_rows_f32: K=%lld n_local=%lld d=%d", (long long)K,
+                   (long long)n_local, d);
+    if (K == 0) return SPEX_OK;
+    hipLaunchKernelGGL(scatter_add_owned_rows_kernel, dim3(grid_for(K)), dim3(kWave * kScoreWaves), 0, (hipStream_t)stream, upd,
+                       pos, K, lo, n_local, d, table, clear_upd);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }

@@ -155,6 +155,29 @@ class PartitionedLightGCN:
             dist.all_reduce(out, group=self.group)
         return out
 
+    def fetch_rows_at(self, padded_pos, out):
+        """fetch_rows() without a plan: on the GPU one launch writes the owned rows and zero-fills the others
+        (spex_gather_owned_rows_f32), then the same all-reduce; on CPU tensors (the gloo tests of the schedule) the
+        plan-based tensor ops."""
+        if out.is_cuda:
+            from . import ops
+            ops.gather_owned_rows(self.light_out, padded_pos, self.rank * self.part.max_rows, out)
+            if self.world > 1 or self.always_collective:
+                dist.all_reduce(out, group=self.group)
+            return out
+        return self.fetch_rows(self.plan_rows(padded_pos), out)
+
+    def add_owned_rows(self, upd, padded_pos, table_local, clear=True):
+        """table_local[owned rows of padded_pos] += upd rows (and clear upd): the owner-computes update."""
+        if upd.is_cuda:
+            from . import ops
+            return ops.scatter_add_owned_rows(upd, padded_pos, self.rank * self.part.max_rows, table_local, clear)
+        own_idx, local = self.plan_rows(padded_pos)
+        table_local.index_add_(0, local, upd.index_select(0, own_idx))
+        if clear:
+            upd.zero_()
+        return table_local
+
     def padded_index(self, users, items):
         """Batch indices (user ids, item ids) -> rows of the padded gathered table."""
         return self.part.to_padded_torch(users), self.part.to_padded_torch(items + self.n_user_rows)

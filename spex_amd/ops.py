@@ -423,3 +423,28 @@ class AttnFuse(torch.autograd.Function):
 
 def attn_fuse(U, X1, X2, p1, p2, c1, c2, base_coef, mix_coef):
     return AttnFuse.apply(U, X1, X2, p1, p2, c1, c2, base_coef, mix_coef)
+
+
+# ------------------------------------------------------------------------------------------------ multi-GPU row exchange
+def gather_owned_rows(table, pos, lo, out):
+    """out[k] = table[pos[k] - lo] where this rank owns the position, 0 elsewhere (spex_gather_owned_rows_f32)."""
+    _need(table, "table"); _need(out, "out")
+    pos = _idx(pos, out.device)
+    if out.shape != (pos.numel(), table.shape[1]):
+        raise ValueError("gather_owned_rows: out must be [len(pos), d]")
+    _lib.call("spex_gather_owned_rows_f32", _ptr(table), _ptr(pos), pos.numel(), int(lo), table.shape[0], table.shape[1],
+              _ptr(out), _stream())
+    _bump(out)
+    return out
+
+
+def scatter_add_owned_rows(upd, pos, lo, table, clear=True):
+    """table[pos[k] - lo] += upd[k] for the positions this rank owns; upd is cleared afterwards (clear=True)."""
+    _need(table, "table"); _need(upd, "upd")
+    pos = _idx(pos, upd.device)
+    if upd.shape != (pos.numel(), table.shape[1]):
+        raise ValueError("scatter_add_owned_rows: upd must be [len(pos), d]")
+    _lib.call("spex_scatter_add_owned_rows_f32", _ptr(upd), _ptr(pos), pos.numel(), int(lo), table.shape[0], table.shape[1],
+              _ptr(table), 1 if clear else 0, _stream())
+    _bump(table, upd)
+    return table

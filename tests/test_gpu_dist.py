@@ -46,6 +46,17 @@ def _worker(rank, world, port, out_dir):
     u = torch.arange(0, 3185, 7, device=dev)
     i = torch.arange(0, 12407, 31, device=dev)[: len(u)]
     pu, pi = P.padded_index(u, i)
+    # the one-launch exchange helpers agree with the plan-based tensor ops
+    pos = torch.cat([pu, pi, pu[:5]])                                   # (positions repeat)
+    a = P.fetch_rows(P.plan_rows(pos), torch.empty(len(pos), 64, device=dev)).clone()
+    b = P.fetch_rows_at(pos, torch.empty(len(pos), 64, device=dev))
+    assert torch.equal(a, b)
+    upd = torch.randn(len(pos), 64, device=dev)
+    t1, t2 = torch.zeros(P.n_local, 64, device=dev), torch.zeros(P.n_local, 64, device=dev)
+    own_idx, local = P.plan_rows(pos)
+    t1.index_add_(0, local, upd.index_select(0, own_idx))
+    P.add_owned_rows(upd, pos, t2, clear=True)
+    assert (t1 - t2).abs().max().item() <= 1e-5 and torch.count_nonzero(upd).item() == 0
     # three exact training steps (BCE + backward + Adam) on the partitioned model
     from spex_amd.dist import PartitionedStepper
     E0_local = torch.from_numpy(E0[P.r0:P.r1].copy()).to(dev)
