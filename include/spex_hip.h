@@ -12,8 +12,10 @@
  *   - every dense pointer is a DEVICE pointer owned by the caller (e.g. torch.Tensor.data_ptr()); the library never
  *     frees or retains them past the call.  Row-major fp32, leading dimension == d, 16-byte aligned.
  *   - host pointers are marked `h_`.
- *   - every call is asynchronous on `stream` unless stated; no hidden device synchronisation, no allocation after
- *     spex_graph_create / spex_workspace_* (safe to capture in a hipGraph).
+ *   - every call is asynchronous on `stream` unless stated; no hidden device synchronisation and no allocation after
+ *     spex_graph_create (safe to capture in a hipGraph) — with three documented exceptions that allocate once: the
+ *     first spex_sddmm_f32 on a handle, the first spex_spmm_f32 / propagate call at d > 64 on a graph with long rows,
+ *     and spex_timer_create.
  *   - return 0 on success, a negative spex_status otherwise; spex_last_error() gives the thread-local message.
  */
 #ifndef SPEX_HIP_H
