@@ -103,6 +103,61 @@ def stage_mint():
     print("mint: train", train.shape, "test.rating rows", len(test_users), "test.negative rows", len(negs))
 
 
+# --------------------------------------------------------------------------- Epinion2 trust paths (config 5 at real scale)
+def stage_paths():
+    """The reference's own trust-path pipeline — Data_process/path/data_process_path.py:28-229 (process_selftrust,
+    built_user, build_path, data_enhancement, neg_sample, data_refine; the `__main__` step-1 order at :276-283) — run
+    in scratch on the `train_trust.txt` the `mint` stage's data_process_rec.py produced from the shipped
+    trust_with_timestamp.mat.  random.seed(2020) and PYTHONHASHSEED=0 make it reproducible (the script samples with the
+    global `random` and iterates sets).  --user_num is the dataset's user count (the padding / negative-pool id space,
+    data_process_path.py:16,85-90,199), everything else the script's defaults (m = 50 walks per user, path_len 6).
+    Stored compactly: padded uint16 path arrays + lengths; the test set is cut to its first 1 024 paths (each carries
+    499 negatives + the target: 16 k test paths would be 16 MB of incompressible ids)."""
+    import random
+    import numpy as np
+    import pickle
+    assert os.environ.get("PYTHONHASHSEED") == "0", "paths stage needs PYTHONHASHSEED=0"
+    rec = os.path.join(SCRATCH, "Data_process", "rec", "epinion2")
+    assert os.path.exists(os.path.join(rec, "train_trust.txt")), "run --stage mint first"
+    wd = os.path.join(SCRATCH, "Data_process", "path")
+    if os.path.isdir(wd):
+        shutil.rmtree(wd)
+    os.makedirs(os.path.join(wd, "epinion2"))
+    shutil.copy(os.path.join(rec, "train_trust.txt"), os.path.join(wd, "epinion2", "trust.txt"))   # :272
+    os.chdir(wd)
+    spec = importlib.util.spec_from_file_location(
+        "ref_data_process_path", os.path.join(REF, "Data_process", "path", "data_process_path.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    d = np.load(os.path.join(GOLD, "epinion2_dataset.npz"))
+    n_users = int(d["train"][:, 0].max()) + 1
+    mod.args = types.SimpleNamespace(root="epinion2", m=50, path_len=6, user_num=n_users, item_num=1000000,
+                                     max_count=10000, max_time=13, fix_len=769)
+    random.seed(2020)
+    import warnings
+    warnings.simplefilter("ignore", DeprecationWarning)     # random.sample on a set (:202), still allowed on 3.10
+    for step in ("process_selftrust", "built_user", "build_path", "data_enhancement", "neg_sample", "data_refine"):
+        getattr(mod, step)()
+    train = pickle.load(open(os.path.join(wd, "epinion2", "train.txt"), "rb"))
+    test2 = pickle.load(open(os.path.join(wd, "epinion2", "test2.txt"), "rb"))
+
+    def pack(paths):
+        lens = np.asarray([len(p) for p in paths], np.uint8)
+        arr = np.full((len(paths), int(lens.max())), n_users, np.uint16)
+        for k, p in enumerate(paths):
+            arr[k, :len(p)] = p
+        return arr, lens
+    tr_arr, tr_len = pack(train[0])
+    n_test = min(1024, len(test2[0]))
+    te_arr, te_len = pack(test2[0][:n_test])
+    assert max(max(p) for p in train[0]) < n_users and n_users < 65535
+    np.savez_compressed(os.path.join(GOLD, "trust_epinion2_paths.npz"), n_users=n_users,
+                        train_paths=tr_arr, train_len=tr_len, train_targets=np.asarray(train[1], np.uint16),
+                        test_paths=te_arr, test_len=te_len, test_targets=np.asarray(test2[1][:n_test], np.uint16),
+                        test_negs=np.asarray(test2[2][:n_test], np.uint16), n_test_total=len(test2[0]))
+    print("paths: train", tr_arr.shape, "len hist", np.bincount(tr_len), "test kept", n_test, "of", len(test2[0]))
+
+
 # --------------------------------------------------------------------------- common
 def install_shims():
     import numpy as np
@@ -722,6 +777,388 @@ def stage_epochs_dual():
     print("dual epochs: loss1", out["loss1"], "loss2", out["loss2"], "tw", out["task_weights"][-1], "trust", out["trust"][-1])
 
 
+# --------------------------------------------------------------------------- dual-task at Epinion2 scale (config 5)
+def _epinion2_trust_raw():
+    """(train paths, targets), (test paths, targets, negatives) as the lists the reference pickles
+    (data_process_path.py:184-188,207-208), rebuilt from the compact fixture the `paths` stage wrote."""
+    import numpy as np
+    t = np.load(os.path.join(GOLD, "trust_epinion2_paths.npz"))
+    tr = ([r[:l].tolist() for r, l in zip(t["train_paths"].astype(np.int64), t["train_len"])],
+          t["train_targets"].astype(np.int64).tolist())
+    te = ([r[:l].tolist() for r, l in zip(t["test_paths"].astype(np.int64), t["test_len"])],
+          t["test_targets"].astype(np.int64).tolist(), t["test_negs"].astype(np.int64).tolist())
+    return tr, te
+
+
+def _dual_setup(argv0="main_auto_expert_s.py"):
+    import torch
+    install_shims()
+    torch.set_num_threads(8)
+    code = os.path.join(SCRATCH, "LightGCN_SPEX", "code")
+    os.makedirs(code, exist_ok=True)
+    os.chdir(code)
+    cache = os.path.join(SCRATCH, "LightGCN_SPEX", "data", "epinion2", "s_pre_adj_mat.npz")
+    if os.path.exists(cache):
+        os.remove(cache)
+    sys.path.insert(0, os.path.join(REF, "LightGCN_SPEX", "code"))
+    sys.argv = [argv0, "--dataset", "epinion2"]
+
+
+def stage_trust_epinion2():
+    """G11 at Epinion2 scale: model_expert_s.LightGCN (seed 2020) on the Epinion2 graph and the reference-minted trust
+    paths: both losses at flag=0 for a fixed rec batch + the paths of its users, every parameter's gradient (tables:
+    sampled rows + column sums + norm), trust scores at the test negatives, trust_test5 on the 1 024 kept test paths."""
+    import numpy as np
+    import torch
+    _dual_setup()
+    import lg_parser
+    import utility1.dataloader as ref_dl
+    import utility1.utils as ref_utils
+    import utility1.model_expert_s as ref_ex
+    from utility2.utils import Data
+    from utility2.batch_test_gnn import trust_test5
+    from collections import defaultdict
+    args = lg_parser.parse_args_r()
+    raw_train, raw_test = _epinion2_trust_raw()
+    ref_utils.set_seed(args.seed)
+    dataset = ref_dl.Loader(args)
+    train2 = Data(raw_train, dataset.n_users, shuffle=False)
+    test2 = Data(raw_test, dataset.n_users, shuffle=False, test=True)
+    model = ref_ex.LightGCN(args, dataset)
+    g = np.load(os.path.join(GOLD, "lightgcn_epinion2.npz"))
+    bu, bi, bl = (torch.from_numpy(g[k][0]) for k in ("batch_users", "batch_items", "batch_labels"))
+    by_user = defaultdict(list)
+    for k, p in enumerate(raw_train[0]):
+        by_user[p[0]].append(k)
+    sl = []
+    for u in sorted(set(bu.numpy().tolist())):
+        sl.extend(by_user[u])
+    sl = np.asarray(sl[:192], dtype=int)              # a batch's worth of paths, longer than the driver's cap of 15
+    model.train()
+    model.zero_grad()
+    loss1, loss2 = model(bu, bi, bl, sl, train2, flag=0)
+    (loss1 + loss2).backward()
+    out = dict(slice_indices=sl, loss1=np.float32(loss1.item()), loss2=np.float32(loss2.item()), seed=args.seed)
+    rng = np.random.default_rng(11)
+    for name, p in model.named_parameters():
+        key = name.replace(".", "__")
+        if p.grad is None:
+            continue
+        gnp = p.grad.numpy()
+        if gnp.shape[0] > 1024:       # the two embedding tables
+            rows = np.sort(rng.choice(gnp.shape[0], 512, replace=False))
+            nz = np.flatnonzero(np.abs(gnp).sum(1) > 0)
+            rows = np.unique(np.concatenate([rows, nz[:256]]))
+            out["gradrows_" + key] = rows
+            out["grad_" + key] = gnp[rows].copy()
+            out["gradcolsum_" + key] = gnp.astype(np.float64).sum(0)
+            out["gradfro_" + key] = np.sqrt((gnp.astype(np.float64) ** 2).sum())
+        else:
+            out["grad_" + key] = gnp.copy()
+    # small parameters by value (the tables are pinned by the seed; their hash is enough)
+    for name, p in model.state_dict().items():
+        if p.numel() <= 64 * 256:
+            out["state_" + name.replace(".", "__")] = p.detach().numpy().copy()
+    out["user_w_sha"] = sha(model.embedding_user.weight.detach().numpy())
+    out["item_w_sha"] = sha(model.embedding_item.weight.detach().numpy())
+    model.eval()
+    with torch.no_grad():
+        scores, negs = model(None, None, None, np.arange(64), test2, flag=2)
+        out["trust_scores_at_negs"] = torch.gather(scores, 1, negs).numpy()
+        out["trust_test5"] = np.asarray(trust_test5(model, test2), np.float64)
+    np.savez_compressed(os.path.join(GOLD, "trust_epinion2.npz"), **out)
+    print("trust epinion2: loss1 %.6f loss2 %.6f test5 %s" % (loss1.item(), loss2.item(), out["trust_test5"]))
+
+
+def stage_epochs_dual_epinion2(n_steps=600):
+    """G13 at Epinion2 scale: main_auto_expert_s.py:22-91 executed with the reference's modules on the Epinion2 graph and
+    the reference-minted trust paths, for the first `n_steps` batches of epoch 0 (a full epoch is 4 906 batches; the
+    dual-task step costs ~1.5 s of reference CPU time), then Test() (:98-114: rec_test over all 3 185 test users +
+    trust_test5).  Stored: per-step path counts, both losses per step for the first 16 steps, running loss sums every
+    100 steps, the task weights, both tasks' metrics, sampled rows of the trained user table, `w`."""
+    import random
+    from collections import defaultdict
+    import numpy as np
+    import torch
+    from torch.utils.data import DataLoader
+    _dual_setup()
+    import lg_parser
+    import utility1.dataloader as ref_dl
+    import utility1.utils as ref_utils
+    import utility1.model_expert_s as ref_ex
+    from utility1.batch_test import rec_test
+    from utility2.utils import Data
+    from utility2.batch_test_gnn import trust_test5
+    args = lg_parser.parse_args_r()
+    raw_train, raw_test = _epinion2_trust_raw()
+    ref_utils.set_seed(args.seed)                                                   # main_auto_expert_s.py:22
+    device = torch.device("cpu")
+    dataset = ref_dl.Loader(args)                                                   # :34
+    train_dataset = ref_dl.LightTrainData(dataset.rec_train_data, dataset.m_item, dataset.train_mat)
+    train_loader = DataLoader(train_dataset, batch_size=256, shuffle=True)          # :36
+    user_path_indx = defaultdict(list)                                              # :42-46
+    path = raw_train[0]
+    for i, p in zip(range(len(path)), path):
+        user_path_indx[p[0]].append(i)
+    train_data2 = Data(raw_train, dataset.n_users, shuffle=False)                   # :47-48
+    test_data2 = Data(raw_test, dataset.n_users, shuffle=False, test=True)
+    trust_batch_size = len(path) // len(train_loader)                               # :49
+    Recmodel = ref_ex.LightGCN(args, dataset).to(device)                            # :51-52
+    optimizer = torch.optim.Adam(Recmodel.parameters(), lr=args.lr)
+    out = dict(n_paths=[], loss1_first=[], loss2_first=[], loss1_cum=[], loss2_cum=[])
+    train_loader.dataset.ng_sample()                                                # :56
+    Recmodel.train()
+    t1 = t2 = 0.0
+    import time
+    t0 = time.time()
+    for step, data in enumerate(train_loader):                                      # :60-87
+        if step == n_steps:
+            break
+        optimizer.zero_grad()
+        user, item, label = data
+        unique_user = set(user.numpy().tolist())
+        path_index = []
+        for u in unique_user:
+            path_index.extend(user_path_indx[u])
+        if len(path_index) > trust_batch_size * 3:
+            path_index = random.sample(path_index, trust_batch_size * 3)
+        out["n_paths"].append(len(path_index))
+        loss1, loss2 = Recmodel(users=user.to(device), items=item.to(device), labels=label.to(device),
+                                slice_indices=np.array(list(path_index), dtype=int), trust_data=train_data2, flag=0)
+        T, n_rec, T_rec = len(path_index), 5, len(user)
+        precision1 = torch.exp(-2 * Recmodel.task_weights[0])
+        precision2 = torch.exp(-2 * Recmodel.task_weights[1])
+        loss = precision1 * loss1 + precision2 * loss2 + 2 * (n_rec + 1) * T_rec * Recmodel.task_weights[0] \
+            + T * Recmodel.task_weights[1]
+        loss.backward()
+        t1 += loss1.item()
+        t2 += loss2.item()
+        if step < 16:
+            out["loss1_first"].append(loss1.item()); out["loss2_first"].append(loss2.item())
+        optimizer.step()
+        if (step + 1) % 100 == 0:
+            out["loss1_cum"].append(t1); out["loss2_cum"].append(t2)
+            print("step", step + 1, "loss1", t1, "loss2", t2, "%.0f s" % (time.time() - t0), flush=True)
+    tw = Recmodel.task_weights.detach().numpy().copy()
+    Recmodel.eval()
+    with torch.no_grad():                                                           # :98-114
+        ret = rec_test(Recmodel, dataset.testRatings, dataset.testNegatives)
+        trust = np.asarray(trust_test5(Recmodel, test_data2), np.float64)
+    uw = Recmodel.embedding_user.weight.detach().numpy()
+    iw = Recmodel.embedding_item.weight.detach().numpy()
+    rows_u = np.sort(np.random.default_rng(1).choice(uw.shape[0], 256, replace=False))
+    rows_i = np.sort(np.random.default_rng(2).choice(iw.shape[0], 256, replace=False))
+    np.savez_compressed(os.path.join(GOLD, "dual_epinion2_epochs.npz"), seed=args.seed, n_steps=n_steps,
+                        trust_batch_size=trust_batch_size, steps_per_epoch=len(train_loader),
+                        **{k: np.asarray(v, np.float64) for k, v in out.items()}, task_weights=tw,
+                        rec_recall=ret["recall"], rec_ndcg=ret["ndcg"], trust=trust,
+                        rows_u=rows_u, rows_i=rows_i, user_w=uw[rows_u], item_w=iw[rows_i],
+                        user_w_colsum=uw.astype(np.float64).sum(0), item_w_colsum=iw.astype(np.float64).sum(0),
+                        w=Recmodel.w.detach().numpy(), att_exp1=Recmodel.att_exp1.detach().numpy(),
+                        att_t=Recmodel.att_t.detach().numpy())
+    print("dual epinion2: loss1", t1, "loss2", t2, "tw", tw, "rec", ret, "trust", trust)
+
+
+# --------------------------------------------------------------------------- NGCF whole-run goldens (config 4)
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """philox4x32-10 on uint32 arrays (Salmon et al. 2011; the generator libspexhip's dropout masks use).  Returns the
+    four output words.  Harness copy of oracle/oracle.py:philox4x32_10 (the harness stays importable on its own)."""
+    import numpy as np
+    M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+    c0, c1, c2, c3 = (np.asarray(x, np.uint32).astype(np.uint64) for x in np.broadcast_arrays(c0, c1, c2, c3))
+    k0, k1 = np.uint64(k0), np.uint64(k1)
+    mask = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c0, M1 * c2
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & mask, p1 >> np.uint64(32), p1 & mask
+        c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+        k0 = (k0 + np.uint64(0x9E3779B9)) & mask
+        k1 = (k1 + np.uint64(0xBB67AE85)) & mask
+    return tuple(x.astype(np.uint32) for x in (c0, c1, c2, c3))
+
+
+def message_keep_mask(n_rows, d, p_drop, seed, step, layer):
+    """The counter-based message-dropout mask of libspexhip's NGCF kernels (include/spex_hip.h, spex_ngcf_layer_*):
+    element e = row * d + col keeps iff u_e >= p_drop, u_e = (word[e & 3] of philox4x32-10(counter = (e >> 2, step,
+    layer, 0), key = seed) >> 8) * 2^-24."""
+    import numpy as np
+    n = n_rows * d
+    assert n % 4 == 0
+    w = philox4x32_10(np.arange(n // 4, dtype=np.uint32), np.uint32(step), np.uint32(layer), np.uint32(0),
+                      seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    u = (np.stack(w, 1).reshape(-1) >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)
+    return (u >= np.float32(p_drop)).reshape(n_rows, d)
+
+
+def write_small_ngcf(rec_dir):
+    """300 users x 200 items, ~3 000 train pairs, 1 held-out item + 30 negatives per user (seed 4), in NGCF's file
+    format (load_data.py:29-31).  load_train_data only trains whole blocks of 256 users (:177,181), so the 50-user
+    `tiny` graph would train on nothing.  Returns the arrays the fixture stores."""
+    import numpy as np
+    rng = np.random.default_rng(4)
+    U, I = 300, 200
+    os.makedirs(rec_dir, exist_ok=True)
+    train, test_pos, test_neg = [], [], []
+    for u in range(U):
+        k = int(rng.integers(3, 18))
+        its = rng.permutation(I)[:k + 31]
+        train.append(np.sort(its[:k]))
+        test_pos.append(int(its[k]))
+        test_neg.append(its[k + 1:k + 31])
+    train[0] = np.unique(np.append(train[0], I - 1))          # the largest item id occurs in the train file
+    if test_pos[0] == I - 1 or (I - 1) in test_neg[0]:
+        train[0] = train[0][train[0] != I - 1]; train[1] = np.unique(np.append(train[1], I - 1))
+    with open(os.path.join(rec_dir, "train.txt"), "w") as f:
+        for u in range(U):
+            f.write(str(u) + "".join(f" {int(i)}" for i in train[u]) + "\n")
+    with open(os.path.join(rec_dir, "test.txt"), "w") as f:
+        for u in range(U):
+            f.write(f"{u} {test_pos[u]}\n")
+    with open(os.path.join(rec_dir, "negative.txt"), "w") as f:
+        for u in range(U):
+            f.write(str(u) + "".join(f" {int(i)}" for i in test_neg[u]) + "\n")
+    pairs = np.asarray([(u, int(i)) for u in range(U) for i in train[u]], np.int64)
+    return dict(train_pairs=pairs, test_pos=np.asarray(test_pos, np.int64), test_neg=np.stack(test_neg).astype(np.int64))
+
+
+def stage_ngcf_epochs(ds, n_epochs):
+    """G12-NGCF: the reference's training run — NGCF_SPEX/code/main_rec.py:18-27,116-148 (setup_seed, the module-level
+    Data singleton of utility/batch_test.py, Model_Wrapper, Adam, train(): load_train_data per epoch, shuffled
+    DataLoader, loss.backward, step; test()) — driven from the reference's modules on CPU.
+    Two harness-side substitutions, both so that the run is a function of the seeds:
+      * load_data's multiprocessing.Pool -> a serial map (the pool's workers all fork from the same `random` state and
+        take chunks in timing order, so the reference's negatives are not reproducible; a serial map draws the same
+        per-user samples from one stream);
+      * each nn.Dropout(p) of the model -> the same arithmetic (x * (keep / (1 - p))) with the keep mask taken from a
+        counter-based generator (message_keep_mask: seed, step, layer) instead of torch's global RNG.
+    Also stored: the sampler's first epoch (G6-NGCF), the three adjacency matrices' hashes (G10+), test() after every
+    epoch, the learned weights."""
+    import random
+    import numpy as np
+    import torch
+    install_shims()
+    torch.set_num_threads(8)
+    code = os.path.join(SCRATCH, "NGCF_SPEX", "code")
+    os.makedirs(code, exist_ok=True)
+    os.chdir(code)
+    data_root = os.path.join(SCRATCH, "NGCF_SPEX", "data") + "/"
+    small = write_small_ngcf(os.path.join(data_root, "small", "rec")) if ds == "small" else {}
+    for c in ("s_adj_mat.npz", "s_norm_adj_mat.npz", "s_mean_adj_mat.npz"):
+        pth = os.path.join(data_root, ds, "rec", c)
+        if os.path.exists(pth):
+            os.remove(pth)
+    sys.path.insert(0, os.path.join(REF, "NGCF_SPEX", "code"))
+    sys.argv = ["main_rec.py", "--data_path", data_root, "--dataset", ds]
+    import utility.load_data as ref_ld
+
+    class SerialPool:
+        def __init__(self, *a, **k):
+            pass
+
+        def map(self, fn, it):
+            return [fn(x) for x in it]
+
+        def close(self):
+            pass
+    real_pool = ref_ld.multiprocessing.Pool
+    import utility.batch_test as ref_bt                        # builds data_generator from sys.argv (batch_test.py:9-16)
+    data_generator, margs = ref_bt.data_generator, ref_bt.args
+    src = open(os.path.join(REF, "NGCF_SPEX", "code", "main_rec.py")).read()
+    import torch.nn as nn
+    import torch.nn.functional as F
+    ns = {"nn": nn, "torch": torch, "F": F, "np": np, "args": margs, "trans_to_cuda": lambda v: v}
+    exec(compile(src[src.index("class Model_Wrapper"):src.index("def train(model, optimizer)")], "<ref Model_Wrapper>", "exec"), ns)
+    Model_Wrapper = ns["Model_Wrapper"]
+
+    def setup_seed(seed):                                       # main_rec.py:18-27
+        torch.manual_seed(seed)
+        random.seed(seed)
+        np.random.seed(seed)
+    setup_seed(2020)
+    out = {"n_users": data_generator.n_users, "n_items": data_generator.n_items, "n_train": data_generator.n_train}
+    plain, norm, mean = data_generator.get_adj_mat()            # main_rec.py:160
+    for name, m in (("plain", plain), ("norm", norm), ("mean", mean)):
+        m = m.tocsr(); m.sort_indices()
+        out[f"{name}_sha"] = np.asarray([sha(m.indptr.astype(np.int32)), sha(m.indices.astype(np.int32)),
+                                         sha(m.data.astype(np.float32))])
+    device = torch.device("cpu")
+    model = Model_Wrapper(data_config={"n_users": data_generator.n_users, "n_items": data_generator.n_items,
+                                       "norm_adj": norm}, device=device).to(device)
+    out.update({"init_" + k.replace(".", "__"): v.detach().numpy().copy() for k, v in model.state_dict().items()
+                if v.numel() <= 64 * 64})
+    out["init_user_sha"] = sha(model.user_embedding.weight.detach().numpy())
+    out["init_item_sha"] = sha(model.item_embedding.weight.detach().numpy())
+    optimizer = torch.optim.Adam(model.parameters(), lr=margs.lr)
+    N = data_generator.n_users + data_generator.n_items
+    p_drop = eval(margs.mess_dropout)
+    DROP_SEED = 2020
+    state = {"step": 0}
+
+    class InjectedDropout(nn.Module):
+        def __init__(self, p, layer):
+            super().__init__()
+            self.p, self.layer = p, layer
+
+        def forward(self, x):
+            if not self.training or self.p == 0.0:
+                return x
+            keep = message_keep_mask(x.shape[0], x.shape[1], self.p, DROP_SEED, state["step"], self.layer)
+            noise = torch.from_numpy(keep.astype(np.float32))
+            noise.div_(1 - self.p)                               # what at::dropout does to its Bernoulli noise
+            return x * noise
+    for i in range(len(model.dropout_list)):
+        model.dropout_list[i] = InjectedDropout(p_drop[i], i)
+
+    losses, recalls, ndcgs, first_batch, step_losses = [], [], [], None, []
+    import time
+    t0 = time.time()
+    for epoch in range(n_epochs):
+        ref_ld.multiprocessing.Pool = SerialPool
+        data_loader = data_generator.load_train_data()           # main_rec.py:121
+        ref_ld.multiprocessing.Pool = real_pool
+        if epoch == 0:
+            u, v, r = data_loader.dataset.tensors
+            out.update(sample_sha=np.asarray([sha(u.numpy()), sha(v.numpy()), sha(r.numpy())]), sample_len=len(u),
+                       sample_head=np.stack([u[:4096].numpy(), v[:4096].numpy(), r[:4096].numpy().astype(np.int64)]))
+        total_loss = 0.0
+        for data in data_loader:                                 # :122-129
+            model.train()
+            optimizer.zero_grad()
+            user, item, labels_list = data
+            if first_batch is None:
+                first_batch = np.stack([user.numpy(), item.numpy(), labels_list.numpy().astype(np.int64)])
+            loss = model(user=user, item=item, labels_list=labels_list, flag=0)
+            loss.backward(retain_graph=True)
+            optimizer.step()
+            total_loss += loss.item()
+            if state["step"] < 32:
+                step_losses.append(loss.item())
+            state["step"] += 1
+            if state["step"] % 500 == 0:
+                print("step", state["step"], "loss sum", total_loss, "%.0f s" % (time.time() - t0), flush=True)
+        losses.append(total_loss)
+        model.eval()
+        ret = ref_bt.test(model, list(data_generator.test_set.keys()), drop_flag=True)   # :134-135
+        recalls.append(ret["recall"]); ndcgs.append(ret["ndcg"])
+        print("epoch", epoch, "loss", total_loss, ret, flush=True)
+    uw, iw = model.user_embedding.weight.detach().numpy(), model.item_embedding.weight.detach().numpy()
+    if ds != "small":
+        rows_u = np.sort(np.random.default_rng(1).choice(uw.shape[0], 256, replace=False))
+        rows_i = np.sort(np.random.default_rng(2).choice(iw.shape[0], 256, replace=False))
+        out.update(rows_u=rows_u, rows_i=rows_i, user_w_colsum=uw.astype(np.float64).sum(0),
+                   item_w_colsum=iw.astype(np.float64).sum(0))
+        uw, iw = uw[rows_u], iw[rows_i]
+    out.update(small)
+    out.update({"final_" + k.replace(".", "__"): v.detach().numpy().copy() for k, v in model.state_dict().items()
+                if v.numel() <= 64 * 64})
+    np.savez_compressed(os.path.join(GOLD, f"ngcf_{ds}_epochs.npz"), seed=2020, drop_seed=DROP_SEED, lr=margs.lr,
+                        mess_dropout=np.asarray(p_drop), n_steps=state["step"],
+                        losses=np.asarray(losses, np.float64), step_losses=np.asarray(step_losses, np.float64),
+                        recall=np.asarray(recalls, np.float64), ndcg=np.asarray(ndcgs, np.float64),
+                        first_batch=first_batch, user_w=uw, item_w=iw, **out)
+    print("ngcf epochs", ds, "losses", losses, "recall", recalls[-1], "ndcg", ndcgs[-1])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--stage", default="all")
@@ -737,6 +1174,8 @@ def main():
             subprocess.run(cmd, check=True, env=env)
     elif a.stage == "mint":
         stage_mint()
+    elif a.stage == "paths":
+        stage_paths()
     elif a.stage == "lightgcn":
         stage_lightgcn(a.skip_epinion_test)
     elif a.stage == "ngcf":
@@ -747,6 +1186,14 @@ def main():
         stage_epochs()
     elif a.stage == "epochs-dual":
         stage_epochs_dual()
+    elif a.stage == "ngcf-epochs":
+        stage_ngcf_epochs("small", 3)
+    elif a.stage == "ngcf-epochs-epinion2":  # ~15 min of CPU: one full NGCF epoch (4.7 k steps) + test() through the reference
+        stage_ngcf_epochs("epinion2", 1)
+    elif a.stage == "trust-epinion2":
+        stage_trust_epinion2()
+    elif a.stage == "epochs-dual-epinion2":  # ~20 min of CPU: 600 dual-task steps + both evaluations through the reference
+        stage_epochs_dual_epinion2()
     elif a.stage == "epochs-epinion2":      # ~25 min of CPU: one full Epinion2 epoch + test() through the reference
         stage_epochs("epinion2", 1)
 

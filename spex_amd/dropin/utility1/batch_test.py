@@ -68,40 +68,7 @@ def _test_all(model, testRatings, testNegatives, dual):
     flat_users = np.repeat(np.asarray(users, np.int64), lens)
     with torch.no_grad():
         scores = _call_model(model, flat_users, flat_items, dual).cpu().numpy().astype(np.float64)
-    kmax = max(Ks)
-    uniform = lens.min() == lens.max()
-    start = np.concatenate([[0], np.cumsum(lens)])
-    rel = np.zeros((n_test_users, kmax))
-    n_pos = np.zeros(n_test_users)
-    fast = np.zeros(n_test_users, bool)
-    if uniform:
-        L = int(lens[0])
-        it = flat_items.reshape(n_test_users, L)
-        sc = scores.reshape(n_test_users, L)
-        # the vectorised path needs distinct candidates per user (dict semantics are then the identity)
-        srt = np.sort(it, axis=1)
-        fast = ~(srt[:, 1:] == srt[:, :-1]).any(1) if L > 1 else np.ones(n_test_users, bool)
-        order = np.argsort(-sc, axis=1, kind="stable")[:, :kmax]
-        top_items = np.take_along_axis(it, order, 1)
-        npos_each = np.array([len(testRatings[u]) for u in users])
-        single = npos_each == 1
-        fast &= single
-        pos_item = np.array([testRatings[u][0] for u in users])
-        k_eff = top_items.shape[1]
-        rel[:, :k_eff] = (top_items == pos_item[:, None])
-        n_pos[:] = 1
-    rec_f, ndcg_f = metrics.rank_metrics_batch(rel, Ks, n_pos)
-    for j, u in enumerate(users):  # same accumulation order as batch_test.py:19-24
-        if fast[j]:
-            re = {"recall": rec_f[j], "ndcg": ndcg_f[j]}
-        else:
-            rating = {}
-            for it_, p in zip(cand[j], scores[start[j]:start[j + 1]].tolist()):
-                rating[it_] = p
-            re = get_performance(testRatings[u], ranklist_by_heapq(testRatings[u], rating))
-        result["recall"] += re["recall"] / n_test_users
-        result["ndcg"] += re["ndcg"] / n_test_users
-    return result
+    return metrics.accumulate_rank_metrics(cand, scores, [testRatings[u] for u in users], Ks)
 
 
 def test(model, testRatings, testNegatives):

@@ -14,47 +14,71 @@ from . import _lib
 
 
 # ------------------------------------------------------------------------------------------------ host CSR builders
-def bipartite_csr(users, items, n_u, n_i, self_loops=False):
+def bipartite_csr(users, items, n_u, n_i, self_loops=False, counts=False):
     """CSR structure of [[0, R], [R^T, 0]] (+ I): rows ascending, columns ascending within a row (= coalesced COO
-    order, dataloader.py:222).  Repeated (u, i) pairs collapse to one entry, as in the reference's dok assignment
-    (dataloader.py:98-100,110)."""
-    key = np.unique(np.asarray(users, np.int64) * np.int64(n_i) + np.asarray(items, np.int64))
+    order, dataloader.py:222).  A repeated (u, i) pair is one stored entry; with counts=True its multiplicity is
+    returned as a fourth array (the reference's LightGCN matrix SUMS repeated pairs: UserItemNet is built by
+    csr_matrix((ones, (u, i))), dataloader.py:110 — NGCF's R is a dok assignment, load_data.py:92, and does not)."""
+    key, mult = np.unique(np.asarray(users, np.int64) * np.int64(n_i) + np.asarray(items, np.int64), return_counts=True)
     uu, ii = key // n_i, key % n_i
     n = n_u + n_i
     rows = np.concatenate([uu, ii + n_u])
     cols = np.concatenate([ii + n_u, uu])
+    mult = np.concatenate([mult, mult])
     if self_loops:
         eye = np.arange(n, dtype=np.int64)
-        rows, cols = np.concatenate([rows, eye]), np.concatenate([cols, eye])
+        rows, cols, mult = np.concatenate([rows, eye]), np.concatenate([cols, eye]), np.concatenate([mult, np.ones(n, mult.dtype)])
     order = np.argsort(rows * np.int64(n) + cols, kind="stable")
-    rows, cols = rows[order], cols[order]
+    rows, cols, mult = rows[order], cols[order], mult[order]
     rowptr = np.zeros(n + 1, np.int64)
     np.cumsum(np.bincount(rows, minlength=n), out=rowptr[1:])
-    return rowptr.astype(np.int32), rows.astype(np.int32), cols.astype(np.int32)
+    out = (rowptr.astype(np.int32), rows.astype(np.int32), cols.astype(np.int32))
+    return out + (mult,) if counts else out
 
 
 def lightgcn_norm_adj(users, items, n_user, m_item):
     """A_hat = D^-1/2 [[0,R],[R^T,0]] D^-1/2 over (n_user + 1 pad row) + m_item nodes; fp32; zero-degree rows stay
-    empty; no self loops.  Mirrors dataloader.py:197-212: val = (d_r^-1/2 * a_rc) * d_c^-1/2 rounded after each
-    product."""
-    rowptr, rows, cols = bipartite_csr(users, items, n_user + 1, m_item)
-    deg = np.diff(rowptr).astype(np.float32)
+    empty; no self loops.  Mirrors dataloader.py:110,197-212: a_rc = number of times the pair occurs in the train file,
+    degree = row sum of those counts, val = (d_r^-1/2 * a_rc) * d_c^-1/2 rounded after each product."""
+    rowptr, rows, cols, mult = bipartite_csr(users, items, n_user + 1, m_item, counts=True)
+    a = mult.astype(np.float32)
+    deg = np.bincount(rows, weights=mult, minlength=len(rowptr) - 1).astype(np.float32)
     with np.errstate(divide="ignore"):
         d_inv = np.power(deg, -0.5).astype(np.float32)
     d_inv[np.isinf(d_inv)] = 0.0
-    val = ((d_inv[rows] * np.float32(1.0)) * d_inv[cols]).astype(np.float32)
+    val = ((d_inv[rows] * a) * d_inv[cols]).astype(np.float32)
     return rowptr, cols, val
 
 
 def ngcf_norm_adj(users, items, n_users, n_items):
     """norm_adj = D^-1 (A + I) (NGCF_SPEX/code/utility/load_data.py:135-144,162), computed in float64 as the
     reference does (sp.eye is float64) and cast to fp32 where the model converts it (NGCF main_rec.py:104)."""
-    rowptr, rows, cols = bipartite_csr(users, items, n_users, n_items, self_loops=True)
-    deg = np.diff(rowptr).astype(np.float64)
-    with np.errstate(divide="ignore"):
-        d_inv = np.power(deg, -1.0)
-    d_inv[np.isinf(d_inv)] = 0.0
-    return rowptr, cols, d_inv[rows].astype(np.float32)
+    return ngcf_adjacency(users, items, n_users, n_items, "norm")
+
+
+def ngcf_adjacency(users, items, n_users, n_items, kind="norm"):
+    """The three matrices of Data.create_adj_mat (load_data.py:122-166) as CSR over n_users + n_items nodes:
+      plain  A = [[0, R], [R^T, 0]], fp32 ones (:124-130,166);
+      norm   D^-1 (A + I): row sums and reciprocals in float64 (sp.eye makes the sum float64, :162), stored fp32;
+      mean   D^-1 A: everything in float32 (:163), zero-degree rows empty."""
+    if kind == "plain":
+        rowptr, rows, cols = bipartite_csr(users, items, n_users, n_items)
+        return rowptr, cols, np.ones(len(cols), np.float32)
+    if kind == "norm":
+        rowptr, rows, cols = bipartite_csr(users, items, n_users, n_items, self_loops=True)
+        deg = np.diff(rowptr).astype(np.float64)
+        with np.errstate(divide="ignore"):
+            d_inv = np.power(deg, -1.0)
+        d_inv[np.isinf(d_inv)] = 0.0
+        return rowptr, cols, d_inv[rows].astype(np.float32)
+    if kind == "mean":
+        rowptr, rows, cols = bipartite_csr(users, items, n_users, n_items)
+        deg = np.diff(rowptr).astype(np.float32)
+        with np.errstate(divide="ignore"):
+            d_inv = np.power(deg, np.float32(-1.0)).astype(np.float32)
+        d_inv[np.isinf(d_inv)] = 0.0
+        return rowptr, cols, d_inv[rows]
+    raise ValueError("kind must be plain, norm or mean")
 
 
 def csr_transpose(rowptr, col, val, n_cols):
