@@ -177,16 +177,41 @@ int spex_scatter_add_owned_rows_f32(float *upd, const int64_t *pos, int64_t K, i
 int spex_adam_step_f32(float *p, const float *g, float *m, float *v, int64_t n, int32_t t, float lr, float beta1,
                        float beta2, float eps, float *zero_buf, void *stream);
 
-/* ------------------------------------------------------------------------------------------------ NGCF epilogue
- * Replaces NGCF_SPEX/code/main_rec.py:77-83 for one layer (inference / dropout off):
- *   s    = LeakyReLU(side W_gc^T + b_gc);  b = LeakyReLU((ego * side) W_bi^T + b_bi);  e1 = s + b
- *   out[r, 0:d] = ego[r,:];  out[r, d:2d] = e1 / max(||e1||_2, 1e-12)
- * side = A ego comes from spex_spmm_f32.  W_*: [d,d] row-major as nn.Linear stores them (out x in); d == 64.
- * e1_out (optional, [n,d]) receives the un-normalised e1 (needed by the backward / a second layer).
+/* ------------------------------------------------------------------------------------------------ NGCF layer
+ * Replaces NGCF_SPEX/code/main_rec.py:77-83 for one layer, given side = A ego from spex_spmm_f32 (:76):
+ *   s    = LeakyReLU(side W_gc^T + b_gc);  b = LeakyReLU((ego * side) W_bi^T + b_bi);  e1 = dropout_p(s + b)
+ *   out[r, 0:d] = ego[r,:] (iff write_ego);  out[r, d:2d] = e1 / max(||e1||_2, 1e-12)
+ * W_*: [d,d] row-major as nn.Linear stores them (out x in); d == 64.  `out` has row stride ld_out >= 2d: layer l of a
+ * deeper model passes out + l*d with write_ego = 0 and lands in its slice of the concatenated table (:85).
+ * e1_out (optional, [n,d]) receives e1 after dropout — the next layer's input (:80-81).
+ * Message dropout (:81, nn.Dropout(p_drop), training only; p_drop = 0 switches it off) is counter-based so that the
+ * backward call reproduces the mask from (seed, step, layer) without storing it: element e = row*64 + col keeps iff
+ * u_e >= p_drop, u_e = (word[e & 3] of philox4x32-10(counter = (e >> 2, step, layer, 0), key = seed) >> 8) * 2^-24; kept
+ * values are multiplied by 1/(1 - p_drop).  pad_row >= 0: rows above it count one less when numbering elements (a table
+ * that keeps the reference's unused pad user row, main_rec.py:67, as an isolated node; -1 = none).
  */
+int spex_ngcf_layer_fwd_f32(const float *ego, const float *side, const float *W_gc, const float *b_gc, const float *W_bi,
+                            const float *b_bi, float *out, int32_t ld_out, int32_t write_ego, float *e1_out, int32_t n,
+                            int32_t d, float slope, float p_drop, uint64_t seed, uint32_t step, uint32_t layer,
+                            int32_t pad_row, void *stream);
+/* The same layer in inference form (dropout off, ego written): kept for ABI-1 callers. */
 int spex_ngcf_layer_f32(const float *ego, const float *side, const float *W_gc, const float *b_gc, const float *W_bi,
                         const float *b_bi, float *out, int32_t ld_out, float *e1_out, int32_t n, int32_t d,
                         float slope, void *stream);
+/* Autograd backward of the layer (loss.backward(), main_rec.py:127).  The layer is recomputed from (ego, side), nothing
+ * else of the forward is kept.  Upstream: g_norm = d loss / d out[:, d:2d] (row stride ld_g), g_next = d loss / d e1
+ * ([n,d], from the next layer's call; NULL for the last layer), g_direct = d loss / d out[:, 0:d] (row stride
+ * ld_direct; layer 0 only, else NULL).  Writes, for every row,
+ *   g_side = d loss / d side   and   g_ego = the part of d loss / d ego that does not pass through side (+ g_direct);
+ * the caller completes d loss / d ego = g_ego + A^T g_side with spex_spmm_f32(A^T, g_side, add_in = g_ego).
+ * gW_gc, gb_gc, gW_bi, gb_bi ([d,d], [d]) are ACCUMULATED with atomics: zero them first.
+ * Rows whose upstream gradients are all zero (after a 256-sample batch: most) cost a read and two zero rows.
+ */
+int spex_ngcf_layer_bwd_f32(const float *ego, const float *side, const float *W_gc, const float *b_gc, const float *W_bi,
+                            const float *b_bi, const float *g_norm, int32_t ld_g, const float *g_next,
+                            const float *g_direct, int32_t ld_direct, int32_t n, int32_t d, float slope, float p_drop,
+                            uint64_t seed, uint32_t step, uint32_t layer, int32_t pad_row, float *g_side, float *g_ego,
+                            float *gW_gc, float *gb_gc, float *gW_bi, float *gb_bi, void *stream);
 
 /* Replaces the two-expert gate of the dual-task model, utility1/model_expert_s.py:156-161:
  *   att = softmax([raw | prop] att_exp, dim=1) ([n,2d] x [2d,2]);  mixed = raw * att[:,0] + prop * att[:,1]

@@ -307,6 +307,47 @@ def ngcf_forward(rowptr, col, val, user_w, item_w, W_gc, b_gc, W_bi, b_bi):
     return np.concatenate([ego, e1 / np.maximum(nrm, np.float32(1e-12))], 1)
 
 
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """philox4x32-10 on uint32 arrays (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11): the
+    counter-based generator behind libspexhip's dropout masks.  Returns the four output words."""
+    M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+    c0, c1, c2, c3 = (np.asarray(x, np.uint32).astype(np.uint64) for x in np.broadcast_arrays(c0, c1, c2, c3))
+    k0, k1 = np.uint64(k0), np.uint64(k1)
+    mask = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c0, M1 * c2
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & mask, p1 >> np.uint64(32), p1 & mask
+        c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+        k0 = (k0 + np.uint64(0x9E3779B9)) & mask
+        k1 = (k1 + np.uint64(0xBB67AE85)) & mask
+    return tuple(x.astype(np.uint32) for x in (c0, c1, c2, c3))
+
+
+def message_keep_mask(n_rows, d, p_drop, seed, step, layer):
+    """The message-dropout mask of spex_ngcf_layer_fwd_f32 / _bwd_f32 (include/spex_hip.h): element e = row * d + col
+    keeps iff u_e >= p_drop, u_e = (word[e & 3] of philox4x32-10(counter = (e >> 2, step, layer, 0), key = seed) >> 8)
+    * 2^-24.  It stands where the reference draws nn.Dropout's Bernoulli noise (NGCF_SPEX/code/main_rec.py:81)."""
+    n = n_rows * d
+    assert n % 4 == 0
+    w = philox4x32_10(np.arange(n // 4, dtype=np.uint32), np.uint32(step), np.uint32(layer), np.uint32(0),
+                      seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    u = (np.stack(w, 1).reshape(-1) >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)
+    return (u >= np.float32(p_drop)).reshape(n_rows, d)
+
+
+def ngcf_layer_torch(ego, side, W_gc, b_gc, W_bi, b_bi, keep=None, p_drop=0.0):
+    """One NGCF layer on torch tensors (any dtype), NGCF_SPEX/code/main_rec.py:77-83, with the dropout noise injected:
+    returns (normalised output, e1 after dropout).  Used with autograd as the checker of the fused backward kernel."""
+    import torch
+    import torch.nn.functional as F
+    e1 = F.leaky_relu(F.linear(side, W_gc, b_gc)) + F.leaky_relu(F.linear(ego * side, W_bi, b_bi))
+    if keep is not None:
+        noise = keep.to(e1.dtype)
+        noise = noise / (1 - p_drop)                 # at::dropout: noise.div_(1 - p), then input * noise
+        e1 = e1 * noise
+    return F.normalize(e1, p=2, dim=1), e1
+
+
 def expert_gate(raw, prop, att):
     """model_expert_s.py:156-161: att = softmax([raw | prop] @ att_exp, dim=1); raw*att0 + prop*att1."""
     z = np.concatenate([raw, prop], 1).astype(np.float32) @ att.astype(np.float32)

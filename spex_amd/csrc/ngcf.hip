@@ -38,10 +38,40 @@ __device__ __forceinline__ float bcast(float v, int src)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kLdsStride = 66;
 
+// Message dropout (NGCF_SPEX/code/main_rec.py:81, nn.Dropout(p) on sum + bi): counter-based, so the forward kernel and
+// the backward kernel (which recomputes the layer) see the same mask without storing it.  Element e = row * 64 + col of
+// the layer's [N, 64] output keeps iff u_e >= p with u_e = (word[e & 3] of philox4x32-10(counter = (e >> 2, step,
+// layer, 0), key = seed) >> 8) * 2^-24; kept values are multiplied by 1 / (1 - p) (at::dropout: x * (mask / (1 - p))).
+// `pad_row`: rows above it count one less (the model keeps the reference's unused pad user row, main_rec.py:67, as an
+// isolated node inside the table; the mask is indexed in the reference's row numbering, which skips it).
+struct MsgDrop {
+    float p, scale;
+    uint32_t k0, k1, step, layer;
+    int pad_row;
+};
+
+__device__ __forceinline__ bool msg_keep(const MsgDrop &dr, int row, int col)
+{
+    const uint32_t e = (uint32_t)(row - (row > dr.pad_row ? 1 : 0)) * 64u + (uint32_t)col;
+    uint32_t c0 = e >> 2, c1 = dr.step, c2 = dr.layer, c3 = 0u, k0 = dr.k0, k1 = dr.k1;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    const uint32_t sel = e & 3u;
+    const uint32_t w = sel == 0u ? c0 : (sel == 1u ? c1 : (sel == 2u ? c2 : c3));
+    return (float)(w >> 8) * 5.9604644775390625e-8f >= dr.p;
+}
+
 __global__ __launch_bounds__(kWave *kWavesPerBlock) void ngcf_layer_kernel(
     const float *__restrict__ ego, const float *__restrict__ side, const float *__restrict__ W_gc,
     const float *__restrict__ b_gc, const float *__restrict__ W_bi, const float *__restrict__ b_bi,
-    float *__restrict__ out, int ld_out, float *__restrict__ e1_out, int n, float slope)
+    float *__restrict__ out, int ld_out, int write_ego, float *__restrict__ e1_out, int n, float slope, const MsgDrop drop)
 {
     __shared__ float s_w[2][64 * kLdsStride];                       // W_gc, W_bi as [out j][in k]
     __shared__ float s_t[kWavesPerBlock][2][16 * kLdsStride];       // per wave: side tile, (ego*side) tile
@@ -88,7 +118,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void ngcf_layer_kernel(
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int r = r0 + i;
-            if (r < n) out[(size_t)r * ld_out + lane] = e_reg[i];
+            if (write_ego && r < n) out[(size_t)r * ld_out + lane] = e_reg[i];
             t_side[i * kLdsStride + lane] = s_reg[i];
             t_prod[i * kLdsStride + lane] = e_reg[i] * s_reg[i];
         }
@@ -122,7 +152,9 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void ngcf_layer_kernel(
                 float x = acc_g[b][q] + bias_g[b], y = acc_b[b][q] + bias_b[b];
                 x = x >= 0.0f ? x : x * slope;
                 y = y >= 0.0f ? y : y * slope;
-                e1[b][q] = x + y;
+                float v = x + y;
+                if (drop.p > 0.0f) v = msg_keep(drop, r0 + 4 * h + q, 16 * b + i16) ? v * drop.scale : 0.0f;
+                e1[b][q] = v;
             }
         }
         // row sums of squares in column order (0..63), as the scalar kernel's butterfly produced them up to rounding:
@@ -148,6 +180,260 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void ngcf_layer_kernel(
                 }
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward of one NGCF layer (autograd of NGCF_SPEX/code/main_rec.py:77-83 given side = A ego from the SpMM).
+// Per row, with s = side W_gc^T + b_gc, t = (ego * side) W_bi^T + b_bi, e1 = LReLU(s) + LReLU(t), e1d = dropout(e1),
+// out = e1d / max(|e1d|, 1e-12) and upstream gradients g_norm (w.r.t. out) and g_next (w.r.t. e1d, from the next layer):
+//   g_e1d = (g_norm - out <g_norm, out>) / |e1d| + g_next;   g_e1 = g_e1d * keep / (1 - p)
+//   G_s = g_e1 * LReLU'(s);  G_t = g_e1 * LReLU'(t)
+//   dW_gc += G_s^T side;  db_gc += sum G_s;  dW_bi += G_t^T (ego * side);  db_bi += sum G_t
+//   g_side = G_s W_gc + (G_t W_bi) * ego;      g_ego = (G_t W_bi) * side (+ g_direct)      [then g_ego += A^T g_side: SpMM]
+// Nothing of the forward is stored besides `side`: the layer is recomputed per 16-row tile on the matrix cores (two
+// [16,64]x[64,64] products), the two input-gradient products are two more, and the weight gradients are a fifth and
+// sixth MFMA product whose contraction runs over the tile's ROWS: with the rows taken in the order 4h + s (lane group
+// h, step s) the A operand is G in the accumulator layout it already has and the B operand is the side / product tile
+// read from LDS in that same layout — no transposes.  One wave per tile, 8 waves per workgroup; tiles whose upstream
+// gradient is all zero (after a 256-sample batch: most rows) write zeros and skip the arithmetic.  Weight gradients
+// are summed per workgroup in LDS (ds_add_f32, row stride 68: 2-way bank conflicts, the minimum for 64 lanes) and
+// leave with one atomic per address and active workgroup.
+constexpr int kBwdWaves = 8;
+constexpr int kDwStride = 68;
+
+__global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
+    const float *__restrict__ ego, const float *__restrict__ side, const float *__restrict__ W_gc,
+    const float *__restrict__ b_gc, const float *__restrict__ W_bi, const float *__restrict__ b_bi,
+    const float *__restrict__ g_norm, int ld_g, const float *__restrict__ g_next, const float *__restrict__ g_direct,
+    int ld_direct, int n, float slope, const MsgDrop drop, float *__restrict__ g_side, float *__restrict__ g_ego,
+    float *gW_gc, float *gb_gc, float *gW_bi, float *gb_bi)
+{
+    __shared__ float s_w[2][64 * kLdsStride];                   // W_gc, W_bi as [out o][in k]
+    __shared__ float s_dw[2][64 * kDwStride];                   // this workgroup's share of dW_gc, dW_bi
+    __shared__ float s_db[2][64];
+    __shared__ float s_t[kBwdWaves][2][16 * kLdsStride];        // per wave: side tile / G_s, product tile / G_t
+    __shared__ int s_active;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int n_tiles = (n + 15) >> 4;
+    for (int i = threadIdx.x; i < 64 * 16; i += blockDim.x) {
+        const int r = i >> 4, c4 = (i & 15) * 4;
+        const float4 a = *reinterpret_cast<const float4 *>(W_gc + r * 64 + c4);
+        const float4 b = *reinterpret_cast<const float4 *>(W_bi + r * 64 + c4);
+        float *pa = &s_w[0][r * kLdsStride + c4], *pb = &s_w[1][r * kLdsStride + c4];
+        pa[0] = a.x; pa[1] = a.y; pa[2] = a.z; pa[3] = a.w;
+        pb[0] = b.x; pb[1] = b.y; pb[2] = b.z; pb[3] = b.w;
+    }
+    for (int i = threadIdx.x; i < 64 * kDwStride; i += blockDim.x) s_dw[0][i] = s_dw[1][i] = 0.0f;
+    if (threadIdx.x < 64) s_db[0][threadIdx.x] = s_db[1][threadIdx.x] = 0.0f;
+    if (threadIdx.x == 0) s_active = 0;
+    __syncthreads();
+    const int i16 = lane & 15, h = lane >> 4;
+    float bias_g[4], bias_b[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        bias_g[b] = b_gc[16 * b + i16];
+        bias_b[b] = b_bi[16 * b + i16];
+    }
+    float *t_side = s_t[wave][0], *t_prod = s_t[wave][1];
+    bool did_work = false;
+    for (int tile = blockIdx.x * kBwdWaves + wave; tile < n_tiles; tile += gridDim.x * kBwdWaves) {
+        const int r0 = tile << 4;
+        // upstream gradients in the accumulator layout: element (row 4h + q, column 16b + i16)
+        float gn[4][4], gx[4][4];
+        bool any = false;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = r0 + 4 * h + q;
+                gn[b][q] = gx[b][q] = 0.0f;
+                if (r < n) {
+                    gn[b][q] = g_norm[(size_t)r * ld_g + 16 * b + i16];
+                    if (g_next) gx[b][q] = g_next[(size_t)r * 64 + 16 * b + i16];
+                }
+                any |= (gn[b][q] != 0.0f) | (gx[b][q] != 0.0f);
+            }
+        }
+        if (!__any(any)) {                                       // no gradient reaches this tile
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int r = r0 + i;
+                if (r < n) {
+                    g_side[(size_t)r * 64 + lane] = 0.0f;
+                    g_ego[(size_t)r * 64 + lane] = g_direct ? g_direct[(size_t)r * ld_direct + lane] : 0.0f;
+                }
+            }
+            continue;
+        }
+        did_work = true;
+        // stage the tile (lane == column) for the recomputation
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = r0 + i;
+            float e = 0.0f, sd = 0.0f;
+            if (r < n) {
+                e = ego[(size_t)r * 64 + lane];
+                sd = side[(size_t)r * 64 + lane];
+            }
+            t_side[i * kLdsStride + lane] = sd;
+            t_prod[i * kLdsStride + lane] = e * sd;
+        }
+        f32x4 acc_g[4], acc_b[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            acc_g[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc_b[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {
+            const int k = 4 * s + h;
+            const float a_g = t_side[i16 * kLdsStride + k];
+            const float a_b = t_prod[i16 * kLdsStride + k];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float w_g = s_w[0][(16 * b + i16) * kLdsStride + k];
+                const float w_b = s_w[1][(16 * b + i16) * kLdsStride + k];
+                acc_g[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_g, w_g, acc_g[b], 0, 0, 0);
+                acc_b[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_b, w_b, acc_b[b], 0, 0, 0);
+            }
+        }
+        // elementwise chain in the accumulator layout
+        float e1d[4][4], kscale[4][4], sq[4], dot[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v = 0.0f;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float x = acc_g[b][q] + bias_g[b], y = acc_b[b][q] + bias_b[b];
+                float e = (x >= 0.0f ? x : x * slope) + (y >= 0.0f ? y : y * slope);
+                float ks = 1.0f;
+                if (drop.p > 0.0f) ks = msg_keep(drop, r0 + 4 * h + q, 16 * b + i16) ? drop.scale : 0.0f;
+                if (drop.p > 0.0f) e = ks != 0.0f ? e * ks : 0.0f;
+                kscale[b][q] = ks;
+                e1d[b][q] = e;
+                v = fmaf(e, e, v);
+            }
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
+            sq[q] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float nrm = sqrtf(sq[q]);
+            const float den = fmaxf(nrm, 1e-12f);
+            float v = 0.0f;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) v = fmaf(gn[b][q], e1d[b][q] / den, v);
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
+            dot[q] = (nrm >= 1e-12f) ? v : 0.0f;                // below eps the clamp holds the denominator constant
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float o = e1d[b][q] / den;
+                const float ge1d = (gn[b][q] - o * dot[q]) / den + gx[b][q];
+                const float ge1 = ge1d * kscale[b][q];
+                const float x = acc_g[b][q] + bias_g[b], y = acc_b[b][q] + bias_b[b];
+                acc_g[b][q] = ge1 * (x > 0.0f ? 1.0f : slope);   // G_s
+                acc_b[b][q] = ge1 * (y > 0.0f ? 1.0f : slope);   // G_t
+            }
+        }
+        // bias gradients: column sums over the tile's 16 rows
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            float cs = (acc_g[b][0] + acc_g[b][1]) + (acc_g[b][2] + acc_g[b][3]);
+            float ct = (acc_b[b][0] + acc_b[b][1]) + (acc_b[b][2] + acc_b[b][3]);
+            cs += __shfl_xor(cs, 16, kWave); cs += __shfl_xor(cs, 32, kWave);
+            ct += __shfl_xor(ct, 16, kWave); ct += __shfl_xor(ct, 32, kWave);
+            if (h == 0) {
+                atomicAdd(&s_db[0][16 * b + i16], cs);
+                atomicAdd(&s_db[1][16 * b + i16], ct);
+            }
+        }
+        // side / product tiles in the accumulator layout (B operands of the weight-gradient products, and the
+        // elementwise factors of the input gradients)
+        float side_c[4][4], prod_c[4][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                side_c[b][q] = t_side[(4 * h + q) * kLdsStride + 16 * b + i16];
+                prod_c[b][q] = t_prod[(4 * h + q) * kLdsStride + 16 * b + i16];
+            }
+        }
+        // dW[o][k] += sum_r G[r][o] X[r][k]: contraction over the tile's rows, row (4h + s) at step s of lane group h
+#pragma unroll
+        for (int bo = 0; bo < 4; ++bo) {
+#pragma unroll
+            for (int bn = 0; bn < 4; ++bn) {
+                f32x4 dg = (f32x4){0.f, 0.f, 0.f, 0.f}, db = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    dg = __builtin_amdgcn_mfma_f32_16x16x4f32(acc_g[bo][st], side_c[bn][st], dg, 0, 0, 0);
+                    db = __builtin_amdgcn_mfma_f32_16x16x4f32(acc_b[bo][st], prod_c[bn][st], db, 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    atomicAdd(&s_dw[0][(16 * bo + 4 * h + q) * kDwStride + 16 * bn + i16], dg[q]);
+                    atomicAdd(&s_dw[1][(16 * bo + 4 * h + q) * kDwStride + 16 * bn + i16], db[q]);
+                }
+            }
+        }
+        // G tiles into LDS (the side / product tiles are in registers now), then the two input-gradient products
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                t_side[(4 * h + q) * kLdsStride + 16 * b + i16] = acc_g[b][q];
+                t_prod[(4 * h + q) * kLdsStride + 16 * b + i16] = acc_b[b][q];
+            }
+        }
+        f32x4 ts[4], tb[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            ts[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            tb[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {
+            const int o = 4 * s + h;
+            const float a_s = t_side[i16 * kLdsStride + o];
+            const float a_t = t_prod[i16 * kLdsStride + o];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float w_g = s_w[0][o * kLdsStride + 16 * b + i16];
+                const float w_b = s_w[1][o * kLdsStride + 16 * b + i16];
+                ts[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_s, w_g, ts[b], 0, 0, 0);
+                tb[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_t, w_b, tb[b], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = r0 + 4 * h + q;
+            if (r < n) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int c = 16 * b + i16;
+                    const float e = ego[(size_t)r * 64 + c];
+                    g_side[(size_t)r * 64 + c] = ts[b][q] + tb[b][q] * e;
+                    float ge = tb[b][q] * side_c[b][q];
+                    if (g_direct) ge += g_direct[(size_t)r * ld_direct + c];
+                    g_ego[(size_t)r * 64 + c] = ge;
+                }
+            }
+        }
+    }
+    if (did_work && lane == 0) s_active = 1;
+    __syncthreads();
+    if (!s_active) return;
+    for (int k = threadIdx.x; k < 64 * 64; k += blockDim.x) {
+        const int o = k >> 6, c = k & 63;
+        atomicAdd(gW_gc + k, s_dw[0][o * kDwStride + c]);
+        atomicAdd(gW_bi + k, s_dw[1][o * kDwStride + c]);
+    }
+    if (threadIdx.x < 64) {
+        atomicAdd(gb_gc + threadIdx.x, s_db[0][threadIdx.x]);
+        atomicAdd(gb_bi + threadIdx.x, s_db[1][threadIdx.x]);
     }
 }
 
@@ -238,21 +524,74 @@ inline unsigned grid_for_rows(int n)
 
 }  // namespace
 
+static MsgDrop make_drop(float p_drop, uint64_t seed, uint32_t step, uint32_t layer, int32_t pad_row)
+{
+    MsgDrop d;
+    d.p = p_drop > 0.0f ? p_drop : 0.0f;
+    d.scale = 1.0f / (float)(1.0 - (double)d.p);          // at::dropout divides its Bernoulli noise by (1 - p) once
+    d.k0 = (uint32_t)seed;
+    d.k1 = (uint32_t)(seed >> 32);
+    d.step = step;
+    d.layer = layer;
+    d.pad_row = pad_row < 0 ? 0x7fffffff : pad_row;
+    return d;
+}
+
+extern "C" int spex_ngcf_layer_fwd_f32(const float *ego, const float *side, const float *W_gc, const float *b_gc,
+                                       const float *W_bi, const float *b_bi, float *out, int32_t ld_out, int32_t write_ego,
+                                       float *e1_out, int32_t n, int32_t d, float slope, float p_drop, uint64_t seed,
+                                       uint32_t step, uint32_t layer, int32_t pad_row, void *stream)
+{
+    SPEX_CHECK_ARG(ego && side && W_gc && b_gc && W_bi && b_bi && out, "spex_ngcf_layer_fwd_f32: NULL pointer");
+    SPEX_CHECK_ARG(n >= 0 && ld_out >= 2 * d, "spex_ngcf_layer_fwd_f32: n=%d ld_out=%d", n, ld_out);
+    SPEX_CHECK_ARG(p_drop >= 0.0f && p_drop < 1.0f, "spex_ngcf_layer_fwd_f32: p_drop=%f", (double)p_drop);
+    if (d != 64) {
+        spex::set_error("spex_ngcf_layer_fwd_f32: only d == 64 is implemented (got %d)", d);
+        return SPEX_ERR_UNSUPPORTED;
+    }
+    SPEX_CHECK_ARG((((uintptr_t)W_gc | (uintptr_t)W_bi) & 15) == 0, "spex_ngcf_layer_fwd_f32: weights must be 16-byte aligned");
+    if (n == 0) return SPEX_OK;
+    const int n_tiles = (n + 15) / 16;  // one wave per 16-row tile
+    hipLaunchKernelGGL(ngcf_layer_kernel, dim3(grid_for_rows(n_tiles)), dim3(kWave * kWavesPerBlock), 0, (hipStream_t)stream,
+                       ego, side, W_gc, b_gc, W_bi, b_bi, out, ld_out, write_ego, e1_out, n, slope,
+                       make_drop(p_drop, seed, step, layer, pad_row));
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}
+
 extern "C" int spex_ngcf_layer_f32(const float *ego, const float *side, const float *W_gc, const float *b_gc,
                                    const float *W_bi, const float *b_bi, float *out, int32_t ld_out, float *e1_out,
                                    int32_t n, int32_t d, float slope, void *stream)
 {
-    SPEX_CHECK_ARG(ego && side && W_gc && b_gc && W_bi && b_bi && out, "spex_ngcf_layer_f32: NULL pointer");
-    SPEX_CHECK_ARG(n >= 0 && ld_out >= 2 * d, "spex_ngcf_layer_f32: n=%d ld_out=%d", n, ld_out);
+    return spex_ngcf_layer_fwd_f32(ego, side, W_gc, b_gc, W_bi, b_bi, out, ld_out, 1, e1_out, n, d, slope, 0.0f, 0, 0, 0, -1,
+                                   stream);
+}
+
+extern "C" int spex_ngcf_layer_bwd_f32(const float *ego, const float *side, const float *W_gc, const float *b_gc,
+                                       const float *W_bi, const float *b_bi, const float *g_norm, int32_t ld_g,
+                                       const float *g_next, const float *g_direct, int32_t ld_direct, int32_t n, int32_t d,
+                                       float slope, float p_drop, uint64_t seed, uint32_t step, uint32_t layer,
+                                       int32_t pad_row, float *g_side, float *g_ego, float *gW_gc, float *gb_gc,
+                                       float *gW_bi, float *gb_bi, void *stream)
+{
+    SPEX_CHECK_ARG(ego && side && W_gc && b_gc && W_bi && b_bi && g_norm && g_side && g_ego && gW_gc && gb_gc && gW_bi && gb_bi,
+                   "spex_ngcf_layer_bwd_f32: NULL pointer");
+    SPEX_CHECK_ARG(n >= 0 && ld_g >= d && (!g_direct || ld_direct >= d), "spex_ngcf_layer_bwd_f32: n=%d ld_g=%d ld_direct=%d", n,
+                   ld_g, ld_direct);
+    SPEX_CHECK_ARG(p_drop >= 0.0f && p_drop < 1.0f, "spex_ngcf_layer_bwd_f32: p_drop=%f", (double)p_drop);
+    SPEX_CHECK_ARG(g_side != g_ego && g_side != side && g_ego != ego, "spex_ngcf_layer_bwd_f32: outputs must not alias inputs");
     if (d != 64) {
-        spex::set_error("spex_ngcf_layer_f32: only d == 64 is implemented (got %d)", d);
+        spex::set_error("spex_ngcf_layer_bwd_f32: only d == 64 is implemented (got %d)", d);
         return SPEX_ERR_UNSUPPORTED;
     }
-    SPEX_CHECK_ARG((((uintptr_t)W_gc | (uintptr_t)W_bi) & 15) == 0, "spex_ngcf_layer_f32: weights must be 16-byte aligned");
+    SPEX_CHECK_ARG((((uintptr_t)W_gc | (uintptr_t)W_bi) & 15) == 0, "spex_ngcf_layer_bwd_f32: weights must be 16-byte aligned");
     if (n == 0) return SPEX_OK;
-    const int n_tiles = (n + 15) / 16;  // one wave per 16-row tile
-    hipLaunchKernelGGL(ngcf_layer_kernel, dim3(grid_for_rows(n_tiles)), dim3(kWave * kWavesPerBlock), 0, (hipStream_t)stream,
-                       ego, side, W_gc, b_gc, W_bi, b_bi, out, ld_out, e1_out, n, slope);
+    const int n_tiles = (n + 15) / 16;
+    int blocks = (n_tiles + kBwdWaves - 1) / kBwdWaves;
+    if (blocks > 128) blocks = 128;      // one 8-wave workgroup per CU on half the chip: 128 x 8 K weight-gradient atomics
+    hipLaunchKernelGGL(ngcf_layer_bwd_kernel, dim3((unsigned)blocks), dim3(kWave * kBwdWaves), 0, (hipStream_t)stream, ego, side,
+                       W_gc, b_gc, W_bi, b_bi, g_norm, ld_g, g_next, g_direct, ld_direct, n, slope,
+                       make_drop(p_drop, seed, step, layer, pad_row), g_side, g_ego, gW_gc, gb_gc, gW_bi, gb_bi);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }

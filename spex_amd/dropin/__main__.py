@@ -5,7 +5,9 @@
 The driver's own imports (`from lg_parser import parse_args_r`, `import utility1.dataloader as dataloader`,
 `import utility1.model as model`, `from utility1.batch_test import test`, main_rec.py:2-13) then resolve to
 spex_amd/dropin/ because it is placed ahead of the script's directory on sys.path; anything this package does not
-provide still resolves to the driver's own directory.
+provide still resolves to the driver's own directory.  A driver that imports `ngcf_parser` (NGCF_SPEX/code/main_*.py)
+gets spex_amd/dropin/ngcf/ instead — its `utility` package is NGCF's (load_data, batch_test, helper, ...), not the
+LightGCN alias of the same name.
 
 Before the script starts, the heavy imports it will make anyway (torch, numpy, scipy, pandas) are done here and frozen
 out of Python's cyclic garbage collector: a full collection over their import-time objects takes ~40 ms and otherwise
@@ -23,7 +25,10 @@ def main():
     here = os.path.dirname(os.path.abspath(__file__))
     repo_root = os.path.dirname(os.path.dirname(here))
     sys.argv = [script] + sys.argv[2:]
-    sys.path[:] = [here] + [p for p in sys.path if p not in ("", here)] + [os.path.dirname(script)]
+    with open(script) as fh:
+        ngcf = "ngcf_parser" in fh.read()
+    root = os.path.join(here, "ngcf") if ngcf else here
+    sys.path[:] = [root] + [p for p in sys.path if p not in ("", here, root)] + [os.path.dirname(script)]
     if repo_root not in sys.path:
         sys.path.insert(1, repo_root)
     import gc

@@ -14,7 +14,7 @@ What changes underneath
     `random.sample` from (all items - positives).  The reference fans the users out to a multiprocessing.Pool whose
     workers each start from the parent's `random` state, so its stream depends on how the pool happens to chunk the
     users; drawn serially from the global `random` the negatives are a pure function of `random.seed` — and equal the
-    reference's whenever its pool is a serial map (that is how the goldens are minted, oracle/gen_golden.py).
+    reference's whenever its pool is a serial map (that is how the test fixtures were minted).
 """
 import random
 

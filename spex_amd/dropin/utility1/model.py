@@ -71,7 +71,7 @@ class LightGCN(BasicModel):
     def flat_table(self):
         """The two embedding tables as ONE [N, d] tensor sharing the parameters' storage (users first): what
         spex_amd.trainer.LightGCNStepper trains in place, so the module's own weights are the trained ones."""
-        return ops._flat_tables(self.embedding_user.weight, self.embedding_item.weight)
+        return ops._flat_tables(self.embedding_user.weight, self.embedding_item.weight, strict=True)
 
     # ------------------------------------------------------------------ dropout (model.py:46-64)
     def set_edge_mask(self, keep):

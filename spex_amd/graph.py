@@ -106,8 +106,27 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _device_of(device):
+    """A torch.device with an explicit index (a bare 'cuda' means the current device)."""
+    device = torch.device(device if device is not None else "cuda")
+    if device.type != "cuda":
+        raise ValueError(f"libspexhip runs on the GPU only (got device {device})")
+    return device if device.index is not None else torch.device("cuda", torch.cuda.current_device())
+
+
+def _launch(device, name, *args):
+    """One libspexhip call on `device`: its current stream is appended as the last argument, and when `device` is not the
+    process's current device the call runs under a device guard — the kernels are queued on the stream of the device
+    that owns the pointers (and the handle's on-demand allocations land there), whatever the caller's current device."""
+    if device.index is None or device.index == torch.cuda.current_device():
+        _lib.call(name, *args, _stream(device))
+    else:
+        with torch.cuda.device(device):
+            _lib.call(name, *args, _stream(device))
 
 
 def _bump(*tensors):
@@ -133,7 +152,7 @@ class SpexGraph:
         if edge_id is not None:
             edge_id = np.ascontiguousarray(edge_id, np.int32)
         self._edge_id_host = edge_id
-        self.device = torch.device(device if device is not None else "cuda")
+        self.device = _device_of(device)
         handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             _lib.call("spex_graph_create", rowptr.ctypes.data_as(ctypes.c_void_p), col.ctypes.data_as(ctypes.c_void_p),
@@ -164,7 +183,9 @@ class SpexGraph:
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             self.detach_timer()
-            _lib.load().spex_graph_destroy(self._h)
+            self.release_workspace()
+            with torch.cuda.device(self.device):
+                _lib.load().spex_graph_destroy(self._h)
             self._h = ctypes.c_void_p()
 
     def __del__(self):
@@ -177,7 +198,8 @@ class SpexGraph:
     def attach_timer(self, capacity, every=1):
         self.detach_timer()
         t = ctypes.c_void_p()
-        _lib.call("spex_timer_create", int(capacity), int(every), ctypes.byref(t))
+        with torch.cuda.device(self.device):          # the timer's events belong to the graph's device
+            _lib.call("spex_timer_create", int(capacity), int(every), ctypes.byref(t))
         _lib.call("spex_timer_attach", self._h, t)
         self._timer, self._timer_cap = t, int(capacity)
 
@@ -213,9 +235,13 @@ class SpexGraph:
         handle are stream-ordered, see spex_hip.h) — no allocation per training step."""
         cache = self.__dict__.setdefault("_scratch_cache", {})
         t = cache.get(key)
-        if t is None or t.shape != shape or t.device != device:
-            t = cache[key] = torch.empty(shape, dtype=torch.float32, device=device)
+        if t is None or t.shape != shape:
+            t = cache[key] = torch.empty(shape, dtype=torch.float32, device=self.device)
         return t
+
+    def release_workspace(self):
+        """Drop the cached propagate / propagate_bwd workspaces (up to five [N, d] tables per handle)."""
+        self.__dict__.pop("_scratch_cache", None)
 
     # -- kernels
     def _chk(self, t, rows, d, name):
@@ -223,6 +249,8 @@ class SpexGraph:
             return
         if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
             raise ValueError(f"{name}: need a contiguous fp32 tensor on the GPU")
+        if t.device != self.device:
+            raise ValueError(f"{name}: tensor on {t.device}, graph on {self.device}")
         if t.shape != (rows, d):
             raise ValueError(f"{name}: shape {tuple(t.shape)} != {(rows, d)}")
 
@@ -235,8 +263,8 @@ class SpexGraph:
         for t, nm in ((Y, "Y"), (add_in, "add_in"), (acc_in, "acc_in"), (acc_out, "acc_out")):
             self._chk(t, self.n_rows, d, nm)
         if self.n_rows > 0:     # (an empty tensor has a NULL data_ptr; nothing to launch anyway)
-            _lib.call("spex_spmm_f32", self._h, _ptr(X), _ptr(Y), _ptr(add_in), float(add_div), _ptr(acc_in),
-                      _ptr(acc_out), float(acc_div), d, _stream())
+            _launch(self.device, "spex_spmm_f32", self._h, _ptr(X), _ptr(Y), _ptr(add_in), float(add_div), _ptr(acc_in),
+                    _ptr(acc_out), float(acc_div), d)
             _bump(Y, acc_out)
         return Y if Y is not None else acc_out
 
@@ -250,9 +278,8 @@ class SpexGraph:
         for t in (idx_a, idx_b):
             if t is not None and not (t.is_cuda and t.dtype == torch.int64 and t.is_contiguous()):
                 raise ValueError("spmm_rows: row lists must be contiguous int64 tensors on the GPU")
-        _lib.call("spex_spmm_rowlist_f32", self._h, _ptr(X), _ptr(idx_a), idx_a.numel(), int(off_a), _ptr(idx_b),
-                  0 if idx_b is None else idx_b.numel(), int(off_b), _ptr(Y), _ptr(acc_in), _ptr(acc_out), float(acc_div), d,
-                  _stream())
+        _launch(self.device, "spex_spmm_rowlist_f32", self._h, _ptr(X), _ptr(idx_a), idx_a.numel(), int(off_a), _ptr(idx_b),
+                  0 if idx_b is None else idx_b.numel(), int(off_b), _ptr(Y), _ptr(acc_in), _ptr(acc_out), float(acc_div), d)
         _bump(Y, acc_out)
         return Y if Y is not None else acc_out
 
@@ -264,8 +291,7 @@ class SpexGraph:
             mean_out = torch.empty_like(E0)
         if layers_out is None and ws is None and n_layers > 1:
             ws = self._scratch("fwd", (2, n, d), E0.device)
-        _lib.call("spex_propagate_f32", self._h, _ptr(E0), _ptr(mean_out), _ptr(layers_out), _ptr(ws), int(n_layers), d,
-                  _stream())
+        _launch(self.device, "spex_propagate_f32", self._h, _ptr(E0), _ptr(mean_out), _ptr(layers_out), _ptr(ws), int(n_layers), d)
         _bump(mean_out, layers_out)
         return mean_out
 
@@ -277,7 +303,7 @@ class SpexGraph:
             grad_E0 = torch.empty_like(g_out)
         if ws is None:
             ws = self._scratch("bwd", (3, n, d), g_out.device)
-        _lib.call("spex_propagate_bwd_f32", self._h, _ptr(g_out), _ptr(grad_E0), _ptr(ws), int(n_layers), d, _stream())
+        _launch(self.device, "spex_propagate_bwd_f32", self._h, _ptr(g_out), _ptr(grad_E0), _ptr(ws), int(n_layers), d)
         _bump(grad_E0)
         return grad_E0
 
@@ -285,6 +311,8 @@ class SpexGraph:
     def _chk_edges(self, t, name):
         if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 1):
             raise ValueError(f"{name}: need a contiguous 1-D fp32 tensor on the GPU")
+        if t.device != self.device:
+            raise ValueError(f"{name}: tensor on {t.device}, graph on {self.device}")
         if t.numel() < self.n_edge_ids:
             raise ValueError(f"{name}: {t.numel()} values for {self.n_edge_ids} edge ids")
 
@@ -298,7 +326,7 @@ class SpexGraph:
     def set_values(self, val):
         """Replace the stored values by val[edge id]; later spmm() launches use them (spex_graph_set_values)."""
         self._chk_edges(val, "val")
-        _lib.call("spex_graph_set_values", self._h, _ptr(val), val.numel(), _stream())
+        _launch(self.device, "spex_graph_set_values", self._h, _ptr(val), val.numel())
 
     def sddmm(self, A, B, out=None):
         """out[edge id] = <A[row], B[col]> on the stored pattern: the SpMM's gradient w.r.t. its values."""
@@ -310,7 +338,7 @@ class SpexGraph:
             out = alloc(self.n_edge_ids, dtype=torch.float32, device=A.device)
         self._chk_edges(out, "out")
         if self.nnz:
-            _lib.call("spex_sddmm_f32", self._h, _ptr(A), _ptr(B), _ptr(out), out.numel(), d, _stream())
+            _launch(self.device, "spex_sddmm_f32", self._h, _ptr(A), _ptr(B), _ptr(out), out.numel(), d)
             _bump(out)
         return out
 
@@ -321,7 +349,7 @@ class SpexGraph:
             out = torch.zeros_like(v)
         self._chk_edges(out, "out")
         if self.nnz:
-            _lib.call("spex_edge_softmax_f32", self._h, _ptr(v), _ptr(out), v.numel(), _stream())
+            _launch(self.device, "spex_edge_softmax_f32", self._h, _ptr(v), _ptr(out), v.numel())
             _bump(out)
         return out
 
@@ -332,6 +360,6 @@ class SpexGraph:
             grad_in = torch.zeros_like(y)
         self._chk_edges(grad_in, "grad_in")
         if self.nnz:
-            _lib.call("spex_edge_softmax_bwd_f32", self._h, _ptr(y), _ptr(grad_y), _ptr(grad_in), y.numel(), _stream())
+            _launch(self.device, "spex_edge_softmax_bwd_f32", self._h, _ptr(y), _ptr(grad_y), _ptr(grad_in), y.numel())
             _bump(grad_in)
         return grad_in

@@ -4,11 +4,12 @@ PyTorch here is plumbing (device memory, streams, autograd bookkeeping); every f
 spex_amd/csrc/ through the C ABI.  No function in this module has a CPU path.
 """
 import ctypes
+import os
 
 import torch
 
 from . import _lib
-from .graph import _bump, _ptr, _stream
+from .graph import _bump, _launch, _ptr
 
 
 def _need(t, name, dtype=torch.float32):
@@ -19,10 +20,20 @@ def _need(t, name, dtype=torch.float32):
                          f"contiguous={t.is_contiguous()})")
 
 
-def _idx(t, device):
-    """Indices as the reference hands them over (int64, possibly on the host: main_rec.py:33-34)."""
+VALIDATE_DEVICE_INDICES = os.environ.get("SPEX_VALIDATE_INDICES") == "1"
+
+
+def _idx(t, device, bound=None):
+    """Indices as the reference hands them over (int64, possibly on the host: main_rec.py:33-34).  With `bound`, indices
+    outside [0, bound) raise IndexError like the reference's table lookup would — checked for free while the indices are
+    still on the host; indices that already live on the device are only checked under SPEX_VALIDATE_INDICES=1 (a
+    synchronising debug mode; the kernels themselves skip such samples instead of gathering out of bounds)."""
     if not torch.is_tensor(t):
         t = torch.as_tensor(t)
+    if bound is not None and t.numel() and (not t.is_cuda or VALIDATE_DEVICE_INDICES):
+        lo, hi = int(t.min()), int(t.max())
+        if lo < 0 or hi >= bound:
+            raise IndexError(f"index {lo if lo < 0 else hi} is out of range for a table of {bound} rows")
     return t.to(device=device, dtype=torch.int64, non_blocking=True).contiguous()
 
 
@@ -34,7 +45,7 @@ def score_bce(users_tab, items_tab, u_idx, i_idx, labels=None, grad_users=None, 
     the score vector (training steps do not read it)."""
     _need(users_tab, "users_tab"); _need(items_tab, "items_tab")
     dev = users_tab.device
-    u_idx, i_idx = _idx(u_idx, dev), _idx(i_idx, dev)
+    u_idx, i_idx = _idx(u_idx, dev, users_tab.shape[0]), _idx(i_idx, dev, items_tab.shape[0])
     B, d = u_idx.numel(), users_tab.shape[1]
     gamma = torch.empty(B, dtype=torch.float32, device=dev) if (want_gamma or labels is None) else None
     if labels is not None:
@@ -44,9 +55,9 @@ def score_bce(users_tab, items_tab, u_idx, i_idx, labels=None, grad_users=None, 
     else:
         loss_sum = None
     _need(grad_users, "grad_users"); _need(grad_items, "grad_items")
-    _lib.call("spex_score_bce_f32", _ptr(users_tab), _ptr(items_tab), users_tab.stride(0), items_tab.stride(0),
+    _launch(users_tab.device, "spex_score_bce_f32", _ptr(users_tab), _ptr(items_tab), users_tab.stride(0), items_tab.stride(0),
               users_tab.shape[0], items_tab.shape[0], _ptr(u_idx), _ptr(i_idx), _ptr(labels), B, d, _ptr(gamma),
-              _ptr(loss_sum), _ptr(grad_users), _ptr(grad_items), float(grad_scale), _stream())
+              _ptr(loss_sum), _ptr(grad_users), _ptr(grad_items), float(grad_scale))
     _bump(grad_users, grad_items, loss_sum)
     return gamma, loss_sum
 
@@ -60,9 +71,8 @@ def bpr_sgd_step(U_read, I_read, U_w, I_w, u, i_pos, i_neg, lr, reg=0.0, loss_su
     u, i_pos, i_neg = _idx(u, dev), _idx(i_pos, dev), _idx(i_neg, dev)
     if loss_sum is None:
         loss_sum = torch.zeros(1, dtype=torch.float32, device=dev)
-    _lib.call("spex_bpr_sgd_step_f32", _ptr(U_read), _ptr(I_read), _ptr(U_w), _ptr(I_w), U_read.shape[0], I_read.shape[0],
-              _ptr(u), _ptr(i_pos), _ptr(i_neg), u.numel(), U_read.shape[1], float(lr), float(reg), _ptr(loss_sum),
-              _stream())
+    _launch(U_read.device, "spex_bpr_sgd_step_f32", _ptr(U_read), _ptr(I_read), _ptr(U_w), _ptr(I_w), U_read.shape[0], I_read.shape[0],
+              _ptr(u), _ptr(i_pos), _ptr(i_neg), u.numel(), U_read.shape[1], float(lr), float(reg), _ptr(loss_sum))
     _bump(U_w, I_w, loss_sum)
     return loss_sum
 
@@ -72,9 +82,9 @@ def bpr_loss_grad(users_tab, items_tab, u, i_pos, i_neg, grad_users=None, grad_i
     dev = users_tab.device
     u, i_pos, i_neg = _idx(u, dev), _idx(i_pos, dev), _idx(i_neg, dev)
     loss_sum = torch.zeros(1, dtype=torch.float32, device=dev)
-    _lib.call("spex_bpr_loss_f32", _ptr(users_tab), _ptr(items_tab), users_tab.shape[0], items_tab.shape[0], _ptr(u),
+    _launch(users_tab.device, "spex_bpr_loss_f32", _ptr(users_tab), _ptr(items_tab), users_tab.shape[0], items_tab.shape[0], _ptr(u),
               _ptr(i_pos), _ptr(i_neg), u.numel(), users_tab.shape[1], _ptr(loss_sum), _ptr(grad_users),
-              _ptr(grad_items), float(grad_scale), _stream())
+              _ptr(grad_items), float(grad_scale))
     _bump(grad_users, grad_items)
     return loss_sum
 
@@ -86,8 +96,8 @@ def adam_step(p, g, m, v, t, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, zero=Non
         _need(x, n)
     if zero is not None and zero.numel() != p.numel():
         raise ValueError("adam_step: `zero` must have as many elements as the parameters")
-    _lib.call("spex_adam_step_f32", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), int(t), float(lr), float(beta1),
-              float(beta2), float(eps), _ptr(zero), _stream())
+    _launch(p.device, "spex_adam_step_f32", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), int(t), float(lr), float(beta1),
+              float(beta2), float(eps), _ptr(zero))
     _bump(p, m, v, zero)
 
 
@@ -98,9 +108,47 @@ def ngcf_layer(ego, side, W_gc, b_gc, W_bi, b_bi, slope=0.01, want_e1=False):
     n, d = ego.shape
     out = torch.empty((n, 2 * d), dtype=torch.float32, device=ego.device)
     e1 = torch.empty((n, d), dtype=torch.float32, device=ego.device) if want_e1 else None
-    _lib.call("spex_ngcf_layer_f32", _ptr(ego), _ptr(side), _ptr(W_gc), _ptr(b_gc), _ptr(W_bi), _ptr(b_bi), _ptr(out),
-              2 * d, _ptr(e1), n, d, float(slope), _stream())
+    _launch(ego.device, "spex_ngcf_layer_f32", _ptr(ego), _ptr(side), _ptr(W_gc), _ptr(b_gc), _ptr(W_bi), _ptr(b_bi), _ptr(out),
+              2 * d, _ptr(e1), n, d, float(slope))
     return (out, e1) if want_e1 else out
+
+
+def ngcf_layer_fwd(ego, side, W_gc, b_gc, W_bi, b_bi, out, layer, write_ego, e1_out=None, slope=0.01, drop=None,
+                   pad_row=-1):
+    """One NGCF layer into its slice of the concatenated table `out` ([n, d * (L + 1)]): normalised output to columns
+    d*(layer+1) .. d*(layer+2), ego to columns 0..d iff write_ego; e1_out receives the layer's un-normalised output
+    (after dropout) = the next layer's input.  drop: None or (p, seed, step) — counter-based message dropout,
+    spex_ngcf_layer_fwd_f32."""
+    for x, n in ((ego, "ego"), (side, "side"), (W_gc, "W_gc"), (b_gc, "b_gc"), (W_bi, "W_bi"), (b_bi, "b_bi"), (out, "out"),
+                 (e1_out, "e1_out")):
+        _need(x, n)
+    n, d = ego.shape
+    p, seed, step = drop if drop is not None else (0.0, 0, 0)
+    base = ctypes.c_void_p(out.data_ptr() + 4 * d * layer)
+    _launch(ego.device, "spex_ngcf_layer_fwd_f32", _ptr(ego), _ptr(side), _ptr(W_gc), _ptr(b_gc), _ptr(W_bi), _ptr(b_bi), base,
+              out.stride(0), 1 if write_ego else 0, _ptr(e1_out), n, d, float(slope), float(p), int(seed), int(step), int(layer),
+              int(pad_row))
+    _bump(out, e1_out)
+
+
+def ngcf_layer_bwd(ego, side, W_gc, b_gc, W_bi, b_bi, g_all, layer, g_next, g_side, g_ego, gW_gc, gb_gc, gW_bi, gb_bi,
+                   slope=0.01, drop=None, pad_row=-1):
+    """Backward of ngcf_layer_fwd for layer `layer` given g_all = d loss / d (concatenated table): reads its slice (and,
+    for layer 0, the ego slice as g_direct), writes g_side / g_ego, accumulates the four weight gradients.
+    spex_ngcf_layer_bwd_f32."""
+    for x, n in ((ego, "ego"), (side, "side"), (W_gc, "W_gc"), (b_gc, "b_gc"), (W_bi, "W_bi"), (b_bi, "b_bi"), (g_all, "g_all"),
+                 (g_next, "g_next"), (g_side, "g_side"), (g_ego, "g_ego"), (gW_gc, "gW_gc"), (gb_gc, "gb_gc"), (gW_bi, "gW_bi"),
+                 (gb_bi, "gb_bi")):
+        _need(x, n)
+    n, d = ego.shape
+    p, seed, step = drop if drop is not None else (0.0, 0, 0)
+    ld = g_all.stride(0)
+    g_norm = ctypes.c_void_p(g_all.data_ptr() + 4 * d * (layer + 1))
+    g_direct = ctypes.c_void_p(g_all.data_ptr()) if layer == 0 else None
+    _launch(ego.device, "spex_ngcf_layer_bwd_f32", _ptr(ego), _ptr(side), _ptr(W_gc), _ptr(b_gc), _ptr(W_bi), _ptr(b_bi), g_norm, ld,
+              _ptr(g_next), g_direct, ld, n, d, float(slope), float(p), int(seed), int(step), int(layer), int(pad_row),
+              _ptr(g_side), _ptr(g_ego), _ptr(gW_gc), _ptr(gb_gc), _ptr(gW_bi), _ptr(gb_bi))
+    _bump(g_side, g_ego, gW_gc, gb_gc, gW_bi, gb_bi)
 
 
 def expert_gate(raw, prop, att_exp):
@@ -108,8 +156,7 @@ def expert_gate(raw, prop, att_exp):
     for x, n in ((raw, "raw"), (prop, "prop"), (att_exp, "att_exp")):
         _need(x, n)
     mixed = torch.empty_like(raw)
-    _lib.call("spex_expert_gate_f32", _ptr(raw), _ptr(prop), _ptr(att_exp), _ptr(mixed), raw.shape[0], raw.shape[1],
-              _stream())
+    _launch(raw.device, "spex_expert_gate_f32", _ptr(raw), _ptr(prop), _ptr(att_exp), _ptr(mixed), raw.shape[0], raw.shape[1])
     return mixed
 
 
@@ -120,20 +167,24 @@ def sample_negatives(rowptr, items, pos_user, num_ng, num_item, seed):
         if not (t.is_cuda and t.dtype == dt and t.is_contiguous()):
             raise ValueError(f"{n}: need a contiguous {dt} CUDA tensor")
     out = torch.empty(pos_user.numel() * num_ng, dtype=torch.int64, device=pos_user.device)
-    _lib.call("spex_sample_negatives", _ptr(rowptr), _ptr(items), rowptr.numel() - 1, _ptr(pos_user), pos_user.numel(),
-              int(num_ng), int(num_item), int(seed), _ptr(out), _stream())
+    _launch(rowptr.device, "spex_sample_negatives", _ptr(rowptr), _ptr(items), rowptr.numel() - 1, _ptr(pos_user), pos_user.numel(),
+              int(num_ng), int(num_item), int(seed), _ptr(out))
     return out
 
 
 # ------------------------------------------------------------------------------------------------ autograd glue
-def _flat_tables(user_w, item_w):
+def _flat_tables(user_w, item_w, strict=False):
     """The two embedding tables as one [N, d] buffer.  The drop-in model allocates them back-to-back so this is a
-    view; otherwise (foreign parameters) it costs one concatenation, like model.py:72."""
+    view; otherwise (foreign parameters, e.g. after load_state_dict(assign=True)) it costs one concatenation, like
+    model.py:72 — or, with strict=True (a caller that will WRITE through the result), raises."""
     if (user_w.is_contiguous() and item_w.is_contiguous()
             and user_w.untyped_storage().data_ptr() == item_w.untyped_storage().data_ptr()
             and user_w.data_ptr() + user_w.numel() * 4 == item_w.data_ptr()):
         n = user_w.shape[0] + item_w.shape[0]
         return torch.as_strided(user_w.detach(), (n, user_w.shape[1]), (user_w.shape[1], 1))
+    if strict:
+        raise RuntimeError("the two embedding tables no longer share one contiguous buffer (parameters were replaced?): "
+                           "call the model's _fuse_tables() before training through flat_table()")
     return torch.cat([user_w.detach(), item_w.detach()])
 
 
@@ -256,6 +307,58 @@ class BPRLoss(torch.autograd.Function):
         return grad * g, None, None, None, None
 
 
+class NGCFPropagate(torch.autograd.Function):
+    """The NGCF propagation (Model_Wrapper.forward, NGCF_SPEX/code/main_rec.py:71-86) on one [N, d] table: per layer one
+    SpMM (side = A ego) and one fused layer kernel; returns the concatenated table [N, d (L + 1)].  Backward per layer:
+    one fused layer-backward kernel (recomputes the layer on the matrix cores, weight gradients included) and one SpMM
+    on A^T with the direct part added in its epilogue.  d == 64 for every layer.
+    weights: flat tuple (W_gc_0, b_gc_0, W_bi_0, b_bi_0, W_gc_1, ...).  drop: None or (p_per_layer, seed, step)."""
+
+    @staticmethod
+    def forward(ctx, user_w, item_w, graph, graph_t, drop, pad_row, *weights):
+        E0 = _flat_tables(user_w, item_w)
+        n, d = E0.shape
+        L = len(weights) // 4
+        out = torch.empty((n, d * (L + 1)), dtype=torch.float32, device=E0.device)
+        egos, sides = [E0], []
+        for l in range(L):
+            W_gc, b_gc, W_bi, b_bi = (w.detach().contiguous() for w in weights[4 * l:4 * l + 4])
+            side = graph.spmm(egos[l])
+            nxt = torch.empty_like(E0) if l < L - 1 else None
+            dl = None if drop is None or drop[0][l] <= 0 else (drop[0][l], drop[1], drop[2])
+            ngcf_layer_fwd(egos[l], side, W_gc, b_gc, W_bi, b_bi, out, l, l == 0, nxt, drop=dl, pad_row=pad_row)
+            sides.append(side)
+            if nxt is not None:
+                egos.append(nxt)
+        if L == 0:
+            out.copy_(E0)
+        ctx.graph_t, ctx.drop, ctx.pad_row, ctx.n_user_rows, ctx.L = graph_t, drop, pad_row, user_w.shape[0], L
+        ctx.save_for_backward(*egos, *sides, *weights)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_all):
+        L = ctx.L
+        saved = ctx.saved_tensors
+        egos, sides, weights = saved[:max(L, 1)], saved[max(L, 1):max(L, 1) + L], saved[max(L, 1) + L:]
+        g_all = g_all.contiguous()
+        u = ctx.n_user_rows
+        if L == 0:
+            return (g_all[:u], g_all[u:], None, None, None, None)
+        grads = [None] * (4 * L)
+        g_next = None
+        for l in range(L - 1, -1, -1):
+            W_gc, b_gc, W_bi, b_bi = (w.detach().contiguous() for w in weights[4 * l:4 * l + 4])
+            g_side, g_ego = torch.empty_like(egos[l]), torch.empty_like(egos[l])
+            gW_gc, gb_gc, gW_bi, gb_bi = (torch.zeros_like(w) for w in (W_gc, b_gc, W_bi, b_bi))
+            dl = None if ctx.drop is None or ctx.drop[0][l] <= 0 else (ctx.drop[0][l], ctx.drop[1], ctx.drop[2])
+            ngcf_layer_bwd(egos[l], sides[l], W_gc, b_gc, W_bi, b_bi, g_all, l, g_next, g_side, g_ego, gW_gc, gb_gc, gW_bi,
+                           gb_bi, drop=dl, pad_row=ctx.pad_row)
+            g_next = ctx.graph_t.spmm(g_side, add_in=g_ego, add_div=1.0)      # d loss / d ego_l
+            grads[4 * l:4 * l + 4] = [gW_gc, gb_gc, gW_bi, gb_bi]
+        return (g_next[:u], g_next[u:], None, None, None, None, *grads)
+
+
 # ------------------------------------------------------------------------------------------------ learned edge values
 class EdgeSoftmax(torch.autograd.Function):
     """Row softmax over the stored entries of `graph` (tf.sparse.softmax on a fixed pattern,
@@ -336,8 +439,8 @@ class PathAttention(torch.autograd.Function):
         out = torch.empty((B, L, n_heads * d), dtype=torch.float32, device=dev)
         w0 = torch.empty((B, L, n_heads), dtype=torch.float32, device=dev)
         if B:
-            _lib.call("spex_path_attention_f32", _ptr(src), n_rows, _ptr(seq), _ptr(seq_l), _ptr(a), B, L, d, n_heads,
-                      1 if positional else 0, _ptr(out), _ptr(w0), _stream())
+            _launch(src.device, "spex_path_attention_f32", _ptr(src), n_rows, _ptr(seq), _ptr(seq_l), _ptr(a), B, L, d, n_heads,
+                      1 if positional else 0, _ptr(out), _ptr(w0))
         ctx.save_for_backward(src, seq, seq_l, a, w0)
         ctx.dims = (B, L, d, n_heads, n_rows, 1 if positional else 0)
         return out
@@ -350,8 +453,8 @@ class PathAttention(torch.autograd.Function):
         g_src = torch.zeros_like(src)
         g_a = torch.zeros_like(a) if ctx.needs_input_grad[3] else None
         if B:
-            _lib.call("spex_path_attention_bwd_f32", _ptr(src), n_rows, _ptr(seq), _ptr(seq_l), _ptr(a), B, L, d, n_heads,
-                      positional, _ptr(w0), _ptr(g), _ptr(g_src), _ptr(g_a), _stream())
+            _launch(src.device, "spex_path_attention_bwd_f32", _ptr(src), n_rows, _ptr(seq), _ptr(seq_l), _ptr(a), B, L, d, n_heads,
+                      positional, _ptr(w0), _ptr(g), _ptr(g_src), _ptr(g_a))
         return g_src, None, None, g_a, None
 
 
@@ -376,8 +479,8 @@ class ExpertGate(torch.autograd.Function):
         g = g.contiguous()
         g_raw, g_prop, g_att = torch.empty_like(raw), torch.empty_like(prop), torch.zeros_like(att_exp)
         if raw.shape[0]:
-            _lib.call("spex_expert_gate_bwd_f32", _ptr(raw), _ptr(prop), _ptr(att_exp), _ptr(g), _ptr(g_raw), _ptr(g_prop),
-                      _ptr(g_att), raw.shape[0], raw.shape[1], _stream())
+            _launch(raw.device, "spex_expert_gate_bwd_f32", _ptr(raw), _ptr(prop), _ptr(att_exp), _ptr(g), _ptr(g_raw), _ptr(g_prop),
+                      _ptr(g_att), raw.shape[0], raw.shape[1])
         return g_raw, g_prop, g_att
 
 
@@ -401,8 +504,8 @@ class AttnFuse(torch.autograd.Function):
             raise ValueError("attn_fuse: parameter blocks must hold w1 | b1 | w2 | b2")
         out = torch.empty_like(X1)
         if n:
-            _lib.call("spex_attn_fuse_f32", _ptr(U), _ptr(X1), _ptr(X2), _ptr(p1), _ptr(p2), n, d, float(c1), float(c2),
-                      float(base_coef), float(mix_coef), _ptr(out), _stream())
+            _launch(X1.device, "spex_attn_fuse_f32", _ptr(U), _ptr(X1), _ptr(X2), _ptr(p1), _ptr(p2), n, d, float(c1), float(c2),
+                      float(base_coef), float(mix_coef), _ptr(out))
         ctx.save_for_backward(U, X1, X2, p1, p2)
         ctx.consts = (float(c1), float(c2), float(base_coef), float(mix_coef))
         return out
@@ -416,8 +519,8 @@ class AttnFuse(torch.autograd.Function):
         gX1, gX2 = torch.empty_like(X1), torch.empty_like(X2)
         gp1, gp2 = torch.zeros_like(p1), torch.zeros_like(p2)
         if n:
-            _lib.call("spex_attn_fuse_bwd_f32", _ptr(U), _ptr(X1), _ptr(X2), _ptr(p1), _ptr(p2), n, d, *ctx.consts, _ptr(g),
-                      _ptr(gU), _ptr(gX1), _ptr(gX2), _ptr(gp1), _ptr(gp2), _stream())
+            _launch(X1.device, "spex_attn_fuse_bwd_f32", _ptr(U), _ptr(X1), _ptr(X2), _ptr(p1), _ptr(p2), n, d, *ctx.consts, _ptr(g),
+                      _ptr(gU), _ptr(gX1), _ptr(gX2), _ptr(gp1), _ptr(gp2))
         return gU, gX1, gX2, gp1, gp2, None, None, None, None
 
 
@@ -432,8 +535,8 @@ def gather_owned_rows(table, pos, lo, out):
     pos = _idx(pos, out.device)
     if out.shape != (pos.numel(), table.shape[1]):
         raise ValueError("gather_owned_rows: out must be [len(pos), d]")
-    _lib.call("spex_gather_owned_rows_f32", _ptr(table), _ptr(pos), pos.numel(), int(lo), table.shape[0], table.shape[1],
-              _ptr(out), _stream())
+    _launch(table.device, "spex_gather_owned_rows_f32", _ptr(table), _ptr(pos), pos.numel(), int(lo), table.shape[0], table.shape[1],
+              _ptr(out))
     _bump(out)
     return out
 
@@ -444,7 +547,7 @@ def scatter_add_owned_rows(upd, pos, lo, table, clear=True):
     pos = _idx(pos, upd.device)
     if upd.shape != (pos.numel(), table.shape[1]):
         raise ValueError("scatter_add_owned_rows: upd must be [len(pos), d]")
-    _lib.call("spex_scatter_add_owned_rows_f32", _ptr(upd), _ptr(pos), pos.numel(), int(lo), table.shape[0], table.shape[1],
-              _ptr(table), 1 if clear else 0, _stream())
+    _launch(upd.device, "spex_scatter_add_owned_rows_f32", _ptr(upd), _ptr(pos), pos.numel(), int(lo), table.shape[0], table.shape[1],
+              _ptr(table), 1 if clear else 0)
     _bump(table, upd)
     return table

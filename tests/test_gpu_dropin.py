@@ -494,3 +494,135 @@ def test_whole_dual_task_run_matches_the_reference(data_root, golden):
             assert np.abs(np.asarray(trust_test5(net, test2)) - g["trust"][epoch]).max() <= 1e-4
     assert rel_err(net.embedding_user.weight.detach().cpu().numpy(), g["user_w"]) <= 5e-5
     assert rel_err(net.w.detach().cpu().numpy(), g["w"]) <= 5e-5
+
+
+# ---------------------------------------------------------------------------------------------- config 5 at Epinion2 scale
+def _epinion2_trust_raw(golden):
+    """The reference-minted Epinion2 trust paths (Data_process/path/data_process_path.py on trust_with_timestamp.mat;
+    oracle/gen_golden.py --stage paths) as the lists main_auto_expert_s.py unpickles."""
+    t = golden("trust_epinion2_paths")
+    tr = ([r[:l].tolist() for r, l in zip(t["train_paths"].astype(np.int64), t["train_len"])],
+          t["train_targets"].astype(np.int64).tolist())
+    te = ([r[:l].tolist() for r, l in zip(t["test_paths"].astype(np.int64), t["test_len"])],
+          t["test_targets"].astype(np.int64).tolist(), t["test_negs"].astype(np.int64).tolist())
+    return tr, te
+
+
+def _dual_epinion2(data_root):
+    import lg_parser
+    import utility1.dataloader as dataloader
+    import utility1.model_expert_s as mex
+    import utility1.utils as utils
+    args = lg_parser.parse_args_r(["--dataset", "epinion2", "--data_path", data_root])
+    utils.set_seed(args.seed)
+    dataset = dataloader.Loader(args)
+    return args, dataset, mex.LightGCN(args, dataset)
+
+
+def test_dual_task_model_matches_reference_epinion2(data_root, golden):
+    """G11 at Epinion2 scale (3 185 users, 12 407 items, 27 004 reference-minted trust paths): same parameters for the
+    same seed, both losses for a 256-sample rec batch + 192 paths, every parameter's gradient, the trust scores at the
+    test negatives and trust_test5 over 1 024 test paths."""
+    from collections import defaultdict
+    from utility2.batch_test_gnn import trust_test5
+    from utility2.utils import Data
+    from test_oracle_golden import sha
+    g, lg = golden("trust_epinion2"), golden("lightgcn_epinion2")
+    raw_train, raw_test = _epinion2_trust_raw(golden)
+    args, dataset, net = _dual_epinion2(data_root)
+    assert sha(net.embedding_user.weight.detach().numpy()) == str(g["user_w_sha"])
+    assert sha(net.embedding_item.weight.detach().numpy()) == str(g["item_w_sha"])
+    for k in g.files:
+        if k.startswith("state_"):
+            assert np.array_equal(net.state_dict()[k[6:].replace("__", ".")].numpy(), g[k]), k
+    net = net.to(DEV)
+    train, test = Data(raw_train, dataset.n_users, shuffle=False), Data(raw_test, dataset.n_users, shuffle=False, test=True)
+    bu, bi, bl = (torch.from_numpy(lg[k][0]) for k in ("batch_users", "batch_items", "batch_labels"))
+    net.train()
+    loss1, loss2 = net(bu, bi, bl, g["slice_indices"], train, flag=0)
+    assert abs(loss1.item() - float(g["loss1"])) <= 2e-6 and abs(loss2.item() - float(g["loss2"])) <= 2e-5
+    (loss1 + loss2).backward()
+    checked = 0
+    for name, p in net.named_parameters():
+        key = name.replace(".", "__")
+        if "grad_" + key not in g.files:
+            continue
+        got = p.grad.cpu().numpy()
+        if "gradrows_" + key in g.files:
+            assert abs(np.sqrt((got.astype(np.float64) ** 2).sum()) - float(g["gradfro_" + key])) <= 5e-5 * float(g["gradfro_" + key]), name
+            cs = g["gradcolsum_" + key]
+            assert np.abs(got.astype(np.float64).sum(0) - cs).max() <= 5e-5 * max(np.abs(cs).max(), 1e-6), name
+            got = got[g["gradrows_" + key]]
+        assert rel_err(got, g["grad_" + key]) <= 5e-5, name
+        checked += 1
+    assert checked >= 12
+    net.eval()
+    with torch.no_grad():
+        scores, negs = net(None, None, None, np.arange(64), test, flag=2)
+        assert rel_err(torch.gather(scores, 1, negs).cpu().numpy(), g["trust_scores_at_negs"]) <= 2e-5
+        assert np.abs(np.asarray(trust_test5(net, test)) - g["trust_test5"]).max() <= 1e-4
+
+
+def test_dual_task_training_run_matches_the_reference_epinion2(data_root, golden):
+    """G13 at Epinion2 scale: the first 600 dual-task steps of main_auto_expert_s.py's epoch 0 (rec batches of 256, the
+    batch users' trust paths capped at 3 x 5 by random.sample, uncertainty-weighted loss, Adam over all ~40 parameters),
+    then rec_test over 3 185 users and trust_test5 — per-step path counts, per-step losses of the first 16 steps, running
+    loss sums every 100 steps, the learned task weights, both tasks' metrics, the trained tables."""
+    import random
+    from collections import defaultdict
+    from torch.utils.data import DataLoader
+    import utility1.dataloader as dl
+    from utility1.batch_test import rec_test
+    from utility2.batch_test_gnn import trust_test5
+    from utility2.utils import Data
+    g = golden("dual_epinion2_epochs")
+    raw_train, raw_test = _epinion2_trust_raw(golden)
+    args, dataset, net = _dual_epinion2(data_root)
+    assert args.seed == int(g["seed"])
+    loader = DataLoader(dl.LightTrainData(dataset.rec_train_data, dataset.m_item, dataset.train_mat), batch_size=256, shuffle=True)
+    assert len(loader) == int(g["steps_per_epoch"])
+    by_user = defaultdict(list)
+    for k, p in enumerate(raw_train[0]):
+        by_user[p[0]].append(k)
+    train2, test2 = Data(raw_train, dataset.n_users, shuffle=False), Data(raw_test, dataset.n_users, shuffle=False, test=True)
+    cap = 3 * (len(raw_train[0]) // len(loader))
+    assert cap == 3 * int(g["trust_batch_size"])
+    net = net.to(DEV)
+    opt = torch.optim.Adam(net.parameters(), lr=args.lr)
+    loader.dataset.ng_sample()
+    net.train()
+    t1 = t2 = 0.0
+    n_steps = int(g["n_steps"])
+    for step, (user, item, label) in enumerate(loader):
+        if step == n_steps:
+            break
+        opt.zero_grad()
+        chosen = []
+        for u in set(user.numpy().tolist()):
+            chosen.extend(by_user[u])
+        if len(chosen) > cap:
+            chosen = random.sample(chosen, cap)
+        assert len(chosen) == int(g["n_paths"][step]), step
+        l1, l2 = net(users=user.to(DEV), items=item.to(DEV), labels=label.to(DEV),
+                     slice_indices=np.array(chosen, dtype=int), trust_data=train2, flag=0)
+        w = net.task_weights
+        (torch.exp(-2 * w[0]) * l1 + torch.exp(-2 * w[1]) * l2 + 2 * 6 * len(user) * w[0] + len(chosen) * w[1]).backward()
+        a, b = l1.item(), l2.item()
+        if step < len(g["loss1_first"]):
+            assert abs(a - g["loss1_first"][step]) <= 2e-5 and abs(b - g["loss2_first"][step]) <= 1e-4 * g["loss2_first"][step], step
+        t1 += a
+        t2 += b
+        opt.step()
+        if (step + 1) % 100 == 0:
+            c = (step + 1) // 100 - 1
+            assert abs(t1 - g["loss1_cum"][c]) <= 5e-5 * g["loss1_cum"][c], (step, t1, g["loss1_cum"][c])
+            assert abs(t2 - g["loss2_cum"][c]) <= 2e-4 * g["loss2_cum"][c], (step, t2, g["loss2_cum"][c])
+    assert np.abs(net.task_weights.detach().cpu().numpy() - g["task_weights"]).max() <= 5e-5
+    net.eval()
+    with torch.no_grad():
+        ret = rec_test(net, dataset.testRatings, dataset.testNegatives)
+        assert np.abs(ret["recall"] - g["rec_recall"]).max() <= 1e-3 and np.abs(ret["ndcg"] - g["rec_ndcg"]).max() <= 1e-3
+        assert np.abs(np.asarray(trust_test5(net, test2)) - g["trust"]).max() <= 2e-3
+    uw, iw = net.embedding_user.weight.detach().cpu().numpy(), net.embedding_item.weight.detach().cpu().numpy()
+    assert rel_err(uw[g["rows_u"]], g["user_w"]) <= 2e-4 and rel_err(iw[g["rows_i"]], g["item_w"]) <= 2e-4
+    assert rel_err(net.w.detach().cpu().numpy(), g["w"]) <= 2e-4

@@ -1,0 +1,246 @@
+"""BASELINE config 4 (NGCF) on the GPU: the fused layer kernels against a torch restatement of the same layer (autograd
+gives the gradients), the drop-in `utility.load_data` / `utility.batch_test` modules and the whole training run
+against goldens minted from the reference (oracle/gen_golden.py --stage ngcf-epochs / ngcf-epochs-epinion2), and a
+main_rec.py-shaped driver through the launcher."""
+import argparse
+import os
+import random
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def ngcf_args(**kw):
+    a = dict(embed_size=64, layer_size="[64]", mess_dropout="[0.1]", regs="[1e-5]")
+    a.update(kw)
+    return argparse.Namespace(**a)
+
+
+# ---------------------------------------------------------------------------------------------- the layer kernels
+@pytest.mark.parametrize("n,p_drop,with_next,with_direct,pad_row", [
+    (1000, 0.0, False, True, -1), (1000, 0.1, False, True, 300), (333, 0.25, True, False, -1), (16, 0.1, True, True, 3),
+    (15593, 0.1, False, True, 3185)])
+def test_layer_forward_and_backward_kernels_vs_torch_autograd(oracle, n, p_drop, with_next, with_direct, pad_row):
+    """spex_ngcf_layer_fwd_f32 / _bwd_f32 on random inputs vs the same layer in torch fp64 with the SAME dropout mask
+    (the counter-based mask restated in NumPy): outputs, both input gradients, all four weight gradients.  Upstream
+    gradients are non-zero on a sparse set of rows only (as after a batch) plus one dense stretch, so both the
+    skip-tile path and the arithmetic path run."""
+    from spex_amd import ops
+    rng = np.random.default_rng(n)
+    ego = rng.normal(size=(n, 64)).astype(np.float32) * 0.3
+    side = rng.normal(size=(n, 64)).astype(np.float32) * 0.3
+    W_gc, W_bi = (rng.normal(size=(64, 64)).astype(np.float32) * 0.2 for _ in range(2))
+    b_gc, b_bi = (rng.normal(size=64).astype(np.float32) * 0.1 for _ in range(2))
+    g_all = np.zeros((n, 128), np.float32)
+    rows = rng.choice(n, min(n, 96), replace=False)
+    g_all[rows] = rng.normal(size=(len(rows), 128)).astype(np.float32)
+    g_all[: min(n, 40)] = rng.normal(size=(min(n, 40), 128)).astype(np.float32)
+    g_next = None
+    if with_next:
+        g_next = np.zeros((n, 64), np.float32)
+        g_next[rows[:20]] = rng.normal(size=(min(20, len(rows)), 64)).astype(np.float32)
+    if not with_direct:
+        g_all[:, :64] = 0.0                                             # layer > 0 gets no direct term
+    seed, step, layer = 0x1234567890ABCDEF, 7, 0 if with_direct else 1
+    # mask in the kernels' numbering: rows above pad_row count one less
+    n_mask_rows = n - (1 if 0 <= pad_row < n else 0)
+    keep_ref = oracle.message_keep_mask(n_mask_rows, 64, p_drop, seed, step, layer) if p_drop > 0 else None
+    keep = None
+    if keep_ref is not None:
+        keep = keep_ref if not (0 <= pad_row < n) else np.concatenate([keep_ref[: pad_row + 1], keep_ref[pad_row:]])
+        # (the pad row itself shares a mask row with its neighbour; its values are never read)
+    # ---- torch fp64 reference with autograd
+    T = lambda a: torch.from_numpy(a).double().requires_grad_(True)
+    te, ts, tWg, tbg, tWb, tbb = T(ego), T(side), T(W_gc), T(b_gc), T(W_bi), T(b_bi)
+    out_n, e1 = oracle.ngcf_layer_torch(te, ts, tWg, tbg, tWb, tbb, None if keep is None else torch.from_numpy(keep), p_drop)
+    loss = (out_n * torch.from_numpy(g_all[:, 64:]).double()).sum()
+    if g_next is not None:
+        loss = loss + (e1 * torch.from_numpy(g_next).double()).sum()
+    loss.backward()
+    # ---- kernels
+    d_ego, d_side = t(ego), t(side)
+    out = torch.zeros(n, 128 if with_direct else 192, device=DEV)
+    e1_out = torch.empty(n, 64, device=DEV)
+    drop = (p_drop, seed, step) if p_drop > 0 else None
+    ops.ngcf_layer_fwd(d_ego, d_side, t(W_gc), t(b_gc), t(W_bi), t(b_bi), out, layer, with_direct, e1_out, drop=drop,
+                       pad_row=pad_row)
+    sl = slice(64 * (layer + 1), 64 * (layer + 2))
+    assert rel_err(out[:, sl].cpu().numpy(), out_n.detach().numpy()) <= 2e-6
+    assert rel_err(e1_out.cpu().numpy(), e1.detach().numpy()) <= 2e-6
+    if with_direct:
+        assert np.array_equal(out[:, :64].cpu().numpy(), ego)
+    g_full = torch.zeros(n, out.shape[1], device=DEV)
+    g_full[:, sl] = t(g_all[:, 64:])
+    if with_direct:
+        g_full[:, :64] = t(g_all[:, :64])
+    g_side, g_ego = torch.full((n, 64), 7.0, device=DEV), torch.full((n, 64), 7.0, device=DEV)
+    gW_gc, gW_bi = torch.zeros(64, 64, device=DEV), torch.zeros(64, 64, device=DEV)
+    gb_gc, gb_bi = torch.zeros(64, device=DEV), torch.zeros(64, device=DEV)
+    ops.ngcf_layer_bwd(d_ego, d_side, t(W_gc), t(b_gc), t(W_bi), t(b_bi), g_full, layer, None if g_next is None else t(g_next),
+                       g_side, g_ego, gW_gc, gb_gc, gW_bi, gb_bi, drop=drop, pad_row=pad_row)
+    want_gego = te.grad.numpy() + (g_all[:, :64] if with_direct else 0.0)
+    assert rel_err(g_side.cpu().numpy(), ts.grad.numpy()) <= 1e-5
+    assert rel_err(g_ego.cpu().numpy(), want_gego) <= 1e-5
+    for got, want, nm in ((gW_gc, tWg.grad, "W_gc"), (gW_bi, tWb.grad, "W_bi"), (gb_gc, tbg.grad, "b_gc"), (gb_bi, tbb.grad, "b_bi")):
+        assert rel_err(got.cpu().numpy(), want.numpy()) <= 2e-5, nm
+
+
+# ---------------------------------------------------------------------------------------------- model vs G7 (two layers too)
+def test_two_layer_model_gradients_vs_torch_ops_on_the_same_weights(golden):
+    """layer_size [64, 64]: the fused path (NGCFPropagate: g_next chaining, slices of the concatenated table) against the
+    torch-op path of the same module on the same graph (eval mode: no dropout)."""
+    import scipy.sparse as sp
+    from spex_amd.ngcf import NGCF
+    g = golden("ngcf_tiny")
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    adj = sp.csr_matrix((g["val"], g["col"], g["rowptr"]), shape=(nu + ni, nu + ni))
+    torch.manual_seed(5)
+    m = NGCF({"n_users": nu, "n_items": ni, "norm_adj": adj}, DEV, ngcf_args(layer_size="[64,64]", mess_dropout="[0.0,0.0]")).to(DEV)
+    bu, bi, bl = (torch.from_numpy(g[k]) for k in ("batch_users", "batch_items", "batch_labels"))
+    m.train()
+    loss = m(bu, bi, bl, flag=0)
+    loss.backward()
+    got = {k: p.grad.detach().cpu().numpy().copy() for k, p in m.named_parameters()}
+    m.zero_grad()
+    m._fused_ok = lambda: False                                         # same module, torch-op layers
+    loss2 = m(bu, bi, bl, flag=0)
+    loss2.backward()
+    assert abs(loss.item() - loss2.item()) <= 2e-6
+    for k, p in m.named_parameters():
+        assert rel_err(got[k], p.grad.cpu().numpy()) <= 2e-5, k
+
+
+# ---------------------------------------------------------------------------------------------- data + eval + whole run
+def _materialise(root, name, train_pairs, test_pos, test_neg):
+    rec = os.path.join(root, name, "rec")
+    os.makedirs(rec, exist_ok=True)
+    order = np.argsort(train_pairs[:, 0], kind="stable")
+    pairs = train_pairs[order]
+    with open(os.path.join(rec, "train.txt"), "w") as f:
+        users, start = np.unique(pairs[:, 0], return_index=True)
+        for k, u in enumerate(users):
+            end = start[k + 1] if k + 1 < len(users) else len(pairs)
+            f.write(str(u) + "".join(" %d" % i for i in pairs[start[k]:end, 1]) + "\n")
+    with open(os.path.join(rec, "test.txt"), "w") as f:
+        for u, p in test_pos:
+            f.write("%d %d\n" % (u, p))
+    with open(os.path.join(rec, "negative.txt"), "w") as f:
+        for u, negs in test_neg:
+            f.write(str(u) + "".join(" %d" % i for i in negs) + "\n")
+    return os.path.join(root, "")
+
+
+@pytest.fixture(scope="module")
+def ngcf_data_root(tmp_path_factory):
+    root = str(tmp_path_factory.mktemp("ngcf_data"))
+    g = np.load(os.path.join(REPO, "tests", "golden", "ngcf_small_epochs.npz"))
+    _materialise(root, "small", g["train_pairs"], list(enumerate(g["test_pos"])), list(enumerate(g["test_neg"])))
+    e = np.load(os.path.join(REPO, "tests", "golden", "epinion2_dataset.npz"))
+    # NGCF's files for Epinion2 are the same interactions in its own format (data_process_rec.py:277-318)
+    _materialise(root, "epinion2", e["train"].astype(np.int64), list(zip(e["test_users"].astype(int), e["test_pos"].astype(int))),
+                 list(zip(e["test_users"].astype(int), e["test_neg"].astype(np.int64))))
+    return root
+
+
+def _run_reference_loop(ds, n_epochs, g, root):
+    """main_rec.py:116-148 on the drop-in modules: Data, NGCF, torch Adam, the DataLoader of load_train_data, test()."""
+    from spex_amd.dropin.ngcf.utility import batch_test
+    from spex_amd.dropin.ngcf.utility.load_data import Data
+    from spex_amd.ngcf import NGCF
+    torch.manual_seed(int(g["seed"]))
+    random.seed(int(g["seed"]))
+    np.random.seed(int(g["seed"]))
+    data = Data(path=root + ds, batch_size=256)
+    batch_test.use_data(data)
+    assert (data.n_users, data.n_items, data.n_train) == (int(g["n_users"]), int(g["n_items"]), int(g["n_train"]))
+    plain, norm, mean = data.get_adj_mat()
+    p = [float(x) for x in g["mess_dropout"]]
+    model = NGCF({"n_users": data.n_users, "n_items": data.n_items, "norm_adj": norm}, DEV,
+                 ngcf_args(mess_dropout=str(p))).to(DEV)
+    model.message_dropout_seed = int(g["drop_seed"])
+    for k in g.files:                                                     # same initial parameters for the same seed
+        if k.startswith("init_") and not k.endswith("_sha"):
+            name = k[5:].replace("__", ".")
+            assert rel_err(model.state_dict()[name].cpu().numpy(), g[k]) == 0.0, name
+    opt = torch.optim.Adam(model.parameters(), lr=float(g["lr"]))
+    step = 0
+    for epoch in range(n_epochs):
+        loader = data.load_train_data()
+        total = 0.0
+        for k, (user, item, labels) in enumerate(loader):
+            if step == 0:
+                assert np.array_equal(torch.stack([user, item, labels.long()]).numpy(), g["first_batch"])
+            model.train()
+            opt.zero_grad()
+            loss = model(user=user.to(DEV), item=item.to(DEV), labels_list=labels.to(DEV), flag=0)
+            loss.backward()
+            opt.step()
+            li = loss.item()
+            if step < len(g["step_losses"]):
+                assert abs(li - g["step_losses"][step]) <= 2e-5 * max(1.0, abs(g["step_losses"][step])), (step, li)
+            total += li
+            step += 1
+        assert abs(total - g["losses"][epoch]) <= 5e-5 * g["losses"][epoch], (epoch, total, g["losses"][epoch])
+        ret = batch_test.test(model, list(data.test_set.keys()), drop_flag=True)
+        assert np.abs(ret["recall"] - g["recall"][epoch]).max() <= 1e-4, (ret, g["recall"][epoch])
+        assert np.abs(ret["ndcg"] - g["ndcg"][epoch]).max() <= 1e-4
+    assert step == int(g["n_steps"])
+    return model
+
+
+def test_whole_ngcf_run_matches_the_reference_small(golden, ngcf_data_root):
+    """G12-NGCF: three epochs on the 300-user graph — same sampler stream, same first batch, same per-step losses, same
+    loss sums, same recall / ndcg after every epoch, same trained weights as the reference run (message dropout on,
+    masks from the shared counter-based generator)."""
+    g = golden("ngcf_small_epochs")
+    model = _run_reference_loop("small", 3, g, ngcf_data_root)
+    sd = model.state_dict()
+    assert rel_err(sd["user_embedding.weight"].cpu().numpy(), g["user_w"]) <= 5e-5
+    assert rel_err(sd["item_embedding.weight"].cpu().numpy(), g["item_w"]) <= 5e-5
+    for k in g.files:
+        if k.startswith("final_"):
+            assert rel_err(sd[k[6:].replace("__", ".")].cpu().numpy(), g[k]) <= 1e-4, k
+
+
+def test_whole_ngcf_epoch_matches_the_reference_epinion2(golden, ngcf_data_root):
+    """The same at BASELINE config 4's size: one full NGCF epoch on Epinion2 (~4.7 k steps) + test()."""
+    path = os.path.join(REPO, "tests", "golden", "ngcf_epinion2_epochs.npz")
+    if not os.path.exists(path):
+        pytest.skip("ngcf_epinion2_epochs.npz not minted")
+    g = golden("ngcf_epinion2_epochs")
+    model = _run_reference_loop("epinion2", 1, g, ngcf_data_root)
+    sd = model.state_dict()
+    uw, iw = sd["user_embedding.weight"].cpu().numpy(), sd["item_embedding.weight"].cpu().numpy()
+    for got, want in ((uw, g["user_w_colsum"]), (iw, g["item_w_colsum"])):
+        assert np.abs(got.astype(np.float64).sum(0) - want).max() <= 5e-5 * np.abs(want).max()
+    assert rel_err(uw[g["rows_u"]], g["user_w"]) <= 2e-4 and rel_err(iw[g["rows_i"]], g["item_w"]) <= 2e-4
+
+
+def test_ngcf_driver_runs_through_the_launcher(ngcf_data_root):
+    """A main_rec.py-shaped NGCF driver (tests/drivers/ngcf_driver.py: the reference's imports by the reference's names)
+    under `python -m spex_amd.dropin`: trains, evaluates, the loss falls."""
+    script = os.path.join(REPO, "tests", "drivers", "ngcf_driver.py")
+    r = subprocess.run([sys.executable, "-m", "spex_amd.dropin", script, "--data_path", ngcf_data_root, "--dataset", "small",
+                        "--epoch", "3"], capture_output=True, text=True, cwd=REPO, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("epoch ")]
+    assert len(lines) == 3
+    losses = [float(ln.split()[3]) for ln in lines]
+    assert losses[-1] < losses[0]

@@ -267,3 +267,126 @@ def test_epoch_order_is_the_dataloaders_own(tiny_loader):
         order = dataloader_epoch_order(len(td)).numpy()
         got = np.stack([td.users_fill[order], td.items_fill[order], td.labels_fill_np[order]])
         assert np.array_equal(got, want[epoch].numpy())
+
+
+# ---------------------------------------------------------------------------------------------- NGCF host modules (config 4)
+def _write_ngcf_files(root, name, pairs, test_pos, test_neg):
+    rec = os.path.join(root, name, "rec")
+    os.makedirs(rec, exist_ok=True)
+    with open(os.path.join(rec, "train.txt"), "w") as f:
+        for u in np.unique(pairs[:, 0]):
+            f.write(str(u) + "".join(" %d" % i for i in pairs[pairs[:, 0] == u, 1]) + "\n")
+    with open(os.path.join(rec, "test.txt"), "w") as f:
+        for u, p in enumerate(test_pos):
+            f.write("%d %d\n" % (u, p))
+        f.write("\n")                                  # a malformed line is skipped, as the reference's try/except does
+    with open(os.path.join(rec, "negative.txt"), "w") as f:
+        for u, n in enumerate(test_neg):
+            f.write(str(u) + "".join(" %d" % i for i in n) + "\n")
+    return os.path.join(root, name)
+
+
+def test_ngcf_parser_defaults_match_reference_flags():
+    from spex_amd.dropin.ngcf.ngcf_parser import parse_args
+    a = parse_args([])
+    assert (a.dataset, a.embed_size, a.layer_size, a.batch_size, a.lr, a.mess_dropout, a.Ks, a.test_flag, a.adj_type, a.epoch,
+            a.regs, a.data_path) == ("epinion2", 64, "[64]", 256, 0.001, "[0.1]", "[10,20,50]", "part", "norm", 50, "[1e-5]",
+                                     "../Data/")
+    b = parse_args(["--dataset", "twitter", "--layer_size", "[64,64]", "--nonhybrid"])
+    assert b.dataset == "twitter" and b.layer_size == "[64,64]" and b.nonhybrid
+
+
+def test_ngcf_data_object_matches_the_reference(golden, tmp_path):
+    """utility.load_data.Data against the golden minted from NGCF_SPEX/code/utility/load_data.py: sizes, the three
+    adjacency matrices bit for bit (sha-256 of rowptr / col / val), and the negative-sampling stream of one epoch for the
+    same random.seed (the reference's train_sample under a serial pool)."""
+    import random
+    from spex_amd.dropin.ngcf.utility.load_data import Data
+    g = golden("ngcf_small_epochs")
+    path = _write_ngcf_files(str(tmp_path), "small", g["train_pairs"], g["test_pos"], g["test_neg"])
+    d = Data(path, 256)
+    assert (d.n_users, d.n_items, d.n_train, d.n_test) == (int(g["n_users"]), int(g["n_items"]), int(g["n_train"]), 300)
+    assert d.exist_users == list(range(300)) and d.test_set[7] == [int(g["test_pos"][7])]
+    assert d.neg_item[3] == g["test_neg"][3].tolist() and d.R.shape == (300, 200) and d.R.nnz == d.n_train
+    for name, m in zip(("plain", "norm", "mean"), d.get_adj_mat()):
+        assert [sha(m.indptr.astype(np.int32)), sha(m.indices.astype(np.int32)), sha(m.data.astype(np.float32))] == g[name + "_sha"].tolist()
+    random.seed(int(g["seed"]))
+    u, v, r = d.sample_epoch()
+    assert len(u) == int(g["sample_len"]) == 6 * sum(len(d.train_items[k]) for k in range(256))    # whole 256-user blocks only
+    assert [sha(u), sha(v), sha(r)] == g["sample_sha"].tolist()
+    assert np.array_equal(np.stack([u[:4096], v[:4096], r[:4096].astype(np.int64)]), g["sample_head"])
+    # per user: 5 x |pos| DISTINCT negatives outside the user's items, then the positives in file order
+    k = len(d.train_items[0])
+    assert len(set(v[:5 * k].tolist())) == 5 * k and not set(v[:5 * k].tolist()) & set(d.train_items[0])
+    assert v[5 * k:6 * k].tolist() == d.train_items[0] and r[:6 * k].tolist() == [0.0] * (5 * k) + [1.0] * k
+    loader = d.load_train_data()
+    assert loader.batch_size == 256 and len(loader.dataset) == len(u)
+
+
+def test_ngcf_eval_ranking_semantics(golden, tmp_path, monkeypatch):
+    """utility.batch_test.test_torch with the scoring launch replaced by exact host dot products (the GPU path is
+    covered in tests/test_gpu_ngcf.py): the reference's per-user ranking — candidates = negatives then held-out items,
+    ties broken by candidate order, recall over all held-out items — on hand-made tables."""
+    from spex_amd.dropin.ngcf.utility import batch_test
+    from spex_amd.dropin.ngcf.utility.load_data import Data
+    g = golden("ngcf_small_epochs")
+    path = _write_ngcf_files(str(tmp_path), "small", g["train_pairs"], g["test_pos"], g["test_neg"])
+    d = Data(path, 256)
+    batch_test.use_data(d)
+    rng = np.random.default_rng(3)
+    ua = torch.from_numpy(rng.integers(-3, 4, size=(d.n_users, 8)).astype(np.float32))     # small integers: exact, many ties
+    ia = torch.from_numpy(rng.integers(-3, 4, size=(d.n_items, 8)).astype(np.float32))
+    monkeypatch.setattr(batch_test, "_scores", lambda a, b, us, its: (a.numpy()[us] * b.numpy()[its]).sum(1))
+    got = batch_test.test_torch(ua, ia, list(d.test_set.keys()))
+    import heapq
+    want = {"recall": np.zeros(3), "ndcg": np.zeros(3)}
+    rate = ua.numpy() @ ia.numpy().T
+    for u in d.test_set:                                  # the reference's test_one_user, restated (batch_test.py:91-116)
+        items = d.neg_item[u] + d.test_set[u]
+        score = {i: rate[u, i] for i in items}
+        top = heapq.nlargest(50, score, key=score.get)
+        r = [1 if i in d.test_set[u] else 0 for i in top]
+        for j, k in enumerate((10, 20, 50)):
+            want["recall"][j] += sum(r[:k]) / len(d.test_set[u]) / len(d.test_set)
+            dcg = sum(x / np.log2(p + 2) for p, x in enumerate(r[:k]))
+            idcg = sum(x / np.log2(p + 2) for p, x in enumerate(sorted(r, reverse=True)[:k]))
+            want["ndcg"][j] += (dcg / idcg if idcg else 0.0) / len(d.test_set)
+    assert np.abs(got["recall"] - want["recall"]).max() <= 1e-12 and np.abs(got["ndcg"] - want["ndcg"]).max() <= 1e-12
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        monkeypatch.undo()
+        batch_test.test_torch(ua, ia, list(d.test_set.keys()))
+
+
+def test_lightgcn_adjacency_sums_repeated_pairs_like_useritemnet():
+    """A train file that repeats a pair: the reference's UserItemNet = csr_matrix((ones, (u, i))) sums the duplicates
+    (dataloader.py:110), so the entry weighs 2 and both degrees count it twice."""
+    import scipy.sparse as sp
+    from spex_amd.graph import lightgcn_norm_adj
+    u, i, nu, mi = np.array([0, 0, 1, 2, 2, 2]), np.array([1, 1, 0, 2, 2, 0]), 3, 3
+    R = sp.csr_matrix((np.ones(len(u)), (u, i)), shape=(nu + 1, mi)).tolil()
+    adj = sp.dok_matrix((nu + 1 + mi, nu + 1 + mi), dtype=np.float32).tolil()
+    adj[:nu + 1, nu + 1:] = R
+    adj[nu + 1:, :nu + 1] = R.T
+    adj = adj.todok()
+    with np.errstate(divide="ignore"):
+        dinv = np.power(np.array(adj.sum(axis=1)), -0.5).flatten()
+    dinv[np.isinf(dinv)] = 0.0
+    want = sp.diags(dinv).dot(adj).dot(sp.diags(dinv)).tocsr()
+    want.sort_indices()
+    rowptr, col, val = lightgcn_norm_adj(u, i, nu, mi)
+    assert np.array_equal(rowptr, want.indptr) and np.array_equal(col, want.indices)
+    assert np.array_equal(val, want.data.astype(np.float32))
+
+
+def test_message_dropout_mask_is_the_oracles_philox(oracle):
+    """Known-answer test of the philox4x32-10 restatement (Random123's published test vectors), so that the mask the
+    goldens were minted with is pinned independently of the kernels."""
+    k = oracle.philox4x32_10
+    assert [int(x[0]) for x in k([0], [0], [0], [0], 0, 0)] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert [int(x[0]) for x in k([0xffffffff], [0xffffffff], [0xffffffff], [0xffffffff], 0xffffffff, 0xffffffff)] == \
+        [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert [int(x[0]) for x in k([0x243f6a88], [0x85a308d3], [0x13198a2e], [0x03707344], 0xa4093822, 0x299f31d0)] == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    m = oracle.message_keep_mask(500, 64, 0.1, 2020, 3, 0)
+    assert m.shape == (500, 64) and abs(m.mean() - 0.9) < 0.01
+    assert not np.array_equal(m, oracle.message_keep_mask(500, 64, 0.1, 2020, 4, 0))
