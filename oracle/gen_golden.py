@@ -1112,6 +1112,16 @@ def stage_ngcf_epochs(ds, n_epochs):
     losses, recalls, ndcgs, first_batch, step_losses = [], [], [], None, []
     import time
     t0 = time.time()
+    # evaluation in mid-run (does not touch any RNG): at the seeded initial weights — pins the evaluation path alone — and
+    # after 500 / 1 500 steps, to show how fast two fp32 runs with different summation orders drift apart
+    eval_at = {0: None, 500: None, 1500: None}
+
+    def maybe_eval():
+        if state["step"] in eval_at and eval_at[state["step"]] is None:
+            model.eval()
+            r = ref_bt.test(model, list(data_generator.test_set.keys()), drop_flag=True)
+            eval_at[state["step"]] = np.concatenate([r["recall"], r["ndcg"]])
+    maybe_eval()
     for epoch in range(n_epochs):
         ref_ld.multiprocessing.Pool = SerialPool
         data_loader = data_generator.load_train_data()           # main_rec.py:121
@@ -1134,6 +1144,7 @@ def stage_ngcf_epochs(ds, n_epochs):
             if state["step"] < 32:
                 step_losses.append(loss.item())
             state["step"] += 1
+            maybe_eval()
             if state["step"] % 500 == 0:
                 print("step", state["step"], "loss sum", total_loss, "%.0f s" % (time.time() - t0), flush=True)
         losses.append(total_loss)
@@ -1155,7 +1166,9 @@ def stage_ngcf_epochs(ds, n_epochs):
                         mess_dropout=np.asarray(p_drop), n_steps=state["step"],
                         losses=np.asarray(losses, np.float64), step_losses=np.asarray(step_losses, np.float64),
                         recall=np.asarray(recalls, np.float64), ndcg=np.asarray(ndcgs, np.float64),
-                        first_batch=first_batch, user_w=uw, item_w=iw, **out)
+                        first_batch=first_batch, user_w=uw, item_w=iw,
+                        eval_steps=np.asarray([k for k, v in eval_at.items() if v is not None]),
+                        eval_metrics=np.asarray([v for v in eval_at.values() if v is not None]), **out)
     print("ngcf epochs", ds, "losses", losses, "recall", recalls[-1], "ndcg", ndcgs[-1])
 
 

@@ -105,11 +105,15 @@ class PartitionedLightGCN:
             dist.all_gather_into_tensor(out, self.send, group=self.group)
         return out
 
-    def propagate(self, E0_local):
-        """mean_l(A^l E0) for this rank's rows (LightGCN.computer(), model.py:66-97)."""
+    def propagate(self, E0_local, keep_first=False):
+        """mean_l(A^l E0) for this rank's rows (LightGCN.computer(), model.py:66-97).  keep_first: the first layer's
+        all-gathered table (= E0 of every rank, padded layout) is gathered into `self.gathered0` and survives the call
+        (the dual-task model reads the whole user block from it)."""
         cur = E0_local
+        if keep_first and getattr(self, "gathered0", None) is None:
+            self.gathered0 = torch.zeros_like(self.gathered)
         for l in range(self.L):
-            X = self.all_gather_rows(cur)
+            X = self.all_gather_rows(cur, out=self.gathered0 if (keep_first and l == 0) else None)
             last = l == self.L - 1
             nxt = None if last else self.send[: self.n_local]     # next layer's all-gather source, no copy
             self.graph.spmm(X, Y=nxt, acc_in=E0_local if l == 0 else self.light_out, acc_out=self.light_out,
@@ -117,21 +121,28 @@ class PartitionedLightGCN:
             cur = nxt
         if self.L == 0:
             self.light_out.copy_(E0_local)
+            if keep_first:
+                self.all_gather_rows(E0_local, out=self.gathered0)
         return self.light_out
 
     def propagate_bwd(self, g_local, grad_out=None):
-        """d loss / d E0 (local rows) from d loss / d light_out (local rows)."""
-        gs = g_local / float(self.L + 1)
+        """d loss / d E0 (local rows) from d loss / d light_out (local rows).  No allocation after the first call: the
+        scaled gradient g/(L+1) lives in a per-model buffer, every intermediate layer is written straight into the
+        all-gather's send buffer."""
+        if getattr(self, "_gs", None) is None or self._gs.shape != g_local.shape or self._gs.device != g_local.device:
+            self._gs = torch.empty_like(g_local)
+        gs = torch.div(g_local, float(self.L + 1), out=self._gs)
+        if grad_out is None:
+            grad_out = torch.empty_like(gs)
         cur = gs
         for l in range(self.L - 1, -1, -1):
             X = self.all_gather_rows(cur)
-            nxt = (grad_out if (l == 0 and grad_out is not None) else torch.empty_like(gs))
+            nxt = grad_out if l == 0 else self.send[: self.n_local]
             self.graph_t.spmm(X, Y=nxt, add_in=gs, add_div=1.0)
             cur = nxt
-        if self.L == 0 and grad_out is not None:
+        if self.L == 0:
             grad_out.copy_(gs)
-            return grad_out
-        return cur
+        return grad_out
 
     def gather_output(self):
         """Full (padded) propagated table on every rank, for scoring."""
@@ -144,28 +155,29 @@ class PartitionedLightGCN:
         own_idx = torch.nonzero(owner == self.rank).reshape(-1)
         return own_idx, padded_pos[own_idx] - self.rank * self.part.max_rows
 
-    def fetch_rows(self, plan, out):
+    def fetch_rows(self, plan, out, table=None):
         """Rows of the propagated table at a batch's positions, on every rank: each rank writes the rows it owns into
         the zeroed buffer and an all-reduce adds the contributions up — a few MB per batch instead of an all-gather of
         the whole table."""
         own_idx, local = plan
         out.zero_()
-        out.index_copy_(0, own_idx, self.light_out.index_select(0, local))
+        out.index_copy_(0, own_idx, (self.light_out if table is None else table).index_select(0, local))
         if self.world > 1 or self.always_collective:
             dist.all_reduce(out, group=self.group)
         return out
 
-    def fetch_rows_at(self, padded_pos, out):
+    def fetch_rows_at(self, padded_pos, out, table=None):
         """fetch_rows() without a plan: on the GPU one launch writes the owned rows and zero-fills the others
         (spex_gather_owned_rows_f32), then the same all-reduce; on CPU tensors (the gloo tests of the schedule) the
-        plan-based tensor ops."""
+        plan-based tensor ops.  table: the rank's rows of the table to read (default: the propagated table)."""
+        table = self.light_out if table is None else table
         if out.is_cuda:
             from . import ops
-            ops.gather_owned_rows(self.light_out, padded_pos, self.rank * self.part.max_rows, out)
+            ops.gather_owned_rows(table, padded_pos, self.rank * self.part.max_rows, out)
             if self.world > 1 or self.always_collective:
                 dist.all_reduce(out, group=self.group)
             return out
-        return self.fetch_rows(self.plan_rows(padded_pos), out)
+        return self.fetch_rows(self.plan_rows(padded_pos), out, table=table)
 
     def add_owned_rows(self, upd, padded_pos, table_local, clear=True):
         """table_local[owned rows of padded_pos] += upd rows (and clear upd): the owner-computes update."""
@@ -191,31 +203,55 @@ class PartitionedStepper:
     """The exact reference training step (BCE, backward through the propagation, Adam — main_rec.py:32-37) on a
     row-partitioned model.  Every rank holds its rows of E0 and of the Adam moments; the batch is replicated; per step
     the exchanges are the per-layer all-gathers (forward and backward) plus one all-reduce of the batch's 2B
-    propagated rows.  Gradient rows are computed everywhere and each rank keeps the ones it owns (owner-computes)."""
+    propagated rows.  Gradient rows are computed everywhere and each rank keeps the ones it owns (owner-computes).
 
-    def __init__(self, part_model, E0_local, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
-        from . import ops
+    A step is a fixed sequence of launches and collectives on pre-allocated buffers — no host synchronisation, no
+    allocation: L x (all-gather, SpMM), gather-owned-rows, all-reduce, scoring, scatter-add-owned-rows, one scaling
+    pass, L x (all-gather, SpMM), Adam (which also clears the gradient table for the next step).
+    `ops`: the kernel namespace (spex_amd.ops on the GPU; the CPU tests of the schedule inject a stand-in)."""
+
+    def __init__(self, part_model, E0_local, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, ops=None):
+        if ops is None:
+            from . import ops
         self.ops, self.P, self.E0 = ops, part_model, E0_local
         self.lr, self.betas, self.eps, self.t = lr, betas, eps, 0
         self.m, self.v = torch.zeros_like(E0_local), torch.zeros_like(E0_local)
-        self.g_local = torch.zeros_like(E0_local)
+        self.g_local = torch.zeros_like(E0_local)          # invariant: all-zero between steps (cleared by the Adam pass)
         self.grad_E0 = torch.zeros_like(E0_local)
+        self._B = -1
 
-    def step_bce(self, users, items, labels):
+    def _buffers(self, B, dev):
+        if B != self._B:
+            d = self.P.d
+            self.rows = torch.zeros((2 * B, d), dtype=torch.float32, device=dev)
+            self.grad_rows = torch.zeros((2 * B, d), dtype=torch.float32, device=dev)   # all-zero between steps too
+            ar = torch.arange(B, device=dev)
+            self.ar_u, self.ar_i = ar, ar + B
+            self._B = B
+
+    def positions(self, users, items):
+        """The batch's rows in the padded gathered layout ([users | items], int64 on the model's device).  A loop that
+        knows its batches ahead (an epoch's shuffled samples) computes these once for the whole epoch."""
+        dev = self.E0.device
+        pu, pi = self.P.padded_index(users.to(dev), items.to(dev))
+        return torch.cat([pu, pi])
+
+    def step_bce(self, users, items, labels, pos=None, loss_acc=None):
+        """One training step.  Returns the batch's mean BCE loss (device tensor) — or, with `loss_acc` (a 1-element device
+        buffer), accumulates the loss SUM into it and returns None."""
         P, ops = self.P, self.ops
         dev = self.E0.device
-        users, items = users.to(dev), items.to(dev)
         B = users.numel()
+        self._buffers(B, dev)
+        if pos is None:
+            pos = self.positions(users, items)
         P.propagate(self.E0)
-        pu, pi = P.padded_index(users, items)
-        plan = P.plan_rows(torch.cat([pu, pi]))
-        rows = P.fetch_rows(plan, torch.empty((2 * B, P.d), dtype=torch.float32, device=dev))
-        grad_rows = torch.zeros_like(rows)
-        ar = torch.arange(B, device=dev)
-        _, loss_sum = ops.score_bce(rows, rows, ar, ar + B, labels.to(dev), grad_rows, grad_rows, 1.0 / B)
-        self.g_local.zero_()
-        self.g_local.index_add_(0, plan[1], grad_rows.index_select(0, plan[0]))
+        rows = P.fetch_rows_at(pos, self.rows)
+        _, loss_sum = ops.score_bce(rows, rows, self.ar_u, self.ar_i, labels.to(dev), self.grad_rows, self.grad_rows, 1.0 / B,
+                                    loss_sum=loss_acc, want_gamma=False)
+        P.add_owned_rows(self.grad_rows, pos, self.g_local, clear=True)
         P.propagate_bwd(self.g_local, grad_out=self.grad_E0)
         self.t += 1
-        ops.adam_step(self.E0, self.grad_E0, self.m, self.v, self.t, self.lr, self.betas[0], self.betas[1], self.eps)
-        return loss_sum / B
+        ops.adam_step(self.E0, self.grad_E0, self.m, self.v, self.t, self.lr, self.betas[0], self.betas[1], self.eps,
+                      zero=self.g_local)
+        return None if loss_acc is not None else loss_sum / B

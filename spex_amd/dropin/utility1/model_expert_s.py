@@ -100,7 +100,10 @@ class LightGCN(_RecLightGCN):
                 ops.expert_gate(raw_i.detach().contiguous(), out_i.contiguous(), self.att_exp2.detach()))
 
     # ------------------------------------------------------------------ trust branch
-    def compute_scores(self, hidden, inputs, mask):
+    def compute_scores(self, hidden, inputs, mask, user_table=None):
+        """user_table: the [n_users + 1, H] user embedding table the logits are taken against (default: this module's own
+        parameter; the row-partitioned model passes the all-gathered block)."""
+        table = self.embedding_user.weight if user_table is None else user_table
         B = mask.shape[0]
         last = torch.sum(mask, 1) - 1
         ht = _rows(hidden.reshape(-1, hidden.shape[2]), torch.arange(B, device=hidden.device) * hidden.shape[1] + last)
@@ -110,24 +113,24 @@ class LightGCN(_RecLightGCN):
         a = torch.sum(alpha * hidden * mask.view(B, -1, 1).float(), 1)
         # the reference leaves p_a undefined under --nonhybrid (NameError at :141); use the pooled vector there
         p_a = a if self.nonhybrid else self.linear_transform(torch.cat([a, ht], 1))
-        b = self.embedding_user.weight[:-1]
-        p_i = _rows(self.embedding_user.weight, inputs) * mask.unsqueeze(2)
+        b = table[:-1]
+        p_i = _rows(table, inputs) * mask.unsqueeze(2)
         p_maxpool = torch.max(p_i, dim=1)[0]
         att = torch.softmax(torch.cat([p_a, p_maxpool], 1) @ self.att_t, 1)
         a = p_a * att[:, 0].unsqueeze(1) + p_maxpool * att[:, 1].unsqueeze(1)
         return a @ b.t()
 
-    def _trust_scores(self, inputs, mask):
-        dev = self.embedding_user.weight.device
+    def _trust_scores(self, inputs, mask, user_table=None):
+        emb = self.embedding_user.weight if user_table is None else user_table
+        dev = emb.device
         inputs = torch.as_tensor(np.asarray(inputs), device=dev).long()
         mask = torch.as_tensor(np.asarray(mask), device=dev).long()
         seq_l = torch.sum(mask, 1)
-        emb = self.embedding_user.weight
         heads = torch.stack([att.a.view(-1) for att in self.in_att])                           # [heads, 2H]
         mul_seq = ops.path_attention(emb, inputs, seq_l, heads, True)                          # [B, L, heads*H], one launch
         mul_one = F.elu(mul_seq.reshape(-1, mul_seq.shape[2]) @ self.w)
         hidden = self.out_att(emb, mul_one.view(mul_seq.shape[0], mul_seq.shape[1], self.hidden_size), seq_l)
-        return self.compute_scores(hidden, inputs, mask)
+        return self.compute_scores(hidden, inputs, mask, user_table)
 
     # ------------------------------------------------------------------ forward (:150-193)
     def forward(self, users, items, labels, slice_indices=None, trust_data=None, flag=0):

@@ -1,7 +1,14 @@
 """Trust-task evaluation behind the reference's `utility2.batch_test_gnn` (trust_test5, :27-44): for each test path the
 model's scores over all users are restricted to the path's candidate list (negatives then the true next user, last),
 the top 50 taken, and recall/ndcg@{10,20,50} computed for the target's position — batched per slice instead of per
-row."""
+row.
+
+Ranking is done where the reference does it: the slice's [B, 500] candidate scores (gathered on the device) are moved
+to the host and ranked by the same torch.topk.  That matters because the reference's own candidate lists repeat the
+target in ~15 % of the test paths (Data_process/path/data_process_path.py:199-204 looks the last user's friends up
+with an int key in a dict keyed by strings, so nothing is excluded from the negative pool): the two copies tie exactly,
+only the last one counts as the hit (:36-37), and which copy ranks first is topk's tie order — which differs between
+the CPU and the GPU implementation and moves NDCG@10 by 0.014 on Epinion2."""
 import numpy as np
 import torch
 
@@ -27,7 +34,7 @@ def trust_test5(model, test_data):
     with torch.no_grad():
         for slice_indices in test_data.generate_batch(model.batch_size):
             scores, cand = model(None, None, None, slice_indices, test_data, 2)
-            top = torch.gather(scores, 1, cand.to(scores.device)).topk(50, dim=1)[1].cpu().numpy()
+            top = torch.gather(scores, 1, cand.to(scores.device)).cpu().topk(50, dim=1)[1].numpy()
             rel = (top == cand.shape[1] - 1).astype(np.float64)                 # the target is the last candidate
             rec, ndcg = metrics.rank_metrics_batch(rel, Ks, np.ones(len(rel)))
             total[:3] += rec.sum(0)

@@ -154,3 +154,158 @@ def test_rccl_backend_smoke_world_size_one(tmp_path):
     ref = g.propagate(torch.from_numpy(np.concatenate([uw, iw])).cuda(), 3).cpu().numpy()
     assert np.array_equal(d["lo"], ref)
     assert np.isfinite(float(d["loss"]))
+
+
+# ---------------------------------------------------------------------------------------------- BASELINE config 3 shape
+def _weibo():
+    from spex_amd.datasets import synthetic_interactions, xavier_uniform_np
+    from spex_amd.graph import lightgcn_norm_adj
+    u, i = synthetic_interactions(6812, 20000, 400000, seed=7)
+    csr = lightgcn_norm_adj(u.numpy(), i.numpy(), 6812, 20000)
+    return csr, xavier_uniform_np(len(csr[0]) - 1, 64, np.random.default_rng(1)), 6813
+
+
+def _weibo_batches(steps, B=256):
+    rng = np.random.default_rng(3)
+    return [(rng.integers(0, 6812, B), rng.integers(0, 20000, B), (rng.random(B) < 1 / 6).astype(np.float32)) for _ in range(steps)]
+
+
+def _weibo_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from spex_amd.dist import PartitionedLightGCN, PartitionedStepper
+    from spex_amd.graph import SpexGraph
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    csr, E0, n_u = _weibo()
+    P = PartitionedLightGCN(*csr, n_u, 3, 64, rank, world,
+                            lambda r, c, v, n_cols: SpexGraph(r, c, v, n_cols=n_cols, device=dev), dev)
+    E0_local = torch.from_numpy(E0[P.r0:P.r1].copy()).to(dev)
+    lo = P.propagate(E0_local).clone()
+    grad = P.propagate_bwd(torch.from_numpy(E0[::-1].copy()[P.r0:P.r1].copy()).to(dev)).clone()
+    st = PartitionedStepper(P, E0_local, lr=1e-3)
+    acc = torch.zeros(1, device=dev)
+    batches = _weibo_batches(4)
+    losses = [st.step_bce(torch.from_numpy(bu).to(dev), torch.from_numpy(bi).to(dev), torch.from_numpy(by).to(dev)).item()
+              for bu, bi, by in batches[:2]]
+    pos = [st.positions(torch.from_numpy(bu), torch.from_numpy(bi)) for bu, bi, _ in batches[2:]]       # precomputed form
+    before = torch.cuda.memory_allocated()
+    for (bu, bi, by), p in zip(batches[2:], pos):
+        st.step_bce(torch.from_numpy(bu).to(dev), torch.from_numpy(bi).to(dev), torch.from_numpy(by).to(dev), pos=p, loss_acc=acc)
+    assert torch.cuda.memory_allocated() <= before + 3 * 256 * 8 + 4096          # nothing but the uploaded batch
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), lo=lo.cpu().numpy(), grad=grad.cpu().numpy(), r0=P.r0, r1=P.r1,
+             trained=E0_local.cpu().numpy(), losses=np.asarray(losses), acc=acc.item(), hubs=P.graph.n_long_rows)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_gpu_weibo_shaped_graph(tmp_path):
+    """BASELINE config 3's shape (6 812 users, hubs beyond 1 024 entries cut across shards, empty rows) row-partitioned
+    over two ranks on the GPU: forward and backward bit-identical to the single-device HIP result, four exact training
+    steps through the launch-only PartitionedStepper (positions precomputed for the last two) within 5e-6 of the
+    single-device stepper."""
+    from spex_amd.graph import SpexGraph
+    from spex_amd.trainer import LightGCNStepper
+    world = 2
+    mp.spawn(_weibo_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    csr, E0, n_u = _weibo()
+    g = SpexGraph(*csr)
+    ref = g.propagate(torch.from_numpy(E0).cuda(), 3).cpu().numpy()
+    ref_grad = g.propagate_bwd(torch.from_numpy(E0[::-1].copy()).cuda(), 3).cpu().numpy()
+    st = LightGCNStepper(g, torch.from_numpy(E0.copy()).cuda(), n_u, n_layers=3, lr=1e-3)
+    ref_losses = [st.step_bce(torch.from_numpy(bu).cuda(), torch.from_numpy(bi).cuda(), torch.from_numpy(by).cuda()).item()
+                  for bu, bi, by in _weibo_batches(4)]
+    lo, grad, trained = np.zeros_like(ref), np.zeros_like(ref), np.zeros_like(ref)
+    hubs = 0
+    for r in range(world):
+        d = np.load(tmp_path / f"rank{r}.npz")
+        r0, r1 = int(d["r0"]), int(d["r1"])
+        lo[r0:r1], grad[r0:r1], trained[r0:r1] = d["lo"], d["grad"], d["trained"]
+        assert np.allclose(d["losses"], ref_losses[:2], rtol=0, atol=2e-6)
+        assert abs(float(d["acc"]) - 256 * (ref_losses[2] + ref_losses[3])) <= 2e-3
+        hubs += int(d["hubs"] > 0)
+    assert hubs == world                                  # long rows on both shards
+    assert np.array_equal(lo, ref) and np.array_equal(grad, ref_grad)
+    want = st.E0.cpu().numpy()
+    assert np.abs(trained - want).max() <= 5e-6 * np.abs(want).max()
+
+
+# ---------------------------------------------------------------------------------------------- BASELINE config 5: partitioned dual-task
+def _dual_worker(rank, world, port, out_dir, data_root, n_steps):
+    import random
+    import sys
+    from collections import defaultdict
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "spex_amd", "dropin"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from torch.utils.data import DataLoader
+    import lg_parser
+    import utility1.dataloader as dl
+    import utility1.model_expert_s as mex
+    import utility1.utils as utils
+    from utility2.utils import Data
+    from spex_amd.dist_dual import PartitionedDualTask
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    t = np.load(os.path.join(GOLDEN, "trust_epinion2_paths.npz"))
+    raw_train = ([r[:l].tolist() for r, l in zip(t["train_paths"].astype(np.int64), t["train_len"])],
+                 t["train_targets"].astype(np.int64).tolist())
+    args = lg_parser.parse_args_r(["--dataset", "epinion2", "--data_path", data_root])
+    utils.set_seed(args.seed)                                             # every rank: the same seeds => the same batches
+    dataset = dl.Loader(args)
+    loader = DataLoader(dl.LightTrainData(dataset.rec_train_data, dataset.m_item, dataset.train_mat), batch_size=256, shuffle=True)
+    by_user = defaultdict(list)
+    for k, p in enumerate(raw_train[0]):
+        by_user[p[0]].append(k)
+    train2 = Data(raw_train, dataset.n_users, shuffle=False)
+    cap = 3 * (len(raw_train[0]) // len(loader))
+    core = mex.LightGCN(args, dataset).to(dev)
+    model = PartitionedDualTask(core, dataset.build_adjacency(), rank, world, dev)
+    opt = torch.optim.Adam(model.trained_parameters(), lr=args.lr)
+    loader.dataset.ng_sample()
+    core.train()
+    l1s, l2s, n_paths = [], [], []
+    for step, (user, item, label) in enumerate(loader):
+        if step == n_steps:
+            break
+        opt.zero_grad()
+        chosen = []
+        for u in set(user.numpy().tolist()):
+            chosen.extend(by_user[u])
+        if len(chosen) > cap:
+            chosen = random.sample(chosen, cap)
+        l1, l2 = model(user, item, label, np.array(chosen, dtype=int), train2)
+        w = model.task_weights
+        (torch.exp(-2 * w[0]) * l1 + torch.exp(-2 * w[1]) * l2 + 2 * 6 * len(user) * w[0] + len(chosen) * w[1]).backward()
+        model.reduce_gate_gradients()
+        opt.step()
+        l1s.append(l1.item()); l2s.append(l2.item()); n_paths.append(len(chosen))
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), loss1=np.asarray(l1s), loss2=np.asarray(l2s), n_paths=np.asarray(n_paths),
+             r0=model.P.r0, r1=model.P.r1, table=model.E0_local.detach().cpu().numpy(),
+             task_weights=model.task_weights.detach().cpu().numpy(), att_exp1=core.att_exp1.detach().cpu().numpy(),
+             w=core.w.detach().cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_dual_task_training_matches_the_reference_epinion2(tmp_path, golden):
+    """BASELINE config 5 (dual-task, row-partitioned) with two ranks on the GPU, on Epinion2 + the reference-minted trust
+    paths: the first 16 training steps of main_auto_expert_s.py (same seeds on both ranks => same batches and paths)
+    reproduce the REFERENCE's per-step losses of both tasks (golden G13, minted from the reference's single-process run),
+    and both ranks hold identical replicated parameters afterwards."""
+    from spex_amd.datasets import materialise_epinion2
+    g = golden("dual_epinion2_epochs")
+    root = materialise_epinion2(str(tmp_path / "data"))
+    world, n_steps = 2, len(g["loss1_first"])
+    mp.spawn(_dual_worker, args=(world, _free_port(), str(tmp_path), root, n_steps), nprocs=world, join=True)
+    d = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    for r in range(world):
+        assert np.array_equal(d[r]["n_paths"], g["n_paths"][:n_steps].astype(int))
+        assert np.abs(d[r]["loss1"] - g["loss1_first"]).max() <= 2e-5, (r, d[r]["loss1"], g["loss1_first"])
+        assert (np.abs(d[r]["loss2"] - g["loss2_first"]) <= 1e-4 * g["loss2_first"]).all(), r
+    for k in ("task_weights", "att_exp1", "w"):
+        assert np.abs(d[0][k] - d[1][k]).max() <= 1e-6 * max(1.0, np.abs(d[0][k]).max()), k
+    assert int(d[0]["r1"]) == int(d[1]["r0"]) and int(d[1]["r1"]) == 3186 + 12407
