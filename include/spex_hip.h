@@ -37,7 +37,7 @@ typedef enum spex_status {
 
 typedef struct spex_graph spex_graph_t;
 
-int spex_version(void);                 /* ABI version, currently 1 */
+int spex_version(void);                 /* ABI version, currently 2 (1 + the NGCF layer fwd/bwd and grouped BPR entries) */
 const char *spex_last_error(void);      /* thread-local, never NULL */
 
 /* ------------------------------------------------------------------------------------------------ graph handle
@@ -156,6 +156,26 @@ int spex_bpr_sgd_step_f32(const float *U_read, const float *I_read, float *U_w, 
 int spex_bpr_loss_f32(const float *users, const float *items, int64_t n_user_rows, int64_t n_item_rows,
                       const int64_t *u, const int64_t *i_pos, const int64_t *i_neg, int64_t T, int32_t d,
                       float *loss_sum, float *grad_users, float *grad_items, float grad_scale, void *stream);
+
+/* The two BPR entry points above without one float atomic per gathered row, for large batches (d == 64).  The batch's
+ * 3 T row updates are binned on the device by destination row (buckets of 64 rows of the joint [users | items] index
+ * space, two-phase counting partition), accumulated per bucket in LDS and flushed to the tables once per touched row —
+ * the arithmetic and the result (up to fp32 re-association of a row's contributions) are those of spex_bpr_sgd_step_f32 /
+ * spex_bpr_loss_f32, which stay the right call below ~16 k triples (one launch, latency-bound).
+ * Batch-synchronous only: the read tables must differ from the updated ones.
+ * ws: caller-owned device scratch, 256-byte aligned, at least spex_bpr_grouped_workspace_bytes(T, n_user_rows,
+ * n_item_rows) bytes; that function returns 0 when the grouped form does not apply (more than 8192 * 64 rows, T >= 2^30):
+ * use the atomic form then.  Four launches on `stream`, no host synchronisation, no allocation.
+ */
+int64_t spex_bpr_grouped_workspace_bytes(int64_t T, int64_t n_user_rows, int64_t n_item_rows);
+int spex_bpr_sgd_step_grouped_f32(const float *U_read, const float *I_read, float *U_w, float *I_w, int64_t n_user_rows,
+                                  int64_t n_item_rows, const int64_t *u, const int64_t *i_pos, const int64_t *i_neg,
+                                  int64_t T, int32_t d, float lr, float reg, float *loss_sum, void *ws, int64_t ws_bytes,
+                                  void *stream);
+int spex_bpr_loss_grouped_f32(const float *users, const float *items, int64_t n_user_rows, int64_t n_item_rows,
+                              const int64_t *u, const int64_t *i_pos, const int64_t *i_neg, int64_t T, int32_t d,
+                              float *loss_sum, float *grad_users, float *grad_items, float grad_scale, void *ws,
+                              int64_t ws_bytes, void *stream);
 
 /* Owner-computes exchange of a batch's rows on a 1-D row-partitioned table ("replicate the batch on all
  * ranks (owner-computes, no comm)" needs the batch's rows of the propagated table everywhere).  pos: device int64[K]

@@ -31,6 +31,11 @@ SIGNATURES = {
                                              c_f32, c_f32, c_vp, c_vp]),
     "spex_bpr_loss_f32": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp,
                                          c_f32, c_vp]),
+    "spex_bpr_grouped_workspace_bytes": (c_i64, [c_i64, c_i64, c_i64]),
+    "spex_bpr_sgd_step_grouped_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32,
+                                                     c_f32, c_f32, c_vp, c_vp, c_i64, c_vp]),
+    "spex_bpr_loss_grouped_f32": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp,
+                                                 c_f32, c_vp, c_i64, c_vp]),
     "spex_gather_owned_rows_f32": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_vp, c_vp]),
     "spex_scatter_add_owned_rows_f32": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_vp, c_i32, c_vp]),
     "spex_adam_step_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp]),

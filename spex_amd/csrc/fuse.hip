@@ -23,9 +23,7 @@ constexpr int kMaxCols = 4;      // d <= 256
 
 __device__ __forceinline__ float wave_sum(float v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
-    return v;
+    return wave_sum_f32(v);
 }
 
 // parameter block of one branch: w1[(U ? d : 0) + d], b1, w2, b2

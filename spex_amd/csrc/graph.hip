@@ -18,7 +18,7 @@ void set_error(const char *fmt, ...)
 }
 }  // namespace spex
 
-extern "C" int spex_version(void) { return 1; }
+extern "C" int spex_version(void) { return 2; }
 extern "C" const char *spex_last_error(void) { return spex::g_err; }
 
 template <typename T>

@@ -16,9 +16,7 @@ namespace {
 
 __device__ __forceinline__ float wave_sum(float v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
-    return v;
+    return wave_sum_f32(v);
 }
 
 __device__ __forceinline__ float bcast(float v, int src)
@@ -164,8 +162,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void ngcf_layer_kernel(
             float v = 0.0f;
 #pragma unroll
             for (int b = 0; b < 4; ++b) v = fmaf(e1[b][q], e1[b][q], v);
-#pragma unroll
-            for (int off = 8; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
+            v = row16_sum_f32(v);
             sq[q] = v;
         }
 #pragma unroll
@@ -314,8 +311,7 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
                 e1d[b][q] = e;
                 v = fmaf(e, e, v);
             }
-#pragma unroll
-            for (int off = 8; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
+            v = row16_sum_f32(v);
             sq[q] = v;
         }
 #pragma unroll
@@ -325,8 +321,7 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
             float v = 0.0f;
 #pragma unroll
             for (int b = 0; b < 4; ++b) v = fmaf(gn[b][q], e1d[b][q] / den, v);
-#pragma unroll
-            for (int off = 8; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
+            v = row16_sum_f32(v);
             dot[q] = (nrm >= 1e-12f) ? v : 0.0f;                // below eps the clamp holds the denominator constant
 #pragma unroll
             for (int b = 0; b < 4; ++b) {

@@ -24,9 +24,7 @@ constexpr int kMaxCols = 4;      // d <= 256: columns per lane held in registers
 
 __device__ __forceinline__ float wave_sum(float v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
-    return v;
+    return wave_sum_f32(v);
 }
 
 struct PathArgs {

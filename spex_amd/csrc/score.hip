@@ -22,9 +22,12 @@ constexpr int kScoreWaves = 16;
 
 __device__ __forceinline__ float wave_sum(float v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
-    return v;
+    return wave_sum_f32(v);
+}
+
+__device__ __forceinline__ float lane_bcast_f(float v, int src)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
 
 __device__ __forceinline__ float softplus_f(float x) { return fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x))); }
@@ -158,6 +161,292 @@ __global__ __launch_bounds__(kWave *kScoreWaves) void bpr_kernel(
     if (loss_sum) block_loss_add(lsum, loss_sum);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Grouped BPR update: the same arithmetic without a float atomic per gathered row.
+//
+// The atomic form above adds three 256-byte rows per triple with hardware float atomics and is bound by their chip-wide
+// rate (~1.3 TB/s of added bytes: 0.32 of the HBM roofline at T = 2^20).  Here the batch's 3 T (triple, role) entries
+// are sorted by DESTINATION row first — a two-phase counting partition into buckets of 64 rows (user rows and item rows
+// in separate buckets), then a 64-bin counting sort inside the workgroup that owns a bucket slice — so that 64
+// consecutive entries belong to one or two rows: a wave sums a run of equal rows in a register and adds it to the table
+// with ONE 256-byte float atomic per run (~2 per 64 entries: ~1.5 % of the atomic form's atomic traffic).
+// Sorting by destination also removes the separate scoring pass: for the entries whose destination is the USER row the
+// wave holds U[u] for the whole run, gathers I[i-] and I[i+] (which it needs for the update anyway), and has the triple's
+// score <U[u], I[i-] - I[i+]> for one DPP reduction; it stores coef_t = a sigmoid(x_t) for the two item-destination entries
+// of the triple, which then cost one gather (U[u]) each.  Gathers per triple: 4 (the atomic form: 3, plus 3 atomic rows).
+//
+//   k_count    thread per triple: per-workgroup LDS histogram of the three destination buckets -> global counts
+//   k_scan     one workgroup: exclusive scans of the counts (entry offsets) and of ceil(count / slice) (first workgroup
+//              of each bucket); clears the cursors
+//   k_scatter  thread per entry: per-workgroup LDS histogram again, ONE global cursor add per bucket and workgroup
+//              reserves a range; entries (triple * 4 + role, row within the bucket) land bucket by bucket
+//   k_users    workgroup per (user bucket, slice of <= 4096 entries): row sort in LDS, scores + loss + coef_t + user rows
+//   k_items    the same for the item buckets, reading coef_t
+// What was tried first and measured (T = 2^20, Epinion2's tables): accumulating a bucket in LDS with ds_add_f32 — one such
+// wave-instruction costs ~200 cycles, 3 M of them 1.06 ms of a 1.34 ms kernel; and 64-lane dot products through
+// __shfl_xor — six ds_bpermute_b32 each on the CU's single LDS pipe, 184 us for 2 M dot products with the gathers removed.
+// Sums inside a run are accumulated in arrival order: like the atomic form, results agree with the closed form to fp32
+// re-association (<= 1e-5 relative), not bit for bit.
+constexpr int kBucketRows = 64;
+constexpr int kSliceEntries = 2048;
+constexpr int kMaxBuckets = 8192;      // LDS histogram of k_count / k_scatter: 32 KB
+constexpr int kBinThreads = 1024;
+
+struct BprGroupedArgs {
+    const float *U_read, *I_read;
+    float *U_w, *I_w;
+    const int64_t *u, *ip, *in;
+    int64_t T, n_user_rows, n_item_rows;
+    float a_coef, b_coef;
+    float *loss_sum;
+    float *coef;          // [T]
+    uint32_t *ent_key;    // [3T] triple * 4 + role (0: user row, 1: positive item row, 2: negative item row)
+    uint32_t *ent_row;    // [3T] destination row within its bucket
+    int32_t *count;       // [n_buckets]
+    int32_t *offset;      // [n_buckets + 1] entry offsets
+    int32_t *wg_first;    // [n_buckets + 1] first update workgroup of each bucket
+    int32_t *cursor;      // [n_buckets]
+    int32_t n_user_buckets, n_buckets;   // user buckets come first
+};
+
+__device__ __forceinline__ bool bpr_valid(const BprGroupedArgs &a, int64_t u, int64_t ip, int64_t in)
+{
+    return u >= 0 && u < a.n_user_rows && ip >= 0 && ip < a.n_item_rows && in >= 0 && in < a.n_item_rows;
+}
+
+__global__ __launch_bounds__(kBinThreads) void bpr_count_kernel(const BprGroupedArgs a)
+{
+    __shared__ int s_hist[kMaxBuckets];
+    for (int b = threadIdx.x; b < a.n_buckets; b += blockDim.x) s_hist[b] = 0;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < a.T; t += stride) {
+        const int64_t u = a.u[t], ip = a.ip[t], in = a.in[t];
+        if (!bpr_valid(a, u, ip, in)) continue;
+        atomicAdd(&s_hist[(int)(u / kBucketRows)], 1);
+        atomicAdd(&s_hist[a.n_user_buckets + (int)(ip / kBucketRows)], 1);
+        atomicAdd(&s_hist[a.n_user_buckets + (int)(in / kBucketRows)], 1);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < a.n_buckets; b += blockDim.x)
+        if (s_hist[b]) atomicAdd(a.count + b, s_hist[b]);
+}
+
+__global__ __launch_bounds__(1024) void bpr_bucket_scan_kernel(const BprGroupedArgs a)
+{
+    __shared__ int s_ent[1024], s_wg[1024];
+    // each thread owns a contiguous run of buckets; two scans at once
+    const int per = (a.n_buckets + 1023) / 1024;
+    const int b0 = threadIdx.x * per, b1 = min(b0 + per, a.n_buckets);
+    int e = 0, w = 0;
+    for (int b = b0; b < b1; ++b) {
+        const int c = a.count[b];
+        e += c;
+        w += (c + kSliceEntries - 1) / kSliceEntries;
+    }
+    s_ent[threadIdx.x] = e;
+    s_wg[threadIdx.x] = w;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {       // Hillis-Steele inclusive scan over the 1024 partial sums
+        int ve = 0, vw = 0;
+        if ((int)threadIdx.x >= off) {
+            ve = s_ent[threadIdx.x - off];
+            vw = s_wg[threadIdx.x - off];
+        }
+        __syncthreads();
+        s_ent[threadIdx.x] += ve;
+        s_wg[threadIdx.x] += vw;
+        __syncthreads();
+    }
+    e = s_ent[threadIdx.x] - e;                      // exclusive prefix of this thread's run
+    w = s_wg[threadIdx.x] - w;
+    for (int b = b0; b < b1; ++b) {
+        const int c = a.count[b];
+        a.offset[b] = e;
+        a.wg_first[b] = w;
+        a.cursor[b] = 0;
+        e += c;
+        w += (c + kSliceEntries - 1) / kSliceEntries;
+    }
+    if (threadIdx.x == 1023) {
+        a.offset[a.n_buckets] = s_ent[1023];
+        a.wg_first[a.n_buckets] = s_wg[1023];
+    }
+}
+
+__global__ __launch_bounds__(kBinThreads) void bpr_bin_scatter_kernel(const BprGroupedArgs a)
+{
+    __shared__ int s_hist[kMaxBuckets];     // counts, then this workgroup's next slot per bucket
+    for (int b = threadIdx.x; b < a.n_buckets; b += blockDim.x) s_hist[b] = 0;
+    __syncthreads();
+    // a workgroup owns a contiguous range of triples; a thread handles a triple's three entries
+    const int64_t per_wg = (a.T + gridDim.x - 1) / gridDim.x;
+    const int64_t t0 = (int64_t)blockIdx.x * per_wg, t1 = min(t0 + per_wg, a.T);
+    for (int64_t t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
+        const int64_t u = a.u[t], ip = a.ip[t], in = a.in[t];
+        if (!bpr_valid(a, u, ip, in)) continue;
+        atomicAdd(&s_hist[(int)(u / kBucketRows)], 1);
+        atomicAdd(&s_hist[a.n_user_buckets + (int)(ip / kBucketRows)], 1);
+        atomicAdd(&s_hist[a.n_user_buckets + (int)(in / kBucketRows)], 1);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < a.n_buckets; b += blockDim.x) {
+        const int c = s_hist[b];
+        s_hist[b] = c ? a.offset[b] + atomicAdd(a.cursor + b, c) : 0;   // reserve [base, base + c) in bucket b
+    }
+    __syncthreads();
+    for (int64_t t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
+        const int64_t u = a.u[t], ip = a.ip[t], in = a.in[t];
+        if (!bpr_valid(a, u, ip, in)) continue;
+        const uint32_t key = (uint32_t)t * 4u;
+        int slot = atomicAdd(&s_hist[(int)(u / kBucketRows)], 1);
+        a.ent_key[slot] = key;
+        a.ent_row[slot] = (uint32_t)(u % kBucketRows);
+        slot = atomicAdd(&s_hist[a.n_user_buckets + (int)(ip / kBucketRows)], 1);
+        a.ent_key[slot] = key + 1u;
+        a.ent_row[slot] = (uint32_t)(ip % kBucketRows);
+        slot = atomicAdd(&s_hist[a.n_user_buckets + (int)(in / kBucketRows)], 1);
+        a.ent_key[slot] = key + 2u;
+        a.ent_row[slot] = (uint32_t)(in % kBucketRows);
+    }
+}
+
+// USERS: the bucket holds user rows (entries of role 0); else item rows (roles 1 and 2).
+template <bool USERS>
+__global__ __launch_bounds__(kWave *kScoreWaves) void bpr_bucket_update_kernel(const BprGroupedArgs a)
+{
+    __shared__ uint32_t s_key[kSliceEntries], s_row[kSliceEntries];
+    __shared__ int s_bin[kBucketRows], s_cur[kBucketRows];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int b_lo = USERS ? 0 : a.n_user_buckets, b_hi = USERS ? a.n_user_buckets : a.n_buckets;
+    const int wg = blockIdx.x + a.wg_first[b_lo];
+    float lsum = 0.0f;
+    if (wg < a.wg_first[b_hi]) {                          // (workgroup-uniform; the loss reduction below needs every wave)
+        int lo = b_lo, hi = b_hi;                         // which bucket: the last b with wg_first[b] <= wg
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (a.wg_first[mid] <= wg) lo = mid; else hi = mid;
+        }
+        const int bucket = lo;
+        const int slice = wg - a.wg_first[bucket];
+        const int beg = a.offset[bucket] + slice * kSliceEntries;
+        const int end = min(beg + kSliceEntries, a.offset[bucket + 1]);
+        const int n_ent = end - beg;
+        const int64_t row0 = (int64_t)(bucket - b_lo) * kBucketRows;
+        // ---- counting sort of the slice by destination row (64 bins), in LDS
+        if (threadIdx.x < kBucketRows) s_bin[threadIdx.x] = 0;
+        __syncthreads();
+        constexpr int kPerThread = kSliceEntries / (kWave * kScoreWaves);      // 4
+        uint32_t my_key[kPerThread], my_row[kPerThread];
+#pragma unroll
+        for (int j = 0; j < kPerThread; ++j) {
+            const int e = threadIdx.x + j * kWave * kScoreWaves;
+            my_row[j] = 0xFFFFFFFFu;
+            if (e < n_ent) {
+                my_key[j] = a.ent_key[beg + e];
+                my_row[j] = a.ent_row[beg + e];
+                atomicAdd(&s_bin[my_row[j]], 1);
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {                                  // exclusive scan of the 64 bins by one wave
+            const int c = s_bin[lane];
+            int incl = c;
+#pragma unroll
+            for (int off = 1; off < kWave; off <<= 1) {
+                const int v = __shfl_up(incl, off, kWave);
+                if (lane >= off) incl += v;
+            }
+            s_cur[lane] = incl - c;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kPerThread; ++j) {
+            if (my_row[j] != 0xFFFFFFFFu) {
+                const int pos = atomicAdd(&s_cur[my_row[j]], 1);
+                s_key[pos] = my_key[j];
+                s_row[pos] = my_row[j];
+            }
+        }
+        __syncthreads();
+        // ---- a wave takes 64 consecutive sorted entries at a time: lane k resolves entry k, the wave walks them with
+        //      v_readlane, a batch of gathers in flight at a time
+        float *__restrict__ dst_tab = USERS ? a.U_w : a.I_w;
+        const float *__restrict__ Ul = a.U_read + lane, *__restrict__ Il = a.I_read + lane;
+        for (int base = wave * kWave; base < n_ent; base += kScoreWaves * kWave) {
+            const int n = min(kWave, n_ent - base);
+            int m_t = 0, m_r = 0, m_a = 0, m_b = 0;       // triple, destination row in the bucket, source rows
+            float m_c = 0.0f;
+            if (lane < n) {
+                const uint32_t key = s_key[base + lane];
+                m_t = (int)(key >> 2);
+                m_r = (int)s_row[base + lane];
+                if (USERS) {
+                    m_a = (int)a.in[m_t];                 // v = c (I[i-] - I[i+]),  c = a sigmoid(<U[u], I[i-] - I[i+]>)
+                    m_b = (int)a.ip[m_t];
+                } else {
+                    const float c = a.coef[m_t];          // v = -c U[u] (positive item) / +c U[u] (negative item)
+                    m_c = (key & 3u) == 1u ? -c : c;
+                    m_a = (int)a.u[m_t];
+                }
+            }
+            // walk the chunk run by run (a run = consecutive entries with the same destination row)
+            for (int i = 0; i < n;) {
+                const int cur = __builtin_amdgcn_readlane(m_r, i);
+                const unsigned long long other = __ballot(lane > i && lane < n && m_r != cur);
+                const int run_end = other ? (int)__builtin_ctzll(other) : n;
+                float own = 0.0f;                           // the destination's own row: scores (users) / regularisation
+                if (USERS) own = Ul[(size_t)(row0 + cur) * kWave];
+                else if (a.b_coef != 0.0f) own = Il[(size_t)(row0 + cur) * kWave];
+                float acc = a.b_coef != 0.0f ? a.b_coef * own * (float)(run_end - i) : 0.0f;
+                constexpr int kBatch = USERS ? 8 : 16;
+                for (; i < run_end; i += kBatch) {
+                    const int nb = min(kBatch, run_end - i);
+                    float xa[kBatch];
+#pragma unroll
+                    for (int j = 0; j < kBatch; ++j) {
+                        const int k = j < nb ? i + j : i + nb - 1;  // a ragged batch re-reads its last entry (unused)
+                        const uint32_t ra = (uint32_t)__builtin_amdgcn_readlane(m_a, k);
+                        if (USERS) {
+                            xa[j] = Il[(size_t)ra * kWave] - Il[(size_t)(uint32_t)__builtin_amdgcn_readlane(m_b, k) * kWave];
+                        } else {
+                            xa[j] = Ul[(size_t)ra * kWave];
+                        }
+                    }
+                    if (USERS) {
+                        // scores of the batch, entry j's into lane j; then sigmoid / softplus for all of them at once
+                        float x_mine = 0.0f;
+#pragma unroll
+                        for (int j = 0; j < kBatch; ++j) {
+                            const float x = wave_sum(own * xa[j]);           // <U[u], I[i-] - I[i+]> = neg score - pos score
+                            if (lane == j) x_mine = x;
+                        }
+                        float c_mine = 0.0f;
+                        const int t_mine = __shfl(m_t, (i + lane) & (kWave - 1), kWave);   // (every lane active: a bpermute
+                        if (lane < nb) {                                                    //  reads 0 from inactive lanes)
+                            c_mine = a.a_coef * sigmoid_f(x_mine);
+                            lsum += softplus_f(x_mine);
+                            a.coef[t_mine] = c_mine;
+                        }
+#pragma unroll
+                        for (int j = 0; j < kBatch; ++j) acc += lane_bcast_f(c_mine, j) * xa[j];   // (lanes >= nb hold 0)
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < kBatch; ++j)
+                            if (j < nb) acc += lane_bcast_f(m_c, i + j) * xa[j];
+                    }
+                }
+                i = run_end;
+                atomicAdd(dst_tab + (size_t)(row0 + cur) * kWave + lane, acc);
+            }
+        }
+    }
+    if (USERS && a.loss_sum) {
+        lsum = wave_sum(lsum);
+        block_loss_add(lsum, a.loss_sum);
+    }
+}
+
 // consecutive triples per wave: 1 until the batch fills the chip a few times over, then up to 16
 inline int bpr_per_wave(int64_t T)
 {
@@ -240,6 +529,92 @@ extern "C" int spex_bpr_sgd_step_f32(const float *U_read, const float *I_read, f
                        -lr / (float)T, -lr * reg / (float)T, loss_sum, per_wave);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
+}
+
+extern "C" int64_t spex_bpr_grouped_workspace_bytes(int64_t T, int64_t n_user_rows, int64_t n_item_rows)
+{
+    if (T < 0 || n_user_rows < 0 || n_item_rows < 0) return -1;
+    const int64_t n_buckets = (n_user_rows + kBucketRows - 1) / kBucketRows + (n_item_rows + kBucketRows - 1) / kBucketRows;
+    if (n_buckets > kMaxBuckets || T >= ((int64_t)1 << 30)) return 0;      // not supported: use the atomic form
+    // coef [T] | ent_key [3T] | ent_row [3T] | count, cursor [n_buckets] | offset, wg_first [n_buckets + 1], 256-B aligned parts
+    auto up = [](int64_t b) { return (b + 255) / 256 * 256; };
+    return up(4 * T) + 2 * up(12 * T) + 2 * up(4 * n_buckets) + 2 * up(4 * (n_buckets + 1));
+}
+
+// Shared by the fused-SGD and the gradient form (same contract as bpr_kernel: a_coef multiplies sigmoid(x), b_coef the row).
+static int launch_bpr_grouped(const float *U_read, const float *I_read, float *U_w, float *I_w, int64_t n_user_rows,
+                              int64_t n_item_rows, const int64_t *u, const int64_t *i_pos, const int64_t *i_neg, int64_t T,
+                              float a_coef, float b_coef, float *loss_sum, void *ws, int64_t ws_bytes, hipStream_t stream)
+{
+    const int64_t need = spex_bpr_grouped_workspace_bytes(T, n_user_rows, n_item_rows);
+    if (need <= 0) {
+        spex::set_error("grouped BPR: %lld rows / %lld triples are outside the grouped form's range (use the atomic form)",
+                        (long long)(n_user_rows + n_item_rows), (long long)T);
+        return SPEX_ERR_UNSUPPORTED;
+    }
+    SPEX_CHECK_ARG(ws && ws_bytes >= need && (((uintptr_t)ws) & 255) == 0, "grouped BPR: workspace of %lld bytes (256-B aligned) needed, got %lld",
+                   (long long)need, (long long)ws_bytes);
+    auto up = [](int64_t b) { return (b + 255) / 256 * 256; };
+    BprGroupedArgs a;
+    a.U_read = U_read; a.I_read = I_read; a.U_w = U_w; a.I_w = I_w; a.u = u; a.ip = i_pos; a.in = i_neg;
+    a.T = T; a.n_user_rows = n_user_rows; a.n_item_rows = n_item_rows; a.a_coef = a_coef; a.b_coef = b_coef; a.loss_sum = loss_sum;
+    a.n_user_buckets = (int32_t)((n_user_rows + kBucketRows - 1) / kBucketRows);
+    a.n_buckets = a.n_user_buckets + (int32_t)((n_item_rows + kBucketRows - 1) / kBucketRows);
+    char *p = (char *)ws;
+    a.coef = (float *)p; p += up(4 * T);
+    a.ent_key = (uint32_t *)p; p += up(12 * T);
+    a.ent_row = (uint32_t *)p; p += up(12 * T);
+    a.count = (int32_t *)p; p += up(4 * (int64_t)a.n_buckets);
+    a.cursor = (int32_t *)p; p += up(4 * (int64_t)a.n_buckets);
+    a.offset = (int32_t *)p; p += up(4 * ((int64_t)a.n_buckets + 1));
+    a.wg_first = (int32_t *)p;
+    SPEX_HIP(hipMemsetAsync(a.count, 0, 4 * (size_t)a.n_buckets, stream));
+    int64_t bin_blocks = (T + (int64_t)kBinThreads * 4 - 1) / ((int64_t)kBinThreads * 4);
+    if (bin_blocks > 1024) bin_blocks = 1024;
+    if (bin_blocks < 1) bin_blocks = 1;
+    hipLaunchKernelGGL(bpr_count_kernel, dim3((unsigned)bin_blocks), dim3(kBinThreads), 0, stream, a);
+    hipLaunchKernelGGL(bpr_bucket_scan_kernel, dim3(1), dim3(1024), 0, stream, a);
+    hipLaunchKernelGGL(bpr_bin_scatter_kernel, dim3((unsigned)bin_blocks), dim3(kBinThreads), 0, stream, a);
+    // upper bounds of sum_b ceil(count_b / slice): every bucket wastes at most one partial slice
+    const int64_t wg_users = a.n_user_buckets + (T + kSliceEntries - 1) / kSliceEntries;
+    const int64_t wg_items = (a.n_buckets - a.n_user_buckets) + (2 * T + kSliceEntries - 1) / kSliceEntries;
+    hipLaunchKernelGGL((bpr_bucket_update_kernel<true>), dim3((unsigned)wg_users), dim3(kWave * kScoreWaves), 0, stream, a);
+    hipLaunchKernelGGL((bpr_bucket_update_kernel<false>), dim3((unsigned)wg_items), dim3(kWave * kScoreWaves), 0, stream, a);
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}
+
+extern "C" int spex_bpr_sgd_step_grouped_f32(const float *U_read, const float *I_read, float *U_w, float *I_w,
+                                             int64_t n_user_rows, int64_t n_item_rows, const int64_t *u, const int64_t *i_pos,
+                                             const int64_t *i_neg, int64_t T, int32_t d, float lr, float reg, float *loss_sum,
+                                             void *ws, int64_t ws_bytes, void *stream)
+{
+    SPEX_CHECK_ARG(U_read && I_read && U_w && I_w && u && i_pos && i_neg, "spex_bpr_sgd_step_grouped_f32: NULL pointer");
+    SPEX_CHECK_ARG(T >= 0, "spex_bpr_sgd_step_grouped_f32: T=%lld", (long long)T);
+    SPEX_CHECK_ARG(U_read != U_w && I_read != I_w, "spex_bpr_sgd_step_grouped_f32: batch-synchronous form only (read tables must differ from the updated tables)");
+    if (d != kWave) {
+        spex::set_error("spex_bpr_sgd_step_grouped_f32: d == 64 only (got %d): use spex_bpr_sgd_step_f32", d);
+        return SPEX_ERR_UNSUPPORTED;
+    }
+    if (T == 0) return SPEX_OK;
+    return launch_bpr_grouped(U_read, I_read, U_w, I_w, n_user_rows, n_item_rows, u, i_pos, i_neg, T, -lr / (float)T,
+                              -lr * reg / (float)T, loss_sum, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int spex_bpr_loss_grouped_f32(const float *users, const float *items, int64_t n_user_rows, int64_t n_item_rows,
+                                         const int64_t *u, const int64_t *i_pos, const int64_t *i_neg, int64_t T, int32_t d,
+                                         float *loss_sum, float *grad_users, float *grad_items, float grad_scale, void *ws,
+                                         int64_t ws_bytes, void *stream)
+{
+    SPEX_CHECK_ARG(users && items && u && i_pos && i_neg && grad_users && grad_items, "spex_bpr_loss_grouped_f32: NULL pointer");
+    SPEX_CHECK_ARG(T >= 0, "spex_bpr_loss_grouped_f32: T=%lld", (long long)T);
+    if (d != kWave) {
+        spex::set_error("spex_bpr_loss_grouped_f32: d == 64 only (got %d): use spex_bpr_loss_f32", d);
+        return SPEX_ERR_UNSUPPORTED;
+    }
+    if (T == 0) return SPEX_OK;
+    return launch_bpr_grouped(users, items, grad_users, grad_items, n_user_rows, n_item_rows, u, i_pos, i_neg, T, grad_scale, 0.0f,
+                              loss_sum, ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int spex_bpr_loss_f32(const float *users, const float *items, int64_t n_user_rows, int64_t n_item_rows,

@@ -41,6 +41,40 @@ constexpr int kSoftmaxTile = 2048; // stored entries per workgroup of the row-so
 
 }  // namespace spex
 
+// Cross-lane sums on the vector ALU's DPP path.  `__shfl_xor` compiles to ds_bpermute_b32 — an LDS-pipe instruction, one
+// pipe per CU shared by four SIMDs — and a 64-lane butterfly is six of them per value: the scoring kernels' dot
+// products were bound by that pipe, not by their gathers (2 M dot products of a 2^20-triple BPR batch: 184 us with the
+// gathers removed).  These use DPP row shifts / broadcasts instead (no LDS traffic).
+namespace spex {
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ float dpp_f32(float v)   // source lane per CTRL; lanes without a valid source read 0
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, true));
+}
+
+// Sum over the 64 lanes, returned to every lane (the value is wave-uniform: it comes back through an SGPR).
+__device__ __forceinline__ float wave_sum_f32(float v)
+{
+    v += dpp_f32<0xb1>(v);          // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4e>(v);          // quad_perm [2,3,0,1]   every lane: its quad's sum
+    v += dpp_f32<0x114>(v);         // row_shr:4
+    v += dpp_f32<0x118>(v);         // row_shr:8             lane 15 of each row: the row's sum
+    v += dpp_f32<0x142, 0xa>(v);    // row_bcast:15 into rows 1 and 3
+    v += dpp_f32<0x143, 0xc>(v);    // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// Sum over each row of 16 lanes, returned to every lane of the row (rotations within the row).
+__device__ __forceinline__ float row16_sum_f32(float v)
+{
+    v += dpp_f32<0x128>(v);         // row_ror:8
+    v += dpp_f32<0x124>(v);         // row_ror:4
+    v += dpp_f32<0x122>(v);         // row_ror:2
+    v += dpp_f32<0x121>(v);         // row_ror:1
+    return v;
+}
+}  // namespace spex
+
 struct spex_timer {
     std::vector<hipEvent_t> start, stop;
     int32_t used = 0;

@@ -62,29 +62,67 @@ def score_bce(users_tab, items_tab, u_idx, i_idx, labels=None, grad_users=None, 
     return gamma, loss_sum
 
 
-def bpr_sgd_step(U_read, I_read, U_w, I_w, u, i_pos, i_neg, lr, reg=0.0, loss_sum=None):
+GROUPED_BPR_MIN_TRIPLES = 1 << 18    # below this the single launch of the atomic form wins (measured crossover ~200 k triples)
+_bpr_ws = {}
+
+
+def _bpr_workspace(T, n_u, n_i, device):
+    """Scratch of the grouped BPR form, cached per device and grown on demand (None when the form does not apply)."""
+    need = _lib.load().spex_bpr_grouped_workspace_bytes(int(T), int(n_u), int(n_i))
+    if need <= 0:
+        return None
+    ws = _bpr_ws.get(device)
+    if ws is None or ws.numel() < need:
+        ws = _bpr_ws[device] = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=device)
+    return ws
+
+
+def bpr_sgd_step(U_read, I_read, U_w, I_w, u, i_pos, i_neg, lr, reg=0.0, loss_sum=None, grouped=None):
     """Fused gather + dot + sigmoid + SGD over triples (north-star extension).  Returns the loss *sum* tensor
-    (accumulated into `loss_sum` when the caller provides — and zeroes — the buffer)."""
+    (accumulated into `loss_sum` when the caller provides — and zeroes — the buffer).
+    grouped: None = pick (the LDS-bucketed form from GROUPED_BPR_MIN_TRIPLES triples up, d == 64, batch-synchronous
+    tables), True / False = force (spex_bpr_sgd_step_grouped_f32 / spex_bpr_sgd_step_f32)."""
     for t, n in ((U_read, "U_read"), (I_read, "I_read"), (U_w, "U_w"), (I_w, "I_w")):
         _need(t, n)
     dev = U_read.device
     u, i_pos, i_neg = _idx(u, dev), _idx(i_pos, dev), _idx(i_neg, dev)
     if loss_sum is None:
         loss_sum = torch.zeros(1, dtype=torch.float32, device=dev)
-    _launch(U_read.device, "spex_bpr_sgd_step_f32", _ptr(U_read), _ptr(I_read), _ptr(U_w), _ptr(I_w), U_read.shape[0], I_read.shape[0],
-              _ptr(u), _ptr(i_pos), _ptr(i_neg), u.numel(), U_read.shape[1], float(lr), float(reg), _ptr(loss_sum))
+    T = u.numel()
+    can_group = (U_read.shape[1] == 64 and U_read.data_ptr() != U_w.data_ptr() and I_read.data_ptr() != I_w.data_ptr())
+    ws = _bpr_workspace(T, U_read.shape[0], I_read.shape[0], dev) if (can_group and grouped is not False) else None
+    if grouped is None:
+        grouped = ws is not None and T >= GROUPED_BPR_MIN_TRIPLES
+    if grouped:
+        if ws is None:
+            raise ValueError("bpr_sgd_step: the grouped form needs d == 64, batch-synchronous tables and <= 8192 * 64 rows")
+        _launch(dev, "spex_bpr_sgd_step_grouped_f32", _ptr(U_read), _ptr(I_read), _ptr(U_w), _ptr(I_w), U_read.shape[0],
+                I_read.shape[0], _ptr(u), _ptr(i_pos), _ptr(i_neg), T, U_read.shape[1], float(lr), float(reg), _ptr(loss_sum),
+                _ptr(ws), ws.numel())
+    else:
+        _launch(dev, "spex_bpr_sgd_step_f32", _ptr(U_read), _ptr(I_read), _ptr(U_w), _ptr(I_w), U_read.shape[0], I_read.shape[0],
+                _ptr(u), _ptr(i_pos), _ptr(i_neg), T, U_read.shape[1], float(lr), float(reg), _ptr(loss_sum))
     _bump(U_w, I_w, loss_sum)
     return loss_sum
 
 
-def bpr_loss_grad(users_tab, items_tab, u, i_pos, i_neg, grad_users=None, grad_items=None, grad_scale=0.0):
+def bpr_loss_grad(users_tab, items_tab, u, i_pos, i_neg, grad_users=None, grad_items=None, grad_scale=0.0, grouped=None):
     _need(users_tab, "users_tab"); _need(items_tab, "items_tab")
     dev = users_tab.device
     u, i_pos, i_neg = _idx(u, dev), _idx(i_pos, dev), _idx(i_neg, dev)
     loss_sum = torch.zeros(1, dtype=torch.float32, device=dev)
-    _launch(users_tab.device, "spex_bpr_loss_f32", _ptr(users_tab), _ptr(items_tab), users_tab.shape[0], items_tab.shape[0], _ptr(u),
-              _ptr(i_pos), _ptr(i_neg), u.numel(), users_tab.shape[1], _ptr(loss_sum), _ptr(grad_users),
-              _ptr(grad_items), float(grad_scale))
+    T = u.numel()
+    ws = None
+    if grad_users is not None and users_tab.shape[1] == 64 and grouped is not False and (grouped or T >= GROUPED_BPR_MIN_TRIPLES):
+        ws = _bpr_workspace(T, users_tab.shape[0], items_tab.shape[0], dev)
+    if ws is not None:
+        _launch(dev, "spex_bpr_loss_grouped_f32", _ptr(users_tab), _ptr(items_tab), users_tab.shape[0], items_tab.shape[0],
+                _ptr(u), _ptr(i_pos), _ptr(i_neg), T, users_tab.shape[1], _ptr(loss_sum), _ptr(grad_users), _ptr(grad_items),
+                float(grad_scale), _ptr(ws), ws.numel())
+    else:
+        _launch(dev, "spex_bpr_loss_f32", _ptr(users_tab), _ptr(items_tab), users_tab.shape[0], items_tab.shape[0], _ptr(u),
+                _ptr(i_pos), _ptr(i_neg), T, users_tab.shape[1], _ptr(loss_sum), _ptr(grad_users),
+                _ptr(grad_items), float(grad_scale))
     _bump(grad_users, grad_items)
     return loss_sum
 

@@ -45,7 +45,7 @@ def G():
 # ---------------------------------------------------------------------------------------------- SpMM
 def test_library_is_the_hip_build():
     from spex_amd import _lib
-    assert _lib.load().spex_version() == 1
+    assert _lib.load().spex_version() == 2
 
 
 @pytest.mark.parametrize("d", [64, 32, 100, 128, 256, 1])
@@ -312,7 +312,8 @@ def test_score_bce_vs_oracle(oracle):
     assert np.isnan(g3[3]) and np.array_equal(np.delete(g3, 3), np.delete(gamma.cpu().numpy(), 3))
 
 
-def test_bpr_kernels_vs_closed_form(oracle):
+@pytest.mark.parametrize("grouped", [False, True])
+def test_bpr_kernels_vs_closed_form(oracle, grouped):
     from spex_amd import ops
     rng = np.random.default_rng(5)
     U, I, T = 200, 400, 3000
@@ -320,17 +321,18 @@ def test_bpr_kernels_vs_closed_form(oracle):
     u, p, n = rng.integers(0, U, T), rng.integers(0, I, T), rng.integers(0, I, T)
     loss_o, Un, In = oracle.bpr_sgd(Ut, It, Ut, It, u, p, n, lr=0.05, reg=1e-3)
     Uw, Iw = t(Ut.copy()), t(It.copy())
-    loss = ops.bpr_sgd_step(t(Ut), t(It), Uw, Iw, t(u), t(p), t(n), lr=0.05, reg=1e-3)
+    loss = ops.bpr_sgd_step(t(Ut), t(It), Uw, Iw, t(u), t(p), t(n), lr=0.05, reg=1e-3, grouped=grouped)
     assert abs(loss.item() / T - loss_o) <= 1e-6
     assert rel_err(Uw.cpu().numpy(), Un) <= 1e-5 and rel_err(Iw.cpu().numpy(), In) <= 1e-5
     # gradient form: finite-difference free check through the closed form (lr=-1 on a zero table == gradient)
     _, dU, dI = oracle.bpr_sgd(Ut, It, np.zeros_like(Ut), np.zeros_like(It), u, p, n, lr=-1.0, reg=0.0)
     gu, gi = torch.zeros(U, 64, device=DEV), torch.zeros(I, 64, device=DEV)
-    ops.bpr_loss_grad(t(Ut), t(It), t(u), t(p), t(n), gu, gi, 1.0 / T)
+    ops.bpr_loss_grad(t(Ut), t(It), t(u), t(p), t(n), gu, gi, 1.0 / T, grouped=grouped)
     assert rel_err(gu.cpu().numpy(), dU) <= 1e-5 and rel_err(gi.cpu().numpy(), dI) <= 1e-5
 
 
-def test_bpr_kernel_run_accumulation_large_batch(oracle):
+@pytest.mark.parametrize("grouped", [False, True])
+def test_bpr_kernel_run_accumulation_large_batch(oracle, grouped):
     """Large batches give a wave several consecutive triples; runs of equal user / positive item are accumulated in
     registers and flushed once.  Sampler order (5 negatives per pair, pairs sorted by user), a shuffled copy, and a few
     out-of-range triples (skipped): all must match the closed form."""
@@ -346,12 +348,12 @@ def test_bpr_kernel_run_accumulation_large_batch(oracle):
         uu, pp, nn = u[order], p[order], n[order]
         loss_o, Un, In = oracle.bpr_sgd(Ut, It, Ut, It, uu, pp, nn, lr=0.5, reg=1e-3)
         Uw, Iw = t(Ut.copy()), t(It.copy())
-        loss = ops.bpr_sgd_step(t(Ut), t(It), Uw, Iw, t(uu), t(pp), t(nn), lr=0.5, reg=1e-3)
+        loss = ops.bpr_sgd_step(t(Ut), t(It), Uw, Iw, t(uu), t(pp), t(nn), lr=0.5, reg=1e-3, grouped=grouped)
         assert abs(loss.item() / len(uu) - loss_o) <= 2e-6
         assert rel_err(Uw.cpu().numpy(), Un) <= 1e-5 and rel_err(Iw.cpu().numpy(), In) <= 1e-5
         _, dU, dI = oracle.bpr_sgd(Ut, It, np.zeros_like(Ut), np.zeros_like(It), uu, pp, nn, lr=-1.0, reg=0.0)
         gu, gi = torch.zeros(U, 64, device=DEV), torch.zeros(I, 64, device=DEV)
-        ops.bpr_loss_grad(t(Ut), t(It), t(uu), t(pp), t(nn), gu, gi, 1.0 / len(uu))
+        ops.bpr_loss_grad(t(Ut), t(It), t(uu), t(pp), t(nn), gu, gi, 1.0 / len(uu), grouped=grouped)
         assert rel_err(gu.cpu().numpy(), dU) <= 1e-5 and rel_err(gi.cpu().numpy(), dI) <= 1e-5
     # out-of-range indices are skipped, the rest of the wave's run is unaffected
     bad = u.copy()
@@ -359,8 +361,44 @@ def test_bpr_kernel_run_accumulation_large_batch(oracle):
     keep = bad < U
     _, Un, In = oracle.bpr_sgd(Ut, It, Ut, It, u[keep], p[keep], n[keep], lr=0.5 * keep.sum() / len(u), reg=0.0)
     Uw, Iw = t(Ut.copy()), t(It.copy())
-    ops.bpr_sgd_step(t(Ut), t(It), Uw, Iw, t(bad), t(p), t(n), lr=0.5, reg=0.0)
+    ops.bpr_sgd_step(t(Ut), t(It), Uw, Iw, t(bad), t(p), t(n), lr=0.5, reg=0.0, grouped=grouped)
     assert rel_err(Uw.cpu().numpy(), Un) <= 1e-5 and rel_err(Iw.cpu().numpy(), In) <= 1e-5
+
+
+def test_grouped_bpr_hot_rows_many_buckets_and_dispatch(oracle):
+    """The LDS-bucketed BPR form at its edges: (a) every triple on the same user and a handful of items — one bucket cut
+    into many slices, the atomic flush path; (b) tables of 25 000 rows (391 buckets, most of them with a single
+    workgroup: the plain-store flush) with Zipf-distributed items; (c) the automatic choice: atomic form below
+    GROUPED_BPR_MIN_TRIPLES, grouped form from there up, and the in-place (hogwild) call never grouped."""
+    from spex_amd import ops
+    rng = np.random.default_rng(23)
+    # (a)
+    U, I, T = 70, 130, 50000
+    Ut, It = rng.normal(size=(U, 64)).astype(np.float32) * 0.2, rng.normal(size=(I, 64)).astype(np.float32) * 0.2
+    u, p, n = np.full(T, 5), rng.integers(0, 3, T), rng.integers(100, 104, T)
+    loss_o, Un, In = oracle.bpr_sgd(Ut, It, Ut, It, u, p, n, lr=0.3, reg=0.0)
+    Uw, Iw = t(Ut.copy()), t(It.copy())
+    loss = ops.bpr_sgd_step(t(Ut), t(It), Uw, Iw, t(u), t(p), t(n), lr=0.3, reg=0.0, grouped=True)
+    assert abs(loss.item() / T - loss_o) <= 2e-6
+    assert rel_err(Uw.cpu().numpy(), Un) <= 2e-5 and rel_err(Iw.cpu().numpy(), In) <= 2e-5
+    # (b)
+    U, I, T = 5000, 20000, 300000
+    Ut, It = rng.normal(size=(U, 64)).astype(np.float32) * 0.1, rng.normal(size=(I, 64)).astype(np.float32) * 0.1
+    u = rng.integers(0, U, T)
+    p = np.minimum((rng.zipf(1.3, T) - 1), I - 1)
+    n = rng.integers(0, I, T)
+    loss_o, Un, In = oracle.bpr_sgd(Ut, It, Ut, It, u, p, n, lr=0.5, reg=1e-3)
+    Uw, Iw = t(Ut.copy()), t(It.copy())
+    loss = ops.bpr_sgd_step(t(Ut), t(It), Uw, Iw, t(u), t(p), t(n), lr=0.5, reg=1e-3)          # auto: grouped
+    assert abs(loss.item() / T - loss_o) <= 2e-6
+    assert rel_err(Uw.cpu().numpy(), Un) <= 1e-5 and rel_err(Iw.cpu().numpy(), In) <= 1e-5
+    untouched = np.setdiff1d(np.arange(I), np.union1d(p, n))
+    assert np.array_equal(Iw.cpu().numpy()[untouched], It[untouched])                         # rows nobody names are not written
+    # (c)
+    assert ops._lib.load().spex_bpr_grouped_workspace_bytes(1000, 8192 * 64, 1) == 0           # too many rows: not offered
+    tab = t(Ut.copy())
+    with pytest.raises(ValueError):
+        ops.bpr_sgd_step(tab, t(It), tab, t(It.copy()), t(u), t(p), t(n), lr=0.1, grouped=True)  # in place: atomic form only
 
 
 def test_adam_kernel_vs_oracle(oracle):
