@@ -125,6 +125,39 @@ def main():
                                 lambda r, c, v, n_cols: SpexGraph(r, c, v, n_cols=n_cols, device=dev), dev)
         graph = P.graph
         E0_local = torch.from_numpy(E0_host[P.r0:P.r1].copy()).to(dev)
+        # The per-layer exchange: RCCL's all-gather, or direct peer writes over the xGMI mesh (spex_amd.dist.PeerAllGather).
+        # SPEX_ALLGATHER = collective | peer | auto (default): auto builds the peer path, checks that it gathers the same
+        # table, times ten propagations each way and keeps the faster; any failure leaves the collective in place.
+        ag_mode = os.environ.get("SPEX_ALLGATHER", "auto")
+        ag_info = {"requested": ag_mode, "used": "collective"}
+        if ag_mode in ("peer", "auto"):
+            try:
+                ref = P.propagate(E0_local).clone()
+                P.set_allgather("peer")
+                same = torch.equal(P.propagate(E0_local), ref)
+                ok = torch.tensor([1.0 if same else 0.0], device=dev)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if ok.item() != 1.0:
+                    raise RuntimeError("peer all-gather produced a different table")
+                times = {}
+                for mode in ("collective", "peer"):
+                    P.set_allgather(mode)
+                    for _ in range(3):
+                        P.propagate(E0_local)
+                    torch.cuda.synchronize(); dist.barrier()
+                    t_ = time.perf_counter()
+                    for _ in range(10):
+                        P.propagate(E0_local)
+                    torch.cuda.synchronize()
+                    tt_ = torch.tensor([time.perf_counter() - t_], device=dev, dtype=torch.float64)
+                    dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+                    times[mode] = tt_.item() / 10
+                use = "peer" if (ag_mode == "peer" or times["peer"] < times["collective"]) else "collective"
+                P.set_allgather(use)
+                ag_info.update(used=use, propagate_ms_collective=times["collective"] * 1e3, propagate_ms_peer=times["peer"] * 1e3)
+            except Exception as e:      # noqa: BLE001 — the collective path always works
+                P.use_peer = False
+                ag_info["peer_error"] = repr(e)[:300]
         pu, pp = P.padded_index(tu, tp)
         _, pn = P.padded_index(tu, tn)
         pos_all = torch.cat([pu, pp, pn])
@@ -148,6 +181,13 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # Python's cyclic GC: a full collection walks every object torch / scipy / numpy created at import — ~40 ms, which
+    # lands once inside any loop longer than ~900 steps (tools/stall_probe.py: 100-step chunks take 2.9 ms of host time,
+    # the chunk with the collection 40-44 ms).  The step loops create no cycles: move everything allocated so far out
+    # of the collector's reach, as a long-running training loop would — before ANY measurement below.
+    gc.collect()
+    gc.freeze()
 
     # ---- stand-alone rates of the pieces (same process, same data).  They run BEFORE the timed region: every bench run
     # makes them anyway, and in front they also bring the GPU to its steady clocks before the K timed steps (the
@@ -233,20 +273,18 @@ def main():
         except Exception as e:  # never lose the headline line to an auxiliary measurement
             aux["aux_error"] = repr(e)
 
-    for _ in range(a.warmup):
-        step()
-    # Python's cyclic GC: a full collection walks every object torch / scipy / numpy created at import — ~40 ms, which
-    # lands once inside any timed region longer than ~900 steps (tools/stall_probe.py: 100-step chunks take 2.9 ms of
-    # host time, the chunk with the collection 40-44 ms).  The step loop creates no cycles: move everything allocated
-    # so far out of the collector's reach, as a long-running training loop would.
-    gc.collect()
-    gc.freeze()
     # one hipEvent pair around the SpMM launches of every n-th propagation of the timed region (three back-to-back
     # launches share the ~3 us an event pair costs on the stream; bracketing single launches charged it to each).
     # At most ~100 brackets per run: with 400 outstanding timing events the runtime's bookkeeping slowed every step
-    # of a 2 000-step run by 14 us.
+    # of a 2 000-step run by 14 us.  The timer is created before the warm-up (creating its events takes ~1 ms) and
+    # reset right before the timed region, so that nothing but a synchronisation separates the warm-up from the K steps:
+    # a gap of tens of milliseconds there (it used to hold a 40 ms garbage collection) lets the GPU clock down and made
+    # a 20-step timed region read 8 us per step slower than a 200-step one.
     every = max(5, a.steps // 100) * (1 if world == 1 else L)
     graph.attach_timer(128, every=every)
+    for _ in range(a.warmup):
+        step()
+    graph.read_timer(reset=True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -281,7 +319,8 @@ def main():
                                ("epinion2 x%d replicas cross-linked by per-interaction permutations; N=%d nnz=%d d=%d L=%d; "
                                 "1-D row partition + RCCL all-gather per layer" % (world, n_nodes, nnz, D, L)),
                    "bpr_triples_per_step": T_TRIPLES, "embeddings": "xavier-uniform seed 2020 (synthetic weights)",
-                   "parallelism": "single GPU" if world == 1 else "row-partition x%d" % world},
+                   "parallelism": "single GPU" if world == 1 else "row-partition x%d" % world,
+                   **({} if world == 1 else {"allgather": ag_info})},
         "roofline": {"bound": "hbm", "kernel": "spmm_chunk_kernel<1>", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "cache_algorithmic_frac": achieved / HBM_PEAK_GBS,

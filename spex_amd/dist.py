@@ -63,6 +63,56 @@ class RowPartition:
         return lrowptr, self.to_padded(lcol).astype(np.int32), lval, leid
 
 
+class PeerAllGather:
+    """All-gather of equal row shards by direct peer writes: every rank copies its shard straight into its slot of every
+    peer's gather buffer — world - 1 concurrent device-to-device copies on separate streams, one per xGMI link of the
+    full mesh (7 links x ~50 GB/s usable on an 8-GPU node) — where a ring moves the same bytes through one link at a time
+    (world - 1 sequential steps).  SURVEY.md 5 ("Distributed communication backend") asks for this schedule.
+
+    The peers' buffers are reached through CUDA/HIP IPC handles exchanged once at construction (torch's own tensor
+    sharing: hipIpcGetMemHandle / hipIpcOpenMemHandle underneath; HSA_ENABLE_IPC_MODE_LEGACY=0 on this pool).
+    Synchronisation needs no custom device code: a rank's copies are ordered before a one-element all-reduce on its
+    compute stream, and that collective completes on any rank only after every rank has entered it — i.e. after every
+    rank's copies have completed — so the SpMM queued behind it reads a complete table.  Two buffers alternate from call
+    to call: a fast rank's copies for call c + 1 land in the other buffer while a slow rank is still reading call c's
+    (it cannot get two calls ahead: it would have to pass the barrier of call c + 1, which the slow rank enters only
+    after its SpMM of call c).
+    """
+
+    def __init__(self, n_padded, max_rows, d, rank, world, device, group=None):
+        import torch.multiprocessing.reductions as reductions
+        self.rank, self.world, self.group, self.max_rows = rank, world, group, max_rows
+        self.bufs = [torch.zeros((n_padded, d), dtype=torch.float32, device=device) for _ in range(2)]
+        mine = [reductions.reduce_tensor(b) for b in self.bufs]
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine, group=group)
+        self.peer = []                                   # peer[q][k]: rank q's buffer k as a tensor usable from this process
+        for q in range(world):
+            self.peer.append(self.bufs if q == rank else [fn(*args) for fn, args in everyone[q]])
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(world)]
+        self.token = torch.zeros(1, dtype=torch.float32, device=device)
+        self.calls = 0
+        dist.barrier(group=group)                        # every handle is opened before anyone writes
+
+    def all_gather(self, send):
+        """send: this rank's padded shard [max_rows, d].  Returns the gathered [world * max_rows, d] table (one of the two
+        alternating buffers), valid for kernels queued on the current stream after this call."""
+        k = self.calls & 1
+        self.calls += 1
+        cur = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        lo = self.rank * self.max_rows
+        for q in range(self.world):
+            st = self.streams[q]
+            st.wait_event(ready)
+            with torch.cuda.stream(st):
+                self.peer[q][k][lo: lo + self.max_rows].copy_(send, non_blocking=True)
+            cur.wait_stream(st)
+        dist.all_reduce(self.token, group=self.group)    # the barrier described above (stream-ordered after the copies)
+        return self.bufs[k]
+
+
 class PartitionedLightGCN:
     """LightGCN propagation + scoring step on one rank of a row-partitioned graph.
 
@@ -72,7 +122,7 @@ class PartitionedLightGCN:
     """
 
     def __init__(self, rowptr, col, val, n_user_rows, n_layers, d, rank, world, graph_factory, device, group=None,
-                 t_csr=None, bounds=None, always_collective=False):
+                 t_csr=None, bounds=None, always_collective=False, allgather="collective"):
         self.part = RowPartition(rowptr, world, bounds)
         self.rank, self.world, self.L, self.d, self.group = rank, world, n_layers, d, group
         self.always_collective = always_collective      # issue the collectives even at world size 1 (backend smoke tests)
@@ -93,17 +143,39 @@ class PartitionedLightGCN:
         self.send = z(p.max_rows, d)                     # padded local shard
         self.light_out = z(self.n_local, d)
         self.out_gathered = z(p.n_padded, d)
+        # allgather: "collective" = torch.distributed's all_gather_into_tensor (RCCL on the GPU); "peer" = direct peer
+        # writes through IPC-mapped buffers (PeerAllGather) for the per-layer exchange
+        self.peer, self.use_peer = None, False
+        if allgather not in ("collective", "peer"):
+            raise ValueError("allgather must be 'collective' or 'peer'")
+        if allgather == "peer":
+            self.set_allgather("peer")
 
     # -- the one exchange step of the data path
     def all_gather_rows(self, local, out=None):
-        out = self.gathered if out is None else out
         if local.data_ptr() != self.send.data_ptr():      # a layer's SpMM writes straight into the send buffer
             self.send[: self.n_local].copy_(local)
+        if self.use_peer and out is None:
+            return self.peer.all_gather(self.send)
+        out = self.gathered if out is None else out
         if self.world == 1 and not self.always_collective:
             out.copy_(self.send)
         else:
             dist.all_gather_into_tensor(out, self.send, group=self.group)
         return out
+
+    def set_allgather(self, mode):
+        """Switch the per-layer exchange between "collective" and "peer" (every rank must make the same call: building the
+        peer path exchanges IPC handles).  At world size 1 both are a local copy."""
+        if mode == "peer" and self.world > 1:
+            if self.peer is None:
+                self.peer = PeerAllGather(self.part.n_padded, self.part.max_rows, self.d, self.rank, self.world, self.device,
+                                          group=self.group)
+            self.use_peer = True
+        elif mode in ("collective", "peer"):
+            self.use_peer = False
+        else:
+            raise ValueError("allgather must be 'collective' or 'peer'")
 
     def propagate(self, E0_local, keep_first=False):
         """mean_l(A^l E0) for this rank's rows (LightGCN.computer(), model.py:66-97).  keep_first: the first layer's
