@@ -269,7 +269,13 @@ def main():
             for _ in range(5):
                 ngcf_train()
             aux["ngcf_train_step_ms_B256"] = time_events(ngcf_train, 100)
-            del net, opt
+            from spex_amd.trainer import NGCFStepper
+            nst = NGCFStepper(net, lr=1e-3)
+            nacc = torch.zeros(1, device=dev)
+            for _ in range(5):
+                nst.step(ub, ib, yb, loss_acc=nacc)
+            aux["ngcf_stepper_step_ms_B256"] = time_events(lambda: nst.step(ub, ib, yb, loss_acc=nacc), 200)
+            del net, opt, nst
         except Exception as e:  # never lose the headline line to an auxiliary measurement
             aux["aux_error"] = repr(e)
 

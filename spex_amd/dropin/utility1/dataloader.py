@@ -142,8 +142,14 @@ class Loader(BasicDataset):
             if self.split:
                 fold_len = n // self.folds
                 bounds = [i * fold_len for i in range(self.folds)] + [n]
-                self.Graph = [SpexGraph(*row_block(rowptr, col, val, bounds[i], bounds[i + 1])[:3], n_cols=n)
-                              for i in range(self.folds)]
+                # edge ids = positions in the unsplit matrix: a dropout mask indexed by them addresses the same entries
+                # in the row blocks, in the unsplit graph and in the transposed blocks the backward pass uses
+                eid = np.arange(len(col), dtype=np.int32)
+                self.fold_bounds = bounds
+                self.Graph = []
+                for i in range(self.folds):
+                    r, c, v, e = row_block(rowptr, col, val, bounds[i], bounds[i + 1], eid)
+                    self.Graph.append(SpexGraph(r, c, v, n_cols=n, edge_id=e))
             else:
                 self.Graph = SpexGraph(rowptr, col, val)
                 print("self.Graph:", self.Graph.size())

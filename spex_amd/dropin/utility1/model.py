@@ -114,21 +114,30 @@ class LightGCN(BasicModel):
             self._cache = ((uw._version, iw._version, uw.data_ptr()), out)
         return out
 
-    def _light_out_folds(self, uw, iw):
-        """--A_split: the adjacency as row blocks, one SpMM per block per layer (model.py:84-89).  Inference path."""
-        if torch.is_grad_enabled() and (uw.requires_grad or iw.requires_grad):
-            raise RuntimeError("--A_split is supported for inference; train with the unsplit graph")
-        cur = ops._flat_tables(uw, iw)
-        acc = cur.clone()
-        for _ in range(self.n_layers):
-            nxt = torch.empty_like(cur)
-            r0 = 0
+    def _transposed_folds(self):
+        """Row blocks of A^T (same block boundaries as the forward folds), each entry carrying its edge id in A."""
+        if getattr(self, "_folds_t", None) is None:
+            rowptr, col, val = self.dataset.build_adjacency()
+            n = len(rowptr) - 1
+            t_rowptr, t_col, t_val, eid = csr_transpose(rowptr, col, val, n)
+            bounds = [0]
             for g in self.Graph:
-                g.spmm(cur, Y=nxt[r0:r0 + g.n_rows])
-                r0 += g.n_rows
-            acc += nxt
-            cur = nxt
-        return acc / float(self.n_layers + 1)
+                bounds.append(bounds[-1] + g.n_rows)
+            from spex_amd.graph import row_block
+            dev = self.embedding_user.weight.device
+            self._folds_t = []
+            for k in range(len(self.Graph)):
+                r, c, v, e = row_block(t_rowptr, t_col, t_val, bounds[k], bounds[k + 1], eid)
+                self._folds_t.append(SpexGraph(r, c, v, n_cols=n, edge_id=e, device=dev))
+        return self._folds_t
+
+    def _light_out_folds(self, uw, iw):
+        """--A_split: the adjacency as row blocks, one SpMM per block per layer (model.py:84-89), training included: the
+        backward pass runs on the row blocks of A^T."""
+        mask = self._mask_for_step()
+        need_grad = torch.is_grad_enabled() and (uw.requires_grad or iw.requires_grad)
+        folds_t = self._transposed_folds() if need_grad else None
+        return ops.PropagateMeanFolds.apply(uw, iw, self.Graph, folds_t, self.n_layers, mask)
 
     def computer(self):
         light_out = self._light_out()

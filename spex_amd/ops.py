@@ -261,6 +261,71 @@ class PropagateMean(torch.autograd.Function):
         return gE0[:u], gE0[u:], None, None, None, None
 
 
+class PropagateMeanFolds(torch.autograd.Function):
+    """PropagateMean with the adjacency held as row blocks (`--A_split`, dataloader.py:167-177, model.py:84-89): one SpMM
+    per block and layer, forward on the blocks of A, backward on the blocks of A^T.  A row's sum is the same fmaf chain
+    whichever block holds the row, so output and gradient are bit-identical to the unsplit path.
+    folds / folds_t: lists of SpexGraph row blocks of A / of A^T (n_cols = N); mask as in PropagateMean (edge ids are
+    positions in the unsplit matrix)."""
+
+    @staticmethod
+    def _masked(graphs, mask, fn):
+        if mask is not None:
+            for g in graphs:
+                g.set_edge_mask(*mask)
+        try:
+            return fn()
+        finally:
+            if mask is not None:
+                for g in graphs:
+                    g.set_edge_mask(0)
+
+    @staticmethod
+    def forward(ctx, user_w, item_w, folds, folds_t, n_layers, mask):
+        E0 = _flat_tables(user_w, item_w)
+        L = n_layers
+        out = torch.empty_like(E0)
+
+        def run():
+            cur = E0
+            for l in range(L):
+                last = l == L - 1
+                nxt = None if last else torch.empty_like(E0)
+                r0 = 0
+                for g in folds:
+                    r1 = r0 + g.n_rows
+                    g.spmm(cur, Y=None if last else nxt[r0:r1], acc_in=(E0 if l == 0 else out)[r0:r1], acc_out=out[r0:r1],
+                           acc_div=float(L + 1) if last else 1.0)
+                    r0 = r1
+                cur = nxt
+            if L == 0:
+                out.copy_(E0)
+            return out
+        PropagateMeanFolds._masked(folds, mask, run)
+        ctx.folds_t, ctx.L, ctx.mask, ctx.n_user_rows = folds_t, L, mask, user_w.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        L, folds_t = ctx.L, ctx.folds_t
+        gs = g_out.contiguous() / float(L + 1)
+
+        def run():
+            cur = gs
+            for _ in range(L):
+                nxt = torch.empty_like(gs)
+                r0 = 0
+                for g in folds_t:
+                    r1 = r0 + g.n_rows
+                    g.spmm(cur, Y=nxt[r0:r1], add_in=gs[r0:r1], add_div=1.0)
+                    r0 = r1
+                cur = nxt
+            return cur
+        gE0 = PropagateMeanFolds._masked(folds_t, ctx.mask, run)
+        u = ctx.n_user_rows
+        return gE0[:u], gE0[u:], None, None, None, None
+
+
 class ScoreBCELoss(torch.autograd.Function):
     """mean BCEWithLogits(<users[u], items[i]>, y) over the batch — model.py:115-120 — on the whole [N, d] table
     (users first, items after `n_user_rows`); backward yields the dense, mostly-zero table gradient that the

@@ -144,3 +144,119 @@ def train_epoch(stepper, train_data, batch_size=256, resample=True, pause_gc=Tru
             gc.enable()
     total = acc[0, 0] / batch_size + (acc[1, 0] / (n - n_full) if n_full < n else 0.0)   # sum of per-batch mean losses
     return total
+
+
+class NGCFStepper:
+    """The NGCF training step (NGCF_SPEX/code/main_rec.py:122-128: forward, BCE, backward, Adam) as a fixed sequence of
+    libspexhip launches on pre-allocated buffers — no autograd, no allocation, no host synchronisation:
+
+        per layer:  SpMM (side = A ego)  ->  fused layer kernel (both 64x64 products, LeakyReLU, message dropout, L2 norm,
+                    concat slice)
+        scoring:    gather . dot . BCE + gradient rows into the [N, 64 (L + 1)] gradient table
+        per layer, last to first:  fused layer backward (recompute, input gradients, weight gradients)  ->  SpMM on A^T
+                    with the direct part added in its epilogue
+        Adam:       one pass over the embedding table, one over the flat block of layer weights (each also clears its
+                    gradient buffer for the next step)
+
+    model: a spex_amd.ngcf.NGCF with 64-wide layers; its parameters are trained IN PLACE (the table is the module's own
+    flat buffer; the layer weights are re-homed into one flat block whose views replace the nn.Linear parameters' data),
+    so `model` can be evaluated / saved as usual at any point.  Message dropout uses the model's counter-based stream
+    (message_dropout_seed, dropout_step).
+    """
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        if not model._fused_ok():
+            raise ValueError("NGCFStepper needs 64-wide layers (the fused layer kernels)")
+        self.model, self.lr, self.betas, self.eps, self.t = model, lr, betas, eps, 0
+        self.E0 = model.flat_table()
+        n, d = self.E0.shape
+        dev = self.E0.device
+        L = self.L = model.n_layers
+        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+        # layer weights in one flat block: [W_gc | b_gc | W_bi | b_bi] per layer
+        per = 2 * (d * d + d)
+        self.W = z(L * per)
+        self.views = []
+        for l, (gc, bi) in enumerate(zip(model.GC_Linear_list, model.Bi_Linear_list)):
+            o = l * per
+            vs = (self.W[o:o + d * d].view(d, d), self.W[o + d * d:o + d * d + d],
+                  self.W[o + d * d + d:o + 2 * d * d + d].view(d, d), self.W[o + 2 * d * d + d:o + per])
+            for v, p in zip(vs, (gc.weight, gc.bias, bi.weight, bi.bias)):
+                v.copy_(p.data)
+                p.data = v                                    # the module's parameters now live in the flat block
+            self.views.append(vs)
+        self.gW = z(L * per)
+        self.g_views = [tuple(self.gW[l * per + a:l * per + b].view(*shape) for a, b, shape in
+                              ((0, d * d, (d, d)), (d * d, d * d + d, (d,)), (d * d + d, 2 * d * d + d, (d, d)),
+                               (2 * d * d + d, per, (d,)))) for l in range(L)]
+        self.mW, self.vW = z(L * per), z(L * per)
+        self.mE, self.vE = z(n, d), z(n, d)
+        self.all_emb = z(n, d * (L + 1))
+        self.g_all = z(n, d * (L + 1))                          # invariant: all-zero between steps
+        self.sides = [z(n, d) for _ in range(L)]
+        self.egos = [self.E0] + [z(n, d) for _ in range(L - 1)]
+        self.g_side, self.g_ego = z(n, d), z(n, d)
+        self.g_next = [z(n, d), z(n, d)]
+        self.loss_acc = z(1)
+        self.n_u = model.n_users + 1
+
+    def step(self, users, items, labels, loss_acc=None):
+        """One training step on a batch (device tensors).  Accumulates the batch's loss SUM into `loss_acc` (default: the
+        stepper's own running buffer) and returns it."""
+        m, L = self.model, self.L
+        acc = self.loss_acc if loss_acc is None else loss_acc
+        drop = None
+        if any(p > 0 for p in m.mess_dropout):
+            drop = (m.mess_dropout, m.message_dropout_seed, m.dropout_step)
+            m.dropout_step += 1
+        pad = m.n_users
+        for l in range(L):
+            m.graph.spmm(self.egos[l], Y=self.sides[l])
+            dl = None if drop is None or drop[0][l] <= 0 else (drop[0][l], drop[1], drop[2])
+            ops.ngcf_layer_fwd(self.egos[l], self.sides[l], *self.views[l], self.all_emb, l, l == 0,
+                               self.egos[l + 1] if l < L - 1 else None, drop=dl, pad_row=pad)
+        B = users.numel()
+        ops.score_bce(self.all_emb[:self.n_u], self.all_emb[self.n_u:], users, items, labels, self.g_all[:self.n_u],
+                      self.g_all[self.n_u:], 1.0 / B, loss_sum=acc, want_gamma=False)
+        g_next = None
+        for l in range(L - 1, -1, -1):
+            dl = None if drop is None or drop[0][l] <= 0 else (drop[0][l], drop[1], drop[2])
+            ops.ngcf_layer_bwd(self.egos[l], self.sides[l], *self.views[l], self.g_all, l, g_next, self.g_side, self.g_ego,
+                               *self.g_views[l], drop=dl, pad_row=pad)
+            out = self.g_next[l & 1]
+            m.graph_t.spmm(self.g_side, Y=out, add_in=self.g_ego, add_div=1.0)
+            g_next = out
+        self.t += 1
+        b1, b2 = self.betas
+        ops.adam_step(self.E0, g_next, self.mE, self.vE, self.t, self.lr, b1, b2, self.eps)
+        ops.adam_step(self.W, self.gW, self.mW, self.vW, self.t, self.lr, b1, b2, self.eps, zero=self.gW)
+        self.g_all.zero_()
+        return acc
+
+
+def train_epoch_ngcf(stepper, data, batch_size=None, pause_gc=True):
+    """train() of NGCF_SPEX/code/main_rec.py:116-131 without the per-step host work of its DataLoader loop: the epoch's
+    samples are drawn like the reference's (Data.sample_epoch: `random` stream), the sample order is the DataLoader's own
+    (dataloader_epoch_order: global torch RNG), the shuffled epoch is moved to the device once, and every batch is one
+    NGCFStepper.step.  Returns the epoch's summed per-batch mean loss (main_rec.py:129 accumulates the same sum)."""
+    us, vs, rs = data.sample_epoch()
+    n = len(us)
+    bs = batch_size or data.batch_size
+    order = dataloader_epoch_order(n).numpy()
+    dev = stepper.E0.device
+    users, items = torch.from_numpy(us[order]).to(dev), torch.from_numpy(vs[order]).to(dev)
+    labels = torch.from_numpy(rs[order]).to(dev)
+    gc_was_on = pause_gc and gc.isenabled()
+    if gc_was_on:
+        gc.disable()
+    n_full = n // bs * bs
+    acc = torch.zeros(2, 1, dtype=torch.float32, device=dev)
+    try:
+        for s in range(0, n_full, bs):
+            stepper.step(users[s:s + bs], items[s:s + bs], labels[s:s + bs], loss_acc=acc[0])
+        if n_full < n:
+            stepper.step(users[n_full:], items[n_full:], labels[n_full:], loss_acc=acc[1])
+    finally:
+        if gc_was_on:
+            gc.enable()
+    return acc[0, 0] / bs + (acc[1, 0] / (n - n_full) if n_full < n else 0.0)

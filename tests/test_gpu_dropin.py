@@ -159,6 +159,40 @@ def test_a_split_folds_match_unsplit(data_root, golden):
     assert rel_err(torch.cat([users, items]).cpu().numpy(), g["light_out"]) <= 1e-6
 
 
+@pytest.mark.parametrize("dropout", [False, True])
+def test_a_split_training_equals_unsplit(data_root, golden, oracle, dropout):
+    """--A_split trains (model.py:84-89 runs the folds under autograd too): forward on the row blocks of A, backward on
+    the row blocks of A^T.  A row's sum does not depend on which block holds it, so loss, propagated table and
+    gradients are BIT-IDENTICAL to the unsplit model — also under edge dropout, where the folds, the unsplit graph and
+    the transposed blocks all look the same entries up in one mask (edge ids = positions in the unsplit matrix)."""
+    g = golden("lightgcn_tiny")
+    extra = ["--dropout", "1", "--keepprob", "0.6"] if dropout else []
+    bu, bi, bl = (torch.from_numpy(g[k][0]) for k in ("batch_users", "batch_items", "batch_labels"))
+    results = []
+    for split in ([], ["--A_split", "1", "--a_fold", "7"]):
+        args, dataset, net = build("tiny", data_root, extra + split)
+        if dropout:
+            net.set_edge_mask(torch.from_numpy(oracle.dropout_keep_mask(g["g9_rand"], 0.6)))
+        net.train()
+        loss = net(bu, bi, bl, flag=0)
+        loss.backward()
+        grad = torch.cat([net.embedding_user.weight.grad, net.embedding_item.weight.grad]).cpu().numpy()
+        table = torch.cat(net.computer()).detach().cpu().numpy()
+        results.append((loss.item(), grad, table))
+    (l0, g0, t0), (l1, g1, t1) = results
+    assert l0 == l1 and np.array_equal(t0, t1) and np.array_equal(g0, g1)
+    if not dropout:
+        assert abs(l0 - float(g["g3_loss"])) <= 2e-6 and rel_err(g1, g["g3_grad"]) <= 1e-5      # and both equal the reference
+    # an optimiser step through the folds moves the parameters
+    args, dataset, net = build("tiny", data_root, ["--A_split", "1", "--a_fold", "7"])
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    before = net.embedding_item.weight.detach().clone()
+    net.train()
+    net(bu, bi, bl, flag=0).backward()
+    opt.step()
+    assert not torch.equal(before, net.embedding_item.weight.detach())
+
+
 def test_bpr_loss_extension_against_torch_fp32(data_root, golden):
     """bpr_loss() has no reference counterpart (parity unpinned): check value and gradient against plain torch ops
     on the same device (dense adjacency, fp64)."""

@@ -235,6 +235,32 @@ def test_whole_ngcf_run_matches_the_reference_small(golden, ngcf_data_root):
             assert rel_err(sd[k[6:].replace("__", ".")].cpu().numpy(), g[k]) <= 1e-4, k
 
 
+def test_on_device_ngcf_epochs_match_the_reference_small(golden, ngcf_data_root):
+    """The same golden through the autograd-free loop: spex_amd.trainer.NGCFStepper (a fixed sequence of launches per
+    step: SpMM, fused layer, scoring, fused layer backward, SpMM^T, two Adam passes) driven by train_epoch_ngcf (the
+    reference's sampler stream and the DataLoader's shuffle order, replayed) — same loss sums and metrics per epoch."""
+    from spex_amd.dropin.ngcf.utility import batch_test
+    from spex_amd.dropin.ngcf.utility.load_data import Data
+    from spex_amd.ngcf import NGCF
+    from spex_amd.trainer import NGCFStepper, train_epoch_ngcf
+    g = golden("ngcf_small_epochs")
+    torch.manual_seed(int(g["seed"])); random.seed(int(g["seed"])); np.random.seed(int(g["seed"]))
+    data = Data(path=ngcf_data_root + "small", batch_size=256)
+    batch_test.use_data(data)
+    _, norm, _ = data.get_adj_mat()
+    model = NGCF({"n_users": data.n_users, "n_items": data.n_items, "norm_adj": norm}, DEV,
+                 ngcf_args(mess_dropout=str([float(x) for x in g["mess_dropout"]]))).to(DEV)
+    model.message_dropout_seed = int(g["drop_seed"])
+    st = NGCFStepper(model, lr=float(g["lr"]))
+    for epoch in range(3):
+        model.train()
+        total = train_epoch_ngcf(st, data).item()
+        assert abs(total - g["losses"][epoch]) <= 5e-5 * g["losses"][epoch], (epoch, total, g["losses"][epoch])
+        ret = batch_test.test(model, list(data.test_set.keys()), drop_flag=True)      # the module sees the trained weights
+        assert np.abs(ret["recall"] - g["recall"][epoch]).max() <= 1e-4 and np.abs(ret["ndcg"] - g["ndcg"][epoch]).max() <= 1e-4
+    assert st.t == int(g["n_steps"]) and model.dropout_step == int(g["n_steps"])
+
+
 def test_whole_ngcf_epoch_matches_the_reference_epinion2(golden, ngcf_data_root):
     """The same at BASELINE config 4's size: one full NGCF epoch on Epinion2 (~4.7 k steps) + test()."""
     path = os.path.join(REPO, "tests", "golden", "ngcf_epinion2_epochs.npz")
