@@ -191,8 +191,8 @@ int spex_scatter_add_owned_rows_f32(float *upd, const int64_t *pos, int64_t K, i
 /* ------------------------------------------------------------------------------------------------ optimiser
  * Replaces torch.optim.Adam(...).step() over the dense embedding tables — LightGCN_SPEX/code/main_rec.py:23,37.
  * One fused pass: m, v, p updated in place (bias-corrected, eps outside the sqrt as torch does), t = step count >= 1.
- * zero_buf (optional, n floats, may not alias the operands): cleared in the same pass — the caller's gradient
- * accumulation table for the next step (saves a separate fill launch per step).
+ * zero_buf (optional, n floats; may be g itself, may not alias p, m or v): cleared in the same pass — the caller's
+ * gradient accumulation table for the next step (saves a separate fill launch per step).
  */
 int spex_adam_step_f32(float *p, const float *g, float *m, float *v, int64_t n, int32_t t, float lr, float beta1,
                        float beta2, float eps, float *zero_buf, void *stream);

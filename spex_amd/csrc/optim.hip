@@ -22,10 +22,12 @@ __device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, flo
     p = p - step_size * (m / denom);
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g,
+// (g and zero_buf carry no __restrict__: the caller may pass the gradient buffer itself to be cleared — every element is
+// read before the same thread clears it)
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *g,
                                                    float *__restrict__ m, float *__restrict__ v, int64_t n4,
                                                    int64_t rem, float w1, float beta2, float w2, float bc2_sqrt,
-                                                   float eps, float step_size, float *__restrict__ zero_buf)
+                                                   float eps, float step_size, float *zero_buf)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -60,7 +62,7 @@ extern "C" int spex_adam_step_f32(float *p, const float *g, float *m, float *v, 
     SPEX_CHECK_ARG(n >= 0 && t >= 1, "spex_adam_step_f32: n=%lld t=%d (t counts from 1)", (long long)n, t);
     SPEX_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)zero_buf) & 15) == 0,
                    "spex_adam_step_f32: pointers must be 16-byte aligned");
-    SPEX_CHECK_ARG(zero_buf != p && zero_buf != m && zero_buf != v && zero_buf != g, "spex_adam_step_f32: zero_buf aliases an operand");
+    SPEX_CHECK_ARG(zero_buf != p && zero_buf != m && zero_buf != v, "spex_adam_step_f32: zero_buf aliases p, m or v");
     if (n == 0) return SPEX_OK;
     const double bc1 = 1.0 - pow((double)beta1, (double)t);
     const double bc2 = 1.0 - pow((double)beta2, (double)t);

@@ -164,7 +164,9 @@ def test_a_split_training_equals_unsplit(data_root, golden, oracle, dropout):
     """--A_split trains (model.py:84-89 runs the folds under autograd too): forward on the row blocks of A, backward on
     the row blocks of A^T.  A row's sum does not depend on which block holds it, so loss, propagated table and
     gradients are BIT-IDENTICAL to the unsplit model — also under edge dropout, where the folds, the unsplit graph and
-    the transposed blocks all look the same entries up in one mask (edge ids = positions in the unsplit matrix)."""
+    the transposed blocks all look the same entries up in one mask (edge ids = positions in the unsplit matrix).
+    (Checked bit for bit on the propagated table; the loss and the gradient start from the scoring kernel's float atomics,
+    whose order varies from launch to launch, so they are compared to 1e-6.)"""
     g = golden("lightgcn_tiny")
     extra = ["--dropout", "1", "--keepprob", "0.6"] if dropout else []
     bu, bi, bl = (torch.from_numpy(g[k][0]) for k in ("batch_users", "batch_items", "batch_labels"))
@@ -180,7 +182,7 @@ def test_a_split_training_equals_unsplit(data_root, golden, oracle, dropout):
         table = torch.cat(net.computer()).detach().cpu().numpy()
         results.append((loss.item(), grad, table))
     (l0, g0, t0), (l1, g1, t1) = results
-    assert l0 == l1 and np.array_equal(t0, t1) and np.array_equal(g0, g1)
+    assert np.array_equal(t0, t1) and abs(l0 - l1) <= 1e-6 and rel_err(g1, g0) <= 1e-6
     if not dropout:
         assert abs(l0 - float(g["g3_loss"])) <= 2e-6 and rel_err(g1, g["g3_grad"]) <= 1e-5      # and both equal the reference
     # an optimiser step through the folds moves the parameters
