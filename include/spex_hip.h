@@ -233,6 +233,44 @@ int spex_ngcf_layer_bwd_f32(const float *ego, const float *side, const float *W_
                             uint64_t seed, uint32_t step, uint32_t layer, int32_t pad_row, float *g_side, float *g_ego,
                             float *gW_gc, float *gb_gc, float *gW_bi, float *gb_bi, void *stream);
 
+/* The same backward for the rows of a device LIST only — the form the LAST layer takes in training: after a B-sample
+ * batch only the batch's <= 2B distinct rows carry a gradient behind it (main_rec.py:89-90), so 2B / 16 tiles replace
+ * n / 16.  list / count: device int32 row list and its length (from spex_unique_rows_i32; max_count bounds the launch).
+ * g_side_c / g_ego_c: COMPACT outputs [max_count, d], entry k belonging to row list[k] — the operands of
+ * spex_spmm_push_rows_f32, which completes d loss / d ego = scatter(g_ego_c) + A^T scatter(g_side_c).
+ * clear_consumed != 0: the rows of g_norm / g_direct that were read are set to zero (they are the only non-zero rows:
+ * the caller's gradient table is all-zero again without a fill pass).  Weight gradients are accumulated as above.
+ */
+int spex_ngcf_layer_bwd_rows_f32(const float *ego, const float *side, const float *W_gc, const float *b_gc,
+                                 const float *W_bi, const float *b_bi, float *g_norm, int32_t ld_g, const float *g_next,
+                                 float *g_direct, int32_t ld_direct, int32_t n, int32_t d, float slope, float p_drop,
+                                 uint64_t seed, uint32_t step, uint32_t layer, int32_t pad_row, const int32_t *list,
+                                 const int32_t *count, int32_t max_count, int32_t clear_consumed, float *g_side_c,
+                                 float *g_ego_c, float *gW_gc, float *gb_gc, float *gW_bi, float *gb_bi, void *stream);
+
+/* ------------------------------------------------------------------------------------------------ row-sparse backward
+ * After a B-sample batch d loss / d (propagated table) is non-zero on <= 2B rows (model.py:115-116), so the FIRST product
+ * of the backward pass, A^T g, touches only the stored entries of those rows (~14 k of Epinion2's 418 k): it is taken
+ * in push form instead of a pull-form SpMM over the whole matrix ("hard parts").
+ *
+ * spex_unique_rows_i32: the distinct values of { idx_a[k] + off_a } U { idx_b[k] + off_b } that lie in [0, n_rows), as a
+ * compact device list (arbitrary order) and its length.  stamp: caller-owned device int32[n_rows], zero-initialised once;
+ * epoch: any non-zero value not used on this stamp table before (a step counter).  No sort, no host round trip.
+ *
+ * spex_spmm_push_rows_f32: for the k-th listed row r = list[k] (k < *count) and every stored entry e of row r of the handle:
+ *   out[col[e], :] += scale * val[e] * src_k,   src_k = src[r, :] if src_indexed else src[k, :]
+ *   and, if add: out[r, :] += scale * add_k (same indexing rule by add_indexed)
+ * i.e. out += scale * (A^T scatter(src) + scatter(add)) for the matrix A held by the handle (scale = 1/(L+1) gives the
+ * first step of the layer-mean's backward, G = (g + A^T g)/(L+1), in one launch).  out: [n_cols, d], accumulated with
+ * 256-byte float atomics — initialise it first (zero, or the term the product is added to).  max_count bounds the launch
+ * (one 16-wave workgroup per list slot).  No edge dropout in this form.
+ */
+int spex_unique_rows_i32(const int64_t *idx_a, int32_t n_a, int64_t off_a, const int64_t *idx_b, int32_t n_b, int64_t off_b,
+                         int32_t n_rows, int32_t *stamp, int32_t epoch, int32_t *list, int32_t *count, void *stream);
+int spex_spmm_push_rows_f32(const spex_graph_t *g, const int32_t *list, const int32_t *count, int32_t max_count,
+                            const float *src, int32_t src_indexed, const float *add, int32_t add_indexed, float scale,
+                            float *out, int32_t d, void *stream);
+
 /* Replaces the two-expert gate of the dual-task model, utility1/model_expert_s.py:156-161:
  *   att = softmax([raw | prop] att_exp, dim=1) ([n,2d] x [2d,2]);  mixed = raw * att[:,0] + prop * att[:,1]
  */

@@ -46,6 +46,11 @@ SIGNATURES = {
     "spex_ngcf_layer_bwd_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32,
                                                c_f32, c_f32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, c_i32, c_vp,
                                                c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "spex_ngcf_layer_bwd_rows_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32,
+                                                    c_f32, c_f32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, c_i32, c_vp,
+                                                    c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "spex_unique_rows_i32": (ctypes.c_int, [c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp]),
+    "spex_spmm_push_rows_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_f32, c_vp, c_i32, c_vp]),
     "spex_expert_gate_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "spex_expert_gate_bwd_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "spex_sample_negatives": (ctypes.c_int, [c_vp, c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, ctypes.c_uint64, c_vp, c_vp]),

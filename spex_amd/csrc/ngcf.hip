@@ -192,18 +192,28 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void ngcf_layer_kernel(
 // [16,64]x[64,64] products), the two input-gradient products are two more, and the weight gradients are a fifth and
 // sixth MFMA product whose contraction runs over the tile's ROWS: with the rows taken in the order 4h + s (lane group
 // h, step s) the A operand is G in the accumulator layout it already has and the B operand is the side / product tile
-// read from LDS in that same layout — no transposes.  One wave per tile, 8 waves per workgroup; tiles whose upstream
-// gradient is all zero (after a 256-sample batch: most rows) write zeros and skip the arithmetic.  Weight gradients
-// are summed per workgroup in LDS (ds_add_f32, row stride 68: 2-way bank conflicts, the minimum for 64 lanes) and
-// leave with one atomic per address and active workgroup.
-constexpr int kBwdWaves = 8;
+// read from LDS in that same layout — no transposes.  One wave per tile, 4 waves per workgroup (one per SIMD: the wave
+// keeps its 2 x 64 x 64 / 64 weight-gradient accumulators in 128 registers across its tiles).
+// Two forms:
+//   dense (ROWS = false)  tiles of 16 consecutive rows; a tile whose upstream gradient is all zero writes zeros and skips
+//                         the arithmetic;
+//   rows  (ROWS = true)   tiles of 16 entries of a device row list (the <= 512 distinct rows of a batch — the only rows
+//                         with a gradient behind the LAST layer): 32 tiles instead of 975, compact [K, 64] outputs for the
+//                         push-form SpMM, and the consumed rows of the gradient table are cleared on the way.
+// Weight gradients: the workgroup's four waves add their register accumulators into LDS one after the other (plain
+// read-add-write between barriers — an LDS float atomic, ds_add_f32, costs ~200 cycles per wave-instruction: the first
+// version of this kernel spent 85 of its 113 us in 128 of them per tile), then one global atomic per address and active
+// workgroup.
+constexpr int kBwdWaves = 4;
 constexpr int kDwStride = 68;
 
+template <bool ROWS>
 __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
     const float *__restrict__ ego, const float *__restrict__ side, const float *__restrict__ W_gc,
     const float *__restrict__ b_gc, const float *__restrict__ W_bi, const float *__restrict__ b_bi,
-    const float *__restrict__ g_norm, int ld_g, const float *__restrict__ g_next, const float *__restrict__ g_direct,
-    int ld_direct, int n, float slope, const MsgDrop drop, float *__restrict__ g_side, float *__restrict__ g_ego,
+    float *g_norm, int ld_g, const float *__restrict__ g_next, float *g_direct,
+    int ld_direct, int n, float slope, const MsgDrop drop, const int32_t *__restrict__ list,
+    const int32_t *__restrict__ count, int clear_consumed, float *__restrict__ g_side, float *__restrict__ g_ego,
     float *gW_gc, float *gb_gc, float *gW_bi, float *gb_bi)
 {
     __shared__ float s_w[2][64 * kLdsStride];                   // W_gc, W_bi as [out o][in k]
@@ -212,7 +222,9 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
     __shared__ float s_t[kBwdWaves][2][16 * kLdsStride];        // per wave: side tile / G_s, product tile / G_t
     __shared__ int s_active;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-    const int n_tiles = (n + 15) >> 4;
+    const int n_items = ROWS ? *count : n;                      // rows to process (listed rows / all rows)
+    const int n_tiles = (n_items + 15) >> 4;
+    if ((int)blockIdx.x * kBwdWaves >= n_tiles) return;         // (workgroup-uniform) nothing for this workgroup
     for (int i = threadIdx.x; i < 64 * 16; i += blockDim.x) {
         const int r = i >> 4, c4 = (i & 15) * 4;
         const float4 a = *reinterpret_cast<const float4 *>(W_gc + r * 64 + c4);
@@ -233,9 +245,26 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
         bias_b[b] = b_bi[16 * b + i16];
     }
     float *t_side = s_t[wave][0], *t_prod = s_t[wave][1];
+    f32x4 dWg[4][4], dWb[4][4];                                  // [out block][in block]: rows 4h + q, column i16
+    float dbg[4] = {0.f, 0.f, 0.f, 0.f}, dbb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int bo = 0; bo < 4; ++bo) {
+#pragma unroll
+        for (int bn = 0; bn < 4; ++bn) {
+            dWg[bo][bn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            dWb[bo][bn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
     bool did_work = false;
     for (int tile = blockIdx.x * kBwdWaves + wave; tile < n_tiles; tile += gridDim.x * kBwdWaves) {
         const int r0 = tile << 4;
+        // the tile's rows: consecutive, or entries of the list (-1 = past the end)
+        int row_q[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = r0 + 4 * h + q;
+            row_q[q] = k < n_items ? (ROWS ? list[k] : k) : -1;
+        }
         // upstream gradients in the accumulator layout: element (row 4h + q, column 16b + i16)
         float gn[4][4], gx[4][4];
         bool any = false;
@@ -243,16 +272,16 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
         for (int b = 0; b < 4; ++b) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int r = r0 + 4 * h + q;
+                const int r = row_q[q];
                 gn[b][q] = gx[b][q] = 0.0f;
-                if (r < n) {
+                if (r >= 0) {
                     gn[b][q] = g_norm[(size_t)r * ld_g + 16 * b + i16];
                     if (g_next) gx[b][q] = g_next[(size_t)r * 64 + 16 * b + i16];
                 }
                 any |= (gn[b][q] != 0.0f) | (gx[b][q] != 0.0f);
             }
         }
-        if (!__any(any)) {                                       // no gradient reaches this tile
+        if (!ROWS && !__any(any)) {                              // no gradient reaches this tile
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int r = r0 + i;
@@ -267,9 +296,10 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
         // stage the tile (lane == column) for the recomputation
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int r = r0 + i;
+            const int k = r0 + i;
+            const int r = k < n_items ? (ROWS ? list[k] : k) : -1;
             float e = 0.0f, sd = 0.0f;
-            if (r < n) {
+            if (r >= 0) {
                 e = ego[(size_t)r * 64 + lane];
                 sd = side[(size_t)r * 64 + lane];
             }
@@ -305,14 +335,15 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
                 const float x = acc_g[b][q] + bias_g[b], y = acc_b[b][q] + bias_b[b];
                 float e = (x >= 0.0f ? x : x * slope) + (y >= 0.0f ? y : y * slope);
                 float ks = 1.0f;
-                if (drop.p > 0.0f) ks = msg_keep(drop, r0 + 4 * h + q, 16 * b + i16) ? drop.scale : 0.0f;
-                if (drop.p > 0.0f) e = ks != 0.0f ? e * ks : 0.0f;
+                if (drop.p > 0.0f) {
+                    ks = (row_q[q] >= 0 && msg_keep(drop, row_q[q], 16 * b + i16)) ? drop.scale : 0.0f;
+                    e = ks != 0.0f ? e * ks : 0.0f;
+                }
                 kscale[b][q] = ks;
                 e1d[b][q] = e;
                 v = fmaf(e, e, v);
             }
-            v = row16_sum_f32(v);
-            sq[q] = v;
+            sq[q] = row16_sum_f32(v);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -327,23 +358,17 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
             for (int b = 0; b < 4; ++b) {
                 const float o = e1d[b][q] / den;
                 const float ge1d = (gn[b][q] - o * dot[q]) / den + gx[b][q];
-                const float ge1 = ge1d * kscale[b][q];
+                const float ge1 = row_q[q] >= 0 ? ge1d * kscale[b][q] : 0.0f;
                 const float x = acc_g[b][q] + bias_g[b], y = acc_b[b][q] + bias_b[b];
                 acc_g[b][q] = ge1 * (x > 0.0f ? 1.0f : slope);   // G_s
                 acc_b[b][q] = ge1 * (y > 0.0f ? 1.0f : slope);   // G_t
             }
         }
-        // bias gradients: column sums over the tile's 16 rows
+        // bias gradients: this lane's share (rows 4h + q of column 16b + i16), summed over lane groups at the end
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            float cs = (acc_g[b][0] + acc_g[b][1]) + (acc_g[b][2] + acc_g[b][3]);
-            float ct = (acc_b[b][0] + acc_b[b][1]) + (acc_b[b][2] + acc_b[b][3]);
-            cs += __shfl_xor(cs, 16, kWave); cs += __shfl_xor(cs, 32, kWave);
-            ct += __shfl_xor(ct, 16, kWave); ct += __shfl_xor(ct, 32, kWave);
-            if (h == 0) {
-                atomicAdd(&s_db[0][16 * b + i16], cs);
-                atomicAdd(&s_db[1][16 * b + i16], ct);
-            }
+            dbg[b] += (acc_g[b][0] + acc_g[b][1]) + (acc_g[b][2] + acc_g[b][3]);
+            dbb[b] += (acc_b[b][0] + acc_b[b][1]) + (acc_b[b][2] + acc_b[b][3]);
         }
         // side / product tiles in the accumulator layout (B operands of the weight-gradient products, and the
         // elementwise factors of the input gradients)
@@ -361,16 +386,10 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
         for (int bo = 0; bo < 4; ++bo) {
 #pragma unroll
             for (int bn = 0; bn < 4; ++bn) {
-                f32x4 dg = (f32x4){0.f, 0.f, 0.f, 0.f}, db = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int st = 0; st < 4; ++st) {
-                    dg = __builtin_amdgcn_mfma_f32_16x16x4f32(acc_g[bo][st], side_c[bn][st], dg, 0, 0, 0);
-                    db = __builtin_amdgcn_mfma_f32_16x16x4f32(acc_b[bo][st], prod_c[bn][st], db, 0, 0, 0);
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    atomicAdd(&s_dw[0][(16 * bo + 4 * h + q) * kDwStride + 16 * bn + i16], dg[q]);
-                    atomicAdd(&s_dw[1][(16 * bo + 4 * h + q) * kDwStride + 16 * bn + i16], db[q]);
+                    dWg[bo][bn] = __builtin_amdgcn_mfma_f32_16x16x4f32(acc_g[bo][st], side_c[bn][st], dWg[bo][bn], 0, 0, 0);
+                    dWb[bo][bn] = __builtin_amdgcn_mfma_f32_16x16x4f32(acc_b[bo][st], prod_c[bn][st], dWb[bo][bn], 0, 0, 0);
                 }
             }
         }
@@ -404,23 +423,56 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int r = r0 + 4 * h + q;
-            if (r < n) {
+            const int r = row_q[q];
+            if (r >= 0) {
+                const size_t o_row = ROWS ? (size_t)(r0 + 4 * h + q) : (size_t)r;      // compact slot / table row
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const int c = 16 * b + i16;
                     const float e = ego[(size_t)r * 64 + c];
-                    g_side[(size_t)r * 64 + c] = ts[b][q] + tb[b][q] * e;
+                    g_side[o_row * 64 + c] = ts[b][q] + tb[b][q] * e;
                     float ge = tb[b][q] * side_c[b][q];
                     if (g_direct) ge += g_direct[(size_t)r * ld_direct + c];
-                    g_ego[(size_t)r * 64 + c] = ge;
+                    g_ego[o_row * 64 + c] = ge;
+                    if (ROWS && clear_consumed) {            // the gradient table is all-zero again after this launch
+                        g_norm[(size_t)r * ld_g + c] = 0.0f;
+                        if (g_direct) g_direct[(size_t)r * ld_direct + c] = 0.0f;
+                    }
                 }
             }
         }
     }
+    // ---- weight gradients: registers -> LDS (one wave at a time, plain adds) -> global atomics
     if (did_work && lane == 0) s_active = 1;
     __syncthreads();
     if (!s_active) return;
+    for (int w = 0; w < kBwdWaves; ++w) {
+        if (wave == w && did_work) {
+#pragma unroll
+            for (int bo = 0; bo < 4; ++bo) {
+#pragma unroll
+                for (int bn = 0; bn < 4; ++bn) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int a_ = (16 * bo + 4 * h + q) * kDwStride + 16 * bn + i16;
+                        s_dw[0][a_] += dWg[bo][bn][q];
+                        s_dw[1][a_] += dWb[bo][bn][q];
+                    }
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                float cs = dbg[b], ct = dbb[b];
+                cs += __shfl_xor(cs, 16, kWave); cs += __shfl_xor(cs, 32, kWave);
+                ct += __shfl_xor(ct, 16, kWave); ct += __shfl_xor(ct, 32, kWave);
+                if (h == 0) {
+                    s_db[0][16 * b + i16] += cs;
+                    s_db[1][16 * b + i16] += ct;
+                }
+            }
+        }
+        __syncthreads();
+    }
     for (int k = threadIdx.x; k < 64 * 64; k += blockDim.x) {
         const int o = k >> 6, c = k & 63;
         atomicAdd(gW_gc + k, s_dw[0][o * kDwStride + c]);
@@ -583,10 +635,41 @@ extern "C" int spex_ngcf_layer_bwd_f32(const float *ego, const float *side, cons
     if (n == 0) return SPEX_OK;
     const int n_tiles = (n + 15) / 16;
     int blocks = (n_tiles + kBwdWaves - 1) / kBwdWaves;
-    if (blocks > 128) blocks = 128;      // one 8-wave workgroup per CU on half the chip: 128 x 8 K weight-gradient atomics
-    hipLaunchKernelGGL(ngcf_layer_bwd_kernel, dim3((unsigned)blocks), dim3(kWave * kBwdWaves), 0, (hipStream_t)stream, ego, side,
-                       W_gc, b_gc, W_bi, b_bi, g_norm, ld_g, g_next, g_direct, ld_direct, n, slope,
-                       make_drop(p_drop, seed, step, layer, pad_row), g_side, g_ego, gW_gc, gb_gc, gW_bi, gb_bi);
+    if (blocks > 128) blocks = 128;      // <= 128 x 8 K weight-gradient atomics; a wave walks its tiles with a stride
+    hipLaunchKernelGGL((ngcf_layer_bwd_kernel<false>), dim3((unsigned)blocks), dim3(kWave * kBwdWaves), 0, (hipStream_t)stream, ego,
+                       side, W_gc, b_gc, W_bi, b_bi, const_cast<float *>(g_norm), ld_g, g_next, const_cast<float *>(g_direct), ld_direct,
+                       n, slope, make_drop(p_drop, seed, step, layer, pad_row), nullptr, nullptr, 0, g_side, g_ego, gW_gc, gb_gc,
+                       gW_bi, gb_bi);
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}
+
+extern "C" int spex_ngcf_layer_bwd_rows_f32(const float *ego, const float *side, const float *W_gc, const float *b_gc,
+                                            const float *W_bi, const float *b_bi, float *g_norm, int32_t ld_g,
+                                            const float *g_next, float *g_direct, int32_t ld_direct, int32_t n, int32_t d,
+                                            float slope, float p_drop, uint64_t seed, uint32_t step, uint32_t layer,
+                                            int32_t pad_row, const int32_t *list, const int32_t *count, int32_t max_count,
+                                            int32_t clear_consumed, float *g_side_c, float *g_ego_c, float *gW_gc, float *gb_gc,
+                                            float *gW_bi, float *gb_bi, void *stream)
+{
+    SPEX_CHECK_ARG(ego && side && W_gc && b_gc && W_bi && b_bi && g_norm && g_side_c && g_ego_c && gW_gc && gb_gc && gW_bi && gb_bi
+                       && list && count,
+                   "spex_ngcf_layer_bwd_rows_f32: NULL pointer");
+    SPEX_CHECK_ARG(n >= 0 && max_count >= 0 && ld_g >= d && (!g_direct || ld_direct >= d),
+                   "spex_ngcf_layer_bwd_rows_f32: n=%d max_count=%d ld_g=%d ld_direct=%d", n, max_count, ld_g, ld_direct);
+    SPEX_CHECK_ARG(p_drop >= 0.0f && p_drop < 1.0f, "spex_ngcf_layer_bwd_rows_f32: p_drop=%f", (double)p_drop);
+    if (d != 64) {
+        spex::set_error("spex_ngcf_layer_bwd_rows_f32: only d == 64 is implemented (got %d)", d);
+        return SPEX_ERR_UNSUPPORTED;
+    }
+    SPEX_CHECK_ARG((((uintptr_t)W_gc | (uintptr_t)W_bi) & 15) == 0, "spex_ngcf_layer_bwd_rows_f32: weights must be 16-byte aligned");
+    if (n == 0 || max_count == 0) return SPEX_OK;
+    const int max_tiles = (max_count + 15) / 16;
+    const int blocks = (max_tiles + kBwdWaves - 1) / kBwdWaves;      // workgroups past the list's actual length exit at once
+    hipLaunchKernelGGL((ngcf_layer_bwd_kernel<true>), dim3((unsigned)blocks), dim3(kWave * kBwdWaves), 0, (hipStream_t)stream, ego,
+                       side, W_gc, b_gc, W_bi, b_bi, g_norm, ld_g, g_next, g_direct, ld_direct, n, slope,
+                       make_drop(p_drop, seed, step, layer, pad_row), list, count, clear_consumed, g_side_c, g_ego_c, gW_gc, gb_gc,
+                       gW_bi, gb_bi);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }

@@ -1,0 +1,82 @@
+// Row-sparse pieces of the training step's backward pass.
+//
+// After a 256-sample batch the gradient with respect to the propagated table is non-zero on at most 512 rows (the
+// batch's users and items, LightGCN_SPEX/code/utility1/model.py:115-116; NGCF_SPEX/code/main_rec.py:89-90).  The first
+// product of the backward pass, A^T g, therefore touches ~14 k of Epinion2's 418 k stored entries: it is evaluated in
+// PUSH form — for every non-zero row r of g, out[c] += A[r, c] * g[r] over the stored entries of row r — instead of the
+// pull-form SpMM over the whole matrix (15 us).  SURVEY.md 7 "hard parts" names this.
+//
+//   spex_unique_rows_i32      the distinct rows of a batch (two index lists with offsets) as a compact device list;
+//                             deduplication by an epoch-stamp table, no sort, no host round trip
+//   spex_spmm_push_rows_f32   out[col[e], :] += scale * val[e] * src_k  for every stored entry e of every listed row (k-th
+//                             listed row r: src_k = src[r] or src[k]), optionally out[r, :] += scale * add_k — 256-byte float atomics
+// Sums arrive in arbitrary order (atomics): results agree with the pull form to fp32 re-association.
+#include "spex_common.h"
+
+using namespace spex;
+
+namespace {
+
+__global__ __launch_bounds__(256) void unique_rows_kernel(const int64_t *__restrict__ idx_a, int n_a, int64_t off_a,
+                                                          const int64_t *__restrict__ idx_b, int n_b, int64_t off_b,
+                                                          int32_t n_rows, int32_t *stamp, int32_t epoch, int32_t *list,
+                                                          int32_t *count)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_a + n_b) return;
+    const int64_t r = k < n_a ? idx_a[k] + off_a : idx_b[k - n_a] + off_b;
+    if (r < 0 || r >= n_rows) return;
+    if (atomicExch(stamp + r, epoch) != epoch) list[atomicAdd(count, 1)] = (int32_t)r;   // first visitor of the row this epoch
+}
+
+// One 16-wave workgroup per listed row: wave w takes the row's entries w, w + 16, ... (a hub row of 1 000 entries is 64
+// atomics per wave, not 1 000 in one).
+__global__ __launch_bounds__(kWave *kWgWaves) void spmm_push_rows_kernel(
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
+    const int32_t *__restrict__ list, const int32_t *__restrict__ count, int n_rows, const float *__restrict__ src,
+    int src_indexed, const float *__restrict__ add, int add_indexed, float scale, float *out, int d)
+{
+    const int k = blockIdx.x;
+    if (k >= *count) return;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int r = list[k];
+    if (r < 0 || r >= n_rows) return;                      // never index the matrix out of range
+    const int beg = rowptr[r], end = rowptr[r + 1];
+    for (int c0 = 0; c0 < d; c0 += kWave) {
+        const int c = c0 + lane;
+        if (c >= d) break;
+        const float g = scale * src[(size_t)(src_indexed ? r : k) * d + c];
+        for (int e = beg + wave; e < end; e += kWgWaves) atomicAdd(out + (size_t)col[e] * d + c, val[e] * g);
+        if (add && wave == 0) atomicAdd(out + (size_t)r * d + c, scale * add[(size_t)(add_indexed ? r : k) * d + c]);
+    }
+}
+
+}  // namespace
+
+extern "C" int spex_unique_rows_i32(const int64_t *idx_a, int32_t n_a, int64_t off_a, const int64_t *idx_b, int32_t n_b,
+                                    int64_t off_b, int32_t n_rows, int32_t *stamp, int32_t epoch, int32_t *list, int32_t *count,
+                                    void *stream)
+{
+    SPEX_CHECK_ARG(n_a >= 0 && n_b >= 0 && (n_a == 0 || idx_a) && (n_b == 0 || idx_b), "spex_unique_rows_i32: bad index lists");
+    SPEX_CHECK_ARG(stamp && list && count && n_rows >= 0 && epoch != 0, "spex_unique_rows_i32: NULL buffer or epoch 0");
+    SPEX_HIP(hipMemsetAsync(count, 0, sizeof(int32_t), (hipStream_t)stream));
+    if (n_a + n_b == 0) return SPEX_OK;
+    hipLaunchKernelGGL(unique_rows_kernel, dim3((unsigned)((n_a + n_b + 255) / 256)), dim3(256), 0, (hipStream_t)stream, idx_a, n_a,
+                       off_a, idx_b, n_b, off_b, n_rows, stamp, epoch, list, count);
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}
+
+extern "C" int spex_spmm_push_rows_f32(const spex_graph_t *g, const int32_t *list, const int32_t *count, int32_t max_count,
+                                       const float *src, int32_t src_indexed, const float *add, int32_t add_indexed, float scale,
+                                       float *out, int32_t d, void *stream)
+{
+    SPEX_CHECK_ARG(g && list && count && src && out, "spex_spmm_push_rows_f32: NULL argument");
+    SPEX_CHECK_ARG(max_count >= 0 && d >= 1, "spex_spmm_push_rows_f32: max_count=%d d=%d", max_count, d);
+    SPEX_CHECK_ARG(g->mask_mode == 0, "spex_spmm_push_rows_f32: edge dropout is not supported in push form");
+    if (max_count == 0 || g->n_rows == 0) return SPEX_OK;
+    hipLaunchKernelGGL(spmm_push_rows_kernel, dim3((unsigned)max_count), dim3(kWave * kWgWaves), 0, (hipStream_t)stream, g->rowptr,
+                       g->col, g->val, list, count, g->n_rows, src, src_indexed, add, add_indexed, scale, out, d);
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}

@@ -164,6 +164,7 @@ class SpexGraph:
         _lib.call("spex_graph_info", self._h, None, None, None, ctypes.byref(nl), ctypes.byref(ns))
         self.n_long_rows, self.n_segments = nl.value, ns.value
         self._mask_ref = None
+        self.mask_mode = 0
 
     # torch.sparse-like surface used by callers that only inspect the graph (dataloader.py:223 prints .size())
     def size(self):
@@ -228,6 +229,7 @@ class SpexGraph:
         if keep is not None:
             assert keep.dtype == torch.uint8 and keep.is_cuda and keep.is_contiguous()
         self._mask_ref = keep  # keep the tensor alive while the handle points at it
+        self.mask_mode = int(mode) if float(keep_prob) < 1.0 else 0
         _lib.call("spex_graph_set_edge_mask", self._h, int(mode), _ptr(keep), float(keep_prob), int(seed))
 
     def _scratch(self, key, shape, device):

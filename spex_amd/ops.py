@@ -189,6 +189,70 @@ def ngcf_layer_bwd(ego, side, W_gc, b_gc, W_bi, b_bi, g_all, layer, g_next, g_si
     _bump(g_side, g_ego, gW_gc, gb_gc, gW_bi, gb_bi)
 
 
+def ngcf_layer_bwd_rows(ego, side, W_gc, b_gc, W_bi, b_bi, g_all, layer, g_next, rows, g_side_c, g_ego_c, gW_gc, gb_gc, gW_bi,
+                        gb_bi, slope=0.01, drop=None, pad_row=-1, clear_consumed=True):
+    """ngcf_layer_bwd for the rows of a UniqueRows list only (the last layer's backward in training): compact outputs
+    g_side_c / g_ego_c [rows.capacity, d]; with clear_consumed the rows of g_all that were read are zeroed.
+    spex_ngcf_layer_bwd_rows_f32."""
+    for x, n in ((ego, "ego"), (side, "side"), (W_gc, "W_gc"), (b_gc, "b_gc"), (W_bi, "W_bi"), (b_bi, "b_bi"), (g_all, "g_all"),
+                 (g_next, "g_next"), (g_side_c, "g_side_c"), (g_ego_c, "g_ego_c"), (gW_gc, "gW_gc"), (gb_gc, "gb_gc"),
+                 (gW_bi, "gW_bi"), (gb_bi, "gb_bi")):
+        _need(x, n)
+    n, d = ego.shape
+    if g_side_c.shape[0] < rows.capacity or g_ego_c.shape[0] < rows.capacity:
+        raise ValueError("ngcf_layer_bwd_rows: compact outputs are smaller than the row list's capacity")
+    p, seed, step = drop if drop is not None else (0.0, 0, 0)
+    ld = g_all.stride(0)
+    g_norm = ctypes.c_void_p(g_all.data_ptr() + 4 * d * (layer + 1))
+    g_direct = ctypes.c_void_p(g_all.data_ptr()) if layer == 0 else None
+    _launch(ego.device, "spex_ngcf_layer_bwd_rows_f32", _ptr(ego), _ptr(side), _ptr(W_gc), _ptr(b_gc), _ptr(W_bi), _ptr(b_bi), g_norm,
+            ld, _ptr(g_next), g_direct, ld, n, d, float(slope), float(p), int(seed), int(step), int(layer), int(pad_row),
+            _ptr(rows.list), _ptr(rows.count), rows.capacity, 1 if clear_consumed else 0, _ptr(g_side_c), _ptr(g_ego_c), _ptr(gW_gc),
+            _ptr(gb_gc), _ptr(gW_bi), _ptr(gb_bi))
+    _bump(g_side_c, g_ego_c, gW_gc, gb_gc, gW_bi, gb_bi, g_all)
+
+
+class UniqueRows:
+    """The distinct rows of a batch as a compact device list (spex_unique_rows_i32): `list` int32[capacity], `count`
+    int32[1], refreshed by update() — one tiny launch, no sort, no host round trip.  n_rows: height of the table the rows
+    index."""
+
+    def __init__(self, n_rows, capacity, device):
+        self.n_rows, self.capacity = int(n_rows), int(capacity)
+        self.stamp = torch.zeros(self.n_rows, dtype=torch.int32, device=device)
+        self.list = torch.zeros(self.capacity, dtype=torch.int32, device=device)
+        self.count = torch.zeros(1, dtype=torch.int32, device=device)
+        self.epoch = 0
+
+    def update(self, idx_a, idx_b=None, off_a=0, off_b=0):
+        n_a, n_b = idx_a.numel(), 0 if idx_b is None else idx_b.numel()
+        if n_a + n_b > self.capacity:
+            raise ValueError(f"UniqueRows: {n_a + n_b} indices for a capacity of {self.capacity}")
+        for t in (idx_a, idx_b):
+            if t is not None and not (t.is_cuda and t.dtype == torch.int64 and t.is_contiguous()):
+                raise ValueError("UniqueRows.update: indices must be contiguous int64 tensors on the GPU")
+        self.epoch = self.epoch % 0x7FFFFFFF + 1          # never 0; a wrap after 2^31 - 1 steps re-uses stamps that are long stale
+        _launch(self.list.device, "spex_unique_rows_i32", _ptr(idx_a), n_a, int(off_a), _ptr(idx_b), n_b, int(off_b), self.n_rows,
+                _ptr(self.stamp), self.epoch, _ptr(self.list), _ptr(self.count))
+        return self
+
+
+def spmm_push_rows(graph, rows, src, out, src_indexed, add=None, add_indexed=False, scale=1.0):
+    """out += scale * (A^T scatter(src) + scatter(add)) for the rows of a UniqueRows list, A = the matrix of `graph`
+    (spex_spmm_push_rows_f32).  src / add: the table itself (indexed=True) or compact [capacity, d] arrays."""
+    _need(src, "src"); _need(out, "out"); _need(add, "add")
+    d = out.shape[1]
+    if out.shape[0] != graph.n_cols or rows.n_rows > graph.n_rows:
+        raise ValueError("spmm_push_rows: out must be [graph.n_cols, d] and the row list must index rows of the graph")
+    for t, ind, nm in ((src, src_indexed, "src"), (add, add_indexed, "add")):
+        if t is not None and (t.shape[1] != d or t.shape[0] < (rows.n_rows if ind else rows.capacity)):
+            raise ValueError(f"spmm_push_rows: {nm} has shape {tuple(t.shape)}")
+    _launch(out.device, "spex_spmm_push_rows_f32", graph._h, _ptr(rows.list), _ptr(rows.count), rows.capacity, _ptr(src),
+            1 if src_indexed else 0, _ptr(add), 1 if add_indexed else 0, float(scale), _ptr(out), d)
+    _bump(out)
+    return out
+
+
 def expert_gate(raw, prop, att_exp):
     """softmax([raw|prop] att_exp) two-way mix — model_expert_s.py:156-161."""
     for x, n in ((raw, "raw"), (prop, "prop"), (att_exp, "att_exp")):

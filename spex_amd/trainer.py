@@ -33,6 +33,7 @@ class LightGCNStepper:
         self.m, self.v = z(n, d), z(n, d)
         self.loss_acc = z(1)          # running loss sum of the fused BPR steps (read it when you need it)
         self.lo_batch = None          # propagated rows of the current batch (propagate_for_batch), allocated on first use
+        self.rows = None              # distinct rows of the current batch (sparse first backward layer), allocated on first use
         self.t = 0
 
     # -- pieces
@@ -70,11 +71,33 @@ class LightGCNStepper:
         B = users.numel()
         _, loss_sum = ops.score_bce(lo[:self.n_u], lo[self.n_u:], users, items, labels, self.g_out[:self.n_u],
                                     self.g_out[self.n_u:], 1.0 / B, loss_sum=loss_acc, want_gamma=False)
-        self.graph_t.propagate_bwd(self.g_out, self.L, grad_E0=self.grad_E0, ws=self.ws_bwd)
+        self.backward_from_batch_rows(users, items)
         self.t += 1
         ops.adam_step(self.E0, self.grad_E0, self.m, self.v, self.t, self.lr, self.betas[0], self.betas[1], self.eps,
                       zero=self.g_out)
         return None if loss_acc is not None else loss_sum / B
+
+    def backward_from_batch_rows(self, users, items):
+        """grad_E0 from g_out (non-zero on the batch's rows only).  The first product of the backward pass, A^T g, touches
+        only the stored entries of those <= 2B rows: it is taken in push form (spex_spmm_push_rows_f32, ~14 k entries on
+        Epinion2) instead of a pull-form SpMM over all 418 k; the remaining L - 1 products are dense.  Falls back to the
+        all-pull form where the push form does not apply (edge dropout on the handle, L < 2)."""
+        L, gt = self.L, self.graph_t
+        if L < 2 or getattr(gt, "mask_mode", 0) != 0:
+            gt.propagate_bwd(self.g_out, L, grad_E0=self.grad_E0, ws=self.ws_bwd)
+            return
+        if self.rows is None or self.rows.capacity < users.numel() + items.numel():
+            self.rows = ops.UniqueRows(self.E0.shape[0], users.numel() + items.numel(), self.E0.device)
+        self.rows.update(users, items, 0, self.n_u)
+        inv = 1.0 / float(L + 1)
+        G = self.ws_bwd[1]
+        G.zero_()
+        ops.spmm_push_rows(gt, self.rows, self.g_out, G, True, add=self.g_out, add_indexed=True, scale=inv)   # G_{L-1}
+        cur = G
+        for l in range(L - 2, -1, -1):
+            nxt = self.grad_E0 if l == 0 else self.ws_bwd[2 - ((L - 2 - l) & 1)]      # ping-pong: never the buffer being read
+            gt.spmm(cur, Y=nxt, add_in=self.g_out, add_div=float(L + 1))                                      # g/(L+1) + A^T G
+            cur = nxt
 
     def step_bpr_sgd(self, users, pos, neg, lr=None, reg=0.0):
         """Propagation + fused BPR-SGD kernel (scores from the propagated table, update on E0).  Returns the running
@@ -196,7 +219,8 @@ class NGCFStepper:
         self.sides = [z(n, d) for _ in range(L)]
         self.egos = [self.E0] + [z(n, d) for _ in range(L - 1)]
         self.g_side, self.g_ego = z(n, d), z(n, d)
-        self.g_next = [z(n, d), z(n, d)]
+        self.g_next = [z(n, d), z(n, d)]                        # g_next[(L-1) & 1] is all-zero between steps (push target)
+        self.rows, self.g_side_c, self.g_ego_c = None, None, None
         self.loss_acc = z(1)
         self.n_u = model.n_users + 1
 
@@ -218,8 +242,22 @@ class NGCFStepper:
         B = users.numel()
         ops.score_bce(self.all_emb[:self.n_u], self.all_emb[self.n_u:], users, items, labels, self.g_all[:self.n_u],
                       self.g_all[self.n_u:], 1.0 / B, loss_sum=acc, want_gamma=False)
-        g_next = None
-        for l in range(L - 1, -1, -1):
+        # backward.  Only the batch's <= 2B distinct rows carry a gradient behind the LAST layer: its backward runs on
+        # those rows (compact tiles), and A^T g_side is a push over their stored entries instead of a pull-form SpMM.
+        if self.rows is None or self.rows.capacity < 2 * B:
+            self.rows = ops.UniqueRows(self.E0.shape[0], 2 * B, self.E0.device)
+            self.g_side_c = torch.zeros((2 * B, self.E0.shape[1]), dtype=torch.float32, device=self.E0.device)
+            self.g_ego_c = torch.zeros_like(self.g_side_c)
+        self.rows.update(users, items, 0, self.n_u)
+        l = L - 1
+        dl = None if drop is None or drop[0][l] <= 0 else (drop[0][l], drop[1], drop[2])
+        ops.ngcf_layer_bwd_rows(self.egos[l], self.sides[l], *self.views[l], self.g_all, l, None, self.rows, self.g_side_c,
+                                self.g_ego_c, *self.g_views[l], drop=dl, pad_row=pad, clear_consumed=(L == 1))
+        g_next = self.g_next[l & 1]
+        if L > 1:
+            g_next.zero_()
+        ops.spmm_push_rows(m.graph, self.rows, self.g_side_c, g_next, False, add=self.g_ego_c, add_indexed=False)
+        for l in range(L - 2, -1, -1):
             dl = None if drop is None or drop[0][l] <= 0 else (drop[0][l], drop[1], drop[2])
             ops.ngcf_layer_bwd(self.egos[l], self.sides[l], *self.views[l], self.g_all, l, g_next, self.g_side, self.g_ego,
                                *self.g_views[l], drop=dl, pad_row=pad)
@@ -228,9 +266,11 @@ class NGCFStepper:
             g_next = out
         self.t += 1
         b1, b2 = self.betas
-        ops.adam_step(self.E0, g_next, self.mE, self.vE, self.t, self.lr, b1, b2, self.eps)
+        # (L == 1: the table gradient is the push target, cleared again by the Adam pass that consumes it)
+        ops.adam_step(self.E0, g_next, self.mE, self.vE, self.t, self.lr, b1, b2, self.eps, zero=g_next if L == 1 else None)
         ops.adam_step(self.W, self.gW, self.mW, self.vW, self.t, self.lr, b1, b2, self.eps, zero=self.gW)
-        self.g_all.zero_()
+        if L > 1:
+            self.g_all.zero_()
         return acc
 
 

@@ -896,3 +896,41 @@ def test_spmm_rowlist_is_the_full_product_at_the_listed_rows(G, golden, epinion2
     ok = torch.tensor([3, 4, 5, 7, 299], device=DEV)
     assert rel_err(got[ok].cpu().numpy(), want[ok].cpu().numpy()) <= 3e-6
     assert torch.equal(got[torch.tensor([3, 7, 299], device=DEV)], want[torch.tensor([3, 7, 299], device=DEV)])
+
+
+# ---------------------------------------------------------------------------------------------- row-sparse backward pieces
+def test_unique_rows_and_push_form_spmm_vs_oracle(G, oracle):
+    """spex_unique_rows_i32 + spex_spmm_push_rows_f32: the distinct rows of a batch with repeats (and an out-of-range index),
+    then out += scale * (A^T scatter(src) + scatter(add)) over those rows — against the oracle's pull-form product with the
+    transposed matrix on the same row-sparse input.  A hub row (1 500 entries) and an empty row are among the listed rows;
+    both source conventions (table-indexed / compact) are used."""
+    from spex_amd import ops
+    rng = np.random.default_rng(31)
+    n = 900
+    deg = rng.integers(0, 40, n)
+    deg[5], deg[17] = 1500, 0
+    rowptr, col, val = random_csr(rng, n, n, np.minimum(deg, n))
+    g = G(rowptr, col, val)
+    ua = rng.integers(0, 400, 256); ub = rng.integers(0, 500, 256)
+    ua[:3] = [5, 5, 17]                                   # hub twice, the empty row
+    ua[9] = 5000                                          # out of range: ignored
+    rows = ops.UniqueRows(n, 512, DEV).update(t(ua), t(ub), 0, 400)
+    want_rows = np.unique(np.concatenate([ua[ua < n], ub + 400]))
+    cnt = int(rows.count.item())
+    got_rows = np.sort(rows.list.cpu().numpy()[:cnt])
+    assert np.array_equal(got_rows, want_rows)
+    rows.update(t(ua), t(ub), 0, 400)                     # a second epoch on the same stamp table gives the same set
+    assert int(rows.count.item()) == cnt
+    listed = rows.list.cpu().numpy()[:cnt]
+    src = np.zeros((n, 64), np.float32)
+    src[want_rows] = rng.normal(size=(len(want_rows), 64)).astype(np.float32)
+    t_csr = oracle.csr_transpose(rowptr, col, val, n)
+    want = np.float32(0.25) * (oracle.spmm(*t_csr, src) + src)
+    out = torch.zeros(n, 64, device=DEV)
+    ops.spmm_push_rows(g, rows, t(src), out, True, add=t(src), add_indexed=True, scale=0.25)
+    assert rel_err(out.cpu().numpy(), want) <= 2e-6
+    compact = np.zeros((512, 64), np.float32)
+    compact[:cnt] = src[listed]
+    out2 = torch.zeros(n, 64, device=DEV)
+    ops.spmm_push_rows(g, rows, t(compact), out2, False)
+    assert rel_err(out2.cpu().numpy(), oracle.spmm(*t_csr, src)) <= 2e-6

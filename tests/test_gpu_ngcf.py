@@ -282,3 +282,40 @@ def test_whole_ngcf_epoch_matches_the_reference_epinion2(golden, ngcf_data_root)
     # random-walk by ~sqrt(4700) * 1e-3 along it (measured: W_gc differs by 0.6 of its largest entry, rows of the tables by
     # 0.1-0.4) while every loss agrees.  (LightGCN has no such direction: its epoch's tables agree to 1e-4.)
     assert all(np.isfinite(v) for v in dev.values())
+
+
+def test_layer_backward_rows_form_equals_dense_form(oracle):
+    """spex_ngcf_layer_bwd_rows_f32 (compact tiles over the batch's distinct rows) against the dense form on the same
+    inputs: same g_side / g_ego at the listed rows, same weight gradients; the consumed rows of the gradient table are
+    cleared."""
+    from spex_amd import ops
+    rng = np.random.default_rng(77)
+    n = 2000
+    ego, side = (torch.from_numpy(rng.normal(size=(n, 64)).astype(np.float32) * 0.3).to(DEV) for _ in range(2))
+    W_gc, W_bi = (torch.from_numpy(rng.normal(size=(64, 64)).astype(np.float32) * 0.2).to(DEV) for _ in range(2))
+    b_gc, b_bi = (torch.from_numpy(rng.normal(size=64).astype(np.float32) * 0.1).to(DEV) for _ in range(2))
+    users, items = torch.from_numpy(rng.integers(0, 700, 200)).to(DEV), torch.from_numpy(rng.integers(0, 1200, 200)).to(DEV)
+    rows = ops.UniqueRows(n, 400, DEV).update(users, items, 0, 700)
+    cnt = int(rows.count.item())
+    listed = rows.list[:cnt].long()
+    g_all = torch.zeros(n, 128, device=DEV)
+    g_all[listed] = torch.from_numpy(rng.normal(size=(cnt, 128)).astype(np.float32)).to(DEV)
+    drop = (0.1, 99, 3)
+    outs = {}
+    for form in ("dense", "rows"):
+        gW = [torch.zeros(64, 64, device=DEV), torch.zeros(64, device=DEV), torch.zeros(64, 64, device=DEV), torch.zeros(64, device=DEV)]
+        ga = g_all.clone()
+        if form == "dense":
+            gs, ge = torch.empty(n, 64, device=DEV), torch.empty(n, 64, device=DEV)
+            ops.ngcf_layer_bwd(ego, side, W_gc, b_gc, W_bi, b_bi, ga, 0, None, gs, ge, *gW, drop=drop, pad_row=700)
+            outs[form] = (gs[listed].cpu().numpy(), ge[listed].cpu().numpy(), [w.cpu().numpy() for w in gW])
+            assert torch.count_nonzero(gs).item() <= cnt * 64 and torch.equal(ga, g_all)
+        else:
+            gs, ge = torch.full((400, 64), 9.0, device=DEV), torch.full((400, 64), 9.0, device=DEV)
+            ops.ngcf_layer_bwd_rows(ego, side, W_gc, b_gc, W_bi, b_bi, ga, 0, None, rows, gs, ge, *gW, drop=drop, pad_row=700)
+            outs[form] = (gs[:cnt].cpu().numpy(), ge[:cnt].cpu().numpy(), [w.cpu().numpy() for w in gW])
+            assert torch.count_nonzero(ga).item() == 0                                   # consumed rows cleared
+    (s0, e0, w0), (s1, e1, w1) = outs["dense"], outs["rows"]
+    assert rel_err(s1, s0) <= 1e-6 and rel_err(e1, e0) <= 1e-6
+    for a, b in zip(w1, w0):
+        assert rel_err(a, b) <= 1e-5
