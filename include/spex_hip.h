@@ -356,6 +356,31 @@ int spex_path_attention_bwd_f32(const float *src, int64_t n_src_rows, const int6
                                 const float *a, int32_t B, int32_t L, int32_t d, int32_t n_heads, int32_t positional,
                                 const float *w0, const float *grad_out, float *grad_src, float *grad_a, void *stream);
 
+/* ------------------------------------------------------------------------------------------------ one-call training step
+ * The exact reference training step — LightGCN_SPEX/code/main_rec.py:32-37: forward (model.py:111-121), BCE,
+ * loss.backward(), optimizer.step() — as ONE call that issues the library's own launches back to back:
+ *   L-1 x spex_spmm_f32 (running layer sum) + spex_spmm_rowlist_f32 (last layer at the batch's rows)
+ *   spex_score_bce_f32 (loss + gradient rows) -> spex_unique_rows_i32 -> spex_spmm_push_rows_f32 ((g + A^T g)/(L+1))
+ *   L-1 x spex_spmm_f32 on A^T (g/(L+1) fused) -> spex_adam_step_f32 over the whole table (which clears g_out again).
+ * The descriptor holds the step's device buffers (all caller-owned, N = graph rows, d == 64):
+ *   E0, m, v, light_out, lo_batch, g_out, grad_E0: [N, d];  ws_fwd: [2, N, d];  ws_bwd: [3, N, d];
+ *   stamp: int32[N], zero-initialised once;  row_list: int32[row_capacity >= 2B];  row_count: int32[1].
+ * g_out must be all-zero before the first call (the call leaves it all-zero).  t and epoch are advanced by the call.
+ * users / items: device int64[B] (items index the item block: row n_user_rows + items[b]); labels: device fp32[B].
+ * *loss_sum (device) accumulates the batch's BCE loss SUM.  L >= 1; no edge dropout (use the separate calls then).
+ */
+typedef struct spex_lightgcn_step {
+    const spex_graph_t *graph, *graph_t;     /* A and A^T (the same handle for the symmetric LightGCN adjacency) */
+    float *E0, *m, *v;
+    float *light_out, *ws_fwd, *lo_batch, *g_out, *ws_bwd, *grad_E0;
+    int32_t *stamp, *row_list, *row_count;
+    int32_t row_capacity, n_user_rows, L, d;
+    float lr, beta1, beta2, eps;
+    int32_t t, epoch;
+} spex_lightgcn_step_t;
+int spex_lightgcn_step_bce_f32(spex_lightgcn_step_t *step, const int64_t *users, const int64_t *items, const float *labels,
+                               int32_t B, float *loss_sum, void *stream);
+
 /* ------------------------------------------------------------------------------------------------ profiling hook
  * Not part of any reference interface: lets a caller time the dominant kernel itself, in place, on the stream it is
  * launched on (bench.py's roofline figure).  While a timer is attached to a graph, every (or every n-th) call of

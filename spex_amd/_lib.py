@@ -65,11 +65,22 @@ SIGNATURES = {
                                                c_vp]),
     "spex_path_attention_bwd_f32": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp,
                                                    c_vp, c_vp, c_vp, c_vp]),
+    "spex_lightgcn_step_bce_f32": (ctypes.c_int, [ctypes.c_void_p, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "spex_timer_create": (ctypes.c_int, [c_i32, c_i32, ctypes.POINTER(c_vp)]),
     "spex_timer_destroy": (ctypes.c_int, [c_vp]),
     "spex_timer_attach": (ctypes.c_int, [c_vp, c_vp]),
     "spex_timer_read": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, ctypes.POINTER(c_i32), ctypes.c_int]),
 }
+
+
+
+class LightGCNStepDesc(ctypes.Structure):
+    """spex_lightgcn_step_t (include/spex_hip.h)."""
+    _fields_ = ([(n, c_vp) for n in ("graph", "graph_t", "E0", "m", "v", "light_out", "ws_fwd", "lo_batch", "g_out", "ws_bwd",
+                                     "grad_E0", "stamp", "row_list", "row_count")]
+                + [(n, c_i32) for n in ("row_capacity", "n_user_rows", "L", "d")]
+                + [(n, c_f32) for n in ("lr", "beta1", "beta2", "eps")] + [("t", c_i32), ("epoch", c_i32)])
+
 
 _lib = None
 

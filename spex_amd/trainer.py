@@ -67,6 +67,8 @@ class LightGCNStepper:
         step is exactly eight launches (3 SpMM, scoring, 3 SpMM, Adam) with nothing between them.  The gradient table
         is cleared by the Adam pass of the previous step.  batch_rows_only: compute the last forward layer at the
         batch's rows only (same arithmetic for those rows; `self.light_out` is then not the whole table)."""
+        if batch_rows_only and loss_acc is not None and self._one_call_ok(users, items, labels):
+            return self._step_bce_one_call(users, items, labels, loss_acc)
         lo = self.propagate_for_batch(users, items) if batch_rows_only else self.propagate()
         B = users.numel()
         _, loss_sum = ops.score_bce(lo[:self.n_u], lo[self.n_u:], users, items, labels, self.g_out[:self.n_u],
@@ -76,6 +78,40 @@ class LightGCNStepper:
         ops.adam_step(self.E0, self.grad_E0, self.m, self.v, self.t, self.lr, self.betas[0], self.betas[1], self.eps,
                       zero=self.g_out)
         return None if loss_acc is not None else loss_sum / B
+
+    # -- the whole step as one library call (spex_lightgcn_step_bce_f32): same launches, issued from native code
+    def _one_call_ok(self, users, items, labels):
+        return (self.L >= 1 and self.E0.shape[1] == 64 and getattr(self.graph, "mask_mode", 0) == 0
+                and getattr(self.graph_t, "mask_mode", 0) == 0 and users.is_cuda and items.is_cuda and labels.is_cuda
+                and users.dtype == torch.int64 and items.dtype == torch.int64 and labels.dtype == torch.float32
+                and users.is_contiguous() and items.is_contiguous() and labels.is_contiguous()
+                and users.numel() == items.numel() == labels.numel() and users.numel() >= 1)
+
+    def _step_bce_one_call(self, users, items, labels, loss_acc):
+        import ctypes
+        from . import _lib
+        from .graph import _bump, _launch
+        B = users.numel()
+        if self.lo_batch is None:
+            self.lo_batch = torch.zeros_like(self.light_out)
+        if self.rows is None or self.rows.capacity < 2 * B:
+            self.rows = ops.UniqueRows(self.E0.shape[0], 2 * B, self.E0.device)
+            self._desc = None
+        if getattr(self, "_desc", None) is None:
+            p = lambda t: t.data_ptr()
+            self._desc = _lib.LightGCNStepDesc(
+                graph=self.graph._h.value, graph_t=self.graph_t._h.value, E0=p(self.E0), m=p(self.m), v=p(self.v),
+                light_out=p(self.light_out), ws_fwd=p(self.ws_fwd), lo_batch=p(self.lo_batch), g_out=p(self.g_out),
+                ws_bwd=p(self.ws_bwd), grad_E0=p(self.grad_E0), stamp=p(self.rows.stamp), row_list=p(self.rows.list),
+                row_count=p(self.rows.count), row_capacity=self.rows.capacity, n_user_rows=self.n_u, L=self.L, d=self.E0.shape[1],
+                lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, t=self.t, epoch=self.rows.epoch)
+        d = self._desc
+        d.t, d.lr = self.t, self.lr
+        _launch(self.E0.device, "spex_lightgcn_step_bce_f32", ctypes.byref(d), ctypes.c_void_p(users.data_ptr()),
+                ctypes.c_void_p(items.data_ptr()), ctypes.c_void_p(labels.data_ptr()), B, ctypes.c_void_p(loss_acc.data_ptr()))
+        self.t, self.rows.epoch = d.t, d.epoch
+        _bump(self.E0, self.m, self.v, loss_acc)
+        return None
 
     def backward_from_batch_rows(self, users, items):
         """grad_E0 from g_out (non-zero on the batch's rows only).  The first product of the backward pass, A^T g, touches

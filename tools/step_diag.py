@@ -15,8 +15,19 @@ st = LightGCNStepper(g, E0, 3186, n_layers=3, lr=1e-3)
 u = torch.randint(0, 3185, (256,), device=dev); i = torch.randint(0, 12407, (256,), device=dev)
 y = (torch.rand(256, device=dev) < 1 / 6).float()
 acc = torch.zeros(1, device=dev)
+import gc; gc.collect(); gc.freeze()
 for name, fn in (("full", lambda: st.step_bce(u, i, y, loss_acc=acc)), ("rows_only", lambda: st.step_bce(u, i, y, loss_acc=acc, batch_rows_only=True)),
-                 ("propagate", st.propagate), ("bpr2048", lambda: st.step_bpr_sgd(u, i, i))):
+                 ("propagate", st.propagate), ("bpr2048", lambda: st.step_bpr_sgd(u, i, i)), ("ngcf_stepper", None)):
+    if name == "ngcf_stepper":
+        import argparse, scipy.sparse as sp
+        from spex_amd.graph import ngcf_norm_adj
+        from spex_amd.ngcf import NGCF
+        from spex_amd.trainer import NGCFStepper
+        nc = ngcf_norm_adj(tr[:, 0], tr[:, 1], 3185, 12407)
+        net = NGCF({"n_users": 3185, "n_items": 12407, "norm_adj": sp.csr_matrix((nc[2], nc[1], nc[0]), shape=(15592, 15592))}, dev,
+                   argparse.Namespace(embed_size=64, layer_size="[64]", mess_dropout="[0.1]", regs="[1e-5]")).to(dev)
+        nst = NGCFStepper(net)
+        fn = lambda: nst.step(u, i, y, loss_acc=acc)
     for _ in range(20): fn()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
