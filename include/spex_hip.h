@@ -197,6 +197,13 @@ int spex_scatter_add_owned_rows_f32(float *upd, const int64_t *pos, int64_t K, i
 int spex_adam_step_f32(float *p, const float *g, float *m, float *v, int64_t n, int32_t t, float lr, float beta1,
                        float beta2, float eps, float *zero_buf, void *stream);
 
+/* The same update for a small parameter block whose gradient arrives as n_parts partial blocks (block j at g_parts +
+ * j * part_stride): g = the blocks added up in order, then Adam.  Used for NGCF's layer weights, whose gradient leaves
+ * spex_ngcf_layer_bwd_rows_f32 as one block per workgroup.
+ */
+int spex_adam_step_sum_f32(float *p, const float *g_parts, int32_t n_parts, int64_t part_stride, float *m, float *v, int64_t n,
+                           int32_t t, float lr, float beta1, float beta2, float eps, void *stream);
+
 /* ------------------------------------------------------------------------------------------------ NGCF layer
  * Replaces NGCF_SPEX/code/main_rec.py:77-83 for one layer, given side = A ego from spex_spmm_f32 (:76):
  *   s    = LeakyReLU(side W_gc^T + b_gc);  b = LeakyReLU((ego * side) W_bi^T + b_bi);  e1 = dropout_p(s + b)
@@ -233,20 +240,26 @@ int spex_ngcf_layer_bwd_f32(const float *ego, const float *side, const float *W_
                             uint64_t seed, uint32_t step, uint32_t layer, int32_t pad_row, float *g_side, float *g_ego,
                             float *gW_gc, float *gb_gc, float *gW_bi, float *gb_bi, void *stream);
 
-/* The same backward for the rows of a device LIST only — the form the LAST layer takes in training: after a B-sample
- * batch only the batch's <= 2B distinct rows carry a gradient behind it (main_rec.py:89-90), so 2B / 16 tiles replace
- * n / 16.  list / count: device int32 row list and its length (from spex_unique_rows_i32; max_count bounds the launch).
- * g_side_c / g_ego_c: COMPACT outputs [max_count, d], entry k belonging to row list[k] — the operands of
- * spex_spmm_push_rows_f32, which completes d loss / d ego = scatter(g_ego_c) + A^T scatter(g_side_c).
+/* The same backward for the rows of a BATCH only — the form the LAST layer takes in training: after a B-sample batch
+ * only the batch's <= 2B distinct rows carry a gradient behind it (main_rec.py:89-90), so 2B / 16 tiles replace n / 16.
+ * The batch is given as it is scored: slot k < n_a is row idx_a[k] + off_a, slot n_a + k is row idx_b[k] + off_b (device
+ * int64); a slot is processed iff no earlier slot names the same row (checked in the kernel: no list, no extra launch).
+ * g_side_c / g_ego_c: COMPACT outputs [n_a + n_b, d], slot k belonging to its row (slots that are skipped are not
+ * written) — the operands of spex_spmm_push_batch_f32, which completes d loss / d ego = scatter(g_ego_c) + A^T scatter(g_side_c).
  * clear_consumed != 0: the rows of g_norm / g_direct that were read are set to zero (they are the only non-zero rows:
- * the caller's gradient table is all-zero again without a fill pass).  Weight gradients are accumulated as above.
+ * the caller's gradient table is all-zero again without a fill pass).
+ * Weight gradients leave as spex_ngcf_layer_bwd_rows_parts(n_a + n_b) partial blocks, block j at gW_parts + j * part_stride,
+ * each laid out [dW_gc d*d | db_gc d | dW_bi d*d | db_bi d] (plain stores; every block is written, unused ones with zeros):
+ * add them up — spex_adam_step_sum_f32 does, inside the optimiser pass.
  */
+int32_t spex_ngcf_layer_bwd_rows_parts(int32_t n_slots);
 int spex_ngcf_layer_bwd_rows_f32(const float *ego, const float *side, const float *W_gc, const float *b_gc,
                                  const float *W_bi, const float *b_bi, float *g_norm, int32_t ld_g, const float *g_next,
                                  float *g_direct, int32_t ld_direct, int32_t n, int32_t d, float slope, float p_drop,
-                                 uint64_t seed, uint32_t step, uint32_t layer, int32_t pad_row, const int32_t *list,
-                                 const int32_t *count, int32_t max_count, int32_t clear_consumed, float *g_side_c,
-                                 float *g_ego_c, float *gW_gc, float *gb_gc, float *gW_bi, float *gb_bi, void *stream);
+                                 uint64_t seed, uint32_t step, uint32_t layer, int32_t pad_row, const int64_t *idx_a,
+                                 int32_t n_a, int64_t off_a, const int64_t *idx_b, int32_t n_b, int64_t off_b,
+                                 int32_t clear_consumed, float *g_side_c, float *g_ego_c, float *gW_parts, int32_t part_stride,
+                                 void *stream);
 
 /* ------------------------------------------------------------------------------------------------ row-sparse backward
  * After a B-sample batch d loss / d (propagated table) is non-zero on <= 2B rows (model.py:115-116), so the FIRST product
@@ -270,6 +283,14 @@ int spex_unique_rows_i32(const int64_t *idx_a, int32_t n_a, int64_t off_a, const
 int spex_spmm_push_rows_f32(const spex_graph_t *g, const int32_t *list, const int32_t *count, int32_t max_count,
                             const float *src, int32_t src_indexed, const float *add, int32_t add_indexed, float scale,
                             float *out, int32_t d, void *stream);
+/* The same product driven by the batch itself (d == 64): slot k (idx_a[k] + off_a, then idx_b[k] + off_b) is processed iff
+ * no earlier slot names its row — ONE launch, where the list form needs a fill, spex_unique_rows_i32 and the push (each
+ * small launch costs ~4 us on the stream).  A slot's row is shared by 16 workgroups, so a hub row's atomics spread over
+ * 16 CUs.  src_indexed / add_indexed = 0 reads the compact arrays at the SLOT index k.
+ */
+int spex_spmm_push_batch_f32(const spex_graph_t *g, const int64_t *idx_a, int32_t n_a, int64_t off_a, const int64_t *idx_b,
+                             int32_t n_b, int64_t off_b, const float *src, int32_t src_indexed, const float *add,
+                             int32_t add_indexed, float scale, float *out, int32_t d, void *stream);
 
 /* Replaces the two-expert gate of the dual-task model, utility1/model_expert_s.py:156-161:
  *   att = softmax([raw | prop] att_exp, dim=1) ([n,2d] x [2d,2]);  mixed = raw * att[:,0] + prop * att[:,1]
@@ -360,12 +381,12 @@ int spex_path_attention_bwd_f32(const float *src, int64_t n_src_rows, const int6
  * The exact reference training step — LightGCN_SPEX/code/main_rec.py:32-37: forward (model.py:111-121), BCE,
  * loss.backward(), optimizer.step() — as ONE call that issues the library's own launches back to back:
  *   L-1 x spex_spmm_f32 (running layer sum) + spex_spmm_rowlist_f32 (last layer at the batch's rows)
- *   spex_score_bce_f32 (loss + gradient rows) -> spex_unique_rows_i32 -> spex_spmm_push_rows_f32 ((g + A^T g)/(L+1))
+ *   spex_score_bce_f32 (loss + gradient rows) -> spex_spmm_push_batch_f32 ((g + A^T g)/(L+1), batch rows only)
  *   L-1 x spex_spmm_f32 on A^T (g/(L+1) fused) -> spex_adam_step_f32 over the whole table (which clears g_out again).
  * The descriptor holds the step's device buffers (all caller-owned, N = graph rows, d == 64):
- *   E0, m, v, light_out, lo_batch, g_out, grad_E0: [N, d];  ws_fwd: [2, N, d];  ws_bwd: [3, N, d];
- *   stamp: int32[N], zero-initialised once;  row_list: int32[row_capacity >= 2B];  row_count: int32[1].
- * g_out must be all-zero before the first call (the call leaves it all-zero).  t and epoch are advanced by the call.
+ *   E0, m, v, light_out, lo_batch, g_out, grad_E0: [N, d];  ws_fwd: [2, N, d];  ws_bwd: [3, N, d].
+ * g_out and the first [N, d] of ws_bwd must be all-zero before the first call (every call leaves them all-zero: the Adam
+ * pass clears both).  t is advanced by the call.
  * users / items: device int64[B] (items index the item block: row n_user_rows + items[b]); labels: device fp32[B].
  * *loss_sum (device) accumulates the batch's BCE loss SUM.  L >= 1; no edge dropout (use the separate calls then).
  */
@@ -373,10 +394,9 @@ typedef struct spex_lightgcn_step {
     const spex_graph_t *graph, *graph_t;     /* A and A^T (the same handle for the symmetric LightGCN adjacency) */
     float *E0, *m, *v;
     float *light_out, *ws_fwd, *lo_batch, *g_out, *ws_bwd, *grad_E0;
-    int32_t *stamp, *row_list, *row_count;
-    int32_t row_capacity, n_user_rows, L, d;
+    int32_t n_user_rows, L, d;
     float lr, beta1, beta2, eps;
-    int32_t t, epoch;
+    int32_t t;
 } spex_lightgcn_step_t;
 int spex_lightgcn_step_bce_f32(spex_lightgcn_step_t *step, const int64_t *users, const int64_t *items, const float *labels,
                                int32_t B, float *loss_sum, void *stream);

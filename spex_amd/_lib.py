@@ -46,9 +46,13 @@ SIGNATURES = {
     "spex_ngcf_layer_bwd_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32,
                                                c_f32, c_f32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, c_i32, c_vp,
                                                c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "spex_ngcf_layer_bwd_rows_parts": (c_i32, [c_i32]),
     "spex_ngcf_layer_bwd_rows_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32,
                                                     c_f32, c_f32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, c_i32, c_vp,
-                                                    c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+                                                    c_i32, c_i64, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp]),
+    "spex_spmm_push_batch_f32": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_vp, c_i32, c_vp, c_i32, c_f32, c_vp,
+                                                c_i32, c_vp]),
+    "spex_adam_step_sum_f32": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i64, c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_f32, c_f32, c_vp]),
     "spex_unique_rows_i32": (ctypes.c_int, [c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "spex_spmm_push_rows_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_f32, c_vp, c_i32, c_vp]),
     "spex_expert_gate_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
@@ -77,9 +81,9 @@ SIGNATURES = {
 class LightGCNStepDesc(ctypes.Structure):
     """spex_lightgcn_step_t (include/spex_hip.h)."""
     _fields_ = ([(n, c_vp) for n in ("graph", "graph_t", "E0", "m", "v", "light_out", "ws_fwd", "lo_batch", "g_out", "ws_bwd",
-                                     "grad_E0", "stamp", "row_list", "row_count")]
-                + [(n, c_i32) for n in ("row_capacity", "n_user_rows", "L", "d")]
-                + [(n, c_f32) for n in ("lr", "beta1", "beta2", "eps")] + [("t", c_i32), ("epoch", c_i32)])
+                                     "grad_E0")]
+                + [(n, c_i32) for n in ("n_user_rows", "L", "d")]
+                + [(n, c_f32) for n in ("lr", "beta1", "beta2", "eps")] + [("t", c_i32)])
 
 
 _lib = None

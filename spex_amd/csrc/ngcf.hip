@@ -212,9 +212,9 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
     const float *__restrict__ ego, const float *__restrict__ side, const float *__restrict__ W_gc,
     const float *__restrict__ b_gc, const float *__restrict__ W_bi, const float *__restrict__ b_bi,
     float *g_norm, int ld_g, const float *__restrict__ g_next, float *g_direct,
-    int ld_direct, int n, float slope, const MsgDrop drop, const int32_t *__restrict__ list,
-    const int32_t *__restrict__ count, int clear_consumed, float *__restrict__ g_side, float *__restrict__ g_ego,
-    float *gW_gc, float *gb_gc, float *gW_bi, float *gb_bi)
+    int ld_direct, int n, float slope, const MsgDrop drop, const int64_t *__restrict__ idx_a, int n_a, int64_t off_a,
+    const int64_t *__restrict__ idx_b, int n_b, int64_t off_b, int clear_consumed, float *__restrict__ g_side,
+    float *__restrict__ g_ego, float *gW_gc, float *gb_gc, float *gW_bi, float *gb_bi, float *partials, int part_stride)
 {
     __shared__ float s_w[2][64 * kLdsStride];                   // W_gc, W_bi as [out o][in k]
     __shared__ float s_dw[2][64 * kDwStride];                   // this workgroup's share of dW_gc, dW_bi
@@ -222,9 +222,8 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
     __shared__ float s_t[kBwdWaves][2][16 * kLdsStride];        // per wave: side tile / G_s, product tile / G_t
     __shared__ int s_active;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-    const int n_items = ROWS ? *count : n;                      // rows to process (listed rows / all rows)
+    const int n_items = ROWS ? n_a + n_b : n;                   // slots to process (batch slots / all rows)
     const int n_tiles = (n_items + 15) >> 4;
-    if ((int)blockIdx.x * kBwdWaves >= n_tiles) return;         // (workgroup-uniform) nothing for this workgroup
     for (int i = threadIdx.x; i < 64 * 16; i += blockDim.x) {
         const int r = i >> 4, c4 = (i & 15) * 4;
         const float4 a = *reinterpret_cast<const float4 *>(W_gc + r * 64 + c4);
@@ -258,13 +257,23 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
     bool did_work = false;
     for (int tile = blockIdx.x * kBwdWaves + wave; tile < n_tiles; tile += gridDim.x * kBwdWaves) {
         const int r0 = tile << 4;
-        // the tile's rows: consecutive, or entries of the list (-1 = past the end)
+        // the tile's rows: consecutive rows, or the rows of 16 batch slots — a slot counts iff it is the first slot that
+        // names its row (-1 otherwise and past the end); lane i keeps slot i's row in `slot_row`
+        int slot_row = -1;
+        if (ROWS) {
+            for (int i = 0; i < 16; ++i) {
+                const int k = r0 + i;
+                if (k >= n_items) break;
+                const long long r = batch_row(idx_a, n_a, off_a, idx_b, off_b, k);
+                const bool ok = r >= 0 && r < n && first_occurrence(idx_a, n_a, off_a, idx_b, off_b, k, r, lane);
+                if (lane == i) slot_row = ok ? (int)r : -1;
+            }
+        } else if (lane < 16 && r0 + lane < n) {
+            slot_row = r0 + lane;
+        }
         int row_q[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = r0 + 4 * h + q;
-            row_q[q] = k < n_items ? (ROWS ? list[k] : k) : -1;
-        }
+        for (int q = 0; q < 4; ++q) row_q[q] = __shfl(slot_row, 4 * h + q, kWave);
         // upstream gradients in the accumulator layout: element (row 4h + q, column 16b + i16)
         float gn[4][4], gx[4][4];
         bool any = false;
@@ -296,8 +305,7 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
         // stage the tile (lane == column) for the recomputation
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int k = r0 + i;
-            const int r = k < n_items ? (ROWS ? list[k] : k) : -1;
+            const int r = __builtin_amdgcn_readlane(slot_row, i);
             float e = 0.0f, sd = 0.0f;
             if (r >= 0) {
                 e = ego[(size_t)r * 64 + lane];
@@ -445,7 +453,7 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
     // ---- weight gradients: registers -> LDS (one wave at a time, plain adds) -> global atomics
     if (did_work && lane == 0) s_active = 1;
     __syncthreads();
-    if (!s_active) return;
+    if (!s_active && !partials) return;
     for (int w = 0; w < kBwdWaves; ++w) {
         if (wave == w && did_work) {
 #pragma unroll
@@ -472,6 +480,22 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
             }
         }
         __syncthreads();
+    }
+    if (partials) {
+        // this workgroup's share as one block [dW_gc 64x64 | db_gc 64 | dW_bi 64x64 | db_bi 64] (plain stores: a CU issues
+        // one 256-byte float atomic per ~50 ns, so 8 K atomic addresses per workgroup were 13 us of this kernel); the
+        // consumer — spex_adam_step_sum_f32 — adds the blocks up
+        float *dst = partials + (size_t)blockIdx.x * part_stride;
+        for (int k = threadIdx.x; k < 64 * 64; k += blockDim.x) {
+            const int o = k >> 6, c = k & 63;
+            dst[k] = s_dw[0][o * kDwStride + c];
+            dst[64 * 64 + 64 + k] = s_dw[1][o * kDwStride + c];
+        }
+        if (threadIdx.x < 64) {
+            dst[64 * 64 + threadIdx.x] = s_db[0][threadIdx.x];
+            dst[2 * 64 * 64 + 64 + threadIdx.x] = s_db[1][threadIdx.x];
+        }
+        return;
     }
     for (int k = threadIdx.x; k < 64 * 64; k += blockDim.x) {
         const int o = k >> 6, c = k & 63;
@@ -571,6 +595,12 @@ inline unsigned grid_for_rows(int n)
 
 }  // namespace
 
+extern "C" int32_t spex_ngcf_layer_bwd_rows_parts(int32_t n_slots)
+{
+    const int tiles = (n_slots + 15) / 16;
+    return (tiles + kBwdWaves - 1) / kBwdWaves;
+}
+
 static MsgDrop make_drop(float p_drop, uint64_t seed, uint32_t step, uint32_t layer, int32_t pad_row)
 {
     MsgDrop d;
@@ -638,8 +668,8 @@ extern "C" int spex_ngcf_layer_bwd_f32(const float *ego, const float *side, cons
     if (blocks > 128) blocks = 128;      // <= 128 x 8 K weight-gradient atomics; a wave walks its tiles with a stride
     hipLaunchKernelGGL((ngcf_layer_bwd_kernel<false>), dim3((unsigned)blocks), dim3(kWave * kBwdWaves), 0, (hipStream_t)stream, ego,
                        side, W_gc, b_gc, W_bi, b_bi, const_cast<float *>(g_norm), ld_g, g_next, const_cast<float *>(g_direct), ld_direct,
-                       n, slope, make_drop(p_drop, seed, step, layer, pad_row), nullptr, nullptr, 0, g_side, g_ego, gW_gc, gb_gc,
-                       gW_bi, gb_bi);
+                       n, slope, make_drop(p_drop, seed, step, layer, pad_row), nullptr, 0, 0, nullptr, 0, 0, 0, g_side, g_ego, gW_gc,
+                       gb_gc, gW_bi, gb_bi, nullptr, 0);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }
@@ -648,28 +678,27 @@ extern "C" int spex_ngcf_layer_bwd_rows_f32(const float *ego, const float *side,
                                             const float *W_bi, const float *b_bi, float *g_norm, int32_t ld_g,
                                             const float *g_next, float *g_direct, int32_t ld_direct, int32_t n, int32_t d,
                                             float slope, float p_drop, uint64_t seed, uint32_t step, uint32_t layer,
-                                            int32_t pad_row, const int32_t *list, const int32_t *count, int32_t max_count,
-                                            int32_t clear_consumed, float *g_side_c, float *g_ego_c, float *gW_gc, float *gb_gc,
-                                            float *gW_bi, float *gb_bi, void *stream)
+                                            int32_t pad_row, const int64_t *idx_a, int32_t n_a, int64_t off_a,
+                                            const int64_t *idx_b, int32_t n_b, int64_t off_b, int32_t clear_consumed,
+                                            float *g_side_c, float *g_ego_c, float *gW_parts, int32_t part_stride, void *stream)
 {
-    SPEX_CHECK_ARG(ego && side && W_gc && b_gc && W_bi && b_bi && g_norm && g_side_c && g_ego_c && gW_gc && gb_gc && gW_bi && gb_bi
-                       && list && count,
+    SPEX_CHECK_ARG(ego && side && W_gc && b_gc && W_bi && b_bi && g_norm && g_side_c && g_ego_c && gW_parts,
                    "spex_ngcf_layer_bwd_rows_f32: NULL pointer");
-    SPEX_CHECK_ARG(n >= 0 && max_count >= 0 && ld_g >= d && (!g_direct || ld_direct >= d),
-                   "spex_ngcf_layer_bwd_rows_f32: n=%d max_count=%d ld_g=%d ld_direct=%d", n, max_count, ld_g, ld_direct);
+    SPEX_CHECK_ARG(n_a >= 0 && n_b >= 0 && (n_a == 0 || idx_a) && (n_b == 0 || idx_b), "spex_ngcf_layer_bwd_rows_f32: bad index lists");
+    SPEX_CHECK_ARG(n >= 0 && ld_g >= d && (!g_direct || ld_direct >= d) && part_stride >= 2 * (d * d + d),
+                   "spex_ngcf_layer_bwd_rows_f32: n=%d ld_g=%d ld_direct=%d part_stride=%d", n, ld_g, ld_direct, part_stride);
     SPEX_CHECK_ARG(p_drop >= 0.0f && p_drop < 1.0f, "spex_ngcf_layer_bwd_rows_f32: p_drop=%f", (double)p_drop);
     if (d != 64) {
         spex::set_error("spex_ngcf_layer_bwd_rows_f32: only d == 64 is implemented (got %d)", d);
         return SPEX_ERR_UNSUPPORTED;
     }
     SPEX_CHECK_ARG((((uintptr_t)W_gc | (uintptr_t)W_bi) & 15) == 0, "spex_ngcf_layer_bwd_rows_f32: weights must be 16-byte aligned");
-    if (n == 0 || max_count == 0) return SPEX_OK;
-    const int max_tiles = (max_count + 15) / 16;
-    const int blocks = (max_tiles + kBwdWaves - 1) / kBwdWaves;      // workgroups past the list's actual length exit at once
+    if (n == 0 || n_a + n_b == 0) return SPEX_OK;
+    const int blocks = spex_ngcf_layer_bwd_rows_parts(n_a + n_b);
     hipLaunchKernelGGL((ngcf_layer_bwd_kernel<true>), dim3((unsigned)blocks), dim3(kWave * kBwdWaves), 0, (hipStream_t)stream, ego,
                        side, W_gc, b_gc, W_bi, b_bi, g_norm, ld_g, g_next, g_direct, ld_direct, n, slope,
-                       make_drop(p_drop, seed, step, layer, pad_row), list, count, clear_consumed, g_side_c, g_ego_c, gW_gc, gb_gc,
-                       gW_bi, gb_bi);
+                       make_drop(p_drop, seed, step, layer, pad_row), idx_a, n_a, off_a, idx_b, n_b, off_b, clear_consumed, g_side_c,
+                       g_ego_c, nullptr, nullptr, nullptr, nullptr, gW_parts, part_stride);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }

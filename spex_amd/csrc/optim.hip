@@ -27,7 +27,7 @@ __device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, flo
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *g,
                                                    float *__restrict__ m, float *__restrict__ v, int64_t n4,
                                                    int64_t rem, float w1, float beta2, float w2, float bc2_sqrt,
-                                                   float eps, float step_size, float *zero_buf)
+                                                   float eps, float step_size, float *zero_buf, float *zero_buf2)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -43,6 +43,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
         reinterpret_cast<float4 *>(m)[i] = M;
         reinterpret_cast<float4 *>(v)[i] = V;
         if (zero_buf) reinterpret_cast<float4 *>(zero_buf)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (zero_buf2) reinterpret_cast<float4 *>(zero_buf2)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     if (blockIdx.x == 0 && (int64_t)threadIdx.x < rem) {
         const int64_t i = n4 * 4 + threadIdx.x;
@@ -50,19 +51,22 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
         adam1(P, g[i], M, V, w1, beta2, w2, bc2_sqrt, eps, step_size);
         p[i] = P; m[i] = M; v[i] = V;
         if (zero_buf) zero_buf[i] = 0.0f;
+        if (zero_buf2) zero_buf2[i] = 0.0f;
     }
 }
 
 }  // namespace
 
-extern "C" int spex_adam_step_f32(float *p, const float *g, float *m, float *v, int64_t n, int32_t t, float lr,
-                                  float beta1, float beta2, float eps, float *zero_buf, void *stream)
+// Internal form with a second buffer to clear (the one-call training step keeps its push target all-zero this way).
+int spex::adam_step_z2(float *p, const float *g, float *m, float *v, int64_t n, int32_t t, float lr, float beta1, float beta2,
+                       float eps, float *zero_buf, float *zero_buf2, void *stream)
 {
     SPEX_CHECK_ARG(p && g && m && v, "spex_adam_step_f32: NULL pointer");
     SPEX_CHECK_ARG(n >= 0 && t >= 1, "spex_adam_step_f32: n=%lld t=%d (t counts from 1)", (long long)n, t);
-    SPEX_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)zero_buf) & 15) == 0,
+    SPEX_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)zero_buf | (uintptr_t)zero_buf2) & 15) == 0,
                    "spex_adam_step_f32: pointers must be 16-byte aligned");
     SPEX_CHECK_ARG(zero_buf != p && zero_buf != m && zero_buf != v, "spex_adam_step_f32: zero_buf aliases p, m or v");
+    SPEX_CHECK_ARG(!zero_buf2 || (zero_buf2 != p && zero_buf2 != m && zero_buf2 != v), "spex_adam_step_f32: zero_buf aliases p, m or v");
     if (n == 0) return SPEX_OK;
     const double bc1 = 1.0 - pow((double)beta1, (double)t);
     const double bc2 = 1.0 - pow((double)beta2, (double)t);
@@ -73,7 +77,43 @@ extern "C" int spex_adam_step_f32(float *p, const float *g, float *m, float *v, 
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, rem,
-                       1.0f - beta1, beta2, 1.0f - beta2, bc2_sqrt, eps, step_size, zero_buf);
+                       1.0f - beta1, beta2, 1.0f - beta2, bc2_sqrt, eps, step_size, zero_buf, zero_buf2);
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}
+
+extern "C" int spex_adam_step_f32(float *p, const float *g, float *m, float *v, int64_t n, int32_t t, float lr,
+                                  float beta1, float beta2, float eps, float *zero_buf, void *stream)
+{
+    return spex::adam_step_z2(p, g, m, v, n, t, lr, beta1, beta2, eps, zero_buf, nullptr, stream);
+}
+
+// Adam over a small parameter block whose gradient arrives as n_parts partial blocks (one per workgroup of the kernel that
+// produced it): g = sum of the parts, taken in part order (deterministic), then the usual update.  One thread per parameter.
+namespace {
+__global__ __launch_bounds__(256) void adam_sum_kernel(float *__restrict__ p, const float *__restrict__ parts, int n_parts,
+                                                       int64_t part_stride, float *__restrict__ m, float *__restrict__ v, int64_t n,
+                                                       float w1, float beta2, float w2, float bc2_sqrt, float eps, float step_size)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float g = 0.0f;
+    for (int k = 0; k < n_parts; ++k) g += parts[(size_t)k * part_stride + i];
+    float P = p[i], M = m[i], V = v[i];
+    adam1(P, g, M, V, w1, beta2, w2, bc2_sqrt, eps, step_size);
+    p[i] = P; m[i] = M; v[i] = V;
+}
+}  // namespace
+
+extern "C" int spex_adam_step_sum_f32(float *p, const float *g_parts, int32_t n_parts, int64_t part_stride, float *m, float *v,
+                                      int64_t n, int32_t t, float lr, float beta1, float beta2, float eps, void *stream)
+{
+    SPEX_CHECK_ARG(p && g_parts && m && v && n >= 0 && n_parts >= 1 && part_stride >= n && t >= 1,
+                   "spex_adam_step_sum_f32: bad argument (n=%lld n_parts=%d stride=%lld t=%d)", (long long)n, n_parts, (long long)part_stride, t);
+    if (n == 0) return SPEX_OK;
+    const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
+    hipLaunchKernelGGL(adam_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g_parts, n_parts,
+                       part_stride, m, v, n, 1.0f - beta1, beta2, 1.0f - beta2, (float)sqrt(bc2), eps, (float)(lr / bc1));
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }

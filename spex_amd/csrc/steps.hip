@@ -19,7 +19,7 @@ extern "C" int spex_lightgcn_step_bce_f32(spex_lightgcn_step_t *s, const int64_t
                                           const float *labels, int32_t B, float *loss_sum, void *stream)
 {
     SPEX_CHECK_ARG(s && s->graph && s->graph_t && s->E0 && s->m && s->v && s->light_out && s->ws_fwd && s->lo_batch && s->g_out
-                       && s->ws_bwd && s->grad_E0 && s->stamp && s->row_list && s->row_count,
+                       && s->ws_bwd && s->grad_E0,
                    "spex_lightgcn_step_bce_f32: NULL field in the step descriptor");
     SPEX_CHECK_ARG(users && items && labels && loss_sum && B >= 1, "spex_lightgcn_step_bce_f32: NULL batch pointer or B < 1");
     const spex_graph *g = s->graph, *gt = s->graph_t;
@@ -27,7 +27,6 @@ extern "C" int spex_lightgcn_step_bce_f32(spex_lightgcn_step_t *s, const int64_t
     SPEX_CHECK_ARG(g->n_rows == g->n_cols && gt->n_rows == g->n_rows && gt->n_cols == g->n_rows, "spex_lightgcn_step_bce_f32: square graphs of one size");
     SPEX_CHECK_ARG(L >= 1 && d == 64 && n_u >= 0 && n_u <= g->n_rows, "spex_lightgcn_step_bce_f32: L=%d d=%d n_user_rows=%d (needs L >= 1, d == 64)", L, d, n_u);
     SPEX_CHECK_ARG(g->mask_mode == 0 && gt->mask_mode == 0, "spex_lightgcn_step_bce_f32: edge dropout is not supported in the one-call step");
-    SPEX_CHECK_ARG(s->row_capacity >= 2 * B, "spex_lightgcn_step_bce_f32: row list capacity %d < 2 B = %d", s->row_capacity, 2 * B);
     const size_t sz = (size_t)g->n_rows * d;
     // ---- forward: layers 0 .. L-2 over the whole graph (running layer sum fused), the last layer at the batch's rows only
     const float *cur = s->E0;
@@ -43,15 +42,11 @@ extern "C" int spex_lightgcn_step_bce_f32(spex_lightgcn_step_t *s, const int64_t
                                 nullptr, loss_sum, s->g_out, s->g_out + (size_t)n_u * d, 1.0f / (float)B, stream));
     // ---- backward: G_{L-1} = (g + A^T g) / (L+1) in push form over the batch's distinct rows, then L-1 pull-form products
     if (L >= 2) {
-        s->epoch = s->epoch % 0x7FFFFFFF + 1;
-        SPEX_TRY(spex_unique_rows_i32(users, B, 0, items, B, n_u, g->n_rows, s->stamp, s->epoch, s->row_list, s->row_count, stream));
-        float *G = s->ws_bwd;
-        SPEX_HIP(hipMemsetAsync(G, 0, sz * sizeof(float), (hipStream_t)stream));
-        SPEX_TRY(spex_spmm_push_rows_f32(gt, s->row_list, s->row_count, 2 * B, s->g_out, 1, s->g_out, 1, 1.0f / (float)(L + 1), G, d,
-                                         stream));
+        float *G = s->ws_bwd;                     // all-zero here: cleared by the previous step's Adam pass (first call: by the caller)
+        SPEX_TRY(spex_spmm_push_batch_f32(gt, users, B, 0, items, B, n_u, s->g_out, 1, s->g_out, 1, 1.0f / (float)(L + 1), G, d, stream));
         const float *c2 = G;
         for (int32_t l = L - 2; l >= 0; --l) {
-            float *nxt = l == 0 ? s->grad_E0 : s->ws_bwd + (size_t)(1 - ((L - 2 - l) & 1)) * sz;   // ping-pong, never the source
+            float *nxt = l == 0 ? s->grad_E0 : s->ws_bwd + (size_t)(1 + ((L - 2 - l) & 1)) * sz;   // ws_bwd[1], [2], [1] ...: never the source, never G
             SPEX_TRY(spex_spmm_f32(gt, c2, nxt, s->g_out, (float)(L + 1), nullptr, nullptr, 1.0f, d, stream));
             c2 = nxt;
         }
@@ -60,6 +55,7 @@ extern "C" int spex_lightgcn_step_bce_f32(spex_lightgcn_step_t *s, const int64_t
     }
     // ---- Adam over the whole table (also clears g_out for the next step)
     s->t += 1;
-    SPEX_TRY(spex_adam_step_f32(s->E0, s->grad_E0, s->m, s->v, (int64_t)sz, s->t, s->lr, s->beta1, s->beta2, s->eps, s->g_out, stream));
+    SPEX_TRY(spex::adam_step_z2(s->E0, s->grad_E0, s->m, s->v, (int64_t)sz, s->t, s->lr, s->beta1, s->beta2, s->eps, s->g_out,
+                                L >= 2 ? s->ws_bwd : nullptr, stream));
     return SPEX_OK;
 }

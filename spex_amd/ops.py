@@ -189,27 +189,46 @@ def ngcf_layer_bwd(ego, side, W_gc, b_gc, W_bi, b_bi, g_all, layer, g_next, g_si
     _bump(g_side, g_ego, gW_gc, gb_gc, gW_bi, gb_bi)
 
 
-def ngcf_layer_bwd_rows(ego, side, W_gc, b_gc, W_bi, b_bi, g_all, layer, g_next, rows, g_side_c, g_ego_c, gW_gc, gb_gc, gW_bi,
-                        gb_bi, slope=0.01, drop=None, pad_row=-1, clear_consumed=True):
-    """ngcf_layer_bwd for the rows of a UniqueRows list only (the last layer's backward in training): compact outputs
-    g_side_c / g_ego_c [rows.capacity, d]; with clear_consumed the rows of g_all that were read are zeroed.
-    spex_ngcf_layer_bwd_rows_f32."""
+def ngcf_layer_bwd_rows(ego, side, W_gc, b_gc, W_bi, b_bi, g_all, layer, g_next, idx_a, idx_b, off_b, g_side_c, g_ego_c, gW_parts,
+                        slope=0.01, drop=None, pad_row=-1, clear_consumed=True):
+    """ngcf_layer_bwd for the rows of a BATCH only (the last layer's backward in training): slot k is row idx_a[k], slot
+    len(idx_a) + k is row idx_b[k] + off_b; compact outputs g_side_c / g_ego_c [len(idx_a) + len(idx_b), d]; the weight
+    gradients leave as partial blocks gW_parts [n_parts, >= 2 (d d + d)] (n_parts = ngcf_bwd_rows_parts(slots)); with
+    clear_consumed the rows of g_all that were read are zeroed.  spex_ngcf_layer_bwd_rows_f32."""
     for x, n in ((ego, "ego"), (side, "side"), (W_gc, "W_gc"), (b_gc, "b_gc"), (W_bi, "W_bi"), (b_bi, "b_bi"), (g_all, "g_all"),
-                 (g_next, "g_next"), (g_side_c, "g_side_c"), (g_ego_c, "g_ego_c"), (gW_gc, "gW_gc"), (gb_gc, "gb_gc"),
-                 (gW_bi, "gW_bi"), (gb_bi, "gb_bi")):
+                 (g_next, "g_next"), (g_side_c, "g_side_c"), (g_ego_c, "g_ego_c"), (gW_parts, "gW_parts")):
         _need(x, n)
     n, d = ego.shape
-    if g_side_c.shape[0] < rows.capacity or g_ego_c.shape[0] < rows.capacity:
-        raise ValueError("ngcf_layer_bwd_rows: compact outputs are smaller than the row list's capacity")
+    n_a, n_b = idx_a.numel(), idx_b.numel()
+    if g_side_c.shape[0] < n_a + n_b or g_ego_c.shape[0] < n_a + n_b or gW_parts.shape[0] < ngcf_bwd_rows_parts(n_a + n_b):
+        raise ValueError("ngcf_layer_bwd_rows: compact outputs / partial blocks are too small for the batch")
+    for t in (idx_a, idx_b):
+        if not (t.is_cuda and t.dtype == torch.int64 and t.is_contiguous()):
+            raise ValueError("ngcf_layer_bwd_rows: the batch must be contiguous int64 tensors on the GPU")
     p, seed, step = drop if drop is not None else (0.0, 0, 0)
     ld = g_all.stride(0)
     g_norm = ctypes.c_void_p(g_all.data_ptr() + 4 * d * (layer + 1))
     g_direct = ctypes.c_void_p(g_all.data_ptr()) if layer == 0 else None
     _launch(ego.device, "spex_ngcf_layer_bwd_rows_f32", _ptr(ego), _ptr(side), _ptr(W_gc), _ptr(b_gc), _ptr(W_bi), _ptr(b_bi), g_norm,
             ld, _ptr(g_next), g_direct, ld, n, d, float(slope), float(p), int(seed), int(step), int(layer), int(pad_row),
-            _ptr(rows.list), _ptr(rows.count), rows.capacity, 1 if clear_consumed else 0, _ptr(g_side_c), _ptr(g_ego_c), _ptr(gW_gc),
-            _ptr(gb_gc), _ptr(gW_bi), _ptr(gb_bi))
-    _bump(g_side_c, g_ego_c, gW_gc, gb_gc, gW_bi, gb_bi, g_all)
+            _ptr(idx_a), n_a, 0, _ptr(idx_b), n_b, int(off_b), 1 if clear_consumed else 0, _ptr(g_side_c), _ptr(g_ego_c),
+            _ptr(gW_parts), gW_parts.stride(0))
+    _bump(g_side_c, g_ego_c, gW_parts, g_all)
+
+
+def ngcf_bwd_rows_parts(n_slots):
+    """Number of partial weight-gradient blocks ngcf_layer_bwd_rows writes for a batch of n_slots slots."""
+    return int(_lib.load().spex_ngcf_layer_bwd_rows_parts(int(n_slots)))
+
+
+def adam_step_sum(p, g_parts, m, v, t, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
+    """Adam over a flat parameter block whose gradient is the sum of the rows of g_parts [n_parts, >= p.numel()]
+    (spex_adam_step_sum_f32)."""
+    for x, n in ((p, "p"), (g_parts, "g_parts"), (m, "m"), (v, "v")):
+        _need(x, n)
+    _launch(p.device, "spex_adam_step_sum_f32", _ptr(p), _ptr(g_parts), g_parts.shape[0], g_parts.stride(0), _ptr(m), _ptr(v),
+            p.numel(), int(t), float(lr), float(beta1), float(beta2), float(eps))
+    _bump(p, m, v)
 
 
 class UniqueRows:
@@ -249,6 +268,26 @@ def spmm_push_rows(graph, rows, src, out, src_indexed, add=None, add_indexed=Fal
             raise ValueError(f"spmm_push_rows: {nm} has shape {tuple(t.shape)}")
     _launch(out.device, "spex_spmm_push_rows_f32", graph._h, _ptr(rows.list), _ptr(rows.count), rows.capacity, _ptr(src),
             1 if src_indexed else 0, _ptr(add), 1 if add_indexed else 0, float(scale), _ptr(out), d)
+    _bump(out)
+    return out
+
+
+def spmm_push_batch(graph, idx_a, idx_b, off_b, src, out, src_indexed, add=None, add_indexed=False, scale=1.0):
+    """out += scale * (A^T scatter(src) + scatter(add)) over the DISTINCT rows of a batch (slot k: row idx_a[k]; slot
+    len(idx_a) + k: row idx_b[k] + off_b), one launch, d == 64 (spex_spmm_push_batch_f32).  src / add: the [N, d] table
+    itself (indexed=True) or compact per-slot arrays."""
+    _need(src, "src"); _need(out, "out"); _need(add, "add")
+    if out.shape != (graph.n_cols, 64):
+        raise ValueError("spmm_push_batch: out must be [graph.n_cols, 64]")
+    for t in (idx_a, idx_b):
+        if not (t.is_cuda and t.dtype == torch.int64 and t.is_contiguous()):
+            raise ValueError("spmm_push_batch: the batch must be contiguous int64 tensors on the GPU")
+    slots = idx_a.numel() + idx_b.numel()
+    for t, ind, nm in ((src, src_indexed, "src"), (add, add_indexed, "add")):
+        if t is not None and (t.shape[1] != 64 or t.shape[0] < (graph.n_rows if ind else slots)):
+            raise ValueError(f"spmm_push_batch: {nm} has shape {tuple(t.shape)}")
+    _launch(out.device, "spex_spmm_push_batch_f32", graph._h, _ptr(idx_a), idx_a.numel(), 0, _ptr(idx_b), idx_b.numel(), int(off_b),
+            _ptr(src), 1 if src_indexed else 0, _ptr(add), 1 if add_indexed else 0, float(scale), _ptr(out), 64)
     _bump(out)
     return out
 

@@ -33,7 +33,6 @@ class LightGCNStepper:
         self.m, self.v = z(n, d), z(n, d)
         self.loss_acc = z(1)          # running loss sum of the fused BPR steps (read it when you need it)
         self.lo_batch = None          # propagated rows of the current batch (propagate_for_batch), allocated on first use
-        self.rows = None              # distinct rows of the current batch (sparse first backward layer), allocated on first use
         self.t = 0
 
     # -- pieces
@@ -94,44 +93,41 @@ class LightGCNStepper:
         B = users.numel()
         if self.lo_batch is None:
             self.lo_batch = torch.zeros_like(self.light_out)
-        if self.rows is None or self.rows.capacity < 2 * B:
-            self.rows = ops.UniqueRows(self.E0.shape[0], 2 * B, self.E0.device)
-            self._desc = None
+        if not getattr(self, "_ws0_clean", False):       # another path used the workspace: restore the all-zero push target
+            self.ws_bwd[0].zero_()
+            self._ws0_clean = True
         if getattr(self, "_desc", None) is None:
             p = lambda t: t.data_ptr()
             self._desc = _lib.LightGCNStepDesc(
                 graph=self.graph._h.value, graph_t=self.graph_t._h.value, E0=p(self.E0), m=p(self.m), v=p(self.v),
                 light_out=p(self.light_out), ws_fwd=p(self.ws_fwd), lo_batch=p(self.lo_batch), g_out=p(self.g_out),
-                ws_bwd=p(self.ws_bwd), grad_E0=p(self.grad_E0), stamp=p(self.rows.stamp), row_list=p(self.rows.list),
-                row_count=p(self.rows.count), row_capacity=self.rows.capacity, n_user_rows=self.n_u, L=self.L, d=self.E0.shape[1],
-                lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, t=self.t, epoch=self.rows.epoch)
+                ws_bwd=p(self.ws_bwd), grad_E0=p(self.grad_E0), n_user_rows=self.n_u, L=self.L, d=self.E0.shape[1],
+                lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, t=self.t)
         d = self._desc
         d.t, d.lr = self.t, self.lr
         _launch(self.E0.device, "spex_lightgcn_step_bce_f32", ctypes.byref(d), ctypes.c_void_p(users.data_ptr()),
                 ctypes.c_void_p(items.data_ptr()), ctypes.c_void_p(labels.data_ptr()), B, ctypes.c_void_p(loss_acc.data_ptr()))
-        self.t, self.rows.epoch = d.t, d.epoch
+        self.t = d.t
         _bump(self.E0, self.m, self.v, loss_acc)
         return None
 
     def backward_from_batch_rows(self, users, items):
         """grad_E0 from g_out (non-zero on the batch's rows only).  The first product of the backward pass, A^T g, touches
-        only the stored entries of those <= 2B rows: it is taken in push form (spex_spmm_push_rows_f32, ~14 k entries on
-        Epinion2) instead of a pull-form SpMM over all 418 k; the remaining L - 1 products are dense.  Falls back to the
+        only the stored entries of those <= 2B rows: it is taken in push form (~14 k entries on
+        Epinion2, spex_spmm_push_batch_f32) instead of a pull-form SpMM over all 418 k; the remaining L - 1 products are dense.  Falls back to the
         all-pull form where the push form does not apply (edge dropout on the handle, L < 2)."""
         L, gt = self.L, self.graph_t
-        if L < 2 or getattr(gt, "mask_mode", 0) != 0:
+        self._ws0_clean = False
+        if L < 2 or self.E0.shape[1] != 64 or getattr(gt, "mask_mode", 0) != 0:
             gt.propagate_bwd(self.g_out, L, grad_E0=self.grad_E0, ws=self.ws_bwd)
             return
-        if self.rows is None or self.rows.capacity < users.numel() + items.numel():
-            self.rows = ops.UniqueRows(self.E0.shape[0], users.numel() + items.numel(), self.E0.device)
-        self.rows.update(users, items, 0, self.n_u)
         inv = 1.0 / float(L + 1)
-        G = self.ws_bwd[1]
+        G = self.ws_bwd[0]
         G.zero_()
-        ops.spmm_push_rows(gt, self.rows, self.g_out, G, True, add=self.g_out, add_indexed=True, scale=inv)   # G_{L-1}
+        ops.spmm_push_batch(gt, users, items, self.n_u, self.g_out, G, True, add=self.g_out, add_indexed=True, scale=inv)   # G_{L-1}
         cur = G
         for l in range(L - 2, -1, -1):
-            nxt = self.grad_E0 if l == 0 else self.ws_bwd[2 - ((L - 2 - l) & 1)]      # ping-pong: never the buffer being read
+            nxt = self.grad_E0 if l == 0 else self.ws_bwd[1 + ((L - 2 - l) & 1)]      # ws_bwd[1], [2], [1] ...: never the source
             gt.spmm(cur, Y=nxt, add_in=self.g_out, add_div=float(L + 1))                                      # g/(L+1) + A^T G
             cur = nxt
 
@@ -151,6 +147,7 @@ class LightGCNStepper:
         lo = self.light_out
         loss_sum = ops.bpr_loss_grad(lo[:self.n_u], lo[self.n_u:], users, pos, neg, self.g_out[:self.n_u],
                                      self.g_out[self.n_u:], 1.0 / T)
+        self._ws0_clean = False
         self.graph_t.propagate_bwd(self.g_out, self.L, grad_E0=self.grad_E0, ws=self.ws_bwd)
         self.t += 1
         ops.adam_step(self.E0, self.grad_E0, self.m, self.v, self.t, self.lr, self.betas[0], self.betas[1], self.eps,
@@ -256,7 +253,7 @@ class NGCFStepper:
         self.egos = [self.E0] + [z(n, d) for _ in range(L - 1)]
         self.g_side, self.g_ego = z(n, d), z(n, d)
         self.g_next = [z(n, d), z(n, d)]                        # g_next[(L-1) & 1] is all-zero between steps (push target)
-        self.rows, self.g_side_c, self.g_ego_c = None, None, None
+        self.g_side_c, self.g_ego_c, self.gW_parts = None, None, None
         self.loss_acc = z(1)
         self.n_u = model.n_users + 1
 
@@ -280,19 +277,20 @@ class NGCFStepper:
                       self.g_all[self.n_u:], 1.0 / B, loss_sum=acc, want_gamma=False)
         # backward.  Only the batch's <= 2B distinct rows carry a gradient behind the LAST layer: its backward runs on
         # those rows (compact tiles), and A^T g_side is a push over their stored entries instead of a pull-form SpMM.
-        if self.rows is None or self.rows.capacity < 2 * B:
-            self.rows = ops.UniqueRows(self.E0.shape[0], 2 * B, self.E0.device)
-            self.g_side_c = torch.zeros((2 * B, self.E0.shape[1]), dtype=torch.float32, device=self.E0.device)
+        if self.g_side_c is None or self.g_side_c.shape[0] < 2 * B:
+            dev, d = self.E0.device, self.E0.shape[1]
+            self.g_side_c = torch.zeros((2 * B, d), dtype=torch.float32, device=dev)
             self.g_ego_c = torch.zeros_like(self.g_side_c)
-        self.rows.update(users, items, 0, self.n_u)
+            self.gW_parts = torch.zeros((ops.ngcf_bwd_rows_parts(2 * B), 2 * (d * d + d)), dtype=torch.float32, device=dev)
         l = L - 1
+        per = self.gW_parts.shape[1]
         dl = None if drop is None or drop[0][l] <= 0 else (drop[0][l], drop[1], drop[2])
-        ops.ngcf_layer_bwd_rows(self.egos[l], self.sides[l], *self.views[l], self.g_all, l, None, self.rows, self.g_side_c,
-                                self.g_ego_c, *self.g_views[l], drop=dl, pad_row=pad, clear_consumed=(L == 1))
+        ops.ngcf_layer_bwd_rows(self.egos[l], self.sides[l], *self.views[l], self.g_all, l, None, users, items, self.n_u,
+                                self.g_side_c, self.g_ego_c, self.gW_parts, drop=dl, pad_row=pad, clear_consumed=(L == 1))
         g_next = self.g_next[l & 1]
         if L > 1:
             g_next.zero_()
-        ops.spmm_push_rows(m.graph, self.rows, self.g_side_c, g_next, False, add=self.g_ego_c, add_indexed=False)
+        ops.spmm_push_batch(m.graph, users, items, self.n_u, self.g_side_c, g_next, False, add=self.g_ego_c, add_indexed=False)
         for l in range(L - 2, -1, -1):
             dl = None if drop is None or drop[0][l] <= 0 else (drop[0][l], drop[1], drop[2])
             ops.ngcf_layer_bwd(self.egos[l], self.sides[l], *self.views[l], self.g_all, l, g_next, self.g_side, self.g_ego,
@@ -304,8 +302,14 @@ class NGCFStepper:
         b1, b2 = self.betas
         # (L == 1: the table gradient is the push target, cleared again by the Adam pass that consumes it)
         ops.adam_step(self.E0, g_next, self.mE, self.vE, self.t, self.lr, b1, b2, self.eps, zero=g_next if L == 1 else None)
-        ops.adam_step(self.W, self.gW, self.mW, self.vW, self.t, self.lr, b1, b2, self.eps, zero=self.gW)
+        # layer weights: the last layer's gradient arrives as partial blocks (summed inside its Adam pass); the other layers'
+        # (dense backward, atomics into gW) go through the plain pass
+        per = self.gW_parts.shape[1]
+        lo = (L - 1) * per
+        ops.adam_step_sum(self.W[lo:lo + per], self.gW_parts, self.mW[lo:lo + per], self.vW[lo:lo + per], self.t, self.lr, b1, b2,
+                          self.eps)
         if L > 1:
+            ops.adam_step(self.W[:lo], self.gW[:lo], self.mW[:lo], self.vW[:lo], self.t, self.lr, b1, b2, self.eps, zero=self.gW[:lo])
             self.g_all.zero_()
         return acc
 

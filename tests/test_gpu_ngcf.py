@@ -285,37 +285,44 @@ def test_whole_ngcf_epoch_matches_the_reference_epinion2(golden, ngcf_data_root)
 
 
 def test_layer_backward_rows_form_equals_dense_form(oracle):
-    """spex_ngcf_layer_bwd_rows_f32 (compact tiles over the batch's distinct rows) against the dense form on the same
-    inputs: same g_side / g_ego at the listed rows, same weight gradients; the consumed rows of the gradient table are
-    cleared."""
+    """spex_ngcf_layer_bwd_rows_f32 (compact tiles over the batch's slots, a row processed at its first slot only) against
+    the dense form on the same inputs: same g_side / g_ego at the batch's distinct rows, same weight gradients (summed
+    from the partial blocks, also through spex_adam_step_sum_f32); the consumed rows of the gradient table are cleared."""
     from spex_amd import ops
     rng = np.random.default_rng(77)
     n = 2000
     ego, side = (torch.from_numpy(rng.normal(size=(n, 64)).astype(np.float32) * 0.3).to(DEV) for _ in range(2))
     W_gc, W_bi = (torch.from_numpy(rng.normal(size=(64, 64)).astype(np.float32) * 0.2).to(DEV) for _ in range(2))
     b_gc, b_bi = (torch.from_numpy(rng.normal(size=64).astype(np.float32) * 0.1).to(DEV) for _ in range(2))
-    users, items = torch.from_numpy(rng.integers(0, 700, 200)).to(DEV), torch.from_numpy(rng.integers(0, 1200, 200)).to(DEV)
-    rows = ops.UniqueRows(n, 400, DEV).update(users, items, 0, 700)
-    cnt = int(rows.count.item())
-    listed = rows.list[:cnt].long()
+    u_np, i_np = rng.integers(0, 700, 200), rng.integers(0, 1200, 200)
+    u_np[:4] = u_np[10]                                                     # repeated users: later slots are skipped
+    users, items = torch.from_numpy(u_np).to(DEV), torch.from_numpy(i_np).to(DEV)
+    slot_rows = np.concatenate([u_np, i_np + 700])
+    first = np.array([r not in slot_rows[:k] for k, r in enumerate(slot_rows)])
+    listed = torch.from_numpy(slot_rows[first]).to(DEV)
     g_all = torch.zeros(n, 128, device=DEV)
-    g_all[listed] = torch.from_numpy(rng.normal(size=(cnt, 128)).astype(np.float32)).to(DEV)
+    g_all[listed] = torch.from_numpy(rng.normal(size=(int(first.sum()), 128)).astype(np.float32)).to(DEV)
     drop = (0.1, 99, 3)
-    outs = {}
-    for form in ("dense", "rows"):
-        gW = [torch.zeros(64, 64, device=DEV), torch.zeros(64, device=DEV), torch.zeros(64, 64, device=DEV), torch.zeros(64, device=DEV)]
-        ga = g_all.clone()
-        if form == "dense":
-            gs, ge = torch.empty(n, 64, device=DEV), torch.empty(n, 64, device=DEV)
-            ops.ngcf_layer_bwd(ego, side, W_gc, b_gc, W_bi, b_bi, ga, 0, None, gs, ge, *gW, drop=drop, pad_row=700)
-            outs[form] = (gs[listed].cpu().numpy(), ge[listed].cpu().numpy(), [w.cpu().numpy() for w in gW])
-            assert torch.count_nonzero(gs).item() <= cnt * 64 and torch.equal(ga, g_all)
-        else:
-            gs, ge = torch.full((400, 64), 9.0, device=DEV), torch.full((400, 64), 9.0, device=DEV)
-            ops.ngcf_layer_bwd_rows(ego, side, W_gc, b_gc, W_bi, b_bi, ga, 0, None, rows, gs, ge, *gW, drop=drop, pad_row=700)
-            outs[form] = (gs[:cnt].cpu().numpy(), ge[:cnt].cpu().numpy(), [w.cpu().numpy() for w in gW])
-            assert torch.count_nonzero(ga).item() == 0                                   # consumed rows cleared
-    (s0, e0, w0), (s1, e1, w1) = outs["dense"], outs["rows"]
-    assert rel_err(s1, s0) <= 1e-6 and rel_err(e1, e0) <= 1e-6
-    for a, b in zip(w1, w0):
-        assert rel_err(a, b) <= 1e-5
+    gW = [torch.zeros(64, 64, device=DEV), torch.zeros(64, device=DEV), torch.zeros(64, 64, device=DEV), torch.zeros(64, device=DEV)]
+    ga = g_all.clone()
+    gs, ge = torch.empty(n, 64, device=DEV), torch.empty(n, 64, device=DEV)
+    ops.ngcf_layer_bwd(ego, side, W_gc, b_gc, W_bi, b_bi, ga, 0, None, gs, ge, *gW, drop=drop, pad_row=700)
+    assert torch.equal(ga, g_all)
+    n_parts = ops.ngcf_bwd_rows_parts(400)
+    parts = torch.full((n_parts, 2 * (64 * 64 + 64)), 7.0, device=DEV)
+    gsc, gec = torch.full((400, 64), 9.0, device=DEV), torch.full((400, 64), 9.0, device=DEV)
+    ops.ngcf_layer_bwd_rows(ego, side, W_gc, b_gc, W_bi, b_bi, ga, 0, None, users, items, 700, gsc, gec, parts, drop=drop, pad_row=700)
+    assert torch.count_nonzero(ga).item() == 0                              # consumed rows cleared
+    sel = torch.from_numpy(np.flatnonzero(first)).to(DEV)
+    assert rel_err(gsc[sel].cpu().numpy(), gs[listed].cpu().numpy()) <= 1e-6
+    assert rel_err(gec[sel].cpu().numpy(), ge[listed].cpu().numpy()) <= 1e-6
+    assert (gsc[~torch.from_numpy(first).to(DEV)] == 9.0).all()             # skipped slots are not written
+    tot = parts.sum(0).cpu().numpy()
+    want = np.concatenate([gW[0].cpu().numpy().ravel(), gW[1].cpu().numpy(), gW[2].cpu().numpy().ravel(), gW[3].cpu().numpy()])
+    assert rel_err(tot, want) <= 1e-5
+    # the optimiser pass that sums the blocks == plain Adam on the summed gradient
+    p1 = torch.from_numpy(rng.normal(size=len(want)).astype(np.float32)).to(DEV)
+    p2, m1, v1, m2, v2 = p1.clone(), torch.zeros_like(p1), torch.zeros_like(p1), torch.zeros_like(p1), torch.zeros_like(p1)
+    ops.adam_step_sum(p1, parts, m1, v1, 1, lr=1e-2)
+    ops.adam_step(p2, parts.sum(0).contiguous(), m2, v2, 1, lr=1e-2)
+    assert rel_err(p1.cpu().numpy(), p2.cpu().numpy()) <= 1e-6
