@@ -137,6 +137,16 @@ int spex_score_bce_f32(const float *users, const float *items, int32_t ldu, int3
                        int32_t d, float *gamma, float *loss_sum, float *grad_users, float *grad_items,
                        float grad_scale, void *stream);
 
+/* The same scoring with the gradient ALSO (or only) as per-sample rows: grad_slots [2B, ld_slots], row b = d loss / d
+ * users[u_idx[b]] of sample b alone (= dg_b * items[i_idx[b]]), row B + b = d loss / d items[i_idx[b]] of sample b — plain
+ * stores, no atomics.  These are the operands of the row-sparse backward (spex_spmm_push_batch_f32,
+ * spex_ngcf_layer_bwd_rows_f32).  grad_users / grad_items may be NULL (no table form wanted).
+ */
+int spex_score_bce_slots_f32(const float *users, const float *items, int32_t ldu, int32_t ldi, int64_t n_user_rows,
+                             int64_t n_item_rows, const int64_t *u_idx, const int64_t *i_idx, const float *labels, int32_t B,
+                             int32_t d, float *loss_sum, float *grad_users, float *grad_items, float grad_scale,
+                             float *grad_slots, int32_t ld_slots, void *stream);
+
 /* North-star extension (no counterpart in the reference): BPR over (u, i+, i-) triples.
  *   x_t = <U_read[u], I_read[i-] - I_read[i+]>;  loss_sum += softplus(x_t)
  * Fused gather + dot + sigmoid + SGD: with s_t = sigmoid(x_t)/T,
@@ -241,24 +251,24 @@ int spex_ngcf_layer_bwd_f32(const float *ego, const float *side, const float *W_
                             float *gW_gc, float *gb_gc, float *gW_bi, float *gb_bi, void *stream);
 
 /* The same backward for the rows of a BATCH only — the form the LAST layer takes in training: after a B-sample batch
- * only the batch's <= 2B distinct rows carry a gradient behind it (main_rec.py:89-90), so 2B / 16 tiles replace n / 16.
+ * only the batch's <= 2B rows carry a gradient behind it (main_rec.py:89-90), so 2B / 16 tiles replace n / 16.
  * The batch is given as it is scored: slot k < n_a is row idx_a[k] + off_a, slot n_a + k is row idx_b[k] + off_b (device
- * int64); a slot is processed iff no earlier slot names the same row (checked in the kernel: no list, no extra launch).
- * g_side_c / g_ego_c: COMPACT outputs [n_a + n_b, d], slot k belonging to its row (slots that are skipped are not
- * written) — the operands of spex_spmm_push_batch_f32, which completes d loss / d ego = scatter(g_ego_c) + A^T scatter(g_side_c).
- * clear_consumed != 0: the rows of g_norm / g_direct that were read are set to zero (they are the only non-zero rows:
- * the caller's gradient table is all-zero again without a fill pass).
- * Weight gradients leave as spex_ngcf_layer_bwd_rows_parts(n_a + n_b) partial blocks, block j at gW_parts + j * part_stride,
- * each laid out [dW_gc d*d | db_gc d | dW_bi d*d | db_bi d] (plain stores; every block is written, unused ones with zeros):
- * add them up — spex_adam_step_sum_f32 does, inside the optimiser pass.
+ * int64).  EVERY slot is processed with its own upstream gradient rows — g_norm_c / g_direct_c are COMPACT, row k = slot k,
+ * exactly what spex_score_bce_slots_f32 writes (the layer's backward is linear in them: a row named by several slots
+ * simply gets several contributions downstream; nothing is deduplicated and no gradient table is involved).
+ * g_side_c / g_ego_c: COMPACT outputs [n_a + n_b, d] — the operands of spex_spmm_push_batch_f32, which completes
+ * d loss / d ego = scatter(g_ego_c) + A^T scatter(g_side_c).
+ * Weight gradients leave as spex_ngcf_layer_bwd_rows_parts(n_a + n_b) partial blocks (one per 16-slot tile), block j at
+ * gW_parts + j * part_stride, each laid out [dW_gc d*d | db_gc d | dW_bi d*d | db_bi d] (plain stores): add them up —
+ * spex_adam_step_sum_f32 does, inside the optimiser pass.
  */
 int32_t spex_ngcf_layer_bwd_rows_parts(int32_t n_slots);
 int spex_ngcf_layer_bwd_rows_f32(const float *ego, const float *side, const float *W_gc, const float *b_gc,
-                                 const float *W_bi, const float *b_bi, float *g_norm, int32_t ld_g, const float *g_next,
-                                 float *g_direct, int32_t ld_direct, int32_t n, int32_t d, float slope, float p_drop,
-                                 uint64_t seed, uint32_t step, uint32_t layer, int32_t pad_row, const int64_t *idx_a,
-                                 int32_t n_a, int64_t off_a, const int64_t *idx_b, int32_t n_b, int64_t off_b,
-                                 int32_t clear_consumed, float *g_side_c, float *g_ego_c, float *gW_parts, int32_t part_stride,
+                                 const float *W_bi, const float *b_bi, const float *g_norm_c, int32_t ld_g,
+                                 const float *g_next, const float *g_direct_c, int32_t ld_direct, int32_t n, int32_t d,
+                                 float slope, float p_drop, uint64_t seed, uint32_t step, uint32_t layer, int32_t pad_row,
+                                 const int64_t *idx_a, int32_t n_a, int64_t off_a, const int64_t *idx_b, int32_t n_b,
+                                 int64_t off_b, float *g_side_c, float *g_ego_c, float *gW_parts, int32_t part_stride,
                                  void *stream);
 
 /* ------------------------------------------------------------------------------------------------ row-sparse backward
@@ -283,14 +293,18 @@ int spex_unique_rows_i32(const int64_t *idx_a, int32_t n_a, int64_t off_a, const
 int spex_spmm_push_rows_f32(const spex_graph_t *g, const int32_t *list, const int32_t *count, int32_t max_count,
                             const float *src, int32_t src_indexed, const float *add, int32_t add_indexed, float scale,
                             float *out, int32_t d, void *stream);
-/* The same product driven by the batch itself (d == 64): slot k (idx_a[k] + off_a, then idx_b[k] + off_b) is processed iff
- * no earlier slot names its row — ONE launch, where the list form needs a fill, spex_unique_rows_i32 and the push (each
- * small launch costs ~4 us on the stream).  A slot's row is shared by 16 workgroups, so a hub row's atomics spread over
- * 16 CUs.  src_indexed / add_indexed = 0 reads the compact arrays at the SLOT index k.
+/* The same product driven by the batch itself (d == 64), EVERY slot contributing its own row: for slot k with row
+ * r = idx_a[k] + off_a (k < n_a) or idx_b[k - n_a] + off_b:
+ *   out[col[e], :] += scale * val[e] * src[k, :]  over the stored entries e of row r;   out[r, :] += scale * add[k, :] (if add)
+ * src / add are COMPACT per-slot arrays (row strides ld_src / ld_add) — the per-sample gradient rows
+ * spex_score_bce_slots_f32 writes, or spex_ngcf_layer_bwd_rows_f32's outputs; rows named by several slots receive several
+ * contributions, so nothing is deduplicated.  ONE launch (each small launch costs ~4 us on the stream: a fill + a
+ * unique pass + the list form would cost more than the pull-form SpMM they replace); a slot's row is shared by 4
+ * workgroups of 4 waves, so a hub row's atomics spread over several CUs.
  */
 int spex_spmm_push_batch_f32(const spex_graph_t *g, const int64_t *idx_a, int32_t n_a, int64_t off_a, const int64_t *idx_b,
-                             int32_t n_b, int64_t off_b, const float *src, int32_t src_indexed, const float *add,
-                             int32_t add_indexed, float scale, float *out, int32_t d, void *stream);
+                             int32_t n_b, int64_t off_b, const float *src, int32_t ld_src, const float *add, int32_t ld_add,
+                             float scale, float *out, int32_t d, void *stream);
 
 /* Replaces the two-expert gate of the dual-task model, utility1/model_expert_s.py:156-161:
  *   att = softmax([raw | prop] att_exp, dim=1) ([n,2d] x [2d,2]);  mixed = raw * att[:,0] + prop * att[:,1]
@@ -381,10 +395,11 @@ int spex_path_attention_bwd_f32(const float *src, int64_t n_src_rows, const int6
  * The exact reference training step — LightGCN_SPEX/code/main_rec.py:32-37: forward (model.py:111-121), BCE,
  * loss.backward(), optimizer.step() — as ONE call that issues the library's own launches back to back:
  *   L-1 x spex_spmm_f32 (running layer sum) + spex_spmm_rowlist_f32 (last layer at the batch's rows)
- *   spex_score_bce_f32 (loss + gradient rows) -> spex_spmm_push_batch_f32 ((g + A^T g)/(L+1), batch rows only)
+ *   spex_score_bce_slots_f32 (loss + gradient rows, table and per-sample) -> spex_spmm_push_batch_f32 ((g + A^T g)/(L+1))
  *   L-1 x spex_spmm_f32 on A^T (g/(L+1) fused) -> spex_adam_step_f32 over the whole table (which clears g_out again).
  * The descriptor holds the step's device buffers (all caller-owned, N = graph rows, d == 64):
- *   E0, m, v, light_out, lo_batch, g_out, grad_E0: [N, d];  ws_fwd: [2, N, d];  ws_bwd: [3, N, d].
+ *   E0, m, v, light_out, lo_batch, g_out, grad_E0: [N, d];  ws_fwd: [2, N, d];  ws_bwd: [3, N, d];
+ *   grad_slots: [slot_capacity, d] with slot_capacity >= 2B (the batch's per-sample gradient rows).
  * g_out and the first [N, d] of ws_bwd must be all-zero before the first call (every call leaves them all-zero: the Adam
  * pass clears both).  t is advanced by the call.
  * users / items: device int64[B] (items index the item block: row n_user_rows + items[b]); labels: device fp32[B].
@@ -393,8 +408,8 @@ int spex_path_attention_bwd_f32(const float *src, int64_t n_src_rows, const int6
 typedef struct spex_lightgcn_step {
     const spex_graph_t *graph, *graph_t;     /* A and A^T (the same handle for the symmetric LightGCN adjacency) */
     float *E0, *m, *v;
-    float *light_out, *ws_fwd, *lo_batch, *g_out, *ws_bwd, *grad_E0;
-    int32_t n_user_rows, L, d;
+    float *light_out, *ws_fwd, *lo_batch, *g_out, *ws_bwd, *grad_E0, *grad_slots;
+    int32_t slot_capacity, n_user_rows, L, d;
     float lr, beta1, beta2, eps;
     int32_t t;
 } spex_lightgcn_step_t;

@@ -27,6 +27,8 @@ SIGNATURES = {
     "spex_propagate_bwd_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "spex_score_bce_f32": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i64, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp,
                                           c_vp, c_vp, c_vp, c_f32, c_vp]),
+    "spex_score_bce_slots_f32": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i64, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp,
+                                                c_vp, c_f32, c_vp, c_i32, c_vp]),
     "spex_bpr_sgd_step_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32,
                                              c_f32, c_f32, c_vp, c_vp]),
     "spex_bpr_loss_f32": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp,
@@ -49,7 +51,7 @@ SIGNATURES = {
     "spex_ngcf_layer_bwd_rows_parts": (c_i32, [c_i32]),
     "spex_ngcf_layer_bwd_rows_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32,
                                                     c_f32, c_f32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, c_i32, c_vp,
-                                                    c_i32, c_i64, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp]),
+                                                    c_i32, c_i64, c_vp, c_i32, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "spex_spmm_push_batch_f32": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_vp, c_i32, c_vp, c_i32, c_f32, c_vp,
                                                 c_i32, c_vp]),
     "spex_adam_step_sum_f32": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i64, c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_f32, c_f32, c_vp]),
@@ -81,8 +83,8 @@ SIGNATURES = {
 class LightGCNStepDesc(ctypes.Structure):
     """spex_lightgcn_step_t (include/spex_hip.h)."""
     _fields_ = ([(n, c_vp) for n in ("graph", "graph_t", "E0", "m", "v", "light_out", "ws_fwd", "lo_batch", "g_out", "ws_bwd",
-                                     "grad_E0")]
-                + [(n, c_i32) for n in ("n_user_rows", "L", "d")]
+                                     "grad_E0", "grad_slots")]
+                + [(n, c_i32) for n in ("slot_capacity", "n_user_rows", "L", "d")]
                 + [(n, c_f32) for n in ("lr", "beta1", "beta2", "eps")] + [("t", c_i32)])
 
 

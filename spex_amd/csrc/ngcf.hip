@@ -211,9 +211,9 @@ template <bool ROWS>
 __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
     const float *__restrict__ ego, const float *__restrict__ side, const float *__restrict__ W_gc,
     const float *__restrict__ b_gc, const float *__restrict__ W_bi, const float *__restrict__ b_bi,
-    float *g_norm, int ld_g, const float *__restrict__ g_next, float *g_direct,
+    const float *__restrict__ g_norm, int ld_g, const float *__restrict__ g_next, const float *__restrict__ g_direct,
     int ld_direct, int n, float slope, const MsgDrop drop, const int64_t *__restrict__ idx_a, int n_a, int64_t off_a,
-    const int64_t *__restrict__ idx_b, int n_b, int64_t off_b, int clear_consumed, float *__restrict__ g_side,
+    const int64_t *__restrict__ idx_b, int n_b, int64_t off_b, float *__restrict__ g_side,
     float *__restrict__ g_ego, float *gW_gc, float *gb_gc, float *gW_bi, float *gb_bi, float *partials, int part_stride)
 {
     __shared__ float s_w[2][64 * kLdsStride];                   // W_gc, W_bi as [out o][in k]
@@ -257,16 +257,16 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
     bool did_work = false;
     for (int tile = blockIdx.x * kBwdWaves + wave; tile < n_tiles; tile += gridDim.x * kBwdWaves) {
         const int r0 = tile << 4;
-        // the tile's rows: consecutive rows, or the rows of 16 batch slots — a slot counts iff it is the first slot that
-        // names its row (-1 otherwise and past the end); lane i keeps slot i's row in `slot_row`
+        // the tile's rows: consecutive rows, or the rows of 16 batch slots (every slot is processed with ITS OWN upstream
+        // gradient row — the layer's backward is linear in it, so rows named by several slots just add up downstream;
+        // -1 = past the end / out of range); lane i keeps slot i's row in `slot_row`
         int slot_row = -1;
         if (ROWS) {
             for (int i = 0; i < 16; ++i) {
                 const int k = r0 + i;
                 if (k >= n_items) break;
                 const long long r = batch_row(idx_a, n_a, off_a, idx_b, off_b, k);
-                const bool ok = r >= 0 && r < n && first_occurrence(idx_a, n_a, off_a, idx_b, off_b, k, r, lane);
-                if (lane == i) slot_row = ok ? (int)r : -1;
+                if (lane == i) slot_row = (r >= 0 && r < n) ? (int)r : -1;
             }
         } else if (lane < 16 && r0 + lane < n) {
             slot_row = r0 + lane;
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
                 const int r = row_q[q];
                 gn[b][q] = gx[b][q] = 0.0f;
                 if (r >= 0) {
-                    gn[b][q] = g_norm[(size_t)r * ld_g + 16 * b + i16];
+                    gn[b][q] = g_norm[(size_t)(ROWS ? r0 + 4 * h + q : r) * ld_g + 16 * b + i16];   // rows form: compact, per slot
                     if (g_next) gx[b][q] = g_next[(size_t)r * 64 + 16 * b + i16];
                 }
                 any |= (gn[b][q] != 0.0f) | (gx[b][q] != 0.0f);
@@ -440,20 +440,47 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
                     const float e = ego[(size_t)r * 64 + c];
                     g_side[o_row * 64 + c] = ts[b][q] + tb[b][q] * e;
                     float ge = tb[b][q] * side_c[b][q];
-                    if (g_direct) ge += g_direct[(size_t)r * ld_direct + c];
+                    if (g_direct) ge += g_direct[(ROWS ? o_row : (size_t)r) * ld_direct + c];
                     g_ego[o_row * 64 + c] = ge;
-                    if (ROWS && clear_consumed) {            // the gradient table is all-zero again after this launch
-                        g_norm[(size_t)r * ld_g + c] = 0.0f;
-                        if (g_direct) g_direct[(size_t)r * ld_direct + c] = 0.0f;
-                    }
                 }
             }
         }
     }
+    if (ROWS) {
+        // rows form: one tile per wave; its weight-gradient share leaves straight from the registers as partial block
+        // `tile` [dW_gc 64x64 | db_gc 64 | dW_bi 64x64 | db_bi 64] (plain stores) — spex_adam_step_sum_f32 adds the blocks up
+        const int tile = blockIdx.x * kBwdWaves + wave;
+        if (tile < n_tiles) {
+            float *dst = partials + (size_t)tile * part_stride;
+#pragma unroll
+            for (int bo = 0; bo < 4; ++bo) {
+#pragma unroll
+                for (int bn = 0; bn < 4; ++bn) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int a_ = (16 * bo + 4 * h + q) * 64 + 16 * bn + i16;
+                        dst[a_] = dWg[bo][bn][q];
+                        dst[64 * 64 + 64 + a_] = dWb[bo][bn][q];
+                    }
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                float cs = dbg[b], ct = dbb[b];
+                cs += __shfl_xor(cs, 16, kWave); cs += __shfl_xor(cs, 32, kWave);
+                ct += __shfl_xor(ct, 16, kWave); ct += __shfl_xor(ct, 32, kWave);
+                if (h == 0) {
+                    dst[64 * 64 + 16 * b + i16] = cs;
+                    dst[2 * 64 * 64 + 64 + 16 * b + i16] = ct;
+                }
+            }
+        }
+        return;
+    }
     // ---- weight gradients: registers -> LDS (one wave at a time, plain adds) -> global atomics
     if (did_work && lane == 0) s_active = 1;
     __syncthreads();
-    if (!s_active && !partials) return;
+    if (!s_active) return;
     for (int w = 0; w < kBwdWaves; ++w) {
         if (wave == w && did_work) {
 #pragma unroll
@@ -480,22 +507,6 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
             }
         }
         __syncthreads();
-    }
-    if (partials) {
-        // this workgroup's share as one block [dW_gc 64x64 | db_gc 64 | dW_bi 64x64 | db_bi 64] (plain stores: a CU issues
-        // one 256-byte float atomic per ~50 ns, so 8 K atomic addresses per workgroup were 13 us of this kernel); the
-        // consumer — spex_adam_step_sum_f32 — adds the blocks up
-        float *dst = partials + (size_t)blockIdx.x * part_stride;
-        for (int k = threadIdx.x; k < 64 * 64; k += blockDim.x) {
-            const int o = k >> 6, c = k & 63;
-            dst[k] = s_dw[0][o * kDwStride + c];
-            dst[64 * 64 + 64 + k] = s_dw[1][o * kDwStride + c];
-        }
-        if (threadIdx.x < 64) {
-            dst[64 * 64 + threadIdx.x] = s_db[0][threadIdx.x];
-            dst[2 * 64 * 64 + 64 + threadIdx.x] = s_db[1][threadIdx.x];
-        }
-        return;
     }
     for (int k = threadIdx.x; k < 64 * 64; k += blockDim.x) {
         const int o = k >> 6, c = k & 63;
@@ -595,11 +606,7 @@ inline unsigned grid_for_rows(int n)
 
 }  // namespace
 
-extern "C" int32_t spex_ngcf_layer_bwd_rows_parts(int32_t n_slots)
-{
-    const int tiles = (n_slots + 15) / 16;
-    return (tiles + kBwdWaves - 1) / kBwdWaves;
-}
+extern "C" int32_t spex_ngcf_layer_bwd_rows_parts(int32_t n_slots) { return (n_slots + 15) / 16; }   // one block per 16-slot tile
 
 static MsgDrop make_drop(float p_drop, uint64_t seed, uint32_t step, uint32_t layer, int32_t pad_row)
 {
@@ -667,25 +674,25 @@ extern "C" int spex_ngcf_layer_bwd_f32(const float *ego, const float *side, cons
     int blocks = (n_tiles + kBwdWaves - 1) / kBwdWaves;
     if (blocks > 128) blocks = 128;      // <= 128 x 8 K weight-gradient atomics; a wave walks its tiles with a stride
     hipLaunchKernelGGL((ngcf_layer_bwd_kernel<false>), dim3((unsigned)blocks), dim3(kWave * kBwdWaves), 0, (hipStream_t)stream, ego,
-                       side, W_gc, b_gc, W_bi, b_bi, const_cast<float *>(g_norm), ld_g, g_next, const_cast<float *>(g_direct), ld_direct,
-                       n, slope, make_drop(p_drop, seed, step, layer, pad_row), nullptr, 0, 0, nullptr, 0, 0, 0, g_side, g_ego, gW_gc,
+                       side, W_gc, b_gc, W_bi, b_bi, g_norm, ld_g, g_next, g_direct, ld_direct,
+                       n, slope, make_drop(p_drop, seed, step, layer, pad_row), nullptr, 0, 0, nullptr, 0, 0, g_side, g_ego, gW_gc,
                        gb_gc, gW_bi, gb_bi, nullptr, 0);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }
 
 extern "C" int spex_ngcf_layer_bwd_rows_f32(const float *ego, const float *side, const float *W_gc, const float *b_gc,
-                                            const float *W_bi, const float *b_bi, float *g_norm, int32_t ld_g,
-                                            const float *g_next, float *g_direct, int32_t ld_direct, int32_t n, int32_t d,
+                                            const float *W_bi, const float *b_bi, const float *g_norm_c, int32_t ld_g,
+                                            const float *g_next, const float *g_direct_c, int32_t ld_direct, int32_t n, int32_t d,
                                             float slope, float p_drop, uint64_t seed, uint32_t step, uint32_t layer,
                                             int32_t pad_row, const int64_t *idx_a, int32_t n_a, int64_t off_a,
-                                            const int64_t *idx_b, int32_t n_b, int64_t off_b, int32_t clear_consumed,
-                                            float *g_side_c, float *g_ego_c, float *gW_parts, int32_t part_stride, void *stream)
+                                            const int64_t *idx_b, int32_t n_b, int64_t off_b, float *g_side_c, float *g_ego_c,
+                                            float *gW_parts, int32_t part_stride, void *stream)
 {
-    SPEX_CHECK_ARG(ego && side && W_gc && b_gc && W_bi && b_bi && g_norm && g_side_c && g_ego_c && gW_parts,
+    SPEX_CHECK_ARG(ego && side && W_gc && b_gc && W_bi && b_bi && g_norm_c && g_side_c && g_ego_c && gW_parts,
                    "spex_ngcf_layer_bwd_rows_f32: NULL pointer");
     SPEX_CHECK_ARG(n_a >= 0 && n_b >= 0 && (n_a == 0 || idx_a) && (n_b == 0 || idx_b), "spex_ngcf_layer_bwd_rows_f32: bad index lists");
-    SPEX_CHECK_ARG(n >= 0 && ld_g >= d && (!g_direct || ld_direct >= d) && part_stride >= 2 * (d * d + d),
+    SPEX_CHECK_ARG(n >= 0 && ld_g >= d && (!g_direct_c || ld_direct >= d) && part_stride >= 2 * (d * d + d),
                    "spex_ngcf_layer_bwd_rows_f32: n=%d ld_g=%d ld_direct=%d part_stride=%d", n, ld_g, ld_direct, part_stride);
     SPEX_CHECK_ARG(p_drop >= 0.0f && p_drop < 1.0f, "spex_ngcf_layer_bwd_rows_f32: p_drop=%f", (double)p_drop);
     if (d != 64) {
@@ -694,11 +701,11 @@ extern "C" int spex_ngcf_layer_bwd_rows_f32(const float *ego, const float *side,
     }
     SPEX_CHECK_ARG((((uintptr_t)W_gc | (uintptr_t)W_bi) & 15) == 0, "spex_ngcf_layer_bwd_rows_f32: weights must be 16-byte aligned");
     if (n == 0 || n_a + n_b == 0) return SPEX_OK;
-    const int blocks = spex_ngcf_layer_bwd_rows_parts(n_a + n_b);
-    hipLaunchKernelGGL((ngcf_layer_bwd_kernel<true>), dim3((unsigned)blocks), dim3(kWave * kBwdWaves), 0, (hipStream_t)stream, ego,
-                       side, W_gc, b_gc, W_bi, b_bi, g_norm, ld_g, g_next, g_direct, ld_direct, n, slope,
-                       make_drop(p_drop, seed, step, layer, pad_row), idx_a, n_a, off_a, idx_b, n_b, off_b, clear_consumed, g_side_c,
-                       g_ego_c, nullptr, nullptr, nullptr, nullptr, gW_parts, part_stride);
+    const int tiles = spex_ngcf_layer_bwd_rows_parts(n_a + n_b);
+    hipLaunchKernelGGL((ngcf_layer_bwd_kernel<true>), dim3((unsigned)((tiles + kBwdWaves - 1) / kBwdWaves)), dim3(kWave * kBwdWaves), 0,
+                       (hipStream_t)stream, ego, side, W_gc, b_gc, W_bi, b_bi, g_norm_c, ld_g, g_next, g_direct_c, ld_direct, n, slope,
+                       make_drop(p_drop, seed, step, layer, pad_row), idx_a, n_a, off_a, idx_b, n_b, off_b, g_side_c, g_ego_c, nullptr,
+                       nullptr, nullptr, nullptr, gW_parts, part_stride);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }

@@ -51,29 +51,29 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_push_rows_kernel(
     }
 }
 
-// The same product driven by the batch itself — no list, no counter, no extra launch: slot k of the batch (users then
-// items) is processed iff no earlier slot names the same row (each wave checks that with one pass over the <= 2B
-// indices: 8 coalesced loads per lane at B = 256).  kPushParts workgroups of 4 waves share a slot's row, entry e going
-// to (part, wave) = (e mod 16, (e div 16) mod 4): the ~50 ns a CU needs per 256-byte float atomic would otherwise put a
-// 1 000-entry hub row's atomics on one CU (51 us; the list form above took 16 us per launch on Epinion2 batches).
-constexpr int kPushParts = 16;
+// The same product driven by the batch itself, EVERY slot contributing: slot k (row idx_a[k] + off_a, then idx_b[k] + off_b)
+// pushes its own source row src[k] — the slot's own gradient row as the scoring kernel leaves it — so rows named by several
+// slots simply receive several contributions and nothing has to be deduplicated (a first version tested "is this the first
+// slot naming the row" with a scan of the batch in every wave: 128 MB of index reads per launch, 16 us).  kPushParts
+// workgroups of 4 waves share a slot's row, entry e going to (part, wave) = (e mod 4, (e div 4) mod 4): the ~50 ns a CU needs
+// per 256-byte float atomic would otherwise put a 1 000-entry hub row's atomics on one CU.
+constexpr int kPushParts = 4;
 constexpr int kPushWaves = 4;
 
 __global__ __launch_bounds__(kWave *kPushWaves) void spmm_push_batch_kernel(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val, int n_rows,
     const int64_t *__restrict__ idx_a, int n_a, int64_t off_a, const int64_t *__restrict__ idx_b, int n_b, int64_t off_b,
-    const float *__restrict__ src, int src_indexed, const float *__restrict__ add, int add_indexed, float scale, float *out)
+    const float *__restrict__ src, int ld_src, const float *__restrict__ add, int ld_add, float scale, float *out)
 {
     const int k = blockIdx.x / kPushParts, part = blockIdx.x % kPushParts;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     const long long r = batch_row(idx_a, n_a, off_a, idx_b, off_b, k);
     if (r < 0 || r >= n_rows) return;
-    if (!first_occurrence(idx_a, n_a, off_a, idx_b, off_b, k, r, lane)) return;
     const int beg = rowptr[r], end = rowptr[r + 1];
-    const float g = scale * src[(size_t)(src_indexed ? r : k) * kWave + lane];
+    const float g = scale * src[(size_t)k * ld_src + lane];
     for (int e = beg + part + kPushParts * wave; e < end; e += kPushParts * kPushWaves)
         atomicAdd(out + (size_t)col[e] * kWave + lane, val[e] * g);
-    if (add && part == 0 && wave == 0) atomicAdd(out + (size_t)r * kWave + lane, scale * add[(size_t)(add_indexed ? r : k) * kWave + lane]);
+    if (add && part == 0 && wave == 0) atomicAdd(out + (size_t)r * kWave + lane, scale * add[(size_t)k * ld_add + lane]);
 }
 
 }  // namespace
@@ -107,8 +107,8 @@ extern "C" int spex_spmm_push_rows_f32(const spex_graph_t *g, const int32_t *lis
 }
 
 extern "C" int spex_spmm_push_batch_f32(const spex_graph_t *g, const int64_t *idx_a, int32_t n_a, int64_t off_a, const int64_t *idx_b,
-                                        int32_t n_b, int64_t off_b, const float *src, int32_t src_indexed, const float *add,
-                                        int32_t add_indexed, float scale, float *out, int32_t d, void *stream)
+                                        int32_t n_b, int64_t off_b, const float *src, int32_t ld_src, const float *add, int32_t ld_add,
+                                        float scale, float *out, int32_t d, void *stream)
 {
     SPEX_CHECK_ARG(g && src && out, "spex_spmm_push_batch_f32: NULL argument");
     SPEX_CHECK_ARG(n_a >= 0 && n_b >= 0 && (n_a == 0 || idx_a) && (n_b == 0 || idx_b), "spex_spmm_push_batch_f32: bad index lists");
@@ -117,10 +117,10 @@ extern "C" int spex_spmm_push_batch_f32(const spex_graph_t *g, const int64_t *id
         spex::set_error("spex_spmm_push_batch_f32: d == 64 only (got %d)", d);
         return SPEX_ERR_UNSUPPORTED;
     }
+    SPEX_CHECK_ARG(ld_src >= d && (!add || ld_add >= d), "spex_spmm_push_batch_f32: ld_src=%d ld_add=%d", ld_src, ld_add);
     if (n_a + n_b == 0 || g->n_rows == 0) return SPEX_OK;
     hipLaunchKernelGGL(spmm_push_batch_kernel, dim3((unsigned)(n_a + n_b) * kPushParts), dim3(kWave * kPushWaves), 0, (hipStream_t)stream,
-                       g->rowptr, g->col, g->val, g->n_rows, idx_a, n_a, off_a, idx_b, n_b, off_b, src, src_indexed, add, add_indexed,
-                       scale, out);
+                       g->rowptr, g->col, g->val, g->n_rows, idx_a, n_a, off_a, idx_b, n_b, off_b, src, ld_src, add, ld_add, scale, out);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }

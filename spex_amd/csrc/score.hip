@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kWave *kScoreWaves) void score_bce_kernel(
     const float *__restrict__ users, const float *__restrict__ items, int ldu, int ldi, const int64_t *__restrict__ u_idx,
     const int64_t *__restrict__ i_idx, const float *__restrict__ labels, int B, int d, int64_t n_user_rows,
     int64_t n_item_rows, float *__restrict__ gamma, float *loss_sum, float *grad_users, float *grad_items,
-    float grad_scale)
+    float grad_scale, float *__restrict__ grad_slots, int ld_slots)
 {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_global = blockIdx.x * kScoreWaves + (threadIdx.x >> 6);
@@ -62,6 +62,8 @@ __global__ __launch_bounds__(kWave *kScoreWaves) void score_bce_kernel(
         const int64_t u = u_idx[b], it = i_idx[b];
         if (u < 0 || u >= n_user_rows || it < 0 || it >= n_item_rows) {  // never gather out of bounds
             if (lane == 0 && gamma) gamma[b] = __int_as_float(0x7fc00000);
+            if (grad_slots)
+                for (int c = lane; c < d; c += kWave) grad_slots[(size_t)b * ld_slots + c] = grad_slots[(size_t)(B + b) * ld_slots + c] = 0.0f;
             continue;
         }
         const float *pu = users + (size_t)u * ldu, *pi = items + (size_t)it * ldi;
@@ -72,6 +74,13 @@ __global__ __launch_bounds__(kWave *kScoreWaves) void score_bce_kernel(
         if (labels) {
             const float y = labels[b];
             lsum += fmaxf(x, 0.0f) - x * y + log1pf(expf(-fabsf(x)));
+            if (grad_slots) {     // the sample's two gradient rows, compact: slot b = user side, slot B + b = item side
+                const float dg = (sigmoid_f(x) - y) * grad_scale;
+                for (int c = lane; c < d; c += kWave) {
+                    grad_slots[(size_t)b * ld_slots + c] = dg * pi[c];
+                    grad_slots[(size_t)(B + b) * ld_slots + c] = dg * pu[c];
+                }
+            }
             if (grad_users) {
                 const float dg = (sigmoid_f(x) - y) * grad_scale;
                 float *gu = grad_users + (size_t)u * ldu, *gi = grad_items + (size_t)it * ldi;
@@ -496,23 +505,43 @@ inline unsigned grid_for(int64_t waves_wanted)
 
 }  // namespace
 
+static int launch_score_bce(const float *users, const float *items, int32_t ldu, int32_t ldi, int64_t n_user_rows,
+                            int64_t n_item_rows, const int64_t *u_idx, const int64_t *i_idx, const float *labels, int32_t B,
+                            int32_t d, float *gamma, float *loss_sum, float *grad_users, float *grad_items, float grad_scale,
+                            float *grad_slots, int32_t ld_slots, void *stream, const char *who)
+{
+    SPEX_CHECK_ARG(users && items && u_idx && i_idx, "%s: NULL table or index pointer", who);
+    SPEX_CHECK_ARG(B >= 0 && d >= 1 && ldu >= d && ldi >= d, "%s: B=%d d=%d ldu=%d ldi=%d", who, B, d, ldu, ldi);
+    SPEX_CHECK_ARG(n_user_rows >= 0 && n_item_rows >= 0, "%s: negative table size", who);
+    SPEX_CHECK_ARG((grad_users == nullptr) == (grad_items == nullptr), "%s: give both grad tables or neither", who);
+    SPEX_CHECK_ARG((!grad_users && !grad_slots) || labels, "%s: gradients need labels", who);
+    SPEX_CHECK_ARG(!grad_slots || ld_slots >= d, "%s: ld_slots=%d < d", who, ld_slots);
+    SPEX_CHECK_ARG(gamma || labels, "%s: nothing to compute", who);
+    if (B == 0) return SPEX_OK;
+    hipLaunchKernelGGL(score_bce_kernel, dim3(grid_for(B)), dim3(kWave * kScoreWaves), 0, (hipStream_t)stream, users,
+                       items, ldu, ldi, u_idx, i_idx, labels, B, d, n_user_rows, n_item_rows, gamma, loss_sum, grad_users,
+                       grad_items, grad_scale, grad_slots, ld_slots);
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}
+
 extern "C" int spex_score_bce_f32(const float *users, const float *items, int32_t ldu, int32_t ldi,
                                   int64_t n_user_rows, int64_t n_item_rows, const int64_t *u_idx, const int64_t *i_idx,
                                   const float *labels, int32_t B, int32_t d, float *gamma, float *loss_sum,
                                   float *grad_users, float *grad_items, float grad_scale, void *stream)
 {
-    SPEX_CHECK_ARG(users && items && u_idx && i_idx, "spex_score_bce_f32: NULL table or index pointer");
-    SPEX_CHECK_ARG(B >= 0 && d >= 1 && ldu >= d && ldi >= d, "spex_score_bce_f32: B=%d d=%d ldu=%d ldi=%d", B, d, ldu, ldi);
-    SPEX_CHECK_ARG(n_user_rows >= 0 && n_item_rows >= 0, "spex_score_bce_f32: negative table size");
-    SPEX_CHECK_ARG((grad_users == nullptr) == (grad_items == nullptr), "spex_score_bce_f32: give both grad tables or neither");
-    SPEX_CHECK_ARG(!grad_users || labels, "spex_score_bce_f32: gradients need labels");
-    SPEX_CHECK_ARG(gamma || labels, "spex_score_bce_f32: nothing to compute");
-    if (B == 0) return SPEX_OK;
-    hipLaunchKernelGGL(score_bce_kernel, dim3(grid_for(B)), dim3(kWave * kScoreWaves), 0, (hipStream_t)stream, users,
-                       items, ldu, ldi, u_idx, i_idx, labels, B, d, n_user_rows, n_item_rows, gamma, loss_sum, grad_users,
-                       grad_items, grad_scale);
-    SPEX_HIP(hipGetLastError());
-    return SPEX_OK;
+    return launch_score_bce(users, items, ldu, ldi, n_user_rows, n_item_rows, u_idx, i_idx, labels, B, d, gamma, loss_sum, grad_users,
+                            grad_items, grad_scale, nullptr, 0, stream, "spex_score_bce_f32");
+}
+
+extern "C" int spex_score_bce_slots_f32(const float *users, const float *items, int32_t ldu, int32_t ldi,
+                                        int64_t n_user_rows, int64_t n_item_rows, const int64_t *u_idx, const int64_t *i_idx,
+                                        const float *labels, int32_t B, int32_t d, float *loss_sum, float *grad_users,
+                                        float *grad_items, float grad_scale, float *grad_slots, int32_t ld_slots, void *stream)
+{
+    SPEX_CHECK_ARG(grad_slots && labels, "spex_score_bce_slots_f32: needs grad_slots and labels");
+    return launch_score_bce(users, items, ldu, ldi, n_user_rows, n_item_rows, u_idx, i_idx, labels, B, d, nullptr, loss_sum, grad_users,
+                            grad_items, grad_scale, grad_slots, ld_slots, stream, "spex_score_bce_slots_f32");
 }
 
 extern "C" int spex_bpr_sgd_step_f32(const float *U_read, const float *I_read, float *U_w, float *I_w,

@@ -77,25 +77,12 @@ __device__ __forceinline__ float row16_sum_f32(float v)
 }
 }  // namespace spex
 
-// A batch as two device index lists with offsets (users; items + n_user_rows): slot k's row, and whether slot k is the
-// first slot naming its row (duplicates of a row are processed once).
+// A batch as two device index lists with offsets (users; items + n_user_rows): slot k's row.
 namespace spex {
 __device__ __forceinline__ long long batch_row(const int64_t *idx_a, int n_a, int64_t off_a, const int64_t *idx_b, int64_t off_b,
                                                int k)
 {
     return k < n_a ? idx_a[k] + off_a : idx_b[k - n_a] + off_b;
-}
-
-// true iff no slot j < k holds row r (wave-uniform result; all 64 lanes must call)
-__device__ __forceinline__ bool first_occurrence(const int64_t *idx_a, int n_a, int64_t off_a, const int64_t *idx_b, int64_t off_b,
-                                                 int k, long long r, int lane)
-{
-    bool dup = false;
-    for (int j0 = 0; j0 < k; j0 += 64) {
-        const int j = j0 + lane;
-        if (j < k) dup |= batch_row(idx_a, n_a, off_a, idx_b, off_b, j) == r;
-    }
-    return __ballot(dup) == 0ull;
 }
 
 }  // namespace spex

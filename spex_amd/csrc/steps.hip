@@ -19,13 +19,14 @@ extern "C" int spex_lightgcn_step_bce_f32(spex_lightgcn_step_t *s, const int64_t
                                           const float *labels, int32_t B, float *loss_sum, void *stream)
 {
     SPEX_CHECK_ARG(s && s->graph && s->graph_t && s->E0 && s->m && s->v && s->light_out && s->ws_fwd && s->lo_batch && s->g_out
-                       && s->ws_bwd && s->grad_E0,
+                       && s->ws_bwd && s->grad_E0 && s->grad_slots,
                    "spex_lightgcn_step_bce_f32: NULL field in the step descriptor");
     SPEX_CHECK_ARG(users && items && labels && loss_sum && B >= 1, "spex_lightgcn_step_bce_f32: NULL batch pointer or B < 1");
     const spex_graph *g = s->graph, *gt = s->graph_t;
     const int32_t L = s->L, d = s->d, n_u = s->n_user_rows;
     SPEX_CHECK_ARG(g->n_rows == g->n_cols && gt->n_rows == g->n_rows && gt->n_cols == g->n_rows, "spex_lightgcn_step_bce_f32: square graphs of one size");
     SPEX_CHECK_ARG(L >= 1 && d == 64 && n_u >= 0 && n_u <= g->n_rows, "spex_lightgcn_step_bce_f32: L=%d d=%d n_user_rows=%d (needs L >= 1, d == 64)", L, d, n_u);
+    SPEX_CHECK_ARG(s->slot_capacity >= 2 * B, "spex_lightgcn_step_bce_f32: slot capacity %d < 2 B = %d", s->slot_capacity, 2 * B);
     SPEX_CHECK_ARG(g->mask_mode == 0 && gt->mask_mode == 0, "spex_lightgcn_step_bce_f32: edge dropout is not supported in the one-call step");
     const size_t sz = (size_t)g->n_rows * d;
     // ---- forward: layers 0 .. L-2 over the whole graph (running layer sum fused), the last layer at the batch's rows only
@@ -38,12 +39,13 @@ extern "C" int spex_lightgcn_step_bce_f32(spex_lightgcn_step_t *s, const int64_t
     SPEX_TRY(spex_spmm_rowlist_f32(g, cur, users, B, 0, items, B, n_u, nullptr, L == 1 ? s->E0 : s->light_out, s->lo_batch,
                                    (float)(L + 1), d, stream));
     // ---- scoring + BCE + gradient rows (g_out is all-zero between steps: the Adam pass below clears it)
-    SPEX_TRY(spex_score_bce_f32(s->lo_batch, s->lo_batch + (size_t)n_u * d, d, d, n_u, g->n_rows - n_u, users, items, labels, B, d,
-                                nullptr, loss_sum, s->g_out, s->g_out + (size_t)n_u * d, 1.0f / (float)B, stream));
-    // ---- backward: G_{L-1} = (g + A^T g) / (L+1) in push form over the batch's distinct rows, then L-1 pull-form products
+    SPEX_TRY(spex_score_bce_slots_f32(s->lo_batch, s->lo_batch + (size_t)n_u * d, d, d, n_u, g->n_rows - n_u, users, items, labels, B, d,
+                                      loss_sum, s->g_out, s->g_out + (size_t)n_u * d, 1.0f / (float)B, s->grad_slots, d, stream));
+    // ---- backward: G_{L-1} = (g + A^T g) / (L+1) in push form, slot by slot, then L-1 pull-form products
     if (L >= 2) {
         float *G = s->ws_bwd;                     // all-zero here: cleared by the previous step's Adam pass (first call: by the caller)
-        SPEX_TRY(spex_spmm_push_batch_f32(gt, users, B, 0, items, B, n_u, s->g_out, 1, s->g_out, 1, 1.0f / (float)(L + 1), G, d, stream));
+        SPEX_TRY(spex_spmm_push_batch_f32(gt, users, B, 0, items, B, n_u, s->grad_slots, d, s->grad_slots, d, 1.0f / (float)(L + 1), G, d,
+                                          stream));
         const float *c2 = G;
         for (int32_t l = L - 2; l >= 0; --l) {
             float *nxt = l == 0 ? s->grad_E0 : s->ws_bwd + (size_t)(1 + ((L - 2 - l) & 1)) * sz;   // ws_bwd[1], [2], [1] ...: never the source, never G

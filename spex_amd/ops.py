@@ -39,7 +39,7 @@ def _idx(t, device, bound=None):
 
 # ------------------------------------------------------------------------------------------------ raw kernels
 def score_bce(users_tab, items_tab, u_idx, i_idx, labels=None, grad_users=None, grad_items=None, grad_scale=0.0,
-              loss_sum=None, want_gamma=True):
+              loss_sum=None, want_gamma=True, grad_slots=None):
     """gamma (and, with labels, the BCE loss *sum* and optional gradient rows).  spex_score_bce_f32.
     loss_sum: a caller-owned 1-element buffer to ACCUMULATE into (no per-call allocation / fill); want_gamma=False skips
     the score vector (training steps do not read it)."""
@@ -55,6 +55,16 @@ def score_bce(users_tab, items_tab, u_idx, i_idx, labels=None, grad_users=None, 
     else:
         loss_sum = None
     _need(grad_users, "grad_users"); _need(grad_items, "grad_items")
+    if grad_slots is not None:
+        # the gradient also (or only) as per-sample rows [2B, ld]: row b = sample b's user-side row, row B + b its item-side row
+        if not (grad_slots.is_cuda and grad_slots.dtype == torch.float32 and grad_slots.stride(1) == 1 and grad_slots.shape[0] >= 2 * B
+                and grad_slots.shape[1] >= d):
+            raise ValueError("score_bce: grad_slots must be an fp32 [>= 2B, >= d] device tensor with unit column stride")
+        _launch(users_tab.device, "spex_score_bce_slots_f32", _ptr(users_tab), _ptr(items_tab), users_tab.stride(0), items_tab.stride(0),
+                users_tab.shape[0], items_tab.shape[0], _ptr(u_idx), _ptr(i_idx), _ptr(labels), B, d, _ptr(loss_sum), _ptr(grad_users),
+                _ptr(grad_items), float(grad_scale), _ptr(grad_slots), grad_slots.stride(0))
+        _bump(grad_users, grad_items, loss_sum, grad_slots)
+        return None, loss_sum
     _launch(users_tab.device, "spex_score_bce_f32", _ptr(users_tab), _ptr(items_tab), users_tab.stride(0), items_tab.stride(0),
               users_tab.shape[0], items_tab.shape[0], _ptr(u_idx), _ptr(i_idx), _ptr(labels), B, d, _ptr(gamma),
               _ptr(loss_sum), _ptr(grad_users), _ptr(grad_items), float(grad_scale))
@@ -189,31 +199,31 @@ def ngcf_layer_bwd(ego, side, W_gc, b_gc, W_bi, b_bi, g_all, layer, g_next, g_si
     _bump(g_side, g_ego, gW_gc, gb_gc, gW_bi, gb_bi)
 
 
-def ngcf_layer_bwd_rows(ego, side, W_gc, b_gc, W_bi, b_bi, g_all, layer, g_next, idx_a, idx_b, off_b, g_side_c, g_ego_c, gW_parts,
-                        slope=0.01, drop=None, pad_row=-1, clear_consumed=True):
+def ngcf_layer_bwd_rows(ego, side, W_gc, b_gc, W_bi, b_bi, g_slots, layer, g_next, idx_a, idx_b, off_b, g_side_c, g_ego_c, gW_parts,
+                        slope=0.01, drop=None, pad_row=-1):
     """ngcf_layer_bwd for the rows of a BATCH only (the last layer's backward in training): slot k is row idx_a[k], slot
-    len(idx_a) + k is row idx_b[k] + off_b; compact outputs g_side_c / g_ego_c [len(idx_a) + len(idx_b), d]; the weight
-    gradients leave as partial blocks gW_parts [n_parts, >= 2 (d d + d)] (n_parts = ngcf_bwd_rows_parts(slots)); with
-    clear_consumed the rows of g_all that were read are zeroed.  spex_ngcf_layer_bwd_rows_f32."""
-    for x, n in ((ego, "ego"), (side, "side"), (W_gc, "W_gc"), (b_gc, "b_gc"), (W_bi, "W_bi"), (b_bi, "b_bi"), (g_all, "g_all"),
+    len(idx_a) + k is row idx_b[k] + off_b, each with its own upstream gradient row g_slots[k] ([slots, d (L + 1)] as
+    score_bce(grad_slots=...) writes it); compact outputs g_side_c / g_ego_c [slots, d]; the weight gradients leave as
+    partial blocks gW_parts [ngcf_bwd_rows_parts(slots), >= 2 (d d + d)].  spex_ngcf_layer_bwd_rows_f32."""
+    for x, n in ((ego, "ego"), (side, "side"), (W_gc, "W_gc"), (b_gc, "b_gc"), (W_bi, "W_bi"), (b_bi, "b_bi"), (g_slots, "g_slots"),
                  (g_next, "g_next"), (g_side_c, "g_side_c"), (g_ego_c, "g_ego_c"), (gW_parts, "gW_parts")):
         _need(x, n)
     n, d = ego.shape
     n_a, n_b = idx_a.numel(), idx_b.numel()
-    if g_side_c.shape[0] < n_a + n_b or g_ego_c.shape[0] < n_a + n_b or gW_parts.shape[0] < ngcf_bwd_rows_parts(n_a + n_b):
-        raise ValueError("ngcf_layer_bwd_rows: compact outputs / partial blocks are too small for the batch")
+    if (g_side_c.shape[0] < n_a + n_b or g_ego_c.shape[0] < n_a + n_b or g_slots.shape[0] < n_a + n_b
+            or gW_parts.shape[0] < ngcf_bwd_rows_parts(n_a + n_b)):
+        raise ValueError("ngcf_layer_bwd_rows: per-slot arrays / partial blocks are too small for the batch")
     for t in (idx_a, idx_b):
         if not (t.is_cuda and t.dtype == torch.int64 and t.is_contiguous()):
             raise ValueError("ngcf_layer_bwd_rows: the batch must be contiguous int64 tensors on the GPU")
     p, seed, step = drop if drop is not None else (0.0, 0, 0)
-    ld = g_all.stride(0)
-    g_norm = ctypes.c_void_p(g_all.data_ptr() + 4 * d * (layer + 1))
-    g_direct = ctypes.c_void_p(g_all.data_ptr()) if layer == 0 else None
+    ld = g_slots.stride(0)
+    g_norm = ctypes.c_void_p(g_slots.data_ptr() + 4 * d * (layer + 1))
+    g_direct = ctypes.c_void_p(g_slots.data_ptr()) if layer == 0 else None
     _launch(ego.device, "spex_ngcf_layer_bwd_rows_f32", _ptr(ego), _ptr(side), _ptr(W_gc), _ptr(b_gc), _ptr(W_bi), _ptr(b_bi), g_norm,
             ld, _ptr(g_next), g_direct, ld, n, d, float(slope), float(p), int(seed), int(step), int(layer), int(pad_row),
-            _ptr(idx_a), n_a, 0, _ptr(idx_b), n_b, int(off_b), 1 if clear_consumed else 0, _ptr(g_side_c), _ptr(g_ego_c),
-            _ptr(gW_parts), gW_parts.stride(0))
-    _bump(g_side_c, g_ego_c, gW_parts, g_all)
+            _ptr(idx_a), n_a, 0, _ptr(idx_b), n_b, int(off_b), _ptr(g_side_c), _ptr(g_ego_c), _ptr(gW_parts), gW_parts.stride(0))
+    _bump(g_side_c, g_ego_c, gW_parts)
 
 
 def ngcf_bwd_rows_parts(n_slots):
@@ -272,22 +282,21 @@ def spmm_push_rows(graph, rows, src, out, src_indexed, add=None, add_indexed=Fal
     return out
 
 
-def spmm_push_batch(graph, idx_a, idx_b, off_b, src, out, src_indexed, add=None, add_indexed=False, scale=1.0):
-    """out += scale * (A^T scatter(src) + scatter(add)) over the DISTINCT rows of a batch (slot k: row idx_a[k]; slot
-    len(idx_a) + k: row idx_b[k] + off_b), one launch, d == 64 (spex_spmm_push_batch_f32).  src / add: the [N, d] table
-    itself (indexed=True) or compact per-slot arrays."""
-    _need(src, "src"); _need(out, "out"); _need(add, "add")
-    if out.shape != (graph.n_cols, 64):
-        raise ValueError("spmm_push_batch: out must be [graph.n_cols, 64]")
+def spmm_push_batch(graph, idx_a, idx_b, off_b, src, out, add=None, scale=1.0):
+    """out += scale * (A^T scatter(src) + scatter(add)), every slot of the batch contributing its own row (slot k: row
+    idx_a[k]; slot len(idx_a) + k: row idx_b[k] + off_b; src / add: per-slot [slots, 64] arrays, e.g. score_bce's
+    grad_slots), one launch, d == 64 (spex_spmm_push_batch_f32)."""
+    if out.shape != (graph.n_cols, 64) or not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous()):
+        raise ValueError("spmm_push_batch: out must be a contiguous fp32 [graph.n_cols, 64] device tensor")
     for t in (idx_a, idx_b):
         if not (t.is_cuda and t.dtype == torch.int64 and t.is_contiguous()):
             raise ValueError("spmm_push_batch: the batch must be contiguous int64 tensors on the GPU")
     slots = idx_a.numel() + idx_b.numel()
-    for t, ind, nm in ((src, src_indexed, "src"), (add, add_indexed, "add")):
-        if t is not None and (t.shape[1] != 64 or t.shape[0] < (graph.n_rows if ind else slots)):
-            raise ValueError(f"spmm_push_batch: {nm} has shape {tuple(t.shape)}")
+    for t, nm in ((src, "src"), (add, "add")):
+        if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.stride(1) == 1 and t.shape[0] >= slots and t.shape[1] >= 64):
+            raise ValueError(f"spmm_push_batch: {nm} must be an fp32 [>= slots, >= 64] device tensor with unit column stride")
     _launch(out.device, "spex_spmm_push_batch_f32", graph._h, _ptr(idx_a), idx_a.numel(), 0, _ptr(idx_b), idx_b.numel(), int(off_b),
-            _ptr(src), 1 if src_indexed else 0, _ptr(add), 1 if add_indexed else 0, float(scale), _ptr(out), 64)
+            _ptr(src), src.stride(0), _ptr(add), 0 if add is None else add.stride(0), float(scale), _ptr(out), 64)
     _bump(out)
     return out
 

@@ -70,13 +70,21 @@ class LightGCNStepper:
             return self._step_bce_one_call(users, items, labels, loss_acc)
         lo = self.propagate_for_batch(users, items) if batch_rows_only else self.propagate()
         B = users.numel()
+        self._slots(B)
         _, loss_sum = ops.score_bce(lo[:self.n_u], lo[self.n_u:], users, items, labels, self.g_out[:self.n_u],
-                                    self.g_out[self.n_u:], 1.0 / B, loss_sum=loss_acc, want_gamma=False)
+                                    self.g_out[self.n_u:], 1.0 / B, loss_sum=loss_acc, want_gamma=False, grad_slots=self.grad_slots)
         self.backward_from_batch_rows(users, items)
         self.t += 1
         ops.adam_step(self.E0, self.grad_E0, self.m, self.v, self.t, self.lr, self.betas[0], self.betas[1], self.eps,
                       zero=self.g_out)
         return None if loss_acc is not None else loss_sum / B
+
+    def _slots(self, B):
+        """The batch's per-sample gradient rows (operands of the push-form first backward product)."""
+        if getattr(self, "grad_slots", None) is None or self.grad_slots.shape[0] < 2 * B:
+            self.grad_slots = torch.zeros((2 * B, self.E0.shape[1]), dtype=torch.float32, device=self.E0.device)
+            self._desc = None
+        return self.grad_slots
 
     # -- the whole step as one library call (spex_lightgcn_step_bce_f32): same launches, issued from native code
     def _one_call_ok(self, users, items, labels):
@@ -93,6 +101,7 @@ class LightGCNStepper:
         B = users.numel()
         if self.lo_batch is None:
             self.lo_batch = torch.zeros_like(self.light_out)
+        self._slots(B)
         if not getattr(self, "_ws0_clean", False):       # another path used the workspace: restore the all-zero push target
             self.ws_bwd[0].zero_()
             self._ws0_clean = True
@@ -101,7 +110,8 @@ class LightGCNStepper:
             self._desc = _lib.LightGCNStepDesc(
                 graph=self.graph._h.value, graph_t=self.graph_t._h.value, E0=p(self.E0), m=p(self.m), v=p(self.v),
                 light_out=p(self.light_out), ws_fwd=p(self.ws_fwd), lo_batch=p(self.lo_batch), g_out=p(self.g_out),
-                ws_bwd=p(self.ws_bwd), grad_E0=p(self.grad_E0), n_user_rows=self.n_u, L=self.L, d=self.E0.shape[1],
+                ws_bwd=p(self.ws_bwd), grad_E0=p(self.grad_E0), grad_slots=p(self.grad_slots),
+                slot_capacity=self.grad_slots.shape[0], n_user_rows=self.n_u, L=self.L, d=self.E0.shape[1],
                 lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, t=self.t)
         d = self._desc
         d.t, d.lr = self.t, self.lr
@@ -124,7 +134,7 @@ class LightGCNStepper:
         inv = 1.0 / float(L + 1)
         G = self.ws_bwd[0]
         G.zero_()
-        ops.spmm_push_batch(gt, users, items, self.n_u, self.g_out, G, True, add=self.g_out, add_indexed=True, scale=inv)   # G_{L-1}
+        ops.spmm_push_batch(gt, users, items, self.n_u, self.grad_slots, G, add=self.grad_slots, scale=inv)   # G_{L-1}
         cur = G
         for l in range(L - 2, -1, -1):
             nxt = self.grad_E0 if l == 0 else self.ws_bwd[1 + ((L - 2 - l) & 1)]      # ws_bwd[1], [2], [1] ...: never the source
@@ -253,7 +263,7 @@ class NGCFStepper:
         self.egos = [self.E0] + [z(n, d) for _ in range(L - 1)]
         self.g_side, self.g_ego = z(n, d), z(n, d)
         self.g_next = [z(n, d), z(n, d)]                        # g_next[(L-1) & 1] is all-zero between steps (push target)
-        self.g_side_c, self.g_ego_c, self.gW_parts = None, None, None
+        self.g_slots, self.g_side_c, self.g_ego_c, self.gW_parts = None, None, None, None
         self.loss_acc = z(1)
         self.n_u = model.n_users + 1
 
@@ -273,24 +283,28 @@ class NGCFStepper:
             ops.ngcf_layer_fwd(self.egos[l], self.sides[l], *self.views[l], self.all_emb, l, l == 0,
                                self.egos[l + 1] if l < L - 1 else None, drop=dl, pad_row=pad)
         B = users.numel()
-        ops.score_bce(self.all_emb[:self.n_u], self.all_emb[self.n_u:], users, items, labels, self.g_all[:self.n_u],
-                      self.g_all[self.n_u:], 1.0 / B, loss_sum=acc, want_gamma=False)
-        # backward.  Only the batch's <= 2B distinct rows carry a gradient behind the LAST layer: its backward runs on
-        # those rows (compact tiles), and A^T g_side is a push over their stored entries instead of a pull-form SpMM.
         if self.g_side_c is None or self.g_side_c.shape[0] < 2 * B:
             dev, d = self.E0.device, self.E0.shape[1]
+            self.g_slots = torch.zeros((2 * B, d * (L + 1)), dtype=torch.float32, device=dev)     # per-sample gradient rows
             self.g_side_c = torch.zeros((2 * B, d), dtype=torch.float32, device=dev)
             self.g_ego_c = torch.zeros_like(self.g_side_c)
             self.gW_parts = torch.zeros((ops.ngcf_bwd_rows_parts(2 * B), 2 * (d * d + d)), dtype=torch.float32, device=dev)
+        # scoring: per-sample gradient rows; the table form too only if earlier layers (dense backward) need their slices
+        tab = (self.g_all[:self.n_u], self.g_all[self.n_u:]) if L > 1 else (None, None)
+        ops.score_bce(self.all_emb[:self.n_u], self.all_emb[self.n_u:], users, items, labels, tab[0], tab[1], 1.0 / B, loss_sum=acc,
+                      want_gamma=False, grad_slots=self.g_slots)
+        # backward.  Only the batch's <= 2B rows carry a gradient behind the LAST layer: its backward runs on the batch's
+        # slots (compact tiles, each slot with its own gradient row), and A^T g_side is a push over their stored entries
+        # instead of a pull-form SpMM.
         l = L - 1
-        per = self.gW_parts.shape[1]
         dl = None if drop is None or drop[0][l] <= 0 else (drop[0][l], drop[1], drop[2])
-        ops.ngcf_layer_bwd_rows(self.egos[l], self.sides[l], *self.views[l], self.g_all, l, None, users, items, self.n_u,
-                                self.g_side_c, self.g_ego_c, self.gW_parts, drop=dl, pad_row=pad, clear_consumed=(L == 1))
+        parts = self.gW_parts[: ops.ngcf_bwd_rows_parts(2 * B)]      # (a ragged last batch writes fewer blocks)
+        ops.ngcf_layer_bwd_rows(self.egos[l], self.sides[l], *self.views[l], self.g_slots, l, None, users, items, self.n_u,
+                                self.g_side_c, self.g_ego_c, parts, drop=dl, pad_row=pad)
         g_next = self.g_next[l & 1]
         if L > 1:
             g_next.zero_()
-        ops.spmm_push_batch(m.graph, users, items, self.n_u, self.g_side_c, g_next, False, add=self.g_ego_c, add_indexed=False)
+        ops.spmm_push_batch(m.graph, users, items, self.n_u, self.g_side_c, g_next, add=self.g_ego_c)
         for l in range(L - 2, -1, -1):
             dl = None if drop is None or drop[0][l] <= 0 else (drop[0][l], drop[1], drop[2])
             ops.ngcf_layer_bwd(self.egos[l], self.sides[l], *self.views[l], self.g_all, l, g_next, self.g_side, self.g_ego,
@@ -306,8 +320,7 @@ class NGCFStepper:
         # (dense backward, atomics into gW) go through the plain pass
         per = self.gW_parts.shape[1]
         lo = (L - 1) * per
-        ops.adam_step_sum(self.W[lo:lo + per], self.gW_parts, self.mW[lo:lo + per], self.vW[lo:lo + per], self.t, self.lr, b1, b2,
-                          self.eps)
+        ops.adam_step_sum(self.W[lo:lo + per], parts, self.mW[lo:lo + per], self.vW[lo:lo + per], self.t, self.lr, b1, b2, self.eps)
         if L > 1:
             ops.adam_step(self.W[:lo], self.gW[:lo], self.mW[:lo], self.vW[:lo], self.t, self.lr, b1, b2, self.eps, zero=self.gW[:lo])
             self.g_all.zero_()

@@ -285,9 +285,10 @@ def test_whole_ngcf_epoch_matches_the_reference_epinion2(golden, ngcf_data_root)
 
 
 def test_layer_backward_rows_form_equals_dense_form(oracle):
-    """spex_ngcf_layer_bwd_rows_f32 (compact tiles over the batch's slots, a row processed at its first slot only) against
-    the dense form on the same inputs: same g_side / g_ego at the batch's distinct rows, same weight gradients (summed
-    from the partial blocks, also through spex_adam_step_sum_f32); the consumed rows of the gradient table are cleared."""
+    """spex_ngcf_layer_bwd_rows_f32 (compact tiles over the batch's slots, every slot with its own gradient row) against
+    the dense form fed with the same gradients scattered into a table: the layer's backward is linear in the upstream
+    gradient, so a row's dense result equals the sum of its slots' compact results; the weight gradients (summed from the
+    partial blocks, also through spex_adam_step_sum_f32) are the same."""
     from spex_amd import ops
     rng = np.random.default_rng(77)
     n = 2000
@@ -295,28 +296,24 @@ def test_layer_backward_rows_form_equals_dense_form(oracle):
     W_gc, W_bi = (torch.from_numpy(rng.normal(size=(64, 64)).astype(np.float32) * 0.2).to(DEV) for _ in range(2))
     b_gc, b_bi = (torch.from_numpy(rng.normal(size=64).astype(np.float32) * 0.1).to(DEV) for _ in range(2))
     u_np, i_np = rng.integers(0, 700, 200), rng.integers(0, 1200, 200)
-    u_np[:4] = u_np[10]                                                     # repeated users: later slots are skipped
+    u_np[:4] = u_np[10]                                                     # a user named by five slots
     users, items = torch.from_numpy(u_np).to(DEV), torch.from_numpy(i_np).to(DEV)
-    slot_rows = np.concatenate([u_np, i_np + 700])
-    first = np.array([r not in slot_rows[:k] for k, r in enumerate(slot_rows)])
-    listed = torch.from_numpy(slot_rows[first]).to(DEV)
-    g_all = torch.zeros(n, 128, device=DEV)
-    g_all[listed] = torch.from_numpy(rng.normal(size=(int(first.sum()), 128)).astype(np.float32)).to(DEV)
+    slot_rows = torch.from_numpy(np.concatenate([u_np, i_np + 700])).to(DEV)
+    g_slots = torch.from_numpy(rng.normal(size=(400, 128)).astype(np.float32)).to(DEV)
+    g_all = torch.zeros(n, 128, device=DEV).index_add_(0, slot_rows, g_slots)
     drop = (0.1, 99, 3)
     gW = [torch.zeros(64, 64, device=DEV), torch.zeros(64, device=DEV), torch.zeros(64, 64, device=DEV), torch.zeros(64, device=DEV)]
-    ga = g_all.clone()
     gs, ge = torch.empty(n, 64, device=DEV), torch.empty(n, 64, device=DEV)
-    ops.ngcf_layer_bwd(ego, side, W_gc, b_gc, W_bi, b_bi, ga, 0, None, gs, ge, *gW, drop=drop, pad_row=700)
-    assert torch.equal(ga, g_all)
+    ops.ngcf_layer_bwd(ego, side, W_gc, b_gc, W_bi, b_bi, g_all, 0, None, gs, ge, *gW, drop=drop, pad_row=700)
     n_parts = ops.ngcf_bwd_rows_parts(400)
+    assert n_parts == 25
     parts = torch.full((n_parts, 2 * (64 * 64 + 64)), 7.0, device=DEV)
     gsc, gec = torch.full((400, 64), 9.0, device=DEV), torch.full((400, 64), 9.0, device=DEV)
-    ops.ngcf_layer_bwd_rows(ego, side, W_gc, b_gc, W_bi, b_bi, ga, 0, None, users, items, 700, gsc, gec, parts, drop=drop, pad_row=700)
-    assert torch.count_nonzero(ga).item() == 0                              # consumed rows cleared
-    sel = torch.from_numpy(np.flatnonzero(first)).to(DEV)
-    assert rel_err(gsc[sel].cpu().numpy(), gs[listed].cpu().numpy()) <= 1e-6
-    assert rel_err(gec[sel].cpu().numpy(), ge[listed].cpu().numpy()) <= 1e-6
-    assert (gsc[~torch.from_numpy(first).to(DEV)] == 9.0).all()             # skipped slots are not written
+    ops.ngcf_layer_bwd_rows(ego, side, W_gc, b_gc, W_bi, b_bi, g_slots, 0, None, users, items, 700, gsc, gec, parts, drop=drop, pad_row=700)
+    got_s = torch.zeros(n, 64, device=DEV).index_add_(0, slot_rows, gsc)
+    got_e = torch.zeros(n, 64, device=DEV).index_add_(0, slot_rows, gec)
+    assert rel_err(got_s.cpu().numpy(), gs.cpu().numpy()) <= 2e-6
+    assert rel_err(got_e.cpu().numpy(), ge.cpu().numpy()) <= 2e-6
     tot = parts.sum(0).cpu().numpy()
     want = np.concatenate([gW[0].cpu().numpy().ravel(), gW[1].cpu().numpy(), gW[2].cpu().numpy().ravel(), gW[3].cpu().numpy()])
     assert rel_err(tot, want) <= 1e-5
@@ -326,3 +323,9 @@ def test_layer_backward_rows_form_equals_dense_form(oracle):
     ops.adam_step_sum(p1, parts, m1, v1, 1, lr=1e-2)
     ops.adam_step(p2, parts.sum(0).contiguous(), m2, v2, 1, lr=1e-2)
     assert rel_err(p1.cpu().numpy(), p2.cpu().numpy()) <= 1e-6
+    # and the scoring kernel's per-sample rows are what sums up to its table form
+    tab = torch.from_numpy(rng.normal(size=(n, 128)).astype(np.float32)).to(DEV)
+    y = torch.from_numpy((rng.random(200) < 0.3).astype(np.float32)).to(DEV)
+    gt_tab, slots = torch.zeros(n, 128, device=DEV), torch.zeros(400, 128, device=DEV)
+    ops.score_bce(tab[:700], tab[700:], users, items, y, gt_tab[:700], gt_tab[700:], 1.0 / 200, grad_slots=slots, want_gamma=False)
+    assert rel_err(torch.zeros(n, 128, device=DEV).index_add_(0, slot_rows, slots).cpu().numpy(), gt_tab.cpu().numpy()) <= 2e-6
