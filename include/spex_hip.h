@@ -416,6 +416,29 @@ typedef struct spex_lightgcn_step {
 int spex_lightgcn_step_bce_f32(spex_lightgcn_step_t *step, const int64_t *users, const int64_t *items, const float *labels,
                                int32_t B, float *loss_sum, void *stream);
 
+/* The single-layer NGCF training step (NGCF_SPEX/code/main_rec.py:122-128 with the default --layer_size [64]) as one call:
+ *   spex_spmm_f32 (side = A ego) -> spex_ngcf_layer_fwd_f32 -> spex_score_bce_slots_f32 -> spex_ngcf_layer_bwd_rows_f32
+ *   -> spex_spmm_push_batch_f32 -> spex_adam_step_f32 (table; clears its gradient) -> spex_adam_step_sum_f32 (layer weights).
+ * Buffers (caller-owned, N = graph rows incl. an isolated pad row if the table keeps one, d == 64):
+ *   E0, mE, vE, side, grad: [N, d] (grad all-zero before the first call; every call leaves it all-zero);  all_emb: [N, 2d];
+ *   W, mW, vW: the layer's weights as one block [W_gc d*d | b_gc d | W_bi d*d | b_bi d] and its Adam moments;
+ *   g_slots: [slot_capacity, 2d];  g_side_c, g_ego_c: [slot_capacity, d];  gW_parts: [slot_capacity / 16, 2 (d*d + d)].
+ * users index rows [0, n_user_rows), items rows n_user_rows + items[b].  Message dropout: (p_drop, seed, dropout_step, layer 0),
+ * dropout_step advanced by the call when p_drop > 0; t advanced by the call.
+ */
+typedef struct spex_ngcf_step {
+    const spex_graph_t *graph;               /* A = D^-1 (A + I) */
+    float *E0, *mE, *vE, *W, *mW, *vW;
+    float *all_emb, *side, *g_slots, *g_side_c, *g_ego_c, *gW_parts, *grad;
+    int32_t slot_capacity, n_user_rows, pad_row;
+    float slope, p_drop;
+    uint64_t seed;
+    int32_t dropout_step, t;
+    float lr, beta1, beta2, eps;
+} spex_ngcf_step_t;
+int spex_ngcf_step_bce_f32(spex_ngcf_step_t *step, const int64_t *users, const int64_t *items, const float *labels, int32_t B,
+                           float *loss_sum, void *stream);
+
 /* ------------------------------------------------------------------------------------------------ profiling hook
  * Not part of any reference interface: lets a caller time the dominant kernel itself, in place, on the stream it is
  * launched on (bench.py's roofline figure).  While a timer is attached to a graph, every (or every n-th) call of

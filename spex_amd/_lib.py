@@ -72,6 +72,7 @@ SIGNATURES = {
     "spex_path_attention_bwd_f32": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp,
                                                    c_vp, c_vp, c_vp, c_vp]),
     "spex_lightgcn_step_bce_f32": (ctypes.c_int, [ctypes.c_void_p, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
+    "spex_ngcf_step_bce_f32": (ctypes.c_int, [ctypes.c_void_p, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "spex_timer_create": (ctypes.c_int, [c_i32, c_i32, ctypes.POINTER(c_vp)]),
     "spex_timer_destroy": (ctypes.c_int, [c_vp]),
     "spex_timer_attach": (ctypes.c_int, [c_vp, c_vp]),
@@ -86,6 +87,15 @@ class LightGCNStepDesc(ctypes.Structure):
                                      "grad_E0", "grad_slots")]
                 + [(n, c_i32) for n in ("slot_capacity", "n_user_rows", "L", "d")]
                 + [(n, c_f32) for n in ("lr", "beta1", "beta2", "eps")] + [("t", c_i32)])
+
+
+class NGCFStepDesc(ctypes.Structure):
+    """spex_ngcf_step_t (include/spex_hip.h)."""
+    _fields_ = ([(n, c_vp) for n in ("graph", "E0", "mE", "vE", "W", "mW", "vW", "all_emb", "side", "g_slots", "g_side_c", "g_ego_c",
+                                     "gW_parts", "grad")]
+                + [(n, c_i32) for n in ("slot_capacity", "n_user_rows", "pad_row")] + [("slope", c_f32), ("p_drop", c_f32)]
+                + [("seed", ctypes.c_uint64), ("dropout_step", c_i32), ("t", c_i32)]
+                + [(n, c_f32) for n in ("lr", "beta1", "beta2", "eps")])
 
 
 _lib = None

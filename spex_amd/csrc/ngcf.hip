@@ -232,8 +232,10 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
         pa[0] = a.x; pa[1] = a.y; pa[2] = a.z; pa[3] = a.w;
         pb[0] = b.x; pb[1] = b.y; pb[2] = b.z; pb[3] = b.w;
     }
-    for (int i = threadIdx.x; i < 64 * kDwStride; i += blockDim.x) s_dw[0][i] = s_dw[1][i] = 0.0f;
-    if (threadIdx.x < 64) s_db[0][threadIdx.x] = s_db[1][threadIdx.x] = 0.0f;
+    if (!ROWS) {                                                 // (the rows form never touches the LDS accumulators)
+        for (int i = threadIdx.x; i < 64 * kDwStride; i += blockDim.x) s_dw[0][i] = s_dw[1][i] = 0.0f;
+        if (threadIdx.x < 64) s_db[0][threadIdx.x] = s_db[1][threadIdx.x] = 0.0f;
+    }
     if (threadIdx.x == 0) s_active = 0;
     __syncthreads();
     const int i16 = lane & 15, h = lane >> 4;
@@ -262,11 +264,9 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
         // -1 = past the end / out of range); lane i keeps slot i's row in `slot_row`
         int slot_row = -1;
         if (ROWS) {
-            for (int i = 0; i < 16; ++i) {
-                const int k = r0 + i;
-                if (k >= n_items) break;
-                const long long r = batch_row(idx_a, n_a, off_a, idx_b, off_b, k);
-                if (lane == i) slot_row = (r >= 0 && r < n) ? (int)r : -1;
+            if (lane < 16 && r0 + lane < n_items) {
+                const long long r = batch_row(idx_a, n_a, off_a, idx_b, off_b, r0 + lane);
+                slot_row = (r >= 0 && r < n) ? (int)r : -1;
             }
         } else if (lane < 16 && r0 + lane < n) {
             slot_row = r0 + lane;

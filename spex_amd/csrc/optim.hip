@@ -98,7 +98,15 @@ __global__ __launch_bounds__(256) void adam_sum_kernel(float *__restrict__ p, co
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float g = 0.0f;
-    for (int k = 0; k < n_parts; ++k) g += parts[(size_t)k * part_stride + i];
+    int k = 0;
+    for (; k + 8 <= n_parts; k += 8) {                   // eight independent loads in flight, added in part order
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = parts[(size_t)(k + j) * part_stride + i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g += x[j];
+    }
+    for (; k < n_parts; ++k) g += parts[(size_t)k * part_stride + i];
     float P = p[i], M = m[i], V = v[i];
     adam1(P, g, M, V, w1, beta2, w2, bc2_sqrt, eps, step_size);
     p[i] = P; m[i] = M; v[i] = V;

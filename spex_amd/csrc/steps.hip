@@ -61,3 +61,39 @@ extern "C" int spex_lightgcn_step_bce_f32(spex_lightgcn_step_t *s, const int64_t
                                 L >= 2 ? s->ws_bwd : nullptr, stream));
     return SPEX_OK;
 }
+
+extern "C" int spex_ngcf_step_bce_f32(spex_ngcf_step_t *s, const int64_t *users, const int64_t *items, const float *labels,
+                                      int32_t B, float *loss_sum, void *stream)
+{
+    SPEX_CHECK_ARG(s && s->graph && s->E0 && s->mE && s->vE && s->W && s->mW && s->vW && s->all_emb && s->side && s->g_slots
+                       && s->g_side_c && s->g_ego_c && s->gW_parts && s->grad,
+                   "spex_ngcf_step_bce_f32: NULL field in the step descriptor");
+    SPEX_CHECK_ARG(users && items && labels && loss_sum && B >= 1, "spex_ngcf_step_bce_f32: NULL batch pointer or B < 1");
+    const spex_graph *g = s->graph;
+    const int32_t d = 64, n = g->n_rows, n_u = s->n_user_rows;
+    SPEX_CHECK_ARG(g->n_rows == g->n_cols && n_u >= 0 && n_u <= n, "spex_ngcf_step_bce_f32: square graph, 0 <= n_user_rows <= N");
+    SPEX_CHECK_ARG(s->slot_capacity >= 2 * B, "spex_ngcf_step_bce_f32: slot capacity %d < 2 B = %d", s->slot_capacity, 2 * B);
+    SPEX_CHECK_ARG(g->mask_mode == 0, "spex_ngcf_step_bce_f32: edge dropout does not apply to NGCF");
+    const float *W_gc = s->W, *b_gc = s->W + d * d, *W_bi = s->W + d * d + d, *b_bi = s->W + 2 * d * d + d;
+    const int32_t per = 2 * (d * d + d);
+    const uint32_t step = (uint32_t)s->dropout_step;
+    // ---- forward: side = A ego; the fused layer writes [ego | normalised layer output] into the concatenated table
+    SPEX_TRY(spex_spmm_f32(g, s->E0, s->side, nullptr, 1.0f, nullptr, nullptr, 1.0f, d, stream));
+    SPEX_TRY(spex_ngcf_layer_fwd_f32(s->E0, s->side, W_gc, b_gc, W_bi, b_bi, s->all_emb, 2 * d, 1, nullptr, n, d, s->slope, s->p_drop,
+                                     s->seed, step, 0, s->pad_row, stream));
+    // ---- scoring: loss + the batch's per-sample gradient rows [2B, 2d]
+    SPEX_TRY(spex_score_bce_slots_f32(s->all_emb, s->all_emb + (size_t)n_u * 2 * d, 2 * d, 2 * d, n_u, n - n_u, users, items, labels, B,
+                                      2 * d, loss_sum, nullptr, nullptr, 1.0f / (float)B, s->g_slots, 2 * d, stream));
+    // ---- backward on the batch's slots, then the push-form A^T product into the (all-zero) table gradient
+    SPEX_TRY(spex_ngcf_layer_bwd_rows_f32(s->E0, s->side, W_gc, b_gc, W_bi, b_bi, s->g_slots + d, 2 * d, nullptr, s->g_slots, 2 * d, n, d,
+                                          s->slope, s->p_drop, s->seed, step, 0, s->pad_row, users, B, 0, items, B, n_u, s->g_side_c,
+                                          s->g_ego_c, s->gW_parts, per, stream));
+    SPEX_TRY(spex_spmm_push_batch_f32(g, users, B, 0, items, B, n_u, s->g_side_c, d, s->g_ego_c, d, 1.0f, s->grad, d, stream));
+    // ---- Adam: the table (its pass clears the gradient again), the layer weights (their pass sums the partial blocks)
+    s->t += 1;
+    if (s->p_drop > 0.0f) s->dropout_step += 1;
+    SPEX_TRY(spex_adam_step_f32(s->E0, s->grad, s->mE, s->vE, (int64_t)n * d, s->t, s->lr, s->beta1, s->beta2, s->eps, s->grad, stream));
+    SPEX_TRY(spex_adam_step_sum_f32(s->W, s->gW_parts, spex_ngcf_layer_bwd_rows_parts(2 * B), per, s->mW, s->vW, per, s->t, s->lr,
+                                    s->beta1, s->beta2, s->eps, stream));
+    return SPEX_OK;
+}

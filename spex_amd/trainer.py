@@ -272,6 +272,8 @@ class NGCFStepper:
         stepper's own running buffer) and returns it."""
         m, L = self.model, self.L
         acc = self.loss_acc if loss_acc is None else loss_acc
+        if L == 1 and self._one_call_ok(users, items, labels):
+            return self._step_one_call(users, items, labels, acc)
         drop = None
         if any(p > 0 for p in m.mess_dropout):
             drop = (m.mess_dropout, m.message_dropout_seed, m.dropout_step)
@@ -325,6 +327,47 @@ class NGCFStepper:
             ops.adam_step(self.W[:lo], self.gW[:lo], self.mW[:lo], self.vW[:lo], self.t, self.lr, b1, b2, self.eps, zero=self.gW[:lo])
             self.g_all.zero_()
         return acc
+
+
+def _ngcf_one_call_ok(users, items, labels):
+    return (users.is_cuda and items.is_cuda and labels.is_cuda and users.dtype == torch.int64 and items.dtype == torch.int64
+            and labels.dtype == torch.float32 and users.is_contiguous() and items.is_contiguous() and labels.is_contiguous()
+            and users.numel() == items.numel() == labels.numel() and users.numel() >= 1)
+
+
+def _ngcf_step_one_call(self, users, items, labels, acc):
+    """The single-layer step as one library call (spex_ngcf_step_bce_f32): the same launches, issued from native code."""
+    import ctypes
+    from . import _lib
+    from .graph import _bump, _launch
+    m = self.model
+    B = users.numel()
+    if self.g_side_c is None or self.g_side_c.shape[0] < 2 * B:
+        dev, d = self.E0.device, self.E0.shape[1]
+        self.g_slots = torch.zeros((2 * B, 2 * d), dtype=torch.float32, device=dev)
+        self.g_side_c = torch.zeros((2 * B, d), dtype=torch.float32, device=dev)
+        self.g_ego_c = torch.zeros_like(self.g_side_c)
+        self.gW_parts = torch.zeros((ops.ngcf_bwd_rows_parts(2 * B), 2 * (d * d + d)), dtype=torch.float32, device=dev)
+        self._desc = None
+    if getattr(self, "_desc", None) is None:
+        p = lambda t: t.data_ptr()
+        self._desc = _lib.NGCFStepDesc(
+            graph=m.graph._h.value, E0=p(self.E0), mE=p(self.mE), vE=p(self.vE), W=p(self.W), mW=p(self.mW), vW=p(self.vW),
+            all_emb=p(self.all_emb), side=p(self.sides[0]), g_slots=p(self.g_slots), g_side_c=p(self.g_side_c),
+            g_ego_c=p(self.g_ego_c), gW_parts=p(self.gW_parts), grad=p(self.g_next[0]), slot_capacity=self.g_slots.shape[0],
+            n_user_rows=self.n_u, pad_row=m.n_users, slope=0.01, p_drop=float(m.mess_dropout[0]), seed=int(m.message_dropout_seed),
+            dropout_step=m.dropout_step, t=self.t, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps)
+    d = self._desc
+    d.t, d.lr, d.dropout_step, d.seed, d.p_drop = self.t, self.lr, m.dropout_step, int(m.message_dropout_seed), float(m.mess_dropout[0])
+    _launch(self.E0.device, "spex_ngcf_step_bce_f32", ctypes.byref(d), ctypes.c_void_p(users.data_ptr()),
+            ctypes.c_void_p(items.data_ptr()), ctypes.c_void_p(labels.data_ptr()), B, ctypes.c_void_p(acc.data_ptr()))
+    self.t, m.dropout_step = d.t, d.dropout_step
+    _bump(self.E0, self.W, acc)
+    return acc
+
+
+NGCFStepper._one_call_ok = staticmethod(_ngcf_one_call_ok)
+NGCFStepper._step_one_call = _ngcf_step_one_call
 
 
 def train_epoch_ngcf(stepper, data, batch_size=None, pause_gc=True):
