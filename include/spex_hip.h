@@ -391,6 +391,38 @@ int spex_path_attention_bwd_f32(const float *src, int64_t n_src_rows, const int6
                                 const float *a, int32_t B, int32_t L, int32_t d, int32_t n_heads, int32_t positional,
                                 const float *w0, const float *grad_out, float *grad_src, float *grad_a, void *stream);
 
+/* ------------------------------------------------------------------------------------------------ trust head
+ * The whole trust branch of the dual-task model as three launches — replaces LightGCN_SPEX/code/utility1/model_expert_s.py
+ * :170-192 (forward, flag 0 / 2): the in_att heads and out_att (utility2/layers.py:15-71), `mul_seq @ w` + ELU (:181-183),
+ * compute_scores (:128-148: soft-attention readout, linear_transform, max-pool, att_t gate, logits against the user table)
+ * and nn.CrossEntropyLoss (:192) with their gradients.  Hidden size must be 64; L <= 16 positions, n_heads <= 4.
+ *
+ * params / grad_params: ONE flat fp32 block, in this order (d = 64, H = n_heads; spex_trust_param_count gives the total):
+ *   attention_0.a .. attention_{H-1}.a [H][2d] | out_att.a [2d] | w [H d, d] | linear_one.weight [d, d] | .bias [d] |
+ *   linear_two.weight [d, d] | .bias [d] | linear_three.weight [d] | linear_transform.weight [d, 2d] | .bias [d] | att_t [2d, 2]
+ * table: the user table incl. its pad row ([n_rows, 64]); seq: [B, L] int64 user ids padded with the pad row; seq_l: [B].
+ *
+ * spex_trust_head_fwd_f32: a2_out [B, 64] = the vector whose product with the user table gives the logits (:146-147);
+ *   ws (optional; spex_trust_workspace_floats(B, L, 64, H) floats) keeps what the backward needs.  hybrid = !nonhybrid.
+ * spex_trust_ce_f32: logits = a2 . table[0:n_users]^T (n_users = n_rows - 1: `b = table[:-1]`), loss = mean_b CE(logits_b,
+ *   targets_b) -> *loss_out (added to it if loss_accumulate; may be NULL); dscore [B, n_users] and loss_b [B] are scratch;
+ *   grad_a2 [B, 64] is written; grad_table [>= n_users, 64] += d loss / d table through the logits.  Gradients are scaled
+ *   by scale * (*scale_dev if scale_dev else 1) — the multi-task precision exp(-2 s) of main_auto_expert_s.py:81-82 read
+ *   on the device.
+ * spex_trust_head_bwd_f32: grad_params (flat block) and grad_table rows are ACCUMULATED with atomics — zero them first.
+ */
+int64_t spex_trust_param_count(int32_t d, int32_t n_heads);                                /* -1: unsupported shape */
+int64_t spex_trust_workspace_floats(int32_t B, int32_t L, int32_t d, int32_t n_heads);     /* -1: unsupported shape */
+int spex_trust_head_fwd_f32(const float *table, int64_t n_rows, const float *params, const int64_t *seq, const int64_t *seq_l,
+                            int32_t B, int32_t L, int32_t d, int32_t n_heads, int32_t hybrid, float *a2_out, float *ws,
+                            void *stream);
+int spex_trust_ce_f32(const float *table, int32_t n_users, const float *a2, const int64_t *targets, int32_t B, int32_t d,
+                      float scale, const float *scale_dev, float *dscore, float *loss_b, float *loss_out,
+                      int32_t loss_accumulate, float *grad_a2, float *grad_table, void *stream);
+int spex_trust_head_bwd_f32(const float *table, int64_t n_rows, const float *params, const int64_t *seq, const int64_t *seq_l,
+                            int32_t B, int32_t L, int32_t d, int32_t n_heads, int32_t hybrid, const float *ws,
+                            const float *grad_a2, float *grad_params, float *grad_table, void *stream);
+
 /* ------------------------------------------------------------------------------------------------ one-call training step
  * The exact reference training step — LightGCN_SPEX/code/main_rec.py:32-37: forward (model.py:111-121), BCE,
  * loss.backward(), optimizer.step() — as ONE call that issues the library's own launches back to back:

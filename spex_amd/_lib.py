@@ -71,6 +71,13 @@ SIGNATURES = {
                                                c_vp]),
     "spex_path_attention_bwd_f32": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp,
                                                    c_vp, c_vp, c_vp, c_vp]),
+    "spex_trust_param_count": (ctypes.c_int64, [c_i32, c_i32]),
+    "spex_trust_workspace_floats": (ctypes.c_int64, [c_i32, c_i32, c_i32, c_i32]),
+    "spex_trust_head_fwd_f32": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "spex_trust_ce_f32": (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp,
+                                         c_vp]),
+    "spex_trust_head_bwd_f32": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp,
+                                               c_vp, c_vp]),
     "spex_lightgcn_step_bce_f32": (ctypes.c_int, [ctypes.c_void_p, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "spex_ngcf_step_bce_f32": (ctypes.c_int, [ctypes.c_void_p, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "spex_timer_create": (ctypes.c_int, [c_i32, c_i32, ctypes.POINTER(c_vp)]),

@@ -127,8 +127,7 @@ class PartitionedDualTask(nn.Module):
         ar = torch.arange(B, device=dev)
         loss1 = self.k.ScoreBCELoss.apply(rows, B, ar, ar, labels.to(device=dev, dtype=torch.float32))
         inputs, mask, targets = trust_data.get_slice(slice_indices)
-        scores = c._trust_scores(inputs, mask, user_table=user_table)
-        loss2 = c.loss_function(scores, torch.as_tensor(np.asarray(targets), device=scores.device).long())
+        loss2 = c.trust_loss(inputs, mask, targets, user_table=user_table)
         return loss1, loss2
 
     def reduce_gate_gradients(self):

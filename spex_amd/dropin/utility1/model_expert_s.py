@@ -120,6 +120,30 @@ class LightGCN(_RecLightGCN):
         a = p_a * att[:, 0].unsqueeze(1) + p_maxpool * att[:, 1].unsqueeze(1)
         return a @ b.t()
 
+    def _trust_param_tensors(self):
+        """The trust head's parameters in the order of the fused kernels' flat block (include/spex_hip.h, trust head)."""
+        return ([att.a for att in self.in_att]
+                + [self.out_att.a, self.w, self.linear_one.weight, self.linear_one.bias, self.linear_two.weight,
+                   self.linear_two.bias, self.linear_three.weight, self.linear_transform.weight, self.linear_transform.bias,
+                   self.att_t])
+
+    def _trust_fused_ok(self, width):
+        return ops.trust_head_supported(self.hidden_size, width, len(self.in_att)) and self.latent_dim == self.hidden_size
+
+    def trust_loss(self, inputs, mask, targets, user_table=None):
+        """flag 0's second output (:176-192): mean cross-entropy of the trust logits.  With hidden size 64 the whole branch,
+        forward and backward, is four launches (ops.TrustHeadLoss); other shapes take the layer-by-layer path."""
+        table = self.embedding_user.weight if user_table is None else user_table
+        inputs, mask = np.asarray(inputs), np.asarray(mask)
+        if not self._trust_fused_ok(inputs.shape[1]):
+            scores = self._trust_scores(inputs, mask, user_table)
+            return self.loss_function(scores, torch.as_tensor(np.asarray(targets), device=scores.device).long())
+        params = torch.cat([t.reshape(-1) for t in self._trust_param_tensors()])
+        return ops.TrustHeadLoss.apply(table, params, torch.from_numpy(inputs.astype(np.int64)),
+                                       torch.from_numpy(mask.sum(1).astype(np.int64)),
+                                       torch.from_numpy(np.asarray(targets).astype(np.int64)), len(self.in_att),
+                                       not self.nonhybrid)
+
     def _trust_scores(self, inputs, mask, user_table=None):
         emb = self.embedding_user.weight if user_table is None else user_table
         dev = emb.device
@@ -148,8 +172,8 @@ class LightGCN(_RecLightGCN):
                 inputs, mask, targets = trust_data.get_slice(slice_indices)
             else:
                 inputs, mask, targets, negs = trust_data.get_slice(slice_indices)
-            scores = self._trust_scores(inputs, mask)
             if flag == 2:
+                scores = self._trust_scores(inputs, mask)
                 return scores, torch.as_tensor(np.asarray(negs), device=scores.device).long()
-            loss2 = self.loss_function(scores, torch.as_tensor(np.asarray(targets), device=scores.device).long())
+            loss2 = self.trust_loss(inputs, mask, targets)
         return loss1, loss2

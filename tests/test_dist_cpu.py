@@ -308,6 +308,7 @@ def _install_cpu_path_attention():
     from oracle import trust_oracle
     from spex_amd import ops
     import utility2.layers as layers
+    ops.trust_head_supported = lambda d, L, n_heads: False          # the fused trust head is HIP-only: layer-by-layer form here
     ops.path_attention = lambda src, seq, seq_l, a, positional: torch.cat(
         [trust_oracle.path_attention(src, seq, seq_l, a[h], True) for h in range(a.shape[0])], dim=2)
     layers.GraphAttentionLayer.forward = lambda self, emb, seq, seq_l: trust_oracle.path_attention(emb, seq, seq_l, self.a, self.concat)

@@ -332,6 +332,60 @@ def test_dual_task_model_matches_reference(data_root, golden):
     assert np.abs(got - g["trust_test5"]).max() <= 1e-9
 
 
+@pytest.mark.parametrize("nonhybrid", [False, True])
+def test_fused_trust_head_matches_the_layer_by_layer_path(data_root, nonhybrid):
+    """The four-launch trust head (spex_trust_head_fwd/ce/bwd) against the same model evaluated layer by layer (attention
+    kernels + torch ops + autograd): loss, every parameter's gradient and the user-table gradient; paths of every length
+    1..L (a full-width path has no padded position for the max-pool's zero), repeated users, repeated targets."""
+    from spex_amd import ops
+    args, dataset, net = _dual_task_model(data_root)
+    net = net.to(DEV)
+    net.nonhybrid = nonhybrid
+    rng = np.random.default_rng(5)
+    n_u, L = dataset.n_users, 7
+    lens = np.r_[np.arange(1, L + 1), rng.integers(1, L + 1, 30)]
+    inputs = np.full((lens.size, L), n_u, dtype=np.int64)
+    for r, l in enumerate(lens):
+        inputs[r, :l] = rng.integers(0, n_u, l)
+    inputs[8, :3] = inputs[8, 0]                                      # the same user at several positions
+    mask = (np.arange(L)[None, :] < lens[:, None]).astype(np.int64)
+    targets = rng.integers(0, n_u, lens.size)
+    with torch.no_grad():                                             # sizeable values so that every branch matters
+        net.embedding_user.weight.mul_(8.0)
+    params = [p for p in net.parameters() if p.requires_grad]
+
+    def run(fused):
+        for p in params:
+            p.grad = None
+        if fused:
+            loss = net.trust_loss(inputs, mask, targets)
+        else:
+            scores = net._trust_scores(inputs, mask)
+            loss = net.loss_function(scores, torch.from_numpy(targets).to(DEV))
+        (loss * 1.7).backward()
+        return loss.item(), {n: (p.grad.clone() if p.grad is not None else None) for n, p in net.named_parameters()}
+
+    assert net._trust_fused_ok(L)
+    l_ref, g_ref = run(False)
+    l_fus, g_fus = run(True)
+    assert abs(l_ref - l_fus) <= 2e-6 * max(1.0, abs(l_ref))
+    checked = 0
+    for name, ref in g_ref.items():
+        if ref is None or not ref.abs().max().item():
+            continue
+        assert g_fus[name] is not None, name
+        assert rel_err(g_fus[name].cpu().numpy(), ref.cpu().numpy()) <= 2e-5, name
+        checked += 1
+    assert checked >= (9 if nonhybrid else 11)
+    # forward-only form (flag 2's scores) through the fused readout
+    with torch.no_grad():
+        flat = torch.cat([t.reshape(-1) for t in net._trust_param_tensors()])
+        a2 = ops.trust_head_forward(net.embedding_user.weight, flat, torch.from_numpy(inputs), torch.from_numpy(lens), len(net.in_att),
+                                    not nonhybrid)
+        scores = net._trust_scores(inputs, mask)
+        assert rel_err((a2 @ net.embedding_user.weight[:-1].t()).cpu().numpy(), scores.cpu().numpy()) <= 2e-5
+
+
 def test_ngcf_model_matches_reference(golden, epinion2):
     """spex_amd.ngcf.NGCF with the reference's weights: forward (fused inference path and autograd path), loss and
     gradients vs G7."""
