@@ -471,6 +471,39 @@ typedef struct spex_ngcf_step {
 int spex_ngcf_step_bce_f32(spex_ngcf_step_t *step, const int64_t *users, const int64_t *items, const float *labels, int32_t B,
                            float *loss_sum, void *stream);
 
+/* The dual-task training step of LightGCN_SPEX/code/main_auto_expert_s.py:63-89 (model_expert_s.LightGCN.forward flag 0 +
+ * uncertainty-weighted loss + loss.backward() + optimizer.step()) as one call issuing 14 launches:
+ *   spex_propagate_f32 -> 2 x spex_expert_gate_f32 -> spex_score_bce_f32 -> 2 x spex_expert_gate_bwd_f32 ->
+ *   spex_propagate_bwd_f32 -> spex_trust_head_fwd_f32 -> spex_trust_ce_f32 -> spex_trust_head_bwd_f32 -> one Adam pass over
+ *   the whole parameter arena, which applies the task precisions exp(-2 s_k) to the two branches' gradients, forms the
+ *   task weights' own gradients (d/ds0 = -2 p1 loss1 + 2 (n_rec + 1) B, d/ds1 = -2 p2 loss2 + T) and clears every
+ *   accumulate-into buffer for the next step.
+ * params / m / v: ONE arena (and its two Adam moments), N = graph rows, P = spex_trust_param_count(64, n_heads):
+ *   [ table N*64 (users incl. pad row, then items) | trust block P | att_exp1 256 | att_exp2 256 | task_weights 2 ]
+ * Work buffers (caller-owned): light, mixed, g_mixed, g_raw, g_prop, g_E0: [N, 64]; ws_fwd [2, N, 64]; ws_bwd [3, N, 64];
+ *   g_user [n_user_rows, 64]; g_small [P + 512]; a2, g_a2 [path_capacity, 64]; trust_ws
+ *   [spex_trust_workspace_floats(path_capacity, path_len, 64, n_heads)]; dscore [path_capacity, n_user_rows - 1];
+ *   loss_b [path_capacity]; loss [2], loss_acc [2], precision [2][2].
+ * Before the first call: g_mixed, g_user, g_small, loss all-zero (every call leaves them so); precision[(t + 1) & 1] =
+ * {exp(-2 s0), exp(-2 s1)} for the current task weights (every call writes the next step's slot).  loss_acc accumulates
+ * (loss1, loss2) of every call — what Train() sums with .item() per step.  t is advanced by the call.
+ * seq: [T, path_len] int64 padded with the pad row's index n_user_rows - 1; T == 0 skips the trust branch (the reference
+ * would produce NaN there: CrossEntropyLoss over an empty batch).
+ */
+typedef struct spex_dual_task_step {
+    const spex_graph_t *graph, *graph_t;
+    float *params, *m, *v;
+    float *light, *ws_fwd, *mixed, *g_mixed, *g_raw, *g_prop, *g_E0, *ws_bwd;
+    float *g_user, *g_small;
+    float *a2, *trust_ws, *dscore, *loss_b, *g_a2;
+    float *loss, *loss_acc, *precision;
+    int32_t path_capacity, path_len, n_user_rows, L, d, n_heads, hybrid, n_rec;
+    float lr, beta1, beta2, eps;
+    int32_t t;
+} spex_dual_task_step_t;
+int spex_dual_task_step_f32(spex_dual_task_step_t *step, const int64_t *users, const int64_t *items, const float *labels, int32_t B,
+                            const int64_t *seq, const int64_t *seq_l, const int64_t *targets, int32_t T, void *stream);
+
 /* ------------------------------------------------------------------------------------------------ profiling hook
  * Not part of any reference interface: lets a caller time the dominant kernel itself, in place, on the stream it is
  * launched on (bench.py's roofline figure).  While a timer is attached to a graph, every (or every n-th) call of

@@ -80,6 +80,7 @@ SIGNATURES = {
                                                c_vp, c_vp]),
     "spex_lightgcn_step_bce_f32": (ctypes.c_int, [ctypes.c_void_p, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "spex_ngcf_step_bce_f32": (ctypes.c_int, [ctypes.c_void_p, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
+    "spex_dual_task_step_f32": (ctypes.c_int, [ctypes.c_void_p, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "spex_timer_create": (ctypes.c_int, [c_i32, c_i32, ctypes.POINTER(c_vp)]),
     "spex_timer_destroy": (ctypes.c_int, [c_vp]),
     "spex_timer_attach": (ctypes.c_int, [c_vp, c_vp]),
@@ -103,6 +104,15 @@ class NGCFStepDesc(ctypes.Structure):
                 + [(n, c_i32) for n in ("slot_capacity", "n_user_rows", "pad_row")] + [("slope", c_f32), ("p_drop", c_f32)]
                 + [("seed", ctypes.c_uint64), ("dropout_step", c_i32), ("t", c_i32)]
                 + [(n, c_f32) for n in ("lr", "beta1", "beta2", "eps")])
+
+
+class DualTaskStepDesc(ctypes.Structure):
+    """spex_dual_task_step_t (include/spex_hip.h)."""
+    _fields_ = ([(n, c_vp) for n in ("graph", "graph_t", "params", "m", "v", "light", "ws_fwd", "mixed", "g_mixed", "g_raw", "g_prop",
+                                     "g_E0", "ws_bwd", "g_user", "g_small", "a2", "trust_ws", "dscore", "loss_b", "g_a2", "loss",
+                                     "loss_acc", "precision")]
+                + [(n, c_i32) for n in ("path_capacity", "path_len", "n_user_rows", "L", "d", "n_heads", "hybrid", "n_rec")]
+                + [(n, c_f32) for n in ("lr", "beta1", "beta2", "eps")] + [("t", c_i32)])
 
 
 _lib = None

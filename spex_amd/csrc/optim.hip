@@ -125,3 +125,79 @@ extern "C" int spex_adam_step_sum_f32(float *p, const float *g_parts, int32_t n_
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Adam over the dual-task model's parameter arena (steps.hip, spex_dual_task_step_f32).  The step's loss is
+//   exp(-2 s0) loss1 + exp(-2 s1) loss2 + 2 (n_rec + 1) B s0 + T s1        (main_auto_expert_s.py:78-82, s = task_weights)
+// and both branches' gradients arrive UNSCALED: the precisions are applied here, where the gradient is read anyway —
+//   table:        p1 (g_E0 + g_raw) + p2 g_user (user rows)      trust block: p2 g_small      gate matrices: p1 g_small
+//   task weights: d/ds0 = -2 p1 loss1 + 2 (n_rec + 1) B,  d/ds1 = -2 p2 loss2 + T
+// p1, p2 are read from prec[t & 1] (a snapshot: the thread that updates the task weights writes exp(-2 s_new) into the
+// other slot for the next step, so no thread reads a weight another one is updating).  The same pass clears every
+// accumulate-into buffer of the next step (g_mixed, g_user, g_small, the step's loss cells).
+namespace {
+struct DualAdamArgs {
+    float *p, *m, *v;
+    const float *g_E0, *g_raw;
+    float *g_user, *g_small, *g_mixed;
+    float *loss, *loss_acc, *prec;
+    int64_t n_table, n_user, n_trust, n_total;     // floats: table, user rows of it, trust block, whole arena (excl. padding)
+    int32_t B, T, n_rec, slot;
+    float w1, beta2, w2, bc2_sqrt, eps, step_size;
+};
+
+__global__ __launch_bounds__(256) void dual_task_adam_kernel(const DualAdamArgs a)
+{
+    const float p1 = a.prec[a.slot * 2], p2 = a.prec[a.slot * 2 + 1];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n_gate_end = a.n_table + a.n_trust + 512;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_gate_end; i += stride) {
+        float g;
+        if (i < a.n_table) {
+            g = p1 * (a.g_E0[i] + a.g_raw[i]);
+            if (i < a.n_user) {
+                g = fmaf(p2, a.g_user[i], g);
+                a.g_user[i] = 0.0f;
+            }
+            a.g_mixed[i] = 0.0f;
+        } else {
+            const int64_t j = i - a.n_table;
+            g = (j < a.n_trust ? p2 : p1) * a.g_small[j];
+            a.g_small[j] = 0.0f;
+        }
+        float P = a.p[i], M = a.m[i], V = a.v[i];
+        adam1(P, g, M, V, a.w1, a.beta2, a.w2, a.bc2_sqrt, a.eps, a.step_size);
+        a.p[i] = P; a.m[i] = M; a.v[i] = V;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const float loss1 = a.loss[0] / (float)a.B, loss2 = a.loss[1];
+        const float g[2] = {-2.0f * p1 * loss1 + 2.0f * (float)(a.n_rec + 1) * (float)a.B, -2.0f * p2 * loss2 + (float)a.T};
+        for (int k = 0; k < 2; ++k) {
+            const int64_t i = n_gate_end + k;
+            float P = a.p[i], M = a.m[i], V = a.v[i];
+            adam1(P, g[k], M, V, a.w1, a.beta2, a.w2, a.bc2_sqrt, a.eps, a.step_size);
+            a.p[i] = P; a.m[i] = M; a.v[i] = V;
+            a.prec[(1 - a.slot) * 2 + k] = expf(-2.0f * P);
+        }
+        a.loss_acc[0] += loss1;
+        a.loss_acc[1] += loss2;
+        a.loss[0] = 0.0f;
+        a.loss[1] = 0.0f;
+    }
+}
+}  // namespace
+
+int spex::dual_task_adam(float *p, float *m, float *v, const float *g_E0, const float *g_raw, float *g_user, float *g_small,
+                         float *g_mixed, float *loss, float *loss_acc, float *prec, int64_t n_table, int64_t n_user, int64_t n_trust,
+                         int32_t B, int32_t T, int32_t n_rec, int32_t t, float lr, float beta1, float beta2, float eps, void *stream)
+{
+    const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
+    const DualAdamArgs a{p, m, v, g_E0, g_raw, g_user, g_small, g_mixed, loss, loss_acc, prec, n_table, n_user, n_trust,
+                         n_table + n_trust + 512 + 2, B, T, n_rec, t & 1, 1.0f - beta1, beta2, 1.0f - beta2, (float)sqrt(bc2), eps,
+                         (float)((double)lr / bc1)};
+    int64_t blocks = (n_table + n_trust + 512 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(dual_task_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}

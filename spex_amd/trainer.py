@@ -396,3 +396,165 @@ def train_epoch_ngcf(stepper, data, batch_size=None, pause_gc=True):
         if gc_was_on:
             gc.enable()
     return acc[0, 0] / bs + (acc[1, 0] / (n - n_full) if n_full < n else 0.0)
+
+
+class DualTaskStepper:
+    """The dual-task training step (LightGCN_SPEX/code/main_auto_expert_s.py:63-89: rec branch + trust branch of
+    utility1/model_expert_s.py, uncertainty-weighted loss, backward, torch Adam over every parameter) as ONE library call
+    of 14 launches on pre-allocated buffers (spex_dual_task_step_f32) — no autograd, no allocation, no host
+    synchronisation.  ≈2.7 ms per step through the reference-shaped autograd path in round 1, ≈1.0 ms with the fused
+    trust head under autograd, and the GPU time of the launches here.
+
+    model: a `utility1.model_expert_s.LightGCN` on the GPU (hidden size 64).  Its parameters are re-homed into one flat arena
+    [table | trust block | att_exp1 | att_exp2 | task_weights] and trained IN PLACE, so `model` can be evaluated
+    (rec_test, trust_test5) or saved at any point.  No edge dropout (the one-call step does not support it).
+    path_capacity: the largest number of paths a step may carry (3 x trust_batch_size in the reference driver, :70-71)."""
+
+    def __init__(self, model, path_capacity, path_len, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, n_rec=5):
+        from . import _lib
+        table = model.flat_table()
+        assert table.is_cuda, "DualTaskStepper: the model must be on the GPU (no CPU fallback)"
+        N, d = table.shape
+        n_heads = len(model.in_att)
+        if not ops.trust_head_supported(d, path_len, n_heads) or model.hidden_size != d:
+            raise ValueError(f"DualTaskStepper needs hidden size 64, <= 16 path positions, <= 4 heads (got {d}, {path_len}, {n_heads})")
+        dev = table.device
+        self.model, self.dev = model, dev
+        self.N, self.d, self.n_u, self.L = N, d, model.num_users + 1, model.n_layers
+        self.path_capacity, self.path_len, self.n_heads = int(path_capacity), int(path_len), n_heads
+        self.lr, self.betas, self.eps, self.n_rec = lr, betas, eps, n_rec
+        P = ops.trust_param_count(n_heads, d)
+        self.n_trust = P
+        total = N * d + P + 512 + 4
+        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+        self.arena, self.m, self.v = z(total), z(total), z(total)
+        # ---- re-home every parameter into the arena (same values, same Parameter objects)
+        off = 0
+
+        def place(param, n):
+            nonlocal off
+            view = self.arena[off: off + n].view(param.shape)
+            view.copy_(param.data)
+            param.data = view
+            off += n
+
+        u, i = model.embedding_user.weight, model.embedding_item.weight
+        place(u, u.numel()); place(i, i.numel())
+        assert off == N * d
+        for t in model._trust_param_tensors():
+            place(t, t.numel())
+        assert off == N * d + P
+        place(model.att_exp1, 256); place(model.att_exp2, 256); place(model.task_weights, 2)
+        model._cache = None
+        # ---- work buffers
+        self.light, self.mixed, self.g_mixed = z(N, d), z(N, d), z(N, d)
+        self.g_raw, self.g_prop, self.g_E0 = z(N, d), z(N, d), z(N, d)
+        self.ws_fwd, self.ws_bwd = z(2, N, d), z(3, N, d)
+        self.g_user, self.g_small = z(self.n_u, d), z(P + 512)
+        T = self.path_capacity
+        self.a2, self.g_a2 = z(T, d), z(T, d)
+        self.trust_ws = z(max(1, int(_lib.load().spex_trust_workspace_floats(T, self.path_len, d, n_heads))))
+        self.dscore, self.loss_b = z(T, self.n_u - 1), z(T)
+        self.loss, self.loss_acc, self.precision = z(2), z(2), z(2, 2)
+        self.t = 0
+        self._desc = None
+        self._graph_t = model.Graph            # the LightGCN adjacency is symmetric
+        self.refresh_precision()
+
+    def refresh_precision(self):
+        """Call after changing task_weights from outside the stepper (the step keeps exp(-2 s) snapshots on the device)."""
+        self.precision[(self.t + 1) & 1] = torch.exp(-2.0 * self.model.task_weights.detach())
+
+    def step(self, users, items, labels, seq, seq_l, targets):
+        """One training step.  users / items: device int64 [B]; labels: device fp32 [B]; seq: device int64 [T, path_len]
+        padded with the pad row index; seq_l, targets: device int64 [T].  Both losses are added to `loss_acc`."""
+        import ctypes
+        from . import _lib
+        from .graph import _bump, _launch
+        B, T = users.numel(), (0 if seq is None else seq.shape[0])
+        for t, dt in ((users, torch.int64), (items, torch.int64), (labels, torch.float32)):
+            if not (t.is_cuda and t.dtype == dt and t.is_contiguous() and t.numel() == B):
+                raise ValueError("DualTaskStepper.step: users / items (int64) and labels (fp32) must be contiguous device tensors of one length")
+        if T:
+            for t in (seq, seq_l, targets):
+                if not (t.is_cuda and t.dtype == torch.int64 and t.is_contiguous()):
+                    raise ValueError("DualTaskStepper.step: seq / seq_l / targets must be contiguous device int64 tensors")
+            if seq.shape[1] != self.path_len or seq_l.numel() != T or targets.numel() != T or T > self.path_capacity:
+                raise ValueError(f"DualTaskStepper.step: {T} paths of width {seq.shape[1]} (capacity {self.path_capacity} x {self.path_len})")
+        if getattr(self.model.Graph, "mask_mode", 0) != 0:
+            raise ValueError("DualTaskStepper.step: edge dropout is not supported in the one-call step")
+        if self._desc is None:
+            p = lambda t: t.data_ptr()
+            self._desc = _lib.DualTaskStepDesc(
+                graph=self.model.Graph._h.value, graph_t=self._graph_t._h.value, params=p(self.arena), m=p(self.m), v=p(self.v),
+                light=p(self.light), ws_fwd=p(self.ws_fwd), mixed=p(self.mixed), g_mixed=p(self.g_mixed), g_raw=p(self.g_raw),
+                g_prop=p(self.g_prop), g_E0=p(self.g_E0), ws_bwd=p(self.ws_bwd), g_user=p(self.g_user), g_small=p(self.g_small),
+                a2=p(self.a2), trust_ws=p(self.trust_ws), dscore=p(self.dscore), loss_b=p(self.loss_b), g_a2=p(self.g_a2),
+                loss=p(self.loss), loss_acc=p(self.loss_acc), precision=p(self.precision), path_capacity=self.path_capacity,
+                path_len=self.path_len, n_user_rows=self.n_u, L=self.L, d=self.d, n_heads=self.n_heads,
+                hybrid=0 if self.model.nonhybrid else 1, n_rec=self.n_rec, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
+                eps=self.eps, t=self.t)
+        dsc = self._desc
+        dsc.t, dsc.lr = self.t, self.lr
+        vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() else None
+        _launch(self.dev, "spex_dual_task_step_f32", ctypes.byref(dsc), vp(users), vp(items), vp(labels), B,
+                vp(seq) if T else None, vp(seq_l) if T else None, vp(targets) if T else None, T)
+        self.t = dsc.t
+        _bump(self.arena, self.m, self.v, self.loss_acc)
+        self.model._cache = None
+
+
+def dual_task_epoch_paths(batch_users, by_user, cap):
+    """The per-batch path selection of main_auto_expert_s.py:64-71, batch by batch in order: every path starting at one
+    of the batch's users, cut to `cap` paths with random.sample (Python's global `random`, like the reference).  Returns the
+    chosen path indices of every batch."""
+    import random
+    chosen_all = []
+    for users in batch_users:
+        chosen = []
+        for u in set(users.tolist()):
+            chosen.extend(by_user[u])
+        if len(chosen) > cap:
+            chosen = random.sample(chosen, cap)
+        chosen_all.append(chosen)
+    return chosen_all
+
+
+def train_epoch_dual(stepper, train_data, trust_data, by_user, cap, batch_size=256, resample=True, pause_gc=True, max_steps=None):
+    """Train() of main_auto_expert_s.py:53-91 on the device: negatives drawn like the reference's (`ng_sample`), the
+    epoch's sample order is the shuffled DataLoader's own, the per-batch paths are chosen by the reference's rule
+    (dual_task_epoch_paths), everything is moved to the device once and every batch is one DualTaskStepper.step.
+    Returns (sum of loss1, sum of loss2) over the epoch's steps as a device tensor."""
+    import numpy as np
+    if resample:
+        train_data.ng_sample()
+    n = len(train_data)
+    order = dataloader_epoch_order(n).numpy()
+    dev = stepper.dev
+    users_h = train_data.users_fill[order]
+    starts = list(range(0, n, batch_size))
+    if max_steps is not None:
+        starts = starts[:max_steps]
+    chosen = dual_task_epoch_paths([users_h[s:s + batch_size] for s in starts], by_user, cap)
+    flat = np.fromiter((k for c in chosen for k in c), dtype=np.int64, count=sum(len(c) for c in chosen))
+    inputs, mask, targets = trust_data.get_slice(flat)
+    seq = torch.from_numpy(np.ascontiguousarray(inputs, dtype=np.int64)).to(dev)
+    seq_l = torch.from_numpy(np.asarray(mask).sum(1).astype(np.int64)).to(dev)
+    tgt = torch.from_numpy(np.asarray(targets).astype(np.int64)).to(dev)
+    users = torch.from_numpy(users_h).to(dev)
+    items = torch.from_numpy(train_data.items_fill[order]).to(dev)
+    labels = torch.from_numpy(train_data.labels_fill_np[order]).to(device=dev, dtype=torch.float32)
+    stepper.loss_acc.zero_()
+    gc_was_on = pause_gc and gc.isenabled()
+    if gc_was_on:
+        gc.disable()
+    try:
+        p0 = 0
+        for s, c in zip(starts, chosen):
+            e, p1 = min(s + batch_size, n), p0 + len(c)
+            stepper.step(users[s:e], items[s:e], labels[s:e], seq[p0:p1] if c else None, seq_l[p0:p1], tgt[p0:p1])
+            p0 = p1
+    finally:
+        if gc_was_on:
+            gc.enable()
+    return stepper.loss_acc.clone()

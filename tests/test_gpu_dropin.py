@@ -716,3 +716,84 @@ def test_dual_task_training_run_matches_the_reference_epinion2(data_root, golden
     uw, iw = net.embedding_user.weight.detach().cpu().numpy(), net.embedding_item.weight.detach().cpu().numpy()
     assert rel_err(uw[g["rows_u"]], g["user_w"]) <= 2e-4 and rel_err(iw[g["rows_i"]], g["item_w"]) <= 2e-4
     assert rel_err(net.w.detach().cpu().numpy(), g["w"]) <= 2e-4
+
+
+def test_dual_task_one_call_step_matches_the_autograd_step(data_root, golden):
+    """spex_dual_task_step_f32 (DualTaskStepper: 14 launches, one library call) against the same step taken through the
+    drop-in model with autograd and torch.optim.Adam: three steps on the tiny graph with the G11 batch and paths — every
+    parameter (tables, ~15 trust-head tensors, gate matrices, task weights) and both losses."""
+    from utility2.utils import Data
+    from spex_amd.trainer import DualTaskStepper
+    g, gl = golden("trust_tiny"), golden("lightgcn_tiny")
+    args, dataset, net = _dual_task_model(data_root)
+    _, _, ref = _dual_task_model(data_root)                         # the same seed: the same initial parameters
+    net, ref = net.to(DEV), ref.to(DEV)
+    lens = g["train_mask"].sum(1)
+    train = Data(([r[:l].tolist() for r, l in zip(g["train_inputs"], lens)], g["train_targets"].tolist()), 50)
+    sl = np.asarray(g["slice_indices"])
+    inputs, mask, targets = train.get_slice(sl)
+    bu, bi, bl = (torch.from_numpy(gl[k][0]).to(DEV) for k in ("batch_users", "batch_items", "batch_labels"))
+    opt = torch.optim.Adam(ref.parameters(), lr=args.lr)
+    st = DualTaskStepper(net, path_capacity=len(sl), path_len=inputs.shape[1], lr=args.lr)
+    seq, seq_l, tgt = (torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64)).to(DEV) for a in (inputs, mask.sum(1), targets))
+    ref.train()
+    want = []
+    for step in range(3):
+        opt.zero_grad()
+        l1, l2 = ref(bu, bi, bl, sl, train, flag=0)
+        w = ref.task_weights
+        (torch.exp(-2 * w[0]) * l1 + torch.exp(-2 * w[1]) * l2 + 2 * 6 * bu.numel() * w[0] + len(sl) * w[1]).backward()
+        opt.step()
+        want.append((l1.item(), l2.item()))
+        st.loss_acc.zero_()
+        st.step(bu, bi, bl.float(), seq, seq_l, tgt)
+        got = st.loss_acc.cpu().numpy()
+        assert abs(got[0] - want[-1][0]) <= 3e-6 and abs(got[1] - want[-1][1]) <= 2e-5, (step, got, want[-1])
+    for (name, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        # Adam's first steps move every touched parameter by ~lr whatever the gradient's size: compare on that scale
+        assert (p.detach() - q.detach()).abs().max().item() <= 0.02 * args.lr * 3, name
+    assert st.t == 3
+    # the module is still the model: evaluation sees the trained values
+    net.eval(); ref.eval()
+    with torch.no_grad():
+        a = net(bu, bi, None, None, None, flag=1)
+        b = ref(bu, bi, None, None, None, flag=1)
+    assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 1e-4
+
+
+def test_dual_task_on_device_epoch_matches_the_reference_epinion2(data_root, golden):
+    """G13 at Epinion2 scale through the on-device epoch loop (trainer.train_epoch_dual + DualTaskStepper): the same 600
+    steps as the reference's run (same negatives, same shuffle, same random.sample path cuts) — running loss sums, the
+    learned task weights, both tasks' metrics and the trained tables."""
+    from collections import defaultdict
+    import utility1.dataloader as dl
+    from utility1.batch_test import rec_test
+    from utility2.batch_test_gnn import trust_test5
+    from utility2.utils import Data
+    from spex_amd.trainer import DualTaskStepper, train_epoch_dual
+    g = golden("dual_epinion2_epochs")
+    raw_train, raw_test = _epinion2_trust_raw(golden)
+    args, dataset, net = _dual_epinion2(data_root)
+    td = dl.LightTrainData(dataset.rec_train_data, dataset.m_item, dataset.train_mat)
+    by_user = defaultdict(list)
+    for k, p in enumerate(raw_train[0]):
+        by_user[p[0]].append(k)
+    train2, test2 = Data(raw_train, dataset.n_users, shuffle=False), Data(raw_test, dataset.n_users, shuffle=False, test=True)
+    cap = 3 * int(g["trust_batch_size"])
+    net = net.to(DEV)
+    st = DualTaskStepper(net, path_capacity=cap, path_len=train2.len_max, lr=args.lr)
+    n_steps = int(g["n_steps"])
+    totals = train_epoch_dual(st, td, train2, by_user, cap, max_steps=n_steps).cpu().numpy()
+    assert st.t == n_steps
+    c = n_steps // 100 - 1
+    assert abs(totals[0] - g["loss1_cum"][c]) <= 5e-5 * g["loss1_cum"][c], (totals, g["loss1_cum"][c])
+    assert abs(totals[1] - g["loss2_cum"][c]) <= 2e-4 * g["loss2_cum"][c], (totals, g["loss2_cum"][c])
+    assert np.abs(net.task_weights.detach().cpu().numpy() - g["task_weights"]).max() <= 5e-5
+    net.eval()
+    with torch.no_grad():
+        ret = rec_test(net, dataset.testRatings, dataset.testNegatives)
+        assert np.abs(ret["recall"] - g["rec_recall"]).max() <= 1e-3 and np.abs(ret["ndcg"] - g["rec_ndcg"]).max() <= 1e-3
+        assert np.abs(np.asarray(trust_test5(net, test2)) - g["trust"]).max() <= 2e-3
+    uw, iw = net.embedding_user.weight.detach().cpu().numpy(), net.embedding_item.weight.detach().cpu().numpy()
+    assert rel_err(uw[g["rows_u"]], g["user_w"]) <= 2e-4 and rel_err(iw[g["rows_i"]], g["item_w"]) <= 2e-4
+    assert rel_err(net.w.detach().cpu().numpy(), g["w"]) <= 2e-4

@@ -18,7 +18,7 @@ targets = rng.integers(0, 3185, 20000).tolist()
 trust = Data((paths, targets), ds.n_users)
 u = torch.from_numpy(rng.integers(0, 3185, 256)); i = torch.from_numpy(rng.integers(0, 12407, 256))
 y = torch.from_numpy((rng.random(256) < 1 / 6).astype(np.int64))
-sl = rng.integers(0, 20000, 300)
+sl = rng.integers(0, 20000, 15)      # the reference driver caps a step at 3 x trust_batch_size = 15 paths
 def step(trust_on):
     opt.zero_grad()
     if trust_on:
@@ -35,3 +35,19 @@ for name, on in (("rec branch only (gate, autograd, torch Adam)", False), ("rec 
     for _ in range(50): step(on)
     torch.cuda.synchronize()
     print("%-48s %.2f ms/step" % (name, (time.perf_counter() - t) / 50 * 1e3))
+
+# the same step as one library call (spex_dual_task_step_f32, trainer.DualTaskStepper): 15 paths per step like the driver's cap
+from spex_amd.trainer import DualTaskStepper
+cap = 15
+st = DualTaskStepper(net, path_capacity=cap, path_len=trust.len_max, lr=1e-3)
+inputs, mask, tg = trust.get_slice(sl[:cap])
+seq = torch.from_numpy(np.ascontiguousarray(inputs, dtype=np.int64)).cuda()
+seq_l = torch.from_numpy(mask.sum(1).astype(np.int64)).cuda()
+tgt = torch.from_numpy(np.asarray(tg).astype(np.int64)).cuda()
+uc, ic, yc = u.cuda(), i.cuda(), y.cuda().float()
+for _ in range(50): st.step(uc, ic, yc, seq, seq_l, tgt)
+torch.cuda.synchronize(); t = time.perf_counter()
+n = 500
+for _ in range(n): st.step(uc, ic, yc, seq, seq_l, tgt)
+torch.cuda.synchronize()
+print("%-48s %.3f ms/step" % ("one-call step (DualTaskStepper), 15 paths", (time.perf_counter() - t) / n * 1e3))
