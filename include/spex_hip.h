@@ -392,36 +392,35 @@ int spex_path_attention_bwd_f32(const float *src, int64_t n_src_rows, const int6
                                 const float *w0, const float *grad_out, float *grad_src, float *grad_a, void *stream);
 
 /* ------------------------------------------------------------------------------------------------ trust head
- * The whole trust branch of the dual-task model as three launches — replaces LightGCN_SPEX/code/utility1/model_expert_s.py
- * :170-192 (forward, flag 0 / 2): the in_att heads and out_att (utility2/layers.py:15-71), `mul_seq @ w` + ELU (:181-183),
- * compute_scores (:128-148: soft-attention readout, linear_transform, max-pool, att_t gate, logits against the user table)
- * and nn.CrossEntropyLoss (:192) with their gradients.  Hidden size must be 64; L <= 16 positions, n_heads <= 4.
+ * The whole trust branch of the dual-task model — replaces LightGCN_SPEX/code/utility1/model_expert_s.py:170-192 (forward,
+ * flag 0 / 2): the in_att heads and out_att (utility2/layers.py:15-71), `mul_seq @ w` + ELU (:181-183), compute_scores
+ * (:128-148: soft-attention readout, linear_transform, max-pool, att_t gate, logits against the user table) and
+ * nn.CrossEntropyLoss (:192) with their gradients.  Hidden size must be 64; L <= 16 positions, n_heads <= 4.
  *
  * params / grad_params: ONE flat fp32 block, in this order (d = 64, H = n_heads; spex_trust_param_count gives the total):
  *   attention_0.a .. attention_{H-1}.a [H][2d] | out_att.a [2d] | w [H d, d] | linear_one.weight [d, d] | .bias [d] |
  *   linear_two.weight [d, d] | .bias [d] | linear_three.weight [d] | linear_transform.weight [d, 2d] | .bias [d] | att_t [2d, 2]
  * table: the user table incl. its pad row ([n_rows, 64]); seq: [B, L] int64 user ids padded with the pad row; seq_l: [B].
+ * hybrid = !nonhybrid (model_expert_s.py:136-141).
  *
- * spex_trust_head_fwd_f32: a2_out [B, 64] = the vector whose product with the user table gives the logits (:146-147);
- *   ws (optional; spex_trust_workspace_floats(B, L, 64, H) floats) keeps what the backward needs.  hybrid = !nonhybrid.
- * spex_trust_ce_f32: logits = a2 . table[0:n_users]^T (n_users = n_rows - 1: `b = table[:-1]`), loss = mean_b CE(logits_b,
- *   targets_b) -> *loss_out (added to it if loss_accumulate; may be NULL); dscore [B, n_users] and loss_b [B] are scratch;
- *   grad_a2 [B, 64] is written; grad_table [>= n_users, 64] += d loss / d table through the logits.  Gradients are scaled
- *   by scale * (*scale_dev if scale_dev else 1) — the multi-task precision exp(-2 s) of main_auto_expert_s.py:81-82 read
- *   on the device.
- * spex_trust_head_bwd_f32: grad_params (flat block) and grad_table rows are ACCUMULATED with atomics — zero them first.
+ * spex_trust_head_fwd_f32 (one launch): a2_out [B, 64] = the vector whose product with the user table gives the logits
+ *   (:146-147) — the evaluation form (flag 2).
+ * spex_trust_head_train_f32 (two launches): forward, logits = a2 . table[0 : n_rows - 1]^T (`b = table[:-1]`), loss =
+ *   mean_b CE(logits_b, targets_b) -> *loss_out (added to it if loss_accumulate; may be NULL), and the whole backward:
+ *   grad_params (flat block) is OVERWRITTEN (one thread per weight sums its contributions in a fixed order: deterministic);
+ *   grad_table [n_rows, 64] is ACCUMULATED (the logits' part by the launch that owns the rows, the paths' own rows with
+ *   atomics) — zero it first or pass the buffer it is to be added to.  Gradients are scaled by scale * (*scale_dev if
+ *   scale_dev else 1) — e.g. the multi-task precision exp(-2 s) of main_auto_expert_s.py:81-82 read on the device.
+ *   Scratch (caller-owned): a2 [B, 64], dscore [B, n_rows - 1], loss_b [B], ws [spex_trust_workspace_floats(B, L, 64, H)].
  */
 int64_t spex_trust_param_count(int32_t d, int32_t n_heads);                                /* -1: unsupported shape */
 int64_t spex_trust_workspace_floats(int32_t B, int32_t L, int32_t d, int32_t n_heads);     /* -1: unsupported shape */
 int spex_trust_head_fwd_f32(const float *table, int64_t n_rows, const float *params, const int64_t *seq, const int64_t *seq_l,
-                            int32_t B, int32_t L, int32_t d, int32_t n_heads, int32_t hybrid, float *a2_out, float *ws,
-                            void *stream);
-int spex_trust_ce_f32(const float *table, int32_t n_users, const float *a2, const int64_t *targets, int32_t B, int32_t d,
-                      float scale, const float *scale_dev, float *dscore, float *loss_b, float *loss_out,
-                      int32_t loss_accumulate, float *grad_a2, float *grad_table, void *stream);
-int spex_trust_head_bwd_f32(const float *table, int64_t n_rows, const float *params, const int64_t *seq, const int64_t *seq_l,
-                            int32_t B, int32_t L, int32_t d, int32_t n_heads, int32_t hybrid, const float *ws,
-                            const float *grad_a2, float *grad_params, float *grad_table, void *stream);
+                            int32_t B, int32_t L, int32_t d, int32_t n_heads, int32_t hybrid, float *a2_out, void *stream);
+int spex_trust_head_train_f32(const float *table, int64_t n_rows, const float *params, const int64_t *seq, const int64_t *seq_l,
+                              const int64_t *targets, int32_t B, int32_t L, int32_t d, int32_t n_heads, int32_t hybrid,
+                              float scale, const float *scale_dev, float *a2, float *dscore, float *loss_b, float *ws,
+                              float *loss_out, int32_t loss_accumulate, float *grad_params, float *grad_table, void *stream);
 
 /* ------------------------------------------------------------------------------------------------ one-call training step
  * The exact reference training step — LightGCN_SPEX/code/main_rec.py:32-37: forward (model.py:111-121), BCE,
@@ -472,16 +471,16 @@ int spex_ngcf_step_bce_f32(spex_ngcf_step_t *step, const int64_t *users, const i
                            float *loss_sum, void *stream);
 
 /* The dual-task training step of LightGCN_SPEX/code/main_auto_expert_s.py:63-89 (model_expert_s.LightGCN.forward flag 0 +
- * uncertainty-weighted loss + loss.backward() + optimizer.step()) as one call issuing 14 launches:
- *   spex_propagate_f32 -> 2 x spex_expert_gate_f32 -> spex_score_bce_f32 -> 2 x spex_expert_gate_bwd_f32 ->
- *   spex_propagate_bwd_f32 -> spex_trust_head_fwd_f32 -> spex_trust_ce_f32 -> spex_trust_head_bwd_f32 -> one Adam pass over
+ * uncertainty-weighted loss + loss.backward() + optimizer.step()) as one call issuing 2 L + 8 launches:
+ *   spex_propagate_f32 (L) -> 2 x spex_expert_gate_f32 -> spex_score_bce_f32 -> 2 x spex_expert_gate_bwd_f32 ->
+ *   spex_propagate_bwd_f32 (L) -> spex_trust_head_train_f32 (2) -> one Adam pass over
  *   the whole parameter arena, which applies the task precisions exp(-2 s_k) to the two branches' gradients, forms the
  *   task weights' own gradients (d/ds0 = -2 p1 loss1 + 2 (n_rec + 1) B, d/ds1 = -2 p2 loss2 + T) and clears every
  *   accumulate-into buffer for the next step.
  * params / m / v: ONE arena (and its two Adam moments), N = graph rows, P = spex_trust_param_count(64, n_heads):
  *   [ table N*64 (users incl. pad row, then items) | trust block P | att_exp1 256 | att_exp2 256 | task_weights 2 ]
  * Work buffers (caller-owned): light, mixed, g_mixed, g_raw, g_prop, g_E0: [N, 64]; ws_fwd [2, N, 64]; ws_bwd [3, N, 64];
- *   g_user [n_user_rows, 64]; g_small [P + 512]; a2, g_a2 [path_capacity, 64]; trust_ws
+ *   g_user [n_user_rows, 64]; g_small [P + 512]; a2 [path_capacity, 64]; trust_ws
  *   [spex_trust_workspace_floats(path_capacity, path_len, 64, n_heads)]; dscore [path_capacity, n_user_rows - 1];
  *   loss_b [path_capacity]; loss [2], loss_acc [2], precision [2][2].
  * Before the first call: g_mixed, g_user, g_small, loss all-zero (every call leaves them so); precision[(t + 1) & 1] =
@@ -495,7 +494,7 @@ typedef struct spex_dual_task_step {
     float *params, *m, *v;
     float *light, *ws_fwd, *mixed, *g_mixed, *g_raw, *g_prop, *g_E0, *ws_bwd;
     float *g_user, *g_small;
-    float *a2, *trust_ws, *dscore, *loss_b, *g_a2;
+    float *a2, *trust_ws, *dscore, *loss_b;
     float *loss, *loss_acc, *precision;
     int32_t path_capacity, path_len, n_user_rows, L, d, n_heads, hybrid, n_rec;
     float lr, beta1, beta2, eps;

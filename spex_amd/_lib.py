@@ -73,11 +73,9 @@ SIGNATURES = {
                                                    c_vp, c_vp, c_vp, c_vp]),
     "spex_trust_param_count": (ctypes.c_int64, [c_i32, c_i32]),
     "spex_trust_workspace_floats": (ctypes.c_int64, [c_i32, c_i32, c_i32, c_i32]),
-    "spex_trust_head_fwd_f32": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
-    "spex_trust_ce_f32": (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp,
-                                         c_vp]),
-    "spex_trust_head_bwd_f32": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp,
-                                               c_vp, c_vp]),
+    "spex_trust_head_fwd_f32": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "spex_trust_head_train_f32": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp,
+                                                 c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "spex_lightgcn_step_bce_f32": (ctypes.c_int, [ctypes.c_void_p, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "spex_ngcf_step_bce_f32": (ctypes.c_int, [ctypes.c_void_p, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "spex_dual_task_step_f32": (ctypes.c_int, [ctypes.c_void_p, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp]),
@@ -109,7 +107,7 @@ class NGCFStepDesc(ctypes.Structure):
 class DualTaskStepDesc(ctypes.Structure):
     """spex_dual_task_step_t (include/spex_hip.h)."""
     _fields_ = ([(n, c_vp) for n in ("graph", "graph_t", "params", "m", "v", "light", "ws_fwd", "mixed", "g_mixed", "g_raw", "g_prop",
-                                     "g_E0", "ws_bwd", "g_user", "g_small", "a2", "trust_ws", "dscore", "loss_b", "g_a2", "loss",
+                                     "g_E0", "ws_bwd", "g_user", "g_small", "a2", "trust_ws", "dscore", "loss_b", "loss",
                                      "loss_acc", "precision")]
                 + [(n, c_i32) for n in ("path_capacity", "path_len", "n_user_rows", "L", "d", "n_heads", "hybrid", "n_rec")]
                 + [(n, c_f32) for n in ("lr", "beta1", "beta2", "eps")] + [("t", c_i32)])

@@ -104,7 +104,7 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
 {
     SPEX_CHECK_ARG(s && s->graph && s->graph_t && s->params && s->m && s->v && s->light && s->ws_fwd && s->mixed && s->g_mixed
                        && s->g_raw && s->g_prop && s->g_E0 && s->ws_bwd && s->g_user && s->g_small && s->a2 && s->trust_ws && s->dscore
-                       && s->loss_b && s->g_a2 && s->loss && s->loss_acc && s->precision,
+                       && s->loss_b && s->loss && s->loss_acc && s->precision,
                    "spex_dual_task_step_f32: NULL field in the step descriptor");
     SPEX_CHECK_ARG(users && items && labels && B >= 1, "spex_dual_task_step_f32: NULL batch pointer or B < 1");
     SPEX_CHECK_ARG(T >= 0 && T <= s->path_capacity && (T == 0 || (seq && seq_l && targets)),
@@ -131,13 +131,9 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
                                       g_att2, N - n_u, d, stream));
     SPEX_TRY(spex_propagate_bwd_f32(gt, s->g_prop, s->g_E0, s->ws_bwd, L, d, stream));
     // ---- trust branch (:170-192) on the raw user table, forward + backward
-    if (T > 0) {
-        SPEX_TRY(spex_trust_head_fwd_f32(E0, n_u, trust_p, seq, seq_l, T, s->path_len, d, H, s->hybrid, s->a2, s->trust_ws, stream));
-        SPEX_TRY(spex_trust_ce_f32(E0, n_u - 1, s->a2, targets, T, d, 1.0f, nullptr, s->dscore, s->loss_b, s->loss + 1, 0, s->g_a2,
-                                   s->g_user, stream));
-        SPEX_TRY(spex_trust_head_bwd_f32(E0, n_u, trust_p, seq, seq_l, T, s->path_len, d, H, s->hybrid, s->trust_ws, s->g_a2, s->g_small,
-                                         s->g_user, stream));
-    }
+    if (T > 0)
+        SPEX_TRY(spex_trust_head_train_f32(E0, n_u, trust_p, seq, seq_l, targets, T, s->path_len, d, H, s->hybrid, 1.0f, nullptr, s->a2,
+                                           s->dscore, s->loss_b, s->trust_ws, s->loss + 1, 0, s->g_small, s->g_user, stream));
     // ---- uncertainty-weighted sum of both losses (main_auto_expert_s.py:78-82) + Adam over every parameter (:89)
     s->t += 1;
     SPEX_TRY(spex::dual_task_adam(s->params, s->m, s->v, s->g_E0, s->g_raw, s->g_user, s->g_small, s->g_mixed, s->loss, s->loss_acc,

@@ -1,6 +1,7 @@
-// The trust head of the dual-task model as three launches (SURVEY.md 8f "next" #1 — the caller on the other side of the
-// shared user table): LightGCN_SPEX/code/utility1/model_expert_s.py:170-192 (`forward`, flag 0/2) with `compute_scores`
-// (:128-148) and the two GraphAttentionLayer stages (utility2/layers.py:15-71), followed by nn.CrossEntropyLoss (:192).
+// The trust head of the dual-task model as TWO launches per training step (SURVEY.md 8f "next" #1 — the caller on the
+// other side of the shared user table): LightGCN_SPEX/code/utility1/model_expert_s.py:170-192 (`forward`, flag 0/2) with
+// `compute_scores` (:128-148) and the two GraphAttentionLayer stages (utility2/layers.py:15-71), followed by
+// nn.CrossEntropyLoss (:192), forward and backward.
 //
 // Per path x_0 .. x_{l-1} (user ids; padded to L with the table's pad row), hidden size 64 == one wavefront, lane == column:
 //   e_i = E[x_i]
@@ -12,11 +13,15 @@
 //   p_a = Wt [a | ht] + bt  (hybrid; else p_a = a);  pm = max_i (e_i * mask_i)  (a padded position contributes 0)   (:136-142)
 //   (g0, g1) = softmax([p_a | pm] @ att_t);  a2 = g0 p_a + g1 pm;  scores = a2 . E[:-1]^T;  loss = mean_b CE(scores_b, target_b)
 // Positions >= l only ever reach masked terms, so they are not evaluated.  In torch this is ~60 small launches forward
-// and ~120 backward per step for <= 15 paths (1.8 ms of a 2.7 ms dual-task step, almost all of it launch latency); here:
-//   trust_head_fwd   one wave per path: everything up to a2 (matrices read straight from L2, vectors staged in LDS)
-//   trust_ce         one workgroup per path: logits against the whole user table, log-sum-exp, loss, d scores (kept in a
-//                    [B, n_users] buffer) and d a2;  then one wave per user row: d E[u] += sum_b d scores[b,u] a2[b]
-//   trust_head_bwd   one wave per path: the chain above backwards; parameter gradients and table rows added with atomics
+// and ~120 backward per step for <= 15 paths (1.8 ms of a 2.7 ms dual-task step, almost all of it launch latency).  Here:
+//   trust_path_kernel   one 8-wave workgroup per path.  Wave 0 runs the forward chain (vectors in LDS, matrices read
+//                       straight from L2 in batches of independent loads); all 8 waves take the logits against the
+//                       whole user table (16 lanes per 256-byte row), the log-sum-exp, the loss, d scores (left in a
+//                       [B, n_users] buffer) and d a2; wave 0 runs the chain backwards, adds the path's table rows with
+//                       atomics and leaves the operands of every weight gradient in a per-path workspace.
+//   trust_reduce_kernel d E[u] += sum_b d scores[b,u] a2[b] (one wave per user row), every weight gradient as a small
+//                       [rows, 64]^T [rows, 64] product over the workspaces (one thread per weight, no atomics,
+//                       deterministic), the bias / vector gradients, the mean loss.
 // All parameters live in ONE flat block (layout below) so that a step's gradients are one buffer and one Adam launch.
 #include <math.h>
 
@@ -29,7 +34,8 @@ namespace {
 constexpr int kD = 64;        // hidden size: one lane per column
 constexpr int kMaxL = 16;     // longest padded path
 constexpr int kMaxH = 4;      // input attention heads
-constexpr int kCeThreads = 1024;
+constexpr int kPathWaves = 8;       // 512 threads: two waves per SIMD, so the chain waves keep 256 VGPRs (two staged weight rows)
+constexpr int kPathThreads = kPathWaves * kWave;
 
 struct Layout {
     int in_att, out_att, w, W1, b1, W2, b2, w3, Wt, bt, att_t, total;
@@ -54,27 +60,23 @@ __host__ __device__ inline Layout layout(int H)
     return o;
 }
 
-// per-path workspace written by the forward for the backward (floats)
+// Per-path workspace: the operands of the weight gradients, written by the path kernel, read by the reduce kernel.
+//   vectors (64 floats each): dq1, ht, a, dpa, pa*dt0, pm*dt0, dw3, dc2, da2h[H];  rows (per position i < l): h_i, du_i, dr_i, M_i
 struct WsLayout {
-    int w0, v0, alpha, r, h, s, a, pa, pm, arg, g0, stride;
+    int dq1, ht, a, dpa, vpa, vpm, dw3, dc2, da2h, Hm, DU, DR, M, stride;
 };
 
 __host__ __device__ inline WsLayout ws_layout(int L, int H)
 {
     WsLayout o;
     int p = 0;
-    o.w0 = p;    p += L * H;
-    o.v0 = p;    p += L;
-    o.alpha = p; p += L;
-    o.g0 = p;    p += 1;
-    p = (p + 63) / 64 * 64;
-    o.r = p;     p += L * kD;
-    o.h = p;     p += L * kD;
-    o.s = p;     p += L * kD;
-    o.a = p;     p += kD;
-    o.pa = p;    p += kD;
-    o.pm = p;    p += kD;
-    o.arg = p;   p += kD;
+    o.dq1 = p; p += kD;  o.ht = p;  p += kD;  o.a = p;   p += kD;  o.dpa = p; p += kD;
+    o.vpa = p; p += kD;  o.vpm = p; p += kD;  o.dw3 = p; p += kD;  o.dc2 = p; p += kD;
+    o.da2h = p; p += H * kD;
+    o.Hm = p;  p += L * kD;
+    o.DU = p;  p += L * kD;
+    o.DR = p;  p += L * kD;
+    o.M = p;   p += L * H * kD;
     o.stride = p;
     return o;
 }
@@ -88,7 +90,51 @@ struct TrustArgs {
     int B, L, H, hybrid;
 };
 
-__device__ __forceinline__ void load_row(const float *row, float4 (&wr)[16])
+struct TrainArgs {
+    const int64_t *targets;  // [B]
+    int n_users;             // logits are taken against table[0 : n_users]
+    float scale;
+    const float *scale_dev;
+    float *a2;               // [B, 64]
+    float *dscore;           // [B, n_users]
+    float *loss_b;           // [B]
+    float *ws;               // [B, ws stride]
+    float *grad_table;
+};
+
+// LDS of the path kernel (floats).  s (the readout's sigmoids) shares dM's space: s is dead before dM is written.
+struct LdsLayout {
+    int e, M, dM, o, h, dh, dO, du, vec, sacc, red, total;
+};
+
+__host__ __device__ inline LdsLayout lds_layout(int L, int H, bool train)
+{
+    LdsLayout o;
+    int p = 0;
+    o.e = p;   p += L * kD;
+    o.M = p;   p += L * H * kD;
+    o.o = p;   p += L * kD;
+    o.h = p;   p += L * kD;
+    o.vec = p; p += 8 * kD;              // [0]: a / dpa, [1]: dq1, [2]: a2, [3]: d a2, [4]: w0 (L*H <= 64), [5]: v0 | alpha
+    o.dM = p;  p += train ? L * H * kD : 0;
+    o.dh = p;  p += train ? L * kD : 0;
+    o.dO = p;  p += train ? L * kD : 0;
+    o.du = p;  p += train ? L * kD : 0;
+    o.sacc = p; p += train ? kPathWaves * kD : 0;
+    o.red = p;  p += train ? 2 * kPathWaves : 0;
+    o.total = p;
+    return o;
+}
+
+// Orders one wave's LDS traffic (lane A writes, lane B reads): the LDS pipe serves a wave's instructions in order, so a
+// compiler-level fence + scheduling barrier is all that is needed — no s_barrier, the other waves are not involved.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void load_row(const float *__restrict__ row, float4 (&wr)[16])
 {
 #pragma unroll
     for (int j = 0; j < 16; ++j) wr[j] = reinterpret_cast<const float4 *>(row)[j];
@@ -121,69 +167,89 @@ __device__ __forceinline__ int path_len(const TrustArgs &p, int b)
     return l < 1 ? 1 : (l > p.L ? p.L : l);
 }
 
-__device__ __forceinline__ float table_at(const TrustArgs &p, int64_t x, int lane)
-{
-    return (x >= 0 && x < p.n_rows) ? p.table[(size_t)x * kD + lane] : 0.0f;   // never gather out of bounds
-}
+struct FwdState {     // what the forward leaves in registers for the backward chain (wave 0)
+    float av, pa, pm, g0, ht;
+    int arg;
+};
 
-// ---------------------------------------------------------------------------------------------------------- forward
-__global__ __launch_bounds__(kWave) void trust_head_fwd_kernel(const TrustArgs p, float *__restrict__ a2_out,
-                                                               float *__restrict__ ws)
+// ------------------------------------------------------------------------------------------------ forward chain (one wave)
+__device__ __forceinline__ FwdState forward_chain(const TrustArgs &p, const LdsLayout &ll, float *s, int b, int l, int lane,
+                                                  float *__restrict__ a2_out)
 {
-    extern __shared__ float4 s_raw[];
-    float *s = reinterpret_cast<float *>(s_raw);
-    const int lane = threadIdx.x, b = blockIdx.x, L = p.L, H = p.H;
+    const int L = p.L, H = p.H;
     const Layout lo = layout(H);
-    const WsLayout wl = ws_layout(L, H);
-    float *e = s, *M = e + L * kD, *o = M + L * H * kD, *h = o + L * kD, *vec = h + L * kD;
-    float *W = ws ? ws + (size_t)b * wl.stride : nullptr;
-    const int l = path_len(p, b);
-    const float *P = p.P;
+    const float *__restrict__ P = p.P;
+    float *e = s + ll.e, *M = s + ll.M, *o = s + ll.o, *h = s + ll.h, *vec = s + ll.vec;
+    float *sg_all = s + ll.dM;                 // the sigmoids (training form only)
+    const bool train = ll.total > ll.dM;         // the training layout carries the backward's arrays after dM
 
-    for (int i = 0; i < l; ++i) e[i * kD + lane] = table_at(p, p.seq[(size_t)b * L + i], lane);
-    // input attention heads
-    for (int i = 0; i < l; ++i) {
-        const float ei = e[i * kD + lane];
-        if (i < l - 1) {
-            const float A = ei + (float)(l - i), Bv = e[(i + 1) * kD + lane] + (float)(l - i - 1);
-            for (int hh = 0; hh < H; ++hh) {
-                const float a1 = P[lo.in_att + hh * 2 * kD + lane], a2 = P[lo.in_att + hh * 2 * kD + kD + lane];
-                const float s1 = wave_sum_f32(A * a1), s2 = wave_sum_f32(A * a2), s3 = wave_sum_f32(Bv * a2);
-                float w0, w1;
-                softmax2(s1 + s2, s1 + s3, w0, w1);
-                M[(i * H + hh) * kD + lane] = w0 * A + w1 * Bv;
-                if (W && lane == 0) W[wl.w0 + i * H + hh] = w0;
+    // path rows: all gathers in flight at once (row index -1 / out of range -> zeros, never an out-of-bounds gather)
+    {
+        float row[kMaxL];
+#pragma unroll
+        for (int i = 0; i < kMaxL; ++i) {
+            row[i] = 0.0f;
+            if (i < l) {
+                const int64_t x = p.seq[(size_t)b * L + i];
+                if (x >= 0 && x < p.n_rows) row[i] = p.table[(size_t)x * kD + lane];
             }
-        } else {
-            for (int hh = 0; hh < H; ++hh) M[(i * H + hh) * kD + lane] = ei;
+        }
+#pragma unroll
+        for (int i = 0; i < kMaxL; ++i)
+            if (i < l) e[i * kD + lane] = row[i];
+    }
+    // input attention heads
+    {
+        float a1[kMaxH], a2[kMaxH];
+#pragma unroll
+        for (int hh = 0; hh < kMaxH; ++hh) {
+            a1[hh] = hh < H ? P[lo.in_att + hh * 2 * kD + lane] : 0.0f;
+            a2[hh] = hh < H ? P[lo.in_att + hh * 2 * kD + kD + lane] : 0.0f;
+        }
+        for (int i = 0; i < l; ++i) {
+            const float ei = e[i * kD + lane];
+            if (i < l - 1) {
+                const float A = ei + (float)(l - i), Bv = e[(i + 1) * kD + lane] + (float)(l - i - 1);
+#pragma unroll
+                for (int hh = 0; hh < kMaxH; ++hh)
+                    if (hh < H) {
+                        const float s1 = wave_sum_f32(A * a1[hh]), s2 = wave_sum_f32(A * a2[hh]), s3 = wave_sum_f32(Bv * a2[hh]);
+                        float w0, w1;
+                        softmax2(s1 + s2, s1 + s3, w0, w1);
+                        M[(i * H + hh) * kD + lane] = w0 * A + w1 * Bv;
+                        if (lane == 0) vec[4 * kD + i * H + hh] = w0;
+                    }
+            } else {
+                for (int hh = 0; hh < H; ++hh) M[(i * H + hh) * kD + lane] = ei;
+            }
         }
     }
-    __syncthreads();
-    // r_i = M_i @ w (w row k is coalesced across lanes; M_i[k] is an LDS broadcast), o_i = ELU(r_i)
+    wave_sync();
+    // r_i = M_i @ w (w row k is coalesced across lanes, 16 independent loads per batch; M_i[k] is an LDS broadcast), o_i = ELU(r_i)
     {
         float acc[kMaxL];
 #pragma unroll
         for (int i = 0; i < kMaxL; ++i) acc[i] = 0.0f;
-        for (int k = 0; k < H * kD; k += 4) {
-            const float w0 = P[lo.w + (k + 0) * kD + lane], w1 = P[lo.w + (k + 1) * kD + lane];
-            const float w2 = P[lo.w + (k + 2) * kD + lane], w3 = P[lo.w + (k + 3) * kD + lane];
+        for (int k0 = 0; k0 < H * kD; k0 += 16) {
+            float wk[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) wk[j] = P[lo.w + (k0 + j) * kD + lane];
 #pragma unroll
             for (int i = 0; i < kMaxL; ++i)
                 if (i < l) {
-                    const float4 m = *reinterpret_cast<const float4 *>(&M[i * H * kD + k]);
-                    acc[i] = fmaf(m.x, w0, acc[i]);
-                    acc[i] = fmaf(m.y, w1, acc[i]);
-                    acc[i] = fmaf(m.z, w2, acc[i]);
-                    acc[i] = fmaf(m.w, w3, acc[i]);
+#pragma unroll
+                    for (int j4 = 0; j4 < 4; ++j4) {
+                        const float4 m = *reinterpret_cast<const float4 *>(&M[i * H * kD + k0 + j4 * 4]);
+                        acc[i] = fmaf(m.x, wk[j4 * 4 + 0], acc[i]);
+                        acc[i] = fmaf(m.y, wk[j4 * 4 + 1], acc[i]);
+                        acc[i] = fmaf(m.z, wk[j4 * 4 + 2], acc[i]);
+                        acc[i] = fmaf(m.w, wk[j4 * 4 + 3], acc[i]);
+                    }
                 }
         }
 #pragma unroll
         for (int i = 0; i < kMaxL; ++i)
-            if (i < l) {
-                const float r = acc[i];
-                if (W) W[wl.r + i * kD + lane] = r;
-                o[i * kD + lane] = r > 0.0f ? r : expm1f(r);
-            }
+            if (i < l) o[i * kD + lane] = acc[i] > 0.0f ? acc[i] : expm1f(acc[i]);
     }
     // output attention layer
     {
@@ -197,39 +263,39 @@ __global__ __launch_bounds__(kWave) void trust_head_fwd_kernel(const TrustArgs p
                 float v0, v1;
                 softmax2(s1 + s2, s1 + s3, v0, v1);
                 hv = v0 * oi + v1 * on;
-                if (W && lane == 0) W[wl.v0 + i] = v0;
+                if (lane == 0) vec[5 * kD + i] = v0;
             }
             h[i * kD + lane] = hv;
-            if (W) W[wl.h + i * kD + lane] = hv;
         }
     }
-    __syncthreads();
+    wave_sync();
     // soft-attention readout
-    float4 wr[16];
+    FwdState st;
+    float4 wr[16], wr2[16];
     const float *ht = h + (l - 1) * kD;
     load_row(P + lo.W1 + lane * kD, wr);
-    const float q1 = P[lo.b1 + lane] + dot_row(wr, ht);
-    load_row(P + lo.W2 + lane * kD, wr);
-    const float b2 = P[lo.b2 + lane], w3 = P[lo.w3 + lane];
+    load_row(P + lo.W2 + lane * kD, wr2);
+    const float b1 = P[lo.b1 + lane], b2 = P[lo.b2 + lane], w3 = P[lo.w3 + lane];
+    const float q1 = b1 + dot_row(wr, ht);
     float av = 0.0f;
     for (int i = 0; i < l; ++i) {
-        const float q2 = b2 + dot_row(wr, h + i * kD);
+        const float q2 = b2 + dot_row(wr2, h + i * kD);
         const float sg = 1.0f / (1.0f + expf(-(q1 + q2)));
         const float alpha = wave_sum_f32(w3 * sg);
-        if (W) {
-            W[wl.s + i * kD + lane] = sg;
-            if (lane == 0) W[wl.alpha + i] = alpha;
+        if (train) {
+            sg_all[i * kD + lane] = sg;
+            if (lane == 0) vec[5 * kD + kMaxL + i] = alpha;
         }
         av = fmaf(alpha, h[i * kD + lane], av);
     }
     vec[lane] = av;
-    __syncthreads();
+    wave_sync();
     float pa = av;
     if (p.hybrid) {
         load_row(P + lo.Wt + lane * 2 * kD, wr);
+        load_row(P + lo.Wt + lane * 2 * kD + kD, wr2);
         pa = P[lo.bt + lane] + dot_row(wr, vec);
-        load_row(P + lo.Wt + lane * 2 * kD + kD, wr);
-        pa += dot_row(wr, ht);
+        pa += dot_row(wr2, ht);
     }
     // max-pool over the path's own rows (a padded position contributes 0)
     float pm = -INFINITY;
@@ -243,23 +309,17 @@ __global__ __launch_bounds__(kWave) void trust_head_fwd_kernel(const TrustArgs p
     const float t1 = wave_sum_f32(pa * P[lo.att_t + lane * 2 + 1] + pm * P[lo.att_t + (kD + lane) * 2 + 1]);
     float g0, g1;
     softmax2(t0, t1, g0, g1);
-    a2_out[(size_t)b * kD + lane] = pa * g0 + pm * g1;
-    if (W) {
-        W[wl.a + lane] = av;
-        W[wl.pa + lane] = pa;
-        W[wl.pm + lane] = pm;
-        W[wl.arg + lane] = __int_as_float(arg);
-        if (lane == 0) W[wl.g0] = g0;
-    }
+    const float a2v = pa * g0 + pm * g1;
+    a2_out[(size_t)b * kD + lane] = a2v;
+    vec[2 * kD + lane] = a2v;
+    st.av = av; st.pa = pa; st.pm = pm; st.g0 = g0; st.arg = arg; st.ht = ht[lane];
+    return st;
 }
 
-// ---------------------------------------------------------------------------------------------------- logits + CE
-// One workgroup per path.  thread t owns users t, t + 1024, ..: score = a2 . E[u] (its own 256-byte row, 16 float4);
-// block max / sum-exp; loss_b = lse - score[target];  d score = (softmax - onehot) * scale / B, left in dscore[b, :];
-// then wave w sums d score[b,u] E[u] over users w, w + 16, .. (lane == column) -> d a2[b].
+// --------------------------------------------------------------------------------------- logits + CE (the whole workgroup)
 __device__ __forceinline__ float block_reduce(float v, float *red, bool is_max)
 {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int off = 32; off > 0; off >>= 1) {
         const float o = __shfl_xor(v, off);
         v = is_max ? fmaxf(v, o) : v + o;
@@ -268,152 +328,106 @@ __device__ __forceinline__ float block_reduce(float v, float *red, bool is_max)
     if (lane == 0) red[wv] = v;
     __syncthreads();
     float r = red[0];
-    for (int k = 1; k < nw; ++k) r = is_max ? fmaxf(r, red[k]) : r + red[k];
+    for (int k = 1; k < kPathWaves; ++k) r = is_max ? fmaxf(r, red[k]) : r + red[k];
     return r;
 }
 
-__global__ __launch_bounds__(kCeThreads) void trust_ce_kernel(const float *__restrict__ table, int n_users,
-                                                             const float *__restrict__ a2, const int64_t *__restrict__ targets,
-                                                             int B, float scale, const float *__restrict__ scale_dev,
-                                                             float *__restrict__ dscore, float *__restrict__ loss_b,
-                                                             float *__restrict__ grad_a2)
+// scores against table[0 : n_users] (16 lanes per 256-byte row), log-sum-exp, loss_b, d scores -> tr.dscore[b, :], d a2 -> vec[3]
+__device__ __forceinline__ void logits_ce(const TrustArgs &p, const TrainArgs &tr, const LdsLayout &ll, float *s, int b)
 {
-    __shared__ float4 s_a2[16];
-    __shared__ float red[kCeThreads / 64];
-    __shared__ float s_acc[kCeThreads / 64][kD];
-    const int b = blockIdx.x, t = threadIdx.x;
-    if (t < 16) s_a2[t] = reinterpret_cast<const float4 *>(a2 + (size_t)b * kD)[t];
-    __syncthreads();
-    float *ds = dscore + (size_t)b * n_users;
+    const int t = threadIdx.x, n_users = tr.n_users;
+    float *vec = s + ll.vec, *red = s + ll.red, *sacc = s + ll.sacc;
+    float *__restrict__ ds = tr.dscore + (size_t)b * n_users;
+    const float *__restrict__ table = p.table;
+    const int sub = t & 15, grp = t >> 4;                        // 64 row groups of 16 lanes
+    const float4 x = reinterpret_cast<const float4 *>(vec + 2 * kD)[sub];
     float mx = -INFINITY;
-    for (int u = t; u < n_users; u += kCeThreads) {
-        const float4 *row = reinterpret_cast<const float4 *>(table + (size_t)u * kD);
-        float acc = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const float4 r = row[j], x = s_a2[j];
-            acc = fmaf(r.x, x.x, acc);
-            acc = fmaf(r.y, x.y, acc);
-            acc = fmaf(r.z, x.z, acc);
-            acc = fmaf(r.w, x.w, acc);
+    for (int u0 = 0; u0 < n_users; u0 += kPathThreads / 16) {
+        const int u = u0 + grp;
+        float part = 0.0f;
+        if (u < n_users) {
+            const float4 r = reinterpret_cast<const float4 *>(table + (size_t)u * kD)[sub];
+            part = fmaf(r.x, x.x, fmaf(r.y, x.y, fmaf(r.z, x.z, r.w * x.w)));
         }
-        ds[u] = acc;
-        mx = fmaxf(mx, acc);
+        const float sc = row16_sum_f32(part);
+        if (u < n_users) {
+            if (sub == 0) ds[u] = sc;
+            mx = fmaxf(mx, sc);
+        }
     }
-    mx = block_reduce(mx, red, true);
+    mx = block_reduce(mx, red, true);                            // (its barriers also publish ds within the workgroup)
     float se = 0.0f;
-    for (int u = t; u < n_users; u += kCeThreads) se += expf(ds[u] - mx);
-    se = block_reduce(se, red, false);
+    for (int u = t; u < n_users; u += kPathThreads) se += expf(ds[u] - mx);
+    se = block_reduce(se, red + kPathWaves, false);
     const float lse = mx + logf(se);
-    const int64_t tg = targets[b];
+    const int64_t tg = tr.targets[b];
     const bool tg_ok = tg >= 0 && tg < n_users;
-    if (t == 0) loss_b[b] = tg_ok ? lse - ds[tg] : 0.0f;     // (thread 0 wrote nothing others read: ds[tg] is global memory)
+    if (t == 0) tr.loss_b[b] = tg_ok ? lse - ds[tg] : 0.0f;
     __syncthreads();
-    const float k = scale * (scale_dev ? *scale_dev : 1.0f) / (float)B;
-    for (int u = t; u < n_users; u += kCeThreads) ds[u] = tg_ok ? (expf(ds[u] - lse) - (u == tg ? 1.0f : 0.0f)) * k : 0.0f;
+    const float k = tr.scale * (tr.scale_dev ? *tr.scale_dev : 1.0f) / (float)p.B;
+    for (int u = t; u < n_users; u += kPathThreads) ds[u] = tg_ok ? (expf(ds[u] - lse) - (u == tg ? 1.0f : 0.0f)) * k : 0.0f;
     __syncthreads();
     const int lane = t & 63, wv = t >> 6;
     float acc = 0.0f;
-    for (int u = wv; u < n_users; u += kCeThreads / 64) acc = fmaf(ds[u], table[(size_t)u * kD + lane], acc);
-    s_acc[wv][lane] = acc;
+    for (int u = wv; u < n_users; u += kPathWaves) acc = fmaf(ds[u], table[(size_t)u * kD + lane], acc);
+    sacc[wv * kD + lane] = acc;
     __syncthreads();
     if (t < kD) {
         float g = 0.0f;
-        for (int w = 0; w < kCeThreads / 64; ++w) g += s_acc[w][t];
-        grad_a2[(size_t)b * kD + t] = g;
+        for (int w = 0; w < kPathWaves; ++w) g += sacc[w * kD + t];
+        vec[3 * kD + t] = g;
     }
 }
 
-// d E[u, :] += sum_b d score[b, u] a2[b, :]  (one wave per user row, no atomics: this launch owns the rows);  block 0 also
-// reduces the per-path losses in path order.
-__global__ __launch_bounds__(256) void trust_table_grad_kernel(const float *__restrict__ dscore, const float *__restrict__ a2,
-                                                              int n_users, int B, const float *__restrict__ loss_b,
-                                                              float *__restrict__ grad_table, float *__restrict__ loss_out,
-                                                              int loss_accumulate)
+// ---------------------------------------------------------------------------------------------- backward chain (one wave)
+__device__ __forceinline__ void backward_chain(const TrustArgs &p, const TrainArgs &tr, const LdsLayout &ll, float *s, int b, int l,
+                                               int lane, const FwdState &st)
 {
-    const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
-    for (int u = wave; u < n_users; u += n_waves) {
-        float acc = 0.0f;
-        for (int b = 0; b < B; ++b) acc = fmaf(dscore[(size_t)b * n_users + u], a2[(size_t)b * kD + lane], acc);
-        grad_table[(size_t)u * kD + lane] += acc;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && loss_out) {
-        float sum = 0.0f;
-        for (int b = 0; b < B; ++b) sum += loss_b[b];
-        sum /= (float)B;
-        *loss_out = loss_accumulate ? *loss_out + sum : sum;
-    }
-}
-
-// --------------------------------------------------------------------------------------------------------- backward
-__global__ __launch_bounds__(kWave) void trust_head_bwd_kernel(const TrustArgs p, const float *__restrict__ ws,
-                                                               const float *__restrict__ grad_a2, float *grad_P,
-                                                               float *grad_table)
-{
-    extern __shared__ float4 s_raw[];
-    float *s = reinterpret_cast<float *>(s_raw);
-    const int lane = threadIdx.x, b = blockIdx.x, L = p.L, H = p.H;
+    const int L = p.L, H = p.H;
     const Layout lo = layout(H);
     const WsLayout wl = ws_layout(L, H);
-    float *e = s, *M = e + L * kD, *dM = M + L * H * kD, *o = dM + L * H * kD, *h = o + L * kD, *dh = h + L * kD;
-    float *dO = dh + L * kD, *du = dO + L * kD, *vec = du + L * kD;      // vec: [4][64]
-    const float *W = ws + (size_t)b * wl.stride;
-    const int l = path_len(p, b);
-    const float *P = p.P;
-    float *G = grad_P;
-
-    // restore the forward's state: rows, attention mixes (from the saved softmax weights), o = ELU(r), h
-    for (int i = 0; i < l; ++i) {
-        e[i * kD + lane] = table_at(p, p.seq[(size_t)b * L + i], lane);
-        const float r = W[wl.r + i * kD + lane];
-        o[i * kD + lane] = r > 0.0f ? r : expm1f(r);
-        h[i * kD + lane] = W[wl.h + i * kD + lane];
-        dO[i * kD + lane] = 0.0f;
-    }
-    for (int i = 0; i < l; ++i) {
-        const float ei = e[i * kD + lane];
-        if (i < l - 1) {
-            const float A = ei + (float)(l - i), Bv = e[(i + 1) * kD + lane] + (float)(l - i - 1);
-            for (int hh = 0; hh < H; ++hh) {
-                const float w0 = W[wl.w0 + i * H + hh];
-                M[(i * H + hh) * kD + lane] = w0 * A + (1.0f - w0) * Bv;
-            }
-        } else {
-            for (int hh = 0; hh < H; ++hh) M[(i * H + hh) * kD + lane] = ei;
-        }
-    }
-    const float av = W[wl.a + lane], pa = W[wl.pa + lane], pm = W[wl.pm + lane], g0 = W[wl.g0], g1 = 1.0f - g0;
-    const int arg = __float_as_int(W[wl.arg + lane]);
-    const float ht = h[(l - 1) * kD + lane];
-    const float da2 = grad_a2[(size_t)b * kD + lane];
+    const float *__restrict__ P = p.P;
+    float *__restrict__ W = tr.ws + (size_t)b * wl.stride;
+    float *grad_table = tr.grad_table;
+    float *e = s + ll.e, *M = s + ll.M, *dM = s + ll.dM, *o = s + ll.o, *h = s + ll.h, *dh = s + ll.dh, *dO = s + ll.dO;
+    float *du = s + ll.du, *vec = s + ll.vec;
+    const float *sg_all = s + ll.dM;
+    const float av = st.av, pa = st.pa, pm = st.pm, g0 = st.g0, g1 = 1.0f - st.g0, ht = st.ht;
+    const float da2 = vec[3 * kD + lane];
 
     // gate between the pooled vector and the max-pool
     const float dg0 = wave_sum_f32(da2 * pa), dg1 = wave_sum_f32(da2 * pm);
     const float dt0 = g0 * g1 * (dg0 - dg1);
     const float dpa = g0 * da2 + (P[lo.att_t + lane * 2] - P[lo.att_t + lane * 2 + 1]) * dt0;
     const float dpm = g1 * da2 + (P[lo.att_t + (kD + lane) * 2] - P[lo.att_t + (kD + lane) * 2 + 1]) * dt0;
-    atomicAdd(G + lo.att_t + lane * 2, pa * dt0);
-    atomicAdd(G + lo.att_t + lane * 2 + 1, -pa * dt0);
-    atomicAdd(G + lo.att_t + (kD + lane) * 2, pm * dt0);
-    atomicAdd(G + lo.att_t + (kD + lane) * 2 + 1, -pm * dt0);
-    if (arg >= 0) {
-        const int64_t x = p.seq[(size_t)b * L + arg];
+    W[wl.vpa + lane] = pa * dt0;
+    W[wl.vpm + lane] = pm * dt0;
+    W[wl.dpa + lane] = p.hybrid ? dpa : 0.0f;
+    W[wl.a + lane] = av;
+    W[wl.ht + lane] = ht;
+    if (st.arg >= 0) {
+        const int64_t x = p.seq[(size_t)b * L + st.arg];
         if (x >= 0 && x < p.n_rows) atomicAdd(grad_table + (size_t)x * kD + lane, dpm);
     }
-    // p_a = Wt [a | ht] + bt
+    // p_a = Wt [a | ht] + bt:  d a[k] = sum_c Wt[c][k] dpa[c],  d ht[k] = sum_c Wt[c][64 + k] dpa[c]   (lane == k: coalesced rows)
     float da = dpa, dht = 0.0f;
     if (p.hybrid) {
-        atomicAdd(G + lo.bt + lane, dpa);
         vec[lane] = dpa;
-        __syncthreads();
+        wave_sync();
         da = 0.0f;
-        for (int c = 0; c < kD; ++c) {
-            const float g = vec[c];
-            da = fmaf(P[lo.Wt + c * 2 * kD + lane], g, da);
-            dht = fmaf(P[lo.Wt + c * 2 * kD + kD + lane], g, dht);
-            atomicAdd(G + lo.Wt + c * 2 * kD + lane, g * av);
-            atomicAdd(G + lo.Wt + c * 2 * kD + kD + lane, g * ht);
+        for (int c0 = 0; c0 < kD; c0 += 16) {
+            float wa[16], wh[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                wa[j] = P[lo.Wt + (c0 + j) * 2 * kD + lane];
+                wh[j] = P[lo.Wt + (c0 + j) * 2 * kD + kD + lane];
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float g = vec[c0 + j];
+                da = fmaf(wa[j], g, da);
+                dht = fmaf(wh[j], g, dht);
+            }
         }
     }
     // a = sum alpha_i h_i,  alpha_i = w3 . s_i,  s_i = sigmoid(q1 + q2_i)
@@ -421,59 +435,61 @@ __global__ __launch_bounds__(kWave) void trust_head_bwd_kernel(const TrustArgs p
         const float w3 = P[lo.w3 + lane];
         float dw3 = 0.0f, dq1 = 0.0f;
         for (int i = 0; i < l; ++i) {
-            const float hi = h[i * kD + lane], si = W[wl.s + i * kD + lane];
+            const float hi = h[i * kD + lane], si = sg_all[i * kD + lane];
             const float dalpha = wave_sum_f32(da * hi);
-            dh[i * kD + lane] = W[wl.alpha + i] * da;
+            dh[i * kD + lane] = vec[5 * kD + kMaxL + i] * da;
             dw3 = fmaf(dalpha, si, dw3);
             const float d = dalpha * w3 * si * (1.0f - si);
             du[i * kD + lane] = d;
+            W[wl.DU + i * kD + lane] = d;
+            W[wl.Hm + i * kD + lane] = hi;
             dq1 += d;
         }
-        atomicAdd(G + lo.w3 + lane, dw3);
-        atomicAdd(G + lo.b1 + lane, dq1);
-        atomicAdd(G + lo.b2 + lane, dq1);
+        W[wl.dw3 + lane] = dw3;
+        W[wl.dq1 + lane] = dq1;
         vec[kD + lane] = dq1;
     }
-    __syncthreads();
-    // linear_one: d W1[c][k] += dq1[c] ht[k];  d ht[k] += sum_c W1[c][k] dq1[c]          (lane == k: coalesced rows)
-    for (int c = 0; c < kD; ++c) {
-        const float g = vec[kD + c];
-        dht = fmaf(P[lo.W1 + c * kD + lane], g, dht);
-        atomicAdd(G + lo.W1 + c * kD + lane, g * ht);
-    }
-    // linear_two: d W2[c][k] += sum_i du_i[c] h_i[k];  d h_i[k] += sum_c W2[c][k] du_i[c]
+    wave_sync();
+    // linear_one / linear_two transposed:  d ht[k] += sum_c W1[c][k] dq1[c];  d h_i[k] += sum_c W2[c][k] du_i[c]
     {
-        float acc[kMaxL], hreg[kMaxL];
+        float acc[kMaxL];
 #pragma unroll
-        for (int i = 0; i < kMaxL; ++i) {
-            acc[i] = 0.0f;
-            hreg[i] = i < l ? h[i * kD + lane] : 0.0f;
-        }
-        for (int c = 0; c < kD; ++c) {
-            const float wv = P[lo.W2 + c * kD + lane];
-            float g = 0.0f;
+        for (int i = 0; i < kMaxL; ++i) acc[i] = 0.0f;
+        for (int c0 = 0; c0 < kD; c0 += 16) {
+            float w1[16], w2[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                w1[j] = P[lo.W1 + (c0 + j) * kD + lane];
+                w2[j] = P[lo.W2 + (c0 + j) * kD + lane];
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) dht = fmaf(w1[j], vec[kD + c0 + j], dht);
 #pragma unroll
             for (int i = 0; i < kMaxL; ++i)
                 if (i < l) {
-                    const float d = du[i * kD + c];
-                    g = fmaf(d, hreg[i], g);
-                    acc[i] = fmaf(wv, d, acc[i]);
+#pragma unroll
+                    for (int j4 = 0; j4 < 4; ++j4) {
+                        const float4 d = *reinterpret_cast<const float4 *>(&du[i * kD + c0 + j4 * 4]);
+                        acc[i] = fmaf(w2[j4 * 4 + 0], d.x, acc[i]);
+                        acc[i] = fmaf(w2[j4 * 4 + 1], d.y, acc[i]);
+                        acc[i] = fmaf(w2[j4 * 4 + 2], d.z, acc[i]);
+                        acc[i] = fmaf(w2[j4 * 4 + 3], d.w, acc[i]);
+                    }
                 }
-            atomicAdd(G + lo.W2 + c * kD + lane, g);
         }
 #pragma unroll
         for (int i = 0; i < kMaxL; ++i)
-            if (i < l) dh[i * kD + lane] += acc[i];
+            if (i < l) dh[i * kD + lane] += acc[i] + (i == l - 1 ? dht : 0.0f);
     }
-    dh[(l - 1) * kD + lane] += dht;
     // output attention layer (the first half of its parameter cancels in the softmax: gradient exactly 0)
     {
         const float c2 = P[lo.out_att + kD + lane];
         float dc2 = 0.0f;
+        for (int i = 0; i < l; ++i) dO[i * kD + lane] = 0.0f;
         for (int i = 0; i < l; ++i) {
             const float g = dh[i * kD + lane];
             if (i < l - 1) {
-                const float delta = o[i * kD + lane] - o[(i + 1) * kD + lane], v0 = W[wl.v0 + i];
+                const float delta = o[i * kD + lane] - o[(i + 1) * kD + lane], v0 = vec[5 * kD + i];
                 const float dz = wave_sum_f32(g * delta) * v0 * (1.0f - v0);
                 dO[i * kD + lane] += v0 * g + dz * c2;
                 dO[(i + 1) * kD + lane] += (1.0f - v0) * g - dz * c2;
@@ -482,29 +498,19 @@ __global__ __launch_bounds__(kWave) void trust_head_bwd_kernel(const TrustArgs p
                 dO[i * kD + lane] += g;
             }
         }
-        atomicAdd(G + lo.out_att + kD + lane, dc2);
+        W[wl.dc2 + lane] = dc2;
     }
-    // ELU, then r = M w:  d w[k][c] += sum_i M_i[k] dr_i[c]  (lane == c);  d M_i[k] = sum_c w[k][c] dr_i[c]  (lane == k mod 64)
+    // ELU (from o alone: o > 0 <=> r > 0, else exp(r) = o + 1), then  d M_i[k] = sum_c w[k][c] dr_i[c]  (lane == k mod 64)
     float *dr = du;     // du is dead
+    for (int i = 0; i < l; ++i) {
+        const float ov = o[i * kD + lane];
+        const float d = dO[i * kD + lane] * (ov > 0.0f ? 1.0f : ov + 1.0f);
+        dr[i * kD + lane] = d;
+        W[wl.DR + i * kD + lane] = d;
+        for (int hh = 0; hh < H; ++hh) W[wl.M + (i * H + hh) * kD + lane] = M[(i * H + hh) * kD + lane];
+    }
+    wave_sync();
     {
-        float drreg[kMaxL];
-#pragma unroll
-        for (int i = 0; i < kMaxL; ++i) {
-            drreg[i] = 0.0f;
-            if (i < l) {
-                const float r = W[wl.r + i * kD + lane];
-                drreg[i] = dO[i * kD + lane] * (r > 0.0f ? 1.0f : expf(r));
-                dr[i * kD + lane] = drreg[i];
-            }
-        }
-        __syncthreads();
-        for (int k = 0; k < H * kD; ++k) {
-            float g = 0.0f;
-#pragma unroll
-            for (int i = 0; i < kMaxL; ++i)
-                if (i < l) g = fmaf(M[i * H * kD + k], drreg[i], g);
-            atomicAdd(G + lo.w + k * kD + lane, g);
-        }
         float4 wr[16];
         for (int hh = 0; hh < H; ++hh) {
             load_row(P + lo.w + (hh * kD + lane) * kD, wr);
@@ -513,11 +519,14 @@ __global__ __launch_bounds__(kWave) void trust_head_bwd_kernel(const TrustArgs p
     }
     // input attention heads
     {
-        float dE[kMaxL], da2h[kMaxH];
+        float dE[kMaxL], da2h[kMaxH], a2[kMaxH];
 #pragma unroll
         for (int i = 0; i < kMaxL; ++i) dE[i] = 0.0f;
 #pragma unroll
-        for (int hh = 0; hh < kMaxH; ++hh) da2h[hh] = 0.0f;
+        for (int hh = 0; hh < kMaxH; ++hh) {
+            da2h[hh] = 0.0f;
+            a2[hh] = hh < H ? P[lo.in_att + hh * 2 * kD + kD + lane] : 0.0f;
+        }
 #pragma unroll
         for (int i = 0; i < kMaxL; ++i) {
             if (i < l - 1) {
@@ -525,11 +534,10 @@ __global__ __launch_bounds__(kWave) void trust_head_bwd_kernel(const TrustArgs p
 #pragma unroll
                 for (int hh = 0; hh < kMaxH; ++hh)
                     if (hh < H) {
-                        const float g = dM[(i * H + hh) * kD + lane], w0 = W[wl.w0 + i * H + hh];
-                        const float a2 = P[lo.in_att + hh * 2 * kD + kD + lane];
+                        const float g = dM[(i * H + hh) * kD + lane], w0 = vec[4 * kD + i * H + hh];
                         const float dz = wave_sum_f32(g * delta) * w0 * (1.0f - w0);
-                        dE[i] += w0 * g + dz * a2;
-                        if (i + 1 < kMaxL) dE[i + 1] += (1.0f - w0) * g - dz * a2;
+                        dE[i] += w0 * g + dz * a2[hh];
+                        if (i + 1 < kMaxL) dE[i + 1] += (1.0f - w0) * g - dz * a2[hh];
                         da2h[hh] = fmaf(dz, delta, da2h[hh]);
                     }
             } else if (i == l - 1) {
@@ -546,7 +554,130 @@ __global__ __launch_bounds__(kWave) void trust_head_bwd_kernel(const TrustArgs p
             }
 #pragma unroll
         for (int hh = 0; hh < kMaxH; ++hh)
-            if (hh < H) atomicAdd(G + lo.in_att + hh * 2 * kD + kD + lane, da2h[hh]);
+            if (hh < H) W[wl.da2h + hh * kD + lane] = da2h[hh];
+    }
+}
+
+// One workgroup per path.  TRAIN: 8 waves (forward chain on wave 0, logits + CE on all, backward chain on wave 0);
+// forward only: launched with one wave.
+template <bool TRAIN>
+__global__ __launch_bounds__(TRAIN ? kPathThreads : kWave) void trust_path_kernel(const TrustArgs p, const TrainArgs tr,
+                                                                                 float *__restrict__ a2_out)
+{
+    extern __shared__ float4 s_raw[];
+    float *s = reinterpret_cast<float *>(s_raw);
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const LdsLayout ll = lds_layout(p.L, p.H, TRAIN);
+    const int l = path_len(p, b);
+    FwdState st{};
+    if (wave == 0) st = forward_chain(p, ll, s, b, l, lane, a2_out);
+    if (!TRAIN) return;
+    __syncthreads();
+    logits_ce(p, tr, ll, s, b);
+    __syncthreads();
+    if (wave == 0) backward_chain(p, tr, ll, s, b, l, lane, st);
+}
+
+// ------------------------------------------------------------------------------------------------------------ reductions
+struct ReduceArgs {
+    const float *dscore, *a2, *loss_b, *ws;
+    const int64_t *seq_l;
+    float *grad_table, *grad_P, *loss_out;
+    int n_users, B, L, H, hybrid, loss_accumulate;
+    int blocks_users, blocks_mat;      // block ranges: [0, blocks_users) user rows, then the weight tiles, then one vector block
+};
+
+__device__ __forceinline__ int clamp_len(int64_t l, int L)
+{
+    return l < 1 ? 1 : (l > L ? L : (int)l);
+}
+
+__global__ __launch_bounds__(256) void trust_reduce_kernel(const ReduceArgs a)
+{
+    const Layout lo = layout(a.H);
+    const WsLayout wl = ws_layout(a.L, a.H);
+    const int t = threadIdx.x;
+    int blk = blockIdx.x;
+    if (blk < a.blocks_users) {
+        // d E[u, :] += sum_b d score[b, u] a2[b, :]  (one wave per user row; this launch owns the rows)
+        const int lane = t & 63;
+        for (int u = blk * 4 + (t >> 6); u < a.n_users; u += a.blocks_users * 4) {
+            float acc = 0.0f;
+            for (int b = 0; b < a.B; ++b) acc = fmaf(a.dscore[(size_t)b * a.n_users + u], a.a2[(size_t)b * kD + lane], acc);
+            a.grad_table[(size_t)u * kD + lane] += acc;
+        }
+        return;
+    }
+    blk -= a.blocks_users;
+    if (blk < a.blocks_mat) {
+        // weight gradients: out[x][y] = sum over rows of A[row][x] * Bm[row][y]; a block covers 4 x-values x 64 y-values
+        //   W1 [c][k]   = sum_b       dq1_b[c] ht_b[k]            16 blocks
+        //   W2 [c][k]   = sum_{b,i}   du_bi[c] h_bi[k]            16 blocks
+        //   Wt [c][k']  = sum_b       dpa_b[c] [a_b | ht_b][k']   32 blocks (one 64-wide half of k' each)
+        //   w  [k][c]   = sum_{b,i}   M_bi[k]  dr_bi[c]           16 H blocks
+        const int y = t & 63, xs = t >> 6;
+        int x, offA, offB, out, ldA = 0;
+        bool per_pos;
+        if (blk < 16) {
+            x = blk * 4 + xs; offA = wl.dq1 + x; offB = wl.ht + y; out = lo.W1 + x * kD + y; per_pos = false;
+        } else if (blk < 32) {
+            x = (blk - 16) * 4 + xs; offA = wl.DU + x; offB = wl.Hm + y; out = lo.W2 + x * kD + y; per_pos = true; ldA = kD;
+        } else if (blk < 64) {
+            const int half = (blk - 32) & 1;
+            x = ((blk - 32) >> 1) * 4 + xs; offA = wl.dpa + x; offB = (half ? wl.ht : wl.a) + y;
+            out = lo.Wt + x * 2 * kD + half * kD + y; per_pos = false;
+        } else {
+            x = (blk - 64) * 4 + xs; offA = wl.M + x; offB = wl.DR + y; out = lo.w + x * kD + y; per_pos = true; ldA = a.H * kD;
+        }
+        float acc = 0.0f;
+        for (int b = 0; b < a.B; ++b) {
+            const float *W = a.ws + (size_t)b * wl.stride;
+            if (per_pos) {
+                const int l = clamp_len(a.seq_l[b], a.L);
+                for (int i = 0; i < l; ++i) acc = fmaf(W[offA + i * ldA], W[offB + i * kD], acc);
+            } else {
+                acc = fmaf(W[offA], W[offB], acc);
+            }
+        }
+        a.grad_P[out] = acc;
+        return;
+    }
+    // vector gradients (sums over paths of per-path vectors) and the loss
+    for (int k = t; k < (7 + a.H) * kD; k += 256) {
+        const int which = k / kD, c = k - which * kD;
+        int off;
+        switch (which) {
+            case 0: off = wl.dq1; break;       // b1 and b2
+            case 1: off = wl.dpa; break;       // bt
+            case 2: off = wl.dw3; break;
+            case 3: off = wl.dc2; break;
+            case 4: off = wl.vpa; break;
+            case 5: off = wl.vpm; break;
+            case 6: off = -1; break;           // (zero halves, below)
+            default: off = wl.da2h + (which - 7) * kD; break;
+        }
+        float sum = 0.0f;
+        if (off >= 0)
+            for (int b = 0; b < a.B; ++b) sum += a.ws[(size_t)b * wl.stride + off + c];
+        switch (which) {
+            case 0: a.grad_P[lo.b1 + c] = sum; a.grad_P[lo.b2 + c] = sum; break;
+            case 1: a.grad_P[lo.bt + c] = sum; break;
+            case 2: a.grad_P[lo.w3 + c] = sum; break;
+            case 3: a.grad_P[lo.out_att + kD + c] = sum; break;
+            case 4: a.grad_P[lo.att_t + c * 2] = sum; a.grad_P[lo.att_t + c * 2 + 1] = -sum; break;
+            case 5: a.grad_P[lo.att_t + (kD + c) * 2] = sum; a.grad_P[lo.att_t + (kD + c) * 2 + 1] = -sum; break;
+            case 6:                                                  // the a1 halves cancel in the softmax: exactly 0
+                a.grad_P[lo.out_att + c] = 0.0f;
+                for (int hh = 0; hh < a.H; ++hh) a.grad_P[lo.in_att + hh * 2 * kD + c] = 0.0f;
+                break;
+            default: a.grad_P[lo.in_att + (which - 7) * 2 * kD + kD + c] = sum; break;
+        }
+    }
+    if (t == 0 && a.loss_out) {
+        float sum = 0.0f;
+        for (int b = 0; b < a.B; ++b) sum += a.loss_b[b];
+        sum /= (float)a.B;
+        *a.loss_out = a.loss_accumulate ? *a.loss_out + sum : sum;
     }
 }
 
@@ -578,52 +709,41 @@ extern "C" int64_t spex_trust_workspace_floats(int32_t B, int32_t L, int32_t d, 
 
 extern "C" int spex_trust_head_fwd_f32(const float *table, int64_t n_rows, const float *params, const int64_t *seq,
                                        const int64_t *seq_l, int32_t B, int32_t L, int32_t d, int32_t n_heads, int32_t hybrid,
-                                       float *a2_out, float *ws, void *stream)
+                                       float *a2_out, void *stream)
 {
     if (int rc = check_head("spex_trust_head_fwd_f32", table, n_rows, params, seq, seq_l, B, L, d, n_heads)) return rc;
     SPEX_CHECK_ARG(a2_out, "spex_trust_head_fwd_f32: NULL output");
     if (B == 0) return SPEX_OK;
     const TrustArgs p{table, n_rows, params, seq, seq_l, B, L, n_heads, hybrid};
-    const size_t lds = ((size_t)L * kD * 3 + (size_t)L * n_heads * kD + 4 * kD) * sizeof(float);
-    hipLaunchKernelGGL(trust_head_fwd_kernel, dim3((unsigned)B), dim3(kWave), lds, (hipStream_t)stream, p, a2_out, ws);
+    const TrainArgs tr{};
+    const size_t lds = (size_t)lds_layout(L, n_heads, false).total * sizeof(float);
+    hipLaunchKernelGGL(trust_path_kernel<false>, dim3((unsigned)B), dim3(kWave), lds, (hipStream_t)stream, p, tr, a2_out);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }
 
-extern "C" int spex_trust_ce_f32(const float *table, int32_t n_users, const float *a2, const int64_t *targets, int32_t B, int32_t d,
-                                 float scale, const float *scale_dev, float *dscore, float *loss_b, float *loss_out,
-                                 int32_t loss_accumulate, float *grad_a2, float *grad_table, void *stream)
+extern "C" int spex_trust_head_train_f32(const float *table, int64_t n_rows, const float *params, const int64_t *seq,
+                                         const int64_t *seq_l, const int64_t *targets, int32_t B, int32_t L, int32_t d,
+                                         int32_t n_heads, int32_t hybrid, float scale, const float *scale_dev, float *a2,
+                                         float *dscore, float *loss_b, float *ws, float *loss_out, int32_t loss_accumulate,
+                                         float *grad_params, float *grad_table, void *stream)
 {
-    SPEX_CHECK_ARG(table && a2 && targets && dscore && loss_b && grad_a2 && grad_table, "spex_trust_ce_f32: NULL pointer");
-    SPEX_CHECK_ARG(B >= 0 && n_users >= 1, "spex_trust_ce_f32: B=%d n_users=%d", B, n_users);
-    if (d != kD) {
-        spex::set_error("spex_trust_ce_f32: needs hidden size 64 (got %d)", d);
-        return SPEX_ERR_UNSUPPORTED;
-    }
-    SPEX_CHECK_ARG((((uintptr_t)table | (uintptr_t)a2) & 15) == 0, "spex_trust_ce_f32: table and a2 must be 16-byte aligned");
+    if (int rc = check_head("spex_trust_head_train_f32", table, n_rows, params, seq, seq_l, B, L, d, n_heads)) return rc;
+    SPEX_CHECK_ARG(targets && a2 && dscore && loss_b && ws && grad_params && grad_table, "spex_trust_head_train_f32: NULL pointer");
+    SPEX_CHECK_ARG(n_rows >= 2, "spex_trust_head_train_f32: the table needs at least one user row besides the pad row");
+    SPEX_CHECK_ARG((((uintptr_t)a2 | (uintptr_t)ws) & 15) == 0, "spex_trust_head_train_f32: a2 and ws must be 16-byte aligned");
     if (B == 0) return SPEX_OK;
-    hipLaunchKernelGGL(trust_ce_kernel, dim3((unsigned)B), dim3(kCeThreads), 0, (hipStream_t)stream, table, n_users, a2, targets, B,
-                       scale, scale_dev, dscore, loss_b, grad_a2);
-    SPEX_HIP(hipGetLastError());
-    int blocks = (n_users + 3) / 4;
-    if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(trust_table_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dscore, a2, n_users, B,
-                       loss_b, grad_table, loss_out, loss_accumulate);
-    SPEX_HIP(hipGetLastError());
-    return SPEX_OK;
-}
-
-extern "C" int spex_trust_head_bwd_f32(const float *table, int64_t n_rows, const float *params, const int64_t *seq,
-                                       const int64_t *seq_l, int32_t B, int32_t L, int32_t d, int32_t n_heads, int32_t hybrid,
-                                       const float *ws, const float *grad_a2, float *grad_params, float *grad_table, void *stream)
-{
-    if (int rc = check_head("spex_trust_head_bwd_f32", table, n_rows, params, seq, seq_l, B, L, d, n_heads)) return rc;
-    SPEX_CHECK_ARG(ws && grad_a2 && grad_params && grad_table, "spex_trust_head_bwd_f32: NULL pointer");
-    if (B == 0) return SPEX_OK;
+    const int n_users = (int)(n_rows - 1);                           // logits against table[:-1]
     const TrustArgs p{table, n_rows, params, seq, seq_l, B, L, n_heads, hybrid};
-    const size_t lds = ((size_t)L * kD * 6 + (size_t)L * n_heads * kD * 2 + 4 * kD) * sizeof(float);
-    hipLaunchKernelGGL(trust_head_bwd_kernel, dim3((unsigned)B), dim3(kWave), lds, (hipStream_t)stream, p, ws, grad_a2, grad_params,
-                       grad_table);
+    const TrainArgs tr{targets, n_users, scale, scale_dev, a2, dscore, loss_b, ws, grad_table};
+    const size_t lds = (size_t)lds_layout(L, n_heads, true).total * sizeof(float);
+    SPEX_CHECK_ARG(lds <= 64 * 1024, "spex_trust_head_train_f32: LDS %zu bytes", lds);
+    hipLaunchKernelGGL(trust_path_kernel<true>, dim3((unsigned)B), dim3(kPathThreads), lds, (hipStream_t)stream, p, tr, a2);
+    SPEX_HIP(hipGetLastError());
+    ReduceArgs r{dscore, a2, loss_b, ws, seq_l, grad_table, grad_params, loss_out, n_users, B, L, n_heads, hybrid, loss_accumulate, 0, 0};
+    r.blocks_users = (n_users + 3) / 4 < 1024 ? (n_users + 3) / 4 : 1024;
+    r.blocks_mat = 64 + 16 * n_heads;
+    hipLaunchKernelGGL(trust_reduce_kernel, dim3((unsigned)(r.blocks_users + r.blocks_mat + 1)), dim3(256), 0, (hipStream_t)stream, r);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }

@@ -687,9 +687,10 @@ def trust_head_supported(d, L, n_heads):
     return d == 64 and 1 <= L <= 16 and 1 <= n_heads <= 4
 
 
-def trust_head_forward(table, params, seq, seq_l, n_heads, hybrid=True, ws=None):
+def trust_head_forward(table, params, seq, seq_l, n_heads, hybrid=True):
     """a2 [B, 64]: the readout vector whose product with the user table is the trust logits (model_expert_s.py:128-147 on
     top of :176-187), one launch.  params: the flat parameter block (layout in include/spex_hip.h)."""
+    table, params = table.contiguous(), params.contiguous()
     _need(table, "table"); _need(params, "params")
     dev = table.device
     seq, seq_l = _idx(seq, dev), _idx(seq_l, dev)
@@ -697,14 +698,14 @@ def trust_head_forward(table, params, seq, seq_l, n_heads, hybrid=True, ws=None)
     a2 = torch.empty((B, 64), dtype=torch.float32, device=dev)
     if B:
         _launch(dev, "spex_trust_head_fwd_f32", _ptr(table), table.shape[0], _ptr(params), _ptr(seq), _ptr(seq_l), B, L,
-                table.shape[1], n_heads, 1 if hybrid else 0, _ptr(a2), _ptr(ws))
+                table.shape[1], n_heads, 1 if hybrid else 0, _ptr(a2))
     return a2
 
 
 class TrustHeadLoss(torch.autograd.Function):
     """mean cross-entropy of the trust logits against `targets` — the whole trust branch of
-    model_expert_s.LightGCN.forward (flag 0), forward and backward, in four launches.  Like ScoreBCELoss the gradients
-    are produced by the forward; backward() scales them by the upstream scalar."""
+    model_expert_s.LightGCN.forward (flag 0), forward and backward, in two launches (spex_trust_head_train_f32).  Like
+    ScoreBCELoss the gradients are produced by the forward; backward() scales them by the upstream scalar."""
 
     @staticmethod
     def forward(ctx, table, params, seq, seq_l, targets, n_heads, hybrid):
@@ -718,19 +719,17 @@ class TrustHeadLoss(torch.autograd.Function):
             raise ValueError(f"trust head: parameter block of {params.numel()} floats, expected {trust_param_count(n_heads, d)}")
         if targets.numel() != B or seq_l.numel() != B:
             raise ValueError("trust head: seq_l / targets do not match the number of paths")
-        ws = torch.empty(int(_lib.load().spex_trust_workspace_floats(B, L, d, n_heads)), dtype=torch.float32, device=dev)
-        a2 = trust_head_forward(table, params, seq, seq_l, n_heads, hybrid, ws)
+        n_ws = int(_lib.load().spex_trust_workspace_floats(B, L, d, n_heads))
         n_users = n_rows - 1
-        scratch = torch.empty(B * n_users + B + B * d, dtype=torch.float32, device=dev)
-        dscore, loss_b, g_a2 = scratch[: B * n_users], scratch[B * n_users: B * n_users + B], scratch[B * n_users + B:]
+        scratch = torch.empty(B * d + n_ws + B * n_users + B, dtype=torch.float32, device=dev)     # a2 | ws | dscore | loss_b
+        a2, ws = scratch[: B * d], scratch[B * d: B * d + n_ws]
+        dscore, loss_b = scratch[B * d + n_ws: B * d + n_ws + B * n_users], scratch[B * d + n_ws + B * n_users:]
         loss = torch.zeros((), dtype=torch.float32, device=dev)
         g_table, g_params = torch.zeros_like(table), torch.zeros_like(params)
         if B:
-            hy = 1 if hybrid else 0
-            _launch(dev, "spex_trust_ce_f32", _ptr(table), n_users, _ptr(a2), _ptr(targets), B, d, 1.0, None, _ptr(dscore),
-                    _ptr(loss_b), _ptr(loss), 0, _ptr(g_a2), _ptr(g_table))
-            _launch(dev, "spex_trust_head_bwd_f32", _ptr(table), n_rows, _ptr(params), _ptr(seq), _ptr(seq_l), B, L, d, n_heads, hy,
-                    _ptr(ws), _ptr(g_a2), _ptr(g_params), _ptr(g_table))
+            _launch(dev, "spex_trust_head_train_f32", _ptr(table), n_rows, _ptr(params), _ptr(seq), _ptr(seq_l), _ptr(targets), B, L, d,
+                    n_heads, 1 if hybrid else 0, 1.0, None, _ptr(a2), _ptr(dscore), _ptr(loss_b), _ptr(ws), _ptr(loss), 0,
+                    _ptr(g_params), _ptr(g_table))
         ctx.save_for_backward(g_table, g_params)
         return loss
 

@@ -401,7 +401,7 @@ def train_epoch_ngcf(stepper, data, batch_size=None, pause_gc=True):
 class DualTaskStepper:
     """The dual-task training step (LightGCN_SPEX/code/main_auto_expert_s.py:63-89: rec branch + trust branch of
     utility1/model_expert_s.py, uncertainty-weighted loss, backward, torch Adam over every parameter) as ONE library call
-    of 14 launches on pre-allocated buffers (spex_dual_task_step_f32) — no autograd, no allocation, no host
+    of 2 L + 8 launches on pre-allocated buffers (spex_dual_task_step_f32) — no autograd, no allocation, no host
     synchronisation.  ≈2.7 ms per step through the reference-shaped autograd path in round 1, ≈1.0 ms with the fused
     trust head under autograd, and the GPU time of the launches here.
 
@@ -452,7 +452,7 @@ class DualTaskStepper:
         self.ws_fwd, self.ws_bwd = z(2, N, d), z(3, N, d)
         self.g_user, self.g_small = z(self.n_u, d), z(P + 512)
         T = self.path_capacity
-        self.a2, self.g_a2 = z(T, d), z(T, d)
+        self.a2 = z(T, d)
         self.trust_ws = z(max(1, int(_lib.load().spex_trust_workspace_floats(T, self.path_len, d, n_heads))))
         self.dscore, self.loss_b = z(T, self.n_u - 1), z(T)
         self.loss, self.loss_acc, self.precision = z(2), z(2), z(2, 2)
@@ -489,7 +489,7 @@ class DualTaskStepper:
                 graph=self.model.Graph._h.value, graph_t=self._graph_t._h.value, params=p(self.arena), m=p(self.m), v=p(self.v),
                 light=p(self.light), ws_fwd=p(self.ws_fwd), mixed=p(self.mixed), g_mixed=p(self.g_mixed), g_raw=p(self.g_raw),
                 g_prop=p(self.g_prop), g_E0=p(self.g_E0), ws_bwd=p(self.ws_bwd), g_user=p(self.g_user), g_small=p(self.g_small),
-                a2=p(self.a2), trust_ws=p(self.trust_ws), dscore=p(self.dscore), loss_b=p(self.loss_b), g_a2=p(self.g_a2),
+                a2=p(self.a2), trust_ws=p(self.trust_ws), dscore=p(self.dscore), loss_b=p(self.loss_b),
                 loss=p(self.loss), loss_acc=p(self.loss_acc), precision=p(self.precision), path_capacity=self.path_capacity,
                 path_len=self.path_len, n_user_rows=self.n_u, L=self.L, d=self.d, n_heads=self.n_heads,
                 hybrid=0 if self.model.nonhybrid else 1, n_rec=self.n_rec, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
