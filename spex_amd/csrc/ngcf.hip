@@ -565,6 +565,12 @@ __global__ __launch_bounds__(kWave *kGateWaves) void expert_gate_bwd_kernel(cons
     __syncthreads();
     const int wave_global = blockIdx.x * kGateWaves + (threadIdx.x >> 6);
     const int n_waves = gridDim.x * kGateWaves;
+    // a lane owns its columns of the parameter gradient: accumulated in registers over the wave's rows (d <= 256) and added
+    // to the workgroup's LDS copy once per wave — per-row LDS float atomics (~200 cycles per wave instruction) made this
+    // kernel 4x slower than the data it streams
+    constexpr int kCols = 4;
+    const bool in_regs = d <= kCols * kWave;
+    float acc[kCols][4] = {};
     for (int r = wave_global; r < n; r += n_waves) {
         float z0 = 0.0f, z1 = 0.0f, da0 = 0.0f, da1 = 0.0f;
         for (int c = lane; c < d; c += kWave) {
@@ -582,14 +588,42 @@ __global__ __launch_bounds__(kWave *kGateWaves) void expert_gate_bwd_kernel(cons
         const float a0 = e0 / (e0 + e1), a1 = e1 / (e0 + e1);
         const float dot = a0 * da0 + a1 * da1;
         const float dz0 = a0 * (da0 - dot), dz1 = a1 * (da1 - dot);
-        for (int c = lane; c < d; c += kWave) {
-            const float a = raw[(size_t)r * d + c], b = prop[(size_t)r * d + c], gg = g[(size_t)r * d + c];
-            d_raw[(size_t)r * d + c] = a0 * gg + dz0 * att[2 * c] + dz1 * att[2 * c + 1];
-            d_prop[(size_t)r * d + c] = a1 * gg + dz0 * att[2 * (d + c)] + dz1 * att[2 * (d + c) + 1];
-            atomicAdd(&s_datt[2 * c], a * dz0);
-            atomicAdd(&s_datt[2 * c + 1], a * dz1);
-            atomicAdd(&s_datt[2 * (d + c)], b * dz0);
-            atomicAdd(&s_datt[2 * (d + c) + 1], b * dz1);
+        if (in_regs) {
+#pragma unroll
+            for (int k = 0; k < kCols; ++k) {
+                const int c = lane + k * kWave;
+                if (c < d) {
+                    const float a = raw[(size_t)r * d + c], b = prop[(size_t)r * d + c], gg = g[(size_t)r * d + c];
+                    d_raw[(size_t)r * d + c] = a0 * gg + dz0 * att[2 * c] + dz1 * att[2 * c + 1];
+                    d_prop[(size_t)r * d + c] = a1 * gg + dz0 * att[2 * (d + c)] + dz1 * att[2 * (d + c) + 1];
+                    acc[k][0] = fmaf(a, dz0, acc[k][0]);
+                    acc[k][1] = fmaf(a, dz1, acc[k][1]);
+                    acc[k][2] = fmaf(b, dz0, acc[k][2]);
+                    acc[k][3] = fmaf(b, dz1, acc[k][3]);
+                }
+            }
+        } else {
+            for (int c = lane; c < d; c += kWave) {
+                const float a = raw[(size_t)r * d + c], b = prop[(size_t)r * d + c], gg = g[(size_t)r * d + c];
+                d_raw[(size_t)r * d + c] = a0 * gg + dz0 * att[2 * c] + dz1 * att[2 * c + 1];
+                d_prop[(size_t)r * d + c] = a1 * gg + dz0 * att[2 * (d + c)] + dz1 * att[2 * (d + c) + 1];
+                atomicAdd(&s_datt[2 * c], a * dz0);
+                atomicAdd(&s_datt[2 * c + 1], a * dz1);
+                atomicAdd(&s_datt[2 * (d + c)], b * dz0);
+                atomicAdd(&s_datt[2 * (d + c) + 1], b * dz1);
+            }
+        }
+    }
+    if (in_regs) {
+#pragma unroll
+        for (int k = 0; k < kCols; ++k) {
+            const int c = lane + k * kWave;
+            if (c < d) {
+                atomicAdd(&s_datt[2 * c], acc[k][0]);
+                atomicAdd(&s_datt[2 * c + 1], acc[k][1]);
+                atomicAdd(&s_datt[2 * (d + c)], acc[k][2]);
+                atomicAdd(&s_datt[2 * (d + c) + 1], acc[k][3]);
+            }
         }
     }
     __syncthreads();

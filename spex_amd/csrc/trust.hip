@@ -342,17 +342,22 @@ __device__ __forceinline__ void logits_ce(const TrustArgs &p, const TrainArgs &t
     const int sub = t & 15, grp = t >> 4;                        // 64 row groups of 16 lanes
     const float4 x = reinterpret_cast<const float4 *>(vec + 2 * kD)[sub];
     float mx = -INFINITY;
-    for (int u0 = 0; u0 < n_users; u0 += kPathThreads / 16) {
-        const int u = u0 + grp;
-        float part = 0.0f;
-        if (u < n_users) {
-            const float4 r = reinterpret_cast<const float4 *>(table + (size_t)u * kD)[sub];
-            part = fmaf(r.x, x.x, fmaf(r.y, x.y, fmaf(r.z, x.z, r.w * x.w)));
+    constexpr int kRows = kPathThreads / 16, kFly = 16;          // row groups per sweep; independent row loads in flight per lane
+    for (int u0 = 0; u0 < n_users; u0 += kRows * kFly) {
+        float4 r[kFly];
+#pragma unroll
+        for (int j = 0; j < kFly; ++j) {
+            const int u = u0 + j * kRows + grp;
+            r[j] = u < n_users ? reinterpret_cast<const float4 *>(table + (size_t)u * kD)[sub] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
-        const float sc = row16_sum_f32(part);
-        if (u < n_users) {
-            if (sub == 0) ds[u] = sc;
-            mx = fmaxf(mx, sc);
+#pragma unroll
+        for (int j = 0; j < kFly; ++j) {
+            const int u = u0 + j * kRows + grp;
+            const float sc = row16_sum_f32(fmaf(r[j].x, x.x, fmaf(r[j].y, x.y, fmaf(r[j].z, x.z, r[j].w * x.w))));
+            if (u < n_users) {
+                if (sub == 0) ds[u] = sc;
+                mx = fmaxf(mx, sc);
+            }
         }
     }
     mx = block_reduce(mx, red, true);                            // (its barriers also publish ds within the workgroup)
@@ -369,7 +374,17 @@ __device__ __forceinline__ void logits_ce(const TrustArgs &p, const TrainArgs &t
     __syncthreads();
     const int lane = t & 63, wv = t >> 6;
     float acc = 0.0f;
-    for (int u = wv; u < n_users; u += kPathWaves) acc = fmaf(ds[u], table[(size_t)u * kD + lane], acc);
+    for (int u0 = wv; u0 < n_users; u0 += kPathWaves * kFly) {
+        float dv[kFly], rv[kFly];
+#pragma unroll
+        for (int j = 0; j < kFly; ++j) {
+            const int u = u0 + j * kPathWaves;
+            dv[j] = u < n_users ? ds[u] : 0.0f;
+            rv[j] = u < n_users ? table[(size_t)u * kD + lane] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < kFly; ++j) acc = fmaf(dv[j], rv[j], acc);
+    }
     sacc[wv * kD + lane] = acc;
     __syncthreads();
     if (t < kD) {
@@ -509,6 +524,12 @@ __device__ __forceinline__ void backward_chain(const TrustArgs &p, const TrainAr
         W[wl.DR + i * kD + lane] = d;
         for (int hh = 0; hh < H; ++hh) W[wl.M + (i * H + hh) * kD + lane] = M[(i * H + hh) * kD + lane];
     }
+    for (int i = l; i < L; ++i) {            // rows of padded positions: zeros, so the reduce kernel walks B x L rows flat
+        W[wl.DU + i * kD + lane] = 0.0f;
+        W[wl.Hm + i * kD + lane] = 0.0f;
+        W[wl.DR + i * kD + lane] = 0.0f;
+        for (int hh = 0; hh < H; ++hh) W[wl.M + (i * H + hh) * kD + lane] = 0.0f;
+    }
     wave_sync();
     {
         float4 wr[16];
@@ -603,7 +624,16 @@ __global__ __launch_bounds__(256) void trust_reduce_kernel(const ReduceArgs a)
         const int lane = t & 63;
         for (int u = blk * 4 + (t >> 6); u < a.n_users; u += a.blocks_users * 4) {
             float acc = 0.0f;
-            for (int b = 0; b < a.B; ++b) acc = fmaf(a.dscore[(size_t)b * a.n_users + u], a.a2[(size_t)b * kD + lane], acc);
+            for (int b0 = 0; b0 < a.B; b0 += 8) {
+                float dv[8], xv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    dv[j] = b0 + j < a.B ? a.dscore[(size_t)(b0 + j) * a.n_users + u] : 0.0f;
+                    xv[j] = b0 + j < a.B ? a.a2[(size_t)(b0 + j) * kD + lane] : 0.0f;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc = fmaf(dv[j], xv[j], acc);
+            }
             a.grad_table[(size_t)u * kD + lane] += acc;
         }
         return;
@@ -630,14 +660,18 @@ __global__ __launch_bounds__(256) void trust_reduce_kernel(const ReduceArgs a)
             x = (blk - 64) * 4 + xs; offA = wl.M + x; offB = wl.DR + y; out = lo.w + x * kD + y; per_pos = true; ldA = a.H * kD;
         }
         float acc = 0.0f;
-        for (int b = 0; b < a.B; ++b) {
-            const float *W = a.ws + (size_t)b * wl.stride;
-            if (per_pos) {
-                const int l = clamp_len(a.seq_l[b], a.L);
-                for (int i = 0; i < l; ++i) acc = fmaf(W[offA + i * ldA], W[offB + i * kD], acc);
-            } else {
-                acc = fmaf(W[offA], W[offB], acc);
+        const int rows = per_pos ? a.B * a.L : a.B, per = per_pos ? a.L : 1;       // padded positions hold zeros
+        for (int r0 = 0; r0 < rows; r0 += 8) {
+            float av[8], bv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = r0 + j, b = r / per, i = r - b * per;
+                const float *W = a.ws + (size_t)b * wl.stride;
+                av[j] = r < rows ? W[offA + i * ldA] : 0.0f;
+                bv[j] = r < rows ? W[offB + i * kD] : 0.0f;
             }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = fmaf(av[j], bv[j], acc);
         }
         a.grad_P[out] = acc;
         return;
