@@ -278,6 +278,34 @@ def main():
                 nst.step(ub, ib, yb, loss_acc=nacc)
             aux["ngcf_stepper_step_ms_B256"] = time_events(lambda: nst.step(ub, ib, yb, loss_acc=nacc), 200)
             del net, opt, nst
+            # BASELINE configs[5]: the dual-task step (rec branch + expert gate + trust head over the shared user table +
+            # uncertainty-weighted loss + Adam over every parameter) as one library call; 15 synthetic paths per step
+            # (the reference driver's cap, 3 x trust_batch_size on Epinion2)
+            import os as _os, sys as _sys
+            _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "spex_amd", "dropin"))
+            import utility1.model_expert_s as mex
+            from spex_amd.trainer import DualTaskStepper
+
+            class _DS:                                   # what model_expert_s.LightGCN reads from its dataset
+                n_users, m_items = n_user, m_item
+                getSparseGraph = staticmethod(lambda: graph)
+            dargs = argparse.Namespace(hiddenSize=64, batchSize=100, nonhybrid=False, nb_heads=3, recdim=64, layer=L, keepprob=0.6,
+                                       A_split=False, dropout=0)
+            dnet = mex.LightGCN(dargs, _DS).to(dev)
+            T_PATHS, P_LEN = 15, 6
+            dst = DualTaskStepper(dnet, path_capacity=T_PATHS, path_len=P_LEN, lr=1e-3)
+            prng = np.random.default_rng(11)
+            plen = prng.integers(2, P_LEN + 1, T_PATHS)
+            pseq = np.full((T_PATHS, P_LEN), n_user, dtype=np.int64)
+            for r, l in enumerate(plen):
+                pseq[r, :l] = prng.choice(n_user, size=l, replace=False)
+            pseq_d, plen_d = torch.from_numpy(pseq).to(dev), torch.from_numpy(plen.astype(np.int64)).to(dev)
+            ptgt = torch.from_numpy(prng.integers(0, n_user, T_PATHS)).to(dev)
+            fn3 = lambda: dst.step(ub, ib, yb, pseq_d, plen_d, ptgt)
+            for _ in range(20):
+                fn3()
+            aux["dual_task_step_ms_B256_T15"] = time_events(fn3, 200)
+            del dnet, dst
         except Exception as e:  # never lose the headline line to an auxiliary measurement
             aux["aux_error"] = repr(e)
 
