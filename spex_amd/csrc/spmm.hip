@@ -257,7 +257,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
     const float *__restrict__ X, const uint32_t *__restrict__ chunk_off, const float *__restrict__ chunk_val,
     const uint32_t *__restrict__ chunk_mask, const int32_t *__restrict__ chunk_row, const int4 *__restrict__ task,
     int n_tasks, float *__restrict__ Y,
-    const float *__restrict__ epi_in, float epi_div, float out_div, float *__restrict__ acc_out,
+    const float *epi_in, float epi_div, float out_div, float *acc_out,   // may alias each other (running sum in place): no __restrict__
     float *__restrict__ partial,
     const DropArgs drop, const int xcd_contiguous)
 {
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
     const int4 t = task[tid];
     const int kind = t.w & 3;
     const float *__restrict__ Xl = X + lane;
-    const float *__restrict__ El = (EPI ? epi_in : X) + lane;
+    const float *El = (EPI ? epi_in : X) + lane;
     int row = t.z;
     float acc = 0.0f;
 
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_wide_kernel(
     const float *__restrict__ X, const uint32_t *__restrict__ chunk_off, const float *__restrict__ chunk_val,
     const uint32_t *__restrict__ chunk_mask, const int32_t *__restrict__ chunk_row, const int4 *__restrict__ task,
     int n_tasks, float *__restrict__ Y,
-    const float *__restrict__ epi_in, float epi_div, float out_div, float *__restrict__ acc_out,
+    const float *epi_in, float epi_div, float out_div, float *acc_out,   // may alias each other (running sum in place): no __restrict__
     float *__restrict__ partial,
     const DropArgs drop, const int xcd_contiguous)
 {
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_wide_kernel(
     const int4 t = task[tid];
     const int kind = t.w & 3;
     const float *__restrict__ Xl = X + lane * V;
-    const float *__restrict__ El = (EPI ? epi_in : X) + lane * V;
+    const float *El = (EPI ? epi_in : X) + lane * V;
     int row = t.z;
     vec acc = (vec)(0.0f);
 
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_rowlist_kernel(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
     const float *__restrict__ X, const int64_t *__restrict__ idx_a, int n_a, int64_t off_a,
     const int64_t *__restrict__ idx_b, int64_t off_b, int32_t n_rows, float *__restrict__ Y,
-    const float *__restrict__ acc_in, float *__restrict__ acc_out, float acc_div)
+    const float *acc_in, float *acc_out, float acc_div)   // documented NOT to alias for duplicates, but kept unqualified
 {
     __shared__ float s_part[kWgWaves][kWave];
     const int lane = threadIdx.x & (kWave - 1);
