@@ -26,11 +26,13 @@ _u8p = ctypes.POINTER(ctypes.c_uint8)
 
 
 def build(force=False):
-    so = os.path.join(_HERE, "libspex_oracle.so")
+    """Build (if stale) and return the oracle library.  SPEX_ORACLE_SANITIZE=1 selects the AddressSanitizer +
+    UndefinedBehaviorSanitizer build (`make sanitize`; run under LD_PRELOAD=libasan — tests/test_oracle_sanitized.py)."""
+    target = "libspex_oracle_san.so" if os.environ.get("SPEX_ORACLE_SANITIZE") == "1" else "libspex_oracle.so"
+    so = os.path.join(_HERE, target)
     src = os.path.join(_HERE, "spex_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s", "libspex_oracle.so"], check=True,
-                       stdout=subprocess.DEVNULL)
+        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s", target], check=True, stdout=subprocess.DEVNULL)
     return so
 
 
@@ -119,7 +121,8 @@ def spmm(rowptr, col, val, X, n_threads=1):
 def spmm_masked(rowptr, col, val, keep, keep_prob, X):
     """__dropout_x (model.py:46-55) + sparse.mm (model.py:91) with an injected keep mask."""
     rowptr, col, val, X = _c(rowptr, np.int32), _c(col, np.int32), _c(val, np.float32), _c(X, np.float32)
-    keep = _c(keep, np.uint8)
+    keep = _c(keep, np.uint8).ravel()
+    assert keep.size == col.size, f"keep mask of {keep.size} entries for {col.size} stored entries"
     n, d = len(rowptr) - 1, X.shape[1]
     Y = np.empty((n, d), np.float32)
     lib().spex_oracle_spmm_csr_masked_f32(_p(rowptr, _i32p), _p(col, _i32p), _p(val, _f32p), _p(keep, _u8p),
