@@ -315,6 +315,24 @@ int spex_expert_gate_f32(const float *raw, const float *prop, const float *att_e
 int spex_expert_gate_bwd_f32(const float *raw, const float *prop, const float *att_exp, const float *grad_mixed,
                              float *grad_raw, float *grad_prop, float *grad_att, int32_t n, int32_t d, void *stream);
 
+/* The gate at a batch's rows only (the training loss reads the gated tables nowhere else, model_expert_s.py:163-166), d == 64.
+ * Slot k names table row r = idx_a[k] + off_a (k < n_a) or idx_b[k - n_a] + off_b (raw / prop: [n_rows, 64] tables holding
+ * users then items); rows below n_user_rows are gated with att_u (att_exp1), the others with att_i (att_exp2).
+ *   forward : mixed_slots[k, :] = the gated row (compact [n_a + n_b, 64]); an out-of-range row gives zeros.
+ *   backward: grad_slots[k, :] = d loss / d mixed_slots[k] (row stride ld_slots) ->
+ *             grad_prop_slots[k, :] (compact, what spex_spmm_push_batch_f32 consumes) and, ACCUMULATED with atomics (zero them
+ *             first): grad_prop[r, :] += d prop, grad_raw[r, :] += d raw (dense [n_rows, 64]), grad_att_u / grad_att_i ([128, 2]).
+ *             A row named by several slots is handled once per slot (the gate's backward is linear in the incoming gradient).
+ */
+int spex_expert_gate_rows_f32(const float *raw, const float *prop, const float *att_u, const float *att_i, const int64_t *idx_a,
+                              int32_t n_a, int64_t off_a, const int64_t *idx_b, int32_t n_b, int64_t off_b, int64_t n_user_rows,
+                              int64_t n_rows, int32_t d, float *mixed_slots, void *stream);
+int spex_expert_gate_rows_bwd_f32(const float *raw, const float *prop, const float *att_u, const float *att_i, const int64_t *idx_a,
+                                  int32_t n_a, int64_t off_a, const int64_t *idx_b, int32_t n_b, int64_t off_b,
+                                  int64_t n_user_rows, int64_t n_rows, int32_t d, const float *grad_slots, int32_t ld_slots,
+                                  float *grad_prop_slots, float *grad_prop, float *grad_raw, float *grad_att_u, float *grad_att_i,
+                                  void *stream);
+
 /* ------------------------------------------------------------------------------------------------ negative sampler
  * Replaces LightTrainData.ng_sample, LightGCN_SPEX/code/utility1/dataloader.py:250-265 (distribution, not stream):
  * for each of n_pos positives (user d_pos_user[p]) draw num_ng items uniformly from [0, num_item), redrawing while the
@@ -471,32 +489,36 @@ int spex_ngcf_step_bce_f32(spex_ngcf_step_t *step, const int64_t *users, const i
                            float *loss_sum, void *stream);
 
 /* The dual-task training step of LightGCN_SPEX/code/main_auto_expert_s.py:63-89 (model_expert_s.LightGCN.forward flag 0 +
- * uncertainty-weighted loss + loss.backward() + optimizer.step()) as one call issuing 2 L + 8 launches:
- *   spex_propagate_f32 (L) -> 2 x spex_expert_gate_f32 -> spex_score_bce_f32 -> 2 x spex_expert_gate_bwd_f32 ->
- *   spex_propagate_bwd_f32 (L) -> spex_trust_head_train_f32 (2) -> one Adam pass over
- *   the whole parameter arena, which applies the task precisions exp(-2 s_k) to the two branches' gradients, forms the
- *   task weights' own gradients (d/ds0 = -2 p1 loss1 + 2 (n_rec + 1) B, d/ds1 = -2 p2 loss2 + T) and clears every
- *   accumulate-into buffer for the next step.
+ * uncertainty-weighted loss + loss.backward() + optimizer.step()) as one call issuing 2 L + 7 launches:
+ *   rec branch, row-sparse like spex_lightgcn_step_bce_f32: (L-1) x spex_spmm_f32 + spex_spmm_rowlist_f32 (last layer at the
+ *   batch's rows) -> spex_expert_gate_rows_f32 -> spex_score_bce_slots_f32 on the 2B gated rows -> spex_expert_gate_rows_bwd_f32
+ *   -> spex_spmm_push_batch_f32 -> (L-1) x spex_spmm_f32 on A^T;   trust branch: spex_trust_head_train_f32 (2 launches);
+ *   then one Adam pass over the whole parameter arena, which applies the task precisions exp(-2 s_k) to the two branches'
+ *   gradients, forms the task weights' own gradients (d/ds0 = -2 p1 loss1 + 2 (n_rec + 1) B, d/ds1 = -2 p2 loss2 + T) and
+ *   clears every accumulate-into buffer for the next step.
  * params / m / v: ONE arena (and its two Adam moments), N = graph rows, P = spex_trust_param_count(64, n_heads):
  *   [ table N*64 (users incl. pad row, then items) | trust block P | att_exp1 256 | att_exp2 256 | task_weights 2 ]
- * Work buffers (caller-owned): light, mixed, g_mixed, g_raw, g_prop, g_E0: [N, 64]; ws_fwd [2, N, 64]; ws_bwd [3, N, 64];
+ * Work buffers (caller-owned): light, lo_batch, g_prop, g_raw, g_E0: [N, 64]; ws_fwd [2, N, 64]; ws_bwd [3, N, 64];
+ *   mixed_slots, grad_slots, g_prop_slots: [slot_capacity, 64] with slot_capacity >= 2B; arange: int64 [slot_capacity] = 0, 1, ..;
  *   g_user [n_user_rows, 64]; g_small [P + 512]; a2 [path_capacity, 64]; trust_ws
  *   [spex_trust_workspace_floats(path_capacity, path_len, 64, n_heads)]; dscore [path_capacity, n_user_rows - 1];
  *   loss_b [path_capacity]; loss [2], loss_acc [2], precision [2][2].
- * Before the first call: g_mixed, g_user, g_small, loss all-zero (every call leaves them so); precision[(t + 1) & 1] =
- * {exp(-2 s0), exp(-2 s1)} for the current task weights (every call writes the next step's slot).  loss_acc accumulates
- * (loss1, loss2) of every call — what Train() sums with .item() per step.  t is advanced by the call.
+ * Before the first call: g_prop, g_raw, the first [N, 64] of ws_bwd, g_user, g_small, loss all-zero (every call leaves them
+ * so); precision[(t + 1) & 1] = {exp(-2 s0), exp(-2 s1)} for the current task weights (every call writes the next step's
+ * slot).  loss_acc accumulates (loss1, loss2) of every call — what Train() sums with .item() per step.  t is advanced.
  * seq: [T, path_len] int64 padded with the pad row's index n_user_rows - 1; T == 0 skips the trust branch (the reference
- * would produce NaN there: CrossEntropyLoss over an empty batch).
+ * would produce NaN there: CrossEntropyLoss over an empty batch).  L >= 1, no edge dropout.
  */
 typedef struct spex_dual_task_step {
     const spex_graph_t *graph, *graph_t;
     float *params, *m, *v;
-    float *light, *ws_fwd, *mixed, *g_mixed, *g_raw, *g_prop, *g_E0, *ws_bwd;
+    float *light, *ws_fwd, *lo_batch, *g_prop, *g_raw, *g_E0, *ws_bwd;
+    float *mixed_slots, *grad_slots, *g_prop_slots;
+    const int64_t *arange;
     float *g_user, *g_small;
     float *a2, *trust_ws, *dscore, *loss_b;
     float *loss, *loss_acc, *precision;
-    int32_t path_capacity, path_len, n_user_rows, L, d, n_heads, hybrid, n_rec;
+    int32_t slot_capacity, path_capacity, path_len, n_user_rows, L, d, n_heads, hybrid, n_rec;
     float lr, beta1, beta2, eps;
     int32_t t;
 } spex_dual_task_step_t;

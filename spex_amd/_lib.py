@@ -59,6 +59,10 @@ SIGNATURES = {
     "spex_spmm_push_rows_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_f32, c_vp, c_i32, c_vp]),
     "spex_expert_gate_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "spex_expert_gate_bwd_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "spex_expert_gate_rows_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_i64, c_i64, c_i32, c_vp,
+                                                 c_vp]),
+    "spex_expert_gate_rows_bwd_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_i64, c_i64, c_i32,
+                                                     c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "spex_sample_negatives": (ctypes.c_int, [c_vp, c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, ctypes.c_uint64, c_vp, c_vp]),
     "spex_graph_set_values": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp]),
     "spex_sddmm_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),
@@ -106,10 +110,11 @@ class NGCFStepDesc(ctypes.Structure):
 
 class DualTaskStepDesc(ctypes.Structure):
     """spex_dual_task_step_t (include/spex_hip.h)."""
-    _fields_ = ([(n, c_vp) for n in ("graph", "graph_t", "params", "m", "v", "light", "ws_fwd", "mixed", "g_mixed", "g_raw", "g_prop",
-                                     "g_E0", "ws_bwd", "g_user", "g_small", "a2", "trust_ws", "dscore", "loss_b", "loss",
-                                     "loss_acc", "precision")]
-                + [(n, c_i32) for n in ("path_capacity", "path_len", "n_user_rows", "L", "d", "n_heads", "hybrid", "n_rec")]
+    _fields_ = ([(n, c_vp) for n in ("graph", "graph_t", "params", "m", "v", "light", "ws_fwd", "lo_batch", "g_prop", "g_raw", "g_E0",
+                                     "ws_bwd", "mixed_slots", "grad_slots", "g_prop_slots", "arange", "g_user", "g_small", "a2",
+                                     "trust_ws", "dscore", "loss_b", "loss", "loss_acc", "precision")]
+                + [(n, c_i32) for n in ("slot_capacity", "path_capacity", "path_len", "n_user_rows", "L", "d", "n_heads", "hybrid",
+                                        "n_rec")]
                 + [(n, c_f32) for n in ("lr", "beta1", "beta2", "eps")] + [("t", c_i32)])
 
 

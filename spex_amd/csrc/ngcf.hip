@@ -630,6 +630,95 @@ __global__ __launch_bounds__(kWave *kGateWaves) void expert_gate_bwd_kernel(cons
     for (int k = threadIdx.x; k < 4 * d; k += blockDim.x) atomicAdd(d_att + k, s_datt[k]);
 }
 
+// The gate at a batch's rows only — the training loss reads the gated tables nowhere else (model_expert_s.py:163-166), so
+// the dual-task step gates <= 2B rows instead of all N.  Slot k names row r = idx_a[k] + off_a (k < n_a) or
+// idx_b[k - n_a] + off_b; rows below n_user_rows use att_u, the others att_i.  d == 64 (lane == column); same arithmetic
+// order as expert_gate_kernel.
+__global__ __launch_bounds__(kWave *kWavesPerBlock) void expert_gate_rows_kernel(
+    const float *__restrict__ raw, const float *__restrict__ prop, const float *__restrict__ att_u, const float *__restrict__ att_i,
+    const int64_t *__restrict__ idx_a, int n_a, int64_t off_a, const int64_t *__restrict__ idx_b, int n_b, int64_t off_b,
+    int64_t n_user_rows, int64_t n_rows, float *__restrict__ mixed_c)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int slot = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (slot >= n_a + n_b) return;
+    const long long r = batch_row(idx_a, n_a, off_a, idx_b, off_b, slot);
+    if (r < 0 || r >= n_rows) {                      // never gather out of bounds; the scoring kernel skips nothing here
+        mixed_c[(size_t)slot * 64 + lane] = 0.0f;
+        return;
+    }
+    const float *att = r < n_user_rows ? att_u : att_i;
+    const float a = raw[(size_t)r * 64 + lane], b = prop[(size_t)r * 64 + lane];
+    float z0 = 0.0f, z1 = 0.0f;
+    z0 = fmaf(a, att[2 * lane], z0);
+    z1 = fmaf(a, att[2 * lane + 1], z1);
+    z0 = fmaf(b, att[2 * (64 + lane)], z0);
+    z1 = fmaf(b, att[2 * (64 + lane) + 1], z1);
+    z0 = wave_sum(z0);
+    z1 = wave_sum(z1);
+    const float mx = fmaxf(z0, z1);
+    const float e0 = expf(z0 - mx), e1 = expf(z1 - mx);
+    const float a0 = e0 / (e0 + e1), a1 = e1 / (e0 + e1);
+    mixed_c[(size_t)slot * 64 + lane] = a * a0 + b * a1;
+}
+
+// Its backward, slot by slot (the gate's Jacobian is linear in the incoming gradient, so a row named by several slots is
+// simply handled once per slot): g_slots[k] = d loss / d mixed_c[k] ->
+//   d_prop_c[k] (compact, the push-form A^T product reads it), and with atomics g_prop[r] += d prop, g_raw[r] += d raw (dense
+//   tables, zeroed by the caller), g_att_u / g_att_i += the two gate matrices' gradients (register accumulators per wave).
+__global__ __launch_bounds__(kWave *kGateWaves) void expert_gate_rows_bwd_kernel(
+    const float *__restrict__ raw, const float *__restrict__ prop, const float *__restrict__ att_u, const float *__restrict__ att_i,
+    const int64_t *__restrict__ idx_a, int n_a, int64_t off_a, const int64_t *__restrict__ idx_b, int n_b, int64_t off_b,
+    int64_t n_user_rows, int64_t n_rows, const float *__restrict__ g_slots, int ld_g, float *__restrict__ d_prop_c, float *g_prop,
+    float *g_raw, float *g_att_u, float *g_att_i)
+{
+    __shared__ float s_att[2][256];
+    const int lane = threadIdx.x & (kWave - 1);
+    for (int k = threadIdx.x; k < 512; k += blockDim.x) (&s_att[0][0])[k] = 0.0f;
+    __syncthreads();
+    float acc[2][4] = {};
+    const int n = n_a + n_b;
+    for (int slot = blockIdx.x * kGateWaves + (threadIdx.x >> 6); slot < n; slot += gridDim.x * kGateWaves) {
+        const long long r = batch_row(idx_a, n_a, off_a, idx_b, off_b, slot);
+        if (r < 0 || r >= n_rows) {
+            d_prop_c[(size_t)slot * 64 + lane] = 0.0f;
+            continue;
+        }
+        const int which = r < n_user_rows ? 0 : 1;
+        const float *att = which ? att_i : att_u;
+        const float a = raw[(size_t)r * 64 + lane], b = prop[(size_t)r * 64 + lane], gg = g_slots[(size_t)slot * ld_g + lane];
+        const float w00 = att[2 * lane], w01 = att[2 * lane + 1], w10 = att[2 * (64 + lane)], w11 = att[2 * (64 + lane) + 1];
+        float z0 = fmaf(b, w10, fmaf(a, w00, 0.0f)), z1 = fmaf(b, w11, fmaf(a, w01, 0.0f));
+        z0 = wave_sum(z0); z1 = wave_sum(z1);
+        const float da0 = wave_sum(gg * a), da1 = wave_sum(gg * b);
+        const float mx = fmaxf(z0, z1);
+        const float e0 = expf(z0 - mx), e1 = expf(z1 - mx);
+        const float a0 = e0 / (e0 + e1), a1 = e1 / (e0 + e1);
+        const float dot = a0 * da0 + a1 * da1;
+        const float dz0 = a0 * (da0 - dot), dz1 = a1 * (da1 - dot);
+        const float d_raw = a0 * gg + dz0 * w00 + dz1 * w01, d_prop = a1 * gg + dz0 * w10 + dz1 * w11;
+        d_prop_c[(size_t)slot * 64 + lane] = d_prop;
+        atomicAdd(g_prop + (size_t)r * 64 + lane, d_prop);
+        atomicAdd(g_raw + (size_t)r * 64 + lane, d_raw);
+        acc[which][0] = fmaf(a, dz0, acc[which][0]);
+        acc[which][1] = fmaf(a, dz1, acc[which][1]);
+        acc[which][2] = fmaf(b, dz0, acc[which][2]);
+        acc[which][3] = fmaf(b, dz1, acc[which][3]);
+    }
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        atomicAdd(&s_att[w][2 * lane], acc[w][0]);
+        atomicAdd(&s_att[w][2 * lane + 1], acc[w][1]);
+        atomicAdd(&s_att[w][2 * (64 + lane)], acc[w][2]);
+        atomicAdd(&s_att[w][2 * (64 + lane) + 1], acc[w][3]);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 256; k += blockDim.x) {
+        if (s_att[0][k] != 0.0f) atomicAdd(g_att_u + k, s_att[0][k]);
+        if (s_att[1][k] != 0.0f) atomicAdd(g_att_i + k, s_att[1][k]);
+    }
+}
+
 inline unsigned grid_for_rows(int n)
 {
     int64_t blocks = ((int64_t)n + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -766,6 +855,50 @@ extern "C" int spex_expert_gate_bwd_f32(const float *raw, const float *prop, con
     if (blocks > 256) blocks = 256;                         // one workgroup per CU: 256 x 4d parameter-gradient atomics
     hipLaunchKernelGGL(expert_gate_bwd_kernel, dim3((unsigned)blocks), dim3(kWave * kGateWaves), (size_t)d * 4 * sizeof(float),
                        (hipStream_t)stream, raw, prop, att_exp, grad_mixed, grad_raw, grad_prop, grad_att, n, d);
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}
+
+extern "C" int spex_expert_gate_rows_f32(const float *raw, const float *prop, const float *att_u, const float *att_i,
+                                         const int64_t *idx_a, int32_t n_a, int64_t off_a, const int64_t *idx_b, int32_t n_b,
+                                         int64_t off_b, int64_t n_user_rows, int64_t n_rows, int32_t d, float *mixed_c, void *stream)
+{
+    SPEX_CHECK_ARG(raw && prop && att_u && att_i && mixed_c && (idx_a || n_a == 0) && (idx_b || n_b == 0),
+                   "spex_expert_gate_rows_f32: NULL pointer");
+    SPEX_CHECK_ARG(n_a >= 0 && n_b >= 0 && n_rows >= 0, "spex_expert_gate_rows_f32: negative size");
+    if (d != 64) {
+        spex::set_error("spex_expert_gate_rows_f32: d = %d (the row form needs d == 64)", d);
+        return SPEX_ERR_UNSUPPORTED;
+    }
+    const int n = n_a + n_b;
+    if (n == 0) return SPEX_OK;
+    hipLaunchKernelGGL(expert_gate_rows_kernel, dim3((unsigned)((n + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kWave * kWavesPerBlock), 0,
+                       (hipStream_t)stream, raw, prop, att_u, att_i, idx_a, n_a, off_a, idx_b, n_b, off_b, n_user_rows, n_rows, mixed_c);
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}
+
+extern "C" int spex_expert_gate_rows_bwd_f32(const float *raw, const float *prop, const float *att_u, const float *att_i,
+                                             const int64_t *idx_a, int32_t n_a, int64_t off_a, const int64_t *idx_b, int32_t n_b,
+                                             int64_t off_b, int64_t n_user_rows, int64_t n_rows, int32_t d, const float *grad_slots,
+                                             int32_t ld_slots, float *grad_prop_slots, float *grad_prop, float *grad_raw,
+                                             float *grad_att_u, float *grad_att_i, void *stream)
+{
+    SPEX_CHECK_ARG(raw && prop && att_u && att_i && grad_slots && grad_prop_slots && grad_prop && grad_raw && grad_att_u && grad_att_i
+                       && (idx_a || n_a == 0) && (idx_b || n_b == 0),
+                   "spex_expert_gate_rows_bwd_f32: NULL pointer");
+    SPEX_CHECK_ARG(n_a >= 0 && n_b >= 0 && n_rows >= 0 && ld_slots >= 64, "spex_expert_gate_rows_bwd_f32: bad size");
+    if (d != 64) {
+        spex::set_error("spex_expert_gate_rows_bwd_f32: d = %d (the row form needs d == 64)", d);
+        return SPEX_ERR_UNSUPPORTED;
+    }
+    const int n = n_a + n_b;
+    if (n == 0) return SPEX_OK;
+    int blocks = (n + kGateWaves - 1) / kGateWaves;
+    if (blocks > 64) blocks = 64;
+    hipLaunchKernelGGL(expert_gate_rows_bwd_kernel, dim3((unsigned)blocks), dim3(kWave * kGateWaves), 0, (hipStream_t)stream, raw, prop, att_u,
+                       att_i, idx_a, n_a, off_a, idx_b, n_b, off_b, n_user_rows, n_rows, grad_slots, ld_slots, grad_prop_slots, grad_prop,
+                       grad_raw, grad_att_u, grad_att_i);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }

@@ -134,12 +134,12 @@ extern "C" int spex_adam_step_sum_f32(float *p, const float *g_parts, int32_t n_
 //   task weights: d/ds0 = -2 p1 loss1 + 2 (n_rec + 1) B,  d/ds1 = -2 p2 loss2 + T
 // p1, p2 are read from prec[t & 1] (a snapshot: the thread that updates the task weights writes exp(-2 s_new) into the
 // other slot for the next step, so no thread reads a weight another one is updating).  The same pass clears every
-// accumulate-into buffer of the next step (g_mixed, g_user, g_small, the step's loss cells).
+// accumulate-into buffer of the next step (g_raw, g_prop, the push target, g_user, g_small, the step's loss cells).
 namespace {
 struct DualAdamArgs {
     float *p, *m, *v;
     const float *g_E0, *g_raw;
-    float *g_user, *g_small, *g_mixed;
+    float *g_raw_w, *g_user, *g_small, *g_prop, *push_zero;     // cleared as they are read (push_zero may be NULL)
     float *loss, *loss_acc, *prec;
     int64_t n_table, n_user, n_trust, n_total;     // floats: table, user rows of it, trust block, whole arena (excl. padding)
     int32_t B, T, n_rec, slot;
@@ -159,7 +159,9 @@ __global__ __launch_bounds__(256) void dual_task_adam_kernel(const DualAdamArgs 
                 g = fmaf(p2, a.g_user[i], g);
                 a.g_user[i] = 0.0f;
             }
-            a.g_mixed[i] = 0.0f;
+            a.g_raw_w[i] = 0.0f;
+            a.g_prop[i] = 0.0f;
+            if (a.push_zero) a.push_zero[i] = 0.0f;
         } else {
             const int64_t j = i - a.n_table;
             g = (j < a.n_trust ? p2 : p1) * a.g_small[j];
@@ -187,12 +189,13 @@ __global__ __launch_bounds__(256) void dual_task_adam_kernel(const DualAdamArgs 
 }
 }  // namespace
 
-int spex::dual_task_adam(float *p, float *m, float *v, const float *g_E0, const float *g_raw, float *g_user, float *g_small,
-                         float *g_mixed, float *loss, float *loss_acc, float *prec, int64_t n_table, int64_t n_user, int64_t n_trust,
+int spex::dual_task_adam(float *p, float *m, float *v, const float *g_E0, float *g_raw, float *g_user, float *g_small,
+                         float *g_prop, float *push_zero, float *loss, float *loss_acc, float *prec, int64_t n_table, int64_t n_user,
+                         int64_t n_trust,
                          int32_t B, int32_t T, int32_t n_rec, int32_t t, float lr, float beta1, float beta2, float eps, void *stream)
 {
     const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
-    const DualAdamArgs a{p, m, v, g_E0, g_raw, g_user, g_small, g_mixed, loss, loss_acc, prec, n_table, n_user, n_trust,
+    const DualAdamArgs a{p, m, v, g_E0, g_raw, g_raw, g_user, g_small, g_prop, push_zero, loss, loss_acc, prec, n_table, n_user, n_trust,
                          n_table + n_trust + 512 + 2, B, T, n_rec, t & 1, 1.0f - beta1, beta2, 1.0f - beta2, (float)sqrt(bc2), eps,
                          (float)((double)lr / bc1)};
     int64_t blocks = (n_table + n_trust + 512 + 255) / 256;

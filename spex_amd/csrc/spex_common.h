@@ -13,8 +13,8 @@ void set_error(const char *fmt, ...);
 int adam_step_z2(float *p, const float *g, float *m, float *v, int64_t n, int32_t t, float lr, float beta1, float beta2, float eps,
                  float *zero_buf, float *zero_buf2, void *stream);   // optim.hip: spex_adam_step_f32 with a second buffer to clear
 
-int dual_task_adam(float *p, float *m, float *v, const float *g_E0, const float *g_raw, float *g_user, float *g_small,
-                   float *g_mixed, float *loss, float *loss_acc, float *prec, int64_t n_table, int64_t n_user, int64_t n_trust,
+int dual_task_adam(float *p, float *m, float *v, const float *g_E0, float *g_raw, float *g_user, float *g_small, float *g_prop,
+                   float *push_zero, float *loss, float *loss_acc, float *prec, int64_t n_table, int64_t n_user, int64_t n_trust,
                    int32_t B, int32_t T, int32_t n_rec, int32_t t, float lr, float beta1, float beta2, float eps,
                    void *stream);   // optim.hip: Adam over the dual-task parameter arena (spex_dual_task_step_f32)
 

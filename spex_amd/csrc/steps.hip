@@ -102,13 +102,14 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
                                        int32_t B, const int64_t *seq, const int64_t *seq_l, const int64_t *targets, int32_t T,
                                        void *stream)
 {
-    SPEX_CHECK_ARG(s && s->graph && s->graph_t && s->params && s->m && s->v && s->light && s->ws_fwd && s->mixed && s->g_mixed
-                       && s->g_raw && s->g_prop && s->g_E0 && s->ws_bwd && s->g_user && s->g_small && s->a2 && s->trust_ws && s->dscore
-                       && s->loss_b && s->loss && s->loss_acc && s->precision,
+    SPEX_CHECK_ARG(s && s->graph && s->graph_t && s->params && s->m && s->v && s->light && s->ws_fwd && s->lo_batch && s->g_prop
+                       && s->g_raw && s->g_E0 && s->ws_bwd && s->mixed_slots && s->grad_slots && s->g_prop_slots && s->arange && s->g_user
+                       && s->g_small && s->a2 && s->trust_ws && s->dscore && s->loss_b && s->loss && s->loss_acc && s->precision,
                    "spex_dual_task_step_f32: NULL field in the step descriptor");
     SPEX_CHECK_ARG(users && items && labels && B >= 1, "spex_dual_task_step_f32: NULL batch pointer or B < 1");
     SPEX_CHECK_ARG(T >= 0 && T <= s->path_capacity && (T == 0 || (seq && seq_l && targets)),
                    "spex_dual_task_step_f32: T=%d paths (capacity %d) or NULL path pointer", T, s->path_capacity);
+    SPEX_CHECK_ARG(s->slot_capacity >= 2 * B, "spex_dual_task_step_f32: slot capacity %d < 2 B = %d", s->slot_capacity, 2 * B);
     const spex_graph *g = s->graph, *gt = s->graph_t;
     const int32_t d = 64, N = g->n_rows, n_u = s->n_user_rows, L = s->L, H = s->n_heads;
     SPEX_CHECK_ARG(g->n_rows == g->n_cols && gt->n_rows == N && gt->n_cols == N, "spex_dual_task_step_f32: square graphs of one size");
@@ -116,28 +117,47 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
     SPEX_CHECK_ARG(g->mask_mode == 0 && gt->mask_mode == 0, "spex_dual_task_step_f32: edge dropout is not supported in the one-call step");
     const int64_t n_trust = spex_trust_param_count(d, H);
     SPEX_CHECK_ARG(n_trust > 0, "spex_dual_task_step_f32: unsupported number of heads %d", H);
-    const size_t n_table = (size_t)N * d, off_u = (size_t)n_u * d;
-    float *E0 = s->params, *trust_p = E0 + n_table, *att1 = trust_p + n_trust, *att2 = att1 + 4 * d;
+    const size_t sz = (size_t)N * d, off_u = (size_t)n_u * d;
+    float *E0 = s->params, *trust_p = E0 + sz, *att1 = trust_p + n_trust, *att2 = att1 + 4 * d;
     float *g_att1 = s->g_small + n_trust, *g_att2 = g_att1 + 4 * d;
-    // ---- rec branch forward: propagation (model_expert_s.py:95-126), two-expert gate (:154-161), dot + BCE (:163-168)
-    SPEX_TRY(spex_propagate_f32(g, E0, s->light, nullptr, s->ws_fwd, L, d, stream));
-    SPEX_TRY(spex_expert_gate_f32(E0, s->light, att1, s->mixed, n_u, d, stream));
-    SPEX_TRY(spex_expert_gate_f32(E0 + off_u, s->light + off_u, att2, s->mixed + off_u, N - n_u, d, stream));
-    SPEX_TRY(spex_score_bce_f32(s->mixed, s->mixed + off_u, d, d, n_u, N - n_u, users, items, labels, B, d, nullptr, s->loss,
-                                s->g_mixed, s->g_mixed + off_u, 1.0f / (float)B, stream));
-    // ---- rec branch backward (gradients of the UNWEIGHTED loss1; the precisions are applied in the Adam pass)
-    SPEX_TRY(spex_expert_gate_bwd_f32(E0, s->light, att1, s->g_mixed, s->g_raw, s->g_prop, g_att1, n_u, d, stream));
-    SPEX_TRY(spex_expert_gate_bwd_f32(E0 + off_u, s->light + off_u, att2, s->g_mixed + off_u, s->g_raw + off_u, s->g_prop + off_u,
-                                      g_att2, N - n_u, d, stream));
-    SPEX_TRY(spex_propagate_bwd_f32(gt, s->g_prop, s->g_E0, s->ws_bwd, L, d, stream));
+    // ---- rec branch forward (model_expert_s.py:95-126,154-168): layers 1 .. L-1 over the whole graph, the last layer, the gate and
+    //      the scores only at the batch's rows
+    const float *cur = E0;
+    for (int32_t l = 0; l + 1 < L; ++l) {
+        float *nxt = s->ws_fwd + (size_t)(l & 1) * sz;
+        SPEX_TRY(spex_spmm_f32(g, cur, nxt, nullptr, 1.0f, l == 0 ? E0 : s->light, s->light, 1.0f, d, stream));
+        cur = nxt;
+    }
+    SPEX_TRY(spex_spmm_rowlist_f32(g, cur, users, B, 0, items, B, n_u, nullptr, L == 1 ? E0 : s->light, s->lo_batch, (float)(L + 1), d,
+                                   stream));
+    SPEX_TRY(spex_expert_gate_rows_f32(E0, s->lo_batch, att1, att2, users, B, 0, items, B, n_u, n_u, N, d, s->mixed_slots, stream));
+    SPEX_TRY(spex_score_bce_slots_f32(s->mixed_slots, s->mixed_slots + (size_t)B * d, d, d, B, B, s->arange, s->arange, labels, B, d,
+                                      s->loss, nullptr, nullptr, 1.0f / (float)B, s->grad_slots, d, stream));
+    // ---- rec branch backward (gradients of the UNWEIGHTED loss1; the precisions are applied in the Adam pass): the gate slot by
+    //      slot (dense d loss / d light and d loss / d E0 rows added with atomics), then the propagation as in the LightGCN step
+    SPEX_TRY(spex_expert_gate_rows_bwd_f32(E0, s->lo_batch, att1, att2, users, B, 0, items, B, n_u, n_u, N, d, s->grad_slots, d,
+                                           s->g_prop_slots, s->g_prop, s->g_raw, g_att1, g_att2, stream));
+    if (L >= 2) {
+        float *G = s->ws_bwd;                     // all-zero here (cleared by the previous step's Adam pass)
+        SPEX_TRY(spex_spmm_push_batch_f32(gt, users, B, 0, items, B, n_u, s->g_prop_slots, d, s->g_prop_slots, d, 1.0f / (float)(L + 1), G, d,
+                                          stream));
+        const float *c2 = G;
+        for (int32_t l = L - 2; l >= 0; --l) {
+            float *nxt = l == 0 ? s->g_E0 : s->ws_bwd + (size_t)(1 + ((L - 2 - l) & 1)) * sz;
+            SPEX_TRY(spex_spmm_f32(gt, c2, nxt, s->g_prop, (float)(L + 1), nullptr, nullptr, 1.0f, d, stream));
+            c2 = nxt;
+        }
+    } else {
+        SPEX_TRY(spex_propagate_bwd_f32(gt, s->g_prop, s->g_E0, s->ws_bwd, L, d, stream));
+    }
     // ---- trust branch (:170-192) on the raw user table, forward + backward
     if (T > 0)
         SPEX_TRY(spex_trust_head_train_f32(E0, n_u, trust_p, seq, seq_l, targets, T, s->path_len, d, H, s->hybrid, 1.0f, nullptr, s->a2,
                                            s->dscore, s->loss_b, s->trust_ws, s->loss + 1, 0, s->g_small, s->g_user, stream));
     // ---- uncertainty-weighted sum of both losses (main_auto_expert_s.py:78-82) + Adam over every parameter (:89)
     s->t += 1;
-    SPEX_TRY(spex::dual_task_adam(s->params, s->m, s->v, s->g_E0, s->g_raw, s->g_user, s->g_small, s->g_mixed, s->loss, s->loss_acc,
-                                  s->precision, (int64_t)n_table, (int64_t)off_u, n_trust, B, T, s->n_rec, s->t, s->lr, s->beta1,
-                                  s->beta2, s->eps, stream));
+    SPEX_TRY(spex::dual_task_adam(s->params, s->m, s->v, s->g_E0, s->g_raw, s->g_user, s->g_small, s->g_prop, L >= 2 ? s->ws_bwd : nullptr,
+                                  s->loss, s->loss_acc, s->precision, (int64_t)sz, (int64_t)off_u, n_trust, B, T, s->n_rec, s->t, s->lr,
+                                  s->beta1, s->beta2, s->eps, stream));
     return SPEX_OK;
 }

@@ -761,6 +761,32 @@ class ExpertGate(torch.autograd.Function):
         return g_raw, g_prop, g_att
 
 
+def expert_gate_rows(raw, prop, att_u, att_i, idx_a, idx_b, n_user_rows):
+    """The two-expert gate at a batch's rows only: slot k names row idx_a[k] (k < len(idx_a)) or n_user_rows + idx_b[k - ..];
+    rows below n_user_rows use att_u, the others att_i.  Returns the compact [len(idx_a) + len(idx_b), 64] gated rows."""
+    _need(raw, "raw"); _need(prop, "prop"); _need(att_u, "att_u"); _need(att_i, "att_i")
+    dev = raw.device
+    idx_a, idx_b = _idx(idx_a, dev), _idx(idx_b, dev)
+    out = torch.empty((idx_a.numel() + idx_b.numel(), raw.shape[1]), dtype=torch.float32, device=dev)
+    _launch(dev, "spex_expert_gate_rows_f32", _ptr(raw), _ptr(prop), _ptr(att_u), _ptr(att_i), _ptr(idx_a), idx_a.numel(), 0, _ptr(idx_b),
+            idx_b.numel(), n_user_rows, n_user_rows, raw.shape[0], raw.shape[1], _ptr(out))
+    return out
+
+
+def expert_gate_rows_bwd(raw, prop, att_u, att_i, idx_a, idx_b, n_user_rows, grad_slots, grad_prop, grad_raw, grad_att_u, grad_att_i):
+    """Backward of expert_gate_rows slot by slot: returns the compact d prop rows; grad_prop / grad_raw ([N, 64]) and the two gate
+    matrices' gradients are accumulated (atomics)."""
+    dev = raw.device
+    idx_a, idx_b = _idx(idx_a, dev), _idx(idx_b, dev)
+    _need(grad_slots, "grad_slots")
+    out = torch.empty((idx_a.numel() + idx_b.numel(), raw.shape[1]), dtype=torch.float32, device=dev)
+    _launch(dev, "spex_expert_gate_rows_bwd_f32", _ptr(raw), _ptr(prop), _ptr(att_u), _ptr(att_i), _ptr(idx_a), idx_a.numel(), 0,
+            _ptr(idx_b), idx_b.numel(), n_user_rows, n_user_rows, raw.shape[0], raw.shape[1], _ptr(grad_slots), grad_slots.stride(0),
+            _ptr(out), _ptr(grad_prop), _ptr(grad_raw), _ptr(grad_att_u), _ptr(grad_att_i))
+    _bump(grad_prop, grad_raw, grad_att_u, grad_att_i)
+    return out
+
+
 def expert_gate_autograd(raw, prop, att_exp):
     return ExpertGate.apply(raw, prop, att_exp)
 

@@ -401,7 +401,7 @@ def train_epoch_ngcf(stepper, data, batch_size=None, pause_gc=True):
 class DualTaskStepper:
     """The dual-task training step (LightGCN_SPEX/code/main_auto_expert_s.py:63-89: rec branch + trust branch of
     utility1/model_expert_s.py, uncertainty-weighted loss, backward, torch Adam over every parameter) as ONE library call
-    of 2 L + 8 launches on pre-allocated buffers (spex_dual_task_step_f32) — no autograd, no allocation, no host
+    of 2 L + 7 launches on pre-allocated buffers (spex_dual_task_step_f32) — no autograd, no allocation, no host
     synchronisation.  ≈2.7 ms per step through the reference-shaped autograd path in round 1, ≈1.0 ms with the fused
     trust head under autograd, and the GPU time of the launches here.
 
@@ -410,7 +410,7 @@ class DualTaskStepper:
     (rec_test, trust_test5) or saved at any point.  No edge dropout (the one-call step does not support it).
     path_capacity: the largest number of paths a step may carry (3 x trust_batch_size in the reference driver, :70-71)."""
 
-    def __init__(self, model, path_capacity, path_len, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, n_rec=5):
+    def __init__(self, model, path_capacity, path_len, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, n_rec=5, batch_capacity=256):
         from . import _lib
         table = model.flat_table()
         assert table.is_cuda, "DualTaskStepper: the model must be on the GPU (no CPU fallback)"
@@ -447,10 +447,12 @@ class DualTaskStepper:
         place(model.att_exp1, 256); place(model.att_exp2, 256); place(model.task_weights, 2)
         model._cache = None
         # ---- work buffers
-        self.light, self.mixed, self.g_mixed = z(N, d), z(N, d), z(N, d)
+        self.light, self.lo_batch = z(N, d), z(N, d)
         self.g_raw, self.g_prop, self.g_E0 = z(N, d), z(N, d), z(N, d)
         self.ws_fwd, self.ws_bwd = z(2, N, d), z(3, N, d)
         self.g_user, self.g_small = z(self.n_u, d), z(P + 512)
+        self.slot_capacity = 0
+        self._slots(2 * int(batch_capacity))
         T = self.path_capacity
         self.a2 = z(T, d)
         self.trust_ws = z(max(1, int(_lib.load().spex_trust_workspace_floats(T, self.path_len, d, n_heads))))
@@ -460,6 +462,15 @@ class DualTaskStepper:
         self._desc = None
         self._graph_t = model.Graph            # the LightGCN adjacency is symmetric
         self.refresh_precision()
+
+    def _slots(self, n):
+        """Per-slot buffers of the rec branch (the batch's 2B gated rows, their gradients, the slot index list)."""
+        if self.slot_capacity < n:
+            z = lambda *s: torch.zeros(s, dtype=torch.float32, device=self.dev)
+            self.mixed_slots, self.grad_slots, self.g_prop_slots = z(n, self.d), z(n, self.d), z(n, self.d)
+            self.arange = torch.arange(n, dtype=torch.int64, device=self.dev)
+            self.slot_capacity = n
+            self._desc = None
 
     def refresh_precision(self):
         """Call after changing task_weights from outside the stepper (the step keeps exp(-2 s) snapshots on the device)."""
@@ -483,17 +494,19 @@ class DualTaskStepper:
                 raise ValueError(f"DualTaskStepper.step: {T} paths of width {seq.shape[1]} (capacity {self.path_capacity} x {self.path_len})")
         if getattr(self.model.Graph, "mask_mode", 0) != 0:
             raise ValueError("DualTaskStepper.step: edge dropout is not supported in the one-call step")
+        self._slots(2 * B)
         if self._desc is None:
             p = lambda t: t.data_ptr()
             self._desc = _lib.DualTaskStepDesc(
                 graph=self.model.Graph._h.value, graph_t=self._graph_t._h.value, params=p(self.arena), m=p(self.m), v=p(self.v),
-                light=p(self.light), ws_fwd=p(self.ws_fwd), mixed=p(self.mixed), g_mixed=p(self.g_mixed), g_raw=p(self.g_raw),
-                g_prop=p(self.g_prop), g_E0=p(self.g_E0), ws_bwd=p(self.ws_bwd), g_user=p(self.g_user), g_small=p(self.g_small),
+                light=p(self.light), ws_fwd=p(self.ws_fwd), lo_batch=p(self.lo_batch), g_prop=p(self.g_prop), g_raw=p(self.g_raw),
+                g_E0=p(self.g_E0), ws_bwd=p(self.ws_bwd), mixed_slots=p(self.mixed_slots), grad_slots=p(self.grad_slots),
+                g_prop_slots=p(self.g_prop_slots), arange=p(self.arange), g_user=p(self.g_user), g_small=p(self.g_small),
                 a2=p(self.a2), trust_ws=p(self.trust_ws), dscore=p(self.dscore), loss_b=p(self.loss_b),
-                loss=p(self.loss), loss_acc=p(self.loss_acc), precision=p(self.precision), path_capacity=self.path_capacity,
-                path_len=self.path_len, n_user_rows=self.n_u, L=self.L, d=self.d, n_heads=self.n_heads,
-                hybrid=0 if self.model.nonhybrid else 1, n_rec=self.n_rec, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
-                eps=self.eps, t=self.t)
+                loss=p(self.loss), loss_acc=p(self.loss_acc), precision=p(self.precision), slot_capacity=self.slot_capacity,
+                path_capacity=self.path_capacity, path_len=self.path_len, n_user_rows=self.n_u, L=self.L, d=self.d,
+                n_heads=self.n_heads, hybrid=0 if self.model.nonhybrid else 1, n_rec=self.n_rec, lr=self.lr, beta1=self.betas[0],
+                beta2=self.betas[1], eps=self.eps, t=self.t)
         dsc = self._desc
         dsc.t, dsc.lr = self.t, self.lr
         vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() else None
