@@ -173,15 +173,13 @@ struct FwdState {     // what the forward leaves in registers for the backward c
 };
 
 // ------------------------------------------------------------------------------------------------ forward chain (one wave)
-__device__ __forceinline__ FwdState forward_chain(const TrustArgs &p, const LdsLayout &ll, float *s, int b, int l, int lane,
-                                                  float *__restrict__ a2_out)
+// forward, part 1 (wave 0): the path's rows and the input attention heads -> e, M (and the heads' softmax weights)
+__device__ __forceinline__ void forward_head(const TrustArgs &p, const LdsLayout &ll, float *s, int b, int l, int lane)
 {
     const int L = p.L, H = p.H;
     const Layout lo = layout(H);
     const float *__restrict__ P = p.P;
-    float *e = s + ll.e, *M = s + ll.M, *o = s + ll.o, *h = s + ll.h, *vec = s + ll.vec;
-    float *sg_all = s + ll.dM;                 // the sigmoids (training form only)
-    const bool train = ll.total > ll.dM;         // the training layout carries the backward's arrays after dM
+    float *e = s + ll.e, *M = s + ll.M, *vec = s + ll.vec;
 
     // path rows: all gathers in flight at once (row index -1 / out of range -> zeros, never an out-of-bounds gather)
     {
@@ -224,13 +222,21 @@ __device__ __forceinline__ FwdState forward_chain(const TrustArgs &p, const LdsL
             }
         }
     }
-    wave_sync();
-    // r_i = M_i @ w (w row k is coalesced across lanes, 16 independent loads per batch; M_i[k] is an LDS broadcast), o_i = ELU(r_i)
+}
+
+// forward, part 2 (kSplit waves, each a quarter of w's rows): acc_i = sum_{k in [k_beg, k_end)} M_i[k] w[k][lane]
+// (w row k is coalesced across lanes, 16 independent loads per batch; M_i[k] is an LDS broadcast)
+__device__ __forceinline__ void forward_mw(const TrustArgs &p, const LdsLayout &ll, const float *s, int l, int lane, int k_beg, int k_end,
+                                           float (&acc)[kMaxL])
+{
+    const int H = p.H;
+    const Layout lo = layout(H);
+    const float *__restrict__ P = p.P;
+    const float *M = s + ll.M;
     {
-        float acc[kMaxL];
 #pragma unroll
         for (int i = 0; i < kMaxL; ++i) acc[i] = 0.0f;
-        for (int k0 = 0; k0 < H * kD; k0 += 16) {
+        for (int k0 = k_beg; k0 < k_end; k0 += 16) {
             float wk[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) wk[j] = P[lo.w + (k0 + j) * kD + lane];
@@ -247,10 +253,22 @@ __device__ __forceinline__ FwdState forward_chain(const TrustArgs &p, const LdsL
                     }
                 }
         }
-#pragma unroll
-        for (int i = 0; i < kMaxL; ++i)
-            if (i < l) o[i * kD + lane] = acc[i] > 0.0f ? acc[i] : expm1f(acc[i]);
     }
+}
+
+// forward, part 3 (wave 0): ELU, the output attention layer, the readout, the gate -> a2
+__device__ __forceinline__ FwdState forward_tail(const TrustArgs &p, const LdsLayout &ll, float *s, int b, int l, int lane,
+                                                 const float (&acc)[kMaxL], float *__restrict__ a2_out)
+{
+    const int L = p.L, H = p.H;
+    const Layout lo = layout(H);
+    const float *__restrict__ P = p.P;
+    float *e = s + ll.e, *o = s + ll.o, *h = s + ll.h, *vec = s + ll.vec;
+    float *sg_all = s + ll.dM;                 // the sigmoids (training form only)
+    const bool train = ll.total > ll.dM;         // the training layout carries the backward's arrays after dM
+#pragma unroll
+    for (int i = 0; i < kMaxL; ++i)
+        if (i < l) o[i * kD + lane] = acc[i] > 0.0f ? acc[i] : expm1f(acc[i]);
     // output attention layer
     {
         const float c1 = P[lo.out_att + lane], c2 = P[lo.out_att + kD + lane];
@@ -372,20 +390,30 @@ __device__ __forceinline__ void logits_ce(const TrustArgs &p, const TrainArgs &t
     const float k = tr.scale * (tr.scale_dev ? *tr.scale_dev : 1.0f) / (float)p.B;
     for (int u = t; u < n_users; u += kPathThreads) ds[u] = tg_ok ? (expf(ds[u] - lse) - (u == tg ? 1.0f : 0.0f)) * k : 0.0f;
     __syncthreads();
-    const int lane = t & 63, wv = t >> 6;
-    float acc = 0.0f;
-    for (int u0 = wv; u0 < n_users; u0 += kPathWaves * kFly) {
-        float dv[kFly], rv[kFly];
+    // d a2 = sum_u d score[u] E[u]: same 16-lanes-per-row sweep (lane holds four columns), the four row groups of a wave
+    // are folded with two cross-lane adds, the waves meet in LDS
+    const int wv = t >> 6;
+    float4 acc4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int u0 = 0; u0 < n_users; u0 += kRows * kFly) {
+        float4 r[kFly];
+        float dv[kFly];
 #pragma unroll
         for (int j = 0; j < kFly; ++j) {
-            const int u = u0 + j * kPathWaves;
+            const int u = u0 + j * kRows + grp;
             dv[j] = u < n_users ? ds[u] : 0.0f;
-            rv[j] = u < n_users ? table[(size_t)u * kD + lane] : 0.0f;
+            r[j] = u < n_users ? reinterpret_cast<const float4 *>(table + (size_t)u * kD)[sub] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
 #pragma unroll
-        for (int j = 0; j < kFly; ++j) acc = fmaf(dv[j], rv[j], acc);
+        for (int j = 0; j < kFly; ++j) {
+            acc4.x = fmaf(dv[j], r[j].x, acc4.x);
+            acc4.y = fmaf(dv[j], r[j].y, acc4.y);
+            acc4.z = fmaf(dv[j], r[j].z, acc4.z);
+            acc4.w = fmaf(dv[j], r[j].w, acc4.w);
+        }
     }
-    sacc[wv * kD + lane] = acc;
+    acc4.x += __shfl_xor(acc4.x, 16); acc4.y += __shfl_xor(acc4.y, 16); acc4.z += __shfl_xor(acc4.z, 16); acc4.w += __shfl_xor(acc4.w, 16);
+    acc4.x += __shfl_xor(acc4.x, 32); acc4.y += __shfl_xor(acc4.y, 32); acc4.z += __shfl_xor(acc4.z, 32); acc4.w += __shfl_xor(acc4.w, 32);
+    if ((t & 63) < 16) reinterpret_cast<float4 *>(sacc + wv * kD)[sub] = acc4;
     __syncthreads();
     if (t < kD) {
         float g = 0.0f;
@@ -591,7 +619,30 @@ __global__ __launch_bounds__(TRAIN ? kPathThreads : kWave) void trust_path_kerne
     const LdsLayout ll = lds_layout(p.L, p.H, TRAIN);
     const int l = path_len(p, b);
     FwdState st{};
-    if (wave == 0) st = forward_chain(p, ll, s, b, l, lane, a2_out);
+    // forward: rows + attention heads on wave 0, `M @ w` split over kSplit waves by rows of w (partials summed in wave order:
+    // deterministic), the rest on wave 0
+    constexpr int kSplit = TRAIN ? 4 : 1;
+    if (wave == 0) forward_head(p, ll, s, b, l, lane);
+    if (TRAIN) __syncthreads(); else wave_sync();
+    float acc[kMaxL];
+    float *part = s + ll.dM;                     // [kSplit - 1][L][64]: dM .. du are free until the backward chain
+    if (wave < kSplit) {
+        const int per = p.H * kD / kSplit;       // 16 H rows of w per wave
+        forward_mw(p, ll, s, l, lane, wave * per, (wave + 1) * per, acc);
+        if (wave > 0)
+            for (int i = 0; i < l; ++i) part[((wave - 1) * p.L + i) * kD + lane] = acc[i];
+    }
+    if (TRAIN) __syncthreads();
+    if (wave == 0) {
+        if (kSplit > 1) {
+#pragma unroll
+            for (int i = 0; i < kMaxL; ++i)
+                if (i < l)
+                    for (int w = 0; w + 1 < kSplit; ++w) acc[i] += part[(w * p.L + i) * kD + lane];
+            wave_sync();                         // part[] is read before forward_tail reuses the region for the sigmoids
+        }
+        st = forward_tail(p, ll, s, b, l, lane, acc, a2_out);
+    }
     if (!TRAIN) return;
     __syncthreads();
     logits_ce(p, tr, ll, s, b);
@@ -661,17 +712,17 @@ __global__ __launch_bounds__(256) void trust_reduce_kernel(const ReduceArgs a)
         }
         float acc = 0.0f;
         const int rows = per_pos ? a.B * a.L : a.B, per = per_pos ? a.L : 1;       // padded positions hold zeros
-        for (int r0 = 0; r0 < rows; r0 += 8) {
-            float av[8], bv[8];
+        for (int r0 = 0; r0 < rows; r0 += 16) {
+            float av[16], bv[16];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < 16; ++j) {
                 const int r = r0 + j, b = r / per, i = r - b * per;
                 const float *W = a.ws + (size_t)b * wl.stride;
                 av[j] = r < rows ? W[offA + i * ldA] : 0.0f;
                 bv[j] = r < rows ? W[offB + i * kD] : 0.0f;
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc = fmaf(av[j], bv[j], acc);
+            for (int j = 0; j < 16; ++j) acc = fmaf(av[j], bv[j], acc);
         }
         a.grad_P[out] = acc;
         return;
