@@ -557,9 +557,9 @@ __global__ __launch_bounds__(kWave *kGateWaves) void expert_gate_bwd_kernel(cons
                                                                            const float *__restrict__ att,
                                                                            const float *__restrict__ g,
                                                                            float *__restrict__ d_raw, float *__restrict__ d_prop,
-                                                                           float *d_att, int n, int d)
+                                                                           float *d_att, int n, int d, int per_wave_slots)
 {
-    extern __shared__ float s_datt[];   // [2d, 2]
+    extern __shared__ float s_datt[];   // [2d, 2] (+ one such block per wave when per_wave_slots)
     const int lane = threadIdx.x & (kWave - 1);
     for (int k = threadIdx.x; k < 4 * d; k += blockDim.x) s_datt[k] = 0.0f;
     __syncthreads();
@@ -614,7 +614,27 @@ __global__ __launch_bounds__(kWave *kGateWaves) void expert_gate_bwd_kernel(cons
             }
         }
     }
-    if (in_regs) {
+    if (in_regs && per_wave_slots) {
+        // every wave leaves its sums in its own LDS slot (slots follow the shared copy), added up after the barrier: LDS float
+        // atomics from 16 waves onto the same words serialise in the LDS unit (~200 cycles per wave instruction)
+        float *mine = s_datt + (size_t)(1 + (threadIdx.x >> 6)) * 4 * d;
+#pragma unroll
+        for (int k = 0; k < kCols; ++k) {
+            const int c = lane + k * kWave;
+            if (c < d) {
+                mine[2 * c] = acc[k][0];
+                mine[2 * c + 1] = acc[k][1];
+                mine[2 * (d + c)] = acc[k][2];
+                mine[2 * (d + c) + 1] = acc[k][3];
+            }
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < 4 * d; k += blockDim.x) {
+            float sum = 0.0f;
+            for (int v = 0; v < kGateWaves; ++v) sum += s_datt[(size_t)(1 + v) * 4 * d + k];
+            s_datt[k] = sum;
+        }
+    } else if (in_regs) {
 #pragma unroll
         for (int k = 0; k < kCols; ++k) {
             const int c = lane + k * kWave;
@@ -672,10 +692,9 @@ __global__ __launch_bounds__(kWave *kGateWaves) void expert_gate_rows_bwd_kernel
     int64_t n_user_rows, int64_t n_rows, const float *__restrict__ g_slots, int ld_g, float *__restrict__ d_prop_c, float *g_prop,
     float *g_raw, float *g_att_u, float *g_att_i)
 {
-    __shared__ float s_att[2][256];
-    const int lane = threadIdx.x & (kWave - 1);
-    for (int k = threadIdx.x; k < 512; k += blockDim.x) (&s_att[0][0])[k] = 0.0f;
-    __syncthreads();
+    __shared__ float s_att[kGateWaves][2][256];    // one slot per wave, summed after the barrier (LDS float atomics from 16 waves
+                                                   // onto the same 512 words serialise in the LDS unit: 12 us for 128 instructions)
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     float acc[2][4] = {};
     const int n = n_a + n_b;
     for (int slot = blockIdx.x * kGateWaves + (threadIdx.x >> 6); slot < n; slot += gridDim.x * kGateWaves) {
@@ -707,15 +726,17 @@ __global__ __launch_bounds__(kWave *kGateWaves) void expert_gate_rows_bwd_kernel
     }
 #pragma unroll
     for (int w = 0; w < 2; ++w) {
-        atomicAdd(&s_att[w][2 * lane], acc[w][0]);
-        atomicAdd(&s_att[w][2 * lane + 1], acc[w][1]);
-        atomicAdd(&s_att[w][2 * (64 + lane)], acc[w][2]);
-        atomicAdd(&s_att[w][2 * (64 + lane) + 1], acc[w][3]);
+        s_att[wave][w][2 * lane] = acc[w][0];
+        s_att[wave][w][2 * lane + 1] = acc[w][1];
+        s_att[wave][w][2 * (64 + lane)] = acc[w][2];
+        s_att[wave][w][2 * (64 + lane) + 1] = acc[w][3];
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < 256; k += blockDim.x) {
-        if (s_att[0][k] != 0.0f) atomicAdd(g_att_u + k, s_att[0][k]);
-        if (s_att[1][k] != 0.0f) atomicAdd(g_att_i + k, s_att[1][k]);
+    for (int k = threadIdx.x; k < 512; k += blockDim.x) {
+        const int w = k >> 8, j = k & 255;
+        float sum = 0.0f;
+        for (int v = 0; v < kGateWaves; ++v) sum += s_att[v][w][j];
+        if (sum != 0.0f) atomicAdd((w ? g_att_i : g_att_u) + j, sum);
     }
 }
 
@@ -853,8 +874,10 @@ extern "C" int spex_expert_gate_bwd_f32(const float *raw, const float *prop, con
     if (n == 0) return SPEX_OK;
     int64_t blocks = ((int64_t)n + kGateWaves - 1) / kGateWaves;
     if (blocks > 256) blocks = 256;                         // one workgroup per CU: 256 x 4d parameter-gradient atomics
-    hipLaunchKernelGGL(expert_gate_bwd_kernel, dim3((unsigned)blocks), dim3(kWave * kGateWaves), (size_t)d * 4 * sizeof(float),
-                       (hipStream_t)stream, raw, prop, att_exp, grad_mixed, grad_raw, grad_prop, grad_att, n, d);
+    const int slots = d <= 128 ? 1 : 0;     // (1 + 16) x 4d floats of LDS: 34 KB at d = 128
+    hipLaunchKernelGGL(expert_gate_bwd_kernel, dim3((unsigned)blocks), dim3(kWave * kGateWaves),
+                       (size_t)d * 4 * sizeof(float) * (slots ? 1 + kGateWaves : 1), (hipStream_t)stream, raw, prop, att_exp, grad_mixed,
+                       grad_raw, grad_prop, grad_att, n, d, slots);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }

@@ -743,7 +743,13 @@ __global__ __launch_bounds__(256) void trust_reduce_kernel(const ReduceArgs a)
         }
         float sum = 0.0f;
         if (off >= 0)
-            for (int b = 0; b < a.B; ++b) sum += a.ws[(size_t)b * wl.stride + off + c];
+            for (int b0 = 0; b0 < a.B; b0 += 16) {          // 16 independent loads in flight, added in path order
+                float x[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) x[j] = b0 + j < a.B ? a.ws[(size_t)(b0 + j) * wl.stride + off + c] : 0.0f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) sum += x[j];
+            }
         switch (which) {
             case 0: a.grad_P[lo.b1 + c] = sum; a.grad_P[lo.b2 + c] = sum; break;
             case 1: a.grad_P[lo.bt + c] = sum; break;
