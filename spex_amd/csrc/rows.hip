@@ -44,10 +44,25 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_push_rows_kernel(
     const int beg = rowptr[r], end = rowptr[r + 1];
     for (int c0 = 0; c0 < d; c0 += kWave) {
         const int c = c0 + lane;
-        if (c >= d) break;
-        const float g = scale * src[(size_t)(src_indexed ? r : k) * d + c];
-        for (int e = beg + wave; e < end; e += kWgWaves) atomicAdd(out + (size_t)col[e] * d + c, val[e] * g);
-        if (add && wave == 0) atomicAdd(out + (size_t)r * d + c, scale * add[(size_t)(add_indexed ? r : k) * d + c]);
+        const bool col_ok = c < d;                         // (every lane stays in the loop: lanes 0..15 carry the run's metadata)
+        const float g = col_ok ? scale * src[(size_t)(src_indexed ? r : k) * d + c] : 0.0f;
+        for (int base = beg + wave * 16; base < end; base += kWgWaves * 16) {   // 16-entry runs: one coalesced (col, val) load each
+            const int cnt = end - base < 16 ? end - base : 16;
+            int my_col = 0;
+            float my_val = 0.0f;
+            if (lane < cnt) {
+                my_col = col[base + lane];
+                my_val = val[base + lane];
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (j < cnt) {
+                    const int cc = __builtin_amdgcn_readlane(my_col, j);
+                    const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_val), j));
+                    if (col_ok) atomicAdd(out + (size_t)cc * d + c, v * g);
+                }
+        }
+        if (add && wave == 0 && col_ok) atomicAdd(out + (size_t)r * d + c, scale * add[(size_t)(add_indexed ? r : k) * d + c]);
     }
 }
 
@@ -71,8 +86,27 @@ __global__ __launch_bounds__(kWave *kPushWaves) void spmm_push_batch_kernel(
     if (r < 0 || r >= n_rows) return;
     const int beg = rowptr[r], end = rowptr[r + 1];
     const float g = scale * src[(size_t)k * ld_src + lane];
-    for (int e = beg + part + kPushParts * wave; e < end; e += kPushParts * kPushWaves)
-        atomicAdd(out + (size_t)col[e] * kWave + lane, val[e] * g);
+    // 16-entry runs dealt round-robin to the slot's 16 waves: ONE coalesced load of the run's (col, val) pairs — lane j holds
+    // entry j — then the atomics are issued back to back (they return nothing, so nothing waits).  The first version walked
+    // the row entry by entry, each atomic behind its own col/val load: a 500-entry row took ~30 dependent round trips per wave
+    // and set the launch time (11-22 us).
+    const int w16 = part * kPushWaves + wave;
+    for (int base = beg + w16 * 16; base < end; base += kPushParts * kPushWaves * 16) {
+        const int cnt = end - base < 16 ? end - base : 16;
+        int my_col = 0;
+        float my_val = 0.0f;
+        if (lane < cnt) {
+            my_col = col[base + lane];
+            my_val = val[base + lane];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (j < cnt) {
+                const int c = __builtin_amdgcn_readlane(my_col, j);
+                const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_val), j));
+                atomicAdd(out + (size_t)c * kWave + lane, v * g);
+            }
+    }
     if (add && part == 0 && wave == 0) atomicAdd(out + (size_t)r * kWave + lane, scale * add[(size_t)k * ld_add + lane]);
 }
 
