@@ -206,6 +206,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void ngcf_layer_kernel(
 // workgroup.
 constexpr int kBwdWaves = 4;
 constexpr int kDwStride = 68;
+constexpr int kBwdStride = 68;     // LDS row stride of the backward's tiles and weights: rows 16-byte aligned for ds_read_b128
 
 template <bool ROWS>
 __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
@@ -216,67 +217,40 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
     const int64_t *__restrict__ idx_b, int n_b, int64_t off_b, float *__restrict__ g_side,
     float *__restrict__ g_ego, float *gW_gc, float *gb_gc, float *gW_bi, float *gb_bi, float *partials, int part_stride)
 {
-    __shared__ float s_w[2][64 * kLdsStride];                   // W_gc, W_bi as [out o][in k]
+    __shared__ float s_w[2][64 * kBwdStride];                   // W_gc, W_bi as [out o][in k]
+    __shared__ float s_wT[2][64 * kBwdStride];                  // and transposed, [in k][out o]: every MFMA operand below is then
+                                                                // 16 consecutive floats per lane (four ds_read_b128)
     __shared__ float s_dw[2][64 * kDwStride];                   // this workgroup's share of dW_gc, dW_bi
     __shared__ float s_db[2][64];
-    __shared__ float s_t[kBwdWaves][2][16 * kLdsStride];        // per wave: side tile / G_s, product tile / G_t
+    __shared__ float s_t[kBwdWaves][2][16 * kBwdStride];        // per wave: side tile / G_s, product tile / G_t
     __shared__ int s_active;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int i16 = lane & 15, h = lane >> 4;
     const int n_items = ROWS ? n_a + n_b : n;                   // slots to process (batch slots / all rows)
     const int n_tiles = (n_items + 15) >> 4;
-    for (int i = threadIdx.x; i < 64 * 16; i += blockDim.x) {
-        const int r = i >> 4, c4 = (i & 15) * 4;
-        const float4 a = *reinterpret_cast<const float4 *>(W_gc + r * 64 + c4);
-        const float4 b = *reinterpret_cast<const float4 *>(W_bi + r * 64 + c4);
-        float *pa = &s_w[0][r * kLdsStride + c4], *pb = &s_w[1][r * kLdsStride + c4];
-        pa[0] = a.x; pa[1] = a.y; pa[2] = a.z; pa[3] = a.w;
-        pb[0] = b.x; pb[1] = b.y; pb[2] = b.z; pb[3] = b.w;
-    }
-    if (!ROWS) {                                                 // (the rows form never touches the LDS accumulators)
-        for (int i = threadIdx.x; i < 64 * kDwStride; i += blockDim.x) s_dw[0][i] = s_dw[1][i] = 0.0f;
-        if (threadIdx.x < 64) s_db[0][threadIdx.x] = s_db[1][threadIdx.x] = 0.0f;
-    }
-    if (threadIdx.x == 0) s_active = 0;
-    __syncthreads();
-    const int i16 = lane & 15, h = lane >> 4;
-    float bias_g[4], bias_b[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        bias_g[b] = b_gc[16 * b + i16];
-        bias_b[b] = b_bi[16 * b + i16];
-    }
-    float *t_side = s_t[wave][0], *t_prod = s_t[wave][1];
-    f32x4 dWg[4][4], dWb[4][4];                                  // [out block][in block]: rows 4h + q, column i16
-    float dbg[4] = {0.f, 0.f, 0.f, 0.f}, dbb[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int bo = 0; bo < 4; ++bo) {
-#pragma unroll
-        for (int bn = 0; bn < 4; ++bn) {
-            dWg[bo][bn] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            dWb[bo][bn] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-    }
-    bool did_work = false;
-    for (int tile = blockIdx.x * kBwdWaves + wave; tile < n_tiles; tile += gridDim.x * kBwdWaves) {
-        const int r0 = tile << 4;
-        // the tile's rows: consecutive rows, or the rows of 16 batch slots (every slot is processed with ITS OWN upstream
-        // gradient row — the layer's backward is linear in it, so rows named by several slots just add up downstream;
-        // -1 = past the end / out of range); lane i keeps slot i's row in `slot_row`
-        int slot_row = -1;
-        if (ROWS) {
-            if (lane < 16 && r0 + lane < n_items) {
-                const long long r = batch_row(idx_a, n_a, off_a, idx_b, off_b, r0 + lane);
-                slot_row = (r >= 0 && r < n) ? (int)r : -1;
+    const int tile_step = gridDim.x * kBwdWaves;
+    // A tile's inputs, requested as early as possible (the kernel is a chain of dependent round trips: slot index -> rows):
+    // the tile's rows — consecutive rows, or the rows of 16 batch slots (every slot is processed with ITS OWN upstream
+    // gradient row — the layer's backward is linear in it, so rows named by several slots just add up downstream; -1 = past
+    // the end / out of range; lane i keeps slot i's row in `slot_row`) —, the upstream gradients in the accumulator layout
+    // (element (row 4h + q, column 16b + i16)) and the ego / side rows (lane == column).
+    auto load_tile = [&](int tl, int &slot_row, int (&row_q)[4], float (&gn)[4][4], float (&gx)[4][4], bool &any, float (&e_reg)[16],
+                         float (&s_reg)[16]) {
+        const int r0 = tl << 4;
+        slot_row = -1;
+        if (tl < n_tiles) {
+            if (ROWS) {
+                if (lane < 16 && r0 + lane < n_items) {
+                    const long long r = batch_row(idx_a, n_a, off_a, idx_b, off_b, r0 + lane);
+                    slot_row = (r >= 0 && r < n) ? (int)r : -1;
+                }
+            } else if (lane < 16 && r0 + lane < n) {
+                slot_row = r0 + lane;
             }
-        } else if (lane < 16 && r0 + lane < n) {
-            slot_row = r0 + lane;
         }
-        int row_q[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) row_q[q] = __shfl(slot_row, 4 * h + q, kWave);
-        // upstream gradients in the accumulator layout: element (row 4h + q, column 16b + i16)
-        float gn[4][4], gx[4][4];
-        bool any = false;
+        any = false;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
 #pragma unroll
@@ -290,6 +264,58 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
                 any |= (gn[b][q] != 0.0f) | (gx[b][q] != 0.0f);
             }
         }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = __builtin_amdgcn_readlane(slot_row, i);
+            e_reg[i] = s_reg[i] = 0.0f;
+            if (r >= 0) {
+                e_reg[i] = ego[(size_t)r * 64 + lane];
+                s_reg[i] = side[(size_t)r * 64 + lane];
+            }
+        }
+    };
+    int tile = blockIdx.x * kBwdWaves + wave;
+    int slot_row, row_q[4];
+    float gn[4][4], gx[4][4], e_reg[16], s_reg[16];
+    bool any;
+    load_tile(tile, slot_row, row_q, gn, gx, any, e_reg, s_reg);        // in flight while the weights are staged
+    for (int i = threadIdx.x; i < 64 * 16; i += blockDim.x) {
+        const int r = i >> 4, c4 = (i & 15) * 4;
+        const float4 a = *reinterpret_cast<const float4 *>(W_gc + r * 64 + c4);
+        const float4 b = *reinterpret_cast<const float4 *>(W_bi + r * 64 + c4);
+        *reinterpret_cast<float4 *>(&s_w[0][r * kBwdStride + c4]) = a;
+        *reinterpret_cast<float4 *>(&s_w[1][r * kBwdStride + c4]) = b;
+        s_wT[0][(c4 + 0) * kBwdStride + r] = a.x; s_wT[0][(c4 + 1) * kBwdStride + r] = a.y;
+        s_wT[0][(c4 + 2) * kBwdStride + r] = a.z; s_wT[0][(c4 + 3) * kBwdStride + r] = a.w;
+        s_wT[1][(c4 + 0) * kBwdStride + r] = b.x; s_wT[1][(c4 + 1) * kBwdStride + r] = b.y;
+        s_wT[1][(c4 + 2) * kBwdStride + r] = b.z; s_wT[1][(c4 + 3) * kBwdStride + r] = b.w;
+    }
+    if (!ROWS) {                                                 // (the rows form never touches the LDS accumulators)
+        for (int i = threadIdx.x; i < 64 * kDwStride; i += blockDim.x) s_dw[0][i] = s_dw[1][i] = 0.0f;
+        if (threadIdx.x < 64) s_db[0][threadIdx.x] = s_db[1][threadIdx.x] = 0.0f;
+    }
+    if (threadIdx.x == 0) s_active = 0;
+    float bias_g[4], bias_b[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        bias_g[b] = b_gc[16 * b + i16];
+        bias_b[b] = b_bi[16 * b + i16];
+    }
+    __syncthreads();
+    float *t_side = s_t[wave][0], *t_prod = s_t[wave][1];
+    f32x4 dWg[4][4], dWb[4][4];                                  // [out block][in block]: rows 4h + q, column i16
+    float dbg[4] = {0.f, 0.f, 0.f, 0.f}, dbb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int bo = 0; bo < 4; ++bo) {
+#pragma unroll
+        for (int bn = 0; bn < 4; ++bn) {
+            dWg[bo][bn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            dWb[bo][bn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    bool did_work = false;
+    for (; tile < n_tiles; tile += tile_step) {
+        const int r0 = tile << 4;
         if (!ROWS && !__any(any)) {                              // no gradient reaches this tile
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -299,38 +325,48 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
                     g_ego[(size_t)r * 64 + lane] = g_direct ? g_direct[(size_t)r * ld_direct + lane] : 0.0f;
                 }
             }
+            load_tile(tile + tile_step, slot_row, row_q, gn, gx, any, e_reg, s_reg);
             continue;
         }
         did_work = true;
         // stage the tile (lane == column) for the recomputation
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int r = __builtin_amdgcn_readlane(slot_row, i);
-            float e = 0.0f, sd = 0.0f;
-            if (r >= 0) {
-                e = ego[(size_t)r * 64 + lane];
-                sd = side[(size_t)r * 64 + lane];
-            }
-            t_side[i * kLdsStride + lane] = sd;
-            t_prod[i * kLdsStride + lane] = e * sd;
+            t_side[i * kBwdStride + lane] = s_reg[i];
+            t_prod[i * kBwdStride + lane] = e_reg[i] * s_reg[i];
         }
+        // recompute s = side W_gc^T, t = (ego * side) W_bi^T.  The contraction index is dealt k = 16 h + j to lane group h, step j
+        // (any bijection works as long as both operands agree): a lane then needs 16 CONSECUTIVE floats of its A row and of each
+        // B row — four ds_read_b128 instead of sixteen ds_read_b32 (the 4 s + h order spent 5 of the kernel's 27 us on LDS reads)
         f32x4 acc_g[4], acc_b[4];
+        {
+            float4 ag[4], ab[4];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            acc_g[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            acc_b[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll 4
-        for (int s = 0; s < 16; ++s) {
-            const int k = 4 * s + h;
-            const float a_g = t_side[i16 * kLdsStride + k];
-            const float a_b = t_prod[i16 * kLdsStride + k];
+            for (int j = 0; j < 4; ++j) {
+                ag[j] = *reinterpret_cast<const float4 *>(&t_side[i16 * kBwdStride + 16 * h + 4 * j]);
+                ab[j] = *reinterpret_cast<const float4 *>(&t_prod[i16 * kBwdStride + 16 * h + 4 * j]);
+            }
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                const float w_g = s_w[0][(16 * b + i16) * kLdsStride + k];
-                const float w_b = s_w[1][(16 * b + i16) * kLdsStride + k];
-                acc_g[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_g, w_g, acc_g[b], 0, 0, 0);
-                acc_b[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_b, w_b, acc_b[b], 0, 0, 0);
+                acc_g[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                acc_b[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                float4 wg[4], wb[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    wg[j] = *reinterpret_cast<const float4 *>(&s_w[0][(16 * b + i16) * kBwdStride + 16 * h + 4 * j]);
+                    wb[j] = *reinterpret_cast<const float4 *>(&s_w[1][(16 * b + i16) * kBwdStride + 16 * h + 4 * j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc_g[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[j].x, wg[j].x, acc_g[b], 0, 0, 0);
+                    acc_b[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[j].x, wb[j].x, acc_b[b], 0, 0, 0);
+                    acc_g[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[j].y, wg[j].y, acc_g[b], 0, 0, 0);
+                    acc_b[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[j].y, wb[j].y, acc_b[b], 0, 0, 0);
+                    acc_g[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[j].z, wg[j].z, acc_g[b], 0, 0, 0);
+                    acc_b[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[j].z, wb[j].z, acc_b[b], 0, 0, 0);
+                    acc_g[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[j].w, wg[j].w, acc_g[b], 0, 0, 0);
+                    acc_b[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[j].w, wb[j].w, acc_b[b], 0, 0, 0);
+                }
             }
         }
         // elementwise chain in the accumulator layout
@@ -385,8 +421,8 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
         for (int b = 0; b < 4; ++b) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                side_c[b][q] = t_side[(4 * h + q) * kLdsStride + 16 * b + i16];
-                prod_c[b][q] = t_prod[(4 * h + q) * kLdsStride + 16 * b + i16];
+                side_c[b][q] = t_side[(4 * h + q) * kBwdStride + 16 * b + i16];
+                prod_c[b][q] = t_prod[(4 * h + q) * kBwdStride + 16 * b + i16];
             }
         }
         // dW[o][k] += sum_r G[r][o] X[r][k]: contraction over the tile's rows, row (4h + s) at step s of lane group h
@@ -406,27 +442,41 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
         for (int b = 0; b < 4; ++b) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                t_side[(4 * h + q) * kLdsStride + 16 * b + i16] = acc_g[b][q];
-                t_prod[(4 * h + q) * kLdsStride + 16 * b + i16] = acc_b[b][q];
+                t_side[(4 * h + q) * kBwdStride + 16 * b + i16] = acc_g[b][q];
+                t_prod[(4 * h + q) * kBwdStride + 16 * b + i16] = acc_b[b][q];
             }
         }
+        // input gradients: t_s = G_s W_gc, t_b = G_t W_bi (contraction over the 64 outputs o, dealt o = 16 h + j like above; the B
+        // operand W[o][column] is read from the transposed copy, where o runs along the row)
         f32x4 ts[4], tb[4];
+        {
+            float4 as[4], at[4];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            ts[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            tb[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll 4
-        for (int s = 0; s < 16; ++s) {
-            const int o = 4 * s + h;
-            const float a_s = t_side[i16 * kLdsStride + o];
-            const float a_t = t_prod[i16 * kLdsStride + o];
+            for (int j = 0; j < 4; ++j) {
+                as[j] = *reinterpret_cast<const float4 *>(&t_side[i16 * kBwdStride + 16 * h + 4 * j]);
+                at[j] = *reinterpret_cast<const float4 *>(&t_prod[i16 * kBwdStride + 16 * h + 4 * j]);
+            }
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                const float w_g = s_w[0][o * kLdsStride + 16 * b + i16];
-                const float w_b = s_w[1][o * kLdsStride + 16 * b + i16];
-                ts[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_s, w_g, ts[b], 0, 0, 0);
-                tb[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_t, w_b, tb[b], 0, 0, 0);
+                ts[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                tb[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                float4 wg[4], wb[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    wg[j] = *reinterpret_cast<const float4 *>(&s_wT[0][(16 * b + i16) * kBwdStride + 16 * h + 4 * j]);
+                    wb[j] = *reinterpret_cast<const float4 *>(&s_wT[1][(16 * b + i16) * kBwdStride + 16 * h + 4 * j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    ts[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[j].x, wg[j].x, ts[b], 0, 0, 0);
+                    tb[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(at[j].x, wb[j].x, tb[b], 0, 0, 0);
+                    ts[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[j].y, wg[j].y, ts[b], 0, 0, 0);
+                    tb[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(at[j].y, wb[j].y, tb[b], 0, 0, 0);
+                    ts[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[j].z, wg[j].z, ts[b], 0, 0, 0);
+                    tb[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(at[j].z, wb[j].z, tb[b], 0, 0, 0);
+                    ts[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[j].w, wg[j].w, ts[b], 0, 0, 0);
+                    tb[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(at[j].w, wb[j].w, tb[b], 0, 0, 0);
+                }
             }
         }
 #pragma unroll
@@ -445,6 +495,7 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
                 }
             }
         }
+        if (!ROWS) load_tile(tile + tile_step, slot_row, row_q, gn, gx, any, e_reg, s_reg);   // (the rows form has one tile per wave)
     }
     if (ROWS) {
         // rows form: one tile per wave; its weight-gradient share leaves straight from the registers as partial block

@@ -54,13 +54,16 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_push_rows_kernel(
                 my_col = col[base + lane];
                 my_val = val[base + lane];
             }
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                if (j < cnt) {
-                    const int cc = __builtin_amdgcn_readlane(my_col, j);
-                    const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_val), j));
-                    if (col_ok) atomicAdd(out + (size_t)cc * d + c, v * g);
-                }
+            // lane 0 is read before the first atomic and the entry loop is a real loop: see spmm_push_batch_kernel
+            const int cc0 = __builtin_amdgcn_readlane(my_col, 0);
+            const float v0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_val), 0));
+            if (col_ok) atomicAdd(out + (size_t)cc0 * d + c, v0 * g);
+#pragma unroll 1
+            for (int j = 1; j < cnt; ++j) {
+                const int cc = __builtin_amdgcn_readlane(my_col, j);
+                const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_val), j));
+                if (col_ok) atomicAdd(out + (size_t)cc * d + c, v * g);
+            }
         }
         if (add && wave == 0 && col_ok) atomicAdd(out + (size_t)r * d + c, scale * add[(size_t)(add_indexed ? r : k) * d + c]);
     }
@@ -90,22 +93,47 @@ __global__ __launch_bounds__(kWave *kPushWaves) void spmm_push_batch_kernel(
     // entry j — then the atomics are issued back to back (they return nothing, so nothing waits).  The first version walked
     // the row entry by entry, each atomic behind its own col/val load: a 500-entry row took ~30 dependent round trips per wave
     // and set the launch time (11-22 us).
+    // 16-entry runs dealt round-robin to the slot's 16 waves: ONE coalesced load of a run's (col, val) pairs — lane j holds
+    // entry j — and v_readlane hands them to the atomics.  Two things matter for the atomics to leave back to back:
+    //   * every run of the wave (4 at a time: rows of up to 1 024 entries in one go) is loaded, and lane 0 of each is read,
+    //     BEFORE the first atomic — gfx9 has one vmcnt counter for loads and atomics, and the compiler's wait insertion
+    //     re-waits conservatively at every control-flow join while a load is pending: with the read inside the guarded,
+    //     unrolled loop it put `s_waitcnt vmcnt(0)` in front of EVERY atomic (each then waited out its predecessor's
+    //     ~350 ns round trip: 13.5 us for batches whose longest row had <= 512 entries, 19 us up to 768, 25 us up to 1 024);
+    //   * the entry loop is a real loop (dynamic trip count), not 16 guarded copies.
     const int w16 = part * kPushWaves + wave;
-    for (int base = beg + w16 * 16; base < end; base += kPushParts * kPushWaves * 16) {
-        const int cnt = end - base < 16 ? end - base : 16;
-        int my_col = 0;
-        float my_val = 0.0f;
-        if (lane < cnt) {
-            my_col = col[base + lane];
-            my_val = val[base + lane];
+    constexpr int kStride = kPushParts * kPushWaves * 16, kPre = 4;
+    float *out_l = out + lane;
+    for (int base0 = beg + w16 * 16; base0 < end; base0 += kPre * kStride) {
+        int my_col[kPre], c0[kPre];
+        float my_val[kPre], v0[kPre];
+#pragma unroll
+        for (int p = 0; p < kPre; ++p) {
+            const int base = base0 + p * kStride;
+            my_col[p] = 0;
+            my_val[p] = 0.0f;
+            if (base + lane < end && lane < 16) {
+                my_col[p] = col[base + lane];
+                my_val[p] = val[base + lane];
+            }
         }
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
-            if (j < cnt) {
-                const int c = __builtin_amdgcn_readlane(my_col, j);
-                const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_val), j));
-                atomicAdd(out + (size_t)c * kWave + lane, v * g);
+        for (int p = 0; p < kPre; ++p) {
+            c0[p] = __builtin_amdgcn_readlane(my_col[p], 0);
+            v0[p] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_val[p]), 0));
+        }
+#pragma unroll
+        for (int p = 0; p < kPre; ++p) {
+            const int base = base0 + p * kStride;
+            const int cnt = end - base < 16 ? end - base : 16;           // (<= 0 past the row's end)
+            if (cnt > 0) atomicAdd(out_l + (size_t)c0[p] * kWave, v0[p] * g);
+#pragma unroll 1
+            for (int j = 1; j < cnt; ++j) {
+                const int c = __builtin_amdgcn_readlane(my_col[p], j);
+                const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_val[p]), j));
+                atomicAdd(out_l + (size_t)c * kWave, v * g);
             }
+        }
     }
     if (add && part == 0 && wave == 0) atomicAdd(out + (size_t)r * kWave + lane, scale * add[(size_t)k * ld_add + lane]);
 }
