@@ -285,9 +285,9 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
         if (EPI == 0) {
             __builtin_nontemporal_store(y, Y + o);
         } else if (EPI == 1) {
-            if (Y) __builtin_nontemporal_store(y, Y + o);
             float s = e + y;
             if (epi_div != 1.0f) s = s / epi_div;
+            if (Y) __builtin_nontemporal_store(y, Y + o);     // both stores after the last use of a loaded value
             __builtin_nontemporal_store(s, acc_out + o);
         } else {
             if (epi_div != 1.0f) e = e / epi_div;
@@ -355,6 +355,11 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
 #pragma unroll
                 for (int u = 0; u < kChunk; ++u) ep[u] = 0.0f;
             }
+            // A chunk that ends rows waits for ALL of its loads here, once.  gfx9 counts loads and stores in one vmcnt and the
+            // compiler re-derives its waits at every control-flow join: without this, the wait for a row's epilogue operand
+            // (loaded under the mask's branches) became `s_waitcnt vmcnt(0)` placed AFTER the previous row's stores were
+            // issued, i.e. every emitted row waited out its predecessor's store round trip.
+            if (EPI != 0) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0); expcnt / lgkmcnt unconstrained
 #pragma unroll
             for (int u = 0; u < kChunk; ++u) {
                 acc = fmaf(lane_bcast(my_val, c * kChunk + u), x[u], acc);
