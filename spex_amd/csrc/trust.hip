@@ -34,7 +34,7 @@ namespace {
 constexpr int kD = 64;        // hidden size: one lane per column
 constexpr int kMaxL = 16;     // longest padded path
 constexpr int kMaxH = 4;      // input attention heads
-constexpr int kPathWaves = 8;       // 512 threads: two waves per SIMD, so the chain waves keep 256 VGPRs (two staged weight rows)
+constexpr int kPathWaves = 16;      // 1024 threads (128 VGPRs per lane): twice the lanes for the logits sweeps
 constexpr int kPathThreads = kPathWaves * kWave;
 
 struct Layout {
