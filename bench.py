@@ -392,7 +392,9 @@ def main():
                 torch.cuda.empty_cache()
                 rp, cc, vv, _ = scaled_graph(a.hbm_log2_nodes, device=dev)
                 n2, nnz2 = len(rp) - 1, len(cc)
+                t_build = time.perf_counter()
                 g2 = SpexGraph(rp, cc, vv, device=dev)
+                out["extra"]["graph_create_s_hbm_graph"] = time.perf_counter() - t_build   # host packing (threaded) + upload
                 del rp, cc, vv
                 X = torch.rand(n2, D, device=dev) - 0.5
                 Y = torch.empty_like(X)

@@ -508,6 +508,11 @@ int spex_ngcf_step_bce_f32(spex_ngcf_step_t *step, const int64_t *users, const i
  * slot).  loss_acc accumulates (loss1, loss2) of every call — what Train() sums with .item() per step.  t is advanced.
  * seq: [T, path_len] int64 padded with the pad row's index n_user_rows - 1; T == 0 skips the trust branch (the reference
  * would produce NaN there: CrossEntropyLoss over an empty batch).  L >= 1, no edge dropout.
+ * Two streams: the rec branch (2L + 4 launches that fill the chip) and the trust branch (two launches of <= path_capacity
+ * workgroups: a latency chain on a few CUs) read the same parameters and write disjoint buffers, so with side_stream set
+ * the trust branch is forked onto it behind everything already queued on `stream` and joined again in front of the Adam
+ * pass (two events per device, created on first use and kept by the library).  Results are identical to the one-stream
+ * order; the caller keeps side_stream alive while steps are in flight.
  */
 typedef struct spex_dual_task_step {
     const spex_graph_t *graph, *graph_t;
@@ -521,6 +526,8 @@ typedef struct spex_dual_task_step {
     int32_t slot_capacity, path_capacity, path_len, n_user_rows, L, d, n_heads, hybrid, n_rec;
     float lr, beta1, beta2, eps;
     int32_t t;
+    void *side_stream;   /* optional second hipStream_t of the caller (NULL: one stream): the trust branch is issued on it and runs
+                          * CONCURRENTLY with the rec branch — the two only meet in the Adam pass (see below) */
 } spex_dual_task_step_t;
 int spex_dual_task_step_f32(spex_dual_task_step_t *step, const int64_t *users, const int64_t *items, const float *labels, int32_t B,
                             const int64_t *seq, const int64_t *seq_l, const int64_t *targets, int32_t T, void *stream);

@@ -115,7 +115,7 @@ class DualTaskStepDesc(ctypes.Structure):
                                      "trust_ws", "dscore", "loss_b", "loss", "loss_acc", "precision")]
                 + [(n, c_i32) for n in ("slot_capacity", "path_capacity", "path_len", "n_user_rows", "L", "d", "n_heads", "hybrid",
                                         "n_rec")]
-                + [(n, c_f32) for n in ("lr", "beta1", "beta2", "eps")] + [("t", c_i32)])
+                + [(n, c_f32) for n in ("lr", "beta1", "beta2", "eps")] + [("t", c_i32), ("side_stream", c_vp)])
 
 
 _lib = None

@@ -98,6 +98,26 @@ extern "C" int spex_ngcf_step_bce_f32(spex_ngcf_step_t *s, const int64_t *users,
     return SPEX_OK;
 }
 
+// Fork / join events of the two-stream dual-task step: one pair per device, created on first use, never destroyed (they
+// outlive every step in flight; a process holds at most a handful).
+static int dual_task_events(hipEvent_t *fork_ev, hipEvent_t *join_ev)
+{
+    constexpr int kMaxDev = 64;
+    static hipEvent_t ev[kMaxDev][2];
+    static bool made[kMaxDev];
+    int dev = 0;
+    SPEX_HIP(hipGetDevice(&dev));
+    SPEX_CHECK_ARG(dev >= 0 && dev < kMaxDev, "spex_dual_task_step_f32: device %d", dev);
+    if (!made[dev]) {
+        SPEX_HIP(hipEventCreateWithFlags(&ev[dev][0], hipEventDisableTiming));
+        SPEX_HIP(hipEventCreateWithFlags(&ev[dev][1], hipEventDisableTiming));
+        made[dev] = true;
+    }
+    *fork_ev = ev[dev][0];
+    *join_ev = ev[dev][1];
+    return SPEX_OK;
+}
+
 extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *users, const int64_t *items, const float *labels,
                                        int32_t B, const int64_t *seq, const int64_t *seq_l, const int64_t *targets, int32_t T,
                                        void *stream)
@@ -120,40 +140,59 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
     const size_t sz = (size_t)N * d, off_u = (size_t)n_u * d;
     float *E0 = s->params, *trust_p = E0 + sz, *att1 = trust_p + n_trust, *att2 = att1 + 4 * d;
     float *g_att1 = s->g_small + n_trust, *g_att2 = g_att1 + 4 * d;
-    // ---- rec branch forward (model_expert_s.py:95-126,154-168): layers 1 .. L-1 over the whole graph, the last layer, the gate and
-    //      the scores only at the batch's rows
-    const float *cur = E0;
-    for (int32_t l = 0; l + 1 < L; ++l) {
-        float *nxt = s->ws_fwd + (size_t)(l & 1) * sz;
-        SPEX_TRY(spex_spmm_f32(g, cur, nxt, nullptr, 1.0f, l == 0 ? E0 : s->light, s->light, 1.0f, d, stream));
-        cur = nxt;
+    // ---- trust branch (:170-192) on the raw user table, forward + backward.  It shares nothing with the rec branch but the
+    //      (read-only) parameters, so with a second stream it is issued FIRST, behind the previous step's Adam pass, and its
+    //      <= path_capacity workgroups run beside the rec branch's launches; the Adam pass waits for both.
+    auto trust_branch = [&](void *st) -> int {
+        return spex_trust_head_train_f32(E0, n_u, trust_p, seq, seq_l, targets, T, s->path_len, d, H, s->hybrid, 1.0f, nullptr, s->a2,
+                                         s->dscore, s->loss_b, s->trust_ws, s->loss + 1, 0, s->g_small, s->g_user, st);
+    };
+    const bool two_streams = s->side_stream != nullptr && s->side_stream != stream && T > 0;
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    if (two_streams) {
+        SPEX_TRY(dual_task_events(&fork_ev, &join_ev));
+        SPEX_HIP(hipEventRecord(fork_ev, (hipStream_t)stream));
+        SPEX_HIP(hipStreamWaitEvent((hipStream_t)s->side_stream, fork_ev, 0));
+        SPEX_TRY(trust_branch(s->side_stream));
+        SPEX_HIP(hipEventRecord(join_ev, (hipStream_t)s->side_stream));
     }
-    SPEX_TRY(spex_spmm_rowlist_f32(g, cur, users, B, 0, items, B, n_u, nullptr, L == 1 ? E0 : s->light, s->lo_batch, (float)(L + 1), d,
-                                   stream));
-    SPEX_TRY(spex_expert_gate_rows_f32(E0, s->lo_batch, att1, att2, users, B, 0, items, B, n_u, n_u, N, d, s->mixed_slots, stream));
-    SPEX_TRY(spex_score_bce_slots_f32(s->mixed_slots, s->mixed_slots + (size_t)B * d, d, d, B, B, s->arange, s->arange, labels, B, d,
-                                      s->loss, nullptr, nullptr, 1.0f / (float)B, s->grad_slots, d, stream));
-    // ---- rec branch backward (gradients of the UNWEIGHTED loss1; the precisions are applied in the Adam pass): the gate slot by
-    //      slot (dense d loss / d light and d loss / d E0 rows added with atomics), then the propagation as in the LightGCN step
-    SPEX_TRY(spex_expert_gate_rows_bwd_f32(E0, s->lo_batch, att1, att2, users, B, 0, items, B, n_u, n_u, N, d, s->grad_slots, d,
-                                           s->g_prop_slots, s->g_prop, s->g_raw, g_att1, g_att2, stream));
-    if (L >= 2) {
-        float *G = s->ws_bwd;                     // all-zero here (cleared by the previous step's Adam pass)
-        SPEX_TRY(spex_spmm_push_batch_f32(gt, users, B, 0, items, B, n_u, s->g_prop_slots, d, s->g_prop_slots, d, 1.0f / (float)(L + 1), G, d,
-                                          stream));
-        const float *c2 = G;
-        for (int32_t l = L - 2; l >= 0; --l) {
-            float *nxt = l == 0 ? s->g_E0 : s->ws_bwd + (size_t)(1 + ((L - 2 - l) & 1)) * sz;
-            SPEX_TRY(spex_spmm_f32(gt, c2, nxt, s->g_prop, (float)(L + 1), nullptr, nullptr, 1.0f, d, stream));
-            c2 = nxt;
+    auto rec_branch = [&]() -> int {
+        // ---- rec branch forward (model_expert_s.py:95-126,154-168): layers 1 .. L-1 over the whole graph, the last layer, the gate and
+        //      the scores only at the batch's rows
+        const float *cur = E0;
+        for (int32_t l = 0; l + 1 < L; ++l) {
+            float *nxt = s->ws_fwd + (size_t)(l & 1) * sz;
+            SPEX_TRY(spex_spmm_f32(g, cur, nxt, nullptr, 1.0f, l == 0 ? E0 : s->light, s->light, 1.0f, d, stream));
+            cur = nxt;
         }
-    } else {
-        SPEX_TRY(spex_propagate_bwd_f32(gt, s->g_prop, s->g_E0, s->ws_bwd, L, d, stream));
-    }
-    // ---- trust branch (:170-192) on the raw user table, forward + backward
-    if (T > 0)
-        SPEX_TRY(spex_trust_head_train_f32(E0, n_u, trust_p, seq, seq_l, targets, T, s->path_len, d, H, s->hybrid, 1.0f, nullptr, s->a2,
-                                           s->dscore, s->loss_b, s->trust_ws, s->loss + 1, 0, s->g_small, s->g_user, stream));
+        SPEX_TRY(spex_spmm_rowlist_f32(g, cur, users, B, 0, items, B, n_u, nullptr, L == 1 ? E0 : s->light, s->lo_batch, (float)(L + 1), d,
+                                       stream));
+        SPEX_TRY(spex_expert_gate_rows_f32(E0, s->lo_batch, att1, att2, users, B, 0, items, B, n_u, n_u, N, d, s->mixed_slots, stream));
+        SPEX_TRY(spex_score_bce_slots_f32(s->mixed_slots, s->mixed_slots + (size_t)B * d, d, d, B, B, s->arange, s->arange, labels, B, d,
+                                          s->loss, nullptr, nullptr, 1.0f / (float)B, s->grad_slots, d, stream));
+        // ---- rec branch backward (gradients of the UNWEIGHTED loss1; the precisions are applied in the Adam pass): the gate slot by
+        //      slot (dense d loss / d light and d loss / d E0 rows added with atomics), then the propagation as in the LightGCN step
+        SPEX_TRY(spex_expert_gate_rows_bwd_f32(E0, s->lo_batch, att1, att2, users, B, 0, items, B, n_u, n_u, N, d, s->grad_slots, d,
+                                               s->g_prop_slots, s->g_prop, s->g_raw, g_att1, g_att2, stream));
+        if (L >= 2) {
+            float *G = s->ws_bwd;                     // all-zero here (cleared by the previous step's Adam pass)
+            SPEX_TRY(spex_spmm_push_batch_f32(gt, users, B, 0, items, B, n_u, s->g_prop_slots, d, s->g_prop_slots, d, 1.0f / (float)(L + 1), G, d,
+                                              stream));
+            const float *c2 = G;
+            for (int32_t l = L - 2; l >= 0; --l) {
+                float *nxt = l == 0 ? s->g_E0 : s->ws_bwd + (size_t)(1 + ((L - 2 - l) & 1)) * sz;
+                SPEX_TRY(spex_spmm_f32(gt, c2, nxt, s->g_prop, (float)(L + 1), nullptr, nullptr, 1.0f, d, stream));
+                c2 = nxt;
+            }
+        } else {
+            SPEX_TRY(spex_propagate_bwd_f32(gt, s->g_prop, s->g_E0, s->ws_bwd, L, d, stream));
+        }
+        return SPEX_OK;
+    };
+    const int rc_rec = rec_branch();
+    if (two_streams) SPEX_HIP(hipStreamWaitEvent((hipStream_t)stream, join_ev, 0));   // joined on every path out of here
+    if (rc_rec != SPEX_OK) return rc_rec;
+    if (T > 0 && !two_streams) SPEX_TRY(trust_branch(stream));                          // one-stream order
     // ---- uncertainty-weighted sum of both losses (main_auto_expert_s.py:78-82) + Adam over every parameter (:89)
     s->t += 1;
     SPEX_TRY(spex::dual_task_adam(s->params, s->m, s->v, s->g_E0, s->g_raw, s->g_user, s->g_small, s->g_prop, L >= 2 ? s->ws_bwd : nullptr,

@@ -94,9 +94,13 @@ class PeerAllGather:
         self.calls = 0
         dist.barrier(group=group)                        # every handle is opened before anyone writes
 
-    def all_gather(self, send):
-        """send: this rank's padded shard [max_rows, d].  Returns the gathered [world * max_rows, d] table (one of the two
-        alternating buffers), valid for kernels queued on the current stream after this call."""
+    def all_gather(self, send, n_rows=None):
+        """send: this rank's padded shard [max_rows, d]; n_rows: its real rows (default: all).  Only the real rows cross
+        the links — the slots keep the padded stride, their tails stay zero as allocated and are never read — so the
+        exchange moves N rows in total where the equal-size collective moves world * max_rows (1.6 x as many on a
+        [users; items] table balanced by stored entries).  Returns the gathered [world * max_rows, d] table (one of the
+        two alternating buffers), valid for kernels queued on the current stream after this call."""
+        n_rows = self.max_rows if n_rows is None else int(n_rows)
         k = self.calls & 1
         self.calls += 1
         cur = torch.cuda.current_stream()
@@ -107,7 +111,7 @@ class PeerAllGather:
             st = self.streams[q]
             st.wait_event(ready)
             with torch.cuda.stream(st):
-                self.peer[q][k][lo: lo + self.max_rows].copy_(send, non_blocking=True)
+                self.peer[q][k][lo: lo + n_rows].copy_(send[:n_rows], non_blocking=True)
             cur.wait_stream(st)
         dist.all_reduce(self.token, group=self.group)    # the barrier described above (stream-ordered after the copies)
         return self.bufs[k]
@@ -156,7 +160,7 @@ class PartitionedLightGCN:
         if local.data_ptr() != self.send.data_ptr():      # a layer's SpMM writes straight into the send buffer
             self.send[: self.n_local].copy_(local)
         if self.use_peer and out is None:
-            return self.peer.all_gather(self.send)
+            return self.peer.all_gather(self.send, self.n_local)
         out = self.gathered if out is None else out
         if self.world == 1 and not self.always_collective:
             out.copy_(self.send)

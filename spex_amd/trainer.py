@@ -10,6 +10,7 @@ synchronisation and no Python between kernels beyond the ctypes calls (capturabl
                                         scores read from the propagated table, updates applied to E0
 """
 import gc
+import os
 
 import torch
 
@@ -410,7 +411,11 @@ class DualTaskStepper:
     (rec_test, trust_test5) or saved at any point.  No edge dropout (the one-call step does not support it).
     path_capacity: the largest number of paths a step may carry (3 x trust_batch_size in the reference driver, :70-71)."""
 
-    def __init__(self, model, path_capacity, path_len, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, n_rec=5, batch_capacity=256):
+    def __init__(self, model, path_capacity, path_len, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, n_rec=5, batch_capacity=256,
+                 two_streams=None):
+        """two_streams (default on; SPEX_DUAL_ONE_STREAM=1 turns it off): the trust branch's two launches — a latency chain on
+        <= path_capacity workgroups — run on a second HIP stream beside the rec branch and join it in front of the Adam
+        pass (spex_dual_task_step_t.side_stream).  Same results as the one-stream order."""
         from . import _lib
         table = model.flat_table()
         assert table.is_cuda, "DualTaskStepper: the model must be on the GPU (no CPU fallback)"
@@ -423,6 +428,9 @@ class DualTaskStepper:
         self.N, self.d, self.n_u, self.L = N, d, model.num_users + 1, model.n_layers
         self.path_capacity, self.path_len, self.n_heads = int(path_capacity), int(path_len), n_heads
         self.lr, self.betas, self.eps, self.n_rec = lr, betas, eps, n_rec
+        if two_streams is None:
+            two_streams = os.environ.get("SPEX_DUAL_ONE_STREAM", "0") != "1"
+        self._side = torch.cuda.Stream(device=dev) if two_streams else None
         P = ops.trust_param_count(n_heads, d)
         self.n_trust = P
         total = N * d + P + 512 + 4
@@ -506,9 +514,13 @@ class DualTaskStepper:
                 loss=p(self.loss), loss_acc=p(self.loss_acc), precision=p(self.precision), slot_capacity=self.slot_capacity,
                 path_capacity=self.path_capacity, path_len=self.path_len, n_user_rows=self.n_u, L=self.L, d=self.d,
                 n_heads=self.n_heads, hybrid=0 if self.model.nonhybrid else 1, n_rec=self.n_rec, lr=self.lr, beta1=self.betas[0],
-                beta2=self.betas[1], eps=self.eps, t=self.t)
+                beta2=self.betas[1], eps=self.eps, t=self.t,
+                side_stream=None if self._side is None else self._side.cuda_stream)
         dsc = self._desc
         dsc.t, dsc.lr = self.t, self.lr
+        if T and self._side is not None:                     # the side stream reads them: keep the allocator from recycling
+            for t in (seq, seq_l, targets):                  # their memory under a step still in flight
+                t.record_stream(self._side)
         vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() else None
         _launch(self.dev, "spex_dual_task_step_f32", ctypes.byref(dsc), vp(users), vp(items), vp(labels), B,
                 vp(seq) if T else None, vp(seq_l) if T else None, vp(targets) if T else None, T)

@@ -123,8 +123,11 @@ def test_two_layer_model_gradients_vs_torch_ops_on_the_same_weights(golden):
     loss2 = m(bu, bi, bl, flag=0)
     loss2.backward()
     assert abs(loss.item() - loss2.item()) <= 2e-6
+    # Both sides are fp32 sums over all rows in different association orders (kernel: per-workgroup partial sums + float
+    # atomics, run-to-run order; torch: rocBLAS / reduce kernels) — measured 0.9e-5 .. 2.1e-5 between runs on the bias
+    # gradients, whose row sums cancel.  The tight gate (each gradient vs fp64 autograd, <= 2e-5) is the layer test above.
     for k, p in m.named_parameters():
-        assert rel_err(got[k], p.grad.cpu().numpy()) <= 2e-5, k
+        assert rel_err(got[k], p.grad.cpu().numpy()) <= 5e-5, k
 
 
 # ---------------------------------------------------------------------------------------------- data + eval + whole run

@@ -50,4 +50,5 @@ torch.cuda.synchronize(); t = time.perf_counter()
 n = 500
 for _ in range(n): st.step(uc, ic, yc, seq, seq_l, tgt)
 torch.cuda.synchronize()
-print("%-48s %.3f ms/step" % ("one-call step (DualTaskStepper), 15 paths", (time.perf_counter() - t) / n * 1e3))
+print("%-48s %.3f ms/step" % ("one-call step (DualTaskStepper), 15 paths, %s" % ("two streams" if st._side is not None else "one stream"),
+                              (time.perf_counter() - t) / n * 1e3))
