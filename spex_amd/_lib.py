@@ -105,7 +105,7 @@ class NGCFStepDesc(ctypes.Structure):
                                      "gW_parts", "grad")]
                 + [(n, c_i32) for n in ("slot_capacity", "n_user_rows", "pad_row")] + [("slope", c_f32), ("p_drop", c_f32)]
                 + [("seed", ctypes.c_uint64), ("dropout_step", c_i32), ("t", c_i32)]
-                + [(n, c_f32) for n in ("lr", "beta1", "beta2", "eps")])
+                + [(n, c_f32) for n in ("lr", "beta1", "beta2", "eps")] + [("side_stream", c_vp)])
 
 
 class DualTaskStepDesc(ctypes.Structure):

@@ -62,6 +62,26 @@ extern "C" int spex_lightgcn_step_bce_f32(spex_lightgcn_step_t *s, const int64_t
     return SPEX_OK;
 }
 
+// Fork / join events of the two-stream steps (dual-task, NGCF): one pair per device, created on first use, never destroyed (they
+// outlive every step in flight; a process holds at most a handful).
+static int step_events(hipEvent_t *fork_ev, hipEvent_t *join_ev)
+{
+    constexpr int kMaxDev = 64;
+    static hipEvent_t ev[kMaxDev][2];
+    static bool made[kMaxDev];
+    int dev = 0;
+    SPEX_HIP(hipGetDevice(&dev));
+    SPEX_CHECK_ARG(dev >= 0 && dev < kMaxDev, "two-stream step: device %d", dev);
+    if (!made[dev]) {
+        SPEX_HIP(hipEventCreateWithFlags(&ev[dev][0], hipEventDisableTiming));
+        SPEX_HIP(hipEventCreateWithFlags(&ev[dev][1], hipEventDisableTiming));
+        made[dev] = true;
+    }
+    *fork_ev = ev[dev][0];
+    *join_ev = ev[dev][1];
+    return SPEX_OK;
+}
+
 extern "C" int spex_ngcf_step_bce_f32(spex_ngcf_step_t *s, const int64_t *users, const int64_t *items, const float *labels,
                                       int32_t B, float *loss_sum, void *stream)
 {
@@ -88,33 +108,30 @@ extern "C" int spex_ngcf_step_bce_f32(spex_ngcf_step_t *s, const int64_t *users,
     SPEX_TRY(spex_ngcf_layer_bwd_rows_f32(s->E0, s->side, W_gc, b_gc, W_bi, b_bi, s->g_slots + d, 2 * d, nullptr, s->g_slots, 2 * d, n, d,
                                           s->slope, s->p_drop, s->seed, step, 0, s->pad_row, users, B, 0, items, B, n_u, s->g_side_c,
                                           s->g_ego_c, s->gW_parts, per, stream));
-    SPEX_TRY(spex_spmm_push_batch_f32(g, users, B, 0, items, B, n_u, s->g_side_c, d, s->g_ego_c, d, 1.0f, s->grad, d, stream));
-    // ---- Adam: the table (its pass clears the gradient again), the layer weights (their pass sums the partial blocks)
+    // ---- Adam: the table (its pass clears the gradient again), the layer weights (their pass sums the partial blocks).  The
+    //      weights' pass needs only the rows backward: with a second stream it runs beside the push-form product and the table's
+    //      pass (a one-workgroup-class launch next to two that fill the chip) and is joined at the end of the step.
     s->t += 1;
     if (s->p_drop > 0.0f) s->dropout_step += 1;
-    SPEX_TRY(spex_adam_step_f32(s->E0, s->grad, s->mE, s->vE, (int64_t)n * d, s->t, s->lr, s->beta1, s->beta2, s->eps, s->grad, stream));
-    SPEX_TRY(spex_adam_step_sum_f32(s->W, s->gW_parts, spex_ngcf_layer_bwd_rows_parts(2 * B), per, s->mW, s->vW, per, s->t, s->lr,
-                                    s->beta1, s->beta2, s->eps, stream));
-    return SPEX_OK;
-}
-
-// Fork / join events of the two-stream dual-task step: one pair per device, created on first use, never destroyed (they
-// outlive every step in flight; a process holds at most a handful).
-static int dual_task_events(hipEvent_t *fork_ev, hipEvent_t *join_ev)
-{
-    constexpr int kMaxDev = 64;
-    static hipEvent_t ev[kMaxDev][2];
-    static bool made[kMaxDev];
-    int dev = 0;
-    SPEX_HIP(hipGetDevice(&dev));
-    SPEX_CHECK_ARG(dev >= 0 && dev < kMaxDev, "spex_dual_task_step_f32: device %d", dev);
-    if (!made[dev]) {
-        SPEX_HIP(hipEventCreateWithFlags(&ev[dev][0], hipEventDisableTiming));
-        SPEX_HIP(hipEventCreateWithFlags(&ev[dev][1], hipEventDisableTiming));
-        made[dev] = true;
+    auto weight_adam = [&](void *st) -> int {
+        return spex_adam_step_sum_f32(s->W, s->gW_parts, spex_ngcf_layer_bwd_rows_parts(2 * B), per, s->mW, s->vW, per, s->t, s->lr,
+                                      s->beta1, s->beta2, s->eps, st);
+    };
+    const bool two_streams = s->side_stream != nullptr && s->side_stream != stream;
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    if (two_streams) {
+        SPEX_TRY(step_events(&fork_ev, &join_ev));
+        SPEX_HIP(hipEventRecord(fork_ev, (hipStream_t)stream));
+        SPEX_HIP(hipStreamWaitEvent((hipStream_t)s->side_stream, fork_ev, 0));
+        SPEX_TRY(weight_adam(s->side_stream));
+        SPEX_HIP(hipEventRecord(join_ev, (hipStream_t)s->side_stream));
     }
-    *fork_ev = ev[dev][0];
-    *join_ev = ev[dev][1];
+    int rc = spex_spmm_push_batch_f32(g, users, B, 0, items, B, n_u, s->g_side_c, d, s->g_ego_c, d, 1.0f, s->grad, d, stream);
+    if (rc == SPEX_OK)
+        rc = spex_adam_step_f32(s->E0, s->grad, s->mE, s->vE, (int64_t)n * d, s->t, s->lr, s->beta1, s->beta2, s->eps, s->grad, stream);
+    if (two_streams) SPEX_HIP(hipStreamWaitEvent((hipStream_t)stream, join_ev, 0));
+    if (rc != SPEX_OK) return rc;
+    if (!two_streams) SPEX_TRY(weight_adam(stream));
     return SPEX_OK;
 }
 
@@ -150,7 +167,7 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
     const bool two_streams = s->side_stream != nullptr && s->side_stream != stream && T > 0;
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
     if (two_streams) {
-        SPEX_TRY(dual_task_events(&fork_ev, &join_ev));
+        SPEX_TRY(step_events(&fork_ev, &join_ev));
         SPEX_HIP(hipEventRecord(fork_ev, (hipStream_t)stream));
         SPEX_HIP(hipStreamWaitEvent((hipStream_t)s->side_stream, fork_ev, 0));
         SPEX_TRY(trust_branch(s->side_stream));

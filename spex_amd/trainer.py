@@ -235,6 +235,11 @@ class NGCFStepper:
         if not model._fused_ok():
             raise ValueError("NGCFStepper needs 64-wide layers (the fused layer kernels)")
         self.model, self.lr, self.betas, self.eps, self.t = model, lr, betas, eps, 0
+        # second stream of the one-call step (spex_ngcf_step_t.side_stream): the layer weights' Adam pass beside the push-form
+        # product and the table's pass; SPEX_NGCF_ONE_STREAM=1 keeps everything on the caller's stream
+        self._side = None
+        if os.environ.get("SPEX_NGCF_ONE_STREAM", "0") != "1" and next(model.parameters()).is_cuda:
+            self._side = torch.cuda.Stream(device=next(model.parameters()).device)
         self.E0 = model.flat_table()
         n, d = self.E0.shape
         dev = self.E0.device
@@ -357,7 +362,8 @@ def _ngcf_step_one_call(self, users, items, labels, acc):
             all_emb=p(self.all_emb), side=p(self.sides[0]), g_slots=p(self.g_slots), g_side_c=p(self.g_side_c),
             g_ego_c=p(self.g_ego_c), gW_parts=p(self.gW_parts), grad=p(self.g_next[0]), slot_capacity=self.g_slots.shape[0],
             n_user_rows=self.n_u, pad_row=m.n_users, slope=0.01, p_drop=float(m.mess_dropout[0]), seed=int(m.message_dropout_seed),
-            dropout_step=m.dropout_step, t=self.t, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps)
+            dropout_step=m.dropout_step, t=self.t, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps,
+            side_stream=None if self._side is None else self._side.cuda_stream)
     d = self._desc
     d.t, d.lr, d.dropout_step, d.seed, d.p_drop = self.t, self.lr, m.dropout_step, int(m.message_dropout_seed), float(m.mess_dropout[0])
     _launch(self.E0.device, "spex_ngcf_step_bce_f32", ctypes.byref(d), ctypes.c_void_p(users.data_ptr()),
