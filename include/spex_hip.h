@@ -306,6 +306,25 @@ int spex_spmm_push_batch_f32(const spex_graph_t *g, const int64_t *idx_a, int32_
                              int32_t n_b, int64_t off_b, const float *src, int32_t ld_src, const float *add, int32_t ld_add,
                              float scale, float *out, int32_t d, void *stream);
 
+/* The batch-sized middle of the exact LightGCN training step (L >= 2, d == 64, no edge dropout) as ONE launch: what the
+ * sequence spex_spmm_rowlist_f32 -> spex_score_bce_slots_f32 -> spex_spmm_push_batch_f32 computes, i.e. for sample b with
+ * rows u = users[b], i = items[b] + n_user_rows (utility1/model.py:91-97 at the batch's rows, :111-121, and autograd's first
+ * backward product):
+ *   light_r = (acc_in[r] + (A X)[r]) / acc_div   for r in {u, i}   — the last layer + layer mean at the two rows (same segment
+ *                                                                     order as spex_spmm_rowlist_f32: bit-identical rows)
+ *   x = <light_u, light_i>;   loss_b = BCEWithLogits(x, labels[b]);   dg = (sigmoid(x) - labels[b]) * grad_scale
+ *   loss_per_sample[b] = loss_b (plain store) if loss_per_sample != NULL, else *loss_sum += loss_b (one atomic per sample)
+ *   g_u = dg * light_i,  g_i = dg * light_u
+ *   g_out[r] += g_r                                                  — dense d loss / d light_out (atomics: rows repeat)
+ *   G[r] += push_scale * g_r;  G[col[e]] += push_scale * val[e] * g_r over the stored entries e of row r of `gt` (= A^T)
+ * g_out and G are accumulated into: zero them first (the step's Adam pass does).  Samples with an index out of range are
+ * skipped (loss 0).  SPEX_BATCH_PARTS workgroups (default 1) share a sample.
+ */
+int spex_lightgcn_batch_f32(const spex_graph_t *g, const spex_graph_t *gt, const float *X, const float *acc_in, float acc_div,
+                            const int64_t *users, const int64_t *items, const float *labels, int32_t B, int32_t n_user_rows,
+                            float grad_scale, float push_scale, float *loss_sum, float *loss_per_sample, float *g_out, float *G,
+                            int32_t d, void *stream);
+
 /* Replaces the two-expert gate of the dual-task model, utility1/model_expert_s.py:156-161:
  *   att = softmax([raw | prop] att_exp, dim=1) ([n,2d] x [2d,2]);  mixed = raw * att[:,0] + prop * att[:,1]
  */
@@ -443,9 +462,11 @@ int spex_trust_head_train_f32(const float *table, int64_t n_rows, const float *p
 /* ------------------------------------------------------------------------------------------------ one-call training step
  * The exact reference training step — LightGCN_SPEX/code/main_rec.py:32-37: forward (model.py:111-121), BCE,
  * loss.backward(), optimizer.step() — as ONE call that issues the library's own launches back to back:
- *   L-1 x spex_spmm_f32 (running layer sum) + spex_spmm_rowlist_f32 (last layer at the batch's rows)
- *   spex_score_bce_slots_f32 (loss + gradient rows, table and per-sample) -> spex_spmm_push_batch_f32 ((g + A^T g)/(L+1))
+ *   L-1 x spex_spmm_f32 (running layer sum)
+ *   spex_lightgcn_batch_f32 (last layer at the batch's rows + scores + BCE + gradient rows + (g + A^T g)/(L+1) in push form;
+ *                            L == 1: spex_spmm_rowlist_f32 -> spex_score_bce_slots_f32 -> one pull-form product instead)
  *   L-1 x spex_spmm_f32 on A^T (g/(L+1) fused) -> spex_adam_step_f32 over the whole table (which clears g_out again).
+ * 2 L + 1 launches (seven for L = 3).
  * The descriptor holds the step's device buffers (all caller-owned, N = graph rows, d == 64):
  *   E0, m, v, light_out, lo_batch, g_out, grad_E0: [N, d];  ws_fwd: [2, N, d];  ws_bwd: [3, N, d];
  *   grad_slots: [slot_capacity, d] with slot_capacity >= 2B (the batch's per-sample gradient rows).

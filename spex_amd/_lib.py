@@ -54,6 +54,8 @@ SIGNATURES = {
                                                     c_i32, c_i64, c_vp, c_i32, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "spex_spmm_push_batch_f32": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_vp, c_i32, c_vp, c_i32, c_f32, c_vp,
                                                 c_i32, c_vp]),
+    "spex_lightgcn_batch_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp,
+                                               c_vp, c_i32, c_vp]),
     "spex_adam_step_sum_f32": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i64, c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_f32, c_f32, c_vp]),
     "spex_unique_rows_i32": (ctypes.c_int, [c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "spex_spmm_push_rows_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_f32, c_vp, c_i32, c_vp]),

@@ -7,17 +7,18 @@
 // costs a ramp plus its own chain of dependent round trips: 6.1 + 5.2 + 9 us for ~14 k gathers, 256 dot products and
 // ~14 k row atomics on Epinion2.  spex_lightgcn_batch_f32 does the three in one kernel:
 //
-//   workgroup (sample b, part p), 16 waves: waves 0-7 own the sample's user row, waves 8-15 its item row
-//     1. last layer at both rows — the row's 64-entry segments dealt to the half's waves exactly as the row-list kernel
-//        deals them to 16 (virtual wave v = w and w + 8 on wave w, separate accumulators), segment sums through LDS in
-//        segment order: bit-identical to spex_spmm_rowlist_f32 / the main kernel for rows of <= 1024 entries;
+//   workgroup (sample b, part p), 16 waves
+//     1. last layer at both rows of the sample — each row's 64-entry segments go to virtual waves v = segment mod 16 exactly
+//        as the row-list kernel deals them (one accumulator chain per virtual wave), the two rows' virtual waves numbered
+//        jointly and dealt to the 16 waves; a segment's 64 gathers are all in flight at once; segment sums meet in LDS and
+//        are added in segment order: bit-identical to spex_spmm_rowlist_f32 / the main kernel for rows of <= 1024 entries;
 //     2. light = (running sum + y) / (L + 1) for both rows -> LDS; every wave forms x = <light_u, light_i>, the sample's loss
-//        share and its own row's gradient g = (sigmoid(x) - label) / B * (the other row);
-//     3. push: out[col[e]] += val[e] * g / (L + 1) over the stored entries of the row in A^T, 16-entry runs dealt over
-//        (part, wave) like spex_spmm_push_batch_f32 deals them, plus out[row] += g / (L + 1) and the dense
-//        d loss / d light row (added by part 0 only).
-//   `parts` workgroups share a sample so that a hub row's ~1 000 row atomics spread over several CUs; each part repeats
-//   the (cheap, L2-resident) forward of its sample instead of reading it back from another workgroup.
+//        and both gradient rows g_u = dg * light_i, g_i = dg * light_u, dg = (sigmoid(x) - label) / B;
+//     3. push: out[col[e]] += val[e] * g / (L + 1) over the stored entries of both rows in A^T, runs of 16 entries numbered
+//        jointly and dealt over (part, wave) — their (col, val) pairs were requested before step 1 —, plus
+//        out[row] += g / (L + 1) and the dense d loss / d light rows (part 0 only).
+//   `parts` workgroups may share a sample (each repeats the cheap, L2-resident forward); measured on Epinion2, B = 256:
+//   1 part is fastest (a second workgroup per sample costs more than a hub row's ~1 000 row atomics on one CU).
 #include "spex_common.h"
 
 using namespace spex;
@@ -30,115 +31,158 @@ __device__ __forceinline__ float lane_bcast(float v, int src)
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-constexpr int kHalfWaves = kWgWaves / 2;     // waves per row
+constexpr int kPre = 2;                      // push runs a wave loads ahead (2 x 16 waves x 16 entries = 512 entries per part)
+
+// One 64-entry segment [e0, e0 + cnt) of a row, all of its gathers in flight at once (one workgroup per CU here: the wave
+// can afford 64 result registers, and the kernel is a latency chain — four dependent gather round trips became one).
+// The fmaf chain runs in entry order exactly like the row-list kernel's.
+__device__ __forceinline__ float segment_sum(const int32_t *__restrict__ col, const float *__restrict__ val, const float *__restrict__ Xl,
+                                             int e0, int cnt, int lane, float acc)
+{
+    int my_col = 0;
+    float my_val = 0.0f;
+    if (lane < cnt) {
+        my_col = col[e0 + lane];
+        my_val = val[e0 + lane];
+    }
+    const int last_col = __builtin_amdgcn_readlane(my_col, (cnt - 1) & 63);
+    if (lane >= cnt) my_col = last_col;                    // padding: value 0 on a row already being fetched
+    float x[4][kChunk];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c * kChunk < cnt) {
+#pragma unroll
+            for (int k = 0; k < kChunk; ++k)
+                x[c][k] = Xl[(size_t)(uint32_t)__builtin_amdgcn_readlane(my_col, c * kChunk + k) * kWave];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c * kChunk < cnt) {
+#pragma unroll
+            for (int k = 0; k < kChunk; ++k) acc = fmaf(lane_bcast(my_val, c * kChunk + k), x[c][k], acc);
+        }
+    }
+    return acc;
+}
 
 __global__ __launch_bounds__(kWave *kWgWaves) void lightgcn_batch_kernel(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
     const int32_t *__restrict__ t_rowptr, const int32_t *__restrict__ t_col, const float *__restrict__ t_val, int n_rows,
     int n_user_rows, const float *__restrict__ X, const float *__restrict__ acc_in, float acc_div,
     const int64_t *__restrict__ users, const int64_t *__restrict__ items, const float *__restrict__ labels, int parts,
-    float grad_scale, float push_scale, float *loss_sum, float *g_out, float *G)
+    float grad_scale, float push_scale, float *loss_sum, float *__restrict__ loss_rows, float *g_out, float *G)
 {
-    __shared__ float s_part[2][kWgWaves][kWave];   // [row half][virtual wave = segment mod 16][column]
+    __shared__ float s_part[2][kWgWaves][kWave];   // [row: user, item][virtual wave of the row-list kernel][column]
     __shared__ float s_light[2][kWave];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int half = wave / kHalfWaves, w8 = wave % kHalfWaves;
     const int b = blockIdx.x / parts, part = blockIdx.x % parts;
     const int64_t u64 = users[b], i64 = items[b];
-    if (u64 < 0 || u64 >= n_user_rows || i64 < 0 || i64 + n_user_rows >= n_rows) return;   // workgroup-uniform: never gather out of range
-    const int r = half ? (int)i64 + n_user_rows : (int)u64;
-    // everything whose address is known now is requested now: both row ranges, the running sum, the label
-    const int beg = rowptr[r], deg = rowptr[r + 1] - beg;
-    const int t_beg = t_rowptr[r], t_end = t_rowptr[r + 1];
-    const float run = acc_in[(size_t)r * kWave + lane];
+    if (u64 < 0 || u64 >= n_user_rows || i64 < 0 || i64 + n_user_rows >= n_rows) {   // workgroup-uniform: never gather out of range
+        if (loss_rows && part == 0 && threadIdx.x == 0) loss_rows[b] = 0.0f;
+        return;
+    }
+    const int row[2] = {(int)u64, (int)i64 + n_user_rows};
+    // everything whose address is known now is requested now: both rows' ranges in both matrices, the label, the running sums
+    const int beg[2] = {rowptr[row[0]], rowptr[row[1]]};
+    const int deg[2] = {rowptr[row[0] + 1] - beg[0], rowptr[row[1] + 1] - beg[1]};
+    const int t_beg[2] = {t_rowptr[row[0]], t_rowptr[row[1]]};
+    const int t_len[2] = {t_rowptr[row[0] + 1] - t_beg[0], t_rowptr[row[1] + 1] - t_beg[1]};
     const float y_lab = labels[b];
-    const int nseg = (deg + kTaskEntries - 1) / kTaskEntries;
-    const float *__restrict__ Xl = X + lane;
-    // ---- 1. last layer at this row: segment sums
+    float run = 0.0f;
+    if (wave < 2) run = acc_in[(size_t)row[wave] * kWave + lane];
+    // the push's runs of 16 entries, both rows' runs numbered jointly and dealt over (part, wave); the first kPre of this wave
+    // are loaded here, ahead of the forward, so that their round trip is off the chain
+    const int n_run0 = (t_len[0] + 15) >> 4, n_runs = n_run0 + ((t_len[1] + 15) >> 4);
+    const int q_step = parts * kWgWaves;
+    int q = part * kWgWaves + wave;
+    int p_col[kPre], p_cnt[kPre], p_side[kPre];
+    float p_val[kPre];
+    auto load_runs = [&](int q0) {
 #pragma unroll
-    for (int vi = 0; vi < 2; ++vi) {
-        const int v = w8 + vi * kHalfWaves;                       // virtual wave of the row-list kernel
-        float acc = 0.0f;
-        for (int sgi = v; sgi < nseg; sgi += kWgWaves) {
-            const int e0 = beg + sgi * kTaskEntries;
-            const int cnt = (deg - sgi * kTaskEntries < kTaskEntries) ? deg - sgi * kTaskEntries : kTaskEntries;
-            int my_col = 0;
-            float my_val = 0.0f;
-            if (lane < cnt) {
-                my_col = col[e0 + lane];
-                my_val = val[e0 + lane];
-            }
-            const int last_col = __builtin_amdgcn_readlane(my_col, (cnt - 1) & 63);
-            if (lane >= cnt) my_col = last_col;                    // padding: value 0 on a row already being fetched
-            for (int c = 0; c * kChunk < cnt; ++c) {
-                float x[kChunk];
-#pragma unroll
-                for (int k = 0; k < kChunk; ++k)
-                    x[k] = Xl[(size_t)(uint32_t)__builtin_amdgcn_readlane(my_col, c * kChunk + k) * kWave];
-#pragma unroll
-                for (int k = 0; k < kChunk; ++k) acc = fmaf(lane_bcast(my_val, c * kChunk + k), x[k], acc);
+        for (int p = 0; p < kPre; ++p) {
+            const int qq = q0 + p * q_step;
+            p_col[p] = 0;
+            p_val[p] = 0.0f;
+            p_cnt[p] = 0;
+            p_side[p] = 0;
+            if (qq < n_runs) {
+                const int side = qq >= n_run0, rr = side ? qq - n_run0 : qq;
+                const int base = t_beg[side] + rr * 16, left = t_len[side] - rr * 16;
+                p_side[p] = side;
+                p_cnt[p] = left < 16 ? left : 16;
+                if (lane < p_cnt[p]) {
+                    p_col[p] = t_col[base + lane];
+                    p_val[p] = t_val[base + lane];
+                }
             }
         }
-        if (v < nseg) s_part[half][v][lane] = acc;
+    };
+    load_runs(q);
+    // ---- 1. last layer at both rows.  Row k's segments go to its virtual waves v = segment mod 16 as in the row-list kernel
+    //         (one accumulator chain per virtual wave); the two rows' virtual waves are numbered jointly and dealt to the 16 waves.
+    const int nseg[2] = {(deg[0] + kTaskEntries - 1) / kTaskEntries, (deg[1] + kTaskEntries - 1) / kTaskEntries};
+    const int nv0 = nseg[0] < kWgWaves ? nseg[0] : kWgWaves, nv = nv0 + (nseg[1] < kWgWaves ? nseg[1] : kWgWaves);
+    const float *__restrict__ Xl = X + lane;
+    for (int j = wave; j < nv; j += kWgWaves) {
+        const int side = j >= nv0, v = side ? j - nv0 : j;
+        float acc = 0.0f;
+        for (int sgi = v; sgi < nseg[side]; sgi += kWgWaves) {
+            const int left = deg[side] - sgi * kTaskEntries;
+            acc = segment_sum(col, val, Xl, beg[side] + sgi * kTaskEntries, left < kTaskEntries ? left : kTaskEntries, lane, acc);
+        }
+        s_part[side][v][lane] = acc;
     }
     __syncthreads();
-    // ---- 2. layer mean at both rows, the score, this row's gradient
-    if (w8 == 0) {
-        float y = nseg > 0 ? s_part[half][0][lane] : 0.0f;
-        const int lim = nseg < kWgWaves ? nseg : kWgWaves;
-        for (int w = 1; w < lim; ++w) y = y + s_part[half][w][lane];          // segment order
+    // ---- 2. layer mean at both rows (waves 0 and 1), the score, both gradient rows
+    if (wave < 2) {
+        const int lim = nseg[wave] < kWgWaves ? nseg[wave] : kWgWaves;
+        float y = lim > 0 ? s_part[wave][0][lane] : 0.0f;
+        for (int w = 1; w < lim; ++w) y = y + s_part[wave][w][lane];          // segment order
         float s = run + y;
         if (acc_div != 1.0f) s = s / acc_div;
-        s_light[half][lane] = s;
+        s_light[wave][lane] = s;
     }
     __syncthreads();
     const float lu = s_light[0][lane], li = s_light[1][lane];
     const float x = wave_sum_f32(fmaf(lu, li, 0.0f));
     const float dg = (sigmoid_f(x) - y_lab) * grad_scale;
-    const float g = dg * (half ? lu : li);
-    if (part == 0 && w8 == 0) {
-        if (half == 0 && lane == 0) atomicAdd(loss_sum, fmaxf(x, 0.0f) - x * y_lab + log1pf(expf(-fabsf(x))));
-        atomicAdd(g_out + (size_t)r * kWave + lane, g);                      // dense d loss / d light_out (rows may repeat in a batch)
-        atomicAdd(G + (size_t)r * kWave + lane, push_scale * g);             // the `g` of (g + A^T g) / (L + 1)
+    const float g2[2] = {dg * li, dg * lu};                                  // d loss / d light at the user row, at the item row
+    if (part == 0 && wave < 2) {
+        if (wave == 0 && lane == 0) {
+            const float bce = fmaxf(x, 0.0f) - x * y_lab + log1pf(expf(-fabsf(x)));
+            if (loss_rows) loss_rows[b] = bce;
+            else atomicAdd(loss_sum, bce);
+        }
+        atomicAdd(g_out + (size_t)row[wave] * kWave + lane, g2[wave]);        // dense d loss / d light_out (rows may repeat in a batch)
+        atomicAdd(G + (size_t)row[wave] * kWave + lane, push_scale * g2[wave]);   // the `g` of (g + A^T g) / (L + 1)
     }
-    // ---- 3. push over the row's entries in A^T: runs of 16 dealt over (part, wave of the half); every run's (col, val) pair
-    //         is loaded and lane 0 of each read before the first atomic, the entry loop is a real loop (rows.hip explains why)
-    const float gs = push_scale * g;
-    const int w_all = part * kHalfWaves + w8;
-    const int stride = parts * kHalfWaves * 16;
-    constexpr int kPre = 2;
+    // ---- 3. push over both rows' entries in A^T.  Lane 0 of every loaded run is read before the first atomic and the entry
+    //         loop is a real loop (rows.hip explains why: one vmcnt for loads and atomics).
     float *out_l = G + lane;
-    for (int base0 = t_beg + w_all * 16; base0 < t_end; base0 += kPre * stride) {
-        int my_col[kPre], c0[kPre];
-        float my_val[kPre], v0[kPre];
+    for (;;) {
+        int c0[kPre];
+        float v0[kPre];
 #pragma unroll
         for (int p = 0; p < kPre; ++p) {
-            const int base = base0 + p * stride;
-            my_col[p] = 0;
-            my_val[p] = 0.0f;
-            if (base + lane < t_end && lane < 16) {
-                my_col[p] = t_col[base + lane];
-                my_val[p] = t_val[base + lane];
-            }
+            c0[p] = __builtin_amdgcn_readlane(p_col[p], 0);
+            v0[p] = lane_bcast(p_val[p], 0);
         }
 #pragma unroll
         for (int p = 0; p < kPre; ++p) {
-            c0[p] = __builtin_amdgcn_readlane(my_col[p], 0);
-            v0[p] = lane_bcast(my_val[p], 0);
-        }
-#pragma unroll
-        for (int p = 0; p < kPre; ++p) {
-            const int base = base0 + p * stride;
-            const int cnt = t_end - base < 16 ? t_end - base : 16;           // (<= 0 past the row's end)
-            if (cnt > 0) atomicAdd(out_l + (size_t)c0[p] * kWave, v0[p] * gs);
+            const float gs = push_scale * (p_side[p] ? g2[1] : g2[0]);
+            if (p_cnt[p] > 0) atomicAdd(out_l + (size_t)c0[p] * kWave, v0[p] * gs);
 #pragma unroll 1
-            for (int j = 1; j < cnt; ++j) {
-                const int c = __builtin_amdgcn_readlane(my_col[p], j);
-                const float v = lane_bcast(my_val[p], j);
+            for (int j = 1; j < p_cnt[p]; ++j) {
+                const int c = __builtin_amdgcn_readlane(p_col[p], j);
+                const float v = lane_bcast(p_val[p], j);
                 atomicAdd(out_l + (size_t)c * kWave, v * gs);
             }
         }
+        q += kPre * q_step;
+        if (q >= n_runs) break;
+        load_runs(q);
     }
 }
 
@@ -146,10 +190,11 @@ __global__ __launch_bounds__(kWave *kWgWaves) void lightgcn_batch_kernel(
 
 extern "C" int spex_lightgcn_batch_f32(const spex_graph_t *g, const spex_graph_t *gt, const float *X, const float *acc_in, float acc_div,
                                        const int64_t *users, const int64_t *items, const float *labels, int32_t B,
-                                       int32_t n_user_rows, float grad_scale, float push_scale, float *loss_sum, float *g_out, float *G,
-                                       int32_t d, void *stream)
+                                       int32_t n_user_rows, float grad_scale, float push_scale, float *loss_sum, float *loss_per_sample,
+                                       float *g_out, float *G, int32_t d, void *stream)
 {
-    SPEX_CHECK_ARG(g && gt && X && acc_in && users && items && labels && loss_sum && g_out && G, "spex_lightgcn_batch_f32: NULL argument");
+    SPEX_CHECK_ARG(g && gt && X && acc_in && users && items && labels && (loss_sum || loss_per_sample) && g_out && G,
+                   "spex_lightgcn_batch_f32: NULL argument");
     SPEX_CHECK_ARG(B >= 0 && n_user_rows >= 0 && n_user_rows <= g->n_rows, "spex_lightgcn_batch_f32: B=%d n_user_rows=%d", B, n_user_rows);
     SPEX_CHECK_ARG(g->n_rows == g->n_cols && gt->n_rows == g->n_rows && gt->n_cols == g->n_rows, "spex_lightgcn_batch_f32: square graphs of one size");
     SPEX_CHECK_ARG(g->mask_mode == 0 && gt->mask_mode == 0, "spex_lightgcn_batch_f32: edge dropout is not supported here");
@@ -160,12 +205,12 @@ extern "C" int spex_lightgcn_batch_f32(const spex_graph_t *g, const spex_graph_t
     if (B == 0 || g->n_rows == 0) return SPEX_OK;
     static const int parts = []() {
         const char *e = getenv("SPEX_BATCH_PARTS");
-        const int p = e ? atoi(e) : 4;
+        const int p = e ? atoi(e) : 1;
         return p < 1 ? 1 : (p > 16 ? 16 : p);
     }();
     hipLaunchKernelGGL(lightgcn_batch_kernel, dim3((unsigned)B * parts), dim3(kWave * kWgWaves), 0, (hipStream_t)stream, g->rowptr, g->col,
                        g->val, gt->rowptr, gt->col, gt->val, g->n_rows, n_user_rows, X, acc_in, acc_div, users, items, labels, parts,
-                       grad_scale, push_scale, loss_sum, g_out, G);
+                       grad_scale, push_scale, loss_sum, loss_per_sample, g_out, G);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }

@@ -11,7 +11,9 @@ namespace spex {
 
 void set_error(const char *fmt, ...);
 int adam_step_z2(float *p, const float *g, float *m, float *v, int64_t n, int32_t t, float lr, float beta1, float beta2, float eps,
-                 float *zero_buf, float *zero_buf2, void *stream);   // optim.hip: spex_adam_step_f32 with a second buffer to clear
+                 float *zero_buf, float *zero_buf2, void *stream, const float *loss_rows = nullptr, int32_t n_loss = 0,
+                 float *loss_sum = nullptr);   // optim.hip: spex_adam_step_f32 with a second buffer to clear and the step's
+                                               // per-sample losses to fold into an accumulator
 
 int dual_task_adam(float *p, float *m, float *v, const float *g_E0, float *g_raw, float *g_user, float *g_small, float *g_prop,
                    float *push_zero, float *loss, float *loss_acc, float *prec, int64_t n_table, int64_t n_user, int64_t n_trust,

@@ -29,36 +29,38 @@ extern "C" int spex_lightgcn_step_bce_f32(spex_lightgcn_step_t *s, const int64_t
     SPEX_CHECK_ARG(s->slot_capacity >= 2 * B, "spex_lightgcn_step_bce_f32: slot capacity %d < 2 B = %d", s->slot_capacity, 2 * B);
     SPEX_CHECK_ARG(g->mask_mode == 0 && gt->mask_mode == 0, "spex_lightgcn_step_bce_f32: edge dropout is not supported in the one-call step");
     const size_t sz = (size_t)g->n_rows * d;
-    // ---- forward: layers 0 .. L-2 over the whole graph (running layer sum fused), the last layer at the batch's rows only
+    // ---- forward: layers 0 .. L-2 over the whole graph (running layer sum fused); the last layer is taken at the batch's rows only
     const float *cur = s->E0;
     for (int32_t l = 0; l + 1 < L; ++l) {
         float *nxt = s->ws_fwd + (size_t)(l & 1) * sz;
         SPEX_TRY(spex_spmm_f32(g, cur, nxt, nullptr, 1.0f, l == 0 ? s->E0 : s->light_out, s->light_out, 1.0f, d, stream));
         cur = nxt;
     }
-    SPEX_TRY(spex_spmm_rowlist_f32(g, cur, users, B, 0, items, B, n_u, nullptr, L == 1 ? s->E0 : s->light_out, s->lo_batch,
-                                   (float)(L + 1), d, stream));
-    // ---- scoring + BCE + gradient rows (g_out is all-zero between steps: the Adam pass below clears it)
-    SPEX_TRY(spex_score_bce_slots_f32(s->lo_batch, s->lo_batch + (size_t)n_u * d, d, d, n_u, g->n_rows - n_u, users, items, labels, B, d,
-                                      loss_sum, s->g_out, s->g_out + (size_t)n_u * d, 1.0f / (float)B, s->grad_slots, d, stream));
-    // ---- backward: G_{L-1} = (g + A^T g) / (L+1) in push form, slot by slot, then L-1 pull-form products
     if (L >= 2) {
-        float *G = s->ws_bwd;                     // all-zero here: cleared by the previous step's Adam pass (first call: by the caller)
-        SPEX_TRY(spex_spmm_push_batch_f32(gt, users, B, 0, items, B, n_u, s->grad_slots, d, s->grad_slots, d, 1.0f / (float)(L + 1), G, d,
-                                          stream));
+        // ---- the batch-sized middle as one launch: last layer + layer mean at the batch's rows, scores + BCE, gradient rows, and the
+        //      first backward product G_{L-1} = (g + A^T g) / (L+1) in push form (g_out and G are all-zero here: the Adam pass below
+        //      clears them for the next step; first call: the caller)
+        float *G = s->ws_bwd;
+        SPEX_TRY(spex_lightgcn_batch_f32(g, gt, cur, s->light_out, (float)(L + 1), users, items, labels, B, n_u, 1.0f / (float)B,
+                                         1.0f / (float)(L + 1), nullptr, s->grad_slots /* per-sample losses, summed by the Adam pass */,
+                                         s->g_out, G, d, stream));
+        // ---- L-1 pull-form products
         const float *c2 = G;
         for (int32_t l = L - 2; l >= 0; --l) {
             float *nxt = l == 0 ? s->grad_E0 : s->ws_bwd + (size_t)(1 + ((L - 2 - l) & 1)) * sz;   // ws_bwd[1], [2], [1] ...: never the source, never G
             SPEX_TRY(spex_spmm_f32(gt, c2, nxt, s->g_out, (float)(L + 1), nullptr, nullptr, 1.0f, d, stream));
             c2 = nxt;
         }
-    } else {    // L == 1: grad = (g + A^T g) / 2, one pull-form product
+    } else {    // L == 1: the last layer at the batch's rows, scoring, then grad = (g + A^T g) / 2 as one pull-form product
+        SPEX_TRY(spex_spmm_rowlist_f32(g, cur, users, B, 0, items, B, n_u, nullptr, s->E0, s->lo_batch, (float)(L + 1), d, stream));
+        SPEX_TRY(spex_score_bce_slots_f32(s->lo_batch, s->lo_batch + (size_t)n_u * d, d, d, n_u, g->n_rows - n_u, users, items, labels, B, d,
+                                          loss_sum, s->g_out, s->g_out + (size_t)n_u * d, 1.0f / (float)B, s->grad_slots, d, stream));
         SPEX_TRY(spex_propagate_bwd_f32(gt, s->g_out, s->grad_E0, s->ws_bwd, L, d, stream));
     }
     // ---- Adam over the whole table (also clears g_out for the next step)
     s->t += 1;
     SPEX_TRY(spex::adam_step_z2(s->E0, s->grad_E0, s->m, s->v, (int64_t)sz, s->t, s->lr, s->beta1, s->beta2, s->eps, s->g_out,
-                                L >= 2 ? s->ws_bwd : nullptr, stream));
+                                L >= 2 ? s->ws_bwd : nullptr, stream, L >= 2 ? s->grad_slots : nullptr, B, loss_sum));
     return SPEX_OK;
 }
 

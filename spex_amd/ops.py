@@ -301,6 +301,32 @@ def spmm_push_batch(graph, idx_a, idx_b, off_b, src, out, add=None, scale=1.0):
     return out
 
 
+def lightgcn_batch(graph, graph_t, X, acc_in, acc_div, users, items, labels, n_user_rows, grad_scale, push_scale, loss_sum, g_out, G,
+                   loss_per_sample=None):
+    """The batch-sized middle of the exact LightGCN step as one launch (spex_lightgcn_batch_f32): last layer + layer mean at
+    the batch's rows, scores + BCE, dense gradient rows added into g_out, and G += push_scale * (g + A^T g) in push form.
+    loss_sum: fp32 [1] (accumulated) — or loss_per_sample: fp32 [B], every sample's loss stored instead; g_out, G: fp32 [N, 64]
+    (accumulated: zero them first)."""
+    n = graph.n_rows
+    for t, nm in ((X, "X"), (acc_in, "acc_in"), (g_out, "g_out"), (G, "G")):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.shape == (n, 64)):
+            raise ValueError(f"lightgcn_batch: {nm} must be a contiguous fp32 [{n}, 64] device tensor")
+    B = users.numel()
+    for t, dt, nm in ((users, torch.int64, "users"), (items, torch.int64, "items"), (labels, torch.float32, "labels")):
+        if not (t.is_cuda and t.dtype == dt and t.is_contiguous() and t.numel() == B):
+            raise ValueError(f"lightgcn_batch: {nm} must be a contiguous device tensor of the batch's length")
+    for t, k, nm in ((loss_sum, 1, "loss_sum"), (loss_per_sample, B, "loss_per_sample")):
+        if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() >= k):
+            raise ValueError(f"lightgcn_batch: {nm} must be a contiguous fp32 device tensor of >= {k} elements")
+    if loss_sum is None and loss_per_sample is None:
+        raise ValueError("lightgcn_batch: needs loss_sum or loss_per_sample")
+    _launch(X.device, "spex_lightgcn_batch_f32", graph._h, graph_t._h, _ptr(X), _ptr(acc_in), float(acc_div), _ptr(users), _ptr(items),
+            _ptr(labels), B, int(n_user_rows), float(grad_scale), float(push_scale), _ptr(loss_sum), _ptr(loss_per_sample), _ptr(g_out),
+            _ptr(G), 64)
+    _bump(loss_sum, loss_per_sample, g_out, G)
+    return loss_sum if loss_per_sample is None else loss_per_sample
+
+
 def expert_gate(raw, prop, att_exp):
     """softmax([raw|prop] att_exp) two-way mix — model_expert_s.py:156-161."""
     for x, n in ((raw, "raw"), (prop, "prop"), (att_exp, "att_exp")):

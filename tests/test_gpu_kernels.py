@@ -929,6 +929,75 @@ def test_spmm_rowlist_is_the_full_product_at_the_listed_rows(G, golden, epinion2
     assert torch.equal(got[torch.tensor([3, 7, 299], device=DEV)], want[torch.tensor([3, 7, 299], device=DEV)])
 
 
+def test_lightgcn_batch_kernel_equals_the_three_launch_sequence(G, golden, epinion2, oracle):
+    """spex_lightgcn_batch_f32 (last layer at the batch's rows + layer mean + scores + BCE + gradient rows + push-form first
+    backward product, one launch) against (a) the sequence it replaces — spmm_rows, score_bce with per-sample rows,
+    spmm_push_batch — and (b) the oracle's loss / dense gradient on the same inputs.  Epinion2 (hub rows of ~1 000 entries
+    among the batch's rows, repeated users and items), B = 256 as in the reference driver; a second batch carries an
+    out-of-range index, which is skipped."""
+    from spex_amd import ops
+    g_, csr, E0 = _epinion2(golden, epinion2)
+    g = G(*csr)                                                          # symmetric: A^T == A
+    n, n_u, L = len(E0), 3186, 3
+    rng = np.random.default_rng(12)
+    X, run = t(E0), t((rng.normal(size=E0.shape) * 0.05).astype(np.float32))
+    deg = np.diff(csr[0])
+    users = rng.integers(0, 3185, 256)
+    items = rng.integers(0, 12407, 256)
+    users[:4] = np.argsort(-deg[:n_u])[:4]                               # the heaviest user rows
+    items[:4] = np.argsort(-deg[n_u:])[:4]                               # the heaviest item rows (~1 000 entries)
+    users[10:14] = users[0]                                              # repeats
+    items[20:30] = items[1]
+    labels = (rng.random(256) < 1 / 6).astype(np.float32)
+    u_d, i_d, y_d = t(users), t(items), t(labels)
+    # (a) the three-launch sequence
+    lo = run.clone()
+    g.spmm_rows(X, u_d, i_d, 0, n_u, acc_in=run, acc_out=lo, acc_div=float(L + 1))
+    slots = torch.zeros(512, 64, device=DEV)
+    loss_a = torch.zeros(1, device=DEV)
+    g_out_a = torch.zeros(n, 64, device=DEV)
+    ops.score_bce(lo[:n_u], lo[n_u:], u_d, i_d, y_d, loss_sum=loss_a, grad_users=g_out_a[:n_u], grad_items=g_out_a[n_u:],
+                  grad_scale=1.0 / 256, grad_slots=slots)
+    G_a = torch.zeros(n, 64, device=DEV)
+    ops.spmm_push_batch(g, u_d, i_d, n_u, slots, G_a, add=slots, scale=1.0 / (L + 1))
+    # the fused launch
+    loss_b, g_out_b, G_b = torch.zeros(1, device=DEV), torch.zeros(n, 64, device=DEV), torch.zeros(n, 64, device=DEV)
+    ops.lightgcn_batch(g, g, X, run, float(L + 1), u_d, i_d, y_d, n_u, 1.0 / 256, 1.0 / (L + 1), loss_b, g_out_b, G_b)
+    assert abs(loss_a.item() - loss_b.item()) <= 1e-5 * abs(loss_a.item())
+    assert rel_err(g_out_b.cpu().numpy(), g_out_a.cpu().numpy()) <= 2e-6       # float atomics: order only
+    assert rel_err(G_b.cpu().numpy(), G_a.cpu().numpy()) <= 2e-6
+    # (b) the oracle: light rows, loss, dense gradient, then (g + A^T g) / (L + 1) in pull form
+    light = (run.cpu().numpy() + oracle.spmm(*csr, E0)) / np.float32(L + 1)
+    x = np.einsum("bd,bd->b", light[users].astype(np.float64), light[items + n_u].astype(np.float64))
+    want_loss = np.sum(np.maximum(x, 0) - x * labels + np.log1p(np.exp(-np.abs(x))))
+    assert abs(loss_b.item() - want_loss) <= 2e-6 * abs(want_loss) + 1e-6
+    dg = ((1.0 / (1.0 + np.exp(-x)) - labels) / 256.0)
+    want_g = np.zeros((n, 64))
+    np.add.at(want_g, users, dg[:, None] * light[items + n_u])
+    np.add.at(want_g, items + n_u, dg[:, None] * light[users])
+    assert rel_err(g_out_b.cpu().numpy(), want_g) <= 5e-6
+    want_G = (want_g + oracle.spmm(*csr, want_g.astype(np.float32)).astype(np.float64)) / (L + 1)
+    assert rel_err(G_b.cpu().numpy(), want_G) <= 1e-5
+    # an out-of-range index skips its sample, everything else is unchanged
+    bad_u = users.copy()
+    bad_u[7] = 999999
+    ok = np.ones(256, bool); ok[7] = False
+    loss_c, g_out_c, G_c = torch.zeros(1, device=DEV), torch.zeros(n, 64, device=DEV), torch.zeros(n, 64, device=DEV)
+    ops.lightgcn_batch(g, g, X, run, float(L + 1), t(bad_u), i_d, y_d, n_u, 1.0 / 256, 1.0 / (L + 1), loss_c, g_out_c, G_c)
+    want_gc = np.zeros((n, 64))
+    np.add.at(want_gc, users[ok], dg[ok, None] * light[items[ok] + n_u])
+    np.add.at(want_gc, items[ok] + n_u, dg[ok, None] * light[users[ok]])
+    assert rel_err(g_out_c.cpu().numpy(), want_gc) <= 5e-6
+    assert torch.isfinite(G_c).all()
+    # per-sample losses instead of the accumulated sum (what the one-call step uses: its Adam pass adds them up in order)
+    per = torch.full((256,), 7.0, device=DEV)
+    ops.lightgcn_batch(g, g, X, run, float(L + 1), t(bad_u), i_d, y_d, n_u, 1.0 / 256, 1.0 / (L + 1), None, torch.zeros_like(g_out_c),
+                       torch.zeros_like(G_c), loss_per_sample=per)
+    want_per = np.maximum(x, 0) - x * labels + np.log1p(np.exp(-np.abs(x)))
+    want_per[7] = 0.0
+    assert np.abs(per.cpu().numpy() - want_per).max() <= 2e-6
+
+
 # ---------------------------------------------------------------------------------------------- row-sparse backward pieces
 def test_unique_rows_and_push_form_spmm_vs_oracle(G, oracle):
     """spex_unique_rows_i32 + spex_spmm_push_rows_f32: the distinct rows of a batch with repeats (and an out-of-range index),
