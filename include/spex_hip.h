@@ -80,8 +80,11 @@ int spex_graph_set_edge_mask(spex_graph_t *g, int mode /*0 off, 1 injected, 2 sa
  *   if acc_out:    acc_out[r,:] = (acc_in[r,:] + y) / acc_div   (running layer sum; acc_div = L+1 on the last layer)
  *
  * X: [n_cols, d]; Y, add_in, acc_in, acc_out: [n_rows, d].  acc_in may equal acc_out.  X must not alias Y / acc_out.
- * Any d >= 1 (d == 64 takes the tuned path: one lane per column).  On a graph with long rows, calls on one handle
- * must be stream-ordered (they share the handle's partial-sum scratch).
+ * Any d >= 1 (d == 64 takes the tuned path: one lane per column).  A graph with long rows sums their segments through a
+ * scratch buffer owned by the handle: calls on ONE stream are ordered by the stream; a call on another stream is made to
+ * wait (an event, inserted by the library) for everything queued on the stream that used the scratch last, so one handle
+ * may be driven from several streams of one host thread.  Concurrent calls from several HOST threads on one handle are
+ * not supported (one handle per thread).
  */
 int spex_spmm_f32(const spex_graph_t *g, const float *X, float *Y, const float *add_in, float add_div,
                   const float *acc_in, float *acc_out, float acc_div, int32_t d, void *stream);

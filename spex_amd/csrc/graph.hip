@@ -65,6 +65,7 @@ extern "C" int spex_graph_destroy(spex_graph_t *g)
                     g->task, g->chunk_off, g->chunk_val, g->chunk_mask, g->chunk_eid, g->chunk_row, g->hub_row, g->hub_seg0, g->row_of, g->tile_row, g->chunk_pad};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (g->scratch_ev) (void)hipEventDestroy(g->scratch_ev);
     delete g;
     return SPEX_OK;
 }

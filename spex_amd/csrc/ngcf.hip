@@ -570,6 +570,210 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Rows form, one WORKGROUP per 16-slot tile: the four waves split every product by output block.  The one-wave-per-tile form
+// above is a single wave's dependent chain of ~400 MFMAs and their LDS operand reads per tile (26 us for the 32 tiles of a
+// 256-sample batch, on 32 of the chip's 1 024 SIMDs); here wave b owns
+//   recompute     columns 16b .. 16b+15 of s and t               (2 x 16 MFMAs, contraction over the 64 inputs)
+//   elementwise   the same 16 columns; the two row sums over all 64 columns go through LDS (4 partials per row)
+//   dW            rows 16b .. 16b+15 of dW_gc, dW_bi             (2 x 16 MFMAs, contraction over the tile's 16 rows)
+//   dX            columns 16b .. 16b+15 of G_s W_gc, G_t W_bi    (2 x 16 MFMAs, contraction over the 64 outputs)
+// with four workgroup barriers (tile + weights staged; sum of squares; <g, out>; G tiles).  Same operand dealing as above
+// (k = 16h + j, transposed weight copy), same arithmetic per element; the 64-column row sums are associated as 4 x 16.
+__global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_rows4_kernel(
+    const float *__restrict__ ego, const float *__restrict__ side, const float *__restrict__ W_gc,
+    const float *__restrict__ b_gc, const float *__restrict__ W_bi, const float *__restrict__ b_bi,
+    const float *__restrict__ g_norm, int ld_g, const float *__restrict__ g_next, const float *__restrict__ g_direct,
+    int ld_direct, int n, float slope, const MsgDrop drop, const int64_t *__restrict__ idx_a, int n_a, int64_t off_a,
+    const int64_t *__restrict__ idx_b, int n_b, int64_t off_b, float *__restrict__ g_side, float *__restrict__ g_ego,
+    float *__restrict__ partials, int part_stride)
+{
+    __shared__ float s_w[2][64 * kBwdStride];                   // W_gc, W_bi as [out o][in k]
+    __shared__ float s_wT[2][64 * kBwdStride];                  // transposed, [in k][out o]
+    __shared__ float s_tile[5][16 * kBwdStride];                // side, ego, ego * side, G_s, G_t
+    __shared__ float s_red[2][kBwdWaves][16];                   // per-wave partial row sums: squares, <g_norm, out>
+    const int lane = threadIdx.x & (kWave - 1), b = threadIdx.x >> 6;      // wave == output block
+    const int i16 = lane & 15, h = lane >> 4;
+    const int n_items = n_a + n_b, tile = blockIdx.x, r0 = tile << 4;
+    float *t_side = s_tile[0], *t_ego = s_tile[1], *t_prod = s_tile[2], *t_gs = s_tile[3], *t_gt = s_tile[4];
+    // ---- the tile's rows (lane i < 16: slot r0 + i), requested first; wave b stages rows 4b .. 4b+3 (lane == column)
+    int slot_row = -1;
+    if (lane < 16 && r0 + lane < n_items) {
+        const long long r = batch_row(idx_a, n_a, off_a, idx_b, off_b, r0 + lane);
+        slot_row = (r >= 0 && r < n) ? (int)r : -1;
+    }
+    int row_q[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) row_q[q] = __shfl(slot_row, 4 * h + q, kWave);
+    float e_reg[4], s_reg[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = __builtin_amdgcn_readlane(slot_row, 4 * b + i);
+        e_reg[i] = s_reg[i] = 0.0f;
+        if (r >= 0) {
+            e_reg[i] = ego[(size_t)r * 64 + lane];
+            s_reg[i] = side[(size_t)r * 64 + lane];
+        }
+    }
+    // upstream gradients of this wave's 16 columns, accumulator layout (row 4h + q, column 16b + i16)
+    float gn[4], gx[4], gd[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        gn[q] = gx[q] = gd[q] = 0.0f;
+        if (row_q[q] >= 0) {
+            gn[q] = g_norm[(size_t)(r0 + 4 * h + q) * ld_g + 16 * b + i16];
+            if (g_next) gx[q] = g_next[(size_t)row_q[q] * 64 + 16 * b + i16];
+            if (g_direct) gd[q] = g_direct[(size_t)(r0 + 4 * h + q) * ld_direct + 16 * b + i16];
+        }
+    }
+    const float bias_g = b_gc[16 * b + i16], bias_b = b_bi[16 * b + i16];
+    for (int i = threadIdx.x; i < 64 * 16; i += blockDim.x) {
+        const int r = i >> 4, c4 = (i & 15) * 4;
+        const float4 a = *reinterpret_cast<const float4 *>(W_gc + r * 64 + c4);
+        const float4 w = *reinterpret_cast<const float4 *>(W_bi + r * 64 + c4);
+        *reinterpret_cast<float4 *>(&s_w[0][r * kBwdStride + c4]) = a;
+        *reinterpret_cast<float4 *>(&s_w[1][r * kBwdStride + c4]) = w;
+        s_wT[0][(c4 + 0) * kBwdStride + r] = a.x; s_wT[0][(c4 + 1) * kBwdStride + r] = a.y;
+        s_wT[0][(c4 + 2) * kBwdStride + r] = a.z; s_wT[0][(c4 + 3) * kBwdStride + r] = a.w;
+        s_wT[1][(c4 + 0) * kBwdStride + r] = w.x; s_wT[1][(c4 + 1) * kBwdStride + r] = w.y;
+        s_wT[1][(c4 + 2) * kBwdStride + r] = w.z; s_wT[1][(c4 + 3) * kBwdStride + r] = w.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        t_side[(4 * b + i) * kBwdStride + lane] = s_reg[i];
+        t_ego[(4 * b + i) * kBwdStride + lane] = e_reg[i];
+        t_prod[(4 * b + i) * kBwdStride + lane] = e_reg[i] * s_reg[i];
+    }
+    __syncthreads();                                                                  // (1) tile + weights staged
+    // ---- recompute this block's columns of s and t
+    f32x4 acc_g = (f32x4){0.f, 0.f, 0.f, 0.f}, acc_b = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+        float4 ag[4], ab[4], wg[4], wb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ag[j] = *reinterpret_cast<const float4 *>(&t_side[i16 * kBwdStride + 16 * h + 4 * j]);
+            ab[j] = *reinterpret_cast<const float4 *>(&t_prod[i16 * kBwdStride + 16 * h + 4 * j]);
+            wg[j] = *reinterpret_cast<const float4 *>(&s_w[0][(16 * b + i16) * kBwdStride + 16 * h + 4 * j]);
+            wb[j] = *reinterpret_cast<const float4 *>(&s_w[1][(16 * b + i16) * kBwdStride + 16 * h + 4 * j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc_g = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[j].x, wg[j].x, acc_g, 0, 0, 0);
+            acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[j].x, wb[j].x, acc_b, 0, 0, 0);
+            acc_g = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[j].y, wg[j].y, acc_g, 0, 0, 0);
+            acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[j].y, wb[j].y, acc_b, 0, 0, 0);
+            acc_g = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[j].z, wg[j].z, acc_g, 0, 0, 0);
+            acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[j].z, wb[j].z, acc_b, 0, 0, 0);
+            acc_g = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[j].w, wg[j].w, acc_g, 0, 0, 0);
+            acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[j].w, wb[j].w, acc_b, 0, 0, 0);
+        }
+    }
+    // ---- elementwise chain on this block's columns; row sums over all 64 columns through LDS
+    float e1d[4], kscale[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float x = acc_g[q] + bias_g, y = acc_b[q] + bias_b;
+        float e = (x >= 0.0f ? x : x * slope) + (y >= 0.0f ? y : y * slope);
+        float ks = 1.0f;
+        if (drop.p > 0.0f) {
+            ks = (row_q[q] >= 0 && msg_keep(drop, row_q[q], 16 * b + i16)) ? drop.scale : 0.0f;
+            e = ks != 0.0f ? e * ks : 0.0f;
+        }
+        kscale[q] = ks;
+        e1d[q] = e;
+        const float v = row16_sum_f32(e * e);
+        if (i16 == 0) s_red[0][b][4 * h + q] = v;
+    }
+    __syncthreads();                                                                  // (2) squares
+    float den[4], nrm[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int rr = 4 * h + q;
+        nrm[q] = sqrtf(((s_red[0][0][rr] + s_red[0][1][rr]) + s_red[0][2][rr]) + s_red[0][3][rr]);
+        den[q] = fmaxf(nrm[q], 1e-12f);
+        const float v = row16_sum_f32(gn[q] * (e1d[q] / den[q]));
+        if (i16 == 0) s_red[1][b][rr] = v;
+    }
+    __syncthreads();                                                                  // (3) <g_norm, out>
+    float Gs[4], Gt[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int rr = 4 * h + q;
+        float dot = ((s_red[1][0][rr] + s_red[1][1][rr]) + s_red[1][2][rr]) + s_red[1][3][rr];
+        dot = (nrm[q] >= 1e-12f) ? dot : 0.0f;                   // below eps the clamp holds the denominator constant
+        const float o = e1d[q] / den[q];
+        const float ge1d = (gn[q] - o * dot) / den[q] + gx[q];
+        const float ge1 = row_q[q] >= 0 ? ge1d * kscale[q] : 0.0f;
+        const float x = acc_g[q] + bias_g, y = acc_b[q] + bias_b;
+        Gs[q] = ge1 * (x > 0.0f ? 1.0f : slope);
+        Gt[q] = ge1 * (y > 0.0f ? 1.0f : slope);
+        t_gs[rr * kBwdStride + 16 * b + i16] = Gs[q];
+        t_gt[rr * kBwdStride + 16 * b + i16] = Gt[q];
+    }
+    // ---- weight gradients, rows 16b .. 16b+15: dW[o][k] = sum_r G[r][o] X[r][k], row 4h + st at step st of lane group h
+    float *dst = partials + (size_t)tile * part_stride;
+    {
+        float cs = (Gs[0] + Gs[1]) + (Gs[2] + Gs[3]), ct = (Gt[0] + Gt[1]) + (Gt[2] + Gt[3]);
+        cs += __shfl_xor(cs, 16, kWave); cs += __shfl_xor(cs, 32, kWave);
+        ct += __shfl_xor(ct, 16, kWave); ct += __shfl_xor(ct, 32, kWave);
+        if (h == 0) {
+            dst[64 * 64 + 16 * b + i16] = cs;
+            dst[2 * 64 * 64 + 64 + 16 * b + i16] = ct;
+        }
+    }
+#pragma unroll
+    for (int bn = 0; bn < 4; ++bn) {
+        f32x4 dWg = (f32x4){0.f, 0.f, 0.f, 0.f}, dWb = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const float sc = t_side[(4 * h + st) * kBwdStride + 16 * bn + i16];
+            const float pc = t_prod[(4 * h + st) * kBwdStride + 16 * bn + i16];
+            dWg = __builtin_amdgcn_mfma_f32_16x16x4f32(Gs[st], sc, dWg, 0, 0, 0);
+            dWb = __builtin_amdgcn_mfma_f32_16x16x4f32(Gt[st], pc, dWb, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int a_ = (16 * b + 4 * h + q) * 64 + 16 * bn + i16;
+            dst[a_] = dWg[q];
+            dst[64 * 64 + 64 + a_] = dWb[q];
+        }
+    }
+    __syncthreads();                                                                  // (4) G tiles complete
+    // ---- input gradients, columns 16b .. 16b+15: ts = G_s W_gc, tb = G_t W_bi (contraction over the 64 outputs o = 16h + j)
+    f32x4 ts = (f32x4){0.f, 0.f, 0.f, 0.f}, tb = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+        float4 as[4], at[4], wg[4], wb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            as[j] = *reinterpret_cast<const float4 *>(&t_gs[i16 * kBwdStride + 16 * h + 4 * j]);
+            at[j] = *reinterpret_cast<const float4 *>(&t_gt[i16 * kBwdStride + 16 * h + 4 * j]);
+            wg[j] = *reinterpret_cast<const float4 *>(&s_wT[0][(16 * b + i16) * kBwdStride + 16 * h + 4 * j]);
+            wb[j] = *reinterpret_cast<const float4 *>(&s_wT[1][(16 * b + i16) * kBwdStride + 16 * h + 4 * j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ts = __builtin_amdgcn_mfma_f32_16x16x4f32(as[j].x, wg[j].x, ts, 0, 0, 0);
+            tb = __builtin_amdgcn_mfma_f32_16x16x4f32(at[j].x, wb[j].x, tb, 0, 0, 0);
+            ts = __builtin_amdgcn_mfma_f32_16x16x4f32(as[j].y, wg[j].y, ts, 0, 0, 0);
+            tb = __builtin_amdgcn_mfma_f32_16x16x4f32(at[j].y, wb[j].y, tb, 0, 0, 0);
+            ts = __builtin_amdgcn_mfma_f32_16x16x4f32(as[j].z, wg[j].z, ts, 0, 0, 0);
+            tb = __builtin_amdgcn_mfma_f32_16x16x4f32(at[j].z, wb[j].z, tb, 0, 0, 0);
+            ts = __builtin_amdgcn_mfma_f32_16x16x4f32(as[j].w, wg[j].w, ts, 0, 0, 0);
+            tb = __builtin_amdgcn_mfma_f32_16x16x4f32(at[j].w, wb[j].w, tb, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (row_q[q] >= 0) {
+            const int rr = 4 * h + q, c = 16 * b + i16;
+            const size_t o = (size_t)(r0 + rr) * 64 + c;                      // compact slot
+            g_side[o] = ts[q] + tb[q] * t_ego[rr * kBwdStride + c];
+            g_ego[o] = tb[q] * t_side[rr * kBwdStride + c] + gd[q];
+        }
+    }
+}
+
+
 __global__ __launch_bounds__(kWave *kWavesPerBlock) void expert_gate_kernel(const float *__restrict__ raw,
                                                                            const float *__restrict__ prop,
                                                                            const float *__restrict__ att,
@@ -897,10 +1101,17 @@ extern "C" int spex_ngcf_layer_bwd_rows_f32(const float *ego, const float *side,
     SPEX_CHECK_ARG((((uintptr_t)W_gc | (uintptr_t)W_bi) & 15) == 0, "spex_ngcf_layer_bwd_rows_f32: weights must be 16-byte aligned");
     if (n == 0 || n_a + n_b == 0) return SPEX_OK;
     const int tiles = spex_ngcf_layer_bwd_rows_parts(n_a + n_b);
-    hipLaunchKernelGGL((ngcf_layer_bwd_kernel<true>), dim3((unsigned)((tiles + kBwdWaves - 1) / kBwdWaves)), dim3(kWave * kBwdWaves), 0,
-                       (hipStream_t)stream, ego, side, W_gc, b_gc, W_bi, b_bi, g_norm_c, ld_g, g_next, g_direct_c, ld_direct, n, slope,
-                       make_drop(p_drop, seed, step, layer, pad_row), idx_a, n_a, off_a, idx_b, n_b, off_b, g_side_c, g_ego_c, nullptr,
-                       nullptr, nullptr, nullptr, gW_parts, part_stride);
+    static const bool one_wave_form = []() { const char *e = getenv("SPEX_NGCF_ROWS_ONE_WAVE"); return e && e[0] == '1'; }();
+    if (one_wave_form)      // the earlier form (one wave per tile), kept for A/B timing
+        hipLaunchKernelGGL((ngcf_layer_bwd_kernel<true>), dim3((unsigned)((tiles + kBwdWaves - 1) / kBwdWaves)), dim3(kWave * kBwdWaves), 0,
+                           (hipStream_t)stream, ego, side, W_gc, b_gc, W_bi, b_bi, g_norm_c, ld_g, g_next, g_direct_c, ld_direct, n, slope,
+                           make_drop(p_drop, seed, step, layer, pad_row), idx_a, n_a, off_a, idx_b, n_b, off_b, g_side_c, g_ego_c, nullptr,
+                           nullptr, nullptr, nullptr, gW_parts, part_stride);
+    else
+        hipLaunchKernelGGL(ngcf_layer_bwd_rows4_kernel, dim3((unsigned)tiles), dim3(kWave * kBwdWaves), 0, (hipStream_t)stream, ego, side,
+                           W_gc, b_gc, W_bi, b_bi, g_norm_c, ld_g, g_next, g_direct_c, ld_direct, n, slope,
+                           make_drop(p_drop, seed, step, layer, pad_row), idx_a, n_a, off_a, idx_b, n_b, off_b, g_side_c, g_ego_c,
+                           gW_parts, part_stride);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }

@@ -124,6 +124,12 @@ struct spex_graph {
     int32_t *long_seg0 = nullptr; // [n_long+1] first segment of each long row
     float *partial = nullptr;     // [n_seg * d_cap] scratch, grown on demand
     int64_t partial_cap = 0;      // floats
+    // The scratch is the one piece of a handle that launches WRITE.  Calls on one stream are ordered by the stream; a call
+    // on another stream first waits (event) for everything queued on the stream that used the scratch last — so two streams
+    // may share a handle (two HOST threads may not: these fields are plain).
+    hipStream_t scratch_stream = nullptr;
+    bool scratch_used = false;
+    hipEvent_t scratch_ev = nullptr;
     // Chunked copy of the matrix for the d == 64 kernel (built when n_cols * 256 B fits a 32-bit buffer offset).
     // A chunk is 16 stored entries: byte offsets of their source rows (col * 256), their values, and a 16-bit mask
     // marking entries that end an output row.  A wave TASK is a run of <= 4 chunks (64 entries): whole consecutive

@@ -752,6 +752,16 @@ int launch_spmm(const spex_graph *g, const float *X, float *Y, const float *add_
     const dim3 grid((unsigned)blocks), block(kWave * per_block), block4(kWave * kWavesPerBlock);
     spex_timer *tm = g->timer;
     if (tm && tm->open) tm->launches[tm->used]++;
+    if (fast ? g->n_hub > 0 : g->n_long > 0) {   // this launch writes the handle's scratch: order it behind its last user
+        spex_graph *gm = const_cast<spex_graph *>(g);
+        if (gm->scratch_used && gm->scratch_stream != stream) {
+            if (!gm->scratch_ev) SPEX_HIP(hipEventCreateWithFlags(&gm->scratch_ev, hipEventDisableTiming));
+            SPEX_HIP(hipEventRecord(gm->scratch_ev, gm->scratch_stream));
+            SPEX_HIP(hipStreamWaitEvent(stream, gm->scratch_ev, 0));
+        }
+        gm->scratch_stream = stream;
+        gm->scratch_used = true;
+    }
     if (fast) {
         const int xcd_contig = ((int64_t)g->n_cols * d * 4 <= (int64_t)16 << 20) ? 1 : 0;  // source table <= 16 MiB
         DropArgs da;

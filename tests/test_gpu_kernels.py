@@ -998,6 +998,29 @@ def test_lightgcn_batch_kernel_equals_the_three_launch_sequence(G, golden, epini
     assert np.abs(per.cpu().numpy() - want_per).max() <= 2e-6
 
 
+def test_one_handle_driven_from_two_streams(G):
+    """A graph with hub rows (> 1024 entries: their segment sums go through the handle's scratch buffer) driven from two
+    streams in alternation: the library orders each launch behind the scratch's previous user, so every product equals the
+    one computed alone on the default stream (bit for bit: the kernel is deterministic)."""
+    rng = np.random.default_rng(77)
+    deg = rng.integers(0, 60, 2000)
+    deg[[3, 500, 1999]] = [3000, 2500, 1100]
+    rowptr, col, val = random_csr(rng, 2000, 4000, deg)
+    g = G(rowptr, col, val, n_cols=4000)
+    Xs = [t(rng.normal(size=(4000, 64)).astype(np.float32)) for _ in range(6)]
+    want = [g.spmm(X).clone() for X in Xs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [torch.empty(2000, 64, device=DEV) for _ in Xs]
+    for rep in range(20):
+        for k, X in enumerate(Xs):
+            with torch.cuda.stream(streams[k & 1]):
+                g.spmm(X, Y=outs[k])
+    torch.cuda.synchronize()
+    for k in range(len(Xs)):
+        assert torch.equal(outs[k], want[k]), k
+
+
 # ---------------------------------------------------------------------------------------------- row-sparse backward pieces
 def test_unique_rows_and_push_form_spmm_vs_oracle(G, oracle):
     """spex_unique_rows_i32 + spex_spmm_push_rows_f32: the distinct rows of a batch with repeats (and an out-of-range index),
