@@ -180,6 +180,100 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void ngcf_layer_kernel(
     }
 }
 
+// The same layer with FOUR waves per 16-row tile (16-wave workgroups = 4 tiles; the weights are staged once per workgroup):
+// wave b of a tile owns output columns 16b .. 16b+15 — 2 x 16 MFMAs instead of 2 x 64, a quarter of the Philox draws — and
+// the row's sum of squares over all 64 columns goes through LDS (4 partials per row, one workgroup barrier).  Operands are
+// dealt k = 16h + j (16 consecutive floats per lane: ds_read_b128), as in the backward kernels.  The one-wave-per-tile form
+// above is a single wave's chain per tile: 13.3 us on Epinion2's 975 tiles (with message dropout), this form: see DESIGN.md.
+constexpr int kFwdStride = 68;
+constexpr int kFwdTiles = 4;                                      // tiles per workgroup
+
+__global__ __launch_bounds__(kWave * 4 * kFwdTiles) void ngcf_layer_fwd4_kernel(
+    const float *__restrict__ ego, const float *__restrict__ side, const float *__restrict__ W_gc,
+    const float *__restrict__ b_gc, const float *__restrict__ W_bi, const float *__restrict__ b_bi,
+    float *__restrict__ out, int ld_out, int write_ego, float *__restrict__ e1_out, int n, float slope, const MsgDrop drop)
+{
+    __shared__ float s_w[2][64 * kFwdStride];                       // W_gc, W_bi as [out j][in k]
+    __shared__ float s_t[kFwdTiles][2][16 * kFwdStride];            // per tile: side, ego * side
+    __shared__ float s_sq[kFwdTiles][4][16];                        // per tile and column block: partial sums of squares per row
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int tl = wave >> 2, b = wave & 3;
+    const int i16 = lane & 15, h = lane >> 4;
+    const int r0 = (blockIdx.x * kFwdTiles + tl) << 4;              // (tiles past the end: every row fails r < n)
+    float *t_side = s_t[tl][0], *t_prod = s_t[tl][1];
+    // this wave's four rows of the tile (lane == column), requested before the weights
+    float e_reg[4], s_reg[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + 4 * b + i;
+        e_reg[i] = s_reg[i] = 0.0f;
+        if (r < n) {
+            e_reg[i] = ego[(size_t)r * 64 + lane];
+            s_reg[i] = side[(size_t)r * 64 + lane];
+        }
+    }
+    const float bias_g = b_gc[16 * b + i16], bias_b = b_bi[16 * b + i16];
+    for (int i = threadIdx.x; i < 64 * 16; i += blockDim.x) {       // 1024 float4 per matrix, coalesced
+        const int r = i >> 4, c4 = (i & 15) * 4;
+        *reinterpret_cast<float4 *>(&s_w[0][r * kFwdStride + c4]) = *reinterpret_cast<const float4 *>(W_gc + r * 64 + c4);
+        *reinterpret_cast<float4 *>(&s_w[1][r * kFwdStride + c4]) = *reinterpret_cast<const float4 *>(W_bi + r * 64 + c4);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + 4 * b + i;
+        if (write_ego && r < n) out[(size_t)r * ld_out + lane] = e_reg[i];      // `ego` passes through to the output's first half
+        t_side[(4 * b + i) * kFwdStride + lane] = s_reg[i];
+        t_prod[(4 * b + i) * kFwdStride + lane] = e_reg[i] * s_reg[i];
+    }
+    __syncthreads();
+    f32x4 acc_g = (f32x4){0.f, 0.f, 0.f, 0.f}, acc_b = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+        float4 ag[4], ab[4], wg[4], wb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ag[j] = *reinterpret_cast<const float4 *>(&t_side[i16 * kFwdStride + 16 * h + 4 * j]);
+            ab[j] = *reinterpret_cast<const float4 *>(&t_prod[i16 * kFwdStride + 16 * h + 4 * j]);
+            wg[j] = *reinterpret_cast<const float4 *>(&s_w[0][(16 * b + i16) * kFwdStride + 16 * h + 4 * j]);
+            wb[j] = *reinterpret_cast<const float4 *>(&s_w[1][(16 * b + i16) * kFwdStride + 16 * h + 4 * j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc_g = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[j].x, wg[j].x, acc_g, 0, 0, 0);
+            acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[j].x, wb[j].x, acc_b, 0, 0, 0);
+            acc_g = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[j].y, wg[j].y, acc_g, 0, 0, 0);
+            acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[j].y, wb[j].y, acc_b, 0, 0, 0);
+            acc_g = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[j].z, wg[j].z, acc_g, 0, 0, 0);
+            acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[j].z, wb[j].z, acc_b, 0, 0, 0);
+            acc_g = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[j].w, wg[j].w, acc_g, 0, 0, 0);
+            acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[j].w, wb[j].w, acc_b, 0, 0, 0);
+        }
+    }
+    // C layout: row 4h + q, column 16b + i16
+    float e1[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float x = acc_g[q] + bias_g, y = acc_b[q] + bias_b;
+        x = x >= 0.0f ? x : x * slope;
+        y = y >= 0.0f ? y : y * slope;
+        float v = x + y;
+        if (drop.p > 0.0f) v = msg_keep(drop, r0 + 4 * h + q, 16 * b + i16) ? v * drop.scale : 0.0f;
+        e1[q] = v;
+        const float sq = row16_sum_f32(v * v);
+        if (i16 == 0) s_sq[tl][b][4 * h + q] = sq;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int rr = 4 * h + q, r = r0 + rr;
+        if (r < n) {
+            const float sq = ((s_sq[tl][0][rr] + s_sq[tl][1][rr]) + s_sq[tl][2][rr]) + s_sq[tl][3][rr];
+            const float den = fmaxf(sqrtf(sq), 1e-12f);
+            out[(size_t)r * ld_out + 64 + 16 * b + i16] = e1[q] / den;
+            if (e1_out) e1_out[(size_t)r * 64 + 16 * b + i16] = e1[q];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Backward of one NGCF layer (autograd of NGCF_SPEX/code/main_rec.py:77-83 given side = A ego from the SpMM).
 // Per row, with s = side W_gc^T + b_gc, t = (ego * side) W_bi^T + b_bi, e1 = LReLU(s) + LReLU(t), e1d = dropout(e1),
@@ -1034,10 +1128,16 @@ extern "C" int spex_ngcf_layer_fwd_f32(const float *ego, const float *side, cons
     }
     SPEX_CHECK_ARG((((uintptr_t)W_gc | (uintptr_t)W_bi) & 15) == 0, "spex_ngcf_layer_fwd_f32: weights must be 16-byte aligned");
     if (n == 0) return SPEX_OK;
-    const int n_tiles = (n + 15) / 16;  // one wave per 16-row tile
-    hipLaunchKernelGGL(ngcf_layer_kernel, dim3(grid_for_rows(n_tiles)), dim3(kWave * kWavesPerBlock), 0, (hipStream_t)stream,
-                       ego, side, W_gc, b_gc, W_bi, b_bi, out, ld_out, write_ego, e1_out, n, slope,
-                       make_drop(p_drop, seed, step, layer, pad_row));
+    const int n_tiles = (n + 15) / 16;
+    static const bool one_wave_form = []() { const char *e = getenv("SPEX_NGCF_FWD_ONE_WAVE"); return e && e[0] == '1'; }();
+    if (one_wave_form)      // the earlier form (one wave per 16-row tile), kept for A/B timing
+        hipLaunchKernelGGL(ngcf_layer_kernel, dim3(grid_for_rows(n_tiles)), dim3(kWave * kWavesPerBlock), 0, (hipStream_t)stream,
+                           ego, side, W_gc, b_gc, W_bi, b_bi, out, ld_out, write_ego, e1_out, n, slope,
+                           make_drop(p_drop, seed, step, layer, pad_row));
+    else                    // four waves per tile, four tiles per workgroup
+        hipLaunchKernelGGL(ngcf_layer_fwd4_kernel, dim3((unsigned)((n_tiles + kFwdTiles - 1) / kFwdTiles)), dim3(kWave * 4 * kFwdTiles), 0,
+                           (hipStream_t)stream, ego, side, W_gc, b_gc, W_bi, b_bi, out, ld_out, write_ego, e1_out, n, slope,
+                           make_drop(p_drop, seed, step, layer, pad_row));
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }
