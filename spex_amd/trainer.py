@@ -235,10 +235,12 @@ class NGCFStepper:
         if not model._fused_ok():
             raise ValueError("NGCFStepper needs 64-wide layers (the fused layer kernels)")
         self.model, self.lr, self.betas, self.eps, self.t = model, lr, betas, eps, 0
-        # second stream of the one-call step (spex_ngcf_step_t.side_stream): the layer weights' Adam pass beside the push-form
-        # product and the table's pass; SPEX_NGCF_ONE_STREAM=1 keeps everything on the caller's stream
+        # spex_ngcf_step_t.side_stream (the layer weights' Adam pass on a second stream beside the push-form product and the
+        # table's pass) is OFF by default: measured on the MI355X it LOSES 10 us per step (69.4 vs 59.3 us) — the 5 us pass it
+        # hides costs a fork and a join, and a cross-stream event wait takes ~5 us to propagate between the two hardware queues.
+        # (The dual-task step gains 49 us from the same mechanism: there the forked branch is 80 us long.)  SPEX_NGCF_TWO_STREAMS=1.
         self._side = None
-        if os.environ.get("SPEX_NGCF_ONE_STREAM", "0") != "1" and next(model.parameters()).is_cuda:
+        if os.environ.get("SPEX_NGCF_TWO_STREAMS", "0") == "1" and next(model.parameters()).is_cuda:
             self._side = torch.cuda.Stream(device=next(model.parameters()).device)
         self.E0 = model.flat_table()
         n, d = self.E0.shape

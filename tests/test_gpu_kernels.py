@@ -998,6 +998,46 @@ def test_lightgcn_batch_kernel_equals_the_three_launch_sequence(G, golden, epini
     assert np.abs(per.cpu().numpy() - want_per).max() <= 2e-6
 
 
+def test_lightgcn_batch_kernel_hub_rows_and_a_non_symmetric_matrix(G, oracle):
+    """The same launch on a NON-symmetric square matrix with rows beyond 1 024 entries (16 virtual waves chaining several
+    segments each), an empty row and a one-entry row among the batch's rows; the push runs over the rows of the transposed
+    handle.  Against the three-launch sequence on the same handles and against the oracle's pull-form product."""
+    from spex_amd import ops
+    rng = np.random.default_rng(5)
+    n, n_u, L = 3000, 1000, 2
+    deg = rng.integers(0, 50, n)
+    deg[[2, 1500, 2999]] = [1500, 2600, 1100]
+    deg[7], deg[1200] = 0, 1
+    rowptr, col, val = random_csr(rng, n, n, deg)
+    val *= 0.05
+    t_csr = oracle.csr_transpose(rowptr, col, val, n)
+    g, gt = G(rowptr, col, val), G(*t_csr[:3])
+    X = t((rng.normal(size=(n, 64)) * 0.3).astype(np.float32))
+    run = t((rng.normal(size=(n, 64)) * 0.3).astype(np.float32))
+    users = rng.integers(0, n_u, 64)
+    items = rng.integers(0, n - n_u, 64)
+    users[:3] = [2, 7, 2]
+    items[:3] = [1500 - n_u, 2999 - n_u, 1200 - n_u]
+    labels = (rng.random(64) < 0.3).astype(np.float32)
+    u_d, i_d, y_d = t(users), t(items), t(labels)
+    lo = run.clone()
+    g.spmm_rows(X, u_d, i_d, 0, n_u, acc_in=run, acc_out=lo, acc_div=float(L + 1))
+    slots = torch.zeros(128, 64, device=DEV)
+    loss_a, g_out_a, G_a = torch.zeros(1, device=DEV), torch.zeros(n, 64, device=DEV), torch.zeros(n, 64, device=DEV)
+    ops.score_bce(lo[:n_u], lo[n_u:], u_d, i_d, y_d, loss_sum=loss_a, grad_users=g_out_a[:n_u], grad_items=g_out_a[n_u:],
+                  grad_scale=1.0 / 64, grad_slots=slots)
+    ops.spmm_push_batch(gt, u_d, i_d, n_u, slots, G_a, add=slots, scale=1.0 / (L + 1))
+    loss_b, g_out_b, G_b = torch.zeros(1, device=DEV), torch.zeros(n, 64, device=DEV), torch.zeros(n, 64, device=DEV)
+    ops.lightgcn_batch(g, gt, X, run, float(L + 1), u_d, i_d, y_d, n_u, 1.0 / 64, 1.0 / (L + 1), loss_b, g_out_b, G_b)
+    assert abs(loss_a.item() - loss_b.item()) <= 1e-5 * abs(loss_a.item())
+    assert rel_err(g_out_b.cpu().numpy(), g_out_a.cpu().numpy()) <= 3e-6
+    assert rel_err(G_b.cpu().numpy(), G_a.cpu().numpy()) <= 3e-6
+    gd = g_out_b.cpu().numpy()
+    # out[c] += val[e] * g[r] over the entries e = (r, c) of gt  <=>  out = gt^T g = A g
+    want_G = (gd.astype(np.float64) + oracle.spmm(rowptr, col, val, gd).astype(np.float64)) / (L + 1)
+    assert rel_err(G_b.cpu().numpy(), want_G) <= 1e-5
+
+
 def test_one_handle_driven_from_two_streams(G):
     """A graph with hub rows (> 1024 entries: their segment sums go through the handle's scratch buffer) driven from two
     streams in alternation: the library orders each launch behind the scratch's previous user, so every product equals the

@@ -17,7 +17,7 @@ for f in glob.glob(os.path.join(src, "bench", "**", "*kernel_stats.csv"), recurs
     shutil.copy(f, os.path.join(dst, "kernel_stats.csv"))
 for f in glob.glob(os.path.join(src, "bench", "**", "*kernel_trace.csv"), recursive=True):
     out = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "trace_by_grid.py"), f, "spmm", "bpr_", "score_bce",
-                          "adam_kernel", "ngcf_layer"], capture_output=True, text=True).stdout
+                          "adam_kernel", "ngcf_layer", "lightgcn_batch", "trust_", "dual_task"], capture_output=True, text=True).stdout
     open(os.path.join(dst, "kernel_trace_by_grid.csv"), "w").write(out)
 if os.path.exists(os.path.join(src, "bench_under_rocprof.json")):
     shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, "bench_under_rocprof.json"))
@@ -36,5 +36,6 @@ for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), 
             dur[name].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 summary = {k: dict({c: sum(v) / len(v) for c, v in cs.items()}, n_dispatches=max(len(v) for v in cs.values()),
                    dur_ns_under_pmc=(sum(dur[k]) / len(dur[k]) if dur[k] else None)) for k, cs in pmc.items()}
-json.dump(summary, open(os.path.join(dst, "pmc_bpr_raw.json"), "w"), indent=1)
+if summary:                                     # (a collection without --pmc passes keeps the stored counters)
+    json.dump(summary, open(os.path.join(dst, "pmc_bpr_raw.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1)[:3000])
