@@ -417,14 +417,13 @@ def main():
                                                    "~2^%d, nnz=%d, d=64 (X = %.2f GB >> 256 MB Infinity Cache), "
                                                    "long rows=%d" % (k, n2, a.hbm_log2_nodes, nnz2, n2 * D * 4 / 1e9,
                                                                      g2.n_long_rows)}
-                if stored.get("hbm_graph_spmm_bytes_per_launch") and str(k) in str(stored.get("hbm_graph", "")):
-                    out["roofline_hbm"]["traffic"] = stored["hbm_graph_spmm_bytes_per_launch"]
+                prof = (stored.get("hbm_graphs") or {}).get(str(k))
+                if prof:        # rocprofv3 --pmc figure of this very graph, stored (profiles/hbm_traffic.json): not measured in this run
+                    out["roofline_hbm"]["traffic"] = prof["spmm_bytes_per_launch"]
                     out["roofline_hbm"]["traffic_is_stored_profile"] = True
-                elif stored.get("hbm_graph_spmm_bytes_per_launch"):
-                    out["roofline_hbm"]["traffic_note"] = ("profiled on %s: %d bytes per launch = %.3f x its algorithmic bytes "
-                                                           "(profiles/hbm_traffic.json)" % (
-                                                               stored.get("hbm_graph"), stored["hbm_graph_spmm_bytes_per_launch"],
-                                                               stored["hbm_graph_spmm_bytes_per_launch"] / algorithmic_bytes(225211104, 8388497)))
+                    out["roofline_hbm"]["traffic_over_algorithmic"] = prof["spmm_bytes_per_launch"] / b2
+                    out["roofline_hbm"]["l2_hit_rate_profiled"] = prof.get("l2_hit_rate")
+                    out["roofline_hbm"]["traffic_source"] = prof.get("source")
                 # the exact training step (3 SpMM fwd, scoring, 3 SpMM bwd, Adam over the whole table) on the same graph
                 del Y, A2
                 st2 = LightGCNStepper(g2, X.mul_(0.1), n2 - (n2 // 15593) * 12407, n_layers=L, lr=lr)
