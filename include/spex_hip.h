@@ -328,6 +328,21 @@ int spex_lightgcn_batch_f32(const spex_graph_t *g, const spex_graph_t *gt, const
                             float grad_scale, float push_scale, float *loss_sum, float *loss_per_sample, float *g_out, float *G,
                             int32_t d, void *stream);
 
+/* Scoring + rows backward of the single-layer NGCF model as ONE launch (what spex_score_bce_slots_f32 followed by
+ * spex_ngcf_layer_bwd_rows_f32 computes — NGCF_SPEX/code/main_rec.py:84-100 and autograd through :77-83 at the batch's rows):
+ * sample b has rows u = users[b], i = n_user_rows + items[b] of the concatenated table all_emb [n, 2d] (= [ego | normalised layer
+ * output], as spex_ngcf_layer_fwd_f32 writes it);  x = <all_emb[u], all_emb[i]>;  loss_per_sample[b] = BCEWithLogits(x, labels[b]);
+ * dg = (sigmoid(x) - labels[b]) * grad_scale;  slot b (row u) receives the upstream gradient dg * all_emb[i], slot B + b (row i)
+ * dg * all_emb[u] — first d columns: the direct gradient of `ego`, last d: the gradient of the normalised output — and the layer's
+ * backward runs on those 2B slots exactly as in spex_ngcf_layer_bwd_rows_f32 (same outputs: g_side_c, g_ego_c [2B, d], gW_parts).
+ * A sample with an index out of range contributes nothing (loss 0).  d == 64.
+ */
+int spex_ngcf_score_bwd_rows_f32(const float *ego, const float *side, const float *W_gc, const float *b_gc, const float *W_bi,
+                                 const float *b_bi, const float *all_emb, const float *labels, float grad_scale, int32_t n, int32_t d,
+                                 float slope, float p_drop, uint64_t seed, uint32_t step, uint32_t layer, int32_t pad_row,
+                                 const int64_t *users, const int64_t *items, int32_t B, int64_t n_user_rows, float *loss_per_sample,
+                                 float *g_side_c, float *g_ego_c, float *gW_parts, int32_t part_stride, void *stream);
+
 /* Replaces the two-expert gate of the dual-task model, utility1/model_expert_s.py:156-161:
  *   att = softmax([raw | prop] att_exp, dim=1) ([n,2d] x [2d,2]);  mixed = raw * att[:,0] + prop * att[:,1]
  */
@@ -490,8 +505,9 @@ int spex_lightgcn_step_bce_f32(spex_lightgcn_step_t *step, const int64_t *users,
                                int32_t B, float *loss_sum, void *stream);
 
 /* The single-layer NGCF training step (NGCF_SPEX/code/main_rec.py:122-128 with the default --layer_size [64]) as one call:
- *   spex_spmm_f32 (side = A ego) -> spex_ngcf_layer_fwd_f32 -> spex_score_bce_slots_f32 -> spex_ngcf_layer_bwd_rows_f32
- *   -> spex_spmm_push_batch_f32 -> spex_adam_step_f32 (table; clears its gradient) -> spex_adam_step_sum_f32 (layer weights).
+ *   spex_spmm_f32 (side = A ego) -> spex_ngcf_layer_fwd_f32 -> spex_ngcf_score_bwd_rows_f32 (scores, BCE, rows backward)
+ *   -> spex_spmm_push_batch_f32 -> spex_adam_step_f32 (table; clears its gradient, adds the step's per-sample losses to
+ *   loss_sum in a fixed order) -> spex_adam_step_sum_f32 (layer weights).  Six launches.
  * Buffers (caller-owned, N = graph rows incl. an isolated pad row if the table keeps one, d == 64):
  *   E0, mE, vE, side, grad: [N, d] (grad all-zero before the first call; every call leaves it all-zero);  all_emb: [N, 2d];
  *   W, mW, vW: the layer's weights as one block [W_gc d*d | b_gc d | W_bi d*d | b_bi d] and its Adam moments;

@@ -674,14 +674,29 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
 //   dX            columns 16b .. 16b+15 of G_s W_gc, G_t W_bi    (2 x 16 MFMAs, contraction over the 64 outputs)
 // with four workgroup barriers (tile + weights staged; sum of squares; <g, out>; G tiles).  Same operand dealing as above
 // (k = 16h + j, transposed weight copy), same arithmetic per element; the 64-column row sums are associated as 4 x 16.
+// SCORE = true folds the scoring step in (single-layer model: the rows backward directly follows it): the upstream gradients
+// are not read from per-sample rows but formed here — slot s belongs to sample k = s mod B (n_a == n_b == B), its row `own`
+// and the sample's other row `oth` of the concatenated table all_emb [N, 2 x 64] give x = <own, oth> (128 columns),
+// dg = (sigmoid(x) - label) * grad_scale, and the slot's gradient row is dg * oth: its first 64 columns are g_direct, its last
+// 64 g_norm.  A sample's loss is stored by its user-side slot (loss_rows[k], plain store).  One launch and the gradient rows'
+// round trip through memory less than spex_score_bce_slots_f32 + this kernel.
+struct ScoreArgs {
+    const float *all_emb;     // [N, 128]
+    const float *labels;      // [B]
+    float *loss_rows;         // [B]
+    float grad_scale;
+};
+
+template <bool SCORE>
 __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_rows4_kernel(
     const float *__restrict__ ego, const float *__restrict__ side, const float *__restrict__ W_gc,
     const float *__restrict__ b_gc, const float *__restrict__ W_bi, const float *__restrict__ b_bi,
     const float *__restrict__ g_norm, int ld_g, const float *__restrict__ g_next, const float *__restrict__ g_direct,
     int ld_direct, int n, float slope, const MsgDrop drop, const int64_t *__restrict__ idx_a, int n_a, int64_t off_a,
     const int64_t *__restrict__ idx_b, int n_b, int64_t off_b, float *__restrict__ g_side, float *__restrict__ g_ego,
-    float *__restrict__ partials, int part_stride)
+    float *__restrict__ partials, int part_stride, const ScoreArgs sc)
 {
+    __shared__ float s_dg[16];
     __shared__ float s_w[2][64 * kBwdStride];                   // W_gc, W_bi as [out o][in k]
     __shared__ float s_wT[2][64 * kBwdStride];                  // transposed, [in k][out o]
     __shared__ float s_tile[5][16 * kBwdStride];                // side, ego, ego * side, G_s, G_t
@@ -691,14 +706,22 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_rows4_kernel(
     const int n_items = n_a + n_b, tile = blockIdx.x, r0 = tile << 4;
     float *t_side = s_tile[0], *t_ego = s_tile[1], *t_prod = s_tile[2], *t_gs = s_tile[3], *t_gt = s_tile[4];
     // ---- the tile's rows (lane i < 16: slot r0 + i), requested first; wave b stages rows 4b .. 4b+3 (lane == column)
-    int slot_row = -1;
+    int slot_row = -1, oth_row = -1;
     if (lane < 16 && r0 + lane < n_items) {
         const long long r = batch_row(idx_a, n_a, off_a, idx_b, off_b, r0 + lane);
         slot_row = (r >= 0 && r < n) ? (int)r : -1;
+        if (SCORE) {            // the sample's other row: slot s < B pairs with slot s + B
+            const int s_ = r0 + lane;
+            const long long o = batch_row(idx_a, n_a, off_a, idx_b, off_b, s_ < n_a ? s_ + n_a : s_ - n_a);
+            oth_row = (o >= 0 && o < n) ? (int)o : -1;                         // a sample with a bad index gets dg = 0: its valid
+        }                                                                       // slot is still processed and receives zero rows
     }
-    int row_q[4];
+    int row_q[4], oth_q[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) row_q[q] = __shfl(slot_row, 4 * h + q, kWave);
+    for (int q = 0; q < 4; ++q) {
+        row_q[q] = __shfl(slot_row, 4 * h + q, kWave);
+        oth_q[q] = SCORE ? __shfl(oth_row, 4 * h + q, kWave) : -1;
+    }
     float e_reg[4], s_reg[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -715,9 +738,51 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_rows4_kernel(
     for (int q = 0; q < 4; ++q) {
         gn[q] = gx[q] = gd[q] = 0.0f;
         if (row_q[q] >= 0) {
-            gn[q] = g_norm[(size_t)(r0 + 4 * h + q) * ld_g + 16 * b + i16];
+            if (SCORE) {        // the other row's columns now, times dg after the barrier
+                const int o = oth_q[q];
+                if (o >= 0) {
+                    gn[q] = sc.all_emb[(size_t)o * 128 + 64 + 16 * b + i16];
+                    gd[q] = sc.all_emb[(size_t)o * 128 + 16 * b + i16];
+                }
+            } else {
+                gn[q] = g_norm[(size_t)(r0 + 4 * h + q) * ld_g + 16 * b + i16];
+                if (g_direct) gd[q] = g_direct[(size_t)(r0 + 4 * h + q) * ld_direct + 16 * b + i16];
+            }
             if (g_next) gx[q] = g_next[(size_t)row_q[q] * 64 + 16 * b + i16];
-            if (g_direct) gd[q] = g_direct[(size_t)(r0 + 4 * h + q) * ld_direct + 16 * b + i16];
+        }
+    }
+    if (SCORE) {                // wave b scores slots 4b .. 4b+3: x over the 128 columns, lane == column (two halves)
+        float own0[4], own1[4], ot0[4], ot1[4], lab[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = __builtin_amdgcn_readlane(slot_row, 4 * b + i), o = __builtin_amdgcn_readlane(oth_row, 4 * b + i);
+            own0[i] = own1[i] = ot0[i] = ot1[i] = lab[i] = 0.0f;
+            if (r >= 0 && o >= 0) {
+                own0[i] = sc.all_emb[(size_t)r * 128 + lane];
+                own1[i] = sc.all_emb[(size_t)r * 128 + 64 + lane];
+                ot0[i] = sc.all_emb[(size_t)o * 128 + lane];
+                ot1[i] = sc.all_emb[(size_t)o * 128 + 64 + lane];
+                const int s_ = r0 + 4 * b + i;
+                lab[i] = sc.labels[s_ < n_a ? s_ : s_ - n_a];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = __builtin_amdgcn_readlane(slot_row, 4 * b + i), o = __builtin_amdgcn_readlane(oth_row, 4 * b + i);
+            const int s_ = r0 + 4 * b + i;
+            // the user-side row leads the product, as in the scoring kernel (users[c] * items[c], columns in order)
+            const bool user_side = s_ < n_a;
+            const float p0 = user_side ? own0[i] : ot0[i], q0 = user_side ? ot0[i] : own0[i];
+            const float p1 = user_side ? own1[i] : ot1[i], q1 = user_side ? ot1[i] : own1[i];
+            const float x = wave_sum(fmaf(p1, q1, fmaf(p0, q0, 0.0f)));
+            float dg = 0.0f;
+            if (r >= 0 && o >= 0) {
+                dg = (1.0f / (1.0f + expf(-x)) - lab[i]) * sc.grad_scale;
+                if (user_side && lane == 0) sc.loss_rows[s_] = fmaxf(x, 0.0f) - x * lab[i] + log1pf(expf(-fabsf(x)));
+            } else if (user_side && lane == 0) {
+                sc.loss_rows[s_] = 0.0f;
+            }
+            if (lane == 0) s_dg[4 * b + i] = dg;
         }
     }
     const float bias_g = b_gc[16 * b + i16], bias_b = b_bi[16 * b + i16];
@@ -738,7 +803,15 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_rows4_kernel(
         t_ego[(4 * b + i) * kBwdStride + lane] = e_reg[i];
         t_prod[(4 * b + i) * kBwdStride + lane] = e_reg[i] * s_reg[i];
     }
-    __syncthreads();                                                                  // (1) tile + weights staged
+    __syncthreads();                                                                  // (1) tile + weights staged (+ dg)
+    if (SCORE) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float dg = s_dg[4 * h + q];
+            gn[q] = dg * gn[q];
+            gd[q] = dg * gd[q];
+        }
+    }
     // ---- recompute this block's columns of s and t
     f32x4 acc_g = (f32x4){0.f, 0.f, 0.f, 0.f}, acc_b = (f32x4){0.f, 0.f, 0.f, 0.f};
     {
@@ -1208,10 +1281,38 @@ extern "C" int spex_ngcf_layer_bwd_rows_f32(const float *ego, const float *side,
                            make_drop(p_drop, seed, step, layer, pad_row), idx_a, n_a, off_a, idx_b, n_b, off_b, g_side_c, g_ego_c, nullptr,
                            nullptr, nullptr, nullptr, gW_parts, part_stride);
     else
-        hipLaunchKernelGGL(ngcf_layer_bwd_rows4_kernel, dim3((unsigned)tiles), dim3(kWave * kBwdWaves), 0, (hipStream_t)stream, ego, side,
-                           W_gc, b_gc, W_bi, b_bi, g_norm_c, ld_g, g_next, g_direct_c, ld_direct, n, slope,
+        hipLaunchKernelGGL((ngcf_layer_bwd_rows4_kernel<false>), dim3((unsigned)tiles), dim3(kWave * kBwdWaves), 0, (hipStream_t)stream,
+                           ego, side, W_gc, b_gc, W_bi, b_bi, g_norm_c, ld_g, g_next, g_direct_c, ld_direct, n, slope,
                            make_drop(p_drop, seed, step, layer, pad_row), idx_a, n_a, off_a, idx_b, n_b, off_b, g_side_c, g_ego_c,
-                           gW_parts, part_stride);
+                           gW_parts, part_stride, ScoreArgs{nullptr, nullptr, nullptr, 0.0f});
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}
+
+extern "C" int spex_ngcf_score_bwd_rows_f32(const float *ego, const float *side, const float *W_gc, const float *b_gc, const float *W_bi,
+                                            const float *b_bi, const float *all_emb, const float *labels, float grad_scale, int32_t n,
+                                            int32_t d, float slope, float p_drop, uint64_t seed, uint32_t step, uint32_t layer,
+                                            int32_t pad_row, const int64_t *users, const int64_t *items, int32_t B,
+                                            int64_t n_user_rows, float *loss_per_sample, float *g_side_c, float *g_ego_c,
+                                            float *gW_parts, int32_t part_stride, void *stream)
+{
+    SPEX_CHECK_ARG(ego && side && W_gc && b_gc && W_bi && b_bi && all_emb && labels && users && items && loss_per_sample && g_side_c
+                       && g_ego_c && gW_parts,
+                   "spex_ngcf_score_bwd_rows_f32: NULL pointer");
+    SPEX_CHECK_ARG(n >= 0 && B >= 0 && n_user_rows >= 0 && n_user_rows <= n && part_stride >= 2 * (d * d + d),
+                   "spex_ngcf_score_bwd_rows_f32: n=%d B=%d n_user_rows=%lld part_stride=%d", n, B, (long long)n_user_rows, part_stride);
+    SPEX_CHECK_ARG(p_drop >= 0.0f && p_drop < 1.0f, "spex_ngcf_score_bwd_rows_f32: p_drop=%f", (double)p_drop);
+    if (d != 64) {
+        spex::set_error("spex_ngcf_score_bwd_rows_f32: only d == 64 is implemented (got %d)", d);
+        return SPEX_ERR_UNSUPPORTED;
+    }
+    SPEX_CHECK_ARG((((uintptr_t)W_gc | (uintptr_t)W_bi) & 15) == 0, "spex_ngcf_score_bwd_rows_f32: weights must be 16-byte aligned");
+    if (n == 0 || B == 0) return SPEX_OK;
+    const int tiles = spex_ngcf_layer_bwd_rows_parts(2 * B);
+    hipLaunchKernelGGL((ngcf_layer_bwd_rows4_kernel<true>), dim3((unsigned)tiles), dim3(kWave * kBwdWaves), 0, (hipStream_t)stream, ego,
+                       side, W_gc, b_gc, W_bi, b_bi, nullptr, 0, nullptr, nullptr, 0, n, slope,
+                       make_drop(p_drop, seed, step, layer, pad_row), users, B, 0, items, B, n_user_rows, g_side_c, g_ego_c, gW_parts,
+                       part_stride, ScoreArgs{all_emb, labels, loss_per_sample, grad_scale});
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }

@@ -103,13 +103,12 @@ extern "C" int spex_ngcf_step_bce_f32(spex_ngcf_step_t *s, const int64_t *users,
     SPEX_TRY(spex_spmm_f32(g, s->E0, s->side, nullptr, 1.0f, nullptr, nullptr, 1.0f, d, stream));
     SPEX_TRY(spex_ngcf_layer_fwd_f32(s->E0, s->side, W_gc, b_gc, W_bi, b_bi, s->all_emb, 2 * d, 1, nullptr, n, d, s->slope, s->p_drop,
                                      s->seed, step, 0, s->pad_row, stream));
-    // ---- scoring: loss + the batch's per-sample gradient rows [2B, 2d]
-    SPEX_TRY(spex_score_bce_slots_f32(s->all_emb, s->all_emb + (size_t)n_u * 2 * d, 2 * d, 2 * d, n_u, n - n_u, users, items, labels, B,
-                                      2 * d, loss_sum, nullptr, nullptr, 1.0f / (float)B, s->g_slots, 2 * d, stream));
-    // ---- backward on the batch's slots, then the push-form A^T product into the (all-zero) table gradient
-    SPEX_TRY(spex_ngcf_layer_bwd_rows_f32(s->E0, s->side, W_gc, b_gc, W_bi, b_bi, s->g_slots + d, 2 * d, nullptr, s->g_slots, 2 * d, n, d,
-                                          s->slope, s->p_drop, s->seed, step, 0, s->pad_row, users, B, 0, items, B, n_u, s->g_side_c,
-                                          s->g_ego_c, s->gW_parts, per, stream));
+    // ---- scoring + backward on the batch's 2B slots in one launch (per-sample losses go to the head of g_slots: the table's Adam
+    //      pass below adds them to loss_sum in a fixed order), then the push-form A^T product into the (all-zero) table gradient
+    float *loss_rows = s->g_slots;
+    SPEX_TRY(spex_ngcf_score_bwd_rows_f32(s->E0, s->side, W_gc, b_gc, W_bi, b_bi, s->all_emb, labels, 1.0f / (float)B, n, d, s->slope,
+                                          s->p_drop, s->seed, step, 0, s->pad_row, users, items, B, n_u, loss_rows, s->g_side_c, s->g_ego_c,
+                                          s->gW_parts, per, stream));
     // ---- Adam: the table (its pass clears the gradient again), the layer weights (their pass sums the partial blocks).  The
     //      weights' pass needs only the rows backward: with a second stream it runs beside the push-form product and the table's
     //      pass (a one-workgroup-class launch next to two that fill the chip) and is joined at the end of the step.
@@ -130,7 +129,8 @@ extern "C" int spex_ngcf_step_bce_f32(spex_ngcf_step_t *s, const int64_t *users,
     }
     int rc = spex_spmm_push_batch_f32(g, users, B, 0, items, B, n_u, s->g_side_c, d, s->g_ego_c, d, 1.0f, s->grad, d, stream);
     if (rc == SPEX_OK)
-        rc = spex_adam_step_f32(s->E0, s->grad, s->mE, s->vE, (int64_t)n * d, s->t, s->lr, s->beta1, s->beta2, s->eps, s->grad, stream);
+        rc = spex::adam_step_z2(s->E0, s->grad, s->mE, s->vE, (int64_t)n * d, s->t, s->lr, s->beta1, s->beta2, s->eps, s->grad, nullptr, stream,
+                                loss_rows, B, loss_sum);
     if (two_streams) SPEX_HIP(hipStreamWaitEvent((hipStream_t)stream, join_ev, 0));
     if (rc != SPEX_OK) return rc;
     if (!two_streams) SPEX_TRY(weight_adam(stream));

@@ -226,6 +226,32 @@ def ngcf_layer_bwd_rows(ego, side, W_gc, b_gc, W_bi, b_bi, g_slots, layer, g_nex
     _bump(g_side_c, g_ego_c, gW_parts)
 
 
+def ngcf_score_bwd_rows(ego, side, W_gc, b_gc, W_bi, b_bi, all_emb, labels, grad_scale, users, items, n_user_rows, loss_per_sample,
+                        g_side_c, g_ego_c, gW_parts, slope=0.01, drop=None, pad_row=-1):
+    """score_bce(grad_slots=...) on the concatenated table all_emb [n, 128] followed by ngcf_layer_bwd_rows (layer 0), as ONE
+    launch: per-sample losses -> loss_per_sample [B]; g_side_c / g_ego_c [2B, 64]; gW_parts as ngcf_layer_bwd_rows writes them.
+    spex_ngcf_score_bwd_rows_f32."""
+    for x, nm in ((ego, "ego"), (side, "side"), (W_gc, "W_gc"), (b_gc, "b_gc"), (W_bi, "W_bi"), (b_bi, "b_bi"), (all_emb, "all_emb"),
+                  (labels, "labels"), (loss_per_sample, "loss_per_sample"), (g_side_c, "g_side_c"), (g_ego_c, "g_ego_c"), (gW_parts, "gW_parts")):
+        _need(x, nm)
+    n, d = ego.shape
+    B = users.numel()
+    if all_emb.shape != (n, 2 * d) or not all_emb.is_contiguous():
+        raise ValueError("ngcf_score_bwd_rows: all_emb must be a contiguous [n, 2 d] table")
+    if (items.numel() != B or labels.numel() != B or loss_per_sample.numel() < B or g_side_c.shape[0] < 2 * B or g_ego_c.shape[0] < 2 * B
+            or gW_parts.shape[0] < ngcf_bwd_rows_parts(2 * B)):
+        raise ValueError("ngcf_score_bwd_rows: per-sample / per-slot arrays are too small for the batch")
+    for t in (users, items):
+        if not (t.is_cuda and t.dtype == torch.int64 and t.is_contiguous()):
+            raise ValueError("ngcf_score_bwd_rows: the batch must be contiguous int64 tensors on the GPU")
+    p, seed, step = drop if drop is not None else (0.0, 0, 0)
+    _launch(ego.device, "spex_ngcf_score_bwd_rows_f32", _ptr(ego), _ptr(side), _ptr(W_gc), _ptr(b_gc), _ptr(W_bi), _ptr(b_bi),
+            _ptr(all_emb), _ptr(labels), float(grad_scale), n, d, float(slope), float(p), int(seed), int(step), 0, int(pad_row),
+            _ptr(users), _ptr(items), B, int(n_user_rows), _ptr(loss_per_sample), _ptr(g_side_c), _ptr(g_ego_c), _ptr(gW_parts),
+            gW_parts.stride(0))
+    _bump(loss_per_sample, g_side_c, g_ego_c, gW_parts)
+
+
 def ngcf_bwd_rows_parts(n_slots):
     """Number of partial weight-gradient blocks ngcf_layer_bwd_rows writes for a batch of n_slots slots."""
     return int(_lib.load().spex_ngcf_layer_bwd_rows_parts(int(n_slots)))

@@ -287,6 +287,45 @@ def test_whole_ngcf_epoch_matches_the_reference_epinion2(golden, ngcf_data_root)
     assert all(np.isfinite(v) for v in dev.values())
 
 
+def test_fused_scoring_and_rows_backward_equals_the_two_launches():
+    """spex_ngcf_score_bwd_rows_f32 against spex_score_bce_slots_f32 + spex_ngcf_layer_bwd_rows_f32 on the same inputs: B = 200
+    (the last tile is partial and one tile straddles the user / item boundary of the slots), repeated users, message dropout
+    on, one sample with an out-of-range item (skipped by both: zero rows, zero loss)."""
+    from spex_amd import ops
+    rng = np.random.default_rng(78)
+    n, n_u, B = 2000, 700, 200
+    ego, side = (torch.from_numpy(rng.normal(size=(n, 64)).astype(np.float32) * 0.3).to(DEV) for _ in range(2))
+    W_gc, W_bi = (torch.from_numpy(rng.normal(size=(64, 64)).astype(np.float32) * 0.2).to(DEV) for _ in range(2))
+    b_gc, b_bi = (torch.from_numpy(rng.normal(size=64).astype(np.float32) * 0.1).to(DEV) for _ in range(2))
+    all_emb = torch.cat([ego, torch.from_numpy(rng.normal(size=(n, 64)).astype(np.float32) * 0.2).to(DEV)], dim=1).contiguous()
+    u_np, i_np = rng.integers(0, n_u, B), rng.integers(0, n - n_u, B)
+    u_np[:4] = u_np[10]
+    i_np[33] = 5000                                                         # out of range
+    users, items = torch.from_numpy(u_np).to(DEV), torch.from_numpy(i_np).to(DEV)
+    y = torch.from_numpy((rng.random(B) < 0.3).astype(np.float32)).to(DEV)
+    drop = (0.1, 99, 3)
+    n_parts = ops.ngcf_bwd_rows_parts(2 * B)
+    # two launches
+    slots = torch.zeros(2 * B, 128, device=DEV)
+    loss_a = torch.zeros(1, device=DEV)
+    ops.score_bce(all_emb[:n_u], all_emb[n_u:], users, items, y, None, None, 1.0 / B, loss_sum=loss_a, grad_slots=slots, want_gamma=False)
+    parts_a = torch.zeros(n_parts, 2 * (64 * 64 + 64), device=DEV)
+    gs_a, ge_a = torch.zeros(2 * B, 64, device=DEV), torch.zeros(2 * B, 64, device=DEV)
+    ops.ngcf_layer_bwd_rows(ego, side, W_gc, b_gc, W_bi, b_bi, slots, 0, None, users, items, n_u, gs_a, ge_a, parts_a, drop=drop, pad_row=n_u)
+    # one launch
+    per = torch.full((B,), 7.0, device=DEV)
+    parts_b = torch.full((n_parts, 2 * (64 * 64 + 64)), 7.0, device=DEV)
+    gs_b, ge_b = torch.zeros(2 * B, 64, device=DEV), torch.zeros(2 * B, 64, device=DEV)
+    ops.ngcf_score_bwd_rows(ego, side, W_gc, b_gc, W_bi, b_bi, all_emb, y, 1.0 / B, users, items, n_u, per, gs_b, ge_b, parts_b,
+                            drop=drop, pad_row=n_u)
+    assert per[33].item() == 0.0
+    assert abs(per.sum().item() - loss_a.item()) <= 1e-5 * abs(loss_a.item())
+    assert rel_err(gs_b.cpu().numpy(), gs_a.cpu().numpy()) <= 2e-6
+    assert rel_err(ge_b.cpu().numpy(), ge_a.cpu().numpy()) <= 2e-6
+    assert (gs_b[33] == 0).all() and (gs_b[B + 33] == 0).all() and (ge_b[33] == 0).all()
+    assert rel_err(parts_b.sum(0).cpu().numpy(), parts_a.sum(0).cpu().numpy()) <= 2e-6
+
+
 def test_layer_backward_rows_form_equals_dense_form(oracle):
     """spex_ngcf_layer_bwd_rows_f32 (compact tiles over the batch's slots, every slot with its own gradient row) against
     the dense form fed with the same gradients scattered into a table: the layer's backward is linear in the upstream
