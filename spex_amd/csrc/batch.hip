@@ -31,6 +31,16 @@ __device__ __forceinline__ float lane_bcast(float v, int src)
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+#ifdef SPEX_STAMPS   // debug build only (tools/batch_stamps.py): phase stamps of workgroup 0 / wave 0, wall_clock64 = 100 MHz
+__device__ unsigned long long g_stamps[16];
+#define STAMP(k)                                                           \
+    do {                                                                   \
+        if (blockIdx.x == 8 && threadIdx.x == 0) g_stamps[k] = wall_clock64(); \
+    } while (0)
+#else
+#define STAMP(k)
+#endif
+
 constexpr int kPre = 2;                      // push runs a wave loads ahead (2 x 16 waves x 16 entries = 512 entries per part)
 
 // One 64-entry segment [e0, e0 + cnt) of a row, all of its gathers in flight at once (one workgroup per CU here: the wave
@@ -78,6 +88,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void lightgcn_batch_kernel(
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int b = blockIdx.x / parts, part = blockIdx.x % parts;
+    STAMP(0);
     const int64_t u64 = users[b], i64 = items[b];
     if (u64 < 0 || u64 >= n_user_rows || i64 < 0 || i64 + n_user_rows >= n_rows) {   // workgroup-uniform: never gather out of range
         if (loss_rows && part == 0 && threadIdx.x == 0) loss_rows[b] = 0.0f;
@@ -120,6 +131,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void lightgcn_batch_kernel(
         }
     };
     load_runs(q);
+    STAMP(1);
     // ---- 1. last layer at both rows.  Row k's segments go to its virtual waves v = segment mod 16 as in the row-list kernel
     //         (one accumulator chain per virtual wave); the two rows' virtual waves are numbered jointly and dealt to the 16 waves.
     const int nseg[2] = {(deg[0] + kTaskEntries - 1) / kTaskEntries, (deg[1] + kTaskEntries - 1) / kTaskEntries};
@@ -134,7 +146,9 @@ __global__ __launch_bounds__(kWave *kWgWaves) void lightgcn_batch_kernel(
         }
         s_part[side][v][lane] = acc;
     }
+    STAMP(2);
     __syncthreads();
+    STAMP(3);
     // ---- 2. layer mean at both rows (waves 0 and 1), the score, both gradient rows
     if (wave < 2) {
         const int lim = nseg[wave] < kWgWaves ? nseg[wave] : kWgWaves;
@@ -145,6 +159,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void lightgcn_batch_kernel(
         s_light[wave][lane] = s;
     }
     __syncthreads();
+    STAMP(4);
     const float lu = s_light[0][lane], li = s_light[1][lane];
     const float x = wave_sum_f32(fmaf(lu, li, 0.0f));
     const float dg = (sigmoid_f(x) - y_lab) * grad_scale;
@@ -161,6 +176,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void lightgcn_batch_kernel(
     // ---- 3. push over both rows' entries in A^T.  Lane 0 of every loaded run is read before the first atomic and the entry
     //         loop is a real loop (rows.hip explains why: one vmcnt for loads and atomics).
     float *out_l = G + lane;
+    STAMP(5);
     for (;;) {
         int c0[kPre];
         float v0[kPre];
@@ -184,9 +200,19 @@ __global__ __launch_bounds__(kWave *kWgWaves) void lightgcn_batch_kernel(
         if (q >= n_runs) break;
         load_runs(q);
     }
+    STAMP(6);
 }
 
 }  // namespace
+
+#ifdef SPEX_STAMPS
+extern "C" int spex_debug_batch_stamps(unsigned long long *out)
+{
+    SPEX_HIP(hipDeviceSynchronize());
+    SPEX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16));
+    return SPEX_OK;
+}
+#endif
 
 extern "C" int spex_lightgcn_batch_f32(const spex_graph_t *g, const spex_graph_t *gt, const float *X, const float *acc_in, float acc_div,
                                        const int64_t *users, const int64_t *items, const float *labels, int32_t B,
