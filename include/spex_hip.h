@@ -343,6 +343,20 @@ int spex_ngcf_score_bwd_rows_f32(const float *ego, const float *side, const floa
                                  const int64_t *users, const int64_t *items, int32_t B, int64_t n_user_rows, float *loss_per_sample,
                                  float *g_side_c, float *g_ego_c, float *gW_parts, int32_t part_stride, void *stream);
 
+/* The forward half of the dual-task model's batch-sized middle (utility1/model_expert_s.py:95-126 at the batch's rows, :154-168)
+ * as ONE launch — what spex_spmm_rowlist_f32 -> spex_expert_gate_rows_f32 -> spex_score_bce_slots_f32 compute: for sample b with
+ * rows u = users[b], i = items[b] + n_user_rows:
+ *   light_r = (acc_in[r] + (A X)[r]) / acc_div,  lo_batch[r] = light_r                       (r in {u, i}; lo_batch is [N, d])
+ *   mixed_r = raw[r] * a0 + light_r * a1,  (a0, a1) = softmax([raw[r] | light_r] att)        (att_u for u, att_i for i)
+ *   x = <mixed_u, mixed_i>;  *loss_sum += BCEWithLogits(x, labels[b]);  dg = (sigmoid(x) - labels[b]) * grad_scale
+ *   grad_slots[b] = dg * mixed_i,  grad_slots[B + b] = dg * mixed_u                          ([2B, d], row stride d)
+ * spex_expert_gate_rows_bwd_f32 and the push-form product follow as before.  d == 64, no edge dropout.
+ */
+int spex_gated_batch_fwd_f32(const spex_graph_t *g, const float *X, const float *acc_in, float acc_div, const float *raw,
+                             const float *att_u, const float *att_i, const int64_t *users, const int64_t *items, const float *labels,
+                             int32_t B, int32_t n_user_rows, float grad_scale, float *loss_sum, float *lo_batch, float *grad_slots,
+                             int32_t d, void *stream);
+
 /* Replaces the two-expert gate of the dual-task model, utility1/model_expert_s.py:156-161:
  *   att = softmax([raw | prop] att_exp, dim=1) ([n,2d] x [2d,2]);  mixed = raw * att[:,0] + prop * att[:,1]
  */
@@ -533,9 +547,9 @@ int spex_ngcf_step_bce_f32(spex_ngcf_step_t *step, const int64_t *users, const i
                            float *loss_sum, void *stream);
 
 /* The dual-task training step of LightGCN_SPEX/code/main_auto_expert_s.py:63-89 (model_expert_s.LightGCN.forward flag 0 +
- * uncertainty-weighted loss + loss.backward() + optimizer.step()) as one call issuing 2 L + 7 launches:
- *   rec branch, row-sparse like spex_lightgcn_step_bce_f32: (L-1) x spex_spmm_f32 + spex_spmm_rowlist_f32 (last layer at the
- *   batch's rows) -> spex_expert_gate_rows_f32 -> spex_score_bce_slots_f32 on the 2B gated rows -> spex_expert_gate_rows_bwd_f32
+ * uncertainty-weighted loss + loss.backward() + optimizer.step()) as one call issuing 2 L + 5 launches:
+ *   rec branch, row-sparse like spex_lightgcn_step_bce_f32: (L-1) x spex_spmm_f32 + spex_gated_batch_fwd_f32 (last layer at the
+ *   batch's rows, gate, scores on the 2B gated rows, per-sample gradient rows) -> spex_expert_gate_rows_bwd_f32
  *   -> spex_spmm_push_batch_f32 -> (L-1) x spex_spmm_f32 on A^T;   trust branch: spex_trust_head_train_f32 (2 launches);
  *   then one Adam pass over the whole parameter arena, which applies the task precisions exp(-2 s_k) to the two branches'
  *   gradients, forms the task weights' own gradients (d/ds0 = -2 p1 loss1 + 2 (n_rec + 1) B, d/ds1 = -2 p2 loss2 + T) and

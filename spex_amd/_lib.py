@@ -57,6 +57,8 @@ SIGNATURES = {
     "spex_ngcf_score_bwd_rows_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_f32, c_f32,
                                                     ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, c_i32, c_vp, c_vp, c_i32, c_i64,
                                                     c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
+    "spex_gated_batch_fwd_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp, c_vp,
+                                                c_vp, c_i32, c_vp]),
     "spex_lightgcn_batch_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp,
                                                c_vp, c_i32, c_vp]),
     "spex_adam_step_sum_f32": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i64, c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_f32, c_f32, c_vp]),

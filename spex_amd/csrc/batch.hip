@@ -210,7 +210,105 @@ __global__ __launch_bounds__(kWave *kWgWaves) void lightgcn_batch_kernel(
     STAMP(6);
 }
 
+
+// The dual-task model's rec branch has the expert gate between the layer mean and the score (utility1/model_expert_s.py:154-168),
+// so its batch-sized middle cannot include the push (the gate's backward comes first).  Its FORWARD half is one launch of the
+// same shape: last layer at the sample's two rows (step 1 above) -> layer mean (written to lo_batch[row]: the gate's backward
+// reads it) -> waves 0 / 1 gate the user / item row (softmax([raw | light] att) two-way mix) -> score, loss, and the two
+// per-sample gradient rows with respect to the GATED rows (grad_slots[b], grad_slots[B + b]) — what spex_spmm_rowlist_f32 ->
+// spex_expert_gate_rows_f32 -> spex_score_bce_slots_f32 computed in three launches.
+__global__ __launch_bounds__(kWave *kWgWaves) void gated_batch_fwd_kernel(
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val, int n_rows, int n_user_rows,
+    const float *__restrict__ X, const float *__restrict__ acc_in, float acc_div, const float *__restrict__ raw,
+    const float *__restrict__ att_u, const float *__restrict__ att_i, const int64_t *__restrict__ users,
+    const int64_t *__restrict__ items, const float *__restrict__ labels, int B, float grad_scale, float *loss_sum,
+    float *__restrict__ lo_batch, float *__restrict__ grad_slots)
+{
+    __shared__ float s_part[2][kWgWaves][kWave];
+    __shared__ float s_mixed[2][kWave];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int b = blockIdx.x;
+    const int64_t u64 = users[b], i64 = items[b];
+    const float y_lab = labels[b];
+    if (u64 < 0 || u64 >= n_user_rows || i64 < 0 || i64 + n_user_rows >= n_rows) {   // workgroup-uniform: never gather out of range
+        if (wave < 2) grad_slots[(size_t)(wave * B + b) * kWave + lane] = 0.0f;       // gated rows of 0: x = 0, no gradient
+        if (threadIdx.x == 0) atomicAdd(loss_sum, 0.693147180559945309f);             // (what the three launches did: BCE(0, y))
+        return;
+    }
+    const int row[2] = {(int)u64, (int)i64 + n_user_rows};
+    const int beg[2] = {rowptr[row[0]], rowptr[row[1]]};
+    const int deg[2] = {rowptr[row[0] + 1] - beg[0], rowptr[row[1] + 1] - beg[1]};
+    float run = 0.0f, a_raw = 0.0f, w00 = 0.0f, w01 = 0.0f, w10 = 0.0f, w11 = 0.0f;
+    if (wave < 2) {                       // the gate's operands, requested with everything else
+        const float *att = wave ? att_i : att_u;
+        run = acc_in[(size_t)row[wave] * kWave + lane];
+        a_raw = raw[(size_t)row[wave] * kWave + lane];
+        w00 = att[2 * lane]; w01 = att[2 * lane + 1];
+        w10 = att[2 * (kWave + lane)]; w11 = att[2 * (kWave + lane) + 1];
+    }
+    const int nseg[2] = {(deg[0] + kTaskEntries - 1) / kTaskEntries, (deg[1] + kTaskEntries - 1) / kTaskEntries};
+    const int nv0 = nseg[0] < kWgWaves ? nseg[0] : kWgWaves, nv = nv0 + (nseg[1] < kWgWaves ? nseg[1] : kWgWaves);
+    const float *__restrict__ Xl = X + lane;
+    for (int j = wave; j < nv; j += kWgWaves) {
+        const int side = j >= nv0, v = side ? j - nv0 : j;
+        float acc = 0.0f;
+        for (int sgi = v; sgi < nseg[side]; sgi += kWgWaves) {
+            const int left = deg[side] - sgi * kTaskEntries;
+            acc = segment_sum(col, val, Xl, beg[side] + sgi * kTaskEntries, left < kTaskEntries ? left : kTaskEntries, lane, acc);
+        }
+        s_part[side][v][lane] = acc;
+    }
+    __syncthreads();
+    if (wave < 2) {
+        const int lim = nseg[wave] < kWgWaves ? nseg[wave] : kWgWaves;
+        float y = lim > 0 ? s_part[wave][0][lane] : 0.0f;
+        for (int w = 1; w < lim; ++w) y = y + s_part[wave][w][lane];          // segment order
+        float s = run + y;
+        if (acc_div != 1.0f) s = s / acc_div;
+        lo_batch[(size_t)row[wave] * kWave + lane] = s;                        // (a row named twice is written twice with the same value)
+        // the gate, as expert_gate_rows_kernel computes it
+        float z0 = fmaf(s, w10, fmaf(a_raw, w00, 0.0f)), z1 = fmaf(s, w11, fmaf(a_raw, w01, 0.0f));
+        z0 = wave_sum_f32(z0);
+        z1 = wave_sum_f32(z1);
+        const float mx = fmaxf(z0, z1);
+        const float e0 = expf(z0 - mx), e1 = expf(z1 - mx);
+        const float a0 = e0 / (e0 + e1), a1 = e1 / (e0 + e1);
+        s_mixed[wave][lane] = a_raw * a0 + s * a1;
+    }
+    __syncthreads();
+    if (wave < 2) {
+        const float mu = s_mixed[0][lane], mi = s_mixed[1][lane];
+        const float x = wave_sum_f32(fmaf(mu, mi, 0.0f));
+        const float dg = (sigmoid_f(x) - y_lab) * grad_scale;
+        grad_slots[(size_t)(wave * B + b) * kWave + lane] = dg * (wave ? mu : mi);
+        if (wave == 0 && lane == 0) atomicAdd(loss_sum, fmaxf(x, 0.0f) - x * y_lab + log1pf(expf(-fabsf(x))));
+    }
+}
+
 }  // namespace
+
+extern "C" int spex_gated_batch_fwd_f32(const spex_graph_t *g, const float *X, const float *acc_in, float acc_div, const float *raw,
+                                       const float *att_u, const float *att_i, const int64_t *users, const int64_t *items,
+                                       const float *labels, int32_t B, int32_t n_user_rows, float grad_scale, float *loss_sum,
+                                       float *lo_batch, float *grad_slots, int32_t d, void *stream)
+{
+    SPEX_CHECK_ARG(g && X && acc_in && raw && att_u && att_i && users && items && labels && loss_sum && lo_batch && grad_slots,
+                   "spex_gated_batch_fwd_f32: NULL argument");
+    SPEX_CHECK_ARG(B >= 0 && n_user_rows >= 0 && n_user_rows <= g->n_rows && g->n_rows == g->n_cols,
+                   "spex_gated_batch_fwd_f32: B=%d n_user_rows=%d on a %d x %d graph", B, n_user_rows, g->n_rows, g->n_cols);
+    SPEX_CHECK_ARG(g->mask_mode == 0, "spex_gated_batch_fwd_f32: edge dropout is not supported here");
+    if (d != kWave) {
+        spex::set_error("spex_gated_batch_fwd_f32: d == 64 only (got %d)", d);
+        return SPEX_ERR_UNSUPPORTED;
+    }
+    if (B == 0 || g->n_rows == 0) return SPEX_OK;
+    hipLaunchKernelGGL(gated_batch_fwd_kernel, dim3((unsigned)B), dim3(kWave * kWgWaves), 0, (hipStream_t)stream, g->rowptr, g->col, g->val,
+                       g->n_rows, n_user_rows, X, acc_in, acc_div, raw, att_u, att_i, users, items, labels, B, grad_scale, loss_sum, lo_batch,
+                       grad_slots);
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}
 
 #ifdef SPEX_STAMPS
 extern "C" int spex_debug_batch_stamps(unsigned long long *out)

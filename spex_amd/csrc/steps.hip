@@ -184,11 +184,9 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
             SPEX_TRY(spex_spmm_f32(g, cur, nxt, nullptr, 1.0f, l == 0 ? E0 : s->light, s->light, 1.0f, d, stream));
             cur = nxt;
         }
-        SPEX_TRY(spex_spmm_rowlist_f32(g, cur, users, B, 0, items, B, n_u, nullptr, L == 1 ? E0 : s->light, s->lo_batch, (float)(L + 1), d,
-                                       stream));
-        SPEX_TRY(spex_expert_gate_rows_f32(E0, s->lo_batch, att1, att2, users, B, 0, items, B, n_u, n_u, N, d, s->mixed_slots, stream));
-        SPEX_TRY(spex_score_bce_slots_f32(s->mixed_slots, s->mixed_slots + (size_t)B * d, d, d, B, B, s->arange, s->arange, labels, B, d,
-                                          s->loss, nullptr, nullptr, 1.0f / (float)B, s->grad_slots, d, stream));
+        // (last layer at the batch's rows + layer mean + gate + scores + per-sample gradient rows: one launch)
+        SPEX_TRY(spex_gated_batch_fwd_f32(g, cur, L == 1 ? E0 : s->light, (float)(L + 1), E0, att1, att2, users, items, labels, B, n_u,
+                                          1.0f / (float)B, s->loss, s->lo_batch, s->grad_slots, d, stream));
         // ---- rec branch backward (gradients of the UNWEIGHTED loss1; the precisions are applied in the Adam pass): the gate slot by
         //      slot (dense d loss / d light and d loss / d E0 rows added with atomics), then the propagation as in the LightGCN step
         SPEX_TRY(spex_expert_gate_rows_bwd_f32(E0, s->lo_batch, att1, att2, users, B, 0, items, B, n_u, n_u, N, d, s->grad_slots, d,

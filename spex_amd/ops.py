@@ -353,6 +353,31 @@ def lightgcn_batch(graph, graph_t, X, acc_in, acc_div, users, items, labels, n_u
     return loss_sum if loss_per_sample is None else loss_per_sample
 
 
+def gated_batch_fwd(graph, X, acc_in, acc_div, raw, att_u, att_i, users, items, labels, n_user_rows, grad_scale, loss_sum, lo_batch,
+                    grad_slots):
+    """Forward half of the dual-task rec branch's batch-sized middle as one launch (spex_gated_batch_fwd_f32): last layer + layer
+    mean at the batch's rows (-> lo_batch rows), expert gate, scores + BCE (-> loss_sum, accumulated), per-sample gradient rows
+    with respect to the gated rows (-> grad_slots [2B, 64])."""
+    n = graph.n_rows
+    for t, nm in ((X, "X"), (acc_in, "acc_in"), (raw, "raw"), (lo_batch, "lo_batch")):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.shape == (n, 64)):
+            raise ValueError(f"gated_batch_fwd: {nm} must be a contiguous fp32 [{n}, 64] device tensor")
+    B = users.numel()
+    for t, nm in ((att_u, "att_u"), (att_i, "att_i")):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == 256):
+            raise ValueError(f"gated_batch_fwd: {nm} must be a contiguous fp32 [128, 2] device tensor")
+    for t, dt, nm in ((users, torch.int64, "users"), (items, torch.int64, "items"), (labels, torch.float32, "labels")):
+        if not (t.is_cuda and t.dtype == dt and t.is_contiguous() and t.numel() == B):
+            raise ValueError(f"gated_batch_fwd: {nm} must be a contiguous device tensor of the batch's length")
+    if not (grad_slots.is_cuda and grad_slots.dtype == torch.float32 and grad_slots.is_contiguous() and grad_slots.shape[0] >= 2 * B
+            and grad_slots.shape[1] == 64):
+        raise ValueError("gated_batch_fwd: grad_slots must be a contiguous fp32 [>= 2B, 64] device tensor")
+    _launch(X.device, "spex_gated_batch_fwd_f32", graph._h, _ptr(X), _ptr(acc_in), float(acc_div), _ptr(raw), _ptr(att_u), _ptr(att_i),
+            _ptr(users), _ptr(items), _ptr(labels), B, int(n_user_rows), float(grad_scale), _ptr(loss_sum), _ptr(lo_batch),
+            _ptr(grad_slots), 64)
+    _bump(loss_sum, lo_batch, grad_slots)
+
+
 def expert_gate(raw, prop, att_exp):
     """softmax([raw|prop] att_exp) two-way mix — model_expert_s.py:156-161."""
     for x, n in ((raw, "raw"), (prop, "prop"), (att_exp, "att_exp")):

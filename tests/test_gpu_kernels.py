@@ -1038,6 +1038,40 @@ def test_lightgcn_batch_kernel_hub_rows_and_a_non_symmetric_matrix(G, oracle):
     assert rel_err(G_b.cpu().numpy(), want_G) <= 1e-5
 
 
+def test_gated_batch_forward_equals_the_three_launch_sequence(G, golden, epinion2):
+    """spex_gated_batch_fwd_f32 (dual-task rec branch: last layer at the batch's rows + layer mean + expert gate + scores + BCE +
+    per-sample gradient rows, one launch) against spmm_rows -> expert_gate_rows -> score_bce(grad_slots) on Epinion2 with hub
+    rows and repeats in the batch."""
+    from spex_amd import ops
+    g_, csr, E0 = _epinion2(golden, epinion2)
+    g = G(*csr)
+    n, n_u, L, B = len(E0), 3186, 3, 256
+    rng = np.random.default_rng(21)
+    X, run, raw = t(E0), t((rng.normal(size=E0.shape) * 0.05).astype(np.float32)), t((rng.normal(size=E0.shape) * 0.1).astype(np.float32))
+    att_u, att_i = t((rng.normal(size=(128, 2)) * 0.5).astype(np.float32)), t((rng.normal(size=(128, 2)) * 0.5).astype(np.float32))
+    deg = np.diff(csr[0])
+    users, items = rng.integers(0, 3185, B), rng.integers(0, 12407, B)
+    users[:4] = np.argsort(-deg[:n_u])[:4]
+    items[:4] = np.argsort(-deg[n_u:])[:4]
+    users[10:14] = users[0]
+    labels = (rng.random(B) < 1 / 6).astype(np.float32)
+    u_d, i_d, y_d = t(users), t(items), t(labels)
+    # three launches
+    lo_a = torch.zeros(n, 64, device=DEV)
+    g.spmm_rows(X, u_d, i_d, 0, n_u, acc_in=run, acc_out=lo_a, acc_div=float(L + 1))
+    mixed = ops.expert_gate_rows(raw, lo_a, att_u, att_i, u_d, i_d, n_u)
+    slots_a, loss_a = torch.zeros(2 * B, 64, device=DEV), torch.zeros(1, device=DEV)
+    ar = torch.arange(B, device=DEV)
+    ops.score_bce(mixed[:B], mixed[B:], ar, ar, y_d, None, None, 1.0 / B, loss_sum=loss_a, grad_slots=slots_a, want_gamma=False)
+    # one launch
+    lo_b, slots_b, loss_b = torch.zeros(n, 64, device=DEV), torch.full((2 * B, 64), 7.0, device=DEV), torch.zeros(1, device=DEV)
+    ops.gated_batch_fwd(g, X, run, float(L + 1), raw, att_u, att_i, u_d, i_d, y_d, n_u, 1.0 / B, loss_b, lo_b, slots_b)
+    rows = torch.cat([u_d, i_d + n_u])
+    assert torch.equal(lo_b[rows], lo_a[rows])                              # the row-list kernel's segments and order
+    assert abs(loss_a.item() - loss_b.item()) <= 1e-5 * abs(loss_a.item())
+    assert rel_err(slots_b.cpu().numpy(), slots_a.cpu().numpy()) <= 2e-6
+
+
 def test_one_handle_driven_from_two_streams(G):
     """A graph with hub rows (> 1024 entries: their segment sums go through the handle's scratch buffer) driven from two
     streams in alternation: the library orders each launch behind the scratch's previous user, so every product equals the
