@@ -43,8 +43,13 @@ static void parallel_parts(int n_parts, F &&body)   // body(part) for part in [0
     }
     std::vector<std::thread> th;
     th.reserve((size_t)n_parts - 1);
-    for (int p = 1; p < n_parts; ++p) th.emplace_back([&body, p]() { body(p); });
+    int started = 1;
+    try {
+        for (; started < n_parts; ++started) th.emplace_back([&body, started]() { body(started); });
+    } catch (...) {                                 // no more threads to be had: the rest of the parts run here
+    }
     body(0);
+    for (int p = started; p < n_parts; ++p) body(p);
     for (auto &t : th) t.join();
 }
 

@@ -5,6 +5,8 @@
 // became host-bound once the row-sparse backward had shortened the kernels.  These entry points take the step's buffers
 // in a plain-C descriptor and issue the same launches back to back (~1 us each), so the loop is GPU-bound again.
 // Nothing here computes: every launch is one of the library's own entry points.
+#include <mutex>
+
 #include "spex_common.h"
 
 using namespace spex;
@@ -71,6 +73,8 @@ static int step_events(hipEvent_t *fork_ev, hipEvent_t *join_ev)
     constexpr int kMaxDev = 64;
     static hipEvent_t ev[kMaxDev][2];
     static bool made[kMaxDev];
+    static std::mutex mu;                          // first use from several host threads
+    std::lock_guard<std::mutex> lock(mu);
     int dev = 0;
     SPEX_HIP(hipGetDevice(&dev));
     SPEX_CHECK_ARG(dev >= 0 && dev < kMaxDev, "two-stream step: device %d", dev);
