@@ -54,6 +54,13 @@ const char *spex_last_error(void);      /* thread-local, never NULL */
  */
 int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, const float *h_val, const int32_t *h_edge_id,
                       int32_t n_rows, int32_t n_cols, int64_t nnz, spex_graph_t **out);
+/* The same with options.  SPEX_GRAPH_TILE_ROWS: lay the d == 64 task table out so that every 16-wave workgroup completes at
+ * most 64 output rows (four 16-row matrix-core tiles) — required by spex_ngcf_spmm_layer_fwd_f32, which keeps a workgroup's
+ * finished rows in LDS and runs the NGCF layer on them; every other entry point works on such a handle as on an ordinary
+ * one.  Needs n_cols * 256 B <= 16 MiB and no row of more than 1024 stored entries (SPEX_ERR_UNSUPPORTED otherwise). */
+#define SPEX_GRAPH_TILE_ROWS 1
+int spex_graph_create_ex(const int32_t *h_rowptr, const int32_t *h_col, const float *h_val, const int32_t *h_edge_id,
+                         int32_t n_rows, int32_t n_cols, int64_t nnz, int32_t flags, spex_graph_t **out);
 int spex_graph_destroy(spex_graph_t *g);
 /* n_rows, n_cols, nnz, number of long rows, number of long-row segments (any pointer may be NULL) */
 int spex_graph_info(const spex_graph_t *g, int32_t *n_rows, int32_t *n_cols, int64_t *nnz, int32_t *n_long_rows,

@@ -67,7 +67,7 @@ extern "C" int spex_graph_destroy(spex_graph_t *g)
 {
     if (!g) return SPEX_OK;
     void *ptrs[] = {g->rowptr, g->col, g->val, g->edge_id, g->seg_beg, g->seg_end, g->long_row, g->long_seg0, g->partial,
-                    g->task, g->chunk_off, g->chunk_val, g->chunk_mask, g->chunk_eid, g->chunk_row, g->hub_row, g->hub_seg0, g->row_of, g->tile_row, g->chunk_pad};
+                    g->task, g->chunk_off, g->chunk_val, g->chunk_mask, g->chunk_eid, g->chunk_row, g->hub_row, g->hub_seg0, g->row_of, g->tile_row, g->chunk_pad, g->wg_rows};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (g->scratch_ev) (void)hipEventDestroy(g->scratch_ev);
@@ -75,9 +75,25 @@ extern "C" int spex_graph_destroy(spex_graph_t *g)
     return SPEX_OK;
 }
 
+static int graph_create_impl(const int32_t *h_rowptr, const int32_t *h_col, const float *h_val, const int32_t *h_edge_id, int32_t n_rows,
+                             int32_t n_cols, int64_t nnz, int32_t flags, spex_graph_t **out);
+
 extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, const float *h_val,
                                  const int32_t *h_edge_id, int32_t n_rows, int32_t n_cols, int64_t nnz,
                                  spex_graph_t **out)
+{
+    return graph_create_impl(h_rowptr, h_col, h_val, h_edge_id, n_rows, n_cols, nnz, 0, out);
+}
+
+extern "C" int spex_graph_create_ex(const int32_t *h_rowptr, const int32_t *h_col, const float *h_val, const int32_t *h_edge_id,
+                                    int32_t n_rows, int32_t n_cols, int64_t nnz, int32_t flags, spex_graph_t **out)
+{
+    SPEX_CHECK_ARG((flags & ~SPEX_GRAPH_TILE_ROWS) == 0, "spex_graph_create_ex: unknown flags 0x%x", flags);
+    return graph_create_impl(h_rowptr, h_col, h_val, h_edge_id, n_rows, n_cols, nnz, flags, out);
+}
+
+static int graph_create_impl(const int32_t *h_rowptr, const int32_t *h_col, const float *h_val, const int32_t *h_edge_id, int32_t n_rows,
+                             int32_t n_cols, int64_t nnz, int32_t flags, spex_graph_t **out)
 {
     SPEX_CHECK_ARG(out, "spex_graph_create: out is NULL");
     *out = nullptr;
@@ -168,6 +184,13 @@ extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, 
     std::vector<int32_t> hub_row, hub_seg0;
     const bool chunked = true;
     g->row_ids = (int64_t)n_cols * 256 <= ((int64_t)16 << 20);
+    const int32_t tile_rows = (flags & SPEX_GRAPH_TILE_ROWS) ? spex::kTileRows : 0;
+    std::vector<int32_t> wg_rows;
+    if (tile_rows && !g->row_ids) {
+        spex::set_error("spex_graph_create_ex: SPEX_GRAPH_TILE_ROWS needs a source table of <= 16 MiB (n_cols = %d)", n_cols);
+        delete g;
+        return SPEX_ERR_UNSUPPORTED;
+    }
     if (chunked) {
         // Planning pass (this thread): add_chunks only RECORDS a job — the rows of a pack, or the range [b, e) of row r0
         // (a segment: no end-of-row flags) — and hands out its chunk range; the entries are written afterwards by
@@ -258,6 +281,7 @@ extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, 
             });
         };
         std::vector<int4> normal;                       // packs of short rows, empty rows
+        std::vector<int32_t> normal_nrows;              // rows each of them completes (tile mode)
         struct Mid { int32_t row, b, e, nseg; };
         std::vector<Mid> mids;                          // rows of 65..1024 entries
         std::vector<int4> hubs;                         // 128-entry segments of rows > 1024 entries
@@ -278,6 +302,7 @@ extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, 
                 OpenTask &ot = open_tasks[k];
                 const int2 c = add_chunks(ot.rows.data(), (int32_t)ot.rows.size(), 0, 0, ot.rows[0]);
                 normal.push_back(make_int4(c.x, c.y, ot.rows[0], 0));
+                normal_nrows.push_back((int32_t)ot.rows.size());
                 open_tasks.erase(open_tasks.begin() + k);
             };
             auto flush_window = [&]() {
@@ -303,6 +328,7 @@ extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, 
                 while (long_i < long_row.size() && long_row[long_i] < r) ++long_i;
                 if (deg == 0) {
                     normal.push_back(make_int4(0, 0, r, 0));   // zero-fill task
+                    normal_nrows.push_back(1);
                 } else if (deg > spex::kWgRowMax) {            // hub: its kLongRow-table segments go through global scratch
                     hub_row.push_back(r);
                     hub_seg0.push_back(long_seg0[long_i]);      // [begin, end) in the kLongRow segment table
@@ -331,6 +357,58 @@ extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, 
                 task.push_back(t);
             }
         };
+        if (tile_rows) {
+            // Tile mode: a workgroup completes at most tile_rows rows; bits 16-23 of task.w = the workgroup-local slot of the
+            // task's first completed row.  Rows of 65..1024 entries first (most segments first), each workgroup topped up with
+            // ordinary tasks; a workgroup that holds such a row has the barrier bit on ALL its tasks, so the table also serves
+            // the ordinary kernels.
+            if (!hubs.empty()) {
+                spex::set_error("spex_graph_create_ex: SPEX_GRAPH_TILE_ROWS does not support rows of more than %d entries", spex::kWgRowMax);
+                delete g;
+                return SPEX_ERR_UNSUPPORTED;
+            }
+            int used_t = 0, used_r = 0;
+            bool has_mid = false;
+            auto close_wg = [&]() {
+                if (used_t == 0) return;
+                while (task.size() % W) task.push_back(null_task);
+                if (has_mid)
+                    for (size_t k = task.size() - W; k < task.size(); ++k) task[k].w |= 4;
+                wg_rows.push_back(used_r);
+                used_t = used_r = 0;
+                has_mid = false;
+            };
+            auto put_normal = [&](size_t k) {
+                const int32_t nr = normal_nrows[k];
+                if (used_t + 1 > W || used_r + nr > tile_rows) close_wg();
+                int4 t = normal[k];
+                t.w |= used_r << 16;
+                task.push_back(t);
+                used_t += 1;
+                used_r += nr;
+            };
+            std::vector<int32_t> order(mids.size());
+            for (size_t m = 0; m < mids.size(); ++m) order[m] = (int32_t)m;
+            std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return mids[a].nseg > mids[b].nseg; });
+            for (int32_t m : order) {
+                const Mid &md = mids[m];
+                if (used_t + md.nseg > W || used_r + 1 > tile_rows) close_wg();
+                for (int32_t sgi = 0; sgi < md.nseg; ++sgi) {
+                    const int32_t sb = md.b + sgi * spex::kTaskEntries;
+                    const int32_t se = sb + spex::kTaskEntries < md.e ? sb + spex::kTaskEntries : md.e;
+                    const int2 c = add_chunks(nullptr, 0, sb, se, md.row);
+                    task.push_back(make_int4(c.x, c.y, md.row,
+                                             1 | 4 | (sgi == 0 ? 8 : 0) | ((used_t + sgi) << 4) | (md.nseg << 8) | (used_r << 16)));
+                }
+                used_t += md.nseg;
+                used_r += 1;
+                has_mid = true;
+                while (next_normal < normal.size() && used_t < W && used_r + normal_nrows[next_normal] <= tile_rows) put_normal(next_normal++);
+            }
+            while (next_normal < normal.size()) put_normal(next_normal++);
+            close_wg();
+            fill_chunks();
+        } else {
         for (const int4 &h : hubs) task.push_back(h);
         fill_wg(false);
         {
@@ -362,8 +440,15 @@ extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, 
         while (next_normal < normal.size()) task.push_back(normal[next_normal++]);
         fill_wg(false);
         fill_chunks();
+        }
     }
     g->n_tasks = (int32_t)task.size();
+    g->tile_rows = tile_rows;
+    g->n_wgs = (int32_t)wg_rows.size();
+    if (getenv("SPEX_DEBUG_PACK"))
+        fprintf(stderr, "[spex] graph %d x %d nnz %lld: %d tasks = %d workgroups, %lld chunks (%.1f %% padding), tile mode %d (%d workgroups)\n",
+                n_rows, n_cols, (long long)nnz, (int)task.size(), (int)task.size() / spex::kWgWaves, (long long)c_mask.size(),
+                nnz ? 100.0 * ((double)c_mask.size() * spex::kChunk - (double)nnz) / (double)nnz : 0.0, tile_rows, g->n_wgs);
     g->n_chunks = (int64_t)c_mask.size();
     g->n_hub = (int32_t)hub_row.size();
 
@@ -395,6 +480,7 @@ extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, 
         (rc = upload(&g->chunk_pad, c_pad.data(), c_pad.size())) ||
         (rc = upload(&g->chunk_eid, c_eid.data(), c_eid.size())) ||
         (rc = upload(&g->chunk_row, c_row.data(), c_row.size())) ||
+        (rc = upload(&g->wg_rows, wg_rows.data(), wg_rows.size())) ||
         (rc = upload(&g->hub_row, hub_row.data(), hub_row.size())) ||
         (rc = upload(&g->hub_seg0, hub_seg0.data(), hub_seg0.size()))) {
         spex_graph_destroy(g);

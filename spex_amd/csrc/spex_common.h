@@ -46,6 +46,7 @@ constexpr int kWgWaves = 16;       // the d == 64 kernel runs 1024-thread workgr
 constexpr int kWgRowMax = kWgWaves * kTaskEntries;  // longest row whose segments are combined inside one workgroup
 constexpr int kOpenTasks = 4;      // first-fit packing of short rows keeps this many tasks open
 constexpr int kChunk = 16;         // entries per chunk = gathers a wave keeps in flight
+constexpr int kTileRows = 64;      // rows a workgroup completes in tile mode (4 MFMA tiles of 16)
 constexpr int kSoftmaxTile = 2048; // stored entries per workgroup of the row-softmax kernels (512 on small graphs)
 
 }  // namespace spex
@@ -149,6 +150,12 @@ struct spex_graph {
     uint32_t *chunk_eid = nullptr;  // [n_chunks * 16] edge id of each entry (keep-mask index); read only under dropout
     bool row_ids = false;           // tasks pack non-adjacent rows (cache-resident graphs): the kernel reads chunk_row
     int32_t *chunk_row = nullptr;   // [n_chunks * 16] output row of each entry, only when row_ids
+    // Tile mode (spex_graph_create_ex, SPEX_GRAPH_TILE_ROWS): every workgroup of the task table completes at most kTileRows rows,
+    // task.w bits 16-23 = the workgroup-local slot of the task's first completed row — what the fused NGCF layer kernel needs
+    // to hold a workgroup's rows in LDS.  0 = ordinary table.
+    int32_t tile_rows = 0;
+    int32_t n_wgs = 0;              // workgroups of the task table (tile mode)
+    int32_t *wg_rows = nullptr;     // [n_wgs] rows each workgroup completes (tile mode)
     int32_t n_hub = 0;              // rows longer than kWgRowMax (global-scratch path of the d == 64 kernel)
     int32_t *hub_row = nullptr;     // [n_hub]
     int32_t *hub_seg0 = nullptr;    // [2 * n_hub] (first, one-past-last) segment of each hub in the kLongRow segment table

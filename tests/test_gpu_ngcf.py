@@ -287,6 +287,33 @@ def test_whole_ngcf_epoch_matches_the_reference_epinion2(golden, ngcf_data_root)
     assert all(np.isfinite(v) for v in dev.values())
 
 
+def test_fused_spmm_and_layer_equals_the_two_launches(epinion2):
+    """spex_ngcf_spmm_layer_fwd_f32 on a tile-mode handle (SPEX_GRAPH_TILE_ROWS) against spex_spmm_f32 + spex_ngcf_layer_fwd_f32
+    on an ordinary handle: `side` bit-identical (same chunks, same fmaf chains, same segment order), the concatenated table
+    to rounding; the NGCF adjacency of Epinion2 (rows of 1 .. 1 000 entries, an isolated pad row), message dropout on.
+    The tile-mode handle also serves the ordinary SpMM (bit-identical product)."""
+    from spex_amd import ops
+    from spex_amd.graph import SpexGraph, ngcf_norm_adj
+    tr = epinion2["train"]
+    rowptr, col, val = ngcf_norm_adj(tr[:, 0], tr[:, 1], 3185, 12407)
+    n = len(rowptr) - 1
+    g_plain, g_tile = SpexGraph(rowptr, col, val), SpexGraph(rowptr, col, val, tile_rows=True)
+    rng = np.random.default_rng(3)
+    ego = torch.from_numpy((rng.normal(size=(n, 64)) * 0.1).astype(np.float32)).to(DEV)
+    W_gc, W_bi = (torch.from_numpy(rng.normal(size=(64, 64)).astype(np.float32) * 0.2).to(DEV) for _ in range(2))
+    b_gc, b_bi = (torch.from_numpy(rng.normal(size=64).astype(np.float32) * 0.1).to(DEV) for _ in range(2))
+    drop = (0.1, 12345, 7)
+    side_a = g_plain.spmm(ego)
+    out_a = torch.zeros(n, 128, device=DEV)
+    ops.ngcf_layer_fwd(ego, side_a, W_gc, b_gc, W_bi, b_bi, out_a, 0, True, drop=drop, pad_row=3185)
+    out_b, side_b = torch.full((n, 128), 7.0, device=DEV), torch.full((n, 64), 7.0, device=DEV)
+    ops.ngcf_spmm_layer_fwd(g_tile, ego, W_gc, b_gc, W_bi, b_bi, out_b, side_b, drop=drop, pad_row=3185)
+    assert torch.equal(side_b, side_a)
+    assert torch.equal(out_b[:, :64], ego)
+    assert rel_err(out_b[:, 64:].cpu().numpy(), out_a[:, 64:].cpu().numpy()) <= 2e-6
+    assert torch.equal(g_tile.spmm(ego), side_a)
+
+
 def test_fused_scoring_and_rows_backward_equals_the_two_launches():
     """spex_ngcf_score_bwd_rows_f32 against spex_score_bce_slots_f32 + spex_ngcf_layer_bwd_rows_f32 on the same inputs: B = 200
     (the last tile is partial and one tile straddles the user / item boundary of the slots), repeated users, message dropout
