@@ -191,7 +191,17 @@ static int graph_create_impl(const int32_t *h_rowptr, const int32_t *h_col, cons
         delete g;
         return SPEX_ERR_UNSUPPORTED;
     }
-    if (chunked) {
+    // The cache-resident launch is fastest when ALL its workgroups are resident at once (2 per CU: 512): a table that needs a few
+    // more than that pays a second dispatch round for them (Epinion2's NGCF adjacency: 518 workgroups, 15.9 us against 14.9).  If
+    // the first-fit packing with kOpenTasks open tasks lands just above, it is redone with 32 (denser: 5.5 % padding instead of
+    // 6.7 %, slightly less local) and kept if that fits; SPEX_OPEN_TASKS pins the number.
+    constexpr int kResidentWgs = 512;
+    int open_tasks_now = getenv("SPEX_OPEN_TASKS") ? atoi(getenv("SPEX_OPEN_TASKS")) : spex::kOpenTasks;
+    for (int attempt = 0; chunked && attempt < 3; ++attempt) {
+        task.clear();
+        wg_rows.clear();
+        hub_row.clear();
+        hub_seg0.clear();
         // Planning pass (this thread): add_chunks only RECORDS a job — the rows of a pack, or the range [b, e) of row r0
         // (a segment: no end-of-row flags) — and hands out its chunk range; the entries are written afterwards by
         // fill_chunks on several threads, each job into its own range (6 s -> 1 s at 2^24 nodes).
@@ -297,7 +307,7 @@ static int graph_create_impl(const int32_t *h_rowptr, const int32_t *h_col, cons
             // neighbouring rows — worth 6 % there.
             struct OpenTask { std::vector<int32_t> rows; int room; };
             std::vector<OpenTask> open_tasks;
-            const int max_open = g->row_ids ? spex::kOpenTasks : 1;
+            const int max_open = g->row_ids ? open_tasks_now : 1;
             auto close_task = [&](size_t k) {
                 OpenTask &ot = open_tasks[k];
                 const int2 c = add_chunks(ot.rows.data(), (int32_t)ot.rows.size(), 0, 0, ot.rows[0]);
@@ -407,6 +417,18 @@ static int graph_create_impl(const int32_t *h_rowptr, const int32_t *h_col, cons
             }
             while (next_normal < normal.size()) put_normal(next_normal++);
             close_wg();
+            {
+                const int n_wgs_now = (int)((task.size() + W - 1) / W);
+                const bool pinned = getenv("SPEX_OPEN_TASKS") != nullptr;
+                if (g->row_ids && !pinned && attempt == 0 && n_wgs_now > kResidentWgs && n_wgs_now <= kResidentWgs + kResidentWgs / 16) {
+                    open_tasks_now = 32;
+                    continue;
+                }
+                if (g->row_ids && !pinned && attempt == 1 && n_wgs_now > kResidentWgs) {      // no use: back to the default
+                    open_tasks_now = spex::kOpenTasks;
+                    continue;
+                }
+            }
             fill_chunks();
         } else {
         for (const int4 &h : hubs) task.push_back(h);
@@ -439,8 +461,21 @@ static int graph_create_impl(const int32_t *h_rowptr, const int32_t *h_col, cons
         }
         while (next_normal < normal.size()) task.push_back(normal[next_normal++]);
         fill_wg(false);
+            {
+                const int n_wgs_now = (int)((task.size() + W - 1) / W);
+                const bool pinned = getenv("SPEX_OPEN_TASKS") != nullptr;
+                if (g->row_ids && !pinned && attempt == 0 && n_wgs_now > kResidentWgs && n_wgs_now <= kResidentWgs + kResidentWgs / 16) {
+                    open_tasks_now = 32;
+                    continue;
+                }
+                if (g->row_ids && !pinned && attempt == 1 && n_wgs_now > kResidentWgs) {      // no use: back to the default
+                    open_tasks_now = spex::kOpenTasks;
+                    continue;
+                }
+            }
         fill_chunks();
         }
+        break;
     }
     g->n_tasks = (int32_t)task.size();
     g->tile_rows = tile_rows;
