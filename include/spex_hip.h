@@ -241,6 +241,14 @@ int spex_ngcf_layer_fwd_f32(const float *ego, const float *side, const float *W_
                             const float *b_bi, float *out, int32_t ld_out, int32_t write_ego, float *e1_out, int32_t n,
                             int32_t d, float slope, float p_drop, uint64_t seed, uint32_t step, uint32_t layer,
                             int32_t pad_row, void *stream);
+/* side = A ego (main_rec.py:76) and the layer (:77-83) in ONE launch on a handle created with SPEX_GRAPH_TILE_ROWS: a workgroup
+ * runs its tasks like spex_spmm_f32, keeps its (<= 64) finished rows in LDS and runs the layer on them; out [n, ld_out >= 2d]
+ * receives [ego | normalised layer output], side_out [n, d] the product (bit-identical to spex_spmm_f32's; the backward
+ * recomputes the layer from it).  d == 64.  Measured no faster than the two launches: an option, not the default.
+ */
+int spex_ngcf_spmm_layer_fwd_f32(const spex_graph_t *g, const float *ego, const float *W_gc, const float *b_gc, const float *W_bi,
+                                 const float *b_bi, float *out, int32_t ld_out, float *side_out, int32_t d, float slope, float p_drop,
+                                 uint64_t seed, uint32_t step, uint32_t layer, int32_t pad_row, void *stream);
 /* The same layer in inference form (dropout off, ego written): kept for ABI-1 callers. */
 int spex_ngcf_layer_f32(const float *ego, const float *side, const float *W_gc, const float *b_gc, const float *W_bi,
                         const float *b_bi, float *out, int32_t ld_out, float *e1_out, int32_t n, int32_t d,
