@@ -404,14 +404,18 @@ def main():
                 g2.attach_timer(10)
                 for _ in range(10):
                     g2.spmm(X, Y=Y, acc_in=A2, acc_out=A2)
-                ms = float(g2.read_timer().mean())
+                ms_all = np.asarray(g2.read_timer(), np.float64)
+                ms = float(ms_all.mean())
                 g2.detach_timer()
                 b2 = algorithmic_bytes(nnz2, n2)
                 ach = b2 / (ms * 1e-3) / 1e9
                 k = round((1 << a.hbm_log2_nodes) / 15593)
                 out["roofline_hbm"] = {"bound": "hbm", "kernel": "spmm_chunk_kernel<1>", "achieved": ach,
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                                       "avg_launch_us": ms * 1e3, "algorithmic_bytes_per_launch": b2,
+                                       "avg_launch_us": ms * 1e3, "launch_us_min_median_max": [float(ms_all.min() * 1e3),
+                                                                                                 float(np.median(ms_all) * 1e3),
+                                                                                                 float(ms_all.max() * 1e3)],
+                                       "algorithmic_bytes_per_launch": b2,
                                        "edges_per_s": nnz2 / (ms * 1e-3),
                                        "workload": "Epinion2 x %d replicas (same degree law, cross-linked), N=%d nodes "
                                                    "~2^%d, nnz=%d, d=64 (X = %.2f GB >> 256 MB Infinity Cache), "
