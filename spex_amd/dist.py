@@ -82,17 +82,35 @@ class PeerAllGather:
     def __init__(self, n_padded, max_rows, d, rank, world, device, group=None):
         import torch.multiprocessing.reductions as reductions
         self.rank, self.world, self.group, self.max_rows = rank, world, group, max_rows
-        self.bufs = [torch.zeros((n_padded, d), dtype=torch.float32, device=device) for _ in range(2)]
-        mine = [reductions.reduce_tensor(b) for b in self.bufs]
+        # Every rank walks the same sequence of collectives whatever fails locally (exporting or opening an IPC handle can fail
+        # on one rank only): a failure is agreed on with a MIN all-reduce and raised on ALL ranks, so the caller's fallback to
+        # the collective path is taken everywhere — a rank that left early would leave the others waiting in a collective.
+        err = None
+        self.bufs, mine = None, None
+        try:
+            self.bufs = [torch.zeros((n_padded, d), dtype=torch.float32, device=device) for _ in range(2)]
+            mine = [reductions.reduce_tensor(b) for b in self.bufs]
+        except Exception as e:                               # noqa: BLE001
+            err = e
         everyone = [None] * world
         dist.all_gather_object(everyone, mine, group=group)
         self.peer = []                                   # peer[q][k]: rank q's buffer k as a tensor usable from this process
-        for q in range(world):
-            self.peer.append(self.bufs if q == rank else [fn(*args) for fn, args in everyone[q]])
-        self.streams = [torch.cuda.Stream(device=device) for _ in range(world)]
-        self.token = torch.zeros(1, dtype=torch.float32, device=device)
+        if err is None and all(e is not None for e in everyone):
+            try:
+                for q in range(world):
+                    self.peer.append(self.bufs if q == rank else [fn(*args) for fn, args in everyone[q]])
+                self.streams = [torch.cuda.Stream(device=device) for _ in range(world)]
+                self.token = torch.zeros(1, dtype=torch.float32, device=device)
+            except Exception as e:                           # noqa: BLE001
+                err = e
+        elif err is None:
+            err = RuntimeError("a peer could not export its buffers")
+        ok = torch.tensor([0.0 if err is not None else 1.0], dtype=torch.float32, device=device if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)   # (also the barrier: every handle is opened before anyone writes)
+        if ok.item() != 1.0:
+            self.peer = []
+            raise RuntimeError("PeerAllGather: IPC set-up failed on at least one rank" + (f" (here: {err!r})" if err is not None else ""))
         self.calls = 0
-        dist.barrier(group=group)                        # every handle is opened before anyone writes
 
     def all_gather(self, send, n_rows=None):
         """send: this rank's padded shard [max_rows, d]; n_rows: its real rows (default: all).  Only the real rows cross
