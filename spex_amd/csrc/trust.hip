@@ -712,17 +712,20 @@ __global__ __launch_bounds__(256) void trust_reduce_kernel(const ReduceArgs a)
         }
         float acc = 0.0f;
         const int rows = per_pos ? a.B * a.L : a.B, per = per_pos ? a.L : 1;       // padded positions hold zeros
-        for (int r0 = 0; r0 < rows; r0 += 16) {
-            float av[16], bv[16];
+        // 32 rows (64 loads) in flight per thread: the per-position products run over B L rows (90 for 15 paths of 6), and every
+        // batch is a dependent round trip — six of them at 16 rows per batch were most of this kernel's 12 us
+        constexpr int kRowsInFlight = 32;
+        for (int r0 = 0; r0 < rows; r0 += kRowsInFlight) {
+            float av[kRowsInFlight], bv[kRowsInFlight];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
+            for (int j = 0; j < kRowsInFlight; ++j) {
                 const int r = r0 + j, b = r / per, i = r - b * per;
                 const float *W = a.ws + (size_t)b * wl.stride;
                 av[j] = r < rows ? W[offA + i * ldA] : 0.0f;
                 bv[j] = r < rows ? W[offB + i * kD] : 0.0f;
             }
 #pragma unroll
-            for (int j = 0; j < 16; ++j) acc = fmaf(av[j], bv[j], acc);
+            for (int j = 0; j < kRowsInFlight; ++j) acc = fmaf(av[j], bv[j], acc);
         }
         a.grad_P[out] = acc;
         return;
