@@ -20,9 +20,18 @@ import torch.distributed as dist
 from .graph import row_block
 
 
-def balanced_row_bounds(rowptr, world, row_cost=4):
-    """Row boundaries r_0=0 < ... < r_P=N giving each rank about the same `entries + row_cost * rows` (an output
-    row costs about as much traffic as one gathered entry: 256 B written + 256 B read of the running sum)."""
+def balanced_row_bounds(rowptr, world, row_cost=None):
+    """Row boundaries r_0=0 < ... < r_P=N giving each rank about the same `entries + row_cost * rows`.
+
+    What a rank pays per layer: its SpMM (~264 B of gather traffic per stored entry at ~7 TB/s, plus ~512 B per output row) and
+    the all-gather, whose equal-size form moves world * max_rows rows of 256 B at the collective's rate (xGMI: ~0.15-0.3 TB/s
+    effective).  In entry units a row therefore costs ~2 for the SpMM alone — and ~45 * world once the exchange is counted
+    (256 B * world / 0.15 TB/s against 264 B / 7 TB/s): with more than one rank the exchange dominates and the bounds should
+    equalise ROWS (no padding in the gathered table: a [users; items] table balanced by entries alone has user shards a quarter
+    the length of item shards, i.e. 1.6 x the bytes on the wire), accepting SpMM shards that differ ~2.4 x in entries.
+    row_cost=None picks 4 for one rank and 45 * world otherwise; results do not depend on the bounds (tests pass explicit ones)."""
+    if row_cost is None:
+        row_cost = 4 if world == 1 else 45 * world
     n = len(rowptr) - 1
     cost = np.asarray(rowptr, np.int64) + row_cost * np.arange(n + 1, dtype=np.int64)
     targets = cost[-1] * np.arange(1, world, dtype=np.float64) / world
