@@ -106,7 +106,10 @@ def test_row_partition_layout(golden, epinion2, world):
     nnz_share = np.diff(rowptr[p.bounds])
     assert nnz_share.sum() == len(col)
     if world > 1:
-        assert nnz_share.max() <= 1.25 * nnz_share.mean() + 1100          # balanced by stored entries (max row 1020)
+        rows = np.diff(p.bounds)                                          # default bounds: the exchange dominates -> rows equalised
+        assert rows.max() <= 1.12 * rows.mean() + 8                       # (the padded all-gather carries world * max_rows rows)
+        nnz4 = np.diff(rowptr[balanced_row_bounds(rowptr, world, row_cost=4)])
+        assert nnz4.max() <= 1.25 * nnz4.mean() + 1100                    # row_cost=4: balanced by stored entries (max row 1020)
     g = np.arange(len(rowptr) - 1)
     pos = p.to_padded(g)
     assert len(np.unique(pos)) == len(g) and pos.max() < p.n_padded
