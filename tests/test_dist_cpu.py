@@ -203,9 +203,10 @@ def _weibo_worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
-    from spex_amd.dist import PartitionedLightGCN, PartitionedStepper
+    from spex_amd.dist import PartitionedLightGCN, PartitionedStepper, balanced_row_bounds
     csr, E0, n_u = weibo_like()
-    P = PartitionedLightGCN(*csr, n_u, 3, 64, rank, world, OracleGraph, "cpu")
+    # bounds balanced by stored entries (row_cost=4): user shards short, item shards long — the padded layout under skew
+    P = PartitionedLightGCN(*csr, n_u, 3, 64, rank, world, OracleGraph, "cpu", bounds=balanced_row_bounds(csr[0], world, row_cost=4))
     E0_local = torch.from_numpy(E0[P.r0:P.r1].copy())
     lo = P.propagate(E0_local).clone()
     grad = P.propagate_bwd(torch.from_numpy(E0[::-1].copy()[P.r0:P.r1].copy())).clone()

@@ -175,13 +175,15 @@ def _weibo_worker(rank, world, port, out_dir):
     sys.path.insert(0, REPO)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from spex_amd.dist import PartitionedLightGCN, PartitionedStepper
+    from spex_amd.dist import PartitionedLightGCN, PartitionedStepper, balanced_row_bounds
     from spex_amd.graph import SpexGraph
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     csr, E0, n_u = _weibo()
+    # bounds balanced by stored entries (row_cost=4): shards skewed in rows — the padded layout under skew
     P = PartitionedLightGCN(*csr, n_u, 3, 64, rank, world,
-                            lambda r, c, v, n_cols: SpexGraph(r, c, v, n_cols=n_cols, device=dev), dev)
+                            lambda r, c, v, n_cols: SpexGraph(r, c, v, n_cols=n_cols, device=dev), dev,
+                            bounds=balanced_row_bounds(csr[0], world, row_cost=4))
     E0_local = torch.from_numpy(E0[P.r0:P.r1].copy()).to(dev)
     lo = P.propagate(E0_local).clone()
     grad = P.propagate_bwd(torch.from_numpy(E0[::-1].copy()[P.r0:P.r1].copy()).to(dev)).clone()
