@@ -208,15 +208,19 @@ class PartitionedLightGCN:
         else:
             raise ValueError("allgather must be 'collective' or 'peer'")
 
-    def propagate(self, E0_local, keep_first=False):
+    def propagate(self, E0_local, keep_first=False, first_gathered=None):
         """mean_l(A^l E0) for this rank's rows (LightGCN.computer(), model.py:66-97).  keep_first: the first layer's
         all-gathered table (= E0 of every rank, padded layout) is gathered into `self.gathered0` and survives the call
-        (the dual-task model reads the whole user block from it)."""
+        (the dual-task model reads the whole user block from it).  first_gathered: that table, kept up to date by the caller
+        (gather_first once, refresh_first_rows after every sparse update) — layer 0's exchange is then skipped."""
         cur = E0_local
         if keep_first and getattr(self, "gathered0", None) is None:
             self.gathered0 = torch.zeros_like(self.gathered)
         for l in range(self.L):
-            X = self.all_gather_rows(cur, out=self.gathered0 if (keep_first and l == 0) else None)
+            if l == 0 and first_gathered is not None:
+                X = first_gathered
+            else:
+                X = self.all_gather_rows(cur, out=self.gathered0 if (keep_first and l == 0) else None)
             last = l == self.L - 1
             nxt = None if last else self.send[: self.n_local]     # next layer's all-gather source, no copy
             self.graph.spmm(X, Y=nxt, acc_in=E0_local if l == 0 else self.light_out, acc_out=self.light_out,
@@ -246,6 +250,22 @@ class PartitionedLightGCN:
         if self.L == 0:
             grad_out.copy_(gs)
         return grad_out
+
+    # -- E0 replicated in its gathered form and kept current by DELTAS: a step that changes few rows of E0 (the BPR-SGD update
+    #    touches <= 3 T rows) need not all-gather the whole table for the next step's first layer — the owners publish the
+    #    post-update values of the touched rows (the same small owner-computes exchange that fetches a batch's rows) and
+    #    every rank patches its copy.  One all-gather of the table per step less.
+    def gather_first(self, E0_local):
+        if getattr(self, "gathered0", None) is None:
+            self.gathered0 = torch.zeros_like(self.gathered)
+        return self.all_gather_rows(E0_local, out=self.gathered0)
+
+    def refresh_first_rows(self, padded_pos, E0_local, scratch):
+        """gathered0[padded_pos] = the owners' current rows of E0 (scratch: [len(padded_pos), d]; repeated positions receive the
+        same value twice)."""
+        rows = self.fetch_rows_at(padded_pos, scratch, table=E0_local)
+        self.gathered0.index_copy_(0, padded_pos, rows)
+        return self.gathered0
 
     def gather_output(self):
         """Full (padded) propagated table on every rank, for scoring."""
