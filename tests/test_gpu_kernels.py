@@ -1072,6 +1072,54 @@ def test_gated_batch_forward_equals_the_three_launch_sequence(G, golden, epinion
     assert rel_err(slots_b.cpu().numpy(), slots_a.cpu().numpy()) <= 2e-6
 
 
+@pytest.mark.parametrize("B", [1, 3, 17])
+def test_batch_kernels_small_batches_and_degenerate_rows(G, oracle, B):
+    """spex_lightgcn_batch_f32 and spex_gated_batch_fwd_f32 on batches of 1 / 3 / 17 samples whose rows include an EMPTY row, a
+    one-entry row and a row of exactly 64 and of 65 entries (segment boundary), against the multi-launch sequences."""
+    from spex_amd import ops
+    rng = np.random.default_rng(100 + B)
+    n, n_u, L = 600, 200, 3
+    deg = rng.integers(1, 30, n)
+    deg[0], deg[1], deg[2], deg[3] = 0, 1, 64, 65
+    deg[n_u], deg[n_u + 1], deg[n_u + 2] = 0, 65, 64
+    rowptr, col, val = random_csr(rng, n, n, deg)
+    val *= 0.1
+    t_csr = oracle.csr_transpose(rowptr, col, val, n)
+    g, gt = G(rowptr, col, val), G(*t_csr[:3])
+    X = t((rng.normal(size=(n, 64)) * 0.3).astype(np.float32))
+    run = t((rng.normal(size=(n, 64)) * 0.3).astype(np.float32))
+    raw = t((rng.normal(size=(n, 64)) * 0.3).astype(np.float32))
+    att_u, att_i = t((rng.normal(size=(128, 2)) * 0.5).astype(np.float32)), t((rng.normal(size=(128, 2)) * 0.5).astype(np.float32))
+    users = np.array(([0, 1, 2, 3] + list(rng.integers(0, n_u, 32)))[:B])
+    items = np.array(([0, 1, 2, 5] + list(rng.integers(0, n - n_u, 32)))[:B])
+    labels = (rng.random(B) < 0.4).astype(np.float32)
+    u_d, i_d, y_d = t(users), t(items), t(labels)
+    lo = run.clone()
+    g.spmm_rows(X, u_d, i_d, 0, n_u, acc_in=run, acc_out=lo, acc_div=float(L + 1))
+    # LightGCN form
+    slots, loss_a = torch.zeros(2 * B, 64, device=DEV), torch.zeros(1, device=DEV)
+    g_out_a, G_a = torch.zeros(n, 64, device=DEV), torch.zeros(n, 64, device=DEV)
+    ops.score_bce(lo[:n_u], lo[n_u:], u_d, i_d, y_d, loss_sum=loss_a, grad_users=g_out_a[:n_u], grad_items=g_out_a[n_u:],
+                  grad_scale=1.0 / B, grad_slots=slots)
+    ops.spmm_push_batch(gt, u_d, i_d, n_u, slots, G_a, add=slots, scale=1.0 / (L + 1))
+    loss_b, g_out_b, G_b = torch.zeros(1, device=DEV), torch.zeros(n, 64, device=DEV), torch.zeros(n, 64, device=DEV)
+    ops.lightgcn_batch(g, gt, X, run, float(L + 1), u_d, i_d, y_d, n_u, 1.0 / B, 1.0 / (L + 1), loss_b, g_out_b, G_b)
+    assert abs(loss_a.item() - loss_b.item()) <= 1e-5 * abs(loss_a.item()) + 1e-7
+    assert rel_err(g_out_b.cpu().numpy(), g_out_a.cpu().numpy()) <= 3e-6
+    assert rel_err(G_b.cpu().numpy(), G_a.cpu().numpy()) <= 3e-6
+    # gated form
+    mixed = ops.expert_gate_rows(raw, lo, att_u, att_i, u_d, i_d, n_u)
+    slots_a, loss_c = torch.zeros(2 * B, 64, device=DEV), torch.zeros(1, device=DEV)
+    ar = torch.arange(B, device=DEV)
+    ops.score_bce(mixed[:B], mixed[B:], ar, ar, y_d, None, None, 1.0 / B, loss_sum=loss_c, grad_slots=slots_a, want_gamma=False)
+    lo_b, slots_b, loss_d = torch.zeros(n, 64, device=DEV), torch.full((2 * B, 64), 7.0, device=DEV), torch.zeros(1, device=DEV)
+    ops.gated_batch_fwd(g, X, run, float(L + 1), raw, att_u, att_i, u_d, i_d, y_d, n_u, 1.0 / B, loss_d, lo_b, slots_b)
+    rows = torch.cat([u_d, i_d + n_u])
+    assert torch.equal(lo_b[rows], lo[rows])
+    assert abs(loss_c.item() - loss_d.item()) <= 1e-5 * abs(loss_c.item()) + 1e-7
+    assert rel_err(slots_b.cpu().numpy(), slots_a.cpu().numpy()) <= 3e-6
+
+
 def test_one_handle_driven_from_two_streams(G):
     """A graph with hub rows (> 1024 entries: their segment sums go through the handle's scratch buffer) driven from two
     streams in alternation: the library orders each launch behind the scratch's previous user, so every product equals the
