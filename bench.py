@@ -250,6 +250,24 @@ def main():
             fn2()
             ms2 = time_events(fn2, 200)
             aux["exact_train_step_ms_B256"] = ms2
+            # the same step on batches shaped like the reference's (dataloader.py:250-277: every observed pair once + 5 uniform
+            # negatives each, shuffled): the positives' items arrive in proportion to their degree, so most batches carry a hub
+            # row, and the batch kernel's push is bound by the per-CU atomic rate
+            trng2 = np.random.default_rng(2022)
+            pairs = trng2.integers(0, uu.numel(), (64, 256))                    # a sample = a random observed pair (u, i) ...
+            tb_y = (trng2.random((64, 256)) < 1 / 6).astype(np.float32)         # ... itself (label 1) or one of its 5 negatives:
+            tb_u = uu.numpy()[pairs]                                            # the SAME user with a uniform item (label 0)
+            tb_i = np.where(tb_y > 0, ii.numpy()[pairs], trng2.integers(0, m_item, (64, 256)))
+            tb = [(torch.from_numpy(tb_u[k].copy()).to(dev), torch.from_numpy(tb_i[k].copy()).to(dev), torch.from_numpy(tb_y[k].copy()).to(dev))
+                  for k in range(64)]
+            state = {"k": 0}
+
+            def fn2b():
+                u_, i_, y_ = tb[state["k"] & 63]
+                state["k"] += 1
+                return stepper.step_bce(u_, i_, y_, loss_acc=acc, batch_rows_only=True)
+            fn2b()
+            aux["exact_train_step_ms_B256_training_batches"] = time_events(fn2b, 256)
             aux["exact_train_step_samples_per_s"] = 256 / (ms2 * 1e-3)
             aux["exact_train_step_edges_per_s"] = 2 * L * nnz / (ms2 * 1e-3)
             # NGCF (BASELINE configs[3] shape): one layer = SpMM on D^-1(A+I) + fused layer kernel; and the whole training
