@@ -20,7 +20,7 @@
 //   Up to `parts` workgroups (SPEX_BATCH_PARTS, default 1) share a sample when its rows are long — each repeats the cheap,
 //   L2-resident forward, the parts of a short sample leave at once.  Measured on Epinion2, B = 256: 80.7 / 83.7 / 89.5 us per
 //   step with 1 / 2 / 4 parts — the extra 1024-thread workgroups (a second dispatch round: one fits per CU) cost more than
-//   halving the longest samples' push gains, although the push is bound by the CU's row-atomic rate (see the kernel).
+//   halving the longest samples' push gains, although the longest sample's push sets the launch time (see the kernel).
 #include "spex_common.h"
 
 using namespace spex;
@@ -108,8 +108,8 @@ __global__ __launch_bounds__(kWave *kWgWaves) void lightgcn_batch_kernel(
     // the push's runs of 16 entries, both rows' runs numbered jointly and dealt over (part, wave); the first kPre of this wave
     // are loaded here, ahead of the forward, so that their round trip is off the chain
     const int n_run0 = (t_len[0] + 15) >> 4, n_runs = n_run0 + ((t_len[1] + 15) >> 4);
-    // A CU retires one 256-byte row atomic per ~30-40 ns, so a sample with 300 stored entries keeps its CU pushing for ~12 us
-    // while the median sample is done in 2.  Only such samples are shared: part p of a sample stays if the sample has more than
+    // A wave issues one 256-byte row atomic per ~150 ns, so a sample with 600 stored entries pushes for ~6 us (38 runs over 16
+    // waves) while the median sample is done in 2.4.  Only such samples are shared: part p of a sample stays if the sample has more than
     // 8 p runs (128 p entries) — the others leave here, before the forward — and the active parts split the runs.
     const int act = (n_runs + 7) / 8 < parts ? ((n_runs + 7) / 8 < 1 ? 1 : (n_runs + 7) / 8) : parts;
     if (part >= act) return;
