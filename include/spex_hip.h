@@ -336,7 +336,8 @@ int spex_spmm_push_batch_f32(const spex_graph_t *g, const int64_t *idx_a, int32_
  *   g_out[r] += g_r                                                  — dense d loss / d light_out (atomics: rows repeat)
  *   G[r] += push_scale * g_r;  G[col[e]] += push_scale * val[e] * g_r over the stored entries e of row r of `gt` (= A^T)
  * g_out and G are accumulated into: zero them first (the step's Adam pass does).  Samples with an index out of range are
- * skipped (loss 0).  SPEX_BATCH_PARTS workgroups (default 1) share a sample.
+ * skipped (loss 0).  Up to SPEX_BATCH_PARTS workgroups (default 3) share a sample whose rows are long (their pushes' atomics
+ * then come from several CUs).
  */
 int spex_lightgcn_batch_f32(const spex_graph_t *g, const spex_graph_t *gt, const float *X, const float *acc_in, float acc_div,
                             const int64_t *users, const int64_t *items, const float *labels, int32_t B, int32_t n_user_rows,

@@ -17,10 +17,12 @@
 //     3. push: out[col[e]] += val[e] * g / (L + 1) over the stored entries of both rows in A^T, runs of 16 entries numbered
 //        jointly and dealt over (part, wave) — their (col, val) pairs were requested before step 1 —, plus
 //        out[row] += g / (L + 1) and the dense d loss / d light rows (part 0 only).
-//   Up to `parts` workgroups (SPEX_BATCH_PARTS, default 1) share a sample when its rows are long — each repeats the cheap,
-//   L2-resident forward, the parts of a short sample leave at once.  Measured on Epinion2, B = 256: 80.7 / 83.7 / 89.5 us per
-//   step with 1 / 2 / 4 parts — the extra 1024-thread workgroups (a second dispatch round: one fits per CU) cost more than
-//   halving the longest samples' push gains, although the longest sample's push sets the launch time (see the kernel).
+//   Up to `parts` workgroups (SPEX_BATCH_PARTS, default 3) share a sample when its rows are long (more than
+//   SPEX_BATCH_RUNS_PER_PART = 16 runs per part) — each repeats the cheap, L2-resident forward, the parts of a shorter sample
+//   leave at once.  The longest sample's push sets the launch time, and the reference's training batches (a random observed pair
+//   or one of its five same-user negatives: users and positive items arrive in proportion to their degree) carry rows of ~1 000
+//   entries all the time.  Measured on Epinion2, B = 256, us per step on uniform / training-shaped batches: 1 part 81.1 / 86.5,
+//   2 parts (16 runs each) 83.6 / 84.7, 3 parts 81.1 / 83.2, 4 parts 89.5 / 91.4 (1 024 workgroups of 1 024 threads).
 #include "spex_common.h"
 
 using namespace spex;
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void lightgcn_batch_kernel(
     const int32_t *__restrict__ t_rowptr, const int32_t *__restrict__ t_col, const float *__restrict__ t_val, int n_rows,
     int n_user_rows, const float *__restrict__ X, const float *__restrict__ acc_in, float acc_div,
     const int64_t *__restrict__ users, const int64_t *__restrict__ items, const float *__restrict__ labels, int parts,
-    float grad_scale, float push_scale, float *loss_sum, float *__restrict__ loss_rows, float *g_out, float *G)
+    float grad_scale, float push_scale, float *loss_sum, float *__restrict__ loss_rows, float *g_out, float *G, int runs_per_part)
 {
     __shared__ float s_part[2][kWgWaves][kWave];   // [row: user, item][virtual wave of the row-list kernel][column]
     __shared__ float s_light[2][kWave];
@@ -109,9 +111,10 @@ __global__ __launch_bounds__(kWave *kWgWaves) void lightgcn_batch_kernel(
     // are loaded here, ahead of the forward, so that their round trip is off the chain
     const int n_run0 = (t_len[0] + 15) >> 4, n_runs = n_run0 + ((t_len[1] + 15) >> 4);
     // A wave issues one 256-byte row atomic per ~150 ns, so a sample with 600 stored entries pushes for ~6 us (38 runs over 16
-    // waves) while the median sample is done in 2.4.  Only such samples are shared: part p of a sample stays if the sample has more than
-    // 8 p runs (128 p entries) — the others leave here, before the forward — and the active parts split the runs.
-    const int act = (n_runs + 7) / 8 < parts ? ((n_runs + 7) / 8 < 1 ? 1 : (n_runs + 7) / 8) : parts;
+    // waves) while the median sample is done in 2.4.  Only such samples are shared: part p of a sample stays if the sample has more
+    // than runs_per_part * p runs — the others leave here, before the forward — and the active parts split the runs.
+    const int want = (n_runs + runs_per_part - 1) / runs_per_part;
+    const int act = want < parts ? (want < 1 ? 1 : want) : parts;
     if (part >= act) return;
     const int q_step = act * kWgWaves;
     int q = part * kWgWaves + wave;
@@ -334,14 +337,19 @@ extern "C" int spex_lightgcn_batch_f32(const spex_graph_t *g, const spex_graph_t
         return SPEX_ERR_UNSUPPORTED;
     }
     if (B == 0 || g->n_rows == 0) return SPEX_OK;
+    static const int runs_per_part = []() {
+        const char *e = getenv("SPEX_BATCH_RUNS_PER_PART");
+        const int p = e ? atoi(e) : 16;
+        return p < 1 ? 1 : p;
+    }();
     static const int parts = []() {
         const char *e = getenv("SPEX_BATCH_PARTS");
-        const int p = e ? atoi(e) : 1;
+        const int p = e ? atoi(e) : 3;
         return p < 1 ? 1 : (p > 16 ? 16 : p);
     }();
     hipLaunchKernelGGL(lightgcn_batch_kernel, dim3((unsigned)B * parts), dim3(kWave * kWgWaves), 0, (hipStream_t)stream, g->rowptr, g->col,
                        g->val, gt->rowptr, gt->col, gt->val, g->n_rows, n_user_rows, X, acc_in, acc_div, users, items, labels, parts,
-                       grad_scale, push_scale, loss_sum, loss_per_sample, g_out, G);
+                       grad_scale, push_scale, loss_sum, loss_per_sample, g_out, G, runs_per_part);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }
