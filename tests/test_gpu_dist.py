@@ -335,6 +335,34 @@ def test_bench_multi_rank_path_rehearsal():
     assert abs(out["value"] - 3 * 2 * 418608 * 20 / (out["ms_per_step"] * 20 * 1e-3)) <= 1e-6 * out["value"]
 
 
+def test_bench_single_gpu_line_is_well_formed():
+    """bench.py as the driver runs it at N = 1 (here with the auxiliary measurements and the 2^24-node graph switched off, a
+    short CPU-baseline leg left on): ONE JSON line carrying the contract's keys, `roofline` and `cpu_baseline` objects with
+    consistent figures."""
+    import json
+    import subprocess
+    import sys
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--steps", "20", "--warmup", "5", "--no-hbm-roofline", "--no-standalone"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=REPO, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["steps"] == 20 and out["warmup"] == 5 and out["unit"] == "edges/s" and out["dtype"] == "f32"
+    assert out["higher_is_better"] is True and out["vs_baseline"] is None and "workload" in out["config"]
+    assert abs(out["value"] - 3 * 418608 * 20 / (out["ms_per_step"] * 20 * 1e-3)) <= 1e-6 * out["value"]
+    rf = out["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and rf["launches_timed"] > 0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) <= 1e-9
+    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["avg_launch_us"] * 1e-6) / 1e9) <= 1e-6 * rf["achieved"]
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "edges/s" and "sample" in cb
+    assert out["value"] > 20 * cb["value"]                  # (a sanity bound, not a target)
+
+
 def _peer_worker(rank, world, port, out_dir):
     import sys
     sys.path.insert(0, REPO)
