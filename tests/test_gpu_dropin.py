@@ -257,6 +257,19 @@ def test_dual_task_driver_runs_through_the_launcher(data_root, golden):
     assert len(rec) == 2 and len(trust) == 2 and len(losses) == 2
     l0, l1 = (float(l.split(",")[1]) + float(l.split(",")[2]) for l in losses)
     assert l1 < l0                                                      # both tasks' summed loss goes down
+    # ... and the run IS the reference's (G13, minted from main_auto_expert_s.py's own loop with the same seed): the printed loss
+    # sums of both tasks and the printed metrics of both tasks, epoch by epoch (5 / 4 printed decimals)
+    import re
+    e13 = golden("dual_tiny_epochs")
+    for ep, line in enumerate(losses):
+        _, a, b = line.split(",")
+        assert abs(float(a) - e13["loss1"][ep]) <= 2e-5 * e13["loss1"][ep] + 2e-5, (ep, a, e13["loss1"][ep])
+        assert abs(float(b) - e13["loss2"][ep]) <= 5e-5 * e13["loss2"][ep] + 2e-5, (ep, b, e13["loss2"][ep])
+    for ep in range(2):
+        nums = [float(x) for x in re.findall(r"-?\d+\.\d+", rec[ep].split(":", 2)[2])]
+        assert np.abs(np.array(nums[:3]) - e13["rec_recall"][ep]).max() <= 1.5e-4 and np.abs(np.array(nums[3:6]) - e13["rec_ndcg"][ep]).max() <= 1.5e-4
+        tnums = [float(x) for x in re.findall(r"-?\d+\.\d+", trust[ep].split(":", 2)[2])]
+        assert np.abs(np.array(tnums[:6]) - np.asarray(e13["trust"][ep]).ravel()[:6]).max() <= 1.5e-4
 
 
 def _dual_task_model(data_root):
