@@ -231,6 +231,16 @@ def test_unmodified_style_driver_runs_through_the_launcher(data_root, tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("Rec:")]
     assert len(lines) >= 2 and "recall=" in lines[-1]
+    # ... and the run IS the reference's (G12 on `tiny`, minted from main_rec.py's own loop with the same seed): the printed loss
+    # sum and the printed HR / NDCG of every epoch
+    import re
+    e12 = np.load(os.path.join(REPO, "tests", "golden", "lightgcn_tiny_epochs.npz"))
+    losses = [l for l in out.stdout.splitlines() if re.fullmatch(r"\d+,\d+\.\d+", l)]
+    assert len(losses) == 2
+    for ep in range(2):
+        assert abs(float(losses[ep].split(",")[1]) - e12["losses"][ep]) <= 2e-5 * e12["losses"][ep] + 2e-5
+        nums = [float(x) for x in re.findall(r"-?\d+\.\d+", lines[ep].split(":", 2)[2])]
+        assert np.abs(np.array(nums[:3]) - e12["recall"][ep]).max() <= 1.5e-4 and np.abs(np.array(nums[3:6]) - e12["ndcg"][ep]).max() <= 1.5e-4
 
 
 def test_dual_task_driver_runs_through_the_launcher(data_root, golden):
