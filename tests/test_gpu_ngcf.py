@@ -162,6 +162,26 @@ def ngcf_data_root(tmp_path_factory):
     return os.path.join(root, "")
 
 
+def test_ngcf_driver_runs_through_the_launcher(ngcf_data_root):
+    """tests/drivers/ngcf_driver.py — NGCF_SPEX/code/main_rec.py's imports and call sequence with the one line a maintainer
+    changes (Model_Wrapper from spex_amd.ngcf) — run as INTEGRATION.md says, `python -m spex_amd.dropin <driver> ...`, three
+    epochs on the 300-user graph: the printed loss sums and HR / NDCG are the reference's own run's (G12-NGCF, same seed;
+    message dropout regenerated from the counter-based mask)."""
+    import re
+    g = np.load(os.path.join(REPO, "tests", "golden", "ngcf_small_epochs.npz"))
+    script = os.path.join(REPO, "tests", "drivers", "ngcf_driver.py")
+    out = subprocess.run([sys.executable, "-m", "spex_amd.dropin", script, "--data_path", ngcf_data_root, "--dataset", "small",
+                          "--epoch", "3"], cwd=REPO, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("epoch ")]
+    assert len(lines) == 3, out.stdout[-2000:]
+    for ep, line in enumerate(lines):
+        nums = [float(x) for x in re.findall(r"-?\d+\.\d+", line)]
+        loss, rec, ndcg = nums[0], np.array(nums[1:4]), np.array(nums[4:7])
+        assert abs(loss - g["losses"][ep]) <= 1e-4 * g["losses"][ep] + 2e-5, (ep, loss, g["losses"][ep])
+        assert np.abs(rec - g["recall"][ep]).max() <= 2e-4 and np.abs(ndcg - g["ndcg"][ep]).max() <= 2e-4, (ep, rec, g["recall"][ep])
+
+
 def _run_reference_loop(ds, n_epochs, g, root, metric_tol=1e-4):
     """main_rec.py:116-148 on the drop-in modules: Data, NGCF, torch Adam, the DataLoader of load_train_data, test()."""
     from spex_amd.dropin.ngcf.utility import batch_test
