@@ -94,6 +94,18 @@ def test_two_ranks_on_gpu_match_single_device(tmp_path):
         assert np.array_equal(d["fu"], ref[d["u"]]) and np.array_equal(d["fi"], ref[3186 + d["i"]])
     assert np.array_equal(lo, ref)          # a row's summation order does not depend on the partition
     assert np.array_equal(grad, ref_grad)
+    # ... and against the CPU oracle, not only against the one-rank HIP result (the single-device gate of test_gpu_kernels.py:
+    # rows cut into segments re-associate <= 16 partial sums)
+    from oracle import oracle as O
+    want_lo = O.propagate_mean(*csr, E0, 3, n_threads=4)
+    rel_err = lambda a, b: float(np.abs(a.astype(np.float64) - b).max() / np.abs(b).max())
+    assert rel_err(lo, want_lo) <= 1e-6
+    tcsr = O.csr_transpose(*csr, len(E0))
+    gl = E0[::-1].copy() / np.float32(4.0)
+    G_ = gl.copy()
+    for _ in range(3):
+        G_ = gl + O.spmm(*tcsr[:3], G_, n_threads=4)
+    assert rel_err(grad, G_) <= 2e-6
     # the same three training steps on one device
     from spex_amd.trainer import LightGCNStepper
     st = LightGCNStepper(g, torch.from_numpy(E0.copy()).cuda(), 3186, n_layers=3, lr=1e-3)
