@@ -37,7 +37,8 @@ typedef enum spex_status {
 
 typedef struct spex_graph spex_graph_t;
 
-int spex_version(void);                 /* ABI version, currently 2 (1 + the NGCF layer fwd/bwd and grouped BPR entries) */
+int spex_version(void);                 /* ABI version, currently 3 (2 + the batch-sized one-launch entries, spex_graph_create_ex, and
+                                         * a trailing side_stream field in the NGCF / dual-task step descriptors) */
 const char *spex_last_error(void);      /* thread-local, never NULL */
 
 /* ------------------------------------------------------------------------------------------------ graph handle

@@ -39,7 +39,7 @@ def test_binding_arity_matches_header():
 
 def test_version_and_error_string():
     lib = _lib.load()
-    assert lib.spex_version() == 2
+    assert lib.spex_version() == 3
     assert isinstance(lib.spex_last_error(), bytes)
 
 
@@ -101,4 +101,4 @@ def test_header_is_plain_c(tmp_path):
     assert r.returncode == 0, r.stderr
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     # NULL rowptr is refused by argument validation before any device call
-    assert out.returncode == 1 and out.stdout.startswith("2 -1 spex_graph_create"), (out.stdout, out.stderr)
+    assert out.returncode == 1 and out.stdout.startswith("3 -1 spex_graph_create"), (out.stdout, out.stderr)
