@@ -31,14 +31,19 @@ typedef enum spex_status {
     SPEX_OK = 0,
     SPEX_ERR_INVALID = -1,     /* bad argument (null pointer, negative size, unsorted CSR, ...) */
     SPEX_ERR_HIP = -2,         /* a HIP runtime call failed                                      */
-    SPEX_ERR_COMM = -3,        /* reserved: collective failure (collectives live in the host layer) */
+    SPEX_ERR_COMM = -3,        /* an RCCL call of the spex_comm_* entries failed                   */
     SPEX_ERR_UNSUPPORTED = -4  /* e.g. the NGCF epilogue at d != 64                              */
 } spex_status;
 
 typedef struct spex_graph spex_graph_t;
 
-int spex_version(void);                 /* ABI version, currently 3 (2 + the batch-sized one-launch entries, spex_graph_create_ex, and
-                                         * a trailing side_stream field in the NGCF / dual-task step descriptors) */
+int spex_version(void);                 /* ABI version, currently 4.  3 = 2 + the batch-sized one-launch entries, spex_graph_create_ex,
+                                         * a trailing side_stream field in the NGCF / dual-task step descriptors.  4 = 3 + the
+                                         * deterministic accumulation mode (`flags` + trailing buffers in the three step descriptors,
+                                         * spex_reduce_slots_f32, spex_lightgcn_batch_slots_f32, spex_expert_gate_rows_bwd_det_f32),
+                                         * per-descriptor fork / join events (ev_fork / ev_join, spex_step_events_release),
+                                         * spex_lightgcn_batch_f32 without its graph_t argument (the push walks the rows of A),
+                                         * loss_per_sample in spex_gated_batch_fwd_f32, and the spex_comm_* collectives */
 const char *spex_last_error(void);      /* thread-local, never NULL */
 
 /* ------------------------------------------------------------------------------------------------ graph handle
@@ -335,15 +340,36 @@ int spex_spmm_push_batch_f32(const spex_graph_t *g, const int64_t *idx_a, int32_
  *   loss_per_sample[b] = loss_b (plain store) if loss_per_sample != NULL, else *loss_sum += loss_b (one atomic per sample)
  *   g_u = dg * light_i,  g_i = dg * light_u
  *   g_out[r] += g_r                                                  — dense d loss / d light_out (atomics: rows repeat)
- *   G[r] += push_scale * g_r;  G[col[e]] += push_scale * val[e] * g_r over the stored entries e of row r of `gt` (= A^T)
+ *   G[r] += push_scale * g_r;  G[col[e]] += push_scale * val[e] * g_r over the stored entries e of row r of `g` ITSELF:
+ *                                                                    G = push_scale (g + A^T g), and A^T g in push form walks
+ *                                                                    the rows of A — (A^T g)[c] = sum_r A[r, c] g[r]
  * g_out and G are accumulated into: zero them first (the step's Adam pass does).  Samples with an index out of range are
  * skipped (loss 0).  Up to SPEX_BATCH_PARTS workgroups (default 3) share a sample whose rows are long (their pushes' atomics
  * then come from several CUs).
  */
-int spex_lightgcn_batch_f32(const spex_graph_t *g, const spex_graph_t *gt, const float *X, const float *acc_in, float acc_div,
+int spex_lightgcn_batch_f32(const spex_graph_t *g, const float *X, const float *acc_in, float acc_div,
                             const int64_t *users, const int64_t *items, const float *labels, int32_t B, int32_t n_user_rows,
                             float grad_scale, float push_scale, float *loss_sum, float *loss_per_sample, float *g_out, float *G,
                             int32_t d, void *stream);
+/* The same launch without the push and without any float atomic (the deterministic step): light_r, x, loss_b, dg as above, then
+ *   grad_slots[b] = g_u,  grad_slots[B + b] = g_i      ([2B, d] per-sample rows, plain stores; out-of-range samples: zeros)
+ * spex_reduce_slots_f32 then adds the slots per table row in ascending slot order. */
+int spex_lightgcn_batch_slots_f32(const spex_graph_t *g, const float *X, const float *acc_in, float acc_div, const int64_t *users,
+                                  const int64_t *items, const float *labels, int32_t B, int32_t n_user_rows, float grad_scale,
+                                  float *loss_sum, float *loss_per_sample, float *grad_slots, int32_t d, void *stream);
+
+/* Deterministic accumulation of a batch's per-slot rows into a dense [n_rows, 64] table — replaces the float atomics of the row-
+ * sparse backward where results must repeat bit for bit (and follows the order of the reference's CPU `index_put_(accumulate)` /
+ * index_select backward, LightGCN_SPEX/code/utility1/model.py:115-116 and NGCF_SPEX/code/main_rec.py:89-90 under autograd):
+ *   slot k names row r_k = idx_a[k] + off_a (k < n_a) or idx_b[k - n_a] + off_b;
+ *   out[r] = scale * (slots[k1] + slots[k2] + ...)  over the slots k1 < k2 < ... with r_k == r, added in ASCENDING slot order
+ *   mode 0: out[r] is overwritten (rows no slot names are left alone);  mode 1: out[r] += the sum (plain read-modify-write: the
+ *   wave that holds the lowest slot of a row owns it).  slots == NULL: the named rows are set to zero (clears what mode 0 wrote).
+ * Rows out of range are skipped.  The duplicate scan is quadratic in the batch (n^2 * 8 bytes of cached reads): a validation-mode
+ * kernel for the reference's batches of 256, not a throughput path.  d == 64. */
+int spex_reduce_slots_f32(const int64_t *idx_a, int32_t n_a, int64_t off_a, const int64_t *idx_b, int32_t n_b, int64_t off_b,
+                          int32_t n_rows, const float *slots, int32_t ld_slots, float scale, float *out, int32_t mode, int32_t d,
+                          void *stream);
 
 /* Scoring + rows backward of the single-layer NGCF model as ONE launch (what spex_score_bce_slots_f32 followed by
  * spex_ngcf_layer_bwd_rows_f32 computes — NGCF_SPEX/code/main_rec.py:84-100 and autograd through :77-83 at the batch's rows):
@@ -365,14 +391,15 @@ int spex_ngcf_score_bwd_rows_f32(const float *ego, const float *side, const floa
  * rows u = users[b], i = items[b] + n_user_rows:
  *   light_r = (acc_in[r] + (A X)[r]) / acc_div,  lo_batch[r] = light_r                       (r in {u, i}; lo_batch is [N, d])
  *   mixed_r = raw[r] * a0 + light_r * a1,  (a0, a1) = softmax([raw[r] | light_r] att)        (att_u for u, att_i for i)
- *   x = <mixed_u, mixed_i>;  *loss_sum += BCEWithLogits(x, labels[b]);  dg = (sigmoid(x) - labels[b]) * grad_scale
+ *   x = <mixed_u, mixed_i>;  loss_b = BCEWithLogits(x, labels[b]);  dg = (sigmoid(x) - labels[b]) * grad_scale
+ *   loss_per_sample[b] = loss_b (plain store) if loss_per_sample != NULL, else *loss_sum += loss_b (one atomic per sample)
  *   grad_slots[b] = dg * mixed_i,  grad_slots[B + b] = dg * mixed_u                          ([2B, d], row stride d)
  * spex_expert_gate_rows_bwd_f32 and the push-form product follow as before.  d == 64, no edge dropout.
  */
 int spex_gated_batch_fwd_f32(const spex_graph_t *g, const float *X, const float *acc_in, float acc_div, const float *raw,
                              const float *att_u, const float *att_i, const int64_t *users, const int64_t *items, const float *labels,
-                             int32_t B, int32_t n_user_rows, float grad_scale, float *loss_sum, float *lo_batch, float *grad_slots,
-                             int32_t d, void *stream);
+                             int32_t B, int32_t n_user_rows, float grad_scale, float *loss_sum, float *loss_per_sample,
+                             float *lo_batch, float *grad_slots, int32_t d, void *stream);
 
 /* Replaces the two-expert gate of the dual-task model, utility1/model_expert_s.py:156-161:
  *   att = softmax([raw | prop] att_exp, dim=1) ([n,2d] x [2d,2]);  mixed = raw * att[:,0] + prop * att[:,1]
@@ -400,6 +427,15 @@ int spex_expert_gate_rows_bwd_f32(const float *raw, const float *prop, const flo
                                   int64_t n_user_rows, int64_t n_rows, int32_t d, const float *grad_slots, int32_t ld_slots,
                                   float *grad_prop_slots, float *grad_prop, float *grad_raw, float *grad_att_u, float *grad_att_i,
                                   void *stream);
+/* The same backward without a float atomic (the deterministic step): grad_prop_slots AND grad_raw_slots leave as compact per-slot
+ * rows ([n_a + n_b, 64]; spex_reduce_slots_f32 adds them per table row in slot order), and every workgroup writes its share of the
+ * two gate gradients to its own block of att_parts — [spex_expert_gate_rows_bwd_parts(n_a + n_b)][512] floats, block p =
+ * [d att_u (256) | d att_i (256)] — to be added in block order. */
+int32_t spex_expert_gate_rows_bwd_parts(int32_t n_slots);
+int spex_expert_gate_rows_bwd_det_f32(const float *raw, const float *prop, const float *att_u, const float *att_i, const int64_t *idx_a,
+                                      int32_t n_a, int64_t off_a, const int64_t *idx_b, int32_t n_b, int64_t off_b,
+                                      int64_t n_user_rows, int64_t n_rows, int32_t d, const float *grad_slots, int32_t ld_slots,
+                                      float *grad_prop_slots, float *grad_raw_slots, float *att_parts, void *stream);
 
 /* ------------------------------------------------------------------------------------------------ negative sampler
  * Replaces LightTrainData.ng_sample, LightGCN_SPEX/code/utility1/dataloader.py:250-265 (distribution, not stream):
@@ -494,8 +530,9 @@ int spex_path_attention_bwd_f32(const float *src, int64_t n_src_rows, const int6
  * spex_trust_head_train_f32 (two launches): forward, logits = a2 . table[0 : n_rows - 1]^T (`b = table[:-1]`), loss =
  *   mean_b CE(logits_b, targets_b) -> *loss_out (added to it if loss_accumulate; may be NULL), and the whole backward:
  *   grad_params (flat block) is OVERWRITTEN (one thread per weight sums its contributions in a fixed order: deterministic);
- *   grad_table [n_rows, 64] is ACCUMULATED (the logits' part by the launch that owns the rows, the paths' own rows with
- *   atomics) — zero it first or pass the buffer it is to be added to.  Gradients are scaled by scale * (*scale_dev if
+ *   grad_table [n_rows, 64] is ACCUMULATED by the launch that owns the rows — the logits' part, then the rows of the paths that
+ *   pass through the user in (path, position) order; no atomics: the whole head repeats bit for bit — zero it first or pass
+ *   the buffer it is to be added to.  Gradients are scaled by scale * (*scale_dev if
  *   scale_dev else 1) — e.g. the multi-task precision exp(-2 s) of main_auto_expert_s.py:81-82 read on the device.
  *   Scratch (caller-owned): a2 [B, 64], dscore [B, n_rows - 1], loss_b [B], ws [spex_trust_workspace_floats(B, L, 64, H)].
  */
@@ -523,7 +560,21 @@ int spex_trust_head_train_f32(const float *table, int64_t n_rows, const float *p
  * pass clears both).  t is advanced by the call.
  * users / items: device int64[B] (items index the item block: row n_user_rows + items[b]); labels: device fp32[B].
  * *loss_sum (device) accumulates the batch's BCE loss SUM.  L >= 1; no edge dropout (use the separate calls then).
+ * graph is walked by the forward AND by the push-form first backward product (A^T g in push form walks the rows of A); graph_t
+ * (A^T) by the pull-form products.  t is advanced only when every launch of the step was queued (a failed call leaves it alone).
+ *
+ * flags & SPEX_STEP_DETERMINISTIC (all three step descriptors): no float atomics anywhere in the step — per-sample gradient rows
+ * are added per table row in ascending slot order (spex_reduce_slots_f32: the order of the reference's CPU index backward), the
+ * whole backward propagation runs in pull form (spex_propagate_bwd_f32: one chain per output row in ascending column order, like
+ * the reference's sparse addmm), per-sample losses are summed in sample order.  Two runs from the same state then produce
+ * bit-identical parameters; the price is one more SpMM-sized launch and two small ones per step (a validation mode: the fast
+ * path's atomics only reorder sums, which Adam amplifies along NGCF's scale-invariant direction over thousands of steps).
  */
+enum {
+    SPEX_STEP_DETERMINISTIC = 1,        /* fixed summation order everywhere (see above) */
+    SPEX_STEP_FIXED_TASK_WEIGHTS = 2    /* dual-task step only: loss = loss1 + loss2 (LightGCN_SPEX/code/main_11.py:69) instead of the
+                                         * uncertainty weighting of main_auto_expert_s.py:78-82; task_weights are left untouched */
+};
 typedef struct spex_lightgcn_step {
     const spex_graph_t *graph, *graph_t;     /* A and A^T (the same handle for the symmetric LightGCN adjacency) */
     float *E0, *m, *v;
@@ -531,6 +582,7 @@ typedef struct spex_lightgcn_step {
     int32_t slot_capacity, n_user_rows, L, d;
     float lr, beta1, beta2, eps;
     int32_t t;
+    int32_t flags;                           /* SPEX_STEP_DETERMINISTIC */
 } spex_lightgcn_step_t;
 int spex_lightgcn_step_bce_f32(spex_lightgcn_step_t *step, const int64_t *users, const int64_t *items, const float *labels,
                                int32_t B, float *loss_sum, void *stream);
@@ -559,7 +611,13 @@ typedef struct spex_ngcf_step {
                           * beside the push-form product and the table's Adam pass and is joined at the end of the call.
                           * Measured SLOWER than one stream on the MI355X (69 vs 59 us per step: a cross-stream fork + join
                           * costs ~10 us, the hidden pass takes 5) — leave NULL unless the forked work is long */
+    void *ev_fork, *ev_join;   /* the two-stream form's events: zero-initialise; created by the library on first use, one pair per
+                                * descriptor; release with spex_step_events_release */
+    const spex_graph_t *graph_t;             /* A^T — SPEX_STEP_DETERMINISTIC only (pull-form first backward product), else NULL */
+    float *g_side_dense, *g_ego_dense;       /* [N, d] each, all-zero before the first call — SPEX_STEP_DETERMINISTIC only */
+    int32_t flags;
 } spex_ngcf_step_t;
+int spex_step_events_release(void **ev_fork, void **ev_join);   /* destroys the pair a descriptor holds (no step in flight) */
 int spex_ngcf_step_bce_f32(spex_ngcf_step_t *step, const int64_t *users, const int64_t *items, const float *labels, int32_t B,
                            float *loss_sum, void *stream);
 
@@ -603,6 +661,11 @@ typedef struct spex_dual_task_step {
     int32_t t;
     void *side_stream;   /* optional second hipStream_t of the caller (NULL: one stream): the trust branch is issued on it and runs
                           * CONCURRENTLY with the rec branch — the two only meet in the Adam pass (see below) */
+    void *ev_fork, *ev_join;   /* as in spex_ngcf_step_t: zero-initialise, release with spex_step_events_release */
+    float *g_raw_slots;        /* [slot_capacity, 64]                                   — SPEX_STEP_DETERMINISTIC only */
+    float *att_parts;          /* [spex_expert_gate_rows_bwd_parts(slot_capacity)][512] — SPEX_STEP_DETERMINISTIC only */
+    float *loss_rows;          /* [slot_capacity / 2] per-sample rec losses             — SPEX_STEP_DETERMINISTIC only */
+    int32_t flags;             /* SPEX_STEP_DETERMINISTIC | SPEX_STEP_FIXED_TASK_WEIGHTS */
 } spex_dual_task_step_t;
 int spex_dual_task_step_f32(spex_dual_task_step_t *step, const int64_t *users, const int64_t *items, const float *labels, int32_t B,
                             const int64_t *seq, const int64_t *seq_l, const int64_t *targets, int32_t T, void *stream);

@@ -226,7 +226,7 @@ def stage_lightgcn(skip_epinion_test=False):
     import numpy as np
     import torch
     install_shims()
-    torch.set_num_threads(8)
+    torch.set_num_threads(int(os.environ.get("SPEX_MINT_THREADS", "8")))
     code = os.path.join(SCRATCH, "LightGCN_SPEX", "code")
     os.makedirs(code, exist_ok=True)
     os.chdir(code)
@@ -442,7 +442,7 @@ def stage_ngcf():
     import numpy as np
     import torch
     install_shims()
-    torch.set_num_threads(8)
+    torch.set_num_threads(int(os.environ.get("SPEX_MINT_THREADS", "8")))
     code = os.path.join(SCRATCH, "NGCF_SPEX", "code")
     os.makedirs(code, exist_ok=True)
     os.chdir(code)
@@ -559,7 +559,7 @@ def stage_trust():
     import numpy as np
     import torch
     install_shims()
-    torch.set_num_threads(8)
+    torch.set_num_threads(int(os.environ.get("SPEX_MINT_THREADS", "8")))
     code = os.path.join(SCRATCH, "LightGCN_SPEX", "code")
     os.makedirs(code, exist_ok=True)
     os.chdir(code)
@@ -625,7 +625,7 @@ def stage_trust():
 
 
 # --------------------------------------------------------------------------- whole training run (G12)
-def stage_epochs(ds="tiny", n_epochs=3):
+def stage_epochs(ds="tiny", n_epochs=3, dropout=None, max_steps=None):
     """G12: the reference's own training run — main_rec.py:15-37,50 executed with the reference's modules (set_seed,
     Loader, LightTrainData.ng_sample, DataLoader(256, shuffle=True), model.LightGCN, torch Adam, test()) for three
     epochs on `tiny`: per-epoch loss sums, per-epoch recall / ndcg, the trained tables.  main_rec.py itself runs at
@@ -634,7 +634,7 @@ def stage_epochs(ds="tiny", n_epochs=3):
     import torch
     from torch.utils.data import DataLoader
     install_shims()
-    torch.set_num_threads(8)
+    torch.set_num_threads(int(os.environ.get("SPEX_MINT_THREADS", "8")))
     code = os.path.join(SCRATCH, "LightGCN_SPEX", "code")
     os.makedirs(code, exist_ok=True)
     os.chdir(code)
@@ -645,6 +645,8 @@ def stage_epochs(ds="tiny", n_epochs=3):
         os.remove(cache)
     sys.path.insert(0, os.path.join(REF, "LightGCN_SPEX", "code"))
     sys.argv = ["main_rec.py", "--dataset", ds]
+    if dropout is not None:                # README.md:119-123: "--dropout=1 --keepprob=0.3"
+        sys.argv += ["--dropout", "1", "--keepprob", str(dropout)]
     import lg_parser
     import utility1.dataloader as ref_dl
     import utility1.model as ref_model
@@ -659,18 +661,30 @@ def stage_epochs(ds="tiny", n_epochs=3):
     Recmodel = ref_model.LightGCN(args, dataset).to(device)                         # :22
     optimizer = torch.optim.Adam(Recmodel.parameters(), lr=args.lr)                 # :23
     losses, recalls, ndcgs, first_batch = [], [], [], None
+    step_losses, mask0 = [], {}
+    nnz = Recmodel.Graph._nnz()
     for epoch in range(n_epochs):
         train_loader.dataset.ng_sample()                                            # :26
         Recmodel.train()
         total_loss = 0.0
-        for data in train_loader:                                                   # :30-37
+        for step, data in enumerate(train_loader):                                  # :30-37
+            if max_steps is not None and step == max_steps:
+                break
             optimizer.zero_grad()
             user, item, label = data
             if first_batch is None:
                 first_batch = np.stack([user.numpy(), item.numpy(), label.numpy()])
+            if dropout is not None and not mask0:
+                # what model.py:50-51 is about to draw for this step (the generator is put back where it was)
+                st = torch.get_rng_state()
+                keep = (torch.rand(nnz) + args.keepprob).int().bool().numpy()
+                torch.set_rng_state(st)
+                mask0 = dict(mask0_sha=sha(keep.astype(np.uint8)), mask0_kept=int(keep.sum()), mask0_head=keep[:4096].copy())
             loss = Recmodel(users=user.to(device), items=item.to(device), labels=label.to(device), flag=0)
             loss.backward()
             total_loss += loss.item()
+            if dropout is not None:
+                step_losses.append(loss.item())
             optimizer.step()
         losses.append(total_loss)
         Recmodel.eval()
@@ -685,7 +699,12 @@ def stage_epochs(ds="tiny", n_epochs=3):
         extra = dict(rows_u=rows_u, rows_i=rows_i, user_w_colsum=uw.astype(np.float64).sum(0),
                      item_w_colsum=iw.astype(np.float64).sum(0))
         uw, iw = uw[rows_u], iw[rows_i]
-    np.savez_compressed(os.path.join(GOLD, f"lightgcn_{ds}_epochs.npz"), seed=args.seed, lr=args.lr,
+    name = f"lightgcn_{ds}_epochs.npz"
+    if dropout is not None:                # G12-dropout: per-step losses of the whole (capped) run, the first step's keep mask
+        name = f"lightgcn_{ds}_dropout.npz"
+        extra.update(mask0, keepprob=args.keepprob, step_losses=np.asarray(step_losses, np.float64),
+                     max_steps=-1 if max_steps is None else max_steps, nnz=nnz)
+    np.savez_compressed(os.path.join(GOLD, name), seed=args.seed, lr=args.lr,
                         losses=np.asarray(losses, np.float64), recall=np.asarray(recalls, np.float64),
                         ndcg=np.asarray(ndcgs, np.float64), first_batch=first_batch, user_w=uw, item_w=iw, **extra)
     print("epochs: losses", losses, "recall", recalls[-1], "ndcg", ndcgs[-1])
@@ -702,7 +721,7 @@ def stage_epochs_dual():
     import torch
     from torch.utils.data import DataLoader
     install_shims()
-    torch.set_num_threads(8)
+    torch.set_num_threads(int(os.environ.get("SPEX_MINT_THREADS", "8")))
     code = os.path.join(SCRATCH, "LightGCN_SPEX", "code")
     os.makedirs(code, exist_ok=True)
     os.chdir(code)
@@ -793,7 +812,7 @@ def _epinion2_trust_raw():
 def _dual_setup(argv0="main_auto_expert_s.py"):
     import torch
     install_shims()
-    torch.set_num_threads(8)
+    torch.set_num_threads(int(os.environ.get("SPEX_MINT_THREADS", "8")))
     code = os.path.join(SCRATCH, "LightGCN_SPEX", "code")
     os.makedirs(code, exist_ok=True)
     os.chdir(code)
@@ -870,7 +889,7 @@ def stage_trust_epinion2():
     print("trust epinion2: loss1 %.6f loss2 %.6f test5 %s" % (loss1.item(), loss2.item(), out["trust_test5"]))
 
 
-def stage_epochs_dual_epinion2(n_steps=600):
+def stage_epochs_dual_epinion2(n_steps=600, full_epoch=False):
     """G13 at Epinion2 scale: main_auto_expert_s.py:22-91 executed with the reference's modules on the Epinion2 graph and
     the reference-minted trust paths, for the first `n_steps` batches of epoch 0 (a full epoch is 4 906 batches; the
     dual-task step costs ~1.5 s of reference CPU time), then Test() (:98-114: rec_test over all 3 185 test users +
@@ -908,12 +927,70 @@ def stage_epochs_dual_epinion2(n_steps=600):
     out = dict(n_paths=[], loss1_first=[], loss2_first=[], loss1_cum=[], loss2_cum=[])
     train_loader.dataset.ng_sample()                                                # :56
     Recmodel.train()
-    t1 = t2 = 0.0
+    t1 = t2 = full1 = full2 = 0.0
+    full_cum1, full_cum2 = [], []
     import time
     t0 = time.time()
+    ckpt = {}
+
+    def table_grad_summary(prefix, gnp, rng):
+        rows = np.sort(rng.choice(gnp.shape[0], 512, replace=False))
+        nz = np.flatnonzero(np.abs(gnp).sum(1) > 0)
+        rows = np.unique(np.concatenate([rows, nz[:256]]))
+        ckpt[prefix + "_rows"] = rows
+        ckpt[prefix] = gnp[rows].copy()
+        ckpt[prefix + "_colsum"] = gnp.astype(np.float64).sum(0)
+        ckpt[prefix + "_fro"] = np.sqrt((gnp.astype(np.float64) ** 2).sum())
+
+    def take_checkpoint(tag, batch, path_index, l1, l2):
+        """Teacher forcing: the reference's FULL parameter state in front of a step, the step's rec batch and path indices,
+        both losses and every gradient of the weighted loss (called between loss.backward() and optimizer.step())."""
+        rng = np.random.default_rng(31)
+        ckpt[f"{tag}_batch"] = batch
+        ckpt[f"{tag}_path_index"] = np.asarray(path_index, np.int64)
+        ckpt[f"{tag}_loss1"] = np.float64(l1)
+        ckpt[f"{tag}_loss2"] = np.float64(l2)
+        for name, p in Recmodel.named_parameters():
+            key = name.replace(".", "__")
+            ckpt[f"{tag}_state_{key}"] = p.detach().numpy().copy()
+            if p.grad is None:
+                continue
+            g = p.grad.numpy()
+            if g.shape[0] > 1024:
+                table_grad_summary(f"{tag}_grad_{key}", g, rng)
+            else:
+                ckpt[f"{tag}_grad_{key}"] = g.copy()
+
+    def evaluate():
+        Recmodel.eval()
+        with torch.no_grad():                                                       # :98-114
+            r = rec_test(Recmodel, dataset.testRatings, dataset.testNegatives)
+            t = np.asarray(trust_test5(Recmodel, test_data2), np.float64)
+        Recmodel.train()
+        return r, t
+
+    def write_600(tw, ret, trust):
+        uw = Recmodel.embedding_user.weight.detach().numpy()
+        iw = Recmodel.embedding_item.weight.detach().numpy()
+        rows_u = np.sort(np.random.default_rng(1).choice(uw.shape[0], 256, replace=False))
+        rows_i = np.sort(np.random.default_rng(2).choice(iw.shape[0], 256, replace=False))
+        np.savez_compressed(os.path.join(GOLD, "dual_epinion2_epochs.npz"), seed=args.seed, n_steps=n_steps,
+                            trust_batch_size=trust_batch_size, steps_per_epoch=len(train_loader),
+                            **{k: np.asarray(v, np.float64) for k, v in out.items()}, task_weights=tw,
+                            rec_recall=ret["recall"], rec_ndcg=ret["ndcg"], trust=trust,
+                            rows_u=rows_u, rows_i=rows_i, user_w=uw[rows_u], item_w=iw[rows_i],
+                            user_w_colsum=uw.astype(np.float64).sum(0), item_w_colsum=iw.astype(np.float64).sum(0),
+                            w=Recmodel.w.detach().numpy(), att_exp1=Recmodel.att_exp1.detach().numpy(),
+                            att_t=Recmodel.att_t.detach().numpy())
+
+    first = None
     for step, data in enumerate(train_loader):                                      # :60-87
         if step == n_steps:
-            break
+            # (evaluation touches no RNG: the run goes on unchanged behind it when the full epoch is minted)
+            tw600 = Recmodel.task_weights.detach().numpy().copy()
+            ret600, trust600 = evaluate()
+            write_600(tw600, ret600, trust600)
+            print("dual epinion2 @%d: loss1" % n_steps, t1, "loss2", t2, "tw", tw600, "rec", ret600, "trust", trust600, flush=True)
         optimizer.zero_grad()
         user, item, label = data
         unique_user = set(user.numpy().tolist())
@@ -931,32 +1008,48 @@ def stage_epochs_dual_epinion2(n_steps=600):
         loss = precision1 * loss1 + precision2 * loss2 + 2 * (n_rec + 1) * T_rec * Recmodel.task_weights[0] \
             + T * Recmodel.task_weights[1]
         loss.backward()
-        t1 += loss1.item()
-        t2 += loss2.item()
+        if first is None:
+            first = (np.stack([user.numpy(), item.numpy(), label.numpy()]), list(path_index))
+        if step == n_steps:
+            take_checkpoint("ckpt%d" % step, np.stack([user.numpy(), item.numpy(), label.numpy()]), path_index,
+                            loss1.item(), loss2.item())
+            np.savez_compressed(os.path.join(GOLD, "dual_epinion2_ckpt.npz"), seed=args.seed, ckpt_step=n_steps,
+                                metrics_rec=np.concatenate([ret600["recall"], ret600["ndcg"]]), metrics_trust=trust600, **ckpt)
+            if not full_epoch:
+                break
+        if step < n_steps:
+            t1 += loss1.item()
+            t2 += loss2.item()
+        full1 += loss1.item()
+        full2 += loss2.item()
         if step < 16:
             out["loss1_first"].append(loss1.item()); out["loss2_first"].append(loss2.item())
         optimizer.step()
         if (step + 1) % 100 == 0:
-            out["loss1_cum"].append(t1); out["loss2_cum"].append(t2)
-            print("step", step + 1, "loss1", t1, "loss2", t2, "%.0f s" % (time.time() - t0), flush=True)
-    tw = Recmodel.task_weights.detach().numpy().copy()
-    Recmodel.eval()
-    with torch.no_grad():                                                           # :98-114
-        ret = rec_test(Recmodel, dataset.testRatings, dataset.testNegatives)
-        trust = np.asarray(trust_test5(Recmodel, test_data2), np.float64)
-    uw = Recmodel.embedding_user.weight.detach().numpy()
-    iw = Recmodel.embedding_item.weight.detach().numpy()
-    rows_u = np.sort(np.random.default_rng(1).choice(uw.shape[0], 256, replace=False))
-    rows_i = np.sort(np.random.default_rng(2).choice(iw.shape[0], 256, replace=False))
-    np.savez_compressed(os.path.join(GOLD, "dual_epinion2_epochs.npz"), seed=args.seed, n_steps=n_steps,
-                        trust_batch_size=trust_batch_size, steps_per_epoch=len(train_loader),
-                        **{k: np.asarray(v, np.float64) for k, v in out.items()}, task_weights=tw,
-                        rec_recall=ret["recall"], rec_ndcg=ret["ndcg"], trust=trust,
-                        rows_u=rows_u, rows_i=rows_i, user_w=uw[rows_u], item_w=iw[rows_i],
-                        user_w_colsum=uw.astype(np.float64).sum(0), item_w_colsum=iw.astype(np.float64).sum(0),
-                        w=Recmodel.w.detach().numpy(), att_exp1=Recmodel.att_exp1.detach().numpy(),
-                        att_t=Recmodel.att_t.detach().numpy())
-    print("dual epinion2: loss1", t1, "loss2", t2, "tw", tw, "rec", ret, "trust", trust)
+            if step < n_steps:
+                out["loss1_cum"].append(t1); out["loss2_cum"].append(t2)
+            full_cum1.append(full1); full_cum2.append(full2)
+            print("step", step + 1, "loss1", full1, "loss2", full2, "%.0f s" % (time.time() - t0), flush=True)
+    if full_epoch:
+        # G13 full epoch: running loss sums every 100 steps, the task weights, both tasks' metrics, and the state the epoch ends
+        # in (teacher forcing: probed with the epoch's first batch and first path selection, no optimizer step)
+        tw = Recmodel.task_weights.detach().numpy().copy()
+        ret, trust = evaluate()
+        optimizer.zero_grad()
+        fb, fp = first
+        loss1, loss2 = Recmodel(users=torch.from_numpy(fb[0]), items=torch.from_numpy(fb[1]), labels=torch.from_numpy(fb[2]),
+                                slice_indices=np.array(fp, dtype=int), trust_data=train_data2, flag=0)
+        T, n_rec, T_rec = len(fp), 5, fb.shape[1]
+        loss = torch.exp(-2 * Recmodel.task_weights[0]) * loss1 + torch.exp(-2 * Recmodel.task_weights[1]) * loss2 \
+            + 2 * (n_rec + 1) * T_rec * Recmodel.task_weights[0] + T * Recmodel.task_weights[1]
+        loss.backward()
+        ckpt.clear()
+        take_checkpoint("ckptend", fb, fp, loss1.item(), loss2.item())
+        np.savez_compressed(os.path.join(GOLD, "dual_epinion2_full_epoch.npz"), seed=args.seed, n_steps=step + 1,
+                            trust_batch_size=trust_batch_size, n_paths=np.asarray(out["n_paths"], np.int64),
+                            loss1_cum=np.asarray(full_cum1), loss2_cum=np.asarray(full_cum2), loss1=full1, loss2=full2,
+                            task_weights=tw, rec_recall=ret["recall"], rec_ndcg=ret["ndcg"], trust=trust, **ckpt)
+        print("dual epinion2 full epoch: loss1", full1, "loss2", full2, "tw", tw, "rec", ret, "trust", trust)
 
 
 # --------------------------------------------------------------------------- NGCF whole-run goldens (config 4)
@@ -1021,7 +1114,7 @@ def write_small_ngcf(rec_dir):
     return dict(train_pairs=pairs, test_pos=np.asarray(test_pos, np.int64), test_neg=np.stack(test_neg).astype(np.int64))
 
 
-def stage_ngcf_epochs(ds, n_epochs):
+def stage_ngcf_epochs(ds, n_epochs, ckpt_steps=()):
     """G12-NGCF: the reference's training run — NGCF_SPEX/code/main_rec.py:18-27,116-148 (setup_seed, the module-level
     Data singleton of utility/batch_test.py, Model_Wrapper, Adam, train(): load_train_data per epoch, shuffled
     DataLoader, loss.backward, step; test()) — driven from the reference's modules on CPU.
@@ -1037,7 +1130,7 @@ def stage_ngcf_epochs(ds, n_epochs):
     import numpy as np
     import torch
     install_shims()
-    torch.set_num_threads(8)
+    torch.set_num_threads(int(os.environ.get("SPEX_MINT_THREADS", "8")))
     code = os.path.join(SCRATCH, "NGCF_SPEX", "code")
     os.makedirs(code, exist_ok=True)
     os.chdir(code)
@@ -1122,6 +1215,32 @@ def stage_ngcf_epochs(ds, n_epochs):
             r = ref_bt.test(model, list(data_generator.test_set.keys()), drop_flag=True)
             eval_at[state["step"]] = np.concatenate([r["recall"], r["ndcg"]])
     maybe_eval()
+    ckpt = {}
+
+    def table_grad_summary(prefix, gnp, rng):
+        rows = np.sort(rng.choice(gnp.shape[0], 512, replace=False))
+        nz = np.flatnonzero(np.abs(gnp).sum(1) > 0)
+        rows = np.unique(np.concatenate([rows, nz[:256]]))
+        ckpt[prefix + "_rows"] = rows
+        ckpt[prefix] = gnp[rows].copy()
+        ckpt[prefix + "_colsum"] = gnp.astype(np.float64).sum(0)
+        ckpt[prefix + "_fro"] = np.sqrt((gnp.astype(np.float64) ** 2).sum())
+
+    def take_checkpoint(tag, batch, loss_value):
+        """Teacher forcing: the reference's FULL parameter state in front of a step, that step's batch and dropout step,
+        its loss and its gradients (model.parameters() hold them: called between loss.backward() and optimizer.step())."""
+        rng = np.random.default_rng(31)
+        ckpt[f"{tag}_drop_step"] = state["step"]
+        ckpt[f"{tag}_batch"] = batch
+        ckpt[f"{tag}_loss"] = np.float64(loss_value)
+        for name, p in model.named_parameters():
+            key = name.replace(".", "__")
+            ckpt[f"{tag}_state_{key}"] = p.detach().numpy().copy()
+            g = p.grad.numpy()
+            if g.shape[0] > 1024:
+                table_grad_summary(f"{tag}_grad_{key}", g, rng)
+            else:
+                ckpt[f"{tag}_grad_{key}"] = g.copy()
     for epoch in range(n_epochs):
         ref_ld.multiprocessing.Pool = SerialPool
         data_loader = data_generator.load_train_data()           # main_rec.py:121
@@ -1139,6 +1258,9 @@ def stage_ngcf_epochs(ds, n_epochs):
                 first_batch = np.stack([user.numpy(), item.numpy(), labels_list.numpy().astype(np.int64)])
             loss = model(user=user, item=item, labels_list=labels_list, flag=0)
             loss.backward(retain_graph=True)
+            if state["step"] in ckpt_steps:
+                take_checkpoint("ckpt%d" % state["step"],
+                                np.stack([user.numpy(), item.numpy(), labels_list.numpy().astype(np.int64)]), loss.item())
             optimizer.step()
             total_loss += loss.item()
             if state["step"] < 32:
@@ -1152,6 +1274,21 @@ def stage_ngcf_epochs(ds, n_epochs):
         ret = ref_bt.test(model, list(data_generator.test_set.keys()), drop_flag=True)   # :134-135
         recalls.append(ret["recall"]); ndcgs.append(ret["ndcg"])
         print("epoch", epoch, "loss", total_loss, ret, flush=True)
+    if ckpt_steps:
+        # the state the run ends in, probed with the run's first batch under the next step's dropout mask (no optimizer step)
+        model.train()
+        optimizer.zero_grad()
+        fb = [torch.from_numpy(first_batch[0]), torch.from_numpy(first_batch[1]), torch.from_numpy(first_batch[2]).float()]
+        loss = model(user=fb[0], item=fb[1], labels_list=fb[2], flag=0)
+        loss.backward()
+        take_checkpoint("ckptend", first_batch, loss.item())
+        optimizer.zero_grad()
+        model.eval()
+        np.savez_compressed(os.path.join(GOLD, f"ngcf_{ds}_ckpt.npz"), seed=2020, drop_seed=DROP_SEED, lr=margs.lr,
+                            mess_dropout=np.asarray(p_drop), n_steps=state["step"], ckpt_steps=np.asarray(sorted(ckpt_steps)),
+                            eval_steps=np.asarray([k for k, v in eval_at.items() if v is not None] + [state["step"]]),
+                            eval_metrics=np.asarray([v for v in eval_at.values() if v is not None]
+                                                    + [np.concatenate([recalls[-1], ndcgs[-1]])]), **ckpt)
     uw, iw = model.user_embedding.weight.detach().numpy(), model.item_embedding.weight.detach().numpy()
     if ds != "small":
         rows_u = np.sort(np.random.default_rng(1).choice(uw.shape[0], 256, replace=False))
@@ -1202,13 +1339,19 @@ def main():
     elif a.stage == "ngcf-epochs":
         stage_ngcf_epochs("small", 3)
     elif a.stage == "ngcf-epochs-epinion2":  # ~15 min of CPU: one full NGCF epoch (4.7 k steps) + test() through the reference
-        stage_ngcf_epochs("epinion2", 1)
+        stage_ngcf_epochs("epinion2", 1, ckpt_steps=(500, 1500))   # + teacher-forced checkpoints (ngcf_epinion2_ckpt.npz)
     elif a.stage == "trust-epinion2":
         stage_trust_epinion2()
     elif a.stage == "epochs-dual-epinion2":  # ~20 min of CPU: 600 dual-task steps + both evaluations through the reference
         stage_epochs_dual_epinion2()
+    elif a.stage == "epochs-dual-epinion2-full":  # ~2.5 h of CPU: the same run continued to the end of epoch 0 (4 906 steps)
+        stage_epochs_dual_epinion2(full_epoch=True)
     elif a.stage == "epochs-epinion2":      # ~25 min of CPU: one full Epinion2 epoch + test() through the reference
         stage_epochs("epinion2", 1)
+    elif a.stage == "epochs-dropout":       # G12-dropout on tiny: three epochs of main_rec.py --dropout 1 --keepprob 0.3
+        stage_epochs("tiny", 3, dropout=0.3)
+    elif a.stage == "epochs-dropout-epinion2":   # ~6 min of CPU: the first 300 steps of that run on Epinion2 + test()
+        stage_epochs("epinion2", 1, dropout=0.3, max_steps=300)
 
 
 if __name__ == "__main__":

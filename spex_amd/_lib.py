@@ -61,9 +61,16 @@ SIGNATURES = {
                                                     ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, c_i32, c_vp, c_vp, c_i32, c_i64,
                                                     c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "spex_gated_batch_fwd_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp, c_vp,
-                                                c_vp, c_i32, c_vp]),
-    "spex_lightgcn_batch_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp,
+                                                c_vp, c_vp, c_i32, c_vp]),
+    "spex_lightgcn_batch_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp,
                                                c_vp, c_i32, c_vp]),
+    "spex_lightgcn_batch_slots_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp,
+                                                     c_i32, c_vp]),
+    "spex_reduce_slots_f32": (ctypes.c_int, [c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_i32, c_vp, c_i32, c_f32, c_vp, c_i32, c_i32, c_vp]),
+    "spex_expert_gate_rows_bwd_parts": (c_i32, [c_i32]),
+    "spex_expert_gate_rows_bwd_det_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_i64, c_i64, c_i32,
+                                                         c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "spex_step_events_release": (ctypes.c_int, [c_vp, c_vp]),
     "spex_adam_step_sum_f32": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i64, c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_f32, c_f32, c_vp]),
     "spex_unique_rows_i32": (ctypes.c_int, [c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "spex_spmm_push_rows_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_f32, c_vp, c_i32, c_vp]),
@@ -106,7 +113,11 @@ class LightGCNStepDesc(ctypes.Structure):
     _fields_ = ([(n, c_vp) for n in ("graph", "graph_t", "E0", "m", "v", "light_out", "ws_fwd", "lo_batch", "g_out", "ws_bwd",
                                      "grad_E0", "grad_slots")]
                 + [(n, c_i32) for n in ("slot_capacity", "n_user_rows", "L", "d")]
-                + [(n, c_f32) for n in ("lr", "beta1", "beta2", "eps")] + [("t", c_i32)])
+                + [(n, c_f32) for n in ("lr", "beta1", "beta2", "eps")] + [("t", c_i32), ("flags", c_i32)])
+
+
+STEP_DETERMINISTIC = 1          # spex_hip.h: SPEX_STEP_DETERMINISTIC
+STEP_FIXED_TASK_WEIGHTS = 2     # spex_hip.h: SPEX_STEP_FIXED_TASK_WEIGHTS
 
 
 class NGCFStepDesc(ctypes.Structure):
@@ -115,7 +126,8 @@ class NGCFStepDesc(ctypes.Structure):
                                      "gW_parts", "grad")]
                 + [(n, c_i32) for n in ("slot_capacity", "n_user_rows", "pad_row")] + [("slope", c_f32), ("p_drop", c_f32)]
                 + [("seed", ctypes.c_uint64), ("dropout_step", c_i32), ("t", c_i32)]
-                + [(n, c_f32) for n in ("lr", "beta1", "beta2", "eps")] + [("side_stream", c_vp)])
+                + [(n, c_f32) for n in ("lr", "beta1", "beta2", "eps")]
+                + [(n, c_vp) for n in ("side_stream", "ev_fork", "ev_join", "graph_t", "g_side_dense", "g_ego_dense")] + [("flags", c_i32)])
 
 
 class DualTaskStepDesc(ctypes.Structure):
@@ -125,7 +137,14 @@ class DualTaskStepDesc(ctypes.Structure):
                                      "trust_ws", "dscore", "loss_b", "loss", "loss_acc", "precision")]
                 + [(n, c_i32) for n in ("slot_capacity", "path_capacity", "path_len", "n_user_rows", "L", "d", "n_heads", "hybrid",
                                         "n_rec")]
-                + [(n, c_f32) for n in ("lr", "beta1", "beta2", "eps")] + [("t", c_i32), ("side_stream", c_vp)])
+                + [(n, c_f32) for n in ("lr", "beta1", "beta2", "eps")] + [("t", c_i32)]
+                + [(n, c_vp) for n in ("side_stream", "ev_fork", "ev_join", "g_raw_slots", "att_parts", "loss_rows")] + [("flags", c_i32)])
+
+
+def release_step_events(desc):
+    """Destroy the fork / join events a two-stream step descriptor holds (spex_step_events_release); safe to call twice."""
+    if desc is not None and (desc.ev_fork or desc.ev_join):
+        call("spex_step_events_release", ctypes.byref(desc, type(desc).ev_fork.offset), ctypes.byref(desc, type(desc).ev_join.offset))
 
 
 _lib = None

@@ -14,9 +14,12 @@
 //        are added in segment order: bit-identical to spex_spmm_rowlist_f32 / the main kernel for rows of <= 1024 entries;
 //     2. light = (running sum + y) / (L + 1) for both rows -> LDS; every wave forms x = <light_u, light_i>, the sample's loss
 //        and both gradient rows g_u = dg * light_i, g_i = dg * light_u, dg = (sigmoid(x) - label) / B;
-//     3. push: out[col[e]] += val[e] * g / (L + 1) over the stored entries of both rows in A^T, runs of 16 entries numbered
-//        jointly and dealt over (part, wave) — their (col, val) pairs were requested before step 1 —, plus
-//        out[row] += g / (L + 1) and the dense d loss / d light rows (part 0 only).
+//     3. push: out[col[e]] += val[e] * g / (L + 1) over the stored entries of both rows OF A (A^T g in push form walks the rows
+//        of A: (A^T g)[c] = sum_r A[r, c] g[r]), runs of 16 entries numbered jointly and dealt over (part, wave) — their
+//        (col, val) pairs were requested before step 1 —, plus out[row] += g / (L + 1) and the dense d loss / d light rows
+//        (part 0 only).
+//   PUSH == false (spex_lightgcn_batch_slots_f32, the deterministic step): steps 1 and 2 only; the sample's two gradient rows
+//   leave with plain stores as grad_slots[b] (user side) and grad_slots[B + b] (item side) — no float atomics anywhere.
 //   Up to `parts` workgroups (SPEX_BATCH_PARTS, default 3) share a sample when its rows are long (more than
 //   SPEX_BATCH_RUNS_PER_PART = 16 runs per part) — each repeats the cheap, L2-resident forward, the parts of a shorter sample
 //   leave at once.  The longest sample's push sets the launch time, and the reference's training batches (a random observed pair
@@ -80,13 +83,17 @@ __device__ __forceinline__ float segment_sum(const int32_t *__restrict__ col, co
     return acc;
 }
 
+template <bool PUSH>
 __global__ __launch_bounds__(kWave *kWgWaves) void lightgcn_batch_kernel(
-    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
-    const int32_t *__restrict__ t_rowptr, const int32_t *__restrict__ t_col, const float *__restrict__ t_val, int n_rows,
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val, int n_rows,
     int n_user_rows, const float *__restrict__ X, const float *__restrict__ acc_in, float acc_div,
     const int64_t *__restrict__ users, const int64_t *__restrict__ items, const float *__restrict__ labels, int parts,
-    float grad_scale, float push_scale, float *loss_sum, float *__restrict__ loss_rows, float *g_out, float *G, int runs_per_part)
+    float grad_scale, float push_scale, float *loss_sum, float *__restrict__ loss_rows, float *g_out, float *G, int runs_per_part,
+    float *__restrict__ grad_slots, int B)
 {
+    // (the push walks the same rows of the same matrix as the forward: t_* are aliases kept for readability)
+    const int32_t *__restrict__ t_rowptr = rowptr, *__restrict__ t_col = col;
+    const float *__restrict__ t_val = val;
     __shared__ float s_part[2][kWgWaves][kWave];   // [row: user, item][virtual wave of the row-list kernel][column]
     __shared__ float s_light[2][kWave];
     const int lane = threadIdx.x & (kWave - 1);
@@ -96,6 +103,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void lightgcn_batch_kernel(
     const int64_t u64 = users[b], i64 = items[b];
     if (u64 < 0 || u64 >= n_user_rows || i64 < 0 || i64 + n_user_rows >= n_rows) {   // workgroup-uniform: never gather out of range
         if (loss_rows && part == 0 && threadIdx.x == 0) loss_rows[b] = 0.0f;
+        if (!PUSH && wave < 2) grad_slots[(size_t)(wave * B + b) * kWave + lane] = 0.0f;
         return;
     }
     const int row[2] = {(int)u64, (int)i64 + n_user_rows};
@@ -114,7 +122,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void lightgcn_batch_kernel(
     // waves) while the median sample is done in 2.4.  Only such samples are shared: part p of a sample stays if the sample has more
     // than runs_per_part * p runs — the others leave here, before the forward — and the active parts split the runs.
     const int want = (n_runs + runs_per_part - 1) / runs_per_part;
-    const int act = want < parts ? (want < 1 ? 1 : want) : parts;
+    const int act = !PUSH ? 1 : (want < parts ? (want < 1 ? 1 : want) : parts);
     if (part >= act) return;
     const int q_step = act * kWgWaves;
     int q = part * kWgWaves + wave;
@@ -140,7 +148,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void lightgcn_batch_kernel(
             }
         }
     };
-    load_runs(q);
+    if (PUSH) load_runs(q);
     STAMP(1);
     // ---- 1. last layer at both rows.  Row k's segments go to its virtual waves v = segment mod 16 as in the row-list kernel
     //         (one accumulator chain per virtual wave); the two rows' virtual waves are numbered jointly and dealt to the 16 waves.
@@ -180,9 +188,14 @@ __global__ __launch_bounds__(kWave *kWgWaves) void lightgcn_batch_kernel(
             if (loss_rows) loss_rows[b] = bce;
             else atomicAdd(loss_sum, bce);
         }
-        atomicAdd(g_out + (size_t)row[wave] * kWave + lane, g2[wave]);        // dense d loss / d light_out (rows may repeat in a batch)
-        atomicAdd(G + (size_t)row[wave] * kWave + lane, push_scale * g2[wave]);   // the `g` of (g + A^T g) / (L + 1)
+        if (!PUSH) {
+            grad_slots[(size_t)(wave * B + b) * kWave + lane] = g2[wave];     // per-sample rows; summed per table row in slot order later
+        } else {
+            atomicAdd(g_out + (size_t)row[wave] * kWave + lane, g2[wave]);        // dense d loss / d light_out (rows may repeat in a batch)
+            atomicAdd(G + (size_t)row[wave] * kWave + lane, push_scale * g2[wave]);   // the `g` of (g + A^T g) / (L + 1)
+        }
     }
+    if (!PUSH) return;
     // ---- 3. push over both rows' entries in A^T.  Lane 0 of every loaded run is read before the first atomic and the entry
     //         loop is a real loop (rows.hip explains why: one vmcnt for loads and atomics).
     float *out_l = G + lane;
@@ -225,7 +238,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void gated_batch_fwd_kernel(
     const float *__restrict__ X, const float *__restrict__ acc_in, float acc_div, const float *__restrict__ raw,
     const float *__restrict__ att_u, const float *__restrict__ att_i, const int64_t *__restrict__ users,
     const int64_t *__restrict__ items, const float *__restrict__ labels, int B, float grad_scale, float *loss_sum,
-    float *__restrict__ lo_batch, float *__restrict__ grad_slots)
+    float *__restrict__ lo_batch, float *__restrict__ grad_slots, float *__restrict__ loss_rows)
 {
     __shared__ float s_part[2][kWgWaves][kWave];
     __shared__ float s_mixed[2][kWave];
@@ -236,7 +249,10 @@ __global__ __launch_bounds__(kWave *kWgWaves) void gated_batch_fwd_kernel(
     const float y_lab = labels[b];
     if (u64 < 0 || u64 >= n_user_rows || i64 < 0 || i64 + n_user_rows >= n_rows) {   // workgroup-uniform: never gather out of range
         if (wave < 2) grad_slots[(size_t)(wave * B + b) * kWave + lane] = 0.0f;       // gated rows of 0: x = 0, no gradient
-        if (threadIdx.x == 0) atomicAdd(loss_sum, 0.693147180559945309f);             // (what the three launches did: BCE(0, y))
+        if (threadIdx.x == 0) {                                                        // (what the three launches did: BCE(0, y))
+            if (loss_rows) loss_rows[b] = 0.693147180559945309f;
+            else atomicAdd(loss_sum, 0.693147180559945309f);
+        }
         return;
     }
     const int row[2] = {(int)u64, (int)i64 + n_user_rows};
@@ -285,7 +301,11 @@ __global__ __launch_bounds__(kWave *kWgWaves) void gated_batch_fwd_kernel(
         const float x = wave_sum_f32(fmaf(mu, mi, 0.0f));
         const float dg = (sigmoid_f(x) - y_lab) * grad_scale;
         grad_slots[(size_t)(wave * B + b) * kWave + lane] = dg * (wave ? mu : mi);
-        if (wave == 0 && lane == 0) atomicAdd(loss_sum, fmaxf(x, 0.0f) - x * y_lab + log1pf(expf(-fabsf(x))));
+        if (wave == 0 && lane == 0) {
+            const float bce = fmaxf(x, 0.0f) - x * y_lab + log1pf(expf(-fabsf(x)));
+            if (loss_rows) loss_rows[b] = bce;            // deterministic step: summed in sample order afterwards
+            else atomicAdd(loss_sum, bce);
+        }
     }
 }
 
@@ -294,9 +314,10 @@ __global__ __launch_bounds__(kWave *kWgWaves) void gated_batch_fwd_kernel(
 extern "C" int spex_gated_batch_fwd_f32(const spex_graph_t *g, const float *X, const float *acc_in, float acc_div, const float *raw,
                                        const float *att_u, const float *att_i, const int64_t *users, const int64_t *items,
                                        const float *labels, int32_t B, int32_t n_user_rows, float grad_scale, float *loss_sum,
-                                       float *lo_batch, float *grad_slots, int32_t d, void *stream)
+                                       float *loss_per_sample, float *lo_batch, float *grad_slots, int32_t d, void *stream)
 {
-    SPEX_CHECK_ARG(g && X && acc_in && raw && att_u && att_i && users && items && labels && loss_sum && lo_batch && grad_slots,
+    SPEX_CHECK_ARG(g && X && acc_in && raw && att_u && att_i && users && items && labels && (loss_sum || loss_per_sample) && lo_batch
+                       && grad_slots,
                    "spex_gated_batch_fwd_f32: NULL argument");
     SPEX_CHECK_ARG(B >= 0 && n_user_rows >= 0 && n_user_rows <= g->n_rows && g->n_rows == g->n_cols,
                    "spex_gated_batch_fwd_f32: B=%d n_user_rows=%d on a %d x %d graph", B, n_user_rows, g->n_rows, g->n_cols);
@@ -308,7 +329,7 @@ extern "C" int spex_gated_batch_fwd_f32(const spex_graph_t *g, const float *X, c
     if (B == 0 || g->n_rows == 0) return SPEX_OK;
     hipLaunchKernelGGL(gated_batch_fwd_kernel, dim3((unsigned)B), dim3(kWave * kWgWaves), 0, (hipStream_t)stream, g->rowptr, g->col, g->val,
                        g->n_rows, n_user_rows, X, acc_in, acc_div, raw, att_u, att_i, users, items, labels, B, grad_scale, loss_sum, lo_batch,
-                       grad_slots);
+                       grad_slots, loss_per_sample);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }
@@ -322,16 +343,38 @@ extern "C" int spex_debug_batch_stamps(unsigned long long *out)
 }
 #endif
 
-extern "C" int spex_lightgcn_batch_f32(const spex_graph_t *g, const spex_graph_t *gt, const float *X, const float *acc_in, float acc_div,
+extern "C" int spex_lightgcn_batch_slots_f32(const spex_graph_t *g, const float *X, const float *acc_in, float acc_div,
+                                             const int64_t *users, const int64_t *items, const float *labels, int32_t B,
+                                             int32_t n_user_rows, float grad_scale, float *loss_sum, float *loss_per_sample,
+                                             float *grad_slots, int32_t d, void *stream)
+{
+    SPEX_CHECK_ARG(g && X && acc_in && users && items && labels && (loss_sum || loss_per_sample) && grad_slots,
+                   "spex_lightgcn_batch_slots_f32: NULL argument");
+    SPEX_CHECK_ARG(B >= 0 && n_user_rows >= 0 && n_user_rows <= g->n_rows, "spex_lightgcn_batch_slots_f32: B=%d n_user_rows=%d", B, n_user_rows);
+    SPEX_CHECK_ARG(g->n_rows == g->n_cols, "spex_lightgcn_batch_slots_f32: square graph");
+    SPEX_CHECK_ARG(g->mask_mode == 0, "spex_lightgcn_batch_slots_f32: edge dropout is not supported here");
+    if (d != kWave) {
+        spex::set_error("spex_lightgcn_batch_slots_f32: d == 64 only (got %d)", d);
+        return SPEX_ERR_UNSUPPORTED;
+    }
+    if (B == 0 || g->n_rows == 0) return SPEX_OK;
+    hipLaunchKernelGGL(lightgcn_batch_kernel<false>, dim3((unsigned)B), dim3(kWave * kWgWaves), 0, (hipStream_t)stream, g->rowptr, g->col,
+                       g->val, g->n_rows, n_user_rows, X, acc_in, acc_div, users, items, labels, 1, grad_scale, 0.0f, loss_sum,
+                       loss_per_sample, nullptr, nullptr, 1, grad_slots, B);
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}
+
+extern "C" int spex_lightgcn_batch_f32(const spex_graph_t *g, const float *X, const float *acc_in, float acc_div,
                                        const int64_t *users, const int64_t *items, const float *labels, int32_t B,
                                        int32_t n_user_rows, float grad_scale, float push_scale, float *loss_sum, float *loss_per_sample,
                                        float *g_out, float *G, int32_t d, void *stream)
 {
-    SPEX_CHECK_ARG(g && gt && X && acc_in && users && items && labels && (loss_sum || loss_per_sample) && g_out && G,
+    SPEX_CHECK_ARG(g && X && acc_in && users && items && labels && (loss_sum || loss_per_sample) && g_out && G,
                    "spex_lightgcn_batch_f32: NULL argument");
     SPEX_CHECK_ARG(B >= 0 && n_user_rows >= 0 && n_user_rows <= g->n_rows, "spex_lightgcn_batch_f32: B=%d n_user_rows=%d", B, n_user_rows);
-    SPEX_CHECK_ARG(g->n_rows == g->n_cols && gt->n_rows == g->n_rows && gt->n_cols == g->n_rows, "spex_lightgcn_batch_f32: square graphs of one size");
-    SPEX_CHECK_ARG(g->mask_mode == 0 && gt->mask_mode == 0, "spex_lightgcn_batch_f32: edge dropout is not supported here");
+    SPEX_CHECK_ARG(g->n_rows == g->n_cols, "spex_lightgcn_batch_f32: square graph");
+    SPEX_CHECK_ARG(g->mask_mode == 0, "spex_lightgcn_batch_f32: edge dropout is not supported here");
     if (d != kWave) {
         spex::set_error("spex_lightgcn_batch_f32: d == 64 only (got %d)", d);
         return SPEX_ERR_UNSUPPORTED;
@@ -347,9 +390,9 @@ extern "C" int spex_lightgcn_batch_f32(const spex_graph_t *g, const spex_graph_t
         const int p = e ? atoi(e) : 3;
         return p < 1 ? 1 : (p > 16 ? 16 : p);
     }();
-    hipLaunchKernelGGL(lightgcn_batch_kernel, dim3((unsigned)B * parts), dim3(kWave * kWgWaves), 0, (hipStream_t)stream, g->rowptr, g->col,
-                       g->val, gt->rowptr, gt->col, gt->val, g->n_rows, n_user_rows, X, acc_in, acc_div, users, items, labels, parts,
-                       grad_scale, push_scale, loss_sum, loss_per_sample, g_out, G, runs_per_part);
+    hipLaunchKernelGGL(lightgcn_batch_kernel<true>, dim3((unsigned)B * parts), dim3(kWave * kWgWaves), 0, (hipStream_t)stream, g->rowptr,
+                       g->col, g->val, g->n_rows, n_user_rows, X, acc_in, acc_div, users, items, labels, parts, grad_scale, push_scale,
+                       loss_sum, loss_per_sample, g_out, G, runs_per_part, nullptr, B);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }

@@ -22,7 +22,7 @@ void set_error(const char *fmt, ...)
 }
 }  // namespace spex
 
-extern "C" int spex_version(void) { return 3; }
+extern "C" int spex_version(void) { return 4; }
 extern "C" const char *spex_last_error(void) { return spex::g_err; }
 
 // Host-side packing runs on a few threads: SPEX_BUILD_THREADS, default min(16, hardware threads); small inputs stay on

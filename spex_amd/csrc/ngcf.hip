@@ -1277,11 +1277,15 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void expert_gate_rows_kernel
 // simply handled once per slot): g_slots[k] = d loss / d mixed_c[k] ->
 //   d_prop_c[k] (compact, the push-form A^T product reads it), and with atomics g_prop[r] += d prop, g_raw[r] += d raw (dense
 //   tables, zeroed by the caller), g_att_u / g_att_i += the two gate matrices' gradients (register accumulators per wave).
+// DET (spex_expert_gate_rows_bwd_det_f32, the deterministic step): no atomics at all — d raw leaves as a compact per-slot row
+// too (d_raw_c; both are summed per table row in slot order by spex_reduce_slots_f32) and the workgroup's share of the two gate
+// gradients goes to its own block of att_parts ([gridDim.x][512], summed in block order afterwards).
+template <bool DET>
 __global__ __launch_bounds__(kWave *kGateWaves) void expert_gate_rows_bwd_kernel(
     const float *__restrict__ raw, const float *__restrict__ prop, const float *__restrict__ att_u, const float *__restrict__ att_i,
     const int64_t *__restrict__ idx_a, int n_a, int64_t off_a, const int64_t *__restrict__ idx_b, int n_b, int64_t off_b,
     int64_t n_user_rows, int64_t n_rows, const float *__restrict__ g_slots, int ld_g, float *__restrict__ d_prop_c, float *g_prop,
-    float *g_raw, float *g_att_u, float *g_att_i)
+    float *g_raw, float *g_att_u, float *g_att_i, float *__restrict__ d_raw_c, float *__restrict__ att_parts)
 {
     __shared__ float s_att[kGateWaves][2][256];    // one slot per wave, summed after the barrier (LDS float atomics from 16 waves
                                                    // onto the same 512 words serialise in the LDS unit: 12 us for 128 instructions)
@@ -1292,6 +1296,7 @@ __global__ __launch_bounds__(kWave *kGateWaves) void expert_gate_rows_bwd_kernel
         const long long r = batch_row(idx_a, n_a, off_a, idx_b, off_b, slot);
         if (r < 0 || r >= n_rows) {
             d_prop_c[(size_t)slot * 64 + lane] = 0.0f;
+            if (DET) d_raw_c[(size_t)slot * 64 + lane] = 0.0f;
             continue;
         }
         const int which = r < n_user_rows ? 0 : 1;
@@ -1308,8 +1313,12 @@ __global__ __launch_bounds__(kWave *kGateWaves) void expert_gate_rows_bwd_kernel
         const float dz0 = a0 * (da0 - dot), dz1 = a1 * (da1 - dot);
         const float d_raw = a0 * gg + dz0 * w00 + dz1 * w01, d_prop = a1 * gg + dz0 * w10 + dz1 * w11;
         d_prop_c[(size_t)slot * 64 + lane] = d_prop;
-        atomicAdd(g_prop + (size_t)r * 64 + lane, d_prop);
-        atomicAdd(g_raw + (size_t)r * 64 + lane, d_raw);
+        if (DET) {
+            d_raw_c[(size_t)slot * 64 + lane] = d_raw;
+        } else {
+            atomicAdd(g_prop + (size_t)r * 64 + lane, d_prop);
+            atomicAdd(g_raw + (size_t)r * 64 + lane, d_raw);
+        }
         acc[which][0] = fmaf(a, dz0, acc[which][0]);
         acc[which][1] = fmaf(a, dz1, acc[which][1]);
         acc[which][2] = fmaf(b, dz0, acc[which][2]);
@@ -1327,7 +1336,8 @@ __global__ __launch_bounds__(kWave *kGateWaves) void expert_gate_rows_bwd_kernel
         const int w = k >> 8, j = k & 255;
         float sum = 0.0f;
         for (int v = 0; v < kGateWaves; ++v) sum += s_att[v][w][j];
-        if (sum != 0.0f) atomicAdd((w ? g_att_i : g_att_u) + j, sum);
+        if (DET) att_parts[(size_t)blockIdx.x * 512 + k] = sum;
+        else if (sum != 0.0f) atomicAdd((w ? g_att_i : g_att_u) + j, sum);
     }
 }
 
@@ -1575,9 +1585,38 @@ extern "C" int spex_expert_gate_rows_bwd_f32(const float *raw, const float *prop
     if (n == 0) return SPEX_OK;
     int blocks = (n + kGateWaves - 1) / kGateWaves;
     if (blocks > 64) blocks = 64;
-    hipLaunchKernelGGL(expert_gate_rows_bwd_kernel, dim3((unsigned)blocks), dim3(kWave * kGateWaves), 0, (hipStream_t)stream, raw, prop, att_u,
-                       att_i, idx_a, n_a, off_a, idx_b, n_b, off_b, n_user_rows, n_rows, grad_slots, ld_slots, grad_prop_slots, grad_prop,
-                       grad_raw, grad_att_u, grad_att_i);
+    hipLaunchKernelGGL(expert_gate_rows_bwd_kernel<false>, dim3((unsigned)blocks), dim3(kWave * kGateWaves), 0, (hipStream_t)stream, raw, prop,
+                       att_u, att_i, idx_a, n_a, off_a, idx_b, n_b, off_b, n_user_rows, n_rows, grad_slots, ld_slots, grad_prop_slots,
+                       grad_prop, grad_raw, grad_att_u, grad_att_i, nullptr, nullptr);
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}
+
+extern "C" int32_t spex_expert_gate_rows_bwd_parts(int32_t n_slots)
+{
+    const int blocks = (n_slots + kGateWaves - 1) / kGateWaves;
+    return blocks > 64 ? 64 : (blocks < 1 ? 1 : blocks);
+}
+
+extern "C" int spex_expert_gate_rows_bwd_det_f32(const float *raw, const float *prop, const float *att_u, const float *att_i,
+                                                 const int64_t *idx_a, int32_t n_a, int64_t off_a, const int64_t *idx_b, int32_t n_b,
+                                                 int64_t off_b, int64_t n_user_rows, int64_t n_rows, int32_t d, const float *grad_slots,
+                                                 int32_t ld_slots, float *grad_prop_slots, float *grad_raw_slots, float *att_parts,
+                                                 void *stream)
+{
+    SPEX_CHECK_ARG(raw && prop && att_u && att_i && grad_slots && grad_prop_slots && grad_raw_slots && att_parts
+                       && (idx_a || n_a == 0) && (idx_b || n_b == 0),
+                   "spex_expert_gate_rows_bwd_det_f32: NULL pointer");
+    SPEX_CHECK_ARG(n_a >= 0 && n_b >= 0 && n_rows >= 0 && ld_slots >= 64, "spex_expert_gate_rows_bwd_det_f32: bad size");
+    if (d != 64) {
+        spex::set_error("spex_expert_gate_rows_bwd_det_f32: d = %d (the row form needs d == 64)", d);
+        return SPEX_ERR_UNSUPPORTED;
+    }
+    const int n = n_a + n_b;
+    if (n == 0) return SPEX_OK;
+    hipLaunchKernelGGL(expert_gate_rows_bwd_kernel<true>, dim3((unsigned)spex_expert_gate_rows_bwd_parts(n)), dim3(kWave * kGateWaves), 0,
+                       (hipStream_t)stream, raw, prop, att_u, att_i, idx_a, n_a, off_a, idx_b, n_b, off_b, n_user_rows, n_rows, grad_slots,
+                       ld_slots, grad_prop_slots, nullptr, nullptr, nullptr, nullptr, grad_raw_slots, att_parts);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }

@@ -153,13 +153,15 @@ struct DualAdamArgs {
     float *g_raw_w, *g_user, *g_small, *g_prop, *push_zero;     // cleared as they are read (push_zero may be NULL)
     float *loss, *loss_acc, *prec;
     int64_t n_table, n_user, n_trust, n_total;     // floats: table, user rows of it, trust block, whole arena (excl. padding)
-    int32_t B, T, n_rec, slot;
+    int32_t B, T, n_rec, slot, fixed;
     float w1, beta2, w2, bc2_sqrt, eps, step_size;
 };
 
 __global__ __launch_bounds__(256) void dual_task_adam_kernel(const DualAdamArgs a)
 {
-    const float p1 = a.prec[a.slot * 2], p2 = a.prec[a.slot * 2 + 1];
+    // fixed: loss = loss1 + loss2 (main_11.py:69) — both precisions 1; the task weights get no gradient (torch's Adam skips a
+    // parameter whose .grad is None: value and moments stay as they are)
+    const float p1 = a.fixed ? 1.0f : a.prec[a.slot * 2], p2 = a.fixed ? 1.0f : a.prec[a.slot * 2 + 1];
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t n_gate_end = a.n_table + a.n_trust + 512;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_gate_end; i += stride) {
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(256) void dual_task_adam_kernel(const DualAdamArgs 
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const float loss1 = a.loss[0] / (float)a.B, loss2 = a.loss[1];
         const float g[2] = {-2.0f * p1 * loss1 + 2.0f * (float)(a.n_rec + 1) * (float)a.B, -2.0f * p2 * loss2 + (float)a.T};
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < 2 && !a.fixed; ++k) {
             const int64_t i = n_gate_end + k;
             float P = a.p[i], M = a.m[i], V = a.v[i];
             adam1(P, g[k], M, V, a.w1, a.beta2, a.w2, a.bc2_sqrt, a.eps, a.step_size);
@@ -203,11 +205,12 @@ __global__ __launch_bounds__(256) void dual_task_adam_kernel(const DualAdamArgs 
 int spex::dual_task_adam(float *p, float *m, float *v, const float *g_E0, float *g_raw, float *g_user, float *g_small,
                          float *g_prop, float *push_zero, float *loss, float *loss_acc, float *prec, int64_t n_table, int64_t n_user,
                          int64_t n_trust,
-                         int32_t B, int32_t T, int32_t n_rec, int32_t t, float lr, float beta1, float beta2, float eps, void *stream)
+                         int32_t B, int32_t T, int32_t n_rec, int32_t t, float lr, float beta1, float beta2, float eps, int fixed_weights,
+                         void *stream)
 {
     const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
     const DualAdamArgs a{p, m, v, g_E0, g_raw, g_raw, g_user, g_small, g_prop, push_zero, loss, loss_acc, prec, n_table, n_user, n_trust,
-                         n_table + n_trust + 512 + 2, B, T, n_rec, t & 1, 1.0f - beta1, beta2, 1.0f - beta2, (float)sqrt(bc2), eps,
+                         n_table + n_trust + 512 + 2, B, T, n_rec, t & 1, fixed_weights, 1.0f - beta1, beta2, 1.0f - beta2, (float)sqrt(bc2), eps,
                          (float)((double)lr / bc1)};
     int64_t blocks = (n_table + n_trust + 512 + 255) / 256;
     if (blocks > 2048) blocks = 2048;

@@ -138,7 +138,108 @@ __global__ __launch_bounds__(kWave *kPushWaves) void spmm_push_batch_kernel(
     if (add && part == 0 && wave == 0) atomicAdd(out + (size_t)r * kWave + lane, scale * add[(size_t)k * ld_add + lane]);
 }
 
+// Deterministic accumulation of a batch's per-slot rows into a dense table — the atomic-free alternative to the float
+// atomics above (SPEX_STEP_DETERMINISTIC).  out[r] = scale * (slots[k1] + slots[k2] + ...) over the slots k1 < k2 < ... that
+// name row r, in ASCENDING slot order — the order in which the reference's CPU index backward (index_put_ with accumulate,
+// LightGCN_SPEX/code/utility1/model.py:115-116 under autograd) adds them, so results repeat bit for bit from run to run.
+// One wave per slot: it scans the batch's row list (64 slots per load), leaves if a lower-numbered slot names the same row,
+// otherwise adds the later duplicates in order and writes the row with a plain store (mode 0) or a plain read-modify-write
+// (mode 1: the wave owns the row in this launch).  The scan is quadratic in the batch (n^2 * 8 B of L2 reads: 2 MB for the
+// reference's 2 x 256 slots), which is what a validation mode can afford; slots == NULL clears the named rows instead.
+constexpr int kReduceWaves = 4;
+
+__global__ __launch_bounds__(kWave *kReduceWaves) void reduce_slots_kernel(
+    const int64_t *__restrict__ idx_a, int n_a, int64_t off_a, const int64_t *__restrict__ idx_b, int n_b, int64_t off_b,
+    int n_rows, const float *__restrict__ slots, int ld_slots, float scale, float *out, int mode)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int k = blockIdx.x * kReduceWaves + (threadIdx.x >> 6);
+    const int n = n_a + n_b;
+    if (k >= n) return;
+    const long long r = batch_row(idx_a, n_a, off_a, idx_b, off_b, k);
+    if (r < 0 || r >= n_rows) return;
+    if (!slots) {                                              // clear form: every slot zeroes its row (idempotent)
+        out[(size_t)r * kWave + lane] = 0.0f;
+        return;
+    }
+    for (int base = 0; base < k; base += kWave) {              // a lower-numbered slot with this row owns it
+        const int kk = base + lane;
+        const bool match = kk < k && batch_row(idx_a, n_a, off_a, idx_b, off_b, kk) == r;
+        if (__ballot(match)) return;
+    }
+    float acc = slots[(size_t)k * ld_slots + lane];
+    for (int base = k & ~(kWave - 1); base < n; base += kWave) {
+        const int kk = base + lane;
+        const bool match = kk > k && kk < n && batch_row(idx_a, n_a, off_a, idx_b, off_b, kk) == r;
+        unsigned long long m = __ballot(match);
+        while (m) {                                            // ascending slot order
+            const int j = (int)__builtin_ctzll(m);
+            m &= m - 1;
+            acc = acc + slots[(size_t)(base + j) * ld_slots + lane];
+        }
+    }
+    if (scale != 1.0f) acc = acc * scale;
+    float *o = out + (size_t)r * kWave + lane;
+    *o = mode == 1 ? *o + acc : acc;
+}
+
+// out[0] (+)= x[0] + x[1] + ... + x[n - 1], added in index order by one thread-free wave pattern: lane j sums x[j], x[j + 64], ...
+// and the 64 partials are combined by the fixed DPP tree — the same order adam_kernel uses for a step's per-sample losses.
+__global__ __launch_bounds__(kWave) void sum_ordered_kernel(const float *__restrict__ x, int n, float scale, float *out, int accumulate)
+{
+    float t = 0.0f;
+    for (int i = threadIdx.x; i < n; i += kWave) t += x[i];
+    t = wave_sum_f32(t);
+    if (threadIdx.x == 0) *out = accumulate ? *out + t * scale : t * scale;
+}
+
+// Sum of n_parts partial blocks of n floats, in part order (deterministic): out[i] (+)= sum_k parts[k][i].
+__global__ __launch_bounds__(256) void sum_parts_kernel(const float *__restrict__ parts, int n_parts, int64_t stride, int n, float *out,
+                                                        int accumulate)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float g = 0.0f;
+    for (int k = 0; k < n_parts; ++k) g += parts[(size_t)k * stride + i];
+    out[i] = accumulate ? out[i] + g : g;
+}
+
 }  // namespace
+
+extern "C" int spex_reduce_slots_f32(const int64_t *idx_a, int32_t n_a, int64_t off_a, const int64_t *idx_b, int32_t n_b, int64_t off_b,
+                                     int32_t n_rows, const float *slots, int32_t ld_slots, float scale, float *out, int32_t mode,
+                                     int32_t d, void *stream)
+{
+    SPEX_CHECK_ARG(n_a >= 0 && n_b >= 0 && (n_a == 0 || idx_a) && (n_b == 0 || idx_b), "spex_reduce_slots_f32: bad index lists");
+    SPEX_CHECK_ARG(out && n_rows >= 0 && (mode == 0 || mode == 1) && (!slots || ld_slots >= d), "spex_reduce_slots_f32: out=%p mode=%d ld=%d",
+                   (void *)out, mode, ld_slots);
+    if (d != kWave) {
+        spex::set_error("spex_reduce_slots_f32: d == 64 only (got %d)", d);
+        return SPEX_ERR_UNSUPPORTED;
+    }
+    const int n = n_a + n_b;
+    if (n == 0 || n_rows == 0) return SPEX_OK;
+    hipLaunchKernelGGL(reduce_slots_kernel, dim3((unsigned)((n + kReduceWaves - 1) / kReduceWaves)), dim3(kWave * kReduceWaves), 0,
+                       (hipStream_t)stream, idx_a, n_a, off_a, idx_b, n_b, off_b, n_rows, slots, ld_slots, scale, out, mode);
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}
+
+int spex::sum_ordered(const float *x, int32_t n, float scale, float *out, int accumulate, void *stream)
+{
+    hipLaunchKernelGGL(sum_ordered_kernel, dim3(1), dim3(kWave), 0, (hipStream_t)stream, x, n, scale, out, accumulate);
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}
+
+int spex::sum_parts(const float *parts, int32_t n_parts, int64_t stride, int32_t n, float *out, int accumulate, void *stream)
+{
+    if (n <= 0) return SPEX_OK;
+    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, parts, n_parts, stride, n, out,
+                       accumulate);
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}
 
 extern "C" int spex_unique_rows_i32(const int64_t *idx_a, int32_t n_a, int64_t off_a, const int64_t *idx_b, int32_t n_b,
                                     int64_t off_b, int32_t n_rows, int32_t *stamp, int32_t epoch, int32_t *list, int32_t *count,

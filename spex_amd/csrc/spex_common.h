@@ -17,8 +17,12 @@ int adam_step_z2(float *p, const float *g, float *m, float *v, int64_t n, int32_
 
 int dual_task_adam(float *p, float *m, float *v, const float *g_E0, float *g_raw, float *g_user, float *g_small, float *g_prop,
                    float *push_zero, float *loss, float *loss_acc, float *prec, int64_t n_table, int64_t n_user, int64_t n_trust,
-                   int32_t B, int32_t T, int32_t n_rec, int32_t t, float lr, float beta1, float beta2, float eps,
+                   int32_t B, int32_t T, int32_t n_rec, int32_t t, float lr, float beta1, float beta2, float eps, int fixed_weights,
                    void *stream);   // optim.hip: Adam over the dual-task parameter arena (spex_dual_task_step_f32)
+
+int sum_ordered(const float *x, int32_t n, float scale, float *out, int accumulate, void *stream);     // rows.hip: fixed-order sum
+int sum_parts(const float *parts, int32_t n_parts, int64_t stride, int32_t n, float *out, int accumulate,
+              void *stream);                                                                        // rows.hip: partial blocks, in order
 
 #define SPEX_CHECK_ARG(cond, ...)             \
     do {                                      \

@@ -290,8 +290,10 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_rows_narrow_kernel
 
 // Edge dropout (MASKED): lane k decides for its own entry (injected mask byte or Philox draw keyed by the entry's edge
 // id, so forward / backward / every layer of a step agree); a dropped entry keeps its slot with value 0 and the
-// source row of the super-chunk's first kept entry (already being fetched), i.e. it adds +0 and costs no extra traffic.
-// (Unlike the reference, a dropped entry whose stand-in source row holds Inf/NaN contributes 0 * Inf = NaN.)
+// source row of the super-chunk's first kept entry (already being fetched), so it costs no extra traffic — and its
+// gathered value is REPLACED by 0 before the fmaf (a wave-uniform select per entry), so that it contributes exactly
+// nothing, as in the reference, where the entry is gone from the matrix: multiplying instead would turn a stand-in row
+// holding Inf / NaN (a diverged table) into 0 * Inf = NaN on a row that never referenced it.
 struct DropArgs {
     const uint32_t *chunk_eid;
     const uint8_t *keep;
@@ -353,6 +355,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
     for (int sc = 0; sc < t.y; sc += 4) {
         const int nc = (t.y - sc < 4) ? t.y - sc : 4;  // chunks in this super-chunk (wave-uniform)
         uint32_t my_off = 0u, my_mask = 0u, own_off = 0u;
+        unsigned long long drop_bits = 0ull;                 // MASKED: entries of this super-chunk that are dropped (wave-uniform)
         int my_row = 0;
         float my_val = 0.0f;
         if (lane < nc * kChunk) {
@@ -378,6 +381,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
             // a dropped entry re-reads the source row of the first KEPT entry of this super-chunk (fetched anyway, so
             // it adds +0 and no traffic); if every entry was dropped each keeps its own row (value 0)
             const bool dropped = my_off == 0xFFFFFFFFu;      // (lanes past the super-chunk hold 0: neither kept nor dropped)
+            drop_bits = __ballot(dropped);
             const unsigned long long kept_lanes = __ballot(!dropped && lane < nc * kChunk);
             const int src = kept_lanes ? (int)__builtin_ctzll(kept_lanes) : 0;
             const uint32_t stand_in = (uint32_t)__builtin_amdgcn_readlane((int)my_off, src);   // wave-uniform
@@ -386,6 +390,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
         if (lane < nc) my_mask = __builtin_nontemporal_load(chunk_mask + t.x + sc + lane);
         for (int c = 0; c < nc; ++c) {
             const uint32_t mask = (uint32_t)__builtin_amdgcn_readlane((int)my_mask, c);
+            const uint32_t dbits = MASKED ? (uint32_t)(drop_bits >> (c * kChunk)) & 0xFFFFu : 0u;
             float x[kChunk], ep[kChunk];
 #pragma unroll
             for (int u = 0; u < kChunk; ++u)
@@ -412,7 +417,8 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
             if (EPI != 0) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0); expcnt / lgkmcnt unconstrained
 #pragma unroll
             for (int u = 0; u < kChunk; ++u) {
-                acc = fmaf(lane_bcast(my_val, c * kChunk + u), x[u], acc);
+                const float xv = (MASKED && (dbits & (1u << u))) ? 0.0f : x[u];     // a dropped entry contributes nothing
+                acc = fmaf(lane_bcast(my_val, c * kChunk + u), xv, acc);
                 if (mask & (1u << u)) {  // only packs of whole rows carry mask bits
                     emit(ROWIDS ? __builtin_amdgcn_readlane(my_row, c * kChunk + u) : row, acc, ep[u]);
                     acc = 0.0f;
@@ -506,6 +512,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_wide_kernel(
     for (int sc = 0; sc < t.y; sc += 4) {
         const int nc = (t.y - sc < 4) ? t.y - sc : 4;  // chunks in this super-chunk (wave-uniform)
         uint32_t my_off = 0u, my_mask = 0u, own_off = 0u;
+        unsigned long long drop_bits = 0ull;                 // MASKED: entries of this super-chunk that are dropped (wave-uniform)
         int my_row = 0;
         float my_val = 0.0f;
         if (lane < nc * kChunk) {
@@ -531,6 +538,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_wide_kernel(
             // a dropped entry re-reads the source row of the first KEPT entry of this super-chunk (fetched anyway, so
             // it adds +0 and no traffic); if every entry was dropped each keeps its own row (value 0)
             const bool dropped = my_off == 0xFFFFFFFFu;      // (lanes past the super-chunk hold 0: neither kept nor dropped)
+            drop_bits = __ballot(dropped);
             const unsigned long long kept_lanes = __ballot(!dropped && lane < nc * kChunk);
             const int src = kept_lanes ? (int)__builtin_ctzll(kept_lanes) : 0;
             const uint32_t stand_in = (uint32_t)__builtin_amdgcn_readlane((int)my_off, src);   // wave-uniform
@@ -539,6 +547,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_wide_kernel(
         if (lane < nc) my_mask = __builtin_nontemporal_load(chunk_mask + t.x + sc + lane);
         for (int c = 0; c < nc; ++c) {
             const uint32_t mask = (uint32_t)__builtin_amdgcn_readlane((int)my_mask, c);
+            const uint32_t dbits = MASKED ? (uint32_t)(drop_bits >> (c * kChunk)) & 0xFFFFu : 0u;
 #pragma unroll
             for (int u0 = 0; u0 < kChunk; u0 += kBatch) {
                 vec x[kBatch], ep[kBatch];
@@ -565,8 +574,9 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_wide_kernel(
 #pragma unroll
                 for (int u = 0; u < kBatch; ++u) {
                     const float a = lane_bcast(my_val, c * kChunk + u0 + u);
+                    const bool gone = MASKED && (dbits & (1u << (u0 + u)));          // a dropped entry contributes nothing
 #pragma unroll
-                    for (int j = 0; j < V; ++j) acc[j] = fmaf(a, x[u][j], acc[j]);
+                    for (int j = 0; j < V; ++j) acc[j] = fmaf(a, gone ? 0.0f : x[u][j], acc[j]);
                     if (bmask & (1u << u)) {  // only packs of whole rows carry mask bits
                         emit(ROWIDS ? __builtin_amdgcn_readlane(my_row, c * kChunk + u0 + u) : row, acc, ep[u]);
                         acc = (vec)(0.0f);

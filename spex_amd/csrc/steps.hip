@@ -31,6 +31,7 @@ extern "C" int spex_lightgcn_step_bce_f32(spex_lightgcn_step_t *s, const int64_t
     SPEX_CHECK_ARG(s->slot_capacity >= 2 * B, "spex_lightgcn_step_bce_f32: slot capacity %d < 2 B = %d", s->slot_capacity, 2 * B);
     SPEX_CHECK_ARG(g->mask_mode == 0 && gt->mask_mode == 0, "spex_lightgcn_step_bce_f32: edge dropout is not supported in the one-call step");
     const size_t sz = (size_t)g->n_rows * d;
+    const bool det = (s->flags & SPEX_STEP_DETERMINISTIC) != 0;
     // ---- forward: layers 0 .. L-2 over the whole graph (running layer sum fused); the last layer is taken at the batch's rows only
     const float *cur = s->E0;
     for (int32_t l = 0; l + 1 < L; ++l) {
@@ -38,12 +39,28 @@ extern "C" int spex_lightgcn_step_bce_f32(spex_lightgcn_step_t *s, const int64_t
         SPEX_TRY(spex_spmm_f32(g, cur, nxt, nullptr, 1.0f, l == 0 ? s->E0 : s->light_out, s->light_out, 1.0f, d, stream));
         cur = nxt;
     }
+    if (det) {
+        // ---- SPEX_STEP_DETERMINISTIC: the same forward (same kernel code for the batch's rows: bit-identical scores), but every sum
+        //      that the fast path leaves to float atomics is taken in a fixed order — the sample's two gradient rows leave as
+        //      per-sample slots, are added per table row in ascending slot order (what the reference's CPU index backward does,
+        //      model.py:115-116), and the whole backward runs in pull form (each output row one chain in ascending column order,
+        //      like the reference's sparse addmm).  Per-sample losses: head of lo_batch, summed in order by the Adam pass.
+        float *loss_rows = s->lo_batch;
+        SPEX_TRY(spex_lightgcn_batch_slots_f32(g, cur, L == 1 ? s->E0 : s->light_out, (float)(L + 1), users, items, labels, B, n_u,
+                                               1.0f / (float)B, nullptr, loss_rows, s->grad_slots, d, stream));
+        SPEX_TRY(spex_reduce_slots_f32(users, B, 0, items, B, n_u, g->n_rows, s->grad_slots, d, 1.0f, s->g_out, 0, d, stream));
+        SPEX_TRY(spex_propagate_bwd_f32(gt, s->g_out, s->grad_E0, s->ws_bwd, L, d, stream));
+        SPEX_TRY(spex::adam_step_z2(s->E0, s->grad_E0, s->m, s->v, (int64_t)sz, s->t + 1, s->lr, s->beta1, s->beta2, s->eps, s->g_out,
+                                    s->ws_bwd /* keeps the fast path's push target all-zero */, stream, loss_rows, B, loss_sum));
+        s->t += 1;
+        return SPEX_OK;
+    }
     if (L >= 2) {
         // ---- the batch-sized middle as one launch: last layer + layer mean at the batch's rows, scores + BCE, gradient rows, and the
-        //      first backward product G_{L-1} = (g + A^T g) / (L+1) in push form (g_out and G are all-zero here: the Adam pass below
-        //      clears them for the next step; first call: the caller)
+        //      first backward product G_{L-1} = (g + A^T g) / (L+1) in push form — over the rows of A itself: (A^T g)[c] = sum_r
+        //      A[r, c] g[r] — (g_out and G are all-zero here: the Adam pass below clears them for the next step; first call: the caller)
         float *G = s->ws_bwd;
-        SPEX_TRY(spex_lightgcn_batch_f32(g, gt, cur, s->light_out, (float)(L + 1), users, items, labels, B, n_u, 1.0f / (float)B,
+        SPEX_TRY(spex_lightgcn_batch_f32(g, cur, s->light_out, (float)(L + 1), users, items, labels, B, n_u, 1.0f / (float)B,
                                          1.0f / (float)(L + 1), nullptr, s->grad_slots /* per-sample losses, summed by the Adam pass */,
                                          s->g_out, G, d, stream));
         // ---- L-1 pull-form products
@@ -59,32 +76,44 @@ extern "C" int spex_lightgcn_step_bce_f32(spex_lightgcn_step_t *s, const int64_t
                                           loss_sum, s->g_out, s->g_out + (size_t)n_u * d, 1.0f / (float)B, s->grad_slots, d, stream));
         SPEX_TRY(spex_propagate_bwd_f32(gt, s->g_out, s->grad_E0, s->ws_bwd, L, d, stream));
     }
-    // ---- Adam over the whole table (also clears g_out for the next step)
-    s->t += 1;
-    SPEX_TRY(spex::adam_step_z2(s->E0, s->grad_E0, s->m, s->v, (int64_t)sz, s->t, s->lr, s->beta1, s->beta2, s->eps, s->g_out,
+    // ---- Adam over the whole table (also clears g_out for the next step); t is advanced only once every launch is queued
+    SPEX_TRY(spex::adam_step_z2(s->E0, s->grad_E0, s->m, s->v, (int64_t)sz, s->t + 1, s->lr, s->beta1, s->beta2, s->eps, s->g_out,
                                 L >= 2 ? s->ws_bwd : nullptr, stream, L >= 2 ? s->grad_slots : nullptr, B, loss_sum));
+    s->t += 1;
     return SPEX_OK;
 }
 
-// Fork / join events of the two-stream steps (dual-task, NGCF): one pair per device, created on first use, never destroyed (they
-// outlive every step in flight; a process holds at most a handful).
-static int step_events(hipEvent_t *fork_ev, hipEvent_t *join_ev)
+// Fork / join events of the two-stream steps (dual-task, NGCF): one pair PER STEP DESCRIPTOR, created on first use and kept in
+// the descriptor's ev_fork / ev_join cells (zero-initialised by the caller, released with spex_step_events_release).  A pair
+// shared per device — the first version — could be re-recorded by a second stepper driven from another host thread between
+// this stepper's record and its wait, so that a join waited for the wrong stream's work.
+static int step_events(void **ev_fork, void **ev_join, hipEvent_t *fork_ev, hipEvent_t *join_ev)
 {
-    constexpr int kMaxDev = 64;
-    static hipEvent_t ev[kMaxDev][2];
-    static bool made[kMaxDev];
-    static std::mutex mu;                          // first use from several host threads
-    std::lock_guard<std::mutex> lock(mu);
-    int dev = 0;
-    SPEX_HIP(hipGetDevice(&dev));
-    SPEX_CHECK_ARG(dev >= 0 && dev < kMaxDev, "two-stream step: device %d", dev);
-    if (!made[dev]) {
-        SPEX_HIP(hipEventCreateWithFlags(&ev[dev][0], hipEventDisableTiming));
-        SPEX_HIP(hipEventCreateWithFlags(&ev[dev][1], hipEventDisableTiming));
-        made[dev] = true;
+    if (!*ev_fork) {
+        hipEvent_t e = nullptr;
+        SPEX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        *ev_fork = e;
     }
-    *fork_ev = ev[dev][0];
-    *join_ev = ev[dev][1];
+    if (!*ev_join) {
+        hipEvent_t e = nullptr;
+        SPEX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        *ev_join = e;
+    }
+    *fork_ev = (hipEvent_t)*ev_fork;
+    *join_ev = (hipEvent_t)*ev_join;
+    return SPEX_OK;
+}
+
+extern "C" int spex_step_events_release(void **ev_fork, void **ev_join)
+{
+    if (ev_fork && *ev_fork) {
+        SPEX_HIP(hipEventDestroy((hipEvent_t)*ev_fork));
+        *ev_fork = nullptr;
+    }
+    if (ev_join && *ev_join) {
+        SPEX_HIP(hipEventDestroy((hipEvent_t)*ev_join));
+        *ev_join = nullptr;
+    }
     return SPEX_OK;
 }
 
@@ -116,28 +145,51 @@ extern "C" int spex_ngcf_step_bce_f32(spex_ngcf_step_t *s, const int64_t *users,
     // ---- Adam: the table (its pass clears the gradient again), the layer weights (their pass sums the partial blocks).  The
     //      weights' pass needs only the rows backward: with a second stream it runs beside the push-form product and the table's
     //      pass (a one-workgroup-class launch next to two that fill the chip) and is joined at the end of the step.
-    s->t += 1;
-    if (s->p_drop > 0.0f) s->dropout_step += 1;
+    //      t / dropout_step are advanced only after every launch of the step has been queued (a failed call leaves them alone).
+    const int32_t t_next = s->t + 1;
     auto weight_adam = [&](void *st) -> int {
-        return spex_adam_step_sum_f32(s->W, s->gW_parts, spex_ngcf_layer_bwd_rows_parts(2 * B), per, s->mW, s->vW, per, s->t, s->lr,
+        return spex_adam_step_sum_f32(s->W, s->gW_parts, spex_ngcf_layer_bwd_rows_parts(2 * B), per, s->mW, s->vW, per, t_next, s->lr,
                                       s->beta1, s->beta2, s->eps, st);
     };
+    const bool det = (s->flags & SPEX_STEP_DETERMINISTIC) != 0;
+    if (det)
+        SPEX_CHECK_ARG(s->graph_t && s->g_side_dense && s->g_ego_dense && s->graph_t->n_rows == n && s->graph_t->n_cols == n
+                           && s->graph_t->mask_mode == 0,
+                       "spex_ngcf_step_bce_f32: SPEX_STEP_DETERMINISTIC needs graph_t (A^T) and the two dense [N, 64] gradient buffers");
     const bool two_streams = s->side_stream != nullptr && s->side_stream != stream;
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    int rc = SPEX_OK;
+    bool forked = false;
     if (two_streams) {
-        SPEX_TRY(step_events(&fork_ev, &join_ev));
+        SPEX_TRY(step_events(&s->ev_fork, &s->ev_join, &fork_ev, &join_ev));
         SPEX_HIP(hipEventRecord(fork_ev, (hipStream_t)stream));
         SPEX_HIP(hipStreamWaitEvent((hipStream_t)s->side_stream, fork_ev, 0));
-        SPEX_TRY(weight_adam(s->side_stream));
-        SPEX_HIP(hipEventRecord(join_ev, (hipStream_t)s->side_stream));
+        forked = true;
+        rc = weight_adam(s->side_stream);
+        if (hipEventRecord(join_ev, (hipStream_t)s->side_stream) != hipSuccess && rc == SPEX_OK) rc = SPEX_ERR_HIP;
     }
-    int rc = spex_spmm_push_batch_f32(g, users, B, 0, items, B, n_u, s->g_side_c, d, s->g_ego_c, d, 1.0f, s->grad, d, stream);
+    if (rc == SPEX_OK) {
+        if (det) {
+            // SPEX_STEP_DETERMINISTIC: the slots' compact rows are added per table row in ascending slot order (dense g_side / g_ego,
+            // both all-zero outside the batch's rows), A^T g_side is the pull-form product over the rows of A^T with g_ego added in
+            // its epilogue, and the touched rows are cleared again — no float atomics (the weight gradients never had any).
+            rc = spex_reduce_slots_f32(users, B, 0, items, B, n_u, n, s->g_side_c, d, 1.0f, s->g_side_dense, 0, d, stream);
+            if (rc == SPEX_OK) rc = spex_reduce_slots_f32(users, B, 0, items, B, n_u, n, s->g_ego_c, d, 1.0f, s->g_ego_dense, 0, d, stream);
+            if (rc == SPEX_OK) rc = spex_spmm_f32(s->graph_t, s->g_side_dense, s->grad, s->g_ego_dense, 1.0f, nullptr, nullptr, 1.0f, d, stream);
+            if (rc == SPEX_OK) rc = spex_reduce_slots_f32(users, B, 0, items, B, n_u, n, nullptr, d, 1.0f, s->g_side_dense, 0, d, stream);
+            if (rc == SPEX_OK) rc = spex_reduce_slots_f32(users, B, 0, items, B, n_u, n, nullptr, d, 1.0f, s->g_ego_dense, 0, d, stream);
+        } else {
+            rc = spex_spmm_push_batch_f32(g, users, B, 0, items, B, n_u, s->g_side_c, d, s->g_ego_c, d, 1.0f, s->grad, d, stream);
+        }
+    }
     if (rc == SPEX_OK)
-        rc = spex::adam_step_z2(s->E0, s->grad, s->mE, s->vE, (int64_t)n * d, s->t, s->lr, s->beta1, s->beta2, s->eps, s->grad, nullptr, stream,
+        rc = spex::adam_step_z2(s->E0, s->grad, s->mE, s->vE, (int64_t)n * d, t_next, s->lr, s->beta1, s->beta2, s->eps, s->grad, nullptr, stream,
                                 loss_rows, B, loss_sum);
-    if (two_streams) SPEX_HIP(hipStreamWaitEvent((hipStream_t)stream, join_ev, 0));
+    if (forked && hipStreamWaitEvent((hipStream_t)stream, join_ev, 0) != hipSuccess && rc == SPEX_OK) rc = SPEX_ERR_HIP;   // joined on every path
+    if (rc == SPEX_OK && !two_streams) rc = weight_adam(stream);
     if (rc != SPEX_OK) return rc;
-    if (!two_streams) SPEX_TRY(weight_adam(stream));
+    s->t = t_next;
+    if (s->p_drop > 0.0f) s->dropout_step += 1;
     return SPEX_OK;
 }
 
@@ -160,6 +212,10 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
     SPEX_CHECK_ARG(g->mask_mode == 0 && gt->mask_mode == 0, "spex_dual_task_step_f32: edge dropout is not supported in the one-call step");
     const int64_t n_trust = spex_trust_param_count(d, H);
     SPEX_CHECK_ARG(n_trust > 0, "spex_dual_task_step_f32: unsupported number of heads %d", H);
+    const bool det = (s->flags & SPEX_STEP_DETERMINISTIC) != 0;
+    if (det)
+        SPEX_CHECK_ARG(s->g_raw_slots && s->att_parts && s->loss_rows,
+                       "spex_dual_task_step_f32: SPEX_STEP_DETERMINISTIC needs g_raw_slots, att_parts and loss_rows");
     const size_t sz = (size_t)N * d, off_u = (size_t)n_u * d;
     float *E0 = s->params, *trust_p = E0 + sz, *att1 = trust_p + n_trust, *att2 = att1 + 4 * d;
     float *g_att1 = s->g_small + n_trust, *g_att2 = g_att1 + 4 * d;
@@ -172,12 +228,15 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
     };
     const bool two_streams = s->side_stream != nullptr && s->side_stream != stream && T > 0;
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    int rc_trust = SPEX_OK;
+    bool forked = false;
     if (two_streams) {
-        SPEX_TRY(step_events(&fork_ev, &join_ev));
+        SPEX_TRY(step_events(&s->ev_fork, &s->ev_join, &fork_ev, &join_ev));
         SPEX_HIP(hipEventRecord(fork_ev, (hipStream_t)stream));
         SPEX_HIP(hipStreamWaitEvent((hipStream_t)s->side_stream, fork_ev, 0));
-        SPEX_TRY(trust_branch(s->side_stream));
-        SPEX_HIP(hipEventRecord(join_ev, (hipStream_t)s->side_stream));
+        forked = true;
+        rc_trust = trust_branch(s->side_stream);
+        if (hipEventRecord(join_ev, (hipStream_t)s->side_stream) != hipSuccess && rc_trust == SPEX_OK) rc_trust = SPEX_ERR_HIP;
     }
     auto rec_branch = [&]() -> int {
         // ---- rec branch forward (model_expert_s.py:95-126,154-168): layers 1 .. L-1 over the whole graph, the last layer, the gate and
@@ -190,14 +249,30 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
         }
         // (last layer at the batch's rows + layer mean + gate + scores + per-sample gradient rows: one launch)
         SPEX_TRY(spex_gated_batch_fwd_f32(g, cur, L == 1 ? E0 : s->light, (float)(L + 1), E0, att1, att2, users, items, labels, B, n_u,
-                                          1.0f / (float)B, s->loss, s->lo_batch, s->grad_slots, d, stream));
+                                          1.0f / (float)B, s->loss, det ? s->loss_rows : nullptr, s->lo_batch, s->grad_slots, d, stream));
+        if (det) {
+            // ---- SPEX_STEP_DETERMINISTIC: every sum the fast path leaves to float atomics is taken in a fixed order — the loss in
+            //      sample order, the gate's backward into per-slot rows + per-workgroup blocks of the two gate gradients (added in
+            //      block order), the slots per table row in ascending slot order, the propagation's backward in pull form.
+            SPEX_TRY(spex::sum_ordered(s->loss_rows, B, 1.0f, s->loss, 1, stream));
+            SPEX_TRY(spex_expert_gate_rows_bwd_det_f32(E0, s->lo_batch, att1, att2, users, B, 0, items, B, n_u, n_u, N, d, s->grad_slots, d,
+                                                       s->g_prop_slots, s->g_raw_slots, s->att_parts, stream));
+            const int32_t n_parts = spex_expert_gate_rows_bwd_parts(2 * B);
+            SPEX_TRY(spex::sum_parts(s->att_parts, n_parts, 512, 256, g_att1, 1, stream));
+            SPEX_TRY(spex::sum_parts(s->att_parts + 256, n_parts, 512, 256, g_att2, 1, stream));
+            SPEX_TRY(spex_reduce_slots_f32(users, B, 0, items, B, n_u, N, s->g_prop_slots, d, 1.0f, s->g_prop, 0, d, stream));
+            SPEX_TRY(spex_reduce_slots_f32(users, B, 0, items, B, n_u, N, s->g_raw_slots, d, 1.0f, s->g_raw, 0, d, stream));
+            SPEX_TRY(spex_propagate_bwd_f32(gt, s->g_prop, s->g_E0, s->ws_bwd, L, d, stream));
+            return SPEX_OK;
+        }
         // ---- rec branch backward (gradients of the UNWEIGHTED loss1; the precisions are applied in the Adam pass): the gate slot by
         //      slot (dense d loss / d light and d loss / d E0 rows added with atomics), then the propagation as in the LightGCN step
         SPEX_TRY(spex_expert_gate_rows_bwd_f32(E0, s->lo_batch, att1, att2, users, B, 0, items, B, n_u, n_u, N, d, s->grad_slots, d,
                                                s->g_prop_slots, s->g_prop, s->g_raw, g_att1, g_att2, stream));
         if (L >= 2) {
             float *G = s->ws_bwd;                     // all-zero here (cleared by the previous step's Adam pass)
-            SPEX_TRY(spex_spmm_push_batch_f32(gt, users, B, 0, items, B, n_u, s->g_prop_slots, d, s->g_prop_slots, d, 1.0f / (float)(L + 1), G, d,
+            // (push form of A^T g: over the rows of A — the forward handle — of the batch's slots)
+            SPEX_TRY(spex_spmm_push_batch_f32(g, users, B, 0, items, B, n_u, s->g_prop_slots, d, s->g_prop_slots, d, 1.0f / (float)(L + 1), G, d,
                                               stream));
             const float *c2 = G;
             for (int32_t l = L - 2; l >= 0; --l) {
@@ -210,14 +285,16 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
         }
         return SPEX_OK;
     };
-    const int rc_rec = rec_branch();
-    if (two_streams) SPEX_HIP(hipStreamWaitEvent((hipStream_t)stream, join_ev, 0));   // joined on every path out of here
-    if (rc_rec != SPEX_OK) return rc_rec;
-    if (T > 0 && !two_streams) SPEX_TRY(trust_branch(stream));                          // one-stream order
-    // ---- uncertainty-weighted sum of both losses (main_auto_expert_s.py:78-82) + Adam over every parameter (:89)
-    s->t += 1;
+    int rc = rec_branch();
+    if (forked && hipStreamWaitEvent((hipStream_t)stream, join_ev, 0) != hipSuccess && rc == SPEX_OK) rc = SPEX_ERR_HIP;   // joined on every path
+    if (rc == SPEX_OK) rc = rc_trust;
+    if (rc == SPEX_OK && T > 0 && !two_streams) rc = trust_branch(stream);                // one-stream order
+    if (rc != SPEX_OK) return rc;
+    // ---- uncertainty-weighted sum of both losses (main_auto_expert_s.py:78-82; SPEX_STEP_FIXED_TASK_WEIGHTS: loss1 + loss2,
+    //      main_11.py:69) + Adam over every parameter (:89); t is advanced once the whole step is queued
     SPEX_TRY(spex::dual_task_adam(s->params, s->m, s->v, s->g_E0, s->g_raw, s->g_user, s->g_small, s->g_prop, L >= 2 ? s->ws_bwd : nullptr,
-                                  s->loss, s->loss_acc, s->precision, (int64_t)sz, (int64_t)off_u, n_trust, B, T, s->n_rec, s->t, s->lr,
-                                  s->beta1, s->beta2, s->eps, stream));
+                                  s->loss, s->loss_acc, s->precision, (int64_t)sz, (int64_t)off_u, n_trust, B, T, s->n_rec, s->t + 1, s->lr,
+                                  s->beta1, s->beta2, s->eps, (s->flags & SPEX_STEP_FIXED_TASK_WEIGHTS) != 0, stream));
+    s->t += 1;
     return SPEX_OK;
 }

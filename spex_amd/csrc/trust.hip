@@ -18,8 +18,10 @@
 //                       straight from L2 in batches of independent loads); all 8 waves take the logits against the
 //                       whole user table (16 lanes per 256-byte row), the log-sum-exp, the loss, d scores (left in a
 //                       [B, n_users] buffer) and d a2; wave 0 runs the chain backwards, adds the path's table rows with
-//                       atomics and leaves the operands of every weight gradient in a per-path workspace.
-//   trust_reduce_kernel d E[u] += sum_b d scores[b,u] a2[b] (one wave per user row), every weight gradient as a small
+//                       atomics and leaves the operands of every weight gradient — and the gradient rows of the path's own
+//                       table rows — in a per-path workspace.
+//   trust_reduce_kernel d E[u] += sum_b d scores[b,u] a2[b] + the path rows that name u, in (path, position) order (one wave
+//                       per user row: this launch owns the rows, nothing is atomic), every weight gradient as a small
 //                       [rows, 64]^T [rows, 64] product over the workspaces (one thread per weight, no atomics,
 //                       deterministic), the bias / vector gradients, the mean loss.
 // All parameters live in ONE flat block (layout below) so that a step's gradients are one buffer and one Adam launch.
@@ -63,7 +65,7 @@ __host__ __device__ inline Layout layout(int H)
 // Per-path workspace: the operands of the weight gradients, written by the path kernel, read by the reduce kernel.
 //   vectors (64 floats each): dq1, ht, a, dpa, pa*dt0, pm*dt0, dw3, dc2, da2h[H];  rows (per position i < l): h_i, du_i, dr_i, M_i
 struct WsLayout {
-    int dq1, ht, a, dpa, vpa, vpm, dw3, dc2, da2h, Hm, DU, DR, M, stride;
+    int dq1, ht, a, dpa, vpa, vpm, dw3, dc2, da2h, Hm, DU, DR, M, DE, stride;
 };
 
 __host__ __device__ inline WsLayout ws_layout(int L, int H)
@@ -77,6 +79,7 @@ __host__ __device__ inline WsLayout ws_layout(int L, int H)
     o.DU = p;  p += L * kD;
     o.DR = p;  p += L * kD;
     o.M = p;   p += L * H * kD;
+    o.DE = p;  p += L * kD;              // d loss / d E[x_i] of the path's own rows (added to the table by the reduce kernel)
     o.stride = p;
     return o;
 }
@@ -431,7 +434,6 @@ __device__ __forceinline__ void backward_chain(const TrustArgs &p, const TrainAr
     const WsLayout wl = ws_layout(L, H);
     const float *__restrict__ P = p.P;
     float *__restrict__ W = tr.ws + (size_t)b * wl.stride;
-    float *grad_table = tr.grad_table;
     float *e = s + ll.e, *M = s + ll.M, *dM = s + ll.dM, *o = s + ll.o, *h = s + ll.h, *dh = s + ll.dh, *dO = s + ll.dO;
     float *du = s + ll.du, *vec = s + ll.vec;
     const float *sg_all = s + ll.dM;
@@ -448,10 +450,7 @@ __device__ __forceinline__ void backward_chain(const TrustArgs &p, const TrainAr
     W[wl.dpa + lane] = p.hybrid ? dpa : 0.0f;
     W[wl.a + lane] = av;
     W[wl.ht + lane] = ht;
-    if (st.arg >= 0) {
-        const int64_t x = p.seq[(size_t)b * L + st.arg];
-        if (x >= 0 && x < p.n_rows) atomicAdd(grad_table + (size_t)x * kD + lane, dpm);
-    }
+    // (dpm goes to the row the max-pool picked for this column: it joins that position's row gradient at the end of the chain)
     // p_a = Wt [a | ht] + bt:  d a[k] = sum_c Wt[c][k] dpa[c],  d ht[k] = sum_c Wt[c][64 + k] dpa[c]   (lane == k: coalesced rows)
     float da = dpa, dht = 0.0f;
     if (p.hybrid) {
@@ -595,12 +594,11 @@ __device__ __forceinline__ void backward_chain(const TrustArgs &p, const TrainAr
                     if (hh < H) dE[i] += dM[(i * H + hh) * kD + lane];
             }
         }
+        // the path's own table rows: plain stores into the workspace — the reduce kernel owns the table rows and adds them in
+        // (path, position) order (float atomics here made the trust branch the one non-repeatable part of the dual-task step)
 #pragma unroll
         for (int i = 0; i < kMaxL; ++i)
-            if (i < l) {
-                const int64_t x = p.seq[(size_t)b * L + i];
-                if (x >= 0 && x < p.n_rows) atomicAdd(grad_table + (size_t)x * kD + lane, dE[i]);
-            }
+            if (i < L) W[wl.DE + i * kD + lane] = i < l ? dE[i] + (st.arg == i ? dpm : 0.0f) : 0.0f;
 #pragma unroll
         for (int hh = 0; hh < kMaxH; ++hh)
             if (hh < H) W[wl.da2h + hh * kD + lane] = da2h[hh];
@@ -653,7 +651,7 @@ __global__ __launch_bounds__(TRAIN ? kPathThreads : kWave) void trust_path_kerne
 // ------------------------------------------------------------------------------------------------------------ reductions
 struct ReduceArgs {
     const float *dscore, *a2, *loss_b, *ws;
-    const int64_t *seq_l;
+    const int64_t *seq, *seq_l;
     float *grad_table, *grad_P, *loss_out;
     int n_users, B, L, H, hybrid, loss_accumulate;
     int blocks_users, blocks_mat;      // block ranges: [0, blocks_users) user rows, then the weight tiles, then one vector block
@@ -673,19 +671,40 @@ __global__ __launch_bounds__(256) void trust_reduce_kernel(const ReduceArgs a)
     if (blk < a.blocks_users) {
         // d E[u, :] += sum_b d score[b, u] a2[b, :]  (one wave per user row; this launch owns the rows)
         const int lane = t & 63;
-        for (int u = blk * 4 + (t >> 6); u < a.n_users; u += a.blocks_users * 4) {
+        const int n_pos = a.B * a.L;
+        for (int u = blk * 4 + (t >> 6); u <= a.n_users; u += a.blocks_users * 4) {     // (row n_users = the pad row: paths only)
             float acc = 0.0f;
-            for (int b0 = 0; b0 < a.B; b0 += 8) {
-                float dv[8], xv[8];
+            if (u < a.n_users)
+                for (int b0 = 0; b0 < a.B; b0 += 8) {
+                    float dv[8], xv[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    dv[j] = b0 + j < a.B ? a.dscore[(size_t)(b0 + j) * a.n_users + u] : 0.0f;
-                    xv[j] = b0 + j < a.B ? a.a2[(size_t)(b0 + j) * kD + lane] : 0.0f;
+                    for (int j = 0; j < 8; ++j) {
+                        dv[j] = b0 + j < a.B ? a.dscore[(size_t)(b0 + j) * a.n_users + u] : 0.0f;
+                        xv[j] = b0 + j < a.B ? a.a2[(size_t)(b0 + j) * kD + lane] : 0.0f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc = fmaf(dv[j], xv[j], acc);
                 }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc = fmaf(dv[j], xv[j], acc);
+            // the rows of the paths that pass through u (model_expert_s.py:175: embedding_user(inputs) under autograd), in
+            // (path, position) order: 64 positions per load, matches walked in ascending order
+            bool any = false;
+            for (int base = 0; base < n_pos; base += 64) {
+                const int idx = base + lane;
+                bool match = false;
+                if (idx < n_pos) {
+                    const int b = idx / a.L, i = idx - b * a.L;
+                    match = i < clamp_len(a.seq_l[b], a.L) && a.seq[idx] == (int64_t)u;
+                }
+                unsigned long long m = __ballot(match);
+                while (m) {
+                    const int idx2 = base + (int)__builtin_ctzll(m);
+                    m &= m - 1;
+                    const int b = idx2 / a.L, i = idx2 - b * a.L;
+                    acc += a.ws[(size_t)b * wl.stride + wl.DE + i * kD + lane];
+                    any = true;
+                }
             }
-            a.grad_table[(size_t)u * kD + lane] += acc;
+            if (u < a.n_users || any) a.grad_table[(size_t)u * kD + lane] += acc;
         }
         return;
     }
@@ -834,7 +853,7 @@ extern "C" int spex_trust_head_train_f32(const float *table, int64_t n_rows, con
     SPEX_CHECK_ARG(lds <= 64 * 1024, "spex_trust_head_train_f32: LDS %zu bytes", lds);
     hipLaunchKernelGGL(trust_path_kernel<true>, dim3((unsigned)B), dim3(kPathThreads), lds, (hipStream_t)stream, p, tr, a2);
     SPEX_HIP(hipGetLastError());
-    ReduceArgs r{dscore, a2, loss_b, ws, seq_l, grad_table, grad_params, loss_out, n_users, B, L, n_heads, hybrid, loss_accumulate, 0, 0};
+    ReduceArgs r{dscore, a2, loss_b, ws, seq, seq_l, grad_table, grad_params, loss_out, n_users, B, L, n_heads, hybrid, loss_accumulate, 0, 0};
     r.blocks_users = (n_users + 3) / 4 < 1024 ? (n_users + 3) / 4 : 1024;
     r.blocks_mat = 64 + 16 * n_heads;
     hipLaunchKernelGGL(trust_reduce_kernel, dim3((unsigned)(r.blocks_users + r.blocks_mat + 1)), dim3(256), 0, (hipStream_t)stream, r);

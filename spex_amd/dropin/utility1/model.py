@@ -15,6 +15,8 @@ How it runs instead of `torch.sparse.mm` in a Python loop:
     loop (batch_test.py:28-33) costs one propagation per epoch instead of 3 185;
   * scoring + BCE + its gradient rows are one kernel.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -52,6 +54,14 @@ class LightGCN(BasicModel):
         self._graph_t = None          # A^T with the edge-id permutation, built on first use under dropout
         self._dropout_calls = 0
         self._injected_mask = None    # test hook: (uint8 device tensor) replaces the sampled mask
+        # Which random stream picks the dropped edges (only read when --dropout 1):
+        #   "philox"    (default, the fast path) a counter-based mask regenerated inside the SpMM kernel: same law as the
+        #               reference's, a different stream;
+        #   "reference" the reference's OWN stream: `torch.rand(nnz)` drawn on the CPU from the global generator once per
+        #               training `computer()` call, exactly where model.py:50 draws it, uploaded as a keep mask (418 KB per step
+        #               on Epinion2) — the validation mode: with the same seed a run drops the same edges as main_rec.py
+        #               --dropout 1 and reproduces its losses step by step (tests: G12-dropout goldens).
+        self.dropout_stream = os.environ.get("SPEX_DROPOUT_STREAM", "philox")
         self._cache = None            # (version_u, version_i, light_out) for eval mode
 
     # ------------------------------------------------------------------ parameter storage
@@ -92,9 +102,21 @@ class LightGCN(BasicModel):
             return None
         if self._injected_mask is not None:
             return (1, self._injected_mask, float(self.keep_prob), 0)
+        if self.dropout_stream == "reference":
+            return (1, self._reference_stream_mask(), float(self.keep_prob), 0)
+        if self.dropout_stream != "philox":
+            raise ValueError(f"dropout_stream must be 'philox' or 'reference' (got {self.dropout_stream!r})")
         self._dropout_calls += 1
         seed = (int(getattr(self.args_r, "seed", 0)) << 32) | (self._dropout_calls & 0xFFFFFFFF)
         return (2, None, float(self.keep_prob), seed)
+
+    def _reference_stream_mask(self):
+        """The keep mask model.py:46-55 would draw for this step: `torch.rand(len(values)) + keep_prob`, `.int().bool()`, from
+        the global CPU generator — one draw per fold under --A_split (model.py:57-64 calls __dropout_x fold by fold), in the
+        stored-entry order of the coalesced adjacency (= the handles' edge ids)."""
+        graphs = self.Graph if isinstance(self.Graph, (list, tuple)) else [self.Graph]
+        keep = torch.cat([(torch.rand(int(g.nnz)) + self.keep_prob).int().bool() for g in graphs])
+        return keep.to(torch.uint8).to(self.embedding_user.weight.device).contiguous()
 
     # ------------------------------------------------------------------ propagation (model.py:66-97)
     def _light_out(self):

@@ -22,6 +22,32 @@ def _need(t, name, dtype=torch.float32):
 
 VALIDATE_DEVICE_INDICES = os.environ.get("SPEX_VALIDATE_INDICES") == "1"
 
+# Deterministic accumulation for the autograd Functions below (SPEX_DETERMINISTIC=1, or set_deterministic(True)): the batch's
+# per-sample gradient rows are added per table row in ascending slot order (reduce_slots) instead of with float atomics, so the
+# table gradient — and with it a whole LightGCN training run through the unchanged driver — repeats bit for bit.  The steppers
+# of spex_amd.trainer take the same switch as a constructor argument (flags & SPEX_STEP_DETERMINISTIC of their descriptors).
+DETERMINISTIC = os.environ.get("SPEX_DETERMINISTIC", "0") == "1"
+
+
+def set_deterministic(on=True):
+    global DETERMINISTIC
+    DETERMINISTIC = bool(on)
+
+
+def _score_bce_table_grad(light_out, n_u, u_idx, i_idx, labels, need_grad):
+    """(loss_sum, dense d loss / d light_out or None) of the mean BCE over a batch — atomics, or under DETERMINISTIC per-sample
+    rows added in slot order."""
+    B = u_idx.numel()
+    grad = torch.zeros_like(light_out) if need_grad else None
+    if need_grad and DETERMINISTIC and light_out.shape[1] == 64:
+        slots = torch.empty((2 * B, 64), dtype=torch.float32, device=light_out.device)
+        _, loss_sum = score_bce(light_out[:n_u], light_out[n_u:], u_idx, i_idx, labels, None, None, 1.0 / B, grad_slots=slots)
+        reduce_slots(u_idx, i_idx, n_u, light_out.shape[0], slots, grad)
+        return loss_sum, grad
+    _, loss_sum = score_bce(light_out[:n_u], light_out[n_u:], u_idx, i_idx, labels, grad[:n_u] if need_grad else None,
+                            grad[n_u:] if need_grad else None, 1.0 / B)
+    return loss_sum, grad
+
 
 def _idx(t, device, bound=None):
     """Indices as the reference hands them over (int64, possibly on the host: main_rec.py:33-34).  With `bound`, indices
@@ -343,10 +369,52 @@ def spmm_push_batch(graph, idx_a, idx_b, off_b, src, out, add=None, scale=1.0):
     return out
 
 
-def lightgcn_batch(graph, graph_t, X, acc_in, acc_div, users, items, labels, n_user_rows, grad_scale, push_scale, loss_sum, g_out, G,
+def reduce_slots(idx_a, idx_b, off_b, n_rows, slots, out, scale=1.0, accumulate=False):
+    """Deterministic accumulation of a batch's per-slot rows into a dense [n_rows, 64] table (spex_reduce_slots_f32): out[r] =
+    scale * sum of the slots naming r, in ascending slot order (overwritten, or added with accumulate); slots=None clears the
+    named rows.  The atomic-free alternative to score_bce's dense gradient tables / spmm_push_batch's `add` term."""
+    if not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.shape == (n_rows, 64)):
+        raise ValueError(f"reduce_slots: out must be a contiguous fp32 [{n_rows}, 64] device tensor")
+    for t in (idx_a, idx_b):
+        if not (t.is_cuda and t.dtype == torch.int64 and t.is_contiguous()):
+            raise ValueError("reduce_slots: the batch must be contiguous int64 tensors on the GPU")
+    n = idx_a.numel() + idx_b.numel()
+    if slots is not None and not (slots.is_cuda and slots.dtype == torch.float32 and slots.stride(1) == 1 and slots.shape[0] >= n
+                                  and slots.shape[1] >= 64):
+        raise ValueError("reduce_slots: slots must be an fp32 [>= slots, >= 64] device tensor with unit column stride")
+    _launch(out.device, "spex_reduce_slots_f32", _ptr(idx_a), idx_a.numel(), 0, _ptr(idx_b), idx_b.numel(), int(off_b), int(n_rows),
+            _ptr(slots), 64 if slots is None else slots.stride(0), float(scale), _ptr(out), 1 if accumulate else 0, 64)
+    _bump(out)
+    return out
+
+
+def lightgcn_batch_slots(graph, X, acc_in, acc_div, users, items, labels, n_user_rows, grad_scale, grad_slots, loss_sum=None,
+                         loss_per_sample=None):
+    """spex_lightgcn_batch_slots_f32: the batch kernel's forward + scoring with the two gradient rows of every sample written
+    as per-sample slots (grad_slots[b], grad_slots[B + b]) — no push, no float atomics (the deterministic step)."""
+    n = graph.n_rows
+    for t, nm in ((X, "X"), (acc_in, "acc_in")):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.shape == (n, 64)):
+            raise ValueError(f"lightgcn_batch_slots: {nm} must be a contiguous fp32 [{n}, 64] device tensor")
+    B = users.numel()
+    for t, dt, nm in ((users, torch.int64, "users"), (items, torch.int64, "items"), (labels, torch.float32, "labels")):
+        if not (t.is_cuda and t.dtype == dt and t.is_contiguous() and t.numel() == B):
+            raise ValueError(f"lightgcn_batch_slots: {nm} must be a contiguous device tensor of the batch's length")
+    if not (grad_slots.is_cuda and grad_slots.dtype == torch.float32 and grad_slots.is_contiguous() and grad_slots.shape[0] >= 2 * B
+            and grad_slots.shape[1] == 64):
+        raise ValueError("lightgcn_batch_slots: grad_slots must be a contiguous fp32 [>= 2B, 64] device tensor")
+    if loss_sum is None and loss_per_sample is None:
+        raise ValueError("lightgcn_batch_slots: needs loss_sum or loss_per_sample")
+    _launch(X.device, "spex_lightgcn_batch_slots_f32", graph._h, _ptr(X), _ptr(acc_in), float(acc_div), _ptr(users), _ptr(items),
+            _ptr(labels), B, int(n_user_rows), float(grad_scale), _ptr(loss_sum), _ptr(loss_per_sample), _ptr(grad_slots), 64)
+    _bump(loss_sum, loss_per_sample, grad_slots)
+
+
+def lightgcn_batch(graph, X, acc_in, acc_div, users, items, labels, n_user_rows, grad_scale, push_scale, loss_sum, g_out, G,
                    loss_per_sample=None):
     """The batch-sized middle of the exact LightGCN step as one launch (spex_lightgcn_batch_f32): last layer + layer mean at
-    the batch's rows, scores + BCE, dense gradient rows added into g_out, and G += push_scale * (g + A^T g) in push form.
+    the batch's rows, scores + BCE, dense gradient rows added into g_out, and G += push_scale * (g + A^T g) in push form (over
+    the rows of `graph` itself: A^T g in push form walks the rows of A).
     loss_sum: fp32 [1] (accumulated) — or loss_per_sample: fp32 [B], every sample's loss stored instead; g_out, G: fp32 [N, 64]
     (accumulated: zero them first)."""
     n = graph.n_rows
@@ -362,7 +430,7 @@ def lightgcn_batch(graph, graph_t, X, acc_in, acc_div, users, items, labels, n_u
             raise ValueError(f"lightgcn_batch: {nm} must be a contiguous fp32 device tensor of >= {k} elements")
     if loss_sum is None and loss_per_sample is None:
         raise ValueError("lightgcn_batch: needs loss_sum or loss_per_sample")
-    _launch(X.device, "spex_lightgcn_batch_f32", graph._h, graph_t._h, _ptr(X), _ptr(acc_in), float(acc_div), _ptr(users), _ptr(items),
+    _launch(X.device, "spex_lightgcn_batch_f32", graph._h, _ptr(X), _ptr(acc_in), float(acc_div), _ptr(users), _ptr(items),
             _ptr(labels), B, int(n_user_rows), float(grad_scale), float(push_scale), _ptr(loss_sum), _ptr(loss_per_sample), _ptr(g_out),
             _ptr(G), 64)
     _bump(loss_sum, loss_per_sample, g_out, G)
@@ -370,7 +438,7 @@ def lightgcn_batch(graph, graph_t, X, acc_in, acc_div, users, items, labels, n_u
 
 
 def gated_batch_fwd(graph, X, acc_in, acc_div, raw, att_u, att_i, users, items, labels, n_user_rows, grad_scale, loss_sum, lo_batch,
-                    grad_slots):
+                    grad_slots, loss_per_sample=None):
     """Forward half of the dual-task rec branch's batch-sized middle as one launch (spex_gated_batch_fwd_f32): last layer + layer
     mean at the batch's rows (-> lo_batch rows), expert gate, scores + BCE (-> loss_sum, accumulated), per-sample gradient rows
     with respect to the gated rows (-> grad_slots [2B, 64])."""
@@ -389,9 +457,9 @@ def gated_batch_fwd(graph, X, acc_in, acc_div, raw, att_u, att_i, users, items, 
             and grad_slots.shape[1] == 64):
         raise ValueError("gated_batch_fwd: grad_slots must be a contiguous fp32 [>= 2B, 64] device tensor")
     _launch(X.device, "spex_gated_batch_fwd_f32", graph._h, _ptr(X), _ptr(acc_in), float(acc_div), _ptr(raw), _ptr(att_u), _ptr(att_i),
-            _ptr(users), _ptr(items), _ptr(labels), B, int(n_user_rows), float(grad_scale), _ptr(loss_sum), _ptr(lo_batch),
-            _ptr(grad_slots), 64)
-    _bump(loss_sum, lo_batch, grad_slots)
+            _ptr(users), _ptr(items), _ptr(labels), B, int(n_user_rows), float(grad_scale), _ptr(loss_sum), _ptr(loss_per_sample),
+            _ptr(lo_batch), _ptr(grad_slots), 64)
+    _bump(loss_sum, loss_per_sample, lo_batch, grad_slots)
 
 
 def expert_gate(raw, prop, att_exp):
@@ -538,12 +606,8 @@ class ScoreBCELoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, light_out, n_user_rows, u_idx, i_idx, labels):
-        users_tab, items_tab = light_out[:n_user_rows], light_out[n_user_rows:]
         B = u_idx.numel()
-        grad = torch.zeros_like(light_out) if ctx.needs_input_grad[0] else None
-        gamma, loss_sum = score_bce(users_tab, items_tab, u_idx, i_idx, labels,
-                                    grad[:n_user_rows] if grad is not None else None,
-                                    grad[n_user_rows:] if grad is not None else None, 1.0 / B)
+        loss_sum, grad = _score_bce_table_grad(light_out, n_user_rows, u_idx, i_idx, labels, ctx.needs_input_grad[0])
         ctx.grad = grad
         return (loss_sum / B).reshape(())
 
@@ -572,9 +636,7 @@ class LightGCNBCELoss(torch.autograd.Function):
         n_u = user_w.shape[0]
         B = u_idx.numel()
         need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
-        grad = torch.zeros_like(light_out) if need else None
-        _, loss_sum = score_bce(light_out[:n_u], light_out[n_u:], u_idx, i_idx, labels,
-                                grad[:n_u] if need else None, grad[n_u:] if need else None, 1.0 / B)
+        loss_sum, grad = _score_bce_table_grad(light_out, n_u, u_idx, i_idx, labels, need)
         ctx.grad, ctx.graph_t, ctx.n_layers, ctx.mask, ctx.n_user_rows = grad, graph_t, n_layers, mask, n_u
         return (loss_sum / B).reshape(())
 

@@ -18,8 +18,12 @@ from . import ops
 
 
 class LightGCNStepper:
-    def __init__(self, graph, E0, n_user_rows, n_layers=3, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, graph_t=None):
+    def __init__(self, graph, E0, n_user_rows, n_layers=3, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, graph_t=None, deterministic=None):
+        """deterministic (default: SPEX_DETERMINISTIC=1 in the environment): the step takes every sum in a fixed order — no float
+        atomics (spex_lightgcn_step_t.flags & SPEX_STEP_DETERMINISTIC): per-sample gradient rows added per table row in ascending
+        slot order, the whole backward in pull form.  Two runs then end in bit-identical tables; ~10 us more per step."""
         assert E0.is_cuda and E0.dtype == torch.float32 and E0.is_contiguous()
+        self.deterministic = (os.environ.get("SPEX_DETERMINISTIC", "0") == "1") if deterministic is None else bool(deterministic)
         self.graph, self.graph_t = graph, (graph_t if graph_t is not None else graph)
         self.E0, self.n_u, self.L = E0, int(n_user_rows), int(n_layers)
         self.lr, self.betas, self.eps = lr, betas, eps
@@ -72,9 +76,18 @@ class LightGCNStepper:
         lo = self.propagate_for_batch(users, items) if batch_rows_only else self.propagate()
         B = users.numel()
         self._slots(B)
-        _, loss_sum = ops.score_bce(lo[:self.n_u], lo[self.n_u:], users, items, labels, self.g_out[:self.n_u],
-                                    self.g_out[self.n_u:], 1.0 / B, loss_sum=loss_acc, want_gamma=False, grad_slots=self.grad_slots)
-        self.backward_from_batch_rows(users, items)
+        if self.deterministic and self.E0.shape[1] == 64:
+            # launch-by-launch form of the deterministic step: per-sample rows only (no dense atomics), added per table row in
+            # slot order, then the all-pull backward
+            _, loss_sum = ops.score_bce(lo[:self.n_u], lo[self.n_u:], users, items, labels, None, None, 1.0 / B, loss_sum=loss_acc,
+                                        want_gamma=False, grad_slots=self.grad_slots)
+            ops.reduce_slots(users, items, self.n_u, self.E0.shape[0], self.grad_slots, self.g_out)
+            self._ws0_clean = False
+            self.graph_t.propagate_bwd(self.g_out, self.L, grad_E0=self.grad_E0, ws=self.ws_bwd)
+        else:
+            _, loss_sum = ops.score_bce(lo[:self.n_u], lo[self.n_u:], users, items, labels, self.g_out[:self.n_u],
+                                        self.g_out[self.n_u:], 1.0 / B, loss_sum=loss_acc, want_gamma=False, grad_slots=self.grad_slots)
+            self.backward_from_batch_rows(users, items)
         self.t += 1
         ops.adam_step(self.E0, self.grad_E0, self.m, self.v, self.t, self.lr, self.betas[0], self.betas[1], self.eps,
                       zero=self.g_out)
@@ -113,9 +126,10 @@ class LightGCNStepper:
                 light_out=p(self.light_out), ws_fwd=p(self.ws_fwd), lo_batch=p(self.lo_batch), g_out=p(self.g_out),
                 ws_bwd=p(self.ws_bwd), grad_E0=p(self.grad_E0), grad_slots=p(self.grad_slots),
                 slot_capacity=self.grad_slots.shape[0], n_user_rows=self.n_u, L=self.L, d=self.E0.shape[1],
-                lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, t=self.t)
+                lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, t=self.t, flags=0)
         d = self._desc
         d.t, d.lr = self.t, self.lr
+        d.flags = _lib.STEP_DETERMINISTIC if self.deterministic else 0
         _launch(self.E0.device, "spex_lightgcn_step_bce_f32", ctypes.byref(d), ctypes.c_void_p(users.data_ptr()),
                 ctypes.c_void_p(items.data_ptr()), ctypes.c_void_p(labels.data_ptr()), B, ctypes.c_void_p(loss_acc.data_ptr()))
         self.t = d.t
@@ -124,18 +138,19 @@ class LightGCNStepper:
 
     def backward_from_batch_rows(self, users, items):
         """grad_E0 from g_out (non-zero on the batch's rows only).  The first product of the backward pass, A^T g, touches
-        only the stored entries of those <= 2B rows: it is taken in push form (~14 k entries on
-        Epinion2, spex_spmm_push_batch_f32) instead of a pull-form SpMM over all 418 k; the remaining L - 1 products are dense.  Falls back to the
-        all-pull form where the push form does not apply (edge dropout on the handle, L < 2)."""
+        only the stored entries of those <= 2B rows OF A: it is taken in push form (~14 k entries on
+        Epinion2, spex_spmm_push_batch_f32 over the forward handle) instead of a pull-form SpMM over all 418 k; the remaining L - 1
+        products are dense, over A^T.  Falls back to the all-pull form where the push form does not apply (edge dropout on the
+        handle, L < 2)."""
         L, gt = self.L, self.graph_t
         self._ws0_clean = False
-        if L < 2 or self.E0.shape[1] != 64 or getattr(gt, "mask_mode", 0) != 0:
+        if L < 2 or self.E0.shape[1] != 64 or getattr(gt, "mask_mode", 0) != 0 or getattr(self.graph, "mask_mode", 0) != 0:
             gt.propagate_bwd(self.g_out, L, grad_E0=self.grad_E0, ws=self.ws_bwd)
             return
         inv = 1.0 / float(L + 1)
         G = self.ws_bwd[0]
         G.zero_()
-        ops.spmm_push_batch(gt, users, items, self.n_u, self.grad_slots, G, add=self.grad_slots, scale=inv)   # G_{L-1}
+        ops.spmm_push_batch(self.graph, users, items, self.n_u, self.grad_slots, G, add=self.grad_slots, scale=inv)   # G_{L-1}
         cur = G
         for l in range(L - 2, -1, -1):
             nxt = self.grad_E0 if l == 0 else self.ws_bwd[1 + ((L - 2 - l) & 1)]      # ws_bwd[1], [2], [1] ...: never the source
@@ -178,16 +193,36 @@ def dataloader_epoch_order(n):
     return torch.randperm(n, generator=g)
 
 
-def train_epoch(stepper, train_data, batch_size=256, resample=True, pause_gc=True):
+def edge_dropout_mask(graph, keep_prob, stream, seed=0, step=0):
+    """The edge-dropout mask tuple of one training step (SpexGraph.set_edge_mask arguments) — model.py:46-55.
+    stream "reference": the reference's own draw, `torch.rand(nnz) + keep_prob` on the CPU from the global generator (one call
+    per step, exactly where model.py:50 makes it), uploaded as a keep mask; "philox": the in-kernel counter-based mask."""
+    if stream == "reference":
+        keep = (torch.rand(int(graph.nnz)) + keep_prob).int().bool()
+        return (1, keep.to(torch.uint8).to(graph.device).contiguous(), float(keep_prob), 0)
+    if stream != "philox":
+        raise ValueError(f"edge dropout stream must be 'reference' or 'philox' (got {stream!r})")
+    return (2, None, float(keep_prob), (int(seed) << 32) | (int(step) & 0xFFFFFFFF))
+
+
+def train_epoch(stepper, train_data, batch_size=256, resample=True, pause_gc=True, edge_dropout=None, max_steps=None,
+                step_losses=None):
     """Train() of main_rec.py:25-38 without the per-step host work of its DataLoader loop: negatives are drawn like the
     reference's (`train_data.ng_sample()`, NumPy global RNG), the epoch's sample order is the DataLoader's own
     (dataloader_epoch_order), the whole shuffled epoch is moved to the device once, and every batch is one
     LightGCNStepper.step_bce (no allocation, no synchronisation).  Same batches, same arithmetic — ≈105 us per step instead
-    of ≈550 us.  Returns the epoch's summed loss as a device tensor (main_rec.py:36 accumulates the same sum)."""
+    of ≈550 us.  Returns the epoch's summed loss as a device tensor (main_rec.py:36 accumulates the same sum).
+    edge_dropout: None, or (keep_prob, stream[, seed]) for `--dropout 1 --keepprob p` (README.md:119-123): a fresh mask per
+    step (edge_dropout_mask) on the stepper's graph and graph_t — which must then be the transposed handle carrying the edge-id
+    permutation, since the masked operator is not symmetric.  max_steps: stop after that many batches; step_losses: a list that
+    receives every step's mean loss (synchronises per step: a validation aid)."""
     if resample:
         train_data.ng_sample()
     n = len(train_data)
     order = dataloader_epoch_order(n).numpy()
+    if edge_dropout is not None and stepper.graph_t is stepper.graph:
+        raise ValueError("train_epoch(edge_dropout=...): the stepper needs graph_t = the transposed handle with the edge-id "
+                         "permutation (LightGCN._transposed()): a masked adjacency is not symmetric")
     dev = stepper.E0.device
     users = torch.from_numpy(train_data.users_fill[order]).to(dev)
     items = torch.from_numpy(train_data.items_fill[order]).to(dev)
@@ -200,13 +235,27 @@ def train_epoch(stepper, train_data, batch_size=256, resample=True, pause_gc=Tru
         gc.disable()
     n_full = n // batch_size * batch_size
     acc = torch.zeros(2, 1, dtype=torch.float32, device=dev)     # loss sums of the full batches / of the ragged last one
+    starts = list(range(0, n, batch_size))
+    if max_steps is not None:
+        starts = starts[:max_steps]
     try:
-        for s in range(0, n_full, batch_size):
-            stepper.step_bce(users[s:s + batch_size], items[s:s + batch_size], labels[s:s + batch_size], loss_acc=acc[0],
-                             batch_rows_only=True)
-        if n_full < n:
-            stepper.step_bce(users[n_full:], items[n_full:], labels[n_full:], loss_acc=acc[1], batch_rows_only=True)
+        for k, s in enumerate(starts):
+            e = min(s + batch_size, n)
+            slot = acc[0] if e - s == batch_size else acc[1]
+            tmp = torch.zeros(1, dtype=torch.float32, device=dev) if step_losses is not None else None
+            if edge_dropout is not None:
+                mask = edge_dropout_mask(stepper.graph, edge_dropout[0], edge_dropout[1], edge_dropout[2] if len(edge_dropout) > 2 else 0, k + 1)
+                stepper.graph.set_edge_mask(*mask)
+                stepper.graph_t.set_edge_mask(*mask)
+            stepper.step_bce(users[s:e], items[s:e], labels[s:e], loss_acc=slot if tmp is None else tmp,
+                             batch_rows_only=edge_dropout is None)
+            if tmp is not None:
+                step_losses.append(tmp.item() / (e - s))
+                slot += tmp
     finally:
+        if edge_dropout is not None:
+            stepper.graph.set_edge_mask(0)
+            stepper.graph_t.set_edge_mask(0)
         if gc_was_on:
             gc.enable()
     total = acc[0, 0] / batch_size + (acc[1, 0] / (n - n_full) if n_full < n else 0.0)   # sum of per-batch mean losses
@@ -231,10 +280,14 @@ class NGCFStepper:
     (message_dropout_seed, dropout_step).
     """
 
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, deterministic=None):
+        """deterministic (default: SPEX_DETERMINISTIC=1 in the environment): no float atomics in the step — the slots' compact
+        gradient rows are added per table row in ascending slot order and A^T g_side is a pull-form product over A^T
+        (spex_ngcf_step_t.flags & SPEX_STEP_DETERMINISTIC; single-layer models, the one-call step)."""
         if not model._fused_ok():
             raise ValueError("NGCFStepper needs 64-wide layers (the fused layer kernels)")
         self.model, self.lr, self.betas, self.eps, self.t = model, lr, betas, eps, 0
+        self.deterministic = (os.environ.get("SPEX_DETERMINISTIC", "0") == "1") if deterministic is None else bool(deterministic)
         # spex_ngcf_step_t.side_stream (the layer weights' Adam pass on a second stream beside the push-form product and the
         # table's pass) is OFF by default: measured on the MI355X it LOSES 10 us per step (69.4 vs 59.3 us) — the 5 us pass it
         # hides costs a fork and a join, and a cross-stream event wait takes ~5 us to propagate between the two hardware queues.
@@ -282,6 +335,8 @@ class NGCFStepper:
         acc = self.loss_acc if loss_acc is None else loss_acc
         if L == 1 and self._one_call_ok(users, items, labels):
             return self._step_one_call(users, items, labels, acc)
+        if self.deterministic:
+            raise ValueError("NGCFStepper(deterministic=True): single-layer models with contiguous int64 / fp32 device batches only")
         drop = None
         if any(p > 0 for p in m.mess_dropout):
             drop = (m.mess_dropout, m.message_dropout_seed, m.dropout_step)
@@ -337,6 +392,20 @@ class NGCFStepper:
         return acc
 
 
+def _drop_desc(stepper):
+    """Forget a two-stream stepper's native step descriptor (rebuilt on the next step), releasing the fork / join events the
+    library keeps in it.  The steps already queued hold no reference to the events once recorded / waited on."""
+    d = getattr(stepper, "_desc", None)
+    stepper._desc = None
+    if d is not None and (getattr(d, "ev_fork", None) or getattr(d, "ev_join", None)):
+        try:
+            torch.cuda.synchronize()
+            from . import _lib
+            _lib.release_step_events(d)
+        except Exception:
+            pass
+
+
 def _ngcf_one_call_ok(users, items, labels):
     return (users.is_cuda and items.is_cuda and labels.is_cuda and users.dtype == torch.int64 and items.dtype == torch.int64
             and labels.dtype == torch.float32 and users.is_contiguous() and items.is_contiguous() and labels.is_contiguous()
@@ -356,7 +425,7 @@ def _ngcf_step_one_call(self, users, items, labels, acc):
         self.g_side_c = torch.zeros((2 * B, d), dtype=torch.float32, device=dev)
         self.g_ego_c = torch.zeros_like(self.g_side_c)
         self.gW_parts = torch.zeros((ops.ngcf_bwd_rows_parts(2 * B), 2 * (d * d + d)), dtype=torch.float32, device=dev)
-        self._desc = None
+        _drop_desc(self)
     if getattr(self, "_desc", None) is None:
         p = lambda t: t.data_ptr()
         self._desc = _lib.NGCFStepDesc(
@@ -365,7 +434,12 @@ def _ngcf_step_one_call(self, users, items, labels, acc):
             g_ego_c=p(self.g_ego_c), gW_parts=p(self.gW_parts), grad=p(self.g_next[0]), slot_capacity=self.g_slots.shape[0],
             n_user_rows=self.n_u, pad_row=m.n_users, slope=0.01, p_drop=float(m.mess_dropout[0]), seed=int(m.message_dropout_seed),
             dropout_step=m.dropout_step, t=self.t, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps,
-            side_stream=None if self._side is None else self._side.cuda_stream)
+            side_stream=None if self._side is None else self._side.cuda_stream, ev_fork=None, ev_join=None, graph_t=None,
+            g_side_dense=None, g_ego_dense=None, flags=0)
+        if self.deterministic:
+            self._desc.graph_t = m.graph_t._h.value
+            self._desc.g_side_dense, self._desc.g_ego_dense = p(self.g_side), p(self.g_ego)     # all-zero between steps
+            self._desc.flags = _lib.STEP_DETERMINISTIC
     d = self._desc
     d.t, d.lr, d.dropout_step, d.seed, d.p_drop = self.t, self.lr, m.dropout_step, int(m.message_dropout_seed), float(m.mess_dropout[0])
     _launch(self.E0.device, "spex_ngcf_step_bce_f32", ctypes.byref(d), ctypes.c_void_p(users.data_ptr()),
@@ -377,6 +451,7 @@ def _ngcf_step_one_call(self, users, items, labels, acc):
 
 NGCFStepper._one_call_ok = staticmethod(_ngcf_one_call_ok)
 NGCFStepper._step_one_call = _ngcf_step_one_call
+NGCFStepper.__del__ = _drop_desc
 
 
 def train_epoch_ngcf(stepper, data, batch_size=None, pause_gc=True):
@@ -420,10 +495,15 @@ class DualTaskStepper:
     path_capacity: the largest number of paths a step may carry (3 x trust_batch_size in the reference driver, :70-71)."""
 
     def __init__(self, model, path_capacity, path_len, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, n_rec=5, batch_capacity=256,
-                 two_streams=None):
+                 two_streams=None, deterministic=None, fixed_task_weights=False):
         """two_streams (default on; SPEX_DUAL_ONE_STREAM=1 turns it off): the trust branch's two launches — a latency chain on
         <= path_capacity workgroups — run on a second HIP stream beside the rec branch and join it in front of the Adam
-        pass (spex_dual_task_step_t.side_stream).  Same results as the one-stream order."""
+        pass (spex_dual_task_step_t.side_stream).  Same results as the one-stream order.
+        deterministic (default: SPEX_DETERMINISTIC=1 in the environment): no float atomics in the step (flags &
+        SPEX_STEP_DETERMINISTIC).  fixed_task_weights: loss = loss1 + loss2 as in main_11.py:69 (flags &
+        SPEX_STEP_FIXED_TASK_WEIGHTS; the task weights stay where they are)."""
+        self.deterministic = (os.environ.get("SPEX_DETERMINISTIC", "0") == "1") if deterministic is None else bool(deterministic)
+        self.fixed_task_weights = bool(fixed_task_weights)
         from . import _lib
         table = model.flat_table()
         assert table.is_cuda, "DualTaskStepper: the model must be on the GPU (no CPU fallback)"
@@ -484,9 +564,14 @@ class DualTaskStepper:
         if self.slot_capacity < n:
             z = lambda *s: torch.zeros(s, dtype=torch.float32, device=self.dev)
             self.mixed_slots, self.grad_slots, self.g_prop_slots = z(n, self.d), z(n, self.d), z(n, self.d)
+            self.g_raw_slots, self.loss_rows = z(n, self.d), z(n)
+            self.att_parts = z(int(_lib_mod().load().spex_expert_gate_rows_bwd_parts(n)) * 512)
             self.arange = torch.arange(n, dtype=torch.int64, device=self.dev)
             self.slot_capacity = n
-            self._desc = None
+            _drop_desc(self)
+
+    def __del__(self):
+        _drop_desc(self)
 
     def refresh_precision(self):
         """Call after changing task_weights from outside the stepper (the step keeps exp(-2 s) snapshots on the device)."""
@@ -523,9 +608,11 @@ class DualTaskStepper:
                 path_capacity=self.path_capacity, path_len=self.path_len, n_user_rows=self.n_u, L=self.L, d=self.d,
                 n_heads=self.n_heads, hybrid=0 if self.model.nonhybrid else 1, n_rec=self.n_rec, lr=self.lr, beta1=self.betas[0],
                 beta2=self.betas[1], eps=self.eps, t=self.t,
-                side_stream=None if self._side is None else self._side.cuda_stream)
+                side_stream=None if self._side is None else self._side.cuda_stream, ev_fork=None, ev_join=None,
+                g_raw_slots=p(self.g_raw_slots), att_parts=p(self.att_parts), loss_rows=p(self.loss_rows), flags=0)
         dsc = self._desc
         dsc.t, dsc.lr = self.t, self.lr
+        dsc.flags = (_lib.STEP_DETERMINISTIC if self.deterministic else 0) | (_lib.STEP_FIXED_TASK_WEIGHTS if self.fixed_task_weights else 0)
         if T and self._side is not None:                     # the side stream reads them: keep the allocator from recycling
             for t in (seq, seq_l, targets):                  # their memory under a step still in flight
                 t.record_stream(self._side)
@@ -535,6 +622,11 @@ class DualTaskStepper:
         self.t = dsc.t
         _bump(self.arena, self.m, self.v, self.loss_acc)
         self.model._cache = None
+
+
+def _lib_mod():
+    from . import _lib
+    return _lib
 
 
 def dual_task_epoch_paths(batch_users, by_user, cap):

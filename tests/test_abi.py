@@ -39,7 +39,7 @@ def test_binding_arity_matches_header():
 
 def test_version_and_error_string():
     lib = _lib.load()
-    assert lib.spex_version() == 3
+    assert lib.spex_version() == 4
     assert isinstance(lib.spex_last_error(), bytes)
 
 
@@ -101,4 +101,30 @@ def test_header_is_plain_c(tmp_path):
     assert r.returncode == 0, r.stderr
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     # NULL rowptr is refused by argument validation before any device call
-    assert out.returncode == 1 and out.stdout.startswith("3 -1 spex_graph_create"), (out.stdout, out.stderr)
+    assert out.returncode == 1 and out.stdout.startswith("4 -1 spex_graph_create"), (out.stdout, out.stderr)
+
+
+def test_step_descriptors_have_the_layout_of_the_header(tmp_path):
+    """The ctypes mirrors of the three step descriptors (spex_amd/_lib.py) against the C compiler's view of include/spex_hip.h:
+    size of each struct and the offset of every field (ABI 4 appended fields to all three)."""
+    import subprocess
+    structs = {"spex_lightgcn_step_t": _lib.LightGCNStepDesc, "spex_ngcf_step_t": _lib.NGCFStepDesc,
+               "spex_dual_task_step_t": _lib.DualTaskStepDesc}
+    lines = ['#include "spex_hip.h"', "#include <stdio.h>", "#include <stddef.h>", "int main(void) {"]
+    for cname, cls in structs.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines.append("return 0; }")
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    r = subprocess.run(["gcc", "-std=c99", "-I", os.path.dirname(HEADER), str(src), "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in structs.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
+    assert _lib.STEP_DETERMINISTIC == 1 and _lib.STEP_FIXED_TASK_WEIGHTS == 2
+    assert re.search(r"SPEX_STEP_DETERMINISTIC = 1", open(HEADER).read()) and re.search(r"SPEX_STEP_FIXED_TASK_WEIGHTS = 2", open(HEADER).read())

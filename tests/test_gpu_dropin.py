@@ -550,6 +550,101 @@ def test_whole_training_run_matches_the_reference(data_root, golden, ds, n_epoch
         assert rel_err(uw, g["user_w"]) <= 1e-4 and rel_err(iw, g["item_w"]) <= 1e-4
 
 
+@pytest.mark.parametrize("ds", ["tiny", "epinion2"])
+def test_reference_stream_dropout_run_matches_the_reference(data_root, golden, ds):
+    """G12-dropout: the reference's recommended LightGCN configuration, `main_rec.py --dropout 1 --keepprob 0.3`
+    (README.md:119-123), minted from the reference's modules on CPU (oracle/gen_golden.py --stage epochs-dropout[-epinion2]:
+    three epochs on tiny, the first 300 steps + test() on Epinion2).  The reference draws every step's edge mask with
+    `torch.rand(nnz)` on the CPU from the global generator (model.py:46-55); the drop-in's "reference" dropout stream draws the
+    same numbers at the same point, so the run drops the same edges and must reproduce EVERY step's loss (2e-5), the loss sum,
+    HR / NDCG (1e-4) and the trained tables — through the unchanged-driver loop and through trainer.train_epoch."""
+    from torch.utils.data import DataLoader
+    import utility1.dataloader as dl
+    from utility1.batch_test import test
+    from spex_amd.trainer import LightGCNStepper, train_epoch
+    g = golden(f"lightgcn_{ds}_dropout")
+    keep_prob, max_steps = float(g["keepprob"]), (None if int(g["max_steps"]) < 0 else int(g["max_steps"]))
+    n_epochs = len(g["losses"])
+    for fast in (False, True):
+        args, dataset, net = build(ds, data_root, ["--dropout", "1", "--keepprob", str(keep_prob)])   # includes set_seed
+        net.dropout_stream = "reference"
+        assert int(net.Graph.nnz) == int(g["nnz"])
+        td = dl.LightTrainData(dataset.rec_train_data, dataset.m_item, dataset.train_mat)
+        loader = DataLoader(td, batch_size=256, shuffle=True)
+        opt = torch.optim.Adam(net.parameters(), lr=args.lr)
+        st = LightGCNStepper(net.Graph, net.flat_table(), net.num_users + 1, n_layers=net.n_layers, lr=args.lr,
+                             graph_t=net._transposed())
+        step_losses = []
+        for epoch in range(n_epochs):
+            if fast:
+                total = train_epoch(st, td, edge_dropout=(keep_prob, "reference"), max_steps=max_steps, step_losses=step_losses).item()
+            else:
+                loader.dataset.ng_sample()
+                net.train()
+                total = 0.0
+                for k, (user, item, label) in enumerate(loader):
+                    if max_steps is not None and k == max_steps:
+                        break
+                    if epoch == 0 and k == 0:
+                        assert np.array_equal(torch.stack([user, item, label]).numpy(), g["first_batch"])
+                    opt.zero_grad()
+                    loss = net(users=user.to(DEV), items=item.to(DEV), labels=label.to(DEV), flag=0)
+                    loss.backward()
+                    step_losses.append(loss.item())
+                    total += loss.item()
+                    opt.step()
+            assert abs(total - g["losses"][epoch]) <= 2e-5 * g["losses"][epoch], (fast, epoch, total, g["losses"][epoch])
+            net.eval()
+            with torch.no_grad():
+                ret = test(net, dataset.testRatings, dataset.testNegatives)
+            assert np.abs(ret["recall"] - g["recall"][epoch]).max() <= 1e-4, (fast, ret["recall"], g["recall"][epoch])
+            assert np.abs(ret["ndcg"] - g["ndcg"][epoch]).max() <= 1e-4
+        assert len(step_losses) == len(g["step_losses"])
+        dev = np.abs(np.asarray(step_losses) - g["step_losses"])
+        assert dev.max() <= 2e-5, (fast, int(dev.argmax()), float(dev.max()))
+        uw, iw = net.embedding_user.weight.detach().cpu().numpy(), net.embedding_item.weight.detach().cpu().numpy()
+        if ds != "tiny":
+            for got, want in ((uw, g["user_w_colsum"]), (iw, g["item_w_colsum"])):
+                assert np.abs(got.astype(np.float64).sum(0) - want).max() <= 2e-5 * np.abs(want).max()
+            uw, iw = uw[g["rows_u"]], iw[g["rows_i"]]
+        assert rel_err(uw, g["user_w"]) <= 5e-5 and rel_err(iw, g["item_w"]) <= 5e-5
+
+
+def test_dropped_entries_contribute_nothing_even_beside_non_finite_rows(data_root, golden):
+    """A dropped edge is GONE from the reference's matrix (model.py:52-54); in the kernel it keeps its slot and gathers a
+    stand-in row, whose value is replaced by 0 before the fmaf — so a table row holding Inf cannot turn into 0 * Inf = NaN on
+    rows whose surviving entries never reference it (round 2 multiplied)."""
+    g = golden("lightgcn_tiny")
+    args, dataset, net = build("tiny", data_root, ["--dropout", "1", "--keepprob", "0.5"])
+    rowptr, col, val = dataset.build_adjacency()
+    n = len(rowptr) - 1
+    rows = np.repeat(np.arange(n), np.diff(rowptr))
+    bad = int(np.bincount(col, minlength=n).argmax())                 # the most referenced source row
+    keep = np.ones(len(col), bool)
+    keep[col == bad] = False                                          # every edge INTO it is dropped ...
+    keep[np.random.default_rng(0).random(len(col)) < 0.3] = False     # ... and a random third of the others
+    keep[col == bad] = False
+    E0 = g["E0"].copy()
+    E0[bad] = np.inf
+    net.train()
+    net.set_edge_mask(torch.from_numpy(keep))
+    with torch.no_grad():
+        net.embedding_user.weight.copy_(torch.from_numpy(E0[: net.num_users + 1]))
+        net.embedding_item.weight.copy_(torch.from_numpy(E0[net.num_users + 1:]))
+        one = net.Graph.spmm
+        net.Graph.set_edge_mask(1, net._injected_mask, 0.5, 0)
+        y = net.Graph.spmm(net.flat_table())
+        net.Graph.set_edge_mask(0)
+    got = y.cpu().numpy()
+    A = np.zeros((n, n), np.float64)
+    A[rows[keep], col[keep]] = val[keep].astype(np.float64) / 0.5
+    Ez = E0.astype(np.float64).copy()
+    Ez[bad] = 0.0                                                     # no surviving entry references the bad row
+    want = A @ Ez
+    assert np.isfinite(got).all()
+    assert rel_err(got, want) <= 1e-6
+
+
 def test_whole_dual_task_run_matches_the_reference(data_root, golden):
     """G13: the reference's dual-task training run (main_auto_expert_s.py:22-120 driven from the reference's modules on
     CPU: rec batches, per-batch path selection incl. random.sample, uncertainty-weighted loss, Adam, rec_test +

@@ -962,7 +962,7 @@ def test_lightgcn_batch_kernel_equals_the_three_launch_sequence(G, golden, epini
     ops.spmm_push_batch(g, u_d, i_d, n_u, slots, G_a, add=slots, scale=1.0 / (L + 1))
     # the fused launch
     loss_b, g_out_b, G_b = torch.zeros(1, device=DEV), torch.zeros(n, 64, device=DEV), torch.zeros(n, 64, device=DEV)
-    ops.lightgcn_batch(g, g, X, run, float(L + 1), u_d, i_d, y_d, n_u, 1.0 / 256, 1.0 / (L + 1), loss_b, g_out_b, G_b)
+    ops.lightgcn_batch(g, X, run, float(L + 1), u_d, i_d, y_d, n_u, 1.0 / 256, 1.0 / (L + 1), loss_b, g_out_b, G_b)
     assert abs(loss_a.item() - loss_b.item()) <= 1e-5 * abs(loss_a.item())
     assert rel_err(g_out_b.cpu().numpy(), g_out_a.cpu().numpy()) <= 2e-6       # float atomics: order only
     assert rel_err(G_b.cpu().numpy(), G_a.cpu().numpy()) <= 2e-6
@@ -983,7 +983,7 @@ def test_lightgcn_batch_kernel_equals_the_three_launch_sequence(G, golden, epini
     bad_u[7] = 999999
     ok = np.ones(256, bool); ok[7] = False
     loss_c, g_out_c, G_c = torch.zeros(1, device=DEV), torch.zeros(n, 64, device=DEV), torch.zeros(n, 64, device=DEV)
-    ops.lightgcn_batch(g, g, X, run, float(L + 1), t(bad_u), i_d, y_d, n_u, 1.0 / 256, 1.0 / (L + 1), loss_c, g_out_c, G_c)
+    ops.lightgcn_batch(g, X, run, float(L + 1), t(bad_u), i_d, y_d, n_u, 1.0 / 256, 1.0 / (L + 1), loss_c, g_out_c, G_c)
     want_gc = np.zeros((n, 64))
     np.add.at(want_gc, users[ok], dg[ok, None] * light[items[ok] + n_u])
     np.add.at(want_gc, items[ok] + n_u, dg[ok, None] * light[users[ok]])
@@ -991,7 +991,7 @@ def test_lightgcn_batch_kernel_equals_the_three_launch_sequence(G, golden, epini
     assert torch.isfinite(G_c).all()
     # per-sample losses instead of the accumulated sum (what the one-call step uses: its Adam pass adds them up in order)
     per = torch.full((256,), 7.0, device=DEV)
-    ops.lightgcn_batch(g, g, X, run, float(L + 1), t(bad_u), i_d, y_d, n_u, 1.0 / 256, 1.0 / (L + 1), None, torch.zeros_like(g_out_c),
+    ops.lightgcn_batch(g, X, run, float(L + 1), t(bad_u), i_d, y_d, n_u, 1.0 / 256, 1.0 / (L + 1), None, torch.zeros_like(g_out_c),
                        torch.zeros_like(G_c), loss_per_sample=per)
     want_per = np.maximum(x, 0) - x * labels + np.log1p(np.exp(-np.abs(x)))
     want_per[7] = 0.0
@@ -1000,8 +1000,10 @@ def test_lightgcn_batch_kernel_equals_the_three_launch_sequence(G, golden, epini
 
 def test_lightgcn_batch_kernel_hub_rows_and_a_non_symmetric_matrix(G, oracle):
     """The same launch on a NON-symmetric square matrix with rows beyond 1 024 entries (16 virtual waves chaining several
-    segments each), an empty row and a one-entry row among the batch's rows; the push runs over the rows of the transposed
-    handle.  Against the three-launch sequence on the same handles and against the oracle's pull-form product."""
+    segments each), an empty row and a one-entry row among the batch's rows.  The first backward product is A^T g: in push form
+    it walks the rows of A itself ((A^T g)[c] = sum_r A[r, c] g[r]), so the result must equal the oracle's PULL-form product on
+    the transposed CSR — what autograd computes for `torch.sparse.mm(A, x)` (round 2 pushed over the rows of the transposed
+    handle, i.e. computed A g: right only for a symmetric matrix).  Also against the three-launch sequence."""
     from spex_amd import ops
     rng = np.random.default_rng(5)
     n, n_u, L = 3000, 1000, 2
@@ -1011,7 +1013,7 @@ def test_lightgcn_batch_kernel_hub_rows_and_a_non_symmetric_matrix(G, oracle):
     rowptr, col, val = random_csr(rng, n, n, deg)
     val *= 0.05
     t_csr = oracle.csr_transpose(rowptr, col, val, n)
-    g, gt = G(rowptr, col, val), G(*t_csr[:3])
+    g = G(rowptr, col, val)
     X = t((rng.normal(size=(n, 64)) * 0.3).astype(np.float32))
     run = t((rng.normal(size=(n, 64)) * 0.3).astype(np.float32))
     users = rng.integers(0, n_u, 64)
@@ -1026,16 +1028,18 @@ def test_lightgcn_batch_kernel_hub_rows_and_a_non_symmetric_matrix(G, oracle):
     loss_a, g_out_a, G_a = torch.zeros(1, device=DEV), torch.zeros(n, 64, device=DEV), torch.zeros(n, 64, device=DEV)
     ops.score_bce(lo[:n_u], lo[n_u:], u_d, i_d, y_d, loss_sum=loss_a, grad_users=g_out_a[:n_u], grad_items=g_out_a[n_u:],
                   grad_scale=1.0 / 64, grad_slots=slots)
-    ops.spmm_push_batch(gt, u_d, i_d, n_u, slots, G_a, add=slots, scale=1.0 / (L + 1))
+    ops.spmm_push_batch(g, u_d, i_d, n_u, slots, G_a, add=slots, scale=1.0 / (L + 1))
     loss_b, g_out_b, G_b = torch.zeros(1, device=DEV), torch.zeros(n, 64, device=DEV), torch.zeros(n, 64, device=DEV)
-    ops.lightgcn_batch(g, gt, X, run, float(L + 1), u_d, i_d, y_d, n_u, 1.0 / 64, 1.0 / (L + 1), loss_b, g_out_b, G_b)
+    ops.lightgcn_batch(g, X, run, float(L + 1), u_d, i_d, y_d, n_u, 1.0 / 64, 1.0 / (L + 1), loss_b, g_out_b, G_b)
     assert abs(loss_a.item() - loss_b.item()) <= 1e-5 * abs(loss_a.item())
     assert rel_err(g_out_b.cpu().numpy(), g_out_a.cpu().numpy()) <= 3e-6
     assert rel_err(G_b.cpu().numpy(), G_a.cpu().numpy()) <= 3e-6
     gd = g_out_b.cpu().numpy()
-    # out[c] += val[e] * g[r] over the entries e = (r, c) of gt  <=>  out = gt^T g = A g
-    want_G = (gd.astype(np.float64) + oracle.spmm(rowptr, col, val, gd).astype(np.float64)) / (L + 1)
+    # out[c] += val[e] * g[r] over the entries e = (r, c) of A  <=>  out = A^T g: the oracle's pull form on the transposed CSR
+    want_G = (gd.astype(np.float64) + oracle.spmm(*t_csr[:3], gd).astype(np.float64)) / (L + 1)
     assert rel_err(G_b.cpu().numpy(), want_G) <= 1e-5
+    not_sym = (gd.astype(np.float64) + oracle.spmm(rowptr, col, val, gd).astype(np.float64)) / (L + 1)
+    assert rel_err(not_sym, want_G) > 1e-2                                   # the matrix really is not symmetric
 
 
 def test_gated_batch_forward_equals_the_three_launch_sequence(G, golden, epinion2):
@@ -1084,8 +1088,7 @@ def test_batch_kernels_small_batches_and_degenerate_rows(G, oracle, B):
     deg[n_u], deg[n_u + 1], deg[n_u + 2] = 0, 65, 64
     rowptr, col, val = random_csr(rng, n, n, deg)
     val *= 0.1
-    t_csr = oracle.csr_transpose(rowptr, col, val, n)
-    g, gt = G(rowptr, col, val), G(*t_csr[:3])
+    g = G(rowptr, col, val)
     X = t((rng.normal(size=(n, 64)) * 0.3).astype(np.float32))
     run = t((rng.normal(size=(n, 64)) * 0.3).astype(np.float32))
     raw = t((rng.normal(size=(n, 64)) * 0.3).astype(np.float32))
@@ -1101,9 +1104,9 @@ def test_batch_kernels_small_batches_and_degenerate_rows(G, oracle, B):
     g_out_a, G_a = torch.zeros(n, 64, device=DEV), torch.zeros(n, 64, device=DEV)
     ops.score_bce(lo[:n_u], lo[n_u:], u_d, i_d, y_d, loss_sum=loss_a, grad_users=g_out_a[:n_u], grad_items=g_out_a[n_u:],
                   grad_scale=1.0 / B, grad_slots=slots)
-    ops.spmm_push_batch(gt, u_d, i_d, n_u, slots, G_a, add=slots, scale=1.0 / (L + 1))
+    ops.spmm_push_batch(g, u_d, i_d, n_u, slots, G_a, add=slots, scale=1.0 / (L + 1))
     loss_b, g_out_b, G_b = torch.zeros(1, device=DEV), torch.zeros(n, 64, device=DEV), torch.zeros(n, 64, device=DEV)
-    ops.lightgcn_batch(g, gt, X, run, float(L + 1), u_d, i_d, y_d, n_u, 1.0 / B, 1.0 / (L + 1), loss_b, g_out_b, G_b)
+    ops.lightgcn_batch(g, X, run, float(L + 1), u_d, i_d, y_d, n_u, 1.0 / B, 1.0 / (L + 1), loss_b, g_out_b, G_b)
     assert abs(loss_a.item() - loss_b.item()) <= 1e-5 * abs(loss_a.item()) + 1e-7
     assert rel_err(g_out_b.cpu().numpy(), g_out_a.cpu().numpy()) <= 3e-6
     assert rel_err(G_b.cpu().numpy(), G_a.cpu().numpy()) <= 3e-6

@@ -269,6 +269,27 @@ def test_epoch_order_is_the_dataloaders_own(tiny_loader):
         assert np.array_equal(got, want[epoch].numpy())
 
 
+def test_reference_stream_dropout_mask_is_the_references_draw(golden):
+    """The "reference" edge-dropout stream (dropin LightGCN.dropout_stream / trainer.edge_dropout_mask) replays model.py:50:
+    after the reference's set-up — set_seed(2020), both nn.Embedding constructions + xavier_uniform_ (model.py:32-35), the
+    shuffled DataLoader's two seed draws (main_rec.py:30) — the first `torch.rand(nnz) + keep_prob` gives the keep mask the
+    REFERENCE drew at step 0 of `main_rec.py --dropout 1 --keepprob 0.3` on Epinion2 (G12-dropout golden: sha-256, kept count,
+    first 4 096 bits).  CPU only: this is the host half of the validation mode; the GPU tests replay the whole run."""
+    import utility1.utils as utils
+    from torch import nn
+    from spex_amd.trainer import dataloader_epoch_order
+    g = golden("lightgcn_epinion2_dropout")
+    utils.set_seed(int(g["seed"]))
+    eu, ei = nn.Embedding(3186, 64), nn.Embedding(12407, 64)
+    nn.init.xavier_uniform_(eu.weight, gain=1)
+    nn.init.xavier_uniform_(ei.weight, gain=1)
+    dataloader_epoch_order(6 * 209304)
+    keep = (torch.rand(int(g["nnz"])) + float(g["keepprob"])).int().bool().numpy()
+    assert int(keep.sum()) == int(g["mask0_kept"])
+    assert np.array_equal(keep[:4096], g["mask0_head"])
+    assert sha(keep.astype(np.uint8)) == str(g["mask0_sha"])
+
+
 # ---------------------------------------------------------------------------------------------- NGCF host modules (config 4)
 def _write_ngcf_files(root, name, pairs, test_pos, test_neg):
     rec = os.path.join(root, name, "rec")
