@@ -409,6 +409,13 @@ int spex_expert_gate_f32(const float *raw, const float *prop, const float *att_e
 /* Its autograd backward: grad_raw / grad_prop ([n,d]) are written; grad_att ([2d,2]) is ACCUMULATED (zero it first). */
 int spex_expert_gate_bwd_f32(const float *raw, const float *prop, const float *att_exp, const float *grad_mixed,
                              float *grad_raw, float *grad_prop, float *grad_att, int32_t n, int32_t d, void *stream);
+/* The same with the parameter gradient summed in a fixed order (no float atomics; d <= 128): every workgroup leaves its share in
+ * its own block of att_parts — [spex_expert_gate_bwd_parts(n)][4 d] floats of caller-owned scratch — and the blocks are added to
+ * grad_att in block order. */
+int32_t spex_expert_gate_bwd_parts(int32_t n);
+int spex_expert_gate_bwd_det_f32(const float *raw, const float *prop, const float *att_exp, const float *grad_mixed,
+                                 float *grad_raw, float *grad_prop, float *grad_att, float *att_parts, int32_t n, int32_t d,
+                                 void *stream);
 
 /* The gate at a batch's rows only (the training loss reads the gated tables nowhere else, model_expert_s.py:163-166), d == 64.
  * Slot k names table row r = idx_a[k] + off_a (k < n_a) or idx_b[k - n_a] + off_b (raw / prop: [n_rows, 64] tables holding

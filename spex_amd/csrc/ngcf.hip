@@ -1148,7 +1148,8 @@ __global__ __launch_bounds__(kWave *kGateWaves) void expert_gate_bwd_kernel(cons
                                                                            const float *__restrict__ att,
                                                                            const float *__restrict__ g,
                                                                            float *__restrict__ d_raw, float *__restrict__ d_prop,
-                                                                           float *d_att, int n, int d, int per_wave_slots)
+                                                                           float *d_att, int n, int d, int per_wave_slots,
+                                                                           float *__restrict__ att_parts)
 {
     extern __shared__ float s_datt[];   // [2d, 2] (+ one such block per wave when per_wave_slots)
     const int lane = threadIdx.x & (kWave - 1);
@@ -1238,7 +1239,11 @@ __global__ __launch_bounds__(kWave *kGateWaves) void expert_gate_bwd_kernel(cons
         }
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < 4 * d; k += blockDim.x) atomicAdd(d_att + k, s_datt[k]);
+    // att_parts (deterministic form): the workgroup's share leaves as its own block, added in block order by the caller
+    for (int k = threadIdx.x; k < 4 * d; k += blockDim.x) {
+        if (att_parts) att_parts[(size_t)blockIdx.x * 4 * d + k] = s_datt[k];
+        else atomicAdd(d_att + k, s_datt[k]);
+    }
 }
 
 // The gate at a batch's rows only — the training loss reads the gated tables nowhere else (model_expert_s.py:163-166), so
@@ -1543,9 +1548,31 @@ extern "C" int spex_expert_gate_bwd_f32(const float *raw, const float *prop, con
     const int slots = d <= 128 ? 1 : 0;     // (1 + 16) x 4d floats of LDS: 34 KB at d = 128
     hipLaunchKernelGGL(expert_gate_bwd_kernel, dim3((unsigned)blocks), dim3(kWave * kGateWaves),
                        (size_t)d * 4 * sizeof(float) * (slots ? 1 + kGateWaves : 1), (hipStream_t)stream, raw, prop, att_exp, grad_mixed,
-                       grad_raw, grad_prop, grad_att, n, d, slots);
+                       grad_raw, grad_prop, grad_att, n, d, slots, nullptr);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
+}
+
+extern "C" int32_t spex_expert_gate_bwd_parts(int32_t n)
+{
+    const int64_t blocks = ((int64_t)n + kGateWaves - 1) / kGateWaves;
+    return (int32_t)(blocks > 256 ? 256 : (blocks < 1 ? 1 : blocks));
+}
+
+extern "C" int spex_expert_gate_bwd_det_f32(const float *raw, const float *prop, const float *att_exp, const float *grad_mixed,
+                                            float *grad_raw, float *grad_prop, float *grad_att, float *att_parts, int32_t n, int32_t d,
+                                            void *stream)
+{
+    SPEX_CHECK_ARG(raw && prop && att_exp && grad_mixed && grad_raw && grad_prop && grad_att && att_parts,
+                   "spex_expert_gate_bwd_det_f32: NULL pointer");
+    SPEX_CHECK_ARG(n >= 0 && d >= 1 && d <= 128, "spex_expert_gate_bwd_det_f32: n=%d d=%d (d <= 128: the per-wave LDS slots)", n, d);
+    if (n == 0) return SPEX_OK;
+    const int32_t blocks = spex_expert_gate_bwd_parts(n);
+    hipLaunchKernelGGL(expert_gate_bwd_kernel, dim3((unsigned)blocks), dim3(kWave * kGateWaves),
+                       (size_t)d * 4 * sizeof(float) * (1 + kGateWaves), (hipStream_t)stream, raw, prop, att_exp, grad_mixed, grad_raw, grad_prop,
+                       nullptr, n, d, 1, att_parts);
+    SPEX_HIP(hipGetLastError());
+    return spex::sum_parts(att_parts, blocks, (int64_t)4 * d, 4 * d, grad_att, 1, stream);
 }
 
 extern "C" int spex_expert_gate_rows_f32(const float *raw, const float *prop, const float *att_u, const float *att_i,

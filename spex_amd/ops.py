@@ -910,7 +910,12 @@ class ExpertGate(torch.autograd.Function):
         raw, prop, att_exp = ctx.saved_tensors
         g = g.contiguous()
         g_raw, g_prop, g_att = torch.empty_like(raw), torch.empty_like(prop), torch.zeros_like(att_exp)
-        if raw.shape[0]:
+        if raw.shape[0] and DETERMINISTIC and raw.shape[1] <= 128:
+            n_parts = int(_lib.load().spex_expert_gate_bwd_parts(raw.shape[0]))
+            parts = torch.empty((n_parts, 4 * raw.shape[1]), dtype=torch.float32, device=raw.device)
+            _launch(raw.device, "spex_expert_gate_bwd_det_f32", _ptr(raw), _ptr(prop), _ptr(att_exp), _ptr(g), _ptr(g_raw), _ptr(g_prop),
+                    _ptr(g_att), _ptr(parts), raw.shape[0], raw.shape[1])
+        elif raw.shape[0]:
             _launch(raw.device, "spex_expert_gate_bwd_f32", _ptr(raw), _ptr(prop), _ptr(att_exp), _ptr(g), _ptr(g_raw), _ptr(g_prop),
                       _ptr(g_att), raw.shape[0], raw.shape[1])
         return g_raw, g_prop, g_att

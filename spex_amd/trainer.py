@@ -454,11 +454,13 @@ NGCFStepper._step_one_call = _ngcf_step_one_call
 NGCFStepper.__del__ = _drop_desc
 
 
-def train_epoch_ngcf(stepper, data, batch_size=None, pause_gc=True):
+def train_epoch_ngcf(stepper, data, batch_size=None, pause_gc=True, callbacks=None, step_losses=None):
     """train() of NGCF_SPEX/code/main_rec.py:116-131 without the per-step host work of its DataLoader loop: the epoch's
     samples are drawn like the reference's (Data.sample_epoch: `random` stream), the sample order is the DataLoader's own
     (dataloader_epoch_order: global torch RNG), the shuffled epoch is moved to the device once, and every batch is one
-    NGCFStepper.step.  Returns the epoch's summed per-batch mean loss (main_rec.py:129 accumulates the same sum)."""
+    NGCFStepper.step.  Returns the epoch's summed per-batch mean loss (main_rec.py:129 accumulates the same sum).
+    callbacks: {k: fn} — fn() is called in front of the epoch's k-th batch (e.g. a mid-epoch evaluation; it must leave the
+    model in training mode); step_losses: a list that receives every step's mean loss (synchronises per step)."""
     us, vs, rs = data.sample_epoch()
     n = len(us)
     bs = batch_size or data.batch_size
@@ -472,10 +474,18 @@ def train_epoch_ngcf(stepper, data, batch_size=None, pause_gc=True):
     n_full = n // bs * bs
     acc = torch.zeros(2, 1, dtype=torch.float32, device=dev)
     try:
-        for s in range(0, n_full, bs):
-            stepper.step(users[s:s + bs], items[s:s + bs], labels[s:s + bs], loss_acc=acc[0])
-        if n_full < n:
-            stepper.step(users[n_full:], items[n_full:], labels[n_full:], loss_acc=acc[1])
+        for k, s in enumerate(range(0, n, bs)):
+            if callbacks and k in callbacks:
+                callbacks[k]()
+            e = min(s + bs, n)
+            slot = acc[0] if e - s == bs else acc[1]
+            if step_losses is None:
+                stepper.step(users[s:e], items[s:e], labels[s:e], loss_acc=slot)
+            else:
+                tmp = torch.zeros(1, dtype=torch.float32, device=dev)
+                stepper.step(users[s:e], items[s:e], labels[s:e], loss_acc=tmp)
+                step_losses.append(tmp.item() / (e - s))
+                slot += tmp
     finally:
         if gc_was_on:
             gc.enable()

@@ -229,21 +229,12 @@ def _run_reference_loop(ds, n_epochs, g, root, metric_tol=1e-4):
             total += li
             step += 1
             maybe_eval()
-        # The epoch's loss sum is a 4 712-step trajectory, not a function value: two mints of the same REFERENCE run gave
-        # 2048.4765 and 2048.3812 (5e-5 apart), and the GPU's run-to-run spread (float atomics reorder the row-gradient sums;
-        # Adam amplifies rounding noise along NGCF's scale-invariant weight direction, see below) reached 2.3e-4 once in eight
-        # runs of this test (typically < 1e-4).  The tight gates are the per-step losses above (2e-5, first 32 steps) and the
-        # small graph's three epochs (1e-4 in everything, test_ngcf_driver_runs_through_the_launcher).
-        assert abs(total - g["losses"][epoch]) <= 5e-4 * g["losses"][epoch], (epoch, total, g["losses"][epoch])
+        assert abs(total - g["losses"][epoch]) <= 1e-4 * g["losses"][epoch], (epoch, total, g["losses"][epoch])
         ret = batch_test.test(model, list(data.test_set.keys()), drop_flag=True)
         drift[("epoch", epoch)] = float(max(np.abs(ret["recall"] - g["recall"][epoch]).max(), np.abs(ret["ndcg"] - g["ndcg"][epoch]).max()))
     print("metric drift vs the reference run:", drift)
-    # The evaluation path itself is pinned at the seeded initial weights (step 0: HR / NDCG within 1e-4, the north-star
-    # gate).  Later checkpoints compare two fp32 training runs whose sums are associated differently (MKL GEMM / ATen
-    # sparse addmm vs MFMA k-order chains and float atomics): the parameters drift apart slowly (checked below) and the
-    # ranking metric moves by a few users out of 3 185 (one user = 3e-4).
     for key, dv in drift.items():
-        assert dv <= (1e-4 if key == 0 or ds == "small" else metric_tol), (key, dv)
+        assert dv <= metric_tol, (key, dv)
     assert step == int(g["n_steps"])
     return model
 
@@ -288,30 +279,151 @@ def test_on_device_ngcf_epochs_match_the_reference_small(golden, ngcf_data_root)
     assert st.t == int(g["n_steps"]) and model.dropout_step == int(g["n_steps"])
 
 
+def _ngcf_epinion2_model(g, root):
+    from spex_amd.dropin.ngcf.utility import batch_test
+    from spex_amd.dropin.ngcf.utility.load_data import Data
+    from spex_amd.ngcf import NGCF
+    torch.manual_seed(int(g["seed"])); random.seed(int(g["seed"])); np.random.seed(int(g["seed"]))
+    data = Data(path=root + "epinion2", batch_size=256)
+    batch_test.use_data(data)
+    _, norm, _ = data.get_adj_mat()
+    model = NGCF({"n_users": data.n_users, "n_items": data.n_items, "norm_adj": norm}, DEV,
+                 ngcf_args(mess_dropout=str([float(x) for x in g["mess_dropout"]]))).to(DEV)
+    model.message_dropout_seed = int(g["drop_seed"])
+    return data, model, batch_test
+
+
+def _unit(w):
+    w = np.asarray(w, np.float64)
+    return w / np.sqrt((w ** 2).sum())
+
+
 def test_whole_ngcf_epoch_matches_the_reference_epinion2(golden, ngcf_data_root):
-    """The same at BASELINE config 4's size: one full NGCF epoch on Epinion2 (~4.7 k steps) + test()."""
-    path = os.path.join(REPO, "tests", "golden", "ngcf_epinion2_epochs.npz")
-    if not os.path.exists(path):
-        pytest.skip("ngcf_epinion2_epochs.npz not minted")
-    g = golden("ngcf_epinion2_epochs")
-    # metric gate at the later checkpoints: 8e-3 = 25 of 3 185 users.  Typical drift is 0.5-2.5e-3; 4.08e-3 was seen once in eleven
-    # runs at step 1 500 (run-to-run: float atomics reorder the gradient sums, the trajectories diverge slowly) — the evaluation path
-    # itself is pinned at 1e-4 on the seeded initial weights (step 0) inside the loop
-    model = _run_reference_loop("epinion2", 1, g, ngcf_data_root, metric_tol=8e-3)
+    """One full NGCF epoch on Epinion2 (BASELINE config 4's size: 4 757 Adam steps, message dropout on) + test() at steps 0 /
+    500 / 1 500 / end, through the on-device loop with the DETERMINISTIC step (trainer.train_epoch_ngcf +
+    NGCFStepper(deterministic=True)): the run is a pure function of the seeds — it repeats bit for bit
+    (tests/test_gpu_deterministic.py) — so its deviation from the reference's run is a FIXED number, not a distribution.
+
+    What can be expected of that number: the REFERENCE'S OWN run is not reproducible (torch's CPU index_put_(accumulate) and
+    threaded reductions; Adam amplifies the last bits along NGCF's scale-invariant weight direction) — two mints of the same
+    reference run (ngcf_epinion2_ref_spread.npz) differ by 1.0e-4 in the epoch's loss sum, by 4.5e-4 / 1.9e-3 / 8.2e-4 in
+    HR / NDCG at steps 500 / 1 500 / end, by 0.39 / 0.22 in the DIRECTION of W_gc / W_bi and by 0.22 / 0.12 in the table rows.
+    A trajectory can therefore be pinned no tighter than that (measured for this build's deterministic run against mint b:
+    1.1e-4, 3.1e-4 / 2.2e-3 / 1.9e-3, 0.50 / 0.24, 0.17 / 0.18 — as far from either mint as they are from each other); what IS
+    pinned to the north-star gates is the FUNCTION at the reference's own trained weights (test_ngcf_teacher_forced_checkpoints:
+    loss 2e-5, gradients 5e-5, HR / NDCG 1e-4 at steps 500 / 1 500 / end), the first 32 per-step losses (2e-5) and the
+    evaluation at step 0 (1e-4).  Every trajectory gate below is TWICE THE REFERENCE'S OWN run-to-run spread in the same
+    measure (for the ranking metrics: of the largest spread it shows at any evaluated step — the drift is not monotone)."""
+    from spex_amd.trainer import NGCFStepper, train_epoch_ngcf
+    g, sp = golden("ngcf_epinion2_epochs"), golden("ngcf_epinion2_ref_spread")
+    ref_loss_spread = abs(sp["losses_a"][0] - sp["losses_b"][0]) / sp["losses_b"][0]
+    ref_metric_spread = {int(k): float(v) for k, v in zip(sp["eval_steps"], np.abs(sp["eval_metrics_a"] - sp["eval_metrics_b"]).max(1))}
+    ref_end_spread = float(max(np.abs(sp["recall_a"] - sp["recall_b"]).max(), np.abs(sp["ndcg_a"] - sp["ndcg_b"]).max()))
+    ref_metric_max = max(max(ref_metric_spread.values()), ref_end_spread)
+    ref_dir = {k: float(np.abs(_unit(sp["final_" + k + "_a"]) - _unit(sp["final_" + k + "_b"])).max() / np.abs(_unit(sp["final_" + k + "_b"])).max())
+               for k in ("GC_Linear_list__0__weight", "Bi_Linear_list__0__weight")}
+    ref_rows = {"user_rows": rel_err(sp["user_w_a"], sp["user_w_b"]), "item_rows": rel_err(sp["item_w_a"], sp["item_w_b"])}
+    data, model, batch_test = _ngcf_epinion2_model(g, ngcf_data_root)
+    users_to_test = list(data.test_set.keys())
+    for k in g.files:                                                     # same initial parameters for the same seed
+        if k.startswith("init_") and not k.endswith("_sha"):
+            assert rel_err(model.state_dict()[k[5:].replace("__", ".")].cpu().numpy(), g[k]) == 0.0, k
+    st = NGCFStepper(model, lr=float(g["lr"]), deterministic=True)
+    eval_at = {int(k): v for k, v in zip(g["eval_steps"], g["eval_metrics"])}
+    drift = {}
+
+    def make_eval(step):
+        def fn():
+            r = batch_test.test(model, users_to_test, drop_flag=True)
+            drift[step] = float(np.abs(np.concatenate([r["recall"], r["ndcg"]]) - eval_at[step]).max())
+            model.train()
+        return fn
+    step_losses = []
+    model.train()
+    total = train_epoch_ngcf(st, data, callbacks={k: make_eval(k) for k in eval_at}, step_losses=step_losses).item()
+    assert st.t == int(g["n_steps"]) and model.dropout_step == int(g["n_steps"])
+    first = np.abs(np.asarray(step_losses[:len(g["step_losses"])]) - g["step_losses"])
+    assert first.max() <= 2e-5, (int(first.argmax()), float(first.max()))               # the function, step by step
+    loss_dev = abs(total - g["losses"][0]) / g["losses"][0]
+    ret = batch_test.test(model, users_to_test, drop_flag=True)
+    end_dev = float(max(np.abs(ret["recall"] - g["recall"][0]).max(), np.abs(ret["ndcg"] - g["ndcg"][0]).max()))
     sd = model.state_dict()
     uw, iw = sd["user_embedding.weight"].cpu().numpy(), sd["item_embedding.weight"].cpu().numpy()
-    dev = {"user_colsum": float(np.abs(uw.astype(np.float64).sum(0) - g["user_w_colsum"]).max() / np.abs(g["user_w_colsum"]).max()),
-           "item_colsum": float(np.abs(iw.astype(np.float64).sum(0) - g["item_w_colsum"]).max() / np.abs(g["item_w_colsum"]).max()),
-           "user_rows": rel_err(uw[g["rows_u"]], g["user_w"]), "item_rows": rel_err(iw[g["rows_i"]], g["item_w"]),
-           "W_gc": rel_err(sd["GC_Linear_list.0.weight"].cpu().numpy(), g["final_GC_Linear_list__0__weight"])}
-    print("trained-parameter drift vs the reference run after 4.7 k Adam steps:", dev)
-    # Reported, not gated: what the two runs share is the FUNCTION (per-step losses to 2e-5 for the first 32 steps, the
-    # epoch's loss sum to 1e-4, HR / NDCG to a few users), not the parameters.  NGCF's output is invariant to a joint positive
-    # rescaling of (W_gc, b_gc, W_bi, b_bi) — LeakyReLU is positively homogeneous and the layer output is L2-normalised — so
-    # the gradient along that direction is zero up to rounding, and Adam turns rounding noise into +-lr steps: the weights
-    # random-walk by ~sqrt(4700) * 1e-3 along it (measured: W_gc differs by 0.6 of its largest entry, rows of the tables by
-    # 0.1-0.4) while every loss agrees.  (LightGCN has no such direction: its epoch's tables agree to 1e-4.)
-    assert all(np.isfinite(v) for v in dev.values())
+    # parameters modulo NGCF's scale direction: the layer output is invariant to a joint positive rescaling of (W_gc, b_gc, W_bi,
+    # b_bi) — LeakyReLU is positively homogeneous and the output is L2-normalised — so only the DIRECTION of the weights is
+    # determined by the loss; table rows are compared after normalising each row (what scoring reads through the layer)
+    dirs = {k: float(np.abs(_unit(sd[k.replace("__", ".")].cpu().numpy()) - _unit(g["final_" + k])).max() / np.abs(_unit(g["final_" + k])).max())
+            for k in ("GC_Linear_list__0__weight", "Bi_Linear_list__0__weight")}
+    rows = {"user_rows": rel_err(uw[g["rows_u"]], g["user_w"]), "item_rows": rel_err(iw[g["rows_i"]], g["item_w"])}
+    print("deterministic NGCF epoch vs the reference run: loss sum dev %.2e (reference's own spread %.2e), metric dev %s / end %.2e "
+          "(reference's own %s / %.2e), weight directions %s (reference's own %s), table rows %s (reference's own %s)"
+          % (loss_dev, ref_loss_spread, drift, end_dev, ref_metric_spread, ref_end_spread, dirs, ref_dir, rows, ref_rows))
+    assert drift[0] <= 1e-4                                                              # the evaluation path, seeded weights
+    assert loss_dev <= 2 * ref_loss_spread, (loss_dev, ref_loss_spread)
+    for k, dv in drift.items():
+        if k:
+            assert dv <= 2 * ref_metric_max, (k, dv, ref_metric_max)
+    assert end_dev <= 2 * ref_metric_max, (end_dev, ref_metric_max)
+    for k in dirs:
+        assert dirs[k] <= 2 * ref_dir[k], (k, dirs[k], ref_dir[k])
+    for k in rows:
+        assert rows[k] <= 2 * ref_rows[k], (k, rows[k], ref_rows[k])
+
+
+@pytest.mark.parametrize("tag", ["ckpt500", "ckpt1500", "ckptend"])
+def test_ngcf_teacher_forced_checkpoints(golden, ngcf_data_root, tag):
+    """Teacher forcing at TRAINED weights: the reference's full parameter state in front of steps 500 / 1 500 and at the end of
+    its Epinion2 epoch (oracle/gen_golden.py --stage ngcf-epochs-epinion2 -> ngcf_epinion2_ckpt.npz: every parameter in fp32,
+    that step's batch and dropout step, its loss, its gradients — weights in full, tables as sampled rows + column sums +
+    Frobenius norm —, and the reference's test() at that state).  Loaded into the GPU model: ONE forward / backward on the same
+    batch with the same dropout mask -> loss <= 2e-5, gradients <= 5e-5; the same step through the one-call stepper (both
+    accumulation modes) -> loss <= 2e-5; test() -> HR / NDCG @ {10, 20, 50} <= 1e-4.  Unlike a trajectory, this pins the
+    function the two implementations compute after hundreds / thousands of Adam steps."""
+    from spex_amd.trainer import NGCFStepper
+    g = golden("ngcf_epinion2_ckpt")
+    data, model, batch_test = _ngcf_epinion2_model(g, ngcf_data_root)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            p.copy_(torch.from_numpy(g[f"{tag}_state_" + name.replace(".", "__")]))
+    user, item, labels = (torch.from_numpy(g[f"{tag}_batch"][k]) for k in range(3))
+    want_loss = float(g[f"{tag}_loss"])
+    # ---- forward / backward through the drop-in model (autograd Functions on the HIP kernels)
+    model.train()
+    model.dropout_step = int(g[f"{tag}_drop_step"])
+    model.zero_grad()
+    loss = model(user=user.to(DEV), item=item.to(DEV), labels_list=labels.float().to(DEV), flag=0)
+    loss.backward()
+    assert abs(loss.item() - want_loss) <= 2e-5, (loss.item(), want_loss)
+    for name, p in model.named_parameters():
+        key = f"{tag}_grad_" + name.replace(".", "__")
+        got = p.grad.cpu().numpy()
+        if key + "_rows" in g.files:                                     # the two tables
+            fro = float(g[key + "_fro"])
+            assert abs(np.sqrt((got.astype(np.float64) ** 2).sum()) - fro) <= 5e-5 * fro, name
+            cs = g[key + "_colsum"]
+            assert np.abs(got.astype(np.float64).sum(0) - cs).max() <= 5e-5 * max(np.abs(cs).max(), 1e-6), name
+            got = got[g[key + "_rows"]]
+        assert rel_err(got, g[key]) <= 5e-5, (name, rel_err(got, g[key]))
+    # ---- the same step through the one-call stepper, both accumulation modes (the loss is read before anything is updated)
+    for det in (False, True):
+        with torch.no_grad():
+            for name, p in model.named_parameters():
+                p.copy_(torch.from_numpy(g[f"{tag}_state_" + name.replace(".", "__")]))
+        model.dropout_step = int(g[f"{tag}_drop_step"])
+        st = NGCFStepper(model, lr=float(g["lr"]), deterministic=det)
+        acc = torch.zeros(1, device=DEV)
+        st.step(user.to(DEV), item.to(DEV), labels.float().to(DEV), loss_acc=acc)
+        assert abs(acc.item() / len(user) - want_loss) <= 2e-5, (det, acc.item() / len(user), want_loss)
+    # ---- evaluation at the reference's trained weights: the north-star gate
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            p.copy_(torch.from_numpy(g[f"{tag}_state_" + name.replace(".", "__")]))
+    model.eval()
+    step = {"ckpt500": 500, "ckpt1500": 1500, "ckptend": int(g["n_steps"])}[tag]
+    want = g["eval_metrics"][list(g["eval_steps"]).index(step)]
+    ret = batch_test.test(model, list(data.test_set.keys()), drop_flag=True)
+    got = np.concatenate([ret["recall"], ret["ndcg"]])
+    assert np.abs(got - want).max() <= 1e-4, (got, want)
 
 
 def test_fused_spmm_and_layer_equals_the_two_launches(epinion2):
