@@ -889,7 +889,7 @@ def stage_trust_epinion2():
     print("trust epinion2: loss1 %.6f loss2 %.6f test5 %s" % (loss1.item(), loss2.item(), out["trust_test5"]))
 
 
-def stage_epochs_dual_epinion2(n_steps=600, full_epoch=False):
+def stage_epochs_dual_epinion2(n_steps=600, full_epoch=False, fixed_weights=False):
     """G13 at Epinion2 scale: main_auto_expert_s.py:22-91 executed with the reference's modules on the Epinion2 graph and
     the reference-minted trust paths, for the first `n_steps` batches of epoch 0 (a full epoch is 4 906 batches; the
     dual-task step costs ~1.5 s of reference CPU time), then Test() (:98-114: rec_test over all 3 185 test users +
@@ -922,6 +922,10 @@ def stage_epochs_dual_epinion2(n_steps=600, full_epoch=False):
     train_data2 = Data(raw_train, dataset.n_users, shuffle=False)                   # :47-48
     test_data2 = Data(raw_test, dataset.n_users, shuffle=False, test=True)
     trust_batch_size = len(path) // len(train_loader)                               # :49
+    # fixed_weights: the same run as main_11.py drives it (:56-69): at most trust_batch_size paths per batch (not 3 x) and
+    # loss = loss1 + loss2 — task_weights get no gradient and stay where they are
+    cap_paths = trust_batch_size if fixed_weights else trust_batch_size * 3
+    out_name = "dual11_epinion2_epochs.npz" if fixed_weights else "dual_epinion2_epochs.npz"
     Recmodel = ref_ex.LightGCN(args, dataset).to(device)                            # :51-52
     optimizer = torch.optim.Adam(Recmodel.parameters(), lr=args.lr)
     out = dict(n_paths=[], loss1_first=[], loss2_first=[], loss1_cum=[], loss2_cum=[])
@@ -974,7 +978,7 @@ def stage_epochs_dual_epinion2(n_steps=600, full_epoch=False):
         iw = Recmodel.embedding_item.weight.detach().numpy()
         rows_u = np.sort(np.random.default_rng(1).choice(uw.shape[0], 256, replace=False))
         rows_i = np.sort(np.random.default_rng(2).choice(iw.shape[0], 256, replace=False))
-        np.savez_compressed(os.path.join(GOLD, "dual_epinion2_epochs.npz"), seed=args.seed, n_steps=n_steps,
+        np.savez_compressed(os.path.join(GOLD, out_name), seed=args.seed, n_steps=n_steps,
                             trust_batch_size=trust_batch_size, steps_per_epoch=len(train_loader),
                             **{k: np.asarray(v, np.float64) for k, v in out.items()}, task_weights=tw,
                             rec_recall=ret["recall"], rec_ndcg=ret["ndcg"], trust=trust,
@@ -997,8 +1001,8 @@ def stage_epochs_dual_epinion2(n_steps=600, full_epoch=False):
         path_index = []
         for u in unique_user:
             path_index.extend(user_path_indx[u])
-        if len(path_index) > trust_batch_size * 3:
-            path_index = random.sample(path_index, trust_batch_size * 3)
+        if len(path_index) > cap_paths:
+            path_index = random.sample(path_index, cap_paths)
         out["n_paths"].append(len(path_index))
         loss1, loss2 = Recmodel(users=user.to(device), items=item.to(device), labels=label.to(device),
                                 slice_indices=np.array(list(path_index), dtype=int), trust_data=train_data2, flag=0)
@@ -1007,14 +1011,17 @@ def stage_epochs_dual_epinion2(n_steps=600, full_epoch=False):
         precision2 = torch.exp(-2 * Recmodel.task_weights[1])
         loss = precision1 * loss1 + precision2 * loss2 + 2 * (n_rec + 1) * T_rec * Recmodel.task_weights[0] \
             + T * Recmodel.task_weights[1]
+        if fixed_weights:
+            loss = loss1 + loss2                                                      # main_11.py:69
         loss.backward()
         if first is None:
             first = (np.stack([user.numpy(), item.numpy(), label.numpy()]), list(path_index))
         if step == n_steps:
             take_checkpoint("ckpt%d" % step, np.stack([user.numpy(), item.numpy(), label.numpy()]), path_index,
                             loss1.item(), loss2.item())
-            np.savez_compressed(os.path.join(GOLD, "dual_epinion2_ckpt.npz"), seed=args.seed, ckpt_step=n_steps,
-                                metrics_rec=np.concatenate([ret600["recall"], ret600["ndcg"]]), metrics_trust=trust600, **ckpt)
+            if not fixed_weights:
+                np.savez_compressed(os.path.join(GOLD, "dual_epinion2_ckpt.npz"), seed=args.seed, ckpt_step=n_steps,
+                                    metrics_rec=np.concatenate([ret600["recall"], ret600["ndcg"]]), metrics_trust=trust600, **ckpt)
             if not full_epoch:
                 break
         if step < n_steps:
@@ -1344,6 +1351,8 @@ def main():
         stage_trust_epinion2()
     elif a.stage == "epochs-dual-epinion2":  # ~20 min of CPU: 600 dual-task steps + both evaluations through the reference
         stage_epochs_dual_epinion2()
+    elif a.stage == "epochs-dual11-epinion2":      # ~2 min of CPU: 300 steps of the fixed-weights driver (main_11.py) + both evaluations
+        stage_epochs_dual_epinion2(n_steps=300, fixed_weights=True)
     elif a.stage == "epochs-dual-epinion2-full":  # ~2.5 h of CPU: the same run continued to the end of epoch 0 (4 906 steps)
         stage_epochs_dual_epinion2(full_epoch=True)
     elif a.stage == "epochs-epinion2":      # ~25 min of CPU: one full Epinion2 epoch + test() through the reference

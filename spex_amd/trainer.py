@@ -655,11 +655,14 @@ def dual_task_epoch_paths(batch_users, by_user, cap):
     return chosen_all
 
 
-def train_epoch_dual(stepper, train_data, trust_data, by_user, cap, batch_size=256, resample=True, pause_gc=True, max_steps=None):
+def train_epoch_dual(stepper, train_data, trust_data, by_user, cap, batch_size=256, resample=True, pause_gc=True, max_steps=None,
+                     cum_every=None, cum_out=None, n_paths_out=None):
     """Train() of main_auto_expert_s.py:53-91 on the device: negatives drawn like the reference's (`ng_sample`), the
     epoch's sample order is the shuffled DataLoader's own, the per-batch paths are chosen by the reference's rule
     (dual_task_epoch_paths), everything is moved to the device once and every batch is one DualTaskStepper.step.
-    Returns (sum of loss1, sum of loss2) over the epoch's steps as a device tensor."""
+    Returns (sum of loss1, sum of loss2) over the epoch's steps as a device tensor.  cum_every / cum_out: every cum_every steps a
+    copy of the running (loss1, loss2) sums is appended to the list cum_out (device tensors: no synchronisation); n_paths_out: a
+    list that receives every step's path count."""
     import numpy as np
     if resample:
         train_data.ng_sample()
@@ -685,10 +688,14 @@ def train_epoch_dual(stepper, train_data, trust_data, by_user, cap, batch_size=2
         gc.disable()
     try:
         p0 = 0
-        for s, c in zip(starts, chosen):
+        for k, (s, c) in enumerate(zip(starts, chosen)):
             e, p1 = min(s + batch_size, n), p0 + len(c)
             stepper.step(users[s:e], items[s:e], labels[s:e], seq[p0:p1] if c else None, seq_l[p0:p1], tgt[p0:p1])
             p0 = p1
+            if cum_every and cum_out is not None and (k + 1) % cum_every == 0:
+                cum_out.append(stepper.loss_acc.clone())
+        if n_paths_out is not None:
+            n_paths_out.extend(len(c) for c in chosen)
     finally:
         if gc_was_on:
             gc.enable()

@@ -1014,3 +1014,146 @@ def test_dual_task_teacher_forced_checkpoint_epinion2(data_root, golden):
         ret = rec_test(net, dataset.testRatings, dataset.testNegatives)
         assert np.abs(np.concatenate([ret["recall"], ret["ndcg"]]) - g["metrics_rec"]).max() <= 1e-4
         assert np.abs(np.asarray(trust_test5(net, test2)) - g["metrics_trust"]).max() <= 1e-4
+
+
+def test_dual_task_full_epoch_matches_the_reference_epinion2(data_root, golden):
+    """G13, the WHOLE epoch: all 4 906 dual-task steps of main_auto_expert_s.py's epoch 0 on Epinion2 (oracle/gen_golden.py --stage
+    epochs-dual-epinion2-full, ~20 min of reference CPU time) through trainer.train_epoch_dual with the deterministic step: the
+    per-step path counts, both running loss sums every 100 steps, the learned task weights, rec_test + trust_test5 after the epoch,
+    the trained parameters — and, teacher-forced, both evaluations at the REFERENCE's end-of-epoch state (1e-4)."""
+    from collections import defaultdict
+    import utility1.dataloader as dl
+    from utility1.batch_test import rec_test
+    from utility2.batch_test_gnn import trust_test5
+    from utility2.utils import Data
+    from spex_amd.trainer import DualTaskStepper, train_epoch_dual
+    path = os.path.join(REPO, "tests", "golden", "dual_epinion2_full_epoch.npz")
+    if not os.path.exists(path):
+        pytest.skip("dual_epinion2_full_epoch.npz not minted")
+    g = golden("dual_epinion2_full_epoch")
+    raw_train, raw_test = _epinion2_trust_raw(golden)
+    args, dataset, net = _dual_epinion2(data_root)
+    td = dl.LightTrainData(dataset.rec_train_data, dataset.m_item, dataset.train_mat)
+    by_user = defaultdict(list)
+    for k, p in enumerate(raw_train[0]):
+        by_user[p[0]].append(k)
+    train2, test2 = Data(raw_train, dataset.n_users, shuffle=False), Data(raw_test, dataset.n_users, shuffle=False, test=True)
+    cap = 3 * int(g["trust_batch_size"])
+    net = net.to(DEV)
+    st = DualTaskStepper(net, path_capacity=cap, path_len=train2.len_max, lr=args.lr, deterministic=True)
+    cum, n_paths = [], []
+    totals = train_epoch_dual(st, td, train2, by_user, cap, cum_every=100, cum_out=cum, n_paths_out=n_paths).cpu().numpy()
+    assert st.t == int(g["n_steps"]) and np.array_equal(np.asarray(n_paths), g["n_paths"])
+    cum = torch.stack(cum).cpu().numpy()
+    dev_cum = (np.abs(cum[:, 0] - g["loss1_cum"]) / g["loss1_cum"]).max(), (np.abs(cum[:, 1] - g["loss2_cum"]) / g["loss2_cum"]).max()
+    net.eval()
+    with torch.no_grad():
+        ret = rec_test(net, dataset.testRatings, dataset.testNegatives)
+        tr5 = np.asarray(trust_test5(net, test2))
+    tag = "ckptend"
+    par = {}
+    for name, p in net.named_parameters():
+        want = g[f"{tag}_state_" + name.replace(".", "__")].reshape(p.shape)
+        got = p.detach().cpu().numpy()
+        if name.endswith(".a"):                                   # attention vectors [2H, 1]: compare the a2 halves only
+            got, want = got[got.shape[0] // 2:], want[want.shape[0] // 2:]
+        par[name] = rel_err(got, want)
+    dev = dict(loss1=abs(totals[0] - float(g["loss1"])) / float(g["loss1"]), loss2=abs(totals[1] - float(g["loss2"])) / float(g["loss2"]),
+               cum1=float(dev_cum[0]), cum2=float(dev_cum[1]),
+               task_w=float(np.abs(net.task_weights.detach().cpu().numpy() - g["task_weights"]).max()),
+               rec=float(max(np.abs(ret["recall"] - g["rec_recall"]).max(), np.abs(ret["ndcg"] - g["rec_ndcg"]).max())),
+               trust=float(np.abs(tr5 - g["trust"]).max()), params=max(par.values()))
+    print("deterministic dual-task FULL epoch (4 906 steps), deviation from the reference's run:", dev, "worst parameter:",
+          max(par, key=par.get))
+    # measured on the MI355X (fixed numbers: the step is deterministic): loss sums 9e-7 / 1.6e-5 (running sums <= 2.3e-5), task
+    # weights 2.4e-6, rec HR / NDCG 2.7e-6 (no user of 3 185 changes rank), trust HR / NDCG 1.0e-3 = ONE of the 1 024 kept test
+    # paths across a top-K boundary after 4 906 steps (the metric's granularity is 9.8e-4); at the reference's own end-of-epoch
+    # parameters both evaluations agree to 1e-4 (below).  The a1 halves of the attention vectors are not compared: A.a1 cancels
+    # in the two-way softmax, their true gradient is zero, the reference's is 1e-8 noise that Adam turns into a random walk.
+    assert dev["loss1"] <= 5e-5 and dev["loss2"] <= 5e-5 and dev["cum1"] <= 5e-5 and dev["cum2"] <= 5e-5, dev
+    assert dev["task_w"] <= 2e-5 and dev["rec"] <= 1e-4 and dev["trust"] <= 1.1 / len(raw_test[0]), dev
+    # teacher forcing at the reference's own end-of-epoch parameters: both evaluations
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            p.copy_(torch.from_numpy(g[f"{tag}_state_" + name.replace(".", "__")]).reshape(p.shape))
+    net._cache = None
+    net.eval()
+    with torch.no_grad():
+        ret = rec_test(net, dataset.testRatings, dataset.testNegatives)
+        assert max(np.abs(ret["recall"] - g["rec_recall"]).max(), np.abs(ret["ndcg"] - g["rec_ndcg"]).max()) <= 1e-4
+        assert np.abs(np.asarray(trust_test5(net, test2)) - g["trust"]).max() <= 1e-4
+
+
+def test_fixed_task_weights_step_matches_main_11(data_root, golden):
+    """main_11.py — the second dual-task driver SURVEY 2 lists: loss = loss1 + loss2 (:69), at most trust_batch_size paths per
+    batch (:58-59) — through the one-call step with SPEX_STEP_FIXED_TASK_WEIGHTS (deterministic accumulation): the reference's
+    first 300 steps on Epinion2 (oracle/gen_golden.py --stage epochs-dual11-epinion2): path counts, per-step losses of the first
+    16 steps, running loss sums, both tasks' metrics, trained tables; task_weights stay at their initial zeros."""
+    from collections import defaultdict
+    import utility1.dataloader as dl
+    from utility1.batch_test import rec_test
+    from utility2.batch_test_gnn import trust_test5
+    from utility2.utils import Data
+    from spex_amd.trainer import DualTaskStepper, train_epoch_dual
+    g = golden("dual11_epinion2_epochs")
+    raw_train, raw_test = _epinion2_trust_raw(golden)
+    args, dataset, net = _dual_epinion2(data_root)
+    td = dl.LightTrainData(dataset.rec_train_data, dataset.m_item, dataset.train_mat)
+    by_user = defaultdict(list)
+    for k, p in enumerate(raw_train[0]):
+        by_user[p[0]].append(k)
+    train2, test2 = Data(raw_train, dataset.n_users, shuffle=False), Data(raw_test, dataset.n_users, shuffle=False, test=True)
+    cap = int(g["trust_batch_size"])
+    net = net.to(DEV)
+    st = DualTaskStepper(net, path_capacity=cap, path_len=train2.len_max, lr=args.lr, deterministic=True, fixed_task_weights=True)
+    n_steps = int(g["n_steps"])
+    cum, n_paths = [], []
+    train_epoch_dual(st, td, train2, by_user, cap, max_steps=n_steps, cum_every=100, cum_out=cum, n_paths_out=n_paths)
+    assert st.t == n_steps and np.array_equal(np.asarray(n_paths), g["n_paths"])
+    cum = torch.stack(cum).cpu().numpy()
+    assert (np.abs(cum[:, 0] - g["loss1_cum"]) / g["loss1_cum"]).max() <= 2e-5 and (np.abs(cum[:, 1] - g["loss2_cum"]) / g["loss2_cum"]).max() <= 2e-5
+    assert torch.equal(net.task_weights.detach().cpu(), torch.zeros(2)) and np.array_equal(g["task_weights"], np.zeros(2, np.float32))
+    net.eval()
+    with torch.no_grad():
+        ret = rec_test(net, dataset.testRatings, dataset.testNegatives)
+        assert max(np.abs(ret["recall"] - g["rec_recall"]).max(), np.abs(ret["ndcg"] - g["rec_ndcg"]).max()) <= 1e-4
+        assert np.abs(np.asarray(trust_test5(net, test2)) - g["trust"]).max() <= 1e-4
+    uw, iw = net.embedding_user.weight.detach().cpu().numpy(), net.embedding_item.weight.detach().cpu().numpy()
+    tab = dict(user=rel_err(uw[g["rows_u"]], g["user_w"]), item=rel_err(iw[g["rows_i"]], g["item_w"]), w=rel_err(net.w.detach().cpu().numpy(), g["w"]))
+    # the same 300 steps through the unchanged-driver loop (autograd path, fixed summation orders): main_11.py:50-72 line by line
+    import random
+    from torch.utils.data import DataLoader
+    from spex_amd import ops
+    args, dataset, ref = _dual_epinion2(data_root)
+    loader = DataLoader(dl.LightTrainData(dataset.rec_train_data, dataset.m_item, dataset.train_mat), batch_size=256, shuffle=True)
+    ref = ref.to(DEV)
+    opt = torch.optim.Adam(ref.parameters(), lr=args.lr)
+    ops.set_deterministic(True)
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    try:
+        loader.dataset.ng_sample()
+        ref.train()
+        for step, (user, item, label) in enumerate(loader):
+            if step == n_steps:
+                break
+            opt.zero_grad()
+            chosen = []
+            for u in set(user.numpy().tolist()):
+                chosen.extend(by_user[u])
+            if len(chosen) > cap:
+                chosen = random.sample(chosen, cap)
+            l1, l2 = ref(users=user.to(DEV), items=item.to(DEV), labels=label.to(DEV), slice_indices=np.array(chosen, dtype=int),
+                         trust_data=train2, flag=0)
+            (l1 + l2).backward()
+            opt.step()
+    finally:
+        ops.set_deterministic(False)
+        torch.use_deterministic_algorithms(False)
+    ru, ri = ref.embedding_user.weight.detach().cpu().numpy(), ref.embedding_item.weight.detach().cpu().numpy()
+    tab_ref = dict(user=rel_err(ru[g["rows_u"]], g["user_w"]), item=rel_err(ri[g["rows_i"]], g["item_w"]), w=rel_err(ref.w.detach().cpu().numpy(), g["w"]))
+    both = dict(user=rel_err(uw, ru), item=rel_err(iw, ri))
+    # measured: one-call step 4.7e-5 / 4.3e-4 (user / item rows), driver loop 7.9e-5 / 6.7e-4, the two paths 1.6e-4 apart — item
+    # rows that only see 3-hop gradients of ~1e-9 move by Adam's lr whatever the gradient's size, so their early steps follow the
+    # sign of rounding noise in every implementation; the function (losses 2e-5, HR / NDCG 1e-4 above) is what is pinned
+    print("main_11, 300 steps, trained tables vs the reference's: one-call step", tab, "driver loop", tab_ref, "step vs loop", both)
+    assert max(tab.values()) <= 1e-3 and max(tab_ref.values()) <= 1e-3, (tab, tab_ref)
