@@ -263,3 +263,32 @@ def test_learned_edge_value_restatements_vs_torch_sparse(oracle):
     Y = torch.sparse.mm(torch.sparse_coo_tensor(idx, tv2, (n_rows, n_cols)), torch.from_numpy(X))
     (Y * torch.from_numpy(G)).sum().backward()
     assert np.allclose(oracle.sddmm(rowptr, col, G, X, np.float64), tv2.grad.numpy(), rtol=1e-12, atol=1e-13)
+
+
+def test_g11_dual_task_restatement_vs_the_reference(golden):
+    """oracle/trust_oracle.py: dual_task_losses — the whole dual-task forward of model_expert_s.py restated in torch fp64 on the
+    CPU — against the reference's own run of the same model (G11, trust_tiny.npz: parameters by value, a rec batch, 30 trust
+    paths): both losses and EVERY parameter's gradient of loss1 + loss2.  This pins the restatement that the config-5 GPU tests
+    on the Weibo-shaped graph (where the reference itself cannot run: its data are not shipped) are held against."""
+    import torch
+    from oracle.trust_oracle import dual_task_losses
+    g, lg = golden("trust_tiny"), golden("lightgcn_tiny")
+    P = {k[6:].replace("__", "."): torch.from_numpy(g[k]).double().requires_grad_(True) for k in g.files
+         if k.startswith("state_") and k != "state_task_weights"}
+    sl = g["slice_indices"]
+    loss1, loss2 = dual_task_losses(lg["rowptr"], lg["col"], lg["val"], P, lg["batch_users"][0], lg["batch_items"][0],
+                                    lg["batch_labels"][0].astype(np.float64), g["train_inputs"][sl], g["train_mask"][sl],
+                                    g["train_targets"][sl])
+    assert abs(loss1.item() - float(g["loss1"])) <= 2e-6 and abs(loss2.item() - float(g["loss2"])) <= 2e-5
+    (loss1 + loss2).backward()
+    checked = 0
+    for name, p in P.items():
+        key = "grad_" + name.replace(".", "__")
+        if key in g.files:
+            want = g[key].reshape(p.shape)
+            err = np.abs(p.grad.numpy() - want).max()
+            # (att_t: a two-way softmax's parameter gradient has exactly antisymmetric columns; the reference's fp32 columns
+            #  differ from that by 3e-7 of their own rounding, hence the absolute alternative)
+            assert err <= 2e-5 * max(np.abs(want).max(), 1e-6) or err <= 1e-6, (name, err)
+            checked += 1
+    assert checked >= 16
