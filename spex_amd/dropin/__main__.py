@@ -7,7 +7,9 @@ The driver's own imports (`from lg_parser import parse_args_r`, `import utility1
 spex_amd/dropin/ because it is placed ahead of the script's directory on sys.path; anything this package does not
 provide still resolves to the driver's own directory.  A driver that imports `ngcf_parser` (NGCF_SPEX/code/main_*.py)
 gets spex_amd/dropin/ngcf/ instead — its `utility` package is NGCF's (load_data, batch_test, helper, ...), not the
-LightGCN alias of the same name.
+LightGCN alias of the same name — and, because NGCF's model class is defined inside the driver itself, the operator hook of
+spex_amd/dropin/sparse_hook.py: the driver's own `torch.sparse.mm(self.norm_adj.to(self.device), ego)` (main_rec.py:76) then
+runs on spex_spmm_f32 (SPEX_SPARSE_MM_HOOK=0 turns the hook off).
 
 Before the script starts, the heavy imports it will make anyway (torch, numpy, scipy, pandas) are done here and frozen
 out of Python's cyclic garbage collector: a full collection over their import-time objects takes ~40 ms and otherwise
@@ -33,6 +35,11 @@ def main():
         sys.path.insert(1, repo_root)
     import gc
     import numpy, pandas, scipy.sparse, torch, torch.utils.data   # noqa: F401,E401  (what the drivers and the modules import)
+    if ngcf and os.environ.get("SPEX_SPARSE_MM_HOOK", "1") != "0":
+        # NGCF's model lives in the driver (main_rec.py:36-113): its torch.sparse.mm(norm_adj.to(device), ego) lands on the HIP
+        # SpMM through the operator hook, with the driver file untouched (spex_amd/dropin/sparse_hook.py)
+        from spex_amd.dropin import sparse_hook
+        sparse_hook.install()
     gc.collect()
     gc.freeze()
     runpy.run_path(script, run_name="__main__")

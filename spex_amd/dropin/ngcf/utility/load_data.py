@@ -101,6 +101,10 @@ class Data(object):
         for kind in ("plain", "norm", "mean"):
             rowptr, col, val = ngcf_adjacency(self._pairs[0], self._pairs[1], self.n_users, self.n_items, kind)
             out.append(sp.csr_matrix((val, col, rowptr), shape=(n, n)))
+        from spex_amd.dropin import sparse_hook
+        if sparse_hook.installed():        # an unchanged driver's own torch.sparse.mm(adj, x) then lands on spex_spmm_f32
+            for m in out:
+                sparse_hook.register_adjacency(m)
         return tuple(out)
 
     # ------------------------------------------------------------------ training samples (:168-195)

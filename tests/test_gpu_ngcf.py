@@ -182,6 +182,36 @@ def test_ngcf_driver_runs_through_the_launcher(ngcf_data_root):
         assert np.abs(rec - g["recall"][ep]).max() <= 2e-4 and np.abs(ndcg - g["ndcg"][ep]).max() <= 2e-4, (ep, rec, g["recall"][ep])
 
 
+def test_unchanged_ngcf_driver_runs_on_the_hip_spmm_through_the_operator_hook(ngcf_data_root):
+    """tests/drivers/ngcf_unchanged_driver.py keeps the model class IN the driver, like NGCF_SPEX/code/main_rec.py:36-113, and calls
+    `torch.sparse.mm(self.norm_adj.to(self.device), ego)` (:76) — it names nothing of libspexhip.  Run through the launcher, the
+    operator hook (spex_amd/dropin/sparse_hook.py) recognises the adjacency the drop-in Data handed out, drops the per-call
+    upload and runs the product and its autograd backward on spex_spmm_f32: EVERY product of the run goes through the hook (none
+    falls back to ATen), and the three epochs on the 300-user graph reproduce the reference's own run (G12-NGCF: loss sums, HR /
+    NDCG per epoch; dropout masks from the goldens' counter-based generator)."""
+    import ast
+    import re
+    g = np.load(os.path.join(REPO, "tests", "golden", "ngcf_small_epochs.npz"))
+    script = os.path.join(REPO, "tests", "drivers", "ngcf_unchanged_driver.py")
+    env = dict(os.environ, SPEX_TEST_COUNTER_DROPOUT=str(int(g["drop_seed"])))
+    out = subprocess.run([sys.executable, "-m", "spex_amd.dropin", script, "--data_path", ngcf_data_root, "--dataset", "small",
+                          "--epoch", "3"], cwd=REPO, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("epoch ")]
+    assert len(lines) == 3, out.stdout[-2000:]
+    for ep, line in enumerate(lines):
+        nums = [float(x) for x in re.findall(r"-?\d+\.\d+", line)]
+        loss, rec, ndcg = nums[0], np.array(nums[1:4]), np.array(nums[4:7])
+        assert abs(loss - g["losses"][ep]) <= 1e-4 * g["losses"][ep] + 2e-5, (ep, loss, g["losses"][ep])
+        assert np.abs(rec - g["recall"][ep]).max() <= 2e-4 and np.abs(ndcg - g["ndcg"][ep]).max() <= 2e-4, (ep, rec, g["recall"][ep])
+    hook = [l for l in out.stdout.splitlines() if l.startswith("sparse_hook ")]
+    assert len(hook) == 1 and hook[0].split()[1] == "True", out.stdout[-800:]
+    stats = ast.literal_eval(hook[0].split(" ", 2)[2])
+    n_steps = int(g["n_steps"])
+    assert stats["fallback_calls"] == 0 and stats["hip_calls"] == n_steps + 3, stats          # one product per step + one per test()
+    assert stats["uploads_avoided"] == stats["hip_calls"] - 1, stats                          # the matrix went to the device once
+
+
 def _run_reference_loop(ds, n_epochs, g, root, metric_tol=1e-4):
     """main_rec.py:116-148 on the drop-in modules: Data, NGCF, torch Adam, the DataLoader of load_train_data, test()."""
     from spex_amd.dropin.ngcf.utility import batch_test
