@@ -677,6 +677,66 @@ typedef struct spex_dual_task_step {
 int spex_dual_task_step_f32(spex_dual_task_step_t *step, const int64_t *users, const int64_t *items, const float *labels, int32_t B,
                             const int64_t *seq, const int64_t *seq_l, const int64_t *targets, int32_t T, void *stream);
 
+/* ------------------------------------------------------------------------------------------------ multi-GPU: collectives + partitioned step
+ * the graph is 1-D row-partitioned over the GPUs of one node (one process per GPU): rank p owns rows
+ * [r_p, r_{p+1}) of A (and of A^T), of every layer's table and of the Adam moments; a layer is an all-gather of the current
+ * layer's rows over xGMI followed by the local SpMM.  The reference's analogue is the serial fold loop of --A_split
+ * (LightGCN_SPEX/code/utility1/model.py:84-89, dataloader.py:167-177).  Layout: shards are padded to max_rows = the largest
+ * shard, the gathered table is [world * max_rows, d] (rank q's rows in slot q), and a rank's block of A has its column indices
+ * rewritten once into that layout, so the SpMM reads the gathered buffer as it arrives.
+ * The collectives run on RCCL, bound at run time (dlopen: the library loads without RCCL; inside a PyTorch process the
+ * librccl torch already holds is the one used).  Errors: SPEX_ERR_COMM with the RCCL message in spex_last_error().
+ */
+#define SPEX_COMM_ID_BYTES 128
+typedef struct spex_comm spex_comm_t;
+/* id_out: SPEX_COMM_ID_BYTES bytes (an ncclUniqueId), created on ONE rank and handed to all by the host (any transport). */
+int spex_comm_unique_id(void *id_out);
+/* Collective over all `world` ranks (ncclCommInitRank), on the calling thread's current device. */
+int spex_comm_create(int32_t rank, int32_t world, const void *unique_id, spex_comm_t **out);
+int spex_comm_destroy(spex_comm_t *comm);
+int spex_comm_info(const spex_comm_t *comm, int32_t *rank, int32_t *world);
+/* All-gather of row shards: send = this rank's rows ([<= max_rows, d], padded shard), recv = the gathered table
+ * [world * max_rows, d].  rows_per_rank == NULL: one equal-size ncclAllGather of the padded shards (world * max_rows rows on
+ * the wire).  rows_per_rank (host, [world]): only the REAL rows move, as one group of point-to-point sends / receives — rank p's
+ * rows straight into slot p of every peer's table, world - 1 transfers in flight at once (one per xGMI link of the full mesh,
+ * where a ring serialises world - 1 steps over one link); the slots' padding tails are never written nor read.  send may be
+ * recv's own slot.  Asynchronous on `stream`. */
+int spex_comm_allgather_rows_f32(spex_comm_t *comm, const float *send, float *recv, int64_t max_rows, int32_t d,
+                                 const int32_t *rows_per_rank, void *stream);
+/* In-place sum over ranks (the owner-computes exchange of a batch's rows: every rank contributes the rows it owns to a zero-filled
+ * buffer). */
+int spex_comm_allreduce_sum_f32(spex_comm_t *comm, float *buf, int64_t n, void *stream);
+
+/* The row-partitioned propagation / exact training step as one native call each (what spex_amd/dist.py's PartitionedLightGCN.
+ * propagate and PartitionedStepper.step_bce issue launch by launch):
+ *   spex_partitioned_propagate_f32: L x (exchange of the current rows, spex_spmm_f32 on the rank's block with the running layer
+ *     sum fused) -> light_out = the rank's rows of mean(E^0 .. E^L)                    (utility1/model.py:66-97)
+ *   spex_partitioned_step_bce_f32: that forward; the batch's 2B propagated rows fetched owner-computes
+ *     (spex_gather_owned_rows_f32 + one all-reduce of 2B rows); scores + BCE + gradient rows on the compact rows; the rows this
+ *     rank owns added into its gradient block (spex_scatter_add_owned_rows_f32 — or, with SPEX_STEP_DETERMINISTIC, per-sample
+ *     rows added in slot order by spex_reduce_slots_f32); backward G_l = g / (L+1) + A^T G_{l+1} as L x (exchange, SpMM on the
+ *     block of A^T); Adam on the rank's rows.  2 L exchanges + 1 small all-reduce per step, no host work between launches.
+ * pos: device int64 [2B] — the batch's rows in the padded gathered layout (users, then items): owner(r) * max_rows + r - r_owner.
+ * The batch is replicated on every rank; every rank accumulates the same loss sum into its own *loss_sum.
+ * Buffers (caller-owned): E0, m, v, light_out, g_local, gs, grad_E0: [n_local, 64] (g_local all-zero before the first call;
+ * every call leaves it so); send: [max_rows, 64]; gathered: [world * max_rows, 64]; rows, grad_rows: [slot_capacity, 64] with
+ * slot_capacity >= 2B (grad_rows all-zero before the first call); arange: device int64 [slot_capacity] = 0, 1, 2, ...
+ * graph / graph_t: this rank's row blocks (n_local rows, world * max_rows columns).  d == 64, L >= 1, no edge dropout. */
+typedef struct spex_partitioned_step {
+    const spex_graph_t *graph, *graph_t;
+    spex_comm_t *comm;
+    const int32_t *rows_per_rank;      /* host [world], or NULL: see spex_comm_allgather_rows_f32 */
+    float *E0, *m, *v;
+    float *light_out, *g_local, *gs, *grad_E0, *send, *gathered, *rows, *grad_rows;
+    const int64_t *arange;
+    int32_t n_local, max_rows, slot_capacity, L, d;
+    float lr, beta1, beta2, eps;
+    int32_t t, flags;                  /* t is advanced by spex_partitioned_step_bce_f32; flags: SPEX_STEP_DETERMINISTIC */
+} spex_partitioned_step_t;
+int spex_partitioned_propagate_f32(spex_partitioned_step_t *step, void *stream);
+int spex_partitioned_step_bce_f32(spex_partitioned_step_t *step, const int64_t *pos, const float *labels, int32_t B, float *loss_sum,
+                                  void *stream);
+
 /* ------------------------------------------------------------------------------------------------ profiling hook
  * Not part of any reference interface: lets a caller time the dominant kernel itself, in place, on the stream it is
  * launched on (bench.py's roofline figure).  While a timer is attached to a graph, every (or every n-th) call of

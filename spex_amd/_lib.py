@@ -102,6 +102,14 @@ SIGNATURES = {
     "spex_lightgcn_step_bce_f32": (ctypes.c_int, [ctypes.c_void_p, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "spex_ngcf_step_bce_f32": (ctypes.c_int, [ctypes.c_void_p, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "spex_dual_task_step_f32": (ctypes.c_int, [ctypes.c_void_p, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp]),
+    "spex_comm_unique_id": (ctypes.c_int, [c_vp]),
+    "spex_comm_create": (ctypes.c_int, [c_i32, c_i32, c_vp, ctypes.POINTER(c_vp)]),
+    "spex_comm_destroy": (ctypes.c_int, [c_vp]),
+    "spex_comm_info": (ctypes.c_int, [c_vp, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
+    "spex_comm_allgather_rows_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp]),
+    "spex_comm_allreduce_sum_f32": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp]),
+    "spex_partitioned_propagate_f32": (ctypes.c_int, [c_vp, c_vp]),
+    "spex_partitioned_step_bce_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "spex_timer_create": (ctypes.c_int, [c_i32, c_i32, ctypes.POINTER(c_vp)]),
     "spex_timer_destroy": (ctypes.c_int, [c_vp]),
     "spex_timer_attach": (ctypes.c_int, [c_vp, c_vp]),
@@ -141,6 +149,17 @@ class DualTaskStepDesc(ctypes.Structure):
                                         "n_rec")]
                 + [(n, c_f32) for n in ("lr", "beta1", "beta2", "eps")] + [("t", c_i32)]
                 + [(n, c_vp) for n in ("side_stream", "ev_fork", "ev_join", "g_raw_slots", "att_parts", "loss_rows")] + [("flags", c_i32)])
+
+
+class PartitionedStepDesc(ctypes.Structure):
+    """spex_partitioned_step_t (include/spex_hip.h)."""
+    _fields_ = ([(n, c_vp) for n in ("graph", "graph_t", "comm", "rows_per_rank", "E0", "m", "v", "light_out", "g_local", "gs", "grad_E0",
+                                     "send", "gathered", "rows", "grad_rows", "arange")]
+                + [(n, c_i32) for n in ("n_local", "max_rows", "slot_capacity", "L", "d")]
+                + [(n, c_f32) for n in ("lr", "beta1", "beta2", "eps")] + [("t", c_i32), ("flags", c_i32)])
+
+
+COMM_ID_BYTES = 128             # spex_hip.h: SPEX_COMM_ID_BYTES
 
 
 def release_step_events(desc):

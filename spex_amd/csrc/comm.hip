@@ -1,0 +1,292 @@
+// Collectives behind the C ABI (spex_comm_init / spex_allgather_rows; 8e: 1-D row partition with an RCCL
+// all-gather of the layer's rows before each SpMM) and the row-partitioned training step as ONE native call.
+//
+// The reference's only analogue is the serial fold loop of --A_split (LightGCN_SPEX/code/utility1/model.py:84-89,
+// dataloader.py:167-177): the same row blocks, one after the other on one device.  Here rank p owns a block of rows of A (and
+// of A^T), of every layer's table and of the Adam moments; a layer is  all-gather of the current rows over xGMI  ->  local
+// SpMM on the block.  Rounds 1-2 issued every collective from Python through torch.distributed; a binding in another language
+// had no multi-GPU path at all and each step paid 3-4 Python-issued collectives against ~50 us of compute.
+//
+// RCCL is bound at RUN time (dlopen / dlsym), not linked: libspexhip.so keeps loading on a machine without RCCL (the
+// single-GPU entry points need none), and inside a PyTorch process the copy of librccl torch has already loaded is the one
+// that is used (RTLD_NOLOAD first) instead of a second copy with its own state.
+//
+//   spex_comm_unique_id      the 128-byte id rank 0 creates and the host hands to every rank (any transport: MPI, a file, a
+//                            torch.distributed broadcast)
+//   spex_comm_create         ncclCommInitRank on the calling thread's current device
+//   spex_comm_allgather_rows_f32   equal padded shards (ncclAllGather), or — with the ranks' real row counts — a grouped
+//                            send / recv of the REAL rows only, every rank writing straight into its slot of every peer's
+//                            table: world - 1 concurrent point-to-point transfers, one per xGMI link of the full mesh, where
+//                            a ring moves the same bytes through one link at a time
+//   spex_comm_allreduce_sum_f32    in place (the owner-computes row exchange; loss / flag cells)
+//   spex_partitioned_propagate_f32 / spex_partitioned_step_bce_f32   L x (exchange + SpMM) forward, the batch's rows fetched
+//                            owner-computes, scoring, L x (exchange + SpMM) backward on A^T's blocks, Adam on the rank's rows
+#include <dlfcn.h>
+#include <string.h>
+#include <mutex>
+
+#include <rccl/rccl.h>
+
+#include "spex_common.h"
+
+using namespace spex;
+
+namespace {
+
+struct Rccl {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok = false;
+};
+
+Rccl &rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, []() {
+        const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char *n : names)                                  // a copy the process already holds (PyTorch's) first
+            if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        for (const char *n : names)
+            if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (!r.lib) return;
+#define SPEX_SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, name))
+        SPEX_SYM(GetUniqueId, "ncclGetUniqueId");
+        SPEX_SYM(CommInitRank, "ncclCommInitRank");
+        SPEX_SYM(CommDestroy, "ncclCommDestroy");
+        SPEX_SYM(AllGather, "ncclAllGather");
+        SPEX_SYM(AllReduce, "ncclAllReduce");
+        SPEX_SYM(Send, "ncclSend");
+        SPEX_SYM(Recv, "ncclRecv");
+        SPEX_SYM(GroupStart, "ncclGroupStart");
+        SPEX_SYM(GroupEnd, "ncclGroupEnd");
+        SPEX_SYM(GetErrorString, "ncclGetErrorString");
+#undef SPEX_SYM
+        r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.AllReduce && r.Send && r.Recv && r.GroupStart
+               && r.GroupEnd && r.GetErrorString;
+    });
+    return r;
+}
+
+#define SPEX_NCCL(call)                                                                                   \
+    do {                                                                                                  \
+        ncclResult_t r_ = (call);                                                                         \
+        if (r_ != ncclSuccess) {                                                                          \
+            ::spex::set_error("%s failed: %s (%s:%d)", #call, rccl().GetErrorString(r_), __FILE__, __LINE__); \
+            return SPEX_ERR_COMM;                                                                         \
+        }                                                                                                 \
+    } while (0)
+
+int need_rccl(const char *who)
+{
+    if (!rccl().ok) {
+        spex::set_error("%s: librccl.so could not be loaded (%s)", who, rccl().lib ? "a symbol is missing" : dlerror());
+        return SPEX_ERR_COMM;
+    }
+    return SPEX_OK;
+}
+
+}  // namespace
+
+struct spex_comm {
+    ncclComm_t comm = nullptr;
+    int32_t rank = 0, world = 1;
+};
+
+extern "C" int spex_comm_unique_id(void *id_out)
+{
+    SPEX_CHECK_ARG(id_out, "spex_comm_unique_id: NULL output");
+    if (int rc = need_rccl("spex_comm_unique_id")) return rc;
+    ncclUniqueId id;
+    SPEX_NCCL(rccl().GetUniqueId(&id));
+    static_assert(sizeof(id) == SPEX_COMM_ID_BYTES, "ncclUniqueId size");
+    memcpy(id_out, &id, sizeof(id));
+    return SPEX_OK;
+}
+
+extern "C" int spex_comm_create(int32_t rank, int32_t world, const void *unique_id, spex_comm_t **out)
+{
+    SPEX_CHECK_ARG(out && unique_id && world >= 1 && rank >= 0 && rank < world, "spex_comm_create: rank %d of %d", rank, world);
+    if (int rc = need_rccl("spex_comm_create")) return rc;
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    spex_comm *c = new spex_comm;
+    c->rank = rank;
+    c->world = world;
+    ncclResult_t r = rccl().CommInitRank(&c->comm, world, id, rank);
+    if (r != ncclSuccess) {
+        spex::set_error("ncclCommInitRank failed: %s", rccl().GetErrorString(r));
+        delete c;
+        return SPEX_ERR_COMM;
+    }
+    *out = c;
+    return SPEX_OK;
+}
+
+extern "C" int spex_comm_destroy(spex_comm_t *c)
+{
+    if (!c) return SPEX_OK;
+    if (c->comm && rccl().ok) rccl().CommDestroy(c->comm);
+    delete c;
+    return SPEX_OK;
+}
+
+extern "C" int spex_comm_info(const spex_comm_t *c, int32_t *rank, int32_t *world)
+{
+    SPEX_CHECK_ARG(c, "spex_comm_info: NULL communicator");
+    if (rank) *rank = c->rank;
+    if (world) *world = c->world;
+    return SPEX_OK;
+}
+
+extern "C" int spex_comm_allgather_rows_f32(spex_comm_t *c, const float *send, float *recv, int64_t max_rows, int32_t d,
+                                            const int32_t *rows_per_rank, void *stream)
+{
+    SPEX_CHECK_ARG(c && send && recv && max_rows >= 0 && d >= 1, "spex_comm_allgather_rows_f32: bad argument");
+    if (max_rows == 0) return SPEX_OK;
+    const size_t slot = (size_t)max_rows * d;
+    if (c->world == 1) {
+        const int64_t rows = rows_per_rank ? rows_per_rank[0] : max_rows;
+        SPEX_CHECK_ARG(rows >= 0 && rows <= max_rows, "spex_comm_allgather_rows_f32: %lld rows in a slot of %lld", (long long)rows, (long long)max_rows);
+        if (send != recv) SPEX_HIP(hipMemcpyAsync(recv, send, (size_t)rows * d * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        return SPEX_OK;
+    }
+    if (!rows_per_rank) {                                            // equal padded shards: the plain collective
+        SPEX_NCCL(rccl().AllGather(send, recv, slot, ncclFloat32, c->comm, (hipStream_t)stream));
+        return SPEX_OK;
+    }
+    // real rows only, point to point: rank p's rows land in slot p of every rank's table (the slots keep the padded stride;
+    // their tails are never read).  One group = world - 1 sends + world - 1 receives in flight at once, one per link.
+    for (int q = 0; q < c->world; ++q)
+        SPEX_CHECK_ARG(rows_per_rank[q] >= 0 && rows_per_rank[q] <= max_rows, "spex_comm_allgather_rows_f32: rank %d has %d rows in a slot of %lld", q,
+                       rows_per_rank[q], (long long)max_rows);
+    const size_t mine = (size_t)rows_per_rank[c->rank] * d;
+    if (send != recv + c->rank * slot && mine)
+        SPEX_HIP(hipMemcpyAsync(recv + c->rank * slot, send, mine * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    SPEX_NCCL(rccl().GroupStart());
+    for (int q = 0; q < c->world; ++q) {
+        if (q == c->rank) continue;
+        if (mine) SPEX_NCCL(rccl().Send(send, mine, ncclFloat32, q, c->comm, (hipStream_t)stream));
+        const size_t theirs = (size_t)rows_per_rank[q] * d;
+        if (theirs) SPEX_NCCL(rccl().Recv(recv + q * slot, theirs, ncclFloat32, q, c->comm, (hipStream_t)stream));
+    }
+    SPEX_NCCL(rccl().GroupEnd());
+    return SPEX_OK;
+}
+
+extern "C" int spex_comm_allreduce_sum_f32(spex_comm_t *c, float *buf, int64_t n, void *stream)
+{
+    SPEX_CHECK_ARG(c && (buf || n == 0) && n >= 0, "spex_comm_allreduce_sum_f32: bad argument");
+    if (n == 0 || c->world == 1) return SPEX_OK;
+    SPEX_NCCL(rccl().AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, c->comm, (hipStream_t)stream));
+    return SPEX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The row-partitioned propagation and training step (spex_amd/dist.py: PartitionedLightGCN.propagate / PartitionedStepper)
+// issued from native code.  Every launch is one of the library's own entry points.
+#define SPEX_TRY(call)                  \
+    do {                                \
+        int rc_ = (call);               \
+        if (rc_ != SPEX_OK) return rc_; \
+    } while (0)
+
+static int check_step(const spex_partitioned_step_t *s, const char *who)
+{
+    SPEX_CHECK_ARG(s && s->graph && s->graph_t && s->comm && s->E0 && s->light_out && s->send && s->gathered,
+                   "%s: NULL field in the step descriptor", who);
+    SPEX_CHECK_ARG(s->d == 64 && s->L >= 1 && s->n_local >= 0 && s->n_local <= s->max_rows, "%s: d=%d L=%d n_local=%d max_rows=%d", who, s->d,
+                   s->L, s->n_local, s->max_rows);
+    SPEX_CHECK_ARG(s->graph->n_rows == s->n_local && s->graph_t->n_rows == s->n_local
+                       && s->graph->n_cols == s->comm->world * s->max_rows && s->graph_t->n_cols == s->graph->n_cols,
+                   "%s: the row blocks must be n_local x (world * max_rows) in the padded layout", who);
+    SPEX_CHECK_ARG(s->graph->mask_mode == 0 && s->graph_t->mask_mode == 0, "%s: edge dropout is not supported in the partitioned step", who);
+    return SPEX_OK;
+}
+
+// one exchange: the rank's rows (already in `send`, or copied there) -> the gathered table
+static int exchange(const spex_partitioned_step_t *s, const float *local, void *stream)
+{
+    const size_t bytes = (size_t)s->n_local * s->d * sizeof(float);
+    if (local != s->send && bytes) SPEX_HIP(hipMemcpyAsync(s->send, local, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return spex_comm_allgather_rows_f32(s->comm, s->send, s->gathered, s->max_rows, s->d, s->rows_per_rank, stream);
+}
+
+extern "C" int spex_partitioned_propagate_f32(spex_partitioned_step_t *s, void *stream)
+{
+    SPEX_TRY(check_step(s, "spex_partitioned_propagate_f32"));
+    if (s->n_local == 0 && s->comm->world == 1) return SPEX_OK;
+    const float *cur = s->E0;
+    for (int32_t l = 0; l < s->L; ++l) {
+        SPEX_TRY(exchange(s, cur, stream));
+        const bool last = l == s->L - 1;
+        float *nxt = last ? nullptr : s->send;                       // the next layer's exchange source, written in place
+        if (s->n_local)
+            SPEX_TRY(spex_spmm_f32(s->graph, s->gathered, nxt, nullptr, 1.0f, l == 0 ? s->E0 : s->light_out, s->light_out,
+                                   last ? (float)(s->L + 1) : 1.0f, s->d, stream));
+        cur = s->send;
+    }
+    return SPEX_OK;
+}
+
+extern "C" int spex_partitioned_step_bce_f32(spex_partitioned_step_t *s, const int64_t *pos, const float *labels, int32_t B,
+                                             float *loss_sum, void *stream)
+{
+    SPEX_TRY(check_step(s, "spex_partitioned_step_bce_f32"));
+    SPEX_CHECK_ARG(s->m && s->v && s->g_local && s->gs && s->grad_E0 && s->rows && s->grad_rows && s->arange,
+                   "spex_partitioned_step_bce_f32: NULL field in the step descriptor");
+    SPEX_CHECK_ARG(pos && labels && loss_sum && B >= 1 && s->slot_capacity >= 2 * B, "spex_partitioned_step_bce_f32: batch of %d for a slot capacity of %d",
+                   B, s->slot_capacity);
+    const int32_t d = s->d, L = s->L;
+    const int64_t lo = (int64_t)s->comm->rank * s->max_rows, n_loc = s->n_local;
+    const bool det = (s->flags & SPEX_STEP_DETERMINISTIC) != 0;
+    // ---- forward: L x (exchange, SpMM on the rank's rows), the batch's 2B rows fetched owner-computes (each rank contributes the
+    //      rows it owns to a zero-filled buffer, one small all-reduce adds them up), scoring on the compact rows
+    SPEX_TRY(spex_partitioned_propagate_f32(s, stream));
+    SPEX_TRY(spex_gather_owned_rows_f32(s->light_out, pos, 2 * (int64_t)B, lo, n_loc, d, s->rows, stream));
+    SPEX_TRY(spex_comm_allreduce_sum_f32(s->comm, s->rows, (int64_t)2 * B * d, stream));
+    const float *users = s->rows, *items = s->rows + (size_t)B * d;    // slot b: the user row of sample b, slot B + b: its item row
+    if (det) {
+        // per-sample gradient rows (plain stores), added per owned table row in ascending slot order: no float atomics
+        // (and per-sample losses, summed in sample order: the gathered table is free between the forward's last SpMM and the
+        //  backward's first exchange — its head holds them)
+        SPEX_CHECK_ARG((int64_t)s->comm->world * s->max_rows * d >= B, "spex_partitioned_step_bce_f32: gathered table smaller than the batch");
+        float *loss_rows = s->gathered;
+        SPEX_TRY(spex::score_bce_slots_rows(users, items, d, d, B, B, s->arange, s->arange, labels, B, d, loss_rows, 1.0f / (float)B,
+                                            s->grad_rows, d, stream));
+        SPEX_TRY(spex::sum_ordered(loss_rows, B, 1.0f, loss_sum, 1, stream));
+        SPEX_TRY(spex_reduce_slots_f32(pos, 2 * B, -lo, nullptr, 0, 0, (int32_t)n_loc, s->grad_rows, d, 1.0f, s->g_local, 0, d, stream));
+        SPEX_HIP(hipMemsetAsync(s->grad_rows, 0, (size_t)2 * B * d * sizeof(float), (hipStream_t)stream));   // the fast path's invariant
+    } else {
+        float *gu = s->grad_rows, *gi = s->grad_rows + (size_t)B * d;
+        SPEX_TRY(spex_score_bce_f32(users, items, d, d, B, B, s->arange, s->arange, labels, B, d, nullptr, loss_sum, gu, gi, 1.0f / (float)B,
+                                    stream));
+        SPEX_TRY(spex_scatter_add_owned_rows_f32(s->grad_rows, pos, 2 * (int64_t)B, lo, n_loc, d, s->g_local, 1, stream));
+    }
+    // ---- backward: G_L = g / (L + 1);  G_l = g / (L + 1) + A^T G_{l+1} on the row blocks of A^T, one exchange per layer
+    const int64_t sz = n_loc * d;
+    SPEX_TRY(spex::scale_div(s->g_local, s->gs, (float)(L + 1), sz, stream));
+    const float *cur = s->gs;
+    for (int32_t l = L - 1; l >= 0; --l) {
+        SPEX_TRY(exchange(s, cur, stream));
+        float *nxt = l == 0 ? s->grad_E0 : s->send;
+        if (n_loc) SPEX_TRY(spex_spmm_f32(s->graph_t, s->gathered, nxt, s->gs, 1.0f, nullptr, nullptr, 1.0f, d, stream));
+        cur = s->send;
+    }
+    // ---- Adam on the rank's rows (its pass clears the gradient rows again; det: g_local is overwritten per touched row, so it is
+    //      cleared densely here as well)
+    if (sz)
+        SPEX_TRY(spex::adam_step_z2(s->E0, s->grad_E0, s->m, s->v, sz, s->t + 1, s->lr, s->beta1, s->beta2, s->eps, s->g_local, nullptr,
+                                    stream));
+    s->t += 1;
+    return SPEX_OK;
+}

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kWave *kScoreWaves) void score_bce_kernel(
     const float *__restrict__ users, const float *__restrict__ items, int ldu, int ldi, const int64_t *__restrict__ u_idx,
     const int64_t *__restrict__ i_idx, const float *__restrict__ labels, int B, int d, int64_t n_user_rows,
     int64_t n_item_rows, float *__restrict__ gamma, float *loss_sum, float *grad_users, float *grad_items,
-    float grad_scale, float *__restrict__ grad_slots, int ld_slots)
+    float grad_scale, float *__restrict__ grad_slots, int ld_slots, float *__restrict__ loss_rows)
 {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_global = blockIdx.x * kScoreWaves + (threadIdx.x >> 6);
@@ -62,6 +62,7 @@ __global__ __launch_bounds__(kWave *kScoreWaves) void score_bce_kernel(
         const int64_t u = u_idx[b], it = i_idx[b];
         if (u < 0 || u >= n_user_rows || it < 0 || it >= n_item_rows) {  // never gather out of bounds
             if (lane == 0 && gamma) gamma[b] = __int_as_float(0x7fc00000);
+            if (lane == 0 && loss_rows) loss_rows[b] = 0.0f;
             if (grad_slots)
                 for (int c = lane; c < d; c += kWave) grad_slots[(size_t)b * ld_slots + c] = grad_slots[(size_t)(B + b) * ld_slots + c] = 0.0f;
             continue;
@@ -73,7 +74,12 @@ __global__ __launch_bounds__(kWave *kScoreWaves) void score_bce_kernel(
         if (lane == 0 && gamma) gamma[b] = x;
         if (labels) {
             const float y = labels[b];
-            lsum += fmaxf(x, 0.0f) - x * y + log1pf(expf(-fabsf(x)));
+            const float bce = fmaxf(x, 0.0f) - x * y + log1pf(expf(-fabsf(x)));
+            if (loss_rows) {                                  // per-sample losses, summed in sample order by the caller
+                if (lane == 0) loss_rows[b] = bce;
+            } else {
+                lsum += bce;
+            }
             if (grad_slots) {     // the sample's two gradient rows, compact: slot b = user side, slot B + b = item side
                 const float dg = (sigmoid_f(x) - y) * grad_scale;
                 for (int c = lane; c < d; c += kWave) {
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(kWave *kScoreWaves) void score_bce_kernel(
             }
         }
     }
-    if (labels && loss_sum) block_loss_add(lsum, loss_sum);
+    if (labels && loss_sum && !loss_rows) block_loss_add(lsum, loss_sum);
 }
 
 // a_coef: multiplies sigmoid(x) (SGD: -lr/T, autograd: grad_scale); b_coef: multiplies the read row (SGD: -lr*reg/T).
@@ -508,7 +514,7 @@ inline unsigned grid_for(int64_t waves_wanted)
 static int launch_score_bce(const float *users, const float *items, int32_t ldu, int32_t ldi, int64_t n_user_rows,
                             int64_t n_item_rows, const int64_t *u_idx, const int64_t *i_idx, const float *labels, int32_t B,
                             int32_t d, float *gamma, float *loss_sum, float *grad_users, float *grad_items, float grad_scale,
-                            float *grad_slots, int32_t ld_slots, void *stream, const char *who)
+                            float *grad_slots, int32_t ld_slots, void *stream, const char *who, float *loss_rows = nullptr)
 {
     SPEX_CHECK_ARG(users && items && u_idx && i_idx, "%s: NULL table or index pointer", who);
     SPEX_CHECK_ARG(B >= 0 && d >= 1 && ldu >= d && ldi >= d, "%s: B=%d d=%d ldu=%d ldi=%d", who, B, d, ldu, ldi);
@@ -520,9 +526,19 @@ static int launch_score_bce(const float *users, const float *items, int32_t ldu,
     if (B == 0) return SPEX_OK;
     hipLaunchKernelGGL(score_bce_kernel, dim3(grid_for(B)), dim3(kWave * kScoreWaves), 0, (hipStream_t)stream, users,
                        items, ldu, ldi, u_idx, i_idx, labels, B, d, n_user_rows, n_item_rows, gamma, loss_sum, grad_users,
-                       grad_items, grad_scale, grad_slots, ld_slots);
+                       grad_items, grad_scale, grad_slots, ld_slots, loss_rows);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
+}
+
+// Internal form for the deterministic steps: per-sample gradient rows AND per-sample losses (plain stores, no atomics at all).
+int spex::score_bce_slots_rows(const float *users, const float *items, int32_t ldu, int32_t ldi, int64_t n_user_rows,
+                               int64_t n_item_rows, const int64_t *u_idx, const int64_t *i_idx, const float *labels, int32_t B, int32_t d,
+                               float *loss_rows, float grad_scale, float *grad_slots, int32_t ld_slots, void *stream)
+{
+    SPEX_CHECK_ARG(loss_rows && grad_slots && labels, "score_bce_slots_rows: NULL pointer");
+    return launch_score_bce(users, items, ldu, ldi, n_user_rows, n_item_rows, u_idx, i_idx, labels, B, d, nullptr, nullptr, nullptr, nullptr,
+                            grad_scale, grad_slots, ld_slots, stream, "score_bce_slots_rows", loss_rows);
 }
 
 extern "C" int spex_score_bce_f32(const float *users, const float *items, int32_t ldu, int32_t ldi,

@@ -20,6 +20,10 @@ int dual_task_adam(float *p, float *m, float *v, const float *g_E0, float *g_raw
                    int32_t B, int32_t T, int32_t n_rec, int32_t t, float lr, float beta1, float beta2, float eps, int fixed_weights,
                    void *stream);   // optim.hip: Adam over the dual-task parameter arena (spex_dual_task_step_f32)
 
+int score_bce_slots_rows(const float *users, const float *items, int32_t ldu, int32_t ldi, int64_t n_user_rows, int64_t n_item_rows,
+                         const int64_t *u_idx, const int64_t *i_idx, const float *labels, int32_t B, int32_t d, float *loss_rows,
+                         float grad_scale, float *grad_slots, int32_t ld_slots, void *stream);     // score.hip: per-sample rows + losses
+int scale_div(const float *in, float *out, float div, int64_t n, void *stream);                          // spmm.hip: out = in / div
 int sum_ordered(const float *x, int32_t n, float scale, float *out, int accumulate, void *stream);     // rows.hip: fixed-order sum
 int sum_parts(const float *parts, int32_t n_parts, int64_t stride, int32_t n, float *out, int accumulate,
               void *stream);                                                                        // rows.hip: partial blocks, in order

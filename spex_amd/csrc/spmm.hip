@@ -950,6 +950,18 @@ extern "C" int spex_propagate_f32(const spex_graph_t *g, const float *E0, float 
     return SPEX_OK;
 }
 
+// out = in / div over n floats (the mean's backward share), for the other translation units.
+int spex::scale_div(const float *in, float *out, float div, int64_t n, void *stream)
+{
+    if (n <= 0) return SPEX_OK;
+    SPEX_CHECK_ARG(in && out && ((((uintptr_t)in) | ((uintptr_t)out)) & 15) == 0, "scale_div: NULL or unaligned pointer");
+    const int64_t n4 = n / 4, rem = n % 4;
+    const int64_t blocks = (n4 + 255) / 256 < 2048 ? ((n4 + 255) / 256 > 0 ? (n4 + 255) / 256 : 1) : 2048;
+    hipLaunchKernelGGL(div_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, out, div, n4, rem);
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}
+
 extern "C" int spex_propagate_bwd_f32(const spex_graph_t *gt, const float *g_out, float *grad_E0, float *ws, int32_t L,
                                       int32_t d, void *stream)
 {

@@ -144,6 +144,57 @@ class PeerAllGather:
         return self.bufs[k]
 
 
+class NativeComm:
+    """libspexhip's own communicator (spex_comm_*: RCCL bound inside the library, include/spex_hip.h) — the collectives of the
+    partitioned path issued from native code instead of through torch.distributed.  The 128-byte id is created on rank 0 and
+    handed to the other ranks by whatever the host has: here a torch.distributed object broadcast over `group` (gloo or nccl),
+    which is only the bootstrap — no tensor of the data path goes through it afterwards.  Creation is collective.
+    One process per GPU (RCCL refuses two ranks on one device); world size 1 works anywhere."""
+
+    def __init__(self, rank, world, device, group=None, unique_id=None):
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        self.rank, self.world, self.device = int(rank), int(world), torch.device(device)
+        if unique_id is None:
+            buf = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
+            if rank == 0:
+                _lib.check(lib.spex_comm_unique_id(buf), "spex_comm_unique_id")
+            box = [bytes(buf.raw)]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0, group=group)
+            unique_id = box[0]
+        assert len(unique_id) == _lib.COMM_ID_BYTES
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.spex_comm_create(self.rank, self.world, unique_id, ctypes.byref(self._h)), "spex_comm_create")
+        self._lib = lib
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.spex_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def allgather_rows(self, send, recv, max_rows, rows_per_rank=None):
+        """recv [world * max_rows, d] <- every rank's send [<= max_rows, d]; rows_per_rank (a ctypes int32 array or None)."""
+        from .graph import _bump, _launch, _ptr
+        _launch(self.device, "spex_comm_allgather_rows_f32", self._h, _ptr(send), _ptr(recv), int(max_rows), send.shape[1], rows_per_rank)
+        _bump(recv)
+        return recv
+
+    def allreduce_sum(self, buf):
+        from .graph import _bump, _launch, _ptr
+        _launch(self.device, "spex_comm_allreduce_sum_f32", self._h, _ptr(buf), buf.numel())
+        _bump(buf)
+        return buf
+
+
 class PartitionedLightGCN:
     """LightGCN propagation + scoring step on one rank of a row-partitioned graph.
 
@@ -176,11 +227,14 @@ class PartitionedLightGCN:
         self.out_gathered = z(p.n_padded, d)
         # allgather: "collective" = torch.distributed's all_gather_into_tensor (RCCL on the GPU); "peer" = direct peer
         # writes through IPC-mapped buffers (PeerAllGather) for the per-layer exchange
+        # "native" / "native-p2p" = libspexhip's own RCCL communicator (NativeComm): the plain equal-size collective, or the
+        # grouped point-to-point form that moves the real rows only
         self.peer, self.use_peer = None, False
-        if allgather not in ("collective", "peer"):
-            raise ValueError("allgather must be 'collective' or 'peer'")
-        if allgather == "peer":
-            self.set_allgather("peer")
+        self.native, self.use_native, self._rows_per_rank = None, False, None
+        if allgather not in ("collective", "peer", "native", "native-p2p"):
+            raise ValueError("allgather must be 'collective', 'peer', 'native' or 'native-p2p'")
+        if allgather != "collective":
+            self.set_allgather(allgather)
 
     # -- the one exchange step of the data path
     def all_gather_rows(self, local, out=None):
@@ -189,6 +243,8 @@ class PartitionedLightGCN:
         if self.use_peer and out is None:
             return self.peer.all_gather(self.send, self.n_local)
         out = self.gathered if out is None else out
+        if self.use_native:
+            return self.native.allgather_rows(self.send, out, self.part.max_rows, self._rows_per_rank)
         if self.world == 1 and not self.always_collective:
             out.copy_(self.send)
         else:
@@ -198,6 +254,14 @@ class PartitionedLightGCN:
     def set_allgather(self, mode):
         """Switch the per-layer exchange between "collective" and "peer" (every rank must make the same call: building the
         peer path exchanges IPC handles).  At world size 1 both are a local copy."""
+        if mode in ("native", "native-p2p"):
+            if self.native is None:
+                self.native = NativeComm(self.rank, self.world, self.device, group=self.group)
+            import ctypes
+            self._rows_per_rank = (ctypes.c_int32 * self.world)(*[int(r) for r in self.part.rows]) if mode == "native-p2p" else None
+            self.use_native, self.use_peer = True, False
+            return
+        self.use_native = False
         if mode == "peer" and self.world > 1:
             if self.peer is None:
                 self.peer = PeerAllGather(self.part.n_padded, self.part.max_rows, self.d, self.rank, self.world, self.device,
@@ -206,7 +270,7 @@ class PartitionedLightGCN:
         elif mode in ("collective", "peer"):
             self.use_peer = False
         else:
-            raise ValueError("allgather must be 'collective' or 'peer'")
+            raise ValueError("allgather must be 'collective', 'peer', 'native' or 'native-p2p'")
 
     def propagate(self, E0_local, keep_first=False, first_gathered=None):
         """mean_l(A^l E0) for this rank's rows (LightGCN.computer(), model.py:66-97).  keep_first: the first layer's
@@ -297,7 +361,9 @@ class PartitionedLightGCN:
         if out.is_cuda:
             from . import ops
             ops.gather_owned_rows(table, padded_pos, self.rank * self.part.max_rows, out)
-            if self.world > 1 or self.always_collective:
+            if self.use_native:
+                self.native.allreduce_sum(out)
+            elif self.world > 1 or self.always_collective:
                 dist.all_reduce(out, group=self.group)
             return out
         return self.fetch_rows(self.plan_rows(padded_pos), out, table=table)
@@ -359,15 +425,48 @@ class PartitionedStepper:
         pu, pi = self.P.padded_index(users.to(dev), items.to(dev))
         return torch.cat([pu, pi])
 
-    def step_bce(self, users, items, labels, pos=None, loss_acc=None):
+    def _native_step(self, pos, labels, B, loss_acc, deterministic):
+        """The whole step as ONE library call (spex_partitioned_step_bce_f32): the exchanges go through the model's NativeComm,
+        nothing is issued from Python between the launches."""
+        import ctypes
+        from . import _lib
+        from .graph import _bump, _launch
+        P = self.P
+        if getattr(self, "_desc", None) is None or self._desc_B != self._B:
+            z = lambda *s: torch.zeros(s, dtype=torch.float32, device=self.E0.device)
+            if getattr(self, "_gs", None) is None:
+                self._gs = z(*self.E0.shape)
+            self._arange = torch.arange(2 * self._B, dtype=torch.int64, device=self.E0.device)
+            p = lambda t: t.data_ptr()
+            self._desc = _lib.PartitionedStepDesc(
+                graph=P.graph._h.value, graph_t=P.graph_t._h.value, comm=P.native._h.value,
+                rows_per_rank=None if P._rows_per_rank is None else ctypes.cast(P._rows_per_rank, ctypes.c_void_p).value,
+                E0=p(self.E0), m=p(self.m), v=p(self.v), light_out=p(P.light_out), g_local=p(self.g_local), gs=p(self._gs),
+                grad_E0=p(self.grad_E0), send=p(P.send), gathered=p(P.gathered), rows=p(self.rows), grad_rows=p(self.grad_rows),
+                arange=p(self._arange), n_local=P.n_local, max_rows=P.part.max_rows, slot_capacity=2 * self._B, L=P.L, d=P.d,
+                lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, t=self.t, flags=0)
+            self._desc_B = self._B
+        d = self._desc
+        d.t, d.lr, d.flags = self.t, self.lr, (_lib.STEP_DETERMINISTIC if deterministic else 0)
+        _launch(self.E0.device, "spex_partitioned_step_bce_f32", ctypes.byref(d), ctypes.c_void_p(pos.data_ptr()),
+                ctypes.c_void_p(labels.data_ptr()), B, ctypes.c_void_p(loss_acc.data_ptr()))
+        self.t = d.t
+        _bump(self.E0, self.m, self.v, loss_acc, P.light_out)
+
+    def step_bce(self, users, items, labels, pos=None, loss_acc=None, deterministic=False):
         """One training step.  Returns the batch's mean BCE loss (device tensor) — or, with `loss_acc` (a 1-element device
-        buffer), accumulates the loss SUM into it and returns None."""
+        buffer), accumulates the loss SUM into it and returns None.  With the model's exchange set to "native" / "native-p2p"
+        (PartitionedLightGCN.set_allgather) the whole step is one native call; deterministic selects its atomic-free mode."""
         P, ops = self.P, self.ops
         dev = self.E0.device
         B = users.numel()
         self._buffers(B, dev)
         if pos is None:
             pos = self.positions(users, items)
+        if getattr(P, "use_native", False) and P.d == 64 and P.L >= 1 and self.E0.is_cuda:
+            acc = loss_acc if loss_acc is not None else torch.zeros(1, dtype=torch.float32, device=dev)
+            self._native_step(pos.contiguous(), labels.to(device=dev, dtype=torch.float32).contiguous(), B, acc, deterministic)
+            return None if loss_acc is not None else acc / B
         P.propagate(self.E0)
         rows = P.fetch_rows_at(pos, self.rows)
         _, loss_sum = ops.score_bce(rows, rows, self.ar_u, self.ar_i, labels.to(dev), self.grad_rows, self.grad_rows, 1.0 / B,

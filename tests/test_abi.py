@@ -109,7 +109,7 @@ def test_step_descriptors_have_the_layout_of_the_header(tmp_path):
     size of each struct and the offset of every field (ABI 4 appended fields to all three)."""
     import subprocess
     structs = {"spex_lightgcn_step_t": _lib.LightGCNStepDesc, "spex_ngcf_step_t": _lib.NGCFStepDesc,
-               "spex_dual_task_step_t": _lib.DualTaskStepDesc}
+               "spex_dual_task_step_t": _lib.DualTaskStepDesc, "spex_partitioned_step_t": _lib.PartitionedStepDesc}
     lines = ['#include "spex_hip.h"', "#include <stdio.h>", "#include <stddef.h>", "int main(void) {"]
     for cname, cls in structs.items():
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
@@ -127,4 +127,5 @@ def test_step_descriptors_have_the_layout_of_the_header(tmp_path):
         for fname, _ in cls._fields_:
             assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
     assert _lib.STEP_DETERMINISTIC == 1 and _lib.STEP_FIXED_TASK_WEIGHTS == 2
+    assert re.search(r"#define SPEX_COMM_ID_BYTES %d\b" % _lib.COMM_ID_BYTES, open(HEADER).read())
     assert re.search(r"SPEX_STEP_DETERMINISTIC = 1", open(HEADER).read()) and re.search(r"SPEX_STEP_FIXED_TASK_WEIGHTS = 2", open(HEADER).read())

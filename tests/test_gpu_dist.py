@@ -417,3 +417,78 @@ def test_peer_write_allgather_matches_the_collective(tmp_path):
     for r in range(world):
         d = np.load(tmp_path / f"rank{r}.npz")
         assert bool(d["same"]) and int(d["calls"]) == 5 * 6
+
+
+# ---------------------------------------------------------------------------------------------- collectives behind the C ABI
+def _native_comm_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, REPO)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    from spex_amd.datasets import epinion2_tables, load_epinion2
+    from spex_amd.dist import NativeComm, PartitionedLightGCN, PartitionedStepper
+    from spex_amd.graph import SpexGraph, lightgcn_norm_adj
+    from spex_amd.trainer import LightGCNStepper
+    tr = load_epinion2()["train"]
+    csr = lightgcn_norm_adj(tr[:, 0], tr[:, 1], 3185, 12407)
+    uw, iw = epinion2_tables(3186, 12407)
+    E0 = torch.from_numpy(np.concatenate([uw, iw])).to(dev)
+    rng = np.random.default_rng(3)
+    batches = [(torch.from_numpy(rng.integers(0, 3185, 256)).to(dev), torch.from_numpy(rng.integers(0, 12407, 256)).to(dev),
+                torch.from_numpy((rng.random(256) < 1 / 6).astype(np.float32)).to(dev)) for _ in range(4)]
+    for b in batches:                                                    # repeated rows inside a batch
+        b[0][:8] = b[0][0]
+    factory = lambda r, c, v, n_cols: SpexGraph(r, c, v, n_cols=n_cols, device=dev)
+    out = {}
+    # raw collectives of the library's own communicator (RCCL bound inside libspexhip), world size 1
+    comm = NativeComm(0, 1, dev)
+    send = torch.randn(100, 64, device=dev)
+    recv = torch.zeros(128, 64, device=dev)
+    import ctypes
+    comm.allgather_rows(send, recv, 128, (ctypes.c_int32 * 1)(100))
+    buf = torch.randn(1000, device=dev)
+    want = buf.clone()
+    comm.allreduce_sum(buf)
+    torch.cuda.synchronize()
+    out["raw_ok"] = bool(torch.equal(recv[:100], send) and float(recv[100:].abs().sum()) == 0.0 and torch.equal(buf, want))
+    comm.close()
+    # the partitioned step three ways: collectives from Python (reference path of rounds 1-2), one native call, native deterministic
+    results = {}
+    for mode, det in (("collective", False), ("native", False), ("native-p2p", True), ("native-p2p", True)):
+        P = PartitionedLightGCN(*csr, 3186, 3, 64, 0, 1, factory, dev, allgather=mode)
+        st = PartitionedStepper(P, E0.clone(), lr=1e-3)
+        acc = torch.zeros(1, device=dev)
+        for bu, bi, by in batches:
+            st.step_bce(bu, bi, by, loss_acc=acc, deterministic=det)
+        torch.cuda.synchronize()
+        results.setdefault((mode, det), []).append((st.E0.clone(), acc.clone(), P.propagate(st.E0).clone() if mode == "collective" else None))
+        if mode != "collective":
+            assert st.t == 4 and st._desc is not None
+    single = LightGCNStepper(SpexGraph(*csr, device=dev), E0.clone(), 3186, n_layers=3, lr=1e-3, deterministic=True)
+    acc1 = torch.zeros(1, device=dev)
+    for bu, bi, by in batches:
+        single.step_bce(bu, bi, by, loss_acc=acc1, batch_rows_only=True)
+    ref_E0, ref_acc, _ = results[("collective", False)][0]
+    nat_E0, nat_acc, _ = results[("native", False)][0]
+    d1, d2 = results[("native-p2p", True)]
+    out["native_vs_python"] = float((nat_E0 - ref_E0).abs().max() / ref_E0.abs().max())
+    out["native_loss"] = abs(nat_acc.item() - ref_acc.item()) / abs(ref_acc.item())
+    out["det_repeats"] = bool(torch.equal(d1[0], d2[0]) and torch.equal(d1[1], d2[1]))
+    out["det_vs_single_device_det"] = float((d1[0] - single.E0).abs().max() / single.E0.abs().max())
+    out["det_loss_vs_single"] = abs(d1[1].item() - acc1.item()) / abs(acc1.item())
+    np.savez(os.path.join(out_dir, "native.npz"), **out)
+
+
+def test_native_communicator_and_one_call_partitioned_step(tmp_path):
+    """The collectives behind the C ABI (spex_comm_*: RCCL bound inside libspexhip) and the row-partitioned training
+    step as ONE native call (spex_partitioned_step_bce_f32), on the test box's one GPU at world size 1 — RCCL's init, its
+    all-gather / all-reduce code paths and the whole launch sequence run for real, only the wire is absent (multi-rank RCCL
+    needs one GPU per rank: bench.py --gpus N checks the native exchange against torch.distributed's at start-up there):
+    the raw collectives; four training steps through the native call against the same steps with the collectives issued from
+    Python; the deterministic mode repeating bit for bit and agreeing with the single-device deterministic stepper."""
+    mp.spawn(_native_comm_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    d = np.load(tmp_path / "native.npz")
+    assert bool(d["raw_ok"])
+    assert float(d["native_vs_python"]) <= 2e-6 and float(d["native_loss"]) <= 1e-6, dict(d)
+    assert bool(d["det_repeats"])
+    assert float(d["det_vs_single_device_det"]) <= 5e-6 and float(d["det_loss_vs_single"]) <= 2e-6, dict(d)
