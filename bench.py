@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--no-hbm-roofline", action="store_true")
     ap.add_argument("--no-standalone", action="store_true")
     ap.add_argument("--hbm-log2-nodes", type=int, default=24)     # the scaled roofline graph is N = 2^24
+    ap.add_argument("--no-strong-scaling", action="store_true")   # N > 1: skip the strong-scaling leg on the 2^24-node graph
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -84,12 +85,20 @@ def main():
     # Rehearsal hook for a one-GPU box: SPEX_BENCH_BACKEND=gloo SPEX_BENCH_SHARE_GPU=1 runs the N-rank code path with
     # every rank on cuda:0 (collectives through gloo).  The driver's real runs use one rank per GPU over RCCL.
     share = os.environ.get("SPEX_BENCH_SHARE_GPU") == "1"
+    # SPEX_BENCH_FORCE_PARTITIONED=1 (tests): run the N > 1 code path — row partition, exchange selection, strong-scaling leg —
+    # at world size 1 through the real `nccl` backend, the closest a one-GPU box gets to the driver's multi-GPU runs
+    part = world > 1 or os.environ.get("SPEX_BENCH_FORCE_PARTITIONED") == "1"
     backend = os.environ.get("SPEX_BENCH_BACKEND", "nccl")
     dev_index = 0 if share else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    if part:
         import torch.distributed as dist
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -112,7 +121,7 @@ def main():
     tn = torch.from_numpy(trng.integers(0, m_item, T_TRIPLES)).to(dev)
     lr = 1e-3
 
-    if world == 1:
+    if not part:
         graph = SpexGraph(rowptr, col, val, device=dev)
         stepper = LightGCNStepper(graph, torch.from_numpy(E0_host).to(dev), n_u, n_layers=L, lr=lr)
         local_nnz, local_rows = nnz, n_nodes
@@ -158,6 +167,68 @@ def main():
             except Exception as e:      # noqa: BLE001 — the collective path always works
                 P.use_peer = False
                 ag_info["peer_error"] = repr(e)[:300]
+        # The same exchange behind the C ABI (spex_comm_*: RCCL bound inside libspexhip, include/spex_hip.h): the equal-size
+        # collective ("native") and the grouped point-to-point form that moves the real rows only ("native-p2p").  Both are
+        # checked against the table the torch.distributed path gathered and timed like the peer path; the fastest verified
+        # schedule runs the timed region.  SPEX_BENCH_NATIVE=0 skips this; one GPU shared by several ranks (the rehearsal
+        # mode) cannot host an RCCL communicator and skips it too.
+        if os.environ.get("SPEX_BENCH_NATIVE", "1") != "0" and not share and backend == "nccl":
+            native_info = {}
+            try:
+                import ctypes
+                from spex_amd import _lib as _slib
+                probe = ctypes.create_string_buffer(_slib.COMM_ID_BYTES)
+                ok = torch.tensor([1.0 if _slib.load().spex_comm_unique_id(probe) == 0 else 0.0], device=dev)   # librccl loads here?
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if ok.item() != 1.0:
+                    raise RuntimeError("librccl could not be bound on every rank")
+                keep_mode = "peer" if P.use_peer else "collective"
+                best = ag_info.get("propagate_ms_" + keep_mode)
+                P.set_allgather("collective")
+                ref = P.propagate(E0_local).clone()
+                if best is None:
+                    for _ in range(3):
+                        P.propagate(E0_local)
+                    torch.cuda.synchronize(); dist.barrier()
+                    t_ = time.perf_counter()
+                    for _ in range(10):
+                        P.propagate(E0_local)
+                    torch.cuda.synchronize()
+                    tt_ = torch.tensor([time.perf_counter() - t_], device=dev, dtype=torch.float64)
+                    dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+                    best = tt_.item() / 10 * 1e3
+                    ag_info["propagate_ms_collective"] = best
+                use = keep_mode
+                for mode in ("native", "native-p2p"):
+                    P.set_allgather(mode)
+                    same = torch.equal(P.propagate(E0_local), ref)
+                    ok = torch.tensor([1.0 if same else 0.0], device=dev)
+                    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                    native_info[mode + "_equal"] = ok.item() == 1.0
+                    if ok.item() != 1.0:
+                        continue
+                    for _ in range(3):
+                        P.propagate(E0_local)
+                    torch.cuda.synchronize(); dist.barrier()
+                    t_ = time.perf_counter()
+                    for _ in range(10):
+                        P.propagate(E0_local)
+                    torch.cuda.synchronize()
+                    tt_ = torch.tensor([time.perf_counter() - t_], device=dev, dtype=torch.float64)
+                    dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+                    ms_ = tt_.item() / 10 * 1e3
+                    native_info["propagate_ms_" + mode] = ms_
+                    if ms_ < best:
+                        best, use = ms_, mode
+                P.set_allgather(use)
+                ag_info["used"] = use
+            except Exception as e:      # noqa: BLE001 — torch.distributed's path stays in place
+                native_info["error"] = repr(e)[:300]
+                try:
+                    P.set_allgather("peer" if ag_info.get("used") == "peer" else "collective")
+                except Exception:       # noqa: BLE001
+                    P.use_native = False
+            ag_info["native"] = native_info
         pu, pp = P.padded_index(tu, tp)
         _, pn = P.padded_index(tu, tn)
         pos_all = torch.cat([pu, pp, pn])
@@ -191,7 +262,7 @@ def main():
             return loss_acc
 
     def barrier():
-        if world > 1:
+        if part:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -206,7 +277,7 @@ def main():
     # makes them anyway, and in front they also bring the GPU to its steady clocks before the K timed steps (the
     # driver's 20-step timed region is 1 ms long).
     aux = {}
-    if world == 1 and not a.no_standalone:
+    if not part and not a.no_standalone:
         try:
             for _ in range(300):                      # bring the GPU to its steady clocks first (the set-up above left it idle)
                 stepper.propagate()
@@ -347,11 +418,11 @@ def main():
     # reset right before the timed region, so that nothing but a synchronisation separates the warm-up from the K steps:
     # a gap of tens of milliseconds there (it used to hold a 40 ms garbage collection) lets the GPU clock down and made
     # a 20-step timed region read 8 us per step slower than a 200-step one.
-    every = max(5, a.steps // 100) * (1 if world == 1 else L)
+    every = max(5, a.steps // 100) * (1 if not part else L)
     graph.attach_timer(128, every=every)
     for _ in range(a.warmup):
         step()
-    if world > 1 and delta["on"]:
+    if part and delta["on"]:
         # the replicated E0 must equal a real all-gather of the owners' rows, bit for bit, on every rank
         same = torch.equal(P.gathered0, P.all_gather_rows(E0_local, out=torch.empty_like(P.gathered0)))
         ok_ = torch.tensor([1.0 if same else 0.0], device=dev)
@@ -391,15 +462,55 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if part:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
     bracket_ms, bracket_launches = graph.read_timer(per_launch=False)
     graph.detach_timer()
 
+    # ---- N > 1: STRONG scaling on the one size where a row partition can win: the 2^24-node graph (450 M stored
+    #      entries, a 4.3 GB table) partitioned over the N ranks — 18.7 / N ms of SpMM per layer against the all-gather of the
+    #      4.3 GB table.  Reported in `extra` (the headline `value` stays the weak-scaling figure the contract names).
+    strong = None
+    if part and not a.no_strong_scaling:
+        try:
+            from spex_amd.datasets import scaled_graph
+            del P, E0_local
+            torch.cuda.empty_cache()
+            t_b = time.perf_counter()
+            rp, cc, vv, n_u2 = scaled_graph(a.hbm_log2_nodes, device=dev)          # identical on every rank (seeded)
+            n2, nnz2 = len(rp) - 1, len(cc)
+            from spex_amd.dist import PartitionedLightGCN as _PL
+            P2 = _PL(rp, cc, vv, n_u2, L, D, rank, world, lambda r, c, v, n_cols: SpexGraph(r, c, v, n_cols=n_cols, device=dev), dev)
+            del rp, cc, vv
+            build_s = time.perf_counter() - t_b
+            if ag_info.get("used") in ("native", "native-p2p"):
+                P2.set_allgather(ag_info["used"])
+            X2 = (torch.rand(P2.n_local, D, device=dev) - 0.5) * 0.1
+            for _ in range(2):
+                P2.propagate(X2)
+            barrier()
+            t_ = time.perf_counter()
+            n_it = 5
+            for _ in range(n_it):
+                P2.propagate(X2)
+            torch.cuda.synchronize()
+            tt_ = torch.tensor([time.perf_counter() - t_], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+            ms_prop = tt_.item() / n_it * 1e3
+            strong = {"workload": "Epinion2 x %d replicas, N=%d nodes ~2^%d, nnz=%d, d=64: ONE graph row-partitioned over %d ranks"
+                                  % (round((1 << a.hbm_log2_nodes) / 15593), n2, a.hbm_log2_nodes, nnz2, world),
+                      "propagation_ms": ms_prop, "edges_per_s": L * nnz2 / (ms_prop * 1e-3), "layers": L,
+                      "exchange": ag_info.get("used", "collective"), "local_rows": P2.n_local, "local_nnz": P2.graph.nnz,
+                      "table_gb": n2 * D * 4 / 1e9, "build_s": build_s,
+                      "single_gpu_reference": "roofline_hbm of the N = 1 run of the same bench (one launch of the whole graph = one layer)"}
+            del P2, X2
+        except Exception as e:      # noqa: BLE001
+            strong = {"error": repr(e)[:300]}
+
     if rank != 0:
-        if world > 1:
+        if part:
             dist.destroy_process_group()
         return
 
@@ -414,12 +525,12 @@ def main():
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("epinion2 (reference preprocessing of the shipped Epinions .mat; N=%d nnz=%d d=%d L=%d)"
-                                % (n_nodes, nnz, D, L)) if world == 1 else
+                                % (n_nodes, nnz, D, L)) if not part else
                                ("epinion2 x%d replicas cross-linked by per-interaction permutations; N=%d nnz=%d d=%d L=%d; "
                                 "1-D row partition + RCCL all-gather per layer" % (world, n_nodes, nnz, D, L)),
                    "bpr_triples_per_step": T_TRIPLES, "embeddings": "xavier-uniform seed 2020 (synthetic weights)",
-                   "parallelism": "single GPU" if world == 1 else "row-partition x%d" % world,
-                   **({} if world == 1 else {"allgather": ag_info, "first_layer_exchange": dict(delta_info, used="deltas of the updated rows" if delta["on"] else "all-gather")})},
+                   "parallelism": "single GPU" if not part else "row-partition x%d" % world,
+                   **({} if not part else {"allgather": ag_info, "first_layer_exchange": dict(delta_info, used="deltas of the updated rows" if delta["on"] else "all-gather")})},
         "roofline": {"bound": "hbm", "kernel": "spmm_chunk_kernel<1>", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "cache_algorithmic_frac": achieved / HBM_PEAK_GBS,
@@ -428,7 +539,7 @@ def main():
                      "compulsory_bytes_per_launch": compulsory_bytes(local_nnz, local_rows),
                      "regime": "cache-resident (4 MB table in L2 / Infinity Cache): `frac` = algorithmic bytes / time / HBM peak is "
                                "a cache-bandwidth figure here, NOT an HBM utilisation — see roofline_hbm for that"},
-        "extra": dict(aux, bpr_triples_per_s_in_step=T_TRIPLES * a.steps / dt),
+        "extra": dict(aux, bpr_triples_per_s_in_step=T_TRIPLES * a.steps / dt, **({"strong_scaling_hbm_graph": strong} if strong else {})),
     }
     traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     stored = {}
@@ -437,7 +548,7 @@ def main():
             stored = json.load(open(traffic_file))
         except Exception:
             stored = {}
-    if world == 1 and stored.get("epinion2_spmm_bytes_per_launch"):
+    if not part and stored.get("epinion2_spmm_bytes_per_launch"):
         tb = stored["epinion2_spmm_bytes_per_launch"]
         out["roofline"]["traffic"] = tb
         out["roofline"]["traffic_is_stored_profile"] = True
@@ -446,7 +557,7 @@ def main():
         out["roofline"]["l2_miss_traffic_GBs"] = tb / (spmm_ms * 1e-3) / 1e9
         out["roofline"]["l2_hit_rate_profiled"] = stored.get("epinion2_l2_hit_rate")
 
-    if world == 1:
+    if not part:
         # ---- HBM-resident graph: where the roofline fraction is meaningful
         if not a.no_hbm_roofline:
             try:
@@ -570,7 +681,7 @@ def main():
                 out["cpu_baseline"] = {"error": repr(e)}
 
     print(json.dumps(out))
-    if world > 1:
+    if part:
         dist.destroy_process_group()
 
 

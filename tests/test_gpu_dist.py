@@ -335,7 +335,8 @@ def test_bench_multi_rank_path_rehearsal():
     import sys
     env = dict(os.environ, SPEX_BENCH_SHARE_GPU="1", SPEX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"]
+           "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+           "--hbm-log2-nodes", "17"]                    # (the strong-scaling leg on a 2^17-node graph here; 2^24 in the driver's runs)
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=REPO, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -345,6 +346,34 @@ def test_bench_multi_rank_path_rehearsal():
     assert out["config"]["parallelism"] == "row-partition x2" and out["value"] > 0 and out["roofline"]["achieved"] > 0
     # whole-job aggregate: L * nnz(Epinion2 x 2) * steps / time
     assert abs(out["value"] - 3 * 2 * 418608 * 20 / (out["ms_per_step"] * 20 * 1e-3)) <= 1e-6 * out["value"]
+    # the strong-scaling leg: ONE graph (here 2^17 nodes) row-partitioned over the two ranks
+    ss = out["extra"]["strong_scaling_hbm_graph"]
+    assert "error" not in ss, ss
+    assert ss["propagation_ms"] > 0 and ss["edges_per_s"] > 0 and ss["local_rows"] > 0 and ss["layers"] == 3
+
+
+def test_bench_partitioned_path_through_the_nccl_backend_and_the_native_exchange():
+    """bench.py's N > 1 code path forced at world size 1 (SPEX_BENCH_FORCE_PARTITIONED=1) through the REAL `nccl` backend: the
+    row partition, torch.distributed's RCCL collectives, the selection among the exchanges — where the library's own
+    communicator (spex_comm_*: "native" and "native-p2p") is built, verified against the torch.distributed table and timed —
+    and the strong-scaling leg.  With one rank nothing crosses a link, but every call of the driver's multi-GPU run is made."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, SPEX_BENCH_FORCE_PARTITIONED="1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--steps", "20", "--warmup", "5", "--hbm-log2-nodes", "17"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=REPO, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    ag = out["config"]["allgather"]
+    assert "error" not in ag["native"], ag
+    assert ag["native"]["native_equal"] is True and ag["native"]["native-p2p_equal"] is True, ag
+    assert ag["native"]["propagate_ms_native"] > 0 and ag["used"] in ("collective", "peer", "native", "native-p2p")
+    ss = out["extra"]["strong_scaling_hbm_graph"]
+    assert "error" not in ss and ss["propagation_ms"] > 0, ss
+    assert out["value"] > 0 and out["n_gpus"] == 1
 
 
 def test_bench_single_gpu_line_is_well_formed():
