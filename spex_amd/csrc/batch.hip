@@ -89,7 +89,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void lightgcn_batch_kernel(
     int n_user_rows, const float *__restrict__ X, const float *__restrict__ acc_in, float acc_div,
     const int64_t *__restrict__ users, const int64_t *__restrict__ items, const float *__restrict__ labels, int parts,
     float grad_scale, float push_scale, float *loss_sum, float *__restrict__ loss_rows, float *g_out, float *G, int runs_per_part,
-    float *__restrict__ grad_slots, int B)
+    float *__restrict__ grad_slots, int B, const float *__restrict__ acc2, const float *__restrict__ acc3)
 {
     // (the push walks the same rows of the same matrix as the forward: t_* are aliases kept for readability)
     const int32_t *__restrict__ t_rowptr = rowptr, *__restrict__ t_col = col;
@@ -113,8 +113,19 @@ __global__ __launch_bounds__(kWave *kWgWaves) void lightgcn_batch_kernel(
     const int t_beg[2] = {t_rowptr[row[0]], t_rowptr[row[1]]};
     const int t_len[2] = {t_rowptr[row[0] + 1] - t_beg[0], t_rowptr[row[1] + 1] - t_beg[1]};
     const float y_lab = labels[b];
+    // acc_in is the running layer sum — or, when the forward layers ran in the plain form (the one-call step: no epilogue operand,
+    // no second output stream per launch), E^0 with acc2 / acc3 the later layers' tables: the sum is formed HERE, at the batch's
+    // rows only, in the same order ((E^0 + E^1) + E^2) + y as the fused epilogues form it — bit-identical
     float run = 0.0f;
-    if (wave < 2) run = acc_in[(size_t)row[wave] * kWave + lane];
+    if (wave < 2) {
+        const size_t o = (size_t)row[wave] * kWave + lane;
+        run = acc_in[o];
+        float r2 = 0.0f, r3 = 0.0f;
+        if (acc2) r2 = acc2[o];
+        if (acc3) r3 = acc3[o];
+        if (acc2) run = run + r2;
+        if (acc3) run = run + r3;
+    }
     // the push's runs of 16 entries, both rows' runs numbered jointly and dealt over (part, wave); the first kPre of this wave
     // are loaded here, ahead of the forward, so that their round trip is off the chain
     const int n_run0 = (t_len[0] + 15) >> 4, n_runs = n_run0 + ((t_len[1] + 15) >> 4);
@@ -238,7 +249,8 @@ __global__ __launch_bounds__(kWave *kWgWaves) void gated_batch_fwd_kernel(
     const float *__restrict__ X, const float *__restrict__ acc_in, float acc_div, const float *__restrict__ raw,
     const float *__restrict__ att_u, const float *__restrict__ att_i, const int64_t *__restrict__ users,
     const int64_t *__restrict__ items, const float *__restrict__ labels, int B, float grad_scale, float *loss_sum,
-    float *__restrict__ lo_batch, float *__restrict__ grad_slots, float *__restrict__ loss_rows)
+    float *__restrict__ lo_batch, float *__restrict__ grad_slots, float *__restrict__ loss_rows, const float *__restrict__ acc2,
+    const float *__restrict__ acc3)
 {
     __shared__ float s_part[2][kWgWaves][kWave];
     __shared__ float s_mixed[2][kWave];
@@ -262,6 +274,11 @@ __global__ __launch_bounds__(kWave *kWgWaves) void gated_batch_fwd_kernel(
     if (wave < 2) {                       // the gate's operands, requested with everything else
         const float *att = wave ? att_i : att_u;
         run = acc_in[(size_t)row[wave] * kWave + lane];
+        float r2 = 0.0f, r3 = 0.0f;                          // (plain-form forward layers: see lightgcn_batch_kernel)
+        if (acc2) r2 = acc2[(size_t)row[wave] * kWave + lane];
+        if (acc3) r3 = acc3[(size_t)row[wave] * kWave + lane];
+        if (acc2) run = run + r2;
+        if (acc3) run = run + r3;
         a_raw = raw[(size_t)row[wave] * kWave + lane];
         w00 = att[2 * lane]; w01 = att[2 * lane + 1];
         w10 = att[2 * (kWave + lane)]; w11 = att[2 * (kWave + lane) + 1];
@@ -316,6 +333,15 @@ extern "C" int spex_gated_batch_fwd_f32(const spex_graph_t *g, const float *X, c
                                        const float *labels, int32_t B, int32_t n_user_rows, float grad_scale, float *loss_sum,
                                        float *loss_per_sample, float *lo_batch, float *grad_slots, int32_t d, void *stream)
 {
+    return spex::gated_batch_fwd_layers(g, X, acc_in, nullptr, nullptr, acc_div, raw, att_u, att_i, users, items, labels, B, n_user_rows,
+                                        grad_scale, loss_sum, loss_per_sample, lo_batch, grad_slots, d, stream);
+}
+
+int spex::gated_batch_fwd_layers(const spex_graph_t *g, const float *X, const float *acc_in, const float *acc2, const float *acc3,
+                                 float acc_div, const float *raw, const float *att_u, const float *att_i, const int64_t *users,
+                                 const int64_t *items, const float *labels, int32_t B, int32_t n_user_rows, float grad_scale,
+                                 float *loss_sum, float *loss_per_sample, float *lo_batch, float *grad_slots, int32_t d, void *stream)
+{
     SPEX_CHECK_ARG(g && X && acc_in && raw && att_u && att_i && users && items && labels && (loss_sum || loss_per_sample) && lo_batch
                        && grad_slots,
                    "spex_gated_batch_fwd_f32: NULL argument");
@@ -329,7 +355,7 @@ extern "C" int spex_gated_batch_fwd_f32(const spex_graph_t *g, const float *X, c
     if (B == 0 || g->n_rows == 0) return SPEX_OK;
     hipLaunchKernelGGL(gated_batch_fwd_kernel, dim3((unsigned)B), dim3(kWave * kWgWaves), 0, (hipStream_t)stream, g->rowptr, g->col, g->val,
                        g->n_rows, n_user_rows, X, acc_in, acc_div, raw, att_u, att_i, users, items, labels, B, grad_scale, loss_sum, lo_batch,
-                       grad_slots, loss_per_sample);
+                       grad_slots, loss_per_sample, acc2, acc3);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }
@@ -348,6 +374,15 @@ extern "C" int spex_lightgcn_batch_slots_f32(const spex_graph_t *g, const float 
                                              int32_t n_user_rows, float grad_scale, float *loss_sum, float *loss_per_sample,
                                              float *grad_slots, int32_t d, void *stream)
 {
+    return spex::lightgcn_batch_slots_layers(g, X, acc_in, nullptr, nullptr, acc_div, users, items, labels, B, n_user_rows, grad_scale,
+                                             loss_sum, loss_per_sample, grad_slots, d, stream);
+}
+
+int spex::lightgcn_batch_slots_layers(const spex_graph_t *g, const float *X, const float *acc_in, const float *acc2, const float *acc3,
+                                      float acc_div, const int64_t *users, const int64_t *items, const float *labels, int32_t B,
+                                      int32_t n_user_rows, float grad_scale, float *loss_sum, float *loss_per_sample, float *grad_slots,
+                                      int32_t d, void *stream)
+{
     SPEX_CHECK_ARG(g && X && acc_in && users && items && labels && (loss_sum || loss_per_sample) && grad_slots,
                    "spex_lightgcn_batch_slots_f32: NULL argument");
     SPEX_CHECK_ARG(B >= 0 && n_user_rows >= 0 && n_user_rows <= g->n_rows, "spex_lightgcn_batch_slots_f32: B=%d n_user_rows=%d", B, n_user_rows);
@@ -360,7 +395,7 @@ extern "C" int spex_lightgcn_batch_slots_f32(const spex_graph_t *g, const float 
     if (B == 0 || g->n_rows == 0) return SPEX_OK;
     hipLaunchKernelGGL(lightgcn_batch_kernel<false>, dim3((unsigned)B), dim3(kWave * kWgWaves), 0, (hipStream_t)stream, g->rowptr, g->col,
                        g->val, g->n_rows, n_user_rows, X, acc_in, acc_div, users, items, labels, 1, grad_scale, 0.0f, loss_sum,
-                       loss_per_sample, nullptr, nullptr, 1, grad_slots, B);
+                       loss_per_sample, nullptr, nullptr, 1, grad_slots, B, acc2, acc3);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }
@@ -369,6 +404,15 @@ extern "C" int spex_lightgcn_batch_f32(const spex_graph_t *g, const float *X, co
                                        const int64_t *users, const int64_t *items, const float *labels, int32_t B,
                                        int32_t n_user_rows, float grad_scale, float push_scale, float *loss_sum, float *loss_per_sample,
                                        float *g_out, float *G, int32_t d, void *stream)
+{
+    return spex::lightgcn_batch_layers(g, X, acc_in, nullptr, nullptr, acc_div, users, items, labels, B, n_user_rows, grad_scale, push_scale,
+                                       loss_sum, loss_per_sample, g_out, G, d, stream);
+}
+
+int spex::lightgcn_batch_layers(const spex_graph_t *g, const float *X, const float *acc_in, const float *acc2, const float *acc3,
+                                float acc_div, const int64_t *users, const int64_t *items, const float *labels, int32_t B,
+                                int32_t n_user_rows, float grad_scale, float push_scale, float *loss_sum, float *loss_per_sample, float *g_out,
+                                float *G, int32_t d, void *stream)
 {
     SPEX_CHECK_ARG(g && X && acc_in && users && items && labels && (loss_sum || loss_per_sample) && g_out && G,
                    "spex_lightgcn_batch_f32: NULL argument");
@@ -392,7 +436,7 @@ extern "C" int spex_lightgcn_batch_f32(const spex_graph_t *g, const float *X, co
     }();
     hipLaunchKernelGGL(lightgcn_batch_kernel<true>, dim3((unsigned)B * parts), dim3(kWave * kWgWaves), 0, (hipStream_t)stream, g->rowptr,
                        g->col, g->val, g->n_rows, n_user_rows, X, acc_in, acc_div, users, items, labels, parts, grad_scale, push_scale,
-                       loss_sum, loss_per_sample, g_out, G, runs_per_part, nullptr, B);
+                       loss_sum, loss_per_sample, g_out, G, runs_per_part, nullptr, B, acc2, acc3);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }

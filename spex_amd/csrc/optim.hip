@@ -28,21 +28,50 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
                                                    float *__restrict__ m, float *__restrict__ v, int64_t n4,
                                                    int64_t rem, float w1, float beta2, float w2, float bc2_sqrt,
                                                    float eps, float step_size, float *zero_buf, float *zero_buf2,
-                                                   const float *__restrict__ loss_rows, int n_loss, float *loss_sum)
+                                                   const float *__restrict__ loss_rows, int n_loss, float *loss_sum,
+                                                   const spex::SmallAdam small, const int main_blocks, const float *add_g,
+                                                   const float add_div)
 {
+    // A second, small parameter block rides in the same launch (the NGCF step's layer weights: 8 320 parameters whose gradient
+    // arrives as partial blocks — a launch of their own cost the step ~5 us of ramp for 33 workgroups): the blocks behind the
+    // table's take one parameter per thread, sum its partial gradients in part order (deterministic) and update it.
+    if ((int)blockIdx.x >= main_blocks) {
+        const int i = ((int)blockIdx.x - main_blocks) * (int)blockDim.x + (int)threadIdx.x;
+        if (i < small.n) {
+            float gs = 0.0f;
+            int k = 0;
+            for (; k + 8 <= small.n_parts; k += 8) {             // eight independent loads in flight, added in part order
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = small.parts[(size_t)(k + j) * small.stride + i];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) gs += x[j];
+            }
+            for (; k < small.n_parts; ++k) gs += small.parts[(size_t)k * small.stride + i];
+            float P = small.p[i], M = small.m[i], V = small.v[i];
+            adam1(P, gs, M, V, w1, beta2, w2, bc2_sqrt, eps, step_size);
+            small.p[i] = P; small.m[i] = M; small.v[i] = V;
+        }
+        return;
+    }
     // the step's per-sample losses (written by the batch kernel with plain stores) are summed HERE, in a fixed order, and added
     // to the epoch's accumulator as ONE addend per step: one atomic per sample onto the accumulator (1.25 M adds of ~0.7 onto a
     // sum that reaches 8.5e5 in an Epinion2 epoch) lost 6e-5 of the epoch's loss to fp32 rounding
-    if (loss_rows && blockIdx.x == gridDim.x - 1 && threadIdx.x < spex::kWave) {
+    if (loss_rows && (int)blockIdx.x == main_blocks - 1 && threadIdx.x < spex::kWave) {
         float t = 0.0f;
         for (int i = threadIdx.x; i < n_loss; i += spex::kWave) t += loss_rows[i];
         t = spex::wave_sum_f32(t);
         if (threadIdx.x == 0) *loss_sum += t;
     }
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t stride = (int64_t)main_blocks * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         float4 P = reinterpret_cast<float4 *>(p)[i];
-        const float4 G = reinterpret_cast<const float4 *>(g)[i];
+        float4 G = reinterpret_cast<const float4 *>(g)[i];
+        if (add_g) {      // gradient = g + add_g / add_div: the mean's own share g/(L+1) of the LAST backward product, added here (this
+                          // pass reads add_g anyway, to clear it) so that that product runs in the plain form
+            const float4 A = reinterpret_cast<const float4 *>(add_g)[i];
+            G.x = G.x + A.x / add_div; G.y = G.y + A.y / add_div; G.z = G.z + A.z / add_div; G.w = G.w + A.w / add_div;
+        }
         float4 M = reinterpret_cast<float4 *>(m)[i];
         float4 V = reinterpret_cast<float4 *>(v)[i];
         adam1(P.x, G.x, M.x, V.x, w1, beta2, w2, bc2_sqrt, eps, step_size);
@@ -58,7 +87,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
     if (blockIdx.x == 0 && (int64_t)threadIdx.x < rem) {
         const int64_t i = n4 * 4 + threadIdx.x;
         float P = p[i], M = m[i], V = v[i];
-        adam1(P, g[i], M, V, w1, beta2, w2, bc2_sqrt, eps, step_size);
+        adam1(P, add_g ? g[i] + add_g[i] / add_div : g[i], M, V, w1, beta2, w2, bc2_sqrt, eps, step_size);
         p[i] = P; m[i] = M; v[i] = V;
         if (zero_buf) zero_buf[i] = 0.0f;
         if (zero_buf2) zero_buf2[i] = 0.0f;
@@ -69,8 +98,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
 
 // Internal form with a second buffer to clear (the one-call training step keeps its push target all-zero this way).
 int spex::adam_step_z2(float *p, const float *g, float *m, float *v, int64_t n, int32_t t, float lr, float beta1, float beta2,
-                       float eps, float *zero_buf, float *zero_buf2, void *stream, const float *loss_rows, int32_t n_loss, float *loss_sum)
+                       float eps, float *zero_buf, float *zero_buf2, void *stream, const float *loss_rows, int32_t n_loss, float *loss_sum,
+                       const spex::SmallAdam *small_in, const float *add_g, float add_div)
 {
+    SPEX_CHECK_ARG(!add_g || ((((uintptr_t)add_g) & 15) == 0 && add_div != 0.0f), "spex_adam_step_f32: add_g unaligned or add_div == 0");
+    spex::SmallAdam small{};
+    if (small_in) small = *small_in;
+    SPEX_CHECK_ARG(small.n == 0 || (small.p && small.m && small.v && small.parts && small.n_parts >= 1 && small.stride >= small.n),
+                   "spex_adam_step_f32: bad second parameter block");
     SPEX_CHECK_ARG(!loss_rows || (loss_sum && n_loss >= 0), "spex_adam_step_f32: loss rows without an accumulator");
     SPEX_CHECK_ARG(p && g && m && v, "spex_adam_step_f32: NULL pointer");
     SPEX_CHECK_ARG(n >= 0 && t >= 1, "spex_adam_step_f32: n=%lld t=%d (t counts from 1)", (long long)n, t);
@@ -87,8 +122,10 @@ int spex::adam_step_z2(float *p, const float *g, float *m, float *v, int64_t n, 
     int64_t blocks = (n4 + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, rem,
-                       1.0f - beta1, beta2, 1.0f - beta2, bc2_sqrt, eps, step_size, zero_buf, zero_buf2, loss_rows, (int)n_loss, loss_sum);
+    const int64_t small_blocks = (small.n + 255) / 256;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)(blocks + small_blocks)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, rem,
+                       1.0f - beta1, beta2, 1.0f - beta2, bc2_sqrt, eps, step_size, zero_buf, zero_buf2, loss_rows, (int)n_loss, loss_sum,
+                       small, (int)blocks, add_g, add_div);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }
@@ -155,6 +192,8 @@ struct DualAdamArgs {
     int64_t n_table, n_user, n_trust, n_total;     // floats: table, user rows of it, trust block, whole arena (excl. padding)
     int32_t B, T, n_rec, slot, fixed;
     float w1, beta2, w2, bc2_sqrt, eps, step_size;
+    float prop_div;      // > 0: g_E0 is the PLAIN last backward product and its g_prop / prop_div share is added here (g_prop is read
+                         // before this pass clears it); 0: g_E0 already holds it
 };
 
 __global__ __launch_bounds__(256) void dual_task_adam_kernel(const DualAdamArgs a)
@@ -167,7 +206,9 @@ __global__ __launch_bounds__(256) void dual_task_adam_kernel(const DualAdamArgs 
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_gate_end; i += stride) {
         float g;
         if (i < a.n_table) {
-            g = p1 * (a.g_E0[i] + a.g_raw[i]);
+            float ge = a.g_E0[i];
+            if (a.prop_div > 0.0f) ge = ge + a.g_prop[i] / a.prop_div;
+            g = p1 * (ge + a.g_raw[i]);
             if (i < a.n_user) {
                 g = fmaf(p2, a.g_user[i], g);
                 a.g_user[i] = 0.0f;
@@ -206,12 +247,12 @@ int spex::dual_task_adam(float *p, float *m, float *v, const float *g_E0, float 
                          float *g_prop, float *push_zero, float *loss, float *loss_acc, float *prec, int64_t n_table, int64_t n_user,
                          int64_t n_trust,
                          int32_t B, int32_t T, int32_t n_rec, int32_t t, float lr, float beta1, float beta2, float eps, int fixed_weights,
-                         void *stream)
+                         void *stream, float prop_div)
 {
     const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
     const DualAdamArgs a{p, m, v, g_E0, g_raw, g_raw, g_user, g_small, g_prop, push_zero, loss, loss_acc, prec, n_table, n_user, n_trust,
                          n_table + n_trust + 512 + 2, B, T, n_rec, t & 1, fixed_weights, 1.0f - beta1, beta2, 1.0f - beta2, (float)sqrt(bc2), eps,
-                         (float)((double)lr / bc1)};
+                         (float)((double)lr / bc1), prop_div};
     int64_t blocks = (n_table + n_trust + 512 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(dual_task_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);

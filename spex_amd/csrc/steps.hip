@@ -32,13 +32,21 @@ extern "C" int spex_lightgcn_step_bce_f32(spex_lightgcn_step_t *s, const int64_t
     SPEX_CHECK_ARG(g->mask_mode == 0 && gt->mask_mode == 0, "spex_lightgcn_step_bce_f32: edge dropout is not supported in the one-call step");
     const size_t sz = (size_t)g->n_rows * d;
     const bool det = (s->flags & SPEX_STEP_DETERMINISTIC) != 0;
-    // ---- forward: layers 0 .. L-2 over the whole graph (running layer sum fused); the last layer is taken at the batch's rows only
+    // ---- forward: layers 0 .. L-2 over the whole graph; the last layer is taken at the batch's rows only.  For L <= 3 the whole-graph
+    //      launches run in the PLAIN form (no epilogue operand, one output stream: 12.3 vs 14.8 us on Epinion2) into the two halves of
+    //      ws_fwd, and the batch kernel forms the layer sum (E^0 + E^1 (+ E^2)) + y at the batch's rows — the only rows the loss
+    //      reads — in the fused epilogues' order; deeper models keep the running sum fused into the launches.
+    const bool plain = L >= 2 && L <= 3;
     const float *cur = s->E0;
     for (int32_t l = 0; l + 1 < L; ++l) {
         float *nxt = s->ws_fwd + (size_t)(l & 1) * sz;
-        SPEX_TRY(spex_spmm_f32(g, cur, nxt, nullptr, 1.0f, l == 0 ? s->E0 : s->light_out, s->light_out, 1.0f, d, stream));
+        if (plain) SPEX_TRY(spex_spmm_f32(g, cur, nxt, nullptr, 1.0f, nullptr, nullptr, 1.0f, d, stream));
+        else SPEX_TRY(spex_spmm_f32(g, cur, nxt, nullptr, 1.0f, l == 0 ? s->E0 : s->light_out, s->light_out, 1.0f, d, stream));
         cur = nxt;
     }
+    // the tables whose rows the batch kernel adds in front of the last layer's product: E^0 (+ E^1 + E^2), or the running sum
+    const float *sum0 = plain || L == 1 ? s->E0 : s->light_out;
+    const float *sum1 = plain ? s->ws_fwd : nullptr, *sum2 = plain && L == 3 ? s->ws_fwd + sz : nullptr;
     if (det) {
         // ---- SPEX_STEP_DETERMINISTIC: the same forward (same kernel code for the batch's rows: bit-identical scores), but every sum
         //      that the fast path leaves to float atomics is taken in a fixed order — the sample's two gradient rows leave as
@@ -46,8 +54,8 @@ extern "C" int spex_lightgcn_step_bce_f32(spex_lightgcn_step_t *s, const int64_t
         //      model.py:115-116), and the whole backward runs in pull form (each output row one chain in ascending column order,
         //      like the reference's sparse addmm).  Per-sample losses: head of lo_batch, summed in order by the Adam pass.
         float *loss_rows = s->lo_batch;
-        SPEX_TRY(spex_lightgcn_batch_slots_f32(g, cur, L == 1 ? s->E0 : s->light_out, (float)(L + 1), users, items, labels, B, n_u,
-                                               1.0f / (float)B, nullptr, loss_rows, s->grad_slots, d, stream));
+        SPEX_TRY(spex::lightgcn_batch_slots_layers(g, cur, sum0, sum1, sum2, (float)(L + 1), users, items, labels, B, n_u,
+                                                   1.0f / (float)B, nullptr, loss_rows, s->grad_slots, d, stream));
         SPEX_TRY(spex_reduce_slots_f32(users, B, 0, items, B, n_u, g->n_rows, s->grad_slots, d, 1.0f, s->g_out, 0, d, stream));
         SPEX_TRY(spex_propagate_bwd_f32(gt, s->g_out, s->grad_E0, s->ws_bwd, L, d, stream));
         SPEX_TRY(spex::adam_step_z2(s->E0, s->grad_E0, s->m, s->v, (int64_t)sz, s->t + 1, s->lr, s->beta1, s->beta2, s->eps, s->g_out,
@@ -60,16 +68,22 @@ extern "C" int spex_lightgcn_step_bce_f32(spex_lightgcn_step_t *s, const int64_t
         //      first backward product G_{L-1} = (g + A^T g) / (L+1) in push form — over the rows of A itself: (A^T g)[c] = sum_r
         //      A[r, c] g[r] — (g_out and G are all-zero here: the Adam pass below clears them for the next step; first call: the caller)
         float *G = s->ws_bwd;
-        SPEX_TRY(spex_lightgcn_batch_f32(g, cur, s->light_out, (float)(L + 1), users, items, labels, B, n_u, 1.0f / (float)B,
-                                         1.0f / (float)(L + 1), nullptr, s->grad_slots /* per-sample losses, summed by the Adam pass */,
-                                         s->g_out, G, d, stream));
-        // ---- L-1 pull-form products
+        SPEX_TRY(spex::lightgcn_batch_layers(g, cur, sum0, sum1, sum2, (float)(L + 1), users, items, labels, B, n_u, 1.0f / (float)B,
+                                             1.0f / (float)(L + 1), nullptr, s->grad_slots /* per-sample losses, summed by the Adam pass */,
+                                             s->g_out, G, d, stream));
+        // ---- L-1 pull-form products G_l = g / (L+1) + A^T G_{l+1}.  The last one (l = 0) runs in the PLAIN form: its g / (L+1) term
+        //      is added by the Adam pass, which reads g_out anyway to clear it (one epilogue stream less on a 15 us launch)
         const float *c2 = G;
         for (int32_t l = L - 2; l >= 0; --l) {
             float *nxt = l == 0 ? s->grad_E0 : s->ws_bwd + (size_t)(1 + ((L - 2 - l) & 1)) * sz;   // ws_bwd[1], [2], [1] ...: never the source, never G
-            SPEX_TRY(spex_spmm_f32(gt, c2, nxt, s->g_out, (float)(L + 1), nullptr, nullptr, 1.0f, d, stream));
+            if (l == 0) SPEX_TRY(spex_spmm_f32(gt, c2, nxt, nullptr, 1.0f, nullptr, nullptr, 1.0f, d, stream));
+            else SPEX_TRY(spex_spmm_f32(gt, c2, nxt, s->g_out, (float)(L + 1), nullptr, nullptr, 1.0f, d, stream));
             c2 = nxt;
         }
+        SPEX_TRY(spex::adam_step_z2(s->E0, s->grad_E0, s->m, s->v, (int64_t)sz, s->t + 1, s->lr, s->beta1, s->beta2, s->eps, s->g_out,
+                                    s->ws_bwd, stream, s->grad_slots, B, loss_sum, nullptr, s->g_out, (float)(L + 1)));
+        s->t += 1;
+        return SPEX_OK;
     } else {    // L == 1: the last layer at the batch's rows, scoring, then grad = (g + A^T g) / 2 as one pull-form product
         SPEX_TRY(spex_spmm_rowlist_f32(g, cur, users, B, 0, items, B, n_u, nullptr, s->E0, s->lo_batch, (float)(L + 1), d, stream));
         SPEX_TRY(spex_score_bce_slots_f32(s->lo_batch, s->lo_batch + (size_t)n_u * d, d, d, n_u, g->n_rows - n_u, users, items, labels, B, d,
@@ -182,11 +196,17 @@ extern "C" int spex_ngcf_step_bce_f32(spex_ngcf_step_t *s, const int64_t *users,
             rc = spex_spmm_push_batch_f32(g, users, B, 0, items, B, n_u, s->g_side_c, d, s->g_ego_c, d, 1.0f, s->grad, d, stream);
         }
     }
+    // (one stream: the layer weights' update rides in the table's Adam launch as 33 extra workgroups — a launch of its own cost
+    //  the step ~5 us of ramp; parts summed in the same order as spex_adam_step_sum_f32 sums them)
+    spex::SmallAdam small;
+    if (!two_streams) {
+        small.p = s->W; small.m = s->mW; small.v = s->vW; small.parts = s->gW_parts;
+        small.n_parts = spex_ngcf_layer_bwd_rows_parts(2 * B); small.stride = per; small.n = per;
+    }
     if (rc == SPEX_OK)
         rc = spex::adam_step_z2(s->E0, s->grad, s->mE, s->vE, (int64_t)n * d, t_next, s->lr, s->beta1, s->beta2, s->eps, s->grad, nullptr, stream,
-                                loss_rows, B, loss_sum);
+                                loss_rows, B, loss_sum, two_streams ? nullptr : &small);
     if (forked && hipStreamWaitEvent((hipStream_t)stream, join_ev, 0) != hipSuccess && rc == SPEX_OK) rc = SPEX_ERR_HIP;   // joined on every path
-    if (rc == SPEX_OK && !two_streams) rc = weight_adam(stream);
     if (rc != SPEX_OK) return rc;
     s->t = t_next;
     if (s->p_drop > 0.0f) s->dropout_step += 1;
@@ -238,18 +258,24 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
         rc_trust = trust_branch(s->side_stream);
         if (hipEventRecord(join_ev, (hipStream_t)s->side_stream) != hipSuccess && rc_trust == SPEX_OK) rc_trust = SPEX_ERR_HIP;
     }
+    bool plain_last = false;          // the rec branch left the g_prop / (L+1) share of its last backward product to the Adam pass
     auto rec_branch = [&]() -> int {
         // ---- rec branch forward (model_expert_s.py:95-126,154-168): layers 1 .. L-1 over the whole graph, the last layer, the gate and
         //      the scores only at the batch's rows
+        //      (whole-graph launches in the plain form for L <= 3, the layer sum formed at the batch's rows: see the LightGCN step)
+        const bool plain = L >= 2 && L <= 3;
         const float *cur = E0;
         for (int32_t l = 0; l + 1 < L; ++l) {
             float *nxt = s->ws_fwd + (size_t)(l & 1) * sz;
-            SPEX_TRY(spex_spmm_f32(g, cur, nxt, nullptr, 1.0f, l == 0 ? E0 : s->light, s->light, 1.0f, d, stream));
+            if (plain) SPEX_TRY(spex_spmm_f32(g, cur, nxt, nullptr, 1.0f, nullptr, nullptr, 1.0f, d, stream));
+            else SPEX_TRY(spex_spmm_f32(g, cur, nxt, nullptr, 1.0f, l == 0 ? E0 : s->light, s->light, 1.0f, d, stream));
             cur = nxt;
         }
         // (last layer at the batch's rows + layer mean + gate + scores + per-sample gradient rows: one launch)
-        SPEX_TRY(spex_gated_batch_fwd_f32(g, cur, L == 1 ? E0 : s->light, (float)(L + 1), E0, att1, att2, users, items, labels, B, n_u,
-                                          1.0f / (float)B, s->loss, det ? s->loss_rows : nullptr, s->lo_batch, s->grad_slots, d, stream));
+        SPEX_TRY(spex::gated_batch_fwd_layers(g, cur, plain || L == 1 ? E0 : s->light, plain ? s->ws_fwd : nullptr,
+                                              plain && L == 3 ? s->ws_fwd + sz : nullptr, (float)(L + 1), E0, att1, att2, users, items,
+                                              labels, B, n_u, 1.0f / (float)B, s->loss, det ? s->loss_rows : nullptr, s->lo_batch,
+                                              s->grad_slots, d, stream));
         if (det) {
             // ---- SPEX_STEP_DETERMINISTIC: every sum the fast path leaves to float atomics is taken in a fixed order — the loss in
             //      sample order, the gate's backward into per-slot rows + per-workgroup blocks of the two gate gradients (added in
@@ -277,9 +303,12 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
             const float *c2 = G;
             for (int32_t l = L - 2; l >= 0; --l) {
                 float *nxt = l == 0 ? s->g_E0 : s->ws_bwd + (size_t)(1 + ((L - 2 - l) & 1)) * sz;
-                SPEX_TRY(spex_spmm_f32(gt, c2, nxt, s->g_prop, (float)(L + 1), nullptr, nullptr, 1.0f, d, stream));
+                // (the last product in the plain form: the Adam pass adds its g_prop / (L+1) share, see the LightGCN step)
+                if (l == 0) SPEX_TRY(spex_spmm_f32(gt, c2, nxt, nullptr, 1.0f, nullptr, nullptr, 1.0f, d, stream));
+                else SPEX_TRY(spex_spmm_f32(gt, c2, nxt, s->g_prop, (float)(L + 1), nullptr, nullptr, 1.0f, d, stream));
                 c2 = nxt;
             }
+            plain_last = true;
         } else {
             SPEX_TRY(spex_propagate_bwd_f32(gt, s->g_prop, s->g_E0, s->ws_bwd, L, d, stream));
         }
@@ -294,7 +323,8 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
     //      main_11.py:69) + Adam over every parameter (:89); t is advanced once the whole step is queued
     SPEX_TRY(spex::dual_task_adam(s->params, s->m, s->v, s->g_E0, s->g_raw, s->g_user, s->g_small, s->g_prop, L >= 2 ? s->ws_bwd : nullptr,
                                   s->loss, s->loss_acc, s->precision, (int64_t)sz, (int64_t)off_u, n_trust, B, T, s->n_rec, s->t + 1, s->lr,
-                                  s->beta1, s->beta2, s->eps, (s->flags & SPEX_STEP_FIXED_TASK_WEIGHTS) != 0, stream));
+                                  s->beta1, s->beta2, s->eps, (s->flags & SPEX_STEP_FIXED_TASK_WEIGHTS) != 0, stream,
+                                  plain_last ? (float)(L + 1) : 0.0f));
     s->t += 1;
     return SPEX_OK;
 }
