@@ -68,6 +68,12 @@ int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, const float
 int spex_graph_create_ex(const int32_t *h_rowptr, const int32_t *h_col, const float *h_val, const int32_t *h_edge_id,
                          int32_t n_rows, int32_t n_cols, int64_t nnz, int32_t flags, spex_graph_t **out);
 int spex_graph_destroy(spex_graph_t *g);
+/* HOST ONLY (no device call, works without a GPU): FNV-1a fingerprints of everything spex_graph_create[_ex] would upload for this
+ * matrix — digest[0] the wave-task table, [1..5] the chunk arrays (source offsets, values, end-of-row masks + padding counts, edge
+ * ids, output rows + workgroup row counts), [6] the long-row segment tables, [7] the hub / tile tables and the table sizes.  The
+ * host packer runs on SPEX_BUILD_THREADS threads (default min(16, cores)); the layout must not depend on that number. */
+int spex_graph_pack_digest(const int32_t *h_rowptr, const int32_t *h_col, const float *h_val, int32_t n_rows, int32_t n_cols,
+                           int64_t nnz, int32_t flags, uint64_t *digest /* [8] */);
 /* n_rows, n_cols, nnz, number of long rows, number of long-row segments (any pointer may be NULL) */
 int spex_graph_info(const spex_graph_t *g, int32_t *n_rows, int32_t *n_cols, int64_t *nnz, int32_t *n_long_rows,
                     int32_t *n_segments);

@@ -76,7 +76,19 @@ extern "C" int spex_graph_destroy(spex_graph_t *g)
 }
 
 static int graph_create_impl(const int32_t *h_rowptr, const int32_t *h_col, const float *h_val, const int32_t *h_edge_id, int32_t n_rows,
-                             int32_t n_cols, int64_t nnz, int32_t flags, spex_graph_t **out);
+                             int32_t n_cols, int64_t nnz, int32_t flags, spex_graph_t **out, uint64_t *digest = nullptr);
+
+// Host only (no device call): the fingerprint of everything spex_graph_create would upload for this matrix — FNV-1a hashes of the
+// task table, the chunk arrays, the segment / hub tables — so that a binding, or the CPU test-suite, can check that the threaded
+// packer (SPEX_BUILD_THREADS) lays the matrix out exactly as the single-thread planner does.
+extern "C" int spex_graph_pack_digest(const int32_t *h_rowptr, const int32_t *h_col, const float *h_val, int32_t n_rows, int32_t n_cols,
+                                      int64_t nnz, int32_t flags, uint64_t *digest)
+{
+    SPEX_CHECK_ARG(digest, "spex_graph_pack_digest: NULL output");
+    SPEX_CHECK_ARG((flags & ~SPEX_GRAPH_TILE_ROWS) == 0, "spex_graph_pack_digest: unknown flags 0x%x", flags);
+    spex_graph_t *unused = nullptr;
+    return graph_create_impl(h_rowptr, h_col, h_val, nullptr, n_rows, n_cols, nnz, flags, &unused, digest);
+}
 
 extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, const float *h_val,
                                  const int32_t *h_edge_id, int32_t n_rows, int32_t n_cols, int64_t nnz,
@@ -92,8 +104,16 @@ extern "C" int spex_graph_create_ex(const int32_t *h_rowptr, const int32_t *h_co
     return graph_create_impl(h_rowptr, h_col, h_val, h_edge_id, n_rows, n_cols, nnz, flags, out);
 }
 
+template <typename T>
+static uint64_t fnv1a(const std::vector<T> &v, uint64_t h = 1469598103934665603ull)
+{
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(v.data());
+    for (size_t i = 0, n = v.size() * sizeof(T); i < n; ++i) h = (h ^ p[i]) * 1099511628211ull;
+    return h;
+}
+
 static int graph_create_impl(const int32_t *h_rowptr, const int32_t *h_col, const float *h_val, const int32_t *h_edge_id, int32_t n_rows,
-                             int32_t n_cols, int64_t nnz, int32_t flags, spex_graph_t **out)
+                             int32_t n_cols, int64_t nnz, int32_t flags, spex_graph_t **out, uint64_t *digest)
 {
     SPEX_CHECK_ARG(out, "spex_graph_create: out is NULL");
     *out = nullptr;
@@ -500,6 +520,18 @@ static int graph_create_impl(const int32_t *h_rowptr, const int32_t *h_col, cons
         }
     }
 
+    if (digest) {       // spex_graph_pack_digest: fingerprints of the packed arrays, nothing goes to the device
+        digest[0] = fnv1a(task);
+        digest[1] = fnv1a(c_off);
+        digest[2] = fnv1a(c_val);
+        digest[3] = fnv1a(c_mask, fnv1a(c_pad));
+        digest[4] = fnv1a(c_eid);
+        digest[5] = fnv1a(c_row, fnv1a(wg_rows));
+        digest[6] = fnv1a(seg_beg, fnv1a(seg_end, fnv1a(long_row, fnv1a(long_seg0))));
+        digest[7] = fnv1a(hub_row, fnv1a(hub_seg0, fnv1a(tile_row))) ^ (uint64_t)task.size() ^ ((uint64_t)c_mask.size() << 32);
+        delete g;
+        return SPEX_OK;
+    }
     int rc = SPEX_OK;
     if ((rc = upload(&g->tile_row, tile_row.data(), tile_row.size())) || (rc = upload(&g->rowptr, h_rowptr, (size_t)n_rows + 1)) || (rc = upload(&g->col, h_col, (size_t)nnz)) ||
         (rc = upload(&g->val, h_val, (size_t)nnz)) ||
