@@ -531,7 +531,7 @@ def main():
                    "bpr_triples_per_step": T_TRIPLES, "embeddings": "xavier-uniform seed 2020 (synthetic weights)",
                    "parallelism": "single GPU" if not part else "row-partition x%d" % world,
                    **({} if not part else {"allgather": ag_info, "first_layer_exchange": dict(delta_info, used="deltas of the updated rows" if delta["on"] else "all-gather")})},
-        "roofline": {"bound": "hbm", "kernel": "spmm_chunk_kernel<1>", "achieved": achieved,
+        "roofline": {"bound": "hbm", "kernel": "spmm_chunk_kernel (the step's three layer launches: <1> running-sum form for layer 1, <0> plain form for layers 2-3)" if not part else "spmm_chunk_kernel<1>", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "cache_algorithmic_frac": achieved / HBM_PEAK_GBS,
                      "avg_launch_us": spmm_ms * 1e3, "launches_timed": n_timed,

@@ -588,6 +588,17 @@ enum {
     SPEX_STEP_FIXED_TASK_WEIGHTS = 2    /* dual-task step only: loss = loss1 + loss2 (LightGCN_SPEX/code/main_11.py:69) instead of the
                                          * uncertainty weighting of main_auto_expert_s.py:78-82; task_weights are left untouched */
 };
+/* The north-star step — LightGCN L-layer propagation + the fused BPR gather + dot + sigmoid + SGD kernel over T triples — as one
+ * call of L + 1 launches: layer 1 with the running sum fused (sum1 = E^0 + E^1), layers 2 .. L in the plain form (no epilogue
+ * operand, one output stream), and the BPR kernel forms the layer mean ((sum1 + E^2) + E^3) / (L + 1) — utility1/model.py:94-95, in
+ * the fused epilogues' order — at its triples' rows only, the rows of the propagated table the step reads; the updates go to E^0.
+ * Same results as spex_propagate_f32 followed by spex_bpr_sgd_step_f32 reading its output (bit-identical rows; float-atomic
+ * updates in both).  E0, sum1: [N, 64]; ws: [2, N, 64]; users index rows [0, n_user_rows), items rows n_user_rows + i.
+ * d == 64, 1 <= L <= 3, no edge dropout; *loss_sum accumulates the batch's softplus sum. */
+int spex_lightgcn_step_bpr_f32(const spex_graph_t *g, float *E0, float *sum1, float *ws, int32_t n_user_rows, int32_t L, int32_t d,
+                               const int64_t *u, const int64_t *i_pos, const int64_t *i_neg, int64_t T, float lr, float reg,
+                               float *loss_sum, void *stream);
+
 typedef struct spex_lightgcn_step {
     const spex_graph_t *graph, *graph_t;     /* A and A^T (the same handle for the symmetric LightGCN adjacency) */
     float *E0, *m, *v;

@@ -109,6 +109,41 @@ __global__ __launch_bounds__(kWave *kScoreWaves) void score_bce_kernel(
 // Measured at T ~ 1 M on Epinion2's tables: 1.5-1.6 G triples/s in random order, 2.25 G in sampler order (hot rows then
 // serialise in the L2: a user's ~330 consecutive triples are flushed by ~20 waves at about the same time); fetching a
 // run's rows ahead of use (48 loads in flight, 98 VGPRs) changed neither figure.
+// The same update with the propagated rows formed ON THE FLY from up to three tables — row r = ((t0[r] + t1[r]) + t2[r]) / div,
+// the layer mean of utility1/model.py:94-95 in the order the SpMM's fused epilogues form it — so that the propagation in front
+// of it can run without its layer-mean epilogue (spex::propagate_plain): the mean is needed at the batch's <= 3 T rows only.
+// Tables hold users first, items from row n_user_rows on; table_w (= E^0) receives the updates and is none of t0 / t1 / t2, so
+// the step stays batch-synchronous.  d == 64, one triple per wave (the step's batches are small: latency-bound by design).
+__global__ __launch_bounds__(kWave *kScoreWaves) void bpr_layers_kernel(
+    const float *__restrict__ t0, const float *__restrict__ t1, const float *__restrict__ t2, float div, float *table_w,
+    const int64_t *__restrict__ u_idx, const int64_t *__restrict__ p_idx, const int64_t *__restrict__ n_idx, int64_t T,
+    int64_t n_user_rows, int64_t n_item_rows, float a_coef, float b_coef, float *loss_sum)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wave_global = (int64_t)blockIdx.x * kScoreWaves + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * kScoreWaves;
+    float lsum = 0.0f;
+    for (int64_t t = wave_global; t < T; t += n_waves) {
+        const int64_t u = u_idx[t], ip = p_idx[t], in = n_idx[t];
+        if (u < 0 || u >= n_user_rows || ip < 0 || ip >= n_item_rows || in < 0 || in >= n_item_rows) continue;
+        const size_t ou = (size_t)u * kWave + lane, op = (size_t)(n_user_rows + ip) * kWave + lane, on = (size_t)(n_user_rows + in) * kWave + lane;
+        float uu = t0[ou], vp = t0[op], vn = t0[on];              // every load of the triple in flight before the first add
+        float u1 = 0.0f, p1 = 0.0f, n1 = 0.0f, u2 = 0.0f, p2 = 0.0f, n2 = 0.0f;
+        if (t1) { u1 = t1[ou]; p1 = t1[op]; n1 = t1[on]; }
+        if (t2) { u2 = t2[ou]; p2 = t2[op]; n2 = t2[on]; }
+        if (t1) { uu = uu + u1; vp = vp + p1; vn = vn + n1; }
+        if (t2) { uu = uu + u2; vp = vp + p2; vn = vn + n2; }
+        if (div != 1.0f) { uu = uu / div; vp = vp / div; vn = vn / div; }
+        const float x = wave_sum(uu * vn) - wave_sum(uu * vp);   // neg_score - pos_score
+        lsum += softplus_f(x);
+        const float a = a_coef * sigmoid_f(x);
+        atomicAdd(table_w + ou, a * (vn - vp) + b_coef * uu);
+        atomicAdd(table_w + op, -a * uu + b_coef * vp);
+        atomicAdd(table_w + on, a * uu + b_coef * vn);
+    }
+    if (loss_sum) block_loss_add(lsum, loss_sum);
+}
+
 __global__ __launch_bounds__(kWave *kScoreWaves) void bpr_kernel(
     const float *__restrict__ U_read, const float *__restrict__ I_read, float *U_w, float *I_w,
     const int64_t *__restrict__ u_idx, const int64_t *__restrict__ p_idx, const int64_t *__restrict__ n_idx, int64_t T,
@@ -572,6 +607,19 @@ extern "C" int spex_bpr_sgd_step_f32(const float *U_read, const float *I_read, f
     hipLaunchKernelGGL(bpr_kernel, dim3(grid_for((T + per_wave - 1) / per_wave)), dim3(kWave * kScoreWaves), 0,
                        (hipStream_t)stream, U_read, I_read, U_w, I_w, u, i_pos, i_neg, T, d, n_user_rows, n_item_rows,
                        -lr / (float)T, -lr * reg / (float)T, loss_sum, per_wave);
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}
+
+int spex::bpr_sgd_layers(const float *t0, const float *t1, const float *t2, float div, float *table_w, int64_t n_user_rows,
+                         int64_t n_item_rows, const int64_t *u, const int64_t *i_pos, const int64_t *i_neg, int64_t T, float lr, float reg,
+                         float *loss_sum, void *stream)
+{
+    SPEX_CHECK_ARG(t0 && table_w && u && i_pos && i_neg && T >= 0 && div != 0.0f, "bpr_sgd_layers: bad argument");
+    SPEX_CHECK_ARG(table_w != t0 && table_w != t1 && table_w != t2, "bpr_sgd_layers: the updated table must not be a read table");
+    if (T == 0) return SPEX_OK;
+    hipLaunchKernelGGL(bpr_layers_kernel, dim3(grid_for(T)), dim3(kWave * kScoreWaves), 0, (hipStream_t)stream, t0, t1, t2, div, table_w, u,
+                       i_pos, i_neg, T, n_user_rows, n_item_rows, -lr / (float)T, -lr * reg / (float)T, loss_sum);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }

@@ -44,6 +44,11 @@ int gated_batch_fwd_layers(const spex_graph_t *g, const float *X, const float *a
 int score_bce_slots_rows(const float *users, const float *items, int32_t ldu, int32_t ldi, int64_t n_user_rows, int64_t n_item_rows,
                          const int64_t *u_idx, const int64_t *i_idx, const float *labels, int32_t B, int32_t d, float *loss_rows,
                          float grad_scale, float *grad_slots, int32_t ld_slots, void *stream);     // score.hip: per-sample rows + losses
+int propagate_plain(const spex_graph_t *g, const float *E0, float *sum1, float *ws, int32_t L, int32_t d, void *stream,
+                    const float **tables);    // spmm.hip: L launches, the layer mean left to the consumer (tables[0..2], L + 1)
+int bpr_sgd_layers(const float *t0, const float *t1, const float *t2, float div, float *table_w, int64_t n_user_rows, int64_t n_item_rows,
+                   const int64_t *u, const int64_t *i_pos, const int64_t *i_neg, int64_t T, float lr, float reg, float *loss_sum,
+                   void *stream);             // score.hip: the fused BPR-SGD kernel reading rows as ((t0 + t1) + t2) / div
 int scale_div(const float *in, float *out, float div, int64_t n, void *stream);                          // spmm.hip: out = in / div
 int sum_ordered(const float *x, int32_t n, float scale, float *out, int accumulate, void *stream);     // rows.hip: fixed-order sum
 int sum_parts(const float *parts, int32_t n_parts, int64_t stride, int32_t n, float *out, int accumulate,

@@ -950,6 +950,34 @@ extern "C" int spex_propagate_f32(const spex_graph_t *g, const float *E0, float 
     return SPEX_OK;
 }
 
+// The propagation with the layer mean LEFT TO THE CONSUMER (the fused BPR step reads the propagated table at its triples' rows
+// only): layer 1 in the running-sum form — sum1 = E^0 + E^1, kept apart so that the consumer may update E^0 while it reads —,
+// the later layers in the PLAIN form (no epilogue operand, one output stream: 12.3 vs 14.8 us per launch on Epinion2) into the
+// two halves of ws, alternating.  tables[0..2]: what the consumer adds, in this order, before dividing by L + 1 — (sum1, E^2,
+// E^3) for L = 3, i.e. ((E^0 + E^1) + E^2) + E^3, the order of the fused epilogues.  1 <= L <= 3.  One timer bracket (the
+// profiling hook) spans the L launches like spex_propagate_f32's.
+int spex::propagate_plain(const spex_graph_t *g, const float *E0, float *sum1, float *ws, int32_t L, int32_t d, void *stream,
+                          const float **tables)
+{
+    SPEX_CHECK_ARG(g && E0 && sum1 && ws && tables, "propagate_plain: NULL argument");
+    SPEX_CHECK_ARG(g->n_rows == g->n_cols && L >= 1 && L <= 3, "propagate_plain: square graph, 1 <= L <= 3 (L = %d)", L);
+    int rc = ensure_partial(const_cast<spex_graph *>(g), d);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t sz = (size_t)g->n_rows * d;
+    TimerBracket bracket(g, s);
+    tables[0] = sum1; tables[1] = nullptr; tables[2] = nullptr;
+    float *e1 = ws, *e2 = ws + sz;
+    rc = launch_spmm(g, E0, L > 1 ? e1 : nullptr, nullptr, 1.0f, E0, sum1, 1.0f, d, s);                     // E^1, sum1 = E^0 + E^1
+    if (rc || L == 1) return rc;
+    rc = launch_spmm(g, e1, e2, nullptr, 1.0f, nullptr, nullptr, 1.0f, d, s);                                 // E^2
+    tables[1] = e2;
+    if (rc || L == 2) return rc;
+    rc = launch_spmm(g, e2, e1, nullptr, 1.0f, nullptr, nullptr, 1.0f, d, s);                                 // E^3 (E^1 is dead: in sum1)
+    tables[2] = e1;
+    return rc;
+}
+
 // out = in / div over n floats (the mean's backward share), for the other translation units.
 int spex::scale_div(const float *in, float *out, float div, int64_t n, void *stream)
 {

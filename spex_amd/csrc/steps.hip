@@ -97,6 +97,28 @@ extern "C" int spex_lightgcn_step_bce_f32(spex_lightgcn_step_t *s, const int64_t
     return SPEX_OK;
 }
 
+// The north-star step — 3-layer propagation + fused BPR-SGD over a batch of triples — as ONE call of L + 1 launches with the
+// layer mean left to the BPR kernel: layer 1 in the running-sum form (sum1 = E^0 + E^1), the later layers PLAIN, and the fused
+// gather + dot + sigmoid + SGD kernel forms ((sum1 + E^2) + E^3) / (L + 1) at its triples' rows only — the rows of the propagated
+// table the step reads.  Same results as spex_propagate_f32 followed by spex_bpr_sgd_step_f32 on its output (the rows are
+// bit-identical; the updates land with float atomics in either form).
+extern "C" int spex_lightgcn_step_bpr_f32(const spex_graph_t *g, float *E0, float *sum1, float *ws, int32_t n_user_rows, int32_t L,
+                                          int32_t d, const int64_t *u, const int64_t *i_pos, const int64_t *i_neg, int64_t T, float lr,
+                                          float reg, float *loss_sum, void *stream)
+{
+    SPEX_CHECK_ARG(g && E0 && sum1 && ws && u && i_pos && i_neg && T >= 0, "spex_lightgcn_step_bpr_f32: NULL argument or T < 0");
+    SPEX_CHECK_ARG(g->n_rows == g->n_cols && n_user_rows >= 0 && n_user_rows <= g->n_rows, "spex_lightgcn_step_bpr_f32: square graph, 0 <= n_user_rows <= N");
+    SPEX_CHECK_ARG(g->mask_mode == 0, "spex_lightgcn_step_bpr_f32: edge dropout is not supported in the one-call step");
+    if (d != 64 || L < 1 || L > 3) {
+        spex::set_error("spex_lightgcn_step_bpr_f32: d == 64 and 1 <= L <= 3 only (d = %d, L = %d): use spex_propagate_f32 + spex_bpr_sgd_step_f32", d, L);
+        return SPEX_ERR_UNSUPPORTED;
+    }
+    const float *tables[3];
+    SPEX_TRY(spex::propagate_plain(g, E0, sum1, ws, L, d, stream, tables));
+    return spex::bpr_sgd_layers(tables[0], tables[1], tables[2], (float)(L + 1), E0, n_user_rows, (int64_t)g->n_rows - n_user_rows, u, i_pos,
+                                i_neg, T, lr, reg, loss_sum, stream);
+}
+
 // Fork / join events of the two-stream steps (dual-task, NGCF): one pair PER STEP DESCRIPTOR, created on first use and kept in
 // the descriptor's ev_fork / ev_join cells (zero-initialised by the caller, released with spex_step_events_release).  A pair
 // shared per device — the first version — could be re-recorded by a second stepper driven from another host thread between

@@ -160,6 +160,19 @@ class LightGCNStepper:
     def step_bpr_sgd(self, users, pos, neg, lr=None, reg=0.0):
         """Propagation + fused BPR-SGD kernel (scores from the propagated table, update on E0).  Returns the running
         loss-sum buffer `loss_acc` (sum over every triple since it was last zeroed; no per-step allocation or sync)."""
+        T = users.numel()
+        if (1 <= self.L <= 3 and self.E0.shape[1] == 64 and getattr(self.graph, "mask_mode", 0) == 0 and T < ops.GROUPED_BPR_MIN_TRIPLES
+                and all(t.is_cuda and t.dtype == torch.int64 and t.is_contiguous() for t in (users, pos, neg))):
+            # one native call, L + 1 launches: the layer mean is formed by the BPR kernel at its triples' rows only, so the
+            # whole-graph launches behind layer 1 run in the plain form (spex_lightgcn_step_bpr_f32).  self.light_out then holds
+            # E^0 + E^1, not the propagated table.
+            import ctypes
+            from .graph import _bump, _launch
+            p = lambda t: ctypes.c_void_p(t.data_ptr())
+            _launch(self.E0.device, "spex_lightgcn_step_bpr_f32", self.graph._h, p(self.E0), p(self.light_out), p(self.ws_fwd), self.n_u,
+                    self.L, 64, p(users), p(pos), p(neg), T, float(self.lr if lr is None else lr), float(reg), p(self.loss_acc))
+            _bump(self.E0, self.loss_acc, self.light_out)
+            return self.loss_acc
         self.propagate()
         lo = self.light_out
         ops.bpr_sgd_step(lo[:self.n_u], lo[self.n_u:], self.E0[:self.n_u], self.E0[self.n_u:], users, pos, neg,

@@ -1191,3 +1191,30 @@ def test_unique_rows_and_push_form_spmm_vs_oracle(G, oracle):
     out3 = torch.zeros(n, 64, device=DEV)
     ops.spmm_push_batch(g, t(ua_ok), t(ub), 400, t(per_slot), out3, add=t(per_slot), scale=0.25)
     assert rel_err(out3.cpu().numpy(), np.float32(0.25) * (oracle.spmm(*t_csr, dense) + dense)) <= 2e-6
+
+
+@pytest.mark.parametrize("L", [1, 2, 3])
+def test_one_call_bpr_step_equals_propagate_then_bpr(G, golden, epinion2, oracle, L):
+    """spex_lightgcn_step_bpr_f32 (layer 1 with the running sum fused, later layers plain, the layer mean formed by the BPR kernel
+    at its triples' rows) against spex_propagate_f32 followed by spex_bpr_sgd_step_f32 on Epinion2: same loss sum, same updated
+    table (float-atomic updates in both forms: order only), and against the oracle's closed-form BPR-SGD step."""
+    from spex_amd import ops
+    from spex_amd.trainer import LightGCNStepper
+    g_, csr, E0 = _epinion2(golden, epinion2)
+    n_u = 3186
+    rng = np.random.default_rng(40 + L)
+    u, p, n = rng.integers(0, 3185, 2048), rng.integers(0, 12407, 2048), rng.integers(0, 12407, 2048)
+    u[:64] = u[0]                                                        # a hot user row
+    ud, pd_, nd = t(u), t(p), t(n)
+    g = G(*csr)
+    st = LightGCNStepper(g, t(E0), n_u, n_layers=L, lr=0.05)
+    loss_new = st.step_bpr_sgd(ud, pd_, nd).item()
+    lo = g.propagate(t(E0), L)
+    U_w = t(E0)
+    loss_old = ops.bpr_sgd_step(lo[:n_u], lo[n_u:], U_w[:n_u], U_w[n_u:], ud, pd_, nd, 0.05, 0.0, grouped=False).item()
+    assert abs(loss_new - loss_old) <= 1e-6 * abs(loss_old)
+    assert rel_err(st.E0.cpu().numpy(), U_w.cpu().numpy()) <= 2e-6
+    lo_h = oracle.propagate_mean(*csr, E0, L)
+    loss_o, Un, In = oracle.bpr_sgd(lo_h[:n_u], lo_h[n_u:], E0[:n_u], E0[n_u:], u, p, n, lr=0.05, reg=0.0)
+    assert abs(loss_new / 2048 - loss_o) <= 2e-6
+    assert np.abs(st.E0.cpu().numpy() - np.concatenate([Un, In])).max() <= 1e-5
