@@ -540,17 +540,21 @@ int spex_path_attention_bwd_f32(const float *src, int64_t n_src_rows, const int6
  *
  * spex_trust_head_fwd_f32 (one launch): a2_out [B, 64] = the vector whose product with the user table gives the logits
  *   (:146-147) — the evaluation form (flag 2).
- * spex_trust_head_train_f32 (two launches): forward, logits = a2 . table[0 : n_rows - 1]^T (`b = table[:-1]`), loss =
+ * spex_trust_head_train_f32 (five launches: the forward chain per path; the logits of ALL paths against tiles of 32 users — the table
+ *   is read once, by ~n_rows / 32 workgroups —; cross-entropy, d scores, the table gradient of each tile's own rows and per-tile
+ *   partials of d a2; the backward chain per path; the reductions): forward, logits = a2 . table[0 : n_rows - 1]^T (`b = table[:-1]`), loss =
  *   mean_b CE(logits_b, targets_b) -> *loss_out (added to it if loss_accumulate; may be NULL), and the whole backward:
  *   grad_params (flat block) is OVERWRITTEN (one thread per weight sums its contributions in a fixed order: deterministic);
  *   grad_table [n_rows, 64] is ACCUMULATED by the launch that owns the rows — the logits' part, then the rows of the paths that
  *   pass through the user in (path, position) order; no atomics: the whole head repeats bit for bit — zero it first or pass
  *   the buffer it is to be added to.  Gradients are scaled by scale * (*scale_dev if
  *   scale_dev else 1) — e.g. the multi-task precision exp(-2 s) of main_auto_expert_s.py:81-82 read on the device.
- *   Scratch (caller-owned): a2 [B, 64], dscore [B, n_rows - 1], loss_b [B], ws [spex_trust_workspace_floats(B, L, 64, H)].
+ *   Scratch (caller-owned): a2 [B, 64], dscore [B, n_rows - 1], loss_b [B], ws [spex_trust_workspace_floats(B, L, 64, H, n_rows)]
+ *   (per-path blocks + the user tiles' partials).
  */
 int64_t spex_trust_param_count(int32_t d, int32_t n_heads);                                /* -1: unsupported shape */
-int64_t spex_trust_workspace_floats(int32_t B, int32_t L, int32_t d, int32_t n_heads);     /* -1: unsupported shape */
+int64_t spex_trust_workspace_floats(int32_t B, int32_t L, int32_t d, int32_t n_heads,
+                                    int64_t n_rows);                                        /* -1: unsupported shape */
 int spex_trust_head_fwd_f32(const float *table, int64_t n_rows, const float *params, const int64_t *seq, const int64_t *seq_l,
                             int32_t B, int32_t L, int32_t d, int32_t n_heads, int32_t hybrid, float *a2_out, void *stream);
 int spex_trust_head_train_f32(const float *table, int64_t n_rows, const float *params, const int64_t *seq, const int64_t *seq_l,
@@ -658,7 +662,7 @@ int spex_ngcf_step_bce_f32(spex_ngcf_step_t *step, const int64_t *users, const i
  * Work buffers (caller-owned): light, lo_batch, g_prop, g_raw, g_E0: [N, 64]; ws_fwd [2, N, 64]; ws_bwd [3, N, 64];
  *   mixed_slots, grad_slots, g_prop_slots: [slot_capacity, 64] with slot_capacity >= 2B; arange: int64 [slot_capacity] = 0, 1, ..;
  *   g_user [n_user_rows, 64]; g_small [P + 512]; a2 [path_capacity, 64]; trust_ws
- *   [spex_trust_workspace_floats(path_capacity, path_len, 64, n_heads)]; dscore [path_capacity, n_user_rows - 1];
+ *   [spex_trust_workspace_floats(path_capacity, path_len, 64, n_heads, n_user_rows)]; dscore [path_capacity, n_user_rows - 1];
  *   loss_b [path_capacity]; loss [2], loss_acc [2], precision [2][2].
  * Before the first call: g_prop, g_raw, the first [N, 64] of ws_bwd, g_user, g_small, loss all-zero (every call leaves them
  * so); precision[(t + 1) & 1] = {exp(-2 s0), exp(-2 s1)} for the current task weights (every call writes the next step's

@@ -96,7 +96,7 @@ SIGNATURES = {
     "spex_path_attention_bwd_f32": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp,
                                                    c_vp, c_vp, c_vp, c_vp]),
     "spex_trust_param_count": (ctypes.c_int64, [c_i32, c_i32]),
-    "spex_trust_workspace_floats": (ctypes.c_int64, [c_i32, c_i32, c_i32, c_i32]),
+    "spex_trust_workspace_floats": (ctypes.c_int64, [c_i32, c_i32, c_i32, c_i32, c_i64]),
     "spex_trust_head_fwd_f32": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "spex_trust_head_train_f32": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp,
                                                  c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),

@@ -874,7 +874,7 @@ class TrustHeadLoss(torch.autograd.Function):
             raise ValueError(f"trust head: parameter block of {params.numel()} floats, expected {trust_param_count(n_heads, d)}")
         if targets.numel() != B or seq_l.numel() != B:
             raise ValueError("trust head: seq_l / targets do not match the number of paths")
-        n_ws = int(_lib.load().spex_trust_workspace_floats(B, L, d, n_heads))
+        n_ws = int(_lib.load().spex_trust_workspace_floats(B, L, d, n_heads, n_rows))
         n_users = n_rows - 1
         scratch = torch.empty(B * d + n_ws + B * n_users + B, dtype=torch.float32, device=dev)     # a2 | ws | dscore | loss_b
         a2, ws = scratch[: B * d], scratch[B * d: B * d + n_ws]

@@ -574,7 +574,7 @@ class DualTaskStepper:
         self._slots(2 * int(batch_capacity))
         T = self.path_capacity
         self.a2 = z(T, d)
-        self.trust_ws = z(max(1, int(_lib.load().spex_trust_workspace_floats(T, self.path_len, d, n_heads))))
+        self.trust_ws = z(max(1, int(_lib.load().spex_trust_workspace_floats(T, self.path_len, d, n_heads, self.n_u))))
         self.dscore, self.loss_b = z(T, self.n_u - 1), z(T)
         self.loss, self.loss_acc, self.precision = z(2), z(2), z(2, 2)
         self.t = 0

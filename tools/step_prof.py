@@ -24,3 +24,14 @@ nst = NGCFStepper(net)
 for _ in range(50):
     nst.step(u, i, y, loss_acc=acc)
 torch.cuda.synchronize()
+# round 3: the north-star step as one call (layer mean left to the BPR kernel) and the deterministic exact step
+tu = torch.randint(0, 3185, (2048,), device=dev); tp = torch.randint(0, 12407, (2048,), device=dev); tn = torch.randint(0, 12407, (2048,), device=dev)
+for _ in range(50):
+    st.step_bpr_sgd(tu, tp, tn)
+det = LightGCNStepper(SpexGraph(*csr, device=dev), E0.clone(), 3186, n_layers=3, lr=1e-3, deterministic=True)
+for _ in range(50):
+    det.step_bce(u, i, y, loss_acc=acc, batch_rows_only=True)
+dnst = NGCFStepper(net, deterministic=True)
+for _ in range(50):
+    dnst.step(u, i, y, loss_acc=acc)
+torch.cuda.synchronize()
