@@ -339,6 +339,12 @@ def main():
                 return stepper.step_bce(u_, i_, y_, loss_acc=acc, batch_rows_only=True)
             fn2b()
             aux["exact_train_step_ms_B256_training_batches"] = time_events(fn2b, 256)
+            # the same step in the deterministic accumulation mode (SPEX_STEP_DETERMINISTIC: no float atomics, all-pull backward)
+            stepper.deterministic = True
+            fn2b()
+            aux["exact_train_step_ms_B256_training_batches_deterministic"] = time_events(fn2b, 256)
+            stepper.deterministic = False
+            fn2b()
             aux["exact_train_step_samples_per_s"] = 256 / (ms2 * 1e-3)
             aux["exact_train_step_edges_per_s"] = 2 * L * nnz / (ms2 * 1e-3)
             # NGCF (BASELINE configs[3] shape): one layer = SpMM on D^-1(A+I) + fused layer kernel; and the whole training
@@ -552,7 +558,7 @@ def main():
         tb = stored["epinion2_spmm_bytes_per_launch"]
         out["roofline"]["traffic"] = tb
         out["roofline"]["traffic_is_stored_profile"] = True
-        out["roofline"]["traffic_source"] = stored.get("source")
+        out["roofline"]["traffic_source"] = stored.get("epinion2_source") or stored.get("source")
         out["roofline"]["l2_miss_traffic_over_compulsory"] = tb / compulsory_bytes(local_nnz, local_rows)
         out["roofline"]["l2_miss_traffic_GBs"] = tb / (spmm_ms * 1e-3) / 1e9
         out["roofline"]["l2_hit_rate_profiled"] = stored.get("epinion2_l2_hit_rate")
