@@ -54,11 +54,13 @@ def compulsory_bytes(nnz, n_rows, d=D):
     return nnz * 8 + n_rows * (4 + 8 * d)
 
 
-def time_events(fn, iters):
+def time_events(fn, iters, finish=None):
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(iters):
         fn()
+    if finish is not None:      # e.g. a pipelined stepper's join: the side stream's last launches are inside the timed region
+        finish()
     e.record()
     e.synchronize()
     return s.elapsed_time(e) / iters  # ms
@@ -401,7 +403,8 @@ def main():
                                        A_split=False, dropout=0)
             dnet = mex.LightGCN(dargs, _DS).to(dev)
             T_PATHS, P_LEN = 15, 6
-            dst = DualTaskStepper(dnet, path_capacity=T_PATHS, path_len=P_LEN, lr=1e-3)
+            # (pipelined: the form trainer.train_epoch_dual runs its loop in — inputs staged before the loop, a join at its end)
+            dst = DualTaskStepper(dnet, path_capacity=T_PATHS, path_len=P_LEN, lr=1e-3, pipelined=True)
             prng = np.random.default_rng(11)
             plen = prng.integers(2, P_LEN + 1, T_PATHS)
             pseq = np.full((T_PATHS, P_LEN), n_user, dtype=np.int64)
@@ -412,7 +415,12 @@ def main():
             fn3 = lambda: dst.step(ub, ib, yb, pseq_d, plen_d, ptgt)
             for _ in range(20):
                 fn3()
-            aux["dual_task_step_ms_B256_T15"] = time_events(fn3, 200)
+            dst.join()
+            aux["dual_task_step_ms_B256_T15"] = time_events(fn3, 500, finish=dst.join)
+            dst.pipelined = False                        # the fork / join form (DualTaskStepper.step's default for per-step inputs)
+            for _ in range(20):
+                fn3()
+            aux["dual_task_step_ms_B256_T15_fork_join"] = time_events(fn3, 200)
             del dnet, dst
         except Exception as e:  # never lose the headline line to an auxiliary measurement
             aux["aux_error"] = repr(e)

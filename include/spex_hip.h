@@ -407,6 +407,25 @@ int spex_gated_batch_fwd_f32(const spex_graph_t *g, const float *X, const float 
                              int32_t B, int32_t n_user_rows, float grad_scale, float *loss_sum, float *loss_per_sample,
                              float *lo_batch, float *grad_slots, int32_t d, void *stream);
 
+/* The WHOLE batch-sized middle of the dual-task rec branch as ONE launch: spex_gated_batch_fwd_f32's forward, then
+ * spex_expert_gate_rows_bwd_f32 (the backward of model_expert_s.py:156-161 at the sample's two rows; linear in the incoming
+ * gradient, so a row named by several samples is handled once per sample) and spex_spmm_push_batch_f32 (the first backward
+ * product of the propagation, A^T g in push form over the rows of A) — three launches of a dependent chain in one kernel.
+ * With d light_r / d raw_r the gate's two outputs for r in {u, i} (same arithmetic as the separate entries), it ACCUMULATES with
+ * float atomics into caller-zeroed buffers:
+ *   g_prop[r] += d light_r;  g_raw[r] += d raw_r;  G[r] += push_scale * d light_r;
+ *   G[col[e]] += val[e] * push_scale * d light_r   over the stored entries e of row r of A;
+ *   g_att[b mod n_att_copies] += the gate matrices' gradients;  *loss_sum += loss_b.
+ * g_att: [n_att_copies][2][128, 2] — copy c holds [d att_u | d att_i] of the samples b = c (mod n_att_copies); the gradient is the
+ * sum of the copies (all samples adding into ONE copy serialise in L2: 256 adds per word; 64 copies cost nothing).
+ * g_prop, G, g_raw: [N, d], three distinct tables.  d == 64, no edge dropout.  (The deterministic step keeps the separate,
+ * atomic-free entries.)
+ */
+int spex_gated_batch_f32(const spex_graph_t *g, const float *X, const float *acc_in, float acc_div, const float *raw,
+                         const float *att_u, const float *att_i, const int64_t *users, const int64_t *items, const float *labels,
+                         int32_t B, int32_t n_user_rows, float grad_scale, float push_scale, float *loss_sum, float *g_prop, float *G,
+                         float *g_raw, float *g_att, int32_t n_att_copies, int32_t d, void *stream);
+
 /* Replaces the two-expert gate of the dual-task model, utility1/model_expert_s.py:156-161:
  *   att = softmax([raw | prop] att_exp, dim=1) ([n,2d] x [2d,2]);  mixed = raw * att[:,0] + prop * att[:,1]
  */
@@ -589,8 +608,10 @@ int spex_trust_head_train_f32(const float *table, int64_t n_rows, const float *p
  */
 enum {
     SPEX_STEP_DETERMINISTIC = 1,        /* fixed summation order everywhere (see above) */
-    SPEX_STEP_FIXED_TASK_WEIGHTS = 2    /* dual-task step only: loss = loss1 + loss2 (LightGCN_SPEX/code/main_11.py:69) instead of the
+    SPEX_STEP_FIXED_TASK_WEIGHTS = 2,   /* dual-task step only: loss = loss1 + loss2 (LightGCN_SPEX/code/main_11.py:69) instead of the
                                          * uncertainty weighting of main_auto_expert_s.py:78-82; task_weights are left untouched */
+    SPEX_STEP_PIPELINED = 4             /* dual-task step only, with side_stream: the Adam pass split by owner over the two streams, no
+                                         * fork / join on the critical cycle; see spex_dual_task_step_t and spex_dual_task_step_join */
 };
 /* The north-star step — LightGCN L-layer propagation + the fused BPR gather + dot + sigmoid + SGD kernel over T triples — as one
  * call of L + 1 launches: layer 1 with the running sum fused (sum1 = E^0 + E^1), layers 2 .. L in the plain form (no epilogue
@@ -674,6 +695,17 @@ int spex_ngcf_step_bce_f32(spex_ngcf_step_t *step, const int64_t *users, const i
  * the trust branch is forked onto it behind everything already queued on `stream` and joined again in front of the Adam
  * pass (two events per device, created on first use and kept by the library).  Results are identical to the one-stream
  * order; the caller keeps side_stream alive while steps are in flight.
+ * flags & SPEX_STEP_PIPELINED (needs side_stream): the fork and the join above cost ~10 us each on this runtime and sit on the
+ * step's critical cycle (Adam -> fork -> trust branch -> join -> Adam).  The pipelined form takes them off it by splitting the
+ * Adam pass by OWNER: the user rows, the trust block and the task weights — everything the trust branch reads or writes — are
+ * updated by a second Adam launch on side_stream, right behind the trust branch (it waits for the rec branch's gradients, which
+ * are ready long before); the item rows and the gate matrices by the launch on `stream`.  The trust branch of step k+1 then
+ * follows step k's update on its own stream with no event between them, and `stream` waits for the side update at the START
+ * of the next call (its rec branch reads the user rows).  Same arithmetic, same results.  The price is the contract: when the
+ * call returns, side_stream is still AHEAD of `stream` — the next pipelined call picks that up itself, anything else that reads
+ * or writes the parameters, the moments, loss_acc or the work buffers must be ordered behind spex_dual_task_step_join(step,
+ * stream); and seq / seq_l / targets are read on side_stream WITHOUT waiting for `stream` (only the first call after a join
+ * forks from it), so they must have been complete before the last join — e.g. staged once per epoch, as Train() allows.
  */
 typedef struct spex_dual_task_step {
     const spex_graph_t *graph, *graph_t;
@@ -693,10 +725,13 @@ typedef struct spex_dual_task_step {
     float *g_raw_slots;        /* [slot_capacity, 64]                                   — SPEX_STEP_DETERMINISTIC only */
     float *att_parts;          /* [spex_expert_gate_rows_bwd_parts(slot_capacity)][512] — SPEX_STEP_DETERMINISTIC only */
     float *loss_rows;          /* [slot_capacity / 2] per-sample rec losses             — SPEX_STEP_DETERMINISTIC only */
-    int32_t flags;             /* SPEX_STEP_DETERMINISTIC | SPEX_STEP_FIXED_TASK_WEIGHTS */
+    int32_t flags;             /* SPEX_STEP_DETERMINISTIC | SPEX_STEP_FIXED_TASK_WEIGHTS | SPEX_STEP_PIPELINED */
+    int32_t side_pending;      /* state of the pipelined form (zero-initialise): work of this descriptor is in flight on side_stream */
 } spex_dual_task_step_t;
 int spex_dual_task_step_f32(spex_dual_task_step_t *step, const int64_t *users, const int64_t *items, const float *labels, int32_t B,
                             const int64_t *seq, const int64_t *seq_l, const int64_t *targets, int32_t T, void *stream);
+/* Orders everything a pipelined step left on side_stream in front of whatever is queued on `stream` next (a no-op otherwise). */
+int spex_dual_task_step_join(spex_dual_task_step_t *step, void *stream);
 
 /* ------------------------------------------------------------------------------------------------ multi-GPU: collectives + partitioned step
  * the graph is 1-D row-partitioned over the GPUs of one node (one process per GPU): rank p owns rows

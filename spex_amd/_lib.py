@@ -63,6 +63,8 @@ SIGNATURES = {
                                                     c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "spex_gated_batch_fwd_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp, c_vp,
                                                 c_vp, c_vp, c_i32, c_vp]),
+    "spex_gated_batch_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp,
+                                            c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "spex_lightgcn_batch_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp,
                                                c_vp, c_i32, c_vp]),
     "spex_lightgcn_batch_slots_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp,
@@ -105,6 +107,7 @@ SIGNATURES = {
     "spex_lightgcn_step_bce_f32": (ctypes.c_int, [ctypes.c_void_p, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "spex_ngcf_step_bce_f32": (ctypes.c_int, [ctypes.c_void_p, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "spex_dual_task_step_f32": (ctypes.c_int, [ctypes.c_void_p, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp]),
+    "spex_dual_task_step_join": (ctypes.c_int, [ctypes.c_void_p, c_vp]),
     "spex_comm_unique_id": (ctypes.c_int, [c_vp]),
     "spex_comm_create": (ctypes.c_int, [c_i32, c_i32, c_vp, ctypes.POINTER(c_vp)]),
     "spex_comm_destroy": (ctypes.c_int, [c_vp]),
@@ -131,6 +134,7 @@ class LightGCNStepDesc(ctypes.Structure):
 
 STEP_DETERMINISTIC = 1          # spex_hip.h: SPEX_STEP_DETERMINISTIC
 STEP_FIXED_TASK_WEIGHTS = 2     # spex_hip.h: SPEX_STEP_FIXED_TASK_WEIGHTS
+STEP_PIPELINED = 4              # spex_hip.h: SPEX_STEP_PIPELINED
 
 
 class NGCFStepDesc(ctypes.Structure):
@@ -151,7 +155,7 @@ class DualTaskStepDesc(ctypes.Structure):
                 + [(n, c_i32) for n in ("slot_capacity", "path_capacity", "path_len", "n_user_rows", "L", "d", "n_heads", "hybrid",
                                         "n_rec")]
                 + [(n, c_f32) for n in ("lr", "beta1", "beta2", "eps")] + [("t", c_i32)]
-                + [(n, c_vp) for n in ("side_stream", "ev_fork", "ev_join", "g_raw_slots", "att_parts", "loss_rows")] + [("flags", c_i32)])
+                + [(n, c_vp) for n in ("side_stream", "ev_fork", "ev_join", "g_raw_slots", "att_parts", "loss_rows")] + [("flags", c_i32), ("side_pending", c_i32)])
 
 
 class PartitionedStepDesc(ctypes.Structure):

@@ -326,6 +326,170 @@ __global__ __launch_bounds__(kWave *kWgWaves) void gated_batch_fwd_kernel(
     }
 }
 
+
+// The WHOLE batch-sized middle of the dual-task rec branch as one launch (spex_gated_batch_f32; the fast, atomic path of
+// spex_dual_task_step_f32): gated_batch_fwd_kernel's forward, then — the gate's Jacobian is linear in the incoming gradient and
+// local to the sample's two rows — the gate's backward in the same two waves (expert_gate_rows_bwd_kernel's arithmetic, operand
+// for operand: d raw, d light, the two gate matrices' gradients), and the first backward product in push form over the rows of A
+// exactly as lightgcn_batch_kernel<true> runs it (runs of 16 entries dealt over (part, wave), loaded ahead of the forward).
+// Three launches (10.1 + 5.0 + 10.2 us on Epinion2, B = 256) and two launch boundaries of a dependent chain become one.
+//   g_prop[r]  += d light            (dense d loss / d light: the epilogue operand of the later backward launches, Adam's share)
+//   G[r]       += push_scale * d light,   G[col[e]] += val[e] * push_scale * d light over the stored entries of row r of A
+//   g_raw[r]   += d raw              (the gate's direct path into E^0)
+//   g_att[b mod n_att_copies] += the gate matrices' gradients ([att_u | att_i], [128, 2] each; 4 values per lane, one atomic each)
+__global__ __launch_bounds__(kWave *kWgWaves) void gated_batch_push_kernel(
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val, int n_rows, int n_user_rows,
+    const float *__restrict__ X, const float *__restrict__ acc_in, float acc_div, const float *__restrict__ raw,
+    const float *__restrict__ att_u, const float *__restrict__ att_i, const int64_t *__restrict__ users,
+    const int64_t *__restrict__ items, const float *__restrict__ labels, int parts, int runs_per_part, float grad_scale,
+    float push_scale, float *loss_sum, float *g_prop, float *G, float *g_raw, float *g_att, int n_att_copies,
+    const float *__restrict__ acc2, const float *__restrict__ acc3)
+{
+    __shared__ float s_part[2][kWgWaves][kWave];
+    __shared__ float s_mixed[2][kWave];
+    __shared__ float s_dprop[2][kWave];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int b = blockIdx.x / parts, part = blockIdx.x % parts;
+    const int64_t u64 = users[b], i64 = items[b];
+    const float y_lab = labels[b];
+    if (u64 < 0 || u64 >= n_user_rows || i64 < 0 || i64 + n_user_rows >= n_rows) {   // workgroup-uniform: never gather out of range
+        if (part == 0 && threadIdx.x == 0) atomicAdd(loss_sum, 0.693147180559945309f);   // gated rows of 0: BCE(0, y), no gradient
+        return;
+    }
+    const int row[2] = {(int)u64, (int)i64 + n_user_rows};
+    const int beg[2] = {rowptr[row[0]], rowptr[row[1]]};
+    const int deg[2] = {rowptr[row[0] + 1] - beg[0], rowptr[row[1] + 1] - beg[1]};
+    float run = 0.0f, a_raw = 0.0f, w00 = 0.0f, w01 = 0.0f, w10 = 0.0f, w11 = 0.0f;
+    if (wave < 2) {                       // the gate's operands, requested with everything else
+        const float *att = wave ? att_i : att_u;
+        const size_t o = (size_t)row[wave] * kWave + lane;
+        run = acc_in[o];
+        float r2 = 0.0f, r3 = 0.0f;                          // (plain-form forward layers: see lightgcn_batch_kernel)
+        if (acc2) r2 = acc2[o];
+        if (acc3) r3 = acc3[o];
+        if (acc2) run = run + r2;
+        if (acc3) run = run + r3;
+        a_raw = raw[o];
+        w00 = att[2 * lane]; w01 = att[2 * lane + 1];
+        w10 = att[2 * (kWave + lane)]; w11 = att[2 * (kWave + lane) + 1];
+    }
+    // the push's runs (the forward's rows again: A^T g in push form walks the rows of A), shared by up to `parts` workgroups
+    const int n_run0 = (deg[0] + 15) >> 4, n_runs = n_run0 + ((deg[1] + 15) >> 4);
+    const int want = (n_runs + runs_per_part - 1) / runs_per_part;
+    const int act = want < parts ? (want < 1 ? 1 : want) : parts;
+    if (part >= act) return;
+    const int q_step = act * kWgWaves;
+    int q = part * kWgWaves + wave;
+    int p_col[kPre], p_cnt[kPre], p_side[kPre];
+    float p_val[kPre];
+    auto load_runs = [&](int q0) {
+#pragma unroll
+        for (int p = 0; p < kPre; ++p) {
+            const int qq = q0 + p * q_step;
+            p_col[p] = 0;
+            p_val[p] = 0.0f;
+            p_cnt[p] = 0;
+            p_side[p] = 0;
+            if (qq < n_runs) {
+                const int side = qq >= n_run0, rr = side ? qq - n_run0 : qq;
+                const int base = beg[side] + rr * 16, left = deg[side] - rr * 16;
+                p_side[p] = side;
+                p_cnt[p] = left < 16 ? left : 16;
+                if (lane < p_cnt[p]) {
+                    p_col[p] = col[base + lane];
+                    p_val[p] = val[base + lane];
+                }
+            }
+        }
+    };
+    load_runs(q);
+    // ---- 1. last layer at both rows (gated_batch_fwd_kernel's / the row-list kernel's order of sums)
+    const int nseg[2] = {(deg[0] + kTaskEntries - 1) / kTaskEntries, (deg[1] + kTaskEntries - 1) / kTaskEntries};
+    const int nv0 = nseg[0] < kWgWaves ? nseg[0] : kWgWaves, nv = nv0 + (nseg[1] < kWgWaves ? nseg[1] : kWgWaves);
+    const float *__restrict__ Xl = X + lane;
+    for (int j = wave; j < nv; j += kWgWaves) {
+        const int side = j >= nv0, v = side ? j - nv0 : j;
+        float acc = 0.0f;
+        for (int sgi = v; sgi < nseg[side]; sgi += kWgWaves) {
+            const int left = deg[side] - sgi * kTaskEntries;
+            acc = segment_sum(col, val, Xl, beg[side] + sgi * kTaskEntries, left < kTaskEntries ? left : kTaskEntries, lane, acc);
+        }
+        s_part[side][v][lane] = acc;
+    }
+    __syncthreads();
+    // ---- 2. layer mean + gate (waves 0 / 1: the user / the item row)
+    float s = 0.0f, a0 = 0.0f, a1 = 0.0f;
+    if (wave < 2) {
+        const int lim = nseg[wave] < kWgWaves ? nseg[wave] : kWgWaves;
+        float y = lim > 0 ? s_part[wave][0][lane] : 0.0f;
+        for (int w = 1; w < lim; ++w) y = y + s_part[wave][w][lane];          // segment order
+        s = run + y;
+        if (acc_div != 1.0f) s = s / acc_div;
+        float z0 = fmaf(s, w10, fmaf(a_raw, w00, 0.0f)), z1 = fmaf(s, w11, fmaf(a_raw, w01, 0.0f));
+        z0 = wave_sum_f32(z0);
+        z1 = wave_sum_f32(z1);
+        const float mx = fmaxf(z0, z1);
+        const float e0 = expf(z0 - mx), e1 = expf(z1 - mx);
+        a0 = e0 / (e0 + e1); a1 = e1 / (e0 + e1);
+        s_mixed[wave][lane] = a_raw * a0 + s * a1;
+    }
+    __syncthreads();
+    // ---- 3. score, loss, d loss / d gated rows, and the gate's backward for this sample's two rows
+    if (wave < 2) {
+        const float mu = s_mixed[0][lane], mi = s_mixed[1][lane];
+        const float x = wave_sum_f32(fmaf(mu, mi, 0.0f));
+        const float dg = (sigmoid_f(x) - y_lab) * grad_scale;
+        const float gg = dg * (wave ? mu : mi);
+        const float da0 = wave_sum_f32(gg * a_raw), da1 = wave_sum_f32(gg * s);
+        const float dot = a0 * da0 + a1 * da1;
+        const float dz0 = a0 * (da0 - dot), dz1 = a1 * (da1 - dot);
+        const float d_raw = a0 * gg + dz0 * w00 + dz1 * w01, d_prop = a1 * gg + dz0 * w10 + dz1 * w11;
+        s_dprop[wave][lane] = d_prop;
+        if (part == 0) {
+            const size_t o = (size_t)row[wave] * kWave + lane;
+            atomicAdd(g_prop + o, d_prop);
+            atomicAdd(G + o, push_scale * d_prop);
+            atomicAdd(g_raw + o, d_raw);
+            // (every sample adds to the same 512 words: 256 x 64 lane-atomics per cache line serialise in L2 — 13 us of a 25 us
+            //  launch when all went to ONE copy — so sample b adds into copy b mod n_att_copies and the caller sums the copies)
+            float *ga = g_att + (size_t)(b % n_att_copies) * 512 + wave * 256;
+            atomicAdd(ga + 2 * lane, fmaf(a_raw, dz0, 0.0f));
+            atomicAdd(ga + 2 * lane + 1, fmaf(a_raw, dz1, 0.0f));
+            atomicAdd(ga + 2 * (kWave + lane), fmaf(s, dz0, 0.0f));
+            atomicAdd(ga + 2 * (kWave + lane) + 1, fmaf(s, dz1, 0.0f));
+            if (wave == 0 && lane == 0) atomicAdd(loss_sum, fmaxf(x, 0.0f) - x * y_lab + log1pf(expf(-fabsf(x))));
+        }
+    }
+    __syncthreads();
+    // ---- 4. push over both rows' entries (lightgcn_batch_kernel's loop)
+    const float g2[2] = {push_scale * s_dprop[0][lane], push_scale * s_dprop[1][lane]};
+    float *out_l = G + lane;
+    for (;;) {
+        int c0[kPre];
+        float v0[kPre];
+#pragma unroll
+        for (int p = 0; p < kPre; ++p) {
+            c0[p] = __builtin_amdgcn_readlane(p_col[p], 0);
+            v0[p] = lane_bcast(p_val[p], 0);
+        }
+#pragma unroll
+        for (int p = 0; p < kPre; ++p) {
+            const float gs = p_side[p] ? g2[1] : g2[0];
+            if (p_cnt[p] > 0) atomicAdd(out_l + (size_t)c0[p] * kWave, v0[p] * gs);
+#pragma unroll 1
+            for (int j = 1; j < p_cnt[p]; ++j) {
+                const int c = __builtin_amdgcn_readlane(p_col[p], j);
+                const float v = lane_bcast(p_val[p], j);
+                atomicAdd(out_l + (size_t)c * kWave, v * gs);
+            }
+        }
+        q += kPre * q_step;
+        if (q >= n_runs) break;
+        load_runs(q);
+    }
+}
+
 }  // namespace
 
 extern "C" int spex_gated_batch_fwd_f32(const spex_graph_t *g, const float *X, const float *acc_in, float acc_div, const float *raw,
@@ -356,6 +520,50 @@ int spex::gated_batch_fwd_layers(const spex_graph_t *g, const float *X, const fl
     hipLaunchKernelGGL(gated_batch_fwd_kernel, dim3((unsigned)B), dim3(kWave * kWgWaves), 0, (hipStream_t)stream, g->rowptr, g->col, g->val,
                        g->n_rows, n_user_rows, X, acc_in, acc_div, raw, att_u, att_i, users, items, labels, B, grad_scale, loss_sum, lo_batch,
                        grad_slots, loss_per_sample, acc2, acc3);
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}
+
+extern "C" int spex_gated_batch_f32(const spex_graph_t *g, const float *X, const float *acc_in, float acc_div, const float *raw,
+                                   const float *att_u, const float *att_i, const int64_t *users, const int64_t *items,
+                                   const float *labels, int32_t B, int32_t n_user_rows, float grad_scale, float push_scale,
+                                   float *loss_sum, float *g_prop, float *G, float *g_raw, float *g_att, int32_t n_att_copies,
+                                   int32_t d, void *stream)
+{
+    return spex::gated_batch_push_layers(g, X, acc_in, nullptr, nullptr, acc_div, raw, att_u, att_i, users, items, labels, B, n_user_rows,
+                                         grad_scale, push_scale, loss_sum, g_prop, G, g_raw, g_att, n_att_copies, d, stream);
+}
+
+static int batch_env(const char *name, int dflt, int lo, int hi)
+{
+    const char *e = getenv(name);
+    const int p = e ? atoi(e) : dflt;
+    return p < lo ? lo : (p > hi ? hi : p);
+}
+
+int spex::gated_batch_push_layers(const spex_graph_t *g, const float *X, const float *acc_in, const float *acc2, const float *acc3,
+                                  float acc_div, const float *raw, const float *att_u, const float *att_i, const int64_t *users,
+                                  const int64_t *items, const float *labels, int32_t B, int32_t n_user_rows, float grad_scale,
+                                  float push_scale, float *loss_sum, float *g_prop, float *G, float *g_raw, float *g_att,
+                                  int32_t n_att_copies, int32_t d, void *stream)
+{
+    SPEX_CHECK_ARG(g && X && acc_in && raw && att_u && att_i && users && items && labels && loss_sum && g_prop && G && g_raw && g_att,
+                   "spex_gated_batch_f32: NULL argument");
+    SPEX_CHECK_ARG(n_att_copies >= 1, "spex_gated_batch_f32: n_att_copies=%d", n_att_copies);
+    SPEX_CHECK_ARG(B >= 0 && n_user_rows >= 0 && n_user_rows <= g->n_rows && g->n_rows == g->n_cols,
+                   "spex_gated_batch_f32: B=%d n_user_rows=%d on a %d x %d graph", B, n_user_rows, g->n_rows, g->n_cols);
+    SPEX_CHECK_ARG(g->mask_mode == 0, "spex_gated_batch_f32: edge dropout is not supported here");
+    SPEX_CHECK_ARG(G != g_prop && G != g_raw && g_prop != g_raw, "spex_gated_batch_f32: g_prop, G and g_raw are three tables");
+    if (d != kWave) {
+        spex::set_error("spex_gated_batch_f32: d == 64 only (got %d)", d);
+        return SPEX_ERR_UNSUPPORTED;
+    }
+    if (B == 0 || g->n_rows == 0) return SPEX_OK;
+    static const int runs_per_part = batch_env("SPEX_BATCH_RUNS_PER_PART", 16, 1, 1 << 20);
+    static const int parts = batch_env("SPEX_BATCH_PARTS", 3, 1, 16);
+    hipLaunchKernelGGL(gated_batch_push_kernel, dim3((unsigned)B * parts), dim3(kWave * kWgWaves), 0, (hipStream_t)stream, g->rowptr, g->col,
+                       g->val, g->n_rows, n_user_rows, X, acc_in, acc_div, raw, att_u, att_i, users, items, labels, parts, runs_per_part,
+                       grad_scale, push_scale, loss_sum, g_prop, G, g_raw, g_att, n_att_copies, acc2, acc3);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }

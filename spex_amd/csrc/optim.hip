@@ -192,8 +192,14 @@ struct DualAdamArgs {
     int64_t n_table, n_user, n_trust, n_total;     // floats: table, user rows of it, trust block, whole arena (excl. padding)
     int32_t B, T, n_rec, slot, fixed;
     float w1, beta2, w2, bc2_sqrt, eps, step_size;
+    float *att_copies;   // the fused batch kernel's copies of the two gate gradients ([n_att_copies][512], sample b -> copy b mod n):
+    int n_att_copies;    //   summed into the gate parameters' gradient and cleared here; n_att_copies == 0: nothing to sum, but the
+    int att_clear;       //   first att_clear floats are cleared (the other paths use the area for per-sample rows)
     float prop_div;      // > 0: g_E0 is the PLAIN last backward product and its g_prop / prop_div share is added here (g_prop is read
                          // before this pass clears it); 0: g_E0 already holds it
+    int part;            // 0: the whole arena; the pipelined step splits the pass in two launches on two streams — 1: the item rows and
+                         // the gate matrices (gradients of the rec branch alone), 2: the user rows, the trust block, the task weights
+    int role;            // number of leading blocks that only sum the gate-gradient copies (0 or 2)
 };
 
 __global__ __launch_bounds__(256) void dual_task_adam_kernel(const DualAdamArgs a)
@@ -201,9 +207,45 @@ __global__ __launch_bounds__(256) void dual_task_adam_kernel(const DualAdamArgs 
     // fixed: loss = loss1 + loss2 (main_11.py:69) — both precisions 1; the task weights get no gradient (torch's Adam skips a
     // parameter whose .grad is None: value and moments stay as they are)
     const float p1 = a.fixed ? 1.0f : a.prec[a.slot * 2], p2 = a.fixed ? 1.0f : a.prec[a.slot * 2 + 1];
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t n_gate_end = a.n_table + a.n_trust + 512;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_gate_end; i += stride) {
+    // ---- role blocks (the first a.role blocks): the 512 gate parameters when their gradient arrives as copies — each thread sums
+    //      its column of the copies (independent, coalesced loads, 16 in flight), is the column's only reader and clears it.  The
+    //      role sits on its own blocks, which do nothing else: as an iteration of the main loop it was a 4 us tail of the launch.
+    if ((int)blockIdx.x < a.role) {
+        const int jj = blockIdx.x * 256 + threadIdx.x;                    // 0 .. 511
+        const int64_t j = a.n_trust + jj, i = a.n_table + j;
+        float gs = a.g_small[j];
+        a.g_small[j] = 0.0f;
+        float *c = a.att_copies + jj;
+        for (int c0 = 0; c0 < a.n_att_copies; c0 += 16) {
+            float part[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) part[k] = c0 + k < a.n_att_copies ? c[(size_t)(c0 + k) * 512] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                gs += part[k];
+                if (c0 + k < a.n_att_copies) c[(size_t)(c0 + k) * 512] = 0.0f;
+            }
+        }
+        float P = a.p[i], M = a.m[i], V = a.v[i];
+        adam1(P, p1 * gs, M, V, a.w1, a.beta2, a.w2, a.bc2_sqrt, a.eps, a.step_size);
+        a.p[i] = P; a.m[i] = M; a.v[i] = V;
+        return;
+    }
+    // ---- main loop over the part's compact index space k -> arena index i:
+    //      part 0 (the whole arena):               i = k                                   [+ the gate parameters unless a role has them]
+    //      part 1 (what the rec branch alone owns): item rows, then the gate parameters     [ditto]; clears the whole push target
+    //      part 2 (what needs both branches):       user rows, then the trust block; the task weights and the loss cells
+    const int64_t gate_k = a.role ? 0 : 512;
+    const int64_t n_item = a.n_table - a.n_user;
+    const int64_t n_k = a.part == 0 ? a.n_table + a.n_trust + gate_k : (a.part == 1 ? n_item + gate_k : a.n_user + a.n_trust);
+    const int64_t stride = (int64_t)(gridDim.x - a.role) * blockDim.x;
+    const int64_t tid = (int64_t)(blockIdx.x - a.role) * blockDim.x + threadIdx.x;
+    for (int64_t k = tid; k < n_k; k += stride) {
+        int64_t i;
+        if (a.part == 0) i = k;                                               // (the gate parameters follow the trust block directly)
+        else if (a.part == 1) i = k < n_item ? a.n_user + k : a.n_table + a.n_trust + (k - n_item);
+        else i = k < a.n_user ? k : a.n_table + (k - a.n_user);
         float g;
         if (i < a.n_table) {
             float ge = a.g_E0[i];
@@ -215,7 +257,7 @@ __global__ __launch_bounds__(256) void dual_task_adam_kernel(const DualAdamArgs 
             }
             a.g_raw_w[i] = 0.0f;
             a.g_prop[i] = 0.0f;
-            if (a.push_zero) a.push_zero[i] = 0.0f;
+            if (a.push_zero && a.part == 0) a.push_zero[i] = 0.0f;
         } else {
             const int64_t j = i - a.n_table;
             g = (j < a.n_trust ? p2 : p1) * a.g_small[j];
@@ -225,7 +267,11 @@ __global__ __launch_bounds__(256) void dual_task_adam_kernel(const DualAdamArgs 
         adam1(P, g, M, V, a.w1, a.beta2, a.w2, a.bc2_sqrt, a.eps, a.step_size);
         a.p[i] = P; a.m[i] = M; a.v[i] = V;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (a.part == 1 && a.push_zero)                                           // (the rec branch's next step is its only user)
+        for (int64_t k = tid; k < a.n_table; k += stride) a.push_zero[k] = 0.0f;
+    if (a.part != 2 && a.n_att_copies == 0)
+        for (int64_t k = tid; k < a.att_clear; k += stride) a.att_copies[k] = 0.0f;
+    if (a.part != 1 && (int)blockIdx.x == a.role && threadIdx.x == 0) {
         const float loss1 = a.loss[0] / (float)a.B, loss2 = a.loss[1];
         const float g[2] = {-2.0f * p1 * loss1 + 2.0f * (float)(a.n_rec + 1) * (float)a.B, -2.0f * p2 * loss2 + (float)a.T};
         for (int k = 0; k < 2 && !a.fixed; ++k) {
@@ -247,15 +293,19 @@ int spex::dual_task_adam(float *p, float *m, float *v, const float *g_E0, float 
                          float *g_prop, float *push_zero, float *loss, float *loss_acc, float *prec, int64_t n_table, int64_t n_user,
                          int64_t n_trust,
                          int32_t B, int32_t T, int32_t n_rec, int32_t t, float lr, float beta1, float beta2, float eps, int fixed_weights,
-                         void *stream, float prop_div)
+                         void *stream, float prop_div, float *att_copies, int32_t n_att_copies, int32_t att_clear, int32_t part)
 {
     const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
+    if (!att_copies) n_att_copies = 0, att_clear = 0;
+    const int role = n_att_copies > 0 && part != 2 ? 2 : 0;
     const DualAdamArgs a{p, m, v, g_E0, g_raw, g_raw, g_user, g_small, g_prop, push_zero, loss, loss_acc, prec, n_table, n_user, n_trust,
                          n_table + n_trust + 512 + 2, B, T, n_rec, t & 1, fixed_weights, 1.0f - beta1, beta2, 1.0f - beta2, (float)sqrt(bc2), eps,
-                         (float)((double)lr / bc1), prop_div};
-    int64_t blocks = (n_table + n_trust + 512 + 255) / 256;
+                         (float)((double)lr / bc1), att_copies, n_att_copies, att_clear, prop_div, part, role};
+    const int64_t n_k = part == 0 ? n_table + n_trust + 512 : (part == 1 ? n_table - n_user + 512 : n_user + n_trust);
+    int64_t blocks = (n_k + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(dual_task_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(dual_task_adam_kernel, dim3((unsigned)(blocks + role)), dim3(256), 0, (hipStream_t)stream, a);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }

@@ -26,7 +26,8 @@ int adam_step_z2(float *p, const float *g, float *m, float *v, int64_t n, int32_
 int dual_task_adam(float *p, float *m, float *v, const float *g_E0, float *g_raw, float *g_user, float *g_small, float *g_prop,
                    float *push_zero, float *loss, float *loss_acc, float *prec, int64_t n_table, int64_t n_user, int64_t n_trust,
                    int32_t B, int32_t T, int32_t n_rec, int32_t t, float lr, float beta1, float beta2, float eps, int fixed_weights,
-                   void *stream, float prop_div = 0.0f);   // optim.hip: Adam over the dual-task parameter arena (spex_dual_task_step_f32)
+                   void *stream, float prop_div = 0.0f, float *att_copies = nullptr, int32_t n_att_copies = 0,
+                   int32_t att_clear = 0, int32_t part = 0);                 // optim.hip: Adam over the dual-task parameter arena (spex_dual_task_step_f32)
 
 // batch.hip: the batch kernels with the layer sum formed at the batch's rows from up to three tables (acc_in + acc2 + acc3, in that
 // order; NULL = absent) — what lets the one-call steps run their forward layers in the plain form
@@ -41,6 +42,11 @@ int gated_batch_fwd_layers(const spex_graph_t *g, const float *X, const float *a
                            const float *raw, const float *att_u, const float *att_i, const int64_t *users, const int64_t *items,
                            const float *labels, int32_t B, int32_t n_user_rows, float grad_scale, float *loss_sum, float *loss_per_sample,
                            float *lo_batch, float *grad_slots, int32_t d, void *stream);
+// (the rec branch's whole batch-sized middle — forward, gate, scores, the gate's backward, push — in one launch: batch.hip)
+int gated_batch_push_layers(const spex_graph_t *g, const float *X, const float *acc_in, const float *acc2, const float *acc3, float acc_div,
+                            const float *raw, const float *att_u, const float *att_i, const int64_t *users, const int64_t *items,
+                            const float *labels, int32_t B, int32_t n_user_rows, float grad_scale, float push_scale, float *loss_sum,
+                            float *g_prop, float *G, float *g_raw, float *g_att, int32_t n_att_copies, int32_t d, void *stream);
 int score_bce_slots_rows(const float *users, const float *items, int32_t ldu, int32_t ldi, int64_t n_user_rows, int64_t n_item_rows,
                          const int64_t *u_idx, const int64_t *i_idx, const float *labels, int32_t B, int32_t d, float *loss_rows,
                          float grad_scale, float *grad_slots, int32_t ld_slots, void *stream);     // score.hip: per-sample rows + losses

@@ -235,6 +235,14 @@ extern "C" int spex_ngcf_step_bce_f32(spex_ngcf_step_t *s, const int64_t *users,
     return SPEX_OK;
 }
 
+extern "C" int spex_dual_task_step_join(spex_dual_task_step_t *s, void *stream)
+{
+    SPEX_CHECK_ARG(s, "spex_dual_task_step_join: NULL descriptor");
+    if (s->side_pending && s->ev_join) SPEX_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)s->ev_join, 0));
+    s->side_pending = 0;
+    return SPEX_OK;
+}
+
 extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *users, const int64_t *items, const float *labels,
                                        int32_t B, const int64_t *seq, const int64_t *seq_l, const int64_t *targets, int32_t T,
                                        void *stream)
@@ -268,10 +276,26 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
         return spex_trust_head_train_f32(E0, n_u, trust_p, seq, seq_l, targets, T, s->path_len, d, H, s->hybrid, 1.0f, nullptr, s->a2,
                                          s->dscore, s->loss_b, s->trust_ws, s->loss + 1, 0, s->g_small, s->g_user, st);
     };
-    const bool two_streams = s->side_stream != nullptr && s->side_stream != stream && T > 0;
+    // SPEX_STEP_PIPELINED: the trust branch and the update of what it reads (user rows, trust block, task weights) live on
+    // side_stream from one step to the next; `stream` and side_stream exchange two events per step, neither on the trust
+    // branch's cycle.  side_pending: side_stream holds work `stream` has not been ordered behind yet.
+    const bool pipelined = (s->flags & SPEX_STEP_PIPELINED) != 0 && s->side_stream != nullptr && s->side_stream != stream;
+    if (s->side_pending && !pipelined) SPEX_TRY(spex_dual_task_step_join(s, stream));      // (the flags changed between two steps)
+    const bool two_streams = !pipelined && s->side_stream != nullptr && s->side_stream != stream && T > 0;
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
     int rc_trust = SPEX_OK;
     bool forked = false;
+    if (pipelined) {
+        SPEX_TRY(step_events(&s->ev_fork, &s->ev_join, &fork_ev, &join_ev));
+        if (!s->side_pending) {            // first step after a join: side_stream starts behind everything queued on `stream`
+            SPEX_HIP(hipEventRecord(fork_ev, (hipStream_t)stream));
+            SPEX_HIP(hipStreamWaitEvent((hipStream_t)s->side_stream, fork_ev, 0));
+        } else {                           // the previous step's side update (user rows!) in front of this step's rec branch
+            SPEX_HIP(hipStreamWaitEvent((hipStream_t)stream, join_ev, 0));
+        }
+        s->side_pending = 1;
+        if (T > 0) rc_trust = trust_branch(s->side_stream);
+    }
     if (two_streams) {
         SPEX_TRY(step_events(&s->ev_fork, &s->ev_join, &fork_ev, &join_ev));
         SPEX_HIP(hipEventRecord(fork_ev, (hipStream_t)stream));
@@ -280,6 +304,11 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
         rc_trust = trust_branch(s->side_stream);
         if (hipEventRecord(join_ev, (hipStream_t)s->side_stream) != hipSuccess && rc_trust == SPEX_OK) rc_trust = SPEX_ERR_HIP;
     }
+    // the fused batch kernel's copies of the two gate gradients live in grad_slots (per-sample rows on the other paths): up to 64
+    // copies of 512 floats, summed and cleared by the Adam pass — which clears the area after the other paths too, so that a
+    // descriptor may change its flags between steps
+    const int32_t att_copies_max = s->slot_capacity / 8 < 64 ? s->slot_capacity / 8 : 64;
+    int32_t att_copies_used = 0;
     bool plain_last = false;          // the rec branch left the g_prop / (L+1) share of its last backward product to the Adam pass
     auto rec_branch = [&]() -> int {
         // ---- rec branch forward (model_expert_s.py:95-126,154-168): layers 1 .. L-1 over the whole graph, the last layer, the gate and
@@ -293,7 +322,30 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
             else SPEX_TRY(spex_spmm_f32(g, cur, nxt, nullptr, 1.0f, l == 0 ? E0 : s->light, s->light, 1.0f, d, stream));
             cur = nxt;
         }
-        // (last layer at the batch's rows + layer mean + gate + scores + per-sample gradient rows: one launch)
+        static const bool fused_middle = []() { const char *e = getenv("SPEX_DUAL_FUSED_MIDDLE"); return !(e && e[0] == '0'); }();
+        if (!det && L >= 2 && fused_middle) {
+            // (fast path: last layer at the batch's rows + layer mean + gate + scores + the gate's backward + the first backward
+            //  product in push form — ONE launch, batch.hip: gated_batch_push_kernel; then the L-1 pull-form launches on A^T, the
+            //  last one plain: the Adam pass adds its g_prop / (L+1) share, see the LightGCN step)
+            float *G = s->ws_bwd;                     // all-zero here (cleared by the previous step's Adam pass)
+            SPEX_TRY(spex::gated_batch_push_layers(g, cur, plain ? E0 : s->light, plain ? s->ws_fwd : nullptr,
+                                                   plain && L == 3 ? s->ws_fwd + sz : nullptr, (float)(L + 1), E0, att1, att2, users, items,
+                                                   labels, B, n_u, 1.0f / (float)B, 1.0f / (float)(L + 1), s->loss, s->g_prop, G, s->g_raw,
+                                                   att_copies_max >= 1 ? s->grad_slots : g_att1, att_copies_max >= 1 ? att_copies_max : 1,
+                                                   d, stream));
+            att_copies_used = att_copies_max;
+            const float *c2 = G;
+            for (int32_t l = L - 2; l >= 0; --l) {
+                float *nxt = l == 0 ? s->g_E0 : s->ws_bwd + (size_t)(1 + ((L - 2 - l) & 1)) * sz;
+                if (l == 0) SPEX_TRY(spex_spmm_f32(gt, c2, nxt, nullptr, 1.0f, nullptr, nullptr, 1.0f, d, stream));
+                else SPEX_TRY(spex_spmm_f32(gt, c2, nxt, s->g_prop, (float)(L + 1), nullptr, nullptr, 1.0f, d, stream));
+                c2 = nxt;
+            }
+            plain_last = true;
+            return SPEX_OK;
+        }
+        // (L == 1 and the deterministic step: last layer at the batch's rows + layer mean + gate + scores + per-sample gradient
+        //  rows in one launch, the gate's backward and the propagation's after it)
         SPEX_TRY(spex::gated_batch_fwd_layers(g, cur, plain || L == 1 ? E0 : s->light, plain ? s->ws_fwd : nullptr,
                                               plain && L == 3 ? s->ws_fwd + sz : nullptr, (float)(L + 1), E0, att1, att2, users, items,
                                               labels, B, n_u, 1.0f / (float)B, s->loss, det ? s->loss_rows : nullptr, s->lo_batch,
@@ -317,15 +369,13 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
         //      slot (dense d loss / d light and d loss / d E0 rows added with atomics), then the propagation as in the LightGCN step
         SPEX_TRY(spex_expert_gate_rows_bwd_f32(E0, s->lo_batch, att1, att2, users, B, 0, items, B, n_u, n_u, N, d, s->grad_slots, d,
                                                s->g_prop_slots, s->g_prop, s->g_raw, g_att1, g_att2, stream));
-        if (L >= 2) {
-            float *G = s->ws_bwd;                     // all-zero here (cleared by the previous step's Adam pass)
-            // (push form of A^T g: over the rows of A — the forward handle — of the batch's slots)
+        if (L >= 2) {            // (SPEX_DUAL_FUSED_MIDDLE=0: the three-launch middle, kept for A/B timing)
+            float *G = s->ws_bwd;
             SPEX_TRY(spex_spmm_push_batch_f32(g, users, B, 0, items, B, n_u, s->g_prop_slots, d, s->g_prop_slots, d, 1.0f / (float)(L + 1), G, d,
                                               stream));
             const float *c2 = G;
             for (int32_t l = L - 2; l >= 0; --l) {
                 float *nxt = l == 0 ? s->g_E0 : s->ws_bwd + (size_t)(1 + ((L - 2 - l) & 1)) * sz;
-                // (the last product in the plain form: the Adam pass adds its g_prop / (L+1) share, see the LightGCN step)
                 if (l == 0) SPEX_TRY(spex_spmm_f32(gt, c2, nxt, nullptr, 1.0f, nullptr, nullptr, 1.0f, d, stream));
                 else SPEX_TRY(spex_spmm_f32(gt, c2, nxt, s->g_prop, (float)(L + 1), nullptr, nullptr, 1.0f, d, stream));
                 c2 = nxt;
@@ -339,6 +389,25 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
     int rc = rec_branch();
     if (forked && hipStreamWaitEvent((hipStream_t)stream, join_ev, 0) != hipSuccess && rc == SPEX_OK) rc = SPEX_ERR_HIP;   // joined on every path
     if (rc == SPEX_OK) rc = rc_trust;
+    if (pipelined) {
+        // the rec branch's gradients -> side_stream; Adam part 2 (user rows, trust block, task weights, loss cells) there, part 1
+        // (item rows, gate matrices) here.  The join event is recorded on every path so that a later join never waits in vain.
+        if (hipEventRecord(fork_ev, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent((hipStream_t)s->side_stream, fork_ev, 0) != hipSuccess)
+            rc = rc == SPEX_OK ? SPEX_ERR_HIP : rc;
+        for (int32_t part = 2; part >= 1 && rc == SPEX_OK; --part)
+            rc = spex::dual_task_adam(s->params, s->m, s->v, s->g_E0, s->g_raw, s->g_user, s->g_small, s->g_prop, L >= 2 ? s->ws_bwd : nullptr,
+                                      s->loss, s->loss_acc, s->precision, (int64_t)sz, (int64_t)off_u, n_trust, B, T, s->n_rec, s->t + 1, s->lr,
+                                      s->beta1, s->beta2, s->eps, (s->flags & SPEX_STEP_FIXED_TASK_WEIGHTS) != 0,
+                                      part == 2 ? s->side_stream : stream, plain_last ? (float)(L + 1) : 0.0f, s->grad_slots, att_copies_used,
+                                      att_copies_max * 512, part);
+        if (hipEventRecord(join_ev, (hipStream_t)s->side_stream) != hipSuccess && rc == SPEX_OK) rc = SPEX_ERR_HIP;
+        if (rc != SPEX_OK) {
+            (void)spex_dual_task_step_join(s, stream);
+            return rc;
+        }
+        s->t += 1;
+        return SPEX_OK;
+    }
     if (rc == SPEX_OK && T > 0 && !two_streams) rc = trust_branch(stream);                // one-stream order
     if (rc != SPEX_OK) return rc;
     // ---- uncertainty-weighted sum of both losses (main_auto_expert_s.py:78-82; SPEX_STEP_FIXED_TASK_WEIGHTS: loss1 + loss2,
@@ -346,7 +415,7 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
     SPEX_TRY(spex::dual_task_adam(s->params, s->m, s->v, s->g_E0, s->g_raw, s->g_user, s->g_small, s->g_prop, L >= 2 ? s->ws_bwd : nullptr,
                                   s->loss, s->loss_acc, s->precision, (int64_t)sz, (int64_t)off_u, n_trust, B, T, s->n_rec, s->t + 1, s->lr,
                                   s->beta1, s->beta2, s->eps, (s->flags & SPEX_STEP_FIXED_TASK_WEIGHTS) != 0, stream,
-                                  plain_last ? (float)(L + 1) : 0.0f));
+                                  plain_last ? (float)(L + 1) : 0.0f, s->grad_slots, att_copies_used, att_copies_max * 512));
     s->t += 1;
     return SPEX_OK;
 }

@@ -462,6 +462,32 @@ def gated_batch_fwd(graph, X, acc_in, acc_div, raw, att_u, att_i, users, items, 
     _bump(loss_sum, loss_per_sample, lo_batch, grad_slots)
 
 
+def gated_batch(graph, X, acc_in, acc_div, raw, att_u, att_i, users, items, labels, n_user_rows, grad_scale, push_scale, loss_sum,
+                g_prop, G, g_raw, g_att):
+    """The dual-task rec branch's whole batch-sized middle as one launch (spex_gated_batch_f32): gated_batch_fwd's forward, the
+    gate's backward at the sample's two rows and the first backward product in push form.  Accumulates (float atomics) into
+    g_prop / G / g_raw ([N, 64], three tables), loss_sum and g_att [copies, 2, 128, 2]: sample b adds the two gate matrices'
+    gradients into copy b mod copies (g_att.sum(0) is [d att_u | d att_i])."""
+    n = graph.n_rows
+    for t, nm in ((X, "X"), (acc_in, "acc_in"), (raw, "raw"), (g_prop, "g_prop"), (G, "G"), (g_raw, "g_raw")):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.shape == (n, 64)):
+            raise ValueError(f"gated_batch: {nm} must be a contiguous fp32 [{n}, 64] device tensor")
+    B = users.numel()
+    for t, nm in ((att_u, "att_u"), (att_i, "att_i")):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == 256):
+            raise ValueError(f"gated_batch: {nm} must be a contiguous fp32 [128, 2] device tensor")
+    if not (g_att.is_cuda and g_att.dtype == torch.float32 and g_att.is_contiguous() and g_att.dim() == 4 and g_att.shape[1:] == (2, 128, 2)
+            and g_att.shape[0] >= 1):
+        raise ValueError("gated_batch: g_att must be a contiguous fp32 [copies, 2, 128, 2] device tensor")
+    for t, dt, nm in ((users, torch.int64, "users"), (items, torch.int64, "items"), (labels, torch.float32, "labels")):
+        if not (t.is_cuda and t.dtype == dt and t.is_contiguous() and t.numel() == B):
+            raise ValueError(f"gated_batch: {nm} must be a contiguous device tensor of the batch's length")
+    _launch(X.device, "spex_gated_batch_f32", graph._h, _ptr(X), _ptr(acc_in), float(acc_div), _ptr(raw), _ptr(att_u), _ptr(att_i),
+            _ptr(users), _ptr(items), _ptr(labels), B, int(n_user_rows), float(grad_scale), float(push_scale), _ptr(loss_sum),
+            _ptr(g_prop), _ptr(G), _ptr(g_raw), _ptr(g_att), g_att.shape[0], 64)
+    _bump(loss_sum, g_prop, G, g_raw, g_att)
+
+
 def expert_gate(raw, prop, att_exp):
     """softmax([raw|prop] att_exp) two-way mix — model_expert_s.py:156-161."""
     for x, n in ((raw, "raw"), (prop, "prop"), (att_exp, "att_exp")):

@@ -518,10 +518,15 @@ class DualTaskStepper:
     path_capacity: the largest number of paths a step may carry (3 x trust_batch_size in the reference driver, :70-71)."""
 
     def __init__(self, model, path_capacity, path_len, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, n_rec=5, batch_capacity=256,
-                 two_streams=None, deterministic=None, fixed_task_weights=False):
+                 two_streams=None, deterministic=None, fixed_task_weights=False, pipelined=False):
         """two_streams (default on; SPEX_DUAL_ONE_STREAM=1 turns it off): the trust branch's two launches — a latency chain on
         <= path_capacity workgroups — run on a second HIP stream beside the rec branch and join it in front of the Adam
         pass (spex_dual_task_step_t.side_stream).  Same results as the one-stream order.
+        pipelined (needs two streams; flags & SPEX_STEP_PIPELINED): the Adam pass split by owner over the two streams, so that no
+        fork / join sits on the trust branch's cycle.  The side stream then runs AHEAD of the current stream between steps: the
+        path inputs of a step must be complete before the previous `join()`, and `join()` must come before anything but the
+        next step touches the model, the moments or `loss_acc` (train_epoch_dual stages an epoch's inputs up front, turns the
+        mode on for its loop — SPEX_DUAL_PIPELINED=0 keeps it off — and joins at the end).
         deterministic (default: SPEX_DETERMINISTIC=1 in the environment): no float atomics in the step (flags &
         SPEX_STEP_DETERMINISTIC).  fixed_task_weights: loss = loss1 + loss2 as in main_11.py:69 (flags &
         SPEX_STEP_FIXED_TASK_WEIGHTS; the task weights stay where they are)."""
@@ -542,6 +547,7 @@ class DualTaskStepper:
         if two_streams is None:
             two_streams = os.environ.get("SPEX_DUAL_ONE_STREAM", "0") != "1"
         self._side = torch.cuda.Stream(device=dev) if two_streams else None
+        self.pipelined = bool(pipelined) and self._side is not None
         P = ops.trust_param_count(n_heads, d)
         self.n_trust = P
         total = N * d + P + 512 + 4
@@ -632,10 +638,11 @@ class DualTaskStepper:
                 n_heads=self.n_heads, hybrid=0 if self.model.nonhybrid else 1, n_rec=self.n_rec, lr=self.lr, beta1=self.betas[0],
                 beta2=self.betas[1], eps=self.eps, t=self.t,
                 side_stream=None if self._side is None else self._side.cuda_stream, ev_fork=None, ev_join=None,
-                g_raw_slots=p(self.g_raw_slots), att_parts=p(self.att_parts), loss_rows=p(self.loss_rows), flags=0)
+                g_raw_slots=p(self.g_raw_slots), att_parts=p(self.att_parts), loss_rows=p(self.loss_rows), flags=0, side_pending=0)
         dsc = self._desc
         dsc.t, dsc.lr = self.t, self.lr
-        dsc.flags = (_lib.STEP_DETERMINISTIC if self.deterministic else 0) | (_lib.STEP_FIXED_TASK_WEIGHTS if self.fixed_task_weights else 0)
+        dsc.flags = ((_lib.STEP_DETERMINISTIC if self.deterministic else 0) | (_lib.STEP_FIXED_TASK_WEIGHTS if self.fixed_task_weights else 0)
+                     | (_lib.STEP_PIPELINED if self.pipelined and self._side is not None else 0))
         if T and self._side is not None:                     # the side stream reads them: keep the allocator from recycling
             for t in (seq, seq_l, targets):                  # their memory under a step still in flight
                 t.record_stream(self._side)
@@ -645,6 +652,14 @@ class DualTaskStepper:
         self.t = dsc.t
         _bump(self.arena, self.m, self.v, self.loss_acc)
         self.model._cache = None
+
+    def join(self):
+        """Order everything a pipelined step left on the side stream in front of the current stream (spex_dual_task_step_join);
+        a no-op for the other forms.  Call before reading the model, the moments or `loss_acc` and before changing them."""
+        if self._desc is not None and self._desc.side_pending:
+            import ctypes
+            from .graph import _launch
+            _launch(self.dev, "spex_dual_task_step_join", ctypes.byref(self._desc))
 
 
 def _lib_mod():
@@ -695,7 +710,14 @@ def train_epoch_dual(stepper, train_data, trust_data, by_user, cap, batch_size=2
     users = torch.from_numpy(users_h).to(dev)
     items = torch.from_numpy(train_data.items_fill[order]).to(dev)
     labels = torch.from_numpy(train_data.labels_fill_np[order]).to(device=dev, dtype=torch.float32)
+    stepper.join()
     stepper.loss_acc.zero_()
+    # the epoch's inputs are complete on the device before its first step and nothing but the steps touches the model inside the
+    # loop: the pipelined form's contract (DualTaskStepper.__init__), so the loop runs in it when the stepper has two streams
+    was_pipelined = stepper.pipelined
+    # (its first step forks the side stream from the current one, behind the uploads above)
+    if stepper._side is not None and os.environ.get("SPEX_DUAL_PIPELINED", "1") != "0":
+        stepper.pipelined = True
     gc_was_on = pause_gc and gc.isenabled()
     if gc_was_on:
         gc.disable()
@@ -706,10 +728,13 @@ def train_epoch_dual(stepper, train_data, trust_data, by_user, cap, batch_size=2
             stepper.step(users[s:e], items[s:e], labels[s:e], seq[p0:p1] if c else None, seq_l[p0:p1], tgt[p0:p1])
             p0 = p1
             if cum_every and cum_out is not None and (k + 1) % cum_every == 0:
+                stepper.join()
                 cum_out.append(stepper.loss_acc.clone())
         if n_paths_out is not None:
             n_paths_out.extend(len(c) for c in chosen)
     finally:
+        stepper.join()
+        stepper.pipelined = was_pipelined
         if gc_was_on:
             gc.enable()
     return stepper.loss_acc.clone()

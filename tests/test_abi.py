@@ -126,6 +126,7 @@ def test_step_descriptors_have_the_layout_of_the_header(tmp_path):
         assert int(got[cname]) == ctypes.sizeof(cls), cname
         for fname, _ in cls._fields_:
             assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
-    assert _lib.STEP_DETERMINISTIC == 1 and _lib.STEP_FIXED_TASK_WEIGHTS == 2
+    assert _lib.STEP_DETERMINISTIC == 1 and _lib.STEP_FIXED_TASK_WEIGHTS == 2 and _lib.STEP_PIPELINED == 4
+    assert re.search(r"SPEX_STEP_PIPELINED = 4", open(HEADER).read())
     assert re.search(r"#define SPEX_COMM_ID_BYTES %d\b" % _lib.COMM_ID_BYTES, open(HEADER).read())
     assert re.search(r"SPEX_STEP_DETERMINISTIC = 1", open(HEADER).read()) and re.search(r"SPEX_STEP_FIXED_TASK_WEIGHTS = 2", open(HEADER).read())

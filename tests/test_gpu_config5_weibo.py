@@ -126,6 +126,17 @@ def test_gated_batch_forward_with_hub_rows_beyond_1024_entries(weibo):
     from oracle import oracle as O
     want = (run.cpu().numpy() + O.spmm(*csr, X.cpu().numpy(), n_threads=8)) / np.float32(L + 1)
     assert rel_err(lo_b[rows].cpu().numpy(), want[rows.cpu().numpy()]) <= 1e-5
+    # the whole middle in one launch (spex_gated_batch_f32: + the gate's backward + the push) against forward -> gate backward -> push
+    z = lambda *sh: torch.zeros(*sh, device=DEV)
+    g_prop, g_raw, G_a, ga_u, ga_i = z(n, 64), z(n, 64), z(n, 64), z(128, 2), z(128, 2)
+    d_prop = ops.expert_gate_rows_bwd(raw, lo_b, att_u, att_i, u_d, i_d, n_u, slots_b, g_prop, g_raw, ga_u, ga_i)
+    ops.spmm_push_batch(g, u_d, i_d, n_u, d_prop, G_a, add=d_prop, scale=1.0 / (L + 1))
+    got = (z(1), z(n, 64), z(n, 64), z(n, 64), z(16, 2, 128, 2))
+    ops.gated_batch(g, X, run, float(L + 1), raw, att_u, att_i, u_d, i_d, y_d, n_u, 1.0 / B, 1.0 / (L + 1), *got)
+    assert abs(got[0].item() - loss_a.item()) <= 1e-5 * abs(loss_a.item())
+    g_att = got[4].sum(0)
+    for nm, a_, b_ in zip(("g_prop", "G", "g_raw", "g_att_u", "g_att_i"), (g_prop, G_a, g_raw, ga_u, ga_i), got[1:4] + (g_att[0], g_att[1])):
+        assert rel_err(b_.cpu().numpy(), a_.cpu().numpy()) <= 5e-6, nm
 
 
 def _paths_for(users, by_user, cap, rng):

@@ -203,7 +203,8 @@ def test_dual_task_deterministic_step_repeats_bit_for_bit(data_root, golden):
         by_user[p[0]].append(k)
     cap = 3 * int(g["trust_batch_size"])
 
-    def run(det):
+    def run(det, pipelined=True):
+        os.environ["SPEX_DUAL_PIPELINED"] = "1" if pipelined else "0"
         args, dataset, net = _dual_epinion2(data_root)                  # includes set_seed: same negatives, shuffle, path cuts
         td = dl.LightTrainData(dataset.rec_train_data, dataset.m_item, dataset.train_mat)
         train2 = Data(raw_train, dataset.n_users, shuffle=False)
@@ -212,9 +213,66 @@ def test_dual_task_deterministic_step_repeats_bit_for_bit(data_root, golden):
         totals = train_epoch_dual(st, td, train2, by_user, cap, max_steps=120)
         torch.cuda.synchronize()
         return st.arena.clone(), st.m.clone(), st.v.clone(), totals.clone()
-    a, b = run(True), run(True)
-    for x, y in zip(a, b):
-        assert torch.equal(x, y)
-    f = run(False)
+    try:
+        a, b = run(True), run(True)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+        # the pipelined form (Adam split by owner over the two streams, what train_epoch_dual runs by default) does the same
+        # arithmetic as the fork / join form: bit-identical in the deterministic mode
+        c = run(True, pipelined=False)
+        for x, y in zip(a, c):
+            assert torch.equal(x, y)
+        f = run(False)
+    finally:
+        os.environ.pop("SPEX_DUAL_PIPELINED", None)
     assert rel_err(f[3].cpu().numpy(), a[3].cpu().numpy()) <= 5e-5
     assert (f[0][-2:] - a[0][-2:]).abs().max().item() <= 2e-5            # the task weights
+
+
+def test_dual_task_pipelined_steps_equal_forked_steps(data_root, golden):
+    """DualTaskStepper.step driven directly, 40 deterministic steps with 0..15 paths per step (steps WITHOUT paths included: the
+    side stream then only carries its share of the Adam pass), a join + an outside read in the middle: the pipelined form, the
+    fork / join form and the one-stream form end in bit-identical arenas, moments and loss sums."""
+    from utility2.utils import Data
+    from spex_amd.trainer import DualTaskStepper
+    raw_train, _ = _epinion2_trust_raw(golden)
+    rng = np.random.default_rng(5)
+    B, steps = 256, 40
+    n_paths = [int(rng.integers(0, 16)) for _ in range(steps)]
+    n_paths[3] = n_paths[17] = 0
+
+    def run(mode):
+        args, dataset, net = _dual_epinion2(data_root)
+        train2 = Data(raw_train, dataset.n_users, shuffle=False)
+        net = net.to(DEV)
+        st = DualTaskStepper(net, path_capacity=15, path_len=train2.len_max, lr=args.lr, deterministic=True,
+                             two_streams=mode != "one", pipelined=mode == "pipelined")
+        r = np.random.default_rng(6)
+        users = torch.from_numpy(r.integers(0, dataset.n_users, (steps, B))).to(DEV)
+        items = torch.from_numpy(r.integers(0, dataset.m_items, (steps, B))).to(DEV)
+        labels = torch.from_numpy((r.random((steps, B)) < 1 / 6).astype(np.float32)).to(DEV)
+        picks = [r.integers(0, len(raw_train[0]), k) for k in n_paths]
+        staged = []
+        for pk in picks:
+            if len(pk) == 0:
+                staged.append((None, None, None))
+                continue
+            inputs, mask, targets = train2.get_slice(pk)
+            staged.append((torch.from_numpy(np.ascontiguousarray(inputs, dtype=np.int64)).to(DEV),
+                           torch.from_numpy(np.asarray(mask).sum(1).astype(np.int64)).to(DEV),
+                           torch.from_numpy(np.asarray(targets).astype(np.int64)).to(DEV)))
+        torch.cuda.synchronize()
+        mid = None
+        for k in range(steps):
+            st.step(users[k], items[k], labels[k], *staged[k])
+            if k == 20:
+                st.join()
+                mid = st.loss_acc.clone()                 # an outside read on the current stream, after the join
+        st.join()
+        torch.cuda.synchronize()
+        return st.arena.clone(), st.m.clone(), st.v.clone(), st.loss_acc.clone(), mid
+    a, b, c = run("pipelined"), run("forked"), run("one")
+    for other in (b, c):
+        for x, y in zip(a, other):
+            assert torch.equal(x, y)
+    assert torch.isfinite(a[0]).all() and a[3][0].item() > 0 and a[3][1].item() > 0

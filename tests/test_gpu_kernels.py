@@ -1076,6 +1076,51 @@ def test_gated_batch_forward_equals_the_three_launch_sequence(G, golden, epinion
     assert rel_err(slots_b.cpu().numpy(), slots_a.cpu().numpy()) <= 2e-6
 
 
+def _gated_middle_three_launches(ops, g, X, run, L, raw, att_u, att_i, u_d, i_d, y_d, n_u):
+    """gated_batch_fwd -> expert_gate_rows_bwd -> spmm_push_batch: the sequence spex_gated_batch_f32 replaces."""
+    n, B = X.shape[0], u_d.numel()
+    z = lambda *s: torch.zeros(*s, device=DEV)
+    lo, slots, loss = z(n, 64), z(2 * B, 64), z(1)
+    ops.gated_batch_fwd(g, X, run, float(L + 1), raw, att_u, att_i, u_d, i_d, y_d, n_u, 1.0 / B, loss, lo, slots)
+    g_prop, g_raw, G_, ga_u, ga_i = z(n, 64), z(n, 64), z(n, 64), z(128, 2), z(128, 2)
+    d_prop = ops.expert_gate_rows_bwd(raw, lo, att_u, att_i, u_d, i_d, n_u, slots, g_prop, g_raw, ga_u, ga_i)
+    ops.spmm_push_batch(g, u_d, i_d, n_u, d_prop, G_, add=d_prop, scale=1.0 / (L + 1))
+    return loss, g_prop, G_, g_raw, ga_u, ga_i
+
+
+def _check_gated_middle(ops, g, X, run, L, raw, att_u, att_i, u_d, i_d, y_d, n_u, tol):
+    want = _gated_middle_three_launches(ops, g, X, run, L, raw, att_u, att_i, u_d, i_d, y_d, n_u)
+    n, B = X.shape[0], u_d.numel()
+    z = lambda *s: torch.zeros(*s, device=DEV)
+    for copies in (1, 64):                     # (one copy of the gate gradients: every sample adds to the same words)
+        got = (z(1), z(n, 64), z(n, 64), z(n, 64), z(copies, 2, 128, 2))
+        ops.gated_batch(g, X, run, float(L + 1), raw, att_u, att_i, u_d, i_d, y_d, n_u, 1.0 / B, 1.0 / (L + 1), *got)
+        assert abs(want[0].item() - got[0].item()) <= 1e-5 * abs(want[0].item()) + 1e-7
+        g_att = got[4].sum(0)
+        for nm, a, b in zip(("g_prop", "G", "g_raw", "g_att_u", "g_att_i"), want[1:], got[1:4] + (g_att[0], g_att[1])):
+            assert rel_err(b.cpu().numpy(), a.cpu().numpy()) <= tol, (nm, copies)
+
+
+def test_gated_batch_one_launch_equals_forward_gate_backward_push(G, golden, epinion2):
+    """spex_gated_batch_f32 (the dual-task rec branch's whole batch-sized middle in one launch) against spex_gated_batch_fwd_f32 ->
+    spex_expert_gate_rows_bwd_f32 -> spex_spmm_push_batch_f32 on Epinion2 with hub rows (shared by several workgroups) and
+    repeated users: dense d light, the pushed table, d raw, both gate gradients, the loss."""
+    from spex_amd import ops
+    g_, csr, E0 = _epinion2(golden, epinion2)
+    g = G(*csr)
+    n_u, L, B = 3186, 3, 256
+    rng = np.random.default_rng(22)
+    X, run, raw = t(E0), t((rng.normal(size=E0.shape) * 0.05).astype(np.float32)), t((rng.normal(size=E0.shape) * 0.1).astype(np.float32))
+    att_u, att_i = t((rng.normal(size=(128, 2)) * 0.5).astype(np.float32)), t((rng.normal(size=(128, 2)) * 0.5).astype(np.float32))
+    deg = np.diff(csr[0])
+    users, items = rng.integers(0, 3185, B), rng.integers(0, 12407, B)
+    users[:4] = np.argsort(-deg[:n_u])[:4]
+    items[:4] = np.argsort(-deg[n_u:])[:4]
+    users[10:14] = users[0]
+    labels = (rng.random(B) < 1 / 6).astype(np.float32)
+    _check_gated_middle(ops, g, X, run, L, raw, att_u, att_i, t(users), t(items), t(labels), n_u, 3e-6)
+
+
 @pytest.mark.parametrize("B", [1, 3, 17])
 def test_batch_kernels_small_batches_and_degenerate_rows(G, oracle, B):
     """spex_lightgcn_batch_f32 and spex_gated_batch_fwd_f32 on batches of 1 / 3 / 17 samples whose rows include an EMPTY row, a
@@ -1121,6 +1166,8 @@ def test_batch_kernels_small_batches_and_degenerate_rows(G, oracle, B):
     assert torch.equal(lo_b[rows], lo[rows])
     assert abs(loss_c.item() - loss_d.item()) <= 1e-5 * abs(loss_c.item()) + 1e-7
     assert rel_err(slots_b.cpu().numpy(), slots_a.cpu().numpy()) <= 3e-6
+    # gated form with the gate's backward and the push in the same launch
+    _check_gated_middle(ops, g, X, run, L, raw, att_u, att_i, u_d, i_d, y_d, n_u, 3e-6)
 
 
 def test_one_handle_driven_from_two_streams(G):
