@@ -403,8 +403,7 @@ def main():
                                        A_split=False, dropout=0)
             dnet = mex.LightGCN(dargs, _DS).to(dev)
             T_PATHS, P_LEN = 15, 6
-            # (pipelined: the form trainer.train_epoch_dual runs its loop in — inputs staged before the loop, a join at its end)
-            dst = DualTaskStepper(dnet, path_capacity=T_PATHS, path_len=P_LEN, lr=1e-3, pipelined=True)
+            dst = DualTaskStepper(dnet, path_capacity=T_PATHS, path_len=P_LEN, lr=1e-3)
             prng = np.random.default_rng(11)
             plen = prng.integers(2, P_LEN + 1, T_PATHS)
             pseq = np.full((T_PATHS, P_LEN), n_user, dtype=np.int64)
@@ -415,12 +414,13 @@ def main():
             fn3 = lambda: dst.step(ub, ib, yb, pseq_d, plen_d, ptgt)
             for _ in range(20):
                 fn3()
-            dst.join()
-            aux["dual_task_step_ms_B256_T15"] = time_events(fn3, 500, finish=dst.join)
-            dst.pipelined = False                        # the fork / join form (DualTaskStepper.step's default for per-step inputs)
-            for _ in range(20):
+            aux["dual_task_step_ms_B256_T15"] = time_events(fn3, 500)      # two streams, fork / join (the default form)
+            dst.pipelined = True                         # SPEX_STEP_PIPELINED: Adam split by owner over the two streams (pays when
+            for _ in range(20):                          # the trust branch is the longer one; not on Epinion2 with 15 paths)
                 fn3()
-            aux["dual_task_step_ms_B256_T15_fork_join"] = time_events(fn3, 200)
+            dst.join()
+            aux["dual_task_step_ms_B256_T15_pipelined"] = time_events(fn3, 500, finish=dst.join)
+            dst.join()
             del dnet, dst
         except Exception as e:  # never lose the headline line to an auxiliary measurement
             aux["aux_error"] = repr(e)

@@ -33,11 +33,15 @@
 // All parameters live in ONE flat block (layout below) so that a step's gradients are one buffer and one Adam launch.
 #include <math.h>
 
+#include <type_traits>
+
 #include "spex_common.h"
 
 using namespace spex;
 
 namespace {
+
+typedef float v2f __attribute__((ext_vector_type(2)));       // packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32)
 
 constexpr int kD = 64;        // hidden size: one lane per column
 constexpr int kMaxL = 16;     // longest padded path
@@ -129,11 +133,21 @@ __host__ __device__ inline LdsLayout lds_layout(int L, int H, bool train)
     o.dh = p;  p += train ? L * kD : 0;
     o.dO = p;  p += train ? L * kD : 0;
     o.du = p;  p += train ? L * kD : 0;
-    o.sacc = p; p += train ? kPathWaves * kD : 0;
+    o.sacc = p; p += train ? (kPathWaves + 1) * kD : 0;      // one row per wave + the target's table row
     o.red = p;  p += train ? 2 * kPathWaves : 0;
     o.total = p;
     return o;
 }
+
+#ifdef SPEX_STAMPS   // debug build only (tools/trust_stamps.py): phase stamps of workgroup 0 / thread 0, wall_clock64 = 100 MHz
+__device__ unsigned long long g_tstamps[32];
+#define TSTAMP(k)                                                            \
+    do {                                                                     \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_tstamps[k] = wall_clock64(); \
+    } while (0)
+#else
+#define TSTAMP(k)
+#endif
 
 // Orders one wave's LDS traffic (lane A writes, lane B reads): the LDS pipe serves a wave's instructions in order, so a
 // compiler-level fence + scheduling barrier is all that is needed — no s_barrier, the other waves are not involved.
@@ -296,6 +310,7 @@ __device__ __forceinline__ FwdState forward_tail(const TrustArgs &p, const LdsLa
         }
     }
     wave_sync();
+    TSTAMP(16);
     // soft-attention readout
     FwdState st;
     float4 wr[16], wr2[16];
@@ -317,6 +332,7 @@ __device__ __forceinline__ FwdState forward_tail(const TrustArgs &p, const LdsLa
     }
     vec[lane] = av;
     wave_sync();
+    TSTAMP(17);
     float pa = av;
     if (p.hybrid) {
         load_row(P + lo.Wt + lane * 2 * kD, wr);
@@ -324,6 +340,7 @@ __device__ __forceinline__ FwdState forward_tail(const TrustArgs &p, const LdsLa
         pa = P[lo.bt + lane] + dot_row(wr, vec);
         pa += dot_row(wr2, ht);
     }
+    TSTAMP(18);
     // max-pool over the path's own rows (a padded position contributes 0)
     float pm = -INFINITY;
     int arg = -1;
@@ -343,6 +360,201 @@ __device__ __forceinline__ FwdState forward_tail(const TrustArgs &p, const LdsLa
     return st;
 }
 
+// ------------------------------------------------------------------------------------ training forward (the whole workgroup)
+// The same chain as forward_head / forward_mw / forward_tail, spread over the workgroup's waves wherever its steps are
+// independent — wave 0 alone ran it as ~8 dependent L2 round trips plus ~100 dependent cross-lane sums while 3 (tiled form) or
+// 15 (fused form) waves waited at the next barrier:
+//   F0  waves 0 .. H-1: the path's rows (every wave gathers them itself: the loads hit the same lines) and ONE input head each
+//   F1  waves 0 .. 3:   `M @ w`, a quarter of w's rows each, all of a quarter's loads in flight at once
+//   F2  wave 0:         partial sums in wave order, ELU, the output attention layer (a serial recurrence over the positions)
+//   F3  waves 1 ..:     the readout's matrix-vector products as independent tasks — W2 h_i per position, W1 ht, Wt[:, d:] ht —
+//                       each wave holding its matrix row in registers
+//   F4  wave 0:         (Wt[:, :d] requested first) sigmoids, alphas, the pooled vector, p_a, the max-pool gate -> a2
+// Every value is formed by the same operations in the same order as in the one-wave chain (bit-identical forward).
+// NW: waves in the workgroup (>= 4).  Training LDS layout only (q rows live in `dh`, q1 / the ht half of p_a in `sacc`).
+__device__ __forceinline__ void forward_mw_all(const TrustArgs &p, const LdsLayout &ll, const float *s, int l, int lane, int k_beg, int n_k,
+                                               float (&acc)[kMaxL])
+{
+    const int H = p.H;
+    const Layout lo = layout(H);
+    const float *__restrict__ P = p.P;
+    const float *M = s + ll.M;
+    float wk[4][16];                                       // n_k <= 64 rows of w, requested together
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (c * 16 < n_k) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) wk[c][j] = P[lo.w + (k_beg + c * 16 + j) * kD + lane];
+        }
+#pragma unroll
+    for (int i = 0; i < kMaxL; ++i) acc[i] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (c * 16 < n_k) {
+#pragma unroll
+            for (int i = 0; i < kMaxL; ++i)
+                if (i < l) {
+#pragma unroll
+                    for (int j4 = 0; j4 < 4; ++j4) {
+                        const float4 m = *reinterpret_cast<const float4 *>(&M[i * H * kD + k_beg + c * 16 + j4 * 4]);
+                        acc[i] = fmaf(m.x, wk[c][j4 * 4 + 0], acc[i]);
+                        acc[i] = fmaf(m.y, wk[c][j4 * 4 + 1], acc[i]);
+                        acc[i] = fmaf(m.z, wk[c][j4 * 4 + 2], acc[i]);
+                        acc[i] = fmaf(m.w, wk[c][j4 * 4 + 3], acc[i]);
+                    }
+                }
+        }
+}
+
+template <int NW>
+__device__ __forceinline__ FwdState forward_train(const TrustArgs &p, const LdsLayout &ll, float *s, int b, int l, int lane, int wave,
+                                                  float *__restrict__ a2_out)
+{
+    static_assert(NW >= 4, "the training chain splits its work over at least four waves");
+    const int L = p.L, H = p.H;
+    const Layout lo = layout(H);
+    const float *__restrict__ P = p.P;
+    float *e = s + ll.e, *M = s + ll.M, *o = s + ll.o, *h = s + ll.h, *vec = s + ll.vec;
+    float *sg_all = s + ll.dM, *part = s + ll.dM, *q = s + ll.dh, *sacc = s + ll.sacc;
+    FwdState st{};
+    TSTAMP(0);
+    // ---- F0: rows + one input head per wave
+    if (wave < H) {
+        const int hh = wave;
+        const float a1 = P[lo.in_att + hh * 2 * kD + lane], a2 = P[lo.in_att + hh * 2 * kD + kD + lane];
+        {
+            float row[kMaxL];
+#pragma unroll
+            for (int i = 0; i < kMaxL; ++i) {
+                row[i] = 0.0f;
+                if (i < l) {
+                    const int64_t x = p.seq[(size_t)b * L + i];
+                    if (x >= 0 && x < p.n_rows) row[i] = p.table[(size_t)x * kD + lane];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < kMaxL; ++i)
+                if (i < l) e[i * kD + lane] = row[i];             // (every head's wave stores the same values)
+        }
+        for (int i = 0; i < l; ++i) {
+            const float ei = e[i * kD + lane];
+            if (i < l - 1) {
+                const float A = ei + (float)(l - i), Bv = e[(i + 1) * kD + lane] + (float)(l - i - 1);
+                const float s1 = wave_sum_f32(A * a1), s2 = wave_sum_f32(A * a2), s3 = wave_sum_f32(Bv * a2);
+                float w0, w1;
+                softmax2(s1 + s2, s1 + s3, w0, w1);
+                M[(i * H + hh) * kD + lane] = w0 * A + w1 * Bv;
+                if (lane == 0) vec[4 * kD + i * H + hh] = w0;
+            } else {
+                M[(i * H + hh) * kD + lane] = ei;
+            }
+        }
+    }
+    const float c1 = P[lo.out_att + lane], c2 = P[lo.out_att + kD + lane];      // (wave 0 needs them in F2: requested early)
+    __syncthreads();
+    TSTAMP(1);
+    // ---- F1: M @ w on four waves
+    float acc[kMaxL];
+    if (wave < 4) {
+        const int per = H * kD / 4;                      // 16 H rows of w per wave
+        forward_mw_all(p, ll, s, l, lane, wave * per, per, acc);
+        if (wave > 0)
+            for (int i = 0; i < l; ++i) part[((wave - 1) * L + i) * kD + lane] = acc[i];
+    }
+    __syncthreads();
+    TSTAMP(2);
+    // ---- F2: wave 0 — partials in wave order, ELU, output attention
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < kMaxL; ++i)
+            if (i < l)
+                for (int w = 0; w + 1 < 4; ++w) acc[i] += part[(w * L + i) * kD + lane];
+#pragma unroll
+        for (int i = 0; i < kMaxL; ++i)
+            if (i < l) o[i * kD + lane] = acc[i] > 0.0f ? acc[i] : expm1f(acc[i]);
+        for (int i = 0; i < l; ++i) {
+            const float oi = o[i * kD + lane];
+            float hv = oi;
+            if (i < l - 1) {
+                const float on = o[(i + 1) * kD + lane];
+                const float s1 = wave_sum_f32(oi * c1), s2 = wave_sum_f32(oi * c2), s3 = wave_sum_f32(on * c2);
+                float v0, v1;
+                softmax2(s1 + s2, s1 + s3, v0, v1);
+                hv = v0 * oi + v1 * on;
+                if (lane == 0) vec[5 * kD + i] = v0;
+            }
+            h[i * kD + lane] = hv;
+        }
+    }
+    __syncthreads();
+    TSTAMP(16);
+    // ---- F3: the readout's matrix-vector products as tasks on waves 1 .. NW-1 (task k < l: q2_k = b2 + W2 h_k; k == l: q1 = b1 + W1 ht;
+    //      k == l + 1: the ht half of p_a)
+    const float *ht = h + (l - 1) * kD;
+    if (wave != 0) {                              // (three separate blocks, one row of 64 registers live at a time)
+        if (wave - 1 < l) {
+            float4 wr[16];
+            load_row(P + lo.W2 + lane * kD, wr);
+            const float b2 = P[lo.b2 + lane];
+            for (int k = wave - 1; k < l; k += NW - 1) q[k * kD + lane] = b2 + dot_row(wr, h + k * kD);
+        }
+        if (wave == 1 + l % (NW - 1)) {
+            float4 wr[16];
+            load_row(P + lo.W1 + lane * kD, wr);
+            sacc[lane] = P[lo.b1 + lane] + dot_row(wr, ht);
+        }
+        if (p.hybrid && wave == 1 + (l + 1) % (NW - 1)) {
+            float4 wr[16];
+            load_row(P + lo.Wt + lane * 2 * kD + kD, wr);
+            sacc[kD + lane] = dot_row(wr, ht);
+        }
+    }
+    __syncthreads();
+    TSTAMP(17);
+    // ---- F4: wave 0 — sigmoids, alphas, pooled vector, p_a, max-pool gate
+    if (wave == 0) {
+        float4 wt[16];                                   // Wt[:, :d], requested here: the sigmoid loop below covers its round trip
+        if (p.hybrid) load_row(P + lo.Wt + lane * 2 * kD, wt);
+        const float w3 = P[lo.w3 + lane];
+        const float q1 = sacc[lane];
+        float av = 0.0f;
+        for (int i = 0; i < l; ++i) {
+            const float q2 = q[i * kD + lane];
+            const float sg = 1.0f / (1.0f + expf(-(q1 + q2)));
+            const float alpha = wave_sum_f32(w3 * sg);
+            sg_all[i * kD + lane] = sg;
+            if (lane == 0) vec[5 * kD + kMaxL + i] = alpha;
+            av = fmaf(alpha, h[i * kD + lane], av);
+        }
+        vec[lane] = av;
+        wave_sync();
+        float pa = av;
+        if (p.hybrid) {
+            pa = P[lo.bt + lane] + dot_row(wt, vec);
+            pa += sacc[kD + lane];
+        }
+        TSTAMP(18);
+        // max-pool over the path's own rows (a padded position contributes 0)
+        float pm = -INFINITY;
+        int arg = -1;
+        for (int i = 0; i < l; ++i) {
+            const float v = e[i * kD + lane];
+            if (v > pm) { pm = v; arg = i; }
+        }
+        if (l < L && !(pm > 0.0f)) { pm = 0.0f; arg = -1; }
+        const float t0 = wave_sum_f32(pa * P[lo.att_t + lane * 2] + pm * P[lo.att_t + (kD + lane) * 2]);
+        const float t1 = wave_sum_f32(pa * P[lo.att_t + lane * 2 + 1] + pm * P[lo.att_t + (kD + lane) * 2 + 1]);
+        float g0, g1;
+        softmax2(t0, t1, g0, g1);
+        const float a2v = pa * g0 + pm * g1;
+        a2_out[(size_t)b * kD + lane] = a2v;
+        vec[2 * kD + lane] = a2v;
+        st.av = av; st.pa = pa; st.pm = pm; st.g0 = g0; st.arg = arg; st.ht = ht[lane];
+    }
+    TSTAMP(3);
+    return st;
+}
+
 // --------------------------------------------------------------------------------------- logits + CE (the whole workgroup)
 __device__ __forceinline__ float block_reduce(float v, float *red, bool is_max)
 {
@@ -359,7 +571,11 @@ __device__ __forceinline__ float block_reduce(float v, float *red, bool is_max)
     return r;
 }
 
-// scores against table[0 : n_users] (16 lanes per 256-byte row), log-sum-exp, loss_b, d scores -> tr.dscore[b, :], d a2 -> vec[3]
+// scores against table[0 : n_users] (16 lanes per 256-byte row), log-sum-exp, loss_b, d scores -> tr.dscore[b, :], d a2 -> vec[3].
+// ONE sweep over the table: d a2 = k (sum_u softmax_u E[u] - E[target]) is accumulated together with the scores, flash-attention
+// style — every 16-lane row group keeps a running (max, sum-exp, sum exp * row) and rescales it when its max moves; the 64 groups
+// are combined in a fixed order at the end.  (The first version swept the table twice — scores, then sum_u d score[u] E[u] —
+// 2 x 815 KB per path through one CU's L1: 28 of the kernel's 70 us.)
 __device__ __forceinline__ void logits_ce(const TrustArgs &p, const TrainArgs &tr, const LdsLayout &ll, float *s, int b)
 {
     const int t = threadIdx.x, n_users = tr.n_users;
@@ -368,118 +584,174 @@ __device__ __forceinline__ void logits_ce(const TrustArgs &p, const TrainArgs &t
     const float *__restrict__ table = p.table;
     const int sub = t & 15, grp = t >> 4;                        // 64 row groups of 16 lanes
     const float4 x = reinterpret_cast<const float4 *>(vec + 2 * kD)[sub];
-    float mx = -INFINITY;
-    constexpr int kRows = (kPathWaves * kWave) / 16, kFly = 16;          // row groups per sweep; independent row loads in flight per lane
-    for (int u0 = 0; u0 < n_users; u0 += kRows * kFly) {
-        float4 r[kFly];
-#pragma unroll
-        for (int j = 0; j < kFly; ++j) {
-            const int u = u0 + j * kRows + grp;
-            r[j] = u < n_users ? reinterpret_cast<const float4 *>(table + (size_t)u * kD)[sub] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        }
-#pragma unroll
-        for (int j = 0; j < kFly; ++j) {
-            const int u = u0 + j * kRows + grp;
-            const float sc = row16_sum_f32(fmaf(r[j].x, x.x, fmaf(r[j].y, x.y, fmaf(r[j].z, x.z, r[j].w * x.w))));
-            if (u < n_users) {
-                if (sub == 0) ds[u] = sc;
-                mx = fmaxf(mx, sc);
-            }
-        }
-    }
-    mx = block_reduce(mx, red, true);                            // (its barriers also publish ds within the workgroup)
-    float se = 0.0f;
-    for (int u = t; u < n_users; u += (kPathWaves * kWave)) se += expf(ds[u] - mx);
-    se = block_reduce(se, red + kPathWaves, false);
-    const float lse = mx + logf(se);
     const int64_t tg = tr.targets[b];
     const bool tg_ok = tg >= 0 && tg < n_users;
-    if (t == 0) tr.loss_b[b] = tg_ok ? lse - ds[tg] : 0.0f;
-    __syncthreads();
-    const float k = tr.scale * (tr.scale_dev ? *tr.scale_dev : 1.0f) / (float)p.B;
-    for (int u = t; u < n_users; u += (kPathWaves * kWave)) ds[u] = tg_ok ? (expf(ds[u] - lse) - (u == tg ? 1.0f : 0.0f)) * k : 0.0f;
-    __syncthreads();
-    // d a2 = sum_u d score[u] E[u]: same 16-lanes-per-row sweep (lane holds four columns), the four row groups of a wave
-    // are folded with two cross-lane adds, the waves meet in LDS
-    const int wv = t >> 6;
-    float4 acc4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    for (int u0 = 0; u0 < n_users; u0 += kRows * kFly) {
-        float4 r[kFly];
-        float dv[kFly];
+    float4 e_tg = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (tg_ok) e_tg = reinterpret_cast<const float4 *>(table + (size_t)tg * kD)[sub];
+    // The sweep is VALU-bound, not memory-bound (16 lanes per row: every instruction serves four rows; 815 KB through one CU is ~6 us of
+    // transfer, the first version's ~56 instructions per row-quad were 17 us): full batches run without a single predicate (no
+    // bounds checks, one score store per batch — lane `sub == j` of a row group keeps row j's score), the exponentials are bare
+    // v_exp_f32 on a base-2 argument, dot and accumulation are packed FMAs, and the next batch's loads are issued before the
+    // current one is consumed.  Only the last, partial batch pays for clamped addresses and masks.
+    constexpr int kRows = (kPathWaves * kWave) / 16, kFly = 8;           // row groups per batch row; rows per batch and lane
+    constexpr float kLog2e = 1.44269504088896340736f;
+    float m_g = -INFINITY, s_g = 0.0f;
+    v2f acc_lo = {0.0f, 0.0f}, acc_hi = {0.0f, 0.0f};
+    const v2f x_lo = {x.x, x.y}, x_hi = {x.z, x.w};
+    const char *__restrict__ tb = reinterpret_cast<const char *>(table);
+    const uint32_t off0 = (uint32_t)grp * (kD * 4) + (uint32_t)sub * 16;
+    auto load_full = [&](int u0, float4 (&dst)[kFly]) {
+#pragma unroll
+        for (int j = 0; j < kFly; ++j)
+            dst[j] = *reinterpret_cast<const float4 *>(tb + (off0 + (uint32_t)(u0 + j * kRows) * (kD * 4)));
+    };
+    auto consume = [&](int u0, const float4 (&r)[kFly], auto tail) {
+        constexpr bool TAIL = decltype(tail)::value;
+        float sc[kFly], keep = 0.0f, bm = -INFINITY;
 #pragma unroll
         for (int j = 0; j < kFly; ++j) {
-            const int u = u0 + j * kRows + grp;
-            dv[j] = u < n_users ? ds[u] : 0.0f;
-            r[j] = u < n_users ? reinterpret_cast<const float4 *>(table + (size_t)u * kD)[sub] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            const v2f lo = {r[j].x, r[j].y}, hi = {r[j].z, r[j].w};
+            const v2f pr = __builtin_elementwise_fma(hi, x_hi, lo * x_lo);
+            float v = row16_sum_f32(pr.x + pr.y);
+            if (TAIL && u0 + j * kRows + grp >= n_users) v = -INFINITY;
+            sc[j] = v;
+            keep = sub == j ? v : keep;
+            bm = fmaxf(bm, v);
         }
+        if (sub < kFly) {
+            const int u = u0 + sub * kRows + grp;
+            if (!TAIL || u < n_users) ds[u] = keep;
+        }
+        if (!TAIL || bm > -INFINITY) {                            // (uniform over the 16 lanes of a group)
+            const float m_new = fmaxf(m_g, bm), f = __builtin_amdgcn_exp2f((m_g - m_new) * kLog2e);   // first batch: 2^-inf = 0
+            s_g *= f;
+            acc_lo *= f;
+            acc_hi *= f;
+            const float mb = m_new * kLog2e;
 #pragma unroll
-        for (int j = 0; j < kFly; ++j) {
-            acc4.x = fmaf(dv[j], r[j].x, acc4.x);
-            acc4.y = fmaf(dv[j], r[j].y, acc4.y);
-            acc4.z = fmaf(dv[j], r[j].z, acc4.z);
-            acc4.w = fmaf(dv[j], r[j].w, acc4.w);
+            for (int j = 0; j < kFly; ++j) {
+                const float w = __builtin_amdgcn_exp2f(fmaf(sc[j], kLog2e, -mb));      // rows beyond n_users: 2^-inf = 0
+                s_g += w;
+                const v2f lo = {r[j].x, r[j].y}, hi = {r[j].z, r[j].w}, w2 = {w, w};
+                acc_lo = __builtin_elementwise_fma(w2, lo, acc_lo);
+                acc_hi = __builtin_elementwise_fma(w2, hi, acc_hi);
+            }
+            m_g = m_new;
+        }
+    };
+    const int n_full = n_users / (kRows * kFly);
+    {
+        float4 r[kFly], rn[kFly];
+        if (n_full > 0) load_full(0, r);
+        for (int k = 0; k < n_full; ++k) {
+            if (k + 1 < n_full) load_full((k + 1) * kRows * kFly, rn);
+            consume(k * kRows * kFly, r, std::false_type{});
+#pragma unroll
+            for (int j = 0; j < kFly; ++j) r[j] = rn[j];
+        }
+        const int u0 = n_full * kRows * kFly;
+        if (u0 < n_users) {
+#pragma unroll
+            for (int j = 0; j < kFly; ++j) {
+                const int u = u0 + j * kRows + grp, uc = u < n_users ? u : n_users - 1;
+                r[j] = reinterpret_cast<const float4 *>(table + (size_t)uc * kD)[sub];
+            }
+            consume(u0, r, std::true_type{});
         }
     }
+    float4 acc4 = make_float4(acc_lo.x, acc_lo.y, acc_hi.x, acc_hi.y);
+    TSTAMP(4);
+    const float mx = block_reduce(m_g, red, true);               // (its barriers also publish ds within the workgroup)
+    const float f_g = m_g > -INFINITY ? expf(m_g - mx) : 0.0f;    // a group without rows contributes nothing
+    const float se = block_reduce(sub == 0 ? s_g * f_g : 0.0f, red + kPathWaves, false);
+    const float lse = mx + logf(se);
+    TSTAMP(5);
+    if (t == 0) tr.loss_b[b] = tg_ok ? lse - ds[tg] : 0.0f;
+    __syncthreads();
+    TSTAMP(6);
+    const float k = tr.scale * (tr.scale_dev ? *tr.scale_dev : 1.0f) / (float)p.B;
+    for (int u = t; u < n_users; u += (kPathWaves * kWave)) ds[u] = tg_ok ? (expf(ds[u] - lse) - (u == tg ? 1.0f : 0.0f)) * k : 0.0f;
+    TSTAMP(7);
+    // d a2: the groups' accumulators on the common maximum, the four row groups of a wave folded with two cross-lane adds, the
+    // waves in LDS in wave order
+    const int wv = t >> 6;
+    acc4.x *= f_g; acc4.y *= f_g; acc4.z *= f_g; acc4.w *= f_g;
     acc4.x += __shfl_xor(acc4.x, 16); acc4.y += __shfl_xor(acc4.y, 16); acc4.z += __shfl_xor(acc4.z, 16); acc4.w += __shfl_xor(acc4.w, 16);
     acc4.x += __shfl_xor(acc4.x, 32); acc4.y += __shfl_xor(acc4.y, 32); acc4.z += __shfl_xor(acc4.z, 32); acc4.w += __shfl_xor(acc4.w, 32);
     if ((t & 63) < 16) reinterpret_cast<float4 *>(sacc + wv * kD)[sub] = acc4;
+    if (t < 16) reinterpret_cast<float4 *>(sacc + kPathWaves * kD)[sub] = e_tg;      // (the row behind sacc: see lds_layout)
     __syncthreads();
     if (t < kD) {
         float g = 0.0f;
         for (int w = 0; w < kPathWaves; ++w) g += sacc[w * kD + t];
-        vec[3 * kD + t] = g;
+        vec[3 * kD + t] = tg_ok ? k * (g / se - sacc[kPathWaves * kD + t]) : 0.0f;
     }
 }
 
-// ---------------------------------------------------------------------------------------------- backward chain (one wave)
-__device__ __forceinline__ void backward_chain(const TrustArgs &p, const TrainArgs &tr, const LdsLayout &ll, float *s, int b, int l,
-                                               int lane, const FwdState &st)
+// ------------------------------------------------------------------------------------ training backward (the whole workgroup)
+// The chain backwards, its independent pieces on separate waves (the one-wave version spent 10 of its 23 us on three dependent
+// `load a row of w, l dot products` rounds and 5 on four dependent batches of W1 / W2 rows):
+//   P0  wave 0:          the gate between pooled vector and max-pool -> d p_a, d pm
+//   P1  waves 1, 2:      Wt^T d p_a — the `a` half and the `ht` half, each wave with all 64 rows in flight
+//   P2  wave 0:          the readout backwards (alphas, sigmoids) -> du_i, d h_i (first term), dq1
+//   P3  waves 1 ..:      W2^T du_i per position (each wave holds W2 in registers);  wave 0: W1^T dq1
+//   P4  wave 0:          the output attention layer and ELU backwards -> dr_i;   the other waves copy M into the workspace
+//   P5  waves 0 .. H-1:  ONE head each — d M_ih = w_h dr_i (the wave's rows of w in registers), then the input head's own backward
+//                        -> that head's share of d e_i (left in the head's dM rows) and its d a2
+//   P6  wave 0:          d e_i = the heads' shares in head order (+ the max-pool's d pm) -> workspace
+// Weight-gradient operands go to the per-path workspace as before; nothing is atomic, every sum has a fixed order.
+template <int NW>
+__device__ __forceinline__ void backward_train(const TrustArgs &p, const TrainArgs &tr, const LdsLayout &ll, float *s, int b, int l,
+                                               int lane, int wave, const FwdState &st)
 {
+    static_assert(NW >= 4, "the training chain splits its work over at least four waves");
     const int L = p.L, H = p.H;
     const Layout lo = layout(H);
     const WsLayout wl = ws_layout(L, H);
     const float *__restrict__ P = p.P;
     float *__restrict__ W = tr.ws + (size_t)b * wl.stride;
     float *e = s + ll.e, *M = s + ll.M, *dM = s + ll.dM, *o = s + ll.o, *h = s + ll.h, *dh = s + ll.dh, *dO = s + ll.dO;
-    float *du = s + ll.du, *vec = s + ll.vec;
+    float *du = s + ll.du, *vec = s + ll.vec, *sacc = s + ll.sacc;
     const float *sg_all = s + ll.dM;
-    const float av = st.av, pa = st.pa, pm = st.pm, g0 = st.g0, g1 = 1.0f - st.g0, ht = st.ht;
-    const float da2 = vec[3 * kD + lane];
-
-    // gate between the pooled vector and the max-pool
-    const float dg0 = wave_sum_f32(da2 * pa), dg1 = wave_sum_f32(da2 * pm);
-    const float dt0 = g0 * g1 * (dg0 - dg1);
-    const float dpa = g0 * da2 + (P[lo.att_t + lane * 2] - P[lo.att_t + lane * 2 + 1]) * dt0;
-    const float dpm = g1 * da2 + (P[lo.att_t + (kD + lane) * 2] - P[lo.att_t + (kD + lane) * 2 + 1]) * dt0;
-    W[wl.vpa + lane] = pa * dt0;
-    W[wl.vpm + lane] = pm * dt0;
-    W[wl.dpa + lane] = p.hybrid ? dpa : 0.0f;
-    W[wl.a + lane] = av;
-    W[wl.ht + lane] = ht;
-    // (dpm goes to the row the max-pool picked for this column: it joins that position's row gradient at the end of the chain)
-    // p_a = Wt [a | ht] + bt:  d a[k] = sum_c Wt[c][k] dpa[c],  d ht[k] = sum_c Wt[c][64 + k] dpa[c]   (lane == k: coalesced rows)
-    float da = dpa, dht = 0.0f;
-    if (p.hybrid) {
+    float dpa = 0.0f, dpm = 0.0f;
+    TSTAMP(8);
+    // ---- P0
+    if (wave == 0) {
+        const float av = st.av, pa = st.pa, pm = st.pm, g0 = st.g0, g1 = 1.0f - st.g0, ht = st.ht;
+        const float da2 = vec[3 * kD + lane];
+        const float dg0 = wave_sum_f32(da2 * pa), dg1 = wave_sum_f32(da2 * pm);
+        const float dt0 = g0 * g1 * (dg0 - dg1);
+        dpa = g0 * da2 + (P[lo.att_t + lane * 2] - P[lo.att_t + lane * 2 + 1]) * dt0;
+        dpm = g1 * da2 + (P[lo.att_t + (kD + lane) * 2] - P[lo.att_t + (kD + lane) * 2 + 1]) * dt0;
+        W[wl.vpa + lane] = pa * dt0;
+        W[wl.vpm + lane] = pm * dt0;
+        W[wl.dpa + lane] = p.hybrid ? dpa : 0.0f;
+        W[wl.a + lane] = av;
+        W[wl.ht + lane] = ht;
         vec[lane] = dpa;
-        wave_sync();
-        da = 0.0f;
-        for (int c0 = 0; c0 < kD; c0 += 16) {
-            float wa[16], wh[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                wa[j] = P[lo.Wt + (c0 + j) * 2 * kD + lane];
-                wh[j] = P[lo.Wt + (c0 + j) * 2 * kD + kD + lane];
-            }
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const float g = vec[c0 + j];
-                da = fmaf(wa[j], g, da);
-                dht = fmaf(wh[j], g, dht);
-            }
-        }
     }
-    // a = sum alpha_i h_i,  alpha_i = w3 . s_i,  s_i = sigmoid(q1 + q2_i)
-    {
+    __syncthreads();
+    TSTAMP(9);
+    // ---- P1: p_a = Wt [a | ht] + bt:  d a[k] = sum_c Wt[c][k] dpa[c] (wave 1),  d ht[k] = sum_c Wt[c][64 + k] dpa[c] (wave 2)
+    if (p.hybrid && (wave == 1 || wave == 2)) {
+        const int half = wave == 1 ? 0 : kD;
+        float wv[4][16];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) wv[c][j] = P[lo.Wt + (c * 16 + j) * 2 * kD + half + lane];
+        float g = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) g = fmaf(wv[c][j], vec[c * 16 + j], g);
+        sacc[half + lane] = g;
+    }
+    __syncthreads();
+    TSTAMP(10);
+    // ---- P2: a = sum alpha_i h_i,  alpha_i = w3 . s_i,  s_i = sigmoid(q1 + q2_i)
+    if (wave == 0) {
+        const float da = p.hybrid ? sacc[lane] : dpa;
         const float w3 = P[lo.w3 + lane];
         float dw3 = 0.0f, dq1 = 0.0f;
         for (int i = 0; i < l; ++i) {
@@ -497,40 +769,49 @@ __device__ __forceinline__ void backward_chain(const TrustArgs &p, const TrainAr
         W[wl.dq1 + lane] = dq1;
         vec[kD + lane] = dq1;
     }
-    wave_sync();
-    // linear_one / linear_two transposed:  d ht[k] += sum_c W1[c][k] dq1[c];  d h_i[k] += sum_c W2[c][k] du_i[c]
+    __syncthreads();
+    TSTAMP(11);
+    // ---- P3: linear_two transposed per position, d h_i[k] += sum_c W2[c][k] du_i[c] (waves 1 ..), linear_one transposed (wave 0)
+    float dht1 = 0.0f;
     {
-        float acc[kMaxL];
+        const float *__restrict__ Wm = P + (wave == 0 ? lo.W1 : lo.W2);
+        const bool busy = wave == 0 || wave - 1 < l;
+        if (busy) {
+            float wv[4][16];
 #pragma unroll
-        for (int i = 0; i < kMaxL; ++i) acc[i] = 0.0f;
-        for (int c0 = 0; c0 < kD; c0 += 16) {
-            float w1[16], w2[16];
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                w1[j] = P[lo.W1 + (c0 + j) * kD + lane];
-                w2[j] = P[lo.W2 + (c0 + j) * kD + lane];
-            }
+                for (int j = 0; j < 16; ++j) wv[c][j] = Wm[(c * 16 + j) * kD + lane];
+            if (wave == 0) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) dht = fmaf(w1[j], vec[kD + c0 + j], dht);
+                for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int i = 0; i < kMaxL; ++i)
-                if (i < l) {
+                    for (int j = 0; j < 16; ++j) dht1 = fmaf(wv[c][j], vec[kD + c * 16 + j], dht1);
+            } else {
+                for (int i = wave - 1; i < l; i += NW - 1) {
+                    float g = 0.0f;
 #pragma unroll
-                    for (int j4 = 0; j4 < 4; ++j4) {
-                        const float4 d = *reinterpret_cast<const float4 *>(&du[i * kD + c0 + j4 * 4]);
-                        acc[i] = fmaf(w2[j4 * 4 + 0], d.x, acc[i]);
-                        acc[i] = fmaf(w2[j4 * 4 + 1], d.y, acc[i]);
-                        acc[i] = fmaf(w2[j4 * 4 + 2], d.z, acc[i]);
-                        acc[i] = fmaf(w2[j4 * 4 + 3], d.w, acc[i]);
-                    }
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int j4 = 0; j4 < 4; ++j4) {
+                            const float4 d = *reinterpret_cast<const float4 *>(&du[i * kD + c * 16 + j4 * 4]);
+                            g = fmaf(wv[c][j4 * 4 + 0], d.x, g);
+                            g = fmaf(wv[c][j4 * 4 + 1], d.y, g);
+                            g = fmaf(wv[c][j4 * 4 + 2], d.z, g);
+                            g = fmaf(wv[c][j4 * 4 + 3], d.w, g);
+                        }
+                    dh[i * kD + lane] += g;
                 }
+            }
         }
-#pragma unroll
-        for (int i = 0; i < kMaxL; ++i)
-            if (i < l) dh[i * kD + lane] += acc[i] + (i == l - 1 ? dht : 0.0f);
     }
-    // output attention layer (the first half of its parameter cancels in the softmax: gradient exactly 0)
-    {
+    __syncthreads();
+    TSTAMP(12);
+    // ---- P4: wave 0 — output attention layer (the first half of its parameter cancels in the softmax: gradient exactly 0), then
+    //      ELU (from o alone: o > 0 <=> r > 0, else exp(r) = o + 1);  the other waves — M and the padded positions' zero rows
+    float *dr = du;     // du is dead
+    if (wave == 0) {
+        dh[(l - 1) * kD + lane] += dht1 + (p.hybrid ? sacc[kD + lane] : 0.0f);
         const float c2 = P[lo.out_att + kD + lane];
         float dc2 = 0.0f;
         for (int i = 0; i < l; ++i) dO[i * kD + lane] = 0.0f;
@@ -547,68 +828,71 @@ __device__ __forceinline__ void backward_chain(const TrustArgs &p, const TrainAr
             }
         }
         W[wl.dc2 + lane] = dc2;
+        for (int i = 0; i < l; ++i) {
+            const float ov = o[i * kD + lane];
+            const float d = dO[i * kD + lane] * (ov > 0.0f ? 1.0f : ov + 1.0f);
+            dr[i * kD + lane] = d;
+            W[wl.DR + i * kD + lane] = d;
+        }
+    } else {
+        for (int r = wave - 1; r < L * H; r += NW - 1) {            // M rows; rows of padded positions: zeros, so the reduce kernel
+            const int i = r / H;                                      // walks B x L rows flat
+            W[wl.M + r * kD + lane] = i < l ? M[r * kD + lane] : 0.0f;
+        }
+        for (int i = l + wave - 1; i < L; i += NW - 1) {
+            W[wl.DU + i * kD + lane] = 0.0f;
+            W[wl.Hm + i * kD + lane] = 0.0f;
+            W[wl.DR + i * kD + lane] = 0.0f;
+        }
     }
-    // ELU (from o alone: o > 0 <=> r > 0, else exp(r) = o + 1), then  d M_i[k] = sum_c w[k][c] dr_i[c]  (lane == k mod 64)
-    float *dr = du;     // du is dead
-    for (int i = 0; i < l; ++i) {
-        const float ov = o[i * kD + lane];
-        const float d = dO[i * kD + lane] * (ov > 0.0f ? 1.0f : ov + 1.0f);
-        dr[i * kD + lane] = d;
-        W[wl.DR + i * kD + lane] = d;
-        for (int hh = 0; hh < H; ++hh) W[wl.M + (i * H + hh) * kD + lane] = M[(i * H + hh) * kD + lane];
-    }
-    for (int i = l; i < L; ++i) {            // rows of padded positions: zeros, so the reduce kernel walks B x L rows flat
-        W[wl.DU + i * kD + lane] = 0.0f;
-        W[wl.Hm + i * kD + lane] = 0.0f;
-        W[wl.DR + i * kD + lane] = 0.0f;
-        for (int hh = 0; hh < H; ++hh) W[wl.M + (i * H + hh) * kD + lane] = 0.0f;
-    }
-    wave_sync();
-    {
+    __syncthreads();
+    TSTAMP(13);
+    // ---- P5: one head per wave: d M_ih[k] = sum_c w[h d + k][c] dr_i[c] (lane == k), then the head's positional attention backwards
+    if (wave < H) {
+        const int hh = wave;
+        const float a2 = P[lo.in_att + hh * 2 * kD + kD + lane];
         float4 wr[16];
-        for (int hh = 0; hh < H; ++hh) {
-            load_row(P + lo.w + (hh * kD + lane) * kD, wr);
-            for (int i = 0; i < l; ++i) dM[(i * H + hh) * kD + lane] = dot_row(wr, dr + i * kD);
-        }
-    }
-    // input attention heads
-    {
-        float dE[kMaxL], da2h[kMaxH], a2[kMaxH];
+        load_row(P + lo.w + (hh * kD + lane) * kD, wr);
+        float g[kMaxL], dE[kMaxL];
 #pragma unroll
-        for (int i = 0; i < kMaxL; ++i) dE[i] = 0.0f;
-#pragma unroll
-        for (int hh = 0; hh < kMaxH; ++hh) {
-            da2h[hh] = 0.0f;
-            a2[hh] = hh < H ? P[lo.in_att + hh * 2 * kD + kD + lane] : 0.0f;
+        for (int i = 0; i < kMaxL; ++i) {
+            dE[i] = 0.0f;
+            g[i] = i < l ? dot_row(wr, dr + i * kD) : 0.0f;
         }
+        float da2h = 0.0f;
 #pragma unroll
         for (int i = 0; i < kMaxL; ++i) {
             if (i < l - 1) {
                 const float delta = e[i * kD + lane] - e[(i + 1) * kD + lane] + 1.0f;
-#pragma unroll
-                for (int hh = 0; hh < kMaxH; ++hh)
-                    if (hh < H) {
-                        const float g = dM[(i * H + hh) * kD + lane], w0 = vec[4 * kD + i * H + hh];
-                        const float dz = wave_sum_f32(g * delta) * w0 * (1.0f - w0);
-                        dE[i] += w0 * g + dz * a2[hh];
-                        if (i + 1 < kMaxL) dE[i + 1] += (1.0f - w0) * g - dz * a2[hh];
-                        da2h[hh] = fmaf(dz, delta, da2h[hh]);
-                    }
+                const float w0 = vec[4 * kD + i * H + hh];
+                const float dz = wave_sum_f32(g[i] * delta) * w0 * (1.0f - w0);
+                dE[i] += w0 * g[i] + dz * a2;
+                if (i + 1 < kMaxL) dE[i + 1] += (1.0f - w0) * g[i] - dz * a2;
+                da2h = fmaf(dz, delta, da2h);
             } else if (i == l - 1) {
-#pragma unroll
-                for (int hh = 0; hh < kMaxH; ++hh)
-                    if (hh < H) dE[i] += dM[(i * H + hh) * kD + lane];
+                dE[i] += g[i];
             }
         }
-        // the path's own table rows: plain stores into the workspace — the reduce kernel owns the table rows and adds them in
-        // (path, position) order (float atomics here made the trust branch the one non-repeatable part of the dual-task step)
 #pragma unroll
         for (int i = 0; i < kMaxL; ++i)
-            if (i < L) W[wl.DE + i * kD + lane] = i < l ? dE[i] + (st.arg == i ? dpm : 0.0f) : 0.0f;
-#pragma unroll
-        for (int hh = 0; hh < kMaxH; ++hh)
-            if (hh < H) W[wl.da2h + hh * kD + lane] = da2h[hh];
+            if (i < l) dM[(i * H + hh) * kD + lane] = dE[i];          // this head's share of d e_i
+        W[wl.da2h + hh * kD + lane] = da2h;
     }
+    __syncthreads();
+    TSTAMP(14);
+    // ---- P6: the path's own table rows: plain stores into the workspace — the reduce kernel owns the table rows and adds them in
+    //      (path, position) order.  d pm goes to the row the max-pool picked for this column.
+    if (wave == 0) {
+        for (int i = 0; i < L; ++i) {
+            float d = 0.0f;
+            if (i < l) {
+                for (int hh = 0; hh < H; ++hh) d += dM[(i * H + hh) * kD + lane];
+                if (st.arg == i) d += dpm;
+            }
+            W[wl.DE + i * kD + lane] = d;
+        }
+    }
+    TSTAMP(15);
 }
 
 // The FUSED training form (round 2; still the faster one for the reference's small trust batches — <= 15 paths against 3 185
@@ -619,42 +903,16 @@ __device__ __forceinline__ void backward_chain(const TrustArgs &p, const TrainAr
 __global__ __launch_bounds__(kPathWaves *kWave) void trust_path_train_kernel(const TrustArgs p, const TrainArgs tr,
                                                                             float *__restrict__ a2_out)
 {
-    constexpr bool TRAIN = true;
     extern __shared__ float4 s_raw[];
     float *s = reinterpret_cast<float *>(s_raw);
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const LdsLayout ll = lds_layout(p.L, p.H, TRAIN);
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const LdsLayout ll = lds_layout(p.L, p.H, true);
     const int l = path_len(p, b);
-    FwdState st{};
-    // forward: rows + attention heads on wave 0, `M @ w` split over kSplit waves by rows of w (partials summed in wave order:
-    // deterministic), the rest on wave 0
-    constexpr int kSplit = TRAIN ? 4 : 1;
-    if (wave == 0) forward_head(p, ll, s, b, l, lane);
-    if (TRAIN) __syncthreads(); else wave_sync();
-    float acc[kMaxL];
-    float *part = s + ll.dM;                     // [kSplit - 1][L][64]: dM .. du are free until the backward chain
-    if (wave < kSplit) {
-        const int per = p.H * kD / kSplit;       // 16 H rows of w per wave
-        forward_mw(p, ll, s, l, lane, wave * per, (wave + 1) * per, acc);
-        if (wave > 0)
-            for (int i = 0; i < l; ++i) part[((wave - 1) * p.L + i) * kD + lane] = acc[i];
-    }
-    if (TRAIN) __syncthreads();
-    if (wave == 0) {
-        if (kSplit > 1) {
-#pragma unroll
-            for (int i = 0; i < kMaxL; ++i)
-                if (i < l)
-                    for (int w = 0; w + 1 < kSplit; ++w) acc[i] += part[(w * p.L + i) * kD + lane];
-            wave_sync();                         // part[] is read before forward_tail reuses the region for the sigmoids
-        }
-        st = forward_tail(p, ll, s, b, l, lane, acc, a2_out);
-    }
-    if (!TRAIN) return;
+    const FwdState st = forward_train<kPathWaves>(p, ll, s, b, l, lane, wave, a2_out);
     __syncthreads();
     logits_ce(p, tr, ll, s, b);
     __syncthreads();
-    if (wave == 0) backward_chain(p, tr, ll, s, b, l, lane, st);
+    backward_train<kPathWaves>(p, tr, ll, s, b, l, lane, wave, st);
 }
 
 // Evaluation form (flag 2): one wave per path, forward chain only.
@@ -684,31 +942,11 @@ __global__ __launch_bounds__(kWave *kFwdWaves) void trust_fwd_kernel(const Trust
 {
     extern __shared__ float4 s_raw[];
     float *s = reinterpret_cast<float *>(s_raw);
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const LdsLayout ll = lds_layout(p.L, p.H, true);
     const WsLayout wl = ws_layout(p.L, p.H);
     const int l = path_len(p, b);
-    FwdState st{};
-    if (wave == 0) forward_head(p, ll, s, b, l, lane);
-    __syncthreads();
-    // `M @ w` split over the four waves by rows of w (partials summed in wave order: deterministic)
-    float acc[kMaxL];
-    float *part = s + ll.dM;                     // [kFwdWaves - 1][L][64]: dM .. du are free in this kernel
-    {
-        const int per = p.H * kD / kFwdWaves;    // 16 H rows of w per wave
-        forward_mw(p, ll, s, l, lane, wave * per, (wave + 1) * per, acc);
-        if (wave > 0)
-            for (int i = 0; i < l; ++i) part[((wave - 1) * p.L + i) * kD + lane] = acc[i];
-    }
-    __syncthreads();
-    if (wave == 0) {
-#pragma unroll
-        for (int i = 0; i < kMaxL; ++i)
-            if (i < l)
-                for (int w = 0; w + 1 < kFwdWaves; ++w) acc[i] += part[(w * p.L + i) * kD + lane];
-        wave_sync();                             // part[] is read before forward_tail reuses the region for the sigmoids
-        st = forward_tail(p, ll, s, b, l, lane, acc, a2_out);
-    }
+    const FwdState st = forward_train<kFwdWaves>(p, ll, s, b, l, lane, wave, a2_out);
     __syncthreads();
     // park the state: the LDS image (coalesced, all waves) + the chain's registers (wave 0)
     float *__restrict__ S = tr.ws + (size_t)b * wl.stride + wl.St;
@@ -725,7 +963,7 @@ __global__ __launch_bounds__(kWave *kFwdWaves) void trust_fwd_kernel(const Trust
 // workgroup owns kTileUsers consecutive users and handles all paths, so the table is read once (not once per path) and by ~100
 // workgroups.  Paths are taken in chunks of kPathChunk (LDS: the chunk's a2 rows and its scores / d scores for the tile).
 constexpr int kTileUsers = 32;
-constexpr int kTiledMinUsers = 4500, kTiledMaxPaths = 24;   // where the tiled launches beat the fused kernel (measured, see the host code)
+constexpr int kTiledMinUsers = 8000, kTiledMaxPaths = 24;   // where the tiled launches beat the fused kernel (measured, see the host code)
 constexpr int kPathChunk = 64;
 constexpr int kTileThreads = 256;
 
@@ -880,7 +1118,7 @@ __global__ __launch_bounds__(kWave *kFwdWaves) void trust_bwd_kernel(const Trust
 {
     extern __shared__ float4 s_raw[];
     float *s = reinterpret_cast<float *>(s_raw);
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const LdsLayout ll = lds_layout(p.L, p.H, true);
     const WsLayout wl = ws_layout(p.L, p.H);
     const int l = path_len(p, b);
@@ -904,17 +1142,17 @@ __global__ __launch_bounds__(kWave *kFwdWaves) void trust_bwd_kernel(const Trust
         sacc[wave * kD + lane] = acc;
     }
     __syncthreads();
+    FwdState st{};
     if (wave == 0) {
         float g = sacc[lane];
         for (int w = 1; w < kFwdWaves; ++w) g += sacc[w * kD + lane];
         (s + ll.vec)[3 * kD + lane] = g;
         const float *R = S + n_img;
-        FwdState st;
         st.av = R[0 * kD + lane]; st.pa = R[1 * kD + lane]; st.pm = R[2 * kD + lane]; st.g0 = R[3 * kD + lane];
         st.ht = R[4 * kD + lane]; st.arg = __float_as_int(R[5 * kD + lane]);
-        wave_sync();
-        backward_chain(p, tr, ll, s, b, l, lane, st);
     }
+    __syncthreads();
+    backward_train<kFwdWaves>(p, tr, ll, s, b, l, lane, wave, st);
 }
 
 // ------------------------------------------------------------------------------------------------------------ reductions
@@ -1128,17 +1366,16 @@ extern "C" int spex_trust_head_train_f32(const float *table, int64_t n_rows, con
     float *part_da2 = ws + (size_t)B * ws_layout(L, n_heads).stride;
     float *part_ms = part_da2 + (size_t)n_tiles * B * kD;
     hipStream_t st = (hipStream_t)stream;
-    // Which form: the fused kernel sweeps the user table once PER PATH through one CU (2 x n_users x 256 B per path), the tiled
+    // Which form: the fused kernel sweeps the user table once PER PATH through one CU (n_users x 256 B per path), the tiled
     // launches read it once for all paths on ~n_users / 32 workgroups but pay three more launch boundaries, the chains' state
     // round trip, and a per-tile loop over the paths.  Measured on the MI355X (tools/trust_forms_time.py, us per call, fused /
-    // tiled): 3 185 users x 15 paths 74.5 / 74.6 (and the fused form overlaps better with the rec branch on the second stream:
-    // dual-task step 114 vs 150 us); 6 812 x 15: 93 / 79; 26 000 x 15: 219 / 108; 3 185 x 45: 93 / 114; 6 812 x 45: 113 / 125;
-    // 3 185 x 192: 179 / 293; 26 000 x 60: 253 / 290.  So: tiled for a LARGE user table with a SMALL trust batch — config 5's own
-    // shape (Weibo: 6 812 users, 15 paths per step) — fused otherwise (Epinion2's 3 185 users).  SPEX_TRUST_TILED=0/1 forces.
-    static const int forced = []() {
-        const char *e = getenv("SPEX_TRUST_TILED");
-        return e ? atoi(e) : -1;
-    }();
+    // tiled; round 3, after the one-sweep logits and the multi-wave chains): 3 185 users x 15 paths 51 / 60; 6 812 x 15: 62 / 64;
+    // 26 000 x 15: 131 / 94; 3 185 x 45: 70 / 99; 6 812 x 45: 82 / 109; 3 185 x 192: 156 / 278; 26 000 x 60: 167 / 275.  (Round 2's
+    // fused kernel: 74.5 at 3 185 x 15, 93 at 6 812 x 15, 219 at 26 000 x 15.)  So: tiled only for a LARGE user table (~8 000 users is
+    // where the lines cross) with a SMALL trust batch, fused otherwise — including both of the reference's datasets (Epinion2
+    // 3 185, Weibo 6 812 users).  SPEX_TRUST_TILED=0/1 forces.
+    const char *force_env = getenv("SPEX_TRUST_TILED");          // (read per call: the tests run both forms in one process)
+    const int forced = force_env && force_env[0] ? atoi(force_env) : -1;
     const bool tiled = forced >= 0 ? forced != 0 : (n_users >= kTiledMinUsers && B <= kTiledMaxPaths);
     if (tiled) {
         hipLaunchKernelGGL(trust_fwd_kernel, dim3((unsigned)B), dim3(kWave * kFwdWaves), lds, st, p, tr, a2);
@@ -1158,3 +1395,12 @@ extern "C" int spex_trust_head_train_f32(const float *table, int64_t n_rows, con
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }
+
+#ifdef SPEX_STAMPS
+extern "C" int spex_debug_trust_stamps(unsigned long long *out)
+{
+    SPEX_HIP(hipDeviceSynchronize());
+    SPEX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tstamps), sizeof(unsigned long long) * 32));
+    return SPEX_OK;
+}
+#endif

@@ -525,8 +525,9 @@ class DualTaskStepper:
         pipelined (needs two streams; flags & SPEX_STEP_PIPELINED): the Adam pass split by owner over the two streams, so that no
         fork / join sits on the trust branch's cycle.  The side stream then runs AHEAD of the current stream between steps: the
         path inputs of a step must be complete before the previous `join()`, and `join()` must come before anything but the
-        next step touches the model, the moments or `loss_acc` (train_epoch_dual stages an epoch's inputs up front, turns the
-        mode on for its loop — SPEX_DUAL_PIPELINED=0 keeps it off — and joins at the end).
+        next step touches the model, the moments or `loss_acc` (train_epoch_dual stages an epoch's inputs up front and, with
+        SPEX_DUAL_PIPELINED=1, turns the mode on for its loop and joins at the end).  Worth it when the trust branch is the
+        longer of the two; on Epinion2 with 15 paths the fork / join form is faster (93 vs 105 us per step).
         deterministic (default: SPEX_DETERMINISTIC=1 in the environment): no float atomics in the step (flags &
         SPEX_STEP_DETERMINISTIC).  fixed_task_weights: loss = loss1 + loss2 as in main_11.py:69 (flags &
         SPEX_STEP_FIXED_TASK_WEIGHTS; the task weights stay where they are)."""
@@ -713,10 +714,12 @@ def train_epoch_dual(stepper, train_data, trust_data, by_user, cap, batch_size=2
     stepper.join()
     stepper.loss_acc.zero_()
     # the epoch's inputs are complete on the device before its first step and nothing but the steps touches the model inside the
-    # loop: the pipelined form's contract (DualTaskStepper.__init__), so the loop runs in it when the stepper has two streams
+    # loop: the pipelined form's contract (DualTaskStepper.__init__), so the loop MAY run in it — SPEX_DUAL_PIPELINED=1.  It pays
+    # when the trust branch is the longer one (round 3's first measurement: 119 -> 102 us per step on Epinion2); with this round's
+    # trust kernel (46 us against the rec branch's ~70) the fork / join form is the faster one again (93 vs 105 us), so that is the
+    # default.  (A pipelined loop's first step forks the side stream from the current one, behind the uploads above.)
     was_pipelined = stepper.pipelined
-    # (its first step forks the side stream from the current one, behind the uploads above)
-    if stepper._side is not None and os.environ.get("SPEX_DUAL_PIPELINED", "1") != "0":
+    if stepper._side is not None and os.environ.get("SPEX_DUAL_PIPELINED", "0") == "1":
         stepper.pipelined = True
     gc_was_on = pause_gc and gc.isenabled()
     if gc_was_on:

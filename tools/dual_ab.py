@@ -4,7 +4,7 @@ shaped batches optional.  The library reads its A/B switches from the environmen
     python tools/dual_ab.py                       # default build
     SPEX_DUAL_FUSED_MIDDLE=0 python tools/dual_ab.py
     SPEX_DUAL_ONE_STREAM=1 python tools/dual_ab.py
-    SPEX_DUAL_PIPELINED=0 python tools/dual_ab.py     # the fork / join form of the two-stream step
+    SPEX_DUAL_PIPELINED=1 python tools/dual_ab.py     # the pipelined form of the two-stream step (SPEX_STEP_PIPELINED)
 
 Under rocprofv3 (`--kernel-trace --stats`) pass --steps 300 to keep the trace small.
 """
@@ -37,7 +37,7 @@ for r, l in enumerate(plen):
     pseq[r, :l] = rng.choice(n_user, size=l, replace=False)
 seq, seq_l = torch.from_numpy(pseq).to(dev), torch.from_numpy(plen.astype(np.int64)).to(dev)
 tgt = torch.from_numpy(rng.integers(0, n_user, T)).to(dev)
-st = DualTaskStepper(net, path_capacity=T, path_len=P_LEN, lr=1e-3, pipelined=os.environ.get("SPEX_DUAL_PIPELINED", "1") != "0")
+st = DualTaskStepper(net, path_capacity=T, path_len=P_LEN, lr=1e-3, pipelined=os.environ.get("SPEX_DUAL_PIPELINED", "0") == "1")
 for _ in range(50):
     st.step(u, i, y, seq, seq_l, tgt)
 st.join(); torch.cuda.synchronize()
