@@ -253,6 +253,16 @@ int spex_ngcf_layer_fwd_f32(const float *ego, const float *side, const float *W_
                             const float *b_bi, float *out, int32_t ld_out, int32_t write_ego, float *e1_out, int32_t n,
                             int32_t d, float slope, float p_drop, uint64_t seed, uint32_t step, uint32_t layer,
                             int32_t pad_row, void *stream);
+/* The same layer at a LIST of rows only: slot k names row idx_a[k] + off_a (k < n_a) or idx_b[k - n_a] + off_b.  `ego`, `side`
+ * and `out` are the dense tables, read / written at those rows (other rows of `out` are left untouched; a row named twice is
+ * stored twice with the same value; an index outside [0, n) is skipped); the dropout mask is indexed by the row.  A one-layer
+ * model's training loss reads the layer's output at the batch's rows only (main_rec.py:96-104): with spex_spmm_rowlist_f32 for
+ * `side` this replaces the whole-table forward of a training step (2B rows instead of N).  Bit-identical rows.
+ */
+int spex_ngcf_layer_fwd_rows_f32(const float *ego, const float *side, const float *W_gc, const float *b_gc, const float *W_bi,
+                                 const float *b_bi, float *out, int32_t ld_out, int32_t write_ego, int32_t n, int32_t d, float slope,
+                                 float p_drop, uint64_t seed, uint32_t step, uint32_t layer, int32_t pad_row, const int64_t *idx_a,
+                                 int32_t n_a, int64_t off_a, const int64_t *idx_b, int32_t n_b, int64_t off_b, void *stream);
 /* side = A ego (main_rec.py:76) and the layer (:77-83) in ONE launch on a handle created with SPEX_GRAPH_TILE_ROWS: a workgroup
  * runs its tasks like spex_spmm_f32, keeps its (<= 64) finished rows in LDS and runs the layer on them; out [n, ld_out >= 2d]
  * receives [ego | normalised layer output], side_out [n, d] the product (bit-identical to spex_spmm_f32's; the backward

@@ -188,10 +188,23 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void ngcf_layer_kernel(
 constexpr int kFwdStride = 68;
 constexpr int kFwdTiles = 4;                                      // tiles per workgroup
 
+// ROWS (spex_ngcf_layer_fwd_rows_f32): the same layer at a LIST of rows — tile slot k names row idx_a[k] + off_a (k < n_a) or
+// idx_b[k - n_a] + off_b; `ego`, `side` and `out` stay the dense tables and are read / written at those rows only (a row named
+// twice is computed twice and stored twice with the same value), the dropout mask is indexed by the row, not by the slot.  A
+// one-layer model's training loss reads the layer's output at the batch's rows only (main_rec.py:96-104), so the step computes
+// it there (2B <= 512 rows instead of N = 15 592 on Epinion2).
+struct RowList {
+    const int64_t *idx_a, *idx_b;
+    int n_a, n_b;
+    int64_t off_a, off_b;
+};
+
+template <bool ROWS>
 __global__ __launch_bounds__(kWave * 4 * kFwdTiles) void ngcf_layer_fwd4_kernel(
     const float *__restrict__ ego, const float *__restrict__ side, const float *__restrict__ W_gc,
     const float *__restrict__ b_gc, const float *__restrict__ W_bi, const float *__restrict__ b_bi,
-    float *__restrict__ out, int ld_out, int write_ego, float *__restrict__ e1_out, int n, float slope, const MsgDrop drop)
+    float *__restrict__ out, int ld_out, int write_ego, float *__restrict__ e1_out, int n, float slope, const MsgDrop drop,
+    const RowList rl)
 {
     __shared__ float s_w[2][64 * kFwdStride];                       // W_gc, W_bi as [out j][in k]
     __shared__ float s_t[kFwdTiles][2][16 * kFwdStride];            // per tile: side, ego * side
@@ -201,13 +214,31 @@ __global__ __launch_bounds__(kWave * 4 * kFwdTiles) void ngcf_layer_fwd4_kernel(
     const int i16 = lane & 15, h = lane >> 4;
     const int r0 = (blockIdx.x * kFwdTiles + tl) << 4;              // (tiles past the end: every row fails r < n)
     float *t_side = s_t[tl][0], *t_prod = s_t[tl][1];
+    // the tile's 16 rows: slot k of the tile -> table row (lane k < 16 holds it), -1 = none
+    int slot_row = -1;
+    if (lane < 16) {
+        const int k = r0 + lane;
+        if (ROWS) {
+            if (k < rl.n_a + rl.n_b) {
+                const long long r = batch_row(rl.idx_a, rl.n_a, rl.off_a, rl.idx_b, rl.off_b, k);
+                slot_row = (r >= 0 && r < n) ? (int)r : -1;
+            }
+        } else {
+            slot_row = k < n ? k : -1;
+        }
+    }
+    int row_q[4];                                                   // rows of this lane's accumulator entries (row 4h + q of the tile)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) row_q[q] = __shfl(slot_row, 4 * h + q, kWave);
     // this wave's four rows of the tile (lane == column), requested before the weights
     float e_reg[4], s_reg[4];
+    int row_i[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int r = r0 + 4 * b + i;
+        const int r = __builtin_amdgcn_readlane(slot_row, 4 * b + i);
+        row_i[i] = r;
         e_reg[i] = s_reg[i] = 0.0f;
-        if (r < n) {
+        if (r >= 0) {
             e_reg[i] = ego[(size_t)r * 64 + lane];
             s_reg[i] = side[(size_t)r * 64 + lane];
         }
@@ -220,8 +251,8 @@ __global__ __launch_bounds__(kWave * 4 * kFwdTiles) void ngcf_layer_fwd4_kernel(
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int r = r0 + 4 * b + i;
-        if (write_ego && r < n) out[(size_t)r * ld_out + lane] = e_reg[i];      // `ego` passes through to the output's first half
+        const int r = row_i[i];
+        if (write_ego && r >= 0) out[(size_t)r * ld_out + lane] = e_reg[i];     // `ego` passes through to the output's first half
         t_side[(4 * b + i) * kFwdStride + lane] = s_reg[i];
         t_prod[(4 * b + i) * kFwdStride + lane] = e_reg[i] * s_reg[i];
     }
@@ -256,7 +287,7 @@ __global__ __launch_bounds__(kWave * 4 * kFwdTiles) void ngcf_layer_fwd4_kernel(
         x = x >= 0.0f ? x : x * slope;
         y = y >= 0.0f ? y : y * slope;
         float v = x + y;
-        if (drop.p > 0.0f) v = msg_keep(drop, r0 + 4 * h + q, 16 * b + i16) ? v * drop.scale : 0.0f;
+        if (drop.p > 0.0f) v = (row_q[q] >= 0 && msg_keep(drop, row_q[q], 16 * b + i16)) ? v * drop.scale : 0.0f;
         e1[q] = v;
         const float sq = row16_sum_f32(v * v);
         if (i16 == 0) s_sq[tl][b][4 * h + q] = sq;
@@ -264,8 +295,8 @@ __global__ __launch_bounds__(kWave * 4 * kFwdTiles) void ngcf_layer_fwd4_kernel(
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int rr = 4 * h + q, r = r0 + rr;
-        if (r < n) {
+        const int rr = 4 * h + q, r = row_q[q];
+        if (r >= 0) {
             const float sq = ((s_sq[tl][0][rr] + s_sq[tl][1][rr]) + s_sq[tl][2][rr]) + s_sq[tl][3][rr];
             const float den = fmaxf(sqrtf(sq), 1e-12f);
             out[(size_t)r * ld_out + 64 + 16 * b + i16] = e1[q] / den;
@@ -1392,9 +1423,34 @@ extern "C" int spex_ngcf_layer_fwd_f32(const float *ego, const float *side, cons
                            ego, side, W_gc, b_gc, W_bi, b_bi, out, ld_out, write_ego, e1_out, n, slope,
                            make_drop(p_drop, seed, step, layer, pad_row));
     else                    // four waves per tile, four tiles per workgroup
-        hipLaunchKernelGGL(ngcf_layer_fwd4_kernel, dim3((unsigned)((n_tiles + kFwdTiles - 1) / kFwdTiles)), dim3(kWave * 4 * kFwdTiles), 0,
+        hipLaunchKernelGGL(ngcf_layer_fwd4_kernel<false>, dim3((unsigned)((n_tiles + kFwdTiles - 1) / kFwdTiles)), dim3(kWave * 4 * kFwdTiles), 0,
                            (hipStream_t)stream, ego, side, W_gc, b_gc, W_bi, b_bi, out, ld_out, write_ego, e1_out, n, slope,
-                           make_drop(p_drop, seed, step, layer, pad_row));
+                           make_drop(p_drop, seed, step, layer, pad_row), RowList{});
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}
+
+extern "C" int spex_ngcf_layer_fwd_rows_f32(const float *ego, const float *side, const float *W_gc, const float *b_gc,
+                                            const float *W_bi, const float *b_bi, float *out, int32_t ld_out, int32_t write_ego,
+                                            int32_t n, int32_t d, float slope, float p_drop, uint64_t seed, uint32_t step,
+                                            uint32_t layer, int32_t pad_row, const int64_t *idx_a, int32_t n_a, int64_t off_a,
+                                            const int64_t *idx_b, int32_t n_b, int64_t off_b, void *stream)
+{
+    SPEX_CHECK_ARG(ego && side && W_gc && b_gc && W_bi && b_bi && out, "spex_ngcf_layer_fwd_rows_f32: NULL pointer");
+    SPEX_CHECK_ARG(n >= 0 && ld_out >= 2 * d, "spex_ngcf_layer_fwd_rows_f32: n=%d ld_out=%d", n, ld_out);
+    SPEX_CHECK_ARG(n_a >= 0 && n_b >= 0 && (n_a == 0 || idx_a) && (n_b == 0 || idx_b), "spex_ngcf_layer_fwd_rows_f32: row lists");
+    SPEX_CHECK_ARG(p_drop >= 0.0f && p_drop < 1.0f, "spex_ngcf_layer_fwd_rows_f32: p_drop=%f", (double)p_drop);
+    if (d != 64) {
+        spex::set_error("spex_ngcf_layer_fwd_rows_f32: only d == 64 is implemented (got %d)", d);
+        return SPEX_ERR_UNSUPPORTED;
+    }
+    SPEX_CHECK_ARG((((uintptr_t)W_gc | (uintptr_t)W_bi) & 15) == 0, "spex_ngcf_layer_fwd_rows_f32: weights must be 16-byte aligned");
+    const int n_slots = n_a + n_b;
+    if (n == 0 || n_slots == 0) return SPEX_OK;
+    const int n_tiles = (n_slots + 15) / 16;
+    hipLaunchKernelGGL(ngcf_layer_fwd4_kernel<true>, dim3((unsigned)((n_tiles + kFwdTiles - 1) / kFwdTiles)), dim3(kWave * 4 * kFwdTiles), 0,
+                       (hipStream_t)stream, ego, side, W_gc, b_gc, W_bi, b_bi, out, ld_out, write_ego, nullptr, n, slope,
+                       make_drop(p_drop, seed, step, layer, pad_row), RowList{idx_a, idx_b, n_a, n_b, off_a, off_b});
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }

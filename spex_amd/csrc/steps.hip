@@ -168,10 +168,21 @@ extern "C" int spex_ngcf_step_bce_f32(spex_ngcf_step_t *s, const int64_t *users,
     const float *W_gc = s->W, *b_gc = s->W + d * d, *W_bi = s->W + d * d + d, *b_bi = s->W + 2 * d * d + d;
     const int32_t per = 2 * (d * d + d);
     const uint32_t step = (uint32_t)s->dropout_step;
-    // ---- forward: side = A ego; the fused layer writes [ego | normalised layer output] into the concatenated table
-    SPEX_TRY(spex_spmm_f32(g, s->E0, s->side, nullptr, 1.0f, nullptr, nullptr, 1.0f, d, stream));
-    SPEX_TRY(spex_ngcf_layer_fwd_f32(s->E0, s->side, W_gc, b_gc, W_bi, b_bi, s->all_emb, 2 * d, 1, nullptr, n, d, s->slope, s->p_drop,
-                                     s->seed, step, 0, s->pad_row, stream));
+    // ---- forward, at the batch's rows ONLY: the descriptor is a one-layer model, whose loss reads the concatenated table nowhere
+    //      else (main_rec.py:96-104) — side = A ego for the 2B rows (spex_spmm_rowlist_f32: the main kernel's sums, bit for bit, for
+    //      rows of <= 1 024 entries) and the layer on 16-slot tiles of those rows, which writes [ego | normalised layer output] into
+    //      the dense tables at the rows the scoring reads.  (11.4 + 10.6 us of whole-table launches on Epinion2 became 6 + 4;
+    //      SPEX_NGCF_DENSE_FORWARD=1 keeps the whole-table forward for A/B timing.)
+    static const bool dense_forward = []() { const char *e = getenv("SPEX_NGCF_DENSE_FORWARD"); return e && e[0] == '1'; }();
+    if (dense_forward) {
+        SPEX_TRY(spex_spmm_f32(g, s->E0, s->side, nullptr, 1.0f, nullptr, nullptr, 1.0f, d, stream));
+        SPEX_TRY(spex_ngcf_layer_fwd_f32(s->E0, s->side, W_gc, b_gc, W_bi, b_bi, s->all_emb, 2 * d, 1, nullptr, n, d, s->slope, s->p_drop,
+                                         s->seed, step, 0, s->pad_row, stream));
+    } else {
+        SPEX_TRY(spex_spmm_rowlist_f32(g, s->E0, users, B, 0, items, B, n_u, s->side, nullptr, nullptr, 1.0f, d, stream));
+        SPEX_TRY(spex_ngcf_layer_fwd_rows_f32(s->E0, s->side, W_gc, b_gc, W_bi, b_bi, s->all_emb, 2 * d, 1, n, d, s->slope, s->p_drop,
+                                              s->seed, step, 0, s->pad_row, users, B, 0, items, B, n_u, stream));
+    }
     // ---- scoring + backward on the batch's 2B slots in one launch (per-sample losses go to the head of g_slots: the table's Adam
     //      pass below adds them to loss_sum in a fixed order), then the push-form A^T product into the (all-zero) table gradient
     float *loss_rows = s->g_slots;

@@ -647,7 +647,7 @@ __device__ __forceinline__ void logits_ce(const TrustArgs &p, const TrainArgs &t
             if (k + 1 < n_full) load_full((k + 1) * kRows * kFly, rn);
             consume(k * kRows * kFly, r, std::false_type{});
 #pragma unroll
-            for (int j = 0; j < kFly; ++j) r[j] = rn[j];
+            for (int j = 0; j < kFly; ++j) r[j] = rn[j];      // (a manual ping-pong of the two buffers spills and is slower: 13.3 vs 11.3 us)
         }
         const int u0 = n_full * kRows * kFly;
         if (u0 < n_users) {

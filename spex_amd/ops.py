@@ -205,6 +205,22 @@ def ngcf_layer_fwd(ego, side, W_gc, b_gc, W_bi, b_bi, out, layer, write_ego, e1_
     _bump(out, e1_out)
 
 
+def ngcf_layer_fwd_rows(ego, side, W_gc, b_gc, W_bi, b_bi, out, idx_a, idx_b, off_b, write_ego=True, slope=0.01, drop=None, pad_row=-1):
+    """The first NGCF layer at a list of rows only (spex_ngcf_layer_fwd_rows_f32): rows idx_a[k] and idx_b[k] + off_b of the dense
+    tables `ego` / `side` -> the same rows of `out` ([n, >= 128]: [ego | normalised layer output]); other rows are left untouched."""
+    for x, nm in ((ego, "ego"), (side, "side"), (W_gc, "W_gc"), (b_gc, "b_gc"), (W_bi, "W_bi"), (b_bi, "b_bi"), (out, "out")):
+        _need(x, nm)
+    n, d = ego.shape
+    for t in (idx_a, idx_b):
+        if not (t.is_cuda and t.dtype == torch.int64 and t.is_contiguous()):
+            raise ValueError("ngcf_layer_fwd_rows: the row lists must be contiguous int64 tensors on the GPU")
+    p, seed, step = drop if drop is not None else (0.0, 0, 0)
+    _launch(ego.device, "spex_ngcf_layer_fwd_rows_f32", _ptr(ego), _ptr(side), _ptr(W_gc), _ptr(b_gc), _ptr(W_bi), _ptr(b_bi), _ptr(out),
+            out.stride(0), 1 if write_ego else 0, n, d, float(slope), float(p), int(seed), int(step), 0, int(pad_row), _ptr(idx_a),
+            idx_a.numel(), 0, _ptr(idx_b), idx_b.numel(), int(off_b))
+    _bump(out)
+
+
 def ngcf_spmm_layer_fwd(graph, ego, W_gc, b_gc, W_bi, b_bi, out, side_out, slope=0.01, drop=None, pad_row=-1):
     """side = A ego and the first NGCF layer in ONE launch (spex_ngcf_spmm_layer_fwd_f32; `graph` built with tile_rows=True):
     out [n, >= 128] receives [ego | normalised layer output], side_out [n, 64] the product (the backward recomputes from it)."""

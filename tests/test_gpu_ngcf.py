@@ -483,6 +483,46 @@ def test_fused_spmm_and_layer_equals_the_two_launches(epinion2):
     assert torch.equal(g_tile.spmm(ego), side_a)
 
 
+def test_row_sparse_forward_equals_the_whole_table_forward_at_the_batch_rows(epinion2):
+    """What the one-call NGCF step runs since round 3: side = A ego at the batch's rows (spex_spmm_rowlist_f32) and the layer at
+    those rows (spex_ngcf_layer_fwd_rows_f32, mask indexed by the ROW) against the whole-table launches — bit-identical rows of
+    `side` and of the concatenated table (hub rows, repeated users, the isolated pad row, an out-of-range index in the batch),
+    every other row of the output untouched."""
+    from spex_amd import ops
+    from spex_amd.graph import SpexGraph, ngcf_norm_adj
+    tr = epinion2["train"]
+    rowptr, col, val = ngcf_norm_adj(tr[:, 0], tr[:, 1], 3185, 12407)
+    n, n_u = len(rowptr) - 1, 3186
+    g = SpexGraph(rowptr, col, val)
+    rng = np.random.default_rng(4)
+    ego = torch.from_numpy((rng.normal(size=(n, 64)) * 0.1).astype(np.float32)).to(DEV)
+    W_gc, W_bi = (torch.from_numpy(rng.normal(size=(64, 64)).astype(np.float32) * 0.2).to(DEV) for _ in range(2))
+    b_gc, b_bi = (torch.from_numpy(rng.normal(size=64).astype(np.float32) * 0.1).to(DEV) for _ in range(2))
+    drop = (0.1, 12345, 7)
+    side_a = g.spmm(ego)
+    out_a = torch.zeros(n, 128, device=DEV)
+    ops.ngcf_layer_fwd(ego, side_a, W_gc, b_gc, W_bi, b_bi, out_a, 0, True, drop=drop, pad_row=3185)
+    B = 250                                                       # not a multiple of 16: the last tile is partly empty
+    deg = np.diff(rowptr)
+    users, items = rng.integers(0, 3185, B), rng.integers(0, 12407, B)
+    users[:3] = np.argsort(-deg[:3185])[:3]
+    items[:3] = np.argsort(-deg[n_u:])[:3]
+    users[5:9] = users[0]
+    users[9] = 3185                                               # the pad row (isolated: side = 0)
+    items[10] = 12407                                             # out of range: skipped
+    u_d, i_d = torch.from_numpy(users).to(DEV), torch.from_numpy(items).to(DEV)
+    side_b, out_b = torch.full((n, 64), 7.0, device=DEV), torch.full((n, 128), 7.0, device=DEV)
+    g.spmm_rows(ego, u_d, i_d, 0, n_u, Y=side_b)
+    ops.ngcf_layer_fwd_rows(ego, side_b, W_gc, b_gc, W_bi, b_bi, out_b, u_d, i_d, n_u, drop=drop, pad_row=3185)
+    rows = np.unique(np.r_[users, items[items < 12407] + n_u])
+    rows_d = torch.from_numpy(rows).to(DEV)
+    assert torch.equal(side_b[rows_d], side_a[rows_d])
+    assert torch.equal(out_b[rows_d], out_a[rows_d])
+    rest = torch.ones(n, dtype=torch.bool, device=DEV)
+    rest[rows_d] = False
+    assert (out_b[rest] == 7.0).all() and (side_b[rest] == 7.0).all()
+
+
 def test_fused_scoring_and_rows_backward_equals_the_two_launches():
     """spex_ngcf_score_bwd_rows_f32 against spex_score_bce_slots_f32 + spex_ngcf_layer_bwd_rows_f32 on the same inputs: B = 200
     (the last tile is partial and one tile straddles the user / item boundary of the slots), repeated users, message dropout
