@@ -14,6 +14,8 @@ every rank scores the (small, replicated) batch against the gathered output tabl
 owns, so the only exchange step on the data path is the per-layer all-gather.
 """
 import numpy as np
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -109,7 +111,8 @@ class PeerAllGather:
                 for q in range(world):
                     self.peer.append(self.bufs if q == rank else [fn(*args) for fn, args in everyone[q]])
                 self.streams = [torch.cuda.Stream(device=device) for _ in range(world)]
-                self.token = torch.zeros(1, dtype=torch.float32, device=device)
+                self.token = torch.zeros(2, dtype=torch.float32, device=device)
+                self.token_step = torch.tensor([1.0, -1.0], dtype=torch.float32, device=device)
             except Exception as e:                           # noqa: BLE001
                 err = e
         elif err is None:
@@ -120,6 +123,12 @@ class PeerAllGather:
             self.peer = []
             raise RuntimeError("PeerAllGather: IPC set-up failed on at least one rank" + (f" (here: {err!r})" if err is not None else ""))
         self.calls = 0
+        # SPEX_PEER_CHECK=1 (tests): the barrier's token carries every rank's call counter as (count, -count) under a MAX
+        # all-reduce, and the host checks after each call that the largest and the smallest counter at the barrier are this
+        # rank's own — i.e. that no rank was a call ahead of another when it wrote (the two-buffer argument above).  It costs a
+        # host synchronisation per call, so it is off otherwise (the token is still reduced: that IS the barrier).
+        self.check = os.environ.get("SPEX_PEER_CHECK", "0") == "1"
+        self.checked = 0
 
     def all_gather(self, send, n_rows=None):
         """send: this rank's padded shard [max_rows, d]; n_rows: its real rows (default: all).  Only the real rows cross
@@ -140,7 +149,13 @@ class PeerAllGather:
             with torch.cuda.stream(st):
                 self.peer[q][k][lo: lo + n_rows].copy_(send[:n_rows], non_blocking=True)
             cur.wait_stream(st)
-        dist.all_reduce(self.token, group=self.group)    # the barrier described above (stream-ordered after the copies)
+        self.token.add_(self.token_step)                 # (count, -count): equal on every rank after the previous barrier's MAX
+        dist.all_reduce(self.token, op=dist.ReduceOp.MAX, group=self.group)    # the barrier described above (stream-ordered after the copies)
+        if self.check:
+            hi, neg_lo = self.token.tolist()
+            if hi != float(self.calls) or -neg_lo != float(self.calls):
+                raise RuntimeError(f"PeerAllGather: ranks met at the barrier of call {self.calls} with counters {int(-neg_lo)}..{int(hi)}")
+            self.checked += 1
         return self.bufs[k]
 
 

@@ -407,7 +407,7 @@ def test_bench_single_gpu_line_is_well_formed():
 def _peer_worker(rank, world, port, out_dir):
     import sys
     sys.path.insert(0, REPO)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", SPEX_PEER_CHECK="1")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from spex_amd.datasets import epinion2_tables, load_epinion2
     from spex_amd.dist import PartitionedLightGCN
@@ -430,7 +430,7 @@ def _peer_worker(rank, world, port, out_dir):
     same = all(torch.equal(a, ref_lo) and torch.equal(b, ref_g) for a, b in outs)
     P.set_allgather("collective")
     same = same and torch.equal(P.propagate(E0_local), ref_lo)
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), same=same, calls=P.peer.calls)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), same=same, calls=P.peer.calls, checked=P.peer.checked)
     dist.barrier()
     del P
     dist.destroy_process_group()
@@ -439,13 +439,15 @@ def _peer_worker(rank, world, port, out_dir):
 def test_peer_write_allgather_matches_the_collective(tmp_path):
     """The direct peer-write all-gather (IPC-mapped peer buffers, one copy per peer, a one-element all-reduce as the
     barrier, two alternating buffers) against torch.distributed's all-gather: identical propagated tables and gradients,
-    forward and backward, over repeated calls.  Two ranks share the test box's one GPU, so this exercises the handle
+    forward and backward, over repeated calls; the barrier's token carries the ranks' call counters and every call checks that
+    they met in the same call (a rank can never write two calls ahead of a peer's reads).  Two ranks share the test box's one GPU, so this exercises the handle
     exchange, the slot arithmetic and the ordering — not the xGMI links."""
     world = 2
     mp.spawn(_peer_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         d = np.load(tmp_path / f"rank{r}.npz")
         assert bool(d["same"]) and int(d["calls"]) == 5 * 6
+        assert int(d["checked"]) == 5 * 6          # every barrier saw every rank in the SAME call (SPEX_PEER_CHECK: no rank a call ahead)
 
 
 # ---------------------------------------------------------------------------------------------- collectives behind the C ABI

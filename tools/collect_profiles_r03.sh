@@ -18,4 +18,14 @@ for pass in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_su
 done
 echo "== push balance" | tee -a $OUT/log.txt
 timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/push -o push -- python3 $R/tools/push_balance_probe.py $OUT/push_features.csv >> $OUT/log.txt 2>&1 || echo "push probe failed" >> $OUT/log.txt
+echo "== dual-task step forms, trust head forms, trust kernel phase stamps" | tee -a $OUT/log.txt
+cd $R
+(timeout -k 10 200 python3 tools/dual_ab.py && SPEX_DUAL_PIPELINED=1 timeout -k 10 200 python3 tools/dual_ab.py && SPEX_DUAL_ONE_STREAM=1 timeout -k 10 200 python3 tools/dual_ab.py \
+  && SPEX_DUAL_FUSED_MIDDLE=0 timeout -k 10 200 python3 tools/dual_ab.py) 2>&1 | grep "dual-task step" > $OUT/dual_step_forms.txt || echo "dual_ab failed" >> $OUT/log.txt
+timeout -k 10 600 python3 tools/trust_forms_time.py > $OUT/trust_forms.txt 2>> $OUT/log.txt || echo "trust forms failed" >> $OUT/log.txt
+if [ -f spex_amd/lib/libspexhip_stamps.so ]; then
+  timeout -k 10 200 python3 tools/trust_stamps.py 2>> $OUT/log.txt | grep -v amdgpu.ids > $OUT/trust_stamps.txt || echo "trust stamps failed" >> $OUT/log.txt
+fi
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dual_step -o dual -- python3 $R/tools/dual_ab.py --steps 300 --reps 2 >> $OUT/log.txt 2>&1 || echo "dual step trace failed" >> $OUT/log.txt
 echo done | tee -a $OUT/log.txt

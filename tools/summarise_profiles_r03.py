@@ -21,7 +21,9 @@ for f in glob.glob(os.path.join(src, "bench", "**", "*kernel_trace.csv"), recurs
     out = subprocess.run([sys.executable, os.path.join(here, "trace_by_grid.py"), f, "spmm", "bpr_", "score_bce", "adam_kernel", "ngcf_layer",
                           "lightgcn_batch", "trust_", "dual_task", "reduce_slots"], capture_output=True, text=True).stdout
     open(os.path.join(dst, "kernel_trace_by_grid.csv"), "w").write(out)
-for f in ("bench_under_rocprof.json", "dual_task_time.txt"):
+for f in glob.glob(os.path.join(src, "dual_step", "**", "*kernel_stats.csv"), recursive=True):      # the one-call dual-task step alone
+    shutil.copy(f, os.path.join(dst, "dual_step_kernel_stats.csv"))
+for f in ("bench_under_rocprof.json", "dual_task_time.txt", "dual_step_forms.txt", "trust_forms.txt", "trust_stamps.txt"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
 if os.path.isdir(os.path.join(src, "pmc_epinion2")):
