@@ -196,7 +196,8 @@ struct DualAdamArgs {
     int n_att_copies;    //   summed into the gate parameters' gradient and cleared here; n_att_copies == 0: nothing to sum, but the
     int att_clear;       //   first att_clear floats are cleared (the other paths use the area for per-sample rows)
     float prop_div;      // > 0: g_E0 is the PLAIN last backward product and its g_prop / prop_div share is added here (g_prop is read
-                         // before this pass clears it); 0: g_E0 already holds it
+                         // before this pass clears it); 0: g_E0 already holds it; < 0: both backward products ran plain (L == 3) and
+                         // the push target (push_zero) is added instead
     int part;            // 0: the whole arena; the pipelined step splits the pass in two launches on two streams — 1: the item rows and
                          // the gate matrices (gradients of the rec branch alone), 2: the user rows, the trust block, the task weights
     int role;            // number of leading blocks that only sum the gate-gradient copies (0 or 2)
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(256) void dual_task_adam_kernel(const DualAdamArgs 
     }
     // ---- main loop over the part's compact index space k -> arena index i:
     //      part 0 (the whole arena):               i = k                                   [+ the gate parameters unless a role has them]
-    //      part 1 (what the rec branch alone owns): item rows, then the gate parameters     [ditto]; clears the whole push target
+    //      part 1 (what the rec branch alone owns): item rows, then the gate parameters     [ditto]
     //      part 2 (what needs both branches):       user rows, then the trust block; the task weights and the loss cells
     const int64_t gate_k = a.role ? 0 : 512;
     const int64_t n_item = a.n_table - a.n_user;
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(256) void dual_task_adam_kernel(const DualAdamArgs 
         if (i < a.n_table) {
             float ge = a.g_E0[i];
             if (a.prop_div > 0.0f) ge = ge + a.g_prop[i] / a.prop_div;
+            else if (a.prop_div < 0.0f) ge = ge + a.push_zero[i];         // (read before this thread clears it below)
             g = p1 * (ge + a.g_raw[i]);
             if (i < a.n_user) {
                 g = fmaf(p2, a.g_user[i], g);
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(256) void dual_task_adam_kernel(const DualAdamArgs 
             }
             a.g_raw_w[i] = 0.0f;
             a.g_prop[i] = 0.0f;
-            if (a.push_zero && a.part == 0) a.push_zero[i] = 0.0f;
+            if (a.push_zero) a.push_zero[i] = 0.0f;                        // (every part clears its own rows of the push target)
         } else {
             const int64_t j = i - a.n_table;
             g = (j < a.n_trust ? p2 : p1) * a.g_small[j];
@@ -267,8 +269,6 @@ __global__ __launch_bounds__(256) void dual_task_adam_kernel(const DualAdamArgs 
         adam1(P, g, M, V, a.w1, a.beta2, a.w2, a.bc2_sqrt, a.eps, a.step_size);
         a.p[i] = P; a.m[i] = M; a.v[i] = V;
     }
-    if (a.part == 1 && a.push_zero)                                           // (the rec branch's next step is its only user)
-        for (int64_t k = tid; k < a.n_table; k += stride) a.push_zero[k] = 0.0f;
     if (a.part != 2 && a.n_att_copies == 0)
         for (int64_t k = tid; k < a.att_clear; k += stride) a.att_copies[k] = 0.0f;
     if (a.part != 1 && (int)blockIdx.x == a.role && threadIdx.x == 0) {

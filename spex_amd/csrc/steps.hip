@@ -72,16 +72,21 @@ extern "C" int spex_lightgcn_step_bce_f32(spex_lightgcn_step_t *s, const int64_t
                                              1.0f / (float)(L + 1), nullptr, s->grad_slots /* per-sample losses, summed by the Adam pass */,
                                              s->g_out, G, d, stream));
         // ---- L-1 pull-form products G_l = g / (L+1) + A^T G_{l+1}.  The last one (l = 0) runs in the PLAIN form: its g / (L+1) term
-        //      is added by the Adam pass, which reads g_out anyway to clear it (one epilogue stream less on a 15 us launch)
+        //      is added by the Adam pass, which reads g_out anyway to clear it (one epilogue stream less on a 15 us launch).
+        //      L == 3 (the reference's depth): BOTH run plain.  With P = G_2 = (g + A^T g) / 4 the gradient is
+        //      A^T (A^T P + g/4) + g/4 = A^T (A^T P) + (A^T g / 4 + g / 4) = A^T (A^T P) + P — and P is the push target, which the
+        //      Adam pass touches anyway (to clear it): it adds P instead of g / 4.  No epilogue operand left in the backward.
+        const bool all_plain = L == 3;
         const float *c2 = G;
         for (int32_t l = L - 2; l >= 0; --l) {
             float *nxt = l == 0 ? s->grad_E0 : s->ws_bwd + (size_t)(1 + ((L - 2 - l) & 1)) * sz;   // ws_bwd[1], [2], [1] ...: never the source, never G
-            if (l == 0) SPEX_TRY(spex_spmm_f32(gt, c2, nxt, nullptr, 1.0f, nullptr, nullptr, 1.0f, d, stream));
+            if (l == 0 || all_plain) SPEX_TRY(spex_spmm_f32(gt, c2, nxt, nullptr, 1.0f, nullptr, nullptr, 1.0f, d, stream));
             else SPEX_TRY(spex_spmm_f32(gt, c2, nxt, s->g_out, (float)(L + 1), nullptr, nullptr, 1.0f, d, stream));
             c2 = nxt;
         }
         SPEX_TRY(spex::adam_step_z2(s->E0, s->grad_E0, s->m, s->v, (int64_t)sz, s->t + 1, s->lr, s->beta1, s->beta2, s->eps, s->g_out,
-                                    s->ws_bwd, stream, s->grad_slots, B, loss_sum, nullptr, s->g_out, (float)(L + 1)));
+                                    s->ws_bwd, stream, s->grad_slots, B, loss_sum, nullptr, all_plain ? G : s->g_out,
+                                    all_plain ? 1.0f : (float)(L + 1)));
         s->t += 1;
         return SPEX_OK;
     } else {    // L == 1: the last layer at the batch's rows, scoring, then grad = (g + A^T g) / 2 as one pull-form product
@@ -348,7 +353,8 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
             const float *c2 = G;
             for (int32_t l = L - 2; l >= 0; --l) {
                 float *nxt = l == 0 ? s->g_E0 : s->ws_bwd + (size_t)(1 + ((L - 2 - l) & 1)) * sz;
-                if (l == 0) SPEX_TRY(spex_spmm_f32(gt, c2, nxt, nullptr, 1.0f, nullptr, nullptr, 1.0f, d, stream));
+                // (L == 3: both products plain, the Adam pass adds the push target P instead of g_prop / 4 — see the LightGCN step)
+                if (l == 0 || L == 3) SPEX_TRY(spex_spmm_f32(gt, c2, nxt, nullptr, 1.0f, nullptr, nullptr, 1.0f, d, stream));
                 else SPEX_TRY(spex_spmm_f32(gt, c2, nxt, s->g_prop, (float)(L + 1), nullptr, nullptr, 1.0f, d, stream));
                 c2 = nxt;
             }
@@ -387,7 +393,8 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
             const float *c2 = G;
             for (int32_t l = L - 2; l >= 0; --l) {
                 float *nxt = l == 0 ? s->g_E0 : s->ws_bwd + (size_t)(1 + ((L - 2 - l) & 1)) * sz;
-                if (l == 0) SPEX_TRY(spex_spmm_f32(gt, c2, nxt, nullptr, 1.0f, nullptr, nullptr, 1.0f, d, stream));
+                // (L == 3: both products plain, the Adam pass adds the push target P instead of g_prop / 4 — see the LightGCN step)
+                if (l == 0 || L == 3) SPEX_TRY(spex_spmm_f32(gt, c2, nxt, nullptr, 1.0f, nullptr, nullptr, 1.0f, d, stream));
                 else SPEX_TRY(spex_spmm_f32(gt, c2, nxt, s->g_prop, (float)(L + 1), nullptr, nullptr, 1.0f, d, stream));
                 c2 = nxt;
             }
@@ -400,6 +407,9 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
     int rc = rec_branch();
     if (forked && hipStreamWaitEvent((hipStream_t)stream, join_ev, 0) != hipSuccess && rc == SPEX_OK) rc = SPEX_ERR_HIP;   // joined on every path
     if (rc == SPEX_OK) rc = rc_trust;
+    // what the Adam pass adds to the last (plain) backward product: g_prop / (L+1), or — L == 3, both products plain — the push
+    // target itself (prop_div < 0)
+    const float prop_div = !plain_last ? 0.0f : (L == 3 ? -1.0f : (float)(L + 1));
     if (pipelined) {
         // the rec branch's gradients -> side_stream; Adam part 2 (user rows, trust block, task weights, loss cells) there, part 1
         // (item rows, gate matrices) here.  The join event is recorded on every path so that a later join never waits in vain.
@@ -409,7 +419,7 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
             rc = spex::dual_task_adam(s->params, s->m, s->v, s->g_E0, s->g_raw, s->g_user, s->g_small, s->g_prop, L >= 2 ? s->ws_bwd : nullptr,
                                       s->loss, s->loss_acc, s->precision, (int64_t)sz, (int64_t)off_u, n_trust, B, T, s->n_rec, s->t + 1, s->lr,
                                       s->beta1, s->beta2, s->eps, (s->flags & SPEX_STEP_FIXED_TASK_WEIGHTS) != 0,
-                                      part == 2 ? s->side_stream : stream, plain_last ? (float)(L + 1) : 0.0f, s->grad_slots, att_copies_used,
+                                      part == 2 ? s->side_stream : stream, prop_div, s->grad_slots, att_copies_used,
                                       att_copies_max * 512, part);
         if (hipEventRecord(join_ev, (hipStream_t)s->side_stream) != hipSuccess && rc == SPEX_OK) rc = SPEX_ERR_HIP;
         if (rc != SPEX_OK) {
@@ -426,7 +436,7 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
     SPEX_TRY(spex::dual_task_adam(s->params, s->m, s->v, s->g_E0, s->g_raw, s->g_user, s->g_small, s->g_prop, L >= 2 ? s->ws_bwd : nullptr,
                                   s->loss, s->loss_acc, s->precision, (int64_t)sz, (int64_t)off_u, n_trust, B, T, s->n_rec, s->t + 1, s->lr,
                                   s->beta1, s->beta2, s->eps, (s->flags & SPEX_STEP_FIXED_TASK_WEIGHTS) != 0, stream,
-                                  plain_last ? (float)(L + 1) : 0.0f, s->grad_slots, att_copies_used, att_copies_max * 512));
+                                  prop_div, s->grad_slots, att_copies_used, att_copies_max * 512));
     s->t += 1;
     return SPEX_OK;
 }
