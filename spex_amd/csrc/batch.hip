@@ -202,7 +202,8 @@ __global__ __launch_bounds__(kWave *kWgWaves) void lightgcn_batch_kernel(
         if (!PUSH) {
             grad_slots[(size_t)(wave * B + b) * kWave + lane] = g2[wave];     // per-sample rows; summed per table row in slot order later
         } else {
-            atomicAdd(g_out + (size_t)row[wave] * kWave + lane, g2[wave]);        // dense d loss / d light_out (rows may repeat in a batch)
+            if (g_out) atomicAdd(g_out + (size_t)row[wave] * kWave + lane, g2[wave]);   // dense d loss / d light_out (rows may repeat in a
+                                                                                         // batch); NULL: nobody reads it (L == 3 step)
             atomicAdd(G + (size_t)row[wave] * kWave + lane, push_scale * g2[wave]);   // the `g` of (g + A^T g) / (L + 1)
         }
     }
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void gated_batch_push_kernel(
         s_dprop[wave][lane] = d_prop;
         if (part == 0) {
             const size_t o = (size_t)row[wave] * kWave + lane;
-            atomicAdd(g_prop + o, d_prop);
+            if (g_prop) atomicAdd(g_prop + o, d_prop);                    // (NULL: nobody reads it — the L == 3 step)
             atomicAdd(G + o, push_scale * d_prop);
             atomicAdd(g_raw + o, d_raw);
             // (every sample adds to the same 512 words: 256 x 64 lane-atomics per cache line serialise in L2 — 13 us of a 25 us
@@ -530,6 +531,7 @@ extern "C" int spex_gated_batch_f32(const spex_graph_t *g, const float *X, const
                                    float *loss_sum, float *g_prop, float *G, float *g_raw, float *g_att, int32_t n_att_copies,
                                    int32_t d, void *stream)
 {
+    SPEX_CHECK_ARG(g_prop, "spex_gated_batch_f32: NULL g_prop");
     return spex::gated_batch_push_layers(g, X, acc_in, nullptr, nullptr, acc_div, raw, att_u, att_i, users, items, labels, B, n_user_rows,
                                          grad_scale, push_scale, loss_sum, g_prop, G, g_raw, g_att, n_att_copies, d, stream);
 }
@@ -547,7 +549,7 @@ int spex::gated_batch_push_layers(const spex_graph_t *g, const float *X, const f
                                   float push_scale, float *loss_sum, float *g_prop, float *G, float *g_raw, float *g_att,
                                   int32_t n_att_copies, int32_t d, void *stream)
 {
-    SPEX_CHECK_ARG(g && X && acc_in && raw && att_u && att_i && users && items && labels && loss_sum && g_prop && G && g_raw && g_att,
+    SPEX_CHECK_ARG(g && X && acc_in && raw && att_u && att_i && users && items && labels && loss_sum && G && g_raw && g_att,
                    "spex_gated_batch_f32: NULL argument");
     SPEX_CHECK_ARG(n_att_copies >= 1, "spex_gated_batch_f32: n_att_copies=%d", n_att_copies);
     SPEX_CHECK_ARG(B >= 0 && n_user_rows >= 0 && n_user_rows <= g->n_rows && g->n_rows == g->n_cols,
@@ -613,6 +615,7 @@ extern "C" int spex_lightgcn_batch_f32(const spex_graph_t *g, const float *X, co
                                        int32_t n_user_rows, float grad_scale, float push_scale, float *loss_sum, float *loss_per_sample,
                                        float *g_out, float *G, int32_t d, void *stream)
 {
+    SPEX_CHECK_ARG(g_out, "spex_lightgcn_batch_f32: NULL g_out");
     return spex::lightgcn_batch_layers(g, X, acc_in, nullptr, nullptr, acc_div, users, items, labels, B, n_user_rows, grad_scale, push_scale,
                                        loss_sum, loss_per_sample, g_out, G, d, stream);
 }
@@ -622,7 +625,7 @@ int spex::lightgcn_batch_layers(const spex_graph_t *g, const float *X, const flo
                                 int32_t n_user_rows, float grad_scale, float push_scale, float *loss_sum, float *loss_per_sample, float *g_out,
                                 float *G, int32_t d, void *stream)
 {
-    SPEX_CHECK_ARG(g && X && acc_in && users && items && labels && (loss_sum || loss_per_sample) && g_out && G,
+    SPEX_CHECK_ARG(g && X && acc_in && users && items && labels && (loss_sum || loss_per_sample) && G,
                    "spex_lightgcn_batch_f32: NULL argument");
     SPEX_CHECK_ARG(B >= 0 && n_user_rows >= 0 && n_user_rows <= g->n_rows, "spex_lightgcn_batch_f32: B=%d n_user_rows=%d", B, n_user_rows);
     SPEX_CHECK_ARG(g->n_rows == g->n_cols, "spex_lightgcn_batch_f32: square graph");

@@ -198,6 +198,7 @@ struct DualAdamArgs {
     float prop_div;      // > 0: g_E0 is the PLAIN last backward product and its g_prop / prop_div share is added here (g_prop is read
                          // before this pass clears it); 0: g_E0 already holds it; < 0: both backward products ran plain (L == 3) and
                          // the push target (push_zero) is added instead
+    int clear_prop;      // 0: g_prop was not written this step (the fused middle of the L == 3 step forms no dense d loss / d light)
     int part;            // 0: the whole arena; the pipelined step splits the pass in two launches on two streams — 1: the item rows and
                          // the gate matrices (gradients of the rec branch alone), 2: the user rows, the trust block, the task weights
     int role;            // number of leading blocks that only sum the gate-gradient copies (0 or 2)
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(256) void dual_task_adam_kernel(const DualAdamArgs 
                 a.g_user[i] = 0.0f;
             }
             a.g_raw_w[i] = 0.0f;
-            a.g_prop[i] = 0.0f;
+            if (a.clear_prop) a.g_prop[i] = 0.0f;
             if (a.push_zero) a.push_zero[i] = 0.0f;                        // (every part clears its own rows of the push target)
         } else {
             const int64_t j = i - a.n_table;
@@ -293,14 +294,15 @@ int spex::dual_task_adam(float *p, float *m, float *v, const float *g_E0, float 
                          float *g_prop, float *push_zero, float *loss, float *loss_acc, float *prec, int64_t n_table, int64_t n_user,
                          int64_t n_trust,
                          int32_t B, int32_t T, int32_t n_rec, int32_t t, float lr, float beta1, float beta2, float eps, int fixed_weights,
-                         void *stream, float prop_div, float *att_copies, int32_t n_att_copies, int32_t att_clear, int32_t part)
+                         void *stream, float prop_div, float *att_copies, int32_t n_att_copies, int32_t att_clear, int32_t part,
+                         int32_t clear_prop)
 {
     const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
     if (!att_copies) n_att_copies = 0, att_clear = 0;
     const int role = n_att_copies > 0 && part != 2 ? 2 : 0;
     const DualAdamArgs a{p, m, v, g_E0, g_raw, g_raw, g_user, g_small, g_prop, push_zero, loss, loss_acc, prec, n_table, n_user, n_trust,
                          n_table + n_trust + 512 + 2, B, T, n_rec, t & 1, fixed_weights, 1.0f - beta1, beta2, 1.0f - beta2, (float)sqrt(bc2), eps,
-                         (float)((double)lr / bc1), att_copies, n_att_copies, att_clear, prop_div, part, role};
+                         (float)((double)lr / bc1), att_copies, n_att_copies, att_clear, prop_div, clear_prop, part, role};
     const int64_t n_k = part == 0 ? n_table + n_trust + 512 : (part == 1 ? n_table - n_user + 512 : n_user + n_trust);
     int64_t blocks = (n_k + 255) / 256;
     if (blocks > 2048) blocks = 2048;

@@ -27,7 +27,7 @@ int dual_task_adam(float *p, float *m, float *v, const float *g_E0, float *g_raw
                    float *push_zero, float *loss, float *loss_acc, float *prec, int64_t n_table, int64_t n_user, int64_t n_trust,
                    int32_t B, int32_t T, int32_t n_rec, int32_t t, float lr, float beta1, float beta2, float eps, int fixed_weights,
                    void *stream, float prop_div = 0.0f, float *att_copies = nullptr, int32_t n_att_copies = 0,
-                   int32_t att_clear = 0, int32_t part = 0);                 // optim.hip: Adam over the dual-task parameter arena (spex_dual_task_step_f32)
+                   int32_t att_clear = 0, int32_t part = 0, int32_t clear_prop = 1);                 // optim.hip: Adam over the dual-task parameter arena (spex_dual_task_step_f32)
 
 // batch.hip: the batch kernels with the layer sum formed at the batch's rows from up to three tables (acc_in + acc2 + acc3, in that
 // order; NULL = absent) — what lets the one-call steps run their forward layers in the plain form

@@ -68,15 +68,15 @@ extern "C" int spex_lightgcn_step_bce_f32(spex_lightgcn_step_t *s, const int64_t
         //      first backward product G_{L-1} = (g + A^T g) / (L+1) in push form — over the rows of A itself: (A^T g)[c] = sum_r
         //      A[r, c] g[r] — (g_out and G are all-zero here: the Adam pass below clears them for the next step; first call: the caller)
         float *G = s->ws_bwd;
+        const bool all_plain = L == 3;              // (see below: nothing reads the dense d loss / d light_out then — it is not formed)
         SPEX_TRY(spex::lightgcn_batch_layers(g, cur, sum0, sum1, sum2, (float)(L + 1), users, items, labels, B, n_u, 1.0f / (float)B,
                                              1.0f / (float)(L + 1), nullptr, s->grad_slots /* per-sample losses, summed by the Adam pass */,
-                                             s->g_out, G, d, stream));
+                                             all_plain ? nullptr : s->g_out, G, d, stream));
         // ---- L-1 pull-form products G_l = g / (L+1) + A^T G_{l+1}.  The last one (l = 0) runs in the PLAIN form: its g / (L+1) term
         //      is added by the Adam pass, which reads g_out anyway to clear it (one epilogue stream less on a 15 us launch).
         //      L == 3 (the reference's depth): BOTH run plain.  With P = G_2 = (g + A^T g) / 4 the gradient is
         //      A^T (A^T P + g/4) + g/4 = A^T (A^T P) + (A^T g / 4 + g / 4) = A^T (A^T P) + P — and P is the push target, which the
         //      Adam pass touches anyway (to clear it): it adds P instead of g / 4.  No epilogue operand left in the backward.
-        const bool all_plain = L == 3;
         const float *c2 = G;
         for (int32_t l = L - 2; l >= 0; --l) {
             float *nxt = l == 0 ? s->grad_E0 : s->ws_bwd + (size_t)(1 + ((L - 2 - l) & 1)) * sz;   // ws_bwd[1], [2], [1] ...: never the source, never G
@@ -84,9 +84,9 @@ extern "C" int spex_lightgcn_step_bce_f32(spex_lightgcn_step_t *s, const int64_t
             else SPEX_TRY(spex_spmm_f32(gt, c2, nxt, s->g_out, (float)(L + 1), nullptr, nullptr, 1.0f, d, stream));
             c2 = nxt;
         }
-        SPEX_TRY(spex::adam_step_z2(s->E0, s->grad_E0, s->m, s->v, (int64_t)sz, s->t + 1, s->lr, s->beta1, s->beta2, s->eps, s->g_out,
-                                    s->ws_bwd, stream, s->grad_slots, B, loss_sum, nullptr, all_plain ? G : s->g_out,
-                                    all_plain ? 1.0f : (float)(L + 1)));
+        SPEX_TRY(spex::adam_step_z2(s->E0, s->grad_E0, s->m, s->v, (int64_t)sz, s->t + 1, s->lr, s->beta1, s->beta2, s->eps,
+                                    all_plain ? nullptr : s->g_out /* untouched (all-zero) in the all-plain step */, s->ws_bwd, stream,
+                                    s->grad_slots, B, loss_sum, nullptr, all_plain ? G : s->g_out, all_plain ? 1.0f : (float)(L + 1)));
         s->t += 1;
         return SPEX_OK;
     } else {    // L == 1: the last layer at the batch's rows, scoring, then grad = (g + A^T g) / 2 as one pull-form product
@@ -325,6 +325,7 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
     // descriptor may change its flags between steps
     const int32_t att_copies_max = s->slot_capacity / 8 < 64 ? s->slot_capacity / 8 : 64;
     int32_t att_copies_used = 0;
+    bool fused_middle_used = false;
     bool plain_last = false;          // the rec branch left the g_prop / (L+1) share of its last backward product to the Adam pass
     auto rec_branch = [&]() -> int {
         // ---- rec branch forward (model_expert_s.py:95-126,154-168): layers 1 .. L-1 over the whole graph, the last layer, the gate and
@@ -346,10 +347,12 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
             float *G = s->ws_bwd;                     // all-zero here (cleared by the previous step's Adam pass)
             SPEX_TRY(spex::gated_batch_push_layers(g, cur, plain ? E0 : s->light, plain ? s->ws_fwd : nullptr,
                                                    plain && L == 3 ? s->ws_fwd + sz : nullptr, (float)(L + 1), E0, att1, att2, users, items,
-                                                   labels, B, n_u, 1.0f / (float)B, 1.0f / (float)(L + 1), s->loss, s->g_prop, G, s->g_raw,
+                                                   labels, B, n_u, 1.0f / (float)B, 1.0f / (float)(L + 1), s->loss,
+                                                   L == 3 ? nullptr : s->g_prop /* L == 3: nothing reads it (all-plain backward) */, G, s->g_raw,
                                                    att_copies_max >= 1 ? s->grad_slots : g_att1, att_copies_max >= 1 ? att_copies_max : 1,
                                                    d, stream));
             att_copies_used = att_copies_max;
+            fused_middle_used = true;
             const float *c2 = G;
             for (int32_t l = L - 2; l >= 0; --l) {
                 float *nxt = l == 0 ? s->g_E0 : s->ws_bwd + (size_t)(1 + ((L - 2 - l) & 1)) * sz;
@@ -410,6 +413,7 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
     // what the Adam pass adds to the last (plain) backward product: g_prop / (L+1), or — L == 3, both products plain — the push
     // target itself (prop_div < 0)
     const float prop_div = !plain_last ? 0.0f : (L == 3 ? -1.0f : (float)(L + 1));
+    const int32_t clear_prop = fused_middle_used && L == 3 ? 0 : 1;      // (the fused middle of the L == 3 step never wrote g_prop)
     if (pipelined) {
         // the rec branch's gradients -> side_stream; Adam part 2 (user rows, trust block, task weights, loss cells) there, part 1
         // (item rows, gate matrices) here.  The join event is recorded on every path so that a later join never waits in vain.
@@ -420,7 +424,7 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
                                       s->loss, s->loss_acc, s->precision, (int64_t)sz, (int64_t)off_u, n_trust, B, T, s->n_rec, s->t + 1, s->lr,
                                       s->beta1, s->beta2, s->eps, (s->flags & SPEX_STEP_FIXED_TASK_WEIGHTS) != 0,
                                       part == 2 ? s->side_stream : stream, prop_div, s->grad_slots, att_copies_used,
-                                      att_copies_max * 512, part);
+                                      att_copies_max * 512, part, clear_prop);
         if (hipEventRecord(join_ev, (hipStream_t)s->side_stream) != hipSuccess && rc == SPEX_OK) rc = SPEX_ERR_HIP;
         if (rc != SPEX_OK) {
             (void)spex_dual_task_step_join(s, stream);
@@ -436,7 +440,7 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
     SPEX_TRY(spex::dual_task_adam(s->params, s->m, s->v, s->g_E0, s->g_raw, s->g_user, s->g_small, s->g_prop, L >= 2 ? s->ws_bwd : nullptr,
                                   s->loss, s->loss_acc, s->precision, (int64_t)sz, (int64_t)off_u, n_trust, B, T, s->n_rec, s->t + 1, s->lr,
                                   s->beta1, s->beta2, s->eps, (s->flags & SPEX_STEP_FIXED_TASK_WEIGHTS) != 0, stream,
-                                  prop_div, s->grad_slots, att_copies_used, att_copies_max * 512));
+                                  prop_div, s->grad_slots, att_copies_used, att_copies_max * 512, 0, clear_prop));
     s->t += 1;
     return SPEX_OK;
 }
