@@ -422,6 +422,40 @@ def main():
             aux["dual_task_step_ms_B256_T15_pipelined"] = time_events(fn3, 500, finish=dst.join)
             dst.join()
             del dnet, dst
+            # BASELINE configs[3] / [5] on their OWN shape (Trust_SPEX/code/main_trust.py:42: 6 812 Weibo users; synthetic interactions
+            # with log-normal user activity and Zipf item popularity, hub rows beyond 1 024 entries): the exact LightGCN step and the
+            # dual-task step (15 paths against the 6 812-user table)
+            from spex_amd.datasets import synthetic_interactions
+            wu_, wi_ = synthetic_interactions(6812, 20000, 400000, seed=7, sigma=1.4)
+            wcsr = lightgcn_norm_adj(wu_.numpy(), wi_.numpy(), 6812, 20000)
+            wgraph = SpexGraph(*wcsr, device=dev)
+            wrng = np.random.default_rng(13)
+            wE0 = torch.from_numpy(np.concatenate([xavier_uniform_np(6813, D, wrng), xavier_uniform_np(20000, D, wrng)])).to(dev)
+            wst = LightGCNStepper(wgraph, wE0.clone(), 6813, n_layers=L, lr=lr)
+            wub = torch.from_numpy(wrng.integers(0, 6812, 256)).to(dev)
+            wib = torch.from_numpy(wrng.integers(0, 20000, 256)).to(dev)
+            wacc = torch.zeros(1, device=dev)
+            fnw = lambda: wst.step_bce(wub, wib, yb, loss_acc=wacc, batch_rows_only=True)
+            for _ in range(10):
+                fnw()
+            aux["weibo_shape"] = {"graph": "6812 users x 20000 items, nnz %d (synthetic: log-normal activity, Zipf popularity), max row %d entries"
+                                           % (len(wcsr[1]), int(np.diff(wcsr[0]).max())),
+                                  "exact_train_step_ms_B256": time_events(fnw, 300)}
+
+            class _WDS:
+                n_users, m_items = 6812, 20000
+                getSparseGraph = staticmethod(lambda: wgraph)
+            wnet = mex.LightGCN(dargs, _WDS).to(dev)
+            wdst = DualTaskStepper(wnet, path_capacity=T_PATHS, path_len=P_LEN, lr=1e-3)
+            wseq = np.full((T_PATHS, P_LEN), 6812, dtype=np.int64)
+            for r, l in enumerate(plen):
+                wseq[r, :l] = wrng.choice(6812, size=l, replace=False)
+            wseq_d, wtgt = torch.from_numpy(wseq).to(dev), torch.from_numpy(wrng.integers(0, 6812, T_PATHS)).to(dev)
+            fnd = lambda: wdst.step(wub, wib, yb, wseq_d, plen_d, wtgt)
+            for _ in range(20):
+                fnd()
+            aux["weibo_shape"]["dual_task_step_ms_B256_T15"] = time_events(fnd, 300)
+            del wnet, wdst, wst, wgraph
         except Exception as e:  # never lose the headline line to an auxiliary measurement
             aux["aux_error"] = repr(e)
 

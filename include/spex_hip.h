@@ -681,10 +681,11 @@ int spex_ngcf_step_bce_f32(spex_ngcf_step_t *step, const int64_t *users, const i
                            float *loss_sum, void *stream);
 
 /* The dual-task training step of LightGCN_SPEX/code/main_auto_expert_s.py:63-89 (model_expert_s.LightGCN.forward flag 0 +
- * uncertainty-weighted loss + loss.backward() + optimizer.step()) as one call issuing 2 L + 5 launches:
- *   rec branch, row-sparse like spex_lightgcn_step_bce_f32: (L-1) x spex_spmm_f32 + spex_gated_batch_fwd_f32 (last layer at the
- *   batch's rows, gate, scores on the 2B gated rows, per-sample gradient rows) -> spex_expert_gate_rows_bwd_f32
- *   -> spex_spmm_push_batch_f32 -> (L-1) x spex_spmm_f32 on A^T;   trust branch: spex_trust_head_train_f32 (2 launches);
+ * uncertainty-weighted loss + loss.backward() + optimizer.step()) as one call issuing 2 L + 3 launches:
+ *   rec branch, row-sparse like spex_lightgcn_step_bce_f32: (L-1) x spex_spmm_f32 + spex_gated_batch_f32 (last layer at the
+ *   batch's rows, gate, scores, the gate's backward and the push-form first backward product: one launch; the deterministic
+ *   step and L == 1: spex_gated_batch_fwd_f32 -> spex_expert_gate_rows_bwd_[det_]f32 -> push / pull) -> (L-1) x spex_spmm_f32 on
+ *   A^T (L == 3: both in the plain form, the Adam pass adds the push target);   trust branch: spex_trust_head_train_f32;
  *   then one Adam pass over the whole parameter arena, which applies the task precisions exp(-2 s_k) to the two branches'
  *   gradients, forms the task weights' own gradients (d/ds0 = -2 p1 loss1 + 2 (n_rec + 1) B, d/ds1 = -2 p2 loss2 + T) and
  *   clears every accumulate-into buffer for the next step.
@@ -695,8 +696,10 @@ int spex_ngcf_step_bce_f32(spex_ngcf_step_t *step, const int64_t *users, const i
  *   g_user [n_user_rows, 64]; g_small [P + 512]; a2 [path_capacity, 64]; trust_ws
  *   [spex_trust_workspace_floats(path_capacity, path_len, 64, n_heads, n_user_rows)]; dscore [path_capacity, n_user_rows - 1];
  *   loss_b [path_capacity]; loss [2], loss_acc [2], precision [2][2].
- * Before the first call: g_prop, g_raw, the first [N, 64] of ws_bwd, g_user, g_small, loss all-zero (every call leaves them
- * so); precision[(t + 1) & 1] = {exp(-2 s0), exp(-2 s1)} for the current task weights (every call writes the next step's
+ * Before the first call: g_prop, g_raw, the first [N, 64] of ws_bwd, g_user, g_small, loss AND grad_slots all-zero (every call
+ * leaves them so: on the fast path — no SPEX_STEP_DETERMINISTIC, L >= 2 — the first min(64, slot_capacity / 8) x 512 floats of
+ * grad_slots hold the copies of the two gate gradients that spex_gated_batch_f32 accumulates, summed and cleared by the Adam pass;
+ * the other paths use the area for per-sample rows and the Adam pass clears it behind them); precision[(t + 1) & 1] = {exp(-2 s0), exp(-2 s1)} for the current task weights (every call writes the next step's
  * slot).  loss_acc accumulates (loss1, loss2) of every call — what Train() sums with .item() per step.  t is advanced.
  * seq: [T, path_len] int64 padded with the pad row's index n_user_rows - 1; T == 0 skips the trust branch (the reference
  * would produce NaN there: CrossEntropyLoss over an empty batch).  L >= 1, no edge dropout.

@@ -217,7 +217,15 @@ static int graph_create_impl(const int32_t *h_rowptr, const int32_t *h_col, cons
     // 6.7 %, slightly less local) and kept if that fits; SPEX_OPEN_TASKS pins the number.
     constexpr int kResidentWgs = 512;
     int open_tasks_now = getenv("SPEX_OPEN_TASKS") ? atoi(getenv("SPEX_OPEN_TASKS")) : spex::kOpenTasks;
-    for (int attempt = 0; chunked && attempt < 3; ++attempt) {
+    // Entries a pack of SHORT rows (<= 64 entries each) may hold.  64 = four chunks = four gather round trips per wave.  A table that
+    // needs a few more workgroups than are resident pays a whole second dispatch round for them (the Weibo-shaped graph: 520 workgroups,
+    // 19.8 us per product instead of ~13); letting the packs hold 80 / 96 / .. entries instead makes some waves run a fifth / sixth
+    // chunk (x 1.25 / 1.5 of a wave's chain) and the table fit in one round.  Every row is still ONE fmaf chain in column order, so the
+    // products do not change by a bit; rows of 65 .. 1 024 entries keep their 64-entry segments (the row-list and batch kernels sum
+    // them the same way).
+    int pack_cap = spex::kTaskEntries;
+    bool final_pass = false;
+    for (int attempt = 0; chunked && attempt < 12; ++attempt) {
         task.clear();
         wg_rows.clear();
         hub_row.clear();
@@ -244,6 +252,15 @@ static int graph_create_impl(const int32_t *h_rowptr, const int32_t *h_col, cons
                 entries = e - b;
             }
             const int64_t nch = (entries + spex::kChunk - 1) / spex::kChunk;
+            jobs.push_back(j);
+            n_planned += nch;
+            return make_int2((int32_t)j.first_chunk, (int32_t)nch);
+        };
+        // a list of rows WITHOUT stored entries (task kind 3): its chunk slots carry the row ids only (c_row), every slot is padding
+        auto add_zero_rows = [&](const int32_t *rows, int32_t n) -> int2 {
+            ChunkJob j{n_planned, (int64_t)pack_rows.size(), -n, 0, 0, rows[0]};
+            for (int32_t i = 0; i < n; ++i) pack_rows.push_back(rows[i]);
+            const int64_t nch = (n + spex::kChunk - 1) / spex::kChunk;
             jobs.push_back(j);
             n_planned += nch;
             return make_int2((int32_t)j.first_chunk, (int32_t)nch);
@@ -278,6 +295,20 @@ static int graph_create_impl(const int32_t *h_rowptr, const int32_t *h_col, cons
                         in_chunk = 0;
                     }
                 };
+                if (j.n_rows < 0) {          // zero-row list: row ids only, all slots padding (value 0 on column 0, never gathered)
+                    const int32_t n = -j.n_rows, nch = (n + spex::kChunk - 1) / spex::kChunk;
+                    for (int32_t k = 0; k < nch * spex::kChunk; ++k, ++pos) {
+                        c_off[pos] = 0u;
+                        c_val[pos] = 0.0f;
+                        c_eid[pos] = 0u;
+                        if (row_ids) c_row[pos] = pack_rows[(size_t)j.rows_off + (k < n ? k : n - 1)];
+                    }
+                    for (int32_t c = 0; c < nch; ++c) {
+                        c_mask[ci + c] = 0u;
+                        c_pad[ci + c] = (uint8_t)spex::kChunk;
+                    }
+                    return;
+                }
                 if (j.n_rows) {
                     for (int32_t i = 0; i < j.n_rows; ++i) {
                         const int32_t r = pack_rows[(size_t)j.rows_off + i];
@@ -325,6 +356,7 @@ static int graph_create_impl(const int32_t *h_rowptr, const int32_t *h_col, cons
             // and issue slots.  A graph that streams from HBM keeps plain next-fit over ADJACENT rows instead (one open
             // task): its kernel then needs no per-entry row ids (4 B/entry less metadata) and writes whole runs of
             // neighbouring rows — worth 6 % there.
+            std::vector<int32_t> empty_rows;
             struct OpenTask { std::vector<int32_t> rows; int room; };
             std::vector<OpenTask> open_tasks;
             const int max_open = g->row_ids ? open_tasks_now : 1;
@@ -349,7 +381,7 @@ static int graph_create_impl(const int32_t *h_rowptr, const int32_t *h_col, cons
                     }
                 }
                 if ((int)open_tasks.size() >= max_open) close_task(0);
-                open_tasks.push_back({{r}, spex::kTaskEntries - deg});
+                open_tasks.push_back({{r}, pack_cap - deg});
                 if (open_tasks.back().room == 0) close_task(open_tasks.size() - 1);
             };
             size_t long_i = 0;
@@ -357,8 +389,16 @@ static int graph_create_impl(const int32_t *h_rowptr, const int32_t *h_col, cons
                 const int32_t b = h_rowptr[r], e = h_rowptr[r + 1], deg = e - b;
                 while (long_i < long_row.size() && long_row[long_i] < r) ++long_i;
                 if (deg == 0) {
-                    normal.push_back(make_int4(0, 0, r, 0));   // zero-fill task
-                    normal_nrows.push_back(1);
+                    // a row without stored entries.  Bin-packed tables (row ids per entry) collect them into lists of up to 64 rows
+                    // per task (below): one wave per EMPTY row made a graph with a long tail of never-seen items — 2 441 of the
+                    // Weibo-shaped graph's 26 813 rows — need 670 workgroups where 512 are resident (two rounds: 21 us per product
+                    // instead of 12).  Tile mode and adjacent-row tables keep the one-row zero-fill task.
+                    if (g->row_ids && !tile_rows) {
+                        empty_rows.push_back(r);
+                    } else {
+                        normal.push_back(make_int4(0, 0, r, 0));   // zero-fill task
+                        normal_nrows.push_back(1);
+                    }
                 } else if (deg > spex::kWgRowMax) {            // hub: its kLongRow-table segments go through global scratch
                     hub_row.push_back(r);
                     hub_seg0.push_back(long_seg0[long_i]);      // [begin, end) in the kLongRow segment table
@@ -374,6 +414,12 @@ static int graph_create_impl(const int32_t *h_rowptr, const int32_t *h_col, cons
                 }
             }
             flush_window();
+            for (size_t k = 0; k < empty_rows.size(); k += (size_t)spex::kTaskEntries) {     // the lightest tasks: last
+                const int32_t n = (int32_t)std::min((size_t)spex::kTaskEntries, empty_rows.size() - k);
+                const int2 c = add_zero_rows(empty_rows.data() + k, n);
+                normal.push_back(make_int4(c.x, c.y, empty_rows[k], 3 | (n << 4)));
+                normal_nrows.push_back(n);
+            }
         }
         // assemble 16-wave workgroups: hub segments, then rows combined in-workgroup (heaviest first, first fit, the
         // rest of such a workgroup filled with ordinary tasks), then the ordinary tasks
@@ -484,12 +530,19 @@ static int graph_create_impl(const int32_t *h_rowptr, const int32_t *h_col, cons
             {
                 const int n_wgs_now = (int)((task.size() + W - 1) / W);
                 const bool pinned = getenv("SPEX_OPEN_TASKS") != nullptr;
-                if (g->row_ids && !pinned && attempt == 0 && n_wgs_now > kResidentWgs && n_wgs_now <= kResidentWgs + kResidentWgs / 16) {
-                    open_tasks_now = 32;
-                    continue;
-                }
-                if (g->row_ids && !pinned && attempt == 1 && n_wgs_now > kResidentWgs) {      // no use: back to the default
-                    open_tasks_now = spex::kOpenTasks;
+                if (g->row_ids && !pinned && !final_pass && n_wgs_now > kResidentWgs) {
+                    if (attempt == 0 && n_wgs_now <= kResidentWgs + kResidentWgs / 16) {       // a denser first fit may do
+                        open_tasks_now = 32;
+                        continue;
+                    }
+                    if (n_wgs_now <= 2 * kResidentWgs && pack_cap < 2 * spex::kTaskEntries) {   // larger packs of short rows (see pack_cap)
+                        open_tasks_now = 32;
+                        pack_cap += spex::kChunk;
+                        continue;
+                    }
+                    open_tasks_now = spex::kOpenTasks;                                          // no use: back to the default
+                    pack_cap = spex::kTaskEntries;
+                    final_pass = true;
                     continue;
                 }
             }

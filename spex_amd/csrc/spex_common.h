@@ -80,7 +80,9 @@ int sum_parts(const float *parts, int32_t n_parts, int64_t stride, int32_t n, fl
 constexpr int kWave = 64;          // CDNA wavefront
 constexpr int kWavesPerBlock = 4;  // 256-thread workgroups
 constexpr int kLongRow = 128;      // generic kernel / hub path: rows with more stored entries are cut into segments
-constexpr int kSegLen = 128;       // entries per such segment (partial rows go through global scratch + the fix-up launch)
+constexpr int kSegLen = 64;        // entries per such segment (partial rows go through global scratch + the fix-up launch); 64 = one
+                                   // wave task of the d == 64 kernel: a hub segment of 128 made its wave run twice as long as every other
+                                   // wave of a one-round launch, i.e. set the launch time (Weibo-shaped graph: 19.8 us per product)
 constexpr int kTaskEntries = 64;   // entries per wave task of the d == 64 kernel (4 chunks: 4 memory round trips)
 constexpr int kWgWaves = 16;       // the d == 64 kernel runs 1024-thread workgroups = 16 wave tasks
 constexpr int kWgRowMax = kWgWaves * kTaskEntries;  // longest row whose segments are combined inside one workgroup

@@ -12,7 +12,7 @@
 //
 //   spmm_chunk_kernel  d == 64, the tuned path (described at its definition): 16-wave workgroups, one wave per
 //                      <= 64-entry task read from the chunked task table, long rows summed through LDS.
-//   spmm_rows_kernel   any d: one wave per row (or per 128-entry segment of a row with more than 128 entries), walking
+//   spmm_rows_kernel   any d: one wave per row (or per kSegLen-entry segment of a row with more than kLongRow entries), walking
 //                      the plain CSR in column tiles of 64; segment sums go through global scratch and
 //                      spmm_long_fixup_kernel adds them in segment order.  Correct everywhere, tuned nowhere.
 //
@@ -352,8 +352,9 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
     // Metadata of up to 4 chunks (64 entries) per vector load — lane k holds entry k — handed to the scalar side with
     // v_readlane.  (Feeding it through s_load instead starves on scalar-cache misses once the matrix streams from
     // HBM: 29 ms vs 13 ms per launch on a 2^23-node graph.)
-    for (int sc = 0; sc < t.y; sc += 4) {
-        const int nc = (t.y - sc < 4) ? t.y - sc : 4;  // chunks in this super-chunk (wave-uniform)
+    const int n_ch = kind == 3 ? 0 : t.y;              // (kind 3: a list of rows without stored entries, handled after the loop)
+    for (int sc = 0; sc < n_ch; sc += 4) {
+        const int nc = (n_ch - sc < 4) ? n_ch - sc : 4;  // chunks in this super-chunk (wave-uniform)
         uint32_t my_off = 0u, my_mask = 0u, own_off = 0u;
         unsigned long long drop_bits = 0ull;                 // MASKED: entries of this super-chunk that are dropped (wave-uniform)
         int my_row = 0;
@@ -432,6 +433,16 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
         if (EPI != 0) e = El[(size_t)t.z * 64];
         emit(t.z, 0.0f, e);
     }
+    if (ROWIDS && kind == 3) {                // a LIST of such rows (<= 64: lane k holds the k-th row id), bin-packed tables only
+        const int count = t.w >> 4;
+        const int my_r = lane < count ? chunk_row[(size_t)t.x * kChunk + lane] : 0;
+        for (int k = 0; k < count; ++k) {
+            const int r = __builtin_amdgcn_readlane(my_r, k);
+            float e = 0.0f;
+            if (EPI != 0) e = El[(size_t)r * 64];
+            emit(r, 0.0f, e);
+        }
+    }
     if (kind == 2) partial[(size_t)(t.w >> 4) * 64 + lane] = acc;  // hub segment: summed by the fix-up launch
     if (t.w & 4) {  // this workgroup combines the segments of rows with 65..1024 entries through LDS
         const bool leader = kind == 1 && (t.w & 8);
@@ -509,8 +520,9 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_wide_kernel(
     // Metadata of up to 4 chunks (64 entries) per vector load — lane k holds entry k — handed to the scalar side with
     // v_readlane.  (Feeding it through s_load instead starves on scalar-cache misses once the matrix streams from
     // HBM: 29 ms vs 13 ms per launch on a 2^23-node graph.)
-    for (int sc = 0; sc < t.y; sc += 4) {
-        const int nc = (t.y - sc < 4) ? t.y - sc : 4;  // chunks in this super-chunk (wave-uniform)
+    const int n_ch = kind == 3 ? 0 : t.y;              // (kind 3: a list of rows without stored entries, handled after the loop)
+    for (int sc = 0; sc < n_ch; sc += 4) {
+        const int nc = (n_ch - sc < 4) ? n_ch - sc : 4;  // chunks in this super-chunk (wave-uniform)
         uint32_t my_off = 0u, my_mask = 0u, own_off = 0u;
         unsigned long long drop_bits = 0ull;                 // MASKED: entries of this super-chunk that are dropped (wave-uniform)
         int my_row = 0;
@@ -590,6 +602,16 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_wide_kernel(
         vec e = (vec)(0.0f);
         if (EPI != 0) e = *reinterpret_cast<const vec *>(El + (size_t)t.z * kRow);
         emit(t.z, (vec)(0.0f), e);
+    }
+    if (ROWIDS && kind == 3) {                // a list of such rows (see the d == 64 kernel)
+        const int count = t.w >> 4;
+        const int my_r = lane < count ? chunk_row[(size_t)t.x * kChunk + lane] : 0;
+        for (int k = 0; k < count; ++k) {
+            const int r = __builtin_amdgcn_readlane(my_r, k);
+            vec e = (vec)(0.0f);
+            if (EPI != 0) e = *reinterpret_cast<const vec *>(El + (size_t)r * kRow);
+            emit(r, (vec)(0.0f), e);
+        }
     }
     if (kind == 2) {  // hub segment: summed by the fix-up launch
 #pragma unroll
@@ -694,6 +716,13 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_long_fixup_kernel(
     for (int c = lane; c < p.d; c += kWave) {
         float y = 0.0f;
         int s = s0;
+        for (; s + 32 <= s1; s += 32) {          // 32 partial rows in flight: a 6 812-entry row has 107 segments — a chain of 27
+            float t[32];                         // round trips with four in flight was most of this launch's 6 us
+#pragma unroll
+            for (int u = 0; u < 32; ++u) t[u] = p.partial[(size_t)(s + u) * p.d + c];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) y = y + t[u];
+        }
         for (; s + 4 <= s1; s += 4) {
             float t[4];
 #pragma unroll

@@ -59,7 +59,7 @@ def test_spmm_matches_oracle_random_graph(G, oracle, d):
     rowptr, col, val = random_csr(rng, n_rows, n_cols, deg)
     X = rng.normal(size=(n_cols, d)).astype(np.float32)
     g = G(rowptr, col, val, n_cols=n_cols)
-    assert g.n_long_rows == 2 and g.n_segments == 4 + 2
+    assert g.n_long_rows == 2 and g.n_segments == 8 + 3          # segments of 64 entries (kSegLen)
     Y = g.spmm(t(X)).cpu().numpy()
     ref = oracle.spmm(rowptr, col, val, X)
     short = np.diff(rowptr) <= (64 if d in (64, 128, 256) else 128)  # rows owned by a single wave
