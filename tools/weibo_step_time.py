@@ -5,6 +5,9 @@ import argparse, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "spex_amd", "dropin"))
+if os.environ.get("SPEX_LIB"):
+    from spex_amd import _lib as _l
+    _l.LIB_PATH = os.environ["SPEX_LIB"]          # A/B against another build of the library
 from spex_amd.datasets import synthetic_interactions, xavier_uniform_np
 from spex_amd.graph import SpexGraph, lightgcn_norm_adj
 from spex_amd.trainer import DualTaskStepper, LightGCNStepper
