@@ -401,6 +401,20 @@ int spex_ngcf_score_bwd_rows_f32(const float *ego, const float *side, const floa
                                  float slope, float p_drop, uint64_t seed, uint32_t step, uint32_t layer, int32_t pad_row,
                                  const int64_t *users, const int64_t *items, int32_t B, int64_t n_user_rows, float *loss_per_sample,
                                  float *g_side_c, float *g_ego_c, float *gW_parts, int32_t part_stride, void *stream);
+/* The same WITHOUT the concatenated table: the layer's forward at the batch's rows, the scoring and the rows backward in one launch.
+ * A tile of the kernel holds both rows of 8 samples (user rows and item rows of samples 8t .. 8t+7), so a sample's other row is in
+ * the tile and x = <ego_u, ego_i> + <out_u, out_i> is formed from the layer output the kernel recomputes anyway (out = the
+ * normalised, dropped-out layer output of main_rec.py:77-83 at that row).  Inputs: `ego` and `side` = A ego, dense tables read at the
+ * batch's rows only (spex_spmm_rowlist_f32 provides `side` there).  Outputs as spex_ngcf_score_bwd_rows_f32 (slot b: users[b],
+ * slot B + b: items[b]; gW_parts: spex_ngcf_layer_bwd_rows_parts(2 B) blocks).  With it a training step of the one-layer model
+ * never materialises the layer's output.  d == 64.
+ */
+int spex_ngcf_fwd_score_bwd_rows_f32(const float *ego, const float *side, const float *W_gc, const float *b_gc, const float *W_bi,
+                                     const float *b_bi, const float *labels, float grad_scale, int32_t n, int32_t d, float slope,
+                                     float p_drop, uint64_t seed, uint32_t step, uint32_t layer, int32_t pad_row,
+                                     const int64_t *users, const int64_t *items, int32_t B, int64_t n_user_rows,
+                                     float *loss_per_sample, float *g_side_c, float *g_ego_c, float *gW_parts, int32_t part_stride,
+                                     void *stream);
 
 /* The forward half of the dual-task model's batch-sized middle (utility1/model_expert_s.py:95-126 at the batch's rows, :154-168)
  * as ONE launch — what spex_spmm_rowlist_f32 -> spex_expert_gate_rows_f32 -> spex_score_bce_slots_f32 compute: for sample b with

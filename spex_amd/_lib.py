@@ -61,6 +61,9 @@ SIGNATURES = {
                                                     c_i32, c_i64, c_vp, c_i32, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "spex_spmm_push_batch_f32": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_vp, c_i32, c_vp, c_i32, c_f32, c_vp,
                                                 c_i32, c_vp]),
+    "spex_ngcf_fwd_score_bwd_rows_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_f32, c_f32,
+                                                        ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, c_i32, c_vp, c_vp, c_i32, c_i64,
+                                                        c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "spex_ngcf_score_bwd_rows_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_f32, c_f32,
                                                     ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, c_i32, c_vp, c_vp, c_i32, c_i64,
                                                     c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),

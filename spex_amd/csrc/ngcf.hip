@@ -887,7 +887,14 @@ struct ScoreArgs {
     float grad_scale;
 };
 
-template <bool SCORE>
+// SCORE == 2 (spex_ngcf_fwd_score_bwd_rows_f32, the one-call step): the tile holds BOTH rows of 8 samples — tile row j < 8 is the
+// user row of sample 8 tile + j (slot 8 tile + j), row 8 + j its item row (slot B + 8 tile + j) — so the other row of every sample is
+// in the same tile and the scores can be formed from the layer output this kernel recomputes anyway: no concatenated table is read,
+// the layer's forward at the batch's rows is not a launch of its own.  After the row norms the normalised outputs go to LDS, wave b
+// scores samples 2b and 2b + 1 (x = <ego_u, ego_i> + <out_u, out_i>, the order of the 128-column dot), dg comes back through LDS and
+// the upstream gradient rows are dg x the partner's [ego | out].  Same arithmetic per element as SCORE == 1 on a table holding the
+// same rows.
+template <int SCORE>
 __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_rows4_kernel(
     const float *__restrict__ ego, const float *__restrict__ side, const float *__restrict__ W_gc,
     const float *__restrict__ b_gc, const float *__restrict__ W_bi, const float *__restrict__ b_bi,
@@ -905,12 +912,15 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_rows4_kernel(
     const int i16 = lane & 15, h = lane >> 4;
     const int n_items = n_a + n_b, tile = blockIdx.x, r0 = tile << 4;
     float *t_side = s_tile[0], *t_ego = s_tile[1], *t_prod = s_tile[2], *t_gs = s_tile[3], *t_gt = s_tile[4];
-    // ---- the tile's rows (lane i < 16: slot r0 + i), requested first; wave b stages rows 4b .. 4b+3 (lane == column)
+    // tile row rr -> slot: consecutive slots, or (SCORE == 2) both rows of samples 8 tile .. 8 tile + 7
+    auto slot_of = [&](int rr) { return SCORE == 2 ? ((rr & 8) ? n_a : 0) + 8 * tile + (rr & 7) : r0 + rr; };
+    auto slot_ok = [&](int rr) { return SCORE == 2 ? 8 * tile + (rr & 7) < n_a : r0 + rr < n_items; };
+    // ---- the tile's rows (lane i < 16: slot_of(i)), requested first; wave b stages rows 4b .. 4b+3 (lane == column)
     int slot_row = -1, oth_row = -1;
-    if (lane < 16 && r0 + lane < n_items) {
-        const long long r = batch_row(idx_a, n_a, off_a, idx_b, off_b, r0 + lane);
+    if (lane < 16 && slot_ok(lane)) {
+        const long long r = batch_row(idx_a, n_a, off_a, idx_b, off_b, slot_of(lane));
         slot_row = (r >= 0 && r < n) ? (int)r : -1;
-        if (SCORE) {            // the sample's other row: slot s < B pairs with slot s + B
+        if (SCORE == 1) {       // the sample's other row: slot s < B pairs with slot s + B
             const int s_ = r0 + lane;
             const long long o = batch_row(idx_a, n_a, off_a, idx_b, off_b, s_ < n_a ? s_ + n_a : s_ - n_a);
             oth_row = (o >= 0 && o < n) ? (int)o : -1;                         // a sample with a bad index gets dg = 0: its valid
@@ -920,7 +930,7 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_rows4_kernel(
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         row_q[q] = __shfl(slot_row, 4 * h + q, kWave);
-        oth_q[q] = SCORE ? __shfl(oth_row, 4 * h + q, kWave) : -1;
+        oth_q[q] = SCORE == 1 ? __shfl(oth_row, 4 * h + q, kWave) : -1;
     }
     float e_reg[4], s_reg[4];
 #pragma unroll
@@ -938,7 +948,8 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_rows4_kernel(
     for (int q = 0; q < 4; ++q) {
         gn[q] = gx[q] = gd[q] = 0.0f;
         if (row_q[q] >= 0) {
-            if (SCORE) {        // the other row's columns now, times dg after the barrier
+            if (SCORE == 2) {   // formed after the row norms (below)
+            } else if (SCORE == 1) {   // the other row's columns now, times dg after the barrier
                 const int o = oth_q[q];
                 if (o >= 0) {
                     gn[q] = sc.all_emb[(size_t)o * 128 + 64 + 16 * b + i16];
@@ -951,7 +962,7 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_rows4_kernel(
             if (g_next) gx[q] = g_next[(size_t)row_q[q] * 64 + 16 * b + i16];
         }
     }
-    if (SCORE) {                // wave b scores slots 4b .. 4b+3: x over the 128 columns, lane == column (two halves)
+    if (SCORE == 1) {           // wave b scores slots 4b .. 4b+3: x over the 128 columns, lane == column (two halves)
         float own0[4], own1[4], ot0[4], ot1[4], lab[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1004,7 +1015,7 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_rows4_kernel(
         t_prod[(4 * b + i) * kBwdStride + lane] = e_reg[i] * s_reg[i];
     }
     __syncthreads();                                                                  // (1) tile + weights staged (+ dg)
-    if (SCORE) {
+    if (SCORE == 1) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float dg = s_dg[4 * h + q];
@@ -1058,6 +1069,45 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_rows4_kernel(
         const int rr = 4 * h + q;
         nrm[q] = sqrtf(((s_red[0][0][rr] + s_red[0][1][rr]) + s_red[0][2][rr]) + s_red[0][3][rr]);
         den[q] = fmaxf(nrm[q], 1e-12f);
+    }
+    if (SCORE == 2) {
+        // the normalised layer output of the tile's 16 rows -> LDS (the G_s tile's space: written only after barrier (3))
+        float *t_o = t_gs;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t_o[(4 * h + q) * kBwdStride + 16 * b + i16] = row_q[q] >= 0 ? e1d[q] / den[q] : 0.0f;
+        __syncthreads();                                                              // (2b) outputs visible
+        // wave b scores samples 2b, 2b + 1 of the tile: lane == column, the user-side row leads the product, ego columns first
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int sj = 2 * b + j, k = 8 * tile + sj;                               // tile-local sample, sample of the batch
+            const int ru = __builtin_amdgcn_readlane(slot_row, sj), ri = __builtin_amdgcn_readlane(slot_row, 8 + sj);
+            const float eu = t_ego[sj * kBwdStride + lane], ei = t_ego[(8 + sj) * kBwdStride + lane];
+            const float ou = t_o[sj * kBwdStride + lane], oi = t_o[(8 + sj) * kBwdStride + lane];
+            const float x = wave_sum(fmaf(ou, oi, fmaf(eu, ei, 0.0f)));
+            float dg = 0.0f;
+            if (k < n_a) {
+                const float lab = sc.labels[k];
+                if (ru >= 0 && ri >= 0) {
+                    dg = (1.0f / (1.0f + expf(-x)) - lab) * sc.grad_scale;
+                    if (lane == 0) sc.loss_rows[k] = fmaxf(x, 0.0f) - x * lab + log1pf(expf(-fabsf(x)));
+                } else if (lane == 0) {
+                    sc.loss_rows[k] = 0.0f;
+                }
+            }
+            if (lane == 0) s_dg[sj] = s_dg[8 + sj] = dg;
+        }
+        __syncthreads();                                                              // (2c) dg
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rr = 4 * h + q, pr = rr ^ 8;                                     // the sample's other row in this tile
+            const float dg = s_dg[rr];
+            gn[q] = row_q[q] >= 0 ? dg * t_o[pr * kBwdStride + 16 * b + i16] : 0.0f;
+            gd[q] = row_q[q] >= 0 ? dg * t_ego[pr * kBwdStride + 16 * b + i16] : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int rr = 4 * h + q;
         const float v = row16_sum_f32(gn[q] * (e1d[q] / den[q]));
         if (i16 == 0) s_red[1][b][rr] = v;
     }
@@ -1133,7 +1183,7 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_rows4_kernel(
     for (int q = 0; q < 4; ++q) {
         if (row_q[q] >= 0) {
             const int rr = 4 * h + q, c = 16 * b + i16;
-            const size_t o = (size_t)(r0 + rr) * 64 + c;                      // compact slot
+            const size_t o = (size_t)slot_of(rr) * 64 + c;                    // compact slot
             g_side[o] = ts[q] + tb[q] * t_ego[rr * kBwdStride + c];
             g_ego[o] = tb[q] * t_side[rr * kBwdStride + c] + gd[q];
         }
@@ -1545,7 +1595,7 @@ extern "C" int spex_ngcf_layer_bwd_rows_f32(const float *ego, const float *side,
                            make_drop(p_drop, seed, step, layer, pad_row), idx_a, n_a, off_a, idx_b, n_b, off_b, g_side_c, g_ego_c, nullptr,
                            nullptr, nullptr, nullptr, gW_parts, part_stride);
     else
-        hipLaunchKernelGGL((ngcf_layer_bwd_rows4_kernel<false>), dim3((unsigned)tiles), dim3(kWave * kBwdWaves), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((ngcf_layer_bwd_rows4_kernel<0>), dim3((unsigned)tiles), dim3(kWave * kBwdWaves), 0, (hipStream_t)stream,
                            ego, side, W_gc, b_gc, W_bi, b_bi, g_norm_c, ld_g, g_next, g_direct_c, ld_direct, n, slope,
                            make_drop(p_drop, seed, step, layer, pad_row), idx_a, n_a, off_a, idx_b, n_b, off_b, g_side_c, g_ego_c,
                            gW_parts, part_stride, ScoreArgs{nullptr, nullptr, nullptr, 0.0f});
@@ -1573,10 +1623,38 @@ extern "C" int spex_ngcf_score_bwd_rows_f32(const float *ego, const float *side,
     SPEX_CHECK_ARG((((uintptr_t)W_gc | (uintptr_t)W_bi) & 15) == 0, "spex_ngcf_score_bwd_rows_f32: weights must be 16-byte aligned");
     if (n == 0 || B == 0) return SPEX_OK;
     const int tiles = spex_ngcf_layer_bwd_rows_parts(2 * B);
-    hipLaunchKernelGGL((ngcf_layer_bwd_rows4_kernel<true>), dim3((unsigned)tiles), dim3(kWave * kBwdWaves), 0, (hipStream_t)stream, ego,
+    hipLaunchKernelGGL((ngcf_layer_bwd_rows4_kernel<1>), dim3((unsigned)tiles), dim3(kWave * kBwdWaves), 0, (hipStream_t)stream, ego,
                        side, W_gc, b_gc, W_bi, b_bi, nullptr, 0, nullptr, nullptr, 0, n, slope,
                        make_drop(p_drop, seed, step, layer, pad_row), users, B, 0, items, B, n_user_rows, g_side_c, g_ego_c, gW_parts,
                        part_stride, ScoreArgs{all_emb, labels, loss_per_sample, grad_scale});
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}
+
+extern "C" int spex_ngcf_fwd_score_bwd_rows_f32(const float *ego, const float *side, const float *W_gc, const float *b_gc,
+                                               const float *W_bi, const float *b_bi, const float *labels, float grad_scale, int32_t n,
+                                               int32_t d, float slope, float p_drop, uint64_t seed, uint32_t step, uint32_t layer,
+                                               int32_t pad_row, const int64_t *users, const int64_t *items, int32_t B,
+                                               int64_t n_user_rows, float *loss_per_sample, float *g_side_c, float *g_ego_c,
+                                               float *gW_parts, int32_t part_stride, void *stream)
+{
+    SPEX_CHECK_ARG(ego && side && W_gc && b_gc && W_bi && b_bi && labels && users && items && loss_per_sample && g_side_c && g_ego_c
+                       && gW_parts,
+                   "spex_ngcf_fwd_score_bwd_rows_f32: NULL pointer");
+    SPEX_CHECK_ARG(n >= 0 && B >= 0 && n_user_rows >= 0 && n_user_rows <= n && part_stride >= 2 * (d * d + d),
+                   "spex_ngcf_fwd_score_bwd_rows_f32: n=%d B=%d n_user_rows=%lld part_stride=%d", n, B, (long long)n_user_rows, part_stride);
+    SPEX_CHECK_ARG(p_drop >= 0.0f && p_drop < 1.0f, "spex_ngcf_fwd_score_bwd_rows_f32: p_drop=%f", (double)p_drop);
+    if (d != 64) {
+        spex::set_error("spex_ngcf_fwd_score_bwd_rows_f32: only d == 64 is implemented (got %d)", d);
+        return SPEX_ERR_UNSUPPORTED;
+    }
+    SPEX_CHECK_ARG((((uintptr_t)W_gc | (uintptr_t)W_bi) & 15) == 0, "spex_ngcf_fwd_score_bwd_rows_f32: weights must be 16-byte aligned");
+    if (n == 0 || B == 0) return SPEX_OK;
+    const int tiles = (B + 7) / 8;                       // == spex_ngcf_layer_bwd_rows_parts(2 B): one block of weight partials per tile
+    hipLaunchKernelGGL((ngcf_layer_bwd_rows4_kernel<2>), dim3((unsigned)tiles), dim3(kWave * kBwdWaves), 0, (hipStream_t)stream, ego,
+                       side, W_gc, b_gc, W_bi, b_bi, nullptr, 0, nullptr, nullptr, 0, n, slope,
+                       make_drop(p_drop, seed, step, layer, pad_row), users, B, 0, items, B, n_user_rows, g_side_c, g_ego_c, gW_parts,
+                       part_stride, ScoreArgs{nullptr, labels, loss_per_sample, grad_scale});
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }

@@ -179,21 +179,31 @@ extern "C" int spex_ngcf_step_bce_f32(spex_ngcf_step_t *s, const int64_t *users,
     //      the dense tables at the rows the scoring reads.  (11.4 + 10.6 us of whole-table launches on Epinion2 became 6 + 4;
     //      SPEX_NGCF_DENSE_FORWARD=1 keeps the whole-table forward for A/B timing.)
     static const bool dense_forward = []() { const char *e = getenv("SPEX_NGCF_DENSE_FORWARD"); return e && e[0] == '1'; }();
+    static const bool self_scoring = []() { const char *e = getenv("SPEX_NGCF_TABLE_SCORING"); return !(e && e[0] == '1'); }();
     if (dense_forward) {
         SPEX_TRY(spex_spmm_f32(g, s->E0, s->side, nullptr, 1.0f, nullptr, nullptr, 1.0f, d, stream));
         SPEX_TRY(spex_ngcf_layer_fwd_f32(s->E0, s->side, W_gc, b_gc, W_bi, b_bi, s->all_emb, 2 * d, 1, nullptr, n, d, s->slope, s->p_drop,
                                          s->seed, step, 0, s->pad_row, stream));
     } else {
         SPEX_TRY(spex_spmm_rowlist_f32(g, s->E0, users, B, 0, items, B, n_u, s->side, nullptr, nullptr, 1.0f, d, stream));
-        SPEX_TRY(spex_ngcf_layer_fwd_rows_f32(s->E0, s->side, W_gc, b_gc, W_bi, b_bi, s->all_emb, 2 * d, 1, n, d, s->slope, s->p_drop,
-                                              s->seed, step, 0, s->pad_row, users, B, 0, items, B, n_u, stream));
+        if (!self_scoring)
+            SPEX_TRY(spex_ngcf_layer_fwd_rows_f32(s->E0, s->side, W_gc, b_gc, W_bi, b_bi, s->all_emb, 2 * d, 1, n, d, s->slope, s->p_drop,
+                                                  s->seed, step, 0, s->pad_row, users, B, 0, items, B, n_u, stream));
     }
     // ---- scoring + backward on the batch's 2B slots in one launch (per-sample losses go to the head of g_slots: the table's Adam
-    //      pass below adds them to loss_sum in a fixed order), then the push-form A^T product into the (all-zero) table gradient
+    //      pass below adds them to loss_sum in a fixed order), then the push-form A^T product into the (all-zero) table gradient.
+    //      Default: the launch also runs the layer's FORWARD at those rows — its tiles hold both rows of 8 samples and score from
+    //      the layer output they recompute anyway, so the concatenated table is never formed (spex_ngcf_fwd_score_bwd_rows_f32;
+    //      SPEX_NGCF_TABLE_SCORING=1 keeps the forward launch + the table for A/B timing)
     float *loss_rows = s->g_slots;
-    SPEX_TRY(spex_ngcf_score_bwd_rows_f32(s->E0, s->side, W_gc, b_gc, W_bi, b_bi, s->all_emb, labels, 1.0f / (float)B, n, d, s->slope,
-                                          s->p_drop, s->seed, step, 0, s->pad_row, users, items, B, n_u, loss_rows, s->g_side_c, s->g_ego_c,
-                                          s->gW_parts, per, stream));
+    if (self_scoring && !dense_forward)
+        SPEX_TRY(spex_ngcf_fwd_score_bwd_rows_f32(s->E0, s->side, W_gc, b_gc, W_bi, b_bi, labels, 1.0f / (float)B, n, d, s->slope, s->p_drop,
+                                                  s->seed, step, 0, s->pad_row, users, items, B, n_u, loss_rows, s->g_side_c, s->g_ego_c,
+                                                  s->gW_parts, per, stream));
+    else
+        SPEX_TRY(spex_ngcf_score_bwd_rows_f32(s->E0, s->side, W_gc, b_gc, W_bi, b_bi, s->all_emb, labels, 1.0f / (float)B, n, d, s->slope,
+                                              s->p_drop, s->seed, step, 0, s->pad_row, users, items, B, n_u, loss_rows, s->g_side_c,
+                                              s->g_ego_c, s->gW_parts, per, stream));
     // ---- Adam: the table (its pass clears the gradient again), the layer weights (their pass sums the partial blocks).  The
     //      weights' pass needs only the rows backward: with a second stream it runs beside the push-form product and the table's
     //      pass (a one-workgroup-class launch next to two that fill the chip) and is joined at the end of the step.

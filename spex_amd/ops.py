@@ -310,6 +310,29 @@ def ngcf_score_bwd_rows(ego, side, W_gc, b_gc, W_bi, b_bi, all_emb, labels, grad
     _bump(loss_per_sample, g_side_c, g_ego_c, gW_parts)
 
 
+def ngcf_fwd_score_bwd_rows(ego, side, W_gc, b_gc, W_bi, b_bi, labels, grad_scale, users, items, n_user_rows, loss_per_sample,
+                            g_side_c, g_ego_c, gW_parts, slope=0.01, drop=None, pad_row=-1):
+    """The layer's forward at the batch's rows, the scoring and the rows backward in ONE launch, without the concatenated table
+    (spex_ngcf_fwd_score_bwd_rows_f32): ego / side are the dense tables (side = A ego valid at the batch's rows); outputs as
+    ngcf_score_bwd_rows."""
+    for x, nm in ((ego, "ego"), (side, "side"), (W_gc, "W_gc"), (b_gc, "b_gc"), (W_bi, "W_bi"), (b_bi, "b_bi"), (labels, "labels"),
+                  (loss_per_sample, "loss_per_sample"), (g_side_c, "g_side_c"), (g_ego_c, "g_ego_c"), (gW_parts, "gW_parts")):
+        _need(x, nm)
+    n, d = ego.shape
+    B = users.numel()
+    if (items.numel() != B or labels.numel() != B or loss_per_sample.numel() < B or g_side_c.shape[0] < 2 * B or g_ego_c.shape[0] < 2 * B
+            or gW_parts.shape[0] < ngcf_bwd_rows_parts(2 * B)):
+        raise ValueError("ngcf_fwd_score_bwd_rows: per-sample / per-slot arrays are too small for the batch")
+    for t in (users, items):
+        if not (t.is_cuda and t.dtype == torch.int64 and t.is_contiguous()):
+            raise ValueError("ngcf_fwd_score_bwd_rows: the batch must be contiguous int64 tensors on the GPU")
+    p, seed, step = drop if drop is not None else (0.0, 0, 0)
+    _launch(ego.device, "spex_ngcf_fwd_score_bwd_rows_f32", _ptr(ego), _ptr(side), _ptr(W_gc), _ptr(b_gc), _ptr(W_bi), _ptr(b_bi),
+            _ptr(labels), float(grad_scale), n, d, float(slope), float(p), int(seed), int(step), 0, int(pad_row), _ptr(users), _ptr(items),
+            B, int(n_user_rows), _ptr(loss_per_sample), _ptr(g_side_c), _ptr(g_ego_c), _ptr(gW_parts), gW_parts.stride(0))
+    _bump(loss_per_sample, g_side_c, g_ego_c, gW_parts)
+
+
 def ngcf_bwd_rows_parts(n_slots):
     """Number of partial weight-gradient blocks ngcf_layer_bwd_rows writes for a batch of n_slots slots."""
     return int(_lib.load().spex_ngcf_layer_bwd_rows_parts(int(n_slots)))

@@ -562,6 +562,45 @@ def test_fused_scoring_and_rows_backward_equals_the_two_launches():
     assert rel_err(parts_b.sum(0).cpu().numpy(), parts_a.sum(0).cpu().numpy()) <= 2e-6
 
 
+@pytest.mark.parametrize("B", [200, 203, 5])
+def test_forward_scoring_and_rows_backward_in_one_launch(B):
+    """spex_ngcf_fwd_score_bwd_rows_f32 (tiles holding both rows of 8 samples: the layer's forward at the batch's rows, the scores and
+    the rows backward, no concatenated table) against spex_ngcf_layer_fwd_rows_f32 + spex_ngcf_score_bwd_rows_f32 on the same inputs:
+    batches that are not multiples of 8, repeated users, message dropout on, the pad row, one sample with an out-of-range item
+    (zero rows, zero loss)."""
+    from spex_amd import ops
+    rng = np.random.default_rng(79 + B)
+    n, n_u = 2000, 700
+    ego, side = (torch.from_numpy(rng.normal(size=(n, 64)).astype(np.float32) * 0.3).to(DEV) for _ in range(2))
+    W_gc, W_bi = (torch.from_numpy(rng.normal(size=(64, 64)).astype(np.float32) * 0.2).to(DEV) for _ in range(2))
+    b_gc, b_bi = (torch.from_numpy(rng.normal(size=64).astype(np.float32) * 0.1).to(DEV) for _ in range(2))
+    u_np, i_np = rng.integers(0, n_u - 1, B), rng.integers(0, n - n_u, B)
+    u_np[:3] = u_np[4]
+    i_np[2] = 5000                                                          # out of range
+    u_np[1] = n_u - 1                                                       # the pad row (mask numbering skips it)
+    users, items = torch.from_numpy(u_np).to(DEV), torch.from_numpy(i_np).to(DEV)
+    y = torch.from_numpy((rng.random(B) < 0.3).astype(np.float32)).to(DEV)
+    drop = (0.1, 99, 3)
+    n_parts = ops.ngcf_bwd_rows_parts(2 * B)
+    z = lambda *sh: torch.zeros(*sh, device=DEV)
+    # two launches: the layer at the batch's rows into the table, then scoring + rows backward from the table
+    all_emb = z(n, 128)
+    ops.ngcf_layer_fwd_rows(ego, side, W_gc, b_gc, W_bi, b_bi, all_emb, users, items, n_u, drop=drop, pad_row=n_u - 1)
+    per_a, parts_a, gs_a, ge_a = torch.full((B,), 7.0, device=DEV), z(n_parts, 2 * (64 * 64 + 64)), z(2 * B, 64), z(2 * B, 64)
+    ops.ngcf_score_bwd_rows(ego, side, W_gc, b_gc, W_bi, b_bi, all_emb, y, 1.0 / B, users, items, n_u, per_a, gs_a, ge_a, parts_a,
+                            drop=drop, pad_row=n_u - 1)
+    # one launch
+    per_b, parts_b, gs_b, ge_b = torch.full((B,), 7.0, device=DEV), torch.full((n_parts, 2 * (64 * 64 + 64)), 7.0, device=DEV), z(2 * B, 64), z(2 * B, 64)
+    ops.ngcf_fwd_score_bwd_rows(ego, side, W_gc, b_gc, W_bi, b_bi, y, 1.0 / B, users, items, n_u, per_b, gs_b, ge_b, parts_b,
+                                drop=drop, pad_row=n_u - 1)
+    assert per_b[2].item() == 0.0 and per_a[2].item() == 0.0
+    assert rel_err(per_b.cpu().numpy(), per_a.cpu().numpy()) <= 2e-6
+    assert rel_err(gs_b.cpu().numpy(), gs_a.cpu().numpy()) <= 3e-6
+    assert rel_err(ge_b.cpu().numpy(), ge_a.cpu().numpy()) <= 3e-6
+    assert (gs_b[2] == 0).all() and (gs_b[B + 2] == 0).all() and (ge_b[2] == 0).all()
+    assert rel_err(parts_b.sum(0).cpu().numpy(), parts_a.sum(0).cpu().numpy()) <= 3e-6
+
+
 def test_layer_backward_rows_form_equals_dense_form(oracle):
     """spex_ngcf_layer_bwd_rows_f32 (compact tiles over the batch's slots, every slot with its own gradient row) against
     the dense form fed with the same gradients scattered into a table: the layer's backward is linear in the upstream
