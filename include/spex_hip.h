@@ -43,7 +43,9 @@ int spex_version(void);                 /* ABI version, currently 4.  3 = 2 + th
                                          * spex_reduce_slots_f32, spex_lightgcn_batch_slots_f32, spex_expert_gate_rows_bwd_det_f32),
                                          * per-descriptor fork / join events (ev_fork / ev_join, spex_step_events_release),
                                          * spex_lightgcn_batch_f32 without its graph_t argument (the push walks the rows of A),
-                                         * loss_per_sample in spex_gated_batch_fwd_f32, and the spex_comm_* collectives */
+                                         * loss_per_sample in spex_gated_batch_fwd_f32, the spex_comm_* collectives, the one-launch
+                                         * middles spex_gated_batch_f32 / spex_ngcf_fwd_score_bwd_rows_f32 (+ spex_ngcf_layer_fwd_rows_f32),
+                                         * SPEX_STEP_PIPELINED with spex_dual_task_step_join and the trailing side_pending cell */
 const char *spex_last_error(void);      /* thread-local, never NULL */
 
 /* ------------------------------------------------------------------------------------------------ graph handle
