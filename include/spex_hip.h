@@ -348,7 +348,9 @@ int spex_spmm_push_batch_f32(const spex_graph_t *g, const int64_t *idx_a, int32_
                              int32_t n_b, int64_t off_b, const float *src, int32_t ld_src, const float *add, int32_t ld_add,
                              float scale, float *out, int32_t d, void *stream);
 
-/* The batch-sized middle of the exact LightGCN training step (L >= 2, d == 64, no edge dropout) as ONE launch: what the
+/* The batch-sized middle of the exact LightGCN training step (L >= 2, d == 64) as ONE launch (under edge dropout — a mask set on the
+ * handle with spex_graph_set_edge_mask — the last layer at the batch's rows and the push apply the handle's keep rule entry by entry,
+ * exactly as spex_spmm_f32 does: kept values / keep_prob, dropped entries contribute nothing): what the
  * sequence spex_spmm_rowlist_f32 -> spex_score_bce_slots_f32 -> spex_spmm_push_batch_f32 computes, i.e. for sample b with
  * rows u = users[b], i = items[b] + n_user_rows (utility1/model.py:91-97 at the batch's rows, :111-121, and autograd's first
  * backward product):
@@ -621,7 +623,10 @@ int spex_trust_head_train_f32(const float *table, int64_t n_rows, const float *p
  * g_out and the first [N, d] of ws_bwd must be all-zero before the first call (every call leaves them all-zero: the Adam
  * pass clears both).  t is advanced by the call.
  * users / items: device int64[B] (items index the item block: row n_user_rows + items[b]); labels: device fp32[B].
- * *loss_sum (device) accumulates the batch's BCE loss SUM.  L >= 1; no edge dropout (use the separate calls then).
+ * *loss_sum (device) accumulates the batch's BCE loss SUM.  L >= 1.  Edge dropout (`--dropout 1 --keepprob p`, the reference's
+ * recommended configuration): set the step's mask on BOTH handles with spex_graph_set_edge_mask before the call — graph_t must
+ * then be the transposed handle created with the edge-id permutation (a masked adjacency is not symmetric) and L >= 2; every
+ * product of the step, the batch kernel's included, drops the same edges.
  * graph is walked by the forward AND by the push-form first backward product (A^T g in push form walks the rows of A); graph_t
  * (A^T) by the pull-form products.  t is advanced only when every launch of the step was queued (a failed call leaves it alone).
  *

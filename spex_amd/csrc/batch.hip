@@ -83,13 +83,54 @@ __device__ __forceinline__ float segment_sum(const int32_t *__restrict__ col, co
     return acc;
 }
 
+// The same segment under edge dropout (model.py:46-55): a kept entry's value is divided by keep_prob, a dropped entry contributes
+// fmaf(0, 0, acc) = acc — exactly what spmm_chunk_kernel<.., MASKED> makes of it (dropped entries keep their place in the chain, so
+// the row's sum is the masked main kernel's, bit for bit).
+__device__ __forceinline__ float segment_sum_masked(const int32_t *__restrict__ col, const float *__restrict__ val,
+                                                    const float *__restrict__ Xl, int e0, int cnt, int lane, float acc,
+                                                    const spex::EdgeDrop &dr)
+{
+    int my_col = 0;
+    float my_val = 0.0f;
+    bool dropped = false;
+    if (lane < cnt) {
+        my_col = col[e0 + lane];
+        const bool kept = spex::edge_kept(dr, e0 + lane);
+        my_val = kept ? val[e0 + lane] / dr.keep_prob : 0.0f;
+        dropped = !kept;
+    }
+    const unsigned long long dbits = __ballot(dropped);
+    const int last_col = __builtin_amdgcn_readlane(my_col, (cnt - 1) & 63);
+    if (lane >= cnt) my_col = last_col;
+    float x[4][kChunk];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c * kChunk < cnt) {
+#pragma unroll
+            for (int k = 0; k < kChunk; ++k)
+                x[c][k] = Xl[(size_t)(uint32_t)__builtin_amdgcn_readlane(my_col, c * kChunk + k) * kWave];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c * kChunk < cnt) {
+#pragma unroll
+            for (int k = 0; k < kChunk; ++k) {
+                const float xv = (dbits >> (c * kChunk + k)) & 1ull ? 0.0f : x[c][k];     // a dropped entry contributes nothing
+                acc = fmaf(lane_bcast(my_val, c * kChunk + k), xv, acc);
+            }
+        }
+    }
+    return acc;
+}
+
 template <bool PUSH>
 __global__ __launch_bounds__(kWave *kWgWaves) void lightgcn_batch_kernel(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val, int n_rows,
     int n_user_rows, const float *__restrict__ X, const float *__restrict__ acc_in, float acc_div,
     const int64_t *__restrict__ users, const int64_t *__restrict__ items, const float *__restrict__ labels, int parts,
     float grad_scale, float push_scale, float *loss_sum, float *__restrict__ loss_rows, float *g_out, float *G, int runs_per_part,
-    float *__restrict__ grad_slots, int B, const float *__restrict__ acc2, const float *__restrict__ acc3)
+    float *__restrict__ grad_slots, int B, const float *__restrict__ acc2, const float *__restrict__ acc3, const spex::EdgeDrop drop)
 {
     // (the push walks the same rows of the same matrix as the forward: t_* are aliases kept for readability)
     const int32_t *__restrict__ t_rowptr = rowptr, *__restrict__ t_col = col;
@@ -155,6 +196,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void lightgcn_batch_kernel(
                 if (lane < p_cnt[p]) {
                     p_col[p] = t_col[base + lane];
                     p_val[p] = t_val[base + lane];
+                    if (drop.mode != 0) p_val[p] = spex::edge_kept(drop, base + lane) ? p_val[p] / drop.keep_prob : 0.0f;   // the forward's mask
                 }
             }
         }
@@ -171,7 +213,10 @@ __global__ __launch_bounds__(kWave *kWgWaves) void lightgcn_batch_kernel(
         float acc = 0.0f;
         for (int sgi = v; sgi < nseg[side]; sgi += kWgWaves) {
             const int left = deg[side] - sgi * kTaskEntries;
-            acc = segment_sum(col, val, Xl, beg[side] + sgi * kTaskEntries, left < kTaskEntries ? left : kTaskEntries, lane, acc);
+            if (drop.mode != 0)
+                acc = segment_sum_masked(col, val, Xl, beg[side] + sgi * kTaskEntries, left < kTaskEntries ? left : kTaskEntries, lane, acc, drop);
+            else
+                acc = segment_sum(col, val, Xl, beg[side] + sgi * kTaskEntries, left < kTaskEntries ? left : kTaskEntries, lane, acc);
         }
         s_part[side][v][lane] = acc;
     }
@@ -536,6 +581,11 @@ extern "C" int spex_gated_batch_f32(const spex_graph_t *g, const float *X, const
                                          grad_scale, push_scale, loss_sum, g_prop, G, g_raw, g_att, n_att_copies, d, stream);
 }
 
+static spex::EdgeDrop edge_drop_of(const spex_graph_t *g)
+{
+    return spex::EdgeDrop{g->keep, g->edge_id, g->mask_mode, g->keep_prob, (uint32_t)g->seed, (uint32_t)(g->seed >> 32)};
+}
+
 static int batch_env(const char *name, int dflt, int lo, int hi)
 {
     const char *e = getenv(name);
@@ -597,7 +647,6 @@ int spex::lightgcn_batch_slots_layers(const spex_graph_t *g, const float *X, con
                    "spex_lightgcn_batch_slots_f32: NULL argument");
     SPEX_CHECK_ARG(B >= 0 && n_user_rows >= 0 && n_user_rows <= g->n_rows, "spex_lightgcn_batch_slots_f32: B=%d n_user_rows=%d", B, n_user_rows);
     SPEX_CHECK_ARG(g->n_rows == g->n_cols, "spex_lightgcn_batch_slots_f32: square graph");
-    SPEX_CHECK_ARG(g->mask_mode == 0, "spex_lightgcn_batch_slots_f32: edge dropout is not supported here");
     if (d != kWave) {
         spex::set_error("spex_lightgcn_batch_slots_f32: d == 64 only (got %d)", d);
         return SPEX_ERR_UNSUPPORTED;
@@ -605,7 +654,7 @@ int spex::lightgcn_batch_slots_layers(const spex_graph_t *g, const float *X, con
     if (B == 0 || g->n_rows == 0) return SPEX_OK;
     hipLaunchKernelGGL(lightgcn_batch_kernel<false>, dim3((unsigned)B), dim3(kWave * kWgWaves), 0, (hipStream_t)stream, g->rowptr, g->col,
                        g->val, g->n_rows, n_user_rows, X, acc_in, acc_div, users, items, labels, 1, grad_scale, 0.0f, loss_sum,
-                       loss_per_sample, nullptr, nullptr, 1, grad_slots, B, acc2, acc3);
+                       loss_per_sample, nullptr, nullptr, 1, grad_slots, B, acc2, acc3, edge_drop_of(g));
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }
@@ -629,7 +678,6 @@ int spex::lightgcn_batch_layers(const spex_graph_t *g, const float *X, const flo
                    "spex_lightgcn_batch_f32: NULL argument");
     SPEX_CHECK_ARG(B >= 0 && n_user_rows >= 0 && n_user_rows <= g->n_rows, "spex_lightgcn_batch_f32: B=%d n_user_rows=%d", B, n_user_rows);
     SPEX_CHECK_ARG(g->n_rows == g->n_cols, "spex_lightgcn_batch_f32: square graph");
-    SPEX_CHECK_ARG(g->mask_mode == 0, "spex_lightgcn_batch_f32: edge dropout is not supported here");
     if (d != kWave) {
         spex::set_error("spex_lightgcn_batch_f32: d == 64 only (got %d)", d);
         return SPEX_ERR_UNSUPPORTED;
@@ -647,7 +695,7 @@ int spex::lightgcn_batch_layers(const spex_graph_t *g, const float *X, const flo
     }();
     hipLaunchKernelGGL(lightgcn_batch_kernel<true>, dim3((unsigned)B * parts), dim3(kWave * kWgWaves), 0, (hipStream_t)stream, g->rowptr,
                        g->col, g->val, g->n_rows, n_user_rows, X, acc_in, acc_div, users, items, labels, parts, grad_scale, push_scale,
-                       loss_sum, loss_per_sample, g_out, G, runs_per_part, nullptr, B, acc2, acc3);
+                       loss_sum, loss_per_sample, g_out, G, runs_per_part, nullptr, B, acc2, acc3, edge_drop_of(g));
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }

@@ -127,6 +127,41 @@ __device__ __forceinline__ float row16_sum_f32(float v)
 }
 }  // namespace spex
 
+namespace spex {
+// philox4x32-10, counter = (edge_id, 0, 0, 0), key = seed.  Returns the first output word.
+__device__ __forceinline__ uint32_t philox_first(uint32_t ctr0, uint32_t k0, uint32_t k1)
+{
+    uint32_t c0 = ctr0, c1 = 0u, c2 = 0u, c3 = 0u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+
+// Edge dropout (model.py:46-55) as the kernels see it: mode 1 = a device keep mask indexed by edge id, mode 2 = the counter-based
+// draw keyed by the edge id; a kept value is divided by keep_prob, a dropped entry contributes nothing.
+struct EdgeDrop {
+    const uint8_t *keep;
+    const int32_t *edge_id;      // entry -> edge id (NULL: the entry index itself)
+    int mode;
+    float keep_prob;
+    uint32_t seed_lo, seed_hi;
+};
+__device__ __forceinline__ bool edge_kept(const EdgeDrop &dr, int entry)
+{
+    const uint32_t eid = (uint32_t)(dr.edge_id ? dr.edge_id[entry] : entry);
+    if (dr.mode == 1) return dr.keep[eid] != 0;
+    const float u01 = (float)(philox_first(eid, dr.seed_lo, dr.seed_hi) >> 8) * 5.9604644775390625e-8f;
+    return (u01 + dr.keep_prob) >= 1.0f;
+}
+}  // namespace spex
+
 // A batch as two device index lists with offsets (users; items + n_user_rows): slot k's row.
 namespace spex {
 __device__ __forceinline__ long long batch_row(const int64_t *idx_a, int n_a, int64_t off_a, const int64_t *idx_b, int64_t off_b,

@@ -54,22 +54,6 @@ struct SpmmParams {
 
 constexpr int kUnroll = 8;
 
-// philox4x32-10, counter = (edge_id, 0, 0, 0), key = seed.  Returns the first output word.
-__device__ __forceinline__ uint32_t philox_first(uint32_t ctr0, uint32_t k0, uint32_t k1)
-{
-    uint32_t c0 = ctr0, c1 = 0u, c2 = 0u, c3 = 0u;
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    return c0;
-}
-
 __device__ __forceinline__ bool edge_kept(const SpmmParams &p, int eid)
 {
     if (p.mask_mode == 1) return p.keep[eid] != 0;

@@ -29,7 +29,13 @@ extern "C" int spex_lightgcn_step_bce_f32(spex_lightgcn_step_t *s, const int64_t
     SPEX_CHECK_ARG(g->n_rows == g->n_cols && gt->n_rows == g->n_rows && gt->n_cols == g->n_rows, "spex_lightgcn_step_bce_f32: square graphs of one size");
     SPEX_CHECK_ARG(L >= 1 && d == 64 && n_u >= 0 && n_u <= g->n_rows, "spex_lightgcn_step_bce_f32: L=%d d=%d n_user_rows=%d (needs L >= 1, d == 64)", L, d, n_u);
     SPEX_CHECK_ARG(s->slot_capacity >= 2 * B, "spex_lightgcn_step_bce_f32: slot capacity %d < 2 B = %d", s->slot_capacity, 2 * B);
-    SPEX_CHECK_ARG(g->mask_mode == 0 && gt->mask_mode == 0, "spex_lightgcn_step_bce_f32: edge dropout is not supported in the one-call step");
+    // edge dropout (model.py:46-55; set per step on BOTH handles with spex_graph_set_edge_mask — graph_t must then be the transposed
+    // handle carrying the edge-id permutation, a masked adjacency is not symmetric): every product of the step uses the handles'
+    // mask — the whole-graph launches through spex_spmm_f32, the batch kernel's last layer and push through the same keep rule.
+    SPEX_CHECK_ARG(g->mask_mode == gt->mask_mode && (g->mask_mode == 0 || (g->keep_prob == gt->keep_prob && g->seed == gt->seed && g->keep == gt->keep)),
+                   "spex_lightgcn_step_bce_f32: graph and graph_t must carry the same edge-dropout mask");
+    SPEX_CHECK_ARG(g->mask_mode == 0 || (gt != g && L >= 2),
+                   "spex_lightgcn_step_bce_f32: edge dropout needs L >= 2 and graph_t = the transposed handle (with its edge-id permutation)");
     const size_t sz = (size_t)g->n_rows * d;
     const bool det = (s->flags & SPEX_STEP_DETERMINISTIC) != 0;
     // ---- forward: layers 0 .. L-2 over the whole graph; the last layer is taken at the batch's rows only.  For L <= 3 the whole-graph

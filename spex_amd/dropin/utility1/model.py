@@ -114,9 +114,9 @@ class LightGCN(BasicModel):
         """The keep mask model.py:46-55 would draw for this step: `torch.rand(len(values)) + keep_prob`, `.int().bool()`, from
         the global CPU generator — one draw per fold under --A_split (model.py:57-64 calls __dropout_x fold by fold), in the
         stored-entry order of the coalesced adjacency (= the handles' edge ids)."""
+        from spex_amd.trainer import reference_keep_mask
         graphs = self.Graph if isinstance(self.Graph, (list, tuple)) else [self.Graph]
-        keep = torch.cat([(torch.rand(int(g.nnz)) + self.keep_prob).int().bool() for g in graphs])
-        return keep.to(torch.uint8).to(self.embedding_user.weight.device).contiguous()
+        return reference_keep_mask([g.nnz for g in graphs], self.keep_prob, self.embedding_user.weight.device)
 
     # ------------------------------------------------------------------ propagation (model.py:66-97)
     def _light_out(self):

@@ -73,7 +73,8 @@ class LightGCNStepper:
         batch's rows only (same arithmetic for those rows; `self.light_out` is then not the whole table)."""
         if batch_rows_only and loss_acc is not None and self._one_call_ok(users, items, labels):
             return self._step_bce_one_call(users, items, labels, loss_acc)
-        lo = self.propagate_for_batch(users, items) if batch_rows_only else self.propagate()
+        masked = getattr(self.graph, "mask_mode", 0) != 0        # (the row-list kernel of the launch-by-launch form takes no mask)
+        lo = self.propagate_for_batch(users, items) if batch_rows_only and not masked else self.propagate()
         B = users.numel()
         self._slots(B)
         if self.deterministic and self.E0.shape[1] == 64:
@@ -102,8 +103,9 @@ class LightGCNStepper:
 
     # -- the whole step as one library call (spex_lightgcn_step_bce_f32): same launches, issued from native code
     def _one_call_ok(self, users, items, labels):
-        return (self.L >= 1 and self.E0.shape[1] == 64 and getattr(self.graph, "mask_mode", 0) == 0
-                and getattr(self.graph_t, "mask_mode", 0) == 0 and users.is_cuda and items.is_cuda and labels.is_cuda
+        masked = getattr(self.graph, "mask_mode", 0) != 0 or getattr(self.graph_t, "mask_mode", 0) != 0
+        return (self.L >= 1 and self.E0.shape[1] == 64 and (not masked or (self.L >= 2 and self.graph_t is not self.graph))
+                and users.is_cuda and items.is_cuda and labels.is_cuda
                 and users.dtype == torch.int64 and items.dtype == torch.int64 and labels.dtype == torch.float32
                 and users.is_contiguous() and items.is_contiguous() and labels.is_contiguous()
                 and users.numel() == items.numel() == labels.numel() and users.numel() >= 1)
@@ -206,13 +208,36 @@ def dataloader_epoch_order(n):
     return torch.randperm(n, generator=g)
 
 
+_rand_staging = {}
+
+
+def reference_keep_mask(nnz_list, keep_prob, device):
+    """The keep mask `(torch.rand(nnz) + keep_prob).int().bool()` of model.py:46-55 for one or several handles (one draw per fold
+    under --A_split), as a device uint8 tensor.  Only the DRAW stays on the CPU — it has to: it is the reference's global
+    generator stream — into a reused pinned buffer; `+ keep_prob`, the truncation and the byte conversion run on the device on the
+    uploaded floats (the same IEEE operations, bit for bit).  Doing those three elementwise passes with CPU tensor ops cost 18 ms per
+    step on the GPU box (torch's intra-op thread pool, sized for the whole machine, on a 16-core share); the draw itself is < 1 ms."""
+    total = int(sum(int(n) for n in nnz_list))
+    if torch.device(device).type != "cuda":
+        keep = torch.cat([(torch.rand(int(n)) + keep_prob).int().bool() for n in nnz_list])
+        return keep.to(torch.uint8).to(device).contiguous()
+    buf = _rand_staging.get(total)
+    if buf is None:
+        buf = _rand_staging[total] = torch.empty(total, dtype=torch.float32).pin_memory()
+    off = 0
+    for n in nnz_list:                                   # torch.rand(n, out=...) draws exactly what torch.rand(n) draws
+        torch.rand(int(n), out=buf[off: off + int(n)])
+        off += int(n)
+    r = buf.to(device)                                   # (synchronous: the pinned buffer is free again when this returns)
+    return (r + keep_prob).int().bool().to(torch.uint8)
+
+
 def edge_dropout_mask(graph, keep_prob, stream, seed=0, step=0):
     """The edge-dropout mask tuple of one training step (SpexGraph.set_edge_mask arguments) — model.py:46-55.
     stream "reference": the reference's own draw, `torch.rand(nnz) + keep_prob` on the CPU from the global generator (one call
     per step, exactly where model.py:50 makes it), uploaded as a keep mask; "philox": the in-kernel counter-based mask."""
     if stream == "reference":
-        keep = (torch.rand(int(graph.nnz)) + keep_prob).int().bool()
-        return (1, keep.to(torch.uint8).to(graph.device).contiguous(), float(keep_prob), 0)
+        return (1, reference_keep_mask([graph.nnz], keep_prob, graph.device), float(keep_prob), 0)
     if stream != "philox":
         raise ValueError(f"edge dropout stream must be 'reference' or 'philox' (got {stream!r})")
     return (2, None, float(keep_prob), (int(seed) << 32) | (int(step) & 0xFFFFFFFF))
@@ -260,8 +285,7 @@ def train_epoch(stepper, train_data, batch_size=256, resample=True, pause_gc=Tru
                 mask = edge_dropout_mask(stepper.graph, edge_dropout[0], edge_dropout[1], edge_dropout[2] if len(edge_dropout) > 2 else 0, k + 1)
                 stepper.graph.set_edge_mask(*mask)
                 stepper.graph_t.set_edge_mask(*mask)
-            stepper.step_bce(users[s:e], items[s:e], labels[s:e], loss_acc=slot if tmp is None else tmp,
-                             batch_rows_only=edge_dropout is None)
+            stepper.step_bce(users[s:e], items[s:e], labels[s:e], loss_acc=slot if tmp is None else tmp, batch_rows_only=True)
             if tmp is not None:
                 step_losses.append(tmp.item() / (e - s))
                 slot += tmp

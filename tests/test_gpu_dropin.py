@@ -613,6 +613,48 @@ def test_reference_stream_dropout_run_matches_the_reference(data_root, golden, d
         assert rel_err(uw, g["user_w"]) <= 5e-5 and rel_err(iw, g["item_w"]) <= 5e-5
 
 
+@pytest.mark.parametrize("mode", ["philox", "reference"])
+def test_one_call_step_under_edge_dropout_equals_the_launch_by_launch_step(data_root, mode):
+    """spex_lightgcn_step_bce_f32 with an edge-dropout mask on both handles (round 3: the batch kernel's last layer and push apply
+    the handles' keep rule; the whole-graph launches always did) against LightGCNStepper's launch-by-launch step (masked dense
+    propagation, scoring, masked all-pull backward, Adam) on Epinion2: six steps with a fresh mask per step — in-kernel Philox
+    draw, and an uploaded keep mask (the reference-stream form) — same losses, same tables to rounding (the one-call step adds
+    duplicate rows and the push with float atomics)."""
+    import utility1.dataloader as dl
+    from spex_amd.trainer import LightGCNStepper, edge_dropout_mask
+    args, dataset, net = build("epinion2", data_root, ["--dropout", "1", "--keepprob", "0.3"])
+    rng = np.random.default_rng(3)
+    B, steps = 256, 6
+    deg = np.diff(dataset.build_adjacency()[0])
+    users = rng.integers(0, dataset.n_users, (steps, B)); items = rng.integers(0, dataset.m_items, (steps, B))
+    users[:, 0] = int(np.argmax(deg[: dataset.n_users]))                     # a hub user and a hub item in every batch
+    items[:, 0] = int(np.argmax(deg[dataset.n_users + 1:]))
+    users[:, 5:8] = users[:, 0:1]
+    labels = (rng.random((steps, B)) < 1 / 6).astype(np.float32)
+    u_d, i_d, y_d = (torch.from_numpy(a).to(DEV) for a in (users, items, labels))
+    E0 = net.flat_table().detach().clone()
+    out = []
+    for one_call in (True, False):
+        torch.manual_seed(11)                                                # the "reference" stream draws from the global generator
+        st = LightGCNStepper(net.Graph, E0.clone(), net.num_users + 1, n_layers=net.n_layers, lr=args.lr, graph_t=net._transposed())
+        acc = torch.zeros(1, device=DEV)
+        per_step = []
+        for k in range(steps):
+            mask = edge_dropout_mask(net.Graph, 0.3, mode, 5, k + 1)
+            st.graph.set_edge_mask(*mask)
+            st.graph_t.set_edge_mask(*mask)
+            before = acc.item()
+            st.step_bce(u_d[k], i_d[k], y_d[k], loss_acc=acc, batch_rows_only=one_call)
+            per_step.append(acc.item() - before)
+        st.graph.set_edge_mask(0)
+        st.graph_t.set_edge_mask(0)
+        out.append((np.asarray(per_step), st.E0.detach().cpu().numpy()))
+    (l_a, E_a), (l_b, E_b) = out
+    assert np.abs(l_a - l_b).max() <= 2e-5 * np.abs(l_b).max()
+    assert rel_err(E_a, E_b) <= 2e-5
+    assert np.abs(E_a - E0.cpu().numpy()).max() > 1e-4                        # (the steps did move the table)
+
+
 def test_dropped_entries_contribute_nothing_even_beside_non_finite_rows(data_root, golden):
     """A dropped edge is GONE from the reference's matrix (model.py:52-54); in the kernel it keeps its slot and gathers a
     stand-in row, whose value is replaced by 0 before the fmaf — so a table row holding Inf cannot turn into 0 * Inf = NaN on
