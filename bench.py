@@ -347,6 +347,28 @@ def main():
             aux["exact_train_step_ms_B256_training_batches_deterministic"] = time_events(fn2b, 256)
             stepper.deterministic = False
             fn2b()
+            # the same step under the reference's recommended edge dropout (`--dropout 1 --keepprob 0.3`, README.md:119-123): a fresh
+            # in-kernel (Philox) mask per step on the forward handle and on the transposed handle with its edge-id permutation
+            try:
+                from spex_amd.graph import csr_transpose
+                from spex_amd.trainer import edge_dropout_mask
+                t_rp, t_c, t_v, t_eid = csr_transpose(rowptr, col, val, n_nodes)
+                graph_tr = SpexGraph(t_rp, t_c, t_v, n_cols=n_nodes, edge_id=t_eid, device=dev)
+                dstp = LightGCNStepper(graph, stepper.E0.clone(), n_u, n_layers=L, lr=lr, graph_t=graph_tr)
+                kd = {"k": 0}
+
+                def fn2d():
+                    kd["k"] += 1
+                    mask = edge_dropout_mask(graph, 0.3, "philox", 7, kd["k"])
+                    graph.set_edge_mask(*mask)
+                    graph_tr.set_edge_mask(*mask)
+                    return dstp.step_bce(ub, ib, yb, loss_acc=acc, batch_rows_only=True)
+                for _ in range(10):
+                    fn2d()
+                aux["exact_train_step_ms_B256_edge_dropout_0.3"] = time_events(fn2d, 256)
+            finally:
+                graph.set_edge_mask(0)
+            del dstp, graph_tr
             aux["exact_train_step_samples_per_s"] = 256 / (ms2 * 1e-3)
             aux["exact_train_step_edges_per_s"] = 2 * L * nnz / (ms2 * 1e-3)
             # NGCF (BASELINE configs[3] shape): one layer = SpMM on D^-1(A+I) + fused layer kernel; and the whole training
