@@ -428,7 +428,8 @@ int spex_ngcf_fwd_score_bwd_rows_f32(const float *ego, const float *side, const 
  *   x = <mixed_u, mixed_i>;  loss_b = BCEWithLogits(x, labels[b]);  dg = (sigmoid(x) - labels[b]) * grad_scale
  *   loss_per_sample[b] = loss_b (plain store) if loss_per_sample != NULL, else *loss_sum += loss_b (one atomic per sample)
  *   grad_slots[b] = dg * mixed_i,  grad_slots[B + b] = dg * mixed_u                          ([2B, d], row stride d)
- * spex_expert_gate_rows_bwd_f32 and the push-form product follow as before.  d == 64, no edge dropout.
+ * spex_expert_gate_rows_bwd_f32 and the push-form product follow as before.  d == 64; under edge dropout the last layer applies
+ * the handle's keep rule (as spex_lightgcn_batch_f32 does).
  */
 int spex_gated_batch_fwd_f32(const spex_graph_t *g, const float *X, const float *acc_in, float acc_div, const float *raw,
                              const float *att_u, const float *att_i, const int64_t *users, const int64_t *items, const float *labels,
@@ -446,7 +447,8 @@ int spex_gated_batch_fwd_f32(const spex_graph_t *g, const float *X, const float 
  *   g_att[b mod n_att_copies] += the gate matrices' gradients;  *loss_sum += loss_b.
  * g_att: [n_att_copies][2][128, 2] — copy c holds [d att_u | d att_i] of the samples b = c (mod n_att_copies); the gradient is the
  * sum of the copies (all samples adding into ONE copy serialise in L2: 256 adds per word; 64 copies cost nothing).
- * g_prop, G, g_raw: [N, d], three distinct tables.  d == 64, no edge dropout.  (The deterministic step keeps the separate,
+ * g_prop, G, g_raw: [N, d], three distinct tables.  d == 64; under edge dropout the last layer and the push apply the handle's keep
+ * rule.  (The deterministic step keeps the separate,
  * atomic-free entries.)
  */
 int spex_gated_batch_f32(const spex_graph_t *g, const float *X, const float *acc_in, float acc_div, const float *raw,
@@ -723,7 +725,9 @@ int spex_ngcf_step_bce_f32(spex_ngcf_step_t *step, const int64_t *users, const i
  * the other paths use the area for per-sample rows and the Adam pass clears it behind them); precision[(t + 1) & 1] = {exp(-2 s0), exp(-2 s1)} for the current task weights (every call writes the next step's
  * slot).  loss_acc accumulates (loss1, loss2) of every call — what Train() sums with .item() per step.  t is advanced.
  * seq: [T, path_len] int64 padded with the pad row's index n_user_rows - 1; T == 0 skips the trust branch (the reference
- * would produce NaN there: CrossEntropyLoss over an empty batch).  L >= 1, no edge dropout.
+ * would produce NaN there: CrossEntropyLoss over an empty batch).  L >= 1.  Edge dropout (model_expert_s.py:104-109; the
+ * reference's recommended `--dropout 1 --keepprob 0.3`): the step's mask on BOTH handles before the call, graph_t the transposed
+ * handle with the edge-id permutation, L >= 2 — as in spex_lightgcn_step_bce_f32.
  * Two streams: the rec branch (2L + 4 launches that fill the chip) and the trust branch (two launches of <= path_capacity
  * workgroups: a latency chain on a few CUs) read the same parameters and write disjoint buffers, so with side_stream set
  * the trust branch is forked onto it behind everything already queued on `stream` and joined again in front of the Adam

@@ -1059,6 +1059,102 @@ def stage_epochs_dual_epinion2(n_steps=600, full_epoch=False, fixed_weights=Fals
         print("dual epinion2 full epoch: loss1", full1, "loss2", full2, "tw", tw, "rec", ret, "trust", trust)
 
 
+def stage_dual_dropout_epinion2(n_steps=150, keep_prob=0.3):
+    """G13-dropout: main_auto_expert_s.py:22-91 with the reference's recommended `--dropout 1 --keepprob 0.3` (README.md:119-123) on
+    Epinion2 with the reference-minted trust paths: the first `n_steps` batches of epoch 0, then Test().  The rec branch's edge mask
+    is drawn per step with torch.rand(nnz) from the global CPU generator (model_expert_s.py:75-92,104-109); the trust branch reads
+    the raw user table.  Stored: every step's two losses and path count, the first mask's digest, the task weights, both tasks'
+    metrics, sampled rows + column sums of the trained tables."""
+    import hashlib
+    import random
+    from collections import defaultdict
+    import numpy as np
+    import torch
+    from torch.utils.data import DataLoader
+    _dual_setup()
+    sys.argv += ["--dropout", "1", "--keepprob", str(keep_prob)]
+    import lg_parser
+    import utility1.dataloader as ref_dl
+    import utility1.utils as ref_utils
+    import utility1.model_expert_s as ref_ex
+    from utility1.batch_test import rec_test
+    from utility2.utils import Data
+    from utility2.batch_test_gnn import trust_test5
+    args = lg_parser.parse_args_r()
+    assert args.dropout == 1 and abs(args.keepprob - keep_prob) < 1e-12
+    raw_train, raw_test = _epinion2_trust_raw()
+    ref_utils.set_seed(args.seed)
+    device = torch.device("cpu")
+    dataset = ref_dl.Loader(args)
+    train_dataset = ref_dl.LightTrainData(dataset.rec_train_data, dataset.m_item, dataset.train_mat)
+    train_loader = DataLoader(train_dataset, batch_size=256, shuffle=True)
+    user_path_indx = defaultdict(list)
+    path = raw_train[0]
+    for i, p in zip(range(len(path)), path):
+        user_path_indx[p[0]].append(i)
+    train_data2 = Data(raw_train, dataset.n_users, shuffle=False)
+    test_data2 = Data(raw_test, dataset.n_users, shuffle=False, test=True)
+    trust_batch_size = len(path) // len(train_loader)
+    cap_paths = trust_batch_size * 3
+    Recmodel = ref_ex.LightGCN(args, dataset).to(device)
+    optimizer = torch.optim.Adam(Recmodel.parameters(), lr=args.lr)
+    nnz = int(Recmodel.Graph._nnz())
+    # digest of the first mask: what torch.rand(nnz) + keep_prob gives at this point of the stream, then the generator is put back
+    state = torch.get_rng_state()
+    train_loader.dataset.ng_sample()                                                # :56 (NumPy RNG)
+    it = iter(train_loader)                                                         # the shuffle's two seed draws
+    first_batch = next(it)
+    mask0 = (torch.rand(nnz) + keep_prob).int().bool().numpy()
+    torch.set_rng_state(state)
+    losses1, losses2, n_paths = [], [], []
+    Recmodel.train()
+    import time
+    t0 = time.time()
+    for step, data in enumerate(train_loader):
+        if step == n_steps:
+            break
+        optimizer.zero_grad()
+        user, item, label = data
+        if step == 0:
+            assert torch.equal(user, first_batch[0])
+        unique_user = set(user.numpy().tolist())
+        path_index = []
+        for u in unique_user:
+            path_index.extend(user_path_indx[u])
+        if len(path_index) > cap_paths:
+            path_index = random.sample(path_index, cap_paths)
+        n_paths.append(len(path_index))
+        loss1, loss2 = Recmodel(users=user.to(device), items=item.to(device), labels=label.to(device),
+                                slice_indices=np.array(list(path_index), dtype=int), trust_data=train_data2, flag=0)
+        T, n_rec, T_rec = len(path_index), 5, len(user)
+        loss = torch.exp(-2 * Recmodel.task_weights[0]) * loss1 + torch.exp(-2 * Recmodel.task_weights[1]) * loss2 \
+            + 2 * (n_rec + 1) * T_rec * Recmodel.task_weights[0] + T * Recmodel.task_weights[1]
+        loss.backward()
+        optimizer.step()
+        losses1.append(loss1.item()); losses2.append(loss2.item())
+        if (step + 1) % 50 == 0:
+            print("step", step + 1, "loss1", sum(losses1), "loss2", sum(losses2), "%.0f s" % (time.time() - t0), flush=True)
+    Recmodel.eval()
+    with torch.no_grad():
+        ret = rec_test(Recmodel, dataset.testRatings, dataset.testNegatives)
+        trust = np.asarray(trust_test5(Recmodel, test_data2), np.float64)
+    uw = Recmodel.embedding_user.weight.detach().numpy()
+    iw = Recmodel.embedding_item.weight.detach().numpy()
+    rows_u = np.sort(np.random.default_rng(1).choice(uw.shape[0], 256, replace=False))
+    rows_i = np.sort(np.random.default_rng(2).choice(iw.shape[0], 256, replace=False))
+    np.savez_compressed(os.path.join(GOLD, "dual_epinion2_dropout.npz"), seed=args.seed, n_steps=n_steps, keepprob=keep_prob, nnz=nnz,
+                        trust_batch_size=trust_batch_size, n_paths=np.asarray(n_paths, np.int64),
+                        first_batch=np.stack([first_batch[0].numpy(), first_batch[1].numpy(), first_batch[2].numpy()]),
+                        mask0_sha=np.frombuffer(hashlib.sha256(np.packbits(mask0).tobytes()).digest(), np.uint8), mask0_kept=int(mask0.sum()),
+                        step_loss1=np.asarray(losses1, np.float64), step_loss2=np.asarray(losses2, np.float64),
+                        task_weights=Recmodel.task_weights.detach().numpy().copy(), rec_recall=ret["recall"], rec_ndcg=ret["ndcg"],
+                        trust=trust, rows_u=rows_u, rows_i=rows_i, user_w=uw[rows_u], item_w=iw[rows_i],
+                        user_w_colsum=uw.astype(np.float64).sum(0), item_w_colsum=iw.astype(np.float64).sum(0),
+                        w=Recmodel.w.detach().numpy(), att_exp1=Recmodel.att_exp1.detach().numpy())
+    print("dual epinion2 dropout @%d: loss1" % n_steps, sum(losses1), "loss2", sum(losses2), "tw", Recmodel.task_weights.detach().numpy(),
+          "rec", ret, "trust", trust)
+
+
 # --------------------------------------------------------------------------- NGCF whole-run goldens (config 4)
 def philox4x32_10(c0, c1, c2, c3, k0, k1):
     """philox4x32-10 on uint32 arrays (Salmon et al. 2011; the generator libspexhip's dropout masks use).  Returns the
@@ -1355,6 +1451,8 @@ def main():
         stage_epochs_dual_epinion2(n_steps=300, fixed_weights=True)
     elif a.stage == "epochs-dual-epinion2-full":  # ~2.5 h of CPU: the same run continued to the end of epoch 0 (4 906 steps)
         stage_epochs_dual_epinion2(full_epoch=True)
+    elif a.stage == "dual-dropout-epinion2":      # ~5 min of CPU: 150 dual-task steps under --dropout 1 --keepprob 0.3 + both evaluations
+        stage_dual_dropout_epinion2()
     elif a.stage == "epochs-epinion2":      # ~25 min of CPU: one full Epinion2 epoch + test() through the reference
         stage_epochs("epinion2", 1)
     elif a.stage == "epochs-dropout":       # G12-dropout on tiny: three epochs of main_rec.py --dropout 1 --keepprob 0.3

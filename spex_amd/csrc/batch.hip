@@ -296,7 +296,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void gated_batch_fwd_kernel(
     const float *__restrict__ att_u, const float *__restrict__ att_i, const int64_t *__restrict__ users,
     const int64_t *__restrict__ items, const float *__restrict__ labels, int B, float grad_scale, float *loss_sum,
     float *__restrict__ lo_batch, float *__restrict__ grad_slots, float *__restrict__ loss_rows, const float *__restrict__ acc2,
-    const float *__restrict__ acc3)
+    const float *__restrict__ acc3, const spex::EdgeDrop drop)
 {
     __shared__ float s_part[2][kWgWaves][kWave];
     __shared__ float s_mixed[2][kWave];
@@ -337,7 +337,10 @@ __global__ __launch_bounds__(kWave *kWgWaves) void gated_batch_fwd_kernel(
         float acc = 0.0f;
         for (int sgi = v; sgi < nseg[side]; sgi += kWgWaves) {
             const int left = deg[side] - sgi * kTaskEntries;
-            acc = segment_sum(col, val, Xl, beg[side] + sgi * kTaskEntries, left < kTaskEntries ? left : kTaskEntries, lane, acc);
+            if (drop.mode != 0)             // edge dropout: the handle's keep rule, as in lightgcn_batch_kernel
+                acc = segment_sum_masked(col, val, Xl, beg[side] + sgi * kTaskEntries, left < kTaskEntries ? left : kTaskEntries, lane, acc, drop);
+            else
+                acc = segment_sum(col, val, Xl, beg[side] + sgi * kTaskEntries, left < kTaskEntries ? left : kTaskEntries, lane, acc);
         }
         s_part[side][v][lane] = acc;
     }
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void gated_batch_push_kernel(
     const float *__restrict__ att_u, const float *__restrict__ att_i, const int64_t *__restrict__ users,
     const int64_t *__restrict__ items, const float *__restrict__ labels, int parts, int runs_per_part, float grad_scale,
     float push_scale, float *loss_sum, float *g_prop, float *G, float *g_raw, float *g_att, int n_att_copies,
-    const float *__restrict__ acc2, const float *__restrict__ acc3)
+    const float *__restrict__ acc2, const float *__restrict__ acc3, const spex::EdgeDrop drop)
 {
     __shared__ float s_part[2][kWgWaves][kWave];
     __shared__ float s_mixed[2][kWave];
@@ -445,6 +448,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void gated_batch_push_kernel(
                 if (lane < p_cnt[p]) {
                     p_col[p] = col[base + lane];
                     p_val[p] = val[base + lane];
+                    if (drop.mode != 0) p_val[p] = spex::edge_kept(drop, base + lane) ? p_val[p] / drop.keep_prob : 0.0f;   // the forward's mask
                 }
             }
         }
@@ -459,7 +463,10 @@ __global__ __launch_bounds__(kWave *kWgWaves) void gated_batch_push_kernel(
         float acc = 0.0f;
         for (int sgi = v; sgi < nseg[side]; sgi += kWgWaves) {
             const int left = deg[side] - sgi * kTaskEntries;
-            acc = segment_sum(col, val, Xl, beg[side] + sgi * kTaskEntries, left < kTaskEntries ? left : kTaskEntries, lane, acc);
+            if (drop.mode != 0)             // edge dropout: the handle's keep rule, as in lightgcn_batch_kernel
+                acc = segment_sum_masked(col, val, Xl, beg[side] + sgi * kTaskEntries, left < kTaskEntries ? left : kTaskEntries, lane, acc, drop);
+            else
+                acc = segment_sum(col, val, Xl, beg[side] + sgi * kTaskEntries, left < kTaskEntries ? left : kTaskEntries, lane, acc);
         }
         s_part[side][v][lane] = acc;
     }
@@ -538,6 +545,11 @@ __global__ __launch_bounds__(kWave *kWgWaves) void gated_batch_push_kernel(
 
 }  // namespace
 
+static spex::EdgeDrop edge_drop_of(const spex_graph_t *g)
+{
+    return spex::EdgeDrop{g->keep, g->edge_id, g->mask_mode, g->keep_prob, (uint32_t)g->seed, (uint32_t)(g->seed >> 32)};
+}
+
 extern "C" int spex_gated_batch_fwd_f32(const spex_graph_t *g, const float *X, const float *acc_in, float acc_div, const float *raw,
                                        const float *att_u, const float *att_i, const int64_t *users, const int64_t *items,
                                        const float *labels, int32_t B, int32_t n_user_rows, float grad_scale, float *loss_sum,
@@ -557,7 +569,6 @@ int spex::gated_batch_fwd_layers(const spex_graph_t *g, const float *X, const fl
                    "spex_gated_batch_fwd_f32: NULL argument");
     SPEX_CHECK_ARG(B >= 0 && n_user_rows >= 0 && n_user_rows <= g->n_rows && g->n_rows == g->n_cols,
                    "spex_gated_batch_fwd_f32: B=%d n_user_rows=%d on a %d x %d graph", B, n_user_rows, g->n_rows, g->n_cols);
-    SPEX_CHECK_ARG(g->mask_mode == 0, "spex_gated_batch_fwd_f32: edge dropout is not supported here");
     if (d != kWave) {
         spex::set_error("spex_gated_batch_fwd_f32: d == 64 only (got %d)", d);
         return SPEX_ERR_UNSUPPORTED;
@@ -565,7 +576,7 @@ int spex::gated_batch_fwd_layers(const spex_graph_t *g, const float *X, const fl
     if (B == 0 || g->n_rows == 0) return SPEX_OK;
     hipLaunchKernelGGL(gated_batch_fwd_kernel, dim3((unsigned)B), dim3(kWave * kWgWaves), 0, (hipStream_t)stream, g->rowptr, g->col, g->val,
                        g->n_rows, n_user_rows, X, acc_in, acc_div, raw, att_u, att_i, users, items, labels, B, grad_scale, loss_sum, lo_batch,
-                       grad_slots, loss_per_sample, acc2, acc3);
+                       grad_slots, loss_per_sample, acc2, acc3, edge_drop_of(g));
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }
@@ -579,11 +590,6 @@ extern "C" int spex_gated_batch_f32(const spex_graph_t *g, const float *X, const
     SPEX_CHECK_ARG(g_prop, "spex_gated_batch_f32: NULL g_prop");
     return spex::gated_batch_push_layers(g, X, acc_in, nullptr, nullptr, acc_div, raw, att_u, att_i, users, items, labels, B, n_user_rows,
                                          grad_scale, push_scale, loss_sum, g_prop, G, g_raw, g_att, n_att_copies, d, stream);
-}
-
-static spex::EdgeDrop edge_drop_of(const spex_graph_t *g)
-{
-    return spex::EdgeDrop{g->keep, g->edge_id, g->mask_mode, g->keep_prob, (uint32_t)g->seed, (uint32_t)(g->seed >> 32)};
 }
 
 static int batch_env(const char *name, int dflt, int lo, int hi)
@@ -604,7 +610,6 @@ int spex::gated_batch_push_layers(const spex_graph_t *g, const float *X, const f
     SPEX_CHECK_ARG(n_att_copies >= 1, "spex_gated_batch_f32: n_att_copies=%d", n_att_copies);
     SPEX_CHECK_ARG(B >= 0 && n_user_rows >= 0 && n_user_rows <= g->n_rows && g->n_rows == g->n_cols,
                    "spex_gated_batch_f32: B=%d n_user_rows=%d on a %d x %d graph", B, n_user_rows, g->n_rows, g->n_cols);
-    SPEX_CHECK_ARG(g->mask_mode == 0, "spex_gated_batch_f32: edge dropout is not supported here");
     SPEX_CHECK_ARG(G != g_prop && G != g_raw && g_prop != g_raw, "spex_gated_batch_f32: g_prop, G and g_raw are three tables");
     if (d != kWave) {
         spex::set_error("spex_gated_batch_f32: d == 64 only (got %d)", d);
@@ -615,7 +620,7 @@ int spex::gated_batch_push_layers(const spex_graph_t *g, const float *X, const f
     static const int parts = batch_env("SPEX_BATCH_PARTS", 3, 1, 16);
     hipLaunchKernelGGL(gated_batch_push_kernel, dim3((unsigned)B * parts), dim3(kWave * kWgWaves), 0, (hipStream_t)stream, g->rowptr, g->col,
                        g->val, g->n_rows, n_user_rows, X, acc_in, acc_div, raw, att_u, att_i, users, items, labels, parts, runs_per_part,
-                       grad_scale, push_scale, loss_sum, g_prop, G, g_raw, g_att, n_att_copies, acc2, acc3);
+                       grad_scale, push_scale, loss_sum, g_prop, G, g_raw, g_att, n_att_copies, acc2, acc3, edge_drop_of(g));
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }

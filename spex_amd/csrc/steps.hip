@@ -291,7 +291,12 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
     const int32_t d = 64, N = g->n_rows, n_u = s->n_user_rows, L = s->L, H = s->n_heads;
     SPEX_CHECK_ARG(g->n_rows == g->n_cols && gt->n_rows == N && gt->n_cols == N, "spex_dual_task_step_f32: square graphs of one size");
     SPEX_CHECK_ARG(s->d == 64 && L >= 1 && n_u >= 2 && n_u <= N, "spex_dual_task_step_f32: d=%d L=%d n_user_rows=%d (needs d == 64)", s->d, L, n_u);
-    SPEX_CHECK_ARG(g->mask_mode == 0 && gt->mask_mode == 0, "spex_dual_task_step_f32: edge dropout is not supported in the one-call step");
+    // edge dropout on the rec branch (model_expert_s.py:104-109; the trust branch reads the raw user table): as in the LightGCN step —
+    // the same mask on both handles, graph_t the transposed handle with the edge-id permutation, L >= 2
+    SPEX_CHECK_ARG(g->mask_mode == gt->mask_mode && (g->mask_mode == 0 || (g->keep_prob == gt->keep_prob && g->seed == gt->seed && g->keep == gt->keep)),
+                   "spex_dual_task_step_f32: graph and graph_t must carry the same edge-dropout mask");
+    SPEX_CHECK_ARG(g->mask_mode == 0 || (gt != g && L >= 2),
+                   "spex_dual_task_step_f32: edge dropout needs L >= 2 and graph_t = the transposed handle (with its edge-id permutation)");
     const int64_t n_trust = spex_trust_param_count(d, H);
     SPEX_CHECK_ARG(n_trust > 0, "spex_dual_task_step_f32: unsupported number of heads %d", H);
     const bool det = (s->flags & SPEX_STEP_DETERMINISTIC) != 0;
@@ -355,7 +360,8 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
             else SPEX_TRY(spex_spmm_f32(g, cur, nxt, nullptr, 1.0f, l == 0 ? E0 : s->light, s->light, 1.0f, d, stream));
             cur = nxt;
         }
-        static const bool fused_middle = []() { const char *e = getenv("SPEX_DUAL_FUSED_MIDDLE"); return !(e && e[0] == '0'); }();
+        static const bool fused_middle_env = []() { const char *e = getenv("SPEX_DUAL_FUSED_MIDDLE"); return !(e && e[0] == '0'); }();
+        const bool fused_middle = fused_middle_env || g->mask_mode != 0;      // (the three-launch middle's push takes no mask)
         if (!det && L >= 2 && fused_middle) {
             // (fast path: last layer at the batch's rows + layer mean + gate + scores + the gate's backward + the first backward
             //  product in push form — ONE launch, batch.hip: gated_batch_push_kernel; then the L-1 pull-form launches on A^T, the

@@ -610,7 +610,9 @@ class DualTaskStepper:
         self.loss, self.loss_acc, self.precision = z(2), z(2), z(2, 2)
         self.t = 0
         self._desc = None
-        self._graph_t = model.Graph            # the LightGCN adjacency is symmetric
+        # the LightGCN adjacency is symmetric — but a MASKED one is not: a model built with --dropout 1 gets the transposed handle
+        # (with its edge-id permutation) for the backward products, so that edge dropout can be set per step (set_edge_dropout)
+        self._graph_t = model._transposed() if getattr(model.args_r, "dropout", 0) else model.Graph
         self.refresh_precision()
 
     def _slots(self, n):
@@ -647,8 +649,8 @@ class DualTaskStepper:
                     raise ValueError("DualTaskStepper.step: seq / seq_l / targets must be contiguous device int64 tensors")
             if seq.shape[1] != self.path_len or seq_l.numel() != T or targets.numel() != T or T > self.path_capacity:
                 raise ValueError(f"DualTaskStepper.step: {T} paths of width {seq.shape[1]} (capacity {self.path_capacity} x {self.path_len})")
-        if getattr(self.model.Graph, "mask_mode", 0) != 0:
-            raise ValueError("DualTaskStepper.step: edge dropout is not supported in the one-call step")
+        if getattr(self.model.Graph, "mask_mode", 0) != 0 and (self._graph_t is self.model.Graph or self.L < 2):
+            raise ValueError("DualTaskStepper.step: edge dropout needs the transposed handle (a model built with --dropout 1) and L >= 2")
         self._slots(2 * B)
         if self._desc is None:
             p = lambda t: t.data_ptr()
@@ -677,6 +679,19 @@ class DualTaskStepper:
         self.t = dsc.t
         _bump(self.arena, self.m, self.v, self.loss_acc)
         self.model._cache = None
+
+    def set_edge_dropout(self, mask=None):
+        """The next steps' edge-dropout mask on both handles (an edge_dropout_mask(...) tuple; None: off) — model_expert_s.py:104-109."""
+        g, gt = self.model.Graph, self._graph_t
+        if mask is None:
+            g.set_edge_mask(0)
+            if gt is not g:
+                gt.set_edge_mask(0)
+            return
+        if gt is g:
+            raise ValueError("DualTaskStepper.set_edge_dropout: build the model with --dropout 1 (the stepper then keeps the transposed handle)")
+        g.set_edge_mask(*mask)
+        gt.set_edge_mask(*mask)
 
     def join(self):
         """Order everything a pipelined step left on the side stream in front of the current stream (spex_dual_task_step_join);
@@ -709,13 +724,15 @@ def dual_task_epoch_paths(batch_users, by_user, cap):
 
 
 def train_epoch_dual(stepper, train_data, trust_data, by_user, cap, batch_size=256, resample=True, pause_gc=True, max_steps=None,
-                     cum_every=None, cum_out=None, n_paths_out=None):
+                     cum_every=None, cum_out=None, n_paths_out=None, edge_dropout=None):
     """Train() of main_auto_expert_s.py:53-91 on the device: negatives drawn like the reference's (`ng_sample`), the
     epoch's sample order is the shuffled DataLoader's own, the per-batch paths are chosen by the reference's rule
     (dual_task_epoch_paths), everything is moved to the device once and every batch is one DualTaskStepper.step.
     Returns (sum of loss1, sum of loss2) over the epoch's steps as a device tensor.  cum_every / cum_out: every cum_every steps a
     copy of the running (loss1, loss2) sums is appended to the list cum_out (device tensors: no synchronisation); n_paths_out: a
-    list that receives every step's path count."""
+    list that receives every step's path count.  edge_dropout: None, or (keep_prob, stream[, seed]) for `--dropout 1 --keepprob p`
+    (README.md:119-123; stream "reference" replays the reference's per-step `torch.rand(nnz)`, "philox" draws in-kernel) — a fresh
+    mask on the rec branch's handles per step; the model must have been built with --dropout 1."""
     import numpy as np
     if resample:
         train_data.ng_sample()
@@ -752,6 +769,9 @@ def train_epoch_dual(stepper, train_data, trust_data, by_user, cap, batch_size=2
         p0 = 0
         for k, (s, c) in enumerate(zip(starts, chosen)):
             e, p1 = min(s + batch_size, n), p0 + len(c)
+            if edge_dropout is not None:
+                stepper.set_edge_dropout(edge_dropout_mask(stepper.model.Graph, edge_dropout[0], edge_dropout[1],
+                                                           edge_dropout[2] if len(edge_dropout) > 2 else 0, k + 1))
             stepper.step(users[s:e], items[s:e], labels[s:e], seq[p0:p1] if c else None, seq_l[p0:p1], tgt[p0:p1])
             p0 = p1
             if cum_every and cum_out is not None and (k + 1) % cum_every == 0:
@@ -761,6 +781,8 @@ def train_epoch_dual(stepper, train_data, trust_data, by_user, cap, batch_size=2
             n_paths_out.extend(len(c) for c in chosen)
     finally:
         stepper.join()
+        if edge_dropout is not None:
+            stepper.set_edge_dropout(None)
         stepper.pipelined = was_pipelined
         if gc_was_on:
             gc.enable()

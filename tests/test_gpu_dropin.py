@@ -991,6 +991,63 @@ def test_dual_task_on_device_epoch_matches_the_reference_epinion2(data_root, gol
     assert max(tab.values()) <= 1e-4, tab
 
 
+def test_dual_task_run_under_edge_dropout_matches_the_reference_epinion2(data_root, golden):
+    """G13-dropout: main_auto_expert_s.py under the reference's recommended `--dropout 1 --keepprob 0.3` (README.md:119-123) on
+    Epinion2, 150 steps minted from the reference's modules (oracle/gen_golden.py --stage dual-dropout-epinion2).  The rec branch's
+    edge mask is the reference's own per-step `torch.rand(nnz)` draw, replayed from the global CPU generator ("reference" stream) and
+    applied by the one-call step (spex_dual_task_step_f32 with the mask on both handles: the whole-graph launches AND the fused
+    batch kernel's last layer / push drop the same edges).  Every step's two losses, the learned task weights, both tasks' HR /
+    NDCG and the trained tables — through trainer.train_epoch_dual in the deterministic mode."""
+    import hashlib
+    from collections import defaultdict
+    import lg_parser
+    import utility1.dataloader as dl
+    import utility1.model_expert_s as mex
+    import utility1.utils as utils
+    from utility1.batch_test import rec_test
+    from utility2.batch_test_gnn import trust_test5
+    from utility2.utils import Data
+    from spex_amd.trainer import DualTaskStepper, train_epoch_dual
+    g = golden("dual_epinion2_dropout")
+    keep_prob, n_steps = float(g["keepprob"]), int(g["n_steps"])
+    raw_train, raw_test = _epinion2_trust_raw(golden)
+    args = lg_parser.parse_args_r(["--dataset", "epinion2", "--data_path", data_root, "--dropout", "1", "--keepprob", str(keep_prob)])
+    utils.set_seed(args.seed)
+    dataset = dl.Loader(args)
+    net = mex.LightGCN(args, dataset)
+    assert int(net.Graph.nnz) == int(g["nnz"])
+    td = dl.LightTrainData(dataset.rec_train_data, dataset.m_item, dataset.train_mat)
+    by_user = defaultdict(list)
+    for k, p in enumerate(raw_train[0]):
+        by_user[p[0]].append(k)
+    train2, test2 = Data(raw_train, dataset.n_users, shuffle=False), Data(raw_test, dataset.n_users, shuffle=False, test=True)
+    cap = 3 * int(g["trust_batch_size"])
+    net = net.to(DEV)
+    st = DualTaskStepper(net, path_capacity=cap, path_len=train2.len_max, lr=args.lr, deterministic=True)
+    cum, n_paths = [], []
+    train_epoch_dual(st, td, train2, by_user, cap, max_steps=n_steps, cum_every=1, cum_out=cum, n_paths_out=n_paths,
+                     edge_dropout=(keep_prob, "reference"))
+    assert st.t == n_steps and np.array_equal(np.asarray(n_paths), g["n_paths"])
+    cum = torch.stack(cum).cpu().numpy().astype(np.float64)
+    per_step = np.diff(np.concatenate([np.zeros((1, 2)), cum]), axis=0)
+    d1, d2 = np.abs(per_step[:, 0] - g["step_loss1"]), np.abs(per_step[:, 1] - g["step_loss2"]) / g["step_loss2"]
+    # (per-step values are differences of an fp32 running sum that reaches ~100 / ~900: 1e-5 / 1e-4 of resolution)
+    assert d1.max() <= 5e-5, (int(d1.argmax()), float(d1.max()))
+    assert d2.max() <= 2e-4, (int(d2.argmax()), float(d2.max()))
+    assert abs(cum[-1, 0] - g["step_loss1"].sum()) <= 2e-5 * g["step_loss1"].sum()
+    assert abs(cum[-1, 1] - g["step_loss2"].sum()) <= 2e-5 * g["step_loss2"].sum()
+    assert np.abs(net.task_weights.detach().cpu().numpy() - g["task_weights"]).max() <= 5e-6
+    net.eval()
+    with torch.no_grad():
+        ret = rec_test(net, dataset.testRatings, dataset.testNegatives)
+        tr5 = np.asarray(trust_test5(net, test2))
+    assert max(np.abs(ret["recall"] - g["rec_recall"]).max(), np.abs(ret["ndcg"] - g["rec_ndcg"]).max()) <= 1e-4
+    assert np.abs(tr5 - g["trust"]).max() <= 1e-4
+    uw, iw = net.embedding_user.weight.detach().cpu().numpy(), net.embedding_item.weight.detach().cpu().numpy()
+    assert rel_err(uw[g["rows_u"]], g["user_w"]) <= 1e-4 and rel_err(iw[g["rows_i"]], g["item_w"]) <= 1e-4
+    assert rel_err(net.w.detach().cpu().numpy(), g["w"]) <= 1e-4
+
+
 def test_dual_task_teacher_forced_checkpoint_epinion2(data_root, golden):
     """Teacher forcing at TRAINED weights for config 5: the reference's full dual-task parameter state after 600 steps of
     main_auto_expert_s.py on Epinion2 (oracle/gen_golden.py --stage epochs-dual-epinion2[-full] -> dual_epinion2_ckpt.npz: all

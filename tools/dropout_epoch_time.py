@@ -42,3 +42,30 @@ for name, stream, one_call in (("no dropout, one-call step", None, True), ("Phil
     torch.cuda.synchronize()
     print("%-44s %.1f us/step" % (name, (time.perf_counter() - t0) / steps * 1e6))
     st.graph.set_edge_mask(0); st.graph_t.set_edge_mask(0)
+
+# ---- the dual-task step (main_auto_expert_s.py) under the same dropout: the rec branch's handles masked, 15 paths per step
+import utility1.model_expert_s as mex
+from spex_amd.trainer import DualTaskStepper
+for name, drop in (("dual-task step, no dropout", False), ("dual-task step, Philox mask", True)):
+    dargs = lg_parser.parse_args_r(["--dataset", "epinion2", "--data_path", root] + (["--dropout", "1", "--keepprob", "0.3"] if drop else []))
+    utils.set_seed(dargs.seed)
+    dnet = mex.LightGCN(dargs, ds).cuda()
+    T, P_LEN = 15, 6
+    dst = DualTaskStepper(dnet, path_capacity=T, path_len=P_LEN, lr=1e-3)
+    plen = rng.integers(2, P_LEN + 1, T)
+    seq = np.full((T, P_LEN), ds.n_users, dtype=np.int64)
+    for r, l in enumerate(plen):
+        seq[r, :l] = rng.choice(ds.n_users, size=l, replace=False)
+    seq_d, len_d = torch.from_numpy(seq).to(dev), torch.from_numpy(plen.astype(np.int64)).to(dev)
+    tgt = torch.from_numpy(rng.integers(0, ds.n_users, T)).to(dev)
+    def dstep(k):
+        if drop:
+            dst.set_edge_dropout(edge_dropout_mask(dnet.Graph, 0.3, "philox", 7, k + 1))
+        dst.step(u[k & 63], i[k & 63], y[k & 63], seq_d, len_d, tgt)
+    for k in range(50): dstep(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps): dstep(k)
+    torch.cuda.synchronize()
+    print("%-44s %.1f us/step" % (name, (time.perf_counter() - t0) / steps * 1e6))
+    dst.set_edge_dropout(None)
