@@ -1046,6 +1046,38 @@ def test_dual_task_run_under_edge_dropout_matches_the_reference_epinion2(data_ro
     uw, iw = net.embedding_user.weight.detach().cpu().numpy(), net.embedding_item.weight.detach().cpu().numpy()
     assert rel_err(uw[g["rows_u"]], g["user_w"]) <= 1e-4 and rel_err(iw[g["rows_i"]], g["item_w"]) <= 1e-4
     assert rel_err(net.w.detach().cpu().numpy(), g["w"]) <= 1e-4
+    # the same run's first 40 steps through the UNCHANGED driver's loop (main_auto_expert_s.py:60-89 on the drop-in model: autograd,
+    # torch.optim.Adam, the model drawing its mask from the reference stream inside forward)
+    import random
+    from torch.utils.data import DataLoader
+    utils.set_seed(args.seed)
+    dataset2 = dl.Loader(args)
+    net2 = mex.LightGCN(args, dataset2).to(DEV)
+    net2.dropout_stream = "reference"
+    td2 = dl.LightTrainData(dataset2.rec_train_data, dataset2.m_item, dataset2.train_mat)
+    loader = DataLoader(td2, batch_size=256, shuffle=True)
+    opt = torch.optim.Adam(net2.parameters(), lr=args.lr)
+    loader.dataset.ng_sample()
+    net2.train()
+    for step, (user, item, label) in enumerate(loader):
+        if step == 40:
+            break
+        if step == 0:
+            assert np.array_equal(torch.stack([user, item, label]).numpy(), g["first_batch"])
+        opt.zero_grad()
+        chosen = []
+        for uu in set(user.numpy().tolist()):
+            chosen.extend(by_user[uu])
+        if len(chosen) > cap:
+            chosen = random.sample(chosen, cap)
+        assert len(chosen) == int(g["n_paths"][step])
+        l1, l2 = net2(users=user.to(DEV), items=item.to(DEV), labels=label.to(DEV), slice_indices=np.array(chosen, dtype=int),
+                      trust_data=train2, flag=0)
+        w_ = net2.task_weights
+        (torch.exp(-2 * w_[0]) * l1 + torch.exp(-2 * w_[1]) * l2 + 2 * 6 * len(user) * w_[0] + len(chosen) * w_[1]).backward()
+        assert abs(l1.item() - g["step_loss1"][step]) <= 2e-5, (step, l1.item(), g["step_loss1"][step])
+        assert abs(l2.item() - g["step_loss2"][step]) <= 1e-4 * g["step_loss2"][step], (step, l2.item(), g["step_loss2"][step])
+        opt.step()
 
 
 def test_dual_task_teacher_forced_checkpoint_epinion2(data_root, golden):
