@@ -12,6 +12,9 @@ import argparse, os, sys, tempfile
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "spex_amd", "dropin"))
+if os.environ.get("SPEX_LIB"):
+    from spex_amd import _lib as _l
+    _l.LIB_PATH = os.environ["SPEX_LIB"]          # A/B against another build of the library
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=2000)
 ap.add_argument("--reps", type=int, default=5)

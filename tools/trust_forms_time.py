@@ -10,6 +10,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "one":
     import numpy as np, torch
     sys.path.insert(0, ROOT)
     from spex_amd import _lib, ops
+    if os.environ.get("SPEX_LIB"):
+        _lib.LIB_PATH = os.environ["SPEX_LIB"]          # A/B against another build of the library
     from spex_amd.graph import _launch, _ptr
     n_users, T, L, H = int(sys.argv[2]), int(sys.argv[3]), 6, 3
     dev = torch.device("cuda:0")
