@@ -478,6 +478,19 @@ def main():
                 fnd()
             aux["weibo_shape"]["dual_task_step_ms_B256_T15"] = time_events(fnd, 300)
             del wnet, wdst, wst, wgraph
+            # BASELINE configs[3] on its own shape (Trust_SPEX/code/main_trust.py:44: 8 930 Twitter users): the NGCF training step
+            tu_, ti_ = synthetic_interactions(8930, 20000, 400000, seed=9, sigma=1.4)
+            tcsr = ngcf_norm_adj(tu_.numpy(), ti_.numpy(), 8930, 20000)
+            tnet = NGCF({"n_users": 8930, "n_items": 20000,
+                         "norm_adj": sp.csr_matrix((tcsr[2], tcsr[1], tcsr[0]), shape=(28930, 28930))}, dev, nargs).to(dev)
+            tst = NGCFStepper(tnet, lr=1e-3)
+            tub = torch.from_numpy(wrng.integers(0, 8930, 256)).to(dev)
+            for _ in range(10):
+                tst.step(tub, wib, yb, loss_acc=nacc)
+            aux["twitter_shape"] = {"graph": "8930 users x 20000 items, NGCF adjacency D^-1(A+I), nnz %d (synthetic), max row %d entries"
+                                             % (len(tcsr[1]), int(np.diff(tcsr[0]).max())),
+                                    "ngcf_stepper_step_ms_B256": time_events(lambda: tst.step(tub, wib, yb, loss_acc=nacc), 300)}
+            del tnet, tst
         except Exception as e:  # never lose the headline line to an auxiliary measurement
             aux["aux_error"] = repr(e)
 
