@@ -284,7 +284,8 @@ def test_reference_stream_dropout_mask_is_the_references_draw(golden):
     nn.init.xavier_uniform_(eu.weight, gain=1)
     nn.init.xavier_uniform_(ei.weight, gain=1)
     dataloader_epoch_order(6 * 209304)
-    keep = (torch.rand(int(g["nnz"])) + float(g["keepprob"])).int().bool().numpy()
+    from spex_amd.trainer import reference_keep_mask
+    keep = reference_keep_mask([int(g["nnz"])], float(g["keepprob"]), "cpu").numpy().astype(bool)     # the product's own replay (host branch)
     assert int(keep.sum()) == int(g["mask0_kept"])
     assert np.array_equal(keep[:4096], g["mask0_head"])
     assert sha(keep.astype(np.uint8)) == str(g["mask0_sha"])
@@ -454,3 +455,15 @@ def test_threaded_packer_lays_the_matrix_out_like_the_single_thread_planner(flag
             os.environ["SPEX_BUILD_THREADS"] = old
     assert len(set(digests.values())) == 1, digests
     assert all(x != 0 for x in digests[1][:4])
+
+
+def test_reference_keep_mask_draws_fold_by_fold_like_the_reference():
+    """reference_keep_mask over several handles (--A_split: model.py:57-64 draws one mask per fold, in fold order) consumes the global
+    generator exactly like the per-fold `torch.rand(len(values)) + keep_prob` calls it replaces."""
+    from spex_amd.trainer import reference_keep_mask
+    torch.manual_seed(77)
+    want = torch.cat([(torch.rand(n) + 0.3).int().bool() for n in (1000, 7, 333)]).numpy()
+    after = torch.rand(1).item()
+    torch.manual_seed(77)
+    got = reference_keep_mask([1000, 7, 333], 0.3, "cpu").numpy().astype(bool)
+    assert np.array_equal(got, want) and torch.rand(1).item() == after
