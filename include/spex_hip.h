@@ -238,6 +238,13 @@ int spex_adam_step_f32(float *p, const float *g, float *m, float *v, int64_t n, 
 int spex_adam_step_sum_f32(float *p, const float *g_parts, int32_t n_parts, int64_t part_stride, float *m, float *v, int64_t n,
                            int32_t t, float lr, float beta1, float beta2, float eps, void *stream);
 
+/* Validation hook for the NGCF entries' message dropout: while d_keep != NULL (per host thread), every NGCF layer entry called with
+ * p_drop > 0 keeps element (row, col) iff d_keep[row' * 64 + col] != 0 (row' = the row in the reference's numbering, see pad_row)
+ * instead of the counter-based draw — so that a run can use the REFERENCE's own nn.Dropout noise (main_rec.py:81:
+ * `torch.empty(N, 64).bernoulli_(1 - p)` from the global CPU generator, drawn by the host where the reference draws it and uploaded
+ * as bytes).  The pointer is read when a launch is queued; NULL restores the counter-based masks. */
+int spex_ngcf_message_mask(const uint8_t *d_keep);
+
 /* ------------------------------------------------------------------------------------------------ NGCF layer
  * Replaces NGCF_SPEX/code/main_rec.py:77-83 for one layer, given side = A ego from spex_spmm_f32 (:76):
  *   s    = LeakyReLU(side W_gc^T + b_gc);  b = LeakyReLU((ego * side) W_bi^T + b_bi);  e1 = dropout_p(s + b)

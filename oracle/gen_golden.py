@@ -1217,7 +1217,7 @@ def write_small_ngcf(rec_dir):
     return dict(train_pairs=pairs, test_pos=np.asarray(test_pos, np.int64), test_neg=np.stack(test_neg).astype(np.int64))
 
 
-def stage_ngcf_epochs(ds, n_epochs, ckpt_steps=()):
+def stage_ngcf_epochs(ds, n_epochs, ckpt_steps=(), native_dropout=False, max_steps=None):
     """G12-NGCF: the reference's training run — NGCF_SPEX/code/main_rec.py:18-27,116-148 (setup_seed, the module-level
     Data singleton of utility/batch_test.py, Model_Wrapper, Adam, train(): load_train_data per epoch, shuffled
     DataLoader, loss.backward, step; test()) — driven from the reference's modules on CPU.
@@ -1228,7 +1228,10 @@ def stage_ngcf_epochs(ds, n_epochs, ckpt_steps=()):
       * each nn.Dropout(p) of the model -> the same arithmetic (x * (keep / (1 - p))) with the keep mask taken from a
         counter-based generator (message_keep_mask: seed, step, layer) instead of torch's global RNG.
     Also stored: the sampler's first epoch (G6-NGCF), the three adjacency matrices' hashes (G10+), test() after every
-    epoch, the learned weights."""
+    epoch, the learned weights.
+    native_dropout: the second substitution is NOT made — the model keeps its nn.Dropout modules and their noise comes from
+    torch's global generator (at::dropout: empty_like(x).bernoulli_(1 - p), one draw of [N, 64] per layer and step) — and every
+    step's loss is stored; max_steps stops the run inside epoch 0.  Written to ngcf_<ds>_native_dropout.npz."""
     import random
     import numpy as np
     import torch
@@ -1303,7 +1306,8 @@ def stage_ngcf_epochs(ds, n_epochs, ckpt_steps=()):
             noise.div_(1 - self.p)                               # what at::dropout does to its Bernoulli noise
             return x * noise
     for i in range(len(model.dropout_list)):
-        model.dropout_list[i] = InjectedDropout(p_drop[i], i)
+        if not native_dropout:
+            model.dropout_list[i] = InjectedDropout(p_drop[i], i)
 
     losses, recalls, ndcgs, first_batch, step_losses = [], [], [], None, []
     import time
@@ -1366,9 +1370,11 @@ def stage_ngcf_epochs(ds, n_epochs, ckpt_steps=()):
                                 np.stack([user.numpy(), item.numpy(), labels_list.numpy().astype(np.int64)]), loss.item())
             optimizer.step()
             total_loss += loss.item()
-            if state["step"] < 32:
+            if state["step"] < 32 or native_dropout:
                 step_losses.append(loss.item())
             state["step"] += 1
+            if max_steps is not None and state["step"] >= max_steps:
+                break
             maybe_eval()
             if state["step"] % 500 == 0:
                 print("step", state["step"], "loss sum", total_loss, "%.0f s" % (time.time() - t0), flush=True)
@@ -1402,7 +1408,8 @@ def stage_ngcf_epochs(ds, n_epochs, ckpt_steps=()):
     out.update(small)
     out.update({"final_" + k.replace(".", "__"): v.detach().numpy().copy() for k, v in model.state_dict().items()
                 if v.numel() <= 64 * 64})
-    np.savez_compressed(os.path.join(GOLD, f"ngcf_{ds}_epochs.npz"), seed=2020, drop_seed=DROP_SEED, lr=margs.lr,
+    np.savez_compressed(os.path.join(GOLD, f"ngcf_{ds}_native_dropout.npz" if native_dropout else f"ngcf_{ds}_epochs.npz"), seed=2020,
+                        drop_seed=DROP_SEED, lr=margs.lr,
                         mess_dropout=np.asarray(p_drop), n_steps=state["step"],
                         losses=np.asarray(losses, np.float64), step_losses=np.asarray(step_losses, np.float64),
                         recall=np.asarray(recalls, np.float64), ndcg=np.asarray(ndcgs, np.float64),
@@ -1443,6 +1450,8 @@ def main():
         stage_ngcf_epochs("small", 3)
     elif a.stage == "ngcf-epochs-epinion2":  # ~15 min of CPU: one full NGCF epoch (4.7 k steps) + test() through the reference
         stage_ngcf_epochs("epinion2", 1, ckpt_steps=(500, 1500))   # + teacher-forced checkpoints (ngcf_epinion2_ckpt.npz)
+    elif a.stage == "ngcf-native-dropout-epinion2":   # ~1 min of CPU: 300 steps of the UNMODIFIED model (torch's own dropout stream) + test()
+        stage_ngcf_epochs("epinion2", 1, native_dropout=True, max_steps=300)
     elif a.stage == "trust-epinion2":
         stage_trust_epinion2()
     elif a.stage == "epochs-dual-epinion2":  # ~20 min of CPU: 600 dual-task steps + both evaluations through the reference

@@ -47,6 +47,7 @@ SIGNATURES = {
     "spex_adam_step_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp]),
     "spex_ngcf_layer_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_f32,
                                            c_vp]),
+    "spex_ngcf_message_mask": (ctypes.c_int, [c_vp]),
     "spex_ngcf_layer_fwd_rows_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32,
                                                     ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, c_i32, c_vp, c_i32, c_i64, c_vp, c_i32,
                                                     c_i64, c_vp]),

@@ -46,11 +46,13 @@ struct MsgDrop {
     float p, scale;
     uint32_t k0, k1, step, layer;
     int pad_row;
+    const uint8_t *mask;     // validation hook (spex_ngcf_message_mask): keep bytes [rows in the reference's numbering][64], or NULL
 };
 
 __device__ __forceinline__ bool msg_keep(const MsgDrop &dr, int row, int col)
 {
     const uint32_t e = (uint32_t)(row - (row > dr.pad_row ? 1 : 0)) * 64u + (uint32_t)col;
+    if (dr.mask) return dr.mask[e] != 0;
     uint32_t c0 = e >> 2, c1 = dr.step, c2 = dr.layer, c3 = 0u, k0 = dr.k0, k1 = dr.k1;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
@@ -1439,9 +1441,20 @@ inline unsigned grid_for_rows(int n)
 
 extern "C" int32_t spex_ngcf_layer_bwd_rows_parts(int32_t n_slots) { return (n_slots + 15) / 16; }   // one block per 16-slot tile
 
+// Validation hook: while a mask is set (per host thread), every NGCF layer entry takes its message-dropout keep decisions from it
+// instead of the counter-based draw — e.g. the reference's own nn.Dropout noise, `torch.empty(N, 64).bernoulli_(1 - p)` drawn on
+// the CPU from the global generator where main_rec.py:81 draws it, uploaded as bytes.  The pointer is read when a launch is queued.
+static thread_local const uint8_t *t_msg_mask = nullptr;
+extern "C" int spex_ngcf_message_mask(const uint8_t *d_keep)
+{
+    t_msg_mask = d_keep;
+    return SPEX_OK;
+}
+
 static MsgDrop make_drop(float p_drop, uint64_t seed, uint32_t step, uint32_t layer, int32_t pad_row)
 {
     MsgDrop d;
+    d.mask = p_drop > 0.0f ? t_msg_mask : nullptr;
     d.p = p_drop > 0.0f ? p_drop : 0.0f;
     d.scale = 1.0f / (float)(1.0 - (double)d.p);          // at::dropout divides its Bernoulli noise by (1 - p) once
     d.k0 = (uint32_t)seed;

@@ -314,7 +314,9 @@ class NGCFStepper:
     model: a spex_amd.ngcf.NGCF with 64-wide layers; its parameters are trained IN PLACE (the table is the module's own
     flat buffer; the layer weights are re-homed into one flat block whose views replace the nn.Linear parameters' data),
     so `model` can be evaluated / saved as usual at any point.  Message dropout uses the model's counter-based stream
-    (message_dropout_seed, dropout_step).
+    (message_dropout_seed, dropout_step); `stepper.dropout_stream = "reference"` (single-layer one-call step): the noise is the
+    reference's own nn.Dropout draw instead — empty(N, 64).bernoulli_(1 - p) from the global CPU generator, once per step where
+    main_rec.py:81 draws it, uploaded and read by the kernels through spex_ngcf_message_mask (validation mode: ~1.5 ms per step).
     """
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, deterministic=None):
@@ -479,8 +481,25 @@ def _ngcf_step_one_call(self, users, items, labels, acc):
             self._desc.flags = _lib.STEP_DETERMINISTIC
     d = self._desc
     d.t, d.lr, d.dropout_step, d.seed, d.p_drop = self.t, self.lr, m.dropout_step, int(m.message_dropout_seed), float(m.mess_dropout[0])
-    _launch(self.E0.device, "spex_ngcf_step_bce_f32", ctypes.byref(d), ctypes.c_void_p(users.data_ptr()),
-            ctypes.c_void_p(items.data_ptr()), ctypes.c_void_p(labels.data_ptr()), B, ctypes.c_void_p(acc.data_ptr()))
+    ref_stream = getattr(self, "dropout_stream", "counter") == "reference" and m.mess_dropout[0] > 0
+    if ref_stream:
+        # validation mode: the step's message-dropout noise is the REFERENCE's — nn.Dropout on the [N, 64] layer output
+        # (main_rec.py:81) is at::dropout: empty_like(x).bernoulli_(1 - p) from the global CPU generator.  The same call on a
+        # reused pinned buffer consumes the generator identically; the bytes go up and the kernels read them through
+        # spex_ngcf_message_mask instead of drawing their counter-based mask.
+        n_ref = m.n_users + m.n_items
+        buf = getattr(self, "_noise_host", None)
+        if buf is None or buf.shape[0] != n_ref:
+            buf = self._noise_host = torch.empty((n_ref, 64), dtype=torch.float32).pin_memory()
+        buf.bernoulli_(1.0 - float(m.mess_dropout[0]))
+        self._msg_mask = (buf.to(self.E0.device) != 0).to(torch.uint8)
+        _lib.call("spex_ngcf_message_mask", ctypes.c_void_p(self._msg_mask.data_ptr()))
+    try:
+        _launch(self.E0.device, "spex_ngcf_step_bce_f32", ctypes.byref(d), ctypes.c_void_p(users.data_ptr()),
+                ctypes.c_void_p(items.data_ptr()), ctypes.c_void_p(labels.data_ptr()), B, ctypes.c_void_p(acc.data_ptr()))
+    finally:
+        if ref_stream:
+            _lib.call("spex_ngcf_message_mask", None)
     self.t, m.dropout_step = d.t, d.dropout_step
     _bump(self.E0, self.W, acc)
     return acc
@@ -491,13 +510,15 @@ NGCFStepper._step_one_call = _ngcf_step_one_call
 NGCFStepper.__del__ = _drop_desc
 
 
-def train_epoch_ngcf(stepper, data, batch_size=None, pause_gc=True, callbacks=None, step_losses=None):
+def train_epoch_ngcf(stepper, data, batch_size=None, pause_gc=True, callbacks=None, step_losses=None, max_steps=None):
     """train() of NGCF_SPEX/code/main_rec.py:116-131 without the per-step host work of its DataLoader loop: the epoch's
     samples are drawn like the reference's (Data.sample_epoch: `random` stream), the sample order is the DataLoader's own
     (dataloader_epoch_order: global torch RNG), the shuffled epoch is moved to the device once, and every batch is one
     NGCFStepper.step.  Returns the epoch's summed per-batch mean loss (main_rec.py:129 accumulates the same sum).
     callbacks: {k: fn} — fn() is called in front of the epoch's k-th batch (e.g. a mid-epoch evaluation; it must leave the
-    model in training mode); step_losses: a list that receives every step's mean loss (synchronises per step)."""
+    model in training mode); step_losses: a list that receives every step's mean loss (synchronises per step); max_steps: stop
+    after that many batches.  (stepper.dropout_stream = "reference": the message-dropout noise is the reference's own per-step
+    draw from the global generator — a validation mode, see NGCFStepper.)"""
     us, vs, rs = data.sample_epoch()
     n = len(us)
     bs = batch_size or data.batch_size
@@ -512,6 +533,8 @@ def train_epoch_ngcf(stepper, data, batch_size=None, pause_gc=True, callbacks=No
     acc = torch.zeros(2, 1, dtype=torch.float32, device=dev)
     try:
         for k, s in enumerate(range(0, n, bs)):
+            if max_steps is not None and k >= max_steps:
+                break
             if callbacks and k in callbacks:
                 callbacks[k]()
             e = min(s + bs, n)
@@ -538,7 +561,7 @@ class DualTaskStepper:
 
     model: a `utility1.model_expert_s.LightGCN` on the GPU (hidden size 64).  Its parameters are re-homed into one flat arena
     [table | trust block | att_exp1 | att_exp2 | task_weights] and trained IN PLACE, so `model` can be evaluated
-    (rec_test, trust_test5) or saved at any point.  No edge dropout (the one-call step does not support it).
+    (rec_test, trust_test5) or saved at any point.  Edge dropout: a model built with --dropout 1, set_edge_dropout per step.
     path_capacity: the largest number of paths a step may carry (3 x trust_batch_size in the reference driver, :70-71)."""
 
     def __init__(self, model, path_capacity, path_len, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, n_rec=5, batch_capacity=256,

@@ -323,6 +323,35 @@ def _ngcf_epinion2_model(g, root):
     return data, model, batch_test
 
 
+def test_ngcf_run_with_the_references_own_dropout_noise(golden, ngcf_data_root):
+    """G12-NGCF with NOTHING substituted in the model: 300 steps of NGCF_SPEX/code/main_rec.py on Epinion2 minted with the
+    reference's nn.Dropout modules left alone (oracle/gen_golden.py --stage ngcf-native-dropout-epinion2: their noise is
+    at::dropout's empty_like(x).bernoulli_(1 - p) from torch's global generator, one [N, 64] draw per step).  The one-call step
+    replays that draw on the host at the same point of the stream and hands the bytes to the kernels (spex_ngcf_message_mask), so
+    the run drops the same activations: every step's loss, then test().  (The other NGCF goldens inject a counter-based mask INTO
+    the reference's model; this one pins the path against the unmodified model.)"""
+    from spex_amd.trainer import NGCFStepper, train_epoch_ngcf
+    g = golden("ngcf_epinion2_native_dropout")
+    data, model, batch_test = _ngcf_epinion2_model(g, ngcf_data_root)
+    st = NGCFStepper(model, lr=float(g["lr"]), deterministic=True)
+    st.dropout_stream = "reference"
+    n_steps = int(g["n_steps"])
+    step_losses = []
+    model.train()
+    total = train_epoch_ngcf(st, data, step_losses=step_losses, max_steps=n_steps).item()
+    assert len(step_losses) == n_steps == len(g["step_losses"])
+    dev = np.abs(np.asarray(step_losses) - g["step_losses"])
+    print("NGCF, reference's own dropout noise, %d steps: max per-step loss deviation %.2e, loss sum %.6f vs %.6f"
+          % (n_steps, dev.max(), total, float(g["losses"][0])))
+    assert dev.max() <= 5e-6, (int(dev.argmax()), float(dev.max()))           # measured on the MI355X: 6.0e-7 over the 300 steps
+    assert abs(total - g["losses"][0]) <= 2e-6 * g["losses"][0]              # (2e-8)
+    ret = batch_test.test(model, list(data.test_set.keys()), drop_flag=True)
+    got = np.concatenate([ret["recall"], ret["ndcg"]])
+    want = np.concatenate([g["recall"][0], g["ndcg"][0]])
+    print("HR / NDCG deviation after %d steps: %.2e" % (n_steps, np.abs(got - want).max()))
+    assert np.abs(got - want).max() <= 1e-4, (got, want)
+
+
 def _unit(w):
     w = np.asarray(w, np.float64)
     return w / np.sqrt((w ** 2).sum())
