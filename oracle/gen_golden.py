@@ -1451,6 +1451,9 @@ def main():
     elif a.stage == "ngcf-epochs-epinion2":  # ~15 min of CPU: one full NGCF epoch (4.7 k steps) + test() through the reference
         stage_ngcf_epochs("epinion2", 1, ckpt_steps=(500, 1500))   # + teacher-forced checkpoints (ngcf_epinion2_ckpt.npz)
     elif a.stage == "ngcf-native-dropout-epinion2":   # ~1 min of CPU: 300 steps of the UNMODIFIED model (torch's own dropout stream) + test()
+        # (300 steps: the window in which two fp32 runs of this model stay together — replayed on the GPU the per-step losses agree
+        #  to 6e-7 there; minted to 1 500 steps the same replay drifts 8e-5 / 2e-3 / 5e-3 per 300-step window, the growth the
+        #  reference's own two mints show, ngcf_epinion2_ref_spread.npz)
         stage_ngcf_epochs("epinion2", 1, native_dropout=True, max_steps=300)
     elif a.stage == "trust-epinion2":
         stage_trust_epinion2()

@@ -343,6 +343,9 @@ def test_ngcf_run_with_the_references_own_dropout_noise(golden, ngcf_data_root):
     dev = np.abs(np.asarray(step_losses) - g["step_losses"])
     print("NGCF, reference's own dropout noise, %d steps: max per-step loss deviation %.2e, loss sum %.6f vs %.6f"
           % (n_steps, dev.max(), total, float(g["losses"][0])))
+    # (300 steps is the window in which two fp32 runs of this model stay together: a 1 500-step mint replayed the same way drifts
+    #  8e-5 / 2e-3 / 5e-3 per 300-step window while its loss SUM still agrees to 1.8e-5 — the chaotic growth the reference's own two
+    #  mints show, not a desynchronised mask stream, which would jump at once)
     assert dev.max() <= 5e-6, (int(dev.argmax()), float(dev.max()))           # measured on the MI355X: 6.0e-7 over the 300 steps
     assert abs(total - g["losses"][0]) <= 2e-6 * g["losses"][0]              # (2e-8)
     ret = batch_test.test(model, list(data.test_set.keys()), drop_flag=True)
