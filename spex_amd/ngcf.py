@@ -118,7 +118,7 @@ class NGCF(nn.Module):
             raise RuntimeError("spex_amd NGCF runs on the GPU only: call .to('cuda') first (no CPU fallback)")
         drop = None
         if self.training and any(p > 0 for p in self.mess_dropout):
-            drop = (tuple(self.mess_dropout), self.message_dropout_seed, self.dropout_step)
+            drop = (tuple(self.mess_dropout), self.message_dropout_seed, self.dropout_step, self._reference_noise())
             self.dropout_step += 1
         if self._fused_ok():
             return ops.NGCFPropagate.apply(uw, iw, self.graph, self.graph_t, drop, self.n_users, *self._layer_weights())
@@ -131,6 +131,27 @@ class NGCF(nn.Module):
             ego = self.dropout_list[i](ego)
             parts.append(F.normalize(ego, p=2, dim=1))
         return torch.cat(parts, dim=1)
+
+    def _reference_noise(self):
+        """dropout_stream == "reference" (validation mode): the step's message-dropout noise is the reference's own — nn.Dropout on
+        each layer's [N, 64] output (main_rec.py:81) is at::dropout's empty_like(x).bernoulli_(1 - p) from torch's global CPU
+        generator, one draw per layer in layer order.  The same calls on reused pinned buffers consume the generator identically;
+        the keep bytes go up and the layer kernels (forward and the recomputing backward) read them through
+        spex_ngcf_message_mask.  Returns one uint8 [N, 64] tensor per layer (None where p == 0), or None for the counter stream."""
+        if getattr(self, "dropout_stream", "counter") != "reference":
+            return None
+        n_ref, dev = self.n_users + self.n_items, self.user_embedding.weight.device
+        bufs = self.__dict__.setdefault("_noise_host", {})
+        masks = []
+        for l, p in enumerate(self.mess_dropout[: self.n_layers]):
+            if p <= 0:
+                masks.append(None)
+                continue
+            if l not in bufs:
+                bufs[l] = torch.empty((n_ref, self.weight_size[l + 1]), dtype=torch.float32).pin_memory()
+            bufs[l].bernoulli_(1.0 - float(p))
+            masks.append((bufs[l].to(dev) != 0).to(torch.uint8))
+        return masks
 
     def forward(self, user, item, labels_list, flag):
         all_emb = self._all_embeddings()

@@ -742,12 +742,31 @@ class BPRLoss(torch.autograd.Function):
         return grad * g, None, None, None, None
 
 
+class _message_mask:
+    """While open, layer `l`'s kernels take their message-dropout keep decisions from drop[3][l] (uint8 [N, 64], rows in the
+    reference's numbering) instead of the counter-based draw: the spex_ngcf_message_mask validation hook, per host thread."""
+
+    def __init__(self, drop, l):
+        masks = drop[3] if drop is not None and len(drop) > 3 else None
+        self.mask = masks[l] if masks is not None else None
+
+    def __enter__(self):
+        if self.mask is not None:
+            _lib.call("spex_ngcf_message_mask", ctypes.c_void_p(self.mask.data_ptr()))
+
+    def __exit__(self, *exc):
+        if self.mask is not None:
+            _lib.call("spex_ngcf_message_mask", None)
+        return False
+
+
 class NGCFPropagate(torch.autograd.Function):
     """The NGCF propagation (Model_Wrapper.forward, NGCF_SPEX/code/main_rec.py:71-86) on one [N, d] table: per layer one
     SpMM (side = A ego) and one fused layer kernel; returns the concatenated table [N, d (L + 1)].  Backward per layer:
     one fused layer-backward kernel (recomputes the layer on the matrix cores, weight gradients included) and one SpMM
     on A^T with the direct part added in its epilogue.  d == 64 for every layer.
-    weights: flat tuple (W_gc_0, b_gc_0, W_bi_0, b_bi_0, W_gc_1, ...).  drop: None or (p_per_layer, seed, step)."""
+    weights: flat tuple (W_gc_0, b_gc_0, W_bi_0, b_bi_0, W_gc_1, ...).  drop: None or (p_per_layer, seed, step[, masks]) — masks:
+    None, or per layer a uint8 keep tensor that replaces the counter-based draw (NGCF.dropout_stream == "reference")."""
 
     @staticmethod
     def forward(ctx, user_w, item_w, graph, graph_t, drop, pad_row, *weights):
@@ -761,7 +780,8 @@ class NGCFPropagate(torch.autograd.Function):
             side = graph.spmm(egos[l])
             nxt = torch.empty_like(E0) if l < L - 1 else None
             dl = None if drop is None or drop[0][l] <= 0 else (drop[0][l], drop[1], drop[2])
-            ngcf_layer_fwd(egos[l], side, W_gc, b_gc, W_bi, b_bi, out, l, l == 0, nxt, drop=dl, pad_row=pad_row)
+            with _message_mask(drop, l):
+                ngcf_layer_fwd(egos[l], side, W_gc, b_gc, W_bi, b_bi, out, l, l == 0, nxt, drop=dl, pad_row=pad_row)
             sides.append(side)
             if nxt is not None:
                 egos.append(nxt)
@@ -787,8 +807,9 @@ class NGCFPropagate(torch.autograd.Function):
             g_side, g_ego = torch.empty_like(egos[l]), torch.empty_like(egos[l])
             gW_gc, gb_gc, gW_bi, gb_bi = (torch.zeros_like(w) for w in (W_gc, b_gc, W_bi, b_bi))
             dl = None if ctx.drop is None or ctx.drop[0][l] <= 0 else (ctx.drop[0][l], ctx.drop[1], ctx.drop[2])
-            ngcf_layer_bwd(egos[l], sides[l], W_gc, b_gc, W_bi, b_bi, g_all, l, g_next, g_side, g_ego, gW_gc, gb_gc, gW_bi,
-                           gb_bi, drop=dl, pad_row=ctx.pad_row)
+            with _message_mask(ctx.drop, l):
+                ngcf_layer_bwd(egos[l], sides[l], W_gc, b_gc, W_bi, b_bi, g_all, l, g_next, g_side, g_ego, gW_gc, gb_gc, gW_bi,
+                               gb_bi, drop=dl, pad_row=ctx.pad_row)
             g_next = ctx.graph_t.spmm(g_side, add_in=g_ego, add_div=1.0)      # d loss / d ego_l
             grads[4 * l:4 * l + 4] = [gW_gc, gb_gc, gW_bi, gb_bi]
         return (g_next[:u], g_next[u:], None, None, None, None, *grads)

@@ -355,6 +355,31 @@ def test_ngcf_run_with_the_references_own_dropout_noise(golden, ngcf_data_root):
     assert np.abs(got - want).max() <= 1e-4, (got, want)
 
 
+def test_ngcf_module_under_the_references_loop_with_its_own_dropout_noise(golden, ngcf_data_root):
+    """The same golden through the MODULE (spex_amd.ngcf.NGCF: autograd over the HIP kernels) under main_rec.py:116-148's own
+    loop — DataLoader(shuffle=True), torch Adam, zero_grad / backward / step — with `model.dropout_stream = "reference"`: the
+    module draws nn.Dropout's noise where the reference does, so nothing but the import line differs from the reference's run.
+    First 64 steps' losses (the shuffle and the per-step noise both come off torch's global generator: a desynchronised stream
+    would show at step 0 or 1)."""
+    g = golden("ngcf_epinion2_native_dropout")
+    data, model, _ = _ngcf_epinion2_model(g, ngcf_data_root)
+    model.dropout_stream = "reference"
+    opt = torch.optim.Adam(model.parameters(), lr=float(g["lr"]))
+    model.train()
+    losses = []
+    for k, (user, item, labels) in enumerate(data.load_train_data()):
+        if k == 64:
+            break
+        opt.zero_grad()
+        loss = model(user=user.to(DEV), item=item.to(DEV), labels_list=labels.to(DEV), flag=0)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    dev = np.abs(np.asarray(losses) - g["step_losses"][:64])
+    print("NGCF module, reference loop + reference noise, 64 steps: max per-step loss deviation %.2e" % dev.max())
+    assert dev.max() <= 5e-6, (int(dev.argmax()), float(dev.max()))
+
+
 def _unit(w):
     w = np.asarray(w, np.float64)
     return w / np.sqrt((w ** 2).sum())
