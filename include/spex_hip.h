@@ -596,9 +596,10 @@ int spex_path_attention_bwd_f32(const float *src, int64_t n_src_rows, const int6
  *
  * spex_trust_head_fwd_f32 (one launch): a2_out [B, 64] = the vector whose product with the user table gives the logits
  *   (:146-147) — the evaluation form (flag 2).
- * spex_trust_head_train_f32 (five launches: the forward chain per path; the logits of ALL paths against tiles of 32 users — the table
- *   is read once, by ~n_rows / 32 workgroups —; cross-entropy, d scores, the table gradient of each tile's own rows and per-tile
- *   partials of d a2; the backward chain per path; the reductions): forward, logits = a2 . table[0 : n_rows - 1]^T (`b = table[:-1]`), loss =
+ * spex_trust_head_train_f32 (two launches: the fused path kernel — forward chain, the logits / cross-entropy / d a2 sweep of the
+ *   user table shared by up to 8 workgroups per path whose last one folds the shares in a fixed order and runs the backward chain —
+ *   and the reductions.  SPEX_TRUST_SPLIT=n caps the workgroups per path, SPEX_TRUST_TILED=1 selects the older five-launch form
+ *   with the logits on tiles of 32 users shared by all paths; both read per call): forward, logits = a2 . table[0 : n_rows - 1]^T (`b = table[:-1]`), loss =
  *   mean_b CE(logits_b, targets_b) -> *loss_out (added to it if loss_accumulate; may be NULL), and the whole backward:
  *   grad_params (flat block) is OVERWRITTEN (one thread per weight sums its contributions in a fixed order: deterministic);
  *   grad_table [n_rows, 64] is ACCUMULATED by the launch that owns the rows — the logits' part, then the rows of the paths that
@@ -606,7 +607,9 @@ int spex_path_attention_bwd_f32(const float *src, int64_t n_src_rows, const int6
  *   the buffer it is to be added to.  Gradients are scaled by scale * (*scale_dev if
  *   scale_dev else 1) — e.g. the multi-task precision exp(-2 s) of main_auto_expert_s.py:81-82 read on the device.
  *   Scratch (caller-owned): a2 [B, 64], dscore [B, n_rows - 1], loss_b [B], ws [spex_trust_workspace_floats(B, L, 64, H, n_rows)]
- *   (per-path blocks + the user tiles' partials).
+ *   (per-path blocks + the user tiles' / the shares' partials and the paths' arrival tickets; the workspace need NOT be zeroed:
+ *   a ticket carries the call's tag, whatever else the word holds counts as "nobody arrived yet").  One workspace serves one
+ *   call at a time (calls on one stream: fine; the same workspace on two streams at once: not).
  */
 int64_t spex_trust_param_count(int32_t d, int32_t n_heads);                                /* -1: unsupported shape */
 int64_t spex_trust_workspace_floats(int32_t B, int32_t L, int32_t d, int32_t n_heads,

@@ -29,6 +29,12 @@ int dual_task_adam(float *p, float *m, float *v, const float *g_E0, float *g_raw
                    void *stream, float prop_div = 0.0f, float *att_copies = nullptr, int32_t n_att_copies = 0,
                    int32_t att_clear = 0, int32_t part = 0, int32_t clear_prop = 1);                 // optim.hip: Adam over the dual-task parameter arena (spex_dual_task_step_f32)
 
+// trust.hip: spex_trust_head_train_f32 with a cap on the fused kernel's workgroups per path (the public entry: 8; beside other work: 1)
+int trust_head_train(const float *table, int64_t n_rows, const float *params, const int64_t *seq, const int64_t *seq_l,
+                     const int64_t *targets, int32_t B, int32_t L, int32_t d, int32_t n_heads, int32_t hybrid, float scale,
+                     const float *scale_dev, float *a2, float *dscore, float *loss_b, float *ws, float *loss_out, int32_t loss_accumulate,
+                     float *grad_params, float *grad_table, int32_t split_cap, void *stream);
+
 // batch.hip: the batch kernels with the layer sum formed at the batch's rows from up to three tables (acc_in + acc2 + acc3, in that
 // order; NULL = absent) — what lets the one-call steps run their forward layers in the plain form
 int lightgcn_batch_layers(const spex_graph_t *g, const float *X, const float *acc_in, const float *acc2, const float *acc3, float acc_div,

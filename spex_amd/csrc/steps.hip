@@ -309,9 +309,12 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
     // ---- trust branch (:170-192) on the raw user table, forward + backward.  It shares nothing with the rec branch but the
     //      (read-only) parameters, so with a second stream it is issued FIRST, behind the previous step's Adam pass, and its
     //      <= path_capacity workgroups run beside the rec branch's launches; the Adam pass waits for both.
+    //      (Beside the rec branch the head keeps to ONE workgroup per path: the rec branch's whole-graph launches bound the step and
+    //      want every CU; alone on the caller's stream it splits each path's sweep over up to eight — except in the deterministic
+    //      step, whose results must not depend on how the streams are arranged: the fold over shares rounds differently.)
     auto trust_branch = [&](void *st) -> int {
-        return spex_trust_head_train_f32(E0, n_u, trust_p, seq, seq_l, targets, T, s->path_len, d, H, s->hybrid, 1.0f, nullptr, s->a2,
-                                         s->dscore, s->loss_b, s->trust_ws, s->loss + 1, 0, s->g_small, s->g_user, st);
+        return spex::trust_head_train(E0, n_u, trust_p, seq, seq_l, targets, T, s->path_len, d, H, s->hybrid, 1.0f, nullptr, s->a2, s->dscore,
+                                      s->loss_b, s->trust_ws, s->loss + 1, 0, s->g_small, s->g_user, st == stream && !det ? 8 : 1, st);
     };
     // SPEX_STEP_PIPELINED: the trust branch and the update of what it reads (user rows, trust block, task weights) live on
     // side_stream from one step to the next; `stream` and side_stream exchange two events per step, neither on the trust

@@ -29,9 +29,13 @@
 //                         no atomics), every weight gradient as a small [rows, 64]^T [rows, 64] product over the workspaces
 //                         (one thread per weight), the bias / vector gradients, the mean loss.  Nothing in the head is atomic:
 //                         it repeats bit for bit.
+// What the library RUNS since round 3 is the fused form — the chains and the sweep in one launch (trust_path_split_kernel: S workgroups
+// per path share the sweep; trust_path_train_kernel: one) + trust_reduce_kernel — which beats the tiled launches at every measured
+// size (host code below); SPEX_TRUST_TILED=1 forces the five launches above.
 // Evaluation (flag 2) keeps the single forward launch (trust_path_kernel<false>).
 // All parameters live in ONE flat block (layout below) so that a step's gradients are one buffer and one Adam launch.
 #include <math.h>
+#include <atomic>
 
 #include <type_traits>
 
@@ -46,6 +50,11 @@ typedef float v2f __attribute__((ext_vector_type(2)));       // packed fp32 math
 constexpr int kD = 64;        // hidden size: one lane per column
 constexpr int kMaxL = 16;     // longest padded path
 constexpr int kMaxH = 4;      // input attention heads
+constexpr int kMaxSplit = 8;         // workgroups per path in the split fused form
+                                     // (= the default; SPEX_TRUST_SPLIT overrides; 0 / 1 = the one-workgroup form.  16 was tried: the
+                                     //  wider fold costs 1.4 us at 3 185 users and gains 3 % at 26 000+)
+constexpr int kCUs = 256;            // MI355X compute units: shares x paths stay within one dispatch round
+constexpr int kSweepBatchRows = 512; // rows per sweep batch of a 16-wave workgroup: (16 * 64 / 16 lanes per row) * 8 in flight
 constexpr int kPathWaves = 16;      // sizes the partial-sum rows of the LDS layout (the chain kernels use the first four)
 
 struct Layout {
@@ -113,11 +122,17 @@ struct TrainArgs {
     float *loss_b;           // [B]
     float *ws;               // [B, ws stride]
     float *grad_table;
+    // the split form (trust_path_split_kernel): S workgroups per path, each sweeping a share of the user table
+    int S;                            // workgroups per path
+    float *part_da2;                  // [S][B][64]  the shares' sum exp * row, each on its own maximum
+    float *part_ms;                   // [S][B][2]   the shares' (max, sum-exp)
+    unsigned long long *tickets;      // [B]         (call tag << 32) | arrivals: whatever an earlier call (or nobody) left there counts as 0
+    uint32_t tag;                     // this call's tag (unique per process)
 };
 
 // LDS of the path kernel (floats).  s (the readout's sigmoids) shares dM's space: s is dead before dM is written.
 struct LdsLayout {
-    int e, M, dM, o, h, dh, dO, du, vec, sacc, red, total;
+    int e, M, dM, o, h, dh, dO, du, vec, sacc, red, tk, total;
 };
 
 __host__ __device__ inline LdsLayout lds_layout(int L, int H, bool train)
@@ -135,6 +150,7 @@ __host__ __device__ inline LdsLayout lds_layout(int L, int H, bool train)
     o.du = p;  p += train ? L * kD : 0;
     o.sacc = p; p += train ? (kPathWaves + 1) * kD : 0;      // one row per wave + the target's table row
     o.red = p;  p += train ? 2 * kPathWaves : 0;
+    o.tk = p;   p += train ? 4 : 0;                          // split form: the path's ticket word as read at kernel start
     o.total = p;
     return o;
 }
@@ -576,7 +592,13 @@ __device__ __forceinline__ float block_reduce(float v, float *red, bool is_max)
 // style — every 16-lane row group keeps a running (max, sum-exp, sum exp * row) and rescales it when its max moves; the 64 groups
 // are combined in a fixed order at the end.  (The first version swept the table twice — scores, then sum_u d score[u] E[u] —
 // 2 x 815 KB per path through one CU's L1: 28 of the kernel's 70 us.)
-__device__ __forceinline__ void logits_ce(const TrustArgs &p, const TrainArgs &tr, const LdsLayout &ll, float *s, int b)
+//
+// SPLIT (trust_path_split_kernel): workgroup `sp` of the path's tr.S sweeps only its share of the batches and publishes
+// (max, sum-exp, sum exp * row) — and its raw scores — with agent-scope stores; the workgroups of a path take a ticket, and the
+// LAST one to arrive folds the shares in share order (a fixed order, whoever is last), writes loss / d scores / d a2 and goes on
+// to the backward chain (returns true); the others are done (false).  No workgroup ever waits for another.
+template <bool SPLIT>
+__device__ __forceinline__ bool logits_ce(const TrustArgs &p, const TrainArgs &tr, const LdsLayout &ll, float *s, int b, int sp)
 {
     const int t = threadIdx.x, n_users = tr.n_users;
     float *vec = s + ll.vec, *red = s + ll.red, *sacc = s + ll.sacc;
@@ -620,7 +642,10 @@ __device__ __forceinline__ void logits_ce(const TrustArgs &p, const TrainArgs &t
         }
         if (sub < kFly) {
             const int u = u0 + sub * kRows + grp;
-            if (!TAIL || u < n_users) ds[u] = keep;
+            if (!TAIL || u < n_users) {
+                if constexpr (SPLIT) __hip_atomic_store(ds + u, keep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else ds[u] = keep;
+            }
         }
         if (!TAIL || bm > -INFINITY) {                            // (uniform over the 16 lanes of a group)
             const float m_new = fmaxf(m_g, bm), f = __builtin_amdgcn_exp2f((m_g - m_new) * kLog2e);   // first batch: 2^-inf = 0
@@ -640,17 +665,26 @@ __device__ __forceinline__ void logits_ce(const TrustArgs &p, const TrainArgs &t
         }
     };
     const int n_full = n_users / (kRows * kFly);
+    int k_beg = 0, k_end = n_full;
+    bool with_tail = n_full * kRows * kFly < n_users;
+    if constexpr (SPLIT) {                                        // this share's batches (the partial one is the last batch)
+        const int nb = n_full + (with_tail ? 1 : 0);
+        k_beg = nb * sp / tr.S;
+        k_end = nb * (sp + 1) / tr.S;
+        with_tail = with_tail && k_end == nb;
+        k_end = k_end < n_full ? k_end : n_full;
+    }
     {
         float4 r[kFly], rn[kFly];
-        if (n_full > 0) load_full(0, r);
-        for (int k = 0; k < n_full; ++k) {
-            if (k + 1 < n_full) load_full((k + 1) * kRows * kFly, rn);
+        if (k_beg < k_end) load_full(k_beg * kRows * kFly, r);
+        for (int k = k_beg; k < k_end; ++k) {
+            if (k + 1 < k_end) load_full((k + 1) * kRows * kFly, rn);
             consume(k * kRows * kFly, r, std::false_type{});
 #pragma unroll
             for (int j = 0; j < kFly; ++j) r[j] = rn[j];      // (a manual ping-pong of the two buffers spills and is slower: 13.3 vs 11.3 us)
         }
         const int u0 = n_full * kRows * kFly;
-        if (u0 < n_users) {
+        if (with_tail) {
 #pragma unroll
             for (int j = 0; j < kFly; ++j) {
                 const int u = u0 + j * kRows + grp, uc = u < n_users ? u : n_users - 1;
@@ -664,6 +698,88 @@ __device__ __forceinline__ void logits_ce(const TrustArgs &p, const TrainArgs &t
     const float mx = block_reduce(m_g, red, true);               // (its barriers also publish ds within the workgroup)
     const float f_g = m_g > -INFINITY ? expf(m_g - mx) : 0.0f;    // a group without rows contributes nothing
     const float se = block_reduce(sub == 0 ? s_g * f_g : 0.0f, red + kPathWaves, false);
+    if constexpr (SPLIT) {
+        const int wv = t >> 6, B = p.B;
+        acc4.x *= f_g; acc4.y *= f_g; acc4.z *= f_g; acc4.w *= f_g;
+        acc4.x += __shfl_xor(acc4.x, 16); acc4.y += __shfl_xor(acc4.y, 16); acc4.z += __shfl_xor(acc4.z, 16); acc4.w += __shfl_xor(acc4.w, 16);
+        acc4.x += __shfl_xor(acc4.x, 32); acc4.y += __shfl_xor(acc4.y, 32); acc4.z += __shfl_xor(acc4.z, 32); acc4.w += __shfl_xor(acc4.w, 32);
+        if ((t & 63) < 16) reinterpret_cast<float4 *>(sacc + wv * kD)[sub] = acc4;
+        __syncthreads();
+        // ---- publish this share: agent-scope stores go through to memory (the path's workgroups may sit on different XCDs, whose
+        //      L2s do not see each other's lines), and every thread has its own stores acknowledged before the barrier in front of
+        //      the ticket.  No agent-scope FENCE anywhere: on gfx950 that is a writeback + invalidate of the XCD's whole L2.
+        if (t < kD) {
+            float g = 0.0f;
+            for (int w = 0; w < kPathWaves; ++w) g += sacc[w * kD + t];
+            __hip_atomic_store(tr.part_da2 + ((size_t)sp * B + b) * kD + t, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (t == 0) {
+            __hip_atomic_store(tr.part_ms + ((size_t)sp * B + b) * 2, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(tr.part_ms + ((size_t)sp * B + b) * 2 + 1, se, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // (s_waitcnt on the thread's own stores)
+        __syncthreads();
+        if (t == 0) {
+            // the ticket word: (this call's tag << 32) | arrivals.  Whatever else is there — an earlier call's word, or nothing the
+            // library ever wrote — counts as "nobody yet": the first share installs the tag by compare-exchange, the others add 1.
+            // (`cur` was read at kernel start — trust_path_split_kernel — to keep that round trip off this path: a stale value only
+            //  makes the exchange fail, and then the tag is in place)
+            unsigned long long cur = *reinterpret_cast<const unsigned long long *>(s + ll.tk);
+            const unsigned long long first = ((unsigned long long)tr.tag << 32) | 1ull;
+            unsigned arrived = 1;
+            if ((unsigned)(cur >> 32) == tr.tag
+                || !__hip_atomic_compare_exchange_strong(tr.tickets + b, &cur, first, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                // (a failed exchange: the word changed under us — only shares of THIS call write it, so the tag is in place now)
+                arrived = (unsigned)__hip_atomic_fetch_add(tr.tickets + b, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+            red[0] = arrived == (unsigned)tr.S ? 1.0f : 0.0f;
+        }
+        __syncthreads();
+        if (red[0] == 0.0f) return false;
+        // ---- the last share to arrive: all S shares are in memory.  Everything the fold needs is requested at once (one round trip
+        //      through memory, not one per share), then folded in share order.
+        float mq[kMaxSplit], sq[kMaxSplit], gq[kMaxSplit];
+#pragma unroll
+        for (int q = 0; q < kMaxSplit; ++q) {
+            const bool on = q < tr.S;
+            const size_t cell = (size_t)(on ? q : 0) * B + b;
+            mq[q] = __hip_atomic_load(tr.part_ms + cell * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sq[q] = __hip_atomic_load(tr.part_ms + cell * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gq[q] = __hip_atomic_load(tr.part_da2 + cell * kD + (t & (kD - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!on) mq[q] = -INFINITY;
+        }
+        constexpr int kThreads = kPathWaves * kWave;
+        float raw[4];                                                  // the first round of raw scores rides along
+#pragma unroll
+        for (int j = 0; j < 4; ++j) raw[j] = t + j * kThreads < n_users ? __hip_atomic_load(ds + t + j * kThreads, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+        const float e_tg_t = tg_ok ? table[(size_t)tg * kD + (t & (kD - 1))] : 0.0f;
+        float big = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < kMaxSplit; ++q) big = fmaxf(big, mq[q]);
+        float se_all = 0.0f, g = 0.0f;
+#pragma unroll
+        for (int q = 0; q < kMaxSplit; ++q) {
+            const float f = mq[q] > -INFINITY ? expf(mq[q] - big) : 0.0f;      // (a share without rows, or beyond S, contributes nothing)
+            se_all += f > 0.0f ? sq[q] * f : 0.0f;
+            g += f > 0.0f ? gq[q] * f : 0.0f;
+        }
+        const float lse = big + logf(se_all);
+        const float k = tr.scale * (tr.scale_dev ? *tr.scale_dev : 1.0f) / (float)p.B;
+        if (t < kD) vec[3 * kD + t] = tg_ok ? k * (g / se_all - e_tg_t) : 0.0f;
+        if (t == 0 && !tg_ok) tr.loss_b[b] = 0.0f;                     // (else: written by the thread that holds the target's raw score)
+        for (int u0 = t;;) {                                           // d scores, four agent-scope loads in flight per thread
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int u = u0 + j * kThreads;
+                if (u < n_users) ds[u] = tg_ok ? (expf(raw[j] - lse) - (u == tg ? 1.0f : 0.0f)) * k : 0.0f;
+                if (tg_ok && u == tg) tr.loss_b[b] = lse - raw[j];
+            }
+            u0 += 4 * kThreads;
+            if (u0 >= n_users) break;                                  // (uniform enough: whole waves leave together except the last)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) raw[j] = u0 + j * kThreads < n_users ? __hip_atomic_load(ds + u0 + j * kThreads, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+        }
+        return true;
+    }
     const float lse = mx + logf(se);
     TSTAMP(5);
     if (t == 0) tr.loss_b[b] = tg_ok ? lse - ds[tg] : 0.0f;
@@ -686,6 +802,7 @@ __device__ __forceinline__ void logits_ce(const TrustArgs &p, const TrainArgs &t
         for (int w = 0; w < kPathWaves; ++w) g += sacc[w * kD + t];
         vec[3 * kD + t] = tg_ok ? k * (g / se - sacc[kPathWaves * kD + t]) : 0.0f;
     }
+    return true;
 }
 
 // ------------------------------------------------------------------------------------ training backward (the whole workgroup)
@@ -895,11 +1012,9 @@ __device__ __forceinline__ void backward_train(const TrustArgs &p, const TrainAr
     TSTAMP(15);
 }
 
-// The FUSED training form (round 2; still the faster one for the reference's small trust batches — <= 15 paths against 3 185
-// users: 72 + 12 us against 89 us for the five tiled launches, whose two chain kernels pay their state's round trip through memory
-// and three more launch boundaries): one 16-wave workgroup per path does everything — forward chain on wave 0 (`M @ w` on four
-// waves), logits + CE on all 16 waves, backward chain on wave 0.  The tiled form takes over when paths x users is large
-// (spex_trust_head_train_f32 picks by size, SPEX_TRUST_TILED forces).
+// The FUSED training form, one workgroup per path (round 2's kernel, rebuilt in round 3): one 16-wave workgroup does everything —
+// forward chain (its independent pieces on separate waves), logits + CE on all 16 waves, backward chain.  Used when the split form
+// below cannot be (many paths: S x paths beyond one dispatch round; a table of a single sweep batch).
 __global__ __launch_bounds__(kPathWaves *kWave) void trust_path_train_kernel(const TrustArgs p, const TrainArgs tr,
                                                                             float *__restrict__ a2_out)
 {
@@ -910,7 +1025,33 @@ __global__ __launch_bounds__(kPathWaves *kWave) void trust_path_train_kernel(con
     const int l = path_len(p, b);
     const FwdState st = forward_train<kPathWaves>(p, ll, s, b, l, lane, wave, a2_out);
     __syncthreads();
-    logits_ce(p, tr, ll, s, b);
+    logits_ce<false>(p, tr, ll, s, b, 0);
+    __syncthreads();
+    backward_train<kPathWaves>(p, tr, ll, s, b, l, lane, wave, st);
+}
+
+// The SPLIT fused form: tr.S workgroups per path.  Every one of them runs the (cheap, deterministic) forward chain — the same
+// instructions on the same inputs: the same bits, so the duplicate writes of a2 / the workspace state are benign — then sweeps its
+// share of the user table; the path's last workgroup to arrive folds the shares and runs the backward chain (logits_ce<true>).
+// The sweep is bounded by what ONE CU can pull (n_users x 256 B through a 64 B / clk L1: ~5 us at 3 185 users, 11 us achieved) —
+// this is the form that puts a path's sweep on S CUs without a launch boundary.  Grid: S x pad8(B) workgroups, share-major, so
+// that the shares of a path have the same workgroup id mod 8 (the same XCD, if the dispatcher deals workgroups round-robin —
+// a locality hint only: correctness rests on the agent-scope accesses).
+__global__ __launch_bounds__(kPathWaves *kWave) void trust_path_split_kernel(const TrustArgs p, const TrainArgs tr, float *__restrict__ a2_out,
+                                                                            int b_pad)
+{
+    extern __shared__ float4 s_raw[];
+    float *s = reinterpret_cast<float *>(s_raw);
+    const int sp = blockIdx.x / b_pad, b = blockIdx.x - sp * b_pad;
+    if (b >= p.B) return;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const LdsLayout ll = lds_layout(p.L, p.H, true);
+    const int l = path_len(p, b);
+    if (threadIdx.x == 0)
+        *reinterpret_cast<unsigned long long *>(s + ll.tk) = __hip_atomic_load(tr.tickets + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const FwdState st = forward_train<kPathWaves>(p, ll, s, b, l, lane, wave, a2_out);
+    __syncthreads();
+    if (!logits_ce<true>(p, tr, ll, s, b, sp)) return;
     __syncthreads();
     backward_train<kPathWaves>(p, tr, ll, s, b, l, lane, wave, st);
 }
@@ -963,7 +1104,6 @@ __global__ __launch_bounds__(kWave *kFwdWaves) void trust_fwd_kernel(const Trust
 // workgroup owns kTileUsers consecutive users and handles all paths, so the table is read once (not once per path) and by ~100
 // workgroups.  Paths are taken in chunks of kPathChunk (LDS: the chunk's a2 rows and its scores / d scores for the tile).
 constexpr int kTileUsers = 32;
-constexpr int kTiledMinUsers = 8000, kTiledMaxPaths = 24;   // where the tiled launches beat the fused kernel (measured, see the host code)
 constexpr int kPathChunk = 64;
 constexpr int kTileThreads = 256;
 
@@ -1352,6 +1492,19 @@ extern "C" int spex_trust_head_train_f32(const float *table, int64_t n_rows, con
                                          float *dscore, float *loss_b, float *ws, float *loss_out, int32_t loss_accumulate,
                                          float *grad_params, float *grad_table, void *stream)
 {
+    return spex::trust_head_train(table, n_rows, params, seq, seq_l, targets, B, L, d, n_heads, hybrid, scale, scale_dev, a2, dscore, loss_b, ws,
+                                  loss_out, loss_accumulate, grad_params, grad_table, kMaxSplit, stream);
+}
+
+// split_cap: the most workgroups per path the fused kernel may use.  The public entry passes kMaxSplit (the head has the chip to
+// itself); the two-stream dual-task step passes 1 — there the head runs BESIDE the rec branch's whole-graph launches, which bound the
+// step, and every CU the head takes is taken from them (Epinion2 step 93.5 us with one workgroup per path, 95.7 with eight; the
+// Weibo shape 139.0 / 147.8).
+int spex::trust_head_train(const float *table, int64_t n_rows, const float *params, const int64_t *seq, const int64_t *seq_l,
+                           const int64_t *targets, int32_t B, int32_t L, int32_t d, int32_t n_heads, int32_t hybrid, float scale,
+                           const float *scale_dev, float *a2, float *dscore, float *loss_b, float *ws, float *loss_out,
+                           int32_t loss_accumulate, float *grad_params, float *grad_table, int32_t split_cap, void *stream)
+{
     if (int rc = check_head("spex_trust_head_train_f32", table, n_rows, params, seq, seq_l, B, L, d, n_heads)) return rc;
     SPEX_CHECK_ARG(targets && a2 && dscore && loss_b && ws && grad_params && grad_table, "spex_trust_head_train_f32: NULL pointer");
     SPEX_CHECK_ARG(n_rows >= 2, "spex_trust_head_train_f32: the table needs at least one user row besides the pad row");
@@ -1359,24 +1512,24 @@ extern "C" int spex_trust_head_train_f32(const float *table, int64_t n_rows, con
     if (B == 0) return SPEX_OK;
     const int n_users = (int)(n_rows - 1);                           // logits against table[:-1]
     const TrustArgs p{table, n_rows, params, seq, seq_l, B, L, n_heads, hybrid};
-    const TrainArgs tr{targets, n_users, scale, scale_dev, a2, dscore, loss_b, ws, grad_table};
+    TrainArgs tr{targets, n_users, scale, scale_dev, a2, dscore, loss_b, ws, grad_table, 1, nullptr, nullptr, nullptr, 0u};
     const size_t lds = (size_t)lds_layout(L, n_heads, true).total * sizeof(float);
     SPEX_CHECK_ARG(lds <= 64 * 1024, "spex_trust_head_train_f32: LDS %zu bytes", lds);
     const int n_tiles = n_user_tiles(n_rows);
     float *part_da2 = ws + (size_t)B * ws_layout(L, n_heads).stride;
     float *part_ms = part_da2 + (size_t)n_tiles * B * kD;
     hipStream_t st = (hipStream_t)stream;
-    // Which form: the fused kernel sweeps the user table once PER PATH through one CU (n_users x 256 B per path), the tiled
-    // launches read it once for all paths on ~n_users / 32 workgroups but pay three more launch boundaries, the chains' state
-    // round trip, and a per-tile loop over the paths.  Measured on the MI355X (tools/trust_forms_time.py, us per call, fused /
-    // tiled; round 3, after the one-sweep logits and the multi-wave chains): 3 185 users x 15 paths 51 / 60; 6 812 x 15: 62 / 64;
-    // 26 000 x 15: 131 / 94; 3 185 x 45: 70 / 99; 6 812 x 45: 82 / 109; 3 185 x 192: 156 / 278; 26 000 x 60: 167 / 275.  (Round 2's
-    // fused kernel: 74.5 at 3 185 x 15, 93 at 6 812 x 15, 219 at 26 000 x 15.)  So: tiled only for a LARGE user table (~8 000 users is
-    // where the lines cross) with a SMALL trust batch, fused otherwise — including both of the reference's datasets (Epinion2
-    // 3 185, Weibo 6 812 users).  SPEX_TRUST_TILED=0/1 forces.
+    // Which form.  The fused kernel sweeps the user table once PER PATH (n_users x 256 B per path — through one CU in its
+    // one-workgroup form, through S CUs in the split form); the tiled launches read it once for all paths on ~n_users / 32
+    // workgroups but pay three more launch boundaries, the chains' state round trip, and a per-tile loop over the paths.  Measured
+    // on the MI355X (tools/trust_forms_time.py, us per call: fused one workgroup / fused split / tiled): 3 185 users x 15 paths
+    // 51.5 / 48.5 / 59.2; 6 812 x 15: 62.0 / 53.7 / 63.8; 26 000 x 15: 129 / 74 / 93; 60 000 x 15: 262 / 124 / 262; 100 000 x 15:
+    // 415 / 182 / 687; 3 185 x 45: 69.8 / 66.6 / 98.5; 26 000 x 60: 167 / 123 / 274; 3 185 x 192: 156 / (S = 1) / 279.  Until the split
+    // form existed the tiled launches won from ~8 000 users on with few paths; now they win nowhere measured: the library always
+    // takes the fused kernel, and SPEX_TRUST_TILED=1 keeps the tiled form reachable (tests run every form; =0 is the default).
     const char *force_env = getenv("SPEX_TRUST_TILED");          // (read per call: the tests run both forms in one process)
     const int forced = force_env && force_env[0] ? atoi(force_env) : -1;
-    const bool tiled = forced >= 0 ? forced != 0 : (n_users >= kTiledMinUsers && B <= kTiledMaxPaths);
+    const bool tiled = forced > 0;
     if (tiled) {
         hipLaunchKernelGGL(trust_fwd_kernel, dim3((unsigned)B), dim3(kWave * kFwdWaves), lds, st, p, tr, a2);
         const TileArgs ta{table, a2, dscore, part_ms, part_da2, loss_b, targets, grad_table, n_users, B, n_tiles, scale / (float)B, scale_dev};
@@ -1384,7 +1537,33 @@ extern "C" int spex_trust_head_train_f32(const float *table, int64_t n_rows, con
         hipLaunchKernelGGL(trust_ce_kernel, dim3((unsigned)n_tiles), dim3(kTileThreads), 0, st, ta);
         hipLaunchKernelGGL(trust_bwd_kernel, dim3((unsigned)B), dim3(kWave * kFwdWaves), lds, st, p, tr, part_da2, n_tiles);
     } else {
-        hipLaunchKernelGGL(trust_path_train_kernel, dim3((unsigned)B), dim3(kPathWaves * kWave), lds, st, p, tr, a2);
+        // the split form: S workgroups per path (the shares live in the tiled form's partial areas of the workspace: [S][B][64]
+        // and [S][B][2] fit in [n_tiles][B][...] with one more tile's (max, sum-exp) cells holding the B tickets)
+        // How many: as many as there are sweep batches, up to kMaxSplit, while S x paths fits one dispatch round of the 256 CUs
+        // (every workgroup repeats the forward chain — free on an idle CU, a second round when there is none — and the fold costs
+        // ~5 us of publish / ticket / fetch round trips through memory whatever S is).  Measured (tools/trust_forms_time.py, us per
+        // call incl. the reduce launch; S = 1 / 3 / 4 / 6 / 8): 3 185 users x 15 paths 51.5 / 49.7 / 48.2 / 47.8 / 46.4; 6 812 x 15:
+        // 62.0 / 55.5 / 53.6 / 51.7 / 50.4; 6 812 x 30: - / 65.1 / 63.6 / 62.0 / 60.0; 6 812 x 45: 81.9 / - / 73.8 (S = 5) / - / 89.9
+        // (360 workgroups: a second round); 26 000 x 15: 128.6 / - / 81.3 (S = 5) / - / 75.7; 3 185 x 192: 156 / 176 (S = 2) / 193 / - / 232.
+        const int b_pad8 = (B + 7) & ~7;
+        const char *split_env = getenv("SPEX_TRUST_SPLIT");
+        int S = split_env && split_env[0] ? atoi(split_env) : (split_cap < kMaxSplit ? split_cap : kMaxSplit);
+        const int n_batches = (n_users + kSweepBatchRows - 1) / kSweepBatchRows;
+        if (!(split_env && split_env[0])) S = S < kCUs / b_pad8 ? S : kCUs / b_pad8;
+        S = S < n_batches ? S : n_batches;
+        S = S < kMaxSplit ? S : kMaxSplit;
+        if (S >= 2 && n_tiles >= S + 1) {
+            static std::atomic<uint32_t> call_tag{0x2f000000u};
+            tr.S = S;
+            tr.part_da2 = part_da2;
+            tr.part_ms = part_ms;
+            tr.tickets = reinterpret_cast<unsigned long long *>(part_ms + (size_t)2 * S * B);
+            tr.tag = call_tag.fetch_add(1u) + 1u;
+            const int b_pad = b_pad8;
+            hipLaunchKernelGGL(trust_path_split_kernel, dim3((unsigned)(S * b_pad)), dim3(kPathWaves * kWave), lds, st, p, tr, a2, b_pad);
+        } else {
+            hipLaunchKernelGGL(trust_path_train_kernel, dim3((unsigned)B), dim3(kPathWaves * kWave), lds, st, p, tr, a2);
+        }
     }
     SPEX_HIP(hipGetLastError());
     ReduceArgs r{dscore, a2, loss_b, ws, seq, seq_l, grad_table, grad_params, loss_out, n_users, B, L, n_heads, hybrid, loss_accumulate,

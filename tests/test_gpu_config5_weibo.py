@@ -398,3 +398,30 @@ def test_trust_head_forms_agree_on_the_weibo_user_table(monkeypatch):
     #  its CE kernel adds the table gradient itself)
     for nm, a, b in zip(("loss", "path losses", "a2", "grad params", "grad table"), fused, tiled):
         assert rel_err(b.cpu().numpy(), a.cpu().numpy()) <= 2e-5, nm
+    # ---- the fused kernel's SPLIT form (S workgroups per path sweep shares of the table; the last to arrive folds them in share
+    #      order): every S agrees with the one-workgroup form to rounding, and REPEATS ITSELF BIT FOR BIT whichever workgroup happens
+    #      to arrive last — on ONE workspace used call after call (the tickets carry a per-call tag: nothing is reset between
+    #      calls), whose first contents are random bits (the library may not assume a zeroed workspace).
+    monkeypatch.setenv("SPEX_TRUST_TILED", "0")
+    junk = torch.randint(-2 ** 31, 2 ** 31 - 1, (n_ws,), dtype=torch.int32, device=DEV).view(torch.float32)
+    z = lambda *sh: torch.zeros(sh, dtype=torch.float32, device=DEV)
+
+    def run_on(ws, split):
+        monkeypatch.setenv("SPEX_TRUST_SPLIT", str(split))
+        a2, ds, lb, loss, gp, gt = z(T, 64), z(T, n_users), z(T), z(1), z(params.numel()), z(n_users + 1, 64)
+        _launch(DEV, "spex_trust_head_train_f32", _ptr(table), n_users + 1, _ptr(params), _ptr(seq_d), _ptr(len_d), _ptr(tgt), T, L, 64, H, 1,
+                1.0, None, _ptr(a2), _ptr(ds), _ptr(lb), _ptr(ws), _ptr(loss), 0, _ptr(gp), _ptr(gt))
+        return loss, lb, a2, gp, gt, ds
+    one = run_on(junk.clone(), 1)
+    for nm, a, b in zip(("loss", "path losses", "a2", "grad params", "grad table", "d scores"), one, fused):     # (`fused`: the library's own S)
+        assert rel_err(b.cpu().numpy(), a.cpu().numpy()) <= 2e-5, nm
+    for split in (2, 4, 8):
+        ws = junk.clone()
+        runs = [run_on(ws, split) for _ in range(12)]
+        torch.cuda.synchronize()
+        for r in runs[1:]:
+            for nm, a, b in zip(("loss", "path losses", "a2", "grad params", "grad table", "d scores"), runs[0], r):
+                assert torch.equal(a, b), (split, nm)
+        assert torch.equal(runs[0][2], one[2])                           # a2: the forward chain does not depend on the split
+        for nm, a, b in zip(("loss", "path losses", "a2", "grad params", "grad table", "d scores"), one, runs[0]):
+            assert rel_err(b.cpu().numpy(), a.cpu().numpy()) <= 2e-5, (split, nm)

@@ -28,4 +28,8 @@ if [ -f spex_amd/lib/libspexhip_stamps.so ]; then
 fi
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dual_step -o dual -- python3 $R/tools/dual_ab.py --steps 300 --reps 2 >> $OUT/log.txt 2>&1 || echo "dual step trace failed" >> $OUT/log.txt
+for sz in "3185 15" "6812 15"; do      # the trust head's two launches on their own (the library's choice of form)
+  n=$(echo $sz | tr ' ' 'x')
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trust_alone/$n -o t -- python3 $R/tools/trust_forms_time.py one $sz >> $OUT/log.txt 2>&1 || echo "trust alone $n failed" >> $OUT/log.txt
+done
 echo done | tee -a $OUT/log.txt

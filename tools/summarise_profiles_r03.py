@@ -26,6 +26,17 @@ for f in glob.glob(os.path.join(src, "dual_step", "**", "*kernel_stats.csv"), re
 for f in ("bench_under_rocprof.json", "dual_task_time.txt", "dual_step_forms.txt", "trust_forms.txt", "trust_stamps.txt"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
+lines = []
+for d in sorted(glob.glob(os.path.join(src, "trust_alone", "*"))):                  # the trust head alone: its launches' durations
+    for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "trust_" in r["Name"]:
+                lines.append("%-10s %-28s calls %4s  avg %7.2f us  min %7.2f  max %7.2f" % (
+                    os.path.basename(d), r["Name"].split("::")[-1].split("(")[0], r["Calls"], float(r["AverageNs"]) / 1e3,
+                    float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
+if lines:
+    open(os.path.join(dst, "trust_kernels_alone.txt"), "w").write(
+        "spex_trust_head_train_f32 alone (tools/trust_forms_time.py one <users> <paths> under rocprofv3 --kernel-trace --stats):\n" + "\n".join(lines) + "\n")
 if os.path.isdir(os.path.join(src, "pmc_epinion2")):
     out = subprocess.run([sys.executable, os.path.join(here, "pmc_spmm_summary.py"), os.path.join(src, "pmc_epinion2"), "epinion2_r03"],
                          capture_output=True, text=True).stdout

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Phase stamps of the fused trust kernel (trust_path_train_kernel), workgroup 0 / thread 0, wall_clock64 (10 ns).  Needs the
+"""Phase stamps of the fused trust kernel in its ONE-workgroup-per-path form (trust_path_train_kernel; SPEX_TRUST_SPLIT=1 is set
+here — in the split form no single workgroup walks every phase), workgroup 0 / thread 0, wall_clock64 (10 ns).  Needs the
 debug library spex_amd/lib/libspexhip_stamps.so (trust.hip compiled with -DSPEX_STAMPS and linked with the other objects):
 
     cd spex_amd/csrc && hipcc $FLAGS -DSPEX_STAMPS -c trust.hip -o /tmp/trust_stamps.o && \
@@ -10,6 +11,7 @@ import ctypes, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ["SPEX_TRUST_SPLIT"] = "1"
 from spex_amd import _lib
 _lib.LIB_PATH = os.path.join(ROOT, "spex_amd", "lib", "libspexhip_stamps.so")
 from spex_amd import ops
