@@ -20,6 +20,8 @@ user row, :67, included), and the graph handle has that many nodes with the pad 
 parameters in place, where the reference concatenates `user_w[:-1]` and `item_w` every step (:72).
 Layer widths other than 64 take the same HIP SpMM with the dense layer expressed in torch ops on the device.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -74,6 +76,9 @@ class NGCF(nn.Module):
         self.rec_loss_function = nn.BCEWithLogitsLoss()
         self.message_dropout_seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
         self.dropout_step = 0          # counts training forwards: names the dropout mask of the step
+        # "reference": replay nn.Dropout's own noise draw instead (see _reference_noise); SPEX_DROPOUT_STREAM sets the default, as
+        # for the LightGCN drop-in's edge dropout
+        self.dropout_stream = "reference" if os.environ.get("SPEX_DROPOUT_STREAM") == "reference" else "counter"
 
         adj = data_config["norm_adj"].tocsr().astype(np.float32)
         adj.sort_indices()

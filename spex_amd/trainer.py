@@ -481,7 +481,7 @@ def _ngcf_step_one_call(self, users, items, labels, acc):
             self._desc.flags = _lib.STEP_DETERMINISTIC
     d = self._desc
     d.t, d.lr, d.dropout_step, d.seed, d.p_drop = self.t, self.lr, m.dropout_step, int(m.message_dropout_seed), float(m.mess_dropout[0])
-    ref_stream = getattr(self, "dropout_stream", "counter") == "reference" and m.mess_dropout[0] > 0
+    ref_stream = getattr(self, "dropout_stream", getattr(m, "dropout_stream", "counter")) == "reference" and m.mess_dropout[0] > 0
     if ref_stream:
         # validation mode: the step's message-dropout noise is the REFERENCE's — nn.Dropout on the [N, 64] layer output
         # (main_rec.py:81) is at::dropout: empty_like(x).bernoulli_(1 - p) from the global CPU generator.  The same call on a
