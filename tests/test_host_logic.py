@@ -467,3 +467,26 @@ def test_reference_keep_mask_draws_fold_by_fold_like_the_reference():
     torch.manual_seed(77)
     got = reference_keep_mask([1000, 7, 333], 0.3, "cpu").numpy().astype(bool)
     assert np.array_equal(got, want) and torch.rand(1).item() == after
+
+
+def test_message_dropout_replay_draws_what_nn_dropout_draws():
+    """The NGCF validation mode (NGCF.dropout_stream / NGCFStepper.dropout_stream = "reference") rests on one fact about torch: on the
+    CPU nn.Dropout(p) in training mode is x * (empty_like(x).bernoulli_(1 - p) / (1 - p)) — ONE bernoulli_ draw of x's shape from the
+    global generator (main_rec.py:81 on the [N, 64] layer output).  Replaying `buf.bernoulli_(1 - p)` on a buffer of the same shape
+    must give nn.Dropout's keep pattern and leave the generator where nn.Dropout leaves it; a torch that draws differently fails here,
+    on the CPU, before the GPU golden does."""
+    n, p = 1237, 0.1
+    x = torch.rand(n, 64) + 0.5                          # no zeros: the output's zeros are exactly the dropped entries
+    drop = torch.nn.Dropout(p)
+    drop.train()
+    torch.manual_seed(2020)
+    out = [drop(x), drop(x)]                             # two layers / two steps in a row
+    after = torch.rand(1).item()
+    torch.manual_seed(2020)
+    buf = torch.empty(n, 64)
+    for o in out:
+        keep = buf.bernoulli_(1.0 - p) != 0
+        assert torch.equal(keep, o != 0)
+        scale = torch.ones(()) / (1.0 - p)                      # at::dropout: noise.div_(1 - p), then x * noise — the kernels' `scale`
+        assert torch.equal(o[keep], (x * scale)[keep])
+    assert torch.rand(1).item() == after
