@@ -67,7 +67,8 @@ extern "C" int spex_graph_destroy(spex_graph_t *g)
 {
     if (!g) return SPEX_OK;
     void *ptrs[] = {g->rowptr, g->col, g->val, g->edge_id, g->seg_beg, g->seg_end, g->long_row, g->long_seg0, g->partial,
-                    g->task, g->chunk_off, g->chunk_val, g->chunk_mask, g->chunk_eid, g->chunk_row, g->hub_row, g->hub_seg0, g->row_of, g->tile_row, g->chunk_pad, g->wg_rows};
+                    g->task, g->chunk_off, g->chunk_val, g->chunk_mask, g->chunk_eid, g->chunk_row, g->hub_row, g->hub_seg0, g->row_of, g->tile_row, g->chunk_pad, g->wg_rows,
+                    g->hub_grp, g->hub_fold, g->hub_ticket};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (g->scratch_ev) (void)hipEventDestroy(g->scratch_ev);
@@ -202,6 +203,8 @@ static int graph_create_impl(const int32_t *h_rowptr, const int32_t *h_col, cons
     std::vector<int32_t> c_row;
     std::vector<float> c_val;
     std::vector<int32_t> hub_row, hub_seg0;
+    std::vector<int4> hub_grp;
+    std::vector<int2> hub_fold;
     const bool chunked = true;
     g->row_ids = (int64_t)n_cols * 256 <= ((int64_t)16 << 20);
     const int32_t tile_rows = (flags & SPEX_GRAPH_TILE_ROWS) ? spex::kTileRows : 0;
@@ -230,6 +233,8 @@ static int graph_create_impl(const int32_t *h_rowptr, const int32_t *h_col, cons
         wg_rows.clear();
         hub_row.clear();
         hub_seg0.clear();
+        hub_grp.clear();
+        hub_fold.clear();
         // Planning pass (this thread): add_chunks only RECORDS a job — the rows of a pack, or the range [b, e) of row r0
         // (a segment: no end-of-row flags) — and hands out its chunk range; the entries are written afterwards by
         // fill_chunks on several threads, each job into its own range (6 s -> 1 s at 2^24 nodes).
@@ -497,8 +502,38 @@ static int graph_create_impl(const int32_t *h_rowptr, const int32_t *h_col, cons
             }
             fill_chunks();
         } else {
-        for (const int4 &h : hubs) task.push_back(h);
-        fill_wg(false);
+        // Hub segments lead the table.  Every hub STARTS a workgroup, so that its segments fall into groups of 16 counted from its own
+        // first segment (the last group topped up with ordinary tasks): the association of a hub row's sum — segments in order within
+        // a group, groups in order — then depends on the row alone, not on where the packer put it (a row block of the partitioned
+        // graph sums its hubs exactly like the whole graph does: tests/test_gpu_dist.py holds the two bit for bit).  spex_common.h:
+        // hub_grp (indexed by task position; ordinary tasks in between hold zeros) / hub_fold.  Hub workgroups carry the barrier bit.
+        {
+            int32_t hub_id = -1, prev_row = -1, n_groups = 0;
+            for (size_t j = 0; j < hubs.size(); ++j) {
+                int4 h = hubs[j];
+                h.w |= 4;
+                const bool new_hub = h.z != prev_row;
+                if (new_hub) {
+                    fill_wg(true);                             // complete the previous hub's last workgroup
+                    ++hub_id;
+                    prev_row = h.z;
+                    hub_fold.push_back(make_int2(n_groups, 0));
+                }
+                hub_grp.resize(task.size(), make_int4(0, 0, 0, 0));
+                if (task.size() % (size_t)W == 0) {           // a group starts: count its waves
+                    size_t k = j;
+                    while (k < hubs.size() && hubs[k].z == h.z && k - j < (size_t)W) ++k;
+                    hub_grp.push_back(make_int4(1, (int32_t)(k - j), n_groups, hub_id));
+                    hub_fold[(size_t)hub_id].y += 1;
+                    ++n_groups;
+                } else {
+                    const int4 lead = hub_grp[task.size() - task.size() % (size_t)W];
+                    hub_grp.push_back(make_int4(0, lead.y, lead.z, hub_id));
+                }
+                task.push_back(h);
+            }
+        }
+        fill_wg(!hubs.empty());
         {
             // bucket the rows by segment count; fill each workgroup greedily with the largest row that still fits
             std::vector<std::vector<int32_t>> by_nseg(W + 1);
@@ -559,6 +594,7 @@ static int graph_create_impl(const int32_t *h_rowptr, const int32_t *h_col, cons
                 nnz ? 100.0 * ((double)c_mask.size() * spex::kChunk - (double)nnz) / (double)nnz : 0.0, tile_rows, g->n_wgs);
     g->n_chunks = (int64_t)c_mask.size();
     g->n_hub = (int32_t)hub_row.size();
+    g->n_hub_tasks = (int32_t)hub_grp.size();
 
     // rows starting in each tile of kSoftmaxTile consecutive entries (row-softmax kernels, edge.hip)
     g->tile = (nnz / spex::kSoftmaxTile < 2048) ? 512 : spex::kSoftmaxTile;
@@ -602,9 +638,20 @@ static int graph_create_impl(const int32_t *h_rowptr, const int32_t *h_col, cons
         (rc = upload(&g->chunk_row, c_row.data(), c_row.size())) ||
         (rc = upload(&g->wg_rows, wg_rows.data(), wg_rows.size())) ||
         (rc = upload(&g->hub_row, hub_row.data(), hub_row.size())) ||
-        (rc = upload(&g->hub_seg0, hub_seg0.data(), hub_seg0.size()))) {
+        (rc = upload(&g->hub_seg0, hub_seg0.data(), hub_seg0.size())) ||
+        (rc = upload(&g->hub_grp, hub_grp.data(), hub_grp.size())) ||
+        (rc = upload(&g->hub_fold, hub_fold.data(), hub_fold.size()))) {
         spex_graph_destroy(g);
         return rc;
+    }
+    if (!hub_fold.empty()) {
+        hipError_t e = hipMalloc((void **)&g->hub_ticket, hub_fold.size() * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMemset(g->hub_ticket, 0, hub_fold.size() * sizeof(unsigned long long));
+        if (e != hipSuccess) {
+            spex::set_error("hipMalloc(hub_ticket) failed: %s", hipGetErrorString(e));
+            spex_graph_destroy(g);
+            return SPEX_ERR_HIP;
+        }
     }
     if (g->n_seg > 0) {
         g->partial_cap = (int64_t)g->n_seg * 64;

@@ -242,6 +242,13 @@ struct spex_graph {
     int32_t n_hub = 0;              // rows longer than kWgRowMax (global-scratch path of the d == 64 kernel)
     int32_t *hub_row = nullptr;     // [n_hub]
     int32_t *hub_seg0 = nullptr;    // [2 * n_hub] (first, one-past-last) segment of each hub in the kLongRow segment table
+    // In-kernel fold of the hubs (d == 64 chunk kernel): the hub segments lead the task table, so 16 consecutive segments of a
+    // hub share a workgroup — a GROUP, summed through LDS by its first wave, which publishes one partial row and takes a ticket
+    // on the hub; the hub's last group to arrive folds the groups' partials in group order and runs the epilogue.
+    int32_t n_hub_tasks = 0;        // hub segment tasks = task[0 : n_hub_tasks]
+    int4 *hub_grp = nullptr;        // [n_hub_tasks] x: 1 = the group's first wave, y: waves in the group, z: the group's partial row, w: hub
+    int2 *hub_fold = nullptr;       // [n_hub] x: the hub's first partial row, y: its number of groups
+    unsigned long long *hub_ticket = nullptr;   // [n_hub] (launch tag << 32) | groups arrived (zeroed at creation, never reset)
     // edge dropout
     int mask_mode = 0;
     const uint8_t *keep = nullptr;

@@ -23,6 +23,8 @@
 //
 // Edge dropout (model.py:46-55) is decided per stored entry while its (col, val) pair is loaded — injected mask byte
 // or Philox draw keyed by the entry's edge id — so forward, backward and all layers of a step drop the same edges.
+#include <atomic>
+
 #include "spex_common.h"
 
 using namespace spex;
@@ -267,8 +269,11 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_rows_narrow_kernel
 //     dependent load;
 //   * tasks are padded to whole chunks with value-0 entries on the task's last real source row (an L1 hit);
 //   * rows of 65..1024 entries are cut into 64-entry segments that all sit in one workgroup; their sums meet in LDS
-//     and are added in segment order by the row's first wave: deterministic, no atomics, no second launch.  Only rows
-//     beyond 1024 entries go through global scratch and the fix-up launch.
+//     and are added in segment order by the row's first wave: deterministic, no atomics, no second launch.  Rows beyond
+//     1024 entries (hubs) go through global scratch: their segments lead the task table in groups of 16 adjacent waves, a
+//     group is summed through LDS the same way and leaves ONE partial row, and the hub's last group to arrive (a ticket in
+//     memory, no waiting) adds the groups in order and runs the epilogue — inside this launch (HubFold; the wide kernels
+//     and SPEX_HUB_FOLD=0 leave one partial row per segment to spmm_long_fixup_kernel instead).
 // The accumulation is one fmaf chain per output element in ascending column order (bit-exact vs the reference's CPU
 // kernel) for every row that fits a task; segmented rows re-associate <= 16 partial sums.
 
@@ -278,6 +283,15 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_rows_narrow_kernel
 // gathered value is REPLACED by 0 before the fmaf (a wave-uniform select per entry), so that it contributes exactly
 // nothing, as in the reference, where the entry is gone from the matrix: multiplying instead would turn a stand-in row
 // holding Inf / NaN (a diverged table) into 0 * Inf = NaN on a row that never referenced it.
+// In-kernel fold of the rows beyond kWgRowMax entries (tag != 0; spex_common.h: hub_grp / hub_fold / hub_ticket).  tag == 0: the
+// hub segments leave one partial row each and spmm_long_fixup_kernel adds them (the wide kernels, and SPEX_HUB_FOLD=0).
+struct HubFold {
+    const int4 *grp;
+    const int2 *fold;
+    unsigned long long *ticket;
+    uint32_t tag;
+};
+
 struct DropArgs {
     const uint32_t *chunk_eid;
     const uint8_t *keep;
@@ -295,7 +309,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
     int n_tasks, float *__restrict__ Y,
     const float *epi_in, float epi_div, float out_div, float *acc_out,   // may alias each other (running sum in place): no __restrict__
     float *__restrict__ partial,
-    const DropArgs drop, const int xcd_contiguous)
+    const DropArgs drop, const int xcd_contiguous, const HubFold hf_args)
 {
     __shared__ float s_part[kWgWaves][kWave];  // segment sums of the rows this workgroup combines
     const int lane = threadIdx.x & (kWave - 1);
@@ -427,18 +441,64 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
             emit(r, 0.0f, e);
         }
     }
-    if (kind == 2) partial[(size_t)(t.w >> 4) * 64 + lane] = acc;  // hub segment: summed by the fix-up launch
-    if (t.w & 4) {  // this workgroup combines the segments of rows with 65..1024 entries through LDS
+    const bool hub = kind == 2 && hf_args.tag != 0u;
+    if (kind == 2 && !hub) partial[(size_t)(t.w >> 4) * 64 + lane] = acc;  // hub segment: summed by the fix-up launch
+    if (t.w & 4) {  // this workgroup combines the segments of rows with 65..1024 entries (and of hub groups) through LDS
         const bool leader = kind == 1 && (t.w & 8);
         const int slot = (t.w >> 4) & 15, nseg = (t.w >> 8) & 31;
+        int4 hg = make_int4(0, 0, 0, 0);
+        if (hub) hg = hf_args.grp[tid];
+        const bool hub_leader = hub && hg.x != 0;
         float e = 0.0f;
-        if (leader && EPI != 0) e = El[(size_t)t.z * 64];
+        if ((leader || hub_leader) && EPI != 0) e = El[(size_t)t.z * 64];
         if (kind == 1 && !leader) s_part[slot][lane] = acc;
+        if (hub && !hub_leader) s_part[wave][lane] = acc;
         __syncthreads();
         if (leader) {
             float y = acc;
             for (int sgi = 1; sgi < nseg; ++sgi) y = y + s_part[slot + sgi][lane];  // segment order: deterministic
             emit(t.z, y, e);
+        }
+        if (hub_leader) {
+            // A hub's segments are adjacent in the table: this wave and the hg.y - 1 behind it hold consecutive segments of row t.z.
+            // Their sum is ONE partial row of the hub; the hub's groups meet through memory: agent-scope store (write-through: the
+            // groups may run on different XCDs), the wave's own stores acknowledged, a ticket on the hub — (launch tag << 32) |
+            // arrivals, anything else in the word counts as "nobody yet" — and the LAST group to arrive adds the partial rows in group
+            // order (whoever is last: the same order, the same bits) and runs the row's epilogue.  No fence (an agent-scope fence on
+            // gfx950 writes back / invalidates the XCD's whole L2), no waiting, no second launch.
+            float y = acc;
+            for (int i = 1; i < hg.y; ++i) y = y + s_part[wave + i][lane];
+            const int2 hf = hf_args.fold[hg.w];
+            bool last = true;
+            if (hf.y > 1) {
+                __hip_atomic_store(partial + (size_t)hg.z * 64 + lane, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                unsigned arrived = 1u;
+                if (lane == 0) {
+                    unsigned long long *tk = hf_args.ticket + hg.w;
+                    unsigned long long cur = __hip_atomic_load(tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long first = ((unsigned long long)hf_args.tag << 32) | 1ull;
+                    if ((unsigned)(cur >> 32) == hf_args.tag
+                        || !__hip_atomic_compare_exchange_strong(tk, &cur, first, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                        arrived = (unsigned)__hip_atomic_fetch_add(tk, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+                }
+                arrived = (unsigned)__builtin_amdgcn_readfirstlane((int)arrived);
+                last = arrived == (unsigned)hf.y;
+                if (last) {
+                    y = 0.0f;
+                    const float *pr = partial + (size_t)hf.x * 64 + lane;
+                    int q = 0;
+                    for (; q + 8 <= hf.y; q += 8) {          // eight partial rows in flight (the kernel lives in 64 VGPRs)
+                        float v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v[u] = __hip_atomic_load(pr + (size_t)(q + u) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) y = y + v[u];
+                    }
+                    for (; q < hf.y; ++q) y = y + __hip_atomic_load(pr + (size_t)q * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (last) emit(t.z, y, e);
         }
     }
 }
@@ -736,14 +796,14 @@ __global__ __launch_bounds__(256) void div_kernel(const float *__restrict__ in, 
 template <int EPI, int V>
 void launch_chunk_v(bool masked, bool row_ids, dim3 grid, dim3 block, hipStream_t stream, const float *X, const spex_graph *g,
                     float *Y, const float *epi_in, float epi_div, float out_div, float *acc_out, const DropArgs &da,
-                    int xcd_contig)
+                    int xcd_contig, const HubFold &hub)
 {
 #define SPEX_GO(M, R)                                                                                                  \
     do {                                                                                                               \
         if (V == 1)                                                                                                    \
             hipLaunchKernelGGL((spmm_chunk_kernel<EPI, M, R>), grid, block, 0, stream, X, g->chunk_off, g->chunk_val,  \
                                g->chunk_mask, g->chunk_row, g->task, g->n_tasks, Y, epi_in, epi_div, out_div, acc_out, \
-                               g->partial, da, xcd_contig);                                                            \
+                               g->partial, da, xcd_contig, hub);                                                       \
         else                                                                                                           \
             hipLaunchKernelGGL((spmm_chunk_wide_kernel<EPI, M, R, (V == 1 ? 2 : V)>), grid, block, 0, stream, X,       \
                                g->chunk_off, g->chunk_val, g->chunk_mask, g->chunk_row, g->task, g->n_tasks, Y, epi_in, \
@@ -768,11 +828,11 @@ void launch_chunk_v(bool masked, bool row_ids, dim3 grid, dim3 block, hipStream_
 template <int EPI>
 void launch_chunk(int d, bool masked, bool row_ids, dim3 grid, dim3 block, hipStream_t stream, const float *X,
                   const spex_graph *g, float *Y, const float *epi_in, float epi_div, float out_div, float *acc_out,
-                  const DropArgs &da, int xcd_contig)
+                  const DropArgs &da, int xcd_contig, const HubFold &hub)
 {
-    if (d == 64) launch_chunk_v<EPI, 1>(masked, row_ids, grid, block, stream, X, g, Y, epi_in, epi_div, out_div, acc_out, da, xcd_contig);
-    else if (d == 128) launch_chunk_v<EPI, 2>(masked, row_ids, grid, block, stream, X, g, Y, epi_in, epi_div, out_div, acc_out, da, xcd_contig);
-    else launch_chunk_v<EPI, 4>(masked, row_ids, grid, block, stream, X, g, Y, epi_in, epi_div, out_div, acc_out, da, xcd_contig);
+    if (d == 64) launch_chunk_v<EPI, 1>(masked, row_ids, grid, block, stream, X, g, Y, epi_in, epi_div, out_div, acc_out, da, xcd_contig, hub);
+    else if (d == 128) launch_chunk_v<EPI, 2>(masked, row_ids, grid, block, stream, X, g, Y, epi_in, epi_div, out_div, acc_out, da, xcd_contig, hub);
+    else launch_chunk_v<EPI, 4>(masked, row_ids, grid, block, stream, X, g, Y, epi_in, epi_div, out_div, acc_out, da, xcd_contig, hub);
 }
 
 // Profiling hook: one hipEvent pair around ALL the SpMM launches of an API call (a 3-layer propagation is one bracket
@@ -815,6 +875,7 @@ int launch_spmm(const spex_graph *g, const float *X, float *Y, const float *add_
     p.mask_mode = g->mask_mode; p.keep = g->keep; p.keep_prob = g->keep_prob;
     p.seed_lo = (uint32_t)g->seed; p.seed_hi = (uint32_t)(g->seed >> 32);
 
+    HubFold hub{nullptr, nullptr, nullptr, 0u};
     const bool masked = g->mask_mode != 0;
     // fast path: d in {64, 128, 256}, chunked table present, and not both epilogues at once
     const bool fast = (d == 64 || d == 128 || d == 256) && g->task != nullptr && !(acc_out && add_in);
@@ -840,9 +901,15 @@ int launch_spmm(const spex_graph *g, const float *X, float *Y, const float *add_
         DropArgs da;
         da.chunk_eid = g->chunk_eid; da.keep = g->keep; da.mode = g->mask_mode; da.keep_prob = g->keep_prob;
         da.seed_lo = (uint32_t)g->seed; da.seed_hi = (uint32_t)(g->seed >> 32);
-        if (acc_out) launch_chunk<1>(d, masked, g->row_ids, grid, block, stream, X, g, Y, acc_in, acc_div, 1.0f, acc_out, da, xcd_contig);
-        else if (add_in) launch_chunk<2>(d, masked, g->row_ids, grid, block, stream, X, g, Y, add_in, add_div, out_div, nullptr, da, xcd_contig);
-        else launch_chunk<0>(d, masked, g->row_ids, grid, block, stream, X, g, Y, nullptr, 1.0f, 1.0f, nullptr, da, xcd_contig);
+        // rows beyond kWgRowMax entries: folded inside the d == 64 launch (SPEX_HUB_FOLD=0: by the fix-up launch, as for the wide kernels)
+        const char *fold_sw = g->n_hub > 0 ? getenv("SPEX_HUB_FOLD") : nullptr;      // (read per launch: the tests run both forms in one process)
+        const bool fold_env = !(fold_sw && fold_sw[0] == '0');
+        static std::atomic<uint32_t> launch_tag{0x51000000u};
+        hub.grp = g->hub_grp; hub.fold = g->hub_fold; hub.ticket = g->hub_ticket;
+        hub.tag = (d == 64 && fold_env && g->n_hub > 0 && g->hub_grp && g->hub_ticket) ? launch_tag.fetch_add(1u) + 1u : 0u;
+        if (acc_out) launch_chunk<1>(d, masked, g->row_ids, grid, block, stream, X, g, Y, acc_in, acc_div, 1.0f, acc_out, da, xcd_contig, hub);
+        else if (add_in) launch_chunk<2>(d, masked, g->row_ids, grid, block, stream, X, g, Y, add_in, add_div, out_div, nullptr, da, xcd_contig, hub);
+        else launch_chunk<0>(d, masked, g->row_ids, grid, block, stream, X, g, Y, nullptr, 1.0f, 1.0f, nullptr, da, xcd_contig, hub);
     } else if (masked) {
         hipLaunchKernelGGL((spmm_rows_kernel<true>), grid, block, 0, stream, p);
     } else if (d <= 32) {
@@ -868,7 +935,7 @@ int launch_spmm(const spex_graph *g, const float *X, float *Y, const float *add_
         hipLaunchKernelGGL((spmm_rows_kernel<false>), grid, block, 0, stream, p);
     }
     if (fast) {
-        if (g->n_hub > 0) {  // only rows longer than kWgRowMax go through global scratch on the fast path
+        if (g->n_hub > 0 && hub.tag == 0u) {  // only rows longer than kWgRowMax go through global scratch on the fast path
             const dim3 fgrid((unsigned)((g->n_hub + kWavesPerBlock - 1) / kWavesPerBlock));
             hipLaunchKernelGGL(spmm_long_fixup_kernel, fgrid, block4, 0, stream, p, g->hub_row, g->hub_seg0, g->hub_seg0 + 1, 2,
                                g->n_hub);

@@ -68,6 +68,72 @@ def test_spmm_matches_oracle_random_graph(G, oracle, d):
     assert np.all(Y[deg == 0] == 0)
 
 
+def test_spmm_folds_hub_rows_inside_the_launch(G, oracle, monkeypatch):
+    """Rows beyond 1 024 entries (hubs: 64-entry segments on many waves).  The d == 64 kernel folds them INSIDE the launch — 16
+    adjacent segments per workgroup summed through LDS, one partial row per group, the hub's last group to arrive adds the groups in
+    order — instead of leaving them to spmm_long_fixup_kernel (SPEX_HUB_FOLD=0, and the wide kernels).  Several hubs whose groups
+    straddle workgroups (1 025 entries = 17 segments; 2 000; 6 812; 20 000 = 313 segments in 20+ groups), every epilogue form and
+    the edge-dropout form: against the oracle, against the fix-up form, and bit for bit against itself over repeated launches on
+    the same handle (the tickets carry a per-launch tag; nothing is reset in between)."""
+    rng = np.random.default_rng(11)
+    n_rows, n_cols = 900, 24000
+    deg = rng.integers(0, 50, n_rows)
+    deg[3], deg[4], deg[400], deg[401], deg[899] = 1025, 2000, 6812, 20000, 1100
+    deg[5] = 1024                                   # the longest row that still folds inside ONE workgroup
+    rowptr, col, val = random_csr(rng, n_rows, n_cols, deg)
+    X = rng.normal(size=(n_cols, 64)).astype(np.float32)
+    add, acc = (rng.normal(size=(n_rows, 64)).astype(np.float32) for _ in range(2))
+    g = G(rowptr, col, val, n_cols=n_cols)
+    ref = oracle.spmm(rowptr, col, val, X)
+    hubs = np.diff(rowptr) > 1024
+
+    def forms():
+        out = [g.spmm(t(X)).clone()]
+        Y, A = torch.empty(n_rows, 64, device=DEV), torch.empty(n_rows, 64, device=DEV)
+        g.spmm(t(X), Y=Y, acc_in=t(acc), acc_out=A, acc_div=4.0)
+        out += [Y.clone(), A.clone()]
+        Y2 = torch.empty(n_rows, 64, device=DEV)
+        g.spmm(t(X), Y=Y2, add_in=t(add), add_div=3.0)
+        out.append(Y2.clone())
+        return out
+    monkeypatch.setenv("SPEX_HUB_FOLD", "0")
+    fix = forms()
+    monkeypatch.delenv("SPEX_HUB_FOLD")
+    runs = [forms() for _ in range(10)]
+    torch.cuda.synchronize()
+    for r in runs[1:]:
+        for a, b in zip(runs[0], r):
+            assert torch.equal(a, b)
+    y = runs[0][0].cpu().numpy()
+    # (hub rows: up to 20 000 N(0, 1) terms in fp32 — the oracle's one sequential chain and the kernel's segment / group sums round
+    #  differently by a few 1e-6 of the largest output; the fp64 sum is the arbiter: the kernel is no further from it than the oracle)
+    exact = np.zeros((n_rows, 64))
+    for r in np.nonzero(hubs)[0]:
+        sl = slice(rowptr[r], rowptr[r + 1])
+        exact[r] = val[sl].astype(np.float64) @ X[col[sl]].astype(np.float64)
+    assert rel_err(y[hubs], exact[hubs]) <= max(2e-6, 1.5 * rel_err(ref[hubs], exact[hubs]))
+    assert rel_err(y[~hubs], ref[~hubs]) <= 3e-6            # (incl. the 1 024-entry row: 16 segment sums re-associated)
+    for a, b in zip(runs[0], fix):                                   # the two forms differ in the association of a hub's sum only
+        a, b = a.cpu().numpy(), b.cpu().numpy()
+        assert np.array_equal(a[~hubs], b[~hubs])
+        assert rel_err(a[hubs], b[hubs]) <= 1e-5
+    assert rel_err(runs[0][2].cpu().numpy(), (acc + ref) / np.float32(4.0)) <= 1e-5
+    assert rel_err(runs[0][3].cpu().numpy(), ref + add / np.float32(3.0)) <= 1e-5
+    # edge dropout: the same keep mask in both forms
+    keep = (rng.random(len(col)) < 0.4).astype(np.uint8)
+    g.set_edge_mask(1, t(keep), 0.4, 0)
+    masked = [g.spmm(t(X)).clone() for _ in range(4)]
+    monkeypatch.setenv("SPEX_HUB_FOLD", "0")
+    masked_fix = g.spmm(t(X)).clone()
+    monkeypatch.delenv("SPEX_HUB_FOLD")
+    g.set_edge_mask(0)
+    for m in masked[1:]:
+        assert torch.equal(m, masked[0])
+    ref_m = oracle.spmm(rowptr, col, np.where(keep != 0, val / np.float32(0.4), np.float32(0.0)).astype(np.float32), X)
+    assert rel_err(masked[0].cpu().numpy(), ref_m) <= 1e-5
+    assert rel_err(masked[0].cpu().numpy(), masked_fix.cpu().numpy()) <= 1e-5
+
+
 def test_spmm_fused_epilogues(G, oracle):
     rng = np.random.default_rng(1)
     n = 400
