@@ -441,7 +441,9 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
             emit(r, 0.0f, e);
         }
     }
-    const bool hub = kind == 2 && hf_args.tag != 0u;
+    // (not in the edge-dropout instantiations: with the fold compiled in, their chunk loop schedules worse — <0, MASKED> 13.1 -> 15.7 us
+    //  on Epinion2, which has no hub at all — so a masked launch leaves its hubs to the fix-up launch, as before)
+    const bool hub = !MASKED && kind == 2 && hf_args.tag != 0u;
     if (kind == 2 && !hub) partial[(size_t)(t.w >> 4) * 64 + lane] = acc;  // hub segment: summed by the fix-up launch
     if (t.w & 4) {  // this workgroup combines the segments of rows with 65..1024 entries (and of hub groups) through LDS
         const bool leader = kind == 1 && (t.w & 8);
@@ -906,7 +908,7 @@ int launch_spmm(const spex_graph *g, const float *X, float *Y, const float *add_
         const bool fold_env = !(fold_sw && fold_sw[0] == '0');
         static std::atomic<uint32_t> launch_tag{0x51000000u};
         hub.grp = g->hub_grp; hub.fold = g->hub_fold; hub.ticket = g->hub_ticket;
-        hub.tag = (d == 64 && fold_env && g->n_hub > 0 && g->hub_grp && g->hub_ticket) ? launch_tag.fetch_add(1u) + 1u : 0u;
+        hub.tag = (d == 64 && !masked && fold_env && g->n_hub > 0 && g->hub_grp && g->hub_ticket) ? launch_tag.fetch_add(1u) + 1u : 0u;
         if (acc_out) launch_chunk<1>(d, masked, g->row_ids, grid, block, stream, X, g, Y, acc_in, acc_div, 1.0f, acc_out, da, xcd_contig, hub);
         else if (add_in) launch_chunk<2>(d, masked, g->row_ids, grid, block, stream, X, g, Y, add_in, add_div, out_div, nullptr, da, xcd_contig, hub);
         else launch_chunk<0>(d, masked, g->row_ids, grid, block, stream, X, g, Y, nullptr, 1.0f, 1.0f, nullptr, da, xcd_contig, hub);
