@@ -72,9 +72,9 @@ def test_spmm_folds_hub_rows_inside_the_launch(G, oracle, monkeypatch):
     """Rows beyond 1 024 entries (hubs: 64-entry segments on many waves).  The d == 64 kernel folds them INSIDE the launch — 16
     adjacent segments per workgroup summed through LDS, one partial row per group, the hub's last group to arrive adds the groups in
     order — instead of leaving them to spmm_long_fixup_kernel (SPEX_HUB_FOLD=0, and the wide kernels).  Several hubs whose groups
-    straddle workgroups (1 025 entries = 17 segments; 2 000; 6 812; 20 000 = 313 segments in 20+ groups), every epilogue form and
-    the edge-dropout form: against the oracle, against the fix-up form, and bit for bit against itself over repeated launches on
-    the same handle (the tickets carry a per-launch tag; nothing is reset in between)."""
+    straddle workgroups (1 025 entries = 17 segments; 2 000; 6 812; 20 000 = 313 segments in 20 groups), every epilogue form:
+    against the oracle / the fp64 sum, against the fix-up form, and bit for bit against itself over repeated launches on the same
+    handle (the tickets carry a per-launch tag; nothing is reset in between).  Edge-dropout launches keep the fix-up launch."""
     rng = np.random.default_rng(11)
     n_rows, n_cols = 900, 24000
     deg = rng.integers(0, 50, n_rows)
