@@ -487,6 +487,8 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
                 arrived = (unsigned)__builtin_amdgcn_readfirstlane((int)arrived);
                 last = arrived == (unsigned)hf.y;
                 if (last) {
+                    // (the word goes back to 0: a launch REPLAYED from a captured HIP graph carries the same tag again)
+                    if (lane == 0) __hip_atomic_store(hf_args.ticket + hg.w, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     y = 0.0f;
                     const float *pr = partial + (size_t)hf.x * 64 + lane;
                     int q = 0;

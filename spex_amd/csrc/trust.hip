@@ -732,6 +732,8 @@ __device__ __forceinline__ bool logits_ce(const TrustArgs &p, const TrainArgs &t
                 // (a failed exchange: the word changed under us — only shares of THIS call write it, so the tag is in place now)
                 arrived = (unsigned)__hip_atomic_fetch_add(tr.tickets + b, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
             red[0] = arrived == (unsigned)tr.S ? 1.0f : 0.0f;
+            // (the last share puts the word back to 0: a launch REPLAYED from a captured HIP graph carries the same tag again)
+            if (arrived == (unsigned)tr.S) __hip_atomic_store(tr.tickets + b, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         if (red[0] == 0.0f) return false;
