@@ -134,6 +134,32 @@ def test_spmm_folds_hub_rows_inside_the_launch(G, oracle, monkeypatch):
     assert torch.equal(masked[0], masked_fix)
 
 
+def test_hub_fold_survives_replay_from_a_captured_graph(G):
+    """A launch replayed from a captured HIP graph carries the SAME ticket tag every time: the hub's last group puts the ticket back
+    to 0, so every replay folds again (without that, the second replay would never see a 'last' group and the hub rows would keep
+    their first result).  Capture one product on a graph with hubs, change X between replays, compare with eager launches."""
+    rng = np.random.default_rng(12)
+    n_rows, n_cols = 300, 9000
+    deg = rng.integers(1, 40, n_rows)
+    deg[2], deg[150] = 3000, 8000
+    rowptr, col, val = random_csr(rng, n_rows, n_cols, deg)
+    g = G(rowptr, col, val, n_cols=n_cols)
+    X, Y = torch.zeros(n_cols, 64, device=DEV), torch.zeros(n_rows, 64, device=DEV)
+    xs = [t(rng.normal(size=(n_cols, 64)).astype(np.float32)) for _ in range(3)]
+    torch.cuda.synchronize()
+    cg = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(cg):
+        g.spmm(X, Y=Y)
+    got = []
+    for x in xs:
+        X.copy_(x)
+        cg.replay()
+        got.append(Y.clone())
+    torch.cuda.synchronize()
+    for x, y in zip(xs, got):
+        assert torch.equal(g.spmm(x), y)
+
+
 def test_spmm_fused_epilogues(G, oracle):
     rng = np.random.default_rng(1)
     n = 400
