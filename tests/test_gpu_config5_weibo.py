@@ -359,6 +359,46 @@ def test_two_ranks_partitioned_dual_task_on_the_weibo_shape(weibo, tmp_path):
     assert np.abs(table - want).max() <= 0.02 * args.lr * n_steps
 
 
+def test_trust_head_split_form_survives_replay_from_a_captured_graph():
+    """The split fused trust kernel replayed from a captured HIP graph (the SAME ticket tag on every replay: the path's last
+    workgroup puts the ticket back to 0): three replays on changing user tables equal the eager calls bit for bit."""
+    from spex_amd import _lib, ops
+    from spex_amd.graph import _launch, _ptr
+    n_users, T, L, H = N_USERS, 15, 6, 3
+    gen = torch.Generator(device="cpu"); gen.manual_seed(8)
+    tables = [(torch.rand(n_users + 1, 64, generator=gen) * 0.6 - 0.3).to(DEV) for _ in range(3)]
+    params = (torch.rand(ops.trust_param_count(H, 64), generator=gen) * 0.4 - 0.2).to(DEV)
+    rng = np.random.default_rng(9)
+    lens = rng.integers(1, L + 1, T)
+    seq = np.full((T, L), n_users, np.int64)
+    for k in range(T):
+        seq[k, :lens[k]] = rng.integers(0, n_users, lens[k])
+    seq_d, len_d, tgt = t(seq), t(lens.astype(np.int64)), t(rng.integers(0, n_users, T))
+    n_ws = int(_lib.load().spex_trust_workspace_floats(T, L, 64, H, n_users + 1))
+    z = lambda *sh: torch.zeros(sh, dtype=torch.float32, device=DEV)
+    table, a2, ws, ds, lb, loss, gp, gt = z(n_users + 1, 64), z(T, 64), z(n_ws), z(T, n_users), z(T), z(1), z(params.numel()), z(n_users + 1, 64)
+
+    def call():
+        _launch(DEV, "spex_trust_head_train_f32", _ptr(table), n_users + 1, _ptr(params), _ptr(seq_d), _ptr(len_d), _ptr(tgt), T, L, 64, H, 1,
+                1.0, None, _ptr(a2), _ptr(ds), _ptr(lb), _ptr(ws), _ptr(loss), 0, _ptr(gp), _ptr(gt))
+    torch.cuda.synchronize()
+    cg = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(cg):
+        call()
+    got = []
+    for tb in tables:
+        table.copy_(tb); gt.zero_()
+        cg.replay()
+        got.append((loss.clone(), lb.clone(), gp.clone(), gt.clone()))
+    torch.cuda.synchronize()
+    for tb, g_ in zip(tables, got):
+        table.copy_(tb); gt.zero_()
+        call()
+        for a, b in zip((loss, lb, gp, gt), g_):
+            assert torch.equal(a, b)
+    assert torch.isfinite(got[0][0]).all() and got[0][0].item() > 0 and not torch.equal(got[0][2], got[1][2])
+
+
 def test_trust_head_forms_agree_on_the_weibo_user_table(monkeypatch):
     """spex_trust_head_train_f32 on a 6 812-user table with 15 paths of up to 6 positions (config 5's trust batch on the Weibo
     shape): the fused kernel (one 16-wave workgroup per path; the form the library picks up to ~8 000 users) and the tiled
