@@ -617,7 +617,7 @@ static int graph_create_impl(const int32_t *h_rowptr, const int32_t *h_col, cons
         digest[4] = fnv1a(c_eid);
         digest[5] = fnv1a(c_row, fnv1a(wg_rows));
         digest[6] = fnv1a(seg_beg, fnv1a(seg_end, fnv1a(long_row, fnv1a(long_seg0))));
-        digest[7] = fnv1a(hub_row, fnv1a(hub_seg0, fnv1a(tile_row))) ^ (uint64_t)task.size() ^ ((uint64_t)c_mask.size() << 32);
+        digest[7] = fnv1a(hub_row, fnv1a(hub_seg0, fnv1a(tile_row, fnv1a(hub_grp, fnv1a(hub_fold))))) ^ (uint64_t)task.size() ^ ((uint64_t)c_mask.size() << 32);
         delete g;
         return SPEX_OK;
     }
