@@ -102,7 +102,9 @@ int spex_graph_set_edge_mask(spex_graph_t *g, int mode /*0 off, 1 injected, 2 sa
  *
  * X: [n_cols, d]; Y, add_in, acc_in, acc_out: [n_rows, d].  acc_in may equal acc_out.  X must not alias Y / acc_out.
  * Any d >= 1 (d == 64 takes the tuned path: one lane per column).  A graph with long rows sums their segments through a
- * scratch buffer owned by the handle: calls on ONE stream are ordered by the stream; a call on another stream is made to
+ * scratch buffer owned by the handle (rows beyond 1 024 entries: groups of 16 segments through LDS, one scratch row per group,
+ * folded by the row's last group inside the d == 64 launch — in a fixed order: results repeat bit for bit; SPEX_HUB_FOLD=0,
+ * edge-dropout launches and other d: a small second launch adds them): calls on ONE stream are ordered by the stream; a call on another stream is made to
  * wait (an event, inserted by the library) for everything queued on the stream that used the scratch last, so one handle
  * may be driven from several streams of one host thread.  Concurrent calls from several HOST threads on one handle are
  * not supported (one handle per thread).
