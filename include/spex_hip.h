@@ -76,6 +76,13 @@ int spex_graph_destroy(spex_graph_t *g);
  * host packer runs on SPEX_BUILD_THREADS threads (default min(16, cores)); the layout must not depend on that number. */
 int spex_graph_pack_digest(const int32_t *h_rowptr, const int32_t *h_col, const float *h_val, int32_t n_rows, int32_t n_cols,
                            int64_t nnz, int32_t flags, uint64_t *digest /* [8] */);
+/* HOST ONLY: how the packer laid out the rows beyond 1 024 entries (hubs) — the tables the d == 64 launch folds them by.  out:
+ * [n_positions, n_hubs, then per task position of the table's head (chunks, row, task word, 1 = first wave of a group, waves in
+ * the group, the group's scratch row, hub), then per hub (its first scratch row, its number of groups)]; *n_out = ints needed
+ * (call with out = NULL, cap = 0 to size).  Invariants: every hub starts a 16-task workgroup; its groups are 16 adjacent segments
+ * (the last one shorter, the workgroup topped up with ordinary tasks); a hub's scratch rows are consecutive. */
+int spex_graph_pack_hub_table(const int32_t *h_rowptr, const int32_t *h_col, const float *h_val, int32_t n_rows, int32_t n_cols,
+                              int64_t nnz, int32_t *out, int64_t cap, int64_t *n_out);
 /* n_rows, n_cols, nnz, number of long rows, number of long-row segments (any pointer may be NULL) */
 int spex_graph_info(const spex_graph_t *g, int32_t *n_rows, int32_t *n_cols, int64_t *nnz, int32_t *n_long_rows,
                     int32_t *n_segments);

@@ -21,6 +21,7 @@ SIGNATURES = {
                                                     ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, c_i32, c_vp]),
     "spex_graph_destroy": (ctypes.c_int, [c_vp]),
     "spex_graph_pack_digest": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_i32, c_vp]),
+    "spex_graph_pack_hub_table": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp, c_i64, c_vp]),
     "spex_graph_info": (ctypes.c_int, [c_vp, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), ctypes.POINTER(c_i64),
                                        ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
     "spex_graph_set_edge_mask": (ctypes.c_int, [c_vp, ctypes.c_int, c_vp, c_f32, ctypes.c_uint64]),

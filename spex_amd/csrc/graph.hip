@@ -77,7 +77,8 @@ extern "C" int spex_graph_destroy(spex_graph_t *g)
 }
 
 static int graph_create_impl(const int32_t *h_rowptr, const int32_t *h_col, const float *h_val, const int32_t *h_edge_id, int32_t n_rows,
-                             int32_t n_cols, int64_t nnz, int32_t flags, spex_graph_t **out, uint64_t *digest = nullptr);
+                             int32_t n_cols, int64_t nnz, int32_t flags, spex_graph_t **out, uint64_t *digest = nullptr,
+                             std::vector<int32_t> *hub_dump = nullptr);
 
 // Host only (no device call): the fingerprint of everything spex_graph_create would upload for this matrix — FNV-1a hashes of the
 // task table, the chunk arrays, the segment / hub tables — so that a binding, or the CPU test-suite, can check that the threaded
@@ -89,6 +90,23 @@ extern "C" int spex_graph_pack_digest(const int32_t *h_rowptr, const int32_t *h_
     SPEX_CHECK_ARG((flags & ~SPEX_GRAPH_TILE_ROWS) == 0, "spex_graph_pack_digest: unknown flags 0x%x", flags);
     spex_graph_t *unused = nullptr;
     return graph_create_impl(h_rowptr, h_col, h_val, nullptr, n_rows, n_cols, nnz, flags, &unused, digest);
+}
+
+// Host only: how the packer laid out the rows beyond kWgRowMax entries (the tables the in-kernel hub fold reads) — for tests of the
+// invariants the kernel relies on: every hub starts a workgroup, its groups are 16 adjacent tasks (the last one shorter), the groups'
+// partial rows are numbered consecutively per hub.  out: [n_positions, n_hubs, n_positions x (chunks, row, task.w, leader, waves in
+// the group, partial row, hub), n_hubs x (first partial row, groups)]; *n_out = ints needed (call with cap = 0 to size).
+extern "C" int spex_graph_pack_hub_table(const int32_t *h_rowptr, const int32_t *h_col, const float *h_val, int32_t n_rows, int32_t n_cols,
+                                         int64_t nnz, int32_t *out, int64_t cap, int64_t *n_out)
+{
+    SPEX_CHECK_ARG(n_out && (out || cap == 0), "spex_graph_pack_hub_table: NULL output");
+    spex_graph_t *unused = nullptr;
+    uint64_t digest[8];
+    std::vector<int32_t> dump;
+    if (int rc = graph_create_impl(h_rowptr, h_col, h_val, nullptr, n_rows, n_cols, nnz, 0, &unused, digest, &dump)) return rc;
+    *n_out = (int64_t)dump.size();
+    if (cap >= (int64_t)dump.size()) std::copy(dump.begin(), dump.end(), out);
+    return SPEX_OK;
 }
 
 extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, const float *h_val,
@@ -114,7 +132,7 @@ static uint64_t fnv1a(const std::vector<T> &v, uint64_t h = 1469598103934665603u
 }
 
 static int graph_create_impl(const int32_t *h_rowptr, const int32_t *h_col, const float *h_val, const int32_t *h_edge_id, int32_t n_rows,
-                             int32_t n_cols, int64_t nnz, int32_t flags, spex_graph_t **out, uint64_t *digest)
+                             int32_t n_cols, int64_t nnz, int32_t flags, spex_graph_t **out, uint64_t *digest, std::vector<int32_t> *hub_dump)
 {
     SPEX_CHECK_ARG(out, "spex_graph_create: out is NULL");
     *out = nullptr;
@@ -610,6 +628,19 @@ static int graph_create_impl(const int32_t *h_rowptr, const int32_t *h_col, cons
     }
 
     if (digest) {       // spex_graph_pack_digest: fingerprints of the packed arrays, nothing goes to the device
+        if (hub_dump) {   // spex_graph_pack_hub_table: the head of the task table (every position the hub groups cover) + the fold table
+            hub_dump->clear();
+            hub_dump->push_back((int32_t)hub_grp.size());
+            hub_dump->push_back((int32_t)hub_fold.size());
+            for (size_t k = 0; k < hub_grp.size(); ++k) {
+                const int4 t = task[k], q = hub_grp[k];
+                for (int32_t v : {t.y, t.z, t.w, q.x, q.y, q.z, q.w}) hub_dump->push_back(v);
+            }
+            for (const int2 &f : hub_fold) {
+                hub_dump->push_back(f.x);
+                hub_dump->push_back(f.y);
+            }
+        }
         digest[0] = fnv1a(task);
         digest[1] = fnv1a(c_off);
         digest[2] = fnv1a(c_val);

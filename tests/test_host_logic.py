@@ -490,3 +490,72 @@ def test_message_dropout_replay_draws_what_nn_dropout_draws():
         scale = torch.ones(()) / (1.0 - p)                      # at::dropout: noise.div_(1 - p), then x * noise — the kernels' `scale`
         assert torch.equal(o[keep], (x * scale)[keep])
     assert torch.rand(1).item() == after
+
+
+def _hub_table(rowptr, col, val, n_cols):
+    import ctypes
+    from spex_amd import _lib
+    lib = _lib.load()
+    rowptr, col, val = (np.ascontiguousarray(a) for a in (rowptr.astype(np.int32), col.astype(np.int32), val.astype(np.float32)))
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    n = ctypes.c_int64(0)
+    args = (p(rowptr), p(col), p(val), len(rowptr) - 1, n_cols, len(col))
+    assert lib.spex_graph_pack_hub_table(*args, None, 0, ctypes.byref(n)) == 0, lib.spex_last_error()
+    out = np.zeros(n.value, np.int32)
+    assert lib.spex_graph_pack_hub_table(*args, p(out), n.value, ctypes.byref(n)) == 0, lib.spex_last_error()
+    n_pos, n_hubs = int(out[0]), int(out[1])
+    return out[2:2 + 7 * n_pos].reshape(n_pos, 7), out[2 + 7 * n_pos:].reshape(n_hubs, 2)
+
+
+@pytest.mark.parametrize("shape", ["mixed", "hubs-only", "no-hub"])
+def test_packer_lays_hubs_out_in_groups_the_kernel_can_fold(shape):
+    """What the d == 64 launch assumes when it folds the rows beyond 1 024 entries by itself (spmm.hip, HubFold), checked on the HOST
+    (spex_graph_pack_hub_table): every hub starts a 16-task workgroup; its 64-entry segments follow in order, 16 to a group, the last
+    group shorter and its workgroup topped up with ordinary (or null) tasks that carry the barrier bit; the first task of a group is
+    its leader and knows the group's size; a hub's scratch rows are consecutive, one per group, and the fold table agrees."""
+    rng = np.random.default_rng(21)
+    if shape == "mixed":
+        n_rows, n_cols = 500, 30000
+        deg = rng.integers(0, 70, n_rows)
+        for r, d_ in ((0, 1025), (1, 1024), (7, 2048), (8, 2049), (250, 20000), (499, 5000)):
+            deg[r] = d_
+    elif shape == "hubs-only":
+        n_rows, n_cols = 3, 9000
+        deg = np.array([3000, 1030, 8999])
+    else:
+        n_rows, n_cols = 200, 5000
+        deg = rng.integers(0, 1025, n_rows)
+    rowptr = np.zeros(n_rows + 1, np.int64)
+    rowptr[1:] = np.cumsum(deg)
+    col = np.concatenate([np.sort(rng.choice(n_cols, d_, replace=False)) for d_ in deg] + [np.zeros(0, np.int64)])
+    val = rng.random(len(col)).astype(np.float32)
+    tasks, fold = _hub_table(rowptr, col, val, n_cols)
+    hubs = [r for r in range(n_rows) if deg[r] > 1024]
+    assert len(fold) == len(hubs)
+    if not hubs:
+        assert len(tasks) == 0
+        return
+    pos, slot = 0, 0
+    for h, r in enumerate(hubs):
+        n_seg = -(-int(deg[r]) // 64)
+        n_grp = -(-n_seg // 16)
+        assert pos % 16 == 0                                            # a hub starts a workgroup
+        assert tuple(fold[h]) == (slot, n_grp)
+        left_entries = int(deg[r])
+        for gi in range(n_grp):
+            size = min(16, n_seg - 16 * gi)
+            for w in range(size):
+                chunks, row, word, leader, waves, part, hub = (int(x) for x in tasks[pos])
+                assert row == r and (word & 3) == 2 and (word & 4)      # a hub segment, barrier bit on
+                assert chunks == -(-min(64, left_entries) // 16)        # 64-entry segments in row order (the last one ragged)
+                left_entries -= min(64, left_entries)
+                assert (leader, waves, part, hub) == (1 if w == 0 else 0, size, slot, h)
+                pos += 1
+            while pos % 16:                                             # the rest of the group's workgroup: ordinary / null tasks
+                if pos < len(tasks):
+                    chunks, row, word, leader, waves, part, hub = (int(x) for x in tasks[pos])
+                    assert (word & 3) != 2 and (word & 4) and (leader, waves) == (0, 0)
+                pos += 1
+            slot += 1
+        assert left_entries == 0
+    assert pos >= len(tasks) > pos - 16
