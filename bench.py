@@ -477,7 +477,44 @@ def main():
             for _ in range(20):
                 fnd()
             aux["weibo_shape"]["dual_task_step_ms_B256_T15"] = time_events(fnd, 300)
-            del wnet, wdst, wst, wgraph
+            del wnet, wdst, wst
+            # ... and both under the reference's recommended edge dropout (`--dropout 1 --keepprob 0.3`, README.md:119-123): the masked
+            # launches fold their hub rows inside the launch (spmm_chunk_kernel<.., MASKED, .., FOLD>), no fix-up launch per product
+            try:
+                from spex_amd.graph import csr_transpose
+                from spex_amd.trainer import edge_dropout_mask
+                w_rp, w_c, w_v, w_eid = csr_transpose(*wcsr, len(wcsr[0]) - 1)
+                wgraph_tr = SpexGraph(w_rp, w_c, w_v, n_cols=len(wcsr[0]) - 1, edge_id=w_eid, device=dev)
+                wdstp = LightGCNStepper(wgraph, wE0.clone(), 6813, n_layers=L, lr=lr, graph_t=wgraph_tr)
+                kw = {"k": 0}
+
+                def fnwd():
+                    kw["k"] += 1
+                    mask = edge_dropout_mask(wgraph, 0.3, "philox", 7, kw["k"])
+                    wgraph.set_edge_mask(*mask)
+                    wgraph_tr.set_edge_mask(*mask)
+                    return wdstp.step_bce(wub, wib, yb, loss_acc=wacc, batch_rows_only=True)
+                for _ in range(10):
+                    fnwd()
+                aux["weibo_shape"]["exact_train_step_ms_B256_edge_dropout_0.3"] = time_events(fnwd, 256)
+                wgraph.set_edge_mask(0)
+                del wdstp, wgraph_tr
+                dargs_d = argparse.Namespace(**dict(vars(dargs), dropout=1, keepprob=0.3))
+                wnet_d = mex.LightGCN(dargs_d, _WDS).to(dev)
+                wdst_d = DualTaskStepper(wnet_d, path_capacity=T_PATHS, path_len=P_LEN, lr=1e-3)
+
+                def fndd():
+                    kw["k"] += 1
+                    wdst_d.set_edge_dropout(edge_dropout_mask(wgraph, 0.3, "philox", 7, kw["k"]))
+                    return wdst_d.step(wub, wib, yb, wseq_d, plen_d, wtgt)
+                for _ in range(20):
+                    fndd()
+                aux["weibo_shape"]["dual_task_step_ms_B256_T15_edge_dropout_0.3"] = time_events(fndd, 256)
+                wdst_d.set_edge_dropout(None)
+                del wnet_d, wdst_d
+            finally:
+                wgraph.set_edge_mask(0)
+            del wgraph
             # BASELINE configs[3] on its own shape (Trust_SPEX/code/main_trust.py:44: 8 930 Twitter users): the NGCF training step
             tu_, ti_ = synthetic_interactions(8930, 20000, 400000, seed=9, sigma=1.4)
             tcsr = ngcf_norm_adj(tu_.numpy(), ti_.numpy(), 8930, 20000)

@@ -54,6 +54,13 @@ Rccl &rccl()
     static std::once_flag once;
     std::call_once(once, []() {
         const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        // SPEX_RCCL_LIB: the library to bind instead (a site's own build of RCCL; tests/stubs/rccl_record_stub.c — a recording
+        // stand-in that lets the exchange's peer / count / offset arithmetic be checked for any world size without a wire)
+        const char *forced = getenv("SPEX_RCCL_LIB");
+        if (forced && forced[0]) {
+            r.lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+            if (!r.lib) return;                                      // a named library that does not load is an error, not a fallback
+        }
         for (const char *n : names)                                  // a copy the process already holds (PyTorch's) first
             if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
         for (const char *n : names)
@@ -100,6 +107,10 @@ int need_rccl(const char *who)
 struct spex_comm {
     ncclComm_t comm = nullptr;
     int32_t rank = 0, world = 1;
+    // world == 1: the exchange is a local copy and no RCCL collective is issued — unless SPEX_COMM_NO_SHORTCUT=1 was set when the
+    // communicator was created (tests: RCCL accepts a one-rank communicator, so ncclAllGather / ncclAllReduce / an empty send-recv
+    // group then really execute on a one-GPU box)
+    bool shortcut = true;
 };
 
 extern "C" int spex_comm_unique_id(void *id_out)
@@ -122,6 +133,8 @@ extern "C" int spex_comm_create(int32_t rank, int32_t world, const void *unique_
     spex_comm *c = new spex_comm;
     c->rank = rank;
     c->world = world;
+    const char *ns = getenv("SPEX_COMM_NO_SHORTCUT");
+    c->shortcut = !(ns && ns[0] == '1');
     ncclResult_t r = rccl().CommInitRank(&c->comm, world, id, rank);
     if (r != ncclSuccess) {
         spex::set_error("ncclCommInitRank failed: %s", rccl().GetErrorString(r));
@@ -154,7 +167,7 @@ extern "C" int spex_comm_allgather_rows_f32(spex_comm_t *c, const float *send, f
     SPEX_CHECK_ARG(c && send && recv && max_rows >= 0 && d >= 1, "spex_comm_allgather_rows_f32: bad argument");
     if (max_rows == 0) return SPEX_OK;
     const size_t slot = (size_t)max_rows * d;
-    if (c->world == 1) {
+    if (c->world == 1 && c->shortcut) {
         const int64_t rows = rows_per_rank ? rows_per_rank[0] : max_rows;
         SPEX_CHECK_ARG(rows >= 0 && rows <= max_rows, "spex_comm_allgather_rows_f32: %lld rows in a slot of %lld", (long long)rows, (long long)max_rows);
         if (send != recv) SPEX_HIP(hipMemcpyAsync(recv, send, (size_t)rows * d * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -173,11 +186,20 @@ extern "C" int spex_comm_allgather_rows_f32(spex_comm_t *c, const float *send, f
     if (send != recv + c->rank * slot && mine)
         SPEX_HIP(hipMemcpyAsync(recv + c->rank * slot, send, mine * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     SPEX_NCCL(rccl().GroupStart());
-    for (int q = 0; q < c->world; ++q) {
+    ncclResult_t bad = ncclSuccess;
+    const char *what = "";
+    for (int q = 0; q < c->world && bad == ncclSuccess; ++q) {
         if (q == c->rank) continue;
-        if (mine) SPEX_NCCL(rccl().Send(send, mine, ncclFloat32, q, c->comm, (hipStream_t)stream));
+        if (mine && (bad = rccl().Send(send, mine, ncclFloat32, q, c->comm, (hipStream_t)stream)) != ncclSuccess) { what = "ncclSend"; break; }
         const size_t theirs = (size_t)rows_per_rank[q] * d;
-        if (theirs) SPEX_NCCL(rccl().Recv(recv + q * slot, theirs, ncclFloat32, q, c->comm, (hipStream_t)stream));
+        if (theirs && (bad = rccl().Recv(recv + q * slot, theirs, ncclFloat32, q, c->comm, (hipStream_t)stream)) != ncclSuccess) what = "ncclRecv";
+    }
+    if (bad != ncclSuccess) {
+        // close the group whatever happened: a group left open on this thread would swallow every later collective (they would be
+        // queued into it and never launch — a hang instead of an error)
+        (void)rccl().GroupEnd();
+        spex::set_error("%s failed inside the all-gather's group: %s", what, rccl().GetErrorString(bad));
+        return SPEX_ERR_COMM;
     }
     SPEX_NCCL(rccl().GroupEnd());
     return SPEX_OK;
@@ -186,7 +208,7 @@ extern "C" int spex_comm_allgather_rows_f32(spex_comm_t *c, const float *send, f
 extern "C" int spex_comm_allreduce_sum_f32(spex_comm_t *c, float *buf, int64_t n, void *stream)
 {
     SPEX_CHECK_ARG(c && (buf || n == 0) && n >= 0, "spex_comm_allreduce_sum_f32: bad argument");
-    if (n == 0 || c->world == 1) return SPEX_OK;
+    if (n == 0 || (c->world == 1 && c->shortcut)) return SPEX_OK;
     SPEX_NCCL(rccl().AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, c->comm, (hipStream_t)stream));
     return SPEX_OK;
 }

@@ -302,7 +302,11 @@ struct DropArgs {
 
 // EPI 0: Y = y;  1: Y = y (optional), acc_out = (acc_in + y) / epi_div;  2: Y = (y + add_in / epi_div) / out_div.
 // ROWIDS: a task's rows are listed per entry (bin-packed tasks) instead of being adjacent from task.z.
-template <int EPI, bool MASKED, bool ROWIDS>
+// FOLD: the hub fold is compiled in.  The unmasked instantiations always carry it (it costs their chunk loop nothing); the
+// edge-dropout ones sit ~20 scalar registers higher (the Philox key schedule lives in SGPRs) and with the fold's operands live across
+// the loop they schedule worse (<0, MASKED> 13.1 -> 15.7 us on Epinion2, a graph without a single hub), so a masked launch takes the
+// FOLD instantiation only on a graph that HAS hubs — where it replaces a ~5 us dependent fix-up launch per product.
+template <int EPI, bool MASKED, bool ROWIDS, bool FOLD>
 __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
     const float *__restrict__ X, const uint32_t *__restrict__ chunk_off, const float *__restrict__ chunk_val,
     const uint32_t *__restrict__ chunk_mask, const int32_t *__restrict__ chunk_row, const int4 *__restrict__ task,
@@ -441,9 +445,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
             emit(r, 0.0f, e);
         }
     }
-    // (not in the edge-dropout instantiations: with the fold compiled in, their chunk loop schedules worse — <0, MASKED> 13.1 -> 15.7 us
-    //  on Epinion2, which has no hub at all — so a masked launch leaves its hubs to the fix-up launch, as before)
-    const bool hub = !MASKED && kind == 2 && hf_args.tag != 0u;
+    const bool hub = FOLD && kind == 2 && hf_args.tag != 0u;
     if (kind == 2 && !hub) partial[(size_t)(t.w >> 4) * 64 + lane] = acc;  // hub segment: summed by the fix-up launch
     if (t.w & 4) {  // this workgroup combines the segments of rows with 65..1024 entries (and of hub groups) through LDS
         const bool leader = kind == 1 && (t.w & 8);
@@ -464,7 +466,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
         if (hub_leader) {
             // A hub's segments are adjacent in the table: this wave and the hg.y - 1 behind it hold consecutive segments of row t.z.
             // Their sum is ONE partial row of the hub; the hub's groups meet through memory: agent-scope store (write-through: the
-            // groups may run on different XCDs), the wave's own stores acknowledged, a ticket on the hub — (launch tag << 32) |
+            // groups may run on different XCDs), the wave's own stores acknowledged (explicit vmcnt(0)), a ticket on the hub — (launch tag << 32) |
             // arrivals, anything else in the word counts as "nobody yet" — and the LAST group to arrive adds the partial rows in group
             // order (whoever is last: the same order, the same bits) and runs the row's epilogue.  No fence (an agent-scope fence on
             // gfx950 writes back / invalidates the XCD's whole L2), no waiting, no second launch.
@@ -474,7 +476,12 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
             bool last = true;
             if (hf.y > 1) {
                 __hip_atomic_store(partial + (size_t)hg.z * 64 + lane, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                // the wave's partial-row store is ACKNOWLEDGED (sc1 write-through: visible to every XCD) before lane 0 touches the
+                // ticket: an explicit s_waitcnt vmcnt(0) — a workgroup-scope release fence emits no vmcnt wait on gfx950, and the
+                // wait the compiler happens to place for the ticket load's data below is not a guarantee.  One wave = one
+                // instruction stream, so the wait covers all 64 lanes' stores.  tests/test_isa_folds.py asserts it in the ISA.
+                __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0); expcnt / lgkmcnt unconstrained
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // (compiler ordering only)
                 unsigned arrived = 1u;
                 if (lane == 0) {
                     unsigned long long *tk = hf_args.ticket + hg.w;
@@ -804,10 +811,14 @@ void launch_chunk_v(bool masked, bool row_ids, dim3 grid, dim3 block, hipStream_
 {
 #define SPEX_GO(M, R)                                                                                                  \
     do {                                                                                                               \
-        if (V == 1)                                                                                                    \
-            hipLaunchKernelGGL((spmm_chunk_kernel<EPI, M, R>), grid, block, 0, stream, X, g->chunk_off, g->chunk_val,  \
-                               g->chunk_mask, g->chunk_row, g->task, g->n_tasks, Y, epi_in, epi_div, out_div, acc_out, \
-                               g->partial, da, xcd_contig, hub);                                                       \
+        if (V == 1 && (!M || hub.tag != 0u))                                                                           \
+            hipLaunchKernelGGL((spmm_chunk_kernel<EPI, M, R, true>), grid, block, 0, stream, X, g->chunk_off,          \
+                               g->chunk_val, g->chunk_mask, g->chunk_row, g->task, g->n_tasks, Y, epi_in, epi_div,     \
+                               out_div, acc_out, g->partial, da, xcd_contig, hub);                                     \
+        else if (V == 1)                                                                                               \
+            hipLaunchKernelGGL((spmm_chunk_kernel<EPI, M, R, !M>), grid, block, 0, stream, X, g->chunk_off,            \
+                               g->chunk_val, g->chunk_mask, g->chunk_row, g->task, g->n_tasks, Y, epi_in, epi_div,     \
+                               out_div, acc_out, g->partial, da, xcd_contig, hub);                                     \
         else                                                                                                           \
             hipLaunchKernelGGL((spmm_chunk_wide_kernel<EPI, M, R, (V == 1 ? 2 : V)>), grid, block, 0, stream, X,       \
                                g->chunk_off, g->chunk_val, g->chunk_mask, g->chunk_row, g->task, g->n_tasks, Y, epi_in, \
@@ -910,7 +921,7 @@ int launch_spmm(const spex_graph *g, const float *X, float *Y, const float *add_
         const bool fold_env = !(fold_sw && fold_sw[0] == '0');
         static std::atomic<uint32_t> launch_tag{0x51000000u};
         hub.grp = g->hub_grp; hub.fold = g->hub_fold; hub.ticket = g->hub_ticket;
-        hub.tag = (d == 64 && !masked && fold_env && g->n_hub > 0 && g->hub_grp && g->hub_ticket) ? launch_tag.fetch_add(1u) + 1u : 0u;
+        hub.tag = (d == 64 && fold_env && g->n_hub > 0 && g->hub_grp && g->hub_ticket) ? launch_tag.fetch_add(1u) + 1u : 0u;
         if (acc_out) launch_chunk<1>(d, masked, g->row_ids, grid, block, stream, X, g, Y, acc_in, acc_div, 1.0f, acc_out, da, xcd_contig, hub);
         else if (add_in) launch_chunk<2>(d, masked, g->row_ids, grid, block, stream, X, g, Y, add_in, add_div, out_div, nullptr, da, xcd_contig, hub);
         else launch_chunk<0>(d, masked, g->row_ids, grid, block, stream, X, g, Y, nullptr, 1.0f, 1.0f, nullptr, da, xcd_contig, hub);

@@ -706,8 +706,9 @@ __device__ __forceinline__ bool logits_ce(const TrustArgs &p, const TrainArgs &t
         if ((t & 63) < 16) reinterpret_cast<float4 *>(sacc + wv * kD)[sub] = acc4;
         __syncthreads();
         // ---- publish this share: agent-scope stores go through to memory (the path's workgroups may sit on different XCDs, whose
-        //      L2s do not see each other's lines), and every thread has its own stores acknowledged before the barrier in front of
-        //      the ticket.  No agent-scope FENCE anywhere: on gfx950 that is a writeback + invalidate of the XCD's whole L2.
+        //      L2s do not see each other's lines), and every thread has its own stores acknowledged (explicit vmcnt(0) below) before
+        //      the barrier in front of the ticket.  No agent-scope FENCE anywhere: on gfx950 that is a writeback + invalidate of the
+        //      XCD's whole L2.
         if (t < kD) {
             float g = 0.0f;
             for (int w = 0; w < kPathWaves; ++w) g += sacc[w * kD + t];
@@ -717,7 +718,13 @@ __device__ __forceinline__ bool logits_ce(const TrustArgs &p, const TrainArgs &t
             __hip_atomic_store(tr.part_ms + ((size_t)sp * B + b) * 2, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(tr.part_ms + ((size_t)sp * B + b) * 2 + 1, se, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // (s_waitcnt on the thread's own stores)
+        // EVERY thread waits here for the acknowledgement of ALL its outstanding stores — the raw scores of the sweep above and the
+        // share just written — with an explicit s_waitcnt vmcnt(0).  (A workgroup-scope release fence emits NO vmcnt wait on gfx950
+        // outside tgsplit mode; an agent-scope release would add a buffer_wbl2 of the XCD's L2.  The stores are sc1 write-through, so
+        // "acknowledged" = visible to every XCD.)  The barrier then orders all threads' acknowledgements before thread 0's ticket.
+        // tests/test_isa_folds.py asserts the wait in the compiled ISA.
+        __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0); expcnt / lgkmcnt unconstrained
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // (compiler ordering + LDS; not what acknowledges the stores)
         __syncthreads();
         if (t == 0) {
             // the ticket word: (this call's tag << 32) | arrivals.  Whatever else is there — an earlier call's word, or nothing the

@@ -463,6 +463,11 @@ class PartitionedStepper:
             self._desc_B = self._B
         d = self._desc
         d.t, d.lr, d.flags = self.t, self.lr, (_lib.STEP_DETERMINISTIC if deterministic else 0)
+        # the exchange form may have been switched since the descriptor was built (set_allgather): refreshed like t / lr / flags; the
+        # ctypes array is kept alive by the stepper for as long as the descriptor points at it
+        self._rpr_keep = P._rows_per_rank
+        d.rows_per_rank = None if P._rows_per_rank is None else ctypes.cast(P._rows_per_rank, ctypes.c_void_p).value
+        d.comm = P.native._h.value
         _launch(self.E0.device, "spex_partitioned_step_bce_f32", ctypes.byref(d), ctypes.c_void_p(pos.data_ptr()),
                 ctypes.c_void_p(labels.data_ptr()), B, ctypes.c_void_p(loss_acc.data_ptr()))
         self.t = d.t

@@ -74,7 +74,7 @@ def test_spmm_folds_hub_rows_inside_the_launch(G, oracle, monkeypatch):
     order — instead of leaving them to spmm_long_fixup_kernel (SPEX_HUB_FOLD=0, and the wide kernels).  Several hubs whose groups
     straddle workgroups (1 025 entries = 17 segments; 2 000; 6 812; 20 000 = 313 segments in 20 groups), every epilogue form:
     against the oracle / the fp64 sum, against the fix-up form, and bit for bit against itself over repeated launches on the same
-    handle (the tickets carry a per-launch tag; nothing is reset in between).  Edge-dropout launches keep the fix-up launch."""
+    handle (the tickets carry a per-launch tag; nothing is reset in between).  Edge-dropout launches fold the same way."""
     rng = np.random.default_rng(11)
     n_rows, n_cols = 900, 24000
     deg = rng.integers(0, 50, n_rows)
@@ -119,19 +119,33 @@ def test_spmm_folds_hub_rows_inside_the_launch(G, oracle, monkeypatch):
         assert rel_err(a[hubs], b[hubs]) <= 1e-5
     assert rel_err(runs[0][2].cpu().numpy(), (acc + ref) / np.float32(4.0)) <= 1e-5
     assert rel_err(runs[0][3].cpu().numpy(), ref + add / np.float32(3.0)) <= 1e-5
-    # edge dropout (the masked instantiations leave their hubs to the fix-up launch in either setting: same bits)
+    # edge dropout (reference README.md:119-123 / utility1/model.py:46-55): the masked launch folds its hubs in the launch too
+    # (spmm_chunk_kernel<.., MASKED, .., FOLD> — taken only on a graph that has hubs); every epilogue form: fold vs fix-up vs oracle
     keep = (rng.random(len(col)) < 0.4).astype(np.uint8)
     g.set_edge_mask(1, t(keep), 0.4, 0)
-    masked = [g.spmm(t(X)).clone() for _ in range(4)]
+    masked = [forms() for _ in range(4)]
     monkeypatch.setenv("SPEX_HUB_FOLD", "0")
-    masked_fix = g.spmm(t(X)).clone()
+    masked_fix = forms()
     monkeypatch.delenv("SPEX_HUB_FOLD")
     g.set_edge_mask(0)
     for m in masked[1:]:
-        assert torch.equal(m, masked[0])
-    ref_m = oracle.spmm(rowptr, col, np.where(keep != 0, val / np.float32(0.4), np.float32(0.0)).astype(np.float32), X)
-    assert rel_err(masked[0].cpu().numpy(), ref_m) <= 1e-5
-    assert torch.equal(masked[0], masked_fix)
+        for a, b in zip(masked[0], m):
+            assert torch.equal(a, b)
+    vm = np.where(keep != 0, val / np.float32(0.4), np.float32(0.0)).astype(np.float32)
+    ref_m = oracle.spmm(rowptr, col, vm, X)
+    exact_m = np.zeros((n_rows, 64))
+    for r in np.nonzero(hubs)[0]:
+        sl = slice(rowptr[r], rowptr[r + 1])
+        exact_m[r] = vm[sl].astype(np.float64) @ X[col[sl]].astype(np.float64)
+    ym = masked[0][0].cpu().numpy()
+    assert rel_err(ym[hubs], exact_m[hubs]) <= max(2e-6, 1.5 * rel_err(ref_m[hubs], exact_m[hubs]))
+    assert rel_err(ym[~hubs], ref_m[~hubs]) <= 3e-6
+    for a, b in zip(masked[0], masked_fix):
+        a, b = a.cpu().numpy(), b.cpu().numpy()
+        assert np.array_equal(a[~hubs], b[~hubs])
+        assert rel_err(a[hubs], b[hubs]) <= 1e-5
+    assert rel_err(masked[0][2].cpu().numpy(), (acc + ref_m) / np.float32(4.0)) <= 1e-5
+    assert rel_err(masked[0][3].cpu().numpy(), ref_m + add / np.float32(3.0)) <= 1e-5
 
 
 def test_hub_fold_survives_replay_from_a_captured_graph(G):
