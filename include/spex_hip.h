@@ -850,6 +850,57 @@ int spex_partitioned_propagate_f32(spex_partitioned_step_t *step, void *stream);
 int spex_partitioned_step_bce_f32(spex_partitioned_step_t *step, const int64_t *pos, const float *labels, int32_t B, float *loss_sum,
                                   void *stream);
 
+/* BASELINE config 5's multi-GPU form — the dual-task step (LightGCN_SPEX/code/main_auto_expert_s.py:53-91 with
+ * utility1/model_expert_s.py) on the row partition, as ONE native call:
+ *   rec branch   L x (exchange, SpMM on the rank's block, running layer sum fused); the FIRST exchange's table (= E^0 of every rank)
+ *                is kept in gathered0.  The batch's 2B rows of E^0 AND of the propagated table are fetched owner-computes (two
+ *                spex_gather_owned_rows_f32 into one buffer, ONE all-reduce of 4B rows), and the gate (model_expert_s.py:154-161),
+ *                the scores, the BCE loss and the gate's backward run on those compact rows — replicated: every rank computes the
+ *                same 2B rows, so the two gate matrices' gradients are COMPLETE on every rank and need no collective (the Python
+ *                schedule of round 3 gated all local rows and all-reduced 1 KB of gate gradients instead).  Each rank adds the
+ *                gradient rows it owns into its blocks (d loss / d propagated rows -> backward L x (exchange, SpMM on the block of
+ *                A^T); d loss / d E^0 rows directly).
+ *   trust branch the user block of gathered0 gathered into the contiguous user_table ([n_user_rows, 64], user_pos = the user rows'
+ *                positions in the padded layout) and spex_trust_head_train_f32 on it — redundantly on every rank (<= path_capacity
+ *                paths), identical results by construction; with side_stream set it runs beside the rec branch (forked behind the
+ *                first exchange, joined in front of the Adam pass).
+ *   Adam         one pass over the rank's arena [n_local x 64 table rows | trust block P | att_exp1 256 | att_exp2 256 |
+ *                task_weights 2]: owner-computes on the table rows (the rank's user rows take the trust head's table gradient at
+ *                rows user_lo ..), replicated — identical gradients, identical updates — on the dense parameters; the task
+ *                precisions and the task weights' own gradients as in spex_dual_task_step_f32.
+ * 2 L exchanges + 1 all-reduce per step.  flags: SPEX_STEP_DETERMINISTIC (owned rows added in slot order, no float atomics),
+ * SPEX_STEP_FIXED_TASK_WEIGHTS.  d == 64, L >= 1, no edge dropout.
+ * Buffers (caller-owned): params / m / v: the arena above; light, g_prop, g_raw, gs, g_E0: [n_local, 64] (g_prop, g_raw all-zero
+ * before the first call; every call leaves them so); send [max_rows, 64]; gathered, gathered0 [world * max_rows, 64];
+ * rows [2 * slot_capacity, 64]; mixed_slots, grad_slots, g_prop_slots, g_raw_slots [slot_capacity, 64], slot_capacity >= 2B;
+ * loss_rows [slot_capacity]; att_parts [spex_expert_gate_rows_bwd_parts(slot_capacity) * 512]; arange int64 [slot_capacity];
+ * g_user [n_user_rows, 64]; g_small [P + 512] (all-zero before the first call); a2, trust_ws, dscore, loss_b, loss [2],
+ * loss_acc [2], precision [2][2] as in spex_dual_task_step_t (trust workspace sized for n_user_rows).
+ * pos: device int64 [2B], the batch's rows in the padded layout (users, then items).  t is advanced by the call. */
+typedef struct spex_partitioned_dual_step {
+    const spex_graph_t *graph, *graph_t;
+    spex_comm_t *comm;
+    const int32_t *rows_per_rank;
+    float *params, *m, *v;
+    float *light, *g_prop, *g_raw, *gs, *g_E0, *send, *gathered, *gathered0;
+    const int64_t *user_pos;
+    float *user_table;
+    float *rows, *mixed_slots, *grad_slots, *g_prop_slots, *g_raw_slots, *loss_rows, *att_parts;
+    const int64_t *arange;
+    float *g_user, *g_small;
+    float *a2, *trust_ws, *dscore, *loss_b;
+    float *loss, *loss_acc, *precision;
+    int32_t n_local, max_rows, n_local_users, user_lo;   /* the rank's first n_local_users rows are user rows user_lo .. */
+    int32_t slot_capacity, path_capacity, path_len, n_user_rows, L, d, n_heads, hybrid, n_rec;
+    float lr, beta1, beta2, eps;
+    int32_t t;
+    void *side_stream, *ev_fork, *ev_join;   /* optional second stream + the library's event cells (zero-initialise; release with
+                                              * spex_step_events_release) */
+    int32_t flags;
+} spex_partitioned_dual_step_t;
+int spex_partitioned_dual_task_step_f32(spex_partitioned_dual_step_t *step, const int64_t *pos, const float *labels, int32_t B,
+                                        const int64_t *seq, const int64_t *seq_l, const int64_t *targets, int32_t T, void *stream);
+
 /* ------------------------------------------------------------------------------------------------ profiling hook
  * Not part of any reference interface: lets a caller time the dominant kernel itself, in place, on the stream it is
  * launched on (bench.py's roofline figure).  While a timer is attached to a graph, every (or every n-th) call of

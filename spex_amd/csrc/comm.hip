@@ -312,3 +312,126 @@ extern "C" int spex_partitioned_step_bce_f32(spex_partitioned_step_t *s, const i
     s->t += 1;
     return SPEX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// BASELINE config 5 on the row partition (main_auto_expert_s.py:53-91): see include/spex_hip.h, spex_partitioned_dual_step_t.
+// Every launch is one of the library's own entry points; the only collectives are the 2 L exchanges and one all-reduce.
+static int exchange_into(spex_comm_t *comm, const int32_t *rows_per_rank, float *send, const float *local, int64_t n_local, int64_t max_rows,
+                         int32_t d, float *table, void *stream)
+{
+    const size_t bytes = (size_t)n_local * d * sizeof(float);
+    if (local != send && bytes) SPEX_HIP(hipMemcpyAsync(send, local, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return spex_comm_allgather_rows_f32(comm, send, table, max_rows, d, rows_per_rank, stream);
+}
+
+extern "C" int spex_partitioned_dual_task_step_f32(spex_partitioned_dual_step_t *s, const int64_t *pos, const float *labels, int32_t B,
+                                                   const int64_t *seq, const int64_t *seq_l, const int64_t *targets, int32_t T, void *stream)
+{
+    const char *who = "spex_partitioned_dual_task_step_f32";
+    SPEX_CHECK_ARG(s && s->graph && s->graph_t && s->comm && s->params && s->m && s->v && s->light && s->g_prop && s->g_raw && s->gs && s->g_E0
+                       && s->send && s->gathered && s->gathered0 && s->user_pos && s->user_table && s->rows && s->mixed_slots && s->grad_slots
+                       && s->g_prop_slots && s->g_raw_slots && s->loss_rows && s->att_parts && s->arange && s->g_user && s->g_small && s->a2
+                       && s->trust_ws && s->dscore && s->loss_b && s->loss && s->loss_acc && s->precision,
+                   "%s: NULL field in the step descriptor", who);
+    SPEX_CHECK_ARG(pos && labels && B >= 1 && s->slot_capacity >= 2 * B, "%s: batch of %d for a slot capacity of %d", who, B, s->slot_capacity);
+    SPEX_CHECK_ARG(T >= 0 && T <= s->path_capacity && (T == 0 || (seq && seq_l && targets)), "%s: T=%d paths (capacity %d) or NULL path pointer", who,
+                   T, s->path_capacity);
+    const int32_t d = 64, L = s->L, H = s->n_heads, n_u = s->n_user_rows;
+    const int64_t n_loc = s->n_local, max_rows = s->max_rows, world = s->comm->world, lo = (int64_t)s->comm->rank * max_rows;
+    SPEX_CHECK_ARG(s->d == 64 && L >= 1 && n_loc >= 0 && n_loc <= max_rows && n_u >= 2, "%s: d=%d L=%d n_local=%d max_rows=%d n_user_rows=%d", who, s->d,
+                   L, s->n_local, s->max_rows, n_u);
+    SPEX_CHECK_ARG(s->graph->n_rows == n_loc && s->graph_t->n_rows == n_loc && s->graph->n_cols == world * max_rows
+                       && s->graph_t->n_cols == s->graph->n_cols,
+                   "%s: the row blocks must be n_local x (world * max_rows) in the padded layout", who);
+    SPEX_CHECK_ARG(s->graph->mask_mode == 0 && s->graph_t->mask_mode == 0, "%s: edge dropout is not supported in the partitioned step", who);
+    SPEX_CHECK_ARG(s->n_local_users >= 0 && s->n_local_users <= n_loc && s->user_lo >= 0 && s->user_lo + s->n_local_users <= n_u,
+                   "%s: %d local user rows from user row %d of %d", who, s->n_local_users, s->user_lo, n_u);
+    const int64_t n_trust = spex_trust_param_count(d, H);
+    SPEX_CHECK_ARG(n_trust > 0, "%s: unsupported number of heads %d", who, H);
+    const bool det = (s->flags & SPEX_STEP_DETERMINISTIC) != 0;
+    const size_t sz = (size_t)n_loc * d;
+    float *E0 = s->params, *trust_p = E0 + sz, *att1 = trust_p + n_trust, *att2 = att1 + 4 * d;
+    float *g_att1 = s->g_small + n_trust, *g_att2 = g_att1 + 4 * d;
+
+    // ---- layer 1's exchange first: its table is E^0 of every rank — what the trust branch reads
+    SPEX_TRY(exchange_into(s->comm, s->rows_per_rank, s->send, E0, n_loc, max_rows, d, s->gathered0, stream));
+    // ---- trust branch (model_expert_s.py:170-192) on the gathered user block, redundantly on every rank; beside the rec branch
+    //      when the caller gave a second stream
+    const bool two_streams = s->side_stream != nullptr && s->side_stream != stream && T > 0;
+    auto trust_branch = [&](void *st) -> int {
+        SPEX_HIP(hipMemsetAsync(s->g_user, 0, (size_t)n_u * d * sizeof(float), (hipStream_t)st));   // (the Adam pass clears the rank's rows only)
+        SPEX_TRY(spex_gather_owned_rows_f32(s->gathered0, s->user_pos, n_u, 0, world * max_rows, d, s->user_table, st));
+        return spex::trust_head_train(s->user_table, n_u, trust_p, seq, seq_l, targets, T, s->path_len, d, H, s->hybrid, 1.0f, nullptr, s->a2,
+                                      s->dscore, s->loss_b, s->trust_ws, s->loss + 1, 0, s->g_small, s->g_user, st == stream && !det ? 8 : 1, st);
+    };
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    int rc_trust = SPEX_OK;
+    bool forked = false;
+    if (two_streams) {
+        if (!s->ev_fork) { hipEvent_t e = nullptr; SPEX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); s->ev_fork = e; }
+        if (!s->ev_join) { hipEvent_t e = nullptr; SPEX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); s->ev_join = e; }
+        fork_ev = (hipEvent_t)s->ev_fork; join_ev = (hipEvent_t)s->ev_join;
+        SPEX_HIP(hipEventRecord(fork_ev, (hipStream_t)stream));
+        SPEX_HIP(hipStreamWaitEvent((hipStream_t)s->side_stream, fork_ev, 0));
+        forked = true;
+        rc_trust = trust_branch(s->side_stream);
+        if (hipEventRecord(join_ev, (hipStream_t)s->side_stream) != hipSuccess && rc_trust == SPEX_OK) rc_trust = SPEX_ERR_HIP;
+    }
+    auto rec_branch = [&]() -> int {
+        // ---- forward (model_expert_s.py:95-126): L x (exchange, SpMM on the rank's rows with the running sum fused)
+        for (int32_t l = 0; l < L; ++l) {
+            if (l > 0) SPEX_TRY(exchange_into(s->comm, s->rows_per_rank, s->send, s->send, n_loc, max_rows, d, s->gathered, stream));
+            const bool last = l == L - 1;
+            if (n_loc)
+                SPEX_TRY(spex_spmm_f32(s->graph, l == 0 ? s->gathered0 : s->gathered, last ? nullptr : s->send, nullptr, 1.0f, l == 0 ? E0 : s->light,
+                                       s->light, last ? (float)(L + 1) : 1.0f, d, stream));
+        }
+        // ---- the batch's rows of E^0 and of the propagated table on every rank: owner-computes, ONE all-reduce of 4B rows
+        float *rows_raw = s->rows, *rows_prop = s->rows + (size_t)2 * B * d;
+        SPEX_TRY(spex_gather_owned_rows_f32(E0, pos, 2 * (int64_t)B, lo, n_loc, d, rows_raw, stream));
+        SPEX_TRY(spex_gather_owned_rows_f32(s->light, pos, 2 * (int64_t)B, lo, n_loc, d, rows_prop, stream));
+        SPEX_TRY(spex_comm_allreduce_sum_f32(s->comm, s->rows, (int64_t)4 * B * d, stream));
+        // ---- gate, scores, BCE, and the gate's backward on the compact rows (slot b: the user row of sample b — att_exp1 —, slot
+        //      B + b: its item row — att_exp2): the same 2B rows on every rank, so g_att1 / g_att2 are complete everywhere
+        SPEX_TRY(spex_expert_gate_rows_f32(rows_raw, rows_prop, att1, att2, s->arange, B, 0, s->arange, B, B, B, 2 * (int64_t)B, d, s->mixed_slots,
+                                           stream));
+        SPEX_TRY(spex::score_bce_slots_rows(s->mixed_slots, s->mixed_slots + (size_t)B * d, d, d, B, B, s->arange, s->arange, labels, B, d,
+                                            s->loss_rows, 1.0f / (float)B, s->grad_slots, d, stream));
+        SPEX_TRY(spex::sum_ordered(s->loss_rows, B, 1.0f, s->loss, 1, stream));
+        SPEX_TRY(spex_expert_gate_rows_bwd_det_f32(rows_raw, rows_prop, att1, att2, s->arange, B, 0, s->arange, B, B, B, 2 * (int64_t)B, d,
+                                                   s->grad_slots, d, s->g_prop_slots, s->g_raw_slots, s->att_parts, stream));
+        const int32_t n_parts = spex_expert_gate_rows_bwd_parts(2 * B);
+        SPEX_TRY(spex::sum_parts(s->att_parts, n_parts, 512, 256, g_att1, 0, stream));
+        SPEX_TRY(spex::sum_parts(s->att_parts + 256, n_parts, 512, 256, g_att2, 0, stream));
+        // ---- the rows this rank owns into its gradient blocks
+        if (det) {
+            SPEX_TRY(spex_reduce_slots_f32(pos, 2 * B, -lo, nullptr, 0, 0, (int32_t)n_loc, s->g_prop_slots, d, 1.0f, s->g_prop, 0, d, stream));
+            SPEX_TRY(spex_reduce_slots_f32(pos, 2 * B, -lo, nullptr, 0, 0, (int32_t)n_loc, s->g_raw_slots, d, 1.0f, s->g_raw, 0, d, stream));
+        } else {
+            SPEX_TRY(spex_scatter_add_owned_rows_f32(s->g_prop_slots, pos, 2 * (int64_t)B, lo, n_loc, d, s->g_prop, 0, stream));
+            SPEX_TRY(spex_scatter_add_owned_rows_f32(s->g_raw_slots, pos, 2 * (int64_t)B, lo, n_loc, d, s->g_raw, 0, stream));
+        }
+        // ---- backward through the propagation: G_L = g / (L + 1);  G_l = g / (L + 1) + A^T G_{l+1} on the blocks of A^T
+        SPEX_TRY(spex::scale_div(s->g_prop, s->gs, (float)(L + 1), (int64_t)sz, stream));
+        const float *cur = s->gs;
+        for (int32_t l = L - 1; l >= 0; --l) {
+            SPEX_TRY(exchange_into(s->comm, s->rows_per_rank, s->send, cur, n_loc, max_rows, d, s->gathered, stream));
+            float *nxt = l == 0 ? s->g_E0 : s->send;
+            if (n_loc) SPEX_TRY(spex_spmm_f32(s->graph_t, s->gathered, nxt, s->gs, 1.0f, nullptr, nullptr, 1.0f, d, stream));
+            cur = s->send;
+        }
+        return SPEX_OK;
+    };
+    int rc = rec_branch();
+    if (forked && hipStreamWaitEvent((hipStream_t)stream, join_ev, 0) != hipSuccess && rc == SPEX_OK) rc = SPEX_ERR_HIP;   // joined on every path
+    if (rc == SPEX_OK) rc = rc_trust;
+    if (rc == SPEX_OK && T > 0 && !two_streams) rc = trust_branch(stream);
+    if (rc != SPEX_OK) return rc;
+    // ---- uncertainty-weighted sum of both losses + Adam (main_auto_expert_s.py:78-89) over the rank's arena: its table rows
+    //      (the first n_local_users of them take the trust head's rows user_lo ..), and the replicated dense parameters
+    SPEX_TRY(spex::dual_task_adam(s->params, s->m, s->v, s->g_E0, s->g_raw, s->g_user + (size_t)s->user_lo * d, s->g_small, s->g_prop, nullptr, s->loss,
+                                  s->loss_acc, s->precision, (int64_t)sz, (int64_t)s->n_local_users * d, n_trust, B, T, s->n_rec, s->t + 1, s->lr,
+                                  s->beta1, s->beta2, s->eps, (s->flags & SPEX_STEP_FIXED_TASK_WEIGHTS) != 0, stream, 0.0f, nullptr, 0, 0, 0, 1));
+    s->t += 1;
+    return SPEX_OK;
+}

@@ -137,3 +137,149 @@ class PartitionedDualTask(nn.Module):
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)
                 dist.all_reduce(p.grad, group=self.group)
+
+
+class PartitionedDualTaskStepper:
+    """The dual-task training step on the row partition as ONE native call (spex_partitioned_dual_task_step_f32) — what
+    DualTaskStepper is to the single-GPU model: no autograd, no allocation, no host work between the launches; the exchanges go
+    through the model's NativeComm (spex_comm_*, RCCL bound inside the library).  main_auto_expert_s.py:53-91.
+
+    model: a PartitionedDualTask (every rank built from the same seed).  Its parameters are re-homed into the rank's flat arena
+    [n_local table rows | trust block | att_exp1 | att_exp2 | task_weights] and trained in place: `model.E0_local` and the core's dense
+    parameters stay valid views, so evaluation / checkpointing read the trained values.  Every rank must pass the same batch and
+    the same paths.  The gate runs on the batch's 2B rows (replicated), so no gate-gradient collective is needed: per step the
+    wire carries 2 L exchanges and one all-reduce of 4B rows.
+    exchange: "native" (equal padded shards, ncclAllGather) or "native-p2p" (real rows, grouped send / recv)."""
+
+    def __init__(self, model, path_capacity, path_len, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, n_rec=5, batch_capacity=256,
+                 exchange="native-p2p", two_streams=True, deterministic=False, fixed_task_weights=False, comm=None):
+        from . import _lib, ops
+        core, P = model.core, model.P
+        dev = model.E0_local.device
+        assert dev.type == "cuda", "PartitionedDualTaskStepper: GPU only (no CPU fallback)"
+        d = P.d
+        n_heads = len(core.in_att)
+        if d != 64 or core.hidden_size != d or not ops.trust_head_supported(d, path_len, n_heads):
+            raise ValueError(f"PartitionedDualTaskStepper needs hidden size 64, <= 16 path positions, <= 4 heads (got {d}, {path_len}, {n_heads})")
+        self.model, self.P, self.dev, self.d, self.L = model, P, dev, d, P.L
+        self.n_u = model.n_user_rows
+        self.path_capacity, self.path_len, self.n_heads = int(path_capacity), int(path_len), n_heads
+        self.lr, self.betas, self.eps, self.n_rec = lr, betas, eps, n_rec
+        self.deterministic, self.fixed_task_weights = bool(deterministic), bool(fixed_task_weights)
+        if comm is not None:
+            P.native = comm
+        P.set_allgather(exchange)
+        self._side = torch.cuda.Stream(device=dev) if two_streams else None
+        n_loc = P.n_local
+        Pn = ops.trust_param_count(n_heads, d)
+        self.n_trust = Pn
+        total = n_loc * d + Pn + 512 + 4
+        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+        self.arena, self.m, self.v = z(total), z(total), z(total)
+        off = 0
+
+        def place(param, n):
+            nonlocal off
+            view = self.arena[off: off + n].view(param.shape)
+            view.copy_(param.data)
+            param.data = view
+            off += n
+
+        place(model.E0_local, n_loc * d)
+        for t in core._trust_param_tensors():
+            place(t, t.numel())
+        assert off == n_loc * d + Pn
+        place(core.att_exp1, 256); place(core.att_exp2, 256); place(core.task_weights, 2)
+        self.light, self.g_prop, self.g_raw, self.gs, self.g_E0 = (z(n_loc, d) for _ in range(5))
+        self.gathered0 = z(P.part.n_padded, d)
+        self.user_table = z(self.n_u, d)
+        self.g_user, self.g_small = z(self.n_u, d), z(Pn + 512)
+        T = self.path_capacity
+        self.a2 = z(T, d)
+        self.trust_ws = z(max(1, int(_lib.load().spex_trust_workspace_floats(T, self.path_len, d, n_heads, self.n_u))))
+        self.dscore, self.loss_b = z(T, self.n_u - 1), z(T)
+        self.loss, self.loss_acc, self.precision = z(2), z(2), z(2, 2)
+        self.t = 0
+        self.slot_capacity = 0
+        self._desc = None
+        self._slots(2 * int(batch_capacity))
+        self.refresh_precision()
+
+    def _slots(self, n):
+        if self.slot_capacity < n:
+            from . import _lib
+            z = lambda *s: torch.zeros(s, dtype=torch.float32, device=self.dev)
+            self.rows = z(2 * n, self.d)
+            self.mixed_slots, self.grad_slots, self.g_prop_slots, self.g_raw_slots = (z(n, self.d) for _ in range(4))
+            self.loss_rows = z(n)
+            self.att_parts = z(int(_lib.load().spex_expert_gate_rows_bwd_parts(n)) * 512)
+            self.arange = torch.arange(n, dtype=torch.int64, device=self.dev)
+            self.slot_capacity = n
+            self._release()
+
+    def _release(self):
+        d = self._desc
+        self._desc = None
+        if d is not None and (d.ev_fork or d.ev_join):
+            try:
+                torch.cuda.synchronize()
+                from . import _lib
+                _lib.release_step_events(d)
+            except Exception:
+                pass
+
+    def __del__(self):
+        self._release()
+
+    def refresh_precision(self):
+        self.precision[(self.t + 1) & 1] = torch.exp(-2.0 * self.model.core.task_weights.detach())
+
+    def positions(self, users, items):
+        pu, pi = self.P.padded_index(users.to(self.dev).long(), items.to(self.dev).long())
+        return torch.cat([pu, pi]).contiguous()
+
+    def step(self, users, items, labels, seq, seq_l, targets, pos=None):
+        """users / items: int64 [B]; labels: fp32 [B]; seq: int64 [T, path_len] padded with the pad row's index; seq_l, targets:
+        int64 [T] — the same on every rank.  Both losses are added to `loss_acc`."""
+        import ctypes
+        from . import _lib
+        from .graph import _bump, _launch
+        P, model = self.P, self.model
+        B, T = users.numel(), (0 if seq is None else seq.shape[0])
+        self._slots(2 * B)
+        if pos is None:
+            pos = self.positions(users, items)
+        labels = labels.to(device=self.dev, dtype=torch.float32).contiguous()
+        if T:
+            seq, seq_l, targets = (t.to(self.dev).long().contiguous() for t in (seq, seq_l, targets))
+            if seq.shape[1] != self.path_len or T > self.path_capacity:
+                raise ValueError(f"PartitionedDualTaskStepper.step: {T} paths of width {seq.shape[1]} (capacity {self.path_capacity} x {self.path_len})")
+        if self._desc is None:
+            p = lambda t: t.data_ptr()
+            self._desc = _lib.PartitionedDualStepDesc(
+                graph=P.graph._h.value, graph_t=P.graph_t._h.value, comm=P.native._h.value, rows_per_rank=None,
+                params=p(self.arena), m=p(self.m), v=p(self.v), light=p(self.light), g_prop=p(self.g_prop), g_raw=p(self.g_raw), gs=p(self.gs),
+                g_E0=p(self.g_E0), send=p(P.send), gathered=p(P.gathered), gathered0=p(self.gathered0), user_pos=p(model.user_pos),
+                user_table=p(self.user_table), rows=p(self.rows), mixed_slots=p(self.mixed_slots), grad_slots=p(self.grad_slots),
+                g_prop_slots=p(self.g_prop_slots), g_raw_slots=p(self.g_raw_slots), loss_rows=p(self.loss_rows), att_parts=p(self.att_parts),
+                arange=p(self.arange), g_user=p(self.g_user), g_small=p(self.g_small), a2=p(self.a2), trust_ws=p(self.trust_ws),
+                dscore=p(self.dscore), loss_b=p(self.loss_b), loss=p(self.loss), loss_acc=p(self.loss_acc), precision=p(self.precision),
+                n_local=P.n_local, max_rows=P.part.max_rows, n_local_users=model.n_local_users,
+                user_lo=P.r0 if model.n_local_users > 0 else 0, slot_capacity=self.slot_capacity, path_capacity=self.path_capacity,
+                path_len=self.path_len, n_user_rows=self.n_u, L=self.L, d=self.d, n_heads=self.n_heads,
+                hybrid=0 if model.core.nonhybrid else 1, n_rec=self.n_rec, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps,
+                t=self.t, side_stream=None if self._side is None else self._side.cuda_stream, ev_fork=None, ev_join=None, flags=0)
+        dsc = self._desc
+        dsc.t, dsc.lr = self.t, self.lr
+        dsc.flags = (_lib.STEP_DETERMINISTIC if self.deterministic else 0) | (_lib.STEP_FIXED_TASK_WEIGHTS if self.fixed_task_weights else 0)
+        self._rpr_keep = P._rows_per_rank
+        dsc.rows_per_rank = None if P._rows_per_rank is None else ctypes.cast(P._rows_per_rank, ctypes.c_void_p).value
+        dsc.comm = P.native._h.value
+        if T and self._side is not None:
+            for t in (seq, seq_l, targets):
+                t.record_stream(self._side)
+        vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() else None
+        _launch(self.dev, "spex_partitioned_dual_task_step_f32", ctypes.byref(dsc), vp(pos), vp(labels), B,
+                vp(seq) if T else None, vp(seq_l) if T else None, vp(targets) if T else None, T)
+        self.t = dsc.t
+        _bump(self.arena, self.m, self.v, self.loss_acc)
