@@ -104,6 +104,16 @@ int need_rccl(const char *who)
 
 }  // namespace
 
+// Device-to-device copy of n floats on `stream`: the library's float4 kernel (x / 1.0f == x bit for bit) where the pointers allow it —
+// a kernel launch costs the host ~1-2 us to issue, hipMemcpyAsync ~10 us on this runtime, and a partitioned step makes a dozen of them.
+static int copy_f32(float *dst, const float *src, size_t n, void *stream)
+{
+    if (n == 0 || dst == src) return SPEX_OK;
+    if (((((uintptr_t)dst) | ((uintptr_t)src)) & 15) == 0) return spex::scale_div(src, dst, 1.0f, (int64_t)n, stream);
+    SPEX_HIP(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return SPEX_OK;
+}
+
 struct spex_comm {
     ncclComm_t comm = nullptr;
     int32_t rank = 0, world = 1;
@@ -170,8 +180,7 @@ extern "C" int spex_comm_allgather_rows_f32(spex_comm_t *c, const float *send, f
     if (c->world == 1 && c->shortcut) {
         const int64_t rows = rows_per_rank ? rows_per_rank[0] : max_rows;
         SPEX_CHECK_ARG(rows >= 0 && rows <= max_rows, "spex_comm_allgather_rows_f32: %lld rows in a slot of %lld", (long long)rows, (long long)max_rows);
-        if (send != recv) SPEX_HIP(hipMemcpyAsync(recv, send, (size_t)rows * d * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
-        return SPEX_OK;
+        return copy_f32(recv, send, (size_t)rows * d, stream);
     }
     if (!rows_per_rank) {                                            // equal padded shards: the plain collective
         SPEX_NCCL(rccl().AllGather(send, recv, slot, ncclFloat32, c->comm, (hipStream_t)stream));
@@ -183,8 +192,7 @@ extern "C" int spex_comm_allgather_rows_f32(spex_comm_t *c, const float *send, f
         SPEX_CHECK_ARG(rows_per_rank[q] >= 0 && rows_per_rank[q] <= max_rows, "spex_comm_allgather_rows_f32: rank %d has %d rows in a slot of %lld", q,
                        rows_per_rank[q], (long long)max_rows);
     const size_t mine = (size_t)rows_per_rank[c->rank] * d;
-    if (send != recv + c->rank * slot && mine)
-        SPEX_HIP(hipMemcpyAsync(recv + c->rank * slot, send, mine * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (int rc = copy_f32(recv + c->rank * slot, send, mine, stream)) return rc;
     SPEX_NCCL(rccl().GroupStart());
     ncclResult_t bad = ncclSuccess;
     const char *what = "";
@@ -238,8 +246,11 @@ static int check_step(const spex_partitioned_step_t *s, const char *who)
 // one exchange: the rank's rows (already in `send`, or copied there) -> the gathered table
 static int exchange(const spex_partitioned_step_t *s, const float *local, void *stream)
 {
-    const size_t bytes = (size_t)s->n_local * s->d * sizeof(float);
-    if (local != s->send && bytes) SPEX_HIP(hipMemcpyAsync(s->send, local, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    // (the real-rows form sends straight from the rows where they lie; the equal-shard form reads max_rows rows, so a shorter
+    //  shard is staged in the padded send buffer first)
+    if (s->rows_per_rank || s->n_local == s->max_rows)
+        return spex_comm_allgather_rows_f32(s->comm, local, s->gathered, s->max_rows, s->d, s->rows_per_rank, stream);
+    if (int rc = copy_f32(s->send, local, (size_t)s->n_local * s->d, stream)) return rc;
     return spex_comm_allgather_rows_f32(s->comm, s->send, s->gathered, s->max_rows, s->d, s->rows_per_rank, stream);
 }
 
@@ -319,8 +330,8 @@ extern "C" int spex_partitioned_step_bce_f32(spex_partitioned_step_t *s, const i
 static int exchange_into(spex_comm_t *comm, const int32_t *rows_per_rank, float *send, const float *local, int64_t n_local, int64_t max_rows,
                          int32_t d, float *table, void *stream)
 {
-    const size_t bytes = (size_t)n_local * d * sizeof(float);
-    if (local != send && bytes) SPEX_HIP(hipMemcpyAsync(send, local, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (rows_per_rank || n_local == max_rows) return spex_comm_allgather_rows_f32(comm, local, table, max_rows, d, rows_per_rank, stream);
+    if (int rc = copy_f32(send, local, (size_t)n_local * d, stream)) return rc;
     return spex_comm_allgather_rows_f32(comm, send, table, max_rows, d, rows_per_rank, stream);
 }
 
@@ -401,8 +412,8 @@ extern "C" int spex_partitioned_dual_task_step_f32(spex_partitioned_dual_step_t 
         SPEX_TRY(spex_expert_gate_rows_bwd_det_f32(rows_raw, rows_prop, att1, att2, s->arange, B, 0, s->arange, B, B, B, 2 * (int64_t)B, d,
                                                    s->grad_slots, d, s->g_prop_slots, s->g_raw_slots, s->att_parts, stream));
         const int32_t n_parts = spex_expert_gate_rows_bwd_parts(2 * B);
-        SPEX_TRY(spex::sum_parts(s->att_parts, n_parts, 512, 256, g_att1, 0, stream));
-        SPEX_TRY(spex::sum_parts(s->att_parts + 256, n_parts, 512, 256, g_att2, 0, stream));
+        SPEX_TRY(spex::sum_parts(s->att_parts, n_parts, 512, 512, g_att1, 0, stream));     // (g_att2 follows g_att1 in g_small: one launch for both)
+        (void)g_att2;
         // ---- the rows this rank owns into its gradient blocks
         if (det) {
             SPEX_TRY(spex_reduce_slots_f32(pos, 2 * B, -lo, nullptr, 0, 0, (int32_t)n_loc, s->g_prop_slots, d, 1.0f, s->g_prop, 0, d, stream));

@@ -195,15 +195,21 @@ def gpu():
                 reduces = [k for k, r in enumerate(lg) if r.op == OP["allreduce"]]
                 assert len(reduces) == 1 and lg[reduces[0]].count == 2 * B * d and lg[reduces[0]].send == st.rows.data_ptr()
                 before, after = lg[: reduces[0]], lg[reduces[0] + 1:]
+                # the rows go out from where they lie — no staging copy: the first forward exchange reads E^0 itself, the first
+                # backward one the scaled gradient, the others the buffer the previous layer's SpMM wrote (this rank's shard is a
+                # full one, n_local == max_rows, so the equal-shard form needs no padding either)
+                src_fwd = [st.E0.data_ptr()] + [send] * (L - 1)
+                src_bwd = [st._gs.data_ptr()] + [send] * (L - 1)
                 if mode == "native-p2p":
                     per = 2 + 3 + 3                                      # GroupStart, 3 sends, 3 receives, GroupEnd
                     assert len(before) == L * per and len(after) == L * per, (len(before), len(after))
                     for k in range(L):                                   # L exchanges forward, L backward: 2L + one all-reduce per step
-                        expect_p2p(before[k * per:(k + 1) * per], rank, world, rows, max_rows, d, send, recv, side.cuda_stream)
-                        expect_p2p(after[k * per:(k + 1) * per], rank, world, rows, max_rows, d, send, recv, side.cuda_stream)
+                        expect_p2p(before[k * per:(k + 1) * per], rank, world, rows, max_rows, d, src_fwd[k], recv, side.cuda_stream)
+                        expect_p2p(after[k * per:(k + 1) * per], rank, world, rows, max_rows, d, src_bwd[k], recv, side.cuda_stream)
                 else:
                     assert len(before) == L and len(after) == L
-                    assert all(r.op == OP["allgather"] and r.count == max_rows * d and r.send == send and r.recv == recv for r in before + after)
+                    assert all(r.op == OP["allgather"] and r.count == max_rows * d and r.recv == recv for r in before + after)
+                    assert [r.send for r in before] == src_fwd and [r.send for r in after] == src_bwd
             side.synchronize()
             assert st.t == 2 and bool(torch.isfinite(st.E0).all()) and bool(torch.isfinite(acc).all())
             # switching the exchange form takes effect on the NEXT step of the same stepper (the descriptor is refreshed)

@@ -1,0 +1,58 @@
+"""Dual-task step on Epinion2, B = 256, 15 paths: DualTaskStepper (single-GPU one-call step) against PartitionedDualTaskStepper at
+world size 1 (the row-partitioned one-call step: the same arithmetic through the partition's schedule — exchanges are local copies
+here).  us per step by HIP events."""
+import argparse, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "spex_amd", "dropin"))
+from spex_amd.datasets import load_epinion2
+from spex_amd.dist_dual import PartitionedDualTask, PartitionedDualTaskStepper
+from spex_amd.graph import SpexGraph, lightgcn_norm_adj
+from spex_amd.trainer import DualTaskStepper
+import utility1.model_expert_s as mex
+dev = torch.device("cuda:0")
+tr = load_epinion2()["train"]
+n_u, n_i, L = 3185, 12407, 3
+csr = lightgcn_norm_adj(tr[:, 0], tr[:, 1], n_u, n_i)
+g = SpexGraph(*csr, device=dev)
+
+
+class _DS:
+    n_users, m_items = n_u, n_i
+    getSparseGraph = staticmethod(lambda: g)
+
+
+dargs = argparse.Namespace(hiddenSize=64, batchSize=100, nonhybrid=False, nb_heads=3, recdim=64, layer=L, keepprob=0.6, A_split=False, dropout=0)
+rng = np.random.default_rng(13)
+B, T, P_LEN = 256, 15, 6
+ub = torch.from_numpy(rng.integers(0, n_u, B)).to(dev); ib = torch.from_numpy(rng.integers(0, n_i, B)).to(dev)
+yb = torch.from_numpy((rng.random(B) < 1 / 6).astype(np.float32)).to(dev)
+plen = rng.integers(2, P_LEN + 1, T)
+seq = np.full((T, P_LEN), n_u, dtype=np.int64)
+for r, l in enumerate(plen):
+    seq[r, :l] = rng.choice(n_u, size=l, replace=False)
+seq_d, len_d = torch.from_numpy(seq).to(dev), torch.from_numpy(plen.astype(np.int64)).to(dev)
+tgt = torch.from_numpy(rng.integers(0, n_u, T)).to(dev)
+
+
+def timed(fn, n=500):
+    for _ in range(30): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+torch.manual_seed(0)
+net = mex.LightGCN(dargs, _DS).to(dev)
+st = DualTaskStepper(net, path_capacity=T, path_len=P_LEN, lr=1e-3)
+print("DualTaskStepper                       : %.1f us" % timed(lambda: st.step(ub, ib, yb, seq_d, len_d, tgt)), flush=True)
+for det in (False, True):
+    torch.manual_seed(0)
+    core = mex.LightGCN(dargs, _DS).to(dev)
+    model = PartitionedDualTask(core, csr, 0, 1, dev)
+    pst = PartitionedDualTaskStepper(model, path_capacity=T, path_len=P_LEN, lr=1e-3, deterministic=det)
+    pos = pst.positions(ub, ib)
+    print("PartitionedDualTaskStepper, world 1%s: %.1f us" % (" det" if det else "    ", timed(lambda: pst.step(ub, ib, yb, seq_d, len_d, tgt, pos=pos))), flush=True)
