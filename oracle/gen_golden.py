@@ -1217,7 +1217,7 @@ def write_small_ngcf(rec_dir):
     return dict(train_pairs=pairs, test_pos=np.asarray(test_pos, np.int64), test_neg=np.stack(test_neg).astype(np.int64))
 
 
-def stage_ngcf_epochs(ds, n_epochs, ckpt_steps=(), native_dropout=False, max_steps=None):
+def stage_ngcf_epochs(ds, n_epochs, ckpt_steps=(), native_dropout=False, max_steps=None, extra_argv=(), suffix=""):
     """G12-NGCF: the reference's training run — NGCF_SPEX/code/main_rec.py:18-27,116-148 (setup_seed, the module-level
     Data singleton of utility/batch_test.py, Model_Wrapper, Adam, train(): load_train_data per epoch, shuffled
     DataLoader, loss.backward, step; test()) — driven from the reference's modules on CPU.
@@ -1231,7 +1231,9 @@ def stage_ngcf_epochs(ds, n_epochs, ckpt_steps=(), native_dropout=False, max_ste
     epoch, the learned weights.
     native_dropout: the second substitution is NOT made — the model keeps its nn.Dropout modules and their noise comes from
     torch's global generator (at::dropout: empty_like(x).bernoulli_(1 - p), one draw of [N, 64] per layer and step) — and every
-    step's loss is stored; max_steps stops the run inside epoch 0.  Written to ngcf_<ds>_native_dropout.npz."""
+    step's loss is stored; max_steps stops the run inside epoch 0.  Written to ngcf_<ds>_native_dropout.npz.
+    extra_argv: further flags of the reference's parser (e.g. --layer_size [64,64] --mess_dropout [0.1,0.1]: a two-layer model,
+    NGCF_SPEX/code/ngcf_parser.py:12); suffix: appended to the output files' stem."""
     import random
     import numpy as np
     import torch
@@ -1247,7 +1249,7 @@ def stage_ngcf_epochs(ds, n_epochs, ckpt_steps=(), native_dropout=False, max_ste
         if os.path.exists(pth):
             os.remove(pth)
     sys.path.insert(0, os.path.join(REF, "NGCF_SPEX", "code"))
-    sys.argv = ["main_rec.py", "--data_path", data_root, "--dataset", ds]
+    sys.argv = ["main_rec.py", "--data_path", data_root, "--dataset", ds] + list(extra_argv)
     import utility.load_data as ref_ld
 
     class SerialPool:
@@ -1393,7 +1395,7 @@ def stage_ngcf_epochs(ds, n_epochs, ckpt_steps=(), native_dropout=False, max_ste
         take_checkpoint("ckptend", first_batch, loss.item())
         optimizer.zero_grad()
         model.eval()
-        np.savez_compressed(os.path.join(GOLD, f"ngcf_{ds}_ckpt.npz"), seed=2020, drop_seed=DROP_SEED, lr=margs.lr,
+        np.savez_compressed(os.path.join(GOLD, f"ngcf_{ds}{suffix}_ckpt.npz"), seed=2020, drop_seed=DROP_SEED, lr=margs.lr,
                             mess_dropout=np.asarray(p_drop), n_steps=state["step"], ckpt_steps=np.asarray(sorted(ckpt_steps)),
                             eval_steps=np.asarray([k for k, v in eval_at.items() if v is not None] + [state["step"]]),
                             eval_metrics=np.asarray([v for v in eval_at.values() if v is not None]
@@ -1408,7 +1410,7 @@ def stage_ngcf_epochs(ds, n_epochs, ckpt_steps=(), native_dropout=False, max_ste
     out.update(small)
     out.update({"final_" + k.replace(".", "__"): v.detach().numpy().copy() for k, v in model.state_dict().items()
                 if v.numel() <= 64 * 64})
-    np.savez_compressed(os.path.join(GOLD, f"ngcf_{ds}_native_dropout.npz" if native_dropout else f"ngcf_{ds}_epochs.npz"), seed=2020,
+    np.savez_compressed(os.path.join(GOLD, f"ngcf_{ds}{suffix}_native_dropout.npz" if native_dropout else f"ngcf_{ds}{suffix}_epochs.npz"), seed=2020,
                         drop_seed=DROP_SEED, lr=margs.lr,
                         mess_dropout=np.asarray(p_drop), n_steps=state["step"],
                         losses=np.asarray(losses, np.float64), step_losses=np.asarray(step_losses, np.float64),
@@ -1455,6 +1457,10 @@ def main():
         #  to 6e-7 there; minted to 1 500 steps the same replay drifts 8e-5 / 2e-3 / 5e-3 per 300-step window, the growth the
         #  reference's own two mints show, ngcf_epinion2_ref_spread.npz)
         stage_ngcf_epochs("epinion2", 1, native_dropout=True, max_steps=300)
+    elif a.stage == "ngcf-2layer-epinion2":   # ~1 min of CPU: 60 steps of the TWO-layer model (--layer_size [64,64]) + test(), with
+        # teacher-forced checkpoints in front of step 40 and at the end (ngcf_epinion2_2layer_ckpt.npz)
+        stage_ngcf_epochs("epinion2", 1, ckpt_steps=(40,), max_steps=60,
+                          extra_argv=["--layer_size", "[64,64]", "--mess_dropout", "[0.1,0.1]"], suffix="_2layer")
     elif a.stage == "trust-epinion2":
         stage_trust_epinion2()
     elif a.stage == "epochs-dual-epinion2":  # ~20 min of CPU: 600 dual-task steps + both evaluations through the reference

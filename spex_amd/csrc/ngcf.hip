@@ -8,6 +8,10 @@
 // Both are bandwidth/latency-bound per row (2 x 256 B in, 512 B out; 8 kflop per row, 128 MFLOP on Epinion2).  The
 // NGCF layer's two [N,64]x[64,64] products run on the matrix cores (f32 MFMA, see the kernel); the gate is a pair of
 // 128-long dot products per row and stays on the vector unit.
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "spex_common.h"
 
 using namespace spex;
@@ -488,153 +492,117 @@ __global__ __launch_bounds__(kWave *kWgWaves) __attribute__((amdgpu_waves_per_eu
 // [16,64]x[64,64] products), the two input-gradient products are two more, and the weight gradients are a fifth and
 // sixth MFMA product whose contraction runs over the tile's ROWS: with the rows taken in the order 4h + s (lane group
 // h, step s) the A operand is G in the accumulator layout it already has and the B operand is the side / product tile
-// read from LDS in that same layout — no transposes.  One wave per tile, 4 waves per workgroup (one per SIMD: the wave
-// keeps its 2 x 64 x 64 / 64 weight-gradient accumulators in 128 registers across its tiles).
+// read from LDS in that same layout — no transposes.  One WORKGROUP of four waves per tile, every product split by output block.
 // Two forms:
-//   dense (ROWS = false)  tiles of 16 consecutive rows; a tile whose upstream gradient is all zero writes zeros and skips
-//                         the arithmetic;
-//   rows  (ROWS = true)   tiles of 16 entries of a device row list (the <= 512 distinct rows of a batch — the only rows
-//                         with a gradient behind the LAST layer): 32 tiles instead of 975, compact [K, 64] outputs for the
-//                         push-form SpMM, and the consumed rows of the gradient table are cleared on the way.
-// Weight gradients: the workgroup's four waves add their register accumulators into LDS one after the other (plain
-// read-add-write between barriers — an LDS float atomic, ds_add_f32, costs ~200 cycles per wave-instruction: the first
-// version of this kernel spent 85 of its 113 us in 128 of them per tile), then one global atomic per address and active
-// workgroup.
+//   dense (ngcf_layer_bwd_dense4_kernel)  tiles of 16 consecutive rows; a tile whose upstream gradient is all zero writes zeros
+//                         and skips the arithmetic; weight gradients as one partial block per workgroup, added in block order;
+//   rows  (ngcf_layer_bwd_rows4_kernel)   tiles of 16 entries of a device row list (the <= 512 distinct rows of a batch — the only
+//                         rows with a gradient behind the LAST layer): 32 tiles instead of 975, compact [K, 64] outputs for the
+//                         push-form SpMM, weight gradients as one partial block per tile (plain stores, summed in order).
 constexpr int kBwdWaves = 4;
-constexpr int kDwStride = 68;
-constexpr int kBwdStride = 68;     // LDS row stride of the backward's tiles and weights: rows 16-byte aligned for ds_read_b128
+constexpr int kBwdStride = 68;     // LDS row stride of the backward's tiles: rows 16-byte aligned for ds_read_b128
+constexpr int kPartFloats = 2 * (64 * 64 + 64);    // one block of weight-gradient partials: [dW_gc | db_gc | dW_bi | db_bi]
 
-template <bool ROWS>
-__global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
+// Dense form (every row of the table; multi-layer models, whose earlier layers see a dense upstream gradient): one WORKGROUP per
+// 16-row tile, the four waves splitting every product by output block exactly as in the rows form below (ngcf_layer_bwd_rows4_kernel:
+// same operand dealing, same arithmetic per element) — the first version walked its tiles with ONE wave each, a dependent chain of
+// ~400 MFMAs per tile in 252 VGPRs (60.9 us for Epinion2's 975 tiles).  A workgroup is persistent over a strided set of tiles, which
+// lets it keep
+//   * both weight matrices in REGISTERS instead of LDS: wave b only ever needs rows 16b .. 16b+15 of W (recompute) and columns
+//     16b .. 16b+15 of W (input gradients), 16 floats per lane each — 64 VGPRs, loaded once; the 70 KB of LDS the rows form spends on
+//     two copies of the weights is gone, so several workgroups share a CU;
+//   * its share of the weight gradients (wave b: rows 16b .. 16b+15 of dW_gc, dW_bi) in MFMA accumulators across its tiles, added to
+//     its own block of partials once at the end — plain stores; a second small launch adds the blocks in order (float atomics from
+//     256+ workgroups onto the same 8 320 addresses cost 10 us per 256 workgroups and would cap the grid at one workgroup per CU).
+// A tile whose upstream gradient is all zero (most tiles behind a 256-sample batch) writes zeros / g_direct and skips the arithmetic.
+__global__ __launch_bounds__(kWave *kBwdWaves) __attribute__((amdgpu_waves_per_eu(2, 2))) void ngcf_layer_bwd_dense4_kernel(
     const float *__restrict__ ego, const float *__restrict__ side, const float *__restrict__ W_gc,
     const float *__restrict__ b_gc, const float *__restrict__ W_bi, const float *__restrict__ b_bi,
     const float *__restrict__ g_norm, int ld_g, const float *__restrict__ g_next, const float *__restrict__ g_direct,
-    int ld_direct, int n, float slope, const MsgDrop drop, const int64_t *__restrict__ idx_a, int n_a, int64_t off_a,
-    const int64_t *__restrict__ idx_b, int n_b, int64_t off_b, float *__restrict__ g_side,
-    float *__restrict__ g_ego, float *gW_gc, float *gb_gc, float *gW_bi, float *gb_bi, float *partials, int part_stride)
+    int ld_direct, int n, float slope, const MsgDrop drop, float *__restrict__ g_side, float *__restrict__ g_ego,
+    float *__restrict__ parts)
 {
-    __shared__ float s_w[2][64 * kBwdStride];                   // W_gc, W_bi as [out o][in k]
-    __shared__ float s_wT[2][64 * kBwdStride];                  // and transposed, [in k][out o]: every MFMA operand below is then
-                                                                // 16 consecutive floats per lane (four ds_read_b128)
-    __shared__ float s_dw[2][64 * kDwStride];                   // this workgroup's share of dW_gc, dW_bi
-    __shared__ float s_db[2][64];
-    __shared__ float s_t[kBwdWaves][2][16 * kBwdStride];        // per wave: side tile / G_s, product tile / G_t
-    __shared__ int s_active;
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    __shared__ float s_tile[5][16 * kBwdStride];                // side, ego, ego * side, G_s, G_t
+    __shared__ float s_red[2][kBwdWaves][16];                   // per-wave partial row sums: squares, <g_norm, out>
+    const int lane = threadIdx.x & (kWave - 1), b = threadIdx.x >> 6;      // wave == output block
     const int i16 = lane & 15, h = lane >> 4;
-    const int n_items = ROWS ? n_a + n_b : n;                   // slots to process (batch slots / all rows)
-    const int n_tiles = (n_items + 15) >> 4;
-    const int tile_step = gridDim.x * kBwdWaves;
-    // A tile's inputs, requested as early as possible (the kernel is a chain of dependent round trips: slot index -> rows):
-    // the tile's rows — consecutive rows, or the rows of 16 batch slots (every slot is processed with ITS OWN upstream
-    // gradient row — the layer's backward is linear in it, so rows named by several slots just add up downstream; -1 = past
-    // the end / out of range; lane i keeps slot i's row in `slot_row`) —, the upstream gradients in the accumulator layout
-    // (element (row 4h + q, column 16b + i16)) and the ego / side rows (lane == column).
-    auto load_tile = [&](int tl, int &slot_row, int (&row_q)[4], float (&gn)[4][4], float (&gx)[4][4], bool &any, float (&e_reg)[16],
-                         float (&s_reg)[16]) {
+    const int n_tiles = (n + 15) >> 4;
+    float *t_side = s_tile[0], *t_ego = s_tile[1], *t_prod = s_tile[2], *t_gs = s_tile[3], *t_gt = s_tile[4];
+    // ---- the weights this wave needs, once: W[o = 16b + i16][k = 16h + 4j ..] (B operand of the recomputation) and
+    //      W[o = 16h + 4j ..][c = 16b + i16] (B operand of the input gradients: the transposed matrix, read with a stride)
+    float4 wg[4], wb[4], wgT[4], wbT[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        wg[j] = *reinterpret_cast<const float4 *>(W_gc + (16 * b + i16) * 64 + 16 * h + 4 * j);
+        wb[j] = *reinterpret_cast<const float4 *>(W_bi + (16 * b + i16) * 64 + 16 * h + 4 * j);
+        const int o = 16 * h + 4 * j, c = 16 * b + i16;
+        wgT[j] = make_float4(W_gc[(o + 0) * 64 + c], W_gc[(o + 1) * 64 + c], W_gc[(o + 2) * 64 + c], W_gc[(o + 3) * 64 + c]);
+        wbT[j] = make_float4(W_bi[(o + 0) * 64 + c], W_bi[(o + 1) * 64 + c], W_bi[(o + 2) * 64 + c], W_bi[(o + 3) * 64 + c]);
+    }
+    const float bias_g = b_gc[16 * b + i16], bias_b = b_bi[16 * b + i16];
+    f32x4 dWg[4], dWb[4];                                        // rows 16b + 4h + q, column block bn
+#pragma unroll
+    for (int bn = 0; bn < 4; ++bn) dWg[bn] = dWb[bn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float dbg = 0.0f, dbb = 0.0f;
+    bool did_work = false;
+    // A tile's inputs: the upstream gradients of this wave's 16 columns in the accumulator layout (row 4h + q, column 16b + i16) and the
+    // rows 4b .. 4b+3 of ego / side (lane == column).  The NEXT tile's are requested before the current one is computed: a tile is a
+    // chain of global round trips and barriers, and a CU holds two such workgroups at most.
+    float gn[4], gx[4], gd[4], e_reg[4], s_reg[4];
+    auto load_tile = [&](int tl) {
         const int r0 = tl << 4;
-        slot_row = -1;
-        if (tl < n_tiles) {
-            if (ROWS) {
-                if (lane < 16 && r0 + lane < n_items) {
-                    const long long r = batch_row(idx_a, n_a, off_a, idx_b, off_b, r0 + lane);
-                    slot_row = (r >= 0 && r < n) ? (int)r : -1;
-                }
-            } else if (lane < 16 && r0 + lane < n) {
-                slot_row = r0 + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = r0 + 4 * h + q;
+            gn[q] = gx[q] = gd[q] = 0.0f;
+            if (tl < n_tiles && r < n) {
+                gn[q] = g_norm[(size_t)r * ld_g + 16 * b + i16];
+                if (g_next) gx[q] = g_next[(size_t)r * 64 + 16 * b + i16];
+                if (g_direct) gd[q] = g_direct[(size_t)r * ld_direct + 16 * b + i16];
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) row_q[q] = __shfl(slot_row, 4 * h + q, kWave);
-        any = false;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = row_q[q];
-                gn[b][q] = gx[b][q] = 0.0f;
-                if (r >= 0) {
-                    gn[b][q] = g_norm[(size_t)(ROWS ? r0 + 4 * h + q : r) * ld_g + 16 * b + i16];   // rows form: compact, per slot
-                    if (g_next) gx[b][q] = g_next[(size_t)r * 64 + 16 * b + i16];
-                }
-                any |= (gn[b][q] != 0.0f) | (gx[b][q] != 0.0f);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int r = __builtin_amdgcn_readlane(slot_row, i);
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + 4 * b + i;
             e_reg[i] = s_reg[i] = 0.0f;
-            if (r >= 0) {
+            if (tl < n_tiles && r < n) {
                 e_reg[i] = ego[(size_t)r * 64 + lane];
                 s_reg[i] = side[(size_t)r * 64 + lane];
             }
         }
     };
-    int tile = blockIdx.x * kBwdWaves + wave;
-    int slot_row, row_q[4];
-    float gn[4][4], gx[4][4], e_reg[16], s_reg[16];
-    bool any;
-    load_tile(tile, slot_row, row_q, gn, gx, any, e_reg, s_reg);        // in flight while the weights are staged
-    for (int i = threadIdx.x; i < 64 * 16; i += blockDim.x) {
-        const int r = i >> 4, c4 = (i & 15) * 4;
-        const float4 a = *reinterpret_cast<const float4 *>(W_gc + r * 64 + c4);
-        const float4 b = *reinterpret_cast<const float4 *>(W_bi + r * 64 + c4);
-        *reinterpret_cast<float4 *>(&s_w[0][r * kBwdStride + c4]) = a;
-        *reinterpret_cast<float4 *>(&s_w[1][r * kBwdStride + c4]) = b;
-        s_wT[0][(c4 + 0) * kBwdStride + r] = a.x; s_wT[0][(c4 + 1) * kBwdStride + r] = a.y;
-        s_wT[0][(c4 + 2) * kBwdStride + r] = a.z; s_wT[0][(c4 + 3) * kBwdStride + r] = a.w;
-        s_wT[1][(c4 + 0) * kBwdStride + r] = b.x; s_wT[1][(c4 + 1) * kBwdStride + r] = b.y;
-        s_wT[1][(c4 + 2) * kBwdStride + r] = b.z; s_wT[1][(c4 + 3) * kBwdStride + r] = b.w;
-    }
-    if (!ROWS) {                                                 // (the rows form never touches the LDS accumulators)
-        for (int i = threadIdx.x; i < 64 * kDwStride; i += blockDim.x) s_dw[0][i] = s_dw[1][i] = 0.0f;
-        if (threadIdx.x < 64) s_db[0][threadIdx.x] = s_db[1][threadIdx.x] = 0.0f;
-    }
-    if (threadIdx.x == 0) s_active = 0;
-    float bias_g[4], bias_b[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        bias_g[b] = b_gc[16 * b + i16];
-        bias_b[b] = b_bi[16 * b + i16];
-    }
-    __syncthreads();
-    float *t_side = s_t[wave][0], *t_prod = s_t[wave][1];
-    f32x4 dWg[4][4], dWb[4][4];                                  // [out block][in block]: rows 4h + q, column i16
-    float dbg[4] = {0.f, 0.f, 0.f, 0.f}, dbb[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int bo = 0; bo < 4; ++bo) {
-#pragma unroll
-        for (int bn = 0; bn < 4; ++bn) {
-            dWg[bo][bn] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            dWb[bo][bn] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-    }
-    bool did_work = false;
-    for (; tile < n_tiles; tile += tile_step) {
+    load_tile(blockIdx.x);
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int r0 = tile << 4;
-        if (!ROWS && !__any(any)) {                              // no gradient reaches this tile
+        // (looked at only now: testing the values where they are loaded would wait for the prefetch on the spot)
+        int any = 0;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int r = r0 + i;
+        for (int q = 0; q < 4; ++q) any |= (gn[q] != 0.0f) | (gx[q] != 0.0f);
+        // (the barrier also separates the previous tile's last LDS reads from this tile's staging)
+        if (!__syncthreads_or(any)) {                            // no gradient reaches this tile
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = r0 + 4 * h + q;
                 if (r < n) {
-                    g_side[(size_t)r * 64 + lane] = 0.0f;
-                    g_ego[(size_t)r * 64 + lane] = g_direct ? g_direct[(size_t)r * ld_direct + lane] : 0.0f;
+                    g_side[(size_t)r * 64 + 16 * b + i16] = 0.0f;
+                    g_ego[(size_t)r * 64 + 16 * b + i16] = gd[q];
                 }
             }
-            load_tile(tile + tile_step, slot_row, row_q, gn, gx, any, e_reg, s_reg);
+            load_tile(tile + gridDim.x);
             continue;
         }
         did_work = true;
-        // stage the tile (lane == column) for the recomputation
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            t_side[i * kBwdStride + lane] = s_reg[i];
-            t_prod[i * kBwdStride + lane] = e_reg[i] * s_reg[i];
+        for (int i = 0; i < 4; ++i) {
+            t_side[(4 * b + i) * kBwdStride + lane] = s_reg[i];
+            t_ego[(4 * b + i) * kBwdStride + lane] = e_reg[i];
+            t_prod[(4 * b + i) * kBwdStride + lane] = e_reg[i] * s_reg[i];
         }
-        // recompute s = side W_gc^T, t = (ego * side) W_bi^T.  The contraction index is dealt k = 16 h + j to lane group h, step j
-        // (any bijection works as long as both operands agree): a lane then needs 16 CONSECUTIVE floats of its A row and of each
-        // B row — four ds_read_b128 instead of sixteen ds_read_b32 (the 4 s + h order spent 5 of the kernel's 27 us on LDS reads)
-        f32x4 acc_g[4], acc_b[4];
+        const float gn_c[4] = {gn[0], gn[1], gn[2], gn[3]}, gx_c[4] = {gx[0], gx[1], gx[2], gx[3]}, gd_c[4] = {gd[0], gd[1], gd[2], gd[3]};
+        load_tile(tile + gridDim.x);                                                      // in flight during this tile's arithmetic
+        __syncthreads();                                                                  // (1) tile staged
+        // ---- recompute this block's columns of s and t (contraction index dealt k = 16h + j, see the rows form)
+        f32x4 acc_g = (f32x4){0.f, 0.f, 0.f, 0.f}, acc_b = (f32x4){0.f, 0.f, 0.f, 0.f};
         {
             float4 ag[4], ab[4];
 #pragma unroll
@@ -643,226 +611,151 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_kernel(
                 ab[j] = *reinterpret_cast<const float4 *>(&t_prod[i16 * kBwdStride + 16 * h + 4 * j]);
             }
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                acc_g[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                acc_b[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                float4 wg[4], wb[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    wg[j] = *reinterpret_cast<const float4 *>(&s_w[0][(16 * b + i16) * kBwdStride + 16 * h + 4 * j]);
-                    wb[j] = *reinterpret_cast<const float4 *>(&s_w[1][(16 * b + i16) * kBwdStride + 16 * h + 4 * j]);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc_g[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[j].x, wg[j].x, acc_g[b], 0, 0, 0);
-                    acc_b[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[j].x, wb[j].x, acc_b[b], 0, 0, 0);
-                    acc_g[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[j].y, wg[j].y, acc_g[b], 0, 0, 0);
-                    acc_b[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[j].y, wb[j].y, acc_b[b], 0, 0, 0);
-                    acc_g[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[j].z, wg[j].z, acc_g[b], 0, 0, 0);
-                    acc_b[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[j].z, wb[j].z, acc_b[b], 0, 0, 0);
-                    acc_g[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[j].w, wg[j].w, acc_g[b], 0, 0, 0);
-                    acc_b[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[j].w, wb[j].w, acc_b[b], 0, 0, 0);
-                }
+            for (int j = 0; j < 4; ++j) {
+                acc_g = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[j].x, wg[j].x, acc_g, 0, 0, 0);
+                acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[j].x, wb[j].x, acc_b, 0, 0, 0);
+                acc_g = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[j].y, wg[j].y, acc_g, 0, 0, 0);
+                acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[j].y, wb[j].y, acc_b, 0, 0, 0);
+                acc_g = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[j].z, wg[j].z, acc_g, 0, 0, 0);
+                acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[j].z, wb[j].z, acc_b, 0, 0, 0);
+                acc_g = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[j].w, wg[j].w, acc_g, 0, 0, 0);
+                acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[j].w, wb[j].w, acc_b, 0, 0, 0);
             }
         }
-        // elementwise chain in the accumulator layout
-        float e1d[4][4], kscale[4][4], sq[4], dot[4];
+        // ---- elementwise chain on this block's columns; row sums over all 64 columns through LDS
+        float e1d[4], kscale[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float v = 0.0f;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const float x = acc_g[b][q] + bias_g[b], y = acc_b[b][q] + bias_b[b];
-                float e = (x >= 0.0f ? x : x * slope) + (y >= 0.0f ? y : y * slope);
-                float ks = 1.0f;
-                if (drop.p > 0.0f) {
-                    ks = (row_q[q] >= 0 && msg_keep(drop, row_q[q], 16 * b + i16)) ? drop.scale : 0.0f;
-                    e = ks != 0.0f ? e * ks : 0.0f;
-                }
-                kscale[b][q] = ks;
-                e1d[b][q] = e;
-                v = fmaf(e, e, v);
+            const int r = r0 + 4 * h + q;
+            const float x = acc_g[q] + bias_g, y = acc_b[q] + bias_b;
+            float e = (x >= 0.0f ? x : x * slope) + (y >= 0.0f ? y : y * slope);
+            float ks = 1.0f;
+            if (drop.p > 0.0f) {
+                ks = (r < n && msg_keep(drop, r, 16 * b + i16)) ? drop.scale : 0.0f;
+                e = ks != 0.0f ? e * ks : 0.0f;
             }
-            sq[q] = row16_sum_f32(v);
+            kscale[q] = ks;
+            e1d[q] = e;
+            const float v = row16_sum_f32(e * e);
+            if (i16 == 0) s_red[0][b][4 * h + q] = v;
         }
+        __syncthreads();                                                                  // (2) squares
+        float den[4], nrm[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float nrm = sqrtf(sq[q]);
-            const float den = fmaxf(nrm, 1e-12f);
-            float v = 0.0f;
+            const int rr = 4 * h + q;
+            nrm[q] = sqrtf(((s_red[0][0][rr] + s_red[0][1][rr]) + s_red[0][2][rr]) + s_red[0][3][rr]);
+            den[q] = fmaxf(nrm[q], 1e-12f);
+            const float v = row16_sum_f32(gn_c[q] * (e1d[q] / den[q]));
+            if (i16 == 0) s_red[1][b][rr] = v;
+        }
+        __syncthreads();                                                                  // (3) <g_norm, out>
+        float Gs[4], Gt[4];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) v = fmaf(gn[b][q], e1d[b][q] / den, v);
-            v = row16_sum_f32(v);
-            dot[q] = (nrm >= 1e-12f) ? v : 0.0f;                // below eps the clamp holds the denominator constant
+        for (int q = 0; q < 4; ++q) {
+            const int rr = 4 * h + q;
+            float dot = ((s_red[1][0][rr] + s_red[1][1][rr]) + s_red[1][2][rr]) + s_red[1][3][rr];
+            dot = (nrm[q] >= 1e-12f) ? dot : 0.0f;               // below eps the clamp holds the denominator constant
+            const float o = e1d[q] / den[q];
+            const float ge1d = (gn_c[q] - o * dot) / den[q] + gx_c[q];
+            const float ge1 = r0 + rr < n ? ge1d * kscale[q] : 0.0f;
+            const float x = acc_g[q] + bias_g, y = acc_b[q] + bias_b;
+            Gs[q] = ge1 * (x > 0.0f ? 1.0f : slope);
+            Gt[q] = ge1 * (y > 0.0f ? 1.0f : slope);
+            t_gs[rr * kBwdStride + 16 * b + i16] = Gs[q];
+            t_gt[rr * kBwdStride + 16 * b + i16] = Gt[q];
+        }
+        // ---- weight gradients, rows 16b .. 16b+15, accumulated over this workgroup's tiles
+        dbg += (Gs[0] + Gs[1]) + (Gs[2] + Gs[3]);
+        dbb += (Gt[0] + Gt[1]) + (Gt[2] + Gt[3]);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const float o = e1d[b][q] / den;
-                const float ge1d = (gn[b][q] - o * dot[q]) / den + gx[b][q];
-                const float ge1 = row_q[q] >= 0 ? ge1d * kscale[b][q] : 0.0f;
-                const float x = acc_g[b][q] + bias_g[b], y = acc_b[b][q] + bias_b[b];
-                acc_g[b][q] = ge1 * (x > 0.0f ? 1.0f : slope);   // G_s
-                acc_b[b][q] = ge1 * (y > 0.0f ? 1.0f : slope);   // G_t
+        for (int bn = 0; bn < 4; ++bn) {
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const float sc = t_side[(4 * h + st) * kBwdStride + 16 * bn + i16];
+                const float pc = t_prod[(4 * h + st) * kBwdStride + 16 * bn + i16];
+                dWg[bn] = __builtin_amdgcn_mfma_f32_16x16x4f32(Gs[st], sc, dWg[bn], 0, 0, 0);
+                dWb[bn] = __builtin_amdgcn_mfma_f32_16x16x4f32(Gt[st], pc, dWb[bn], 0, 0, 0);
             }
         }
-        // bias gradients: this lane's share (rows 4h + q of column 16b + i16), summed over lane groups at the end
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            dbg[b] += (acc_g[b][0] + acc_g[b][1]) + (acc_g[b][2] + acc_g[b][3]);
-            dbb[b] += (acc_b[b][0] + acc_b[b][1]) + (acc_b[b][2] + acc_b[b][3]);
-        }
-        // side / product tiles in the accumulator layout (B operands of the weight-gradient products, and the
-        // elementwise factors of the input gradients)
-        float side_c[4][4], prod_c[4][4];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                side_c[b][q] = t_side[(4 * h + q) * kBwdStride + 16 * b + i16];
-                prod_c[b][q] = t_prod[(4 * h + q) * kBwdStride + 16 * b + i16];
-            }
-        }
-        // dW[o][k] += sum_r G[r][o] X[r][k]: contraction over the tile's rows, row (4h + s) at step s of lane group h
-#pragma unroll
-        for (int bo = 0; bo < 4; ++bo) {
-#pragma unroll
-            for (int bn = 0; bn < 4; ++bn) {
-#pragma unroll
-                for (int st = 0; st < 4; ++st) {
-                    dWg[bo][bn] = __builtin_amdgcn_mfma_f32_16x16x4f32(acc_g[bo][st], side_c[bn][st], dWg[bo][bn], 0, 0, 0);
-                    dWb[bo][bn] = __builtin_amdgcn_mfma_f32_16x16x4f32(acc_b[bo][st], prod_c[bn][st], dWb[bo][bn], 0, 0, 0);
-                }
-            }
-        }
-        // G tiles into LDS (the side / product tiles are in registers now), then the two input-gradient products
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                t_side[(4 * h + q) * kBwdStride + 16 * b + i16] = acc_g[b][q];
-                t_prod[(4 * h + q) * kBwdStride + 16 * b + i16] = acc_b[b][q];
-            }
-        }
-        // input gradients: t_s = G_s W_gc, t_b = G_t W_bi (contraction over the 64 outputs o, dealt o = 16 h + j like above; the B
-        // operand W[o][column] is read from the transposed copy, where o runs along the row)
-        f32x4 ts[4], tb[4];
+        __syncthreads();                                                                  // (4) G tiles complete
+        // ---- input gradients, columns 16b .. 16b+15: ts = G_s W_gc, tb = G_t W_bi (contraction over the 64 outputs o = 16h + j)
+        f32x4 ts = (f32x4){0.f, 0.f, 0.f, 0.f}, tb = (f32x4){0.f, 0.f, 0.f, 0.f};
         {
             float4 as[4], at[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                as[j] = *reinterpret_cast<const float4 *>(&t_side[i16 * kBwdStride + 16 * h + 4 * j]);
-                at[j] = *reinterpret_cast<const float4 *>(&t_prod[i16 * kBwdStride + 16 * h + 4 * j]);
+                as[j] = *reinterpret_cast<const float4 *>(&t_gs[i16 * kBwdStride + 16 * h + 4 * j]);
+                at[j] = *reinterpret_cast<const float4 *>(&t_gt[i16 * kBwdStride + 16 * h + 4 * j]);
             }
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                ts[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                tb[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                float4 wg[4], wb[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    wg[j] = *reinterpret_cast<const float4 *>(&s_wT[0][(16 * b + i16) * kBwdStride + 16 * h + 4 * j]);
-                    wb[j] = *reinterpret_cast<const float4 *>(&s_wT[1][(16 * b + i16) * kBwdStride + 16 * h + 4 * j]);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    ts[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[j].x, wg[j].x, ts[b], 0, 0, 0);
-                    tb[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(at[j].x, wb[j].x, tb[b], 0, 0, 0);
-                    ts[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[j].y, wg[j].y, ts[b], 0, 0, 0);
-                    tb[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(at[j].y, wb[j].y, tb[b], 0, 0, 0);
-                    ts[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[j].z, wg[j].z, ts[b], 0, 0, 0);
-                    tb[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(at[j].z, wb[j].z, tb[b], 0, 0, 0);
-                    ts[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[j].w, wg[j].w, ts[b], 0, 0, 0);
-                    tb[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(at[j].w, wb[j].w, tb[b], 0, 0, 0);
-                }
+            for (int j = 0; j < 4; ++j) {
+                ts = __builtin_amdgcn_mfma_f32_16x16x4f32(as[j].x, wgT[j].x, ts, 0, 0, 0);
+                tb = __builtin_amdgcn_mfma_f32_16x16x4f32(at[j].x, wbT[j].x, tb, 0, 0, 0);
+                ts = __builtin_amdgcn_mfma_f32_16x16x4f32(as[j].y, wgT[j].y, ts, 0, 0, 0);
+                tb = __builtin_amdgcn_mfma_f32_16x16x4f32(at[j].y, wbT[j].y, tb, 0, 0, 0);
+                ts = __builtin_amdgcn_mfma_f32_16x16x4f32(as[j].z, wgT[j].z, ts, 0, 0, 0);
+                tb = __builtin_amdgcn_mfma_f32_16x16x4f32(at[j].z, wbT[j].z, tb, 0, 0, 0);
+                ts = __builtin_amdgcn_mfma_f32_16x16x4f32(as[j].w, wgT[j].w, ts, 0, 0, 0);
+                tb = __builtin_amdgcn_mfma_f32_16x16x4f32(at[j].w, wbT[j].w, tb, 0, 0, 0);
             }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int r = row_q[q];
-            if (r >= 0) {
-                const size_t o_row = ROWS ? (size_t)(r0 + 4 * h + q) : (size_t)r;      // compact slot / table row
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int c = 16 * b + i16;
-                    const float e = ego[(size_t)r * 64 + c];
-                    g_side[o_row * 64 + c] = ts[b][q] + tb[b][q] * e;
-                    float ge = tb[b][q] * side_c[b][q];
-                    if (g_direct) ge += g_direct[(ROWS ? o_row : (size_t)r) * ld_direct + c];
-                    g_ego[o_row * 64 + c] = ge;
-                }
+            const int rr = 4 * h + q, r = r0 + rr, c = 16 * b + i16;
+            if (r < n) {
+                g_side[(size_t)r * 64 + c] = ts[q] + tb[q] * t_ego[rr * kBwdStride + c];
+                g_ego[(size_t)r * 64 + c] = tb[q] * t_side[rr * kBwdStride + c] + gd_c[q];
             }
         }
-        if (!ROWS) load_tile(tile + tile_step, slot_row, row_q, gn, gx, any, e_reg, s_reg);   // (the rows form has one tile per wave)
     }
-    if (ROWS) {
-        // rows form: one tile per wave; its weight-gradient share leaves straight from the registers as partial block
-        // `tile` [dW_gc 64x64 | db_gc 64 | dW_bi 64x64 | db_bi 64] (plain stores) — spex_adam_step_sum_f32 adds the blocks up
-        const int tile = blockIdx.x * kBwdWaves + wave;
-        if (tile < n_tiles) {
-            float *dst = partials + (size_t)tile * part_stride;
+    // ---- this workgroup's share of the weight gradients: its own block of `parts` ([dW_gc 64x64 | db_gc 64 | dW_bi 64x64 | db_bi 64],
+    //      plain stores — zeros from a workgroup none of whose tiles carried a gradient); ngcf_add_parts_kernel adds the blocks in order
+    (void)did_work;
+    float *dst = parts + (size_t)blockIdx.x * kPartFloats;
 #pragma unroll
-            for (int bo = 0; bo < 4; ++bo) {
+    for (int bn = 0; bn < 4; ++bn) {
 #pragma unroll
-                for (int bn = 0; bn < 4; ++bn) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int a_ = (16 * bo + 4 * h + q) * 64 + 16 * bn + i16;
-                        dst[a_] = dWg[bo][bn][q];
-                        dst[64 * 64 + 64 + a_] = dWb[bo][bn][q];
-                    }
-                }
-            }
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                float cs = dbg[b], ct = dbb[b];
-                cs += __shfl_xor(cs, 16, kWave); cs += __shfl_xor(cs, 32, kWave);
-                ct += __shfl_xor(ct, 16, kWave); ct += __shfl_xor(ct, 32, kWave);
-                if (h == 0) {
-                    dst[64 * 64 + 16 * b + i16] = cs;
-                    dst[2 * 64 * 64 + 64 + 16 * b + i16] = ct;
-                }
-            }
+        for (int q = 0; q < 4; ++q) {
+            const int a_ = (16 * b + 4 * h + q) * 64 + 16 * bn + i16;
+            dst[a_] = dWg[bn][q];
+            dst[64 * 64 + 64 + a_] = dWb[bn][q];
         }
-        return;
     }
-    // ---- weight gradients: registers -> LDS (one wave at a time, plain adds) -> global atomics
-    if (did_work && lane == 0) s_active = 1;
+    dbg += __shfl_xor(dbg, 16, kWave); dbg += __shfl_xor(dbg, 32, kWave);
+    dbb += __shfl_xor(dbb, 16, kWave); dbb += __shfl_xor(dbb, 32, kWave);
+    if (h == 0) {
+        dst[64 * 64 + 16 * b + i16] = dbg;
+        dst[2 * 64 * 64 + 64 + 16 * b + i16] = dbb;
+    }
+}
+
+// gW += sum over the workgroups' blocks in a FIXED order (no atomics, the same bits every run): a workgroup owns 32 consecutive
+// weights, thread (k, g) adds blocks g, g + 8, g + 16, ... (eight loads in flight), the eight partial sums meet in LDS and are added in
+// group order.  (One thread per weight walking all 512 blocks was a 64-round-trip chain: 24 us — as long as the backward itself.)
+__global__ __launch_bounds__(256) void ngcf_add_parts_kernel(const float *__restrict__ parts, int n_parts, float *gW_gc, float *gb_gc,
+                                                             float *gW_bi, float *gb_bi)
+{
+    __shared__ float s_sum[8][32];
+    const int kk = threadIdx.x & 31, g = threadIdx.x >> 5, k = blockIdx.x * 32 + kk;     // kPartFloats is a multiple of 32
+    float acc = 0.0f;
+    int w = g;
+    for (; w + 56 < n_parts; w += 64) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = parts[(size_t)(w + 8 * u) * kPartFloats + k];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; w < n_parts; w += 8) acc += parts[(size_t)w * kPartFloats + k];
+    s_sum[g][kk] = acc;
     __syncthreads();
-    if (!s_active) return;
-    for (int w = 0; w < kBwdWaves; ++w) {
-        if (wave == w && did_work) {
+    if (g == 0) {
+        float t = s_sum[0][kk];
 #pragma unroll
-            for (int bo = 0; bo < 4; ++bo) {
-#pragma unroll
-                for (int bn = 0; bn < 4; ++bn) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int a_ = (16 * bo + 4 * h + q) * kDwStride + 16 * bn + i16;
-                        s_dw[0][a_] += dWg[bo][bn][q];
-                        s_dw[1][a_] += dWb[bo][bn][q];
-                    }
-                }
-            }
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                float cs = dbg[b], ct = dbb[b];
-                cs += __shfl_xor(cs, 16, kWave); cs += __shfl_xor(cs, 32, kWave);
-                ct += __shfl_xor(ct, 16, kWave); ct += __shfl_xor(ct, 32, kWave);
-                if (h == 0) {
-                    s_db[0][16 * b + i16] += cs;
-                    s_db[1][16 * b + i16] += ct;
-                }
-            }
-        }
-        __syncthreads();
-    }
-    for (int k = threadIdx.x; k < 64 * 64; k += blockDim.x) {
-        const int o = k >> 6, c = k & 63;
-        atomicAdd(gW_gc + k, s_dw[0][o * kDwStride + c]);
-        atomicAdd(gW_bi + k, s_dw[1][o * kDwStride + c]);
-    }
-    if (threadIdx.x < 64) {
-        atomicAdd(gb_gc + threadIdx.x, s_db[0][threadIdx.x]);
-        atomicAdd(gb_bi + threadIdx.x, s_db[1][threadIdx.x]);
+        for (int u = 1; u < 8; ++u) t += s_sum[u][kk];
+        float *dst = k < 4096 ? gW_gc + k : (k < 4160 ? gb_gc + (k - 4096) : (k < 8256 ? gW_bi + (k - 4160) : gb_bi + (k - 8256)));
+        *dst += t;
     }
 }
 
@@ -1451,6 +1344,31 @@ extern "C" int spex_ngcf_message_mask(const uint8_t *d_keep)
     return SPEX_OK;
 }
 
+// Scratch of the dense layer backward (the workgroups' weight-gradient blocks), one buffer per (device, stream): launches on one stream
+// are ordered, two streams never share a buffer.  Grown on demand (hipMalloc: the first call at a size must not sit inside a stream
+// capture), kept for the life of the process.
+static int stream_scratch(hipStream_t stream, size_t bytes, float **out)
+{
+    struct Buf { float *p = nullptr; size_t cap = 0; };
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, Buf> bufs;
+    int dev = 0;
+    SPEX_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    Buf &b = bufs[std::make_pair(dev, stream)];
+    if (b.cap < bytes) {
+        if (b.p) {
+            SPEX_HIP(hipStreamSynchronize(stream));
+            SPEX_HIP(hipFree(b.p));
+            b.p = nullptr; b.cap = 0;
+        }
+        SPEX_HIP(hipMalloc((void **)&b.p, bytes));
+        b.cap = bytes;
+    }
+    *out = b.p;
+    return SPEX_OK;
+}
+
 static MsgDrop make_drop(float p_drop, uint64_t seed, uint32_t step, uint32_t layer, int32_t pad_row)
 {
     MsgDrop d;
@@ -1570,12 +1488,17 @@ extern "C" int spex_ngcf_layer_bwd_f32(const float *ego, const float *side, cons
     SPEX_CHECK_ARG((((uintptr_t)W_gc | (uintptr_t)W_bi) & 15) == 0, "spex_ngcf_layer_bwd_f32: weights must be 16-byte aligned");
     if (n == 0) return SPEX_OK;
     const int n_tiles = (n + 15) / 16;
-    int blocks = (n_tiles + kBwdWaves - 1) / kBwdWaves;
-    if (blocks > 128) blocks = 128;      // <= 128 x 8 K weight-gradient atomics; a wave walks its tiles with a stride
-    hipLaunchKernelGGL((ngcf_layer_bwd_kernel<false>), dim3((unsigned)blocks), dim3(kWave * kBwdWaves), 0, (hipStream_t)stream, ego,
-                       side, W_gc, b_gc, W_bi, b_bi, g_norm, ld_g, g_next, g_direct, ld_direct,
-                       n, slope, make_drop(p_drop, seed, step, layer, pad_row), nullptr, 0, 0, nullptr, 0, 0, g_side, g_ego, gW_gc,
-                       gb_gc, gW_bi, gb_bi, nullptr, 0);
+    // persistent workgroups (two fit a CU): each walks its tiles with a stride and leaves ONE block of weight-gradient partials in the
+    // stream's scratch; the second launch adds the blocks to the caller's gradients in block order (deterministic, no atomics)
+    static const int wg_cap = []() { const char *e = getenv("SPEX_NGCF_BWD_WGS"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
+    const int blocks = n_tiles < wg_cap ? n_tiles : wg_cap;
+    float *parts = nullptr;
+    if (int rc = stream_scratch((hipStream_t)stream, (size_t)blocks * kPartFloats * sizeof(float), &parts)) return rc;
+    hipLaunchKernelGGL(ngcf_layer_bwd_dense4_kernel, dim3((unsigned)blocks), dim3(kWave * kBwdWaves), 0, (hipStream_t)stream, ego, side, W_gc,
+                       b_gc, W_bi, b_bi, g_norm, ld_g, g_next, g_direct, ld_direct, n, slope, make_drop(p_drop, seed, step, layer, pad_row),
+                       g_side, g_ego, parts);
+    hipLaunchKernelGGL(ngcf_add_parts_kernel, dim3(kPartFloats / 32), dim3(256), 0, (hipStream_t)stream, parts, blocks, gW_gc, gb_gc,
+                       gW_bi, gb_bi);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }
@@ -1601,17 +1524,10 @@ extern "C" int spex_ngcf_layer_bwd_rows_f32(const float *ego, const float *side,
     SPEX_CHECK_ARG((((uintptr_t)W_gc | (uintptr_t)W_bi) & 15) == 0, "spex_ngcf_layer_bwd_rows_f32: weights must be 16-byte aligned");
     if (n == 0 || n_a + n_b == 0) return SPEX_OK;
     const int tiles = spex_ngcf_layer_bwd_rows_parts(n_a + n_b);
-    static const bool one_wave_form = []() { const char *e = getenv("SPEX_NGCF_ROWS_ONE_WAVE"); return e && e[0] == '1'; }();
-    if (one_wave_form)      // the earlier form (one wave per tile), kept for A/B timing
-        hipLaunchKernelGGL((ngcf_layer_bwd_kernel<true>), dim3((unsigned)((tiles + kBwdWaves - 1) / kBwdWaves)), dim3(kWave * kBwdWaves), 0,
-                           (hipStream_t)stream, ego, side, W_gc, b_gc, W_bi, b_bi, g_norm_c, ld_g, g_next, g_direct_c, ld_direct, n, slope,
-                           make_drop(p_drop, seed, step, layer, pad_row), idx_a, n_a, off_a, idx_b, n_b, off_b, g_side_c, g_ego_c, nullptr,
-                           nullptr, nullptr, nullptr, gW_parts, part_stride);
-    else
-        hipLaunchKernelGGL((ngcf_layer_bwd_rows4_kernel<0>), dim3((unsigned)tiles), dim3(kWave * kBwdWaves), 0, (hipStream_t)stream,
-                           ego, side, W_gc, b_gc, W_bi, b_bi, g_norm_c, ld_g, g_next, g_direct_c, ld_direct, n, slope,
-                           make_drop(p_drop, seed, step, layer, pad_row), idx_a, n_a, off_a, idx_b, n_b, off_b, g_side_c, g_ego_c,
-                           gW_parts, part_stride, ScoreArgs{nullptr, nullptr, nullptr, 0.0f});
+    hipLaunchKernelGGL((ngcf_layer_bwd_rows4_kernel<0>), dim3((unsigned)tiles), dim3(kWave * kBwdWaves), 0, (hipStream_t)stream,
+                       ego, side, W_gc, b_gc, W_bi, b_bi, g_norm_c, ld_g, g_next, g_direct_c, ld_direct, n, slope,
+                       make_drop(p_drop, seed, step, layer, pad_row), idx_a, n_a, off_a, idx_b, n_b, off_b, g_side_c, g_ego_c,
+                       gW_parts, part_stride, ScoreArgs{nullptr, nullptr, nullptr, 0.0f});
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }

@@ -285,6 +285,15 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_rows_narrow_kernel
 // holding Inf / NaN (a diverged table) into 0 * Inf = NaN on a row that never referenced it.
 // In-kernel fold of the rows beyond kWgRowMax entries (tag != 0; spex_common.h: hub_grp / hub_fold / hub_ticket).  tag == 0: the
 // hub segments leave one partial row each and spmm_long_fixup_kernel adds them (the wide kernels, and SPEX_HUB_FOLD=0).
+#ifndef SPEX_EPI_NT
+#define SPEX_EPI_NT 1
+#endif
+#if SPEX_EPI_NT
+#define SPEX_EPI_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define SPEX_EPI_LOAD(p) (*(p))
+#endif
+
 struct HubFold {
     const int4 *grp;
     const int2 *fold;
@@ -354,7 +363,49 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
     // Metadata of up to 4 chunks (64 entries) per vector load — lane k holds entry k — handed to the scalar side with
     // v_readlane.  (Feeding it through s_load instead starves on scalar-cache misses once the matrix streams from
     // HBM: 29 ms vs 13 ms per launch on a 2^23-node graph.)
-    const int n_ch = kind == 3 ? 0 : t.y;              // (kind 3: a list of rows without stored entries, handled after the loop)
+    // A LIST of rows without stored entries (kind 3, bin-packed tables only; <= 64 rows, lane k holds the k-th row id): y = 0, the
+    // epilogue still applies.  Done on the VECTOR side, four rows per instruction (16 lanes x float4 per row), sixteen rows' operands
+    // in flight: taken one row at a time through the scalar emit path (load, wait, store) the list was a chain of up to 64 dependent
+    // round trips — 32 us on the Weibo shape with its 2 441 empty rows, whose epilogue launches took twice as long as its plain ones —
+    // and batching THAT path held sixteen row ids in SGPRs across the chunk loop (+1.5 us on Epinion2's <1> launch).
+    if (ROWIDS && kind == 3) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const int count = t.w >> 4;
+        const int my_r = lane < count ? chunk_row[(size_t)t.x * kChunk + lane] : -1;
+        const int sub = lane & 15, grp = lane >> 4;
+        const f4 zero = (f4)(0.0f);
+        for (int k0 = 0; k0 < count; k0 += 16) {
+            int r[4];
+            f4 e[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                r[j] = __shfl(my_r, (k0 + 4 * j + grp) & 63, kWave);
+                if (k0 + 4 * j + grp >= count) r[j] = -1;
+                e[j] = zero;
+                if (EPI != 0 && r[j] >= 0) e[j] = *reinterpret_cast<const f4 *>(epi_in + (size_t)r[j] * 64 + sub * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (r[j] < 0) continue;
+                const size_t o = (size_t)r[j] * 64 + sub * 4;
+                if (EPI == 0) {
+                    __builtin_nontemporal_store(zero, reinterpret_cast<f4 *>(Y + o));
+                } else if (EPI == 1) {
+                    f4 sv = e[j] + zero;
+                    if (epi_div != 1.0f) sv = sv / epi_div;
+                    if (Y) __builtin_nontemporal_store(zero, reinterpret_cast<f4 *>(Y + o));
+                    __builtin_nontemporal_store(sv, reinterpret_cast<f4 *>(acc_out + o));
+                } else {
+                    f4 ev = e[j];
+                    if (epi_div != 1.0f) ev = ev / epi_div;
+                    f4 sv = zero + ev;
+                    if (out_div != 1.0f) sv = sv / out_div;
+                    __builtin_nontemporal_store(sv, reinterpret_cast<f4 *>(Y + o));
+                }
+            }
+        }
+    }
+    const int n_ch = kind == 3 ? 0 : t.y;              // (kind 3: handled above)
     for (int sc = 0; sc < n_ch; sc += 4) {
         const int nc = (n_ch - sc < 4) ? n_ch - sc : 4;  // chunks in this super-chunk (wave-uniform)
         uint32_t my_off = 0u, my_mask = 0u, own_off = 0u;
@@ -405,7 +456,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
                     ep[u] = 0.0f;
                     if (mask & (1u << u)) {
                         const int rr = ROWIDS ? __builtin_amdgcn_readlane(my_row, c * kChunk + u) : r;
-                        ep[u] = __builtin_nontemporal_load(El + (size_t)rr * 64);
+                        ep[u] = SPEX_EPI_LOAD(El + (size_t)rr * 64);
                         ++r;
                     }
                 }
@@ -434,16 +485,6 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
         float e = 0.0f;
         if (EPI != 0) e = El[(size_t)t.z * 64];
         emit(t.z, 0.0f, e);
-    }
-    if (ROWIDS && kind == 3) {                // a LIST of such rows (<= 64: lane k holds the k-th row id), bin-packed tables only
-        const int count = t.w >> 4;
-        const int my_r = lane < count ? chunk_row[(size_t)t.x * kChunk + lane] : 0;
-        for (int k = 0; k < count; ++k) {
-            const int r = __builtin_amdgcn_readlane(my_r, k);
-            float e = 0.0f;
-            if (EPI != 0) e = El[(size_t)r * 64];
-            emit(r, 0.0f, e);
-        }
     }
     const bool hub = FOLD && kind == 2 && hf_args.tag != 0u;
     if (kind == 2 && !hub) partial[(size_t)(t.w >> 4) * 64 + lane] = acc;  // hub segment: summed by the fix-up launch
@@ -661,11 +702,16 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_wide_kernel(
     if (ROWIDS && kind == 3) {                // a list of such rows (see the d == 64 kernel)
         const int count = t.w >> 4;
         const int my_r = lane < count ? chunk_row[(size_t)t.x * kChunk + lane] : 0;
-        for (int k = 0; k < count; ++k) {
-            const int r = __builtin_amdgcn_readlane(my_r, k);
-            vec e = (vec)(0.0f);
-            if (EPI != 0) e = *reinterpret_cast<const vec *>(El + (size_t)r * kRow);
-            emit(r, (vec)(0.0f), e);
+        for (int k0 = 0; k0 < count; k0 += kBatch) {    // the rows' epilogue operands in flight together (see the d == 64 kernel)
+            vec e[kBatch];
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                e[u] = (vec)(0.0f);
+                if (EPI != 0 && k0 + u < count) e[u] = *reinterpret_cast<const vec *>(El + (size_t)__builtin_amdgcn_readlane(my_r, (k0 + u) & 63) * kRow);
+            }
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u)
+                if (k0 + u < count) emit(__builtin_amdgcn_readlane(my_r, (k0 + u) & 63), (vec)(0.0f), e[u]);
         }
     }
     if (kind == 2) {  // hub segment: summed by the fix-up launch
@@ -912,6 +958,10 @@ int launch_spmm(const spex_graph *g, const float *X, float *Y, const float *add_
         gm->scratch_used = true;
     }
     if (fast) {
+        // (rows are moved as float4 where a wave handles several rows per instruction: every table 16-byte aligned — any row of a
+        //  contiguous fp32 [*, 64 V] tensor is)
+        SPEX_CHECK_ARG(((((uintptr_t)X) | ((uintptr_t)Y) | ((uintptr_t)add_in) | ((uintptr_t)acc_in) | ((uintptr_t)acc_out)) & 15) == 0,
+                       "spex_spmm_f32: X / Y / add_in / acc_in / acc_out must be 16-byte aligned");
         const int xcd_contig = ((int64_t)g->n_cols * d * 4 <= (int64_t)16 << 20) ? 1 : 0;  // source table <= 16 MiB
         DropArgs da;
         da.chunk_eid = g->chunk_eid; da.keep = g->keep; da.mode = g->mask_mode; da.keep_prob = g->keep_prob;

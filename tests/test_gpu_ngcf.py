@@ -309,7 +309,7 @@ def test_on_device_ngcf_epochs_match_the_reference_small(golden, ngcf_data_root)
     assert st.t == int(g["n_steps"]) and model.dropout_step == int(g["n_steps"])
 
 
-def _ngcf_epinion2_model(g, root):
+def _ngcf_epinion2_model(g, root, layer_size="[64]"):
     from spex_amd.dropin.ngcf.utility import batch_test
     from spex_amd.dropin.ngcf.utility.load_data import Data
     from spex_amd.ngcf import NGCF
@@ -318,7 +318,7 @@ def _ngcf_epinion2_model(g, root):
     batch_test.use_data(data)
     _, norm, _ = data.get_adj_mat()
     model = NGCF({"n_users": data.n_users, "n_items": data.n_items, "norm_adj": norm}, DEV,
-                 ngcf_args(mess_dropout=str([float(x) for x in g["mess_dropout"]]))).to(DEV)
+                 ngcf_args(mess_dropout=str([float(x) for x in g["mess_dropout"]]), layer_size=layer_size)).to(DEV)
     model.message_dropout_seed = int(g["drop_seed"])
     return data, model, batch_test
 
@@ -511,6 +511,69 @@ def test_ngcf_teacher_forced_checkpoints(golden, ngcf_data_root, tag):
     ret = batch_test.test(model, list(data.test_set.keys()), drop_flag=True)
     got = np.concatenate([ret["recall"], ret["ndcg"]])
     assert np.abs(got - want).max() <= 1e-4, (got, want)
+
+
+@pytest.mark.parametrize("tag", ["ckpt40", "ckptend"])
+def test_two_layer_ngcf_teacher_forced_against_the_reference(golden, ngcf_data_root, tag):
+    """NGCF beyond one layer (`--layer_size [64,64] --mess_dropout [0.1,0.1]`, NGCF_SPEX/code/ngcf_parser.py:12; the layer loop of
+    main_rec.py:71-93) pinned against the REFERENCE: its full parameter state in front of step 40 and after 60 steps of its Epinion2
+    run (oracle/gen_golden.py --stage ngcf-2layer-epinion2 -> ngcf_epinion2_2layer_ckpt.npz: that step's batch, dropout step, loss,
+    every gradient — the four weight matrices of BOTH layers in full, the tables as sampled rows + column sums + Frobenius norm).
+    Loaded into the GPU model: one forward / backward through the module (dense layer forward, rows-form backward of the last layer,
+    push-form A^T product, the 4-wave DENSE backward of the first layer, pull-form A^T product) -> loss <= 2e-5, gradients <= 5e-5;
+    the same step through NGCFStepper -> the same loss, and the parameters one Adam step later agree with the module + torch Adam;
+    test() at the reference's trained 2-layer weights -> HR / NDCG <= 1e-4."""
+    from spex_amd.trainer import NGCFStepper
+    g = golden("ngcf_epinion2_2layer_ckpt")
+    data, model, batch_test = _ngcf_epinion2_model(g, ngcf_data_root, layer_size="[64,64]")
+    assert model.n_layers == 2
+
+    def load_state():
+        with torch.no_grad():
+            for name, p in model.named_parameters():
+                p.copy_(torch.from_numpy(g[f"{tag}_state_" + name.replace(".", "__")]))
+        model.dropout_step = int(g[f"{tag}_drop_step"])
+    load_state()
+    user, item, labels = (torch.from_numpy(g[f"{tag}_batch"][k]) for k in range(3))
+    want_loss = float(g[f"{tag}_loss"])
+    model.train()
+    model.zero_grad()
+    loss = model(user=user.to(DEV), item=item.to(DEV), labels_list=labels.float().to(DEV), flag=0)
+    loss.backward()
+    assert abs(loss.item() - want_loss) <= 2e-5, (loss.item(), want_loss)
+    for name, p in model.named_parameters():
+        key = f"{tag}_grad_" + name.replace(".", "__")
+        got = p.grad.cpu().numpy()
+        if key + "_rows" in g.files:                                     # the two tables
+            fro = float(g[key + "_fro"])
+            assert abs(np.sqrt((got.astype(np.float64) ** 2).sum()) - fro) <= 5e-5 * fro, name
+            cs = g[key + "_colsum"]
+            assert np.abs(got.astype(np.float64).sum(0) - cs).max() <= 5e-5 * max(np.abs(cs).max(), 1e-6), name
+            got = got[g[key + "_rows"]]
+        assert rel_err(got, g[key]) <= 5e-5, (name, rel_err(got, g[key]))
+    # ---- one optimiser step two ways from the same state: module + torch Adam, and the stepper
+    opt = torch.optim.Adam(model.parameters(), lr=float(g["lr"]))
+    opt.step()
+    want = {n: p.detach().clone() for n, p in model.named_parameters()}
+    load_state()
+    st = NGCFStepper(model, lr=float(g["lr"]))
+    acc = torch.zeros(1, device=DEV)
+    st.step(user.to(DEV), item.to(DEV), labels.float().to(DEV), loss_acc=acc)
+    assert abs(acc.item() / len(user) - want_loss) <= 2e-5, (acc.item() / len(user), want_loss)
+    for n, p in model.named_parameters():
+        # (Adam's FIRST step moves a weight by lr * g / (|g| + 1e-8): ~lr whatever the gradient's size, and for the few elements
+        #  whose gradient is itself at rounding level the quotient amplifies that rounding — so the bulk is compared through the mean,
+        #  the worst element only against the step size)
+        dv = (p.detach() - want[n]).abs()
+        assert float(dv.mean()) <= 2e-3 * float(g["lr"]) and float(dv.max()) <= 1.01 * float(g["lr"]), (n, float(dv.mean()), float(dv.max()))
+    # ---- evaluation at the reference's 2-layer weights after its 60 steps
+    if tag == "ckptend":
+        load_state()
+        model.eval()
+        ret = batch_test.test(model, list(data.test_set.keys()), drop_flag=True)
+        got = np.concatenate([ret["recall"], ret["ndcg"]])
+        want_m = g["eval_metrics"][list(g["eval_steps"]).index(int(g["n_steps"]))]
+        assert np.abs(got - want_m).max() <= 1e-4, (got, want_m)
 
 
 def test_fused_spmm_and_layer_equals_the_two_launches(epinion2):
