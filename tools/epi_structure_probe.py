@@ -5,6 +5,9 @@ import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if os.environ.get("SPEX_LIB"):
+    from spex_amd import _lib as _l
+    _l.LIB_PATH = os.path.abspath(os.environ["SPEX_LIB"])
 from spex_amd.datasets import synthetic_interactions
 from spex_amd.graph import SpexGraph, lightgcn_norm_adj
 dev = torch.device("cuda:0")
