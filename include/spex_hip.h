@@ -37,15 +37,12 @@ typedef enum spex_status {
 
 typedef struct spex_graph spex_graph_t;
 
-int spex_version(void);                 /* ABI version, currently 4.  3 = 2 + the batch-sized one-launch entries, spex_graph_create_ex,
-                                         * a trailing side_stream field in the NGCF / dual-task step descriptors.  4 = 3 + the
-                                         * deterministic accumulation mode (`flags` + trailing buffers in the three step descriptors,
-                                         * spex_reduce_slots_f32, spex_lightgcn_batch_slots_f32, spex_expert_gate_rows_bwd_det_f32),
-                                         * per-descriptor fork / join events (ev_fork / ev_join, spex_step_events_release),
-                                         * spex_lightgcn_batch_f32 without its graph_t argument (the push walks the rows of A),
-                                         * loss_per_sample in spex_gated_batch_fwd_f32, the spex_comm_* collectives, the one-launch
-                                         * middles spex_gated_batch_f32 / spex_ngcf_fwd_score_bwd_rows_f32 (+ spex_ngcf_layer_fwd_rows_f32),
-                                         * SPEX_STEP_PIPELINED with spex_dual_task_step_join and the trailing side_pending cell */
+int spex_version(void);                 /* ABI version, currently 5.  5 = 4 minus what round 3's measurements retired
+                                         * (spex_graph_create_ex / SPEX_GRAPH_TILE_ROWS and spex_ngcf_spmm_layer_fwd_f32, the `flags`
+                                         * argument of spex_graph_pack_digest, the tiled trust head, the one-wave NGCF kernels, the
+                                         * narrow d <= 32 SpMM), plus spex_partitioned_dual_task_step_f32 (config 5 row-partitioned
+                                         * as one call).  4 = 3 + the deterministic accumulation mode, per-descriptor fork / join
+                                         * events, the spex_comm_* collectives, the one-launch middles, SPEX_STEP_PIPELINED. */
 const char *spex_last_error(void);      /* thread-local, never NULL */
 
 /* ------------------------------------------------------------------------------------------------ graph handle
@@ -62,20 +59,13 @@ const char *spex_last_error(void);      /* thread-local, never NULL */
  */
 int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, const float *h_val, const int32_t *h_edge_id,
                       int32_t n_rows, int32_t n_cols, int64_t nnz, spex_graph_t **out);
-/* The same with options.  SPEX_GRAPH_TILE_ROWS: lay the d == 64 task table out so that every 16-wave workgroup completes at
- * most 64 output rows (four 16-row matrix-core tiles) — required by spex_ngcf_spmm_layer_fwd_f32, which keeps a workgroup's
- * finished rows in LDS and runs the NGCF layer on them; every other entry point works on such a handle as on an ordinary
- * one.  Needs n_cols * 256 B <= 16 MiB and no row of more than 1024 stored entries (SPEX_ERR_UNSUPPORTED otherwise). */
-#define SPEX_GRAPH_TILE_ROWS 1
-int spex_graph_create_ex(const int32_t *h_rowptr, const int32_t *h_col, const float *h_val, const int32_t *h_edge_id,
-                         int32_t n_rows, int32_t n_cols, int64_t nnz, int32_t flags, spex_graph_t **out);
 int spex_graph_destroy(spex_graph_t *g);
-/* HOST ONLY (no device call, works without a GPU): FNV-1a fingerprints of everything spex_graph_create[_ex] would upload for this
+/* HOST ONLY (no device call, works without a GPU): FNV-1a fingerprints of everything spex_graph_create would upload for this
  * matrix — digest[0] the wave-task table, [1..5] the chunk arrays (source offsets, values, end-of-row masks + padding counts, edge
- * ids, output rows + workgroup row counts), [6] the long-row segment tables, [7] the hub / tile tables and the table sizes.  The
+ * ids, output rows), [6] the long-row segment tables, [7] the hub tables and the table sizes.  The
  * host packer runs on SPEX_BUILD_THREADS threads (default min(16, cores)); the layout must not depend on that number. */
 int spex_graph_pack_digest(const int32_t *h_rowptr, const int32_t *h_col, const float *h_val, int32_t n_rows, int32_t n_cols,
-                           int64_t nnz, int32_t flags, uint64_t *digest /* [8] */);
+                           int64_t nnz, uint64_t *digest /* [8] */);
 /* HOST ONLY: how the packer laid out the rows beyond 1 024 entries (hubs) — the tables the d == 64 launch folds them by.  out:
  * [n_positions, n_hubs, then per task position of the table's head (chunks, row, task word, 1 = first wave of a group, waves in
  * the group, the group's scratch row, hub), then per hub (its first scratch row, its number of groups)]; *n_out = ints needed
@@ -281,14 +271,6 @@ int spex_ngcf_layer_fwd_rows_f32(const float *ego, const float *side, const floa
                                  const float *b_bi, float *out, int32_t ld_out, int32_t write_ego, int32_t n, int32_t d, float slope,
                                  float p_drop, uint64_t seed, uint32_t step, uint32_t layer, int32_t pad_row, const int64_t *idx_a,
                                  int32_t n_a, int64_t off_a, const int64_t *idx_b, int32_t n_b, int64_t off_b, void *stream);
-/* side = A ego (main_rec.py:76) and the layer (:77-83) in ONE launch on a handle created with SPEX_GRAPH_TILE_ROWS: a workgroup
- * runs its tasks like spex_spmm_f32, keeps its (<= 64) finished rows in LDS and runs the layer on them; out [n, ld_out >= 2d]
- * receives [ego | normalised layer output], side_out [n, d] the product (bit-identical to spex_spmm_f32's; the backward
- * recomputes the layer from it).  d == 64.  Measured no faster than the two launches: an option, not the default.
- */
-int spex_ngcf_spmm_layer_fwd_f32(const spex_graph_t *g, const float *ego, const float *W_gc, const float *b_gc, const float *W_bi,
-                                 const float *b_bi, float *out, int32_t ld_out, float *side_out, int32_t d, float slope, float p_drop,
-                                 uint64_t seed, uint32_t step, uint32_t layer, int32_t pad_row, void *stream);
 /* The same layer in inference form (dropout off, ego written): kept for ABI-1 callers. */
 int spex_ngcf_layer_f32(const float *ego, const float *side, const float *W_gc, const float *b_gc, const float *W_bi,
                         const float *b_bi, float *out, int32_t ld_out, float *e1_out, int32_t n, int32_t d,
@@ -607,8 +589,7 @@ int spex_path_attention_bwd_f32(const float *src, int64_t n_src_rows, const int6
  *   (:146-147) — the evaluation form (flag 2).
  * spex_trust_head_train_f32 (two launches: the fused path kernel — forward chain, the logits / cross-entropy / d a2 sweep of the
  *   user table shared by up to 8 workgroups per path whose last one folds the shares in a fixed order and runs the backward chain —
- *   and the reductions.  SPEX_TRUST_SPLIT=n caps the workgroups per path, SPEX_TRUST_TILED=1 selects the older five-launch form
- *   with the logits on tiles of 32 users shared by all paths; both read per call): forward, logits = a2 . table[0 : n_rows - 1]^T (`b = table[:-1]`), loss =
+ *   and the reductions.  SPEX_TRUST_SPLIT=n caps the workgroups per path — a test hook, read per call): forward, logits = a2 . table[0 : n_rows - 1]^T (`b = table[:-1]`), loss =
  *   mean_b CE(logits_b, targets_b) -> *loss_out (added to it if loss_accumulate; may be NULL), and the whole backward:
  *   grad_params (flat block) is OVERWRITTEN (one thread per weight sums its contributions in a fixed order: deterministic);
  *   grad_table [n_rows, 64] is ACCUMULATED by the launch that owns the rows — the logits' part, then the rows of the paths that

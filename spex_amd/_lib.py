@@ -16,11 +16,8 @@ SIGNATURES = {
     "spex_version": (ctypes.c_int, []),
     "spex_last_error": (ctypes.c_char_p, []),
     "spex_graph_create": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, ctypes.POINTER(c_vp)]),
-    "spex_graph_create_ex": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_i32, ctypes.POINTER(c_vp)]),
-    "spex_ngcf_spmm_layer_fwd_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_f32, c_f32,
-                                                    ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, c_i32, c_vp]),
     "spex_graph_destroy": (ctypes.c_int, [c_vp]),
-    "spex_graph_pack_digest": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_i32, c_vp]),
+    "spex_graph_pack_digest": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp]),
     "spex_graph_pack_hub_table": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp, c_i64, c_vp]),
     "spex_graph_info": (ctypes.c_int, [c_vp, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), ctypes.POINTER(c_i64),
                                        ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),

@@ -20,8 +20,7 @@
 //        (part 0 only).
 //   PUSH == false (spex_lightgcn_batch_slots_f32, the deterministic step): steps 1 and 2 only; the sample's two gradient rows
 //   leave with plain stores as grad_slots[b] (user side) and grad_slots[B + b] (item side) — no float atomics anywhere.
-//   Up to `parts` workgroups (SPEX_BATCH_PARTS, default 3) share a sample when its rows are long (more than
-//   SPEX_BATCH_RUNS_PER_PART = 16 runs per part) — each repeats the cheap, L2-resident forward, the parts of a shorter sample
+//   Up to kBatchParts = 3 workgroups share a sample when its rows are long (more than kBatchRunsPerPart = 16 runs per part) — each repeats the cheap, L2-resident forward, the parts of a shorter sample
 //   leave at once.  The longest sample's push sets the launch time, and the reference's training batches (a random observed pair
 //   or one of its five same-user negatives: users and positive items arrive in proportion to their degree) carry rows of ~1 000
 //   entries all the time.  Measured on Epinion2, B = 256, us per step on uniform / training-shaped batches: 1 part 81.1 / 86.5,
@@ -29,6 +28,8 @@
 #include "spex_common.h"
 
 using namespace spex;
+
+constexpr int kBatchParts = 3, kBatchRunsPerPart = 16;      // measured: see the table above
 
 namespace {
 
@@ -592,13 +593,6 @@ extern "C" int spex_gated_batch_f32(const spex_graph_t *g, const float *X, const
                                          grad_scale, push_scale, loss_sum, g_prop, G, g_raw, g_att, n_att_copies, d, stream);
 }
 
-static int batch_env(const char *name, int dflt, int lo, int hi)
-{
-    const char *e = getenv(name);
-    const int p = e ? atoi(e) : dflt;
-    return p < lo ? lo : (p > hi ? hi : p);
-}
-
 int spex::gated_batch_push_layers(const spex_graph_t *g, const float *X, const float *acc_in, const float *acc2, const float *acc3,
                                   float acc_div, const float *raw, const float *att_u, const float *att_i, const int64_t *users,
                                   const int64_t *items, const float *labels, int32_t B, int32_t n_user_rows, float grad_scale,
@@ -616,8 +610,7 @@ int spex::gated_batch_push_layers(const spex_graph_t *g, const float *X, const f
         return SPEX_ERR_UNSUPPORTED;
     }
     if (B == 0 || g->n_rows == 0) return SPEX_OK;
-    static const int runs_per_part = batch_env("SPEX_BATCH_RUNS_PER_PART", 16, 1, 1 << 20);
-    static const int parts = batch_env("SPEX_BATCH_PARTS", 3, 1, 16);
+    constexpr int runs_per_part = kBatchRunsPerPart, parts = kBatchParts;
     hipLaunchKernelGGL(gated_batch_push_kernel, dim3((unsigned)B * parts), dim3(kWave * kWgWaves), 0, (hipStream_t)stream, g->rowptr, g->col,
                        g->val, g->n_rows, n_user_rows, X, acc_in, acc_div, raw, att_u, att_i, users, items, labels, parts, runs_per_part,
                        grad_scale, push_scale, loss_sum, g_prop, G, g_raw, g_att, n_att_copies, acc2, acc3, edge_drop_of(g));
@@ -688,16 +681,7 @@ int spex::lightgcn_batch_layers(const spex_graph_t *g, const float *X, const flo
         return SPEX_ERR_UNSUPPORTED;
     }
     if (B == 0 || g->n_rows == 0) return SPEX_OK;
-    static const int runs_per_part = []() {
-        const char *e = getenv("SPEX_BATCH_RUNS_PER_PART");
-        const int p = e ? atoi(e) : 16;
-        return p < 1 ? 1 : p;
-    }();
-    static const int parts = []() {
-        const char *e = getenv("SPEX_BATCH_PARTS");
-        const int p = e ? atoi(e) : 3;
-        return p < 1 ? 1 : (p > 16 ? 16 : p);
-    }();
+    constexpr int runs_per_part = kBatchRunsPerPart, parts = kBatchParts;
     hipLaunchKernelGGL(lightgcn_batch_kernel<true>, dim3((unsigned)B * parts), dim3(kWave * kWgWaves), 0, (hipStream_t)stream, g->rowptr,
                        g->col, g->val, g->n_rows, n_user_rows, X, acc_in, acc_div, users, items, labels, parts, grad_scale, push_scale,
                        loss_sum, loss_per_sample, g_out, G, runs_per_part, nullptr, B, acc2, acc3, edge_drop_of(g));

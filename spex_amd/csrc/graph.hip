@@ -22,7 +22,7 @@ void set_error(const char *fmt, ...)
 }
 }  // namespace spex
 
-extern "C" int spex_version(void) { return 4; }
+extern "C" int spex_version(void) { return 5; }
 extern "C" const char *spex_last_error(void) { return spex::g_err; }
 
 // Host-side packing runs on a few threads: SPEX_BUILD_THREADS, default min(16, hardware threads); small inputs stay on
@@ -84,12 +84,11 @@ static int graph_create_impl(const int32_t *h_rowptr, const int32_t *h_col, cons
 // task table, the chunk arrays, the segment / hub tables — so that a binding, or the CPU test-suite, can check that the threaded
 // packer (SPEX_BUILD_THREADS) lays the matrix out exactly as the single-thread planner does.
 extern "C" int spex_graph_pack_digest(const int32_t *h_rowptr, const int32_t *h_col, const float *h_val, int32_t n_rows, int32_t n_cols,
-                                      int64_t nnz, int32_t flags, uint64_t *digest)
+                                      int64_t nnz, uint64_t *digest)
 {
     SPEX_CHECK_ARG(digest, "spex_graph_pack_digest: NULL output");
-    SPEX_CHECK_ARG((flags & ~SPEX_GRAPH_TILE_ROWS) == 0, "spex_graph_pack_digest: unknown flags 0x%x", flags);
     spex_graph_t *unused = nullptr;
-    return graph_create_impl(h_rowptr, h_col, h_val, nullptr, n_rows, n_cols, nnz, flags, &unused, digest);
+    return graph_create_impl(h_rowptr, h_col, h_val, nullptr, n_rows, n_cols, nnz, 0, &unused, digest);
 }
 
 // Host only: how the packer laid out the rows beyond kWgRowMax entries (the tables the in-kernel hub fold reads) — for tests of the
@@ -114,13 +113,6 @@ extern "C" int spex_graph_create(const int32_t *h_rowptr, const int32_t *h_col, 
                                  spex_graph_t **out)
 {
     return graph_create_impl(h_rowptr, h_col, h_val, h_edge_id, n_rows, n_cols, nnz, 0, out);
-}
-
-extern "C" int spex_graph_create_ex(const int32_t *h_rowptr, const int32_t *h_col, const float *h_val, const int32_t *h_edge_id,
-                                    int32_t n_rows, int32_t n_cols, int64_t nnz, int32_t flags, spex_graph_t **out)
-{
-    SPEX_CHECK_ARG((flags & ~SPEX_GRAPH_TILE_ROWS) == 0, "spex_graph_create_ex: unknown flags 0x%x", flags);
-    return graph_create_impl(h_rowptr, h_col, h_val, h_edge_id, n_rows, n_cols, nnz, flags, out);
 }
 
 template <typename T>
@@ -225,19 +217,16 @@ static int graph_create_impl(const int32_t *h_rowptr, const int32_t *h_col, cons
     std::vector<int2> hub_fold;
     const bool chunked = true;
     g->row_ids = (int64_t)n_cols * 256 <= ((int64_t)16 << 20);
-    const int32_t tile_rows = (flags & SPEX_GRAPH_TILE_ROWS) ? spex::kTileRows : 0;
+    (void)flags;
+    const int32_t tile_rows = 0;                 // (round 3's tile mode — at most 64 rows per workgroup, for a fused SpMM + NGCF layer launch
+                                                 //  that measured no faster than two launches — is gone; the bookkeeping below stays inert)
     std::vector<int32_t> wg_rows;
-    if (tile_rows && !g->row_ids) {
-        spex::set_error("spex_graph_create_ex: SPEX_GRAPH_TILE_ROWS needs a source table of <= 16 MiB (n_cols = %d)", n_cols);
-        delete g;
-        return SPEX_ERR_UNSUPPORTED;
-    }
     // The cache-resident launch is fastest when ALL its workgroups are resident at once (2 per CU: 512): a table that needs a few
     // more than that pays a second dispatch round for them (Epinion2's NGCF adjacency: 518 workgroups, 15.9 us against 14.9).  If
     // the first-fit packing with kOpenTasks open tasks lands just above, it is redone with 32 (denser: 5.5 % padding instead of
-    // 6.7 %, slightly less local) and kept if that fits; SPEX_OPEN_TASKS pins the number.
+    // 6.7 %, slightly less local) and kept if that fits.
     constexpr int kResidentWgs = 512;
-    int open_tasks_now = getenv("SPEX_OPEN_TASKS") ? atoi(getenv("SPEX_OPEN_TASKS")) : spex::kOpenTasks;
+    int open_tasks_now = spex::kOpenTasks;
     // Entries a pack of SHORT rows (<= 64 entries each) may hold.  64 = four chunks = four gather round trips per wave.  A table that
     // needs a few more workgroups than are resident pays a whole second dispatch round for them (the Weibo-shaped graph: 520 workgroups,
     // 19.8 us per product instead of ~13); letting the packs hold 80 / 96 / .. entries instead makes some waves run a fifth / sixth
@@ -456,70 +445,7 @@ static int graph_create_impl(const int32_t *h_rowptr, const int32_t *h_col, cons
                 task.push_back(t);
             }
         };
-        if (tile_rows) {
-            // Tile mode: a workgroup completes at most tile_rows rows; bits 16-23 of task.w = the workgroup-local slot of the
-            // task's first completed row.  Rows of 65..1024 entries first (most segments first), each workgroup topped up with
-            // ordinary tasks; a workgroup that holds such a row has the barrier bit on ALL its tasks, so the table also serves
-            // the ordinary kernels.
-            if (!hubs.empty()) {
-                spex::set_error("spex_graph_create_ex: SPEX_GRAPH_TILE_ROWS does not support rows of more than %d entries", spex::kWgRowMax);
-                delete g;
-                return SPEX_ERR_UNSUPPORTED;
-            }
-            int used_t = 0, used_r = 0;
-            bool has_mid = false;
-            auto close_wg = [&]() {
-                if (used_t == 0) return;
-                while (task.size() % W) task.push_back(null_task);
-                if (has_mid)
-                    for (size_t k = task.size() - W; k < task.size(); ++k) task[k].w |= 4;
-                wg_rows.push_back(used_r);
-                used_t = used_r = 0;
-                has_mid = false;
-            };
-            auto put_normal = [&](size_t k) {
-                const int32_t nr = normal_nrows[k];
-                if (used_t + 1 > W || used_r + nr > tile_rows) close_wg();
-                int4 t = normal[k];
-                t.w |= used_r << 16;
-                task.push_back(t);
-                used_t += 1;
-                used_r += nr;
-            };
-            std::vector<int32_t> order(mids.size());
-            for (size_t m = 0; m < mids.size(); ++m) order[m] = (int32_t)m;
-            std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return mids[a].nseg > mids[b].nseg; });
-            for (int32_t m : order) {
-                const Mid &md = mids[m];
-                if (used_t + md.nseg > W || used_r + 1 > tile_rows) close_wg();
-                for (int32_t sgi = 0; sgi < md.nseg; ++sgi) {
-                    const int32_t sb = md.b + sgi * spex::kTaskEntries;
-                    const int32_t se = sb + spex::kTaskEntries < md.e ? sb + spex::kTaskEntries : md.e;
-                    const int2 c = add_chunks(nullptr, 0, sb, se, md.row);
-                    task.push_back(make_int4(c.x, c.y, md.row,
-                                             1 | 4 | (sgi == 0 ? 8 : 0) | ((used_t + sgi) << 4) | (md.nseg << 8) | (used_r << 16)));
-                }
-                used_t += md.nseg;
-                used_r += 1;
-                has_mid = true;
-                while (next_normal < normal.size() && used_t < W && used_r + normal_nrows[next_normal] <= tile_rows) put_normal(next_normal++);
-            }
-            while (next_normal < normal.size()) put_normal(next_normal++);
-            close_wg();
-            {
-                const int n_wgs_now = (int)((task.size() + W - 1) / W);
-                const bool pinned = getenv("SPEX_OPEN_TASKS") != nullptr;
-                if (g->row_ids && !pinned && attempt == 0 && n_wgs_now > kResidentWgs && n_wgs_now <= kResidentWgs + kResidentWgs / 16) {
-                    open_tasks_now = 32;
-                    continue;
-                }
-                if (g->row_ids && !pinned && attempt == 1 && n_wgs_now > kResidentWgs) {      // no use: back to the default
-                    open_tasks_now = spex::kOpenTasks;
-                    continue;
-                }
-            }
-            fill_chunks();
-        } else {
+        {
         // Hub segments lead the table.  Every hub STARTS a workgroup, so that its segments fall into groups of 16 counted from its own
         // first segment (the last group topped up with ordinary tasks): the association of a hub row's sum — segments in order within
         // a group, groups in order — then depends on the row alone, not on where the packer put it (a row block of the partitioned
@@ -582,7 +508,7 @@ static int graph_create_impl(const int32_t *h_rowptr, const int32_t *h_col, cons
         fill_wg(false);
             {
                 const int n_wgs_now = (int)((task.size() + W - 1) / W);
-                const bool pinned = getenv("SPEX_OPEN_TASKS") != nullptr;
+                const bool pinned = false;
                 if (g->row_ids && !pinned && !final_pass && n_wgs_now > kResidentWgs) {
                     if (attempt == 0 && n_wgs_now <= kResidentWgs + kResidentWgs / 16) {       // a denser first fit may do
                         open_tasks_now = 32;

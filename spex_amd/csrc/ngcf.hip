@@ -38,7 +38,6 @@ __device__ __forceinline__ float bcast(float v, int src)
 // in registers.  8 kflop per row is tiny — the kernel stays bandwidth/latency-bound — but the MFMA form needs 128
 // matrix instructions per tile where the vector form needed 2 x 64 x (v_readlane + v_fmac) per ROW.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kLdsStride = 66;
 
 // Message dropout (NGCF_SPEX/code/main_rec.py:81, nn.Dropout(p) on sum + bi): counter-based, so the forward kernel and
 // the backward kernel (which recomputes the layer) see the same mask without storing it.  Element e = row * 64 + col of
@@ -72,119 +71,6 @@ __device__ __forceinline__ bool msg_keep(const MsgDrop &dr, int row, int col)
     return (float)(w >> 8) * 5.9604644775390625e-8f >= dr.p;
 }
 
-__global__ __launch_bounds__(kWave *kWavesPerBlock) void ngcf_layer_kernel(
-    const float *__restrict__ ego, const float *__restrict__ side, const float *__restrict__ W_gc,
-    const float *__restrict__ b_gc, const float *__restrict__ W_bi, const float *__restrict__ b_bi,
-    float *__restrict__ out, int ld_out, int write_ego, float *__restrict__ e1_out, int n, float slope, const MsgDrop drop)
-{
-    __shared__ float s_w[2][64 * kLdsStride];                       // W_gc, W_bi as [out j][in k]
-    __shared__ float s_t[kWavesPerBlock][2][16 * kLdsStride];       // per wave: side tile, (ego*side) tile
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-    const int n_tiles = (n + 15) >> 4;
-    int tile = blockIdx.x * kWavesPerBlock + wave;
-    // The wave's first tile is requested BEFORE the weights are staged (32 independent row loads in flight while the
-    // workgroup fills s_w and waits at the barrier): the kernel is a chain of dependent memory round trips — with the
-    // tile fetched after the barrier, in four batches of four rows, it took 15.4 us on Epinion2.
-    float e_reg[16], s_reg[16];
-    auto fetch_tile = [&](int tl) {
-        const int r0 = tl << 4;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int r = r0 + i;
-            e_reg[i] = s_reg[i] = 0.0f;
-            if (tl < n_tiles && r < n) {
-                e_reg[i] = ego[(size_t)r * 64 + lane];
-                s_reg[i] = side[(size_t)r * 64 + lane];
-            }
-        }
-    };
-    fetch_tile(tile);
-    for (int i = threadIdx.x; i < 64 * 16; i += blockDim.x) {       // 1024 float4 per matrix, coalesced
-        const int r = i >> 4, c4 = (i & 15) * 4;
-        const float4 a = *reinterpret_cast<const float4 *>(W_gc + r * 64 + c4);
-        const float4 b = *reinterpret_cast<const float4 *>(W_bi + r * 64 + c4);
-        float *pa = &s_w[0][r * kLdsStride + c4], *pb = &s_w[1][r * kLdsStride + c4];
-        pa[0] = a.x; pa[1] = a.y; pa[2] = a.z; pa[3] = a.w;
-        pb[0] = b.x; pb[1] = b.y; pb[2] = b.z; pb[3] = b.w;
-    }
-    __syncthreads();
-    const int i16 = lane & 15, h = lane >> 4;                       // MFMA operand coordinates of this lane
-    float bias_g[4], bias_b[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        bias_g[b] = b_gc[16 * b + i16];
-        bias_b[b] = b_bi[16 * b + i16];
-    }
-    float *t_side = s_t[wave][0], *t_prod = s_t[wave][1];
-    for (; tile < n_tiles; tile += gridDim.x * kWavesPerBlock) {
-        const int r0 = tile << 4;
-        // stage the tile (lane == column: coalesced 256-byte rows) and pass `ego` through to the output's first half
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int r = r0 + i;
-            if (write_ego && r < n) out[(size_t)r * ld_out + lane] = e_reg[i];
-            t_side[i * kLdsStride + lane] = s_reg[i];
-            t_prod[i * kLdsStride + lane] = e_reg[i] * s_reg[i];
-        }
-        fetch_tile(tile + gridDim.x * kWavesPerBlock);              // the next tile of this wave, if any, overlaps the MFMAs
-        // (each wave only reads back its own tile: no workgroup barrier, the LDS ops of one wave are ordered)
-        f32x4 acc_g[4], acc_b[4];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            acc_g[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            acc_b[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll 4
-        for (int s = 0; s < 16; ++s) {
-            const int k = 4 * s + h;
-            const float a_g = t_side[i16 * kLdsStride + k];
-            const float a_b = t_prod[i16 * kLdsStride + k];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const float w_g = s_w[0][(16 * b + i16) * kLdsStride + k];
-                const float w_b = s_w[1][(16 * b + i16) * kLdsStride + k];
-                acc_g[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_g, w_g, acc_g[b], 0, 0, 0);
-                acc_b[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_b, w_b, acc_b[b], 0, 0, 0);
-            }
-        }
-        // C layout: col = 16 b + i16, row = 4 h + reg
-        float e1[4][4], sq[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float x = acc_g[b][q] + bias_g[b], y = acc_b[b][q] + bias_b[b];
-                x = x >= 0.0f ? x : x * slope;
-                y = y >= 0.0f ? y : y * slope;
-                float v = x + y;
-                if (drop.p > 0.0f) v = msg_keep(drop, r0 + 4 * h + q, 16 * b + i16) ? v * drop.scale : 0.0f;
-                e1[b][q] = v;
-            }
-        }
-        // row sums of squares in column order (0..63), as the scalar kernel's butterfly produced them up to rounding:
-        // first the lane's own 4 column blocks, then the 16 lanes of the row group
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float v = 0.0f;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) v = fmaf(e1[b][q], e1[b][q], v);
-            v = row16_sum_f32(v);
-            sq[q] = v;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int r = r0 + 4 * h + q;
-            if (r < n) {
-                const float den = fmaxf(sqrtf(sq[q]), 1e-12f);
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    out[(size_t)r * ld_out + 64 + 16 * b + i16] = e1[b][q] / den;
-                    if (e1_out) e1_out[(size_t)r * 64 + 16 * b + i16] = e1[b][q];
-                }
-            }
-        }
-    }
-}
 
 // The same layer with FOUR waves per 16-row tile (16-wave workgroups = 4 tiles; the weights are staged once per workgroup):
 // wave b of a tile owns output columns 16b .. 16b+15 — 2 x 16 MFMAs instead of 2 x 64, a quarter of the Philox draws — and
@@ -307,175 +193,6 @@ __global__ __launch_bounds__(kWave * 4 * kFwdTiles) void ngcf_layer_fwd4_kernel(
             const float den = fmaxf(sqrtf(sq), 1e-12f);
             out[(size_t)r * ld_out + 64 + 16 * b + i16] = e1[q] / den;
             if (e1_out) e1_out[(size_t)r * 64 + 16 * b + i16] = e1[q];
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// SpMM + layer in ONE launch: side = A ego never round-trips before the layer reads it.
-//
-// The two kernels want different decompositions — the SpMM's unit is a 64-entry task of bin-packed rows or a slice of a long
-// row, the layer's a 16-row tile that must be complete in one workgroup.  They meet in a task table laid out in TILE MODE
-// (spex_graph_create_ex, SPEX_GRAPH_TILE_ROWS): the ordinary table, except that a 16-task workgroup completes at most 64 rows
-// and every task carries the workgroup-local slot of its first completed row.  A workgroup then
-//   1. runs its 16 tasks exactly like spmm_chunk_kernel<0, false, true> (same chunks, same fmaf chains, long rows combined
-//      through LDS in segment order), but a finished row goes to slot k of an LDS tile [64][68] instead of to memory —
-//      LDS stores are not counted in vmcnt, so nothing in the gather loop ever waits for a store;
-//   2. barrier; its 16 waves = 4 tiles x 4 column blocks run the layer (ngcf_layer_fwd4_kernel's arithmetic): A operand `side`
-//      from the LDS tile, `ego` straight from memory in the operand layout (16 consecutive floats per lane), weights staged at
-//      kernel start, dropout, row L2-norm through LDS, and stores of [ego | normalised layer output] and of `side` (the rows
-//      backward recomputes from it).
-// Rows are identified by slot -> row id (written to LDS with the row); slots past the workgroup's row count are idle.
-__device__ __forceinline__ float lane_bcast_f(float v, int src)
-{
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
-}
-
-__global__ __launch_bounds__(kWave *kWgWaves) __attribute__((amdgpu_waves_per_eu(8, 8))) void ngcf_spmm_layer_kernel(
-    const float *__restrict__ ego, const uint32_t *__restrict__ chunk_off, const float *__restrict__ chunk_val,
-    const uint32_t *__restrict__ chunk_mask, const int32_t *__restrict__ chunk_row, const int4 *__restrict__ task,
-    const int32_t *__restrict__ wg_rows, const float *__restrict__ W_gc, const float *__restrict__ b_gc,
-    const float *__restrict__ W_bi, const float *__restrict__ b_bi, float *__restrict__ out, int ld_out, float *__restrict__ side_out,
-    float slope, const MsgDrop drop)
-{
-    __shared__ float s_w[2][64 * kFwdStride];              // W_gc, W_bi as [out j][in k]
-    __shared__ float s_side[kTileRows * kFwdStride];       // the workgroup's finished rows of A ego
-    __shared__ float s_ego[kTileRows * kFwdStride];        // and their `ego` rows (staged after step 1)
-    __shared__ float s_part[kWgWaves][kWave];              // segment sums of rows with 65..1024 entries
-    __shared__ float s_sq[4][4][16];
-    __shared__ int s_rowid[kTileRows];
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int wg = blockIdx.x;
-    const int4 t = task[wg * kWgWaves + wave];
-    const int n_wg_rows = wg_rows[wg];
-    // ---- weights (used after the barrier) and this wave's metadata are requested together
-    for (int i = threadIdx.x; i < 64 * 16; i += blockDim.x) {
-        const int r = i >> 4, c4 = (i & 15) * 4;
-        *reinterpret_cast<float4 *>(&s_w[0][r * kFwdStride + c4]) = *reinterpret_cast<const float4 *>(W_gc + r * 64 + c4);
-        *reinterpret_cast<float4 *>(&s_w[1][r * kFwdStride + c4]) = *reinterpret_cast<const float4 *>(W_bi + r * 64 + c4);
-    }
-    // ---- 1. the workgroup's tasks (spmm_chunk_kernel<0, false, true> with the emit going to LDS)
-    {
-        const int kind = t.w & 3;
-        const float *__restrict__ Xl = ego + lane;
-        int slot = (t.w >> 16) & 0xFF;
-        float acc = 0.0f;
-        for (int sc = 0; sc < t.y; sc += 4) {
-            const int nc = (t.y - sc < 4) ? t.y - sc : 4;
-            uint32_t my_off = 0u, my_mask = 0u;
-            int my_row = 0;
-            float my_val = 0.0f;
-            if (lane < nc * kChunk) {
-                const size_t e = (size_t)(t.x + sc) * kChunk + lane;
-                my_off = __builtin_nontemporal_load(chunk_off + e);
-                my_val = __builtin_nontemporal_load(chunk_val + e);
-                my_row = __builtin_nontemporal_load(chunk_row + e);
-            }
-            if (lane < nc) my_mask = __builtin_nontemporal_load(chunk_mask + t.x + sc + lane);
-            for (int c = 0; c < nc; ++c) {
-                const uint32_t mask = (uint32_t)__builtin_amdgcn_readlane((int)my_mask, c);
-                float x[kChunk];
-#pragma unroll
-                for (int u = 0; u < kChunk; ++u)
-                    x[u] = Xl[(size_t)(uint32_t)__builtin_amdgcn_readlane((int)my_off, c * kChunk + u) * 64];
-#pragma unroll
-                for (int u = 0; u < kChunk; ++u) {
-                    acc = fmaf(lane_bcast_f(my_val, c * kChunk + u), x[u], acc);
-                    if (mask & (1u << u)) {  // only packs of whole rows carry mask bits
-                        s_side[slot * kFwdStride + lane] = acc;
-                        if (lane == 0) s_rowid[slot] = __builtin_amdgcn_readlane(my_row, c * kChunk + u);
-                        acc = 0.0f;
-                        ++slot;
-                    }
-                }
-            }
-        }
-        if (kind == 0 && t.y == 0 && t.z >= 0) {           // a row without stored entries: side = 0
-            s_side[slot * kFwdStride + lane] = 0.0f;
-            if (lane == 0) s_rowid[slot] = t.z;
-        }
-        const bool leader = kind == 1 && (t.w & 8);
-        const int pslot = (t.w >> 4) & 15, nseg = (t.w >> 8) & 31;
-        if (kind == 1 && !leader) s_part[pslot][lane] = acc;
-        __syncthreads();
-        if (leader) {
-            float y = acc;
-            for (int sgi = 1; sgi < nseg; ++sgi) y = y + s_part[pslot + sgi][lane];    // segment order: deterministic
-            s_side[slot * kFwdStride + lane] = y;
-            if (lane == 0) s_rowid[slot] = t.z;
-        }
-    }
-    __syncthreads();
-    // ---- 2. the layer on the workgroup's rows: tile tl (slots 16 tl ..), column block b.  First the tile's `ego` rows: wave
-    //         (tl, b) fetches rows 4b .. 4b+3 (lane == column), passes them through to the output, stores `side`, and stages
-    //         them in LDS for the product operand (holding them in registers in the operand layout cost 24 VGPRs too many:
-    //         the kernel must stay within 64 to keep two workgroups per CU for step 1)
-    const int tl = wave >> 2, b = wave & 3;
-    const int i16 = lane & 15, h = lane >> 4;
-    const bool live = 16 * tl < n_wg_rows;                  // (an idle tile still meets the barriers)
-    if (live) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int sl = 16 * tl + 4 * b + i;
-            float e = 0.0f;
-            if (sl < n_wg_rows) {
-                const int r = s_rowid[sl];
-                e = ego[(size_t)r * 64 + lane];
-                out[(size_t)r * ld_out + lane] = e;
-                side_out[(size_t)r * 64 + lane] = s_side[sl * kFwdStride + lane];
-            }
-            s_ego[sl * kFwdStride + lane] = e;
-        }
-    }
-    __syncthreads();
-    int row_q[4] = {-1, -1, -1, -1};
-    float e1[4] = {0.f, 0.f, 0.f, 0.f};
-    if (live) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) row_q[q] = (16 * tl + 4 * h + q) < n_wg_rows ? s_rowid[16 * tl + 4 * h + q] : -1;
-        const int a_slot = 16 * tl + i16;                   // A-operand row of this lane (rows past the count hold zeros / stale
-        const bool a_ok = a_slot < n_wg_rows;               // data: their products only reach accumulator rows nobody stores)
-        const float bias_g = b_gc[16 * b + i16], bias_b = b_bi[16 * b + i16];
-        f32x4 acc_g = (f32x4){0.f, 0.f, 0.f, 0.f}, acc_b = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float4 ag = *reinterpret_cast<const float4 *>(&s_side[a_slot * kFwdStride + 16 * h + 4 * j]);
-            const float4 eg = *reinterpret_cast<const float4 *>(&s_ego[a_slot * kFwdStride + 16 * h + 4 * j]);
-            if (!a_ok) ag = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 wg_ = *reinterpret_cast<const float4 *>(&s_w[0][(16 * b + i16) * kFwdStride + 16 * h + 4 * j]);
-            const float4 wb = *reinterpret_cast<const float4 *>(&s_w[1][(16 * b + i16) * kFwdStride + 16 * h + 4 * j]);
-            acc_g = __builtin_amdgcn_mfma_f32_16x16x4f32(ag.x, wg_.x, acc_g, 0, 0, 0);
-            acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(eg.x * ag.x, wb.x, acc_b, 0, 0, 0);
-            acc_g = __builtin_amdgcn_mfma_f32_16x16x4f32(ag.y, wg_.y, acc_g, 0, 0, 0);
-            acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(eg.y * ag.y, wb.y, acc_b, 0, 0, 0);
-            acc_g = __builtin_amdgcn_mfma_f32_16x16x4f32(ag.z, wg_.z, acc_g, 0, 0, 0);
-            acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(eg.z * ag.z, wb.z, acc_b, 0, 0, 0);
-            acc_g = __builtin_amdgcn_mfma_f32_16x16x4f32(ag.w, wg_.w, acc_g, 0, 0, 0);
-            acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(eg.w * ag.w, wb.w, acc_b, 0, 0, 0);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float x = acc_g[q] + bias_g, y = acc_b[q] + bias_b;
-            x = x >= 0.0f ? x : x * slope;
-            y = y >= 0.0f ? y : y * slope;
-            float v = x + y;
-            if (drop.p > 0.0f) v = (row_q[q] >= 0 && msg_keep(drop, row_q[q], 16 * b + i16)) ? v * drop.scale : 0.0f;
-            e1[q] = v;
-            const float sq = row16_sum_f32(v * v);
-            if (i16 == 0) s_sq[tl][b][4 * h + q] = sq;
-        }
-    }
-    __syncthreads();
-    if (live) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int rr = 4 * h + q, r = row_q[q];
-            if (r >= 0) {
-                const float sq = ((s_sq[tl][0][rr] + s_sq[tl][1][rr]) + s_sq[tl][2][rr]) + s_sq[tl][3][rr];
-                const float den = fmaxf(sqrtf(sq), 1e-12f);
-                out[(size_t)r * ld_out + 64 + 16 * b + i16] = e1[q] / den;
-            }
         }
     }
 }
@@ -1398,15 +1115,10 @@ extern "C" int spex_ngcf_layer_fwd_f32(const float *ego, const float *side, cons
     SPEX_CHECK_ARG((((uintptr_t)W_gc | (uintptr_t)W_bi) & 15) == 0, "spex_ngcf_layer_fwd_f32: weights must be 16-byte aligned");
     if (n == 0) return SPEX_OK;
     const int n_tiles = (n + 15) / 16;
-    static const bool one_wave_form = []() { const char *e = getenv("SPEX_NGCF_FWD_ONE_WAVE"); return e && e[0] == '1'; }();
-    if (one_wave_form)      // the earlier form (one wave per 16-row tile), kept for A/B timing
-        hipLaunchKernelGGL(ngcf_layer_kernel, dim3(grid_for_rows(n_tiles)), dim3(kWave * kWavesPerBlock), 0, (hipStream_t)stream,
-                           ego, side, W_gc, b_gc, W_bi, b_bi, out, ld_out, write_ego, e1_out, n, slope,
-                           make_drop(p_drop, seed, step, layer, pad_row));
-    else                    // four waves per tile, four tiles per workgroup
-        hipLaunchKernelGGL(ngcf_layer_fwd4_kernel<false>, dim3((unsigned)((n_tiles + kFwdTiles - 1) / kFwdTiles)), dim3(kWave * 4 * kFwdTiles), 0,
-                           (hipStream_t)stream, ego, side, W_gc, b_gc, W_bi, b_bi, out, ld_out, write_ego, e1_out, n, slope,
-                           make_drop(p_drop, seed, step, layer, pad_row), RowList{});
+    // four waves per tile, four tiles per workgroup
+    hipLaunchKernelGGL(ngcf_layer_fwd4_kernel<false>, dim3((unsigned)((n_tiles + kFwdTiles - 1) / kFwdTiles)), dim3(kWave * 4 * kFwdTiles), 0,
+                       (hipStream_t)stream, ego, side, W_gc, b_gc, W_bi, b_bi, out, ld_out, write_ego, e1_out, n, slope,
+                       make_drop(p_drop, seed, step, layer, pad_row), RowList{});
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }
@@ -1432,30 +1144,6 @@ extern "C" int spex_ngcf_layer_fwd_rows_f32(const float *ego, const float *side,
     hipLaunchKernelGGL(ngcf_layer_fwd4_kernel<true>, dim3((unsigned)((n_tiles + kFwdTiles - 1) / kFwdTiles)), dim3(kWave * 4 * kFwdTiles), 0,
                        (hipStream_t)stream, ego, side, W_gc, b_gc, W_bi, b_bi, out, ld_out, write_ego, nullptr, n, slope,
                        make_drop(p_drop, seed, step, layer, pad_row), RowList{idx_a, idx_b, n_a, n_b, off_a, off_b});
-    SPEX_HIP(hipGetLastError());
-    return SPEX_OK;
-}
-
-extern "C" int spex_ngcf_spmm_layer_fwd_f32(const spex_graph_t *g, const float *ego, const float *W_gc, const float *b_gc, const float *W_bi,
-                                            const float *b_bi, float *out, int32_t ld_out, float *side_out, int32_t d, float slope,
-                                            float p_drop, uint64_t seed, uint32_t step, uint32_t layer, int32_t pad_row, void *stream)
-{
-    SPEX_CHECK_ARG(g && ego && W_gc && b_gc && W_bi && b_bi && out && side_out, "spex_ngcf_spmm_layer_fwd_f32: NULL pointer");
-    SPEX_CHECK_ARG(g->tile_rows == kTileRows && g->wg_rows && g->row_ids,
-                   "spex_ngcf_spmm_layer_fwd_f32: the graph handle was not created with SPEX_GRAPH_TILE_ROWS");
-    SPEX_CHECK_ARG(g->n_rows == g->n_cols && ld_out >= 2 * d, "spex_ngcf_spmm_layer_fwd_f32: square graph, ld_out >= 2 d");
-    SPEX_CHECK_ARG(g->mask_mode == 0, "spex_ngcf_spmm_layer_fwd_f32: edge dropout does not apply to NGCF");
-    SPEX_CHECK_ARG(p_drop >= 0.0f && p_drop < 1.0f, "spex_ngcf_spmm_layer_fwd_f32: p_drop=%f", (double)p_drop);
-    SPEX_CHECK_ARG(ego != out && ego != side_out, "spex_ngcf_spmm_layer_fwd_f32: outputs must not alias ego");
-    if (d != 64) {
-        spex::set_error("spex_ngcf_spmm_layer_fwd_f32: only d == 64 is implemented (got %d)", d);
-        return SPEX_ERR_UNSUPPORTED;
-    }
-    SPEX_CHECK_ARG((((uintptr_t)W_gc | (uintptr_t)W_bi | (uintptr_t)ego) & 15) == 0, "spex_ngcf_spmm_layer_fwd_f32: 16-byte alignment");
-    if (g->n_rows == 0 || g->n_wgs == 0) return SPEX_OK;
-    hipLaunchKernelGGL(ngcf_spmm_layer_kernel, dim3((unsigned)g->n_wgs), dim3(kWave * kWgWaves), 0, (hipStream_t)stream, ego, g->chunk_off,
-                       g->chunk_val, g->chunk_mask, g->chunk_row, g->task, g->wg_rows, W_gc, b_gc, W_bi, b_bi, out, ld_out, side_out, slope,
-                       make_drop(p_drop, seed, step, layer, pad_row));
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }
@@ -1490,8 +1178,7 @@ extern "C" int spex_ngcf_layer_bwd_f32(const float *ego, const float *side, cons
     const int n_tiles = (n + 15) / 16;
     // persistent workgroups (two fit a CU): each walks its tiles with a stride and leaves ONE block of weight-gradient partials in the
     // stream's scratch; the second launch adds the blocks to the caller's gradients in block order (deterministic, no atomics)
-    static const int wg_cap = []() { const char *e = getenv("SPEX_NGCF_BWD_WGS"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
-    const int blocks = n_tiles < wg_cap ? n_tiles : wg_cap;
+    const int blocks = n_tiles < 512 ? n_tiles : 512;      // (measured on Epinion2's 975 tiles: 256 workgroups 27.9 us, 512: 24.3, 975: slower)
     float *parts = nullptr;
     if (int rc = stream_scratch((hipStream_t)stream, (size_t)blocks * kPartFloats * sizeof(float), &parts)) return rc;
     hipLaunchKernelGGL(ngcf_layer_bwd_dense4_kernel, dim3((unsigned)blocks), dim3(kWave * kBwdWaves), 0, (hipStream_t)stream, ego, side, W_gc,

@@ -196,56 +196,6 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_rows_kernel(const 
 }
 
 
-// Narrow embeddings (d <= 32): the wave-per-row kernel above leaves 64 - d lanes idle.  Here a wave owns 64 / W rows, W = the
-// power of two >= d lanes per row (d = 32: two rows per wave, d = 8: eight): lane = (row of the wave, column), every row keeps its
-// own fmaf chain in ascending entry order (bit-identical to the oracle, like the kernel above), eight (index, value) pairs and then
-// eight gathers in flight per lane; the W lanes of a row read the same index (one request).  Rows beyond kLongRow entries stay
-// with the segment tasks of the kernel above and the fix-up launch.  No edge dropout in this form.
-template <int W>
-__global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_rows_narrow_kernel(const SpmmParams p)
-{
-    constexpr int kRowsPerWave = kWave / W;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = xcd_contiguous_block(blockIdx.x, gridDim.x) * kWavesPerBlock + (threadIdx.x >> 6);
-    const int r = wave * kRowsPerWave + lane / W, c = lane % W;
-    const int d = p.d;
-    if (r >= p.n_rows || c >= d) return;
-    const int beg = p.rowptr[r], end = p.rowptr[r + 1];
-    if (end - beg > kLongRow) return;
-    const float *__restrict__ Xc = p.X + c;
-    float acc = 0.0f;
-    int e = beg;
-    for (; e + 8 <= end; e += 8) {
-        int cc[8];
-        float vv[8], x[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            cc[u] = p.col[e + u];
-            vv[u] = p.val[e + u];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) x[u] = Xc[(size_t)cc[u] * d];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc = fmaf(vv[u], x[u], acc);
-    }
-    if (e < end) {
-        int cc[8];
-        float vv[8], x[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const bool ok = e + u < end;
-            cc[u] = ok ? p.col[e + u] : 0;
-            vv[u] = ok ? p.val[e + u] : 0.0f;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) x[u] = e + u < end ? Xc[(size_t)cc[u] * d] : 0.0f;
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (e + u < end) acc = fmaf(vv[u], x[u], acc);
-    }
-    finish_row(p, r, c, acc);
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // d == 64 kernel: 16-wave workgroups, one wave per TASK (a run of <= 4 sixteen-entry chunks, see spex_common.h),
 // lane == embedding column.
@@ -977,25 +927,6 @@ int launch_spmm(const spex_graph *g, const float *X, float *Y, const float *add_
         else launch_chunk<0>(d, masked, g->row_ids, grid, block, stream, X, g, Y, nullptr, 1.0f, 1.0f, nullptr, da, xcd_contig, hub);
     } else if (masked) {
         hipLaunchKernelGGL((spmm_rows_kernel<true>), grid, block, 0, stream, p);
-    } else if (d <= 32) {
-        // narrow rows: several rows per wave; the long rows' segments keep the wave-per-segment kernel (p.n_rows = 0: segments only)
-        if (g->n_seg > 0) {
-            SpmmParams ps = p;
-            ps.n_rows = 0;
-            const int64_t sb = (((int64_t)g->n_seg + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8 * 8;
-            hipLaunchKernelGGL((spmm_rows_kernel<false>), dim3((unsigned)sb), block, 0, stream, ps);
-        }
-        const int w = d > 16 ? 32 : (d > 8 ? 16 : (d > 4 ? 8 : (d > 2 ? 4 : (d > 1 ? 2 : 1))));
-        const int64_t waves = ((int64_t)g->n_rows + kWave / w - 1) / (kWave / w);
-        const dim3 ngrid((unsigned)(((waves + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8 * 8));
-        switch (w) {
-            case 32: hipLaunchKernelGGL((spmm_rows_narrow_kernel<32>), ngrid, block, 0, stream, p); break;
-            case 16: hipLaunchKernelGGL((spmm_rows_narrow_kernel<16>), ngrid, block, 0, stream, p); break;
-            case 8: hipLaunchKernelGGL((spmm_rows_narrow_kernel<8>), ngrid, block, 0, stream, p); break;
-            case 4: hipLaunchKernelGGL((spmm_rows_narrow_kernel<4>), ngrid, block, 0, stream, p); break;
-            case 2: hipLaunchKernelGGL((spmm_rows_narrow_kernel<2>), ngrid, block, 0, stream, p); break;
-            default: hipLaunchKernelGGL((spmm_rows_narrow_kernel<1>), ngrid, block, 0, stream, p); break;
-        }
     } else {
         hipLaunchKernelGGL((spmm_rows_kernel<false>), grid, block, 0, stream, p);
     }

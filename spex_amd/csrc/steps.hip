@@ -182,34 +182,16 @@ extern "C" int spex_ngcf_step_bce_f32(spex_ngcf_step_t *s, const int64_t *users,
     // ---- forward, at the batch's rows ONLY: the descriptor is a one-layer model, whose loss reads the concatenated table nowhere
     //      else (main_rec.py:96-104) — side = A ego for the 2B rows (spex_spmm_rowlist_f32: the main kernel's sums, bit for bit, for
     //      rows of <= 1 024 entries) and the layer on 16-slot tiles of those rows, which writes [ego | normalised layer output] into
-    //      the dense tables at the rows the scoring reads.  (11.4 + 10.6 us of whole-table launches on Epinion2 became 6 + 4;
-    //      SPEX_NGCF_DENSE_FORWARD=1 keeps the whole-table forward for A/B timing.)
-    static const bool dense_forward = []() { const char *e = getenv("SPEX_NGCF_DENSE_FORWARD"); return e && e[0] == '1'; }();
-    static const bool self_scoring = []() { const char *e = getenv("SPEX_NGCF_TABLE_SCORING"); return !(e && e[0] == '1'); }();
-    if (dense_forward) {
-        SPEX_TRY(spex_spmm_f32(g, s->E0, s->side, nullptr, 1.0f, nullptr, nullptr, 1.0f, d, stream));
-        SPEX_TRY(spex_ngcf_layer_fwd_f32(s->E0, s->side, W_gc, b_gc, W_bi, b_bi, s->all_emb, 2 * d, 1, nullptr, n, d, s->slope, s->p_drop,
-                                         s->seed, step, 0, s->pad_row, stream));
-    } else {
-        SPEX_TRY(spex_spmm_rowlist_f32(g, s->E0, users, B, 0, items, B, n_u, s->side, nullptr, nullptr, 1.0f, d, stream));
-        if (!self_scoring)
-            SPEX_TRY(spex_ngcf_layer_fwd_rows_f32(s->E0, s->side, W_gc, b_gc, W_bi, b_bi, s->all_emb, 2 * d, 1, n, d, s->slope, s->p_drop,
-                                                  s->seed, step, 0, s->pad_row, users, B, 0, items, B, n_u, stream));
-    }
+    //      the dense tables at the rows the scoring reads.  (11.4 + 10.6 us of whole-table launches on Epinion2 became 6 + 4.)
+    SPEX_TRY(spex_spmm_rowlist_f32(g, s->E0, users, B, 0, items, B, n_u, s->side, nullptr, nullptr, 1.0f, d, stream));
     // ---- scoring + backward on the batch's 2B slots in one launch (per-sample losses go to the head of g_slots: the table's Adam
     //      pass below adds them to loss_sum in a fixed order), then the push-form A^T product into the (all-zero) table gradient.
     //      Default: the launch also runs the layer's FORWARD at those rows — its tiles hold both rows of 8 samples and score from
-    //      the layer output they recompute anyway, so the concatenated table is never formed (spex_ngcf_fwd_score_bwd_rows_f32;
-    //      SPEX_NGCF_TABLE_SCORING=1 keeps the forward launch + the table for A/B timing)
+    //      the layer output they recompute anyway, so the concatenated table is never formed (spex_ngcf_fwd_score_bwd_rows_f32)
     float *loss_rows = s->g_slots;
-    if (self_scoring && !dense_forward)
-        SPEX_TRY(spex_ngcf_fwd_score_bwd_rows_f32(s->E0, s->side, W_gc, b_gc, W_bi, b_bi, labels, 1.0f / (float)B, n, d, s->slope, s->p_drop,
-                                                  s->seed, step, 0, s->pad_row, users, items, B, n_u, loss_rows, s->g_side_c, s->g_ego_c,
-                                                  s->gW_parts, per, stream));
-    else
-        SPEX_TRY(spex_ngcf_score_bwd_rows_f32(s->E0, s->side, W_gc, b_gc, W_bi, b_bi, s->all_emb, labels, 1.0f / (float)B, n, d, s->slope,
-                                              s->p_drop, s->seed, step, 0, s->pad_row, users, items, B, n_u, loss_rows, s->g_side_c,
-                                              s->g_ego_c, s->gW_parts, per, stream));
+    SPEX_TRY(spex_ngcf_fwd_score_bwd_rows_f32(s->E0, s->side, W_gc, b_gc, W_bi, b_bi, labels, 1.0f / (float)B, n, d, s->slope, s->p_drop,
+                                              s->seed, step, 0, s->pad_row, users, items, B, n_u, loss_rows, s->g_side_c, s->g_ego_c,
+                                              s->gW_parts, per, stream));
     // ---- Adam: the table (its pass clears the gradient again), the layer weights (their pass sums the partial blocks).  The
     //      weights' pass needs only the rows backward: with a second stream it runs beside the push-form product and the table's
     //      pass (a one-workgroup-class launch next to two that fill the chip) and is joined at the end of the step.
@@ -363,9 +345,7 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
             else SPEX_TRY(spex_spmm_f32(g, cur, nxt, nullptr, 1.0f, l == 0 ? E0 : s->light, s->light, 1.0f, d, stream));
             cur = nxt;
         }
-        static const bool fused_middle_env = []() { const char *e = getenv("SPEX_DUAL_FUSED_MIDDLE"); return !(e && e[0] == '0'); }();
-        const bool fused_middle = fused_middle_env || g->mask_mode != 0;      // (the three-launch middle's push takes no mask)
-        if (!det && L >= 2 && fused_middle) {
+        if (!det && L >= 2) {
             // (fast path: last layer at the batch's rows + layer mean + gate + scores + the gate's backward + the first backward
             //  product in push form — ONE launch, batch.hip: gated_batch_push_kernel; then the L-1 pull-form launches on A^T, the
             //  last one plain: the Adam pass adds its g_prop / (L+1) share, see the LightGCN step)
@@ -410,26 +390,11 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
             SPEX_TRY(spex_propagate_bwd_f32(gt, s->g_prop, s->g_E0, s->ws_bwd, L, d, stream));
             return SPEX_OK;
         }
-        // ---- rec branch backward (gradients of the UNWEIGHTED loss1; the precisions are applied in the Adam pass): the gate slot by
-        //      slot (dense d loss / d light and d loss / d E0 rows added with atomics), then the propagation as in the LightGCN step
+        // ---- L == 1: rec branch backward (gradients of the UNWEIGHTED loss1; the precisions are applied in the Adam pass): the gate slot
+        //      by slot (dense d loss / d light and d loss / d E0 rows added with atomics), then the one pull-form product
         SPEX_TRY(spex_expert_gate_rows_bwd_f32(E0, s->lo_batch, att1, att2, users, B, 0, items, B, n_u, n_u, N, d, s->grad_slots, d,
                                                s->g_prop_slots, s->g_prop, s->g_raw, g_att1, g_att2, stream));
-        if (L >= 2) {            // (SPEX_DUAL_FUSED_MIDDLE=0: the three-launch middle, kept for A/B timing)
-            float *G = s->ws_bwd;
-            SPEX_TRY(spex_spmm_push_batch_f32(g, users, B, 0, items, B, n_u, s->g_prop_slots, d, s->g_prop_slots, d, 1.0f / (float)(L + 1), G, d,
-                                              stream));
-            const float *c2 = G;
-            for (int32_t l = L - 2; l >= 0; --l) {
-                float *nxt = l == 0 ? s->g_E0 : s->ws_bwd + (size_t)(1 + ((L - 2 - l) & 1)) * sz;
-                // (L == 3: both products plain, the Adam pass adds the push target P instead of g_prop / 4 — see the LightGCN step)
-                if (l == 0 || L == 3) SPEX_TRY(spex_spmm_f32(gt, c2, nxt, nullptr, 1.0f, nullptr, nullptr, 1.0f, d, stream));
-                else SPEX_TRY(spex_spmm_f32(gt, c2, nxt, s->g_prop, (float)(L + 1), nullptr, nullptr, 1.0f, d, stream));
-                c2 = nxt;
-            }
-            plain_last = true;
-        } else {
-            SPEX_TRY(spex_propagate_bwd_f32(gt, s->g_prop, s->g_E0, s->ws_bwd, L, d, stream));
-        }
+        SPEX_TRY(spex_propagate_bwd_f32(gt, s->g_prop, s->g_E0, s->ws_bwd, L, d, stream));
         return SPEX_OK;
     };
     int rc = rec_branch();

@@ -14,24 +14,15 @@
 //   (g0, g1) = softmax([p_a | pm] @ att_t);  a2 = g0 p_a + g1 pm;  scores = a2 . E[:-1]^T;  loss = mean_b CE(scores_b, target_b)
 // Positions >= l only ever reach masked terms, so they are not evaluated.  In torch this is ~60 small launches forward
 // and ~120 backward per step for <= 15 paths (1.8 ms of a 2.7 ms dual-task step, almost all of it launch latency).  Here, in
-// training, five launches (round 2: two — one 16-wave workgroup per path did everything, so the logits of a path moved the whole
-// user table, 2 x 815 KB, through ONE CU, and 15 workgroups = 6 % of the chip carried the 70 us kernel):
-//   trust_fwd_kernel      one 4-wave workgroup per path: the forward chain (vectors in LDS, matrices read straight from L2 in
-//                         batches of independent loads; `M @ w` split over the four waves) -> a2; the chain's state (rows,
-//                         heads' outputs, softmax weights, sigmoids: the LDS image) is parked in the path's workspace
-//   trust_logits_kernel   the logits of ALL paths against a tile of 32 users per workgroup (the table is read ONCE for all paths,
-//                         by ~100 workgroups): raw scores + per-tile (max, sum-exp) partials
-//   trust_ce_kernel       same tiles: log-sum-exp from the partials (fixed tile order), the path losses, d scores, the table
-//                         gradient of the tile's own user rows (this launch owns them) and per-tile partials of d a2
-//   trust_bwd_kernel      one workgroup per path: d a2 = sum of its partials in tile order; the state back into LDS; the chain
-//                         backwards; operands of every weight gradient and the path's own row gradients -> workspace
+// training, two launches:
+//   trust_path_split_kernel / trust_path_train_kernel   the chains and the sweep of the user table in one launch: one 16-wave workgroup
+//                         per path (train), or S workgroups per path sharing the sweep (split), whose LAST arriver folds the shares
+//                         in a fixed order and runs the backward chain; operands of every weight gradient and the path's own row
+//                         gradients -> workspace
 //   trust_reduce_kernel   the path rows that name a user added to the table in (path, position) order (one wave per user row,
-//                         no atomics), every weight gradient as a small [rows, 64]^T [rows, 64] product over the workspaces
-//                         (one thread per weight), the bias / vector gradients, the mean loss.  Nothing in the head is atomic:
-//                         it repeats bit for bit.
-// What the library RUNS since round 3 is the fused form — the chains and the sweep in one launch (trust_path_split_kernel: S workgroups
-// per path share the sweep; trust_path_train_kernel: one) + trust_reduce_kernel — which beats the tiled launches at every measured
-// size (host code below); SPEX_TRUST_TILED=1 forces the five launches above.
+//                         no atomics), the logits' share of the table gradient, every weight gradient as a small [rows, 64]^T
+//                         [rows, 64] product over the workspaces (one thread per weight), the bias / vector gradients, the mean
+//                         loss.  Nothing in the head is atomic: it repeats bit for bit.
 // Evaluation (flag 2) keeps the single forward launch (trust_path_kernel<false>).
 // All parameters live in ONE flat block (layout below) so that a step's gradients are one buffer and one Adam launch.
 #include <math.h>
@@ -1082,228 +1073,6 @@ __global__ __launch_bounds__(kWave) void trust_path_kernel(const TrustArgs p, co
     forward_tail(p, ll, s, b, l, lane, acc, a2_out);
 }
 
-constexpr int kFwdWaves = 4;          // forward / backward chain kernels: wave 0 runs the chain, four waves split `M @ w` and the copies
-// (six FwdState rows are parked behind the LDS image: av, pa, pm, g0, ht, arg)
-
-__host__ __device__ inline int state_prefix(const LdsLayout &ll, int L) { return ll.dM + L * kD; }   // e, M, o, h, vec, sigmoids
-
-// Training, launch 1: forward chain of one path -> a2; the chain's state goes to the path's workspace.
-__global__ __launch_bounds__(kWave *kFwdWaves) void trust_fwd_kernel(const TrustArgs p, const TrainArgs tr, float *__restrict__ a2_out)
-{
-    extern __shared__ float4 s_raw[];
-    float *s = reinterpret_cast<float *>(s_raw);
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const LdsLayout ll = lds_layout(p.L, p.H, true);
-    const WsLayout wl = ws_layout(p.L, p.H);
-    const int l = path_len(p, b);
-    const FwdState st = forward_train<kFwdWaves>(p, ll, s, b, l, lane, wave, a2_out);
-    __syncthreads();
-    // park the state: the LDS image (coalesced, all waves) + the chain's registers (wave 0)
-    float *__restrict__ S = tr.ws + (size_t)b * wl.stride + wl.St;
-    const int n_img = state_prefix(ll, p.L);
-    for (int k = threadIdx.x; k < n_img; k += kWave * kFwdWaves) S[k] = s[k];
-    if (wave == 0) {
-        float *R = S + n_img;
-        R[0 * kD + lane] = st.av; R[1 * kD + lane] = st.pa; R[2 * kD + lane] = st.pm; R[3 * kD + lane] = st.g0;
-        R[4 * kD + lane] = st.ht; R[5 * kD + lane] = __int_as_float(st.arg);
-    }
-}
-
-// Training, launches 2 and 3: the logits, their cross-entropy and both products of d scores, tiled over the USER table — every
-// workgroup owns kTileUsers consecutive users and handles all paths, so the table is read once (not once per path) and by ~100
-// workgroups.  Paths are taken in chunks of kPathChunk (LDS: the chunk's a2 rows and its scores / d scores for the tile).
-constexpr int kTileUsers = 32;
-constexpr int kPathChunk = 64;
-constexpr int kTileThreads = 256;
-
-struct TileArgs {
-    const float *table;      // [n_users + 1, 64]
-    const float *a2;         // [B, 64]
-    float *ds;               // [B, n_users] raw scores
-    float *part_ms;          // [n_tiles][B][2] per-tile (max, sum exp(score - max))
-    float *part_da2;         // [n_tiles][B][64] per-tile partials of d a2
-    float *loss_b;           // [B]
-    const int64_t *targets;  // [B]
-    float *grad_table;
-    int n_users, B, n_tiles;
-    float k;                 // scale / B (times *scale_dev if given)
-    const float *scale_dev;
-};
-
-__global__ __launch_bounds__(kTileThreads) void trust_logits_kernel(const TileArgs a)
-{
-    __shared__ float s_a2[kPathChunk][kD];
-    __shared__ float s_sc[kPathChunk][kTileUsers];
-    const int t = threadIdx.x, sub = t & 15, grp = t >> 4;                 // 16 row groups of 16 lanes: users grp and grp + 16 of the tile
-    const int u0 = blockIdx.x * kTileUsers;
-    float4 r[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int u = u0 + grp + 16 * j;
-        r[j] = u < a.n_users ? reinterpret_cast<const float4 *>(a.table + (size_t)u * kD)[sub] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
-    for (int b0 = 0; b0 < a.B; b0 += kPathChunk) {
-        const int nb = a.B - b0 < kPathChunk ? a.B - b0 : kPathChunk;
-        __syncthreads();
-        for (int k = t; k < nb * kD; k += kTileThreads) (&s_a2[0][0])[k] = a.a2[(size_t)b0 * kD + k];
-        __syncthreads();
-        for (int bl = 0; bl < nb; ++bl) {
-            const float4 x = reinterpret_cast<const float4 *>(s_a2[bl])[sub];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const float sc = row16_sum_f32(fmaf(r[j].x, x.x, fmaf(r[j].y, x.y, fmaf(r[j].z, x.z, r[j].w * x.w))));
-                const int ul = grp + 16 * j, u = u0 + ul;
-                if (sub == 0) {
-                    s_sc[bl][ul] = u < a.n_users ? sc : -INFINITY;
-                    if (u < a.n_users) a.ds[(size_t)(b0 + bl) * a.n_users + u] = sc;
-                }
-            }
-        }
-        __syncthreads();
-        if (t < nb) {                                                      // the tile's (max, sum-exp) of path b0 + t, users in order
-            float mx = -INFINITY;
-            for (int ul = 0; ul < kTileUsers; ++ul) mx = fmaxf(mx, s_sc[t][ul]);
-            float se = 0.0f;
-            for (int ul = 0; ul < kTileUsers; ++ul) se += expf(s_sc[t][ul] - mx);   // (exp(-inf) = 0 past the table's end)
-            float *pm = a.part_ms + ((size_t)blockIdx.x * a.B + b0 + t) * 2;
-            pm[0] = mx;
-            pm[1] = se;
-        }
-    }
-}
-
-__global__ __launch_bounds__(kTileThreads) void trust_ce_kernel(const TileArgs a)
-{
-    __shared__ float s_a2[kPathChunk][kD];
-    __shared__ float s_ds[kPathChunk][kTileUsers];
-    __shared__ float s_E[kTileUsers][kD];
-    __shared__ float s_lse[kPathChunk];
-    const int t = threadIdx.x;
-    const int u0 = blockIdx.x * kTileUsers;
-    const float k = a.k * (a.scale_dev ? *a.scale_dev : 1.0f);
-    for (int q = t; q < kTileUsers * kD; q += kTileThreads) {
-        const int ul = q >> 6, c = q & 63, u = u0 + ul;
-        s_E[ul][c] = u < a.n_users ? a.table[(size_t)u * kD + c] : 0.0f;
-    }
-    float4 gt[2] = {make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f)};   // table gradient: (user, 4 columns) x 2 per thread
-    for (int b0 = 0; b0 < a.B; b0 += kPathChunk) {
-        const int nb = a.B - b0 < kPathChunk ? a.B - b0 : kPathChunk;
-        __syncthreads();
-        // log-sum-exp of the chunk's paths from the tiles' partials: a wave per path (paths wave, wave + 4, ...), lane j takes tiles
-        // j, j + 64, ... — every load of a path in flight at once (a thread per path walking ~100 tiles serially cost 35 us) —, then
-        // a fixed cross-lane tree: the same order in every workgroup and every run
-        {
-            const int lane = t & 63, wv = t >> 6;
-            for (int bl = wv; bl < nb; bl += kTileThreads / kWave) {
-                const int b = b0 + bl;
-                float mx = -INFINITY;
-                for (int tl = lane; tl < a.n_tiles; tl += kWave) mx = fmaxf(mx, a.part_ms[((size_t)tl * a.B + b) * 2]);
-                for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-                float se = 0.0f;
-                for (int tl = lane; tl < a.n_tiles; tl += kWave) {
-                    const float2 pm = *reinterpret_cast<const float2 *>(a.part_ms + ((size_t)tl * a.B + b) * 2);
-                    se += pm.y * expf(pm.x - mx);
-                }
-                se = wave_sum_f32(se);
-                const float lse = mx + logf(se);
-                if (lane == 0) {
-                    s_lse[bl] = lse;
-                    if (blockIdx.x == 0) {
-                        const int64_t tg = a.targets[b];
-                        a.loss_b[b] = (tg >= 0 && tg < a.n_users) ? lse - a.ds[(size_t)b * a.n_users + tg] : 0.0f;
-                    }
-                }
-            }
-        }
-        for (int q = t; q < nb * kD; q += kTileThreads) (&s_a2[0][0])[q] = a.a2[(size_t)b0 * kD + q];
-        __syncthreads();
-        for (int q = t; q < nb * kTileUsers; q += kTileThreads) {          // d score of (path, user) in this tile
-            const int bl = q / kTileUsers, ul = q - bl * kTileUsers, u = u0 + ul, b = b0 + bl;
-            float d = 0.0f;
-            const int64_t tg = a.targets[b];
-            if (u < a.n_users && tg >= 0 && tg < a.n_users)
-                d = (expf(a.ds[(size_t)b * a.n_users + u] - s_lse[bl]) - (u == tg ? 1.0f : 0.0f)) * k;
-            s_ds[bl][ul] = d;
-        }
-        __syncthreads();
-        // d a2 partial of (path, 4 columns): sum over the tile's users in order
-        for (int q = t; q < nb * 16; q += kTileThreads) {
-            const int bl = q >> 4, c4 = q & 15;
-            float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#pragma unroll 8
-            for (int ul = 0; ul < kTileUsers; ++ul) {
-                const float d = s_ds[bl][ul];
-                const float4 e = reinterpret_cast<const float4 *>(s_E[ul])[c4];
-                acc.x = fmaf(d, e.x, acc.x); acc.y = fmaf(d, e.y, acc.y); acc.z = fmaf(d, e.z, acc.z); acc.w = fmaf(d, e.w, acc.w);
-            }
-            reinterpret_cast<float4 *>(a.part_da2 + ((size_t)blockIdx.x * a.B + b0 + bl) * kD)[c4] = acc;
-        }
-        // table gradient of the tile's own rows: sum over the chunk's paths in order
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int q = t + j * kTileThreads, ul = q >> 4, c4 = q & 15;
-            for (int bl = 0; bl < nb; ++bl) {
-                const float d = s_ds[bl][ul];
-                const float4 x = reinterpret_cast<const float4 *>(s_a2[bl])[c4];
-                gt[j].x = fmaf(d, x.x, gt[j].x); gt[j].y = fmaf(d, x.y, gt[j].y); gt[j].z = fmaf(d, x.z, gt[j].z); gt[j].w = fmaf(d, x.w, gt[j].w);
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {                                          // this launch owns the rows: plain read-modify-write
-        const int q = t + j * kTileThreads, ul = q >> 4, c4 = q & 15, u = u0 + ul;
-        if (u < a.n_users) {
-            float4 *g = reinterpret_cast<float4 *>(a.grad_table + (size_t)u * kD) + c4;
-            float4 v = *g;
-            v.x += gt[j].x; v.y += gt[j].y; v.z += gt[j].z; v.w += gt[j].w;
-            *g = v;
-        }
-    }
-}
-
-// Training, launch 4: d a2 from the tiles' partials, the state back into LDS, the chain backwards (wave 0).
-__global__ __launch_bounds__(kWave *kFwdWaves) void trust_bwd_kernel(const TrustArgs p, const TrainArgs tr, const float *__restrict__ part_da2,
-                                                                   int n_tiles)
-{
-    extern __shared__ float4 s_raw[];
-    float *s = reinterpret_cast<float *>(s_raw);
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const LdsLayout ll = lds_layout(p.L, p.H, true);
-    const WsLayout wl = ws_layout(p.L, p.H);
-    const int l = path_len(p, b);
-    const float *__restrict__ S = tr.ws + (size_t)b * wl.stride + wl.St;
-    const int n_img = state_prefix(ll, p.L);
-    for (int k = threadIdx.x; k < n_img; k += kWave * kFwdWaves) s[k] = S[k];
-    // d a2[b] = sum over tiles, in tile order: each wave takes a contiguous quarter (eight loads in flight), wave 0 adds the four
-    float *sacc = s + ll.sacc;
-    {
-        const int per = (n_tiles + kFwdWaves - 1) / kFwdWaves, t0 = wave * per, t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
-        float acc = 0.0f;
-        int tl = t0;
-        for (; tl + 8 <= t1; tl += 8) {
-            float x[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = part_da2[((size_t)(tl + j) * p.B + b) * kD + lane];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc += x[j];
-        }
-        for (; tl < t1; ++tl) acc += part_da2[((size_t)tl * p.B + b) * kD + lane];
-        sacc[wave * kD + lane] = acc;
-    }
-    __syncthreads();
-    FwdState st{};
-    if (wave == 0) {
-        float g = sacc[lane];
-        for (int w = 1; w < kFwdWaves; ++w) g += sacc[w * kD + lane];
-        (s + ll.vec)[3 * kD + lane] = g;
-        const float *R = S + n_img;
-        st.av = R[0 * kD + lane]; st.pa = R[1 * kD + lane]; st.pm = R[2 * kD + lane]; st.g0 = R[3 * kD + lane];
-        st.ht = R[4 * kD + lane]; st.arg = __float_as_int(R[5 * kD + lane]);
-    }
-    __syncthreads();
-    backward_train<kFwdWaves>(p, tr, ll, s, b, l, lane, wave, st);
-}
-
 // ------------------------------------------------------------------------------------------------------------ reductions
 struct ReduceArgs {
     const float *dscore, *a2, *loss_b, *ws;
@@ -1471,6 +1240,7 @@ extern "C" int64_t spex_trust_param_count(int32_t d, int32_t n_heads)
     return (d == kD && n_heads >= 1 && n_heads <= kMaxH) ? layout(n_heads).total : -1;
 }
 
+constexpr int kTileUsers = 32;       // the workspace's shares area is sized in units of 32 users (spex_trust_workspace_floats: ABI)
 static int n_user_tiles(int64_t n_rows) { return (int)((n_rows - 1 + kTileUsers - 1) / kTileUsers); }
 
 // per-path blocks | per-tile partials of d a2 [n_tiles][B][64] | per-tile (max, sum-exp) [n_tiles][B][2]
@@ -1528,26 +1298,13 @@ int spex::trust_head_train(const float *table, int64_t n_rows, const float *para
     float *part_da2 = ws + (size_t)B * ws_layout(L, n_heads).stride;
     float *part_ms = part_da2 + (size_t)n_tiles * B * kD;
     hipStream_t st = (hipStream_t)stream;
-    // Which form.  The fused kernel sweeps the user table once PER PATH (n_users x 256 B per path — through one CU in its
-    // one-workgroup form, through S CUs in the split form); the tiled launches read it once for all paths on ~n_users / 32
-    // workgroups but pay three more launch boundaries, the chains' state round trip, and a per-tile loop over the paths.  Measured
-    // on the MI355X (tools/trust_forms_time.py, us per call: fused one workgroup / fused split / tiled): 3 185 users x 15 paths
-    // 51.5 / 48.5 / 59.2; 6 812 x 15: 62.0 / 53.7 / 63.8; 26 000 x 15: 129 / 74 / 93; 60 000 x 15: 262 / 124 / 262; 100 000 x 15:
-    // 415 / 182 / 687; 3 185 x 45: 69.8 / 66.6 / 98.5; 26 000 x 60: 167 / 123 / 274; 3 185 x 192: 156 / (S = 1) / 279.  Until the split
-    // form existed the tiled launches won from ~8 000 users on with few paths; now they win nowhere measured: the library always
-    // takes the fused kernel, and SPEX_TRUST_TILED=1 keeps the tiled form reachable (tests run every form; =0 is the default).
-    const char *force_env = getenv("SPEX_TRUST_TILED");          // (read per call: the tests run both forms in one process)
-    const int forced = force_env && force_env[0] ? atoi(force_env) : -1;
-    const bool tiled = forced > 0;
-    if (tiled) {
-        hipLaunchKernelGGL(trust_fwd_kernel, dim3((unsigned)B), dim3(kWave * kFwdWaves), lds, st, p, tr, a2);
-        const TileArgs ta{table, a2, dscore, part_ms, part_da2, loss_b, targets, grad_table, n_users, B, n_tiles, scale / (float)B, scale_dev};
-        hipLaunchKernelGGL(trust_logits_kernel, dim3((unsigned)n_tiles), dim3(kTileThreads), 0, st, ta);
-        hipLaunchKernelGGL(trust_ce_kernel, dim3((unsigned)n_tiles), dim3(kTileThreads), 0, st, ta);
-        hipLaunchKernelGGL(trust_bwd_kernel, dim3((unsigned)B), dim3(kWave * kFwdWaves), lds, st, p, tr, part_da2, n_tiles);
-    } else {
-        // the split form: S workgroups per path (the shares live in the tiled form's partial areas of the workspace: [S][B][64]
-        // and [S][B][2] fit in [n_tiles][B][...] with one more tile's (max, sum-exp) cells holding the B tickets)
+    // The fused kernel sweeps the user table once PER PATH (n_users x 256 B per path — through one CU in its one-workgroup form,
+    // through S CUs in the split form).  (Rounds 2-3 also carried a five-launch form with the logits tiled over the user table — read
+    // once for all paths on ~n_users / 32 workgroups; since the split form exists it won at no measured size — 3 185 users x 15 paths
+    // 48.5 vs 59.2 us, 26 000 x 15: 74 vs 93, 100 000 x 15: 182 vs 687 — and was removed in round 4.)
+    {
+        // the split form: S workgroups per path (the shares live behind the per-path blocks of the workspace: [S][B][64] and [S][B][2]
+        // fit in the [n_tiles][B][...] area spex_trust_workspace_floats sizes, one more tile's cells holding the B tickets)
         // How many: as many as there are sweep batches, up to kMaxSplit, while S x paths fits one dispatch round of the 256 CUs
         // (every workgroup repeats the forward chain — free on an idle CU, a second round when there is none — and the fold costs
         // ~5 us of publish / ticket / fetch round trips through memory whatever S is).  Measured (tools/trust_forms_time.py, us per
@@ -1576,7 +1333,7 @@ int spex::trust_head_train(const float *table, int64_t n_rows, const float *para
     }
     SPEX_HIP(hipGetLastError());
     ReduceArgs r{dscore, a2, loss_b, ws, seq, seq_l, grad_table, grad_params, loss_out, n_users, B, L, n_heads, hybrid, loss_accumulate,
-                 tiled ? 0 : 1, 0, 0};
+                 1, 0, 0};
     r.blocks_users = (n_users + 3) / 4 < 1024 ? (n_users + 3) / 4 : 1024;
     r.blocks_mat = 64 + 16 * n_heads;
     hipLaunchKernelGGL(trust_reduce_kernel, dim3((unsigned)(r.blocks_users + r.blocks_mat + 1)), dim3(256), 0, (hipStream_t)stream, r);

@@ -141,9 +141,7 @@ class SpexGraph:
     """A CSR matrix (or a row block of one) resident in HBM.  Stands where the reference keeps its
     torch.sparse.FloatTensor `Graph` (dataloader.py:221-222; model.py:38)."""
 
-    def __init__(self, rowptr, col, val, n_cols=None, edge_id=None, device=None, tile_rows=False):
-        """tile_rows: lay the task table out for the fused SpMM + NGCF layer launch (spex_graph_create_ex with
-        SPEX_GRAPH_TILE_ROWS: a workgroup completes at most 64 rows); every other operation works on such a handle too."""
+    def __init__(self, rowptr, col, val, n_cols=None, edge_id=None, device=None):
         rowptr = np.ascontiguousarray(rowptr, np.int32)
         col = np.ascontiguousarray(col, np.int32)
         val = np.ascontiguousarray(val, np.float32)
@@ -156,14 +154,10 @@ class SpexGraph:
         self._edge_id_host = edge_id
         self.device = _device_of(device)
         handle = ctypes.c_void_p()
-        self.tile_rows = bool(tile_rows)
         with torch.cuda.device(self.device):
             args = (rowptr.ctypes.data_as(ctypes.c_void_p), col.ctypes.data_as(ctypes.c_void_p), val.ctypes.data_as(ctypes.c_void_p),
                     edge_id.ctypes.data_as(ctypes.c_void_p) if edge_id is not None else None, self.n_rows, self.n_cols, self.nnz)
-            if tile_rows:
-                _lib.call("spex_graph_create_ex", *args, 1, ctypes.byref(handle))       # SPEX_GRAPH_TILE_ROWS
-            else:
-                _lib.call("spex_graph_create", *args, ctypes.byref(handle))
+            _lib.call("spex_graph_create", *args, ctypes.byref(handle))
         self._h = handle
         nl, ns = ctypes.c_int32(), ctypes.c_int32()
         _lib.call("spex_graph_info", self._h, None, None, None, ctypes.byref(nl), ctypes.byref(ns))

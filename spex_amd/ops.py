@@ -221,22 +221,6 @@ def ngcf_layer_fwd_rows(ego, side, W_gc, b_gc, W_bi, b_bi, out, idx_a, idx_b, of
     _bump(out)
 
 
-def ngcf_spmm_layer_fwd(graph, ego, W_gc, b_gc, W_bi, b_bi, out, side_out, slope=0.01, drop=None, pad_row=-1):
-    """side = A ego and the first NGCF layer in ONE launch (spex_ngcf_spmm_layer_fwd_f32; `graph` built with tile_rows=True):
-    out [n, >= 128] receives [ego | normalised layer output], side_out [n, 64] the product (the backward recomputes from it)."""
-    for x, nm in ((ego, "ego"), (W_gc, "W_gc"), (b_gc, "b_gc"), (W_bi, "W_bi"), (b_bi, "b_bi"), (out, "out"), (side_out, "side_out")):
-        _need(x, nm)
-    n, d = ego.shape
-    if not getattr(graph, "tile_rows", False):
-        raise ValueError("ngcf_spmm_layer_fwd: the graph must be built with tile_rows=True")
-    if graph.n_rows != n or graph.n_cols != n or out.shape[0] != n or out.shape[1] < 2 * d or side_out.shape != (n, d):
-        raise ValueError("ngcf_spmm_layer_fwd: shapes (square graph of ego's rows, out [n, >= 2d], side_out [n, d])")
-    p, seed, step = drop if drop is not None else (0.0, 0, 0)
-    _launch(ego.device, "spex_ngcf_spmm_layer_fwd_f32", graph._h, _ptr(ego), _ptr(W_gc), _ptr(b_gc), _ptr(W_bi), _ptr(b_bi), _ptr(out),
-            out.stride(0), _ptr(side_out), d, float(slope), float(p), int(seed), int(step), 0, int(pad_row))
-    _bump(out, side_out)
-
-
 def ngcf_layer_bwd(ego, side, W_gc, b_gc, W_bi, b_bi, g_all, layer, g_next, g_side, g_ego, gW_gc, gb_gc, gW_bi, gb_bi,
                    slope=0.01, drop=None, pad_row=-1):
     """Backward of ngcf_layer_fwd for layer `layer` given g_all = d loss / d (concatenated table): reads its slice (and,

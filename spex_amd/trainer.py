@@ -327,13 +327,10 @@ class NGCFStepper:
             raise ValueError("NGCFStepper needs 64-wide layers (the fused layer kernels)")
         self.model, self.lr, self.betas, self.eps, self.t = model, lr, betas, eps, 0
         self.deterministic = (os.environ.get("SPEX_DETERMINISTIC", "0") == "1") if deterministic is None else bool(deterministic)
-        # spex_ngcf_step_t.side_stream (the layer weights' Adam pass on a second stream beside the push-form product and the
-        # table's pass) is OFF by default: measured on the MI355X it LOSES 10 us per step (69.4 vs 59.3 us) — the 5 us pass it
-        # hides costs a fork and a join, and a cross-stream event wait takes ~5 us to propagate between the two hardware queues.
-        # (The dual-task step gains 49 us from the same mechanism: there the forked branch is 80 us long.)  SPEX_NGCF_TWO_STREAMS=1.
+        # spex_ngcf_step_t.side_stream (the layer weights' Adam pass on a second stream beside the push-form product and the table's
+        # pass) stays unused: measured on the MI355X it LOSES 10 us per step (69.4 vs 59.3 us) — the 5 us pass it hides costs a fork and
+        # a join, and a cross-stream event wait takes ~5 us to propagate between the two hardware queues.
         self._side = None
-        if os.environ.get("SPEX_NGCF_TWO_STREAMS", "0") == "1" and next(model.parameters()).is_cuda:
-            self._side = torch.cuda.Stream(device=next(model.parameters()).device)
         self.E0 = model.flat_table()
         n, d = self.E0.shape
         dev = self.E0.device
@@ -566,7 +563,7 @@ class DualTaskStepper:
 
     def __init__(self, model, path_capacity, path_len, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, n_rec=5, batch_capacity=256,
                  two_streams=None, deterministic=None, fixed_task_weights=False, pipelined=False):
-        """two_streams (default on; SPEX_DUAL_ONE_STREAM=1 turns it off): the trust branch's two launches — a latency chain on
+        """two_streams (default on): the trust branch's two launches — a latency chain on
         <= path_capacity workgroups — run on a second HIP stream beside the rec branch and join it in front of the Adam
         pass (spex_dual_task_step_t.side_stream).  Same results as the one-stream order.
         pipelined (needs two streams; flags & SPEX_STEP_PIPELINED): the Adam pass split by owner over the two streams, so that no
@@ -593,7 +590,7 @@ class DualTaskStepper:
         self.path_capacity, self.path_len, self.n_heads = int(path_capacity), int(path_len), n_heads
         self.lr, self.betas, self.eps, self.n_rec = lr, betas, eps, n_rec
         if two_streams is None:
-            two_streams = os.environ.get("SPEX_DUAL_ONE_STREAM", "0") != "1"
+            two_streams = True
         self._side = torch.cuda.Stream(device=dev) if two_streams else None
         self.pipelined = bool(pipelined) and self._side is not None
         P = ops.trust_param_count(n_heads, d)

@@ -39,7 +39,7 @@ def test_binding_arity_matches_header():
 
 def test_version_and_error_string():
     lib = _lib.load()
-    assert lib.spex_version() == 4
+    assert lib.spex_version() == 5
     assert isinstance(lib.spex_last_error(), bytes)
 
 
@@ -101,7 +101,7 @@ def test_header_is_plain_c(tmp_path):
     assert r.returncode == 0, r.stderr
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     # NULL rowptr is refused by argument validation before any device call
-    assert out.returncode == 1 and out.stdout.startswith("4 -1 spex_graph_create"), (out.stdout, out.stderr)
+    assert out.returncode == 1 and out.stdout.startswith("5 -1 spex_graph_create"), (out.stdout, out.stderr)
 
 
 def test_step_descriptors_have_the_layout_of_the_header(tmp_path):

@@ -355,16 +355,14 @@ def test_dual_task_model_matches_reference(data_root, golden):
     assert np.abs(got - g["trust_test5"]).max() <= 1e-9
 
 
-@pytest.mark.parametrize("form", ["fused", "fused-1wg", "fused-7wg", "tiled"])
+@pytest.mark.parametrize("form", ["fused", "fused-1wg", "fused-7wg"])
 @pytest.mark.parametrize("nonhybrid", [False, True])
 def test_fused_trust_head_matches_the_layer_by_layer_path(data_root, nonhybrid, form, monkeypatch):
-    """The trust head's training call (spex_trust_head_train_f32) in ALL of its forms — the fused kernel (split over the library's
-    choice of workgroups per path; one workgroup per path; seven: SPEX_TRUST_SPLIT forces) and the tiled launches
-    (SPEX_TRUST_TILED forces; the library picks by size otherwise) — against the same model evaluated layer
+    """The trust head's training call (spex_trust_head_train_f32) in all of its forms — the fused kernel split over the library's
+    choice of workgroups per path; one workgroup per path; seven (SPEX_TRUST_SPLIT forces) — against the same model evaluated layer
     by layer (attention kernels + torch ops + autograd): loss, every parameter's gradient and the user-table gradient; paths of
     every length 1..L (a full-width path has no padded position for the max-pool's zero), repeated users, repeated targets."""
     from spex_amd import ops
-    monkeypatch.setenv("SPEX_TRUST_TILED", "1" if form == "tiled" else "0")
     if form.endswith("wg"):
         monkeypatch.setenv("SPEX_TRUST_SPLIT", form[6:-2])
     args, dataset, net = _dual_task_model(data_root)

@@ -45,7 +45,7 @@ def G():
 # ---------------------------------------------------------------------------------------------- SpMM
 def test_library_is_the_hip_build():
     from spex_amd import _lib
-    assert _lib.load().spex_version() == 4
+    assert _lib.load().spex_version() == 5
 
 
 @pytest.mark.parametrize("d", [64, 32, 100, 128, 256, 1])

@@ -576,33 +576,6 @@ def test_two_layer_ngcf_teacher_forced_against_the_reference(golden, ngcf_data_r
         assert np.abs(got - want_m).max() <= 1e-4, (got, want_m)
 
 
-def test_fused_spmm_and_layer_equals_the_two_launches(epinion2):
-    """spex_ngcf_spmm_layer_fwd_f32 on a tile-mode handle (SPEX_GRAPH_TILE_ROWS) against spex_spmm_f32 + spex_ngcf_layer_fwd_f32
-    on an ordinary handle: `side` bit-identical (same chunks, same fmaf chains, same segment order), the concatenated table
-    to rounding; the NGCF adjacency of Epinion2 (rows of 1 .. 1 000 entries, an isolated pad row), message dropout on.
-    The tile-mode handle also serves the ordinary SpMM (bit-identical product)."""
-    from spex_amd import ops
-    from spex_amd.graph import SpexGraph, ngcf_norm_adj
-    tr = epinion2["train"]
-    rowptr, col, val = ngcf_norm_adj(tr[:, 0], tr[:, 1], 3185, 12407)
-    n = len(rowptr) - 1
-    g_plain, g_tile = SpexGraph(rowptr, col, val), SpexGraph(rowptr, col, val, tile_rows=True)
-    rng = np.random.default_rng(3)
-    ego = torch.from_numpy((rng.normal(size=(n, 64)) * 0.1).astype(np.float32)).to(DEV)
-    W_gc, W_bi = (torch.from_numpy(rng.normal(size=(64, 64)).astype(np.float32) * 0.2).to(DEV) for _ in range(2))
-    b_gc, b_bi = (torch.from_numpy(rng.normal(size=64).astype(np.float32) * 0.1).to(DEV) for _ in range(2))
-    drop = (0.1, 12345, 7)
-    side_a = g_plain.spmm(ego)
-    out_a = torch.zeros(n, 128, device=DEV)
-    ops.ngcf_layer_fwd(ego, side_a, W_gc, b_gc, W_bi, b_bi, out_a, 0, True, drop=drop, pad_row=3185)
-    out_b, side_b = torch.full((n, 128), 7.0, device=DEV), torch.full((n, 64), 7.0, device=DEV)
-    ops.ngcf_spmm_layer_fwd(g_tile, ego, W_gc, b_gc, W_bi, b_bi, out_b, side_b, drop=drop, pad_row=3185)
-    assert torch.equal(side_b, side_a)
-    assert torch.equal(out_b[:, :64], ego)
-    assert rel_err(out_b[:, 64:].cpu().numpy(), out_a[:, 64:].cpu().numpy()) <= 2e-6
-    assert torch.equal(g_tile.spmm(ego), side_a)
-
-
 def test_row_sparse_forward_equals_the_whole_table_forward_at_the_batch_rows(epinion2):
     """What the one-call NGCF step runs since round 3: side = A ego at the batch's rows (spex_spmm_rowlist_f32) and the layer at
     those rows (spex_ngcf_layer_fwd_rows_f32, mask indexed by the ROW) against the whole-table launches — bit-identical rows of
