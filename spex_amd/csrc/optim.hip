@@ -234,38 +234,50 @@ __global__ __launch_bounds__(256) void dual_task_adam_kernel(const DualAdamArgs 
         a.p[i] = P; a.m[i] = M; a.v[i] = V;
         return;
     }
-    // ---- main loop over the part's compact index space k -> arena index i:
-    //      part 0 (the whole arena):               i = k                                   [+ the gate parameters unless a role has them]
-    //      part 1 (what the rec branch alone owns): item rows, then the gate parameters     [ditto]
-    //      part 2 (what needs both branches):       user rows, then the trust block; the task weights and the loss cells
-    const int64_t gate_k = a.role ? 0 : 512;
-    const int64_t n_item = a.n_table - a.n_user;
-    const int64_t n_k = a.part == 0 ? a.n_table + a.n_trust + gate_k : (a.part == 1 ? n_item + gate_k : a.n_user + a.n_trust);
+    // ---- the table rows of this part, FOUR parameters per thread and step (float4: the scalar form moved 4 bytes per lane and load
+    //      — 11.7 us for the 1 M-parameter Epinion2 arena where the LightGCN step's float4 pass takes 8):
+    //      part 0: the whole table;  part 1 (what the rec branch alone owns): the item rows;  part 2: the user rows.
+    //      (n_table and n_user are multiples of 64: whole rows)
     const int64_t stride = (int64_t)(gridDim.x - a.role) * blockDim.x;
     const int64_t tid = (int64_t)(blockIdx.x - a.role) * blockDim.x + threadIdx.x;
-    for (int64_t k = tid; k < n_k; k += stride) {
-        int64_t i;
-        if (a.part == 0) i = k;                                               // (the gate parameters follow the trust block directly)
-        else if (a.part == 1) i = k < n_item ? a.n_user + k : a.n_table + a.n_trust + (k - n_item);
-        else i = k < a.n_user ? k : a.n_table + (k - a.n_user);
-        float g;
-        if (i < a.n_table) {
-            float ge = a.g_E0[i];
-            if (a.prop_div > 0.0f) ge = ge + a.g_prop[i] / a.prop_div;
-            else if (a.prop_div < 0.0f) ge = ge + a.push_zero[i];         // (read before this thread clears it below)
-            g = p1 * (ge + a.g_raw[i]);
-            if (i < a.n_user) {
-                g = fmaf(p2, a.g_user[i], g);
-                a.g_user[i] = 0.0f;
-            }
-            a.g_raw_w[i] = 0.0f;
-            if (a.clear_prop) a.g_prop[i] = 0.0f;
-            if (a.push_zero) a.push_zero[i] = 0.0f;                        // (every part clears its own rows of the push target)
-        } else {
-            const int64_t j = i - a.n_table;
-            g = (j < a.n_trust ? p2 : p1) * a.g_small[j];
-            a.g_small[j] = 0.0f;
+    const int64_t q_lo = (a.part == 1 ? a.n_user : 0) / 4, q_hi = (a.part == 2 ? a.n_user : a.n_table) / 4, q_user = a.n_user / 4;
+    for (int64_t q = q_lo + tid; q < q_hi; q += stride) {
+        float4 ge = reinterpret_cast<const float4 *>(a.g_E0)[q];
+        if (a.prop_div > 0.0f) {
+            const float4 gp = reinterpret_cast<const float4 *>(a.g_prop)[q];
+            ge.x = ge.x + gp.x / a.prop_div; ge.y = ge.y + gp.y / a.prop_div; ge.z = ge.z + gp.z / a.prop_div; ge.w = ge.w + gp.w / a.prop_div;
+        } else if (a.prop_div < 0.0f) {                                  // (read before this thread clears it below)
+            const float4 pz = reinterpret_cast<const float4 *>(a.push_zero)[q];
+            ge.x = ge.x + pz.x; ge.y = ge.y + pz.y; ge.z = ge.z + pz.z; ge.w = ge.w + pz.w;
         }
+        const float4 gr = reinterpret_cast<const float4 *>(a.g_raw)[q];
+        float4 g = make_float4(p1 * (ge.x + gr.x), p1 * (ge.y + gr.y), p1 * (ge.z + gr.z), p1 * (ge.w + gr.w));
+        const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (q < q_user) {
+            const float4 gu = reinterpret_cast<const float4 *>(a.g_user)[q];
+            g.x = fmaf(p2, gu.x, g.x); g.y = fmaf(p2, gu.y, g.y); g.z = fmaf(p2, gu.z, g.z); g.w = fmaf(p2, gu.w, g.w);
+            reinterpret_cast<float4 *>(a.g_user)[q] = zero4;
+        }
+        reinterpret_cast<float4 *>(a.g_raw_w)[q] = zero4;
+        if (a.clear_prop) reinterpret_cast<float4 *>(a.g_prop)[q] = zero4;
+        if (a.push_zero) reinterpret_cast<float4 *>(a.push_zero)[q] = zero4;         // (every part clears its own rows of the push target)
+        float4 P = reinterpret_cast<float4 *>(a.p)[q], M = reinterpret_cast<float4 *>(a.m)[q], V = reinterpret_cast<float4 *>(a.v)[q];
+        adam1(P.x, g.x, M.x, V.x, a.w1, a.beta2, a.w2, a.bc2_sqrt, a.eps, a.step_size);
+        adam1(P.y, g.y, M.y, V.y, a.w1, a.beta2, a.w2, a.bc2_sqrt, a.eps, a.step_size);
+        adam1(P.z, g.z, M.z, V.z, a.w1, a.beta2, a.w2, a.bc2_sqrt, a.eps, a.step_size);
+        adam1(P.w, g.w, M.w, V.w, a.w1, a.beta2, a.w2, a.bc2_sqrt, a.eps, a.step_size);
+        reinterpret_cast<float4 *>(a.p)[q] = P;
+        reinterpret_cast<float4 *>(a.m)[q] = M;
+        reinterpret_cast<float4 *>(a.v)[q] = V;
+    }
+    // ---- the small dense parameters behind the table, one per thread:  part 0: trust block [+ the gate parameters unless a role has
+    //      them];  part 1: the gate parameters [ditto];  part 2: the trust block
+    const int64_t gate_k = a.role ? 0 : 512;
+    const int64_t j_lo = a.part == 1 ? a.n_trust : 0, j_hi = a.part == 2 ? a.n_trust : a.n_trust + gate_k;
+    for (int64_t j = j_lo + tid; j < j_hi; j += stride) {
+        const int64_t i = a.n_table + j;
+        const float g = (j < a.n_trust ? p2 : p1) * a.g_small[j];
+        a.g_small[j] = 0.0f;
         float P = a.p[i], M = a.m[i], V = a.v[i];
         adam1(P, g, M, V, a.w1, a.beta2, a.w2, a.bc2_sqrt, a.eps, a.step_size);
         a.p[i] = P; a.m[i] = M; a.v[i] = V;
@@ -303,7 +315,10 @@ int spex::dual_task_adam(float *p, float *m, float *v, const float *g_E0, float 
     const DualAdamArgs a{p, m, v, g_E0, g_raw, g_raw, g_user, g_small, g_prop, push_zero, loss, loss_acc, prec, n_table, n_user, n_trust,
                          n_table + n_trust + 512 + 2, B, T, n_rec, t & 1, fixed_weights, 1.0f - beta1, beta2, 1.0f - beta2, (float)sqrt(bc2), eps,
                          (float)((double)lr / bc1), att_copies, n_att_copies, att_clear, prop_div, clear_prop, part, role};
-    const int64_t n_k = part == 0 ? n_table + n_trust + 512 : (part == 1 ? n_table - n_user + 512 : n_user + n_trust);
+    SPEX_CHECK_ARG((n_table & 3) == 0 && (n_user & 3) == 0 && ((((uintptr_t)p) | ((uintptr_t)m) | ((uintptr_t)v) | ((uintptr_t)g_E0) | ((uintptr_t)g_raw) | ((uintptr_t)g_user)
+                                                                  | ((uintptr_t)g_prop) | ((uintptr_t)push_zero)) & 15) == 0,
+                   "dual_task_adam: the table blocks must be whole rows of 16-byte aligned buffers");
+    const int64_t n_k = (part == 0 ? n_table : (part == 1 ? n_table - n_user : n_user)) / 4;      // float4 steps over the part's table rows
     int64_t blocks = (n_k + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;

@@ -248,7 +248,7 @@ struct spex_graph {
     int32_t n_hub_tasks = 0;        // hub segment tasks = task[0 : n_hub_tasks]
     int4 *hub_grp = nullptr;        // [n_hub_tasks] x: 1 = the group's first wave, y: waves in the group, z: the group's partial row, w: hub
     int2 *hub_fold = nullptr;       // [n_hub] x: the hub's first partial row, y: its number of groups
-    unsigned long long *hub_ticket = nullptr;   // [n_hub] (launch tag << 32) | groups arrived (zeroed at creation, never reset)
+    unsigned long long *hub_ticket = nullptr;   // [n_hub] arrival counter: every folding launch adds the hub's group count (zeroed at creation, never reset)
     // edge dropout
     int mask_mode = 0;
     const uint8_t *keep = nullptr;

@@ -457,8 +457,8 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
         if (hub_leader) {
             // A hub's segments are adjacent in the table: this wave and the hg.y - 1 behind it hold consecutive segments of row t.z.
             // Their sum is ONE partial row of the hub; the hub's groups meet through memory: agent-scope store (write-through: the
-            // groups may run on different XCDs), the wave's own stores acknowledged (explicit vmcnt(0)), a ticket on the hub — (launch tag << 32) |
-            // arrivals, anything else in the word counts as "nobody yet" — and the LAST group to arrive adds the partial rows in group
+            // groups may run on different XCDs), the wave's own stores acknowledged (explicit vmcnt(0)), a ticket on the hub (an arrival
+            // counter, see below) and the LAST group to arrive adds the partial rows in group
             // order (whoever is last: the same order, the same bits) and runs the row's epilogue.  No fence (an agent-scope fence on
             // gfx950 writes back / invalidates the XCD's whole L2), no waiting, no second launch.
             float y = acc;
@@ -468,25 +468,20 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
             if (hf.y > 1) {
                 __hip_atomic_store(partial + (size_t)hg.z * 64 + lane, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // the wave's partial-row store is ACKNOWLEDGED (sc1 write-through: visible to every XCD) before lane 0 touches the
-                // ticket: an explicit s_waitcnt vmcnt(0) — a workgroup-scope release fence emits no vmcnt wait on gfx950, and the
-                // wait the compiler happens to place for the ticket load's data below is not a guarantee.  One wave = one
-                // instruction stream, so the wait covers all 64 lanes' stores.  tests/test_isa_folds.py asserts it in the ISA.
+                // ticket: an explicit s_waitcnt vmcnt(0) — a workgroup-scope release fence emits no vmcnt wait on gfx950.  One wave =
+                // one instruction stream, so the wait covers all 64 lanes' stores.  tests/test_isa_folds.py asserts it in the ISA.
                 __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0); expcnt / lgkmcnt unconstrained
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // (compiler ordering only)
-                unsigned arrived = 1u;
-                if (lane == 0) {
-                    unsigned long long *tk = hf_args.ticket + hg.w;
-                    unsigned long long cur = __hip_atomic_load(tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned long long first = ((unsigned long long)hf_args.tag << 32) | 1ull;
-                    if ((unsigned)(cur >> 32) == hf_args.tag
-                        || !__hip_atomic_compare_exchange_strong(tk, &cur, first, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                        arrived = (unsigned)__hip_atomic_fetch_add(tk, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-                }
-                arrived = (unsigned)__builtin_amdgcn_readfirstlane((int)arrived);
-                last = arrived == (unsigned)hf.y;
+                // The ticket is a COUNTER that is never reset: the handle zeroes it at creation and every launch that folds adds
+                // exactly hf.y arrivals to it (launches on one handle are ordered: they share its scratch), so the group whose
+                // increment lands on a multiple of hf.y is the launch's last — ONE read-modify-write round trip through memory on the
+                // hub's tail.  (Round 3 carried a per-launch tag in the word: a load, a compare-exchange and often an add — three
+                // dependent agent-scope round trips, ~2 us of the hub rows' 5.)  A replay from a captured graph adds hf.y again.
+                unsigned long long arrived = 0ull;
+                if (lane == 0) arrived = __hip_atomic_fetch_add(hf_args.ticket + hg.w, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+                const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(arrived % (unsigned long long)hf.y));
+                last = lo == 0u;
                 if (last) {
-                    // (the word goes back to 0: a launch REPLAYED from a captured HIP graph carries the same tag again)
-                    if (lane == 0) __hip_atomic_store(hf_args.ticket + hg.w, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     y = 0.0f;
                     const float *pr = partial + (size_t)hf.x * 64 + lane;
                     int q = 0;
@@ -919,9 +914,8 @@ int launch_spmm(const spex_graph *g, const float *X, float *Y, const float *add_
         // rows beyond kWgRowMax entries: folded inside the d == 64 launch (SPEX_HUB_FOLD=0: by the fix-up launch, as for the wide kernels)
         const char *fold_sw = g->n_hub > 0 ? getenv("SPEX_HUB_FOLD") : nullptr;      // (read per launch: the tests run both forms in one process)
         const bool fold_env = !(fold_sw && fold_sw[0] == '0');
-        static std::atomic<uint32_t> launch_tag{0x51000000u};
         hub.grp = g->hub_grp; hub.fold = g->hub_fold; hub.ticket = g->hub_ticket;
-        hub.tag = (d == 64 && fold_env && g->n_hub > 0 && g->hub_grp && g->hub_ticket) ? launch_tag.fetch_add(1u) + 1u : 0u;
+        hub.tag = (d == 64 && fold_env && g->n_hub > 0 && g->hub_grp && g->hub_ticket) ? 1u : 0u;      // (on / off)
         if (acc_out) launch_chunk<1>(d, masked, g->row_ids, grid, block, stream, X, g, Y, acc_in, acc_div, 1.0f, acc_out, da, xcd_contig, hub);
         else if (add_in) launch_chunk<2>(d, masked, g->row_ids, grid, block, stream, X, g, Y, add_in, add_div, out_div, nullptr, da, xcd_contig, hub);
         else launch_chunk<0>(d, masked, g->row_ids, grid, block, stream, X, g, Y, nullptr, 1.0f, 1.0f, nullptr, da, xcd_contig, hub);
