@@ -1,10 +1,9 @@
 """The one-call dual-task step (spex_dual_task_step_f32) on Epinion2, B = 256, 15 paths: µs per step by HIP events, training-
-shaped batches optional.  The library reads its A/B switches from the environment once, so variants are separate runs:
+shaped batches optional.
 
-    python tools/dual_ab.py                       # default build
-    SPEX_DUAL_FUSED_MIDDLE=0 python tools/dual_ab.py
-    SPEX_DUAL_ONE_STREAM=1 python tools/dual_ab.py
+    python tools/dual_ab.py                           # the default form: two streams, fork / join
     SPEX_DUAL_PIPELINED=1 python tools/dual_ab.py     # the pipelined form of the two-stream step (SPEX_STEP_PIPELINED)
+    SPEX_LIB=<other build> python tools/dual_ab.py    # A/B against another build of the library
 
 Under rocprofv3 (`--kernel-trace --stats`) pass --steps 300 to keep the trace small.
 """

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """The trust head's training forms against each other (spex_trust_head_train_f32): the FUSED kernel (one 16-wave workgroup per
 path: forward chain, logits over the whole user table, backward chain), its SPLIT form (S workgroups per path, each sweeping a
-share of the table; the path's last one folds the shares and runs the backward chain) and the TILED launches (chains per path, logits / CE /
-table gradient on tiles of 32 users shared by all paths) for several (users, paths) sizes.  SPEX_TRUST_TILED is read once per
-process, so every (form, size) runs in its own subprocess.  Prints us per call (forward + backward + reductions)."""
+share of the table; the path's last one folds the shares and runs the backward chain) for several (users, paths) sizes
+(SPEX_TRUST_SPLIT caps the workgroups per path; every (form, size) runs in its own subprocess).  Prints us per call (forward +
+backward + reductions).  (Round 3's table also had the five-launch TILED form, removed in round 4: profiles/r03/trust_forms.txt.)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "one":
@@ -40,11 +40,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "one":
     e1.record(); torch.cuda.synchronize()
     print("%.2f %.6f" % (e0.elapsed_time(e1) / n * 1e3, loss.item()))
     sys.exit(0)
-print("%8s %6s %12s %12s %12s   (us per call; loss agreement)" % ("users", "paths", "fused, S=1", "fused, split", "tiled"))
+print("%8s %6s %12s %12s   (us per call; loss agreement)" % ("users", "paths", "fused, S=1", "fused, split"))
 for n_users, T in ((3185, 15), (3185, 45), (6812, 15), (6812, 45), (3185, 192), (26000, 15), (26000, 60), (60000, 15), (100000, 15)):
     res = []
-    for env in ({"SPEX_TRUST_TILED": "0", "SPEX_TRUST_SPLIT": "1"}, {"SPEX_TRUST_TILED": "0"}, {"SPEX_TRUST_TILED": "1"}):
+    for env in ({"SPEX_TRUST_SPLIT": "1"}, {}):
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "one", str(n_users), str(T)], capture_output=True, text=True,
                              env=dict(os.environ, **env))
         res.append(out.stdout.strip().split() if out.returncode == 0 else ["nan", out.stderr[-200:]])
-    print("%8d %6d %12s %12s %12s   losses %s %s %s" % (n_users, T, res[0][0], res[1][0], res[2][0], res[0][1], res[1][1], res[2][1]))
+    print("%8d %6d %12s %12s   losses %s %s" % (n_users, T, res[0][0], res[1][0], res[0][1], res[1][1]))
