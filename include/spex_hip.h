@@ -703,6 +703,37 @@ int spex_step_events_release(void **ev_fork, void **ev_join);   /* destroys the 
 int spex_ngcf_step_bce_f32(spex_ngcf_step_t *step, const int64_t *users, const int64_t *items, const float *labels, int32_t B,
                            float *loss_sum, void *stream);
 
+/* NGCF with MORE than one layer (`--layer_size [64,64,..]`, NGCF_SPEX/code/ngcf_parser.py:12; the layer loop of main_rec.py:71-93) —
+ * the training step as one call of the library's own launches, L >= 2 layers of width 64:
+ *   forward   layers 0 .. L-2 over the whole table (spex_spmm_f32 -> spex_ngcf_layer_fwd_f32: their outputs feed the next layer's
+ *             product everywhere); the LAST layer at the batch's rows only (spex_spmm_rowlist_f32 -> spex_ngcf_layer_fwd_rows_f32: the
+ *             loss reads the concatenated table nowhere else, main_rec.py:96-104)
+ *   scoring   spex_score_bce_slots_f32 on the concatenated table [N, 64 (L + 1)]: per-sample gradient rows + the table form the
+ *             earlier layers read
+ *   backward  last layer on the batch's slots (spex_ngcf_layer_bwd_rows_f32) -> push-form A^T product (spex_spmm_push_batch_f32) ->
+ *             for l = L-2 .. 0: spex_ngcf_layer_bwd_f32 (dense, four waves per tile) -> spex_spmm_f32 on A^T with g_ego added
+ *   Adam      the table; the last layer's weights from their partial blocks; the other layers' weights (their pass clears gW).
+ * Buffers (caller-owned; N = graph rows incl. the isolated pad row if the table keeps one; per = 2 (64 * 64 + 64)):
+ *   E0, mE, vE: [N, 64];  W, mW, vW, gW: [L][per] (layer l: [W_gc | b_gc | W_bi | b_bi]; gW all-zero before the first call, every call
+ *   leaves it so);  all_emb, g_all: [N, 64 (L + 1)] (g_all all-zero before the first call; every call leaves it so);
+ *   sides: [L][N, 64];  egos: [L - 1][N, 64] (the inputs of layers 1 .. L-1);  g_slots: [slot_capacity, 64 (L + 1)];
+ *   g_side_c, g_ego_c: [slot_capacity, 64];  gW_parts: [slot_capacity / 16, per];  g_side, g_ego: [N, 64];  g_next: [2][N, 64].
+ * p_drop: host [L] (message dropout per layer), mask = (seed, dropout_step, layer); dropout_step advanced when any p_drop > 0;
+ * t advanced by the call.  Float atomics in the scoring tables and the push (no deterministic mode for L >= 2). */
+typedef struct spex_ngcf_deep_step {
+    const spex_graph_t *graph, *graph_t;     /* A = D^-1 (A + I) and its transpose */
+    float *E0, *mE, *vE, *W, *mW, *vW, *gW;
+    float *all_emb, *g_all, *sides, *egos, *g_slots, *g_side_c, *g_ego_c, *gW_parts, *g_side, *g_ego, *g_next;
+    const float *p_drop;
+    int32_t L, slot_capacity, n_user_rows, pad_row;
+    float slope;
+    uint64_t seed;
+    int32_t dropout_step, t;
+    float lr, beta1, beta2, eps;
+} spex_ngcf_deep_step_t;
+int spex_ngcf_deep_step_bce_f32(spex_ngcf_deep_step_t *step, const int64_t *users, const int64_t *items, const float *labels, int32_t B,
+                                float *loss_sum, void *stream);
+
 /* The dual-task training step of LightGCN_SPEX/code/main_auto_expert_s.py:63-89 (model_expert_s.LightGCN.forward flag 0 +
  * uncertainty-weighted loss + loss.backward() + optimizer.step()) as one call issuing 2 L + 3 launches:
  *   rec branch, row-sparse like spex_lightgcn_step_bce_f32: (L-1) x spex_spmm_f32 + spex_gated_batch_f32 (last layer at the

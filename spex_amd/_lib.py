@@ -121,6 +121,7 @@ SIGNATURES = {
     "spex_comm_allreduce_sum_f32": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp]),
     "spex_partitioned_propagate_f32": (ctypes.c_int, [c_vp, c_vp]),
     "spex_partitioned_step_bce_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
+    "spex_ngcf_deep_step_bce_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "spex_partitioned_dual_task_step_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "spex_timer_create": (ctypes.c_int, [c_i32, c_i32, ctypes.POINTER(c_vp)]),
     "spex_timer_destroy": (ctypes.c_int, [c_vp]),
@@ -151,6 +152,15 @@ class NGCFStepDesc(ctypes.Structure):
                 + [("seed", ctypes.c_uint64), ("dropout_step", c_i32), ("t", c_i32)]
                 + [(n, c_f32) for n in ("lr", "beta1", "beta2", "eps")]
                 + [(n, c_vp) for n in ("side_stream", "ev_fork", "ev_join", "graph_t", "g_side_dense", "g_ego_dense")] + [("flags", c_i32)])
+
+
+class NGCFDeepStepDesc(ctypes.Structure):
+    """spex_ngcf_deep_step_t (include/spex_hip.h)."""
+    _fields_ = ([(n, c_vp) for n in ("graph", "graph_t", "E0", "mE", "vE", "W", "mW", "vW", "gW", "all_emb", "g_all", "sides", "egos", "g_slots",
+                                     "g_side_c", "g_ego_c", "gW_parts", "g_side", "g_ego", "g_next", "p_drop")]
+                + [(n, c_i32) for n in ("L", "slot_capacity", "n_user_rows", "pad_row")] + [("slope", c_f32)]
+                + [("seed", ctypes.c_uint64), ("dropout_step", c_i32), ("t", c_i32)]
+                + [(n, c_f32) for n in ("lr", "beta1", "beta2", "eps")])
 
 
 class DualTaskStepDesc(ctypes.Structure):

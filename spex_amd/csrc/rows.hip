@@ -287,3 +287,30 @@ extern "C" int spex_spmm_push_batch_f32(const spex_graph_t *g, const int64_t *id
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }
+
+// x[0 : n] = 0 as a kernel launch (hipMemsetAsync costs the host ~10 us a call on this runtime; a launch ~1-2).
+namespace {
+__global__ __launch_bounds__(256) void zero_kernel(float *__restrict__ x, int64_t n4, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+        reinterpret_cast<float4 *>(x)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (blockIdx.x == 0)
+        for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) x[i] = 0.0f;
+}
+}  // namespace
+
+int spex::zero_f32(float *x, int64_t n, void *stream)
+{
+    if (n <= 0) return SPEX_OK;
+    if ((((uintptr_t)x) & 15) != 0) {
+        SPEX_HIP(hipMemsetAsync(x, 0, (size_t)n * sizeof(float), (hipStream_t)stream));
+        return SPEX_OK;
+    }
+    const int64_t n4 = n / 4;
+    int64_t blocks = (n4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(zero_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n4, n);
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}

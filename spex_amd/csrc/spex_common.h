@@ -62,6 +62,7 @@ int bpr_sgd_layers(const float *t0, const float *t1, const float *t2, float div,
                    const int64_t *u, const int64_t *i_pos, const int64_t *i_neg, int64_t T, float lr, float reg, float *loss_sum,
                    void *stream);             // score.hip: the fused BPR-SGD kernel reading rows as ((t0 + t1) + t2) / div
 int scale_div(const float *in, float *out, float div, int64_t n, void *stream);                          // spmm.hip: out = in / div
+int zero_f32(float *x, int64_t n, void *stream);                                                       // rows.hip: x[0 : n] = 0 (a kernel launch)
 int sum_ordered(const float *x, int32_t n, float scale, float *out, int accumulate, void *stream);     // rows.hip: fixed-order sum
 int sum_parts(const float *parts, int32_t n_parts, int64_t stride, int32_t n, float *out, int accumulate,
               void *stream);                                                                        // rows.hip: partial blocks, in order

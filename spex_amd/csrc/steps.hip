@@ -249,6 +249,90 @@ extern "C" int spex_ngcf_step_bce_f32(spex_ngcf_step_t *s, const int64_t *users,
     return SPEX_OK;
 }
 
+// NGCF with L >= 2 layers: see include/spex_hip.h (spex_ngcf_deep_step_t).  What NGCFStepper.step issued launch by launch from Python
+// (~16 launches at ~9 us of host time each) as one native sequence, with the last layer's forward taken at the batch's rows only.
+extern "C" int spex_ngcf_deep_step_bce_f32(spex_ngcf_deep_step_t *s, const int64_t *users, const int64_t *items, const float *labels,
+                                           int32_t B, float *loss_sum, void *stream)
+{
+    const char *who = "spex_ngcf_deep_step_bce_f32";
+    SPEX_CHECK_ARG(s && s->graph && s->graph_t && s->E0 && s->mE && s->vE && s->W && s->mW && s->vW && s->gW && s->all_emb && s->g_all && s->sides
+                       && s->egos && s->g_slots && s->g_side_c && s->g_ego_c && s->gW_parts && s->g_side && s->g_ego && s->g_next && s->p_drop,
+                   "%s: NULL field in the step descriptor", who);
+    SPEX_CHECK_ARG(users && items && labels && loss_sum && B >= 1, "%s: NULL batch pointer or B < 1", who);
+    const spex_graph *g = s->graph, *gt = s->graph_t;
+    const int32_t d = 64, n = g->n_rows, n_u = s->n_user_rows, L = s->L, ld = d * (L + 1), per = 2 * (d * d + d);
+    SPEX_CHECK_ARG(L >= 2 && L <= 8, "%s: L = %d (two to eight layers; one layer: spex_ngcf_step_bce_f32)", who, L);
+    SPEX_CHECK_ARG(g->n_rows == g->n_cols && gt->n_rows == n && gt->n_cols == n && n_u >= 0 && n_u <= n, "%s: square graphs of one size, 0 <= n_user_rows <= N", who);
+    SPEX_CHECK_ARG(s->slot_capacity >= 2 * B, "%s: slot capacity %d < 2 B = %d", who, s->slot_capacity, 2 * B);
+    SPEX_CHECK_ARG(g->mask_mode == 0 && gt->mask_mode == 0, "%s: edge dropout does not apply to NGCF", who);
+    const size_t sz = (size_t)n * d;
+    const uint32_t step = (uint32_t)s->dropout_step;
+    bool any_drop = false;
+    for (int32_t l = 0; l < L; ++l) {
+        SPEX_CHECK_ARG(s->p_drop[l] >= 0.0f && s->p_drop[l] < 1.0f, "%s: p_drop[%d] = %f", who, l, (double)s->p_drop[l]);
+        any_drop = any_drop || s->p_drop[l] > 0.0f;
+    }
+    auto Wl = [&](int32_t l, const float *&W_gc, const float *&b_gc, const float *&W_bi, const float *&b_bi) {
+        const float *w = s->W + (size_t)l * per;
+        W_gc = w; b_gc = w + d * d; W_bi = w + d * d + d; b_bi = w + 2 * d * d + d;
+    };
+    auto ego_of = [&](int32_t l) -> float * { return l == 0 ? s->E0 : s->egos + (size_t)(l - 1) * sz; };
+    const float *W_gc, *b_gc, *W_bi, *b_bi;
+    // ---- forward: whole-table layers 0 .. L-2 (each writes [ego |] its normalised output into the concatenated table and its
+    //      un-normalised output = the next layer's input), then the last layer at the batch's rows only
+    for (int32_t l = 0; l + 1 < L; ++l) {
+        float *side = s->sides + (size_t)l * sz;
+        SPEX_TRY(spex_spmm_f32(g, ego_of(l), side, nullptr, 1.0f, nullptr, nullptr, 1.0f, d, stream));
+        Wl(l, W_gc, b_gc, W_bi, b_bi);
+        SPEX_TRY(spex_ngcf_layer_fwd_f32(ego_of(l), side, W_gc, b_gc, W_bi, b_bi, s->all_emb + (size_t)d * l, ld, l == 0 ? 1 : 0, ego_of(l + 1), n, d,
+                                         s->slope, s->p_drop[l], s->seed, step, (uint32_t)l, s->pad_row, stream));
+    }
+    {
+        const int32_t l = L - 1;
+        float *side = s->sides + (size_t)l * sz;
+        SPEX_TRY(spex_spmm_rowlist_f32(g, ego_of(l), users, B, 0, items, B, n_u, side, nullptr, nullptr, 1.0f, d, stream));
+        Wl(l, W_gc, b_gc, W_bi, b_bi);
+        SPEX_TRY(spex_ngcf_layer_fwd_rows_f32(ego_of(l), side, W_gc, b_gc, W_bi, b_bi, s->all_emb + (size_t)d * l, ld, 0, n, d, s->slope, s->p_drop[l],
+                                              s->seed, step, (uint32_t)l, s->pad_row, users, B, 0, items, B, n_u, stream));
+    }
+    // ---- scoring on the concatenated rows: per-sample gradient rows (the last layer's backward) + the table form (earlier layers)
+    SPEX_TRY(spex_score_bce_slots_f32(s->all_emb, s->all_emb + (size_t)n_u * ld, ld, ld, n_u, n - n_u, users, items, labels, B, ld, loss_sum,
+                                      s->g_all, s->g_all + (size_t)n_u * ld, 1.0f / (float)B, s->g_slots, ld, stream));
+    // ---- backward: the last layer on the batch's slots, A^T g_side in push form, then the dense layers
+    float *g_next = s->g_next + (size_t)((L - 1) & 1) * sz;
+    {
+        const int32_t l = L - 1;
+        Wl(l, W_gc, b_gc, W_bi, b_bi);
+        SPEX_TRY(spex_ngcf_layer_bwd_rows_f32(ego_of(l), s->sides + (size_t)l * sz, W_gc, b_gc, W_bi, b_bi, s->g_slots + (size_t)d * (l + 1), ld, nullptr,
+                                              nullptr, ld, n, d, s->slope, s->p_drop[l], s->seed, step, (uint32_t)l, s->pad_row, users, B, 0, items, B,
+                                              n_u, s->g_side_c, s->g_ego_c, s->gW_parts, per, stream));
+        SPEX_TRY(spex::zero_f32(g_next, (int64_t)sz, stream));
+        SPEX_TRY(spex_spmm_push_batch_f32(g, users, B, 0, items, B, n_u, s->g_side_c, d, s->g_ego_c, d, 1.0f, g_next, d, stream));
+    }
+    for (int32_t l = L - 2; l >= 0; --l) {
+        Wl(l, W_gc, b_gc, W_bi, b_bi);
+        float *gw = s->gW + (size_t)l * per;
+        SPEX_TRY(spex_ngcf_layer_bwd_f32(ego_of(l), s->sides + (size_t)l * sz, W_gc, b_gc, W_bi, b_bi, s->g_all + (size_t)d * (l + 1), ld, g_next,
+                                         l == 0 ? s->g_all : nullptr, ld, n, d, s->slope, s->p_drop[l], s->seed, step, (uint32_t)l, s->pad_row,
+                                         s->g_side, s->g_ego, gw, gw + d * d, gw + d * d + d, gw + 2 * d * d + d, stream));
+        float *out = s->g_next + (size_t)(l & 1) * sz;
+        SPEX_TRY(spex_spmm_f32(gt, s->g_side, out, s->g_ego, 1.0f, nullptr, nullptr, 1.0f, d, stream));
+        g_next = out;
+    }
+    // ---- Adam: the table, the last layer's weights (from their partial blocks), the other layers' (their pass clears gW); the table
+    //      form of the scoring gradient is cleared for the next step
+    const int32_t t_next = s->t + 1;
+    SPEX_TRY(spex::adam_step_z2(s->E0, g_next, s->mE, s->vE, (int64_t)sz, t_next, s->lr, s->beta1, s->beta2, s->eps, nullptr, nullptr, stream));
+    const size_t lo = (size_t)(L - 1) * per;
+    SPEX_TRY(spex_adam_step_sum_f32(s->W + lo, s->gW_parts, spex_ngcf_layer_bwd_rows_parts(2 * B), per, s->mW + lo, s->vW + lo, per, t_next, s->lr,
+                                    s->beta1, s->beta2, s->eps, stream));
+    SPEX_TRY(spex::adam_step_z2(s->W, s->gW, s->mW, s->vW, (int64_t)lo, t_next, s->lr, s->beta1, s->beta2, s->eps, s->gW, nullptr, stream));
+    SPEX_TRY(spex::zero_f32(s->g_all, (int64_t)n * ld, stream));
+    s->t = t_next;
+    if (any_drop) s->dropout_step += 1;
+    return SPEX_OK;
+}
+
 extern "C" int spex_dual_task_step_join(spex_dual_task_step_t *s, void *stream)
 {
     SPEX_CHECK_ARG(s, "spex_dual_task_step_join: NULL descriptor");

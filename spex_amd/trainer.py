@@ -356,10 +356,11 @@ class NGCFStepper:
         self.mE, self.vE = z(n, d), z(n, d)
         self.all_emb = z(n, d * (L + 1))
         self.g_all = z(n, d * (L + 1))                          # invariant: all-zero between steps
-        self.sides = [z(n, d) for _ in range(L)]
-        self.egos = [self.E0] + [z(n, d) for _ in range(L - 1)]
+        self._sides_all, self._egos_all, self._g_next_all = z(L, n, d), z(max(L - 1, 1), n, d), z(2, n, d)   # (contiguous: the deep step's descriptor)
+        self.sides = [self._sides_all[l] for l in range(L)]
+        self.egos = [self.E0] + [self._egos_all[l] for l in range(L - 1)]
         self.g_side, self.g_ego = z(n, d), z(n, d)
-        self.g_next = [z(n, d), z(n, d)]                        # g_next[(L-1) & 1] is all-zero between steps (push target)
+        self.g_next = [self._g_next_all[0], self._g_next_all[1]]   # g_next[(L-1) & 1] is all-zero between steps (push target)
         self.g_slots, self.g_side_c, self.g_ego_c, self.gW_parts = None, None, None, None
         self.loss_acc = z(1)
         self.n_u = model.n_users + 1
@@ -371,6 +372,9 @@ class NGCFStepper:
         acc = self.loss_acc if loss_acc is None else loss_acc
         if L == 1 and self._one_call_ok(users, items, labels):
             return self._step_one_call(users, items, labels, acc)
+        if (L >= 2 and not self.deterministic and self._one_call_ok(users, items, labels)
+                and getattr(self, "dropout_stream", getattr(m, "dropout_stream", "counter")) != "reference"):
+            return self._step_deep_one_call(users, items, labels, acc)
         if self.deterministic:
             raise ValueError("NGCFStepper(deterministic=True): single-layer models with contiguous int64 / fp32 device batches only")
         drop = None
@@ -502,7 +506,46 @@ def _ngcf_step_one_call(self, users, items, labels, acc):
     return acc
 
 
+def _ngcf_step_deep_one_call(self, users, items, labels, acc):
+    """L >= 2 layers as one library call (spex_ngcf_deep_step_bce_f32): whole-table forward of layers 0 .. L-2, the last layer at the
+    batch's rows, scoring, rows backward + push, the dense layer backwards with their A^T products, the Adam passes — main_rec.py:71-93,
+    116-128 for `--layer_size [64,64,..]`."""
+    import ctypes
+    from . import _lib
+    from .graph import _bump, _launch
+    m, L = self.model, self.L
+    B = users.numel()
+    d = self.E0.shape[1]
+    if self.g_side_c is None or self.g_side_c.shape[0] < 2 * B or self.g_slots.shape[1] != d * (L + 1):
+        dev = self.E0.device
+        self.g_slots = torch.zeros((2 * B, d * (L + 1)), dtype=torch.float32, device=dev)
+        self.g_side_c = torch.zeros((2 * B, d), dtype=torch.float32, device=dev)
+        self.g_ego_c = torch.zeros_like(self.g_side_c)
+        self.gW_parts = torch.zeros((ops.ngcf_bwd_rows_parts(2 * B), 2 * (d * d + d)), dtype=torch.float32, device=dev)
+        self._deep_desc = None
+    if getattr(self, "_deep_desc", None) is None:
+        p = lambda t: t.data_ptr()
+        self._p_drop = (ctypes.c_float * L)(*[float(x) for x in m.mess_dropout[:L]])
+        self._deep_desc = _lib.NGCFDeepStepDesc(
+            graph=m.graph._h.value, graph_t=m.graph_t._h.value, E0=p(self.E0), mE=p(self.mE), vE=p(self.vE), W=p(self.W), mW=p(self.mW),
+            vW=p(self.vW), gW=p(self.gW), all_emb=p(self.all_emb), g_all=p(self.g_all), sides=p(self._sides_all), egos=p(self._egos_all),
+            g_slots=p(self.g_slots), g_side_c=p(self.g_side_c), g_ego_c=p(self.g_ego_c), gW_parts=p(self.gW_parts), g_side=p(self.g_side),
+            g_ego=p(self.g_ego), g_next=p(self._g_next_all), p_drop=ctypes.cast(self._p_drop, ctypes.c_void_p).value, L=L,
+            slot_capacity=self.g_slots.shape[0], n_user_rows=self.n_u, pad_row=m.n_users, slope=0.01, seed=int(m.message_dropout_seed),
+            dropout_step=m.dropout_step, t=self.t, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps)
+    dsc = self._deep_desc
+    for l in range(L):
+        self._p_drop[l] = float(m.mess_dropout[l])
+    dsc.t, dsc.lr, dsc.dropout_step, dsc.seed = self.t, self.lr, m.dropout_step, int(m.message_dropout_seed)
+    _launch(self.E0.device, "spex_ngcf_deep_step_bce_f32", ctypes.byref(dsc), ctypes.c_void_p(users.data_ptr()),
+            ctypes.c_void_p(items.data_ptr()), ctypes.c_void_p(labels.data_ptr()), B, ctypes.c_void_p(acc.data_ptr()))
+    self.t, m.dropout_step = dsc.t, dsc.dropout_step
+    _bump(self.E0, self.W, acc)
+    return acc
+
+
 NGCFStepper._one_call_ok = staticmethod(_ngcf_one_call_ok)
+NGCFStepper._step_deep_one_call = _ngcf_step_deep_one_call
 NGCFStepper._step_one_call = _ngcf_step_one_call
 NGCFStepper.__del__ = _drop_desc
 

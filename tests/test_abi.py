@@ -110,7 +110,7 @@ def test_step_descriptors_have_the_layout_of_the_header(tmp_path):
     import subprocess
     structs = {"spex_lightgcn_step_t": _lib.LightGCNStepDesc, "spex_ngcf_step_t": _lib.NGCFStepDesc,
                "spex_dual_task_step_t": _lib.DualTaskStepDesc, "spex_partitioned_step_t": _lib.PartitionedStepDesc,
-               "spex_partitioned_dual_step_t": _lib.PartitionedDualStepDesc}
+               "spex_partitioned_dual_step_t": _lib.PartitionedDualStepDesc, "spex_ngcf_deep_step_t": _lib.NGCFDeepStepDesc}
     lines = ['#include "spex_hip.h"', "#include <stdio.h>", "#include <stddef.h>", "int main(void) {"]
     for cname, cls in structs.items():
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))

@@ -576,6 +576,45 @@ def test_two_layer_ngcf_teacher_forced_against_the_reference(golden, ngcf_data_r
         assert np.abs(got - want_m).max() <= 1e-4, (got, want_m)
 
 
+def test_deep_one_call_step_equals_the_launch_by_launch_step(golden, ngcf_data_root):
+    """spex_ngcf_deep_step_bce_f32 (L = 2 and 3: whole-table forward of the earlier layers, last layer at the batch's rows, scoring, rows
+    backward + push, dense 4-wave layer backwards with their A^T products, Adam — one native call) against NGCFStepper's launch-by-launch
+    path (every layer's forward over the whole table) from the same state: four steps, losses and every parameter (the two differ only
+    in the order of float atomics; Adam's first steps amplify nothing here because both see the same gradients to rounding)."""
+    from spex_amd.trainer import NGCFStepper
+    g = golden("ngcf_epinion2_2layer_ckpt")
+    rng = np.random.default_rng(17)
+    for layers in ("[64,64]", "[64,64,64]"):
+        L = layers.count("64")
+        res = []
+        for native in (True, False):
+            gg = dict(seed=g["seed"], drop_seed=g["drop_seed"], mess_dropout=np.asarray([0.1] * L))
+            data, model, _ = _ngcf_epinion2_model(gg, ngcf_data_root, layer_size=layers)
+            assert model.n_layers == L
+            model.train()
+            st = NGCFStepper(model, lr=1e-3)
+            if not native:
+                st._one_call_ok = lambda *a: False
+            acc = torch.zeros(1, device=DEV)
+            losses = []
+            brng = np.random.default_rng(5)
+            for k in range(4):
+                u = torch.from_numpy(brng.integers(0, data.n_users, 256)).to(DEV)
+                i = torch.from_numpy(brng.integers(0, data.n_items, 256)).to(DEV)
+                y = torch.from_numpy((brng.random(256) < 1 / 6).astype(np.float32)).to(DEV)
+                u[:6] = u[0]                                                         # repeated rows inside the batch
+                before = acc.item()
+                st.step(u, i, y, loss_acc=acc)
+                losses.append(acc.item() - before)
+            assert (getattr(st, "_deep_desc", None) is not None) == native and st.t == 4 and model.dropout_step == 4
+            res.append((losses, {n: p.detach().clone() for n, p in model.named_parameters()}))
+        (l_a, p_a), (l_b, p_b) = res
+        assert np.abs(np.asarray(l_a) - np.asarray(l_b)).max() <= 2e-4, (l_a, l_b)        # loss SUMS over 256 samples (~177)
+        for n in p_a:
+            dv = (p_a[n] - p_b[n]).abs()
+            assert float(dv.mean()) <= 2e-6 and float(dv.max()) <= 1e-3 + 1e-7, (layers, n, float(dv.mean()), float(dv.max()))
+
+
 def test_row_sparse_forward_equals_the_whole_table_forward_at_the_batch_rows(epinion2):
     """What the one-call NGCF step runs since round 3: side = A ego at the batch's rows (spex_spmm_rowlist_f32) and the layer at
     those rows (spex_ngcf_layer_fwd_rows_f32, mask indexed by the ROW) against the whole-table launches — bit-identical rows of
