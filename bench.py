@@ -739,6 +739,10 @@ def main():
                                                                                                  float(np.median(ms_all) * 1e3),
                                                                                                  float(ms_all.max() * 1e3)],
                                        "algorithmic_bytes_per_launch": b2,
+                                       # the launch timed here is the forward-layer form with the layer mean fused (acc_in read, acc_out written:
+                                       # SURVEY 8d "adds N*4d read + write per layer if acc is kept in HBM") — `frac` keeps the base formula
+                                       "algorithmic_bytes_incl_fused_mean_streams": b2 + 2 * n2 * D * 4,
+                                       "frac_incl_fused_mean_streams": (b2 + 2 * n2 * D * 4) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                        "copy_bandwidth_GBs": copy_gbs, "frac_of_copy_bandwidth": ach / copy_gbs,
                                        "edges_per_s": nnz2 / (ms * 1e-3),
                                        "workload": "Epinion2 x %d replicas (same degree law, cross-linked), N=%d nodes "

@@ -323,7 +323,7 @@ def _ngcf_epinion2_model(g, root, layer_size="[64]"):
     return data, model, batch_test
 
 
-def test_ngcf_run_with_the_references_own_dropout_noise(golden, ngcf_data_root):
+def test_ngcf_first_300_steps_with_the_references_own_dropout_noise(golden, ngcf_data_root):
     """G12-NGCF with NOTHING substituted in the model: 300 steps of NGCF_SPEX/code/main_rec.py on Epinion2 minted with the
     reference's nn.Dropout modules left alone (oracle/gen_golden.py --stage ngcf-native-dropout-epinion2: their noise is
     at::dropout's empty_like(x).bernoulli_(1 - p) from torch's global generator, one [N, 64] draw per step).  The one-call step
