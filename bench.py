@@ -174,7 +174,9 @@ def main():
         # checked against the table the torch.distributed path gathered and timed like the peer path; the fastest verified
         # schedule runs the timed region.  SPEX_BENCH_NATIVE=0 skips this; one GPU shared by several ranks (the rehearsal
         # mode) cannot host an RCCL communicator and skips it too.
-        if os.environ.get("SPEX_BENCH_NATIVE", "1") != "0" and not share and backend == "nccl":
+        # (SPEX_RCCL_LIB set: the library binds a stand-in — tests/stubs/rccl_shm_stub.c moves the data between ranks that share a GPU —
+        #  so the rehearsal can run this selection code with real data before the driver's multi-GPU run does)
+        if os.environ.get("SPEX_BENCH_NATIVE", "1") != "0" and ((not share and backend == "nccl") or os.environ.get("SPEX_RCCL_LIB")):
             native_info = {}
             try:
                 import ctypes

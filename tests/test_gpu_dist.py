@@ -376,6 +376,36 @@ def test_bench_partitioned_path_through_the_nccl_backend_and_the_native_exchange
     assert out["value"] > 0 and out["n_gpus"] == 1
 
 
+def test_bench_multi_rank_rehearsal_verifies_the_native_exchange_with_real_data(tmp_path):
+    """The same rehearsal with libspexhip bound to the functional shared-memory stand-in for RCCL (tests/stubs/rccl_shm_stub.c through
+    SPEX_RCCL_LIB): bench.py's start-up selection then really builds the native communicator on both ranks, checks that "native" and
+    "native-p2p" gather the very table torch.distributed's all-gather does — with data moving between the two processes — and times
+    them; the code the driver's multi-GPU run executes first thing.  (The stand-in is stream-synchronous and slow, so it is not
+    expected to be the schedule kept; RCCL itself is not involved.)"""
+    import json
+    import subprocess
+    import sys
+    so = str(tmp_path / "librccl_shm_stub.so")
+    subprocess.run(["gcc", "-shared", "-fPIC", "-O1", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                    os.path.join(REPO, "tests", "stubs", "rccl_shm_stub.c"), "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-o", so],
+                   check=True)
+    env = dict(os.environ, SPEX_BENCH_SHARE_GPU="1", SPEX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", SPEX_RCCL_LIB=so,
+               SPEX_ALLGATHER="collective")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3",
+           "--no-strong-scaling"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=REPO, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    nat = out["config"]["allgather"]["native"]
+    assert "error" not in nat, nat
+    assert nat["native_equal"] is True and nat["native-p2p_equal"] is True, nat
+    assert nat["propagate_ms_native"] > 0 and nat["propagate_ms_native-p2p"] > 0
+    assert out["n_gpus"] == 2 and out["value"] > 0
+
+
 def test_bench_single_gpu_line_is_well_formed():
     """bench.py as the driver runs it at N = 1 (here with the auxiliary measurements and the 2^24-node graph switched off, a
     short CPU-baseline leg left on): ONE JSON line carrying the contract's keys, `roofline` and `cpu_baseline` objects with
