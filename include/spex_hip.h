@@ -674,7 +674,8 @@ int spex_lightgcn_step_bce_f32(spex_lightgcn_step_t *step, const int64_t *users,
  *   -> spex_spmm_push_batch_f32 -> spex_adam_step_f32 (table; clears its gradient, adds the step's per-sample losses to
  *   loss_sum in a fixed order) -> spex_adam_step_sum_f32 (layer weights).  Six launches.
  * Buffers (caller-owned, N = graph rows incl. an isolated pad row if the table keeps one, d == 64):
- *   E0, mE, vE, side, grad: [N, d] (grad all-zero before the first call; every call leaves it all-zero);  all_emb: [N, 2d];
+ *   E0, mE, vE, side, grad: [N, d] (grad all-zero before the first call; every call leaves it all-zero);  all_emb: unused since ABI 5
+ *   (the step no longer forms the concatenated table; the field keeps the layout, NULL is accepted);
  *   W, mW, vW: the layer's weights as one block [W_gc d*d | b_gc d | W_bi d*d | b_bi d] and its Adam moments;
  *   g_slots: [slot_capacity, 2d];  g_side_c, g_ego_c: [slot_capacity, d];  gW_parts: [slot_capacity / 16, 2 (d*d + d)].
  * users index rows [0, n_user_rows), items rows n_user_rows + items[b].  Message dropout: (p_drop, seed, dropout_step, layer 0),

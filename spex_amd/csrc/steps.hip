@@ -167,7 +167,7 @@ extern "C" int spex_step_events_release(void **ev_fork, void **ev_join)
 extern "C" int spex_ngcf_step_bce_f32(spex_ngcf_step_t *s, const int64_t *users, const int64_t *items, const float *labels,
                                       int32_t B, float *loss_sum, void *stream)
 {
-    SPEX_CHECK_ARG(s && s->graph && s->E0 && s->mE && s->vE && s->W && s->mW && s->vW && s->all_emb && s->side && s->g_slots
+    SPEX_CHECK_ARG(s && s->graph && s->E0 && s->mE && s->vE && s->W && s->mW && s->vW && s->side && s->g_slots
                        && s->g_side_c && s->g_ego_c && s->gW_parts && s->grad,
                    "spex_ngcf_step_bce_f32: NULL field in the step descriptor");
     SPEX_CHECK_ARG(users && items && labels && loss_sum && B >= 1, "spex_ngcf_step_bce_f32: NULL batch pointer or B < 1");
