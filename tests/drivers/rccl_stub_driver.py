@@ -230,6 +230,48 @@ def gpu():
         _launch(dev, "spex_partitioned_propagate_f32", ctypes.byref(st._desc))
         lg = stub.take()
         assert len(lg) == L * 8 and sum(1 for r in lg if r.op == OP["allreduce"]) == 0
+        # ---- the one-call partitioned DUAL-TASK step (spex_partitioned_dual_task_step_f32): 2L exchanges and ONE all-reduce of the
+        #      batch's rows of E^0 and of the propagated table together (4B rows) — no gate-gradient collective; the first exchange's
+        #      table is the kept one (gathered0), the trust branch issues no collective
+        import argparse
+        sys.path.insert(0, os.path.join(REPO, "spex_amd", "dropin"))
+        import utility1.model_expert_s as mex
+        from spex_amd.dist_dual import PartitionedDualTask, PartitionedDualTaskStepper
+
+        class _DS:
+            n_users, m_items = n_user, n_item
+            getSparseGraph = staticmethod(lambda: None)
+        dargs = argparse.Namespace(hiddenSize=64, batchSize=100, nonhybrid=False, nb_heads=3, recdim=64, layer=L, keepprob=0.6, A_split=False,
+                                   dropout=0)
+        torch.manual_seed(1)
+        core = mex.LightGCN(dargs, _DS).to(dev)
+        dmodel = PartitionedDualTask(core, csr, rank, world, dev)        # (its own PartitionedLightGCN; default row bounds)
+        dst = PartitionedDualTaskStepper(dmodel, path_capacity=5, path_len=4, exchange="native-p2p", two_streams=False,
+                                         comm=NativeComm(rank, world, dev, unique_id=bytes(idb.raw)))
+        stub.take()
+        DP = dmodel.P
+        drows = [int(r) for r in DP.part.rows]
+        seq = torch.tensor([[1, 2, n_user, n_user], [3, 4, 5, n_user], [7, n_user, n_user, n_user]], dtype=torch.int64, device=dev)
+        seq_l = torch.tensor([2, 3, 1], dtype=torch.int64, device=dev)
+        tgt = torch.tensor([9, 10, 11], dtype=torch.int64, device=dev)
+        dst.step(users, items, labels, seq, seq_l, tgt)
+        lg = stub.take()
+        reduces = [k for k, r in enumerate(lg) if r.op == OP["allreduce"]]
+        assert len(reduces) == 1 and lg[reduces[0]].count == 4 * B * d and lg[reduces[0]].send == dst.rows.data_ptr(), [(r.op, r.count) for r in lg]
+        before, after = lg[: reduces[0]], lg[reduces[0] + 1:]
+        per = 2 + 3 + 3
+        assert len(before) == L * per and len(after) == L * per, (len(before), len(after))
+        dsend = DP.send.data_ptr()
+        expect_p2p(before[:per], rank, world, drows, DP.part.max_rows, d, dst.arena.data_ptr(), dst.gathered0.data_ptr(), side.cuda_stream)   # E^0 itself -> gathered0
+        for k in range(1, L):
+            expect_p2p(before[k * per:(k + 1) * per], rank, world, drows, DP.part.max_rows, d, dsend, DP.gathered.data_ptr(), side.cuda_stream)
+        expect_p2p(after[:per], rank, world, drows, DP.part.max_rows, d, dst.gs.data_ptr(), DP.gathered.data_ptr(), side.cuda_stream)
+        for k in range(1, L):
+            expect_p2p(after[k * per:(k + 1) * per], rank, world, drows, DP.part.max_rows, d, dsend, DP.gathered.data_ptr(), side.cuda_stream)
+        side.synchronize()
+        assert dst.t == 1 and bool(torch.isfinite(dst.arena).all()) and bool(torch.isfinite(dst.loss_acc).all())
+        DP.native.close()
+        stub.take()
     side.synchronize()
     P.native.close()
     assert [x.op for x in stub.take()] == [OP["destroy"]]

@@ -32,5 +32,7 @@ def test_native_exchange_call_sequence_world_2_4_8_without_a_wire(tmp_path):
 @pytest.mark.gpu
 def test_partitioned_step_call_sequence_world_4_rank_2_on_the_recording_stub(tmp_path):
     """GPU (the step's kernels run for real, the wire is absent): own-slot copy, 2L exchanges + one all-reduce per step, every call
-    on the caller's stream, both exchange forms, the deterministic mode, and a switch of the form between steps."""
+    on the caller's stream, both exchange forms, the deterministic mode, a switch of the form between steps — and the one-call
+    partitioned DUAL-TASK step: 2L exchanges (the first into the kept table, straight from E^0) + ONE all-reduce of 4B rows, no
+    gate-gradient collective."""
     _run("gpu", tmp_path)
