@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -211,7 +212,9 @@ struct spex_graph {
     int64_t partial_cap = 0;      // floats
     // The scratch is the one piece of a handle that launches WRITE.  Calls on one stream are ordered by the stream; a call
     // on another stream first waits (event) for everything queued on the stream that used the scratch last — so two streams
-    // may share a handle (two HOST threads may not: these fields are plain).
+    // may share a handle, and so may two HOST threads: a launch that writes the scratch holds scratch_mu from the ordering
+    // decision until its kernels are queued (otherwise the other thread's event could be recorded in front of them).
+    std::mutex scratch_mu;
     hipStream_t scratch_stream = nullptr;
     bool scratch_used = false;
     hipEvent_t scratch_ev = nullptr;

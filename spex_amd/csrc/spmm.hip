@@ -23,7 +23,7 @@
 //
 // Edge dropout (model.py:46-55) is decided per stored entry while its (col, val) pair is loaded — injected mask byte
 // or Philox draw keyed by the entry's edge id — so forward, backward and all layers of a step drop the same edges.
-#include <atomic>
+#include <mutex>
 
 #include "spex_common.h"
 
@@ -892,8 +892,10 @@ int launch_spmm(const spex_graph *g, const float *X, float *Y, const float *add_
     const dim3 grid((unsigned)blocks), block(kWave * per_block), block4(kWave * kWavesPerBlock);
     spex_timer *tm = g->timer;
     if (tm && tm->open) tm->launches[tm->used]++;
+    std::unique_lock<std::mutex> scratch_lock;   // (held until the launches below are queued)
     if (fast ? g->n_hub > 0 : g->n_long > 0) {   // this launch writes the handle's scratch: order it behind its last user
         spex_graph *gm = const_cast<spex_graph *>(g);
+        scratch_lock = std::unique_lock<std::mutex>(gm->scratch_mu);
         if (gm->scratch_used && gm->scratch_stream != stream) {
             if (!gm->scratch_ev) SPEX_HIP(hipEventCreateWithFlags(&gm->scratch_ev, hipEventDisableTiming));
             SPEX_HIP(hipEventRecord(gm->scratch_ev, gm->scratch_stream));

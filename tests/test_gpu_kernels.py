@@ -1299,6 +1299,44 @@ def test_one_handle_driven_from_two_streams(G):
         assert torch.equal(outs[k], want[k]), k
 
 
+def test_one_handle_driven_from_two_host_threads(G):
+    """The same handle from two HOST threads, each on its own stream (ctypes releases the GIL inside the library call): the launch
+    that writes the handle's scratch holds the handle's mutex from the ordering decision until its kernels are queued, so the two
+    threads' launches interleave in some order but never overlap on the scratch — every product equals the serial one bit for bit
+    (hub rows folded in the launch: partial rows + arrival counters are the shared state)."""
+    import threading
+    rng = np.random.default_rng(78)
+    deg = rng.integers(0, 60, 2000)
+    deg[[3, 500, 1999]] = [3000, 2500, 1100]
+    rowptr, col, val = random_csr(rng, 2000, 4000, deg)
+    g = G(rowptr, col, val, n_cols=4000)
+    Xs = [t(rng.normal(size=(4000, 64)).astype(np.float32)) for _ in range(2)]
+    want = [g.spmm(X).clone() for X in Xs]
+    torch.cuda.synchronize()
+    outs = [[torch.empty(2000, 64, device=DEV) for _ in range(150)] for _ in Xs]
+    errs = []
+
+    def worker(k):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for rep in range(150):
+                    g.spmm(Xs[k], Y=outs[k][rep])
+            st.synchronize()
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for k in range(2):
+        for rep in range(150):
+            assert torch.equal(outs[k][rep], want[k]), (k, rep)
+
+
 # ---------------------------------------------------------------------------------------------- row-sparse backward pieces
 def test_unique_rows_and_push_form_spmm_vs_oracle(G, oracle):
     """spex_unique_rows_i32 + spex_spmm_push_rows_f32: the distinct rows of a batch with repeats (and an out-of-range index),
