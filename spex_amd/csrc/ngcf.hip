@@ -71,6 +71,49 @@ __device__ __forceinline__ bool msg_keep(const MsgDrop &dr, int row, int col)
     return (float)(w >> 8) * 5.9604644775390625e-8f >= dr.p;
 }
 
+// The same decisions for the four rows a lane holds in the accumulator layout (rows row[0..3], column col = 16 b + i16), with ONE
+// Philox evaluation per lane instead of four.  A draw is keyed by (row, col / 4) and yields the four words of columns 4m .. 4m + 3:
+// the four lanes of a quad (i16 = 4m .. 4m + 3: same rows, same column group) used to compute the identical ten rounds each, once per
+// row.  Here quad lane s draws for row[s] and the quad exchanges the words with DPP broadcasts: lane s takes word s (its own column)
+// of the draw made by quad lane q for row[q].  Same mask, bit for bit; the ten rounds are ~40 quarter-rate integer multiplies —
+// ~1.3 us per tile and wave saved.  (row[q] < 0 — an absent slot — yields an unspecified value: callers test the row themselves.)
+__device__ __forceinline__ void msg_keep4(const MsgDrop &dr, const int (&row)[4], int col, bool (&keep)[4])
+{
+#ifdef SPEX_NO_QUAD_PHILOX
+    const bool every_lane_draws = true;
+#else
+    const bool every_lane_draws = false;
+#endif
+    if (dr.mask || every_lane_draws) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) keep[q] = row[q] >= 0 && msg_keep(dr, row[q], col);
+        return;
+    }
+    const int s = (int)(threadIdx.x & 3u);                        // == col & 3 (col = 16 b + i16, i16 = lane & 15)
+    const int my_row = s == 0 ? row[0] : (s == 1 ? row[1] : (s == 2 ? row[2] : row[3]));
+    const uint32_t e = (uint32_t)(my_row - (my_row > dr.pad_row ? 1 : 0)) * 64u + (uint32_t)col;
+    uint32_t c0 = e >> 2, c1 = dr.step, c2 = dr.layer, c3 = 0u, k0 = dr.k0, k1 = dr.k1;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+#define SPEX_QUAD_BCAST(v, q) ((uint32_t)__builtin_amdgcn_mov_dpp((int)(v), (q) * 0x55, 0xF, 0xF, true))
+#define SPEX_KEEP_FROM(q)                                                                                                       \
+    {                                                                                                                           \
+        const uint32_t w0 = SPEX_QUAD_BCAST(c0, q), w1 = SPEX_QUAD_BCAST(c1, q), w2 = SPEX_QUAD_BCAST(c2, q), w3 = SPEX_QUAD_BCAST(c3, q); \
+        const uint32_t w = s == 0 ? w0 : (s == 1 ? w1 : (s == 2 ? w2 : w3));                                                    \
+        keep[q] = (float)(w >> 8) * 5.9604644775390625e-8f >= dr.p;                                                             \
+    }
+    SPEX_KEEP_FROM(0) SPEX_KEEP_FROM(1) SPEX_KEEP_FROM(2) SPEX_KEEP_FROM(3)
+#undef SPEX_KEEP_FROM
+#undef SPEX_QUAD_BCAST
+}
+
 
 // The same layer with FOUR waves per 16-row tile (16-wave workgroups = 4 tiles; the weights are staged once per workgroup):
 // wave b of a tile owns output columns 16b .. 16b+15 — 2 x 16 MFMAs instead of 2 x 64, a quarter of the Philox draws — and
@@ -173,13 +216,15 @@ __global__ __launch_bounds__(kWave * 4 * kFwdTiles) void ngcf_layer_fwd4_kernel(
     }
     // C layout: row 4h + q, column 16b + i16
     float e1[4];
+    bool keep4[4] = {true, true, true, true};
+    if (drop.p > 0.0f) msg_keep4(drop, row_q, 16 * b + i16, keep4);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         float x = acc_g[q] + bias_g, y = acc_b[q] + bias_b;
         x = x >= 0.0f ? x : x * slope;
         y = y >= 0.0f ? y : y * slope;
         float v = x + y;
-        if (drop.p > 0.0f) v = (row_q[q] >= 0 && msg_keep(drop, row_q[q], 16 * b + i16)) ? v * drop.scale : 0.0f;
+        if (drop.p > 0.0f) v = (row_q[q] >= 0 && keep4[q]) ? v * drop.scale : 0.0f;
         e1[q] = v;
         const float sq = row16_sum_f32(v * v);
         if (i16 == 0) s_sq[tl][b][4 * h + q] = sq;
@@ -341,6 +386,11 @@ __global__ __launch_bounds__(kWave *kBwdWaves) __attribute__((amdgpu_waves_per_e
         }
         // ---- elementwise chain on this block's columns; row sums over all 64 columns through LDS
         float e1d[4], kscale[4];
+        bool keep4[4] = {true, true, true, true};
+        if (drop.p > 0.0f) {
+            const int rows4[4] = {r0 + 4 * h, r0 + 4 * h + 1, r0 + 4 * h + 2, r0 + 4 * h + 3};
+            msg_keep4(drop, rows4, 16 * b + i16, keep4);
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r = r0 + 4 * h + q;
@@ -348,7 +398,7 @@ __global__ __launch_bounds__(kWave *kBwdWaves) __attribute__((amdgpu_waves_per_e
             float e = (x >= 0.0f ? x : x * slope) + (y >= 0.0f ? y : y * slope);
             float ks = 1.0f;
             if (drop.p > 0.0f) {
-                ks = (r < n && msg_keep(drop, r, 16 * b + i16)) ? drop.scale : 0.0f;
+                ks = (r < n && keep4[q]) ? drop.scale : 0.0f;
                 e = ks != 0.0f ? e * ks : 0.0f;
             }
             kscale[q] = ks;
@@ -660,13 +710,15 @@ __global__ __launch_bounds__(kWave *kBwdWaves) void ngcf_layer_bwd_rows4_kernel(
     }
     // ---- elementwise chain on this block's columns; row sums over all 64 columns through LDS
     float e1d[4], kscale[4];
+    bool keep4[4] = {true, true, true, true};
+    if (drop.p > 0.0f) msg_keep4(drop, row_q, 16 * b + i16, keep4);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float x = acc_g[q] + bias_g, y = acc_b[q] + bias_b;
         float e = (x >= 0.0f ? x : x * slope) + (y >= 0.0f ? y : y * slope);
         float ks = 1.0f;
         if (drop.p > 0.0f) {
-            ks = (row_q[q] >= 0 && msg_keep(drop, row_q[q], 16 * b + i16)) ? drop.scale : 0.0f;
+            ks = (row_q[q] >= 0 && keep4[q]) ? drop.scale : 0.0f;
             e = ks != 0.0f ? e * ks : 0.0f;
         }
         kscale[q] = ks;

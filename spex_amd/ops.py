@@ -39,10 +39,18 @@ def _score_bce_table_grad(light_out, n_u, u_idx, i_idx, labels, need_grad):
     rows added in slot order."""
     B = u_idx.numel()
     grad = torch.zeros_like(light_out) if need_grad else None
-    if need_grad and DETERMINISTIC and light_out.shape[1] == 64:
-        slots = torch.empty((2 * B, 64), dtype=torch.float32, device=light_out.device)
+    W = light_out.shape[1]
+    if need_grad and DETERMINISTIC and W % 64 == 0:
+        slots = torch.empty((2 * B, W), dtype=torch.float32, device=light_out.device)
         _, loss_sum = score_bce(light_out[:n_u], light_out[n_u:], u_idx, i_idx, labels, None, None, 1.0 / B, grad_slots=slots)
-        reduce_slots(u_idx, i_idx, n_u, light_out.shape[0], slots, grad)
+        if W == 64:
+            reduce_slots(u_idx, i_idx, n_u, light_out.shape[0], slots, grad)
+        else:       # NGCF's concatenated table [N, 64 (L + 1)]: one 64-column block at a time (a validation mode, not a fast path)
+            tmp = torch.empty((light_out.shape[0], 64), dtype=torch.float32, device=light_out.device)
+            for c in range(0, W, 64):
+                tmp.zero_()
+                reduce_slots(u_idx, i_idx, n_u, light_out.shape[0], slots[:, c:c + 64], tmp)
+                grad[:, c:c + 64] = tmp
         return loss_sum, grad
     _, loss_sum = score_bce(light_out[:n_u], light_out[n_u:], u_idx, i_idx, labels, grad[:n_u] if need_grad else None,
                             grad[n_u:] if need_grad else None, 1.0 / B)

@@ -273,14 +273,40 @@ def test_whole_ngcf_run_matches_the_reference_small(golden, ngcf_data_root):
     """G12-NGCF: three epochs on the 300-user graph — same sampler stream, same first batch, same per-step losses, same
     loss sums, same recall / ndcg after every epoch, same trained weights as the reference run (message dropout on,
     masks from the shared counter-based generator)."""
+    from spex_amd import ops
     g = golden("ngcf_small_epochs")
-    model = _run_reference_loop("small", 3, g, ngcf_data_root)
+    # in the deterministic accumulation mode: the module's scoring backward then adds its per-sample rows in slot order, the dense layer
+    # backward has had no float atomic since round 4, the products never had any — the run is a function of the seeds, so this
+    # test either holds or does not (with the scoring's float atomics the final weights of this scale-invariant model landed on
+    # either side of the 1e-4 line from run to run: ~1 in 4 runs failed at 9e-4)
+    ops.set_deterministic(True)
+    try:
+        model = _run_reference_loop("small", 3, g, ngcf_data_root)
+    finally:
+        ops.set_deterministic(False)
     sd = model.state_dict()
     assert rel_err(sd["user_embedding.weight"].cpu().numpy(), g["user_w"]) <= 5e-5
     assert rel_err(sd["item_embedding.weight"].cpu().numpy(), g["item_w"]) <= 5e-5
     for k in g.files:
         if k.startswith("final_"):
             assert rel_err(sd[k[6:].replace("__", ".")].cpu().numpy(), g[k]) <= 1e-4, k
+
+
+def test_ngcf_module_run_repeats_bit_for_bit_in_the_deterministic_mode(golden, ngcf_data_root):
+    """The three epochs of the small run through the MODULE (autograd over the HIP kernels, torch Adam) twice under ops.set_deterministic:
+    identical parameters, bit for bit — the scoring backward adds its per-sample rows in slot order (every 64-column block of NGCF's
+    concatenated table), the dense layer backward adds its workgroups' weight-gradient blocks in block order (no float atomic since
+    round 4), the SpMM products are one fmaf chain per element."""
+    from spex_amd import ops
+    g = golden("ngcf_small_epochs")
+    ops.set_deterministic(True)
+    try:
+        a = {k: v.clone() for k, v in _run_reference_loop("small", 3, g, ngcf_data_root).state_dict().items()}
+        b = _run_reference_loop("small", 3, g, ngcf_data_root).state_dict()
+    finally:
+        ops.set_deterministic(False)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
 
 
 def test_on_device_ngcf_epochs_match_the_reference_small(golden, ngcf_data_root):
@@ -609,7 +635,7 @@ def test_deep_one_call_step_equals_the_launch_by_launch_step(golden, ngcf_data_r
             assert (getattr(st, "_deep_desc", None) is not None) == native and st.t == 4 and model.dropout_step == 4
             res.append((losses, {n: p.detach().clone() for n, p in model.named_parameters()}))
         (l_a, p_a), (l_b, p_b) = res
-        assert np.abs(np.asarray(l_a) - np.asarray(l_b)).max() <= 2e-4, (l_a, l_b)        # loss SUMS over 256 samples (~177)
+        assert np.abs(np.asarray(l_a) - np.asarray(l_b)).max() <= 2e-3, (l_a, l_b)        # differences of a running fp32 sum near 1 700: ulp 1.2e-4
         for n in p_a:
             dv = (p_a[n] - p_b[n]).abs()
             assert float(dv.mean()) <= 2e-6 and float(dv.max()) <= 1e-3 + 1e-7, (layers, n, float(dv.mean()), float(dv.max()))
