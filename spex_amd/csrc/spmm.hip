@@ -292,20 +292,34 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
     int row = t.z;
     float acc = 0.0f;
 
+    // v / div for a wave-uniform divisor, as REAL branches: written `if (div != 1.0f) v = v / div;` the compiler computes the quotient
+    // always and selects (an fp32 division is ~11 vector instructions; two per emitted row in the backward form — 0.4 M of the launch's
+    // 3 M vector instructions on Epinion2, spent on divisors that are 1.0 in most launches).  A power-of-two divisor (L + 1 = 4: the
+    // reference's depth) is one exact multiply — x / 2^k == x * 2^-k bit for bit.  (The empty asm keeps each arm from being speculated.)
+    const float epi_inv = 1.0f / epi_div, out_inv = 1.0f / out_div;      // (once per wave; exact for a power of two)
+    auto scaled = [](float v, float div, float inv) {
+        if (div != 1.0f) {
+            if ((__float_as_uint(div) & 0x007FFFFFu) == 0u) {
+                v = v * inv;
+                asm volatile("" : "+v"(v));
+            } else {
+                v = v / div;
+                asm volatile("" : "+v"(v));
+            }
+        }
+        return v;
+    };
     auto emit = [&](int r, float y, float e) {
         const size_t o = (size_t)r * 64 + lane;
         // outputs are streamed (non-temporal): they should not evict the gather source from the XCD's L2
         if (EPI == 0) {
             __builtin_nontemporal_store(y, Y + o);
         } else if (EPI == 1) {
-            float s = e + y;
-            if (epi_div != 1.0f) s = s / epi_div;
+            const float s = scaled(e + y, epi_div, epi_inv);
             if (Y) __builtin_nontemporal_store(y, Y + o);     // both stores after the last use of a loaded value
             __builtin_nontemporal_store(s, acc_out + o);
         } else {
-            if (epi_div != 1.0f) e = e / epi_div;
-            float s = y + e;
-            if (out_div != 1.0f) s = s / out_div;
+            const float s = scaled(y + scaled(e, epi_div, epi_inv), out_div, out_inv);
             __builtin_nontemporal_store(s, Y + o);
         }
     };
@@ -392,27 +406,30 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
             if (dropped) my_off = kept_lanes ? stand_in : own_off;
         }
         if (lane < nc) my_mask = __builtin_nontemporal_load(chunk_mask + t.x + sc + lane);
+        float ep[kChunk];
+#pragma unroll
+        for (int u = 0; u < kChunk; ++u) ep[u] = 0.0f;
         for (int c = 0; c < nc; ++c) {
             const uint32_t mask = (uint32_t)__builtin_amdgcn_readlane((int)my_mask, c);
             const uint32_t dbits = MASKED ? (uint32_t)(drop_bits >> (c * kChunk)) & 0xFFFFu : 0u;
-            float x[kChunk], ep[kChunk];
+            float x[kChunk];
 #pragma unroll
             for (int u = 0; u < kChunk; ++u)
                 x[u] = Xl[(size_t)(uint32_t)__builtin_amdgcn_readlane((int)my_off, c * kChunk + u) * 64];
+            // (ep[] lives ACROSS the chunks — declared in front of the loop — and is written only where a row ends: an entry that ends
+            //  no row keeps whatever the register held, which nothing reads.  Defined per chunk, every such entry cost a v_mov to
+            //  zero it, and a chunk without any row end sixteen of them plus the register shuffles of the join: ~0.6 M of the
+            //  1.0 M vector instructions the epilogue forms issue beyond the plain form's 2.1 M on Epinion2)
             if (EPI != 0 && mask != 0u) {
                 int r = row;
 #pragma unroll
                 for (int u = 0; u < kChunk; ++u) {
-                    ep[u] = 0.0f;
                     if (mask & (1u << u)) {
                         const int rr = ROWIDS ? __builtin_amdgcn_readlane(my_row, c * kChunk + u) : r;
                         ep[u] = SPEX_EPI_LOAD(El + (size_t)rr * 64);
                         ++r;
                     }
                 }
-            } else {
-#pragma unroll
-                for (int u = 0; u < kChunk; ++u) ep[u] = 0.0f;
             }
             // A chunk that ends rows waits for ALL of its loads here, once.  gfx9 counts loads and stores in one vmcnt and the
             // compiler re-derives its waits at every control-flow join: without this, the wait for a row's epilogue operand
