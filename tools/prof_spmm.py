@@ -9,6 +9,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if os.environ.get("SPEX_LIB"):
+    from spex_amd import _lib as _l
+    _l.LIB_PATH = os.path.abspath(os.environ["SPEX_LIB"])          # A/B against another build of the library
 from spex_amd.datasets import load_epinion2, scaled_graph  # noqa: E402
 from spex_amd.graph import SpexGraph, lightgcn_norm_adj  # noqa: E402
 
