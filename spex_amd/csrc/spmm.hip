@@ -436,6 +436,15 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_chunk_kernel(
             // (loaded under the mask's branches) became `s_waitcnt vmcnt(0)` placed AFTER the previous row's stores were
             // issued, i.e. every emitted row waited out its predecessor's store round trip.
             if (EPI != 0) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0); expcnt / lgkmcnt unconstrained
+            if (EPI == 0 && mask == 0u) {   // no row ends in this chunk (about every second chunk on Epinion2): sixteen fmafs, no per-entry
+                                           // test (plain form only: in the epilogue forms the second copy of the loop costs the 65th VGPR)
+#pragma unroll
+                for (int u = 0; u < kChunk; ++u) {
+                    const float xv = (MASKED && (dbits & (1u << u))) ? 0.0f : x[u];
+                    acc = fmaf(lane_bcast(my_val, c * kChunk + u), xv, acc);
+                }
+                continue;
+            }
 #pragma unroll
             for (int u = 0; u < kChunk; ++u) {
                 const float xv = (MASKED && (dbits & (1u << u))) ? 0.0f : x[u];     // a dropped entry contributes nothing
