@@ -281,7 +281,10 @@ int spex_ngcf_layer_f32(const float *ego, const float *side, const float *W_gc, 
  * ld_direct; layer 0 only, else NULL).  Writes, for every row,
  *   g_side = d loss / d side   and   g_ego = the part of d loss / d ego that does not pass through side (+ g_direct);
  * the caller completes d loss / d ego = g_ego + A^T g_side with spex_spmm_f32(A^T, g_side, add_in = g_ego).
- * gW_gc, gb_gc, gW_bi, gb_bi ([d,d], [d]) are ACCUMULATED with atomics: zero them first.
+ * gW_gc, gb_gc, gW_bi, gb_bi ([d,d], [d]) are ACCUMULATED (zero them first) — since ABI 5 without a float atomic: every workgroup
+ * leaves its share as one block of a per-(device, stream) scratch the library keeps, and a second small launch adds the blocks to
+ * the four arrays in block order (deterministic; plain read-modify-write: two calls that accumulate into the SAME arrays must be
+ * ordered, e.g. on one stream).  The scratch is allocated on the first call at a size (not inside a stream capture).
  * Rows whose upstream gradients are all zero (after a 256-sample batch: most) cost a read and two zero rows.
  */
 int spex_ngcf_layer_bwd_f32(const float *ego, const float *side, const float *W_gc, const float *b_gc, const float *W_bi,
