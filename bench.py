@@ -540,7 +540,7 @@ def main():
     # reset right before the timed region, so that nothing but a synchronisation separates the warm-up from the K steps:
     # a gap of tens of milliseconds there (it used to hold a 40 ms garbage collection) lets the GPU clock down and made
     # a 20-step timed region read 8 us per step slower than a 200-step one.
-    every = max(10, a.steps // 100) * (1 if not part else L)      # (K = 20: brackets around the propagations of steps 0 and 10)
+    every = max(5, a.steps // 100) * (1 if not part else L)
     graph.attach_timer(128, every=every)
     for _ in range(a.warmup):
         step()
