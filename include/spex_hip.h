@@ -123,6 +123,17 @@ int spex_spmm_f32(const spex_graph_t *g, const float *X, float *Y, const float *
 int spex_spmm_rowlist_f32(const spex_graph_t *g, const float *X, const int64_t *idx_a, int32_t n_a, int64_t off_a,
                           const int64_t *idx_b, int32_t n_b, int64_t off_b, float *Y, const float *acc_in, float *acc_out,
                           float acc_div, int32_t d, void *stream);
+/* The same rows on a ROW PARTITION (d == 64; the partitioned steps' last forward layer, model.py:91-97 at the rows of model.py:115-116):
+ * slot k names position pos[k] of the padded global layout; `g` is the rank's block (n_local rows) and lo the rank's first position.
+ * For a slot the rank owns (r = pos[k] - lo in [0, n_local)):
+ *   out_prop[k] = (acc_in[r] [+ acc2[r] [+ acc3[r]]] + (A X)[r]) / acc_div  (the row-list kernel's order of sums; acc2 / acc3: further
+ *                 layer tables, NULL = absent),   out_raw[k] = raw[r]  (if out_raw)
+ * and ZEROS for every other slot: out_prop / out_raw ([n, 64], compact) are the operands of the owner-computes all-reduce
+ * (spex_comm_allreduce_sum_f32) that leaves the batch's rows on every rank.  One launch instead of a whole-block product + two
+ * spex_gather_owned_rows_f32. */
+int spex_spmm_owned_rows_f32(const spex_graph_t *g, const float *X, const int64_t *pos, int32_t n, int64_t lo, const float *acc_in,
+                             const float *acc2, const float *acc3, float acc_div, const float *raw, float *out_prop, float *out_raw,
+                             int32_t d, void *stream);
 
 /* Whole LightGCN.computer(), utility1/model.py:66-97, for a graph held entirely on this device (n_rows == n_cols):
  *   E^{l+1} = A E^l (l < L);  mean_out = (E^0 + ... + E^L) / (L+1).
@@ -845,10 +856,13 @@ int spex_comm_allreduce_sum_f32(spex_comm_t *comm, float *buf, int64_t n, void *
  *     rank owns added into its gradient block (spex_scatter_add_owned_rows_f32 — or, with SPEX_STEP_DETERMINISTIC, per-sample
  *     rows added in slot order by spex_reduce_slots_f32); backward G_l = g / (L+1) + A^T G_{l+1} as L x (exchange, SpMM on the
  *     block of A^T); Adam on the rank's rows.  2 L exchanges + 1 small all-reduce per step, no host work between launches.
+ *   Every exchange is IN PLACE: a layer's SpMM writes its output into the rank's own slot (rows rank * max_rows ..) of the table the
+ *   next exchange completes (gathered and gathered1 alternate), so no send buffer and no copy of a layer's rows exist (before: 2 L
+ *   staging copies per step).
  * pos: device int64 [2B] — the batch's rows in the padded gathered layout (users, then items): owner(r) * max_rows + r - r_owner.
  * The batch is replicated on every rank; every rank accumulates the same loss sum into its own *loss_sum.
  * Buffers (caller-owned): E0, m, v, light_out, g_local, gs, grad_E0: [n_local, 64] (g_local all-zero before the first call;
- * every call leaves it so); send: [max_rows, 64]; gathered: [world * max_rows, 64]; rows, grad_rows: [slot_capacity, 64] with
+ * every call leaves it so); gathered, gathered1: [world * max_rows, 64] each (two tables); rows, grad_rows: [slot_capacity, 64] with
  * slot_capacity >= 2B (grad_rows all-zero before the first call); arange: device int64 [slot_capacity] = 0, 1, 2, ...
  * graph / graph_t: this rank's row blocks (n_local rows, world * max_rows columns).  d == 64, L >= 1, no edge dropout. */
 typedef struct spex_partitioned_step {
@@ -856,7 +870,7 @@ typedef struct spex_partitioned_step {
     spex_comm_t *comm;
     const int32_t *rows_per_rank;      /* host [world], or NULL: see spex_comm_allgather_rows_f32 */
     float *E0, *m, *v;
-    float *light_out, *g_local, *gs, *grad_E0, *send, *gathered, *rows, *grad_rows;
+    float *light_out, *g_local, *gs, *grad_E0, *gathered1, *gathered, *rows, *grad_rows;
     const int64_t *arange;
     int32_t n_local, max_rows, slot_capacity, L, d;
     float lr, beta1, beta2, eps;
@@ -884,10 +898,21 @@ int spex_partitioned_step_bce_f32(spex_partitioned_step_t *step, const int64_t *
  *                task_weights 2]: owner-computes on the table rows (the rank's user rows take the trust head's table gradient at
  *                rows user_lo ..), replicated — identical gradients, identical updates — on the dense parameters; the task
  *                precisions and the task weights' own gradients as in spex_dual_task_step_f32.
- * 2 L exchanges + 1 all-reduce per step.  flags: SPEX_STEP_DETERMINISTIC (owned rows added in slot order, no float atomics),
- * SPEX_STEP_FIXED_TASK_WEIGHTS.  d == 64, L >= 1, no edge dropout.
+ * 2 L exchanges + 1 all-reduce per step, every exchange in place (see spex_partitioned_step_t).  flags: SPEX_STEP_DETERMINISTIC (owned
+ * rows added in slot order, no float atomics), SPEX_STEP_FIXED_TASK_WEIGHTS.  d == 64, L >= 1, no edge dropout.
+ * FAST PATH (graph_push and gathered2 given, L >= 2, not deterministic) — spex_dual_task_step_f32's schedule on the partition:
+ *   forward layers 1 .. L-1 over the block (plain form for L <= 3), the LAST layer at the batch's rows only, on their owners
+ *   (spex_spmm_owned_rows_f32: layer mean + raw rows, zeros elsewhere) -> the one all-reduce of 4B rows -> gate, scores, BCE, the
+ *   gate's backward and the owner-computes adds in ONE launch on the replicated compact rows -> the backward's FIRST product in push
+ *   form WITHOUT an exchange (every rank holds all 2B gradient rows and pushes them through graph_push = its own columns of A) ->
+ *   L - 1 pull-form products on A^T's block.  2 L - 1 exchanges + 1 all-reduce; 2 L - 2 whole-block launches instead of 2 L and
+ *   three batch-sized launches instead of nine.
+ *   graph_push: handle of the (world * max_rows) x n_local matrix whose row p holds the entries A[p, c] for the columns c the rank
+ *   owns (local column indices) — the transpose of the rank's block of A^T; gathered2 [world * max_rows, 64]: its own slot is the
+ *   push target, all-zero before the first call (the Adam pass leaves it so).  gathered2 NULL: the launch-by-launch schedule above —
+ *   the same choice on EVERY rank (the two schedules differ in their collectives); a rank without rows passes graph_push = NULL.
  * Buffers (caller-owned): params / m / v: the arena above; light, g_prop, g_raw, gs, g_E0: [n_local, 64] (g_prop, g_raw all-zero
- * before the first call; every call leaves them so); send [max_rows, 64]; gathered, gathered0 [world * max_rows, 64];
+ * before the first call; every call leaves them so); gathered, gathered1, gathered0 [world * max_rows, 64] (three tables);
  * rows [2 * slot_capacity, 64]; mixed_slots, grad_slots, g_prop_slots, g_raw_slots [slot_capacity, 64], slot_capacity >= 2B;
  * loss_rows [slot_capacity]; att_parts [spex_expert_gate_rows_bwd_parts(slot_capacity) * 512]; arange int64 [slot_capacity];
  * g_user [n_user_rows, 64]; g_small [P + 512] (all-zero before the first call); a2, trust_ws, dscore, loss_b, loss [2],
@@ -898,7 +923,7 @@ typedef struct spex_partitioned_dual_step {
     spex_comm_t *comm;
     const int32_t *rows_per_rank;
     float *params, *m, *v;
-    float *light, *g_prop, *g_raw, *gs, *g_E0, *send, *gathered, *gathered0;
+    float *light, *g_prop, *g_raw, *gs, *g_E0, *gathered1, *gathered, *gathered0;
     const int64_t *user_pos;
     float *user_table;
     float *rows, *mixed_slots, *grad_slots, *g_prop_slots, *g_raw_slots, *loss_rows, *att_parts;
@@ -913,6 +938,8 @@ typedef struct spex_partitioned_dual_step {
     void *side_stream, *ev_fork, *ev_join;   /* optional second stream + the library's event cells (zero-initialise; release with
                                               * spex_step_events_release) */
     int32_t flags;
+    const spex_graph_t *graph_push;          /* fast path (see above); NULL: the launch-by-launch schedule */
+    float *gathered2;
 } spex_partitioned_dual_step_t;
 int spex_partitioned_dual_task_step_f32(spex_partitioned_dual_step_t *step, const int64_t *pos, const float *labels, int32_t B,
                                         const int64_t *seq, const int64_t *seq_l, const int64_t *targets, int32_t T, void *stream);

@@ -25,6 +25,7 @@ SIGNATURES = {
     "spex_spmm_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_f32, c_i32, c_vp]),
     "spex_spmm_rowlist_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_vp, c_vp, c_vp, c_f32, c_i32,
                                              c_vp]),
+    "spex_spmm_owned_rows_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "spex_propagate_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "spex_propagate_bwd_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "spex_score_bce_f32": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i64, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp,
@@ -177,7 +178,7 @@ class DualTaskStepDesc(ctypes.Structure):
 class PartitionedStepDesc(ctypes.Structure):
     """spex_partitioned_step_t (include/spex_hip.h)."""
     _fields_ = ([(n, c_vp) for n in ("graph", "graph_t", "comm", "rows_per_rank", "E0", "m", "v", "light_out", "g_local", "gs", "grad_E0",
-                                     "send", "gathered", "rows", "grad_rows", "arange")]
+                                     "gathered1", "gathered", "rows", "grad_rows", "arange")]
                 + [(n, c_i32) for n in ("n_local", "max_rows", "slot_capacity", "L", "d")]
                 + [(n, c_f32) for n in ("lr", "beta1", "beta2", "eps")] + [("t", c_i32), ("flags", c_i32)])
 
@@ -185,13 +186,14 @@ class PartitionedStepDesc(ctypes.Structure):
 class PartitionedDualStepDesc(ctypes.Structure):
     """spex_partitioned_dual_step_t (include/spex_hip.h)."""
     _fields_ = ([(n, c_vp) for n in ("graph", "graph_t", "comm", "rows_per_rank", "params", "m", "v", "light", "g_prop", "g_raw", "gs", "g_E0",
-                                     "send", "gathered", "gathered0", "user_pos", "user_table", "rows", "mixed_slots", "grad_slots",
+                                     "gathered1", "gathered", "gathered0", "user_pos", "user_table", "rows", "mixed_slots", "grad_slots",
                                      "g_prop_slots", "g_raw_slots", "loss_rows", "att_parts", "arange", "g_user", "g_small", "a2", "trust_ws",
                                      "dscore", "loss_b", "loss", "loss_acc", "precision")]
                 + [(n, c_i32) for n in ("n_local", "max_rows", "n_local_users", "user_lo", "slot_capacity", "path_capacity", "path_len",
                                         "n_user_rows", "L", "d", "n_heads", "hybrid", "n_rec")]
                 + [(n, c_f32) for n in ("lr", "beta1", "beta2", "eps")] + [("t", c_i32)]
-                + [(n, c_vp) for n in ("side_stream", "ev_fork", "ev_join")] + [("flags", c_i32)])
+                + [(n, c_vp) for n in ("side_stream", "ev_fork", "ev_join")] + [("flags", c_i32)]
+                + [(n, c_vp) for n in ("graph_push", "gathered2")])
 
 
 COMM_ID_BYTES = 128             # spex_hip.h: SPEX_COMM_ID_BYTES

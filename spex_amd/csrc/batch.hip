@@ -544,6 +544,62 @@ __global__ __launch_bounds__(kWave *kWgWaves) void gated_batch_push_kernel(
     }
 }
 
+
+// The dual-task rec branch's batch-sized middle on a ROW PARTITION (comm.hip: spex_partitioned_dual_task_step_f32, fast path): the
+// batch's rows arrive COMPACT and complete on every rank (rows_raw / rows_prop [2B, 64]: slot b = sample b's user row, slot B + b
+// its item row — the owner-computes all-reduce behind spex_spmm_owned_rows_f32), so gate, score, loss and the gate's backward are
+// gated_batch_push_kernel's steps 2-3 on them, operand for operand, computed REDUNDANTLY by every rank (two waves per sample): the
+// loss and the two gate matrices' gradients are therefore complete everywhere without a collective.  What leaves:
+//   g_prop_slots[slot] = d loss / d propagated row (plain store; every rank pushes every slot through ITS columns of A afterwards)
+//   and, for a slot whose row this rank owns (lo <= pos[slot] < lo + n_local; r = pos[slot] - lo):
+//   P[r] += push_scale * d_prop  (the g term of (g + A^T g) / (L+1)),  g_raw[r] += d_raw,  g_prop[r] += d_prop (if g_prop)
+__global__ __launch_bounds__(2 * kWave) void gated_rows_train_kernel(
+    const float *__restrict__ rows_raw, const float *__restrict__ rows_prop, const float *__restrict__ att_u,
+    const float *__restrict__ att_i, const int64_t *__restrict__ pos, int64_t lo, int n_local, const float *__restrict__ labels, int B,
+    float grad_scale, float push_scale, float *loss_sum, float *__restrict__ g_prop_slots, float *g_prop, float *P, float *g_raw,
+    float *g_att, int n_att_copies)
+{
+    __shared__ float s_mixed[2][kWave];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int b = blockIdx.x;
+    const size_t slot = (size_t)wave * B + b;
+    const float y_lab = labels[b];
+    const float *att = wave ? att_i : att_u;
+    const float a_raw = rows_raw[slot * kWave + lane], s = rows_prop[slot * kWave + lane];
+    const float w00 = att[2 * lane], w01 = att[2 * lane + 1], w10 = att[2 * (kWave + lane)], w11 = att[2 * (kWave + lane) + 1];
+    const int64_t r64 = pos[slot] - lo;
+    float z0 = fmaf(s, w10, fmaf(a_raw, w00, 0.0f)), z1 = fmaf(s, w11, fmaf(a_raw, w01, 0.0f));
+    z0 = wave_sum_f32(z0);
+    z1 = wave_sum_f32(z1);
+    const float mx = fmaxf(z0, z1);
+    const float e0 = expf(z0 - mx), e1 = expf(z1 - mx);
+    const float a0 = e0 / (e0 + e1), a1 = e1 / (e0 + e1);
+    s_mixed[wave][lane] = a_raw * a0 + s * a1;
+    __syncthreads();
+    const float mu = s_mixed[0][lane], mi = s_mixed[1][lane];
+    const float x = wave_sum_f32(fmaf(mu, mi, 0.0f));
+    const float dg = (sigmoid_f(x) - y_lab) * grad_scale;
+    const float gg = dg * (wave ? mu : mi);
+    const float da0 = wave_sum_f32(gg * a_raw), da1 = wave_sum_f32(gg * s);
+    const float dot = a0 * da0 + a1 * da1;
+    const float dz0 = a0 * (da0 - dot), dz1 = a1 * (da1 - dot);
+    const float d_raw = a0 * gg + dz0 * w00 + dz1 * w01, d_prop = a1 * gg + dz0 * w10 + dz1 * w11;
+    g_prop_slots[slot * kWave + lane] = d_prop;
+    if (r64 >= 0 && r64 < n_local) {                                   // wave-uniform: the rows this rank owns
+        const size_t o = (size_t)r64 * kWave + lane;
+        if (g_prop) atomicAdd(g_prop + o, d_prop);
+        atomicAdd(P + o, push_scale * d_prop);
+        atomicAdd(g_raw + o, d_raw);
+    }
+    float *ga = g_att + (size_t)(b % n_att_copies) * 512 + wave * 256;   // (copies: see gated_batch_push_kernel)
+    atomicAdd(ga + 2 * lane, fmaf(a_raw, dz0, 0.0f));
+    atomicAdd(ga + 2 * lane + 1, fmaf(a_raw, dz1, 0.0f));
+    atomicAdd(ga + 2 * (kWave + lane), fmaf(s, dz0, 0.0f));
+    atomicAdd(ga + 2 * (kWave + lane) + 1, fmaf(s, dz1, 0.0f));
+    if (wave == 0 && lane == 0) atomicAdd(loss_sum, fmaxf(x, 0.0f) - x * y_lab + log1pf(expf(-fabsf(x))));
+}
+
 }  // namespace
 
 static spex::EdgeDrop edge_drop_of(const spex_graph_t *g)
@@ -685,6 +741,21 @@ int spex::lightgcn_batch_layers(const spex_graph_t *g, const float *X, const flo
     hipLaunchKernelGGL(lightgcn_batch_kernel<true>, dim3((unsigned)B * parts), dim3(kWave * kWgWaves), 0, (hipStream_t)stream, g->rowptr,
                        g->col, g->val, g->n_rows, n_user_rows, X, acc_in, acc_div, users, items, labels, parts, grad_scale, push_scale,
                        loss_sum, loss_per_sample, g_out, G, runs_per_part, nullptr, B, acc2, acc3, edge_drop_of(g));
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}
+
+int spex::gated_rows_train(const float *rows_raw, const float *rows_prop, const float *att_u, const float *att_i, const int64_t *pos,
+                           int64_t lo, int32_t n_local, const float *labels, int32_t B, float grad_scale, float push_scale, float *loss_sum,
+                           float *g_prop_slots, float *g_prop, float *P, float *g_raw, float *g_att, int32_t n_att_copies, void *stream)
+{
+    SPEX_CHECK_ARG(rows_raw && rows_prop && att_u && att_i && pos && labels && loss_sum && g_prop_slots && P && g_raw && g_att,
+                   "gated_rows_train: NULL argument");
+    SPEX_CHECK_ARG(B >= 0 && n_local >= 0 && n_att_copies >= 1, "gated_rows_train: B=%d n_local=%d n_att_copies=%d", B, n_local, n_att_copies);
+    SPEX_CHECK_ARG(P != g_prop && P != g_raw && g_prop != g_raw, "gated_rows_train: g_prop, P and g_raw are three tables");
+    if (B == 0) return SPEX_OK;
+    hipLaunchKernelGGL(gated_rows_train_kernel, dim3((unsigned)B), dim3(2 * kWave), 0, (hipStream_t)stream, rows_raw, rows_prop, att_u, att_i,
+                       pos, lo, n_local, labels, B, grad_scale, push_scale, loss_sum, g_prop_slots, g_prop, P, g_raw, g_att, n_att_copies);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }

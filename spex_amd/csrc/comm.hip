@@ -232,8 +232,9 @@ extern "C" int spex_comm_allreduce_sum_f32(spex_comm_t *c, float *buf, int64_t n
 
 static int check_step(const spex_partitioned_step_t *s, const char *who)
 {
-    SPEX_CHECK_ARG(s && s->graph && s->graph_t && s->comm && s->E0 && s->light_out && s->send && s->gathered,
+    SPEX_CHECK_ARG(s && s->graph && s->graph_t && s->comm && s->E0 && s->light_out && s->gathered && s->gathered1,
                    "%s: NULL field in the step descriptor", who);
+    SPEX_CHECK_ARG(s->gathered != s->gathered1, "%s: gathered and gathered1 are two tables", who);
     SPEX_CHECK_ARG(s->d == 64 && s->L >= 1 && s->n_local >= 0 && s->n_local <= s->max_rows, "%s: d=%d L=%d n_local=%d max_rows=%d", who, s->d,
                    s->L, s->n_local, s->max_rows);
     SPEX_CHECK_ARG(s->graph->n_rows == s->n_local && s->graph_t->n_rows == s->n_local
@@ -243,30 +244,39 @@ static int check_step(const spex_partitioned_step_t *s, const char *who)
     return SPEX_OK;
 }
 
-// one exchange: the rank's rows (already in `send`, or copied there) -> the gathered table
-static int exchange(const spex_partitioned_step_t *s, const float *local, void *stream)
+// One exchange IN PLACE: the rank's rows lie in their own slot of `table` (rows rank * max_rows ..) — the SpMM that produced them wrote
+// them there — or are copied there from `local` first; the peers' rows arrive in the other slots.  No staging buffer and, for a layer's
+// output, no copy: the collective sends from the slot it also receives around (ncclAllGather's in-place form; the point-to-point form
+// sends the real rows from where they lie).  Round 3 wrote every layer into a send buffer and copied it into the slot: 2 L + 1 copies
+// of the rank's rows per step.
+static int exchange_in_place(spex_comm_t *comm, const int32_t *rows_per_rank, const float *local, int64_t n_local, int64_t max_rows, int32_t d,
+                             float *table, void *stream)
 {
-    // (the real-rows form sends straight from the rows where they lie; the equal-shard form reads max_rows rows, so a shorter
-    //  shard is staged in the padded send buffer first)
-    if (s->rows_per_rank || s->n_local == s->max_rows)
-        return spex_comm_allgather_rows_f32(s->comm, local, s->gathered, s->max_rows, s->d, s->rows_per_rank, stream);
-    if (int rc = copy_f32(s->send, local, (size_t)s->n_local * s->d, stream)) return rc;
-    return spex_comm_allgather_rows_f32(s->comm, s->send, s->gathered, s->max_rows, s->d, s->rows_per_rank, stream);
+    float *own = table + (size_t)comm->rank * max_rows * d;
+    if (local && local != own)
+        if (int rc = copy_f32(own, local, (size_t)n_local * d, stream)) return rc;
+    return spex_comm_allgather_rows_f32(comm, own, table, max_rows, d, rows_per_rank, stream);
+}
+
+static inline float *own_slot(const spex_comm_t *comm, float *table, int64_t max_rows, int32_t d)
+{
+    return table + (size_t)comm->rank * max_rows * d;
 }
 
 extern "C" int spex_partitioned_propagate_f32(spex_partitioned_step_t *s, void *stream)
 {
     SPEX_TRY(check_step(s, "spex_partitioned_propagate_f32"));
     if (s->n_local == 0 && s->comm->world == 1) return SPEX_OK;
-    const float *cur = s->E0;
+    float *T[2] = {s->gathered, s->gathered1};
     for (int32_t l = 0; l < s->L; ++l) {
-        SPEX_TRY(exchange(s, cur, stream));
+        // layer l reads T[l & 1] (its own slot: E^0 copied in for l == 0, the previous layer's output otherwise) and writes its output
+        // into the own slot of the other table
+        SPEX_TRY(exchange_in_place(s->comm, s->rows_per_rank, l == 0 ? s->E0 : nullptr, s->n_local, s->max_rows, s->d, T[l & 1], stream));
         const bool last = l == s->L - 1;
-        float *nxt = last ? nullptr : s->send;                       // the next layer's exchange source, written in place
+        float *nxt = last ? nullptr : own_slot(s->comm, T[(l + 1) & 1], s->max_rows, s->d);
         if (s->n_local)
-            SPEX_TRY(spex_spmm_f32(s->graph, s->gathered, nxt, nullptr, 1.0f, l == 0 ? s->E0 : s->light_out, s->light_out,
+            SPEX_TRY(spex_spmm_f32(s->graph, T[l & 1], nxt, nullptr, 1.0f, l == 0 ? s->E0 : s->light_out, s->light_out,
                                    last ? (float)(s->L + 1) : 1.0f, s->d, stream));
-        cur = s->send;
     }
     return SPEX_OK;
 }
@@ -308,12 +318,11 @@ extern "C" int spex_partitioned_step_bce_f32(spex_partitioned_step_t *s, const i
     // ---- backward: G_L = g / (L + 1);  G_l = g / (L + 1) + A^T G_{l+1} on the row blocks of A^T, one exchange per layer
     const int64_t sz = n_loc * d;
     SPEX_TRY(spex::scale_div(s->g_local, s->gs, (float)(L + 1), sz, stream));
-    const float *cur = s->gs;
-    for (int32_t l = L - 1; l >= 0; --l) {
-        SPEX_TRY(exchange(s, cur, stream));
-        float *nxt = l == 0 ? s->grad_E0 : s->send;
-        if (n_loc) SPEX_TRY(spex_spmm_f32(s->graph_t, s->gathered, nxt, s->gs, 1.0f, nullptr, nullptr, 1.0f, d, stream));
-        cur = s->send;
+    float *T[2] = {s->gathered, s->gathered1};
+    for (int32_t l = L - 1, k = 0; l >= 0; --l, ++k) {
+        SPEX_TRY(exchange_in_place(s->comm, s->rows_per_rank, k == 0 ? s->gs : nullptr, n_loc, s->max_rows, d, T[k & 1], stream));
+        float *nxt = l == 0 ? s->grad_E0 : own_slot(s->comm, T[(k + 1) & 1], s->max_rows, d);
+        if (n_loc) SPEX_TRY(spex_spmm_f32(s->graph_t, T[k & 1], nxt, s->gs, 1.0f, nullptr, nullptr, 1.0f, d, stream));
     }
     // ---- Adam on the rank's rows (its pass clears the gradient rows again; det: g_local is overwritten per touched row, so it is
     //      cleared densely here as well)
@@ -326,24 +335,20 @@ extern "C" int spex_partitioned_step_bce_f32(spex_partitioned_step_t *s, const i
 
 // ---------------------------------------------------------------------------------------------------------------------
 // BASELINE config 5 on the row partition (main_auto_expert_s.py:53-91): see include/spex_hip.h, spex_partitioned_dual_step_t.
-// Every launch is one of the library's own entry points; the only collectives are the 2 L exchanges and one all-reduce.
-static int exchange_into(spex_comm_t *comm, const int32_t *rows_per_rank, float *send, const float *local, int64_t n_local, int64_t max_rows,
-                         int32_t d, float *table, void *stream)
-{
-    if (rows_per_rank || n_local == max_rows) return spex_comm_allgather_rows_f32(comm, local, table, max_rows, d, rows_per_rank, stream);
-    if (int rc = copy_f32(send, local, (size_t)n_local * d, stream)) return rc;
-    return spex_comm_allgather_rows_f32(comm, send, table, max_rows, d, rows_per_rank, stream);
-}
-
+// Every launch is one of the library's own entry points.  Collectives per step: fast path 2 L - 1 exchanges + one all-reduce (the
+// backward's first product needs none: every rank holds the batch's gradient rows), deterministic path 2 L + one all-reduce.
 extern "C" int spex_partitioned_dual_task_step_f32(spex_partitioned_dual_step_t *s, const int64_t *pos, const float *labels, int32_t B,
                                                    const int64_t *seq, const int64_t *seq_l, const int64_t *targets, int32_t T, void *stream)
 {
     const char *who = "spex_partitioned_dual_task_step_f32";
     SPEX_CHECK_ARG(s && s->graph && s->graph_t && s->comm && s->params && s->m && s->v && s->light && s->g_prop && s->g_raw && s->gs && s->g_E0
-                       && s->send && s->gathered && s->gathered0 && s->user_pos && s->user_table && s->rows && s->mixed_slots && s->grad_slots
+                       && s->gathered && s->gathered1 && s->gathered0 && s->user_pos && s->user_table && s->rows && s->mixed_slots && s->grad_slots
                        && s->g_prop_slots && s->g_raw_slots && s->loss_rows && s->att_parts && s->arange && s->g_user && s->g_small && s->a2
                        && s->trust_ws && s->dscore && s->loss_b && s->loss && s->loss_acc && s->precision,
                    "%s: NULL field in the step descriptor", who);
+    SPEX_CHECK_ARG(s->gathered != s->gathered1 && s->gathered != s->gathered0 && s->gathered1 != s->gathered0 && s->gathered2 != s->gathered
+                       && s->gathered2 != s->gathered1 && s->gathered2 != s->gathered0,
+                   "%s: gathered, gathered0, gathered1 and gathered2 are separate tables", who);
     SPEX_CHECK_ARG(pos && labels && B >= 1 && s->slot_capacity >= 2 * B, "%s: batch of %d for a slot capacity of %d", who, B, s->slot_capacity);
     SPEX_CHECK_ARG(T >= 0 && T <= s->path_capacity && (T == 0 || (seq && seq_l && targets)), "%s: T=%d paths (capacity %d) or NULL path pointer", who,
                    T, s->path_capacity);
@@ -360,17 +365,26 @@ extern "C" int spex_partitioned_dual_task_step_f32(spex_partitioned_dual_step_t 
     const int64_t n_trust = spex_trust_param_count(d, H);
     SPEX_CHECK_ARG(n_trust > 0, "%s: unsupported number of heads %d", who, H);
     const bool det = (s->flags & SPEX_STEP_DETERMINISTIC) != 0;
+    // the fast path (spex_dual_task_step_f32's schedule on the partition): needs the push structure, its zero-kept table and L >= 2
+    //  (a rank without rows has nothing to push and needs no structure — but must walk the same sequence of collectives as its peers:
+    //   the choice depends on gathered2 and the flags, which the caller sets alike on every rank)
+    const bool fast = !det && L >= 2 && s->gathered2 != nullptr && (s->graph_push != nullptr || n_loc == 0);
+    if (fast && n_loc)
+        SPEX_CHECK_ARG(s->graph_push->n_rows == world * max_rows && s->graph_push->n_cols == n_loc && s->graph_push->mask_mode == 0,
+                       "%s: graph_push must be the (world * max_rows) x n_local transpose of the rank's block of A^T", who);
     const size_t sz = (size_t)n_loc * d;
     float *E0 = s->params, *trust_p = E0 + sz, *att1 = trust_p + n_trust, *att2 = att1 + 4 * d;
     float *g_att1 = s->g_small + n_trust, *g_att2 = g_att1 + 4 * d;
+    float *Tb[2] = {s->gathered, s->gathered1};
+    auto own = [&](float *table) { return own_slot(s->comm, table, max_rows, d); };
 
     // ---- layer 1's exchange first: its table is E^0 of every rank — what the trust branch reads
-    SPEX_TRY(exchange_into(s->comm, s->rows_per_rank, s->send, E0, n_loc, max_rows, d, s->gathered0, stream));
+    SPEX_TRY(exchange_in_place(s->comm, s->rows_per_rank, E0, n_loc, max_rows, d, s->gathered0, stream));
     // ---- trust branch (model_expert_s.py:170-192) on the gathered user block, redundantly on every rank; beside the rec branch
     //      when the caller gave a second stream
     const bool two_streams = s->side_stream != nullptr && s->side_stream != stream && T > 0;
     auto trust_branch = [&](void *st) -> int {
-        SPEX_HIP(hipMemsetAsync(s->g_user, 0, (size_t)n_u * d * sizeof(float), (hipStream_t)st));   // (the Adam pass clears the rank's rows only)
+        SPEX_TRY(spex::zero_f32(s->g_user, (int64_t)n_u * d, st));               // (the Adam pass clears the rank's rows only)
         SPEX_TRY(spex_gather_owned_rows_f32(s->gathered0, s->user_pos, n_u, 0, world * max_rows, d, s->user_table, st));
         return spex::trust_head_train(s->user_table, n_u, trust_p, seq, seq_l, targets, T, s->path_len, d, H, s->hybrid, 1.0f, nullptr, s->a2,
                                       s->dscore, s->loss_b, s->trust_ws, s->loss + 1, 0, s->g_small, s->g_user, st == stream && !det ? 8 : 1, st);
@@ -388,14 +402,68 @@ extern "C" int spex_partitioned_dual_task_step_f32(spex_partitioned_dual_step_t 
         rc_trust = trust_branch(s->side_stream);
         if (hipEventRecord(join_ev, (hipStream_t)s->side_stream) != hipSuccess && rc_trust == SPEX_OK) rc_trust = SPEX_ERR_HIP;
     }
+    // (the gate gradients' copies of the fast path live in grad_slots — per-sample rows on the deterministic path —, summed and cleared
+    //  by the Adam pass, which clears the area after the deterministic path too: a descriptor may change its flags between steps)
+    const int32_t att_copies_max = s->slot_capacity / 8 < 64 ? s->slot_capacity / 8 : 64;
+    int32_t att_copies_used = 0;
+    auto rec_fast = [&]() -> int {
+        // ---- forward (model_expert_s.py:95-126): layers 1 .. L-1 over the rank's block, every output written into its own slot of the
+        //      next exchange's table; plain form for L <= 3 (the layer tables E^1, E^2 stay in the two tables' own slots and the layer
+        //      sum is formed at the batch's rows), running sum in `light` beyond
+        const bool plain = L <= 3;
+        for (int32_t l = 0; l + 1 < L; ++l) {
+            const float *X = l == 0 ? s->gathered0 : Tb[(l - 1) & 1];
+            if (l > 0) SPEX_TRY(exchange_in_place(s->comm, s->rows_per_rank, nullptr, n_loc, max_rows, d, Tb[(l - 1) & 1], stream));
+            if (!n_loc) continue;
+            if (plain) SPEX_TRY(spex_spmm_f32(s->graph, X, own(Tb[l & 1]), nullptr, 1.0f, nullptr, nullptr, 1.0f, d, stream));
+            else SPEX_TRY(spex_spmm_f32(s->graph, X, own(Tb[l & 1]), nullptr, 1.0f, l == 0 ? E0 : s->light, s->light, 1.0f, d, stream));
+        }
+        // ---- the LAST layer at the batch's rows only, on their owners: layer mean + raw rows, compact, zero elsewhere — ONE launch and
+        //      ONE all-reduce of 4B rows put the batch's rows of E^0 and of the propagated table on every rank
+        float *Xl = Tb[(L - 2) & 1];
+        SPEX_TRY(exchange_in_place(s->comm, s->rows_per_rank, nullptr, n_loc, max_rows, d, Xl, stream));
+        float *rows_raw = s->rows, *rows_prop = s->rows + (size_t)2 * B * d;
+        SPEX_TRY(spex_spmm_owned_rows_f32(s->graph, Xl, pos, 2 * B, lo, plain ? E0 : s->light, plain ? own(Tb[0]) : nullptr,
+                                          plain && L == 3 ? own(Tb[1]) : nullptr, (float)(L + 1), E0, rows_prop, rows_raw, d, stream));
+        SPEX_TRY(spex_comm_allreduce_sum_f32(s->comm, s->rows, (int64_t)4 * B * d, stream));
+        // ---- gate, scores, BCE, the gate's backward on the compact rows — replicated: loss and gate gradients are complete on every
+        //      rank —, the owned rows' shares added where they belong (batch.hip: gated_rows_train_kernel); P = the own slot of
+        //      gathered2, all-zero here (cleared by the previous step's Adam pass)
+        float *P = own(s->gathered2);
+        SPEX_TRY(spex::gated_rows_train(rows_raw, rows_prop, att1, att2, pos, lo, (int32_t)n_loc, labels, B, 1.0f / (float)B, 1.0f / (float)(L + 1),
+                                        s->loss, s->g_prop_slots, L == 3 ? nullptr : s->g_prop, P, s->g_raw,
+                                        att_copies_max >= 1 ? s->grad_slots : g_att1, att_copies_max >= 1 ? att_copies_max : 1, stream));
+        att_copies_used = att_copies_max;
+        // ---- the backward's first product in push form, WITHOUT an exchange: every rank holds all 2B gradient rows and pushes them
+        //      through its own columns of A (graph_push: row = a position of the padded layout, columns = the rank's rows):
+        //      P = (g + A^T g) / (L+1) on the rank's rows
+        if (n_loc)
+            SPEX_TRY(spex_spmm_push_batch_f32(s->graph_push, pos, 2 * B, 0, nullptr, 0, 0, s->g_prop_slots, d, nullptr, 0, 1.0f / (float)(L + 1), P,
+                                              d, stream));
+        // ---- the L-1 pull-form products on A^T's block: P's table is exchanged in place, the outputs alternate between the two
+        //      forward tables' own slots (dead by now); the last one plain — the Adam pass adds its g_prop / (L+1) share; L == 3: both
+        //      plain, the Adam pass adds P instead (spex_dual_task_step_f32's schedule)
+        float *Xb = s->gathered2;
+        for (int32_t l = L - 2, k = 0; l >= 0; --l, ++k) {
+            SPEX_TRY(exchange_in_place(s->comm, s->rows_per_rank, nullptr, n_loc, max_rows, d, Xb, stream));
+            float *nxt = l == 0 ? s->g_E0 : own(Tb[k & 1]);
+            if (n_loc) {
+                if (l == 0 || L == 3) SPEX_TRY(spex_spmm_f32(s->graph_t, Xb, nxt, nullptr, 1.0f, nullptr, nullptr, 1.0f, d, stream));
+                else SPEX_TRY(spex_spmm_f32(s->graph_t, Xb, nxt, s->g_prop, (float)(L + 1), nullptr, nullptr, 1.0f, d, stream));
+            }
+            Xb = Tb[k & 1];
+        }
+        return SPEX_OK;
+    };
     auto rec_branch = [&]() -> int {
-        // ---- forward (model_expert_s.py:95-126): L x (exchange, SpMM on the rank's rows with the running sum fused)
+        // ---- forward (model_expert_s.py:95-126): L x (exchange in place, SpMM on the rank's rows with the running sum fused)
         for (int32_t l = 0; l < L; ++l) {
-            if (l > 0) SPEX_TRY(exchange_into(s->comm, s->rows_per_rank, s->send, s->send, n_loc, max_rows, d, s->gathered, stream));
+            const float *X = l == 0 ? s->gathered0 : Tb[(l - 1) & 1];
+            if (l > 0) SPEX_TRY(exchange_in_place(s->comm, s->rows_per_rank, nullptr, n_loc, max_rows, d, Tb[(l - 1) & 1], stream));
             const bool last = l == L - 1;
             if (n_loc)
-                SPEX_TRY(spex_spmm_f32(s->graph, l == 0 ? s->gathered0 : s->gathered, last ? nullptr : s->send, nullptr, 1.0f, l == 0 ? E0 : s->light,
-                                       s->light, last ? (float)(L + 1) : 1.0f, d, stream));
+                SPEX_TRY(spex_spmm_f32(s->graph, X, last ? nullptr : own(Tb[l & 1]), nullptr, 1.0f, l == 0 ? E0 : s->light, s->light,
+                                       last ? (float)(L + 1) : 1.0f, d, stream));
         }
         // ---- the batch's rows of E^0 and of the propagated table on every rank: owner-computes, ONE all-reduce of 4B rows
         float *rows_raw = s->rows, *rows_prop = s->rows + (size_t)2 * B * d;
@@ -424,25 +492,28 @@ extern "C" int spex_partitioned_dual_task_step_f32(spex_partitioned_dual_step_t 
         }
         // ---- backward through the propagation: G_L = g / (L + 1);  G_l = g / (L + 1) + A^T G_{l+1} on the blocks of A^T
         SPEX_TRY(spex::scale_div(s->g_prop, s->gs, (float)(L + 1), (int64_t)sz, stream));
-        const float *cur = s->gs;
-        for (int32_t l = L - 1; l >= 0; --l) {
-            SPEX_TRY(exchange_into(s->comm, s->rows_per_rank, s->send, cur, n_loc, max_rows, d, s->gathered, stream));
-            float *nxt = l == 0 ? s->g_E0 : s->send;
-            if (n_loc) SPEX_TRY(spex_spmm_f32(s->graph_t, s->gathered, nxt, s->gs, 1.0f, nullptr, nullptr, 1.0f, d, stream));
-            cur = s->send;
+        for (int32_t l = L - 1, k = 0; l >= 0; --l, ++k) {
+            SPEX_TRY(exchange_in_place(s->comm, s->rows_per_rank, k == 0 ? s->gs : nullptr, n_loc, max_rows, d, Tb[k & 1], stream));
+            float *nxt = l == 0 ? s->g_E0 : own(Tb[(k + 1) & 1]);
+            if (n_loc) SPEX_TRY(spex_spmm_f32(s->graph_t, Tb[k & 1], nxt, s->gs, 1.0f, nullptr, nullptr, 1.0f, d, stream));
         }
         return SPEX_OK;
     };
-    int rc = rec_branch();
+    int rc = fast ? rec_fast() : rec_branch();
     if (forked && hipStreamWaitEvent((hipStream_t)stream, join_ev, 0) != hipSuccess && rc == SPEX_OK) rc = SPEX_ERR_HIP;   // joined on every path
     if (rc == SPEX_OK) rc = rc_trust;
     if (rc == SPEX_OK && T > 0 && !two_streams) rc = trust_branch(stream);
     if (rc != SPEX_OK) return rc;
     // ---- uncertainty-weighted sum of both losses + Adam (main_auto_expert_s.py:78-89) over the rank's arena: its table rows
-    //      (the first n_local_users of them take the trust head's rows user_lo ..), and the replicated dense parameters
-    SPEX_TRY(spex::dual_task_adam(s->params, s->m, s->v, s->g_E0, s->g_raw, s->g_user + (size_t)s->user_lo * d, s->g_small, s->g_prop, nullptr, s->loss,
+    //      (the first n_local_users of them take the trust head's rows user_lo ..), and the replicated dense parameters.
+    //      Fast path: the plain last product's g_prop / (L+1) share (L == 3: the push target P) is added here, the gate gradients'
+    //      copies are summed here, and P is cleared for the next step.
+    float *P = s->gathered2 ? own(s->gathered2) : nullptr;
+    SPEX_TRY(spex::dual_task_adam(s->params, s->m, s->v, s->g_E0, s->g_raw, s->g_user + (size_t)s->user_lo * d, s->g_small, s->g_prop, P, s->loss,
                                   s->loss_acc, s->precision, (int64_t)sz, (int64_t)s->n_local_users * d, n_trust, B, T, s->n_rec, s->t + 1, s->lr,
-                                  s->beta1, s->beta2, s->eps, (s->flags & SPEX_STEP_FIXED_TASK_WEIGHTS) != 0, stream, 0.0f, nullptr, 0, 0, 0, 1));
+                                  s->beta1, s->beta2, s->eps, (s->flags & SPEX_STEP_FIXED_TASK_WEIGHTS) != 0, stream,
+                                  fast ? (L == 3 ? -1.0f : (float)(L + 1)) : 0.0f, s->grad_slots, att_copies_used, att_copies_max * 512, 0,
+                                  fast && L == 3 ? 0 : 1));
     s->t += 1;
     return SPEX_OK;
 }

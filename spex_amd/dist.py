@@ -230,9 +230,12 @@ class PartitionedLightGCN:
         self.graph = graph_factory(lr, lc, lv, n_cols=p.n_padded)
         if t_csr is None:       # symmetric adjacency: A^T == A
             self.graph_t = self.graph
+            self._t_block = (lr, lc, lv)
         else:
             tr, tc, tv, _ = p.local_block(*t_csr[:3], rank)
             self.graph_t = graph_factory(tr, tc, tv, n_cols=p.n_padded)
+            self._t_block = (tr, tc, tv)
+        self._graph_factory, self._graph_push, self._tables = graph_factory, None, {}
         self.r0, self.r1 = int(p.bounds[rank]), int(p.bounds[rank + 1])
         self.n_local = self.r1 - self.r0
         z = lambda *s: torch.zeros(s, dtype=torch.float32, device=self.device)
@@ -250,6 +253,29 @@ class PartitionedLightGCN:
             raise ValueError("allgather must be 'collective', 'peer', 'native' or 'native-p2p'")
         if allgather != "collective":
             self.set_allgather(allgather)
+
+    # -- what the one-call native steps need beside the Python-issued schedule's buffers
+    def table(self, k):
+        """The k-th further [n_padded, d] exchange table (all-zero when first asked for): the native steps exchange IN PLACE — a layer's
+        SpMM writes into the rank's own slot of the table the next exchange completes — and alternate between `gathered` and these."""
+        if k not in self._tables:
+            self._tables[k] = torch.zeros_like(self.gathered)
+        return self._tables[k]
+
+    def push_graph(self):
+        """The (n_padded x n_local) transpose of the rank's block of A^T: row p holds A[p, c] for the columns c this rank owns — the
+        structure the backward's first product walks in push form (every rank holds the batch's gradient rows, so that product needs
+        no exchange: include/spex_hip.h, spex_partitioned_dual_step_t).  Built on first use."""
+        if self._graph_push is None:
+            import numpy as np
+            import scipy.sparse as sp
+            tr, tc, tv = self._t_block
+            blk = sp.csr_matrix((np.asarray(tv), np.asarray(tc), np.asarray(tr)), shape=(self.n_local, self.part.n_padded))
+            push = blk.T.tocsr()                             # (stored entries kept one by one: nothing is summed)
+            push.sort_indices()
+            self._graph_push = self._graph_factory(push.indptr.astype(np.int64), push.indices.astype(np.int32), push.data.astype(np.float32),
+                                                   n_cols=self.n_local)
+        return self._graph_push
 
     # -- the one exchange step of the data path
     def all_gather_rows(self, local, out=None):
@@ -457,7 +483,7 @@ class PartitionedStepper:
                 graph=P.graph._h.value, graph_t=P.graph_t._h.value, comm=P.native._h.value,
                 rows_per_rank=None if P._rows_per_rank is None else ctypes.cast(P._rows_per_rank, ctypes.c_void_p).value,
                 E0=p(self.E0), m=p(self.m), v=p(self.v), light_out=p(P.light_out), g_local=p(self.g_local), gs=p(self._gs),
-                grad_E0=p(self.grad_E0), send=p(P.send), gathered=p(P.gathered), rows=p(self.rows), grad_rows=p(self.grad_rows),
+                grad_E0=p(self.grad_E0), gathered1=p(P.table(1)), gathered=p(P.gathered), rows=p(self.rows), grad_rows=p(self.grad_rows),
                 arange=p(self._arange), n_local=P.n_local, max_rows=P.part.max_rows, slot_capacity=2 * self._B, L=P.L, d=P.d,
                 lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, t=self.t, flags=0)
             self._desc_B = self._B

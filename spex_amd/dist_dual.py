@@ -152,7 +152,7 @@ class PartitionedDualTaskStepper:
     exchange: "native" (equal padded shards, ncclAllGather) or "native-p2p" (real rows, grouped send / recv)."""
 
     def __init__(self, model, path_capacity, path_len, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, n_rec=5, batch_capacity=256,
-                 exchange="native-p2p", two_streams=True, deterministic=False, fixed_task_weights=False, comm=None):
+                 exchange="native-p2p", two_streams=True, deterministic=False, fixed_task_weights=False, comm=None, fast=True):
         from . import _lib, ops
         core, P = model.core, model.P
         dev = model.E0_local.device
@@ -166,6 +166,7 @@ class PartitionedDualTaskStepper:
         self.path_capacity, self.path_len, self.n_heads = int(path_capacity), int(path_len), n_heads
         self.lr, self.betas, self.eps, self.n_rec = lr, betas, eps, n_rec
         self.deterministic, self.fixed_task_weights = bool(deterministic), bool(fixed_task_weights)
+        self.fast = bool(fast)          # False: the launch-by-launch schedule (2 L exchanges, nine batch-sized launches) — tests
         if comm is not None:
             P.native = comm
         P.set_allgather(exchange)
@@ -259,7 +260,7 @@ class PartitionedDualTaskStepper:
             self._desc = _lib.PartitionedDualStepDesc(
                 graph=P.graph._h.value, graph_t=P.graph_t._h.value, comm=P.native._h.value, rows_per_rank=None,
                 params=p(self.arena), m=p(self.m), v=p(self.v), light=p(self.light), g_prop=p(self.g_prop), g_raw=p(self.g_raw), gs=p(self.gs),
-                g_E0=p(self.g_E0), send=p(P.send), gathered=p(P.gathered), gathered0=p(self.gathered0), user_pos=p(model.user_pos),
+                g_E0=p(self.g_E0), gathered1=p(P.table(1)), gathered=p(P.gathered), gathered0=p(self.gathered0), user_pos=p(model.user_pos),
                 user_table=p(self.user_table), rows=p(self.rows), mixed_slots=p(self.mixed_slots), grad_slots=p(self.grad_slots),
                 g_prop_slots=p(self.g_prop_slots), g_raw_slots=p(self.g_raw_slots), loss_rows=p(self.loss_rows), att_parts=p(self.att_parts),
                 arange=p(self.arange), g_user=p(self.g_user), g_small=p(self.g_small), a2=p(self.a2), trust_ws=p(self.trust_ws),
@@ -268,7 +269,9 @@ class PartitionedDualTaskStepper:
                 user_lo=P.r0 if model.n_local_users > 0 else 0, slot_capacity=self.slot_capacity, path_capacity=self.path_capacity,
                 path_len=self.path_len, n_user_rows=self.n_u, L=self.L, d=self.d, n_heads=self.n_heads,
                 hybrid=0 if model.core.nonhybrid else 1, n_rec=self.n_rec, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps,
-                t=self.t, side_stream=None if self._side is None else self._side.cuda_stream, ev_fork=None, ev_join=None, flags=0)
+                t=self.t, side_stream=None if self._side is None else self._side.cuda_stream, ev_fork=None, ev_join=None, flags=0,
+                graph_push=P.push_graph()._h.value if self.fast and P.n_local > 0 and self.L >= 2 else None,
+                gathered2=p(P.table(2)) if self.fast else None)
         dsc = self._desc
         dsc.t, dsc.lr = self.t, self.lr
         dsc.flags = (_lib.STEP_DETERMINISTIC if self.deterministic else 0) | (_lib.STEP_FIXED_TASK_WEIGHTS if self.fixed_task_weights else 0)

@@ -195,21 +195,21 @@ def gpu():
                 reduces = [k for k, r in enumerate(lg) if r.op == OP["allreduce"]]
                 assert len(reduces) == 1 and lg[reduces[0]].count == 2 * B * d and lg[reduces[0]].send == st.rows.data_ptr()
                 before, after = lg[: reduces[0]], lg[reduces[0] + 1:]
-                # the rows go out from where they lie — no staging copy: the first forward exchange reads E^0 itself, the first
-                # backward one the scaled gradient, the others the buffer the previous layer's SpMM wrote (this rank's shard is a
-                # full one, n_local == max_rows, so the equal-shard form needs no padding either)
-                src_fwd = [st.E0.data_ptr()] + [send] * (L - 1)
-                src_bwd = [st._gs.data_ptr()] + [send] * (L - 1)
+                # every exchange is IN PLACE: the rows go out from the rank's own slot of the table they are received around (the
+                # layer's SpMM wrote them there; E^0 and the scaled gradient are copied in), and the two tables alternate
+                tables = [recv, P.table(1).data_ptr()]
+                slot_of = lambda t: t + rank * max_rows * d * 4
                 if mode == "native-p2p":
                     per = 2 + 3 + 3                                      # GroupStart, 3 sends, 3 receives, GroupEnd
                     assert len(before) == L * per and len(after) == L * per, (len(before), len(after))
                     for k in range(L):                                   # L exchanges forward, L backward: 2L + one all-reduce per step
-                        expect_p2p(before[k * per:(k + 1) * per], rank, world, rows, max_rows, d, src_fwd[k], recv, side.cuda_stream)
-                        expect_p2p(after[k * per:(k + 1) * per], rank, world, rows, max_rows, d, src_bwd[k], recv, side.cuda_stream)
+                        expect_p2p(before[k * per:(k + 1) * per], rank, world, rows, max_rows, d, slot_of(tables[k & 1]), tables[k & 1], side.cuda_stream)
+                        expect_p2p(after[k * per:(k + 1) * per], rank, world, rows, max_rows, d, slot_of(tables[k & 1]), tables[k & 1], side.cuda_stream)
                 else:
                     assert len(before) == L and len(after) == L
-                    assert all(r.op == OP["allgather"] and r.count == max_rows * d and r.recv == recv for r in before + after)
-                    assert [r.send for r in before] == src_fwd and [r.send for r in after] == src_bwd
+                    assert all(r.op == OP["allgather"] and r.count == max_rows * d for r in before + after)
+                    for lg_half in (before, after):
+                        assert [(r.send, r.recv) for r in lg_half] == [(slot_of(tables[k & 1]), tables[k & 1]) for k in range(L)]
             side.synchronize()
             assert st.t == 2 and bool(torch.isfinite(st.E0).all()) and bool(torch.isfinite(acc).all())
             # switching the exchange form takes effect on the NEXT step of the same stepper (the descriptor is refreshed)
@@ -230,9 +230,11 @@ def gpu():
         _launch(dev, "spex_partitioned_propagate_f32", ctypes.byref(st._desc))
         lg = stub.take()
         assert len(lg) == L * 8 and sum(1 for r in lg if r.op == OP["allreduce"]) == 0
-        # ---- the one-call partitioned DUAL-TASK step (spex_partitioned_dual_task_step_f32): 2L exchanges and ONE all-reduce of the
-        #      batch's rows of E^0 and of the propagated table together (4B rows) — no gate-gradient collective; the first exchange's
-        #      table is the kept one (gathered0), the trust branch issues no collective
+        # ---- the one-call partitioned DUAL-TASK step (spex_partitioned_dual_task_step_f32): ONE all-reduce of the batch's rows of E^0
+        #      and of the propagated table together (4B rows) — no gate-gradient collective; the first exchange's table is the kept
+        #      one (gathered0), the trust branch issues no collective.  Fast path: L exchanges in front of the all-reduce, L - 1
+        #      behind it (the backward's first product is the push: no exchange), the first of them on gathered2 (the push target's
+        #      table); launch-by-launch schedule (fast=False): L + L
         import argparse
         sys.path.insert(0, os.path.join(REPO, "spex_amd", "dropin"))
         import utility1.model_expert_s as mex
@@ -246,30 +248,32 @@ def gpu():
         torch.manual_seed(1)
         core = mex.LightGCN(dargs, _DS).to(dev)
         dmodel = PartitionedDualTask(core, csr, rank, world, dev)        # (its own PartitionedLightGCN; default row bounds)
-        dst = PartitionedDualTaskStepper(dmodel, path_capacity=5, path_len=4, exchange="native-p2p", two_streams=False,
-                                         comm=NativeComm(rank, world, dev, unique_id=bytes(idb.raw)))
-        stub.take()
-        DP = dmodel.P
-        drows = [int(r) for r in DP.part.rows]
+        dcomm = NativeComm(rank, world, dev, unique_id=bytes(idb.raw))
         seq = torch.tensor([[1, 2, n_user, n_user], [3, 4, 5, n_user], [7, n_user, n_user, n_user]], dtype=torch.int64, device=dev)
         seq_l = torch.tensor([2, 3, 1], dtype=torch.int64, device=dev)
         tgt = torch.tensor([9, 10, 11], dtype=torch.int64, device=dev)
-        dst.step(users, items, labels, seq, seq_l, tgt)
-        lg = stub.take()
-        reduces = [k for k, r in enumerate(lg) if r.op == OP["allreduce"]]
-        assert len(reduces) == 1 and lg[reduces[0]].count == 4 * B * d and lg[reduces[0]].send == dst.rows.data_ptr(), [(r.op, r.count) for r in lg]
-        before, after = lg[: reduces[0]], lg[reduces[0] + 1:]
-        per = 2 + 3 + 3
-        assert len(before) == L * per and len(after) == L * per, (len(before), len(after))
-        dsend = DP.send.data_ptr()
-        expect_p2p(before[:per], rank, world, drows, DP.part.max_rows, d, dst.arena.data_ptr(), dst.gathered0.data_ptr(), side.cuda_stream)   # E^0 itself -> gathered0
-        for k in range(1, L):
-            expect_p2p(before[k * per:(k + 1) * per], rank, world, drows, DP.part.max_rows, d, dsend, DP.gathered.data_ptr(), side.cuda_stream)
-        expect_p2p(after[:per], rank, world, drows, DP.part.max_rows, d, dst.gs.data_ptr(), DP.gathered.data_ptr(), side.cuda_stream)
-        for k in range(1, L):
-            expect_p2p(after[k * per:(k + 1) * per], rank, world, drows, DP.part.max_rows, d, dsend, DP.gathered.data_ptr(), side.cuda_stream)
-        side.synchronize()
-        assert dst.t == 1 and bool(torch.isfinite(dst.arena).all()) and bool(torch.isfinite(dst.loss_acc).all())
+        for fast in (True, False):
+            dst = PartitionedDualTaskStepper(dmodel, path_capacity=5, path_len=4, exchange="native-p2p", two_streams=False, comm=dcomm, fast=fast)
+            stub.take()
+            DP = dmodel.P
+            drows = [int(r) for r in DP.part.rows]
+            dmax = DP.part.max_rows
+            dst.step(users, items, labels, seq, seq_l, tgt)
+            lg = stub.take()
+            reduces = [k for k, r in enumerate(lg) if r.op == OP["allreduce"]]
+            assert len(reduces) == 1 and lg[reduces[0]].count == 4 * B * d and lg[reduces[0]].send == dst.rows.data_ptr(), [(r.op, r.count) for r in lg]
+            before, after = lg[: reduces[0]], lg[reduces[0] + 1:]
+            per = 2 + 3 + 3
+            tb = [DP.gathered.data_ptr(), DP.table(1).data_ptr()]
+            fwd = [dst.gathered0.data_ptr()] + [tb[(l - 1) & 1] for l in range(1, L)]           # E^0 -> gathered0, then the layers' tables
+            bwd = ([DP.table(2).data_ptr()] + [tb[k & 1] for k in range(L - 2)]) if fast else [tb[k & 1] for k in range(L)]
+            assert len(before) == len(fwd) * per and len(after) == len(bwd) * per, (fast, len(before), len(after))
+            for k, t in enumerate(fwd):
+                expect_p2p(before[k * per:(k + 1) * per], rank, world, drows, dmax, d, t + rank * dmax * d * 4, t, side.cuda_stream)
+            for k, t in enumerate(bwd):
+                expect_p2p(after[k * per:(k + 1) * per], rank, world, drows, dmax, d, t + rank * dmax * d * 4, t, side.cuda_stream)
+            side.synchronize()
+            assert dst.t == 1 and bool(torch.isfinite(dst.arena).all()) and bool(torch.isfinite(dst.loss_acc).all())
         DP.native.close()
         stub.take()
     side.synchronize()
