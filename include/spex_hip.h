@@ -859,11 +859,20 @@ int spex_comm_allreduce_sum_f32(spex_comm_t *comm, float *buf, int64_t n, void *
  *   Every exchange is IN PLACE: a layer's SpMM writes its output into the rank's own slot (rows rank * max_rows ..) of the table the
  *   next exchange completes (gathered and gathered1 alternate), so no send buffer and no copy of a layer's rows exist (before: 2 L
  *   staging copies per step).
+ *   FAST PATH of spex_partitioned_step_bce_f32 (gathered2 given, L >= 2, not deterministic; the same choice on EVERY rank — the two
+ *   schedules differ in their collectives) — spex_lightgcn_step_bce_f32's schedule on the partition: forward layers 1 .. L-1 over the
+ *   block (plain form for L <= 3), the LAST layer at the batch's rows on their owners (spex_spmm_owned_rows_f32) -> the all-reduce of
+ *   2B rows -> scores, BCE, gradient rows and the owner-computes adds in ONE launch on the replicated rows -> the backward's FIRST
+ *   product in push form WITHOUT an exchange (every rank holds all 2B gradient rows and pushes them through graph_push = its own
+ *   columns of A) -> L - 1 pull-form products on A^T's block, the last one plain (Adam adds its g / (L+1) share; L == 3: both plain,
+ *   Adam adds the push target).  2 L - 1 exchanges + 1 all-reduce.  graph_push: handle of the (world * max_rows) x n_local matrix
+ *   whose row p holds A[p, c] for the columns c the rank owns (local column indices) = the transpose of the rank's block of A^T;
+ *   gathered2 [world * max_rows, 64]: its own slot is the push target, all-zero before the first call (the Adam pass leaves it so).
  * pos: device int64 [2B] — the batch's rows in the padded gathered layout (users, then items): owner(r) * max_rows + r - r_owner.
  * The batch is replicated on every rank; every rank accumulates the same loss sum into its own *loss_sum.
  * Buffers (caller-owned): E0, m, v, light_out, g_local, gs, grad_E0: [n_local, 64] (g_local all-zero before the first call;
  * every call leaves it so); gathered, gathered1: [world * max_rows, 64] each (two tables); rows, grad_rows: [slot_capacity, 64] with
- * slot_capacity >= 2B (grad_rows all-zero before the first call); arange: device int64 [slot_capacity] = 0, 1, 2, ...
+ * slot_capacity >= 2B; arange: device int64 [slot_capacity] = 0, 1, 2, ...
  * graph / graph_t: this rank's row blocks (n_local rows, world * max_rows columns).  d == 64, L >= 1, no edge dropout. */
 typedef struct spex_partitioned_step {
     const spex_graph_t *graph, *graph_t;
@@ -875,6 +884,8 @@ typedef struct spex_partitioned_step {
     int32_t n_local, max_rows, slot_capacity, L, d;
     float lr, beta1, beta2, eps;
     int32_t t, flags;                  /* t is advanced by spex_partitioned_step_bce_f32; flags: SPEX_STEP_DETERMINISTIC */
+    const spex_graph_t *graph_push;    /* fast path of spex_partitioned_step_bce_f32 (below); NULL on a rank without rows */
+    float *gathered2;                  /* NULL: the launch-by-launch schedule */
 } spex_partitioned_step_t;
 int spex_partitioned_propagate_f32(spex_partitioned_step_t *step, void *stream);
 int spex_partitioned_step_bce_f32(spex_partitioned_step_t *step, const int64_t *pos, const float *labels, int32_t B, float *loss_sum,

@@ -180,7 +180,8 @@ class PartitionedStepDesc(ctypes.Structure):
     _fields_ = ([(n, c_vp) for n in ("graph", "graph_t", "comm", "rows_per_rank", "E0", "m", "v", "light_out", "g_local", "gs", "grad_E0",
                                      "gathered1", "gathered", "rows", "grad_rows", "arange")]
                 + [(n, c_i32) for n in ("n_local", "max_rows", "slot_capacity", "L", "d")]
-                + [(n, c_f32) for n in ("lr", "beta1", "beta2", "eps")] + [("t", c_i32), ("flags", c_i32)])
+                + [(n, c_f32) for n in ("lr", "beta1", "beta2", "eps")] + [("t", c_i32), ("flags", c_i32)]
+                + [(n, c_vp) for n in ("graph_push", "gathered2")])
 
 
 class PartitionedDualStepDesc(ctypes.Structure):

@@ -600,6 +600,39 @@ __global__ __launch_bounds__(2 * kWave) void gated_rows_train_kernel(
     if (wave == 0 && lane == 0) atomicAdd(loss_sum, fmaxf(x, 0.0f) - x * y_lab + log1pf(expf(-fabsf(x))));
 }
 
+
+// The LightGCN step's batch-sized middle on a ROW PARTITION (comm.hip: spex_partitioned_step_bce_f32, fast path): the batch's
+// propagated rows arrive compact and complete on every rank (rows [2B, 64]: slot b = sample b's user row, slot B + b its item row),
+// so score, loss and the two gradient rows are lightgcn_batch_kernel's step 2 on them (utility1/model.py:111-121 + autograd), computed
+// redundantly by every rank — one wave per sample.  grad_slots[slot] = the slot's gradient row (plain store: every rank pushes every
+// slot through its own columns of A afterwards); for a slot whose row this rank owns: P[r] += push_scale * g, g_out[r] += g (if g_out).
+__global__ __launch_bounds__(4 * kWave) void score_rows_train_kernel(const float *__restrict__ rows, const int64_t *__restrict__ pos, int64_t lo,
+                                                                    int n_local, const float *__restrict__ labels, int B, float grad_scale,
+                                                                    float push_scale, float *loss_sum, float *__restrict__ grad_slots,
+                                                                    float *g_out, float *P)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float lu = rows[(size_t)b * kWave + lane], li = rows[(size_t)(B + b) * kWave + lane];
+    const float y_lab = labels[b];
+    const float x = wave_sum_f32(fmaf(lu, li, 0.0f));
+    const float dg = (sigmoid_f(x) - y_lab) * grad_scale;
+    const float g2[2] = {dg * li, dg * lu};
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        const size_t slot = (size_t)w * B + b;
+        grad_slots[slot * kWave + lane] = g2[w];
+        const int64_t r64 = pos[slot] - lo;
+        if (r64 >= 0 && r64 < n_local) {
+            const size_t o = (size_t)r64 * kWave + lane;
+            if (g_out) atomicAdd(g_out + o, g2[w]);
+            atomicAdd(P + o, push_scale * g2[w]);
+        }
+    }
+    if (lane == 0) atomicAdd(loss_sum, fmaxf(x, 0.0f) - x * y_lab + log1pf(expf(-fabsf(x))));
+}
+
 }  // namespace
 
 static spex::EdgeDrop edge_drop_of(const spex_graph_t *g)
@@ -756,6 +789,18 @@ int spex::gated_rows_train(const float *rows_raw, const float *rows_prop, const 
     if (B == 0) return SPEX_OK;
     hipLaunchKernelGGL(gated_rows_train_kernel, dim3((unsigned)B), dim3(2 * kWave), 0, (hipStream_t)stream, rows_raw, rows_prop, att_u, att_i,
                        pos, lo, n_local, labels, B, grad_scale, push_scale, loss_sum, g_prop_slots, g_prop, P, g_raw, g_att, n_att_copies);
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}
+
+int spex::score_rows_train(const float *rows, const int64_t *pos, int64_t lo, int32_t n_local, const float *labels, int32_t B, float grad_scale,
+                           float push_scale, float *loss_sum, float *grad_slots, float *g_out, float *P, void *stream)
+{
+    SPEX_CHECK_ARG(rows && pos && labels && loss_sum && grad_slots && P, "score_rows_train: NULL argument");
+    SPEX_CHECK_ARG(B >= 0 && n_local >= 0 && P != g_out, "score_rows_train: B=%d n_local=%d, or P aliases g_out", B, n_local);
+    if (B == 0) return SPEX_OK;
+    hipLaunchKernelGGL(score_rows_train_kernel, dim3((unsigned)((B + 3) / 4)), dim3(4 * kWave), 0, (hipStream_t)stream, rows, pos, lo, n_local,
+                       labels, B, grad_scale, push_scale, loss_sum, grad_slots, g_out, P);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }

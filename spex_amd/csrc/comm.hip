@@ -292,6 +292,61 @@ extern "C" int spex_partitioned_step_bce_f32(spex_partitioned_step_t *s, const i
     const int32_t d = s->d, L = s->L;
     const int64_t lo = (int64_t)s->comm->rank * s->max_rows, n_loc = s->n_local;
     const bool det = (s->flags & SPEX_STEP_DETERMINISTIC) != 0;
+    const int64_t sz = n_loc * d;
+    // ---- the fast path: spex_lightgcn_step_bce_f32's schedule on the partition (see spex_partitioned_dual_task_step_f32 below, whose rec
+    //      branch is this with the gate in the middle).  The same choice on every rank: the two schedules differ in their collectives.
+    const bool fast = !det && L >= 2 && s->gathered2 != nullptr && (s->graph_push != nullptr || n_loc == 0);
+    if (fast) {
+        if (n_loc)
+            SPEX_CHECK_ARG(s->graph_push->n_rows == s->comm->world * s->max_rows && s->graph_push->n_cols == n_loc && s->graph_push->mask_mode == 0,
+                           "spex_partitioned_step_bce_f32: graph_push must be the (world * max_rows) x n_local transpose of the rank's block of A^T");
+        SPEX_CHECK_ARG(s->gathered2 != s->gathered && s->gathered2 != s->gathered1, "spex_partitioned_step_bce_f32: gathered2 is a third table");
+        float *Tb[2] = {s->gathered, s->gathered1};
+        auto own = [&](float *table) { return own_slot(s->comm, table, s->max_rows, d); };
+        // forward layers 1 .. L-1 over the block (plain form for L <= 3: E^1, E^2 stay in the two tables' own slots), E^0 through table 1
+        const bool plain = L <= 3;
+        for (int32_t l = 0; l + 1 < L; ++l) {
+            float *X = Tb[(l + 1) & 1];                                  // E^0 -> gathered1, E^1 -> gathered, E^2 -> gathered1, ...
+            SPEX_TRY(exchange_in_place(s->comm, s->rows_per_rank, l == 0 ? s->E0 : nullptr, n_loc, s->max_rows, d, X, stream));
+            if (!n_loc) continue;
+            if (plain) SPEX_TRY(spex_spmm_f32(s->graph, X, own(Tb[l & 1]), nullptr, 1.0f, nullptr, nullptr, 1.0f, d, stream));
+            else SPEX_TRY(spex_spmm_f32(s->graph, X, own(Tb[l & 1]), nullptr, 1.0f, l == 0 ? s->E0 : s->light_out, s->light_out, 1.0f, d, stream));
+        }
+        // the last layer at the batch's rows on their owners, one all-reduce of 2B rows
+        float *Xl = Tb[(L - 2) & 1];
+        SPEX_TRY(exchange_in_place(s->comm, s->rows_per_rank, nullptr, n_loc, s->max_rows, d, Xl, stream));
+        // (L == 3: E^1 lies in gathered's own slot, E^2 in gathered1's — E^0's copy there was overwritten by layer 2's output, E^0 itself
+        //  is the parameter block; L == 2: E^1 in gathered's own slot)
+        SPEX_TRY(spex_spmm_owned_rows_f32(s->graph, Xl, pos, 2 * B, lo, plain ? s->E0 : s->light_out, plain ? own(Tb[0]) : nullptr,
+                                          plain && L == 3 ? own(Tb[1]) : nullptr, (float)(L + 1), nullptr, s->rows, nullptr, d, stream));
+        SPEX_TRY(spex_comm_allreduce_sum_f32(s->comm, s->rows, (int64_t)2 * B * d, stream));
+        // scores + BCE + gradient rows on the compact rows (replicated), the owned rows' shares added; the first backward product in
+        // push form through the rank's own columns of A — no exchange; P = gathered2's own slot, kept all-zero by the Adam pass
+        float *P = own(s->gathered2);
+        const bool all_plain = L == 3;
+        SPEX_TRY(spex::score_rows_train(s->rows, pos, lo, (int32_t)n_loc, labels, B, 1.0f / (float)B, 1.0f / (float)(L + 1), loss_sum, s->grad_rows,
+                                        all_plain ? nullptr : s->g_local, P, stream));
+        if (n_loc)
+            SPEX_TRY(spex_spmm_push_batch_f32(s->graph_push, pos, 2 * B, 0, nullptr, 0, 0, s->grad_rows, d, nullptr, 0, 1.0f / (float)(L + 1), P, d,
+                                              stream));
+        float *Xb = s->gathered2;
+        for (int32_t l = L - 2, k = 0; l >= 0; --l, ++k) {
+            SPEX_TRY(exchange_in_place(s->comm, s->rows_per_rank, nullptr, n_loc, s->max_rows, d, Xb, stream));
+            float *nxt = l == 0 ? s->grad_E0 : own(Tb[k & 1]);
+            if (n_loc) {
+                if (l == 0 || all_plain) SPEX_TRY(spex_spmm_f32(s->graph_t, Xb, nxt, nullptr, 1.0f, nullptr, nullptr, 1.0f, d, stream));
+                else SPEX_TRY(spex_spmm_f32(s->graph_t, Xb, nxt, s->g_local, (float)(L + 1), nullptr, nullptr, 1.0f, d, stream));
+            }
+            Xb = Tb[k & 1];
+        }
+        // Adam adds the plain last product's share (g / (L+1); L == 3: the push target P) and clears both tables for the next step
+        if (sz)
+            SPEX_TRY(spex::adam_step_z2(s->E0, s->grad_E0, s->m, s->v, sz, s->t + 1, s->lr, s->beta1, s->beta2, s->eps,
+                                        all_plain ? nullptr : s->g_local, P, stream, nullptr, 0, nullptr, nullptr, all_plain ? P : s->g_local,
+                                        all_plain ? 1.0f : (float)(L + 1)));
+        s->t += 1;
+        return SPEX_OK;
+    }
     // ---- forward: L x (exchange, SpMM on the rank's rows), the batch's 2B rows fetched owner-computes (each rank contributes the
     //      rows it owns to a zero-filled buffer, one small all-reduce adds them up), scoring on the compact rows
     SPEX_TRY(spex_partitioned_propagate_f32(s, stream));
@@ -308,15 +363,13 @@ extern "C" int spex_partitioned_step_bce_f32(spex_partitioned_step_t *s, const i
                                             s->grad_rows, d, stream));
         SPEX_TRY(spex::sum_ordered(loss_rows, B, 1.0f, loss_sum, 1, stream));
         SPEX_TRY(spex_reduce_slots_f32(pos, 2 * B, -lo, nullptr, 0, 0, (int32_t)n_loc, s->grad_rows, d, 1.0f, s->g_local, 0, d, stream));
-        SPEX_HIP(hipMemsetAsync(s->grad_rows, 0, (size_t)2 * B * d * sizeof(float), (hipStream_t)stream));   // the fast path's invariant
     } else {
-        float *gu = s->grad_rows, *gi = s->grad_rows + (size_t)B * d;
-        SPEX_TRY(spex_score_bce_f32(users, items, d, d, B, B, s->arange, s->arange, labels, B, d, nullptr, loss_sum, gu, gi, 1.0f / (float)B,
-                                    stream));
-        SPEX_TRY(spex_scatter_add_owned_rows_f32(s->grad_rows, pos, 2 * (int64_t)B, lo, n_loc, d, s->g_local, 1, stream));
+        // (per-sample rows by plain stores, then the owned ones added with atomics: no buffer has to be all-zero between steps)
+        SPEX_TRY(spex_score_bce_slots_f32(users, items, d, d, B, B, s->arange, s->arange, labels, B, d, loss_sum, nullptr, nullptr, 1.0f / (float)B,
+                                          s->grad_rows, d, stream));
+        SPEX_TRY(spex_scatter_add_owned_rows_f32(s->grad_rows, pos, 2 * (int64_t)B, lo, n_loc, d, s->g_local, 0, stream));
     }
     // ---- backward: G_L = g / (L + 1);  G_l = g / (L + 1) + A^T G_{l+1} on the row blocks of A^T, one exchange per layer
-    const int64_t sz = n_loc * d;
     SPEX_TRY(spex::scale_div(s->g_local, s->gs, (float)(L + 1), sz, stream));
     float *T[2] = {s->gathered, s->gathered1};
     for (int32_t l = L - 1, k = 0; l >= 0; --l, ++k) {

@@ -440,7 +440,8 @@ class PartitionedStepper:
     pass, L x (all-gather, SpMM), Adam (which also clears the gradient table for the next step).
     `ops`: the kernel namespace (spex_amd.ops on the GPU; the CPU tests of the schedule inject a stand-in)."""
 
-    def __init__(self, part_model, E0_local, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, ops=None):
+    def __init__(self, part_model, E0_local, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, ops=None, fast=True):
+        self.fast = bool(fast)          # the one-call native step's fast path (False: its launch-by-launch schedule) — every rank alike
         if ops is None:
             from . import ops
         self.ops, self.P, self.E0 = ops, part_model, E0_local
@@ -485,7 +486,9 @@ class PartitionedStepper:
                 E0=p(self.E0), m=p(self.m), v=p(self.v), light_out=p(P.light_out), g_local=p(self.g_local), gs=p(self._gs),
                 grad_E0=p(self.grad_E0), gathered1=p(P.table(1)), gathered=p(P.gathered), rows=p(self.rows), grad_rows=p(self.grad_rows),
                 arange=p(self._arange), n_local=P.n_local, max_rows=P.part.max_rows, slot_capacity=2 * self._B, L=P.L, d=P.d,
-                lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, t=self.t, flags=0)
+                lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, t=self.t, flags=0,
+                graph_push=P.push_graph()._h.value if self.fast and P.n_local > 0 and P.L >= 2 else None,
+                gathered2=p(P.table(2)) if self.fast else None)
             self._desc_B = self._B
         d = self._desc
         d.t, d.lr, d.flags = self.t, self.lr, (_lib.STEP_DETERMINISTIC if deterministic else 0)

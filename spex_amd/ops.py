@@ -1082,6 +1082,28 @@ def gather_owned_rows(table, pos, lo, out):
     return out
 
 
+def spmm_owned_rows(graph, X, pos, lo, acc_in, acc_div, out_prop, raw=None, out_raw=None, acc2=None, acc3=None):
+    """The partitioned steps' last forward layer at a batch's rows (spex_spmm_owned_rows_f32; utility1/model.py:91-97 at the rows of
+    :115-116): for the positions this rank owns, out_prop[k] = (acc_in[r] [+ acc2[r] [+ acc3[r]]] + (A X)[r]) / acc_div with
+    r = pos[k] - lo and out_raw[k] = raw[r]; ZERO rows elsewhere (the operands of the owner-computes all-reduce).  `graph`: the
+    rank's row block."""
+    _need(X, "X"); _need(acc_in, "acc_in"); _need(out_prop, "out_prop")
+    for t, name in ((raw, "raw"), (out_raw, "out_raw"), (acc2, "acc2"), (acc3, "acc3")):
+        if t is not None:
+            _need(t, name)
+    pos = _idx(pos, out_prop.device)
+    d = X.shape[1]
+    if out_prop.shape != (pos.numel(), d) or (out_raw is not None and out_raw.shape != out_prop.shape):
+        raise ValueError("spmm_owned_rows: out_prop / out_raw must be [len(pos), d]")
+    if X.shape[0] != graph.n_cols or any(t is not None and t.shape != (graph.n_rows, d) for t in (acc_in, acc2, acc3, raw)):
+        raise ValueError("spmm_owned_rows: X must be [n_cols, d], the row operands [n_rows, d]")
+    _launch(X.device, "spex_spmm_owned_rows_f32", graph._h, _ptr(X), _ptr(pos), pos.numel(), int(lo), _ptr(acc_in),
+            None if acc2 is None else _ptr(acc2), None if acc3 is None else _ptr(acc3), float(acc_div), None if raw is None else _ptr(raw),
+            _ptr(out_prop), None if out_raw is None else _ptr(out_raw), d)
+    _bump(out_prop, *([] if out_raw is None else [out_raw]))
+    return out_prop
+
+
 def scatter_add_owned_rows(upd, pos, lo, table, clear=True):
     """table[pos[k] - lo] += upd[k] for the positions this rank owns; upd is cleared afterwards (clear=True)."""
     _need(table, "table"); _need(upd, "upd")

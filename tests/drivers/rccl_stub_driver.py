@@ -5,8 +5,8 @@ wire — this pins the peer / count / offset / stream / grouping arithmetic of s
   python rccl_stub_driver.py cpu    no GPU needed: the rank's rows already sit in its own slot (send == recv + rank * slot), so
                                     the library issues no device copy and the pointers are never dereferenced
   python rccl_stub_driver.py gpu    world = 4, rank = 2 on cuda:0: both all-gather forms incl. the own-slot copy, the all-reduce,
-                                    spex_partitioned_propagate_f32 and spex_partitioned_step_bce_f32 (2L exchanges + one
-                                    all-reduce per step, every call on the caller's stream)
+                                    spex_partitioned_propagate_f32, spex_partitioned_step_bce_f32 and the dual-task step (in-place
+                                    exchanges, 2L - 1 (fast path) or 2L of them + one all-reduce per step, the caller's stream)
 
 The schedule's reference analogue: the serial fold loop of --A_split, LightGCN_SPEX/code/utility1/model.py:84-89."""
 import ctypes
@@ -199,17 +199,24 @@ def gpu():
                 # layer's SpMM wrote them there; E^0 and the scaled gradient are copied in), and the two tables alternate
                 tables = [recv, P.table(1).data_ptr()]
                 slot_of = lambda t: t + rank * max_rows * d * 4
+                if det:     # launch by launch: L exchanges forward, L backward (2L + one all-reduce per step), the two tables alternating
+                    fwd = bwd = [tables[k & 1] for k in range(L)]
+                else:       # fast path: E^0 through table 1, then alternating; the backward's first product is the push — NO exchange —,
+                            # its L - 1 pull products start from the push target's table (2L - 1 + one all-reduce per step)
+                    fwd = [tables[(k + 1) & 1] for k in range(L)]
+                    bwd = [P.table(2).data_ptr()] + [tables[k & 1] for k in range(L - 2)]
                 if mode == "native-p2p":
                     per = 2 + 3 + 3                                      # GroupStart, 3 sends, 3 receives, GroupEnd
-                    assert len(before) == L * per and len(after) == L * per, (len(before), len(after))
-                    for k in range(L):                                   # L exchanges forward, L backward: 2L + one all-reduce per step
-                        expect_p2p(before[k * per:(k + 1) * per], rank, world, rows, max_rows, d, slot_of(tables[k & 1]), tables[k & 1], side.cuda_stream)
-                        expect_p2p(after[k * per:(k + 1) * per], rank, world, rows, max_rows, d, slot_of(tables[k & 1]), tables[k & 1], side.cuda_stream)
+                    assert len(before) == len(fwd) * per and len(after) == len(bwd) * per, (det, len(before), len(after))
+                    for k, tb in enumerate(fwd):
+                        expect_p2p(before[k * per:(k + 1) * per], rank, world, rows, max_rows, d, slot_of(tb), tb, side.cuda_stream)
+                    for k, tb in enumerate(bwd):
+                        expect_p2p(after[k * per:(k + 1) * per], rank, world, rows, max_rows, d, slot_of(tb), tb, side.cuda_stream)
                 else:
-                    assert len(before) == L and len(after) == L
+                    assert len(before) == len(fwd) and len(after) == len(bwd)
                     assert all(r.op == OP["allgather"] and r.count == max_rows * d for r in before + after)
-                    for lg_half in (before, after):
-                        assert [(r.send, r.recv) for r in lg_half] == [(slot_of(tables[k & 1]), tables[k & 1]) for k in range(L)]
+                    assert [(r.send, r.recv) for r in before] == [(slot_of(tb), tb) for tb in fwd]
+                    assert [(r.send, r.recv) for r in after] == [(slot_of(tb), tb) for tb in bwd]
             side.synchronize()
             assert st.t == 2 and bool(torch.isfinite(st.E0).all()) and bool(torch.isfinite(acc).all())
             # switching the exchange form takes effect on the NEXT step of the same stepper (the descriptor is refreshed)
@@ -219,7 +226,7 @@ def gpu():
             lg = stub.take()
             n_ag = sum(1 for r in lg if r.op == OP["allgather"])
             n_sr = sum(1 for r in lg if r.op in (OP["send"], OP["recv"]))
-            assert (n_ag, n_sr) == ((2 * L, 0) if other == "native" else (0, 2 * L * 6)), (other, n_ag, n_sr)
+            assert (n_ag, n_sr) == ((2 * L - 1, 0) if other == "native" else (0, (2 * L - 1) * 6)), (other, n_ag, n_sr)
         # spex_partitioned_propagate_f32 on its own: L exchanges, nothing else
         P.set_allgather("native-p2p")
         st = PartitionedStepper(P, E0_local.clone(), lr=1e-3)

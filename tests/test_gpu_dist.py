@@ -577,6 +577,7 @@ def test_native_communicator_and_one_call_partitioned_step(tmp_path):
     mp.spawn(_native_comm_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
     d = np.load(tmp_path / "native.npz")
     assert bool(d["raw_ok"]) and bool(d["rccl_one_rank_ok"])
-    assert float(d["native_vs_python"]) <= 2e-6 and float(d["native_loss"]) <= 1e-6, dict(d)
+    # (the loss accumulator: an fp32 sum of 4 x 256 per-sample losses added by float atomics in arrival order on either side)
+    assert float(d["native_vs_python"]) <= 2e-6 and float(d["native_loss"]) <= 3e-6, dict(d)
     assert bool(d["det_repeats"])
     assert float(d["det_vs_single_device_det"]) <= 5e-6 and float(d["det_loss_vs_single"]) <= 2e-6, dict(d)

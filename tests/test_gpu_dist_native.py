@@ -116,7 +116,7 @@ def test_native_exchange_and_one_call_step_with_real_data_between_ranks(tmp_path
         d = np.load(tmp_path / f"light{world}_{r}.npz")
         assert bool(d["native_prop_equal"]) and bool(d["native-p2p_prop_equal"]), r
         assert float(d["native_step"]) <= 2e-6 and float(d["native-p2p_step"]) <= 2e-6, dict(d)
-        assert float(d["native_loss"]) <= 1e-6 and float(d["native-p2p_loss"]) <= 1e-6
+        assert float(d["native_loss"]) <= 3e-6 and float(d["native-p2p_loss"]) <= 3e-6   # (fp32 sums of per-sample losses in arrival order)
         assert bool(d["det_repeats"]) and float(d["det_step"]) <= 5e-6
         lo[int(d["r0"]):int(d["r1"])] = d["lo"]
     assert np.array_equal(lo, ref)
@@ -206,3 +206,107 @@ def test_one_call_partitioned_dual_task_step_reproduces_the_reference_losses(tmp
             assert np.array_equal(d[0][k], d[r][k]) or np.abs(d[0][k] - d[r][k]).max() <= 1e-7 * max(1.0, np.abs(d[0][k]).max()), k
         assert int(d[r - 1]["r1"]) == int(d[r]["r0"])
     assert int(d[0]["r0"]) == 0 and int(d[-1]["r1"]) == 3186 + 12407
+
+
+@pytest.mark.parametrize("L", [2, 3, 4])
+def test_partitioned_dual_fast_path_equals_the_launch_by_launch_schedule(L):
+    """spex_partitioned_dual_task_step_f32's fast path (plain forward layers, the last one at the batch's rows on their owners, one
+    launch for gate + scores + the gate's backward, the backward's first product in push form without an exchange, the layer-mean
+    share of the last product left to the Adam pass — for L == 3 the all-plain backward) against the launch-by-launch schedule of
+    the same call (fast=False): the same arithmetic in another order of float additions, so after four steps every parameter of the
+    arena, both Adam moments and both loss sums agree to rounding.  World size 1 (real RCCL communicator, local-copy shortcut);
+    L = 2 / 3 / 4 take the three branches of the schedule (model_expert_s.py:95-126,154-168; main_auto_expert_s.py:53-91)."""
+    import argparse
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "spex_amd", "dropin"))
+    import utility1.model_expert_s as mex
+    from spex_amd.datasets import load_epinion2
+    from spex_amd.dist_dual import PartitionedDualTask, PartitionedDualTaskStepper
+    from spex_amd.graph import lightgcn_norm_adj
+    dev = torch.device("cuda:0")
+    tr = load_epinion2()["train"]
+    n_u, n_i = 3185, 12407
+    csr = lightgcn_norm_adj(tr[:, 0], tr[:, 1], n_u, n_i)
+
+    class _DS:
+        n_users, m_items = n_u, n_i
+        getSparseGraph = staticmethod(lambda: None)
+    dargs = argparse.Namespace(hiddenSize=64, batchSize=100, nonhybrid=False, nb_heads=3, recdim=64, layer=L, keepprob=0.6, A_split=False, dropout=0)
+    rng = np.random.default_rng(17)
+    B, T, P_LEN = 256, 9, 6
+    batches = []
+    for _ in range(4):
+        ub = torch.from_numpy(np.r_[rng.integers(0, n_u, B - 8), np.full(8, 7)]).to(dev)        # a user named nine times in the batch
+        ib = torch.from_numpy(rng.integers(0, n_i, B)).to(dev)
+        yb = torch.from_numpy((rng.random(B) < 1 / 6).astype(np.float32)).to(dev)
+        plen = rng.integers(2, P_LEN + 1, T)
+        seq = np.full((T, P_LEN), n_u, dtype=np.int64)
+        for r, l in enumerate(plen):
+            seq[r, :l] = rng.choice(n_u, size=l, replace=False)
+        batches.append((ub, ib, yb, torch.from_numpy(seq).to(dev), torch.from_numpy(plen.astype(np.int64)).to(dev),
+                        torch.from_numpy(rng.integers(0, n_u, T)).to(dev)))
+    out = {}
+    for fast in (True, False):
+        torch.manual_seed(0)
+        core = mex.LightGCN(dargs, _DS).to(dev)
+        model = PartitionedDualTask(core, csr, 0, 1, dev)
+        st = PartitionedDualTaskStepper(model, path_capacity=T, path_len=P_LEN, lr=1e-3, fast=fast)
+        for b in batches:
+            st.step(*b)
+        torch.cuda.synchronize()
+        out[fast] = [x.detach().cpu().numpy().astype(np.float64) for x in (st.arena, st.m, st.v, st.loss_acc)]
+        # what the step must leave all-zero for the next one
+        assert float(st.g_prop.abs().sum()) == 0.0 and float(st.g_raw.abs().sum()) == 0.0 and float(st.g_small.abs().sum()) == 0.0
+        if fast:
+            assert float(model.P.table(2)[: model.P.n_local].abs().sum()) == 0.0                  # the push target (rank 0's own slot)
+            assert float(st.grad_slots.abs().sum()) == 0.0                                       # the gate gradients' copies
+        model.P.native.close()
+    for a, b, name in zip(out[True], out[False], ("parameters", "m", "v", "loss sums")):
+        err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+        assert err <= 5e-6, (L, name, err)
+
+
+@pytest.mark.parametrize("L", [2, 3, 4])
+def test_partitioned_lightgcn_fast_path_equals_the_launch_by_launch_schedule(L):
+    """spex_partitioned_step_bce_f32's fast path (last forward layer at the batch's rows on their owners, scores + owner-computes adds
+    in one launch, the backward's first product in push form without an exchange, the mean's share of the last product added by the
+    Adam pass; L == 3: the all-plain backward) against the launch-by-launch schedule of the same call and against the single-device
+    one-call step (LightGCNStepper): three steps on Epinion2, world size 1, L = 2 / 3 / 4 (utility1/model.py:66-121, main_rec.py:32-37)."""
+    from spex_amd.datasets import epinion2_tables, load_epinion2
+    from spex_amd.dist import PartitionedLightGCN, PartitionedStepper
+    from spex_amd.graph import SpexGraph, lightgcn_norm_adj
+    from spex_amd.trainer import LightGCNStepper
+    dev = torch.device("cuda:0")
+    tr = load_epinion2()["train"]
+    n_u, n_i = 3185, 12407
+    csr = lightgcn_norm_adj(tr[:, 0], tr[:, 1], n_u, n_i)
+    uw, iw = epinion2_tables(n_u + 1, n_i)
+    E0 = torch.from_numpy(np.concatenate([uw, iw])).to(dev)
+    rng = np.random.default_rng(23)
+    B = 256
+    batches = [(torch.from_numpy(np.r_[rng.integers(0, n_u, B - 6), np.full(6, 11)]).to(dev), torch.from_numpy(rng.integers(0, n_i, B)).to(dev),
+                torch.from_numpy((rng.random(B) < 1 / 6).astype(np.float32)).to(dev)) for _ in range(3)]
+    out = {}
+    for fast in (True, False):
+        P = PartitionedLightGCN(*csr, n_u + 1, L, 64, 0, 1, lambda r, c, v, n_cols: SpexGraph(r, c, v, n_cols=n_cols, device=dev), dev,
+                                allgather="native-p2p")
+        st = PartitionedStepper(P, E0.clone(), lr=1e-3, fast=fast)
+        acc = torch.zeros(1, device=dev)
+        for u, i, y in batches:
+            st.step_bce(u, i, y, loss_acc=acc)
+        torch.cuda.synchronize()
+        out[fast] = [x.cpu().numpy().astype(np.float64) for x in (st.E0, st.m, st.v, acc)]
+        assert float(st.g_local.abs().sum()) == 0.0
+        if fast:
+            assert float(P.table(2)[: P.n_local].abs().sum()) == 0.0                       # the push target is left all-zero
+        P.native.close()
+    single = LightGCNStepper(SpexGraph(*csr, device=dev), E0.clone(), n_u + 1, n_layers=L, lr=1e-3)
+    acc = torch.zeros(1, device=dev)
+    for u, i, y in batches:
+        single.step_bce(u, i, y, loss_acc=acc)
+    torch.cuda.synchronize()
+    out["single"] = [x.cpu().numpy().astype(np.float64) for x in (single.E0, single.m, single.v, acc)]
+    for other in (False, "single"):
+        for a, b, name in zip(out[True], out[other], ("table", "m", "v", "loss sum")):
+            err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+            assert err <= 5e-6, (L, other, name, err)

@@ -1000,6 +1000,60 @@ def test_attn_fuse_kernels_vs_torch_autograd(with_base, d):
             assert err <= 2e-5 * rf.grad.abs().max().item() + 1e-6, err
 
 
+def test_spmm_owned_rows_is_the_row_list_product_on_the_owner_and_zero_elsewhere(G, golden, epinion2, oracle):
+    """spex_spmm_owned_rows_f32 (the partitioned steps' last forward layer, utility1/model.py:91-97 at the rows of :115-116): on a row
+    block of Epinion2's adjacency the owned slots hold exactly what the row-list kernel computes for the local row (same segments,
+    same order), with the layer tables added in layer order and the raw row beside it; slots of other ranks' positions, negative
+    and too large positions are ZERO; plus hub rows (> 1 024 entries) and an empty row against the oracle."""
+    from spex_amd import ops
+    g_, csr, E0 = _epinion2(golden, epinion2)
+    rowptr, col, val = csr
+    n = len(rowptr) - 1
+    r0, r1 = 4000, 9000                                                   # a block holding user AND item rows
+    lrp = (rowptr[r0:r1 + 1] - rowptr[r0]).astype(np.int64)
+    sl = slice(rowptr[r0], rowptr[r1])
+    blk = G(lrp, col[sl], val[sl], n_cols=n)
+    rng = np.random.default_rng(41)
+    X = t(E0)
+    acc, a2, a3, raw = (t(rng.normal(size=(r1 - r0, 64)).astype(np.float32)) for _ in range(4))
+    pos = torch.from_numpy(np.r_[rng.integers(0, n, 500), [r0, r1 - 1, r0 - 1, r1, -5, n + 3, r0, r0]]).to(DEV)
+    own = ((pos >= r0) & (pos < r1)).cpu().numpy()
+    assert own.sum() > 100 and (~own).sum() > 100
+    loc = (pos - r0).clamp(0, r1 - r0 - 1)
+    for tables in ((None, None), (a2, None), (a2, a3)):
+        full = torch.empty(r1 - r0, 64, device=DEV)
+        blk.spmm_rows(X, torch.arange(r1 - r0, device=DEV), Y=full)       # the row-list kernel at every local row
+        run = acc.clone()
+        for tb in tables:
+            if tb is not None:
+                run = run + tb
+        want = ((run + full) / 4.0)[loc]
+        out_p, out_r = torch.full((len(pos), 64), 7.0, device=DEV), torch.full((len(pos), 64), 7.0, device=DEV)
+        ops.spmm_owned_rows(blk, X, pos, r0, acc, 4.0, out_p, raw=raw, out_raw=out_r, acc2=tables[0], acc3=tables[1])
+        assert torch.equal(out_p[own], want[own]) and torch.equal(out_r[own], raw[loc][own])
+        assert float(out_p[~own].abs().sum()) == 0.0 and float(out_r[~own].abs().sum()) == 0.0
+    out_p = torch.full((len(pos), 64), 7.0, device=DEV)
+    ops.spmm_owned_rows(blk, X, pos, r0, acc, 1.0, out_p)                  # no raw rows wanted
+    assert torch.equal(out_p[own], (acc + full)[loc][own])
+    # hub rows, an empty row
+    deg = rng.integers(0, 50, 300)
+    deg[3], deg[4], deg[5] = 0, 1500, 2600
+    rp2, c2, v2 = random_csr(rng, 300, 3000, deg)
+    g2 = G(rp2, c2, v2, n_cols=3000)
+    X2 = rng.normal(size=(3000, 64)).astype(np.float32)
+    acc2_ = rng.normal(size=(300, 64)).astype(np.float32)
+    want2 = (acc2_ + oracle.spmm(rp2, c2, v2, X2)) / 3.0
+    pos2 = torch.tensor([1003, 1004, 1005, 1299, 1300, 999, 1004], device=DEV)
+    out2 = torch.empty(7, 64, device=DEV)
+    ops.spmm_owned_rows(g2, t(X2), pos2, 1000, t(acc2_), 3.0, out2)
+    got2 = out2.cpu().numpy()
+    for k, r in enumerate([3, 4, 5, 299, None, None, 4]):
+        if r is None:
+            assert not got2[k].any()
+        else:
+            assert rel_err(got2[k], want2[r]) <= 3e-6, (k, r)
+
+
 def test_spmm_rowlist_is_the_full_product_at_the_listed_rows(G, golden, epinion2):
     """spex_spmm_rowlist_f32: bit-identical to the full launch at the listed rows (every row of Epinion2 has <= 1024
     entries: same segments, same order), other rows untouched; plus a graph with hub rows, empty rows and bad indices."""

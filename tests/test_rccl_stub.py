@@ -31,8 +31,10 @@ def test_native_exchange_call_sequence_world_2_4_8_without_a_wire(tmp_path):
 
 @pytest.mark.gpu
 def test_partitioned_step_call_sequence_world_4_rank_2_on_the_recording_stub(tmp_path):
-    """GPU (the step's kernels run for real, the wire is absent): own-slot copy, 2L exchanges + one all-reduce per step, every call
-    on the caller's stream, both exchange forms, the deterministic mode, a switch of the form between steps — and the one-call
-    partitioned DUAL-TASK step: 2L exchanges (the first into the kept table, straight from E^0) + ONE all-reduce of 4B rows, no
-    gate-gradient collective."""
+    """GPU (the step's kernels run for real, the wire is absent): every exchange IN PLACE (sent from the rank's own slot of the table
+    it is received around, the two tables alternating), every call on the caller's stream, both exchange forms, a switch of the form
+    between steps; per step one all-reduce and — fast path — 2L - 1 exchanges (none in front of the backward's first product: it is
+    the push; the first backward exchange is the push target's table), — deterministic mode / fast=False — 2L.  The one-call
+    partitioned DUAL-TASK step alike: the first exchange into the kept table (E^0), ONE all-reduce of 4B rows, no gate-gradient
+    collective."""
     _run("gpu", tmp_path)
