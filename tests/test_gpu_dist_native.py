@@ -310,3 +310,44 @@ def test_partitioned_lightgcn_fast_path_equals_the_launch_by_launch_schedule(L):
         for a, b, name in zip(out[True], out[other], ("table", "m", "v", "loss sum")):
             err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
             assert err <= 5e-6, (L, other, name, err)
+
+
+@pytest.mark.parametrize("L", [2, 3, 4])
+def test_partitioned_fast_path_on_a_non_symmetric_matrix_against_the_oracle(L, oracle):
+    """The fast path's push structure is the transpose of the rank's block of A^T (PartitionedLightGCN.push_graph): on a NON-symmetric
+    A with a hub row the gradient of one spex_partitioned_step_bce_f32 — read back from Adam's first moment, m = (1 - beta1) g — is
+    the oracle's d loss / d E0 (forward on A, backward on A^T: autograd of utility1/model.py:83-97,111-121), on the fast path and
+    on the launch-by-launch schedule alike (a push over the rows of A^T instead of A's would pass every symmetric test)."""
+    from spex_amd.dist import PartitionedLightGCN, PartitionedStepper
+    from spex_amd.graph import SpexGraph
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(31 + L)
+    n, n_u, B = 2000, 800, 96
+    deg = rng.integers(0, 40, n)
+    deg[5], deg[900], deg[7] = 1500, 1100, 0
+    rowptr = np.zeros(n + 1, np.int64)
+    cols = []
+    for r in range(n):
+        cols.append(np.sort(rng.choice(n, int(deg[r]), replace=False)))
+        rowptr[r + 1] = rowptr[r] + deg[r]
+    col = np.concatenate(cols).astype(np.int32)
+    val = (rng.random(len(col)).astype(np.float32) * 0.2 + 0.01)
+    rowptr = rowptr.astype(np.int32)
+    t_csr = oracle.csr_transpose(rowptr, col, val, n)
+    E0 = (rng.normal(size=(n, 64)) * 0.3).astype(np.float32)
+    u = np.r_[rng.integers(0, n_u, B - 3), [5, 5, 7]]                      # the hub row twice, the empty row once
+    i = np.r_[rng.integers(0, n - n_u, B - 1), [900 - n_u]]
+    y = (rng.random(B) < 0.3).astype(np.float32)
+    _, loss, G = oracle.lightgcn_loss_and_grad(rowptr, col, val, E0, n_u, L, u, i, y, n_threads=4, t_csr=t_csr)
+    for fast in (True, False):
+        P = PartitionedLightGCN(rowptr, col, val, n_u, L, 64, 0, 1, lambda r, c, v, n_cols: SpexGraph(r, c, v, n_cols=n_cols, device=dev), dev,
+                                t_csr=t_csr, allgather="native")
+        st = PartitionedStepper(P, torch.from_numpy(E0).to(dev), lr=1e-3, fast=fast)
+        acc = torch.zeros(1, device=dev)
+        st.step_bce(torch.from_numpy(u).to(dev), torch.from_numpy(i).to(dev), torch.from_numpy(y).to(dev), loss_acc=acc)
+        torch.cuda.synchronize()
+        got = st.m.cpu().numpy().astype(np.float64) / (1.0 - 0.9)
+        err = np.abs(got - G).max() / np.abs(G).max()
+        assert err <= 2e-5, (L, fast, err)
+        assert abs(acc.item() / B - float(loss)) <= 2e-6 * max(1.0, abs(float(loss))), (acc.item() / B, loss)
+        P.native.close()
