@@ -359,6 +359,52 @@ def test_two_ranks_partitioned_dual_task_on_the_weibo_shape(weibo, tmp_path):
     assert np.abs(table - want).max() <= 0.02 * args.lr * n_steps
 
 
+@pytest.mark.parametrize("fast", [True, False])
+def test_one_call_partitioned_dual_step_on_the_weibo_shape_equals_the_one_gpu_step(weibo, fast):
+    """spex_partitioned_dual_task_step_f32 on config 5's own shape (hub rows of > 1 024 and > 6 000 stored entries named by the batch):
+    the fast path — the last forward layer at the batch's rows by spex_spmm_owned_rows_f32 (a hub row is > 100 segments), the first
+    backward product pushed through the column structure (a hub COLUMN there) — and the launch-by-launch schedule against the
+    single-device one-call step (DualTaskStepper, itself pinned to autograd and the fp64 oracle above): both losses of each of three
+    steps, every parameter afterwards.  World size 1 (main_auto_expert_s.py:53-91, utility1/model_expert_s.py:95-168)."""
+    from collections import defaultdict
+    from utility2.utils import Data
+    from spex_amd.dist_dual import PartitionedDualTask, PartitionedDualTaskStepper
+    from spex_amd.trainer import DualTaskStepper
+    args, dataset, net = build_dual(weibo["data_root"])
+    _, _, core = build_dual(weibo["data_root"])                      # the same seed: the same initial parameters
+    net, core = net.to(DEV), core.to(DEV)
+    csr = dataset.build_adjacency()
+    n_u = N_USERS + 1
+    raw_train = weibo["raw_train"]
+    by_user = defaultdict(list)
+    for k, p in enumerate(raw_train[0]):
+        by_user[p[0]].append(k)
+    train2 = Data(raw_train, dataset.n_users, shuffle=False)
+    rng = np.random.default_rng(5)
+    cap = 15
+    single = DualTaskStepper(net, path_capacity=cap, path_len=train2.len_max, lr=args.lr)
+    model = PartitionedDualTask(core, csr, 0, 1, torch.device("cuda:0"))
+    part = PartitionedDualTaskStepper(model, path_capacity=cap, path_len=train2.len_max, lr=args.lr, fast=fast)
+    assert model.P.graph.n_long_rows >= 2
+    for step in range(3):
+        users, items, labels = hub_batch(csr, n_u, 256, rng)
+        sl = _paths_for(users, by_user, cap, rng)
+        inputs, mask, targets = train2.get_slice(sl)
+        seq, seq_l, tgt = (torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64)).to(DEV) for a in (inputs, np.asarray(mask).sum(1), targets))
+        single.loss_acc.zero_(); part.loss_acc.zero_()
+        single.step(t(users), t(items), t(labels), seq, seq_l, tgt)
+        part.step(t(users), t(items), t(labels), seq, seq_l, tgt)
+        a, b = single.loss_acc.cpu().numpy(), part.loss_acc.cpu().numpy()
+        assert abs(a[0] - b[0]) <= 3e-6 and abs(a[1] - b[1]) <= 2e-5 * abs(a[1]), (step, a, b)
+    want = torch.cat([net.embedding_user.weight, net.embedding_item.weight]).detach()
+    assert (model.E0_local.detach() - want).abs().max().item() <= 0.02 * args.lr * 3
+    for (name, p_), (_, q_) in zip(net.named_parameters(), core.named_parameters()):
+        if name.startswith("embedding_"):
+            continue                                                 # (the partitioned model keeps its table rows in E0_local)
+        assert (p_.detach() - q_.detach()).abs().max().item() <= 0.02 * args.lr * 3, name
+    model.P.native.close()
+
+
 def test_trust_head_split_form_survives_replay_from_a_captured_graph():
     """The split fused trust kernel replayed from a captured HIP graph (the SAME ticket tag on every replay: the path's last
     workgroup puts the ticket back to 0): three replays on changing user tables equal the eager calls bit for bit."""
