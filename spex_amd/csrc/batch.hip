@@ -545,92 +545,160 @@ __global__ __launch_bounds__(kWave *kWgWaves) void gated_batch_push_kernel(
 }
 
 
-// The dual-task rec branch's batch-sized middle on a ROW PARTITION (comm.hip: spex_partitioned_dual_task_step_f32, fast path): the
-// batch's rows arrive COMPACT and complete on every rank (rows_raw / rows_prop [2B, 64]: slot b = sample b's user row, slot B + b
-// its item row — the owner-computes all-reduce behind spex_spmm_owned_rows_f32), so gate, score, loss and the gate's backward are
-// gated_batch_push_kernel's steps 2-3 on them, operand for operand, computed REDUNDANTLY by every rank (two waves per sample): the
-// loss and the two gate matrices' gradients are therefore complete everywhere without a collective.  What leaves:
-//   g_prop_slots[slot] = d loss / d propagated row (plain store; every rank pushes every slot through ITS columns of A afterwards)
-//   and, for a slot whose row this rank owns (lo <= pos[slot] < lo + n_local; r = pos[slot] - lo):
-//   P[r] += push_scale * d_prop  (the g term of (g + A^T g) / (L+1)),  g_raw[r] += d_raw,  g_prop[r] += d_prop (if g_prop)
-__global__ __launch_bounds__(2 * kWave) void gated_rows_train_kernel(
+
+// The batch-sized middle of the one-call steps on a ROW PARTITION (comm.hip: the fast paths of spex_partitioned_step_bce_f32 and
+// spex_partitioned_dual_task_step_f32).  The batch's rows arrive COMPACT and complete on every rank (rows_prop / rows_raw [2B, 64]:
+// slot b = sample b's user row, slot B + b its item row — the owner-computes all-reduce behind spex_spmm_owned_rows_f32), so
+// everything between the forward and the first backward product is one launch, computed REDUNDANTLY by every rank (which is why
+// the loss and the two gate matrices' gradients are complete everywhere without a collective):
+//   GATED  gate, score, loss and the gate's backward — gated_batch_push_kernel's steps 2-3, operand for operand (waves 0 / 1)
+//   plain  score, loss, the two gradient rows — lightgcn_batch_kernel's step 2
+//   part 0 of a sample, for a slot whose row this rank owns (lo <= pos[slot] < lo + n_local; r = pos[slot] - lo):
+//          P[r] += push_scale * d_prop  (the g term of (g + A^T g) / (L+1)),  g_prop[r] += d_prop (if g_prop),  g_raw[r] += d_raw
+//   then the first backward product in push form WITHOUT an exchange: every rank pushes BOTH gradient rows of EVERY sample through
+//   its own columns of A — the matrix (rowptr, col, val) is the (world * max_rows) x n_local transpose of the rank's block of A^T,
+//   row p = the entries A[p, c] for the rank's columns c: P[col[e]] += push_scale * val[e] * d_prop over the entries of rows
+//   pos[b], pos[B + b] (runs of 16 entries dealt over (part, wave) and loaded ahead, as in lightgcn_batch_kernel<true>).
+// rowptr == NULL: a rank without rows (nothing to push, nothing owned) — it still forms the loss and the gate gradients.
+template <bool GATED>
+__global__ __launch_bounds__(kWave *kWgWaves) void rows_train_push_kernel(
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val, int n_push_rows,
     const float *__restrict__ rows_raw, const float *__restrict__ rows_prop, const float *__restrict__ att_u,
     const float *__restrict__ att_i, const int64_t *__restrict__ pos, int64_t lo, int n_local, const float *__restrict__ labels, int B,
-    float grad_scale, float push_scale, float *loss_sum, float *__restrict__ g_prop_slots, float *g_prop, float *P, float *g_raw,
+    int parts, int runs_per_part, float grad_scale, float push_scale, float *loss_sum, float *g_prop, float *P, float *g_raw,
     float *g_att, int n_att_copies)
 {
     __shared__ float s_mixed[2][kWave];
+    __shared__ float s_dprop[2][kWave];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int b = blockIdx.x;
-    const size_t slot = (size_t)wave * B + b;
+    const int b = blockIdx.x / parts, part = blockIdx.x % parts;
+    const int64_t p64[2] = {pos[b], pos[(size_t)B + b]};
     const float y_lab = labels[b];
-    const float *att = wave ? att_i : att_u;
-    const float a_raw = rows_raw[slot * kWave + lane], s = rows_prop[slot * kWave + lane];
-    const float w00 = att[2 * lane], w01 = att[2 * lane + 1], w10 = att[2 * (kWave + lane)], w11 = att[2 * (kWave + lane) + 1];
-    const int64_t r64 = pos[slot] - lo;
-    float z0 = fmaf(s, w10, fmaf(a_raw, w00, 0.0f)), z1 = fmaf(s, w11, fmaf(a_raw, w01, 0.0f));
-    z0 = wave_sum_f32(z0);
-    z1 = wave_sum_f32(z1);
-    const float mx = fmaxf(z0, z1);
-    const float e0 = expf(z0 - mx), e1 = expf(z1 - mx);
-    const float a0 = e0 / (e0 + e1), a1 = e1 / (e0 + e1);
-    s_mixed[wave][lane] = a_raw * a0 + s * a1;
-    __syncthreads();
-    const float mu = s_mixed[0][lane], mi = s_mixed[1][lane];
-    const float x = wave_sum_f32(fmaf(mu, mi, 0.0f));
-    const float dg = (sigmoid_f(x) - y_lab) * grad_scale;
-    const float gg = dg * (wave ? mu : mi);
-    const float da0 = wave_sum_f32(gg * a_raw), da1 = wave_sum_f32(gg * s);
-    const float dot = a0 * da0 + a1 * da1;
-    const float dz0 = a0 * (da0 - dot), dz1 = a1 * (da1 - dot);
-    const float d_raw = a0 * gg + dz0 * w00 + dz1 * w01, d_prop = a1 * gg + dz0 * w10 + dz1 * w11;
-    g_prop_slots[slot * kWave + lane] = d_prop;
-    if (r64 >= 0 && r64 < n_local) {                                   // wave-uniform: the rows this rank owns
-        const size_t o = (size_t)r64 * kWave + lane;
-        if (g_prop) atomicAdd(g_prop + o, d_prop);
-        atomicAdd(P + o, push_scale * d_prop);
-        atomicAdd(g_raw + o, d_raw);
-    }
-    float *ga = g_att + (size_t)(b % n_att_copies) * 512 + wave * 256;   // (copies: see gated_batch_push_kernel)
-    atomicAdd(ga + 2 * lane, fmaf(a_raw, dz0, 0.0f));
-    atomicAdd(ga + 2 * lane + 1, fmaf(a_raw, dz1, 0.0f));
-    atomicAdd(ga + 2 * (kWave + lane), fmaf(s, dz0, 0.0f));
-    atomicAdd(ga + 2 * (kWave + lane) + 1, fmaf(s, dz1, 0.0f));
-    if (wave == 0 && lane == 0) atomicAdd(loss_sum, fmaxf(x, 0.0f) - x * y_lab + log1pf(expf(-fabsf(x))));
-}
-
-
-// The LightGCN step's batch-sized middle on a ROW PARTITION (comm.hip: spex_partitioned_step_bce_f32, fast path): the batch's
-// propagated rows arrive compact and complete on every rank (rows [2B, 64]: slot b = sample b's user row, slot B + b its item row),
-// so score, loss and the two gradient rows are lightgcn_batch_kernel's step 2 on them (utility1/model.py:111-121 + autograd), computed
-// redundantly by every rank — one wave per sample.  grad_slots[slot] = the slot's gradient row (plain store: every rank pushes every
-// slot through its own columns of A afterwards); for a slot whose row this rank owns: P[r] += push_scale * g, g_out[r] += g (if g_out).
-__global__ __launch_bounds__(4 * kWave) void score_rows_train_kernel(const float *__restrict__ rows, const int64_t *__restrict__ pos, int64_t lo,
-                                                                    int n_local, const float *__restrict__ labels, int B, float grad_scale,
-                                                                    float push_scale, float *loss_sum, float *__restrict__ grad_slots,
-                                                                    float *g_out, float *P)
-{
-    const int lane = threadIdx.x & (kWave - 1);
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= B) return;
-    const float lu = rows[(size_t)b * kWave + lane], li = rows[(size_t)(B + b) * kWave + lane];
-    const float y_lab = labels[b];
-    const float x = wave_sum_f32(fmaf(lu, li, 0.0f));
-    const float dg = (sigmoid_f(x) - y_lab) * grad_scale;
-    const float g2[2] = {dg * li, dg * lu};
+    int beg[2] = {0, 0}, deg[2] = {0, 0};
 #pragma unroll
-    for (int w = 0; w < 2; ++w) {
-        const size_t slot = (size_t)w * B + b;
-        grad_slots[slot * kWave + lane] = g2[w];
-        const int64_t r64 = pos[slot] - lo;
-        if (r64 >= 0 && r64 < n_local) {
-            const size_t o = (size_t)r64 * kWave + lane;
-            if (g_out) atomicAdd(g_out + o, g2[w]);
-            atomicAdd(P + o, push_scale * g2[w]);
+    for (int w = 0; w < 2; ++w)
+        if (rowptr && p64[w] >= 0 && p64[w] < n_push_rows) {
+            beg[w] = rowptr[p64[w]];
+            deg[w] = rowptr[p64[w] + 1] - beg[w];
+        }
+    float a_raw = 0.0f, s = 0.0f, w00 = 0.0f, w01 = 0.0f, w10 = 0.0f, w11 = 0.0f;
+    if (wave < 2) {                       // the operands, requested with everything else
+        const size_t o = ((size_t)wave * B + b) * kWave + lane;
+        s = rows_prop[o];
+        if (GATED) {
+            const float *att = wave ? att_i : att_u;
+            a_raw = rows_raw[o];
+            w00 = att[2 * lane]; w01 = att[2 * lane + 1];
+            w10 = att[2 * (kWave + lane)]; w11 = att[2 * (kWave + lane) + 1];
         }
     }
-    if (lane == 0) atomicAdd(loss_sum, fmaxf(x, 0.0f) - x * y_lab + log1pf(expf(-fabsf(x))));
+    const int n_run0 = (deg[0] + 15) >> 4, n_runs = n_run0 + ((deg[1] + 15) >> 4);
+    const int want = (n_runs + runs_per_part - 1) / runs_per_part;
+    const int act = want < parts ? (want < 1 ? 1 : want) : parts;
+    if (part >= act) return;
+    const int q_step = act * kWgWaves;
+    int q = part * kWgWaves + wave;
+    int p_col[kPre], p_cnt[kPre], p_side[kPre];
+    float p_val[kPre];
+    auto load_runs = [&](int q0) {
+#pragma unroll
+        for (int p = 0; p < kPre; ++p) {
+            const int qq = q0 + p * q_step;
+            p_col[p] = 0;
+            p_val[p] = 0.0f;
+            p_cnt[p] = 0;
+            p_side[p] = 0;
+            if (qq < n_runs) {
+                const int side = qq >= n_run0, rr = side ? qq - n_run0 : qq;
+                const int base = beg[side] + rr * 16, left = deg[side] - rr * 16;
+                p_side[p] = side;
+                p_cnt[p] = left < 16 ? left : 16;
+                if (lane < p_cnt[p]) {
+                    p_col[p] = col[base + lane];
+                    p_val[p] = val[base + lane];
+                }
+            }
+        }
+    };
+    load_runs(q);
+    // ---- gate (GATED) -> the rows that are scored
+    float a0 = 0.0f, a1 = 0.0f;
+    if (wave < 2) {
+        float mixed = s;
+        if (GATED) {
+            float z0 = fmaf(s, w10, fmaf(a_raw, w00, 0.0f)), z1 = fmaf(s, w11, fmaf(a_raw, w01, 0.0f));
+            z0 = wave_sum_f32(z0);
+            z1 = wave_sum_f32(z1);
+            const float mx = fmaxf(z0, z1);
+            const float e0 = expf(z0 - mx), e1 = expf(z1 - mx);
+            a0 = e0 / (e0 + e1); a1 = e1 / (e0 + e1);
+            mixed = a_raw * a0 + s * a1;
+        }
+        s_mixed[wave][lane] = mixed;
+    }
+    __syncthreads();
+    // ---- score, loss, d loss / d scored rows (and through the gate), the owned rows' shares
+    if (wave < 2) {
+        const float mu = s_mixed[0][lane], mi = s_mixed[1][lane];
+        const float x = wave_sum_f32(fmaf(mu, mi, 0.0f));
+        const float dg = (sigmoid_f(x) - y_lab) * grad_scale;
+        const float gg = dg * (wave ? mu : mi);
+        float d_raw = 0.0f, d_prop = gg, dz0 = 0.0f, dz1 = 0.0f;
+        if (GATED) {
+            const float da0 = wave_sum_f32(gg * a_raw), da1 = wave_sum_f32(gg * s);
+            const float dot = a0 * da0 + a1 * da1;
+            dz0 = a0 * (da0 - dot); dz1 = a1 * (da1 - dot);
+            d_raw = a0 * gg + dz0 * w00 + dz1 * w01;
+            d_prop = a1 * gg + dz0 * w10 + dz1 * w11;
+        }
+        s_dprop[wave][lane] = d_prop;
+        if (part == 0) {
+            const int64_t r64 = p64[wave] - lo;
+            if (r64 >= 0 && r64 < n_local) {                              // wave-uniform: the rows this rank owns
+                const size_t o = (size_t)r64 * kWave + lane;
+                if (g_prop) atomicAdd(g_prop + o, d_prop);
+                atomicAdd(P + o, push_scale * d_prop);
+                if (GATED) atomicAdd(g_raw + o, d_raw);
+            }
+            if (GATED) {
+                float *ga = g_att + (size_t)(b % n_att_copies) * 512 + wave * 256;   // (copies: see gated_batch_push_kernel)
+                atomicAdd(ga + 2 * lane, fmaf(a_raw, dz0, 0.0f));
+                atomicAdd(ga + 2 * lane + 1, fmaf(a_raw, dz1, 0.0f));
+                atomicAdd(ga + 2 * (kWave + lane), fmaf(s, dz0, 0.0f));
+                atomicAdd(ga + 2 * (kWave + lane) + 1, fmaf(s, dz1, 0.0f));
+            }
+            if (wave == 0 && lane == 0) atomicAdd(loss_sum, fmaxf(x, 0.0f) - x * y_lab + log1pf(expf(-fabsf(x))));
+        }
+    }
+    if (n_runs == 0) return;                                               // (workgroup-uniform)
+    __syncthreads();
+    // ---- push over both rows' entries in the rank's columns (lightgcn_batch_kernel's loop)
+    const float g2[2] = {push_scale * s_dprop[0][lane], push_scale * s_dprop[1][lane]};
+    float *out_l = P + lane;
+    for (;;) {
+        int c0[kPre];
+        float v0[kPre];
+#pragma unroll
+        for (int p = 0; p < kPre; ++p) {
+            c0[p] = __builtin_amdgcn_readlane(p_col[p], 0);
+            v0[p] = lane_bcast(p_val[p], 0);
+        }
+#pragma unroll
+        for (int p = 0; p < kPre; ++p) {
+            const float gs = p_side[p] ? g2[1] : g2[0];
+            if (p_cnt[p] > 0) atomicAdd(out_l + (size_t)c0[p] * kWave, v0[p] * gs);
+#pragma unroll 1
+            for (int j = 1; j < p_cnt[p]; ++j) {
+                const int c = __builtin_amdgcn_readlane(p_col[p], j);
+                const float v = lane_bcast(p_val[p], j);
+                atomicAdd(out_l + (size_t)c * kWave, v * gs);
+            }
+        }
+        q += kPre * q_step;
+        if (q >= n_runs) break;
+        load_runs(q);
+    }
 }
 
 }  // namespace
@@ -778,29 +846,28 @@ int spex::lightgcn_batch_layers(const spex_graph_t *g, const float *X, const flo
     return SPEX_OK;
 }
 
-int spex::gated_rows_train(const float *rows_raw, const float *rows_prop, const float *att_u, const float *att_i, const int64_t *pos,
-                           int64_t lo, int32_t n_local, const float *labels, int32_t B, float grad_scale, float push_scale, float *loss_sum,
-                           float *g_prop_slots, float *g_prop, float *P, float *g_raw, float *g_att, int32_t n_att_copies, void *stream)
+int spex::rows_train_push(const spex_graph_t *push, const float *rows_raw, const float *rows_prop, const float *att_u, const float *att_i,
+                          const int64_t *pos, int64_t lo, int32_t n_local, const float *labels, int32_t B, float grad_scale, float push_scale,
+                          float *loss_sum, float *g_prop, float *P, float *g_raw, float *g_att, int32_t n_att_copies, void *stream)
 {
-    SPEX_CHECK_ARG(rows_raw && rows_prop && att_u && att_i && pos && labels && loss_sum && g_prop_slots && P && g_raw && g_att,
-                   "gated_rows_train: NULL argument");
-    SPEX_CHECK_ARG(B >= 0 && n_local >= 0 && n_att_copies >= 1, "gated_rows_train: B=%d n_local=%d n_att_copies=%d", B, n_local, n_att_copies);
-    SPEX_CHECK_ARG(P != g_prop && P != g_raw && g_prop != g_raw, "gated_rows_train: g_prop, P and g_raw are three tables");
+    const bool gated = rows_raw != nullptr;
+    SPEX_CHECK_ARG(rows_prop && pos && labels && loss_sum && P, "rows_train_push: NULL argument");
+    SPEX_CHECK_ARG(!gated || (att_u && att_i && g_raw && g_att && n_att_copies >= 1), "rows_train_push: the gated form needs att_u, att_i, g_raw, g_att");
+    SPEX_CHECK_ARG(B >= 0 && n_local >= 0, "rows_train_push: B=%d n_local=%d", B, n_local);
+    SPEX_CHECK_ARG(!push || (push->n_cols == n_local && push->mask_mode == 0), "rows_train_push: the push structure has %d columns for %d local rows",
+                   push ? push->n_cols : 0, n_local);
+    SPEX_CHECK_ARG(P != g_prop && P != g_raw && (!g_prop || g_prop != g_raw), "rows_train_push: g_prop, P and g_raw are three tables");
     if (B == 0) return SPEX_OK;
-    hipLaunchKernelGGL(gated_rows_train_kernel, dim3((unsigned)B), dim3(2 * kWave), 0, (hipStream_t)stream, rows_raw, rows_prop, att_u, att_i,
-                       pos, lo, n_local, labels, B, grad_scale, push_scale, loss_sum, g_prop_slots, g_prop, P, g_raw, g_att, n_att_copies);
-    SPEX_HIP(hipGetLastError());
-    return SPEX_OK;
-}
-
-int spex::score_rows_train(const float *rows, const int64_t *pos, int64_t lo, int32_t n_local, const float *labels, int32_t B, float grad_scale,
-                           float push_scale, float *loss_sum, float *grad_slots, float *g_out, float *P, void *stream)
-{
-    SPEX_CHECK_ARG(rows && pos && labels && loss_sum && grad_slots && P, "score_rows_train: NULL argument");
-    SPEX_CHECK_ARG(B >= 0 && n_local >= 0 && P != g_out, "score_rows_train: B=%d n_local=%d, or P aliases g_out", B, n_local);
-    if (B == 0) return SPEX_OK;
-    hipLaunchKernelGGL(score_rows_train_kernel, dim3((unsigned)((B + 3) / 4)), dim3(4 * kWave), 0, (hipStream_t)stream, rows, pos, lo, n_local,
-                       labels, B, grad_scale, push_scale, loss_sum, grad_slots, g_out, P);
+    constexpr int parts = kBatchParts, runs_per_part = kBatchRunsPerPart;
+    const int32_t *rp = push && push->n_rows > 0 ? push->rowptr : nullptr;
+    if (gated)
+        hipLaunchKernelGGL(rows_train_push_kernel<true>, dim3((unsigned)B * parts), dim3(kWave * kWgWaves), 0, (hipStream_t)stream, rp,
+                           push ? push->col : nullptr, push ? push->val : nullptr, push ? push->n_rows : 0, rows_raw, rows_prop, att_u, att_i, pos, lo,
+                           n_local, labels, B, parts, runs_per_part, grad_scale, push_scale, loss_sum, g_prop, P, g_raw, g_att, n_att_copies);
+    else
+        hipLaunchKernelGGL(rows_train_push_kernel<false>, dim3((unsigned)B * parts), dim3(kWave * kWgWaves), 0, (hipStream_t)stream, rp,
+                           push ? push->col : nullptr, push ? push->val : nullptr, push ? push->n_rows : 0, nullptr, rows_prop, nullptr, nullptr, pos, lo,
+                           n_local, labels, B, parts, runs_per_part, grad_scale, push_scale, loss_sum, g_prop, P, nullptr, nullptr, 1);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }

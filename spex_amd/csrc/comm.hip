@@ -324,11 +324,9 @@ extern "C" int spex_partitioned_step_bce_f32(spex_partitioned_step_t *s, const i
         // push form through the rank's own columns of A — no exchange; P = gathered2's own slot, kept all-zero by the Adam pass
         float *P = own(s->gathered2);
         const bool all_plain = L == 3;
-        SPEX_TRY(spex::score_rows_train(s->rows, pos, lo, (int32_t)n_loc, labels, B, 1.0f / (float)B, 1.0f / (float)(L + 1), loss_sum, s->grad_rows,
-                                        all_plain ? nullptr : s->g_local, P, stream));
-        if (n_loc)
-            SPEX_TRY(spex_spmm_push_batch_f32(s->graph_push, pos, 2 * B, 0, nullptr, 0, 0, s->grad_rows, d, nullptr, 0, 1.0f / (float)(L + 1), P, d,
-                                              stream));
+        SPEX_TRY(spex::rows_train_push(n_loc ? s->graph_push : nullptr, nullptr, s->rows, nullptr, nullptr, pos, lo, (int32_t)n_loc, labels, B,
+                                       1.0f / (float)B, 1.0f / (float)(L + 1), loss_sum, all_plain ? nullptr : s->g_local, P, nullptr, nullptr, 1,
+                                       stream));
         float *Xb = s->gathered2;
         for (int32_t l = L - 2, k = 0; l >= 0; --l, ++k) {
             SPEX_TRY(exchange_in_place(s->comm, s->rows_per_rank, nullptr, n_loc, s->max_rows, d, Xb, stream));
@@ -480,19 +478,15 @@ extern "C" int spex_partitioned_dual_task_step_f32(spex_partitioned_dual_step_t 
                                           plain && L == 3 ? own(Tb[1]) : nullptr, (float)(L + 1), E0, rows_prop, rows_raw, d, stream));
         SPEX_TRY(spex_comm_allreduce_sum_f32(s->comm, s->rows, (int64_t)4 * B * d, stream));
         // ---- gate, scores, BCE, the gate's backward on the compact rows — replicated: loss and gate gradients are complete on every
-        //      rank —, the owned rows' shares added where they belong (batch.hip: gated_rows_train_kernel); P = the own slot of
-        //      gathered2, all-zero here (cleared by the previous step's Adam pass)
+        //      rank —, the owned rows' shares added where they belong, and the backward's first product in push form, WITHOUT an
+        //      exchange: every rank holds all 2B gradient rows and pushes them through its own columns of A (graph_push: row = a
+        //      position of the padded layout, columns = the rank's rows): P = (g + A^T g) / (L+1) on the rank's rows.  ONE launch
+        //      (batch.hip: rows_train_push_kernel); P = the own slot of gathered2, all-zero here (cleared by the previous step's Adam)
         float *P = own(s->gathered2);
-        SPEX_TRY(spex::gated_rows_train(rows_raw, rows_prop, att1, att2, pos, lo, (int32_t)n_loc, labels, B, 1.0f / (float)B, 1.0f / (float)(L + 1),
-                                        s->loss, s->g_prop_slots, L == 3 ? nullptr : s->g_prop, P, s->g_raw,
-                                        att_copies_max >= 1 ? s->grad_slots : g_att1, att_copies_max >= 1 ? att_copies_max : 1, stream));
+        SPEX_TRY(spex::rows_train_push(n_loc ? s->graph_push : nullptr, rows_raw, rows_prop, att1, att2, pos, lo, (int32_t)n_loc, labels, B,
+                                       1.0f / (float)B, 1.0f / (float)(L + 1), s->loss, L == 3 ? nullptr : s->g_prop, P, s->g_raw,
+                                       att_copies_max >= 1 ? s->grad_slots : g_att1, att_copies_max >= 1 ? att_copies_max : 1, stream));
         att_copies_used = att_copies_max;
-        // ---- the backward's first product in push form, WITHOUT an exchange: every rank holds all 2B gradient rows and pushes them
-        //      through its own columns of A (graph_push: row = a position of the padded layout, columns = the rank's rows):
-        //      P = (g + A^T g) / (L+1) on the rank's rows
-        if (n_loc)
-            SPEX_TRY(spex_spmm_push_batch_f32(s->graph_push, pos, 2 * B, 0, nullptr, 0, 0, s->g_prop_slots, d, nullptr, 0, 1.0f / (float)(L + 1), P,
-                                              d, stream));
         // ---- the L-1 pull-form products on A^T's block: P's table is exchanged in place, the outputs alternate between the two
         //      forward tables' own slots (dead by now); the last one plain — the Adam pass adds its g_prop / (L+1) share; L == 3: both
         //      plain, the Adam pass adds P instead (spex_dual_task_step_f32's schedule)

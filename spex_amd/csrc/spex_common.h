@@ -54,14 +54,12 @@ int gated_batch_push_layers(const spex_graph_t *g, const float *X, const float *
                             const float *raw, const float *att_u, const float *att_i, const int64_t *users, const int64_t *items,
                             const float *labels, int32_t B, int32_t n_user_rows, float grad_scale, float push_scale, float *loss_sum,
                             float *g_prop, float *G, float *g_raw, float *g_att, int32_t n_att_copies, int32_t d, void *stream);
-// (the same middle on a row partition, on the batch's compact replicated rows — gate, scores, the gate's backward, owner-computes
-//  adds: batch.hip)
-int gated_rows_train(const float *rows_raw, const float *rows_prop, const float *att_u, const float *att_i, const int64_t *pos, int64_t lo,
-                     int32_t n_local, const float *labels, int32_t B, float grad_scale, float push_scale, float *loss_sum,
-                     float *g_prop_slots, float *g_prop, float *P, float *g_raw, float *g_att, int32_t n_att_copies, void *stream);
-// (the LightGCN step's middle on a row partition: scores, loss, gradient rows, owner-computes adds on the compact rows: batch.hip)
-int score_rows_train(const float *rows, const int64_t *pos, int64_t lo, int32_t n_local, const float *labels, int32_t B, float grad_scale,
-                     float push_scale, float *loss_sum, float *grad_slots, float *g_out, float *P, void *stream);
+// (the batch-sized middle of the partitioned one-call steps on the batch's compact replicated rows — [gate,] scores, [the gate's
+//  backward,] owner-computes adds, and the first backward product pushed through the rank's own columns of A: batch.hip;
+//  rows_raw == NULL: the LightGCN form; push == NULL: a rank without rows)
+int rows_train_push(const spex_graph_t *push, const float *rows_raw, const float *rows_prop, const float *att_u, const float *att_i,
+                    const int64_t *pos, int64_t lo, int32_t n_local, const float *labels, int32_t B, float grad_scale, float push_scale,
+                    float *loss_sum, float *g_prop, float *P, float *g_raw, float *g_att, int32_t n_att_copies, void *stream);
 int score_bce_slots_rows(const float *users, const float *items, int32_t ldu, int32_t ldi, int64_t n_user_rows, int64_t n_item_rows,
                          const int64_t *u_idx, const int64_t *i_idx, const float *labels, int32_t B, int32_t d, float *loss_rows,
                          float grad_scale, float *grad_slots, int32_t ld_slots, void *stream);     // score.hip: per-sample rows + losses

@@ -24,7 +24,7 @@ class _DS:
 
 dargs = argparse.Namespace(hiddenSize=64, batchSize=100, nonhybrid=False, nb_heads=3, recdim=64, layer=L, keepprob=0.6, A_split=False, dropout=0)
 rng = np.random.default_rng(13)
-B, T, P_LEN = 256, 15, 6
+B, T, P_LEN = 256, int(os.environ.get("DUAL_PART_PATHS", "15")), 6            # DUAL_PART_PATHS=0: the rec branch alone
 ub = torch.from_numpy(rng.integers(0, n_u, B)).to(dev); ib = torch.from_numpy(rng.integers(0, n_i, B)).to(dev)
 yb = torch.from_numpy((rng.random(B) < 1 / 6).astype(np.float32)).to(dev)
 plen = rng.integers(2, P_LEN + 1, T)
@@ -33,6 +33,8 @@ for r, l in enumerate(plen):
     seq[r, :l] = rng.choice(n_u, size=l, replace=False)
 seq_d, len_d = torch.from_numpy(seq).to(dev), torch.from_numpy(plen.astype(np.int64)).to(dev)
 tgt = torch.from_numpy(rng.integers(0, n_u, T)).to(dev)
+if T == 0:
+    seq_d = len_d = tgt = None
 
 
 def timed(fn, n=500, reps=3):
@@ -57,12 +59,12 @@ def timed(fn, n=500, reps=3):
 
 torch.manual_seed(0)
 net = mex.LightGCN(dargs, _DS).to(dev)
-st = DualTaskStepper(net, path_capacity=T, path_len=P_LEN, lr=1e-3)
+st = DualTaskStepper(net, path_capacity=max(T, 1), path_len=P_LEN, lr=1e-3)
 print("DualTaskStepper                                     : %.1f us (host enqueue %.1f)" % timed(lambda: st.step(ub, ib, yb, seq_d, len_d, tgt)), flush=True)
 for det, fast, tag in ((False, True, "fast path      "), (False, False, "launch by launch"), (True, True, "deterministic   ")):
     torch.manual_seed(0)
     core = mex.LightGCN(dargs, _DS).to(dev)
     model = PartitionedDualTask(core, csr, 0, 1, dev)
-    pst = PartitionedDualTaskStepper(model, path_capacity=T, path_len=P_LEN, lr=1e-3, deterministic=det, fast=fast)
+    pst = PartitionedDualTaskStepper(model, path_capacity=max(T, 1), path_len=P_LEN, lr=1e-3, deterministic=det, fast=fast)
     pos = pst.positions(ub, ib)
     print("PartitionedDualTaskStepper, world 1, %s: %.1f us (host enqueue %.1f)" % ((tag,) + timed(lambda: pst.step(ub, ib, yb, seq_d, len_d, tgt, pos=pos))), flush=True)
