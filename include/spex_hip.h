@@ -926,7 +926,7 @@ int spex_partitioned_step_bce_f32(spex_partitioned_step_t *step, const int64_t *
  * before the first call; every call leaves them so); gathered, gathered1, gathered0 [world * max_rows, 64] (three tables);
  * rows [2 * slot_capacity, 64]; mixed_slots, grad_slots, g_prop_slots, g_raw_slots [slot_capacity, 64], slot_capacity >= 2B;
  * loss_rows [slot_capacity]; att_parts [spex_expert_gate_rows_bwd_parts(slot_capacity) * 512]; arange int64 [slot_capacity];
- * g_user [n_user_rows, 64]; g_small [P + 512] (all-zero before the first call); a2, trust_ws, dscore, loss_b, loss [2],
+ * g_user [n_user_rows, 64] and g_small [P + 512] (both all-zero before the first call; the Adam pass leaves them so); a2, trust_ws, dscore, loss_b, loss [2],
  * loss_acc [2], precision [2][2] as in spex_dual_task_step_t (trust workspace sized for n_user_rows).
  * pos: device int64 [2B], the batch's rows in the padded layout (users, then items).  t is advanced by the call. */
 typedef struct spex_partitioned_dual_step {

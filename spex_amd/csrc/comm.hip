@@ -434,9 +434,15 @@ extern "C" int spex_partitioned_dual_task_step_f32(spex_partitioned_dual_step_t 
     // ---- trust branch (model_expert_s.py:170-192) on the gathered user block, redundantly on every rank; beside the rec branch
     //      when the caller gave a second stream
     const bool two_streams = s->side_stream != nullptr && s->side_stream != stream && T > 0;
+    // (g_user is all-zero here: the Adam pass clears the rank's own user rows as it reads them and the other ranks' rows beside them.
+    //  The user block is gathered on the CALLER's stream, in front of the fork: with a launch of its own in front of it the trust kernel
+    //  reached the GPU while layer 1's product held every CU — its 15 workgroups want a whole CU's registers each and waited the launch
+    //  out, ~10 us on the side branch, which at world size 1 is the step's longest chain; forked behind the gather both start together.)
+    //  (the launch-by-launch schedule's rec branch is the longer chain by far: there the gather stays on the side branch)
+    const bool gather_first = fast && two_streams;
+    if (gather_first) SPEX_TRY(spex_gather_owned_rows_f32(s->gathered0, s->user_pos, n_u, 0, world * max_rows, d, s->user_table, stream));
     auto trust_branch = [&](void *st) -> int {
-        SPEX_TRY(spex::zero_f32(s->g_user, (int64_t)n_u * d, st));               // (the Adam pass clears the rank's rows only)
-        SPEX_TRY(spex_gather_owned_rows_f32(s->gathered0, s->user_pos, n_u, 0, world * max_rows, d, s->user_table, st));
+        if (!gather_first) SPEX_TRY(spex_gather_owned_rows_f32(s->gathered0, s->user_pos, n_u, 0, world * max_rows, d, s->user_table, st));
         return spex::trust_head_train(s->user_table, n_u, trust_p, seq, seq_l, targets, T, s->path_len, d, H, s->hybrid, 1.0f, nullptr, s->a2,
                                       s->dscore, s->loss_b, s->trust_ws, s->loss + 1, 0, s->g_small, s->g_user, st == stream && !det ? 8 : 1, st);
     };
@@ -560,7 +566,8 @@ extern "C" int spex_partitioned_dual_task_step_f32(spex_partitioned_dual_step_t 
                                   s->loss_acc, s->precision, (int64_t)sz, (int64_t)s->n_local_users * d, n_trust, B, T, s->n_rec, s->t + 1, s->lr,
                                   s->beta1, s->beta2, s->eps, (s->flags & SPEX_STEP_FIXED_TASK_WEIGHTS) != 0, stream,
                                   fast ? (L == 3 ? -1.0f : (float)(L + 1)) : 0.0f, s->grad_slots, att_copies_used, att_copies_max * 512, 0,
-                                  fast && L == 3 ? 0 : 1));
+                                  fast && L == 3 ? 0 : 1, s->g_user, (int64_t)s->user_lo * d,
+                                  s->g_user + (size_t)(s->user_lo + s->n_local_users) * d, (int64_t)(n_u - s->user_lo - s->n_local_users) * d));
     s->t += 1;
     return SPEX_OK;
 }

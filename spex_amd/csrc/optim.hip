@@ -202,6 +202,8 @@ struct DualAdamArgs {
     int part;            // 0: the whole arena; the pipelined step splits the pass in two launches on two streams — 1: the item rows and
                          // the gate matrices (gradients of the rec branch alone), 2: the user rows, the trust block, the task weights
     int role;            // number of leading blocks that only sum the gate-gradient copies (0 or 2)
+    float *zero_a, *zero_b;      // two further ranges cleared by this pass (the partitioned step: the trust head's table-gradient rows of
+    int64_t n_zero_a, n_zero_b;  //   the OTHER ranks' users — g_user in front of and behind the rank's own rows); multiples of 4 floats
 };
 
 __global__ __launch_bounds__(256) void dual_task_adam_kernel(const DualAdamArgs a)
@@ -284,6 +286,11 @@ __global__ __launch_bounds__(256) void dual_task_adam_kernel(const DualAdamArgs 
     }
     if (a.part != 2 && a.n_att_copies == 0)
         for (int64_t k = tid; k < a.att_clear; k += stride) a.att_copies[k] = 0.0f;
+    if (a.part != 1) {
+        const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int64_t k = tid; k < a.n_zero_a / 4; k += stride) reinterpret_cast<float4 *>(a.zero_a)[k] = zero4;
+        for (int64_t k = tid; k < a.n_zero_b / 4; k += stride) reinterpret_cast<float4 *>(a.zero_b)[k] = zero4;
+    }
     if (a.part != 1 && (int)blockIdx.x == a.role && threadIdx.x == 0) {
         const float loss1 = a.loss[0] / (float)a.B, loss2 = a.loss[1];
         const float g[2] = {-2.0f * p1 * loss1 + 2.0f * (float)(a.n_rec + 1) * (float)a.B, -2.0f * p2 * loss2 + (float)a.T};
@@ -307,14 +314,17 @@ int spex::dual_task_adam(float *p, float *m, float *v, const float *g_E0, float 
                          int64_t n_trust,
                          int32_t B, int32_t T, int32_t n_rec, int32_t t, float lr, float beta1, float beta2, float eps, int fixed_weights,
                          void *stream, float prop_div, float *att_copies, int32_t n_att_copies, int32_t att_clear, int32_t part,
-                         int32_t clear_prop)
+                         int32_t clear_prop, float *zero_a, int64_t n_zero_a, float *zero_b, int64_t n_zero_b)
 {
     const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
     if (!att_copies) n_att_copies = 0, att_clear = 0;
     const int role = n_att_copies > 0 && part != 2 ? 2 : 0;
     const DualAdamArgs a{p, m, v, g_E0, g_raw, g_raw, g_user, g_small, g_prop, push_zero, loss, loss_acc, prec, n_table, n_user, n_trust,
                          n_table + n_trust + 512 + 2, B, T, n_rec, t & 1, fixed_weights, 1.0f - beta1, beta2, 1.0f - beta2, (float)sqrt(bc2), eps,
-                         (float)((double)lr / bc1), att_copies, n_att_copies, att_clear, prop_div, clear_prop, part, role};
+                         (float)((double)lr / bc1), att_copies, n_att_copies, att_clear, prop_div, clear_prop, part, role,
+                         zero_a, zero_b, zero_a ? n_zero_a : 0, zero_b ? n_zero_b : 0};
+    SPEX_CHECK_ARG(((n_zero_a | n_zero_b) & 3) == 0 && n_zero_a >= 0 && n_zero_b >= 0 && ((((uintptr_t)zero_a) | ((uintptr_t)zero_b)) & 15) == 0,
+                   "dual_task_adam: the extra ranges to clear must be whole float4s of 16-byte aligned buffers");
     SPEX_CHECK_ARG((n_table & 3) == 0 && (n_user & 3) == 0 && ((((uintptr_t)p) | ((uintptr_t)m) | ((uintptr_t)v) | ((uintptr_t)g_E0) | ((uintptr_t)g_raw) | ((uintptr_t)g_user)
                                                                   | ((uintptr_t)g_prop) | ((uintptr_t)push_zero)) & 15) == 0,
                    "dual_task_adam: the table blocks must be whole rows of 16-byte aligned buffers");

@@ -28,7 +28,8 @@ int dual_task_adam(float *p, float *m, float *v, const float *g_E0, float *g_raw
                    float *push_zero, float *loss, float *loss_acc, float *prec, int64_t n_table, int64_t n_user, int64_t n_trust,
                    int32_t B, int32_t T, int32_t n_rec, int32_t t, float lr, float beta1, float beta2, float eps, int fixed_weights,
                    void *stream, float prop_div = 0.0f, float *att_copies = nullptr, int32_t n_att_copies = 0,
-                   int32_t att_clear = 0, int32_t part = 0, int32_t clear_prop = 1);                 // optim.hip: Adam over the dual-task parameter arena (spex_dual_task_step_f32)
+                   int32_t att_clear = 0, int32_t part = 0, int32_t clear_prop = 1, float *zero_a = nullptr, int64_t n_zero_a = 0,
+                   float *zero_b = nullptr, int64_t n_zero_b = 0);           // optim.hip: Adam over the dual-task parameter arena (spex_dual_task_step_f32)
 
 // trust.hip: spex_trust_head_train_f32 with a cap on the fused kernel's workgroups per path (the public entry: 8; beside other work: 1)
 int trust_head_train(const float *table, int64_t n_rows, const float *params, const int64_t *seq, const int64_t *seq_l,
