@@ -28,7 +28,9 @@ for f in ("bench_under_rocprof.json", "bench_steps20.json", "bench.json", "dual_
     p = os.path.join(src, f)
     if os.path.exists(p) and os.path.getsize(p):
         txt = "".join(ln for ln in open(p) if "amdgpu.ids" not in ln and not ln.startswith(("W2026", "E2026", "I2026")))
-        open(os.path.join(dst, f), "w").write(txt)
+        # (profiles/r04/dual_part_time.txt is the event-timed run WITHOUT the profiler, kept with its history: the profiled run's output
+        #  goes beside it)
+        open(os.path.join(dst, "dual_part_time_under_rocprof.txt" if f == "dual_part_time.txt" else f), "w").write(txt)
 if os.path.isdir(os.path.join(src, "pmc_epinion2")):
     out = subprocess.run([sys.executable, os.path.join(here, "pmc_spmm_summary.py"), os.path.join(src, "pmc_epinion2"), "epinion2_r04"],
                          capture_output=True, text=True).stdout
