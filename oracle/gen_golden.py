@@ -625,7 +625,7 @@ def stage_trust():
 
 
 # --------------------------------------------------------------------------- whole training run (G12)
-def stage_epochs(ds="tiny", n_epochs=3, dropout=None, max_steps=None):
+def stage_epochs(ds="tiny", n_epochs=3, dropout=None, max_steps=None, n_layers=None):
     """G12: the reference's own training run — main_rec.py:15-37,50 executed with the reference's modules (set_seed,
     Loader, LightTrainData.ng_sample, DataLoader(256, shuffle=True), model.LightGCN, torch Adam, test()) for three
     epochs on `tiny`: per-epoch loss sums, per-epoch recall / ndcg, the trained tables.  main_rec.py itself runs at
@@ -647,6 +647,8 @@ def stage_epochs(ds="tiny", n_epochs=3, dropout=None, max_steps=None):
     sys.argv = ["main_rec.py", "--dataset", ds]
     if dropout is not None:                # README.md:119-123: "--dropout=1 --keepprob=0.3"
         sys.argv += ["--dropout", "1", "--keepprob", str(dropout)]
+    if n_layers is not None:               # lg_parser.py:10 "--layer" (default 3): a run of another depth -> lightgcn_{ds}_L{n}.npz,
+        sys.argv += ["--layer", str(n_layers)]      # with every step's loss
     import lg_parser
     import utility1.dataloader as ref_dl
     import utility1.model as ref_model
@@ -683,7 +685,7 @@ def stage_epochs(ds="tiny", n_epochs=3, dropout=None, max_steps=None):
             loss = Recmodel(users=user.to(device), items=item.to(device), labels=label.to(device), flag=0)
             loss.backward()
             total_loss += loss.item()
-            if dropout is not None:
+            if dropout is not None or n_layers is not None:
                 step_losses.append(loss.item())
             optimizer.step()
         losses.append(total_loss)
@@ -704,6 +706,10 @@ def stage_epochs(ds="tiny", n_epochs=3, dropout=None, max_steps=None):
         name = f"lightgcn_{ds}_dropout.npz"
         extra.update(mask0, keepprob=args.keepprob, step_losses=np.asarray(step_losses, np.float64),
                      max_steps=-1 if max_steps is None else max_steps, nnz=nnz)
+    if n_layers is not None:
+        assert dropout is None and int(args.layer) == n_layers
+        name = f"lightgcn_{ds}_L{n_layers}.npz"
+        extra.update(n_layers=n_layers, step_losses=np.asarray(step_losses, np.float64), max_steps=-1 if max_steps is None else max_steps)
     np.savez_compressed(os.path.join(GOLD, name), seed=args.seed, lr=args.lr,
                         losses=np.asarray(losses, np.float64), recall=np.asarray(recalls, np.float64),
                         ndcg=np.asarray(ndcgs, np.float64), first_batch=first_batch, user_w=uw, item_w=iw, **extra)
@@ -1477,6 +1483,8 @@ def main():
         stage_epochs("tiny", 3, dropout=0.3)
     elif a.stage == "epochs-dropout-epinion2":   # ~6 min of CPU: the first 300 steps of that run on Epinion2 + test()
         stage_epochs("epinion2", 1, dropout=0.3, max_steps=300)
+    elif a.stage in ("epochs-L2-epinion2", "epochs-L4-epinion2"):   # ~2 min of CPU each: the first 120 steps of main_rec.py --layer 2 / 4 + test()
+        stage_epochs("epinion2", 1, max_steps=120, n_layers=int(a.stage[8]))
 
 
 if __name__ == "__main__":

@@ -106,6 +106,27 @@ def test_g3_loss_and_grad(oracle, golden, epinion2, ds):
     assert np.isclose(np.sqrt((G.astype(np.float64) ** 2).sum()), g["g3_grad_fro"], rtol=1e-5)
 
 
+@pytest.mark.parametrize("L", [2, 4])
+def test_g3_first_step_loss_at_other_depths(oracle, golden, epinion2, L):
+    """The oracle at the reference's other depths (`main_rec.py --layer 2` / `--layer 4`; goldens lightgcn_epinion2_L{2,4}.npz, minted by
+    oracle/gen_golden.py --stage epochs-L{2,4}-epinion2): the first training step's mean BCE loss — the seeded initial tables, the
+    reference's own first batch, L layers of utility1/model.py:83-97 (the later steps need the run's batches: the GPU replay,
+    tests/test_gpu_dropin.py: test_two_and_four_layer_runs_match_the_reference, reproduces all 120)."""
+    import torch
+    _, csr, _, n_u = _epinion2_setup(oracle, golden, epinion2)
+    g = golden(f"lightgcn_epinion2_L{L}")
+    # the run's initial tables: main_rec.py:15,22 — set_seed, then model.py:32-35 (two nn.Embedding, xavier_uniform_ on each)
+    torch.manual_seed(int(g["seed"]))
+    eu, ei = torch.nn.Embedding(n_u, 64), torch.nn.Embedding(len(csr[0]) - 1 - n_u, 64)
+    torch.nn.init.xavier_uniform_(eu.weight, gain=1)
+    torch.nn.init.xavier_uniform_(ei.weight, gain=1)
+    E0 = torch.cat([eu.weight, ei.weight]).detach().numpy()
+    u, i, y = (g["first_batch"][k] for k in range(3))
+    _, loss, G = oracle.lightgcn_loss_and_grad(*csr, E0, n_u, L, u.astype(np.int64), i.astype(np.int64), y.astype(np.float32), n_threads=8)
+    assert abs(float(loss) - float(g["step_losses"][0])) <= 2e-6, (L, float(loss), float(g["step_losses"][0]))
+    assert np.isfinite(G).all() and np.abs(G).max() > 0
+
+
 # ---------------------------------------------------------------- G4 Adam
 def test_g4_adam_tiny(oracle, golden):
     g = golden("lightgcn_tiny")
