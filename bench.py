@@ -581,6 +581,7 @@ def main():
     # launch's latency after the synchronisation and the closing synchronisation (~90 us in all: 4-5 us per step of a 20-step region,
     # nothing of a 2 000-step one) — `extra.timed_region` reports both so the two figures can be told apart
     ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev_a.record(); ev_b.record()          # (torch creates the hipEvent at an event's FIRST record: not inside the timed region)
     barrier()
     t0 = time.perf_counter()
     ev_a.record()
