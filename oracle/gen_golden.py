@@ -895,18 +895,23 @@ def stage_trust_epinion2():
     print("trust epinion2: loss1 %.6f loss2 %.6f test5 %s" % (loss1.item(), loss2.item(), out["trust_test5"]))
 
 
-def stage_epochs_dual_epinion2(n_steps=600, full_epoch=False, fixed_weights=False):
+def stage_epochs_dual_epinion2(n_steps=600, full_epoch=False, fixed_weights=False, n_layers=None):
     """G13 at Epinion2 scale: main_auto_expert_s.py:22-91 executed with the reference's modules on the Epinion2 graph and
     the reference-minted trust paths, for the first `n_steps` batches of epoch 0 (a full epoch is 4 906 batches; the
     dual-task step costs ~1.5 s of reference CPU time), then Test() (:98-114: rec_test over all 3 185 test users +
     trust_test5).  Stored: per-step path counts, both losses per step for the first 16 steps, running loss sums every
-    100 steps, the task weights, both tasks' metrics, sampled rows of the trained user table, `w`."""
+    100 steps, the task weights, both tasks' metrics, sampled rows of the trained user table, `w`.
+    n_layers: the reference's --layer (lg_parser.py:10; default 3) — a run at another depth goes to dual_epinion2_L{n}_epochs.npz
+    (no checkpoint file)."""
     import random
     from collections import defaultdict
     import numpy as np
     import torch
     from torch.utils.data import DataLoader
     _dual_setup()
+    if n_layers is not None:
+        assert not full_epoch and not fixed_weights
+        sys.argv += ["--layer", str(n_layers)]
     import lg_parser
     import utility1.dataloader as ref_dl
     import utility1.utils as ref_utils
@@ -915,6 +920,7 @@ def stage_epochs_dual_epinion2(n_steps=600, full_epoch=False, fixed_weights=Fals
     from utility2.utils import Data
     from utility2.batch_test_gnn import trust_test5
     args = lg_parser.parse_args_r()
+    assert n_layers is None or int(args.layer) == n_layers
     raw_train, raw_test = _epinion2_trust_raw()
     ref_utils.set_seed(args.seed)                                                   # main_auto_expert_s.py:22
     device = torch.device("cpu")
@@ -932,6 +938,8 @@ def stage_epochs_dual_epinion2(n_steps=600, full_epoch=False, fixed_weights=Fals
     # loss = loss1 + loss2 — task_weights get no gradient and stay where they are
     cap_paths = trust_batch_size if fixed_weights else trust_batch_size * 3
     out_name = "dual11_epinion2_epochs.npz" if fixed_weights else "dual_epinion2_epochs.npz"
+    if n_layers is not None:
+        out_name = f"dual_epinion2_L{n_layers}_epochs.npz"
     Recmodel = ref_ex.LightGCN(args, dataset).to(device)                            # :51-52
     optimizer = torch.optim.Adam(Recmodel.parameters(), lr=args.lr)
     out = dict(n_paths=[], loss1_first=[], loss2_first=[], loss1_cum=[], loss2_cum=[])
@@ -1025,7 +1033,7 @@ def stage_epochs_dual_epinion2(n_steps=600, full_epoch=False, fixed_weights=Fals
         if step == n_steps:
             take_checkpoint("ckpt%d" % step, np.stack([user.numpy(), item.numpy(), label.numpy()]), path_index,
                             loss1.item(), loss2.item())
-            if not fixed_weights:
+            if not fixed_weights and n_layers is None:
                 np.savez_compressed(os.path.join(GOLD, "dual_epinion2_ckpt.npz"), seed=args.seed, ckpt_step=n_steps,
                                     metrics_rec=np.concatenate([ret600["recall"], ret600["ndcg"]]), metrics_trust=trust600, **ckpt)
             if not full_epoch:
@@ -1471,6 +1479,8 @@ def main():
         stage_trust_epinion2()
     elif a.stage == "epochs-dual-epinion2":  # ~20 min of CPU: 600 dual-task steps + both evaluations through the reference
         stage_epochs_dual_epinion2()
+    elif a.stage == "epochs-dual-L2-epinion2":     # ~8 min of CPU: 100 steps of main_auto_expert_s.py --layer 2 + both evaluations
+        stage_epochs_dual_epinion2(n_steps=100, n_layers=2)
     elif a.stage == "epochs-dual11-epinion2":      # ~2 min of CPU: 300 steps of the fixed-weights driver (main_11.py) + both evaluations
         stage_epochs_dual_epinion2(n_steps=300, fixed_weights=True)
     elif a.stage == "epochs-dual-epinion2-full":  # ~2.5 h of CPU: the same run continued to the end of epoch 0 (4 906 steps)

@@ -819,12 +819,12 @@ def _epinion2_trust_raw(golden):
     return tr, te
 
 
-def _dual_epinion2(data_root):
+def _dual_epinion2(data_root, extra=()):
     import lg_parser
     import utility1.dataloader as dataloader
     import utility1.model_expert_s as mex
     import utility1.utils as utils
-    args = lg_parser.parse_args_r(["--dataset", "epinion2", "--data_path", data_root])
+    args = lg_parser.parse_args_r(["--dataset", "epinion2", "--data_path", data_root, *extra])
     utils.set_seed(args.seed)
     dataset = dataloader.Loader(args)
     return args, dataset, mex.LightGCN(args, dataset)
@@ -1002,19 +1002,25 @@ def test_dual_task_one_call_step_matches_the_autograd_step(data_root, golden):
     assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 1e-4
 
 
-def test_dual_task_on_device_epoch_matches_the_reference_epinion2(data_root, golden):
+@pytest.mark.parametrize("name,extra,deterministic", [("dual_epinion2_epochs", (), True), ("dual_epinion2_L2_epochs", ("--layer", "2"), True),
+                                                    ("dual_epinion2_L2_epochs", ("--layer", "2"), False)])
+def test_dual_task_on_device_epoch_matches_the_reference_epinion2(data_root, golden, name, extra, deterministic):
     """G13 at Epinion2 scale through the on-device epoch loop (trainer.train_epoch_dual + DualTaskStepper): the same 600
     steps as the reference's run (same negatives, same shuffle, same random.sample path cuts) — running loss sums, the
-    learned task weights, both tasks' metrics and the trained tables."""
+    learned task weights, both tasks' metrics and the trained tables.
+    dual_epinion2_L2_epochs: the first 100 steps of `main_auto_expert_s.py --layer 2` (oracle/gen_golden.py --stage
+    epochs-dual-L2-epinion2) — every other dual-task golden is the default depth 3, whose one-call step runs the all-plain backward;
+    at L = 2 the single backward product is plain and the Adam pass adds the mean's share (utility1/model_expert_s.py:95-126 and
+    its autograd) — in the deterministic mode and on the fast path (float atomics: same gates)."""
     from collections import defaultdict
     import utility1.dataloader as dl
     from utility1.batch_test import rec_test
     from utility2.batch_test_gnn import trust_test5
     from utility2.utils import Data
     from spex_amd.trainer import DualTaskStepper, train_epoch_dual
-    g = golden("dual_epinion2_epochs")
+    g = golden(name)
     raw_train, raw_test = _epinion2_trust_raw(golden)
-    args, dataset, net = _dual_epinion2(data_root)
+    args, dataset, net = _dual_epinion2(data_root, extra)
     td = dl.LightTrainData(dataset.rec_train_data, dataset.m_item, dataset.train_mat)
     by_user = defaultdict(list)
     for k, p in enumerate(raw_train[0]):
@@ -1022,7 +1028,7 @@ def test_dual_task_on_device_epoch_matches_the_reference_epinion2(data_root, gol
     train2, test2 = Data(raw_train, dataset.n_users, shuffle=False), Data(raw_test, dataset.n_users, shuffle=False, test=True)
     cap = 3 * int(g["trust_batch_size"])
     net = net.to(DEV)
-    st = DualTaskStepper(net, path_capacity=cap, path_len=train2.len_max, lr=args.lr, deterministic=True)
+    st = DualTaskStepper(net, path_capacity=cap, path_len=train2.len_max, lr=args.lr, deterministic=deterministic)
     n_steps = int(g["n_steps"])
     totals = train_epoch_dual(st, td, train2, by_user, cap, max_steps=n_steps).cpu().numpy()
     assert st.t == n_steps
@@ -1040,12 +1046,12 @@ def test_dual_task_on_device_epoch_matches_the_reference_epinion2(data_root, gol
     # rec task 2.8e-7 (no user changes rank), of the trust task 1e-15.  (Two mints of the reference's own run agree to 1e-8
     # here: LightGCN has no scale-invariant direction for Adam to amplify noise along.)  Round 2's gates of 1e-3 / 2e-3 on the
     # metrics absorbed the float atomics' reordering and nothing else; they are back at the north-star gate.
-    print("deterministic dual-task run, 600 steps, deviation from the reference's run:", dev)
+    print("dual-task run (%s, deterministic=%s), %d steps, deviation from the reference's run:" % (name, deterministic, n_steps), dev)
     assert dev["loss1"] <= 2e-5 and dev["loss2"] <= 2e-5 and dev["task_w"] <= 5e-6, dev
     assert dev["rec"] <= 1e-4 and dev["trust"] <= 1e-4, dev
     uw, iw = net.embedding_user.weight.detach().cpu().numpy(), net.embedding_item.weight.detach().cpu().numpy()
     tab = dict(user=rel_err(uw[g["rows_u"]], g["user_w"]), item=rel_err(iw[g["rows_i"]], g["item_w"]), w=rel_err(net.w.detach().cpu().numpy(), g["w"]))
-    print("trained tables vs the reference's after 600 steps:", tab)
+    print("trained tables vs the reference's after %d steps:" % n_steps, tab)
     assert max(tab.values()) <= 1e-4, tab
 
 

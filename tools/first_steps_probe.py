@@ -18,6 +18,8 @@ for trial in range(3):
     torch.cuda.synchronize()
     time.sleep(0.002 * trial)
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
+    for e in evs: e.record()              # (torch creates the hipEvent at the FIRST record: keep that out of the timed loop)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     evs[0].record()
     hs = []
