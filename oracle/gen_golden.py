@@ -1479,8 +1479,8 @@ def main():
         stage_trust_epinion2()
     elif a.stage == "epochs-dual-epinion2":  # ~20 min of CPU: 600 dual-task steps + both evaluations through the reference
         stage_epochs_dual_epinion2()
-    elif a.stage == "epochs-dual-L2-epinion2":     # ~8 min of CPU: 100 steps of main_auto_expert_s.py --layer 2 + both evaluations
-        stage_epochs_dual_epinion2(n_steps=100, n_layers=2)
+    elif a.stage in ("epochs-dual-L2-epinion2", "epochs-dual-L4-epinion2"):   # ~3 min of CPU each: 100 steps of main_auto_expert_s.py
+        stage_epochs_dual_epinion2(n_steps=100, n_layers=int(a.stage[13]))       # --layer 2 / 4 + both evaluations
     elif a.stage == "epochs-dual11-epinion2":      # ~2 min of CPU: 300 steps of the fixed-weights driver (main_11.py) + both evaluations
         stage_epochs_dual_epinion2(n_steps=300, fixed_weights=True)
     elif a.stage == "epochs-dual-epinion2-full":  # ~2.5 h of CPU: the same run continued to the end of epoch 0 (4 906 steps)

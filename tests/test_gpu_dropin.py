@@ -1003,15 +1003,17 @@ def test_dual_task_one_call_step_matches_the_autograd_step(data_root, golden):
 
 
 @pytest.mark.parametrize("name,extra,deterministic", [("dual_epinion2_epochs", (), True), ("dual_epinion2_L2_epochs", ("--layer", "2"), True),
-                                                    ("dual_epinion2_L2_epochs", ("--layer", "2"), False)])
+                                                    ("dual_epinion2_L2_epochs", ("--layer", "2"), False),
+                                                    ("dual_epinion2_L4_epochs", ("--layer", "4"), True), ("dual_epinion2_L4_epochs", ("--layer", "4"), False)])
 def test_dual_task_on_device_epoch_matches_the_reference_epinion2(data_root, golden, name, extra, deterministic):
     """G13 at Epinion2 scale through the on-device epoch loop (trainer.train_epoch_dual + DualTaskStepper): the same 600
     steps as the reference's run (same negatives, same shuffle, same random.sample path cuts) — running loss sums, the
     learned task weights, both tasks' metrics and the trained tables.
-    dual_epinion2_L2_epochs: the first 100 steps of `main_auto_expert_s.py --layer 2` (oracle/gen_golden.py --stage
-    epochs-dual-L2-epinion2) — every other dual-task golden is the default depth 3, whose one-call step runs the all-plain backward;
-    at L = 2 the single backward product is plain and the Adam pass adds the mean's share (utility1/model_expert_s.py:95-126 and
-    its autograd) — in the deterministic mode and on the fast path (float atomics: same gates)."""
+    dual_epinion2_L{2,4}_epochs: the first 100 steps of `main_auto_expert_s.py --layer 2` / `--layer 4` (oracle/gen_golden.py --stage
+    epochs-dual-L{2,4}-epinion2) — every other dual-task golden is the default depth 3, whose one-call step runs the all-plain backward;
+    at L = 2 the single backward product is plain and the Adam pass adds the mean's share, at L = 4 the forward keeps its running sum
+    and the middle backward products take the add form (utility1/model_expert_s.py:95-126 and its autograd) — in the deterministic
+    mode and on the fast path (float atomics: same gates)."""
     from collections import defaultdict
     import utility1.dataloader as dl
     from utility1.batch_test import rec_test
