@@ -123,7 +123,7 @@ def test_native_exchange_and_one_call_step_with_real_data_between_ranks(tmp_path
 
 
 # ---------------------------------------------------------------------------------------------- BASELINE config 5: the one-call dual-task step
-def _dual_native_worker(rank, world, port, out_dir, data_root, n_steps, stub, det):
+def _dual_native_worker(rank, world, port, out_dir, data_root, n_steps, stub, det, L=3):
     import random
     from collections import defaultdict
     dev = _setup(rank, world, port, stub)
@@ -137,7 +137,7 @@ def _dual_native_worker(rank, world, port, out_dir, data_root, n_steps, stub, de
     t = np.load(os.path.join(GOLDEN, "trust_epinion2_paths.npz"))
     raw_train = ([r[:l].tolist() for r, l in zip(t["train_paths"].astype(np.int64), t["train_len"])],
                  t["train_targets"].astype(np.int64).tolist())
-    args = lg_parser.parse_args_r(["--dataset", "epinion2", "--data_path", data_root])
+    args = lg_parser.parse_args_r(["--dataset", "epinion2", "--data_path", data_root, "--layer", str(L)])
     utils.set_seed(args.seed)                                             # every rank: the same seeds => the same batches
     dataset = dl.Loader(args)
     loader = DataLoader(dl.LightTrainData(dataset.rec_train_data, dataset.m_item, dataset.train_mat), batch_size=256, shuffle=True)
@@ -170,7 +170,7 @@ def _dual_native_worker(rank, world, port, out_dir, data_root, n_steps, stub, de
         cur = st.loss_acc.cpu().numpy().astype(np.float64)
         l1s.append(cur[0] - prev[0]); l2s.append(cur[1] - prev[1]); n_paths.append(len(chosen))
         prev = cur
-    np.savez(os.path.join(out_dir, f"dual{world}_{int(det)}_{rank}.npz"), loss1=np.asarray(l1s), loss2=np.asarray(l2s), n_paths=np.asarray(n_paths),
+    np.savez(os.path.join(out_dir, f"dual{world}_{int(det)}_{L}_{rank}.npz"), loss1=np.asarray(l1s), loss2=np.asarray(l2s), n_paths=np.asarray(n_paths),
              r0=model.P.r0, r1=model.P.r1, table=model.E0_local.detach().cpu().numpy(),
              task_weights=model.task_weights.detach().cpu().numpy(), att_exp1=core.att_exp1.detach().cpu().numpy(),
              w=core.w.detach().cpu().numpy())
@@ -183,20 +183,22 @@ def rank_world_p2p(world):
     return world != 3                                       # world 3 takes the equal-shard form, the others the send / recv form
 
 
-@pytest.mark.parametrize("world,det", [(1, False), (2, False), (2, True), (3, False)])
-def test_one_call_partitioned_dual_task_step_reproduces_the_reference_losses(tmp_path, golden, world, det):
+@pytest.mark.parametrize("world,det,L", [(1, False, 3), (2, False, 3), (2, True, 3), (3, False, 3), (2, False, 2), (2, False, 4)])
+def test_one_call_partitioned_dual_task_step_reproduces_the_reference_losses(tmp_path, golden, world, det, L):
     """BASELINE config 5 row-partitioned, every step ONE native call (spex_partitioned_dual_task_step_f32): the first 16 training
     steps of main_auto_expert_s.py on Epinion2 + the reference-minted trust paths reproduce the REFERENCE's per-step losses of both
     tasks (golden G13) at world 1 (real RCCL communicator, local-copy shortcut), 2 and 3 (shm stand-in: real data between the
     ranks); every rank ends with identical replicated parameters (the gate gradients need no collective: the batch's rows are
-    gated redundantly), and the ranks' table rows tile the whole table."""
+    gated redundantly), and the ranks' table rows tile the whole table.  L = 2 / 4: `main_auto_expert_s.py --layer 2` / `--layer 4`
+    (goldens dual_epinion2_L{2,4}_epochs) — the fast path's other two schedules (the mean's share of the one pull product added by the
+    Adam pass; the running-sum forward and add-form products)."""
     from spex_amd.datasets import materialise_epinion2
-    g = golden("dual_epinion2_epochs")
+    g = golden("dual_epinion2_epochs" if L == 3 else f"dual_epinion2_L{L}_epochs")
     root = materialise_epinion2(str(tmp_path / "data"))
     stub = _build_shm_stub(tmp_path) if world > 1 else ""
     n_steps = len(g["loss1_first"])
-    mp.spawn(_dual_native_worker, args=(world, _free_port(), str(tmp_path), root, n_steps, stub, det), nprocs=world, join=True)
-    d = [np.load(tmp_path / f"dual{world}_{int(det)}_{r}.npz") for r in range(world)]
+    mp.spawn(_dual_native_worker, args=(world, _free_port(), str(tmp_path), root, n_steps, stub, det, L), nprocs=world, join=True)
+    d = [np.load(tmp_path / f"dual{world}_{int(det)}_{L}_{r}.npz") for r in range(world)]
     for r in range(world):
         assert np.array_equal(d[r]["n_paths"], g["n_paths"][:n_steps].astype(int))
         assert np.abs(d[r]["loss1"] - g["loss1_first"]).max() <= 2e-5, (r, d[r]["loss1"], g["loss1_first"])
