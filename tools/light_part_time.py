@@ -41,7 +41,7 @@ def timed(fn, n=500, reps=3):
 
 
 st = LightGCNStepper(SpexGraph(*csr, device=dev), E0.clone(), n_u + 1, n_layers=L, lr=1e-3)
-print("LightGCNStepper                                 : %.1f us (host enqueue %.1f)" % timed(lambda: st.step_bce(ub, ib, yb, loss_acc=acc)), flush=True)
+print("LightGCNStepper (one-call step)                 : %.1f us (host enqueue %.1f)" % timed(lambda: st.step_bce(ub, ib, yb, loss_acc=acc, batch_rows_only=True)), flush=True)
 for det, fast, tag in ((False, True, "fast path       "), (False, False, "launch by launch"), (True, True, "deterministic   ")):
     P = PartitionedLightGCN(*csr, n_u + 1, L, 64, 0, 1, lambda r, c, v, n_cols: SpexGraph(r, c, v, n_cols=n_cols, device=dev), dev, allgather="native-p2p")
     pst = PartitionedStepper(P, E0.clone(), lr=1e-3, fast=fast)
