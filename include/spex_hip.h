@@ -873,7 +873,10 @@ int spex_comm_allreduce_sum_f32(spex_comm_t *comm, float *buf, int64_t n, void *
  * Buffers (caller-owned): E0, m, v, light_out, g_local, gs, grad_E0: [n_local, 64] (g_local all-zero before the first call;
  * every call leaves it so); gathered, gathered1: [world * max_rows, 64] each (two tables); rows, grad_rows: [slot_capacity, 64] with
  * slot_capacity >= 2B; arange: device int64 [slot_capacity] = 0, 1, 2, ...
- * graph / graph_t: this rank's row blocks (n_local rows, world * max_rows columns).  d == 64, L >= 1, no edge dropout. */
+ * graph / graph_t: this rank's row blocks (n_local rows, world * max_rows columns).  d == 64, L >= 1.
+ * Edge dropout (utility1/model.py:46-64; since round 4): set the SAME mask on graph and graph_t (spex_graph_set_edge_mask), both created
+ * with the entries' GLOBAL edge ids (spex_graph_create's edge_id: the entry's index in A; for the block of A^T the permutation), graph_t a
+ * handle of its own — every rank then drops the same edges of A and of A^T.  A masked step takes the launch-by-launch schedule. */
 typedef struct spex_partitioned_step {
     const spex_graph_t *graph, *graph_t;
     spex_comm_t *comm;
@@ -910,7 +913,8 @@ int spex_partitioned_step_bce_f32(spex_partitioned_step_t *step, const int64_t *
  *                rows user_lo ..), replicated — identical gradients, identical updates — on the dense parameters; the task
  *                precisions and the task weights' own gradients as in spex_dual_task_step_f32.
  * 2 L exchanges + 1 all-reduce per step, every exchange in place (see spex_partitioned_step_t).  flags: SPEX_STEP_DETERMINISTIC (owned
- * rows added in slot order, no float atomics), SPEX_STEP_FIXED_TASK_WEIGHTS.  d == 64, L >= 1, no edge dropout.
+ * rows added in slot order, no float atomics), SPEX_STEP_FIXED_TASK_WEIGHTS.  d == 64, L >= 1.  Edge dropout on the rec branch
+ * (model_expert_s.py:104-109): as for spex_partitioned_step_t — the same mask on both handles, the launch-by-launch schedule.
  * FAST PATH (graph_push and gathered2 given, L >= 2, not deterministic) — spex_dual_task_step_f32's schedule on the partition:
  *   forward layers 1 .. L-1 over the block (plain form for L <= 3), the LAST layer at the batch's rows only, on their owners
  *   (spex_spmm_owned_rows_f32: layer mean + raw rows, zeros elsewhere) -> the one all-reduce of 4B rows -> gate, scores, BCE, the

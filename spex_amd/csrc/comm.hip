@@ -240,7 +240,14 @@ static int check_step(const spex_partitioned_step_t *s, const char *who)
     SPEX_CHECK_ARG(s->graph->n_rows == s->n_local && s->graph_t->n_rows == s->n_local
                        && s->graph->n_cols == s->comm->world * s->max_rows && s->graph_t->n_cols == s->graph->n_cols,
                    "%s: the row blocks must be n_local x (world * max_rows) in the padded layout", who);
-    SPEX_CHECK_ARG(s->graph->mask_mode == 0 && s->graph_t->mask_mode == 0, "%s: edge dropout is not supported in the partitioned step", who);
+    // edge dropout (utility1/model.py:46-64): the same mask on both handles — the blocks carry the entries' GLOBAL edge ids, so every
+    // rank drops the same edges of A and of A^T —, graph_t a handle of its own (a masked operator is not symmetric); the steps then take
+    // the launch-by-launch schedule, whose products are all whole-block launches
+    SPEX_CHECK_ARG(s->graph->mask_mode == s->graph_t->mask_mode
+                       && (s->graph->mask_mode == 0
+                           || (s->graph_t != s->graph && s->graph->keep_prob == s->graph_t->keep_prob && s->graph->seed == s->graph_t->seed
+                               && s->graph->keep == s->graph_t->keep)),
+                   "%s: edge dropout needs the same mask on graph and graph_t, graph_t a separate handle carrying the edge-id permutation", who);
     return SPEX_OK;
 }
 
@@ -295,7 +302,7 @@ extern "C" int spex_partitioned_step_bce_f32(spex_partitioned_step_t *s, const i
     const int64_t sz = n_loc * d;
     // ---- the fast path: spex_lightgcn_step_bce_f32's schedule on the partition (see spex_partitioned_dual_task_step_f32 below, whose rec
     //      branch is this with the gate in the middle).  The same choice on every rank: the two schedules differ in their collectives.
-    const bool fast = !det && L >= 2 && s->gathered2 != nullptr && (s->graph_push != nullptr || n_loc == 0);
+    const bool fast = !det && L >= 2 && s->gathered2 != nullptr && (s->graph_push != nullptr || n_loc == 0) && s->graph->mask_mode == 0;
     if (fast) {
         if (n_loc)
             SPEX_CHECK_ARG(s->graph_push->n_rows == s->comm->world * s->max_rows && s->graph_push->n_cols == n_loc && s->graph_push->mask_mode == 0,
@@ -410,7 +417,11 @@ extern "C" int spex_partitioned_dual_task_step_f32(spex_partitioned_dual_step_t 
     SPEX_CHECK_ARG(s->graph->n_rows == n_loc && s->graph_t->n_rows == n_loc && s->graph->n_cols == world * max_rows
                        && s->graph_t->n_cols == s->graph->n_cols,
                    "%s: the row blocks must be n_local x (world * max_rows) in the padded layout", who);
-    SPEX_CHECK_ARG(s->graph->mask_mode == 0 && s->graph_t->mask_mode == 0, "%s: edge dropout is not supported in the partitioned step", who);
+    SPEX_CHECK_ARG(s->graph->mask_mode == s->graph_t->mask_mode
+                       && (s->graph->mask_mode == 0
+                           || (s->graph_t != s->graph && s->graph->keep_prob == s->graph_t->keep_prob && s->graph->seed == s->graph_t->seed
+                               && s->graph->keep == s->graph_t->keep)),
+                   "%s: edge dropout needs the same mask on graph and graph_t, graph_t a separate handle carrying the edge-id permutation", who);
     SPEX_CHECK_ARG(s->n_local_users >= 0 && s->n_local_users <= n_loc && s->user_lo >= 0 && s->user_lo + s->n_local_users <= n_u,
                    "%s: %d local user rows from user row %d of %d", who, s->n_local_users, s->user_lo, n_u);
     const int64_t n_trust = spex_trust_param_count(d, H);
@@ -419,7 +430,9 @@ extern "C" int spex_partitioned_dual_task_step_f32(spex_partitioned_dual_step_t 
     // the fast path (spex_dual_task_step_f32's schedule on the partition): needs the push structure, its zero-kept table and L >= 2
     //  (a rank without rows has nothing to push and needs no structure — but must walk the same sequence of collectives as its peers:
     //   the choice depends on gathered2 and the flags, which the caller sets alike on every rank)
-    const bool fast = !det && L >= 2 && s->gathered2 != nullptr && (s->graph_push != nullptr || n_loc == 0);
+    //  (under edge dropout — model_expert_s.py:104-109, the rec branch only — the launch-by-launch schedule: all its products are
+    //   whole-block launches, which apply the handles' mask)
+    const bool fast = !det && L >= 2 && s->gathered2 != nullptr && (s->graph_push != nullptr || n_loc == 0) && s->graph->mask_mode == 0;
     if (fast && n_loc)
         SPEX_CHECK_ARG(s->graph_push->n_rows == world * max_rows && s->graph_push->n_cols == n_loc && s->graph_push->mask_mode == 0,
                        "%s: graph_push must be the (world * max_rows) x n_local transpose of the rank's block of A^T", who);

@@ -219,22 +219,39 @@ class PartitionedLightGCN:
     """
 
     def __init__(self, rowptr, col, val, n_user_rows, n_layers, d, rank, world, graph_factory, device, group=None,
-                 t_csr=None, bounds=None, always_collective=False, allgather="collective"):
+                 t_csr=None, bounds=None, always_collective=False, allgather="collective", edge_ids=False):
         self.part = RowPartition(rowptr, world, bounds)
         self.rank, self.world, self.L, self.d, self.group = rank, world, n_layers, d, group
         self.always_collective = always_collective      # issue the collectives even at world size 1 (backend smoke tests)
         self.n_user_rows = n_user_rows
         self.device = torch.device(device)
         p = self.part
-        lr, lc, lv, _ = p.local_block(rowptr, col, val, rank)
-        self.graph = graph_factory(lr, lc, lv, n_cols=p.n_padded)
-        if t_csr is None:       # symmetric adjacency: A^T == A
-            self.graph_t = self.graph
-            self._t_block = (lr, lc, lv)
-        else:
-            tr, tc, tv, _ = p.local_block(*t_csr[:3], rank)
-            self.graph_t = graph_factory(tr, tc, tv, n_cols=p.n_padded)
+        # edge_ids (edge dropout, utility1/model.py:46-64): the blocks carry their entries' GLOBAL edge ids — the entry's index in A;
+        # for the block of A^T the transposition's permutation — so that a mask (injected, indexed by edge id; or sampled, keyed by
+        # it) drops the same edges of A and of A^T on every rank.  A masked operator is not symmetric: graph_t is then a handle of
+        # its own even for a symmetric A.  graph_factory must accept edge_id=.
+        self.edge_ids = bool(edge_ids)
+        if self.edge_ids:
+            from .graph import csr_transpose
+            lr, lc, lv, le = p.local_block(rowptr, col, val, rank, np.arange(len(col), dtype=np.int32))
+            self.graph = graph_factory(lr, lc, lv, n_cols=p.n_padded, edge_id=le)
+            full_t = csr_transpose(rowptr, col, val, len(rowptr) - 1) if t_csr is None else t_csr
+            if len(full_t) < 4 or full_t[3] is None:
+                raise ValueError("PartitionedLightGCN(edge_ids=True): t_csr must carry the edge-id permutation (graph.csr_transpose)")
+            tr, tc, tv, te = p.local_block(*full_t[:3], rank, full_t[3])
+            self.graph_t = graph_factory(tr, tc, tv, n_cols=p.n_padded, edge_id=te)
             self._t_block = (tr, tc, tv)
+            self.nnz_global = int(len(col))
+        else:
+            lr, lc, lv, _ = p.local_block(rowptr, col, val, rank)
+            self.graph = graph_factory(lr, lc, lv, n_cols=p.n_padded)
+            if t_csr is None:       # symmetric adjacency: A^T == A
+                self.graph_t = self.graph
+                self._t_block = (lr, lc, lv)
+            else:
+                tr, tc, tv, _ = p.local_block(*t_csr[:3], rank)
+                self.graph_t = graph_factory(tr, tc, tv, n_cols=p.n_padded)
+                self._t_block = (tr, tc, tv)
         self._graph_factory, self._graph_push, self._tables = graph_factory, None, {}
         self.r0, self.r1 = int(p.bounds[rank]), int(p.bounds[rank + 1])
         self.n_local = self.r1 - self.r0
@@ -253,6 +270,16 @@ class PartitionedLightGCN:
             raise ValueError("allgather must be 'collective', 'peer', 'native' or 'native-p2p'")
         if allgather != "collective":
             self.set_allgather(allgather)
+
+    def set_edge_mask(self, mode=0, keep=None, keep_prob=1.0, seed=0):
+        """The step's edge-dropout mask on both blocks (SpexGraph.set_edge_mask's arguments; trainer.edge_dropout_mask(...) builds
+        them — for an injected mask `keep` is indexed by GLOBAL edge id, length = the whole matrix's stored entries).  Every rank
+        must set the same mask.  mode 0 clears it."""
+        if not self.edge_ids and mode != 0:
+            raise ValueError("PartitionedLightGCN.set_edge_mask: build the model with edge_ids=True")
+        self.graph.set_edge_mask(mode, keep, keep_prob, seed)
+        if self.graph_t is not self.graph:
+            self.graph_t.set_edge_mask(mode, keep, keep_prob, seed)
 
     # -- what the one-call native steps need beside the Python-issued schedule's buffers
     def table(self, k):

@@ -77,7 +77,7 @@ class PartitionedDualTask(nn.Module):
     graph_factory / kernels: injection points of the CPU schedule tests (defaults: SpexGraph, spex_amd.ops).
     """
 
-    def __init__(self, core, csr, rank, world, device, group=None, graph_factory=None, kernels=None):
+    def __init__(self, core, csr, rank, world, device, group=None, graph_factory=None, kernels=None, edge_ids=False):
         super().__init__()
         self.core = core
         self.k = kernels if kernels is not None else _default_ops
@@ -86,8 +86,10 @@ class PartitionedDualTask(nn.Module):
         n_u = core.num_users + 1
         if graph_factory is None:
             from .graph import SpexGraph
-            graph_factory = lambda r, c, v, n_cols: SpexGraph(r, c, v, n_cols=n_cols, device=dev)
-        self.P = PartitionedLightGCN(*csr, n_u, core.n_layers, core.latent_dim, rank, world, graph_factory, dev, group=group)
+            graph_factory = lambda r, c, v, n_cols, edge_id=None: SpexGraph(r, c, v, n_cols=n_cols, edge_id=edge_id, device=dev)
+        # edge_ids: blocks with global edge ids, for edge dropout on the rec branch (model_expert_s.py:104-109; P.set_edge_mask per step)
+        self.P = PartitionedLightGCN(*csr[:3], n_u, core.n_layers, core.latent_dim, rank, world, graph_factory, dev, group=group,
+                                     edge_ids=edge_ids)
         P = self.P
         full = torch.cat([core.embedding_user.weight.detach(), core.embedding_item.weight.detach()])
         self.E0_local = nn.Parameter(full[P.r0:P.r1].clone().to(dev))

@@ -89,6 +89,19 @@ def _light_worker(rank, world, port, out_dir, stub):
         out["%s_prop_equal" % key[0]] = bool(torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]))
         out["%s_step" % key[0]] = float((got[2] - ref[2]).abs().max() / ref[2].abs().max())
         out["%s_loss" % key[0]] = abs(got[3].item() - ref[3].item()) / abs(ref[3].item())
+    # ---- the reference's recommended configuration on the partition (`--dropout 1 --keepprob 0.3`, README.md:119-123): blocks with
+    #      GLOBAL edge ids, the sampled mask keyed by them — every rank drops the same edges of A and of A^T as one device does
+    from spex_amd.trainer import edge_dropout_mask
+    efactory = lambda r, c, v, n_cols, edge_id=None: SpexGraph(r, c, v, n_cols=n_cols, edge_id=edge_id, device=dev)
+    P = PartitionedLightGCN(*csr, 3186, 3, 64, rank, world, efactory, dev, bounds=bounds, allgather="native-p2p", edge_ids=True)
+    st = PartitionedStepper(P, torch.from_numpy(E0[P.r0:P.r1].copy()).to(dev), lr=1e-3)
+    acc = torch.zeros(1, device=dev)
+    for k, (bu, bi, by) in enumerate(batches):
+        P.set_edge_mask(*edge_dropout_mask(P.graph, 0.3, "philox", 5, k + 1))
+        st.step_bce(bu, bi, by, loss_acc=acc)
+    torch.cuda.synchronize()
+    out["dropout_trained"], out["dropout_loss"] = st.E0.cpu().numpy(), acc.item()
+    P.native.close()
     d1, d2 = res[("native-p2p", True)]
     out["det_repeats"] = bool(torch.equal(d1[2], d2[2]) and torch.equal(d1[3], d2[3]))
     out["det_step"] = float((d1[2] - ref[2]).abs().max() / ref[2].abs().max())
@@ -102,7 +115,9 @@ def _light_worker(rank, world, port, out_dir, stub):
 def test_native_exchange_and_one_call_step_with_real_data_between_ranks(tmp_path, world):
     """world 2 and 3 (uneven shards) on Epinion2: both native exchange forms give the very tables torch.distributed's all-gather
     gives (forward and backward propagation bit-identical), three one-call native training steps equal the Python-issued steps
-    (<= 2e-6), the deterministic mode repeats bit for bit; and the ranks' rows together are the single-device result."""
+    (<= 2e-6), the deterministic mode repeats bit for bit; and the ranks' rows together are the single-device result.  And under edge
+    dropout (`--dropout 1 --keepprob 0.3`, utility1/model.py:46-64): three one-call steps with a fresh sampled mask per step on blocks
+    that carry GLOBAL edge ids equal the same steps under the same masks on one device (5e-6)."""
     from spex_amd.datasets import epinion2_tables, load_epinion2
     from spex_amd.graph import SpexGraph, lightgcn_norm_adj
     stub = _build_shm_stub(tmp_path)
@@ -111,15 +126,36 @@ def test_native_exchange_and_one_call_step_with_real_data_between_ranks(tmp_path
     csr = lightgcn_norm_adj(tr[:, 0], tr[:, 1], 3185, 12407)
     uw, iw = epinion2_tables(3186, 12407)
     ref = SpexGraph(*csr).propagate(torch.from_numpy(np.concatenate([uw, iw])).cuda(), 3).cpu().numpy()
+    # the same three steps under the same sampled masks on ONE device (the launch-by-launch stepper: masked whole-graph products)
+    from spex_amd.graph import csr_transpose
+    from spex_amd.trainer import LightGCNStepper, edge_dropout_mask
+    g1 = SpexGraph(*csr)
+    t_rp, t_c, t_v, t_e = csr_transpose(*csr, len(csr[0]) - 1)
+    single = LightGCNStepper(g1, torch.from_numpy(np.concatenate([uw, iw])).cuda(), 3186, n_layers=3, lr=1e-3,
+                             graph_t=SpexGraph(t_rp, t_c, t_v, n_cols=len(csr[0]) - 1, edge_id=t_e))
+    rng = np.random.default_rng(3)
+    acc1 = torch.zeros(1, device="cuda")
+    for k in range(3):
+        bu, bi = torch.from_numpy(rng.integers(0, 3185, 256)).cuda(), torch.from_numpy(rng.integers(0, 12407, 256)).cuda()
+        by = torch.from_numpy((rng.random(256) < 1 / 6).astype(np.float32)).cuda()
+        mask = edge_dropout_mask(g1, 0.3, "philox", 5, k + 1)
+        single.graph.set_edge_mask(*mask); single.graph_t.set_edge_mask(*mask)
+        single.step_bce(bu, bi, by, loss_acc=acc1)
+    want_drop = single.E0.cpu().numpy()
+    got_drop = np.zeros_like(want_drop)
     lo = np.zeros_like(ref)
     for r in range(world):
         d = np.load(tmp_path / f"light{world}_{r}.npz")
+        got_drop[int(d["r0"]):int(d["r1"])] = d["dropout_trained"]
+        assert abs(float(d["dropout_loss"]) - acc1.item()) <= 2e-6 * abs(acc1.item()), (r, float(d["dropout_loss"]), acc1.item())
         assert bool(d["native_prop_equal"]) and bool(d["native-p2p_prop_equal"]), r
         assert float(d["native_step"]) <= 2e-6 and float(d["native-p2p_step"]) <= 2e-6, dict(d)
         assert float(d["native_loss"]) <= 3e-6 and float(d["native-p2p_loss"]) <= 3e-6   # (fp32 sums of per-sample losses in arrival order)
         assert bool(d["det_repeats"]) and float(d["det_step"]) <= 5e-6
         lo[int(d["r0"]):int(d["r1"])] = d["lo"]
     assert np.array_equal(lo, ref)
+    assert np.abs(got_drop - want_drop).max() <= 5e-6 * np.abs(want_drop).max()
+    assert np.abs(want_drop - np.concatenate([uw, iw])).max() > 1e-4                                   # (the masked steps did move the table)
 
 
 # ---------------------------------------------------------------------------------------------- BASELINE config 5: the one-call dual-task step
@@ -353,3 +389,97 @@ def test_partitioned_fast_path_on_a_non_symmetric_matrix_against_the_oracle(L, o
         assert err <= 2e-5, (L, fast, err)
         assert abs(acc.item() / B - float(loss)) <= 2e-6 * max(1.0, abs(float(loss))), (acc.item() / B, loss)
         P.native.close()
+
+
+def test_partitioned_steps_under_edge_dropout_equal_the_one_gpu_steps():
+    """Edge dropout on the row partition (the reference's recommended `--dropout 1 --keepprob 0.3`, README.md:119-123;
+    utility1/model.py:46-64, model_expert_s.py:104-109), world size 1: blocks built with GLOBAL edge ids (edge_ids=True) take the
+    step's mask on both handles and the one-call steps run their launch-by-launch schedule, whose products are whole-block masked
+    launches.  (a) spex_partitioned_step_bce_f32 with an INJECTED keep mask (the reference-stream form: an array indexed by edge id)
+    and with the sampled one against LightGCNStepper under the same masks; (b) spex_partitioned_dual_task_step_f32 with sampled masks
+    against DualTaskStepper under the same masks (the rec branch drops edges, the trust branch reads the raw table): losses and every
+    parameter after three steps."""
+    import argparse
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "spex_amd", "dropin"))
+    import utility1.model_expert_s as mex
+    from spex_amd.datasets import epinion2_tables, load_epinion2
+    from spex_amd.dist import PartitionedLightGCN, PartitionedStepper
+    from spex_amd.dist_dual import PartitionedDualTask, PartitionedDualTaskStepper
+    from spex_amd.graph import SpexGraph, csr_transpose, lightgcn_norm_adj
+    from spex_amd.trainer import DualTaskStepper, LightGCNStepper, edge_dropout_mask
+    dev = torch.device("cuda:0")
+    tr = load_epinion2()["train"]
+    n_u, n_i, L = 3185, 12407, 3
+    csr = lightgcn_norm_adj(tr[:, 0], tr[:, 1], n_u, n_i)
+    n, nnz = len(csr[0]) - 1, len(csr[1])
+    uw, iw = epinion2_tables(n_u + 1, n_i)
+    E0 = torch.from_numpy(np.concatenate([uw, iw])).to(dev)
+    rng = np.random.default_rng(29)
+    B = 256
+    batches = [(torch.from_numpy(rng.integers(0, n_u, B)).to(dev), torch.from_numpy(rng.integers(0, n_i, B)).to(dev),
+                torch.from_numpy((rng.random(B) < 1 / 6).astype(np.float32)).to(dev)) for _ in range(3)]
+    keep = torch.from_numpy((rng.random(nnz) < 0.3).astype(np.uint8)).to(dev)
+    masks = [(1, keep, 0.3, 0), edge_dropout_mask(None, 0.3, "philox", 9, 2), edge_dropout_mask(None, 0.3, "philox", 9, 3)]
+    efactory = lambda r, c, v, n_cols, edge_id=None: SpexGraph(r, c, v, n_cols=n_cols, edge_id=edge_id, device=dev)
+    t_rp, t_c, t_v, t_e = csr_transpose(*csr, n)
+    # ---- (a) LightGCN
+    P = PartitionedLightGCN(*csr, n_u + 1, L, 64, 0, 1, efactory, dev, allgather="native-p2p", edge_ids=True)
+    assert P.graph_t is not P.graph
+    part = PartitionedStepper(P, E0.clone(), lr=1e-3)
+    single = LightGCNStepper(SpexGraph(*csr, device=dev), E0.clone(), n_u + 1, n_layers=L, lr=1e-3,
+                             graph_t=SpexGraph(t_rp, t_c, t_v, n_cols=n, edge_id=t_e, device=dev))
+    acc_p, acc_s = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+    for (u, i, y), mask in zip(batches, masks):
+        P.set_edge_mask(*mask)
+        single.graph.set_edge_mask(*mask); single.graph_t.set_edge_mask(*mask)
+        part.step_bce(u, i, y, loss_acc=acc_p)
+        single.step_bce(u, i, y, loss_acc=acc_s)
+    torch.cuda.synchronize()
+    assert abs(acc_p.item() - acc_s.item()) <= 2e-6 * abs(acc_s.item())
+    err = (part.E0 - single.E0).abs().max().item() / single.E0.abs().max().item()
+    assert err <= 5e-6, err
+    unmasked = PartitionedStepper(PartitionedLightGCN(*csr, n_u + 1, L, 64, 0, 1, efactory, dev, allgather="native-p2p"), E0.clone(), lr=1e-3)
+    for u, i, y in batches:
+        unmasked.step_bce(u, i, y, loss_acc=torch.zeros(1, device=dev))
+    assert (unmasked.E0 - part.E0).abs().max().item() > 1e-4                              # (the masks mattered)
+    P.set_edge_mask(0)
+    P.native.close(); unmasked.P.native.close()
+    # ---- (b) the dual-task step
+    g1 = SpexGraph(*csr, device=dev)
+
+    class _DS:
+        n_users, m_items = n_u, n_i
+        getSparseGraph = staticmethod(lambda: g1)
+    dargs = argparse.Namespace(hiddenSize=64, batchSize=100, nonhybrid=False, nb_heads=3, recdim=64, layer=L, keepprob=0.3, A_split=False, dropout=1)
+    T, P_LEN = 9, 6
+    plen = rng.integers(2, P_LEN + 1, T)
+    seq = np.full((T, P_LEN), n_u, dtype=np.int64)
+    for r, l in enumerate(plen):
+        seq[r, :l] = rng.choice(n_u, size=l, replace=False)
+    seq_d, len_d = torch.from_numpy(seq).to(dev), torch.from_numpy(plen.astype(np.int64)).to(dev)
+    tgt = torch.from_numpy(rng.integers(0, n_u, T)).to(dev)
+    torch.manual_seed(0)
+    net = mex.LightGCN(dargs, _DS).to(dev)
+    dsingle = DualTaskStepper(net, path_capacity=T, path_len=P_LEN, lr=1e-3)
+    torch.manual_seed(0)
+    core = mex.LightGCN(dargs, _DS).to(dev)
+    model = PartitionedDualTask(core, csr, 0, 1, dev, edge_ids=True)
+    dpart = PartitionedDualTaskStepper(model, path_capacity=T, path_len=P_LEN, lr=1e-3)
+    for k, (u, i, y) in enumerate(batches):
+        mask = edge_dropout_mask(None, 0.3, "philox", 21, k + 1)
+        dsingle.set_edge_dropout(mask)
+        model.P.set_edge_mask(*mask)
+        dsingle.step(u, i, y, seq_d, len_d, tgt)
+        dpart.step(u, i, y, seq_d, len_d, tgt)
+    torch.cuda.synchronize()
+    a, b = dsingle.loss_acc.cpu().numpy(), dpart.loss_acc.cpu().numpy()
+    assert np.abs(a - b).max() <= 3e-6 * np.abs(a).max(), (a, b)
+    want = torch.cat([net.embedding_user.weight, net.embedding_item.weight]).detach()
+    assert (model.E0_local.detach() - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+    for (name, p_), (_, q_) in zip(net.named_parameters(), core.named_parameters()):
+        if not name.startswith("embedding_"):
+            # (Adam's first steps move every touched parameter by ~lr whatever the gradient's size: compare on that scale)
+            assert (p_.detach() - q_.detach()).abs().max().item() <= 0.02 * 1e-3 * 3, name
+    dsingle.set_edge_dropout(None)
+    model.P.native.close()
