@@ -130,7 +130,7 @@ int spex_spmm_rowlist_f32(const spex_graph_t *g, const float *X, const int64_t *
  *                 layer tables, NULL = absent),   out_raw[k] = raw[r]  (if out_raw)
  * and ZEROS for every other slot: out_prop / out_raw ([n, 64], compact) are the operands of the owner-computes all-reduce
  * (spex_comm_allreduce_sum_f32) that leaves the batch's rows on every rank.  One launch instead of a whole-block product + two
- * spex_gather_owned_rows_f32. */
+ * spex_gather_owned_rows_f32.  A mask on the handle (edge dropout) is applied entry by entry, as spex_spmm_f32 applies it. */
 int spex_spmm_owned_rows_f32(const spex_graph_t *g, const float *X, const int64_t *pos, int32_t n, int64_t lo, const float *acc_in,
                              const float *acc2, const float *acc3, float acc_div, const float *raw, float *out_prop, float *out_raw,
                              int32_t d, void *stream);
@@ -876,7 +876,9 @@ int spex_comm_allreduce_sum_f32(spex_comm_t *comm, float *buf, int64_t n, void *
  * graph / graph_t: this rank's row blocks (n_local rows, world * max_rows columns).  d == 64, L >= 1.
  * Edge dropout (utility1/model.py:46-64; since round 4): set the SAME mask on graph and graph_t (spex_graph_set_edge_mask), both created
  * with the entries' GLOBAL edge ids (spex_graph_create's edge_id: the entry's index in A; for the block of A^T the permutation), graph_t a
- * handle of its own — every rank then drops the same edges of A and of A^T.  A masked step takes the launch-by-launch schedule. */
+ * handle of its own — every rank then drops the same edges of A and of A^T.  The fast path stays available when graph_push carries the
+ * same mask (and, per entry, the global edge id of the entry of A it came from): its rows-only layer and its push apply the keep rule
+ * entry by entry; with an unmasked graph_push a masked step takes the launch-by-launch schedule. */
 typedef struct spex_partitioned_step {
     const spex_graph_t *graph, *graph_t;
     spex_comm_t *comm;
@@ -914,7 +916,7 @@ int spex_partitioned_step_bce_f32(spex_partitioned_step_t *step, const int64_t *
  *                precisions and the task weights' own gradients as in spex_dual_task_step_f32.
  * 2 L exchanges + 1 all-reduce per step, every exchange in place (see spex_partitioned_step_t).  flags: SPEX_STEP_DETERMINISTIC (owned
  * rows added in slot order, no float atomics), SPEX_STEP_FIXED_TASK_WEIGHTS.  d == 64, L >= 1.  Edge dropout on the rec branch
- * (model_expert_s.py:104-109): as for spex_partitioned_step_t — the same mask on both handles, the launch-by-launch schedule.
+ * (model_expert_s.py:104-109): as for spex_partitioned_step_t — the same mask on both handles (and on graph_push for the fast path).
  * FAST PATH (graph_push and gathered2 given, L >= 2, not deterministic) — spex_dual_task_step_f32's schedule on the partition:
  *   forward layers 1 .. L-1 over the block (plain form for L <= 3), the LAST layer at the batch's rows only, on their owners
  *   (spex_spmm_owned_rows_f32: layer mean + raw rows, zeros elsewhere) -> the one all-reduce of 4B rows -> gate, scores, BCE, the

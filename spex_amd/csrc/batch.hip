@@ -546,6 +546,65 @@ __global__ __launch_bounds__(kWave *kWgWaves) void gated_batch_push_kernel(
 
 
 
+// The last forward layer of a ROW-PARTITIONED step at the batch's rows (d == 64; comm.hip).  Slot k names position pos[k] of the
+// padded global layout; on the rank that owns it (lo <= pos[k] < lo + n_rows) the row-list kernel's sum for the rank's local row
+// r = pos[k] - lo — wave w takes segments w, w + 16, ... as one chain, the waves' sums are added in wave order: the same bits for
+// every row of up to 1 024 entries — gives the layer mean (acc_in [+ acc2 + acc3] + A X)[r] / acc_div, stored COMPACT at out_prop[k]
+// beside the raw row out_raw[k] = raw[r]; every other slot is ZERO-filled on this rank: the two buffers are the operands of the
+// owner-computes all-reduce that hands every rank the batch's rows.  Replaces a whole-block launch + two gather launches.  Under
+// edge dropout (a mask on the handle) the entries are kept / dropped by the handle's rule, exactly as spmm_chunk_kernel<.., MASKED>.
+__global__ __launch_bounds__(kWave *kWgWaves) void owned_rows_kernel(
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
+    const float *__restrict__ X, const int64_t *__restrict__ pos, int64_t lo, int32_t n_rows, const float *__restrict__ acc_in,
+    const float *__restrict__ acc2, const float *__restrict__ acc3, float acc_div, const float *__restrict__ raw,
+    float *__restrict__ out_prop, float *__restrict__ out_raw, const spex::EdgeDrop drop)
+{
+    __shared__ float s_part[kWgWaves][kWave];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const size_t ko = (size_t)blockIdx.x * kWave + lane;
+    const int64_t r64 = pos[blockIdx.x] - lo;
+    if (r64 < 0 || r64 >= n_rows) {                               // workgroup-uniform: another rank's row (or no row at all)
+        if (wave == 0) out_prop[ko] = 0.0f;
+        if (wave == 1 && out_raw) out_raw[ko] = 0.0f;
+        return;
+    }
+    const int r = (int)r64;
+    const size_t o = (size_t)r * kWave + lane;
+    float run = 0.0f, r2 = 0.0f, r3 = 0.0f;
+    if (wave == 0) {                                               // the epilogue's operands, requested with the row's entries
+        run = acc_in[o];
+        if (acc2) r2 = acc2[o];
+        if (acc3) r3 = acc3[o];
+    }
+    if (wave == 1 && out_raw) out_raw[ko] = raw[o];
+    const int beg = rowptr[r], deg = rowptr[r + 1] - beg;
+    const int nseg = (deg + kTaskEntries - 1) / kTaskEntries;
+    const float *__restrict__ Xl = X + lane;
+    float acc = 0.0f;
+    for (int sgi = wave; sgi < nseg; sgi += kWgWaves) {
+        const int left = deg - sgi * kTaskEntries;
+        if (drop.mode != 0)
+            acc = segment_sum_masked(col, val, Xl, beg + sgi * kTaskEntries, left < kTaskEntries ? left : kTaskEntries, lane, acc, drop);
+        else
+            acc = segment_sum(col, val, Xl, beg + sgi * kTaskEntries, left < kTaskEntries ? left : kTaskEntries, lane, acc);
+    }
+    if (nseg > 1) {
+        if (wave != 0 && wave < nseg) s_part[wave][lane] = acc;
+        __syncthreads();
+    }
+    if (wave == 0) {
+        float y = acc;
+        const int lim = nseg < kWgWaves ? nseg : kWgWaves;
+        for (int w = 1; w < lim; ++w) y = y + s_part[w][lane];    // wave order
+        if (acc2) run = run + r2;                                  // (the layer tables in layer order, as the one-GPU batch kernels add them)
+        if (acc3) run = run + r3;
+        float s = run + y;
+        if (acc_div != 1.0f) s = s / acc_div;
+        out_prop[ko] = s;
+    }
+}
+
 // The batch-sized middle of the one-call steps on a ROW PARTITION (comm.hip: the fast paths of spex_partitioned_step_bce_f32 and
 // spex_partitioned_dual_task_step_f32).  The batch's rows arrive COMPACT and complete on every rank (rows_prop / rows_raw [2B, 64]:
 // slot b = sample b's user row, slot B + b its item row — the owner-computes all-reduce behind spex_spmm_owned_rows_f32), so
@@ -558,7 +617,8 @@ __global__ __launch_bounds__(kWave *kWgWaves) void gated_batch_push_kernel(
 //   then the first backward product in push form WITHOUT an exchange: every rank pushes BOTH gradient rows of EVERY sample through
 //   its own columns of A — the matrix (rowptr, col, val) is the (world * max_rows) x n_local transpose of the rank's block of A^T,
 //   row p = the entries A[p, c] for the rank's columns c: P[col[e]] += push_scale * val[e] * d_prop over the entries of rows
-//   pos[b], pos[B + b] (runs of 16 entries dealt over (part, wave) and loaded ahead, as in lightgcn_batch_kernel<true>).
+//   pos[b], pos[B + b] (runs of 16 entries dealt over (part, wave) and loaded ahead, as in lightgcn_batch_kernel<true>; under edge
+//   dropout the structure carries the entries' global edge ids and the forward's mask: kept values / keep_prob, dropped ones nothing).
 // rowptr == NULL: a rank without rows (nothing to push, nothing owned) — it still forms the loss and the gate gradients.
 template <bool GATED>
 __global__ __launch_bounds__(kWave *kWgWaves) void rows_train_push_kernel(
@@ -566,7 +626,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void rows_train_push_kernel(
     const float *__restrict__ rows_raw, const float *__restrict__ rows_prop, const float *__restrict__ att_u,
     const float *__restrict__ att_i, const int64_t *__restrict__ pos, int64_t lo, int n_local, const float *__restrict__ labels, int B,
     int parts, int runs_per_part, float grad_scale, float push_scale, float *loss_sum, float *g_prop, float *P, float *g_raw,
-    float *g_att, int n_att_copies)
+    float *g_att, int n_att_copies, const spex::EdgeDrop drop)
 {
     __shared__ float s_mixed[2][kWave];
     __shared__ float s_dprop[2][kWave];
@@ -617,6 +677,7 @@ __global__ __launch_bounds__(kWave *kWgWaves) void rows_train_push_kernel(
                 if (lane < p_cnt[p]) {
                     p_col[p] = col[base + lane];
                     p_val[p] = val[base + lane];
+                    if (drop.mode != 0) p_val[p] = spex::edge_kept(drop, base + lane) ? p_val[p] / drop.keep_prob : 0.0f;   // the forward's mask
                 }
             }
         }
@@ -854,8 +915,9 @@ int spex::rows_train_push(const spex_graph_t *push, const float *rows_raw, const
     SPEX_CHECK_ARG(rows_prop && pos && labels && loss_sum && P, "rows_train_push: NULL argument");
     SPEX_CHECK_ARG(!gated || (att_u && att_i && g_raw && g_att && n_att_copies >= 1), "rows_train_push: the gated form needs att_u, att_i, g_raw, g_att");
     SPEX_CHECK_ARG(B >= 0 && n_local >= 0, "rows_train_push: B=%d n_local=%d", B, n_local);
-    SPEX_CHECK_ARG(!push || (push->n_cols == n_local && push->mask_mode == 0), "rows_train_push: the push structure has %d columns for %d local rows",
+    SPEX_CHECK_ARG(!push || push->n_cols == n_local, "rows_train_push: the push structure has %d columns for %d local rows",
                    push ? push->n_cols : 0, n_local);
+    const spex::EdgeDrop drop = push ? edge_drop_of(push) : spex::EdgeDrop{nullptr, nullptr, 0, 1.0f, 0u, 0u};
     SPEX_CHECK_ARG(P != g_prop && P != g_raw && (!g_prop || g_prop != g_raw), "rows_train_push: g_prop, P and g_raw are three tables");
     if (B == 0) return SPEX_OK;
     constexpr int parts = kBatchParts, runs_per_part = kBatchRunsPerPart;
@@ -863,11 +925,28 @@ int spex::rows_train_push(const spex_graph_t *push, const float *rows_raw, const
     if (gated)
         hipLaunchKernelGGL(rows_train_push_kernel<true>, dim3((unsigned)B * parts), dim3(kWave * kWgWaves), 0, (hipStream_t)stream, rp,
                            push ? push->col : nullptr, push ? push->val : nullptr, push ? push->n_rows : 0, rows_raw, rows_prop, att_u, att_i, pos, lo,
-                           n_local, labels, B, parts, runs_per_part, grad_scale, push_scale, loss_sum, g_prop, P, g_raw, g_att, n_att_copies);
+                           n_local, labels, B, parts, runs_per_part, grad_scale, push_scale, loss_sum, g_prop, P, g_raw, g_att, n_att_copies, drop);
     else
         hipLaunchKernelGGL(rows_train_push_kernel<false>, dim3((unsigned)B * parts), dim3(kWave * kWgWaves), 0, (hipStream_t)stream, rp,
                            push ? push->col : nullptr, push ? push->val : nullptr, push ? push->n_rows : 0, nullptr, rows_prop, nullptr, nullptr, pos, lo,
-                           n_local, labels, B, parts, runs_per_part, grad_scale, push_scale, loss_sum, g_prop, P, nullptr, nullptr, 1);
+                           n_local, labels, B, parts, runs_per_part, grad_scale, push_scale, loss_sum, g_prop, P, nullptr, nullptr, 1, drop);
+    SPEX_HIP(hipGetLastError());
+    return SPEX_OK;
+}
+
+extern "C" int spex_spmm_owned_rows_f32(const spex_graph_t *g, const float *X, const int64_t *pos, int32_t n, int64_t lo,
+                                        const float *acc_in, const float *acc2, const float *acc3, float acc_div, const float *raw,
+                                        float *out_prop, float *out_raw, int32_t d, void *stream)
+{
+    SPEX_CHECK_ARG(g && X && out_prop && acc_in && n >= 0 && (n == 0 || pos), "spex_spmm_owned_rows_f32: NULL argument");
+    SPEX_CHECK_ARG(acc_div != 0.0f && (!out_raw || raw) && (!acc3 || acc2), "spex_spmm_owned_rows_f32: acc_div == 0, out_raw without raw, or acc3 without acc2");
+    if (d != kWave) {
+        spex::set_error("spex_spmm_owned_rows_f32: d == 64 only (got %d)", d);
+        return SPEX_ERR_UNSUPPORTED;
+    }
+    if (n == 0) return SPEX_OK;
+    hipLaunchKernelGGL(owned_rows_kernel, dim3((unsigned)n), dim3(kWave * kWgWaves), 0, (hipStream_t)stream, g->rowptr, g->col, g->val, X, pos, lo,
+                       g->n_rows, acc_in, acc2, acc3, acc_div, raw, out_prop, out_raw, edge_drop_of(g));
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }

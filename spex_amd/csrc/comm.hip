@@ -265,6 +265,16 @@ static int exchange_in_place(spex_comm_t *comm, const int32_t *rows_per_rank, co
     return spex_comm_allgather_rows_f32(comm, own, table, max_rows, d, rows_per_rank, stream);
 }
 
+// edge dropout and the fast path: its rows-only layer reads `graph` and its push reads `graph_push` entry by entry with the handles' keep
+// rule — the push structure must then carry the same mask as the blocks (and the entries' global edge ids); otherwise a masked step
+// takes the launch-by-launch schedule, whose products are whole-block launches
+static inline bool push_mask_matches(const spex_graph_t *g, const spex_graph_t *push, int64_t n_loc)
+{
+    if (g->mask_mode == 0) return push == nullptr || push->mask_mode == 0;
+    if (n_loc == 0) return true;                                     // (a rank without rows pushes nothing)
+    return push != nullptr && push->mask_mode == g->mask_mode && push->keep_prob == g->keep_prob && push->seed == g->seed && push->keep == g->keep;
+}
+
 static inline float *own_slot(const spex_comm_t *comm, float *table, int64_t max_rows, int32_t d)
 {
     return table + (size_t)comm->rank * max_rows * d;
@@ -302,10 +312,11 @@ extern "C" int spex_partitioned_step_bce_f32(spex_partitioned_step_t *s, const i
     const int64_t sz = n_loc * d;
     // ---- the fast path: spex_lightgcn_step_bce_f32's schedule on the partition (see spex_partitioned_dual_task_step_f32 below, whose rec
     //      branch is this with the gate in the middle).  The same choice on every rank: the two schedules differ in their collectives.
-    const bool fast = !det && L >= 2 && s->gathered2 != nullptr && (s->graph_push != nullptr || n_loc == 0) && s->graph->mask_mode == 0;
+    const bool fast = !det && L >= 2 && s->gathered2 != nullptr && (s->graph_push != nullptr || n_loc == 0)
+                      && push_mask_matches(s->graph, s->graph_push, n_loc);
     if (fast) {
         if (n_loc)
-            SPEX_CHECK_ARG(s->graph_push->n_rows == s->comm->world * s->max_rows && s->graph_push->n_cols == n_loc && s->graph_push->mask_mode == 0,
+            SPEX_CHECK_ARG(s->graph_push->n_rows == s->comm->world * s->max_rows && s->graph_push->n_cols == n_loc,
                            "spex_partitioned_step_bce_f32: graph_push must be the (world * max_rows) x n_local transpose of the rank's block of A^T");
         SPEX_CHECK_ARG(s->gathered2 != s->gathered && s->gathered2 != s->gathered1, "spex_partitioned_step_bce_f32: gathered2 is a third table");
         float *Tb[2] = {s->gathered, s->gathered1};
@@ -430,11 +441,12 @@ extern "C" int spex_partitioned_dual_task_step_f32(spex_partitioned_dual_step_t 
     // the fast path (spex_dual_task_step_f32's schedule on the partition): needs the push structure, its zero-kept table and L >= 2
     //  (a rank without rows has nothing to push and needs no structure — but must walk the same sequence of collectives as its peers:
     //   the choice depends on gathered2 and the flags, which the caller sets alike on every rank)
-    //  (under edge dropout — model_expert_s.py:104-109, the rec branch only — the launch-by-launch schedule: all its products are
-    //   whole-block launches, which apply the handles' mask)
-    const bool fast = !det && L >= 2 && s->gathered2 != nullptr && (s->graph_push != nullptr || n_loc == 0) && s->graph->mask_mode == 0;
+    //  (under edge dropout — model_expert_s.py:104-109, the rec branch only — the fast path needs the mask on the push structure too;
+    //   without it the launch-by-launch schedule, whose products are all whole-block launches)
+    const bool fast = !det && L >= 2 && s->gathered2 != nullptr && (s->graph_push != nullptr || n_loc == 0)
+                      && push_mask_matches(s->graph, s->graph_push, n_loc);
     if (fast && n_loc)
-        SPEX_CHECK_ARG(s->graph_push->n_rows == world * max_rows && s->graph_push->n_cols == n_loc && s->graph_push->mask_mode == 0,
+        SPEX_CHECK_ARG(s->graph_push->n_rows == world * max_rows && s->graph_push->n_cols == n_loc,
                        "%s: graph_push must be the (world * max_rows) x n_local transpose of the rank's block of A^T", who);
     const size_t sz = (size_t)n_loc * d;
     float *E0 = s->params, *trust_p = E0 + sz, *att1 = trust_p + n_trust, *att2 = att1 + 4 * d;

@@ -773,76 +773,6 @@ __global__ __launch_bounds__(kWave *kWgWaves) void spmm_rowlist_kernel(
     }
 }
 
-// The last forward layer of a ROW-PARTITIONED step at the batch's rows (d == 64; comm.hip).  Slot k names position pos[k] of the
-// padded global layout; on the rank that owns it (lo <= pos[k] < lo + n_rows) the row-list kernel's sum for the rank's local row
-// r = pos[k] - lo gives the layer mean (acc_in [+ acc2 + acc3] + A X)[r] / acc_div, stored COMPACT at out_prop[k] beside the raw
-// row out_raw[k] = raw[r]; every other slot is ZERO-filled on this rank: the two buffers are the operands of the owner-computes
-// all-reduce that hands every rank the batch's rows.  Replaces a whole-block launch + two gather launches.
-__global__ __launch_bounds__(kWave *kWgWaves) void spmm_owned_rows_kernel(
-    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
-    const float *__restrict__ X, const int64_t *__restrict__ pos, int64_t lo, int32_t n_rows, const float *__restrict__ acc_in,
-    const float *__restrict__ acc2, const float *__restrict__ acc3, float acc_div, const float *__restrict__ raw,
-    float *__restrict__ out_prop, float *__restrict__ out_raw)
-{
-    __shared__ float s_part[kWgWaves][kWave];
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const size_t ko = (size_t)blockIdx.x * 64 + lane;
-    const int64_t r64 = pos[blockIdx.x] - lo;
-    if (r64 < 0 || r64 >= n_rows) {                               // workgroup-uniform: another rank's row (or no row at all)
-        if (wave == 0) out_prop[ko] = 0.0f;
-        if (wave == 1 && out_raw) out_raw[ko] = 0.0f;
-        return;
-    }
-    const int r = (int)r64;
-    const size_t o = (size_t)r * 64 + lane;
-    float run = 0.0f, r2 = 0.0f, r3 = 0.0f;
-    if (wave == 0) {                                               // the epilogue's operands, requested with the row's entries
-        run = acc_in[o];
-        if (acc2) r2 = acc2[o];
-        if (acc3) r3 = acc3[o];
-    }
-    if (wave == 1 && out_raw) out_raw[ko] = raw[o];
-    const int beg = rowptr[r], deg = rowptr[r + 1] - beg;
-    const int nseg = (deg + kTaskEntries - 1) / kTaskEntries;
-    const float *__restrict__ Xl = X + lane;
-    float acc = 0.0f;
-    for (int sgi = wave; sgi < nseg; sgi += kWgWaves) {
-        const int e0 = beg + sgi * kTaskEntries;
-        const int cnt = (deg - sgi * kTaskEntries < kTaskEntries) ? deg - sgi * kTaskEntries : kTaskEntries;
-        int my_col = 0;
-        float my_val = 0.0f;
-        if (lane < cnt) {
-            my_col = col[e0 + lane];
-            my_val = val[e0 + lane];
-        }
-        const int last_col = __builtin_amdgcn_readlane(my_col, (cnt - 1) & 63);
-        if (lane >= cnt) my_col = last_col;
-        for (int c = 0; c * kChunk < cnt; ++c) {
-            float x[kChunk];
-#pragma unroll
-            for (int u = 0; u < kChunk; ++u)
-                x[u] = Xl[(size_t)(uint32_t)__builtin_amdgcn_readlane(my_col, c * kChunk + u) * 64];
-#pragma unroll
-            for (int u = 0; u < kChunk; ++u) acc = fmaf(lane_bcast(my_val, c * kChunk + u), x[u], acc);
-        }
-    }
-    if (nseg > 1) {
-        if (wave != 0 && wave < nseg) s_part[wave][lane] = acc;
-        __syncthreads();
-    }
-    if (wave == 0) {
-        float y = acc;
-        const int lim = nseg < kWgWaves ? nseg : kWgWaves;
-        for (int w = 1; w < lim; ++w) y = y + s_part[w][lane];    // segment order
-        if (acc2) run = run + r2;                                  // (the layer tables in layer order, as the one-GPU batch kernels add them)
-        if (acc3) run = run + r3;
-        float s = run + y;
-        if (acc_div != 1.0f) s = s / acc_div;
-        out_prop[ko] = s;
-    }
-}
-
 // One wave per long row: add its segment partials in order, then the shared epilogue.
 __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_long_fixup_kernel(const SpmmParams p,
                                                                                const int32_t *__restrict__ rows,
@@ -1086,23 +1016,6 @@ extern "C" int spex_spmm_rowlist_f32(const spex_graph_t *g, const float *X, cons
     if (n_a + n_b == 0 || g->n_rows == 0) return SPEX_OK;
     hipLaunchKernelGGL(spmm_rowlist_kernel, dim3((unsigned)(n_a + n_b)), dim3(kWave * kWgWaves), 0, (hipStream_t)stream, g->rowptr,
                        g->col, g->val, X, idx_a, n_a, off_a, idx_b, off_b, g->n_rows, Y, acc_in, acc_out, acc_div);
-    SPEX_HIP(hipGetLastError());
-    return SPEX_OK;
-}
-
-extern "C" int spex_spmm_owned_rows_f32(const spex_graph_t *g, const float *X, const int64_t *pos, int32_t n, int64_t lo,
-                                        const float *acc_in, const float *acc2, const float *acc3, float acc_div, const float *raw,
-                                        float *out_prop, float *out_raw, int32_t d, void *stream)
-{
-    SPEX_CHECK_ARG(g && X && out_prop && acc_in && n >= 0 && (n == 0 || pos), "spex_spmm_owned_rows_f32: NULL argument");
-    SPEX_CHECK_ARG(acc_div != 0.0f && (!out_raw || raw) && (!acc3 || acc2), "spex_spmm_owned_rows_f32: acc_div == 0, out_raw without raw, or acc3 without acc2");
-    if (d != 64 || g->mask_mode != 0) {
-        spex::set_error("spex_spmm_owned_rows_f32: d == 64 without edge dropout only (d = %d, mask mode %d)", d, g->mask_mode);
-        return SPEX_ERR_UNSUPPORTED;
-    }
-    if (n == 0) return SPEX_OK;
-    hipLaunchKernelGGL(spmm_owned_rows_kernel, dim3((unsigned)n), dim3(kWave * kWgWaves), 0, (hipStream_t)stream, g->rowptr, g->col, g->val, X,
-                       pos, lo, g->n_rows, acc_in, acc2, acc3, acc_div, raw, out_prop, out_raw);
     SPEX_HIP(hipGetLastError());
     return SPEX_OK;
 }

@@ -241,6 +241,7 @@ class PartitionedLightGCN:
             tr, tc, tv, te = p.local_block(*full_t[:3], rank, full_t[3])
             self.graph_t = graph_factory(tr, tc, tv, n_cols=p.n_padded, edge_id=te)
             self._t_block = (tr, tc, tv)
+            self._t_block_eid = te
             self.nnz_global = int(len(col))
         else:
             lr, lc, lv, _ = p.local_block(rowptr, col, val, rank)
@@ -253,6 +254,7 @@ class PartitionedLightGCN:
                 self.graph_t = graph_factory(tr, tc, tv, n_cols=p.n_padded)
                 self._t_block = (tr, tc, tv)
         self._graph_factory, self._graph_push, self._tables = graph_factory, None, {}
+        self._edge_mask = (0, None, 1.0, 0)            # the mask last set (re-applied to the push structure when it is built)
         self.r0, self.r1 = int(p.bounds[rank]), int(p.bounds[rank + 1])
         self.n_local = self.r1 - self.r0
         z = lambda *s: torch.zeros(s, dtype=torch.float32, device=self.device)
@@ -277,9 +279,12 @@ class PartitionedLightGCN:
         must set the same mask.  mode 0 clears it."""
         if not self.edge_ids and mode != 0:
             raise ValueError("PartitionedLightGCN.set_edge_mask: build the model with edge_ids=True")
+        self._edge_mask = (mode, keep, keep_prob, seed)
         self.graph.set_edge_mask(mode, keep, keep_prob, seed)
         if self.graph_t is not self.graph:
             self.graph_t.set_edge_mask(mode, keep, keep_prob, seed)
+        if self._graph_push is not None and self.edge_ids:   # (the fast path's push reads it entry by entry with the same keep rule)
+            self._graph_push.set_edge_mask(mode, keep, keep_prob, seed)
 
     # -- what the one-call native steps need beside the Python-issued schedule's buffers
     def table(self, k):
@@ -297,11 +302,16 @@ class PartitionedLightGCN:
             import numpy as np
             import scipy.sparse as sp
             tr, tc, tv = self._t_block
-            blk = sp.csr_matrix((np.asarray(tv), np.asarray(tc), np.asarray(tr)), shape=(self.n_local, self.part.n_padded))
-            push = blk.T.tocsr()                             # (stored entries kept one by one: nothing is summed)
-            push.sort_indices()
-            self._graph_push = self._graph_factory(push.indptr.astype(np.int64), push.indices.astype(np.int32), push.data.astype(np.float32),
-                                                   n_cols=self.n_local)
+            # (transposed through the entries' INDICES, so that values and — under edge dropout — global edge ids follow their entry)
+            idx = sp.csr_matrix((np.arange(1, len(tc) + 1, dtype=np.int64), np.asarray(tc), np.asarray(tr)),
+                                shape=(self.n_local, self.part.n_padded)).T.tocsr()          # (stored entries kept one by one: nothing is summed)
+            idx.sort_indices()
+            perm = idx.data - 1
+            kw = {"edge_id": np.ascontiguousarray(np.asarray(self._t_block_eid)[perm]).astype(np.int32)} if self.edge_ids else {}
+            self._graph_push = self._graph_factory(idx.indptr.astype(np.int64), idx.indices.astype(np.int32),
+                                                   np.ascontiguousarray(np.asarray(tv, np.float32)[perm]), n_cols=self.n_local, **kw)
+            if self.edge_ids:
+                self._graph_push.set_edge_mask(*self._edge_mask)
         return self._graph_push
 
     # -- the one exchange step of the data path

@@ -394,8 +394,8 @@ def test_partitioned_fast_path_on_a_non_symmetric_matrix_against_the_oracle(L, o
 def test_partitioned_steps_under_edge_dropout_equal_the_one_gpu_steps():
     """Edge dropout on the row partition (the reference's recommended `--dropout 1 --keepprob 0.3`, README.md:119-123;
     utility1/model.py:46-64, model_expert_s.py:104-109), world size 1: blocks built with GLOBAL edge ids (edge_ids=True) take the
-    step's mask on both handles and the one-call steps run their launch-by-launch schedule, whose products are whole-block masked
-    launches.  (a) spex_partitioned_step_bce_f32 with an INJECTED keep mask (the reference-stream form: an array indexed by edge id)
+    step's mask on both handles AND on the push structure, and the one-call steps keep their fast path — the rows-only last layer and
+    the push apply the handles' keep rule entry by entry, the other products are masked whole-block launches.  (a) spex_partitioned_step_bce_f32 with an INJECTED keep mask (the reference-stream form: an array indexed by edge id)
     and with the sampled one against LightGCNStepper under the same masks; (b) spex_partitioned_dual_task_step_f32 with sampled masks
     against DualTaskStepper under the same masks (the rec branch drops edges, the trust branch reads the raw table): losses and every
     parameter after three steps."""
@@ -439,6 +439,14 @@ def test_partitioned_steps_under_edge_dropout_equal_the_one_gpu_steps():
     assert abs(acc_p.item() - acc_s.item()) <= 2e-6 * abs(acc_s.item())
     err = (part.E0 - single.E0).abs().max().item() / single.E0.abs().max().item()
     assert err <= 5e-6, err
+    # the masked steps ran the FAST path: its push structure exists, carries global edge ids and the step's mask
+    assert P._graph_push is not None and P._graph_push.mask_mode == 2 and P._graph_push._edge_id_host is not None
+    slow = PartitionedStepper(P, E0.clone(), lr=1e-3, fast=False)                         # ... and equals the launch-by-launch schedule
+    acc_l = torch.zeros(1, device=dev)
+    for (u, i, y), mask in zip(batches, masks):
+        P.set_edge_mask(*mask)
+        slow.step_bce(u, i, y, loss_acc=acc_l)
+    assert (slow.E0 - part.E0).abs().max().item() <= 5e-6 * part.E0.abs().max().item() and abs(acc_l.item() - acc_p.item()) <= 2e-6 * acc_p.item()
     unmasked = PartitionedStepper(PartitionedLightGCN(*csr, n_u + 1, L, 64, 0, 1, efactory, dev, allgather="native-p2p"), E0.clone(), lr=1e-3)
     for u, i, y in batches:
         unmasked.step_bce(u, i, y, loss_acc=torch.zeros(1, device=dev))

@@ -1035,6 +1035,17 @@ def test_spmm_owned_rows_is_the_row_list_product_on_the_owner_and_zero_elsewhere
     out_p = torch.full((len(pos), 64), 7.0, device=DEV)
     ops.spmm_owned_rows(blk, X, pos, r0, acc, 1.0, out_p)                  # no raw rows wanted
     assert torch.equal(out_p[own], (acc + full)[loc][own])
+    # under edge dropout (a mask on the handle): the masked whole-block product's rows (model.py:46-64)
+    for mask in ((2, None, 0.3, (5 << 32) | 7), (1, torch.from_numpy((rng.random(len(col)) < 0.4).astype(np.uint8)).to(DEV), 0.4, 0)):
+        blk_e = G(lrp, col[sl], val[sl], n_cols=n, edge_id=np.arange(rowptr[r0], rowptr[r1], dtype=np.int32))   # global edge ids
+        blk_e.set_edge_mask(*mask)
+        masked = blk_e.spmm(X)
+        out_m = torch.empty(len(pos), 64, device=DEV)
+        ops.spmm_owned_rows(blk_e, X, pos, r0, acc, 4.0, out_m)
+        assert rel_err(out_m[own].cpu().numpy(), ((acc + masked) / 4.0)[loc][own].cpu().numpy()) <= 2e-6
+        assert float(out_m[~own].abs().sum()) == 0.0
+        assert (masked - full).abs().max().item() > 1e-3                   # (the mask mattered)
+        blk_e.set_edge_mask(0)
     # hub rows, an empty row
     deg = rng.integers(0, 50, 300)
     deg[3], deg[4], deg[5] = 0, 1500, 2600
