@@ -49,3 +49,35 @@ for det, fast, tag in ((False, True, "fast path       "), (False, False, "launch
     print("PartitionedStepper, world 1, %s   : %.1f us (host enqueue %.1f)"
           % ((tag,) + timed(lambda: pst.step_bce(ub, ib, yb, pos=pos, loss_acc=acc, deterministic=det))), flush=True)
     P.native.close()
+
+# ---- the same under the reference's recommended edge dropout (--dropout 1 --keepprob 0.3): a fresh sampled mask per step
+from spex_amd.graph import csr_transpose
+from spex_amd.trainer import edge_dropout_mask
+n = len(csr[0]) - 1
+t_rp, t_c, t_v, t_e = csr_transpose(*csr, n)
+g1 = SpexGraph(*csr, device=dev)
+st = LightGCNStepper(g1, E0.clone(), n_u + 1, n_layers=L, lr=1e-3, graph_t=SpexGraph(t_rp, t_c, t_v, n_cols=n, edge_id=t_e, device=dev))
+k = {"k": 0}
+
+
+def single_masked():
+    k["k"] += 1
+    mask = edge_dropout_mask(None, 0.3, "philox", 7, k["k"])
+    st.graph.set_edge_mask(*mask); st.graph_t.set_edge_mask(*mask)
+    st.step_bce(ub, ib, yb, loss_acc=acc, batch_rows_only=True)
+
+
+print("edge dropout 0.3: LightGCNStepper (one-call step)     : %.1f us (host enqueue %.1f)" % timed(single_masked), flush=True)
+efactory = lambda r, c, v, n_cols, edge_id=None: SpexGraph(r, c, v, n_cols=n_cols, edge_id=edge_id, device=dev)
+for fast in (True, False):
+    P = PartitionedLightGCN(*csr, n_u + 1, L, 64, 0, 1, efactory, dev, allgather="native-p2p", edge_ids=True)
+    pst = PartitionedStepper(P, E0.clone(), lr=1e-3, fast=fast)
+    pos = pst.positions(ub, ib)
+
+    def part_masked():
+        k["k"] += 1
+        P.set_edge_mask(*edge_dropout_mask(None, 0.3, "philox", 7, k["k"]))
+        pst.step_bce(ub, ib, yb, pos=pos, loss_acc=acc)
+    print("edge dropout 0.3: PartitionedStepper, world 1, %s: %.1f us (host enqueue %.1f)"
+          % ((("fast path       " if fast else "launch by launch"),) + timed(part_masked)), flush=True)
+    P.native.close()
