@@ -77,6 +77,12 @@ def main():
     ap.add_argument("--hbm-log2-nodes", type=int, default=24)     # the scaled roofline graph is N = 2^24
     ap.add_argument("--no-strong-scaling", action="store_true")   # N > 1: skip the strong-scaling leg on the 2^24-node graph
     a = ap.parse_args()
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner on stdout when its first communicator is created (the
+    # N > 1 runs; the world-size-1 communicator of `extra.partitioned_one_call_steps_world1`): keep the real stdout for the line and
+    # point file descriptor 1 at stderr for everything a library may print in between.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -445,7 +451,36 @@ def main():
             dst.join()
             aux["dual_task_step_ms_B256_T15_pipelined"] = time_events(fn3, 500, finish=dst.join)
             dst.join()
-            del dnet, dst
+            del dst
+            # the ROW-PARTITIONED one-call steps (spex_partitioned_step_bce_f32 / spex_partitioned_dual_task_step_f32) at world
+            # size 1, where every exchange is the library's local-copy shortcut (in place: nothing is copied but E^0): what the
+            # partition's schedule itself costs beside the one-GPU steps above — 2L - 1 exchanges + one all-reduce per step on N GPUs
+            try:
+                from spex_amd.dist import PartitionedLightGCN, PartitionedStepper
+                from spex_amd.dist_dual import PartitionedDualTask, PartitionedDualTaskStepper
+                pP = PartitionedLightGCN(rowptr, col, val, n_u, L, D, 0, 1, lambda r, c, v, n_cols: SpexGraph(r, c, v, n_cols=n_cols, device=dev),
+                                         dev, allgather="native-p2p")
+                pst = PartitionedStepper(pP, torch.from_numpy(E0_host).to(dev), lr=lr)
+                ppos = pst.positions(ub, ib)
+                fnp = lambda: pst.step_bce(ub, ib, yb, pos=ppos, loss_acc=acc)
+                for _ in range(10):
+                    fnp()
+                part1 = {"exact_train_step_ms_B256": time_events(fnp, 300)}
+                pP.native.close()
+                del pst, pP
+                pmodel = PartitionedDualTask(dnet, (rowptr, col, val), 0, 1, dev)
+                pdst = PartitionedDualTaskStepper(pmodel, path_capacity=T_PATHS, path_len=P_LEN, lr=1e-3)
+                dpos = pdst.positions(ub, ib)
+                fnpd = lambda: pdst.step(ub, ib, yb, pseq_d, plen_d, ptgt, pos=dpos)
+                for _ in range(20):
+                    fnpd()
+                part1["dual_task_step_ms_B256_T15"] = time_events(fnpd, 300)
+                pmodel.P.native.close()
+                del pdst, pmodel
+                aux["partitioned_one_call_steps_world1"] = part1
+            except Exception as e:      # noqa: BLE001 — RCCL could not be bound, ...: the one-GPU figures stand
+                aux["partitioned_one_call_steps_world1"] = {"error": repr(e)[:200]}
+            del dnet
             # BASELINE configs[3] / [5] on their OWN shape (Trust_SPEX/code/main_trust.py:42: 6 812 Weibo users; synthetic interactions
             # with log-normal user activity and Zipf item popularity, hub rows beyond 1 024 entries): the exact LightGCN step and the
             # dual-task step (15 paths against the 6 812-user table)
@@ -838,7 +873,7 @@ def main():
             except Exception as e:
                 out["cpu_baseline"] = {"error": repr(e)}
 
-    print(json.dumps(out))
+    print(json.dumps(out), file=real_stdout, flush=True)
     if part:
         dist.destroy_process_group()
 
