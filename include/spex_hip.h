@@ -862,9 +862,9 @@ int spex_comm_allreduce_sum_f32(spex_comm_t *comm, float *buf, int64_t n, void *
  *   FAST PATH of spex_partitioned_step_bce_f32 (gathered2 given, L >= 2, not deterministic; the same choice on EVERY rank — the two
  *   schedules differ in their collectives) — spex_lightgcn_step_bce_f32's schedule on the partition: forward layers 1 .. L-1 over the
  *   block (plain form for L <= 3), the LAST layer at the batch's rows on their owners (spex_spmm_owned_rows_f32) -> the all-reduce of
- *   2B rows -> scores, BCE, gradient rows and the owner-computes adds in ONE launch on the replicated rows -> the backward's FIRST
- *   product in push form WITHOUT an exchange (every rank holds all 2B gradient rows and pushes them through graph_push = its own
- *   columns of A) -> L - 1 pull-form products on A^T's block, the last one plain (Adam adds its g / (L+1) share; L == 3: both plain,
+ *   2B rows -> scores, BCE, gradient rows, the owner-computes adds AND the backward's FIRST product in push form in ONE launch on the
+ *   replicated rows — no exchange for it: every rank holds all 2B gradient rows and pushes them through graph_push = its own
+ *   columns of A -> L - 1 pull-form products on A^T's block, the last one plain (Adam adds its g / (L+1) share; L == 3: both plain,
  *   Adam adds the push target).  2 L - 1 exchanges + 1 all-reduce.  graph_push: handle of the (world * max_rows) x n_local matrix
  *   whose row p holds A[p, c] for the columns c the rank owns (local column indices) = the transpose of the rank's block of A^T;
  *   gathered2 [world * max_rows, 64]: its own slot is the push target, all-zero before the first call (the Adam pass leaves it so).
@@ -920,10 +920,11 @@ int spex_partitioned_step_bce_f32(spex_partitioned_step_t *step, const int64_t *
  * FAST PATH (graph_push and gathered2 given, L >= 2, not deterministic) — spex_dual_task_step_f32's schedule on the partition:
  *   forward layers 1 .. L-1 over the block (plain form for L <= 3), the LAST layer at the batch's rows only, on their owners
  *   (spex_spmm_owned_rows_f32: layer mean + raw rows, zeros elsewhere) -> the one all-reduce of 4B rows -> gate, scores, BCE, the
- *   gate's backward and the owner-computes adds in ONE launch on the replicated compact rows -> the backward's FIRST product in push
- *   form WITHOUT an exchange (every rank holds all 2B gradient rows and pushes them through graph_push = its own columns of A) ->
- *   L - 1 pull-form products on A^T's block.  2 L - 1 exchanges + 1 all-reduce; 2 L - 2 whole-block launches instead of 2 L and
- *   three batch-sized launches instead of nine.
+ *   gate's backward, the owner-computes adds AND the backward's FIRST product in push form, in ONE launch on the replicated compact
+ *   rows — that product needs NO exchange: every rank holds all 2B gradient rows and pushes them through graph_push = its own
+ *   columns of A -> L - 1 pull-form products on A^T's block.  2 L - 1 exchanges + 1 all-reduce; 2 L - 2 whole-block launches instead
+ *   of 2 L and two batch-sized launches instead of nine.  (grad_slots doubles as the gate gradients' scratch copies on this path; the
+ *   trust branch's user block is gathered in front of the fork.)
  *   graph_push: handle of the (world * max_rows) x n_local matrix whose row p holds the entries A[p, c] for the columns c the rank
  *   owns (local column indices) — the transpose of the rank's block of A^T; gathered2 [world * max_rows, 64]: its own slot is the
  *   push target, all-zero before the first call (the Adam pass leaves it so).  gathered2 NULL: the launch-by-launch schedule above —

@@ -20,7 +20,10 @@
 //                            a ring moves the same bytes through one link at a time
 //   spex_comm_allreduce_sum_f32    in place (the owner-computes row exchange; loss / flag cells)
 //   spex_partitioned_propagate_f32 / spex_partitioned_step_bce_f32   L x (exchange + SpMM) forward, the batch's rows fetched
-//                            owner-computes, scoring, L x (exchange + SpMM) backward on A^T's blocks, Adam on the rank's rows
+//                            owner-computes, scoring, L x (exchange + SpMM) backward on A^T's blocks, Adam on the rank's rows —
+//                            every exchange in place; fast path: the one-GPU step's schedule (rows-only last layer, push-form
+//                            first backward product without an exchange: 2 L - 1 exchanges + one all-reduce)
+//   spex_partitioned_dual_task_step_f32   the dual-task step (rec branch + gate + trust head) on the partition, same two schedules
 #include <dlfcn.h>
 #include <string.h>
 #include <mutex>
