@@ -358,6 +358,8 @@ class PartitionedLightGCN:
         cur = E0_local
         if keep_first and getattr(self, "gathered0", None) is None:
             self.gathered0 = torch.zeros_like(self.gathered)
+        if self.use_native and self.L >= 1 and E0_local.is_cuda:
+            return self._propagate_in_place(E0_local, keep_first, first_gathered)
         for l in range(self.L):
             if l == 0 and first_gathered is not None:
                 X = first_gathered
@@ -374,6 +376,43 @@ class PartitionedLightGCN:
                 self.all_gather_rows(E0_local, out=self.gathered0)
         return self.light_out
 
+    # -- the native exchange forms IN PLACE (what the one-call native steps do, comm.hip: exchange_in_place): a layer's SpMM writes its
+    #    output into the rank's own slot of the table the NEXT exchange completes — `gathered` and table(1) alternate — and the
+    #    collective sends from the slot it also receives around (ncclAllGather's in-place form; the point-to-point form sends the real
+    #    rows from where they lie): no send buffer, no copy of a layer's rows.
+    def _own_slot(self, table):
+        lo = self.rank * self.part.max_rows
+        return table[lo: lo + self.part.max_rows]
+
+    def _exchange_in_place(self, table, local=None):
+        if local is not None:
+            table[self.rank * self.part.max_rows: self.rank * self.part.max_rows + self.n_local].copy_(local)
+        return self.native.allgather_rows(self._own_slot(table), table, self.part.max_rows, self._rows_per_rank)
+
+    def _propagate_in_place(self, E0_local, keep_first, first_gathered):
+        T = [self.gathered, self.table(1)]
+        lo = self.rank * self.part.max_rows
+        for l in range(self.L):
+            if l == 0:
+                X = first_gathered if first_gathered is not None else \
+                    self._exchange_in_place(self.gathered0 if keep_first else T[1], E0_local)
+            else:
+                X = self._exchange_in_place(T[(l - 1) & 1])
+            last = l == self.L - 1
+            nxt = None if last else T[l & 1][lo: lo + self.n_local]       # layer l's output: own slot of the next exchange's table
+            self.graph.spmm(X, Y=nxt, acc_in=E0_local if l == 0 else self.light_out, acc_out=self.light_out,
+                            acc_div=float(self.L + 1) if last else 1.0)
+        return self.light_out
+
+    def _propagate_bwd_in_place(self, gs, grad_out):
+        T = [self.gathered, self.table(1)]
+        lo = self.rank * self.part.max_rows
+        for k, l in enumerate(range(self.L - 1, -1, -1)):
+            X = self._exchange_in_place(T[k & 1], gs if k == 0 else None)
+            nxt = grad_out if l == 0 else T[(k + 1) & 1][lo: lo + self.n_local]
+            self.graph_t.spmm(X, Y=nxt, add_in=gs, add_div=1.0)
+        return grad_out
+
     def propagate_bwd(self, g_local, grad_out=None):
         """d loss / d E0 (local rows) from d loss / d light_out (local rows).  No allocation after the first call: the
         scaled gradient g/(L+1) lives in a per-model buffer, every intermediate layer is written straight into the
@@ -383,6 +422,8 @@ class PartitionedLightGCN:
         gs = torch.div(g_local, float(self.L + 1), out=self._gs)
         if grad_out is None:
             grad_out = torch.empty_like(gs)
+        if self.use_native and self.L >= 1 and gs.is_cuda:
+            return self._propagate_bwd_in_place(gs, grad_out)
         cur = gs
         for l in range(self.L - 1, -1, -1):
             X = self.all_gather_rows(cur)
