@@ -682,6 +682,15 @@ typedef struct spex_lightgcn_step {
 } spex_lightgcn_step_t;
 int spex_lightgcn_step_bce_f32(spex_lightgcn_step_t *step, const int64_t *users, const int64_t *items, const float *labels,
                                int32_t B, float *loss_sum, void *stream);
+/* Train() of main_rec.py:30-37 over a whole pre-shuffled, device-resident epoch as ONE call: batch k = samples [k B, min((k+1) B, n))
+ * through spex_lightgcn_step_bce_f32 (at most max_steps batches; < 0: all).  *loss_full accumulates the loss sums of the full batches,
+ * *loss_ragged that of a shorter last batch (main_rec.py:36 adds per-batch MEAN losses: loss_full / B + loss_ragged / (n mod B)).
+ * keep_prob < 1: edge dropout (model.py:46-55) with the in-kernel sampled mask, a fresh one per step — seed = (drop_seed << 32) | step,
+ * steps counted from 1, exactly what spex_graph_set_edge_mask(g, 2, NULL, keep_prob, seed) on both handles before each step gives; the
+ * handles are left unmasked.  (The descriptor's graph handles are modified by that: not const here.) */
+int spex_lightgcn_epoch_bce_f32(spex_lightgcn_step_t *step, const int64_t *users, const int64_t *items, const float *labels, int64_t n,
+                                int32_t B, int64_t max_steps, float keep_prob, uint32_t drop_seed, float *loss_full, float *loss_ragged,
+                                void *stream);
 
 /* The single-layer NGCF training step (NGCF_SPEX/code/main_rec.py:122-128 with the default --layer_size [64]) as one call:
  *   spex_spmm_f32 (side = A ego) -> spex_ngcf_layer_fwd_f32 -> spex_ngcf_score_bwd_rows_f32 (scores, BCE, rows backward)

@@ -108,6 +108,40 @@ extern "C" int spex_lightgcn_step_bce_f32(spex_lightgcn_step_t *s, const int64_t
     return SPEX_OK;
 }
 
+// Train() of main_rec.py:30-37 over a whole (pre-shuffled, device-resident) epoch as ONE call: batch k = samples [k B, min((k+1) B, n))
+// through spex_lightgcn_step_bce_f32 — the host issues ~6 launches per step and nothing else (the Python loop around the one-call
+// step cost 7 us per 70 us step: slicing three tensors, building the call).  Loss sums of the full batches -> loss_full, of the ragged
+// last batch -> loss_ragged (the caller forms main_rec.py:36's sum of per-batch MEAN losses from the two).
+// keep_prob < 1: edge dropout with the in-kernel sampled mask (model.py:46-55), a fresh one per step — seed (drop_seed << 32) | step,
+// step counted from 1 — set on both handles as spex_graph_set_edge_mask(.., 2, ..) would; the handles are left unmasked.
+extern "C" int spex_lightgcn_epoch_bce_f32(spex_lightgcn_step_t *s, const int64_t *users, const int64_t *items, const float *labels,
+                                           int64_t n, int32_t B, int64_t max_steps, float keep_prob, uint32_t drop_seed, float *loss_full,
+                                           float *loss_ragged, void *stream)
+{
+    SPEX_CHECK_ARG(s && s->graph && s->graph_t, "spex_lightgcn_epoch_bce_f32: NULL step descriptor or graph");
+    SPEX_CHECK_ARG(users && items && labels && loss_full && loss_ragged && n >= 0 && B >= 1, "spex_lightgcn_epoch_bce_f32: NULL pointer, n < 0 or B < 1");
+    SPEX_CHECK_ARG(keep_prob > 0.0f && keep_prob <= 1.0f, "spex_lightgcn_epoch_bce_f32: keep_prob %g", keep_prob);
+    spex_graph *g = const_cast<spex_graph *>(s->graph), *gt = const_cast<spex_graph *>(s->graph_t);
+    const bool drop = keep_prob < 1.0f;
+    int rc = SPEX_OK;
+    int64_t k = 0;
+    for (int64_t b0 = 0; b0 < n && rc == SPEX_OK && (max_steps < 0 || k < max_steps); b0 += B, ++k) {
+        const int32_t nb = (int32_t)(n - b0 < B ? n - b0 : B);
+        if (drop) {
+            const uint64_t seed = ((uint64_t)drop_seed << 32) | (uint64_t)(uint32_t)(k + 1);
+            rc = spex_graph_set_edge_mask(g, 2, nullptr, keep_prob, seed);
+            if (rc == SPEX_OK && gt != g) rc = spex_graph_set_edge_mask(gt, 2, nullptr, keep_prob, seed);
+            if (rc != SPEX_OK) break;
+        }
+        rc = spex_lightgcn_step_bce_f32(s, users + b0, items + b0, labels + b0, nb, nb == B ? loss_full : loss_ragged, stream);
+    }
+    if (drop) {
+        (void)spex_graph_set_edge_mask(g, 0, nullptr, 1.0f, 0);
+        if (gt != g) (void)spex_graph_set_edge_mask(gt, 0, nullptr, 1.0f, 0);
+    }
+    return rc;
+}
+
 // The north-star step — 3-layer propagation + fused BPR-SGD over a batch of triples — as ONE call of L + 1 launches with the
 // layer mean left to the BPR kernel: layer 1 in the running-sum form (sum1 = E^0 + E^1), the later layers PLAIN, and the fused
 // gather + dot + sigmoid + SGD kernel forms ((sum1 + E^2) + E^3) / (L + 1) at its triples' rows only — the rows of the propagated

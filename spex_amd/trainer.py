@@ -110,11 +110,9 @@ class LightGCNStepper:
                 and users.is_contiguous() and items.is_contiguous() and labels.is_contiguous()
                 and users.numel() == items.numel() == labels.numel() and users.numel() >= 1)
 
-    def _step_bce_one_call(self, users, items, labels, loss_acc):
-        import ctypes
+    def _prepare_desc(self, B):
+        """The one-call step's descriptor for batches of up to B samples (built once, refreshed per call)."""
         from . import _lib
-        from .graph import _bump, _launch
-        B = users.numel()
         if self.lo_batch is None:
             self.lo_batch = torch.zeros_like(self.light_out)
         self._slots(B)
@@ -132,11 +130,36 @@ class LightGCNStepper:
         d = self._desc
         d.t, d.lr = self.t, self.lr
         d.flags = _lib.STEP_DETERMINISTIC if self.deterministic else 0
+        return d
+
+    def _step_bce_one_call(self, users, items, labels, loss_acc):
+        import ctypes
+        from .graph import _bump, _launch
+        B = users.numel()
+        d = self._prepare_desc(B)
         _launch(self.E0.device, "spex_lightgcn_step_bce_f32", ctypes.byref(d), ctypes.c_void_p(users.data_ptr()),
                 ctypes.c_void_p(items.data_ptr()), ctypes.c_void_p(labels.data_ptr()), B, ctypes.c_void_p(loss_acc.data_ptr()))
         self.t = d.t
         _bump(self.E0, self.m, self.v, loss_acc)
         return None
+
+    def epoch_bce(self, users, items, labels, batch_size, loss_full, loss_ragged, max_steps=None, keep_prob=1.0, drop_seed=0):
+        """A whole pre-shuffled, device-resident epoch as ONE native call (spex_lightgcn_epoch_bce_f32; main_rec.py:30-37): batch k =
+        samples [k B, (k+1) B) through the one-call step, nothing but its launches issued by the host.  loss_full / loss_ragged:
+        1-element device accumulators (loss sums of the full batches / of a shorter last one).  keep_prob < 1: the in-kernel sampled
+        edge mask, a fresh one per step (seed (drop_seed << 32) | step — trainer.edge_dropout_mask's "philox" stream)."""
+        import ctypes
+        from .graph import _bump, _launch
+        if not self._one_call_ok(users[:1], items[:1], labels[:1]):
+            raise ValueError("LightGCNStepper.epoch_bce: needs d == 64 and contiguous int64 / fp32 device tensors")
+        if keep_prob < 1.0 and (self.L < 2 or self.graph_t is self.graph):
+            raise ValueError("LightGCNStepper.epoch_bce: edge dropout needs L >= 2 and graph_t = the transposed handle with the edge-id permutation")
+        d = self._prepare_desc(min(int(batch_size), users.numel()))
+        vp = lambda t: ctypes.c_void_p(t.data_ptr())
+        _launch(self.E0.device, "spex_lightgcn_epoch_bce_f32", ctypes.byref(d), vp(users), vp(items), vp(labels), users.numel(), int(batch_size),
+                -1 if max_steps is None else int(max_steps), float(keep_prob), int(drop_seed) & 0xFFFFFFFF, vp(loss_full), vp(loss_ragged))
+        self.t = d.t
+        _bump(self.E0, self.m, self.v, loss_full, loss_ragged)
 
     def backward_from_batch_rows(self, users, items):
         """grad_E0 from g_out (non-zero on the batch's rows only).  The first product of the backward pass, A^T g, touches
@@ -276,6 +299,22 @@ def train_epoch(stepper, train_data, batch_size=256, resample=True, pause_gc=Tru
     starts = list(range(0, n, batch_size))
     if max_steps is not None:
         starts = starts[:max_steps]
+    # the whole epoch as ONE native call where nothing has to happen on the host between two steps: no per-step loss read-back, no
+    # host-drawn mask (the reference-stream dropout mask is drawn on the CPU per step; the sampled one is keyed in the kernel)
+    native_ok = (step_losses is None and (edge_dropout is None or edge_dropout[1] == "philox") and hasattr(stepper, "epoch_bce")
+                 and n > 0 and stepper._one_call_ok(users[:1], items[:1], labels[:1])
+                 and (edge_dropout is None or (stepper.L >= 2 and stepper.graph_t is not stepper.graph)))
+    if native_ok:
+        try:
+            kp = 1.0 if edge_dropout is None else float(edge_dropout[0])
+            seed = 0 if edge_dropout is None or len(edge_dropout) < 3 else int(edge_dropout[2])
+            stepper.epoch_bce(users, items, labels, batch_size, acc[0], acc[1], max_steps=max_steps, keep_prob=kp, drop_seed=seed)
+        finally:
+            if gc_was_on:
+                gc.enable()
+        n_done = min(n, len(starts) * batch_size)
+        ragged = n_done - n_done // batch_size * batch_size
+        return acc[0, 0] / batch_size + (acc[1, 0] / ragged if ragged else 0.0)
     try:
         for k, s in enumerate(starts):
             e = min(s + batch_size, n)

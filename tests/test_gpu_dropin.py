@@ -614,6 +614,37 @@ def test_reference_stream_dropout_run_matches_the_reference(data_root, golden, d
         assert rel_err(uw, g["user_w"]) <= 5e-5 and rel_err(iw, g["item_w"]) <= 5e-5
 
 
+@pytest.mark.parametrize("dropout", [None, (0.3, "philox", 11)])
+def test_native_epoch_loop_equals_the_python_loop(data_root, dropout):
+    """trainer.train_epoch issues the whole epoch as ONE native call (spex_lightgcn_epoch_bce_f32: batch k = samples [kB, (k+1)B) of
+    the shuffled, device-resident epoch through the one-call step — Train() of main_rec.py:30-37) where nothing has to happen on the
+    host between two steps; asking for per-step losses keeps the Python loop around the one-call step.  Same batches, same masks
+    (the sampled edge-dropout stream is keyed by (seed, step) in the kernel), same arithmetic: 300 steps + a ragged tail agree in
+    the loss sum and the trained table to the float atomics' reordering."""
+    import utility1.dataloader as dl
+    from spex_amd.trainer import LightGCNStepper, train_epoch
+    extra = [] if dropout is None else ["--dropout", "1", "--keepprob", str(dropout[0])]
+    out = []
+    for native in (True, False):
+        args, dataset, net = build("epinion2", data_root, extra)
+        td = dl.LightTrainData(dataset.rec_train_data, dataset.m_item, dataset.train_mat)
+        st = LightGCNStepper(net.Graph, net.flat_table(), net.num_users + 1, n_layers=net.n_layers, lr=args.lr,
+                             graph_t=net._transposed() if dropout is not None else None)
+        per_step = None if native else []
+        total = train_epoch(st, td, edge_dropout=dropout, max_steps=300, step_losses=per_step).item()
+        # a short "epoch" with a ragged last batch: 3 full batches + 77 samples
+        class _Tail:
+            users_fill, items_fill, labels_fill_np = td.users_fill[:845], td.items_fill[:845], td.labels_fill_np[:845]
+            def __len__(self):
+                return 845
+        total2 = train_epoch(st, _Tail(), resample=False, edge_dropout=dropout, step_losses=None if native else []).item()
+        assert st.t == 304 and getattr(st.graph, "mask_mode", 0) == 0
+        out.append((total, total2, st.E0.detach().cpu().numpy().copy()))
+    (a1, a2, Ea), (b1, b2, Eb) = out
+    assert abs(a1 - b1) <= 2e-6 * abs(b1) and abs(a2 - b2) <= 2e-6 * abs(b2), (a1, b1, a2, b2)
+    assert rel_err(Ea, Eb) <= 2e-5
+
+
 @pytest.mark.parametrize("L", [2, 4])
 def test_two_and_four_layer_runs_match_the_reference(data_root, golden, L):
     """The reference at another depth (`main_rec.py --layer 2` / `--layer 4`, lg_parser.py:10; oracle/gen_golden.py --stage
