@@ -266,8 +266,51 @@ def edge_dropout_mask(graph, keep_prob, stream, seed=0, step=0):
     return (2, None, float(keep_prob), (int(seed) << 32) | (int(step) & 0xFFFFFFFF))
 
 
+def epoch_arrays(train_data, resample=True):
+    """One epoch's samples as the reference's loop would meet them (main_rec.py:26-31): negatives drawn by `train_data.ng_sample()`
+    (NumPy's global stream), then the DataLoader's shuffle (torch's global stream) applied — three host arrays (users, items, labels)."""
+    if resample:
+        train_data.ng_sample()
+    order = dataloader_epoch_order(len(train_data)).numpy()
+    return train_data.users_fill[order], train_data.items_fill[order], train_data.labels_fill_np[order]
+
+
+def train_epochs(stepper, train_data, n_epochs, batch_size=256, edge_dropout=None, after_epoch=None):
+    """n_epochs x train_epoch with the NEXT epoch's negatives and shuffle prepared on a second host thread while the GPU trains the
+    current one (an Epinion2 epoch: 0.14 s of sampling beside 0.38 s of steps — the native epoch call releases the GIL, and the
+    sampler's NumPy / torch generators are touched by that thread alone meanwhile, in the order a sequential loop would touch them:
+    same negatives, same shuffles, same run).  after_epoch(epoch, loss_sum_tensor) runs between epochs (evaluation: the reference's
+    Test() draws no random numbers — a callback that does would see them drawn AFTER the next epoch's).  Returns the per-epoch loss
+    sums (main_rec.py:36)."""
+    import threading
+    nxt = epoch_arrays(train_data)
+    totals = []
+    for ep in range(n_epochs):
+        arrays, box, th = nxt, {}, None
+        if ep + 1 < n_epochs:
+            def work():
+                try:
+                    box["v"] = epoch_arrays(train_data)
+                except BaseException as e:       # noqa: BLE001 — re-raised on the caller's thread
+                    box["e"] = e
+            th = threading.Thread(target=work)
+            th.start()
+        try:
+            total = train_epoch(stepper, train_data, batch_size=batch_size, edge_dropout=edge_dropout, arrays=arrays)
+        finally:
+            if th is not None:
+                th.join()
+        if "e" in box:
+            raise box["e"]
+        nxt = box.get("v")
+        totals.append(total)
+        if after_epoch is not None:
+            after_epoch(ep, total)
+    return [float(t) for t in totals]
+
+
 def train_epoch(stepper, train_data, batch_size=256, resample=True, pause_gc=True, edge_dropout=None, max_steps=None,
-                step_losses=None):
+                step_losses=None, arrays=None):
     """Train() of main_rec.py:25-38 without the per-step host work of its DataLoader loop: negatives are drawn like the
     reference's (`train_data.ng_sample()`, NumPy global RNG), the epoch's sample order is the DataLoader's own
     (dataloader_epoch_order), the whole shuffled epoch is moved to the device once, and every batch is one
@@ -276,18 +319,17 @@ def train_epoch(stepper, train_data, batch_size=256, resample=True, pause_gc=Tru
     edge_dropout: None, or (keep_prob, stream[, seed]) for `--dropout 1 --keepprob p` (README.md:119-123): a fresh mask per
     step (edge_dropout_mask) on the stepper's graph and graph_t — which must then be the transposed handle carrying the edge-id
     permutation, since the masked operator is not symmetric.  max_steps: stop after that many batches; step_losses: a list that
-    receives every step's mean loss (synchronises per step: a validation aid)."""
-    if resample:
-        train_data.ng_sample()
-    n = len(train_data)
-    order = dataloader_epoch_order(n).numpy()
+    receives every step's mean loss (synchronises per step: a validation aid).  arrays: the epoch's (users, items, labels) host arrays
+    already sampled and shuffled (epoch_arrays) — train_epochs prepares the next epoch's while this one runs."""
+    users_h, items_h, labels_h = arrays if arrays is not None else epoch_arrays(train_data, resample)
+    n = len(users_h)
     if edge_dropout is not None and stepper.graph_t is stepper.graph:
         raise ValueError("train_epoch(edge_dropout=...): the stepper needs graph_t = the transposed handle with the edge-id "
                          "permutation (LightGCN._transposed()): a masked adjacency is not symmetric")
     dev = stepper.E0.device
-    users = torch.from_numpy(train_data.users_fill[order]).to(dev)
-    items = torch.from_numpy(train_data.items_fill[order]).to(dev)
-    labels = torch.from_numpy(train_data.labels_fill_np[order]).to(device=dev, dtype=torch.float32)
+    users = torch.from_numpy(users_h).to(dev)
+    items = torch.from_numpy(items_h).to(dev)
+    labels = torch.from_numpy(labels_h).to(device=dev, dtype=torch.float32)
     # A full (generation-2) collection of Python's cyclic GC walks every object torch / scipy / pandas created at import:
     # ~40 ms, i.e. ~400 steps' worth of launches, whenever it triggers inside the loop (tools/stall_probe.py).  The loop
     # creates no reference cycles: pause the collector for its duration.

@@ -645,6 +645,42 @@ def test_native_epoch_loop_equals_the_python_loop(data_root, dropout):
     assert rel_err(Ea, Eb) <= 2e-5
 
 
+def test_train_epochs_prepares_the_next_epoch_beside_the_current_one(data_root):
+    """trainer.train_epochs: the next epoch's negatives (LightTrainData.ng_sample, NumPy's global stream) and shuffle (the DataLoader's
+    order, torch's global stream) are drawn on a second host thread while the native epoch call trains the current one — in the order a
+    sequential loop draws them (main_rec.py:25-37), so two epochs of 150 steps equal two sequential train_epoch calls: loss sums and
+    the trained table to the float atomics' reordering."""
+    import utility1.dataloader as dl
+    from spex_amd.trainer import LightGCNStepper, train_epoch, train_epochs
+
+    class _Short:            # the first 150 batches of the real training data (a whole epoch is 4 906)
+        def __init__(self, td):
+            self.td = td
+        def ng_sample(self):
+            self.td.ng_sample()
+        def __len__(self):
+            return 150 * 256
+        users_fill = property(lambda self: self.td.users_fill[: 2 * len(self)])
+        items_fill = property(lambda self: self.td.items_fill[: 2 * len(self)])
+        labels_fill_np = property(lambda self: self.td.labels_fill_np[: 2 * len(self)])
+    out = []
+    for overlapped in (True, False):
+        args, dataset, net = build("epinion2", data_root)
+        td = _Short(dl.LightTrainData(dataset.rec_train_data, dataset.m_item, dataset.train_mat))
+        st = LightGCNStepper(net.Graph, net.flat_table(), net.num_users + 1, n_layers=net.n_layers, lr=args.lr)
+        if overlapped:
+            seen = []
+            totals = train_epochs(st, td, 2, after_epoch=lambda ep, t: seen.append(ep))
+            assert seen == [0, 1]
+        else:
+            totals = [train_epoch(st, td).item() for _ in range(2)]
+        assert st.t == 300
+        out.append((totals, st.E0.detach().cpu().numpy().copy()))
+    (ta, Ea), (tb, Eb) = out
+    assert np.abs(np.asarray(ta) - np.asarray(tb)).max() <= 2e-6 * max(tb), (ta, tb)
+    assert rel_err(Ea, Eb) <= 2e-5
+
+
 @pytest.mark.parametrize("L", [2, 4])
 def test_two_and_four_layer_runs_match_the_reference(data_root, golden, L):
     """The reference at another depth (`main_rec.py --layer 2` / `--layer 4`, lg_parser.py:10; oracle/gen_golden.py --stage

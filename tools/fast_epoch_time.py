@@ -29,3 +29,12 @@ for ep in range(3):
     t3 = time.perf_counter()
     print("epoch %d: sample %.2f s, train %.2f s (%d steps, %.0f us/step), test %.2f s, loss %.2f HR@10 %.4f"
           % (ep, t1 - t0, t2 - t1, (len(td) + 255) // 256, (t2 - t1) / ((len(td) + 255) // 256) * 1e6, t3 - t2, loss, ret["recall"][0]))
+
+# ---- the same three epochs with the next epoch's sampling and shuffle prepared on a second host thread beside the GPU (train_epochs)
+from spex_amd.trainer import train_epochs
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+tot = train_epochs(st, td, 3)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print("train_epochs, 3 epochs with overlapped sampling: %.2f s per epoch (sequential: sample + train above); losses %s" % (dt / 3, ["%.2f" % t for t in tot]))
