@@ -552,3 +552,68 @@ def test_packer_lays_hubs_out_in_groups_the_kernel_can_fold(shape):
             slot += 1
         assert left_entries == 0
     assert pos >= len(tasks) > pos - 16
+
+
+@pytest.mark.parametrize("edge_ids", [False, True])
+def test_partition_push_structure_is_the_block_of_the_transpose_read_by_column(edge_ids):
+    """Host logic of the partitioned fast path (spex_amd/dist.py: PartitionedLightGCN.push_graph, no GPU): the structure the exchange-free
+    first backward product walks is the transpose of the rank's block of A^T — row p (a position of the padded global layout) holds
+    exactly the entries A[g(p), c] for the columns c the rank owns, with LOCAL column indices, the entries' values and, under edge
+    dropout (edge_ids=True), the index of the entry of A each came from (so that A, A^T and the push drop the same edges:
+    utility1/model.py:46-64).  Checked entry by entry on a NON-symmetric matrix with an uneven 3-way partition."""
+    import types
+    from spex_amd.dist import PartitionedLightGCN
+    from spex_amd.graph import csr_transpose
+    rng = np.random.default_rng(4)
+    n = 57
+    dense = (rng.random((n, n)) < 0.15) * rng.uniform(0.1, 1.0, (n, n))
+    dense[5, :] = rng.uniform(0.1, 1.0, n)                                   # a full row and a full column
+    dense[:, 9] = rng.uniform(0.1, 1.0, n)
+    dense = dense.astype(np.float32)
+    rowptr = np.zeros(n + 1, np.int32)
+    col, val = [], []
+    for r in range(n):
+        nz = np.flatnonzero(dense[r])
+        col.extend(nz); val.extend(dense[r, nz]); rowptr[r + 1] = len(col)
+    col, val = np.asarray(col, np.int32), np.asarray(val, np.float32)
+    made = []
+
+    def factory(rp, c, v, n_cols, edge_id=None):
+        g = types.SimpleNamespace(host=(np.asarray(rp), np.asarray(c), np.asarray(v)), n_cols=n_cols, n_rows=len(rp) - 1, edge_id=edge_id,
+                                  masks=[], set_edge_mask=lambda *a: g.masks.append(a))
+        made.append(g)
+        return g
+    bounds = np.array([0, 11, 40, n])
+    world, rank = 3, 1
+    t_csr = csr_transpose(rowptr, col, val, n)
+    P = PartitionedLightGCN(rowptr, col, val, 20, 3, 64, rank, world, factory, "cpu", t_csr=t_csr, bounds=bounds, edge_ids=edge_ids)
+    if edge_ids:
+        P.set_edge_mask(2, None, 0.3, 77)                                    # set BEFORE the push structure exists: re-applied at creation
+    push = P.push_graph()
+    assert push is P.push_graph() and push.n_cols == P.n_local == 29 and push.n_rows == P.part.n_padded
+    prp, pc, pv = push.host
+    pos_of = P.part.to_padded(np.arange(n))                                  # global row -> padded position
+    seen = 0
+    entry_of = {(int(r), int(c)): k for r in range(n) for k, c in zip(range(rowptr[r], rowptr[r + 1]), col[rowptr[r]:rowptr[r + 1]])}
+    for g_row in range(n):
+        p = int(pos_of[g_row])
+        cols_local = pc[prp[p]:prp[p + 1]]
+        want = [c for c in col[rowptr[g_row]:rowptr[g_row + 1]] if bounds[rank] <= c < bounds[rank + 1]]
+        assert [int(c) + int(bounds[rank]) for c in cols_local] == [int(c) for c in want], g_row     # ascending, local indices
+        for k, c in zip(range(prp[p], prp[p + 1]), cols_local):
+            gc = int(c) + int(bounds[rank])
+            assert pv[k] == dense[g_row, gc]
+            if edge_ids:
+                assert int(push.edge_id[k]) == entry_of[(g_row, gc)]
+            seen += 1
+    padded_rows = set(int(x) for x in pos_of)
+    for p in range(P.part.n_padded):                                         # the slots' padding positions hold nothing
+        if p not in padded_rows:
+            assert prp[p + 1] == prp[p]
+    assert seen == len(pc) == int((dense[:, bounds[rank]:bounds[rank + 1]] != 0).sum())
+    if edge_ids:
+        assert push.masks == [(2, None, 0.3, 77)] and P.graph.masks[-1] == (2, None, 0.3, 77) and P.graph_t.masks[-1] == (2, None, 0.3, 77)
+        P.set_edge_mask(0)
+        assert push.masks[-1][0] == 0
+    else:
+        assert push.edge_id is None
