@@ -617,3 +617,46 @@ def test_partition_push_structure_is_the_block_of_the_transpose_read_by_column(e
         assert push.masks[-1][0] == 0
     else:
         assert push.edge_id is None
+
+
+def test_train_epochs_draws_the_generators_like_a_sequential_loop():
+    """Host logic of trainer.train_epochs (no GPU: a recording stand-in for the stepper): the next epoch's negatives (the train data's
+    ng_sample: NumPy's global generator) and shuffle (dataloader_epoch_order: torch's global generator) are drawn on a second thread
+    while the current epoch is being issued — and must come out exactly as a sequential `ng_sample(); train_epoch()` loop draws them
+    (main_rec.py:25-31): the same batches in the same order, epoch after epoch."""
+    from spex_amd.trainer import train_epoch, train_epochs
+
+    class Data:
+        def __init__(self):
+            self.n = 1000
+        def ng_sample(self):
+            self.users_fill = np.random.randint(0, 50, self.n).astype(np.int64)
+            self.items_fill = np.random.randint(0, 70, self.n).astype(np.int64)
+            self.labels_fill_np = (np.random.random(self.n) < 0.2).astype(np.float32)
+        def __len__(self):
+            return self.n
+
+    class Recorder:
+        def __init__(self):
+            self.E0 = torch.zeros(1)
+            self.graph = self.graph_t = None
+            self.seen = []
+        def _one_call_ok(self, *a):
+            return False                                     # (no native epoch on the CPU: the Python loop around step_bce)
+        def step_bce(self, users, items, labels, loss_acc=None, batch_rows_only=False):
+            self.seen.append((users.numpy().copy(), items.numpy().copy(), labels.numpy().copy()))
+            loss_acc += float(len(users))
+    runs = []
+    for overlapped in (True, False):
+        np.random.seed(5); torch.manual_seed(5)
+        rec, td = Recorder(), Data()
+        if overlapped:
+            totals = train_epochs(rec, td, 3, batch_size=256)
+        else:
+            totals = [float(train_epoch(rec, td, batch_size=256)) for _ in range(3)]
+        runs.append((rec.seen, totals))
+    (a, ta), (b, tb) = runs
+    assert len(a) == len(b) == 3 * 4 and ta == tb
+    for x, y in zip(a, b):
+        assert all(np.array_equal(p, q) for p, q in zip(x, y))
+    assert not np.array_equal(a[0][0], a[4][0])                                       # (the epochs do differ)
