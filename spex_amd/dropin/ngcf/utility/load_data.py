@@ -44,6 +44,136 @@ def train_sample(u, hu, ai):
     return [[u] * (n_neg + len(pos)), items, [0] * n_neg + [1] * len(pos)]
 
 
+# ------------------------------------------------------------------------------------------------------------------------------
+# train_sample() for a whole epoch WITHOUT a Python-level draw per negative (0.9 s per Epinion2 epoch — five times the GPU time of the
+# epoch's 4 700 training steps).  What `random.sample(tuple(all_items - set(pos)), 5 |pos|)` does on CPython 3.10 (Lib/random.py):
+#   * the population: the set difference iterates in ascending item order (small ints hash to themselves and the result's table is
+#     larger than the largest item) — checked on a probe below, not assumed;
+#   * n > setsize (= 21 + 4 ** ceil(log(3k, 4)) for k > 5): k times `j = randbelow(n)`, redrawn while j was selected before;
+#     randbelow(n) = getrandbits(n.bit_length()) redrawn while >= n;  getrandbits(b <= 32) = one MT19937 output >> (32 - b).
+#     So the user's negatives are the first k DISTINCT values < n of the stream's outputs >> (32 - b): one vectorised pass;
+#   * n <= setsize (users with more than ~270 items; 63 of Epinion2's 3 185): the pool-swap form, whose threshold changes every draw —
+#     replayed draw by draw on the same stream.
+# The stream is NumPy's MT19937 started from `random.getstate()` (the same generator, the same state layout); afterwards `random` is
+# left exactly where a draw-by-draw run would have left it.
+_MT_BLOCK = 1 << 18
+
+
+def _blocked_replay_applies(all_items):
+    import sys
+    if sys.version_info >= (3, 11) or not isinstance(all_items, set) or not all_items:
+        return False                        # (3.11 removed random.sample(set); its tuple(set) order is still probed below)
+    n = len(all_items)
+    if n >= (1 << 31) or all_items != set(range(n)):
+        return False
+    probe = tuple(all_items - {0, n // 3, n - 1})
+    return list(probe) == sorted(probe)     # the population's order, as the replay takes it
+
+
+class _PyMTStream:
+    """The outputs `random`'s generator is about to produce, block by block, with the generator itself untouched until sync()."""
+
+    def __init__(self):
+        st = random.getstate()
+        self._gauss = st[2]
+        self._bg = np.random.MT19937()
+        self._bg.state = {"bit_generator": "MT19937", "state": {"key": np.array(st[1][:-1], dtype=np.uint32), "pos": int(st[1][-1])}}
+        self._next_block()
+
+    def _next_block(self):
+        self._start = self._bg.state                                  # (a dict holding its own copy of the key)
+        self.buf = self._bg.random_raw(_MT_BLOCK).astype(np.uint32)
+        self.cur = 0
+
+    def take(self, m):
+        """The next m outputs WITHOUT consuming them (may cross into a new block: the unconsumed tail is carried over)."""
+        while self.cur + m > len(self.buf):
+            tail = self.buf[self.cur:]
+            # restart the bookkeeping at the first unconsumed output: state at block start advanced by `cur`
+            bg = np.random.MT19937(); bg.state = self._start
+            if self.cur:
+                bg.random_raw(self.cur)
+            self._start = bg.state
+            self.buf = np.concatenate([tail, self._bg.random_raw(_MT_BLOCK).astype(np.uint32)])
+            self.cur = 0
+        return self.buf[self.cur: self.cur + m]
+
+    def consume(self, m):
+        self.cur += m
+
+    def sync(self):
+        """Put `random` where the stream stands."""
+        bg = np.random.MT19937(); bg.state = self._start
+        if self.cur:
+            bg.random_raw(self.cur)
+        st = bg.state["state"]
+        random.setstate((3, tuple(int(x) for x in st["key"]) + (int(st["pos"]),), self._gauss))
+
+
+def _sample_epoch_blocked(users, train_items, n_items):
+    from math import ceil, log
+    stream = _PyMTStream()
+    mask = np.ones(n_items, dtype=bool)
+    out_u, out_v, out_r = [], [], []
+    for u in users:
+        pos = train_items[u]
+        k = 5 * len(pos)
+        pos_arr = np.asarray(pos, dtype=np.int64)
+        mask[pos_arr] = False
+        cand = np.flatnonzero(mask)                                   # all items - positives, ascending
+        mask[pos_arr] = True
+        n = len(cand)
+        if k > n:
+            raise ValueError("Sample larger than population or is negative")      # (random.sample's own error)
+        setsize = 21 + (4 ** ceil(log(k * 3, 4)) if k > 5 else 0)
+        if n <= setsize:
+            # the pool-swap form, draw by draw on the stream (the threshold n - i changes with every draw): j = randbelow(n - i),
+            # result[i] = pool[j], pool[j] = pool[n - i - 1]
+            pool = cand.tolist()
+            neg = [0] * k
+            m = 2 * k + 64
+            w = stream.take(m).tolist()
+            p_ = 0
+            for i in range(k):
+                t = n - i
+                sh = 32 - t.bit_length()
+                while True:
+                    if p_ >= m:
+                        m *= 2
+                        w = stream.take(m).tolist()
+                    r = w[p_] >> sh
+                    p_ += 1
+                    if r < t:
+                        break
+                neg[i] = pool[r]
+                pool[r] = pool[t - 1]
+            stream.consume(p_)
+            neg = np.asarray(neg, dtype=np.int64)
+        else:
+            shift = 32 - int(n).bit_length()
+            m = k + (k >> 1) + 64
+            while True:
+                r = stream.take(m) >> np.uint32(shift)
+                ok = np.flatnonzero(r < n)
+                vals = r[ok]
+                _, first = np.unique(vals, return_index=True)          # first occurrence of every value among the accepted draws
+                if len(first) >= k:
+                    first.sort()
+                    first = first[:k]
+                    neg = cand[vals[first].astype(np.int64)]
+                    stream.consume(int(ok[first[-1]]) + 1)
+                    break
+                m *= 2
+        out_u.append(np.full(k + len(pos), u, dtype=np.int64))
+        out_v.append(neg); out_v.append(pos_arr)
+        r_ = np.zeros(k + len(pos), dtype=np.float32); r_[k:] = 1.0
+        out_r.append(r_)
+    stream.sync()
+    if not out_u:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.float32)
+    return np.concatenate(out_u), np.concatenate(out_v), np.concatenate(out_r)
+
+
 class Data(object):
     def __init__(self, path, batch_size):
         self.path, self.batch_size = path, batch_size
@@ -113,11 +243,15 @@ class Data(object):
             free = list(set(range(self.n_items)) - set(its))
             self.neg_pools[u] = [random.choice(free) for _ in range(100)]
 
-    def sample_epoch(self):
+    def sample_epoch(self, fast=True):
         """The epoch's (users, items, labels) as int64 / int64 / float32 arrays, in the reference's order: users in
-        file order, whole blocks of 256 users only, per user the negatives then the positives."""
+        file order, whole blocks of 256 users only, per user the negatives then the positives.
+        fast: the blocked replay of the `random` stream (_sample_epoch_blocked: the same negatives, the same generator state
+        afterwards, ~6 x faster); False — or a Python whose random.sample / set order the replay does not know — the loop below."""
         users = list(self.train_items.keys())
         users = users[: len(users) // TRAIN_USER_BLOCK * TRAIN_USER_BLOCK]
+        if fast and _blocked_replay_applies(self.all_items):
+            return _sample_epoch_blocked(users, self.train_items, len(self.all_items))
         us, vs, rs = [], [], []
         for u in users:
             a, b, c = train_sample(u, self.train_items, self.all_items)

@@ -660,3 +660,43 @@ def test_train_epochs_draws_the_generators_like_a_sequential_loop():
     for x, y in zip(a, b):
         assert all(np.array_equal(p, q) for p, q in zip(x, y))
     assert not np.array_equal(a[0][0], a[4][0])                                       # (the epochs do differ)
+
+
+def test_ngcf_blocked_sampler_replay_is_random_sample_draw_for_draw(epinion2):
+    """NGCF's epoch sampler (NGCF_SPEX/code/utility/load_data.py:13-23,176-195: per user `random.sample(all_items - positives,
+    5 |positives|)`) replayed in blocks on the generator's own output stream (dropin/ngcf/utility/load_data.py: _sample_epoch_blocked:
+    the selection-set form as one vectorised pass per user, the pool-swap form of the heavy users draw by draw) against the
+    draw-by-draw loop: on Epinion2 (3 072 users in whole blocks of 256, 63 of them on the pool-swap form) the same 1.2 M samples, and
+    `random` left in the same state — so the NEXT epoch is the same too; plus the tiny cases (k <= 5, a user with one item)."""
+    import random
+    from collections import defaultdict
+    import spex_amd.dropin.ngcf.utility.load_data as ld
+    tr = epinion2["train"]
+    ti = defaultdict(list)
+    for u, i in tr:
+        ti[int(u)].append(int(i))
+    ti = dict(ti)
+    n_items = int(tr[:, 1].max()) + 1
+    ai = set(range(n_items))
+    users = list(ti.keys())
+    users = users[: len(users) // 256 * 256]
+    assert ld._blocked_replay_applies(ai)
+    random.seed(2020)
+    vs = []
+    for u in users:
+        vs.extend(ld.train_sample(u, ti, ai)[1])
+    state_slow = random.getstate()
+    random.seed(2020)
+    fu, fv, fr = ld._sample_epoch_blocked(users, ti, n_items)
+    assert np.array_equal(np.asarray(vs), fv) and random.getstate() == state_slow
+    assert len(fu) == len(fv) == len(fr) == 6 * sum(len(ti[u]) for u in users) and fr.sum() == sum(len(ti[u]) for u in users)
+    small = {0: [1], 1: [0, 2, 3], 2: list(range(0, 40, 2)), 3: [5]}
+    random.seed(3)
+    want = []
+    for u in small:
+        want.extend(ld.train_sample(u, small, set(range(120)))[1])
+    st = random.getstate()
+    random.seed(3)
+    got = ld._sample_epoch_blocked(list(small), small, 120)
+    assert np.array_equal(np.asarray(want), got[1]) and random.getstate() == st
+    assert not ld._blocked_replay_applies({1, 2, 5}) and not ld._blocked_replay_applies(list(range(9)))     # (not 0 .. n-1 as a set: the loop)
