@@ -726,6 +726,11 @@ typedef struct spex_ngcf_step {
 int spex_step_events_release(void **ev_fork, void **ev_join);   /* destroys the pair a descriptor holds (no step in flight) */
 int spex_ngcf_step_bce_f32(spex_ngcf_step_t *step, const int64_t *users, const int64_t *items, const float *labels, int32_t B,
                            float *loss_sum, void *stream);
+/* train() of NGCF_SPEX/code/main_rec.py:116-131 over a whole pre-shuffled, device-resident epoch as ONE call: batch k = samples
+ * [k B, min((k+1) B, n)) through spex_ngcf_step_bce_f32 (at most max_steps batches; < 0: all); *loss_full / *loss_ragged as in
+ * spex_lightgcn_epoch_bce_f32. */
+int spex_ngcf_epoch_bce_f32(spex_ngcf_step_t *step, const int64_t *users, const int64_t *items, const float *labels, int64_t n, int32_t B,
+                            int64_t max_steps, float *loss_full, float *loss_ragged, void *stream);
 
 /* NGCF with MORE than one layer (`--layer_size [64,64,..]`, NGCF_SPEX/code/ngcf_parser.py:12; the layer loop of main_rec.py:71-93) —
  * the training step as one call of the library's own launches, L >= 2 layers of width 64:

@@ -142,6 +142,23 @@ extern "C" int spex_lightgcn_epoch_bce_f32(spex_lightgcn_step_t *s, const int64_
     return rc;
 }
 
+// train() of NGCF_SPEX/code/main_rec.py:116-131 over a whole pre-shuffled, device-resident epoch as ONE call: batch k = samples
+// [k B, min((k+1) B, n)) through spex_ngcf_step_bce_f32 (the default one-layer model; the step advances its own Adam and dropout
+// counters) — the host issues the launches and nothing else.  Loss sums as in spex_lightgcn_epoch_bce_f32.
+extern "C" int spex_ngcf_epoch_bce_f32(spex_ngcf_step_t *s, const int64_t *users, const int64_t *items, const float *labels, int64_t n,
+                                       int32_t B, int64_t max_steps, float *loss_full, float *loss_ragged, void *stream)
+{
+    SPEX_CHECK_ARG(s && users && items && labels && loss_full && loss_ragged && n >= 0 && B >= 1,
+                   "spex_ngcf_epoch_bce_f32: NULL pointer, n < 0 or B < 1");
+    int rc = SPEX_OK;
+    int64_t k = 0;
+    for (int64_t b0 = 0; b0 < n && rc == SPEX_OK && (max_steps < 0 || k < max_steps); b0 += B, ++k) {
+        const int32_t nb = (int32_t)(n - b0 < B ? n - b0 : B);
+        rc = spex_ngcf_step_bce_f32(s, users + b0, items + b0, labels + b0, nb, nb == B ? loss_full : loss_ragged, stream);
+    }
+    return rc;
+}
+
 // The north-star step — 3-layer propagation + fused BPR-SGD over a batch of triples — as ONE call of L + 1 launches with the
 // layer mean left to the BPR kernel: layer 1 in the running-sum form (sum1 = E^0 + E^1), the later layers PLAIN, and the fused
 // gather + dot + sigmoid + SGD kernel forms ((sum1 + E^2) + E^3) / (L + 1) at its triples' rows only — the rows of the propagated

@@ -59,15 +59,22 @@ def train_sample(u, hu, ai):
 _MT_BLOCK = 1 << 18
 
 
-def _blocked_replay_applies(all_items):
+def _blocked_replay_applies(all_items, train_items):
+    """Does `tuple(all_items - set(pos))` iterate in ascending item order for every user?  Small non-negative ints hash to themselves,
+    so a set iterates ascending as long as its hash table has more slots than its largest member — and the table of the difference
+    grows with the number of members: the user with the MOST positives has the smallest one.  That user's tuple is checked, not
+    assumed; anything unexpected (another Python, other item types) keeps the draw-by-draw loop."""
     import sys
-    if sys.version_info >= (3, 11) or not isinstance(all_items, set) or not all_items:
-        return False                        # (3.11 removed random.sample(set); its tuple(set) order is still probed below)
-    n = len(all_items)
-    if n >= (1 << 31) or all_items != set(range(n)):
+    if sys.version_info >= (3, 11) or not isinstance(all_items, set) or not all_items or not train_items:
         return False
-    probe = tuple(all_items - {0, n // 3, n - 1})
-    return list(probe) == sorted(probe)     # the population's order, as the replay takes it
+    try:
+        if min(all_items) < 0 or max(all_items) >= (1 << 31):
+            return False
+        heavy = max(train_items, key=lambda u: len(train_items[u]))
+        probe = tuple(all_items - set(train_items[heavy]))
+    except TypeError:
+        return False
+    return all(type(x) is int for x in probe[:64]) and list(probe) == sorted(probe)
 
 
 class _PyMTStream:
@@ -110,26 +117,38 @@ class _PyMTStream:
         random.setstate((3, tuple(int(x) for x in st["key"]) + (int(st["pos"]),), self._gauss))
 
 
-def _sample_epoch_blocked(users, train_items, n_items):
+def _sample_epoch_blocked(users, train_items, all_items):
     from math import ceil, log
     stream = _PyMTStream()
-    mask = np.ones(n_items, dtype=bool)
-    out_u, out_v, out_r = [], [], []
+    items_sorted = np.fromiter(sorted(all_items), dtype=np.int64, count=len(all_items))     # the population's order (ids may have gaps)
+    n_all = len(items_sorted)
+    dense = bool(n_all and items_sorted[-1] == n_all - 1)                # ids 0 .. n-1 without gaps: an item is its own rank
+    total = 6 * sum(len(train_items[u]) for u in users)
+    out_u, out_v, out_r = np.empty(total, np.int64), np.empty(total, np.int64), np.zeros(total, np.float32)
+    first_at = np.empty(n_all, dtype=np.int64)                           # scratch: where a rank was first seen among a user's draws
+    w_ = 0
     for u in users:
         pos = train_items[u]
-        k = 5 * len(pos)
+        n_pos = len(pos)
+        k = 5 * n_pos
         pos_arr = np.asarray(pos, dtype=np.int64)
-        mask[pos_arr] = False
-        cand = np.flatnonzero(mask)                                   # all items - positives, ascending
-        mask[pos_arr] = True
-        n = len(cand)
+        # the population — all items minus the user's, ascending — is never built: its j-th member is the item of rank
+        # j + #{positives' ranks <= that rank}
+        ranks = np.sort(pos_arr) if dense else np.searchsorted(items_sorted, np.sort(pos_arr))
+        p_adj = ranks - np.arange(n_pos)
+        if n_pos > 1 and (np.diff(p_adj) < 0).any():                     # (a positive listed twice: set(pos) has fewer members)
+            ranks = np.unique(ranks)
+            p_adj = ranks - np.arange(len(ranks))
+        n = n_all - len(p_adj)
         if k > n:
             raise ValueError("Sample larger than population or is negative")      # (random.sample's own error)
         setsize = 21 + (4 ** ceil(log(k * 3, 4)) if k > 5 else 0)
         if n <= setsize:
             # the pool-swap form, draw by draw on the stream (the threshold n - i changes with every draw): j = randbelow(n - i),
             # result[i] = pool[j], pool[j] = pool[n - i - 1]
-            pool = cand.tolist()
+            pool = np.arange(n)
+            pool = pool + np.searchsorted(p_adj, pool, side="right")
+            pool = (pool if dense else items_sorted[pool]).tolist()
             neg = [0] * k
             m = 2 * k + 64
             w = stream.take(m).tolist()
@@ -148,30 +167,31 @@ def _sample_epoch_blocked(users, train_items, n_items):
                 neg[i] = pool[r]
                 pool[r] = pool[t - 1]
             stream.consume(p_)
-            neg = np.asarray(neg, dtype=np.int64)
+            out_v[w_: w_ + k] = neg
         else:
             shift = 32 - int(n).bit_length()
             m = k + (k >> 1) + 64
             while True:
                 r = stream.take(m) >> np.uint32(shift)
                 ok = np.flatnonzero(r < n)
-                vals = r[ok]
-                _, first = np.unique(vals, return_index=True)          # first occurrence of every value among the accepted draws
-                if len(first) >= k:
-                    first.sort()
-                    first = first[:k]
-                    neg = cand[vals[first].astype(np.int64)]
-                    stream.consume(int(ok[first[-1]]) + 1)
+                vals = r[ok].astype(np.int64)
+                idx = np.arange(len(vals))
+                first_at[vals[::-1]] = idx[::-1]                        # (assigned back to front: the FIRST occurrence's index stays)
+                fresh = np.flatnonzero(first_at[vals] == idx)           # the accepted draws that are not repeats, in order
+                if len(fresh) >= k:
+                    fresh = fresh[:k]
+                    j = vals[fresh]
+                    j = j + np.searchsorted(p_adj, j, side="right")
+                    out_v[w_: w_ + k] = j if dense else items_sorted[j]
+                    stream.consume(int(ok[fresh[-1]]) + 1)
                     break
                 m *= 2
-        out_u.append(np.full(k + len(pos), u, dtype=np.int64))
-        out_v.append(neg); out_v.append(pos_arr)
-        r_ = np.zeros(k + len(pos), dtype=np.float32); r_[k:] = 1.0
-        out_r.append(r_)
+        out_u[w_: w_ + k + n_pos] = u
+        out_v[w_ + k: w_ + k + n_pos] = pos_arr
+        out_r[w_ + k: w_ + k + n_pos] = 1.0
+        w_ += k + n_pos
     stream.sync()
-    if not out_u:
-        return np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.float32)
-    return np.concatenate(out_u), np.concatenate(out_v), np.concatenate(out_r)
+    return out_u, out_v, out_r
 
 
 class Data(object):
@@ -250,8 +270,8 @@ class Data(object):
         afterwards, ~6 x faster); False — or a Python whose random.sample / set order the replay does not know — the loop below."""
         users = list(self.train_items.keys())
         users = users[: len(users) // TRAIN_USER_BLOCK * TRAIN_USER_BLOCK]
-        if fast and _blocked_replay_applies(self.all_items):
-            return _sample_epoch_blocked(users, self.train_items, len(self.all_items))
+        if fast and _blocked_replay_applies(self.all_items, self.train_items):
+            return _sample_epoch_blocked(users, self.train_items, self.all_items)
         us, vs, rs = [], [], []
         for u in users:
             a, b, c = train_sample(u, self.train_items, self.all_items)

@@ -12,6 +12,7 @@ synchronisation and no Python between kernels beyond the ctypes calls (capturabl
 import gc
 import os
 
+import numpy as np
 import torch
 
 from . import ops
@@ -533,13 +534,10 @@ def _ngcf_one_call_ok(users, items, labels):
             and users.numel() == items.numel() == labels.numel() and users.numel() >= 1)
 
 
-def _ngcf_step_one_call(self, users, items, labels, acc):
-    """The single-layer step as one library call (spex_ngcf_step_bce_f32): the same launches, issued from native code."""
-    import ctypes
+def _ngcf_prepare_desc(self, B):
+    """The single-layer one-call step's descriptor for batches of up to B samples (built once, refreshed per call)."""
     from . import _lib
-    from .graph import _bump, _launch
     m = self.model
-    B = users.numel()
     if self.g_side_c is None or self.g_side_c.shape[0] < 2 * B:
         dev, d = self.E0.device, self.E0.shape[1]
         self.g_slots = torch.zeros((2 * B, 2 * d), dtype=torch.float32, device=dev)
@@ -563,6 +561,35 @@ def _ngcf_step_one_call(self, users, items, labels, acc):
             self._desc.flags = _lib.STEP_DETERMINISTIC
     d = self._desc
     d.t, d.lr, d.dropout_step, d.seed, d.p_drop = self.t, self.lr, m.dropout_step, int(m.message_dropout_seed), float(m.mess_dropout[0])
+    return d
+
+
+def _ngcf_epoch(self, users, items, labels, batch_size, loss_full, loss_ragged, max_steps=None):
+    """A whole pre-shuffled, device-resident epoch of the single-layer model as ONE native call (spex_ngcf_epoch_bce_f32; train() of
+    NGCF_SPEX/code/main_rec.py:116-131): nothing but the steps' launches is issued by the host.  Counter-based message dropout only
+    (the reference-stream validation mode draws its noise on the host per step)."""
+    import ctypes
+    from .graph import _bump, _launch
+    m = self.model
+    if self.L != 1 or not self._one_call_ok(users[:1], items[:1], labels[:1]) \
+            or (getattr(self, "dropout_stream", getattr(m, "dropout_stream", "counter")) == "reference" and m.mess_dropout[0] > 0):
+        raise ValueError("NGCFStepper.epoch: the single-layer model with the counter-based dropout stream and contiguous int64 / fp32 device tensors")
+    d = _ngcf_prepare_desc(self, min(int(batch_size), users.numel()))
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    _launch(self.E0.device, "spex_ngcf_epoch_bce_f32", ctypes.byref(d), vp(users), vp(items), vp(labels), users.numel(), int(batch_size),
+            -1 if max_steps is None else int(max_steps), vp(loss_full), vp(loss_ragged))
+    self.t, m.dropout_step = d.t, d.dropout_step
+    _bump(self.E0, self.W, loss_full, loss_ragged)
+
+
+def _ngcf_step_one_call(self, users, items, labels, acc):
+    """The single-layer step as one library call (spex_ngcf_step_bce_f32): the same launches, issued from native code."""
+    import ctypes
+    from . import _lib
+    from .graph import _bump, _launch
+    m = self.model
+    B = users.numel()
+    d = _ngcf_prepare_desc(self, B)
     ref_stream = getattr(self, "dropout_stream", getattr(m, "dropout_stream", "counter")) == "reference" and m.mess_dropout[0] > 0
     if ref_stream:
         # validation mode: the step's message-dropout noise is the REFERENCE's — nn.Dropout on the [N, 64] layer output
@@ -628,10 +655,49 @@ def _ngcf_step_deep_one_call(self, users, items, labels, acc):
 NGCFStepper._one_call_ok = staticmethod(_ngcf_one_call_ok)
 NGCFStepper._step_deep_one_call = _ngcf_step_deep_one_call
 NGCFStepper._step_one_call = _ngcf_step_one_call
+NGCFStepper.epoch = _ngcf_epoch
 NGCFStepper.__del__ = _drop_desc
 
 
-def train_epoch_ngcf(stepper, data, batch_size=None, pause_gc=True, callbacks=None, step_losses=None, max_steps=None):
+def epoch_arrays_ngcf(data):
+    """One NGCF epoch's samples as the reference's loop meets them (main_rec.py:118-121): Data.sample_epoch (the `random` stream), then
+    the DataLoader's shuffle (torch's global stream) — three host arrays."""
+    us, vs, rs = data.sample_epoch()
+    order = dataloader_epoch_order(len(us)).numpy()
+    return us[order], vs[order], rs[order]
+
+
+def train_epochs_ngcf(stepper, data, n_epochs, batch_size=None, after_epoch=None):
+    """n_epochs x train_epoch_ngcf with the NEXT epoch's samples and shuffle prepared on a second host thread while the current epoch
+    runs as one native call (see train_epochs: same generators, same order of draws, same run).  Returns the per-epoch loss sums."""
+    import threading
+    nxt = epoch_arrays_ngcf(data)
+    totals = []
+    for ep in range(n_epochs):
+        arrays, box, th = nxt, {}, None
+        if ep + 1 < n_epochs:
+            def work():
+                try:
+                    box["v"] = epoch_arrays_ngcf(data)
+                except BaseException as e:       # noqa: BLE001 — re-raised on the caller's thread
+                    box["e"] = e
+            th = threading.Thread(target=work)
+            th.start()
+        try:
+            total = train_epoch_ngcf(stepper, data, batch_size=batch_size, arrays=arrays)
+        finally:
+            if th is not None:
+                th.join()
+        if "e" in box:
+            raise box["e"]
+        nxt = box.get("v")
+        totals.append(total)
+        if after_epoch is not None:
+            after_epoch(ep, total)
+    return [float(t) for t in totals]
+
+
+def train_epoch_ngcf(stepper, data, batch_size=None, pause_gc=True, callbacks=None, step_losses=None, max_steps=None, arrays=None):
     """train() of NGCF_SPEX/code/main_rec.py:116-131 without the per-step host work of its DataLoader loop: the epoch's
     samples are drawn like the reference's (Data.sample_epoch: `random` stream), the sample order is the DataLoader's own
     (dataloader_epoch_order: global torch RNG), the shuffled epoch is moved to the device once, and every batch is one
@@ -640,18 +706,30 @@ def train_epoch_ngcf(stepper, data, batch_size=None, pause_gc=True, callbacks=No
     model in training mode); step_losses: a list that receives every step's mean loss (synchronises per step); max_steps: stop
     after that many batches.  (stepper.dropout_stream = "reference": the message-dropout noise is the reference's own per-step
     draw from the global generator — a validation mode, see NGCFStepper.)"""
-    us, vs, rs = data.sample_epoch()
+    us, vs, rs = arrays if arrays is not None else epoch_arrays_ngcf(data)
     n = len(us)
     bs = batch_size or data.batch_size
-    order = dataloader_epoch_order(n).numpy()
     dev = stepper.E0.device
-    users, items = torch.from_numpy(us[order]).to(dev), torch.from_numpy(vs[order]).to(dev)
-    labels = torch.from_numpy(rs[order]).to(dev)
+    users, items = torch.from_numpy(np.ascontiguousarray(us)).to(dev), torch.from_numpy(np.ascontiguousarray(vs)).to(dev)
+    labels = torch.from_numpy(np.ascontiguousarray(rs)).to(dev)
     gc_was_on = pause_gc and gc.isenabled()
     if gc_was_on:
         gc.disable()
     n_full = n // bs * bs
     acc = torch.zeros(2, 1, dtype=torch.float32, device=dev)
+    m_ = stepper.model
+    native_ok = (not callbacks and step_losses is None and n > 0 and getattr(stepper, "L", 0) == 1 and hasattr(stepper, "epoch")
+                 and stepper._one_call_ok(users[:1], items[:1], labels[:1])
+                 and not (getattr(stepper, "dropout_stream", getattr(m_, "dropout_stream", "counter")) == "reference" and m_.mess_dropout[0] > 0))
+    if native_ok:
+        try:
+            stepper.epoch(users, items, labels, bs, acc[0], acc[1], max_steps=max_steps)
+        finally:
+            if gc_was_on:
+                gc.enable()
+        n_done = n if max_steps is None else min(n, int(max_steps) * bs)
+        ragged = n_done - n_done // bs * bs
+        return acc[0, 0] / bs + (acc[1, 0] / ragged if ragged else 0.0)
     try:
         for k, s in enumerate(range(0, n, bs)):
             if max_steps is not None and k >= max_steps:

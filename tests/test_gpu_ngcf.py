@@ -309,6 +309,39 @@ def test_ngcf_module_run_repeats_bit_for_bit_in_the_deterministic_mode(golden, n
         assert torch.equal(a[k], b[k]), k
 
 
+def test_native_ngcf_epoch_and_overlapped_sampling_equal_the_python_loop(golden, ngcf_data_root):
+    """trainer.train_epoch_ngcf issues the single-layer model's epoch as ONE native call (spex_ngcf_epoch_bce_f32: train() of
+    NGCF_SPEX/code/main_rec.py:116-131, batch after batch) where nothing has to happen on the host between two steps; asking for
+    per-step losses keeps the Python loop; trainer.train_epochs_ngcf prepares the next epoch's samples (Data.sample_epoch: the blocked
+    replay of the `random` stream) and shuffle on a second thread meanwhile.  Three epochs on the 300-user graph in the DETERMINISTIC
+    step, where a run is a pure function of its inputs: the three ways end in bit-identical parameters and loss sums."""
+    from spex_amd.dropin.ngcf.utility.load_data import Data
+    from spex_amd.ngcf import NGCF
+    from spex_amd.trainer import NGCFStepper, train_epoch_ngcf, train_epochs_ngcf
+    g = golden("ngcf_small_epochs")
+    out = []
+    for way in ("native", "python", "overlapped"):
+        torch.manual_seed(int(g["seed"])); random.seed(int(g["seed"])); np.random.seed(int(g["seed"]))
+        data = Data(path=ngcf_data_root + "small", batch_size=256)
+        _, norm, _ = data.get_adj_mat()
+        model = NGCF({"n_users": data.n_users, "n_items": data.n_items, "norm_adj": norm}, DEV,
+                     ngcf_args(mess_dropout=str([float(x) for x in g["mess_dropout"]]))).to(DEV)
+        model.message_dropout_seed = int(g["drop_seed"])
+        model.train()
+        st = NGCFStepper(model, lr=float(g["lr"]), deterministic=True)
+        if way == "overlapped":
+            totals = train_epochs_ngcf(st, data, 3)
+        else:
+            totals = [train_epoch_ngcf(st, data, step_losses=[] if way == "python" else None).item() for _ in range(3)]
+        assert st.t == int(g["n_steps"]) and model.dropout_step == int(g["n_steps"])
+        out.append((totals, [p.detach().clone() for p in model.parameters()]))
+        for ep in range(3):
+            assert abs(totals[ep] - g["losses"][ep]) <= 5e-5 * g["losses"][ep]
+    for totals, params in out[1:]:
+        assert np.allclose(totals, out[0][0], rtol=1e-6, atol=0)
+        assert all(torch.equal(a, b) for a, b in zip(params, out[0][1]))
+
+
 def test_on_device_ngcf_epochs_match_the_reference_small(golden, ngcf_data_root):
     """The same golden through the autograd-free loop: spex_amd.trainer.NGCFStepper (a fixed sequence of launches per
     step: SpMM, fused layer, scoring, fused layer backward, SpMM^T, two Adam passes) driven by train_epoch_ngcf (the

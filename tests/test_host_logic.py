@@ -680,14 +680,14 @@ def test_ngcf_blocked_sampler_replay_is_random_sample_draw_for_draw(epinion2):
     ai = set(range(n_items))
     users = list(ti.keys())
     users = users[: len(users) // 256 * 256]
-    assert ld._blocked_replay_applies(ai)
+    assert ld._blocked_replay_applies(ai, ti)
     random.seed(2020)
     vs = []
     for u in users:
         vs.extend(ld.train_sample(u, ti, ai)[1])
     state_slow = random.getstate()
     random.seed(2020)
-    fu, fv, fr = ld._sample_epoch_blocked(users, ti, n_items)
+    fu, fv, fr = ld._sample_epoch_blocked(users, ti, ai)
     assert np.array_equal(np.asarray(vs), fv) and random.getstate() == state_slow
     assert len(fu) == len(fv) == len(fr) == 6 * sum(len(ti[u]) for u in users) and fr.sum() == sum(len(ti[u]) for u in users)
     small = {0: [1], 1: [0, 2, 3], 2: list(range(0, 40, 2)), 3: [5]}
@@ -697,6 +697,22 @@ def test_ngcf_blocked_sampler_replay_is_random_sample_draw_for_draw(epinion2):
         want.extend(ld.train_sample(u, small, set(range(120)))[1])
     st = random.getstate()
     random.seed(3)
-    got = ld._sample_epoch_blocked(list(small), small, 120)
+    got = ld._sample_epoch_blocked(list(small), small, set(range(120)))
     assert np.array_equal(np.asarray(want), got[1]) and random.getstate() == st
-    assert not ld._blocked_replay_applies({1, 2, 5}) and not ld._blocked_replay_applies(list(range(9)))     # (not 0 .. n-1 as a set: the loop)
+    # item ids with GAPS, the set grown by updates as Data grows it (items seen in the training file), a positive listed twice
+    gappy = {0: [3, 40, 7], 1: [90, 3, 3, 55], 2: [7], 3: list(range(100, 160, 3))}
+    seen = set()
+    for its in gappy.values():
+        seen.update(its)
+    seen.update(range(200, 420, 2))
+    assert ld._blocked_replay_applies(seen, gappy)
+    random.seed(11)
+    want = []
+    for u in gappy:
+        want.extend(ld.train_sample(u, gappy, seen)[1])
+    st = random.getstate()
+    random.seed(11)
+    got = ld._sample_epoch_blocked(list(gappy), gappy, seen)
+    assert np.array_equal(np.asarray(want), got[1]) and random.getstate() == st
+    assert not ld._blocked_replay_applies(list(range(9)), small) and not ld._blocked_replay_applies({"a", "b"}, {0: ["a"]})   # (the loop)
+    assert not ld._blocked_replay_applies({1, 2, 3, 10 ** 6}, {0: [1]})          # an id beyond the set's table: it does not iterate ascending
