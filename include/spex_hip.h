@@ -828,6 +828,15 @@ typedef struct spex_dual_task_step {
 } spex_dual_task_step_t;
 int spex_dual_task_step_f32(spex_dual_task_step_t *step, const int64_t *users, const int64_t *items, const float *labels, int32_t B,
                             const int64_t *seq, const int64_t *seq_l, const int64_t *targets, int32_t T, void *stream);
+/* Train() of main_auto_expert_s.py:60-91 over a whole pre-shuffled, device-resident epoch as ONE call: batch k = samples
+ * [k B, min((k+1) B, n)) (at most max_steps batches; < 0: all) with the paths [path_off[k], path_off[k+1]) of the epoch's staged path
+ * arrays — seq [n_paths, path_len], seq_l, targets on the device, path_off a HOST array of n_batches + 1 ascending offsets (the
+ * reference selects each batch's paths with random.sample, :64-71: done up front on the host) — through spex_dual_task_step_f32; the
+ * losses accumulate in the descriptor's loss_acc.  keep_prob < 1: the rec branch's sampled edge mask, a fresh one per step, as in
+ * spex_lightgcn_epoch_bce_f32.  With SPEX_STEP_PIPELINED, finish with spex_dual_task_step_join. */
+int spex_dual_task_epoch_f32(spex_dual_task_step_t *step, const int64_t *users, const int64_t *items, const float *labels, int64_t n,
+                             int32_t B, int64_t max_steps, const int64_t *seq, const int64_t *seq_l, const int64_t *targets,
+                             const int64_t *path_off, float keep_prob, uint32_t drop_seed, void *stream);
 /* Orders everything a pipelined step left on side_stream in front of whatever is queued on `stream` next (a no-op otherwise). */
 int spex_dual_task_step_join(spex_dual_task_step_t *step, void *stream);
 

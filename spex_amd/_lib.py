@@ -116,6 +116,8 @@ SIGNATURES = {
     "spex_ngcf_step_bce_f32": (ctypes.c_int, [ctypes.c_void_p, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "spex_ngcf_epoch_bce_f32": (ctypes.c_int, [ctypes.c_void_p, c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp]),
     "spex_dual_task_step_f32": (ctypes.c_int, [ctypes.c_void_p, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp]),
+    "spex_dual_task_epoch_f32": (ctypes.c_int, [ctypes.c_void_p, c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_f32,
+                                                ctypes.c_uint32, c_vp]),
     "spex_dual_task_step_join": (ctypes.c_int, [ctypes.c_void_p, c_vp]),
     "spex_comm_unique_id": (ctypes.c_int, [c_vp]),
     "spex_comm_create": (ctypes.c_int, [c_i32, c_i32, c_vp, ctypes.POINTER(c_vp)]),

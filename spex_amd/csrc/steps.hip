@@ -569,3 +569,43 @@ extern "C" int spex_dual_task_step_f32(spex_dual_task_step_t *s, const int64_t *
     s->t += 1;
     return SPEX_OK;
 }
+
+// Train() of main_auto_expert_s.py:60-91 over a whole pre-shuffled, device-resident epoch as ONE call: batch k = samples [k B, (k+1) B)
+// with the paths [path_off[k], path_off[k+1]) of the epoch's staged path arrays (seq [*, path_len], seq_l, targets: the reference's
+// per-batch selection, made up front by the host) through spex_dual_task_step_f32.  Both losses accumulate in the descriptor's
+// loss_acc.  keep_prob < 1: the rec branch's sampled edge mask, a fresh one per step (as spex_lightgcn_epoch_bce_f32).
+extern "C" int spex_dual_task_epoch_f32(spex_dual_task_step_t *s, const int64_t *users, const int64_t *items, const float *labels, int64_t n,
+                                        int32_t B, int64_t max_steps, const int64_t *seq, const int64_t *seq_l, const int64_t *targets,
+                                        const int64_t *path_off, float keep_prob, uint32_t drop_seed, void *stream)
+{
+    SPEX_CHECK_ARG(s && s->graph && s->graph_t && users && items && labels && path_off && n >= 0 && B >= 1,
+                   "spex_dual_task_epoch_f32: NULL pointer, n < 0 or B < 1");
+    SPEX_CHECK_ARG(keep_prob > 0.0f && keep_prob <= 1.0f, "spex_dual_task_epoch_f32: keep_prob %g", keep_prob);
+    spex_graph *g = const_cast<spex_graph *>(s->graph), *gt = const_cast<spex_graph *>(s->graph_t);
+    const bool drop = keep_prob < 1.0f;
+    int rc = SPEX_OK;
+    int64_t k = 0;
+    for (int64_t b0 = 0; b0 < n && rc == SPEX_OK && (max_steps < 0 || k < max_steps); b0 += B, ++k) {
+        const int32_t nb = (int32_t)(n - b0 < B ? n - b0 : B);
+        const int64_t p0 = path_off[k], T = path_off[k + 1] - p0;
+        if (T < 0 || (T > 0 && !(seq && seq_l && targets))) {
+            spex::set_error("spex_dual_task_epoch_f32: batch %lld has %lld paths (offsets must ascend; path arrays must be given)", (long long)k,
+                            (long long)T);
+            rc = SPEX_ERR_INVALID;
+            break;
+        }
+        if (drop) {
+            const uint64_t seed = ((uint64_t)drop_seed << 32) | (uint64_t)(uint32_t)(k + 1);
+            rc = spex_graph_set_edge_mask(g, 2, nullptr, keep_prob, seed);
+            if (rc == SPEX_OK && gt != g) rc = spex_graph_set_edge_mask(gt, 2, nullptr, keep_prob, seed);
+            if (rc != SPEX_OK) break;
+        }
+        rc = spex_dual_task_step_f32(s, users + b0, items + b0, labels + b0, nb, T ? seq + p0 * s->path_len : nullptr, T ? seq_l + p0 : nullptr,
+                                     T ? targets + p0 : nullptr, (int32_t)T, stream);
+    }
+    if (drop) {
+        (void)spex_graph_set_edge_mask(g, 0, nullptr, 1.0f, 0);
+        if (gt != g) (void)spex_graph_set_edge_mask(gt, 0, nullptr, 1.0f, 0);
+    }
+    return rc;
+}

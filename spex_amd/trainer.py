@@ -873,6 +873,20 @@ class DualTaskStepper:
                 raise ValueError(f"DualTaskStepper.step: {T} paths of width {seq.shape[1]} (capacity {self.path_capacity} x {self.path_len})")
         if getattr(self.model.Graph, "mask_mode", 0) != 0 and (self._graph_t is self.model.Graph or self.L < 2):
             raise ValueError("DualTaskStepper.step: edge dropout needs the transposed handle (a model built with --dropout 1) and L >= 2")
+        dsc = self._prepare_desc(B)
+        if T and self._side is not None:                     # the side stream reads them: keep the allocator from recycling
+            for t in (seq, seq_l, targets):                  # their memory under a step still in flight
+                t.record_stream(self._side)
+        vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() else None
+        _launch(self.dev, "spex_dual_task_step_f32", ctypes.byref(dsc), vp(users), vp(items), vp(labels), B,
+                vp(seq) if T else None, vp(seq_l) if T else None, vp(targets) if T else None, T)
+        self.t = dsc.t
+        _bump(self.arena, self.m, self.v, self.loss_acc)
+        self.model._cache = None
+
+    def _prepare_desc(self, B):
+        """The one-call step's descriptor for batches of up to B samples (built once, refreshed per call)."""
+        from . import _lib
         self._slots(2 * B)
         if self._desc is None:
             p = lambda t: t.data_ptr()
@@ -892,12 +906,41 @@ class DualTaskStepper:
         dsc.t, dsc.lr = self.t, self.lr
         dsc.flags = ((_lib.STEP_DETERMINISTIC if self.deterministic else 0) | (_lib.STEP_FIXED_TASK_WEIGHTS if self.fixed_task_weights else 0)
                      | (_lib.STEP_PIPELINED if self.pipelined and self._side is not None else 0))
-        if T and self._side is not None:                     # the side stream reads them: keep the allocator from recycling
-            for t in (seq, seq_l, targets):                  # their memory under a step still in flight
+        return dsc
+
+    def epoch(self, users, items, labels, batch_size, seq, seq_l, targets, path_off, max_steps=None, keep_prob=1.0, drop_seed=0):
+        """A whole pre-shuffled, device-resident epoch as ONE native call (spex_dual_task_epoch_f32; Train() of
+        main_auto_expert_s.py:60-91): batch k = samples [k B, (k+1) B) with the staged paths [path_off[k], path_off[k+1]) (path_off: a
+        host int64 array of n_batches + 1 offsets).  Both losses are added to `loss_acc`.  keep_prob < 1: the in-kernel sampled edge
+        mask on the rec branch, a fresh one per step (seed (drop_seed << 32) | step)."""
+        import ctypes
+        import numpy as np
+        from .graph import _bump, _launch
+        for t, dt in ((users, torch.int64), (items, torch.int64), (labels, torch.float32)):
+            if not (t.is_cuda and t.dtype == dt and t.is_contiguous() and t.numel() == users.numel()):
+                raise ValueError("DualTaskStepper.epoch: users / items (int64) and labels (fp32) must be contiguous device tensors of one length")
+        path_off = np.ascontiguousarray(path_off, dtype=np.int64)
+        n_paths = int(path_off[-1])
+        if n_paths:
+            for t in (seq, seq_l, targets):
+                if not (t.is_cuda and t.dtype == torch.int64 and t.is_contiguous()):
+                    raise ValueError("DualTaskStepper.epoch: seq / seq_l / targets must be contiguous device int64 tensors")
+            if seq.shape[1] != self.path_len or seq.shape[0] < n_paths or seq_l.numel() < n_paths or targets.numel() < n_paths \
+                    or int(np.diff(path_off).max()) > self.path_capacity:
+                raise ValueError("DualTaskStepper.epoch: the staged paths do not match path_off / the stepper's capacity")
+        n_batches = (users.numel() + int(batch_size) - 1) // int(batch_size)
+        if len(path_off) < (n_batches if max_steps is None else min(n_batches, int(max_steps))) + 1:
+            raise ValueError("DualTaskStepper.epoch: path_off needs one offset per batch + 1")
+        if keep_prob < 1.0 and (self._graph_t is self.model.Graph or self.L < 2):
+            raise ValueError("DualTaskStepper.epoch: edge dropout needs the transposed handle (a model built with --dropout 1) and L >= 2")
+        dsc = self._prepare_desc(min(int(batch_size), users.numel()))
+        if n_paths and self._side is not None:
+            for t in (seq, seq_l, targets):
                 t.record_stream(self._side)
         vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() else None
-        _launch(self.dev, "spex_dual_task_step_f32", ctypes.byref(dsc), vp(users), vp(items), vp(labels), B,
-                vp(seq) if T else None, vp(seq_l) if T else None, vp(targets) if T else None, T)
+        _launch(self.dev, "spex_dual_task_epoch_f32", ctypes.byref(dsc), vp(users), vp(items), vp(labels), users.numel(), int(batch_size),
+                -1 if max_steps is None else int(max_steps), vp(seq) if n_paths else None, vp(seq_l) if n_paths else None,
+                vp(targets) if n_paths else None, path_off.ctypes.data_as(ctypes.c_void_p), float(keep_prob), int(drop_seed) & 0xFFFFFFFF)
         self.t = dsc.t
         _bump(self.arena, self.m, self.v, self.loss_acc)
         self.model._cache = None
@@ -945,8 +988,55 @@ def dual_task_epoch_paths(batch_users, by_user, cap):
     return chosen_all
 
 
+def epoch_arrays_dual(train_data, trust_data, by_user, cap, batch_size=256, resample=True, max_steps=None):
+    """One dual-task epoch's inputs as the reference's loop meets them (main_auto_expert_s.py:56-71): negatives (`ng_sample`: NumPy's
+    global stream), the DataLoader's shuffle (torch's), every batch's paths cut to `cap` by random.sample (Python's `random`) — host
+    arrays (users, items, labels, path inputs, path lengths, path targets) and the per-batch path lists."""
+    import numpy as np
+    users_h, items_h, labels_h = epoch_arrays(train_data, resample)
+    starts = list(range(0, len(users_h), batch_size))
+    if max_steps is not None:
+        starts = starts[:max_steps]
+    chosen = dual_task_epoch_paths([users_h[s:s + batch_size] for s in starts], by_user, cap)
+    flat = np.fromiter((k for c in chosen for k in c), dtype=np.int64, count=sum(len(c) for c in chosen))
+    inputs, mask, targets = trust_data.get_slice(flat)
+    return (users_h, items_h, labels_h, np.ascontiguousarray(inputs, dtype=np.int64), np.asarray(mask).sum(1).astype(np.int64),
+            np.asarray(targets).astype(np.int64), chosen)
+
+
+def train_epochs_dual(stepper, train_data, trust_data, by_user, cap, n_epochs, batch_size=256, edge_dropout=None, after_epoch=None):
+    """n_epochs x train_epoch_dual with the NEXT epoch's negatives, shuffle and path selection prepared on a second host thread while
+    the current epoch runs as one native call (see train_epochs: the three generators are drawn by that thread alone meanwhile, in the
+    order a sequential loop draws them — the same run).  Returns the per-epoch (loss1, loss2) sums."""
+    import threading
+    nxt = epoch_arrays_dual(train_data, trust_data, by_user, cap, batch_size)
+    totals = []
+    for ep in range(n_epochs):
+        arrays, box, th = nxt, {}, None
+        if ep + 1 < n_epochs:
+            def work():
+                try:
+                    box["v"] = epoch_arrays_dual(train_data, trust_data, by_user, cap, batch_size)
+                except BaseException as e:       # noqa: BLE001 — re-raised on the caller's thread
+                    box["e"] = e
+            th = threading.Thread(target=work)
+            th.start()
+        try:
+            total = train_epoch_dual(stepper, train_data, trust_data, by_user, cap, batch_size=batch_size, edge_dropout=edge_dropout, arrays=arrays)
+        finally:
+            if th is not None:
+                th.join()
+        if "e" in box:
+            raise box["e"]
+        nxt = box.get("v")
+        totals.append(total)
+        if after_epoch is not None:
+            after_epoch(ep, total)
+    return [t.cpu().numpy() for t in totals]
+
+
 def train_epoch_dual(stepper, train_data, trust_data, by_user, cap, batch_size=256, resample=True, pause_gc=True, max_steps=None,
-                     cum_every=None, cum_out=None, n_paths_out=None, edge_dropout=None):
+                     cum_every=None, cum_out=None, n_paths_out=None, edge_dropout=None, arrays=None):
     """Train() of main_auto_expert_s.py:53-91 on the device: negatives drawn like the reference's (`ng_sample`), the
     epoch's sample order is the shuffled DataLoader's own, the per-batch paths are chosen by the reference's rule
     (dual_task_epoch_paths), everything is moved to the device once and every batch is one DualTaskStepper.step.
@@ -956,26 +1046,41 @@ def train_epoch_dual(stepper, train_data, trust_data, by_user, cap, batch_size=2
     (README.md:119-123; stream "reference" replays the reference's per-step `torch.rand(nnz)`, "philox" draws in-kernel) — a fresh
     mask on the rec branch's handles per step; the model must have been built with --dropout 1."""
     import numpy as np
-    if resample:
-        train_data.ng_sample()
-    n = len(train_data)
-    order = dataloader_epoch_order(n).numpy()
+    if arrays is None:
+        arrays = epoch_arrays_dual(train_data, trust_data, by_user, cap, batch_size, resample, max_steps)
+    users_h, items_h, labels_h, seq_h, seq_l_h, tgt_h, chosen = arrays
+    n = len(users_h)
     dev = stepper.dev
-    users_h = train_data.users_fill[order]
     starts = list(range(0, n, batch_size))
     if max_steps is not None:
         starts = starts[:max_steps]
-    chosen = dual_task_epoch_paths([users_h[s:s + batch_size] for s in starts], by_user, cap)
-    flat = np.fromiter((k for c in chosen for k in c), dtype=np.int64, count=sum(len(c) for c in chosen))
-    inputs, mask, targets = trust_data.get_slice(flat)
-    seq = torch.from_numpy(np.ascontiguousarray(inputs, dtype=np.int64)).to(dev)
-    seq_l = torch.from_numpy(np.asarray(mask).sum(1).astype(np.int64)).to(dev)
-    tgt = torch.from_numpy(np.asarray(targets).astype(np.int64)).to(dev)
+        chosen = chosen[:max_steps]
+    seq, seq_l, tgt = torch.from_numpy(seq_h).to(dev), torch.from_numpy(seq_l_h).to(dev), torch.from_numpy(tgt_h).to(dev)
     users = torch.from_numpy(users_h).to(dev)
-    items = torch.from_numpy(train_data.items_fill[order]).to(dev)
-    labels = torch.from_numpy(train_data.labels_fill_np[order]).to(device=dev, dtype=torch.float32)
+    items = torch.from_numpy(items_h).to(dev)
+    labels = torch.from_numpy(labels_h).to(device=dev, dtype=torch.float32)
     stepper.join()
     stepper.loss_acc.zero_()
+    # the whole epoch as ONE native call where nothing has to happen on the host between two steps (no running sums asked for, no
+    # host-drawn mask, not the pipelined form — whose side stream the loop below manages step by step)
+    if (not cum_every and (edge_dropout is None or edge_dropout[1] == "philox") and hasattr(stepper, "epoch") and n > 0
+            and not (stepper._side is not None and os.environ.get("SPEX_DUAL_PIPELINED", "0") == "1") and not stepper.pipelined):
+        gc_was_on = pause_gc and gc.isenabled()
+        if gc_was_on:
+            gc.disable()
+        try:
+            path_off = np.zeros(len(chosen) + 1, dtype=np.int64)
+            np.cumsum([len(c) for c in chosen], out=path_off[1:])
+            kp = 1.0 if edge_dropout is None else float(edge_dropout[0])
+            seed = 0 if edge_dropout is None or len(edge_dropout) < 3 else int(edge_dropout[2])
+            stepper.epoch(users, items, labels, batch_size, seq, seq_l, tgt, path_off, max_steps=max_steps, keep_prob=kp, drop_seed=seed)
+            if n_paths_out is not None:
+                n_paths_out.extend(len(c) for c in chosen)
+        finally:
+            stepper.join()
+            if gc_was_on:
+                gc.enable()
+        return stepper.loss_acc.clone()
     # the epoch's inputs are complete on the device before its first step and nothing but the steps touches the model inside the
     # loop: the pipelined form's contract (DualTaskStepper.__init__), so the loop MAY run in it — SPEX_DUAL_PIPELINED=1.  It pays
     # when the trust branch is the longer one (round 3's first measurement: 119 -> 102 us per step on Epinion2); with this round's

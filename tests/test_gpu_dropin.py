@@ -1124,6 +1124,54 @@ def test_dual_task_on_device_epoch_matches_the_reference_epinion2(data_root, gol
     assert max(tab.values()) <= 1e-4, tab
 
 
+def test_native_dual_task_epoch_and_overlapped_preparation_equal_the_python_loop(data_root, golden):
+    """trainer.train_epoch_dual issues the epoch as ONE native call (spex_dual_task_epoch_f32: Train() of main_auto_expert_s.py:60-91,
+    batch after batch with the staged paths of each) where nothing has to happen on the host between two steps; asking for running
+    sums keeps the Python loop around the one-call step; trainer.train_epochs_dual prepares the next epoch's negatives, shuffle and
+    path cuts on a second thread meanwhile.  DETERMINISTIC step (a run is a pure function of its inputs): 2 x 200 steps the three ways
+    end in bit-identical parameters and loss sums; and under the sampled edge dropout the native loop equals the Python loop."""
+    from collections import defaultdict
+    import utility1.dataloader as dl
+    from utility2.utils import Data
+    from spex_amd.trainer import DualTaskStepper, train_epoch_dual, train_epochs_dual
+    raw_train, _ = _epinion2_trust_raw(golden)
+    by_user = defaultdict(list)
+    for k, p in enumerate(raw_train[0]):
+        by_user[p[0]].append(k)
+
+    class _Short:            # the first 200 batches of the real training data (a whole epoch is 4 906)
+        def __init__(self, td):
+            self.td = td
+        def ng_sample(self):
+            self.td.ng_sample()
+        def __len__(self):
+            return 200 * 256
+        users_fill = property(lambda self: self.td.users_fill[: 2 * len(self)])
+        items_fill = property(lambda self: self.td.items_fill[: 2 * len(self)])
+        labels_fill_np = property(lambda self: self.td.labels_fill_np[: 2 * len(self)])
+    out = {}
+    for way in ("native", "python", "overlapped", "native-dropout", "python-dropout"):
+        drop = ("--dropout", "1", "--keepprob", "0.3") if way.endswith("dropout") else ()
+        args, dataset, net = _dual_epinion2(data_root, drop)
+        td = _Short(dl.LightTrainData(dataset.rec_train_data, dataset.m_item, dataset.train_mat))
+        train2 = Data(raw_train, dataset.n_users, shuffle=False)
+        cap = 3 * (len(raw_train[0]) // 4906)
+        net = net.to(DEV)
+        st = DualTaskStepper(net, path_capacity=cap, path_len=train2.len_max, lr=args.lr, deterministic=True)
+        ed = (0.3, "philox", 5) if drop else None
+        if way == "overlapped":
+            totals = train_epochs_dual(st, td, train2, by_user, cap, 2)
+        else:
+            kw = dict(cum_every=10 ** 9, cum_out=[]) if way.startswith("python") else {}
+            totals = [train_epoch_dual(st, td, train2, by_user, cap, edge_dropout=ed, **kw).cpu().numpy() for _ in range(2)]
+        assert st.t == 400 and getattr(net.Graph, "mask_mode", 0) == 0
+        out[way] = (np.stack(totals), [p.detach().clone() for p in net.parameters()])
+    for a, b in (("python", "native"), ("overlapped", "native"), ("python-dropout", "native-dropout")):
+        assert np.array_equal(out[a][0], out[b][0]), (a, out[a][0], out[b][0])
+        assert all(torch.equal(x, y) for x, y in zip(out[a][1], out[b][1])), a
+    assert not np.array_equal(out["native"][0], out["native-dropout"][0])
+
+
 def test_dual_task_run_under_edge_dropout_matches_the_reference_epinion2(data_root, golden):
     """G13-dropout: main_auto_expert_s.py under the reference's recommended `--dropout 1 --keepprob 0.3` (README.md:119-123) on
     Epinion2, 150 steps minted from the reference's modules (oracle/gen_golden.py --stage dual-dropout-epinion2).  The rec branch's
